@@ -1,0 +1,195 @@
+"""ctypes front-end of the CPU oracle (oracle/*.c).
+
+TEST INFRASTRUCTURE ONLY — see oracle/README.md.  Only tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg may import this module; the product package never does.
+
+Every function takes/returns numpy arrays.  `prec` selects the build: "f32" (bit-exact
+integer parity target, CPU baseline) or "f64" (gradient checking).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_BUILD = os.path.join(_HERE, "_build")
+_LIBS = {}
+
+
+def build(force=False):
+    """Compile the C restatement with gcc (oracle/Makefile)."""
+    kinds = [k for k in ("splat", "sdf") if os.path.exists(os.path.join(_HERE, f"{k}_oracle.c"))]
+    targets = [f"_build/liborc_{k}_{p}.so" for k in kinds for p in ("f32", "f64")]
+    subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []) + targets)
+
+
+def _lib(kind, prec):
+    key = (kind, prec)
+    if key not in _LIBS:
+        path = os.path.join(_BUILD, f"liborc_{kind}_{prec}.so")
+        if not os.path.exists(path):
+            build()
+        _LIBS[key] = C.CDLL(path)
+    return _LIBS[key]
+
+
+def _dt(prec):
+    return np.float32 if prec == "f32" else np.float64
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _r(x, prec):
+    return C.c_float(x) if prec == "f32" else C.c_double(x)
+
+
+def _c(a, dt):
+    return None if a is None else np.ascontiguousarray(a, dtype=dt)
+
+
+# ----------------------------------------------------------------------------------------------
+# P1 projection
+# ----------------------------------------------------------------------------------------------
+def projection_2dgs_fwd(means, quats, scales, viewmats, Ks, W, H, near=0.05, far=300.0, radius_clip=0.0,
+                        seed=0, prec="f32"):
+    dt = _dt(prec)
+    means, quats, scales, viewmats, Ks = (_c(a, dt) for a in (means, quats, scales, viewmats, Ks))
+    N, Cn = means.shape[0], viewmats.shape[0]
+    cap = max(N * Cn, 1)
+    cam = np.zeros(cap, np.int64); gid = np.zeros(cap, np.int64); radii = np.zeros(cap, np.int32)
+    m2d = np.zeros((cap, 2), dt); dep = np.zeros(cap, dt); rt = np.zeros((cap, 3, 3), dt)
+    nrm = np.zeros((cap, 3), dt); smp = np.zeros((cap, 3), dt); sw = np.zeros((cap, 1), dt)
+    f = _lib("splat", prec).orc_projection_2dgs_fwd
+    f.restype = C.c_int64
+    M = f(C.c_int64(N), C.c_int64(Cn), _p(means), _p(quats), _p(scales), _p(viewmats), _p(Ks), C.c_int(W),
+          C.c_int(H), _r(near, prec), _r(far, prec), _r(radius_clip, prec), C.c_uint64(seed), _p(cam), _p(gid),
+          _p(radii), _p(m2d), _p(dep), _p(rt), _p(nrm), _p(smp), _p(sw))
+    return dict(camera_ids=cam[:M].copy(), gaussian_ids=gid[:M].copy(), radii=radii[:M].copy(),
+                means2d=m2d[:M].copy(), depths=dep[:M].copy(), ray_transforms=rt[:M].copy(),
+                normals=nrm[:M].copy(), samples=smp[:M].copy(), samples_weights=sw[:M].copy())
+
+
+def projection_2dgs_bwd(means, quats, scales, viewmats, Ks, W, H, camera_ids, gaussian_ids, v_means2d, v_depths,
+                        v_ray_transforms, v_normals, v_samples=None, seed=0, prec="f32"):
+    dt = _dt(prec)
+    means, quats, scales, viewmats, Ks = (_c(a, dt) for a in (means, quats, scales, viewmats, Ks))
+    N, Cn, M = means.shape[0], viewmats.shape[0], camera_ids.shape[0]
+    cam, gid = _c(camera_ids, np.int64), _c(gaussian_ids, np.int64)
+    v_means2d, v_depths, v_rt, v_normals, v_samples = (
+        _c(a, dt) for a in (v_means2d, v_depths, v_ray_transforms, v_normals, v_samples))
+    vm = np.zeros((N, 3), dt); vq = np.zeros((N, 4), dt); vs = np.zeros((N, 3), dt)
+    _lib("splat", prec).orc_projection_2dgs_bwd(
+        C.c_int64(N), C.c_int64(Cn), C.c_int64(M), _p(means), _p(quats), _p(scales), _p(viewmats), _p(Ks),
+        C.c_int(W), C.c_int(H), C.c_uint64(seed), _p(cam), _p(gid), _p(v_means2d), _p(v_depths), _p(v_rt),
+        _p(v_normals), _p(v_samples), _p(vm), _p(vq), _p(vs))
+    return vm, vq, vs
+
+
+# ----------------------------------------------------------------------------------------------
+# P2 view colours
+# ----------------------------------------------------------------------------------------------
+def view_colors_fwd(viewmats, means, sh_coeffs, camera_ids, gaussian_ids, sh_degree, prec="f32"):
+    dt = _dt(prec)
+    viewmats, means, sh = _c(viewmats, dt), _c(means, dt), _c(sh_coeffs, dt)
+    cam, gid = _c(camera_ids, np.int64), _c(gaussian_ids, np.int64)
+    M, K = cam.shape[0], sh.shape[1]
+    out = np.zeros((M, 3), dt)
+    _lib("splat", prec).orc_view_colors_fwd(C.c_int64(M), C.c_int64(K), C.c_int(sh_degree), _p(viewmats),
+                                            _p(means), _p(sh), _p(cam), _p(gid), _p(out))
+    return out
+
+
+def view_colors_bwd(viewmats, means, sh_coeffs, camera_ids, gaussian_ids, sh_degree, v_colors, prec="f32"):
+    dt = _dt(prec)
+    viewmats, means, sh, v_colors = _c(viewmats, dt), _c(means, dt), _c(sh_coeffs, dt), _c(v_colors, dt)
+    cam, gid = _c(camera_ids, np.int64), _c(gaussian_ids, np.int64)
+    M, K = cam.shape[0], sh.shape[1]
+    v_sh = np.zeros_like(sh); v_means = np.zeros_like(means)
+    _lib("splat", prec).orc_view_colors_bwd(C.c_int64(M), C.c_int64(K), C.c_int(sh_degree), _p(viewmats),
+                                            _p(means), _p(sh), _p(cam), _p(gid), _p(v_colors), _p(v_sh),
+                                            _p(v_means))
+    return v_sh, v_means
+
+
+# ----------------------------------------------------------------------------------------------
+# P3 tile binning
+# ----------------------------------------------------------------------------------------------
+def tile_encode(W, H, tile_size, means2d, radii, depths, camera_ids, n_cameras, prec="f32"):
+    """Returns tiles_per_gauss int32[M], isect_ids int64[I], flatten_ids int32[I], isect_offsets int32[C,th,tw].
+    `depths` is always reinterpreted from float32 bits (the key uses raw fp32 depth bits)."""
+    dt = _dt(prec)
+    m2d, radii = _c(means2d, dt), _c(radii, np.int32)
+    cam = _c(camera_ids, np.int64)
+    M = radii.shape[0]
+    depth_bits = np.ascontiguousarray(depths, dtype=np.float32).view(np.uint32)
+    tpg = np.zeros(max(M, 1), np.int32)
+    lib = _lib("splat", prec)
+    lib.orc_tile_count.restype = C.c_int64
+    I = lib.orc_tile_count(C.c_int64(M), C.c_int(W), C.c_int(H), C.c_int(tile_size), _p(m2d), _p(radii), _p(tpg))
+    tw, th = (W + tile_size - 1) // tile_size, (H + tile_size - 1) // tile_size
+    ids = np.zeros(max(I, 1), np.int64); flat = np.zeros(max(I, 1), np.int32)
+    offs = np.zeros((n_cameras, th, tw), np.int32)
+    lib.orc_tile_encode(C.c_int64(M), C.c_int64(n_cameras), C.c_int(W), C.c_int(H), C.c_int(tile_size), _p(m2d),
+                        _p(radii), _p(depth_bits), _p(cam), C.c_int64(I), _p(ids), _p(flat), _p(offs))
+    return tpg[:M].copy(), ids[:I].copy(), flat[:I].copy(), offs
+
+
+# ----------------------------------------------------------------------------------------------
+# P4 compositing
+# ----------------------------------------------------------------------------------------------
+def rasterize_2dgs_fwd(means2d, ray_transforms, colors, opacities, normals, W, H, tile_size, isect_offsets,
+                       flatten_ids, backgrounds=None, masks=None, prec="f32"):
+    dt = _dt(prec)
+    m2d, rt, col, opa, nrm, bg = (_c(a, dt) for a in (means2d, ray_transforms, colors, opacities, normals,
+                                                      backgrounds))
+    offs, flat = _c(isect_offsets, np.int32), _c(flatten_ids, np.int32)
+    masks = _c(masks, np.uint8)
+    Cn, M, I = offs.shape[0], opa.shape[0], flat.shape[0]
+    rc = np.zeros((Cn, H, W, 3), dt); rd = np.zeros((Cn, H, W, 1), dt); ra = np.zeros((Cn, H, W, 1), dt)
+    rn = np.zeros((Cn, H, W, 3), dt); rm = np.zeros((Cn, H, W, 1), dt)
+    last = np.zeros((Cn, H, W), np.int32); med = np.zeros((Cn, H, W), np.int32)
+    vis = np.zeros((max(M, 1), 1), dt)
+    _lib("splat", prec).orc_rasterize_2dgs_fwd(
+        C.c_int64(Cn), C.c_int64(M), C.c_int64(I), C.c_int(W), C.c_int(H), C.c_int(tile_size), _p(m2d), _p(rt),
+        _p(col), _p(opa), _p(nrm), _p(bg), _p(masks), _p(offs), _p(flat), _p(rc), _p(rd), _p(ra), _p(rn), _p(rm),
+        _p(last), _p(med), _p(vis))
+    return dict(render_colors=rc, render_depths=rd, render_alphas=ra, render_normals=rn, render_median=rm,
+                last_ids=last, median_ids=med, visibilities=vis[:M])
+
+
+def rasterize_2dgs_bwd(means2d, ray_transforms, colors, opacities, normals, W, H, tile_size, isect_offsets,
+                       flatten_ids, render_alphas, last_ids, median_ids, v_render_colors, v_render_depths,
+                       v_render_alphas, v_render_normals, v_render_median, backgrounds=None, masks=None,
+                       absgrad=True, prec="f32"):
+    """Gradients are returned as float64 arrays irrespective of `prec`."""
+    dt = _dt(prec)
+    m2d, rt, col, opa, nrm, bg = (_c(a, dt) for a in (means2d, ray_transforms, colors, opacities, normals,
+                                                      backgrounds))
+    offs, flat = _c(isect_offsets, np.int32), _c(flatten_ids, np.int32)
+    masks = _c(masks, np.uint8)
+    ralpha, last, med = _c(render_alphas, dt), _c(last_ids, np.int32), _c(median_ids, np.int32)
+    vc, vd, va, vn, vmed = (_c(a, dt) for a in (v_render_colors, v_render_depths, v_render_alphas,
+                                                v_render_normals, v_render_median))
+    Cn, M, I = offs.shape[0], opa.shape[0], flat.shape[0]
+    Mz = max(M, 1)
+    g = dict(v_means2d=np.zeros((Mz, 2)), v_ray_transforms=np.zeros((Mz, 3, 3)), v_colors=np.zeros((Mz, 3)),
+             v_opacities=np.zeros(Mz), v_normals=np.zeros((Mz, 3)), v_densify=np.zeros((Mz, 2)),
+             v_means2d_abs=np.zeros((Mz, 2)) if absgrad else None)
+    _lib("splat", prec).orc_rasterize_2dgs_bwd(
+        C.c_int64(Cn), C.c_int64(M), C.c_int64(I), C.c_int(W), C.c_int(H), C.c_int(tile_size), _p(m2d), _p(rt),
+        _p(col), _p(opa), _p(nrm), _p(bg), _p(masks), _p(offs), _p(flat), _p(ralpha), _p(last), _p(med), _p(vc),
+        _p(vd), _p(va), _p(vn), _p(vmed), _p(g["v_means2d"]), _p(g["v_ray_transforms"]), _p(g["v_colors"]),
+        _p(g["v_opacities"]), _p(g["v_normals"]), _p(g["v_densify"]), _p(g["v_means2d_abs"]))
+    return {k: (v[:M] if v is not None else None) for k, v in g.items()}
+
+
+def set_threads(n):
+    """OpenMP thread count for the raster loops (cpu_baseline reports it as `cores`)."""
+    os.environ["OMP_NUM_THREADS"] = str(n)
+    try:
+        C.CDLL("libgomp.so.1").omp_set_num_threads(C.c_int(n))
+    except OSError:
+        pass

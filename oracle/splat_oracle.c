@@ -1,0 +1,713 @@
+/*
+ * splat_oracle.c — CPU restatement of the 2D-Gaussian-splat hot path of GS-SDF.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the product: only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library, and only
+ * as the checker / the timed CPU baseline.  The product path (gs-sdf_amd/) never links it.
+ *
+ * PARITY UNPINNED.  The arithmetic of this path lives in the reference's un-vendored
+ * submodule jianhengLiu/gsplat_cpp (a fork of nerfstudio gsplat's 2DGS kernels, pinned SHA
+ * unknown: /root/reference/.gitmodules:1-18, directory empty) and the reference ships no
+ * tests or golden vectors.  This file therefore restates the published algorithm (2DGS,
+ * Huang et al. SIGGRAPH'24; gsplat >= 1.4 `fully_fused_projection_2dgs`,
+ * `isect_tiles`/`isect_offset_encode`, `rasterize_to_pixels_2dgs`) anchored on the
+ * reference's own call sites:
+ *     include/neural_gaussian/neural_gaussian.cpp:188-192  (projection, 9 outputs)
+ *     include/neural_gaussian/neural_gaussian.cpp:199-200  (view colours / SH)
+ *     include/neural_gaussian/neural_gaussian.cpp:207-209  (tile_encode)
+ *     include/neural_gaussian/neural_gaussian.cpp:215-223  (rasterize, 7 outputs)
+ *     include/neural_gaussian/neural_gaussian.cpp:626-633  (consumers of densify grads)
+ * Fork-specific outputs whose definition cannot be recovered (`samples`, `samples_weights`,
+ * `render_depths`, `visibilities`) follow the decisions frozen in DESIGN.md section "SPEC".
+ * The oracle is validated by itself (tests/test_oracle_selfcheck.py): f64-vs-f32 agreement,
+ * finite differences and an independent torch-autograd restatement of every VJP.
+ *
+ * The file is compiled twice: -DREAL=float  -> liborc_splat_f32.so (bit-exact integer parity,
+ * CPU baseline) and -DREAL=double -> liborc_splat_f64.so (gradient checking).
+ * Build flags must keep IEEE semantics: -O2 -ffp-contract=off, no -ffast-math.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#ifndef REAL
+#define REAL float
+#endif
+
+#ifdef REAL_IS_FLOAT
+#define R_SQRT(x) sqrtf(x)
+#define R_CEIL(x) ceilf(x)
+#define R_FLOOR(x) floorf(x)
+#else
+#define R_SQRT(x) sqrt(x)
+#define R_CEIL(x) ceil(x)
+#define R_FLOOR(x) floor(x)
+#endif
+
+#define TILE_ALPHA_MIN ((REAL)(1.0 / 255.0))
+#define ALPHA_MAX ((REAL)0.999)
+#define T_EPS ((REAL)1e-4)
+#define FILTER_INV_SQUARE ((REAL)2.0)
+
+static inline REAL rmax(REAL a, REAL b) { return a > b ? a : b; }
+static inline REAL rmin(REAL a, REAL b) { return a < b ? a : b; }
+
+/* ---------------------------------------------------------------------------------------
+ * counter-based normal pair used for the fork's stochastic `samples` (SPEC S-3)
+ * ------------------------------------------------------------------------------------- */
+static inline uint32_t mix32(uint32_t h) {
+  h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+  return h;
+}
+static void sample_eps(uint64_t seed, uint32_t gid, REAL *eu, REAL *ev) {
+  if (seed == 0) { *eu = 0; *ev = 0; return; }
+  uint32_t h1 = mix32(gid * 2u + 0x9E3779B9u * (uint32_t)seed + (uint32_t)(seed >> 32));
+  uint32_t h2 = mix32(h1 ^ 0x68E31DA4u);
+  double u1 = ((double)(h1 >> 8) + 1.0) / 16777216.0; /* (0,1] */
+  double u2 = (double)(h2 >> 8) / 16777216.0;          /* [0,1) */
+  double r = sqrt(-2.0 * log(u1));
+  *eu = (REAL)(r * cos(6.283185307179586 * u2));
+  *ev = (REAL)(r * sin(6.283185307179586 * u2));
+}
+
+/* quaternion (w,x,y,z) -> rotation, reference formula include/utils/utils.cpp:538-558,
+ * after normalisation (gsplat normalises inside the kernel). */
+static void quat_to_rot(const REAL *q, REAL *qn, REAL *inv_norm, REAL R[9]) {
+  REAL w = q[0], x = q[1], y = q[2], z = q[3];
+  REAL n2 = ((w * w + x * x) + y * y) + z * z;
+  REAL inv = (REAL)1 / R_SQRT(n2);
+  w *= inv; x *= inv; y *= inv; z *= inv;
+  qn[0] = w; qn[1] = x; qn[2] = y; qn[3] = z; *inv_norm = inv;
+  R[0] = 1 - 2 * (y * y + z * z); R[1] = 2 * (x * y - w * z);     R[2] = 2 * (x * z + w * y);
+  R[3] = 2 * (x * y + w * z);     R[4] = 1 - 2 * (x * x + z * z); R[5] = 2 * (y * z - w * x);
+  R[6] = 2 * (x * z - w * y);     R[7] = 2 * (y * z + w * x);     R[8] = 1 - 2 * (x * x + y * y);
+}
+
+typedef struct {
+  int culled;
+  REAL mc[3];        /* camera-space centre */
+  REAL Rq[9];        /* splat rotation (world) */
+  REAL Rc[9];        /* R_view * Rq */
+  REAL qn[4], inv_norm;
+  REAL Mu[3], Mv[3], Mw[3];
+  REAL f[3];         /* (1,1,-1)/distance */
+  REAL mean2d[2];
+  REAL radius;
+  REAL mult;         /* normal flip */
+} proj_t;
+
+/* SPEC A.1 (gsplat fully_fused_projection_fwd_2dgs; reference call neural_gaussian.cpp:190) */
+static void project_one(const REAL *mean, const REAL *quat, const REAL *scale, const REAL *vm,
+                        const REAL *K, int W, int H, REAL near_p, REAL far_p, REAL radius_clip,
+                        proj_t *o) {
+  o->culled = 1;
+  const REAL R00 = vm[0], R01 = vm[1], R02 = vm[2], t0 = vm[3];
+  const REAL R10 = vm[4], R11 = vm[5], R12 = vm[6], t1 = vm[7];
+  const REAL R20 = vm[8], R21 = vm[9], R22 = vm[10], t2 = vm[11];
+  o->mc[0] = ((R00 * mean[0] + R01 * mean[1]) + R02 * mean[2]) + t0;
+  o->mc[1] = ((R10 * mean[0] + R11 * mean[1]) + R12 * mean[2]) + t1;
+  o->mc[2] = ((R20 * mean[0] + R21 * mean[1]) + R22 * mean[2]) + t2;
+  if (o->mc[2] < near_p || o->mc[2] > far_p) return;
+  quat_to_rot(quat, o->qn, &o->inv_norm, o->Rq);
+  const REAL *q = o->Rq;
+  REAL *c = o->Rc;
+  for (int j = 0; j < 3; ++j) {
+    c[0 + j] = (R00 * q[0 + j] + R01 * q[3 + j]) + R02 * q[6 + j];
+    c[3 + j] = (R10 * q[0 + j] + R11 * q[3 + j]) + R12 * q[6 + j];
+    c[6 + j] = (R20 * q[0 + j] + R21 * q[3 + j]) + R22 * q[6 + j];
+  }
+  const REAL su = scale[0], sv = scale[1];
+  /* H rows: H[i] = (su*Rc[i][0], sv*Rc[i][1], mc[i]) */
+  REAL H0[3] = {su * c[0], sv * c[1], o->mc[0]};
+  REAL H1[3] = {su * c[3], sv * c[4], o->mc[1]};
+  REAL H2[3] = {su * c[6], sv * c[7], o->mc[2]};
+  const REAL fx = K[0], cx = K[2], fy = K[4], cy = K[5];
+  for (int j = 0; j < 3; ++j) {
+    o->Mu[j] = fx * H0[j] + cx * H2[j];
+    o->Mv[j] = fy * H1[j] + cy * H2[j];
+    o->Mw[j] = H2[j];
+  }
+  const REAL *Mu = o->Mu, *Mv = o->Mv, *Mw = o->Mw;
+  REAL dist = (Mw[0] * Mw[0] + Mw[1] * Mw[1]) - Mw[2] * Mw[2];
+  if (dist == 0) return;
+  REAL inv = (REAL)1 / dist;
+  o->f[0] = inv; o->f[1] = inv; o->f[2] = -inv;
+  const REAL *f = o->f;
+  o->mean2d[0] = (f[0] * Mu[0] * Mw[0] + f[1] * Mu[1] * Mw[1]) + f[2] * Mu[2] * Mw[2];
+  o->mean2d[1] = (f[0] * Mv[0] * Mw[0] + f[1] * Mv[1] * Mw[1]) + f[2] * Mv[2] * Mw[2];
+  REAL tx = (f[0] * Mu[0] * Mu[0] + f[1] * Mu[1] * Mu[1]) + f[2] * Mu[2] * Mu[2];
+  REAL ty = (f[0] * Mv[0] * Mv[0] + f[1] * Mv[1] * Mv[1]) + f[2] * Mv[2] * Mv[2];
+  REAL hx = o->mean2d[0] * o->mean2d[0] - tx;
+  REAL hy = o->mean2d[1] * o->mean2d[1] - ty;
+  REAL ext = rmax((REAL)1e-4, rmax(hx, hy));
+  REAL radius = R_CEIL((REAL)3 * R_SQRT(ext));
+  if (!(radius > radius_clip)) return; /* also drops NaN */
+  if (o->mean2d[0] + radius <= 0 || o->mean2d[0] - radius >= (REAL)W ||
+      o->mean2d[1] + radius <= 0 || o->mean2d[1] - radius >= (REAL)H)
+    return;
+  if (!(radius < (REAL)2147483000.0)) return; /* int32 overflow guard (inf) */
+  o->radius = radius;
+  REAL dotv = (-c[2]) * o->mc[0] + (-c[5]) * o->mc[1] + (-c[8]) * o->mc[2];
+  o->mult = dotv > 0 ? (REAL)1 : (REAL)-1;
+  o->culled = 0;
+}
+
+/* Packed projection forward.  Outputs have capacity C*N rows; returns M (nnz).
+ * Row order: increasing (camera, gaussian).  */
+int64_t orc_projection_2dgs_fwd(int64_t N, int64_t C, const REAL *means, const REAL *quats,
+                                const REAL *scales, const REAL *viewmats, const REAL *Ks, int W,
+                                int H, REAL near_p, REAL far_p, REAL radius_clip, uint64_t seed,
+                                int64_t *camera_ids, int64_t *gaussian_ids, int32_t *radii,
+                                REAL *means2d, REAL *depths, REAL *ray_transforms, REAL *normals,
+                                REAL *samples, REAL *samples_weights) {
+  int64_t m = 0;
+  for (int64_t c = 0; c < C; ++c) {
+    for (int64_t n = 0; n < N; ++n) {
+      proj_t p;
+      project_one(means + 3 * n, quats + 4 * n, scales + 3 * n, viewmats + 16 * c, Ks + 9 * c, W, H,
+                  near_p, far_p, radius_clip, &p);
+      if (p.culled) continue;
+      camera_ids[m] = c; gaussian_ids[m] = n; radii[m] = (int32_t)p.radius;
+      means2d[2 * m] = p.mean2d[0]; means2d[2 * m + 1] = p.mean2d[1];
+      depths[m] = p.mc[2];
+      for (int j = 0; j < 3; ++j) {
+        ray_transforms[9 * m + j] = p.Mu[j];
+        ray_transforms[9 * m + 3 + j] = p.Mv[j];
+        ray_transforms[9 * m + 6 + j] = p.Mw[j];
+        normals[3 * m + j] = p.mult * p.Rc[3 * j + 2];
+      }
+      REAL eu, ev;
+      sample_eps(seed, (uint32_t)n, &eu, &ev);
+      for (int j = 0; j < 3; ++j)
+        samples[3 * m + j] = means[3 * n + j] + (scales[3 * n] * eu) * p.Rq[3 * j] +
+                             (scales[3 * n + 1] * ev) * p.Rq[3 * j + 1];
+      samples_weights[m] = (REAL)exp(-0.5 * (double)(eu * eu + ev * ev));
+      ++m;
+    }
+  }
+  return m;
+}
+
+/* SPEC A.6: VJP of the projection.  Dense [N,.] outputs (sparse_grad=false,
+ * neural_gaussian.cpp:529), accumulated over cameras. Outputs must be zeroed by the caller. */
+void orc_projection_2dgs_bwd(int64_t N, int64_t C, int64_t M, const REAL *means, const REAL *quats,
+                             const REAL *scales, const REAL *viewmats, const REAL *Ks, int W, int H,
+                             uint64_t seed, const int64_t *camera_ids, const int64_t *gaussian_ids,
+                             const REAL *v_means2d, const REAL *v_depths,
+                             const REAL *v_ray_transforms, const REAL *v_normals,
+                             const REAL *v_samples, REAL *v_means, REAL *v_quats, REAL *v_scales) {
+  (void)N; (void)C;
+  for (int64_t m = 0; m < M; ++m) {
+    int64_t c = camera_ids[m], n = gaussian_ids[m];
+    const REAL *vm = viewmats + 16 * c, *K = Ks + 9 * c;
+    proj_t p;
+    project_one(means + 3 * n, quats + 4 * n, scales + 3 * n, vm, K, W, H, (REAL)-1e30, (REAL)1e30,
+                (REAL)-1, &p);
+    /* recompute without culling; dist==0 rows never reach here */
+    const REAL *Mu = p.Mu, *Mv = p.Mv, *Mw = p.Mw, *f = p.f;
+    REAL vMu[3], vMv[3], vMw[3];
+    for (int j = 0; j < 3; ++j) {
+      vMu[j] = v_ray_transforms[9 * m + j];
+      vMv[j] = v_ray_transforms[9 * m + 3 + j];
+      vMw[j] = v_ray_transforms[9 * m + 6 + j];
+    }
+    REAL gx = v_means2d[2 * m], gy = v_means2d[2 * m + 1];
+    for (int j = 0; j < 3; ++j) {
+      vMu[j] += gx * f[j] * Mw[j];
+      vMv[j] += gy * f[j] * Mw[j];
+      vMw[j] += gx * (f[j] * Mu[j] - 2 * f[j] * Mw[j] * p.mean2d[0]) +
+                gy * (f[j] * Mv[j] - 2 * f[j] * Mw[j] * p.mean2d[1]);
+    }
+    const REAL fx = K[0], cx = K[2], fy = K[4], cy = K[5];
+    REAL vH0[3], vH1[3], vH2[3];
+    for (int j = 0; j < 3; ++j) {
+      vH0[j] = fx * vMu[j];
+      vH1[j] = fy * vMv[j];
+      vH2[j] = cx * vMu[j] + cy * vMv[j] + vMw[j];
+    }
+    const REAL su = scales[3 * n], sv = scales[3 * n + 1];
+    const REAL *c9 = p.Rc;
+    REAL v_mc[3] = {vH0[2], vH1[2], vH2[2] + v_depths[m]};
+    REAL v_su = vH0[0] * c9[0] + vH1[0] * c9[3] + vH2[0] * c9[6];
+    REAL v_sv = vH0[1] * c9[1] + vH1[1] * c9[4] + vH2[1] * c9[7];
+    REAL vRc[9];
+    vRc[0] = su * vH0[0]; vRc[3] = su * vH1[0]; vRc[6] = su * vH2[0];
+    vRc[1] = sv * vH0[1]; vRc[4] = sv * vH1[1]; vRc[7] = sv * vH2[1];
+    vRc[2] = p.mult * v_normals[3 * m]; vRc[5] = p.mult * v_normals[3 * m + 1];
+    vRc[8] = p.mult * v_normals[3 * m + 2];
+    /* Rc = Rv * Rq  ->  vRq = Rv^T vRc ; mc = Rv mu + t -> v_mu = Rv^T v_mc */
+    REAL Rv[9] = {vm[0], vm[1], vm[2], vm[4], vm[5], vm[6], vm[8], vm[9], vm[10]};
+    REAL vRq[9];
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j)
+        vRq[3 * i + j] = Rv[0 + i] * vRc[0 + j] + Rv[3 + i] * vRc[3 + j] + Rv[6 + i] * vRc[6 + j];
+    REAL v_mu[3];
+    for (int i = 0; i < 3; ++i) v_mu[i] = Rv[0 + i] * v_mc[0] + Rv[3 + i] * v_mc[1] + Rv[6 + i] * v_mc[2];
+    /* samples = mu + su*eu*Rq[:,0] + sv*ev*Rq[:,1] */
+    REAL eu, ev;
+    sample_eps(seed, (uint32_t)n, &eu, &ev);
+    if (v_samples) {
+      const REAL *vs = v_samples + 3 * m;
+      for (int i = 0; i < 3; ++i) {
+        v_mu[i] += vs[i];
+        vRq[3 * i + 0] += su * eu * vs[i];
+        vRq[3 * i + 1] += sv * ev * vs[i];
+        v_su += eu * p.Rq[3 * i + 0] * vs[i];
+        v_sv += ev * p.Rq[3 * i + 1] * vs[i];
+      }
+    }
+    /* rotation -> normalised quaternion */
+    REAL w = p.qn[0], x = p.qn[1], y = p.qn[2], z = p.qn[3];
+    const REAL *g = vRq;
+    REAL vq[4];
+    vq[0] = 2 * (x * (g[7] - g[5]) + y * (g[2] - g[6]) + z * (g[3] - g[1]));
+    vq[1] = 2 * (-2 * x * (g[4] + g[8]) + y * (g[1] + g[3]) + z * (g[2] + g[6]) + w * (g[7] - g[5]));
+    vq[2] = 2 * (x * (g[1] + g[3]) - 2 * y * (g[0] + g[8]) + z * (g[5] + g[7]) + w * (g[2] - g[6]));
+    vq[3] = 2 * (x * (g[2] + g[6]) + y * (g[5] + g[7]) - 2 * z * (g[0] + g[4]) + w * (g[3] - g[1]));
+    REAL dotq = vq[0] * w + vq[1] * x + vq[2] * y + vq[3] * z;
+    for (int i = 0; i < 4; ++i) v_quats[4 * n + i] += (vq[i] - dotq * p.qn[i]) * p.inv_norm;
+    for (int i = 0; i < 3; ++i) v_means[3 * n + i] += v_mu[i];
+    v_scales[3 * n] += v_su;
+    v_scales[3 * n + 1] += v_sv;
+  }
+}
+
+/* ---------------------------------------------------------------------------------------
+ * P2: view-dependent colours (gsplat_cpp::get_view_colors, neural_gaussian.cpp:199-200)
+ * SPEC A.2: rgb = max(SH(dir) . coeffs + 0.5, 0), dir = normalise(mean - campos)
+ * ------------------------------------------------------------------------------------- */
+static void cam_pos(const REAL *vm, REAL cp[3]) {
+  /* campos = inverse(viewmat)[:3,3] = -A^{-1} t  (A = upper 3x3, adjugate inverse: the view
+   * matrix is fp32 and only approximately orthonormal, so A^T is not used) */
+  REAL a = vm[0], b = vm[1], c = vm[2], d = vm[4], e = vm[5], f = vm[6], g = vm[8], h = vm[9], i = vm[10];
+  REAL A00 = e * i - f * h, A01 = c * h - b * i, A02 = b * f - c * e;
+  REAL A10 = f * g - d * i, A11 = a * i - c * g, A12 = c * d - a * f;
+  REAL A20 = d * h - e * g, A21 = b * g - a * h, A22 = a * e - b * d;
+  REAL det = a * A00 + b * A10 + c * A20;
+  REAL id = (REAL)1 / det;
+  REAL t0 = vm[3], t1 = vm[7], t2 = vm[11];
+  cp[0] = -((A00 * t0 + A01 * t1) + A02 * t2) * id;
+  cp[1] = -((A10 * t0 + A11 * t1) + A12 * t2) * id;
+  cp[2] = -((A20 * t0 + A21 * t1) + A22 * t2) * id;
+}
+
+#define SH_C0 0.28209479177387814
+#define SH_C1 0.4886025119029199
+static const double SH_C2[5] = {1.0925484305920792, -1.0925484305920792, 0.31539156525252005,
+                                -1.0925484305920792, 0.5462742152960396};
+static const double SH_C3[7] = {-0.5900435899266435, 2.890611442640554,  -0.4570457994644658,
+                                0.3731763325901154,  -0.4570457994644658, 1.445305721320277,
+                                -0.5900435899266435};
+
+static void sh_basis(int deg, REAL x, REAL y, REAL z, REAL *b) {
+  b[0] = (REAL)SH_C0;
+  if (deg < 1) return;
+  b[1] = (REAL)(-SH_C1) * y; b[2] = (REAL)SH_C1 * z; b[3] = (REAL)(-SH_C1) * x;
+  if (deg < 2) return;
+  REAL xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+  b[4] = (REAL)SH_C2[0] * xy; b[5] = (REAL)SH_C2[1] * yz; b[6] = (REAL)SH_C2[2] * (2 * zz - xx - yy);
+  b[7] = (REAL)SH_C2[3] * xz; b[8] = (REAL)SH_C2[4] * (xx - yy);
+  if (deg < 3) return;
+  b[9] = (REAL)SH_C3[0] * y * (3 * xx - yy); b[10] = (REAL)SH_C3[1] * xy * z;
+  b[11] = (REAL)SH_C3[2] * y * (4 * zz - xx - yy);
+  b[12] = (REAL)SH_C3[3] * z * (2 * zz - 3 * xx - 3 * yy);
+  b[13] = (REAL)SH_C3[4] * x * (4 * zz - xx - yy); b[14] = (REAL)SH_C3[5] * z * (xx - yy);
+  b[15] = (REAL)SH_C3[6] * x * (xx - 3 * yy);
+}
+/* d basis / d (x,y,z), each 16x3 */
+static void sh_basis_grad(int deg, REAL x, REAL y, REAL z, REAL db[16][3]) {
+  memset(db, 0, sizeof(REAL) * 48);
+  if (deg < 1) return;
+  db[1][1] = (REAL)(-SH_C1); db[2][2] = (REAL)SH_C1; db[3][0] = (REAL)(-SH_C1);
+  if (deg < 2) return;
+  REAL xx = x * x, yy = y * y, zz = z * z;
+  db[4][0] = (REAL)SH_C2[0] * y; db[4][1] = (REAL)SH_C2[0] * x;
+  db[5][1] = (REAL)SH_C2[1] * z; db[5][2] = (REAL)SH_C2[1] * y;
+  db[6][0] = (REAL)SH_C2[2] * (-2 * x); db[6][1] = (REAL)SH_C2[2] * (-2 * y); db[6][2] = (REAL)SH_C2[2] * (4 * z);
+  db[7][0] = (REAL)SH_C2[3] * z; db[7][2] = (REAL)SH_C2[3] * x;
+  db[8][0] = (REAL)SH_C2[4] * (2 * x); db[8][1] = (REAL)SH_C2[4] * (-2 * y);
+  if (deg < 3) return;
+  db[9][0] = (REAL)SH_C3[0] * 6 * x * y; db[9][1] = (REAL)SH_C3[0] * (3 * xx - 3 * yy);
+  db[10][0] = (REAL)SH_C3[1] * y * z; db[10][1] = (REAL)SH_C3[1] * x * z; db[10][2] = (REAL)SH_C3[1] * x * y;
+  db[11][0] = (REAL)SH_C3[2] * (-2 * x * y); db[11][1] = (REAL)SH_C3[2] * (4 * zz - xx - 3 * yy);
+  db[11][2] = (REAL)SH_C3[2] * 8 * y * z;
+  db[12][0] = (REAL)SH_C3[3] * (-6 * x * z); db[12][1] = (REAL)SH_C3[3] * (-6 * y * z);
+  db[12][2] = (REAL)SH_C3[3] * (6 * zz - 3 * xx - 3 * yy);
+  db[13][0] = (REAL)SH_C3[4] * (4 * zz - 3 * xx - yy); db[13][1] = (REAL)SH_C3[4] * (-2 * x * y);
+  db[13][2] = (REAL)SH_C3[4] * 8 * x * z;
+  db[14][0] = (REAL)SH_C3[5] * 2 * x * z; db[14][1] = (REAL)SH_C3[5] * (-2 * y * z);
+  db[14][2] = (REAL)SH_C3[5] * (xx - yy);
+  db[15][0] = (REAL)SH_C3[6] * (3 * xx - 3 * yy); db[15][1] = (REAL)SH_C3[6] * (-6 * x * y);
+}
+
+/* sh_coeffs: [N,K,3]; out colors [M,3] */
+void orc_view_colors_fwd(int64_t M, int64_t K, int sh_degree, const REAL *viewmats, const REAL *means,
+                         const REAL *sh_coeffs, const int64_t *camera_ids, const int64_t *gaussian_ids,
+                         REAL *colors) {
+  for (int64_t m = 0; m < M; ++m) {
+    int64_t n = gaussian_ids[m];
+    REAL cp[3];
+    cam_pos(viewmats + 16 * camera_ids[m], cp);
+    REAL d[3] = {means[3 * n] - cp[0], means[3 * n + 1] - cp[1], means[3 * n + 2] - cp[2]};
+    REAL len = (REAL)sqrt((double)(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]));
+    REAL inv = len > 0 ? 1 / len : 0;
+    REAL b[16];
+    sh_basis(sh_degree, d[0] * inv, d[1] * inv, d[2] * inv, b);
+    int nb = (sh_degree + 1) * (sh_degree + 1);
+    for (int ch = 0; ch < 3; ++ch) {
+      REAL acc = 0;
+      for (int k = 0; k < nb; ++k) acc += b[k] * sh_coeffs[(n * K + k) * 3 + ch];
+      colors[3 * m + ch] = rmax(acc + (REAL)0.5, 0);
+    }
+  }
+}
+
+/* outputs v_sh [N,K,3] and v_means [N,3] must be zeroed by the caller */
+void orc_view_colors_bwd(int64_t M, int64_t K, int sh_degree, const REAL *viewmats, const REAL *means,
+                         const REAL *sh_coeffs, const int64_t *camera_ids, const int64_t *gaussian_ids,
+                         const REAL *v_colors, REAL *v_sh, REAL *v_means) {
+  for (int64_t m = 0; m < M; ++m) {
+    int64_t n = gaussian_ids[m];
+    REAL cp[3];
+    cam_pos(viewmats + 16 * camera_ids[m], cp);
+    REAL d[3] = {means[3 * n] - cp[0], means[3 * n + 1] - cp[1], means[3 * n + 2] - cp[2]};
+    REAL len = (REAL)sqrt((double)(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]));
+    REAL inv = len > 0 ? 1 / len : 0;
+    REAL u[3] = {d[0] * inv, d[1] * inv, d[2] * inv};
+    REAL b[16], db[16][3];
+    sh_basis(sh_degree, u[0], u[1], u[2], b);
+    sh_basis_grad(sh_degree, u[0], u[1], u[2], db);
+    int nb = (sh_degree + 1) * (sh_degree + 1);
+    REAL vu[3] = {0, 0, 0};
+    for (int ch = 0; ch < 3; ++ch) {
+      REAL acc = 0;
+      for (int k = 0; k < nb; ++k) acc += b[k] * sh_coeffs[(n * K + k) * 3 + ch];
+      if (!(acc + (REAL)0.5 > 0)) continue; /* clamp_min gate */
+      REAL g = v_colors[3 * m + ch];
+      for (int k = 0; k < nb; ++k) {
+        v_sh[(n * K + k) * 3 + ch] += g * b[k];
+        REAL cf = g * sh_coeffs[(n * K + k) * 3 + ch];
+        vu[0] += cf * db[k][0]; vu[1] += cf * db[k][1]; vu[2] += cf * db[k][2];
+      }
+    }
+    /* u = d/|d| :  v_d = (v_u - (v_u.u) u)/|d| */
+    REAL dot = vu[0] * u[0] + vu[1] * u[1] + vu[2] * u[2];
+    for (int i = 0; i < 3; ++i) v_means[3 * n + i] += (vu[i] - dot * u[i]) * inv;
+  }
+}
+
+/* ---------------------------------------------------------------------------------------
+ * P3: tile binning (gsplat_cpp::tile_encode, neural_gaussian.cpp:207-209).  SPEC A.3.
+ * Integer outputs: the bit-exact parity target.
+ * ------------------------------------------------------------------------------------- */
+static void tile_rect(const REAL *mean2d, int32_t radius, int tile_size, int tw, int th, int *x0,
+                      int *y0, int *x1, int *y1) {
+  REAL r = (REAL)radius / (REAL)tile_size;
+  REAL tx = mean2d[0] / (REAL)tile_size, ty = mean2d[1] / (REAL)tile_size;
+  REAL a;
+  a = R_FLOOR(tx - r); *x0 = (int)rmin(rmax(a, 0), (REAL)tw);
+  a = R_CEIL(tx + r);  *x1 = (int)rmin(rmax(a, 0), (REAL)tw);
+  a = R_FLOOR(ty - r); *y0 = (int)rmin(rmax(a, 0), (REAL)th);
+  a = R_CEIL(ty + r);  *y1 = (int)rmin(rmax(a, 0), (REAL)th);
+}
+
+int64_t orc_tile_count(int64_t M, int W, int H, int tile_size, const REAL *means2d,
+                       const int32_t *radii, int32_t *tiles_per_gauss) {
+  int tw = (W + tile_size - 1) / tile_size, th = (H + tile_size - 1) / tile_size;
+  int64_t total = 0;
+  for (int64_t m = 0; m < M; ++m) {
+    int32_t cnt = 0;
+    if (radii[m] > 0) {
+      int x0, y0, x1, y1;
+      tile_rect(means2d + 2 * m, radii[m], tile_size, tw, th, &x0, &y0, &x1, &y1);
+      cnt = (y1 - y0) * (x1 - x0);
+    }
+    tiles_per_gauss[m] = cnt;
+    total += cnt;
+  }
+  return total;
+}
+
+static int tile_bits_for(int64_t n_tiles) {
+  int b = 0;
+  while ((1LL << (b + 1)) <= n_tiles) ++b; /* floor(log2) */
+  return b + 1;
+}
+
+/* LSD radix sort, 8 bits per pass, stable; sorts (key,val) on bits [0,nbits) */
+static void radix_sort_pairs(uint64_t *keys, int32_t *vals, int64_t n, int nbits) {
+  uint64_t *k2 = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)(n > 0 ? n : 1));
+  int32_t *v2 = (int32_t *)malloc(sizeof(int32_t) * (size_t)(n > 0 ? n : 1));
+  for (int shift = 0; shift < nbits; shift += 8) {
+    int64_t hist[257];
+    memset(hist, 0, sizeof(hist));
+    for (int64_t i = 0; i < n; ++i) hist[((keys[i] >> shift) & 0xFF) + 1]++;
+    for (int b = 0; b < 256; ++b) hist[b + 1] += hist[b];
+    for (int64_t i = 0; i < n; ++i) {
+      int64_t d = hist[(keys[i] >> shift) & 0xFF]++;
+      k2[d] = keys[i]; v2[d] = vals[i];
+    }
+    memcpy(keys, k2, sizeof(uint64_t) * (size_t)n);
+    memcpy(vals, v2, sizeof(int32_t) * (size_t)n);
+  }
+  free(k2); free(v2);
+}
+
+/* emits keys, sorts, builds offsets.  isect_ids [I] (sorted keys), flatten_ids [I],
+ * isect_offsets [C*th*tw]. depths are always passed as float32 bits (depth_bits). */
+void orc_tile_encode(int64_t M, int64_t C, int W, int H, int tile_size, const REAL *means2d,
+                     const int32_t *radii, const uint32_t *depth_bits, const int64_t *camera_ids,
+                     int64_t I, int64_t *isect_ids, int32_t *flatten_ids, int32_t *isect_offsets) {
+  int tw = (W + tile_size - 1) / tile_size, th = (H + tile_size - 1) / tile_size;
+  int64_t n_tiles = (int64_t)tw * th;
+  int tbits = tile_bits_for(n_tiles);
+  int cbits = tile_bits_for(C);
+  uint64_t *keys = (uint64_t *)isect_ids;
+  int64_t pos = 0;
+  for (int64_t m = 0; m < M; ++m) {
+    if (radii[m] <= 0) continue;
+    int x0, y0, x1, y1;
+    tile_rect(means2d + 2 * m, radii[m], tile_size, tw, th, &x0, &y0, &x1, &y1);
+    uint64_t cid = (uint64_t)camera_ids[m];
+    for (int y = y0; y < y1; ++y)
+      for (int x = x0; x < x1; ++x) {
+        uint64_t tile_id = (uint64_t)y * tw + x;
+        keys[pos] = (cid << (32 + tbits)) | (tile_id << 32) | (uint64_t)depth_bits[m];
+        flatten_ids[pos] = (int32_t)m;
+        ++pos;
+      }
+  }
+  (void)I;
+  radix_sort_pairs(keys, flatten_ids, pos, 32 + tbits + cbits);
+  /* offsets: first sorted position whose (cam,tile) >= this tile */
+  int64_t total_tiles = C * n_tiles;
+  int64_t cur = 0;
+  for (int64_t t = 0; t < total_tiles; ++t) {
+    int64_t c = t / n_tiles, tl = t % n_tiles;
+    uint64_t tk = ((uint64_t)c << tbits) | (uint64_t)tl;
+    while (cur < pos && (keys[cur] >> 32) < tk) ++cur;
+    isect_offsets[t] = (int32_t)cur;
+  }
+}
+
+/* ---------------------------------------------------------------------------------------
+ * P4: compositing forward (rasterize_to_pixels_2dgs, neural_gaussian.cpp:215-223). SPEC A.4.
+ * ------------------------------------------------------------------------------------- */
+typedef struct {
+  int valid;      /* contributes (alpha >= 1/255) */
+  int branch3d;   /* g3 <= g2 */
+  int clamped;    /* opac*vis > 0.999 */
+  REAL hu[3], hv[3], z[3], s[2], d[2], vis, alpha, dep;
+} pix_eval_t;
+
+static inline void eval_pair(REAL px, REAL py, const REAL *xy, REAL opac, const REAL *M,
+                             pix_eval_t *e) {
+  const REAL *Mu = M, *Mv = M + 3, *Mw = M + 6;
+  e->valid = 0;
+  for (int j = 0; j < 3; ++j) { e->hu[j] = px * Mw[j] - Mu[j]; e->hv[j] = py * Mw[j] - Mv[j]; }
+  e->z[0] = e->hu[1] * e->hv[2] - e->hu[2] * e->hv[1];
+  e->z[1] = e->hu[2] * e->hv[0] - e->hu[0] * e->hv[2];
+  e->z[2] = e->hu[0] * e->hv[1] - e->hu[1] * e->hv[0];
+  if (e->z[2] == 0) return;
+  e->s[0] = e->z[0] / e->z[2]; e->s[1] = e->z[1] / e->z[2];
+  REAL g3 = e->s[0] * e->s[0] + e->s[1] * e->s[1];
+  e->d[0] = xy[0] - px; e->d[1] = xy[1] - py;
+  REAL g2 = FILTER_INV_SQUARE * (e->d[0] * e->d[0] + e->d[1] * e->d[1]);
+  e->branch3d = g3 <= g2;
+  REAL sigma = (REAL)0.5 * (e->branch3d ? g3 : g2);
+  e->vis = (REAL)exp(-(double)sigma);
+  REAL a = opac * e->vis;
+  e->clamped = a > ALPHA_MAX;
+  e->alpha = rmin(ALPHA_MAX, a);
+  if (!(sigma >= 0) || !(e->alpha >= TILE_ALPHA_MIN)) return;
+  e->dep = e->branch3d ? (e->s[0] * Mw[0] + e->s[1] * Mw[1]) + Mw[2] : Mw[2];
+  e->valid = 1;
+}
+
+/* backgrounds: [C,3] or NULL; masks: uint8 [C,th,tw] or NULL (0 => tile skipped: bg only) */
+void orc_rasterize_2dgs_fwd(int64_t C, int64_t M, int64_t I, int W, int H, int tile_size,
+                            const REAL *means2d, const REAL *ray_transforms, const REAL *colors,
+                            const REAL *opacities, const REAL *normals, const REAL *backgrounds,
+                            const uint8_t *masks, const int32_t *isect_offsets,
+                            const int32_t *flatten_ids, REAL *render_colors, REAL *render_depths,
+                            REAL *render_alphas, REAL *render_normals, REAL *render_median,
+                            int32_t *last_ids, int32_t *median_ids, REAL *visibilities) {
+  int tw = (W + tile_size - 1) / tile_size, th = (H + tile_size - 1) / tile_size;
+  int64_t n_tiles = (int64_t)tw * th;
+  for (int64_t m = 0; m < M; ++m) visibilities[m] = 0;
+#pragma omp parallel for schedule(dynamic, 4)
+  for (int64_t t = 0; t < C * n_tiles; ++t) {
+    int64_t c = t / n_tiles, tl = t % n_tiles;
+    int ty = (int)(tl / tw), tx = (int)(tl % tw);
+    int32_t start = isect_offsets[t];
+    int32_t end = (t == C * n_tiles - 1) ? (int32_t)I : isect_offsets[t + 1];
+    int masked = masks && !masks[t];
+    int32_t len = masked ? 0 : end - start;
+    REAL *vis_local = (REAL *)calloc((size_t)(len > 0 ? len : 1), sizeof(REAL));
+    for (int yy = 0; yy < tile_size; ++yy)
+      for (int xx = 0; xx < tile_size; ++xx) {
+        int i = ty * tile_size + yy, j = tx * tile_size + xx;
+        if (i >= H || j >= W) continue;
+        int64_t pid = (c * H + i) * (int64_t)W + j;
+        REAL px = (REAL)j + (REAL)0.5, py = (REAL)i + (REAL)0.5;
+        REAL T = 1, col[3] = {0, 0, 0}, nrm[3] = {0, 0, 0}, dsum = 0, med = 0;
+        int32_t cur = 0, med_idx = 0; /* gsplat initialises both to 0 */
+        for (int32_t k = 0; k < len; ++k) {
+          int32_t g = flatten_ids[start + k];
+          pix_eval_t e;
+          eval_pair(px, py, means2d + 2 * g, opacities[g], ray_transforms + 9 * g, &e);
+          if (!e.valid) continue;
+          REAL nT = T * (1 - e.alpha);
+          if (nT <= T_EPS) break;
+          REAL w = e.alpha * T;
+          for (int ch = 0; ch < 3; ++ch) {
+            col[ch] += colors[3 * g + ch] * w;
+            nrm[ch] += normals[3 * g + ch] * w;
+          }
+          dsum += e.dep * w;
+          if (T > (REAL)0.5) { med = e.dep; med_idx = start + k; }
+          if (w > vis_local[k]) vis_local[k] = w;
+          cur = start + k;
+          T = nT;
+        }
+        for (int ch = 0; ch < 3; ++ch) {
+          render_colors[3 * pid + ch] = backgrounds ? col[ch] + T * backgrounds[3 * c + ch] : col[ch];
+          render_normals[3 * pid + ch] = nrm[ch];
+        }
+        render_depths[pid] = dsum;
+        render_alphas[pid] = 1 - T;
+        render_median[pid] = med;
+        last_ids[pid] = cur;
+        median_ids[pid] = med_idx;
+      }
+#pragma omp critical
+    for (int32_t k = 0; k < len; ++k) {
+      int32_t g = flatten_ids[start + k];
+      if (vis_local[k] > visibilities[g]) visibilities[g] = vis_local[k];
+    }
+    free(vis_local);
+  }
+}
+
+/* SPEC A.5: VJP of the compositing.  Gradient buffers [M,.] must be zeroed by the caller.
+ * v_means2d_abs may be NULL.  Gradient outputs are double regardless of REAL (deterministic
+ * per-tile accumulation, cross-tile merge in double). */
+void orc_rasterize_2dgs_bwd(int64_t C, int64_t M, int64_t I, int W, int H, int tile_size,
+                            const REAL *means2d, const REAL *ray_transforms, const REAL *colors,
+                            const REAL *opacities, const REAL *normals, const REAL *backgrounds,
+                            const uint8_t *masks, const int32_t *isect_offsets,
+                            const int32_t *flatten_ids, const REAL *render_alphas,
+                            const int32_t *last_ids, const int32_t *median_ids,
+                            const REAL *v_render_colors, const REAL *v_render_depths,
+                            const REAL *v_render_alphas, const REAL *v_render_normals,
+                            const REAL *v_render_median, double *v_means2d,
+                            double *v_ray_transforms, double *v_colors, double *v_opacities,
+                            double *v_normals, double *v_densify, double *v_means2d_abs) {
+  int tw = (W + tile_size - 1) / tile_size, th = (H + tile_size - 1) / tile_size;
+  int64_t n_tiles = (int64_t)tw * th;
+  (void)M;
+  enum { NG = 22 }; /* per-splat accumulators: xy2 M9 col3 opac1 nrm3 dens2 abs2 */
+#pragma omp parallel for schedule(dynamic, 4)
+  for (int64_t t = 0; t < C * n_tiles; ++t) {
+    int64_t c = t / n_tiles, tl = t % n_tiles;
+    int ty = (int)(tl / tw), tx = (int)(tl % tw);
+    int32_t start = isect_offsets[t];
+    int32_t end = (t == C * n_tiles - 1) ? (int32_t)I : isect_offsets[t + 1];
+    if (masks && !masks[t]) continue;
+    int32_t len = end - start;
+    if (len <= 0) continue;
+    double *acc = (double *)calloc((size_t)len * NG, sizeof(double));
+    for (int yy = 0; yy < tile_size; ++yy)
+      for (int xx = 0; xx < tile_size; ++xx) {
+        int i = ty * tile_size + yy, j = tx * tile_size + xx;
+        if (i >= H || j >= W) continue;
+        int64_t pid = (c * H + i) * (int64_t)W + j;
+        REAL px = (REAL)j + (REAL)0.5, py = (REAL)i + (REAL)0.5;
+        const REAL T_final = 1 - render_alphas[pid];
+        REAL T = T_final;
+        const int32_t bin_final = last_ids[pid], med_idx = median_ids[pid];
+        const REAL *vC = v_render_colors + 3 * pid, *vN = v_render_normals + 3 * pid;
+        const REAL vD = v_render_depths[pid], vA = v_render_alphas[pid], vMed = v_render_median[pid];
+        REAL bufC[3] = {0, 0, 0}, bufN[3] = {0, 0, 0}, bufD = 0;
+        REAL bgdot = 0;
+        if (backgrounds)
+          bgdot = backgrounds[3 * c] * vC[0] + backgrounds[3 * c + 1] * vC[1] + backgrounds[3 * c + 2] * vC[2];
+        for (int32_t idx = bin_final; idx >= start; --idx) {
+          int32_t g = flatten_ids[idx];
+          pix_eval_t e;
+          const REAL *Mrow = ray_transforms + 9 * g;
+          eval_pair(px, py, means2d + 2 * g, opacities[g], Mrow, &e);
+          if (!e.valid) continue;
+          double *a = acc + (size_t)(idx - start) * NG;
+          const REAL ra = 1 / (1 - e.alpha);
+          T *= ra;
+          const REAL fac = e.alpha * T;
+          REAL v_alpha = 0;
+          for (int ch = 0; ch < 3; ++ch) {
+            a[11 + ch] += fac * vC[ch];
+            a[15 + ch] += fac * vN[ch];
+            v_alpha += (colors[3 * g + ch] * T - bufC[ch] * ra) * vC[ch];
+            v_alpha += (normals[3 * g + ch] * T - bufN[ch] * ra) * vN[ch];
+          }
+          v_alpha += (e.dep * T - bufD * ra) * vD;
+          v_alpha += T_final * ra * vA;
+          v_alpha += -T_final * ra * bgdot;
+          REAL v_dep = fac * vD + (idx == med_idx ? vMed : 0);
+          for (int ch = 0; ch < 3; ++ch) {
+            bufC[ch] += colors[3 * g + ch] * fac;
+            bufN[ch] += normals[3 * g + ch] * fac;
+          }
+          bufD += e.dep * fac;
+          REAL v_sigma = 0;
+          if (!e.clamped) {
+            a[14] += e.vis * v_alpha;                 /* v_opacity */
+            v_sigma = -opacities[g] * e.vis * v_alpha; /* d alpha / d sigma */
+          }
+          const REAL *Mw = Mrow + 6;
+          if (e.branch3d) {
+            /* sigma = 0.5 (s.s); dep = s.x Mw.x + s.y Mw.y + Mw.z */
+            REAL v_s[2] = {v_sigma * e.s[0] + v_dep * Mw[0], v_sigma * e.s[1] + v_dep * Mw[1]};
+            REAL vsx = v_s[0] / e.z[2], vsy = v_s[1] / e.z[2];
+            REAL v_z[3] = {vsx, vsy, -(vsx * e.s[0] + vsy * e.s[1])};
+            /* z = hu x hv */
+            REAL v_hu[3] = {e.hv[1] * v_z[2] - e.hv[2] * v_z[1], e.hv[2] * v_z[0] - e.hv[0] * v_z[2],
+                            e.hv[0] * v_z[1] - e.hv[1] * v_z[0]};
+            REAL v_hv[3] = {v_z[1] * e.hu[2] - v_z[2] * e.hu[1], v_z[2] * e.hu[0] - v_z[0] * e.hu[2],
+                            v_z[0] * e.hu[1] - v_z[1] * e.hu[0]};
+            REAL vMw[3] = {px * v_hu[0] + py * v_hv[0] + v_dep * e.s[0],
+                           px * v_hu[1] + py * v_hv[1] + v_dep * e.s[1],
+                           px * v_hu[2] + py * v_hv[2] + v_dep};
+            for (int k = 0; k < 3; ++k) {
+              a[2 + k] += -v_hu[k];
+              a[5 + k] += -v_hv[k];
+              a[8 + k] += vMw[k];
+            }
+            /* densification signal (2DGS: dL/dM[2]*depth, dL/dM[5]*depth) SPEC S-4 */
+            a[18] += -v_hu[2] * Mw[2];
+            a[19] += -v_hv[2] * Mw[2];
+          } else {
+            /* sigma = 0.5*2*(d.d) ; dep = Mw.z */
+            REAL gx = v_sigma * FILTER_INV_SQUARE * e.d[0], gy = v_sigma * FILTER_INV_SQUARE * e.d[1];
+            a[0] += gx; a[1] += gy;
+            a[20] += fabs((double)gx); a[21] += fabs((double)gy);
+            a[10] += v_dep;
+          }
+        }
+      }
+#pragma omp critical
+    for (int32_t k = 0; k < len; ++k) {
+      int32_t g = flatten_ids[start + k];
+      const double *a = acc + (size_t)k * NG;
+      v_means2d[2 * g] += a[0]; v_means2d[2 * g + 1] += a[1];
+      for (int q = 0; q < 9; ++q) v_ray_transforms[9 * g + q] += a[2 + q];
+      for (int q = 0; q < 3; ++q) { v_colors[3 * g + q] += a[11 + q]; v_normals[3 * g + q] += a[15 + q]; }
+      v_opacities[g] += a[14];
+      v_densify[2 * g] += a[18]; v_densify[2 * g + 1] += a[19];
+      if (v_means2d_abs) { v_means2d_abs[2 * g] += a[20]; v_means2d_abs[2 * g + 1] += a[21]; }
+    }
+    free(acc);
+  }
+}
+
+int orc_real_bytes(void) { return (int)sizeof(REAL); }
