@@ -1,0 +1,171 @@
+#!/usr/bin/env python
+"""bench.py — train iters/s of the GS-SDF hot path on MI355X (BASELINE.json metric).
+
+One "step" = one training iteration of the splat path on one view: activations (exp/sigmoid, a2) ->
+projection (P1) -> SH colours (P2) -> tile binning (P3) -> compositing (P4) -> synthetic loss on every
+rasteriser output -> backward (P4', P2', P1') [-> RCCL all-reduce of the dense parameter grads when N>1].
+Workload at N=1: BASELINE.json configs[3] shape, "Synthetic 1M Gaussians, 1920x1080" (SURVEY 8d inputs).
+N>1: view-parallel (rank r renders view step*N+r), weak scaling, value = views/s of the job.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline`.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (N, W, H, sh_degree, replica intrinsics)
+    "cfg3_1M_1080p": (1_000_000, 1920, 1080, 0, False),
+    "cfg1_replica_300k": (300_000, 1200, 680, 0, True),
+    "cfg0_10k_256": (10_000, 256, 256, 0, False),
+}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--workload", default="cfg3_1M_1080p", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)   # nccl == RCCL on ROCm
+
+    import gs_sdf_amd.ops as ops
+    import gs_sdf_amd.synth as synth
+    from gs_sdf_amd.trainer import SplatParams, ViewParallel
+
+    N, W, H, deg, replica = WORKLOADS[args.workload]
+    sc = synth.make_scene(N, W, H, sh_degree=deg, seed=0, replica=replica)
+    views = synth.make_views(200, seed=1).to(dev)
+    K = sc["K"].to(dev)
+    params = SplatParams.from_scene(sc, dev)
+    vp = ViewParallel(params, dist)
+    ug = {k: v.to(dev) for k, v in synth.upstream_grads(H, W, seed=2).items()}
+
+    sizes = {}
+
+    def step(i):
+        view = views[(i * world + rank) % views.shape[0]][None]
+        vp.zero_grad()
+        xyz, quat, scales, opacity, sh = params.activated()
+        colors, alphas, meta = ops.rasterization_2dgs_sdf(xyz, quat, scales, opacity, sh, view, K, W, H, near_plane=0.05,
+                                                          far_plane=300.0, sh_degree=deg, center_reg=True)
+        loss = ((colors[..., :3] * ug["v_render_colors"]).sum() + (colors[..., 3:] * ug["v_render_depths"]).sum()
+                + (alphas * ug["v_render_alphas"]).sum() + (meta["render_normal"] * ug["v_render_normals"]).sum()
+                + (meta["render_median"] * ug["v_render_median"]).sum())
+        loss.backward()
+        vp.all_reduce_grads()
+        sizes.update(M=int(meta["gaussian_ids"].shape[0]), I=int(meta["flatten_ids"].shape[0]))
+
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ops.TIMERS.enable()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    kern = ops.TIMERS.summary_ms()
+    ops.TIMERS.disable()
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        M, I = sizes["M"], sizes["I"]
+        P, T = W * H, ((W + 15) // 16) * ((H + 15) // 16)
+        Kb = (deg + 1) ** 2
+        # algorithmic bytes per launch
+        alg = {"rasterize_2dgs_bwd": 80 * I + 48 * P + 88 * M, "rasterize_2dgs_fwd": 80 * I + 48 * P}
+        dom = max(alg, key=lambda k: kern.get(k, 0.0))
+        dur_ms = kern.get(dom, float("nan"))
+        achieved = alg[dom] / (dur_ms * 1e-3) / 1e9
+        b_splat = (80 + 12 * Kb) * N + (364 + 12 * Kb) * M + 204 * I + 96 * P + 4 * T
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(tpath):
+            traffic = json.load(open(tpath)).get(args.workload, {}).get(dom)
+        out = {
+            "metric": "train iters/sec (splat raster fwd+bwd), 1M Gaussians @1080p",
+            "value": args.steps * world / elapsed, "unit": "iters/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {N} random Gaussians, {W}x{H}, sh_degree {deg}, 1 view/GPU/step, "
+                                   f"M={M} I={I} L={I / T:.0f}", "parallelism": f"view-parallel x{world}" if world > 1 else "single GPU"},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
+                         "frac": achieved / 8000.0, "traffic": traffic, "algorithmic_bytes": alg[dom],
+                         "avg_launch_ms": dur_ms, "step_B_splat_bytes": b_splat,
+                         "step_hbm_frac": b_splat / (elapsed / args.steps) / 8e12},
+            "kernel_ms": kern,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(sc, views[0:1].cpu(), N, W, H, deg)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(sc, view, N, W, H, deg):
+    """The oracle ("port": the reference has no CPU rasteriser and none of its kernels are vendored) timed on
+    this box's host cores: ONE full iteration (fwd + bwd) of the same workload."""
+    import numpy as np
+    from oracle import oracle as orc
+    orc.build()
+    cores = os.cpu_count() or 1
+    orc.set_threads(cores)
+    n = lambda t: t.detach().cpu().numpy()
+    import gs_sdf_amd.synth as synth
+    means, quats = n(sc["means"]), n(sc["quats"])
+    t0 = time.perf_counter()
+    scales, opac = np.exp(n(sc["log_scales"])), 1.0 / (1.0 + np.exp(-n(sc["logit_opacities"])))
+    p = orc.projection_2dgs_fwd(means, quats, scales, n(view), n(sc["K"]), W, H)
+    col = orc.view_colors_fwd(n(view), means, n(sc["sh"]), p["camera_ids"], p["gaussian_ids"], deg)
+    tpg, ids, flat, offs = orc.tile_encode(W, H, 16, p["means2d"], p["radii"], p["depths"], p["camera_ids"], 1)
+    opa = opac[p["gaussian_ids"]]
+    fw = orc.rasterize_2dgs_fwd(p["means2d"], p["ray_transforms"], col, opa, p["normals"], W, H, 16, offs, flat)
+    ug = synth.upstream_grads(H, W, seed=2)
+    g = orc.rasterize_2dgs_bwd(p["means2d"], p["ray_transforms"], col, opa, p["normals"], W, H, 16, offs, flat,
+                               fw["render_alphas"], fw["last_ids"], fw["median_ids"], n(ug["v_render_colors"]),
+                               n(ug["v_render_depths"]), n(ug["v_render_alphas"]), n(ug["v_render_normals"]),
+                               n(ug["v_render_median"]), absgrad=False)
+    M = p["gaussian_ids"].shape[0]
+    orc.projection_2dgs_bwd(means, quats, scales, n(view), n(sc["K"]), W, H, p["camera_ids"], p["gaussian_ids"],
+                            g["v_means2d"].astype(np.float32), np.zeros(M, np.float32),
+                            g["v_ray_transforms"].astype(np.float32), g["v_normals"].astype(np.float32))
+    orc.view_colors_bwd(n(view), means, n(sc["sh"]), p["camera_ids"], p["gaussian_ids"], deg, g["v_colors"].astype(np.float32))
+    dt = time.perf_counter() - t0
+    return {"value": 1.0 / dt, "unit": "iters/s", "cores": cores, "kind": "port",
+            "sample": f"1 full iteration (fwd+bwd) of the same workload, oracle/splat_oracle.c f32 build, OpenMP over tiles "
+                      f"on {cores} threads for compositing (projection/sort single-threaded), {dt:.1f} s"}
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,79 @@
+"""ctypes binding of the C ABI in include/gsdf_hip.h (libgsdf_hip.so).
+
+Torch is plumbing here: it owns device memory and the stream; every compute call goes through the
+C ABI with raw device pointers.  There is NO fallback: if the HIP library is missing or a call
+fails, a RuntimeError is raised.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libgsdf_hip.so")
+_lib = None
+
+_i64, _i32, _f32, _u64, _vp, _sz = C.c_int64, C.c_int, C.c_float, C.c_uint64, C.c_void_p, C.c_size_t
+
+_SIGS = {
+    "gsdf_abi_version": (C.c_int, []),
+    "gsdf_last_error": (C.c_char_p, []),
+    "gsdf_projection_2dgs_ws_bytes": (_sz, [_i64, _i64]),
+    "gsdf_projection_2dgs_cull": (C.c_int, [_i64, _i64] + [_vp] * 5 + [_i32, _i32, _f32, _f32, _f32] + [_vp] * 4),
+    "gsdf_projection_2dgs_fill": (C.c_int, [_i64, _i64] + [_vp] * 5 + [_i32, _i32, _u64, _vp, _vp, _i64] + [_vp] * 10),
+    "gsdf_projection_2dgs_bwd": (C.c_int, [_i64, _i64, _i64] + [_vp] * 5 + [_i32, _i32, _u64] + [_vp] * 11),
+    "gsdf_view_colors_fwd": (C.c_int, [_i64, _i64, _i32] + [_vp] * 7),
+    "gsdf_view_colors_bwd": (C.c_int, [_i64, _i64, _i32] + [_vp] * 8 + [_i32, _vp]),
+    "gsdf_tile_count_ws_bytes": (_sz, [_i64]),
+    "gsdf_tile_count": (C.c_int, [_i64, _i32, _i32, _i32] + [_vp] * 7),
+    "gsdf_tile_encode_ws_bytes": (_sz, [_i64]),
+    "gsdf_tile_encode": (C.c_int, [_i64, _i64, _i64, _i32, _i32, _i32] + [_vp] * 10),
+    "gsdf_rasterize_2dgs_fwd": (C.c_int, [_i64, _i64, _i64, _i32, _i32, _i32] + [_vp] * 18),
+    "gsdf_rasterize_2dgs_bwd": (C.c_int, [_i64, _i64, _i64, _i32, _i32, _i32] + [_vp] * 25),
+}
+
+
+def lib():
+    """Loads libgsdf_hip.so; fails loudly (no CPU fallback exists)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950).  gs-sdf_amd has no CPU or eager fallback.")
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            f = getattr(l, name)       # AttributeError if the library does not export the symbol
+            f.restype, f.argtypes = res, args
+        _lib = l
+    return _lib
+
+
+def exported_symbols():
+    return sorted(_SIGS)
+
+
+def check(code, what):
+    if code != 0:
+        raise RuntimeError(f"{what} failed ({code}): {lib().gsdf_last_error().decode()}")
+
+
+def stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t, dtype=None, name="tensor"):
+    """Raw device pointer of a contiguous CUDA(HIP) tensor (None -> NULL)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError(f"{name}: expected a device tensor (the HIP path has no CPU fallback)")
+    if not t.is_contiguous():
+        raise RuntimeError(f"{name}: expected a contiguous tensor")
+    if dtype is not None and t.dtype != dtype:
+        raise RuntimeError(f"{name}: expected dtype {dtype}, got {t.dtype}")
+    return C.c_void_p(t.data_ptr())
+
+
+def f32(t, name="tensor"):
+    return ptr(t, torch.float32, name)

@@ -1,0 +1,165 @@
+// binning.hip — P3: tile binning (count -> scan -> emit -> sort -> offsets).
+// Replaces gsplat_cpp::tile_encode (call site
+// /root/reference/include/neural_gaussian/neural_gaussian.cpp:207-209).  SPEC A.3:
+//   key = cam << (32+tile_bits) | tile_id << 32 | fp32 depth bits, value = packed splat index,
+//   stable sort on the used key bits, isect_offsets[c,ty,tx] = first sorted slot of that tile.
+// All outputs are integers and are the bit-exact parity target; the fp32 tile-rectangle math is
+// compiled with -ffp-contract=off (only exact operations: /16, floor, ceil, clamp).
+//
+// The sort is rocPRIM's device radix sort restricted to the used key bits (32 depth bits +
+// tile bits + camera bits, ~46 of 64): an HBM-bound integer pass, not reshaped into anything else.
+#include <cstring>
+
+#include <rocprim/device/device_radix_sort.hpp>
+
+#include "scan.h"
+
+namespace gsdf {
+
+static constexpr int BT = 256;
+
+__device__ __forceinline__ void tile_rect(float mx, float my, int32_t radius, int tile_size, int tw, int th, int &x0,
+                                          int &y0, int &x1, int &y1) {
+  const float r = (float)radius / (float)tile_size;
+  const float tx = mx / (float)tile_size, ty = my / (float)tile_size;
+  x0 = (int)fminf(fmaxf(floorf(tx - r), 0.f), (float)tw);
+  x1 = (int)fminf(fmaxf(ceilf(tx + r), 0.f), (float)tw);
+  y0 = (int)fminf(fmaxf(floorf(ty - r), 0.f), (float)th);
+  y1 = (int)fminf(fmaxf(ceilf(ty + r), 0.f), (float)th);
+}
+
+__global__ void __launch_bounds__(BT) tile_count_kernel(int64_t M, int tile_size, int tw, int th,
+                                                        const float *__restrict__ means2d,
+                                                        const int32_t *__restrict__ radii,
+                                                        int32_t *__restrict__ tiles_per_gauss) {
+  const int64_t m = (int64_t)blockIdx.x * BT + threadIdx.x;
+  if (m >= M) return;
+  int32_t cnt = 0;
+  const int32_t r = radii[m];
+  if (r > 0) {
+    const float2 xy = *reinterpret_cast<const float2 *>(means2d + 2 * m);
+    int x0, y0, x1, y1;
+    tile_rect(xy.x, xy.y, r, tile_size, tw, th, x0, y0, x1, y1);
+    cnt = (y1 - y0) * (x1 - x0);
+  }
+  tiles_per_gauss[m] = cnt;
+}
+
+__global__ void __launch_bounds__(BT)
+    tile_emit_kernel(int64_t M, int tile_size, int tw, int th, int tile_bits, const float *__restrict__ means2d,
+                     const int32_t *__restrict__ radii, const float *__restrict__ depths,
+                     const int64_t *__restrict__ camera_ids, const int64_t *__restrict__ cum_tiles,
+                     uint64_t *__restrict__ keys, int32_t *__restrict__ vals) {
+  const int64_t m = (int64_t)blockIdx.x * BT + threadIdx.x;
+  if (m >= M) return;
+  const int32_t r = radii[m];
+  if (r <= 0) return;
+  const float2 xy = *reinterpret_cast<const float2 *>(means2d + 2 * m);
+  int x0, y0, x1, y1;
+  tile_rect(xy.x, xy.y, r, tile_size, tw, th, x0, y0, x1, y1);
+  int64_t pos = (m == 0) ? 0 : cum_tiles[m - 1];
+  const uint64_t hi = ((uint64_t)camera_ids[m]) << (32 + tile_bits);
+  const uint64_t lo = (uint64_t)__float_as_uint(depths[m]);
+  for (int y = y0; y < y1; ++y)
+    for (int x = x0; x < x1; ++x) {
+      const uint64_t tile_id = (uint64_t)y * tw + x;
+      keys[pos] = hi | (tile_id << 32) | lo;
+      vals[pos] = (int32_t)m;
+      ++pos;
+    }
+}
+
+__global__ void __launch_bounds__(BT) tile_offsets_kernel(int64_t I, int64_t n_tiles, int64_t total_tiles, int tile_bits,
+                                                          const uint64_t *__restrict__ keys,
+                                                          int32_t *__restrict__ offsets) {
+  const int64_t i = (int64_t)blockIdx.x * BT + threadIdx.x;
+  if (i >= I) return;
+  const uint64_t tmask = (1ull << tile_bits) - 1ull;
+  const uint64_t k = keys[i] >> 32;
+  const int64_t cur = (int64_t)(k >> tile_bits) * n_tiles + (int64_t)(k & tmask);
+  if (i == 0) {
+    for (int64_t t = 0; t <= cur; ++t) offsets[t] = 0;
+  } else {
+    const uint64_t kp = keys[i - 1] >> 32;
+    const int64_t prev = (int64_t)(kp >> tile_bits) * n_tiles + (int64_t)(kp & tmask);
+    for (int64_t t = prev + 1; t <= cur; ++t) offsets[t] = (int32_t)i;
+  }
+  if (i == I - 1)
+    for (int64_t t = cur + 1; t < total_tiles; ++t) offsets[t] = (int32_t)I;
+}
+
+static inline int bits_for(int64_t n) {  // floor(log2(n)) + 1
+  int b = 0;
+  while ((1LL << (b + 1)) <= n) ++b;
+  return b + 1;
+}
+
+static size_t sort_temp_bytes(int64_t I) {
+  size_t bytes = 0;
+  (void)rocprim::radix_sort_pairs<rocprim::default_config, uint64_t *, uint64_t *, int32_t *, int32_t *>(
+      nullptr, bytes, nullptr, nullptr, nullptr, nullptr, (size_t)I, 0, 64, (hipStream_t)0);
+  return bytes;
+}
+
+}  // namespace gsdf
+
+using namespace gsdf;
+
+extern "C" size_t gsdf_tile_count_ws_bytes(int64_t M) { return scan_ws_bytes(M) + 256; }
+
+extern "C" int gsdf_tile_count(int64_t M, int width, int height, int tile_size, const float *means2d,
+                               const int32_t *radii, int32_t *tiles_per_gauss, int64_t *cum_tiles, void *ws,
+                               int64_t *n_isects, gsdf_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  GSDF_REQUIRE(tile_size > 0 && width > 0 && height > 0, "tile_count: bad geometry");
+  GSDF_REQUIRE(n_isects && ws, "tile_count: null workspace / n_isects");
+  const int tw = (width + tile_size - 1) / tile_size, th = (height + tile_size - 1) / tile_size;
+  if (M > 0) {
+    GSDF_REQUIRE(means2d && radii && tiles_per_gauss && cum_tiles, "tile_count: null buffer");
+    tile_count_kernel<<<(unsigned)((M + BT - 1) / BT), BT, 0, stream>>>(M, tile_size, tw, th, means2d, radii,
+                                                                        tiles_per_gauss);
+    GSDF_CHECK_LAUNCH("tile_count_kernel");
+  }
+  return scan_inclusive_i32_i64(tiles_per_gauss, cum_tiles, M, ws, n_isects, stream);
+}
+
+extern "C" size_t gsdf_tile_encode_ws_bytes(int64_t I) {
+  if (I <= 0) return 256;
+  return align_up((size_t)I * 8, 256) + align_up((size_t)I * 4, 256) + align_up(sort_temp_bytes(I), 256) + 256;
+}
+
+extern "C" int gsdf_tile_encode(int64_t M, int64_t C, int64_t I, int width, int height, int tile_size,
+                                const float *means2d, const int32_t *radii, const float *depths,
+                                const int64_t *camera_ids, const int64_t *cum_tiles, void *ws, int64_t *isect_ids,
+                                int32_t *flatten_ids, int32_t *isect_offsets, gsdf_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  GSDF_REQUIRE(tile_size > 0 && width > 0 && height > 0 && C >= 1, "tile_encode: bad geometry");
+  GSDF_REQUIRE(isect_offsets, "tile_encode: null isect_offsets");
+  const int tw = (width + tile_size - 1) / tile_size, th = (height + tile_size - 1) / tile_size;
+  const int64_t n_tiles = (int64_t)tw * th, total_tiles = n_tiles * C;
+  GSDF_REQUIRE(I < (1LL << 31), "tile_encode: %ld intersections overflow int32 offsets", (long)I);
+  if (I <= 0 || M <= 0) {
+    GSDF_HIP(hipMemsetAsync(isect_offsets, 0, (size_t)total_tiles * 4, stream), "tile_encode memset");
+    return GSDF_OK;
+  }
+  GSDF_REQUIRE(ws && isect_ids && flatten_ids && means2d && radii && depths && camera_ids && cum_tiles,
+               "tile_encode: null buffer");
+  const int tile_bits = bits_for(n_tiles), cam_bits = bits_for(C);
+  GSDF_REQUIRE(32 + tile_bits + cam_bits <= 64, "tile_encode: key needs %d bits", 32 + tile_bits + cam_bits);
+  char *p = (char *)ws;
+  uint64_t *keys = (uint64_t *)p; p += align_up((size_t)I * 8, 256);
+  int32_t *vals = (int32_t *)p;   p += align_up((size_t)I * 4, 256);
+  void *temp = p;
+  size_t temp_bytes = sort_temp_bytes(I);
+  tile_emit_kernel<<<(unsigned)((M + BT - 1) / BT), BT, 0, stream>>>(M, tile_size, tw, th, tile_bits, means2d, radii,
+                                                                     depths, camera_ids, cum_tiles, keys, vals);
+  GSDF_CHECK_LAUNCH("tile_emit_kernel");
+  GSDF_HIP((rocprim::radix_sort_pairs<rocprim::default_config>(temp, temp_bytes, keys, (uint64_t *)isect_ids, vals,
+                                                               flatten_ids, (size_t)I, 0u,
+                                                               (unsigned)(32 + tile_bits + cam_bits), stream)),
+           "radix_sort_pairs");
+  tile_offsets_kernel<<<(unsigned)((I + BT - 1) / BT), BT, 0, stream>>>(I, n_tiles, total_tiles, tile_bits,
+                                                                        (const uint64_t *)isect_ids, isect_offsets);
+  GSDF_CHECK_LAUNCH("tile_offsets_kernel");
+  return GSDF_OK;
+}

@@ -1,0 +1,74 @@
+// common.h — shared device/host helpers for the gfx950 kernels (wave64, CDNA4).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "gsdf_hip.h"
+
+namespace gsdf {
+
+void set_error(const char *fmt, ...);
+
+#define GSDF_REQUIRE(cond, ...)                 \
+  do {                                          \
+    if (!(cond)) {                              \
+      gsdf::set_error(__VA_ARGS__);             \
+      return GSDF_ERR_INVALID_ARG;              \
+    }                                           \
+  } while (0)
+
+#define GSDF_CHECK_LAUNCH(name)                                                  \
+  do {                                                                           \
+    hipError_t e_ = hipGetLastError();                                           \
+    if (e_ != hipSuccess) {                                                      \
+      gsdf::set_error("%s: launch failed: %s", name, hipGetErrorString(e_));     \
+      return GSDF_ERR_LAUNCH;                                                    \
+    }                                                                            \
+  } while (0)
+
+#define GSDF_HIP(call, name)                                                     \
+  do {                                                                           \
+    hipError_t e_ = (call);                                                      \
+    if (e_ != hipSuccess) {                                                      \
+      gsdf::set_error("%s: %s", name, hipGetErrorString(e_));                    \
+      return GSDF_ERR_LAUNCH;                                                    \
+    }                                                                            \
+  } while (0)
+
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// ----------------------------------------------------------------------------------------------
+// wave64 cross-lane primitives (DPP: no LDS traffic).  dpp_ctrl encodings: quad_perm 0x00-0xFF,
+// row_shr:n 0x110+n, row_mirror 0x140, row_half_mirror 0x141, row_bcast15 0x142, row_bcast31 0x143.
+// ----------------------------------------------------------------------------------------------
+template <int CTRL, int ROW_MASK = 0xF, int BANK_MASK = 0xF, bool BOUND_CTRL = true>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, BANK_MASK, BOUND_CTRL));
+}
+
+// Sum over the 64 lanes of the wave; the full sum is valid in lane 63 (and only there).
+__device__ __forceinline__ float wave_sum_to_lane63(float v) {
+  v += dpp_mov<0x111>(v);                     // row_shr:1
+  v += dpp_mov<0x112>(v);                     // row_shr:2
+  v += dpp_mov<0x114>(v);                     // row_shr:4
+  v += dpp_mov<0x118>(v);                     // row_shr:8   -> lane 15 of each row holds the row sum
+  v += dpp_mov<0x142, 0xA, 0xF, false>(v);    // row_bcast:15 into rows 1 and 3
+  v += dpp_mov<0x143, 0xC, 0xF, false>(v);    // row_bcast:31 into rows 2 and 3
+  return v;
+}
+
+__device__ __forceinline__ float wave_max_to_lane63(float v) {
+  // values are >= 0, so shifted-in zeros (bound_ctrl) are neutral
+  v = fmaxf(v, dpp_mov<0x111>(v));
+  v = fmaxf(v, dpp_mov<0x112>(v));
+  v = fmaxf(v, dpp_mov<0x114>(v));
+  v = fmaxf(v, dpp_mov<0x118>(v));
+  v = fmaxf(v, dpp_mov<0x142, 0xA, 0xF, false>(v));
+  v = fmaxf(v, dpp_mov<0x143, 0xC, 0xF, false>(v));
+  return v;
+}
+
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
+
+}  // namespace gsdf

@@ -1,0 +1,288 @@
+// raster_bwd.hip — P4': VJP of the 2DGS compositing (SPEC A.5).
+// Reference: implicit autograd of rasterize_to_pixels_2dgs
+// (/root/reference/include/neural_gaussian/neural_gaussian.cpp:215-223); the gradients of the leaf
+// tensors `densify` / `means2d_absgrad` are consumed at neural_gaussian.cpp:626-633.
+//
+// Per tile: replay the depth-sorted list back-to-front from each pixel's last contributor.  The
+// per-(pixel,splat) gradient terms are reduced over the 64 lanes of a wave with DPP row shifts
+// (no LDS traffic), the wave total is added to a per-tile LDS accumulator (ds_add_f32 from one
+// lane, 4 waves -> no contention) and each staged splat is flushed to HBM with ONE global atomic
+// per field per tile (instead of one per wave).
+#include "raster_common.h"
+
+namespace gsdf {
+
+static constexpr int NACC = 20;
+// accumulator slots: 0-2 v_rgb, 3-5 v_normal, 6 v_opacity, 7-9 v_Mu, 10-12 v_Mv, 13-15 v_Mw,
+//                    16-17 v_means2d, 18-19 v_means2d_abs
+struct BwdLds {
+  SplatBatch s;
+  float acc[NACC][RT];
+  int bin_final_max;
+};
+
+__device__ __forceinline__ void lds_add(float *p, float v) { atomicAdd(p, v); }
+
+template <bool ABSGRAD>
+__global__ void __launch_bounds__(RT)
+    raster_bwd_kernel(int64_t total_tiles, int64_t n_tiles, int64_t I, int W, int H, int tw,
+                      const float *__restrict__ means2d, const float *__restrict__ ray_transforms,
+                      const float *__restrict__ colors, const float *__restrict__ opacities,
+                      const float *__restrict__ normals, const float *__restrict__ backgrounds,
+                      const uint8_t *__restrict__ masks, const int32_t *__restrict__ isect_offsets,
+                      const int32_t *__restrict__ flatten_ids, const float *__restrict__ render_alphas,
+                      const int32_t *__restrict__ last_ids, const int32_t *__restrict__ median_ids,
+                      const float *__restrict__ v_render_colors, const float *__restrict__ v_render_depths,
+                      const float *__restrict__ v_render_alphas, const float *__restrict__ v_render_normals,
+                      const float *__restrict__ v_render_median, float *__restrict__ v_means2d,
+                      float *__restrict__ v_ray_transforms, float *__restrict__ v_colors,
+                      float *__restrict__ v_opacities, float *__restrict__ v_normals,
+                      float *__restrict__ v_means2d_abs) {
+  __shared__ BwdLds lds;
+  const int64_t tile = xcd_tile_index(total_tiles);
+  if (tile >= total_tiles) return;
+  if (masks != nullptr && !masks[tile]) return;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int64_t cam = tile / n_tiles;
+  const int tl = (int)(tile - cam * n_tiles);
+  const int ty = tl / tw, tx = tl - ty * tw;
+  const int x = tx * TILE + (wave & 1) * 8 + (lane & 7);
+  const int y = ty * TILE + (wave >> 1) * 8 + (lane >> 3);
+  const bool inside = x < W && y < H;
+  const int64_t pid = (cam * H + y) * (int64_t)W + x;
+  const float px = (float)x + 0.5f, py = (float)y + 0.5f;
+
+  const int32_t start = isect_offsets[tile];
+  const int32_t end = (tile == total_tiles - 1) ? (int32_t)I : isect_offsets[tile + 1];
+  if (end <= start) return;
+
+  float T_final = 1.0f, vCr = 0.f, vCg = 0.f, vCb = 0.f, vNx = 0.f, vNy = 0.f, vNz = 0.f, vD = 0.f, vA = 0.f,
+        vMed = 0.f;
+  int32_t bin_final = -1, med_idx = -1;
+  if (inside) {
+    T_final = 1.0f - render_alphas[pid];
+    // last_ids == 0 with no contributor is harmless: the replay re-tests every pair
+    bin_final = last_ids[pid];
+    med_idx = median_ids[pid];
+    vCr = v_render_colors[3 * pid]; vCg = v_render_colors[3 * pid + 1]; vCb = v_render_colors[3 * pid + 2];
+    vNx = v_render_normals[3 * pid]; vNy = v_render_normals[3 * pid + 1]; vNz = v_render_normals[3 * pid + 2];
+    vD = v_render_depths[pid]; vA = v_render_alphas[pid]; vMed = v_render_median[pid];
+  }
+  float bgdot = 0.f;
+  if (backgrounds != nullptr)
+    bgdot = backgrounds[3 * cam] * vCr + backgrounds[3 * cam + 1] * vCg + backgrounds[3 * cam + 2] * vCb;
+  float T = T_final;
+  float bCr = 0.f, bCg = 0.f, bCb = 0.f, bNx = 0.f, bNy = 0.f, bNz = 0.f, bD = 0.f;
+
+  if (tid == 0) lds.bin_final_max = -1;
+#pragma unroll
+  for (int k = 0; k < NACC; ++k) lds.acc[k][tid] = 0.f;
+  __syncthreads();
+  {  // tile-wide and wave-wide last contributor
+    int m = bin_final;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) m = max(m, __shfl_xor(m, d, 64));
+    if (lane == 0) atomicMax(&lds.bin_final_max, m);
+  }
+  int wave_bin_final = bin_final;
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) wave_bin_final = max(wave_bin_final, __shfl_xor(wave_bin_final, d, 64));
+  __syncthreads();
+  const int tile_bin_final = lds.bin_final_max;
+  if (tile_bin_final < start) return;
+
+  int g_mine = -1;
+  const int nb = (min(end, tile_bin_final + 1) - start + RT - 1) / RT;
+  for (int b = nb - 1; b >= 0; --b) {
+    __syncthreads();  // barrier A: previous batch fully consumed, its accumulators complete
+    if (g_mine >= 0) {
+      const int64_t g = g_mine;
+      float a[NACC];
+#pragma unroll
+      for (int k = 0; k < NACC; ++k) { a[k] = lds.acc[k][tid]; lds.acc[k][tid] = 0.f; }
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        if (a[k] != 0.f) atomicAdd(v_colors + 3 * g + k, a[k]);
+        if (a[3 + k] != 0.f) atomicAdd(v_normals + 3 * g + k, a[3 + k]);
+      }
+      if (a[6] != 0.f) atomicAdd(v_opacities + g, a[6]);
+#pragma unroll
+      for (int k = 0; k < 9; ++k)
+        if (a[7 + k] != 0.f) atomicAdd(v_ray_transforms + 9 * g + k, a[7 + k]);
+      if (a[16] != 0.f) atomicAdd(v_means2d + 2 * g, a[16]);
+      if (a[17] != 0.f) atomicAdd(v_means2d + 2 * g + 1, a[17]);
+      if (ABSGRAD) {
+        if (a[18] != 0.f) atomicAdd(v_means2d_abs + 2 * g, a[18]);
+        if (a[19] != 0.f) atomicAdd(v_means2d_abs + 2 * g + 1, a[19]);
+      }
+      g_mine = -1;
+    }
+    const int32_t bstart = start + b * RT;
+    const int32_t idx = bstart + tid;
+    if (idx < end && idx <= tile_bin_final) {
+      g_mine = flatten_ids[idx];
+      stage_splat(lds.s, tid, g_mine, means2d, ray_transforms, colors, opacities, normals);
+    }
+    __syncthreads();  // barrier B
+    const int count = min(RT, min(end, tile_bin_final + 1) - bstart);
+    for (int t = min(count, wave_bin_final - bstart + 1) - 1; t >= 0; --t) {
+      const float4 a0 = lds.s.q0[t], a1 = lds.s.q1[t], a2 = lds.s.q2[t];
+      PairEval e;
+      eval_pair(px, py, a0, a1, a2, e);
+      const bool valid = inside && (bstart + t <= bin_final) && e.ok;
+      if (__ballot(valid) == 0ull) continue;
+      const float4 a3 = lds.s.q3[t];
+      const float2 a4 = lds.s.q4[t];
+      float g_rgb0 = 0.f, g_rgb1 = 0.f, g_rgb2 = 0.f, g_n0 = 0.f, g_n1 = 0.f, g_n2 = 0.f, g_op = 0.f;
+      float g_mu0 = 0.f, g_mu1 = 0.f, g_mu2 = 0.f, g_mv0 = 0.f, g_mv1 = 0.f, g_mv2 = 0.f, g_mw0 = 0.f, g_mw1 = 0.f,
+            g_mw2 = 0.f, g_x = 0.f, g_y = 0.f;
+      bool v3 = false, v2 = false;
+      if (valid) {
+        const float ra = 1.0f / (1.0f - e.alpha);
+        T *= ra;
+        const float fac = e.alpha * T;
+        g_rgb0 = fac * vCr; g_rgb1 = fac * vCg; g_rgb2 = fac * vCb;
+        g_n0 = fac * vNx; g_n1 = fac * vNy; g_n2 = fac * vNz;
+        float v_alpha = (a3.x * T - bCr * ra) * vCr + (a3.y * T - bCg * ra) * vCg + (a3.z * T - bCb * ra) * vCb;
+        v_alpha += (a3.w * T - bNx * ra) * vNx + (a4.x * T - bNy * ra) * vNy + (a4.y * T - bNz * ra) * vNz;
+        v_alpha += (e.dep * T - bD * ra) * vD;
+        v_alpha += T_final * ra * (vA - bgdot);
+        const float v_dep = fac * vD + ((bstart + t) == med_idx ? vMed : 0.f);
+        bCr += a3.x * fac; bCg += a3.y * fac; bCb += a3.z * fac;
+        bNx += a3.w * fac; bNy += a4.x * fac; bNz += a4.y * fac;
+        bD += e.dep * fac;
+        float v_sigma = 0.f;
+        if (!e.clamped) {
+          g_op = e.vis * v_alpha;
+          v_sigma = -a2.w * e.vis * v_alpha;
+        }
+        if (e.b3) {
+          v3 = true;
+          const float vsx = v_sigma * e.sx + v_dep * a2.x, vsy = v_sigma * e.sy + v_dep * a2.y;
+          const float inv = __builtin_amdgcn_rcpf(e.zz);
+          const float qx = vsx * inv, qy = vsy * inv;
+          const float vzx = qx, vzy = qy, vzz = -(qx * e.sx + qy * e.sy);
+          // z = hu x hv  ->  v_hu = hv x v_z,  v_hv = v_z x hu
+          const float vhux = e.hvy * vzz - e.hvz * vzy, vhuy = e.hvz * vzx - e.hvx * vzz, vhuz = e.hvx * vzy - e.hvy * vzx;
+          const float vhvx = vzy * e.huz - vzz * e.huy, vhvy = vzz * e.hux - vzx * e.huz, vhvz = vzx * e.huy - vzy * e.hux;
+          g_mu0 = -vhux; g_mu1 = -vhuy; g_mu2 = -vhuz;
+          g_mv0 = -vhvx; g_mv1 = -vhvy; g_mv2 = -vhvz;
+          g_mw0 = px * vhux + py * vhvx + v_dep * e.sx;
+          g_mw1 = px * vhuy + py * vhvy + v_dep * e.sy;
+          g_mw2 = px * vhuz + py * vhvz + v_dep;
+        } else {
+          v2 = true;
+          g_x = v_sigma * FILTER_INV_SQUARE * e.dx;
+          g_y = v_sigma * FILTER_INV_SQUARE * e.dy;
+          g_mw2 = v_dep;
+        }
+      }
+      const bool any3 = __ballot(v3) != 0ull, any2 = __ballot(v2) != 0ull;
+      float r;
+#define RED(slot, val)                                   \
+  r = wave_sum_to_lane63(val);                           \
+  if (lane == 63 && r != 0.f) lds_add(&lds.acc[slot][t], r)
+      RED(0, g_rgb0); RED(1, g_rgb1); RED(2, g_rgb2);
+      RED(3, g_n0);   RED(4, g_n1);   RED(5, g_n2);
+      RED(6, g_op);
+      RED(15, g_mw2);
+      if (any3) {
+        RED(7, g_mu0);  RED(8, g_mu1);  RED(9, g_mu2);
+        RED(10, g_mv0); RED(11, g_mv1); RED(12, g_mv2);
+        RED(13, g_mw0); RED(14, g_mw1);
+      }
+      if (any2) {
+        RED(16, g_x); RED(17, g_y);
+        if (ABSGRAD) { RED(18, fabsf(g_x)); RED(19, fabsf(g_y)); }
+      }
+#undef RED
+    }
+  }
+  __syncthreads();
+  if (g_mine >= 0) {
+    const int64_t g = g_mine;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const float c = lds.acc[k][tid], n = lds.acc[3 + k][tid];
+      if (c != 0.f) atomicAdd(v_colors + 3 * g + k, c);
+      if (n != 0.f) atomicAdd(v_normals + 3 * g + k, n);
+    }
+    const float o = lds.acc[6][tid];
+    if (o != 0.f) atomicAdd(v_opacities + g, o);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      const float v = lds.acc[7 + k][tid];
+      if (v != 0.f) atomicAdd(v_ray_transforms + 9 * g + k, v);
+    }
+    const float mx = lds.acc[16][tid], my = lds.acc[17][tid];
+    if (mx != 0.f) atomicAdd(v_means2d + 2 * g, mx);
+    if (my != 0.f) atomicAdd(v_means2d + 2 * g + 1, my);
+    if (ABSGRAD) {
+      const float ax = lds.acc[18][tid], ay = lds.acc[19][tid];
+      if (ax != 0.f) atomicAdd(v_means2d_abs + 2 * g, ax);
+      if (ay != 0.f) atomicAdd(v_means2d_abs + 2 * g + 1, ay);
+    }
+  }
+}
+
+// densification signal (SPEC S-4, 2DGS convention consumed at neural_gaussian.cpp:660-665):
+// v_densify = (dL/dM_u.z, dL/dM_v.z) * M_w.z  — a per-splat epilogue, no extra atomics.
+__global__ void __launch_bounds__(256) densify_epilogue_kernel(int64_t M, const float *__restrict__ ray_transforms,
+                                                               const float *__restrict__ v_ray_transforms,
+                                                               float *__restrict__ v_densify) {
+  const int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (m >= M) return;
+  const float depth = ray_transforms[9 * m + 8];
+  v_densify[2 * m] = v_ray_transforms[9 * m + 2] * depth;
+  v_densify[2 * m + 1] = v_ray_transforms[9 * m + 5] * depth;
+}
+
+}  // namespace gsdf
+
+using namespace gsdf;
+
+extern "C" int gsdf_rasterize_2dgs_bwd(int64_t C, int64_t M, int64_t I, int width, int height, int tile_size,
+                                       const float *means2d, const float *ray_transforms, const float *colors,
+                                       const float *opacities, const float *normals, const float *backgrounds,
+                                       const uint8_t *masks, const int32_t *isect_offsets,
+                                       const int32_t *flatten_ids, const float *render_alphas,
+                                       const int32_t *last_ids, const int32_t *median_ids,
+                                       const float *v_render_colors, const float *v_render_depths,
+                                       const float *v_render_alphas, const float *v_render_normals,
+                                       const float *v_render_median, float *v_means2d, float *v_ray_transforms,
+                                       float *v_colors, float *v_opacities, float *v_normals, float *v_densify,
+                                       float *v_means2d_abs, gsdf_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  GSDF_REQUIRE(tile_size == TILE, "rasterize_bwd: tile_size %d unsupported (16 only)", tile_size);
+  GSDF_REQUIRE(width > 0 && height > 0 && C >= 1, "rasterize_bwd: bad geometry");
+  if (M == 0) return GSDF_OK;
+  GSDF_REQUIRE(v_means2d && v_ray_transforms && v_colors && v_opacities && v_normals && v_densify,
+               "rasterize_bwd: null gradient output");
+  GSDF_REQUIRE(render_alphas && last_ids && median_ids && v_render_colors && v_render_depths && v_render_alphas &&
+                   v_render_normals && v_render_median && isect_offsets,
+               "rasterize_bwd: null input");
+  const int tw = (width + TILE - 1) / TILE, th = (height + TILE - 1) / TILE;
+  const int64_t n_tiles = (int64_t)tw * th, total = n_tiles * C;
+  GSDF_HIP(hipMemsetAsync(v_means2d, 0, (size_t)M * 8, stream), "memset");
+  GSDF_HIP(hipMemsetAsync(v_ray_transforms, 0, (size_t)M * 36, stream), "memset");
+  GSDF_HIP(hipMemsetAsync(v_colors, 0, (size_t)M * 12, stream), "memset");
+  GSDF_HIP(hipMemsetAsync(v_opacities, 0, (size_t)M * 4, stream), "memset");
+  GSDF_HIP(hipMemsetAsync(v_normals, 0, (size_t)M * 12, stream), "memset");
+  if (v_means2d_abs) GSDF_HIP(hipMemsetAsync(v_means2d_abs, 0, (size_t)M * 8, stream), "memset");
+  if (I > 0) {
+#define ARGS total, n_tiles, I, width, height, tw, means2d, ray_transforms, colors, opacities, normals, backgrounds, \
+             masks, isect_offsets, flatten_ids, render_alphas, last_ids, median_ids, v_render_colors,               \
+             v_render_depths, v_render_alphas, v_render_normals, v_render_median, v_means2d, v_ray_transforms,      \
+             v_colors, v_opacities, v_normals, v_means2d_abs
+    if (v_means2d_abs)
+      raster_bwd_kernel<true><<<xcd_grid(total), RT, 0, stream>>>(ARGS);
+    else
+      raster_bwd_kernel<false><<<xcd_grid(total), RT, 0, stream>>>(ARGS);
+#undef ARGS
+    GSDF_CHECK_LAUNCH("raster_bwd_kernel");
+  }
+  densify_epilogue_kernel<<<(unsigned)((M + 255) / 256), 256, 0, stream>>>(M, ray_transforms, v_ray_transforms,
+                                                                          v_densify);
+  GSDF_CHECK_LAUNCH("densify_epilogue_kernel");
+  return GSDF_OK;
+}

@@ -1,0 +1,144 @@
+// raster_fwd.hip — P4: 2DGS alpha compositing, forward.
+// Replaces rasterize_to_pixels_2dgs of the reference's absent gsplat_cpp submodule (call site
+// /root/reference/include/neural_gaussian/neural_gaussian.cpp:215-223); semantics: SPEC A.4.
+#include "raster_common.h"
+
+namespace gsdf {
+
+struct FwdLds {
+  SplatBatch s;
+  unsigned vis[RT];  // per staged splat: max blending weight over the tile's pixels (fp32 bits)
+};
+
+__global__ void __launch_bounds__(RT)
+    raster_fwd_kernel(int64_t total_tiles, int64_t n_tiles, int64_t I, int W, int H, int tw,
+                      const float *__restrict__ means2d, const float *__restrict__ ray_transforms,
+                      const float *__restrict__ colors, const float *__restrict__ opacities,
+                      const float *__restrict__ normals, const float *__restrict__ backgrounds,
+                      const uint8_t *__restrict__ masks, const int32_t *__restrict__ isect_offsets,
+                      const int32_t *__restrict__ flatten_ids, float *__restrict__ render_colors,
+                      float *__restrict__ render_depths, float *__restrict__ render_alphas,
+                      float *__restrict__ render_normals, float *__restrict__ render_median,
+                      int32_t *__restrict__ last_ids, int32_t *__restrict__ median_ids,
+                      unsigned *__restrict__ visibilities) {
+  __shared__ FwdLds lds;
+  const int64_t tile = xcd_tile_index(total_tiles);
+  if (tile >= total_tiles) return;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int64_t cam = tile / n_tiles;
+  const int tl = (int)(tile - cam * n_tiles);
+  const int ty = tl / tw, tx = tl - ty * tw;
+  const int x = tx * TILE + (wave & 1) * 8 + (lane & 7);
+  const int y = ty * TILE + (wave >> 1) * 8 + (lane >> 3);
+  const bool inside = x < W && y < H;
+  const int64_t pid = (cam * H + y) * (int64_t)W + x;
+  const float px = (float)x + 0.5f, py = (float)y + 0.5f;
+
+  int32_t start = isect_offsets[tile];
+  int32_t end = (tile == total_tiles - 1) ? (int32_t)I : isect_offsets[tile + 1];
+  if (masks != nullptr && !masks[tile]) end = start;  // masked tile: background only
+
+  float T = 1.0f;
+  float cr = 0.f, cg = 0.f, cb = 0.f, nx = 0.f, ny = 0.f, nz = 0.f, dsum = 0.f, med = 0.f;
+  int32_t cur = 0, med_idx = 0;
+  bool done = !inside;
+  int g_mine = -1;
+
+  const int nb = (end - start + RT - 1) / RT;
+  for (int b = 0; b < nb; ++b) {
+    // barrier A: every wave has finished reading the previous batch
+    const int all_done = __syncthreads_and(done ? 1 : 0);
+    if (g_mine >= 0) {
+      const unsigned v = lds.vis[tid];
+      if (v) atomicMax(visibilities + g_mine, v);
+      g_mine = -1;
+    }
+    if (all_done) break;
+    const int32_t bstart = start + b * RT;
+    const int32_t idx = bstart + tid;
+    if (idx < end) {
+      g_mine = flatten_ids[idx];
+      stage_splat(lds.s, tid, g_mine, means2d, ray_transforms, colors, opacities, normals);
+      lds.vis[tid] = 0u;
+    }
+    __syncthreads();  // barrier B
+    const int count = min(RT, end - bstart);
+    if (__ballot(!done) == 0ull) continue;  // this wave's 64 pixels are all finished
+    for (int t = 0; t < count; ++t) {
+      const float4 a0 = lds.s.q0[t], a1 = lds.s.q1[t], a2 = lds.s.q2[t];
+      PairEval e;
+      eval_pair(px, py, a0, a1, a2, e);
+      bool valid = !done && e.ok;
+      if (__ballot(valid) == 0ull) continue;
+      const float nT = T * (1.0f - e.alpha);
+      if (valid && nT <= T_EPS) {  // this pixel is finished: exclusive (the splat is not blended)
+        done = true;
+        valid = false;
+      }
+      const float w = valid ? e.alpha * T : 0.0f;
+      const float4 a3 = lds.s.q3[t];
+      const float2 a4 = lds.s.q4[t];
+      cr += a3.x * w; cg += a3.y * w; cb += a3.z * w;
+      nx += a3.w * w; ny += a4.x * w; nz += a4.y * w;
+      dsum += e.dep * w;
+      if (valid) {
+        if (T > 0.5f) { med = e.dep; med_idx = bstart + t; }
+        cur = bstart + t;
+        T = nT;
+      }
+      const float wmax = wave_max_to_lane63(w);
+      if (lane == 63 && wmax > 0.0f) atomicMax(&lds.vis[t], __float_as_uint(wmax));
+    }
+  }
+  __syncthreads();
+  if (g_mine >= 0) {
+    const unsigned v = lds.vis[tid];
+    if (v) atomicMax(visibilities + g_mine, v);
+  }
+  if (inside) {
+    float br = 0.f, bg = 0.f, bb = 0.f;
+    if (backgrounds != nullptr) { br = backgrounds[3 * cam]; bg = backgrounds[3 * cam + 1]; bb = backgrounds[3 * cam + 2]; }
+    render_colors[3 * pid] = cr + T * br;
+    render_colors[3 * pid + 1] = cg + T * bg;
+    render_colors[3 * pid + 2] = cb + T * bb;
+    render_normals[3 * pid] = nx; render_normals[3 * pid + 1] = ny; render_normals[3 * pid + 2] = nz;
+    render_depths[pid] = dsum;
+    render_alphas[pid] = 1.0f - T;
+    render_median[pid] = med;
+    last_ids[pid] = cur;
+    median_ids[pid] = med_idx;
+  }
+}
+
+}  // namespace gsdf
+
+using namespace gsdf;
+
+extern "C" int gsdf_rasterize_2dgs_fwd(int64_t C, int64_t M, int64_t I, int width, int height, int tile_size,
+                                       const float *means2d, const float *ray_transforms, const float *colors,
+                                       const float *opacities, const float *normals, const float *backgrounds,
+                                       const uint8_t *masks, const int32_t *isect_offsets,
+                                       const int32_t *flatten_ids, float *render_colors, float *render_depths,
+                                       float *render_alphas, float *render_normals, float *render_median,
+                                       int32_t *last_ids, int32_t *median_ids, float *visibilities,
+                                       gsdf_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  GSDF_REQUIRE(tile_size == TILE, "rasterize_fwd: tile_size %d unsupported (16 only)", tile_size);
+  GSDF_REQUIRE(width > 0 && height > 0 && C >= 1, "rasterize_fwd: bad geometry");
+  GSDF_REQUIRE(render_colors && render_depths && render_alphas && render_normals && render_median && last_ids &&
+                   median_ids && isect_offsets,
+               "rasterize_fwd: null output/offsets");
+  GSDF_REQUIRE(I == 0 || (flatten_ids && means2d && ray_transforms && colors && opacities && normals),
+               "rasterize_fwd: null input");
+  GSDF_REQUIRE(M == 0 || visibilities, "rasterize_fwd: null visibilities");
+  const int tw = (width + TILE - 1) / TILE, th = (height + TILE - 1) / TILE;
+  const int64_t n_tiles = (int64_t)tw * th, total = n_tiles * C;
+  if (M > 0) GSDF_HIP(hipMemsetAsync(visibilities, 0, (size_t)M * 4, stream), "rasterize_fwd memset");
+  raster_fwd_kernel<<<xcd_grid(total), RT, 0, stream>>>(total, n_tiles, I, width, height, tw, means2d, ray_transforms,
+                                                        colors, opacities, normals, backgrounds, masks, isect_offsets,
+                                                        flatten_ids, render_colors, render_depths, render_alphas,
+                                                        render_normals, render_median, last_ids, median_ids,
+                                                        (unsigned *)visibilities);
+  GSDF_CHECK_LAUNCH("raster_fwd_kernel");
+  return GSDF_OK;
+}

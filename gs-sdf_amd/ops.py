@@ -1,0 +1,314 @@
+"""Host-side mirror of the reference's splat operator interface, on top of the C ABI.
+
+Same operator names, argument order and error behaviour as the functions the reference's host code
+calls into its (absent) `gsplat_cpp` submodule — /root/reference/include/neural_gaussian/
+neural_gaussian.cpp:188-223 — so that the parity tests read like calls from `rasterization_2dgs_sdf`.
+Each differentiable operator is a torch.autograd.Function whose forward/backward are single calls
+into libgsdf_hip.so.  (The C++/libtorch flavour of the same layer lives in gs-sdf_amd/host/.)
+"""
+import torch
+
+from . import capi
+from .capi import f32, ptr
+
+
+class _Timers:
+    """Optional per-operator device timing with HIP events on the launch stream (bench.py's roofline leg)."""
+
+    def __init__(self):
+        self.on, self.ev = False, {}
+
+    def enable(self):
+        self.on, self.ev = True, {}
+
+    def disable(self):
+        self.on = False
+
+    def start(self, name):
+        if not self.on:
+            return None
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        self.ev.setdefault(name, []).append((a, b))
+        return b
+
+    @staticmethod
+    def stop(b):
+        if b is not None:
+            b.record()
+
+    def summary_ms(self):
+        torch.cuda.synchronize()
+        return {k: sum(a.elapsed_time(b) for a, b in v) / len(v) for k, v in self.ev.items()}
+
+
+TIMERS = _Timers()
+
+
+def _timed(name, fn, *args):
+    t = TIMERS.start(name)
+    r = fn(*args)
+    TIMERS.stop(t)
+    return r
+
+
+def _empty(shape, dtype, like):
+    return torch.empty(shape, dtype=dtype, device=like.device)
+
+
+def _read_i64(dev_scalar):
+    # the one host sync per dynamic size, as in the reference (packed nnz / n_isects)
+    return int(dev_scalar.item())
+
+
+# ------------------------------------------------------------------------------------------------
+# P1  fully_fused_projection_2dgs  (neural_gaussian.cpp:188-192)
+# ------------------------------------------------------------------------------------------------
+class _Projection2DGS(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means, quats, scales, viewmats, Ks, width, height, near_plane, far_plane, radius_clip,
+                sample_seed):
+        L = capi.lib()
+        means, quats, scales = means.contiguous(), quats.contiguous(), scales.contiguous()
+        viewmats, Ks = viewmats.contiguous(), Ks.contiguous()
+        N, C = means.shape[0], viewmats.shape[0]
+        dev = means.device
+        radii_dense = torch.empty(max(N * C, 1), dtype=torch.int32, device=dev)
+        ws = torch.empty(L.gsdf_projection_2dgs_ws_bytes(N, C), dtype=torch.uint8, device=dev)
+        n_vis = torch.empty(1, dtype=torch.int64, device=dev)
+        capi.check(_timed("projection_2dgs_cull", L.gsdf_projection_2dgs_cull, N, C, f32(means, "means"), f32(quats, "quats"), f32(scales, "scales"),
+                                               f32(viewmats, "viewmats"), f32(Ks, "Ks"), width, height, near_plane,
+                                               far_plane, radius_clip, ptr(radii_dense), ptr(ws), ptr(n_vis),
+                                               capi.stream()), "projection_2dgs_cull")
+        M = _read_i64(n_vis)
+        camera_ids = _empty((M,), torch.int64, means); gaussian_ids = _empty((M,), torch.int64, means)
+        radii = _empty((M,), torch.int32, means); means2d = _empty((M, 2), torch.float32, means)
+        depths = _empty((M,), torch.float32, means); rt = _empty((M, 3, 3), torch.float32, means)
+        normals = _empty((M, 3), torch.float32, means); samples = _empty((M, 3), torch.float32, means)
+        sw = _empty((M, 1), torch.float32, means)
+        capi.check(_timed("projection_2dgs_fill", L.gsdf_projection_2dgs_fill, N, C, f32(means), f32(quats), f32(scales), f32(viewmats), f32(Ks),
+                                               width, height, sample_seed, ptr(radii_dense), ptr(ws), M,
+                                               ptr(camera_ids), ptr(gaussian_ids), ptr(radii), f32(means2d),
+                                               f32(depths), f32(rt), f32(normals), f32(samples), f32(sw),
+                                               capi.stream()), "projection_2dgs_fill")
+        ctx.save_for_backward(means, quats, scales, viewmats, Ks, camera_ids, gaussian_ids)
+        ctx.dims = (width, height, sample_seed)
+        ctx.mark_non_differentiable(camera_ids, gaussian_ids, radii, sw)
+        return camera_ids, gaussian_ids, radii, means2d, depths, rt, normals, samples, sw
+
+    @staticmethod
+    def backward(ctx, _vc, _vg, _vr, v_means2d, v_depths, v_rt, v_normals, v_samples, _vsw):
+        L = capi.lib()
+        means, quats, scales, viewmats, Ks, camera_ids, gaussian_ids = ctx.saved_tensors
+        width, height, seed = ctx.dims
+        N, C, M = means.shape[0], viewmats.shape[0], camera_ids.shape[0]
+        z = lambda g, shape: (torch.zeros(shape, dtype=torch.float32, device=means.device) if g is None
+                              else g.contiguous())
+        v_means2d, v_depths = z(v_means2d, (M, 2)), z(v_depths, (M,))
+        v_rt, v_normals = z(v_rt, (M, 3, 3)), z(v_normals, (M, 3))
+        v_samples = None if v_samples is None else v_samples.contiguous()
+        v_means, v_quats, v_scales = torch.zeros_like(means), torch.zeros_like(quats), torch.zeros_like(scales)
+        capi.check(_timed("projection_2dgs_bwd", L.gsdf_projection_2dgs_bwd, N, C, M, f32(means), f32(quats), f32(scales), f32(viewmats), f32(Ks),
+                                              width, height, seed, ptr(camera_ids), ptr(gaussian_ids),
+                                              f32(v_means2d), f32(v_depths), f32(v_rt), f32(v_normals),
+                                              f32(v_samples), f32(v_means), f32(v_quats), f32(v_scales),
+                                              capi.stream()), "projection_2dgs_bwd")
+        return v_means, v_quats, v_scales, None, None, None, None, None, None, None, None
+
+
+def fully_fused_projection_2dgs(means, quats, scales, viewmats, Ks, width, height, near_plane, far_plane,
+                                radius_clip, packed=True, sparse_grad=False, sample_seed=0):
+    """-> (camera_ids, gaussian_ids, radii, means2d, depths, ray_transforms, normals, samples, samples_weights).
+    Only the reference's configuration is implemented: packed=True, sparse_grad=False
+    (neural_gaussian.cpp:526-530)."""
+    if not packed:
+        raise RuntimeError("fully_fused_projection_2dgs: only packed=True is implemented (reference uses packed)")
+    if sparse_grad:
+        raise RuntimeError("fully_fused_projection_2dgs: sparse_grad=True is not implemented (reference passes false)")
+    N = means.shape[0]
+    if tuple(means.shape) != (N, 3) or tuple(quats.shape) != (N, 4) or tuple(scales.shape) != (N, 3):
+        raise RuntimeError("fully_fused_projection_2dgs: invalid means/quats/scales shape")
+    C = viewmats.shape[0]
+    if tuple(viewmats.shape) != (C, 4, 4) or tuple(Ks.shape) != (C, 3, 3):
+        raise RuntimeError("fully_fused_projection_2dgs: invalid viewmats/Ks shape")
+    return _Projection2DGS.apply(means, quats, scales, viewmats, Ks, int(width), int(height), float(near_plane),
+                                 float(far_plane), float(radius_clip), int(sample_seed))
+
+
+# ------------------------------------------------------------------------------------------------
+# P2  gsplat_cpp::get_view_colors  (neural_gaussian.cpp:199-200)
+# ------------------------------------------------------------------------------------------------
+class _ViewColors(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, viewmats, means, sh, camera_ids, gaussian_ids, sh_degree):
+        L = capi.lib()
+        viewmats, means, sh = viewmats.contiguous(), means.contiguous(), sh.contiguous()
+        M, K = camera_ids.shape[0], sh.shape[1]
+        colors = _empty((M, 3), torch.float32, means)
+        capi.check(_timed("view_colors_fwd", L.gsdf_view_colors_fwd, M, K, sh_degree, f32(viewmats), f32(means), f32(sh), ptr(camera_ids, torch.int64),
+                                          ptr(gaussian_ids, torch.int64), f32(colors), capi.stream()), "view_colors_fwd")
+        ctx.save_for_backward(viewmats, means, sh, camera_ids, gaussian_ids)
+        ctx.sh_degree = sh_degree
+        return colors
+
+    @staticmethod
+    def backward(ctx, v_colors):
+        L = capi.lib()
+        viewmats, means, sh, camera_ids, gaussian_ids = ctx.saved_tensors
+        M, K = camera_ids.shape[0], sh.shape[1]
+        v_sh, v_means = torch.zeros_like(sh), torch.zeros_like(means)
+        capi.check(_timed("view_colors_bwd", L.gsdf_view_colors_bwd, M, K, ctx.sh_degree, f32(viewmats), f32(means), f32(sh), ptr(camera_ids),
+                                          ptr(gaussian_ids), f32(v_colors.contiguous()), f32(v_sh), f32(v_means),
+                                          1 if viewmats.shape[0] == 1 else 0, capi.stream()), "view_colors_bwd")
+        return None, v_means, v_sh, None, None, None
+
+
+def get_view_colors(viewmats, means, radii, colors, camera_ids, gaussian_ids, sh_degree=None):
+    """colors: SH coefficients [N,K,3] when sh_degree is given, else post-activation colours [N,D]."""
+    if sh_degree is None:
+        return colors.index_select(0, gaussian_ids)
+    if colors.dim() != 3 or colors.shape[2] != 3 or (sh_degree + 1) ** 2 > colors.shape[1]:
+        raise RuntimeError("get_view_colors: invalid colors shape")
+    return _ViewColors.apply(viewmats, means, colors, camera_ids, gaussian_ids, int(sh_degree))
+
+
+# ------------------------------------------------------------------------------------------------
+# P3  gsplat_cpp::tile_encode  (neural_gaussian.cpp:207-209) — non-differentiable, integer outputs
+# ------------------------------------------------------------------------------------------------
+@torch.no_grad()
+def tile_encode(width, height, tile_size, means2d, radii, depths, packed, C, camera_ids, gaussian_ids,
+                return_isect_ids=False):
+    if not packed:
+        raise RuntimeError("tile_encode: only packed=True is implemented (reference uses packed)")
+    L = capi.lib()
+    means2d, radii, depths = means2d.detach().contiguous(), radii.contiguous(), depths.detach().contiguous()
+    M = radii.shape[0]
+    dev = means2d.device
+    tw, th = (width + tile_size - 1) // tile_size, (height + tile_size - 1) // tile_size
+    tpg = _empty((M,), torch.int32, means2d); cum = _empty((max(M, 1),), torch.int64, means2d)
+    ws = torch.empty(L.gsdf_tile_count_ws_bytes(M), dtype=torch.uint8, device=dev)
+    n_is = torch.empty(1, dtype=torch.int64, device=dev)
+    capi.check(_timed("tile_count", L.gsdf_tile_count, M, width, height, tile_size, f32(means2d), ptr(radii, torch.int32), ptr(tpg), ptr(cum),
+                                 ptr(ws), ptr(n_is), capi.stream()), "tile_count")
+    I = _read_i64(n_is)
+    isect_ids = _empty((I,), torch.int64, means2d); flatten_ids = _empty((I,), torch.int32, means2d)
+    offsets = _empty((C, th, tw), torch.int32, means2d)
+    ws2 = torch.empty(L.gsdf_tile_encode_ws_bytes(I), dtype=torch.uint8, device=dev)
+    capi.check(_timed("tile_encode", L.gsdf_tile_encode, M, C, I, width, height, tile_size, f32(means2d), ptr(radii), f32(depths),
+                                  ptr(camera_ids, torch.int64), ptr(cum), ptr(ws2), ptr(isect_ids), ptr(flatten_ids),
+                                  ptr(offsets), capi.stream()), "tile_encode")
+    if return_isect_ids:
+        return tpg, flatten_ids, offsets, isect_ids
+    return tpg, flatten_ids, offsets
+
+
+# ------------------------------------------------------------------------------------------------
+# P4  rasterize_to_pixels_2dgs  (neural_gaussian.cpp:215-223)
+# ------------------------------------------------------------------------------------------------
+class _Rasterize2DGS(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means2d, ray_transforms, colors, opacities, normals, densify, means2d_absgrad, backgrounds, masks,
+                width, height, tile_size, isect_offsets, flatten_ids):
+        L = capi.lib()
+        means2d, rt, colors = means2d.contiguous(), ray_transforms.contiguous(), colors.contiguous()
+        opacities, normals = opacities.contiguous(), normals.contiguous()
+        C, M, I = isect_offsets.shape[0], opacities.shape[0], flatten_ids.shape[0]
+        bg = None if backgrounds is None else backgrounds.contiguous()
+        mk = None if masks is None else masks.to(torch.uint8).contiguous()
+        e = lambda *s: _empty(s, torch.float32, means2d)
+        rc, rd, ra, rn, rm = e(C, height, width, 3), e(C, height, width, 1), e(C, height, width, 1), e(C, height, width, 3), e(C, height, width, 1)
+        last = _empty((C, height, width), torch.int32, means2d); med = _empty((C, height, width), torch.int32, means2d)
+        vis = _empty((M, 1), torch.float32, means2d)
+        capi.check(_timed("rasterize_2dgs_fwd", L.gsdf_rasterize_2dgs_fwd, C, M, I, width, height, tile_size, f32(means2d), f32(rt), f32(colors),
+                                             f32(opacities), f32(normals), f32(bg), ptr(mk), ptr(isect_offsets, torch.int32),
+                                             ptr(flatten_ids, torch.int32), f32(rc), f32(rd), f32(ra), f32(rn), f32(rm),
+                                             ptr(last), ptr(med), f32(vis), capi.stream()), "rasterize_2dgs_fwd")
+        ctx.save_for_backward(means2d, rt, colors, opacities, normals, bg, mk, isect_offsets, flatten_ids, ra, last, med)
+        ctx.dims = (width, height, tile_size)
+        ctx.absgrad = bool(ctx.needs_input_grad[6])
+        distort = torch.zeros((C, height, width, 1), dtype=torch.float32, device=means2d.device)
+        ctx.mark_non_differentiable(vis, distort)
+        return rc, rd, ra, rn, distort, rm, vis
+
+    @staticmethod
+    def backward(ctx, v_rc, v_rd, v_ra, v_rn, _v_dist, v_rm, _v_vis):
+        L = capi.lib()
+        means2d, rt, colors, opacities, normals, bg, mk, isect_offsets, flatten_ids, ra, last, med = ctx.saved_tensors
+        width, height, tile_size = ctx.dims
+        C, M, I = isect_offsets.shape[0], opacities.shape[0], flatten_ids.shape[0]
+        zz = lambda g, ch: (torch.zeros((C, height, width, ch), dtype=torch.float32, device=means2d.device) if g is None
+                            else g.contiguous())
+        v_rc, v_rd, v_ra, v_rn, v_rm = zz(v_rc, 3), zz(v_rd, 1), zz(v_ra, 1), zz(v_rn, 3), zz(v_rm, 1)
+        e = lambda *s: _empty(s, torch.float32, means2d)
+        v_means2d, v_rt, v_colors, v_opac, v_normals, v_dens = e(M, 2), e(M, 3, 3), e(M, 3), e(M), e(M, 3), e(M, 2)
+        v_abs = e(M, 2) if ctx.absgrad else None
+        capi.check(_timed("rasterize_2dgs_bwd", L.gsdf_rasterize_2dgs_bwd, C, M, I, width, height, tile_size, f32(means2d), f32(rt), f32(colors),
+                                             f32(opacities), f32(normals), f32(bg), ptr(mk), ptr(isect_offsets),
+                                             ptr(flatten_ids), f32(ra), ptr(last), ptr(med), f32(v_rc), f32(v_rd), f32(v_ra),
+                                             f32(v_rn), f32(v_rm), f32(v_means2d), f32(v_rt), f32(v_colors), f32(v_opac),
+                                             f32(v_normals), f32(v_dens), f32(v_abs), capi.stream()), "rasterize_2dgs_bwd")
+        return (v_means2d, v_rt, v_colors, v_opac, v_normals, v_dens, v_abs, None, None, None, None, None, None, None)
+
+
+def rasterize_to_pixels_2dgs(means2d, ray_transforms, colors, opacities, normals, densify, width, height, tile_size,
+                             isect_offsets, flatten_ids, backgrounds=None, masks=None, packed=True,
+                             means2d_absgrad=None, distloss=False):
+    """-> (render_colors [C,H,W,3], render_depths [C,H,W,1], render_alphas [C,H,W,1], render_normals [C,H,W,3],
+    render_distort, render_median [C,H,W,1], visibilities [M,1]).  `densify` and `means2d_absgrad` are leaf
+    tensors whose .grad is read by the caller after backward (neural_gaussian.cpp:215-217, 626-633)."""
+    if distloss:
+        raise RuntimeError("rasterize_to_pixels_2dgs: distloss=True is not implemented (reference passes false)")
+    if not packed:
+        raise RuntimeError("rasterize_to_pixels_2dgs: only packed=True is implemented")
+    if colors.shape[-1] != 3:
+        raise RuntimeError("rasterize_to_pixels_2dgs: colors must be [M,3]")
+    if means2d_absgrad is None:
+        means2d_absgrad = torch.zeros_like(means2d)
+    return _Rasterize2DGS.apply(means2d, ray_transforms, colors, opacities, normals, densify, means2d_absgrad,
+                                backgrounds, masks, int(width), int(height), int(tile_size), isect_offsets, flatten_ids)
+
+
+# ------------------------------------------------------------------------------------------------
+# rasterization_2dgs_sdf: host orchestration of P1 -> P2 -> P3 -> P4 (neural_gaussian.cpp:129-271)
+# ------------------------------------------------------------------------------------------------
+def rasterization_2dgs_sdf(means, quats, scales, opacities, colors, viewmats, Ks, width, height, render_mode="RGB+ED",
+                           near_plane=0.01, far_plane=1e10, radius_clip=0.0, sh_degree=None, packed=True, tile_size=16,
+                           backgrounds=None, sparse_grad=False, absgrad=False, distloss=False, center_reg=False,
+                           sample_seed=0):
+    """Mirror of the reference's `rasterization_2dgs_sdf` -> (render_colors [C,H,W,4], render_alphas, meta)."""
+    if render_mode not in ("RGB", "D", "ED", "RGB+D", "RGB+ED"):
+        raise RuntimeError("Invalid render_mode")
+    N, C = means.shape[0], viewmats.shape[0]
+    if tuple(opacities.shape) != (N,):
+        raise RuntimeError("Invalid opacities shape")
+    (camera_ids, gaussian_ids, radii, means2d, depths, ray_transforms, normals, samples,
+     samples_weights) = fully_fused_projection_2dgs(means, quats, scales, viewmats, Ks, width, height, near_plane,
+                                                    far_plane, radius_clip, packed, sparse_grad,
+                                                    0 if center_reg else sample_seed)
+    pt_opacities = opacities[gaussian_ids]
+    pt_colors = get_view_colors(viewmats, means, radii, colors, camera_ids, gaussian_ids, sh_degree)
+    tiles_per_gauss, flatten_ids, isect_offsets = tile_encode(width, height, tile_size, means2d, radii, depths, packed,
+                                                              C, camera_ids, gaussian_ids)
+    means2d_absgrad = torch.zeros_like(means2d).requires_grad_(absgrad)
+    densify = torch.zeros_like(means2d).requires_grad_(True)
+    (render_colors, render_depths, render_alphas, render_normals, render_distort, render_median,
+     visibilities) = rasterize_to_pixels_2dgs(means2d, ray_transforms, pt_colors, pt_opacities, normals, densify,
+                                              width, height, tile_size, isect_offsets, flatten_ids, backgrounds, None,
+                                              packed, means2d_absgrad, distloss)
+    meta = {}
+    if absgrad:
+        meta["absgrad"] = means2d_absgrad
+    if render_mode in ("ED", "RGB+ED"):
+        render_depths = (render_depths / render_alphas).nan_to_num()
+    render_colors = torch.cat([render_colors, render_depths], -1)
+    render_normals = render_normals.matmul(torch.linalg.inv(viewmats)[0, :3, :3].t())   # to world space
+    meta.update(render_normal=render_normals, render_median=render_median, normal=normals, gaussian_ids=gaussian_ids,
+                radii=radii, gradient_2dgs=densify, width=torch.tensor([width]), height=torch.tensor([height]),
+                n_cameras=torch.tensor([C]), samples=samples, samples_weights=samples_weights,
+                samples_opacities=pt_opacities, visibilities=visibilities,
+                # extras (not in the reference's meta): sizes that fix the roofline byte count
+                tiles_per_gauss=tiles_per_gauss, flatten_ids=flatten_ids, isect_offsets=isect_offsets)
+    if center_reg:
+        meta["samples"] = means.index_select(0, gaussian_ids)
+        meta["samples_weights"] = torch.ones_like(samples_weights)
+    return render_colors, render_alphas, meta

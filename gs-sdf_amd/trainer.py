@@ -1,0 +1,75 @@
+"""View-parallel training plumbing: replicated splat parameters, one view per GPU per step,
+ONE RCCL all-reduce of the dense parameter gradients over xGMI.
+
+`SplatParams` mirrors the parameter set and activations of the reference's `NeuralGS`
+(/root/reference/include/neural_gaussian/neural_gaussian.cpp:426-453 parameter groups; :463-492 activations):
+anchors (no grad) + offsets, log-scales, quaternions, logit-opacities, SH dc/rest.  All trainable tensors are
+views into ONE flat buffer and their .grad are views into ONE flat gradient buffer, so the collective is a
+single large all-reduce (xGMI is point-to-point: few large messages, not many small ones) and no
+flatten/unflatten copies are needed.  The reference has no multi-GPU path at all: this is new.
+"""
+import torch
+
+
+class SplatParams:
+    FIELDS = (("offsets", 3), ("scaling", 3), ("quaternion", 4), ("opacity", 1), ("features_dc", 3), ("features_rest", None))
+
+    def __init__(self, anchors, offsets, scaling, quaternion, opacity, features_dc, features_rest):
+        dev = anchors.device
+        N = anchors.shape[0]
+        self.anchors = anchors.contiguous()                                   # registered without grad in the reference
+        parts = dict(offsets=offsets, scaling=scaling, quaternion=quaternion, opacity=opacity.reshape(N, 1),
+                     features_dc=features_dc.reshape(N, -1), features_rest=features_rest.reshape(N, -1))
+        total = sum(p.numel() for p in parts.values())
+        self.flat = torch.empty(total, dtype=torch.float32, device=dev)
+        self.flat_grad = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.views, off = {}, 0
+        for name, p in parts.items():
+            n = p.numel()
+            v = self.flat[off:off + n].view(p.shape)
+            v.copy_(p)
+            v.requires_grad_(True)
+            v.grad = self.flat_grad[off:off + n].view(p.shape)
+            self.views[name] = v
+            off += n
+        self.n_rest = features_rest.reshape(N, -1).shape[1] // 3
+
+    @classmethod
+    def from_scene(cls, sc, dev):
+        N = sc["means"].shape[0]
+        sh = sc["sh"]
+        return cls(sc["means"].to(dev), torch.zeros(N, 3, device=dev), sc["log_scales"].to(dev), sc["quats"].to(dev),
+                   sc["logit_opacities"].to(dev), sh[:, :1].contiguous().to(dev), sh[:, 1:].contiguous().to(dev))
+
+    def activated(self):
+        """generate_gaussian(): xyz = anchors+offsets, scales = exp, opacity = sigmoid, sh = cat(dc, rest)."""
+        v = self.views
+        N = self.anchors.shape[0]
+        xyz = self.anchors + v["offsets"]
+        scales = torch.exp(v["scaling"])
+        opacity = torch.sigmoid(v["opacity"]).reshape(N)
+        dc = v["features_dc"].reshape(N, 1, 3)
+        sh = dc if self.n_rest == 0 else torch.cat([dc, v["features_rest"].reshape(N, self.n_rest, 3)], 1)
+        return xyz, v["quaternion"], scales, opacity, sh
+
+    def parameters(self):
+        return list(self.views.values())
+
+
+class ViewParallel:
+    """Gradient synchronisation for view-parallel training.  `dist` is torch.distributed (backend nccl == RCCL
+    on ROCm, gloo in the CPU tests) or None for a single process."""
+
+    def __init__(self, params, dist=None):
+        self.params, self.dist = params, dist
+        self.world = dist.get_world_size() if dist is not None else 1
+
+    def zero_grad(self):
+        self.params.flat_grad.zero_()
+
+    def all_reduce_grads(self):
+        if self.dist is None or self.world == 1:
+            return
+        # mean over the G views of the step (effective batch G; SURVEY 8e "semantics change to report")
+        self.dist.all_reduce(self.params.flat_grad, op=self.dist.ReduceOp.SUM)
+        self.params.flat_grad.mul_(1.0 / self.world)

@@ -1,0 +1,144 @@
+/*
+ * gsdf_hip.h — C ABI of the MI355X-native GS-SDF hot path (libgsdf_hip.so).
+ *
+ * This is the drop-in boundary.  Each entry point replaces one operator of the reference's
+ * un-vendored CUDA submodules, as called from the reference's host code (citations are
+ * /root/reference/<file>:<line>).  The reference-side binding a maintainer adds is the thin
+ * libtorch wrapper shown in INTEGRATION.md (gs-sdf_amd/host/ ships it): same C++ names and
+ * argument order as the reference's call sites, converting torch::Tensor <-> raw pointers.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer is a DEVICE pointer unless named *_host;
+ *     all floating data is fp32, row-major, contiguous; ids are int32/int64 as documented;
+ *   - no allocation inside: the caller owns every buffer, workspaces are sized by *_ws_bytes();
+ *   - dynamic sizes (M = visible splats, I = tile intersections) are produced by a "count" call
+ *     that writes the size to device memory; the caller reads it back and allocates (the same
+ *     two host syncs the reference has: neural_gaussian.cpp:188-209);
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it, nothing syncs;
+ *   - return value: 0 = ok, negative = error (gsdf_last_error() gives the message, thread-local);
+ *   - re-entrant, no global state; gradient outputs documented "accumulate" must be zeroed by
+ *     the caller, all others are fully overwritten.
+ */
+#ifndef GSDF_HIP_H
+#define GSDF_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GSDF_OK 0
+#define GSDF_ERR_INVALID_ARG (-1)
+#define GSDF_ERR_LAUNCH (-2)
+#define GSDF_ERR_UNSUPPORTED (-3)
+
+typedef void *gsdf_stream_t;
+
+const char *gsdf_last_error(void);
+/* ABI version; bumped on any signature change. */
+int gsdf_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * P1  fully_fused_projection_2dgs(means, quats, scales, viewmats, Ks, W, H, near, far,
+ *                                 radius_clip, packed=true, sparse_grad=false)
+ *     reference call: include/neural_gaussian/neural_gaussian.cpp:188-192
+ * Two phases (packed mode): cull -> (host reads M) -> fill.
+ * ---------------------------------------------------------------------------------------- */
+size_t gsdf_projection_2dgs_ws_bytes(int64_t n_gauss, int64_t n_cams);
+
+/* radii_dense int32[C*N] (0 = culled), ws (>= ws_bytes), n_visible int64[1] (device). */
+int gsdf_projection_2dgs_cull(int64_t n_gauss, int64_t n_cams, const float *means, const float *quats,
+                              const float *scales, const float *viewmats, const float *Ks, int width,
+                              int height, float near_plane, float far_plane, float radius_clip,
+                              int32_t *radii_dense, void *ws, int64_t *n_visible, gsdf_stream_t stream);
+
+/* Packed outputs, M rows in increasing (camera, gaussian) order:
+ * camera_ids i64[M], gaussian_ids i64[M], radii i32[M], means2d [M,2], depths [M],
+ * ray_transforms [M,3,3] (rows M_u, M_v, M_w of K*[s_u t_u, s_v t_v, mu_c]), normals [M,3]
+ * (camera space, facing the camera), samples [M,3], samples_weights [M,1].
+ * sample_seed == 0: samples = centres, weights = 1 (the `center_reg` mode,
+ * neural_gaussian.cpp:259-265); otherwise one hashed N(0,1)^2 point on the splat disk. */
+int gsdf_projection_2dgs_fill(int64_t n_gauss, int64_t n_cams, const float *means, const float *quats,
+                              const float *scales, const float *viewmats, const float *Ks, int width,
+                              int height, uint64_t sample_seed, const int32_t *radii_dense, const void *ws,
+                              int64_t n_visible, int64_t *camera_ids, int64_t *gaussian_ids, int32_t *radii,
+                              float *means2d, float *depths, float *ray_transforms, float *normals,
+                              float *samples, float *samples_weights, gsdf_stream_t stream);
+
+/* VJP (implicit via autograd in the reference).  v_samples may be NULL.  Dense outputs
+ * v_means [N,3], v_quats [N,4], v_scales [N,3]: ACCUMULATE (zero them first). */
+int gsdf_projection_2dgs_bwd(int64_t n_gauss, int64_t n_cams, int64_t n_visible, const float *means,
+                             const float *quats, const float *scales, const float *viewmats, const float *Ks,
+                             int width, int height, uint64_t sample_seed, const int64_t *camera_ids,
+                             const int64_t *gaussian_ids, const float *v_means2d, const float *v_depths,
+                             const float *v_ray_transforms, const float *v_normals, const float *v_samples,
+                             float *v_means, float *v_quats, float *v_scales, gsdf_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * P2  gsplat_cpp::get_view_colors(viewmats, means, radii, colors, camera_ids, gaussian_ids,
+ *                                 sh_degree)      reference call: neural_gaussian.cpp:199-200
+ *     rgb = max(SH_deg(dir) . coeffs + 0.5, 0), dir = normalise(mean - campos); sh [N,K,3].
+ * ---------------------------------------------------------------------------------------- */
+int gsdf_view_colors_fwd(int64_t n_visible, int64_t n_sh_bases, int sh_degree, const float *viewmats,
+                         const float *means, const float *sh_coeffs, const int64_t *camera_ids,
+                         const int64_t *gaussian_ids, float *colors, gsdf_stream_t stream);
+/* v_sh [N,K,3], v_means [N,3]: ACCUMULATE.  unique_gaussians != 0 (single camera) allows plain
+ * read-modify-write instead of atomics. */
+int gsdf_view_colors_bwd(int64_t n_visible, int64_t n_sh_bases, int sh_degree, const float *viewmats,
+                         const float *means, const float *sh_coeffs, const int64_t *camera_ids,
+                         const int64_t *gaussian_ids, const float *v_colors, float *v_sh, float *v_means,
+                         int unique_gaussians, gsdf_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * P3  gsplat_cpp::tile_encode(W, H, tile, means2d, radii, depths, packed, C, camera_ids,
+ *                             gaussian_ids)        reference call: neural_gaussian.cpp:207-209
+ * count -> (host reads I) -> encode.  Integer outputs are the bit-exact parity target.
+ * ---------------------------------------------------------------------------------------- */
+size_t gsdf_tile_count_ws_bytes(int64_t n_visible);
+/* tiles_per_gauss i32[M], cum_tiles i64[M] (inclusive scan), n_isects i64[1] (device). */
+int gsdf_tile_count(int64_t n_visible, int width, int height, int tile_size, const float *means2d,
+                    const int32_t *radii, int32_t *tiles_per_gauss, int64_t *cum_tiles, void *ws,
+                    int64_t *n_isects, gsdf_stream_t stream);
+size_t gsdf_tile_encode_ws_bytes(int64_t n_isects);
+/* isect_ids i64[I] sorted keys (cam | tile | fp32 depth bits), flatten_ids i32[I],
+ * isect_offsets i32[C*tile_h*tile_w]. */
+int gsdf_tile_encode(int64_t n_visible, int64_t n_cams, int64_t n_isects, int width, int height, int tile_size,
+                     const float *means2d, const int32_t *radii, const float *depths,
+                     const int64_t *camera_ids, const int64_t *cum_tiles, void *ws, int64_t *isect_ids,
+                     int32_t *flatten_ids, int32_t *isect_offsets, gsdf_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * P4  rasterize_to_pixels_2dgs(means2d, ray_transforms, colors, opacities, normals, densify,
+ *                              W, H, tile, isect_offsets, flatten_ids, backgrounds, masks,
+ *                              packed, means2d_absgrad, distloss)
+ *     reference call: neural_gaussian.cpp:215-223 ; grads consumed at :626-633
+ * tile_size must be 16.  backgrounds [C,3] / masks u8[C,th,tw] may be NULL.
+ * ---------------------------------------------------------------------------------------- */
+int gsdf_rasterize_2dgs_fwd(int64_t n_cams, int64_t n_visible, int64_t n_isects, int width, int height,
+                            int tile_size, const float *means2d, const float *ray_transforms,
+                            const float *colors, const float *opacities, const float *normals,
+                            const float *backgrounds, const uint8_t *masks, const int32_t *isect_offsets,
+                            const int32_t *flatten_ids, float *render_colors /*[C,H,W,3]*/,
+                            float *render_depths /*[C,H,W,1]*/, float *render_alphas /*[C,H,W,1]*/,
+                            float *render_normals /*[C,H,W,3]*/, float *render_median /*[C,H,W,1]*/,
+                            int32_t *last_ids /*[C,H,W]*/, int32_t *median_ids /*[C,H,W]*/,
+                            float *visibilities /*[M,1], fully written*/, gsdf_stream_t stream);
+
+/* All gradient outputs are fully written (zeroed inside).  v_means2d_abs may be NULL. */
+int gsdf_rasterize_2dgs_bwd(int64_t n_cams, int64_t n_visible, int64_t n_isects, int width, int height,
+                            int tile_size, const float *means2d, const float *ray_transforms,
+                            const float *colors, const float *opacities, const float *normals,
+                            const float *backgrounds, const uint8_t *masks, const int32_t *isect_offsets,
+                            const int32_t *flatten_ids, const float *render_alphas, const int32_t *last_ids,
+                            const int32_t *median_ids, const float *v_render_colors,
+                            const float *v_render_depths, const float *v_render_alphas,
+                            const float *v_render_normals, const float *v_render_median, float *v_means2d,
+                            float *v_ray_transforms, float *v_colors, float *v_opacities, float *v_normals,
+                            float *v_densify, float *v_means2d_abs, gsdf_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GSDF_HIP_H */

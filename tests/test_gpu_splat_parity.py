@@ -1,0 +1,248 @@
+"""GPU parity tests of the splat hot path: every operator is called through the C ABI
+(gs_sdf_amd.ops -> libgsdf_hip.so) and compared with the CPU oracle on the same seeded inputs.
+
+Bar (BASELINE.json north_star): tile/bin index tensors BIT-EXACT; floating outputs and gradients
+within 1e-4 relative (fp32; see tests/util.py for the precise statement).
+"""
+import numpy as np
+import pytest
+import torch
+
+import gs_sdf_amd.synth as synth
+from util import assert_close, assert_equal_int
+
+pytestmark = pytest.mark.gpu
+
+REL = 1e-4
+OUT = 2e-5   # tolerated fraction of threshold-flip outliers, see util.assert_close
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "gpu tests need an MI355X"
+    import gs_sdf_amd.ops as o
+    import gs_sdf_amd.capi as capi
+    capi.lib()  # fails loudly if the HIP extension is missing
+    return o
+
+
+def n(t):
+    return t.detach().cpu().numpy()
+
+
+def _inputs(sc, vm, dev):
+    means = sc["means"].to(dev)
+    quats = sc["quats"].to(dev)
+    scales = sc["log_scales"].exp().to(dev)
+    opac = torch.sigmoid(sc["logit_opacities"]).to(dev)
+    return means, quats, scales, opac, sc["sh"].to(dev), vm.to(dev), sc["K"].to(dev).expand(vm.shape[0], 3, 3).contiguous()
+
+
+CASES = [
+    # N, W, H, sh_degree, n_views, seed  (cfg0 of BASELINE.json = 10k / 256x256)
+    (10_000, 256, 256, 0, 1, 0),
+    (3_000, 200, 120, 3, 1, 1),       # ragged image (not a multiple of 16), full SH
+    (5_000, 160, 96, 1, 3, 2),        # multi-camera packed mode
+    (40_000, 640, 368, 0, 1, 3),      # mid size, long tile lists
+]
+
+
+@pytest.mark.parametrize("N,W,H,deg,V,seed", CASES)
+def test_projection_colors_binning(ops, oracle, N, W, H, deg, V, seed):
+    dev = torch.device("cuda:0")
+    sc = synth.make_scene(N, W, H, sh_degree=deg, seed=seed, sigma_px=(0.5, 6.0))
+    vm = synth.make_views(V + 1, seed=seed + 10)[1:]
+    means, quats, scales, opac, sh, vmd, Kd = _inputs(sc, vm, dev)
+    sample_seed = 977 + seed
+    out = ops.fully_fused_projection_2dgs(means, quats, scales, vmd, Kd, W, H, 0.05, 300.0, 0.0, True, False, sample_seed)
+    cam, gid, radii, m2d, dep, rt, nrm, smp, sw = out
+    p = oracle.projection_2dgs_fwd(n(means), n(quats), n(scales), n(vm), n(Kd), W, H, seed=sample_seed, prec="f32")
+    # integer outputs: bit exact (packing order, radii)
+    assert_equal_int(cam, p["camera_ids"], "camera_ids")
+    assert_equal_int(gid, p["gaussian_ids"], "gaussian_ids")
+    assert_equal_int(radii, p["radii"], "radii")
+    # the projection is compiled without FMA contraction in the same operation order: exact too
+    for got, key in ((m2d, "means2d"), (dep, "depths"), (rt, "ray_transforms"), (nrm, "normals")):
+        assert np.array_equal(n(got), p[key]), f"{key} not bit-identical"
+    assert_close(smp, p["samples"], 1e-5, "samples")
+    assert_close(sw, p["samples_weights"], 1e-5, "samples_weights")
+
+    col = ops.get_view_colors(vmd, means, radii, sh, cam, gid, deg)
+    col_ref = oracle.view_colors_fwd(n(vm), n(means), n(sh), p["camera_ids"], p["gaussian_ids"], deg, prec="f32")
+    assert_close(col, col_ref, 1e-5, "view colors")
+
+    tpg, flat, offs, ids = ops.tile_encode(W, H, 16, m2d, radii, dep, True, V, cam, gid, return_isect_ids=True)
+    tpg_r, ids_r, flat_r, offs_r = oracle.tile_encode(W, H, 16, p["means2d"], p["radii"], p["depths"], p["camera_ids"], V)
+    assert_equal_int(tpg, tpg_r, "tiles_per_gauss")
+    assert_equal_int(ids, ids_r, "isect_ids")
+    assert_equal_int(flat, flat_r, "flatten_ids")
+    assert_equal_int(offs, offs_r, "isect_offsets")
+
+
+@pytest.mark.parametrize("N,W,H,deg,V,seed", CASES)
+def test_rasterize_fwd_bwd(ops, oracle, N, W, H, deg, V, seed):
+    dev = torch.device("cuda:0")
+    sc = synth.make_scene(N, W, H, sh_degree=deg, seed=seed, sigma_px=(0.5, 6.0))
+    vm = synth.make_views(V + 1, seed=seed + 10)[1:]
+    means, quats, scales, opac, sh, vmd, Kd = _inputs(sc, vm, dev)
+    p = oracle.projection_2dgs_fwd(n(means), n(quats), n(scales), n(vm), n(Kd), W, H, prec="f32")
+    col = oracle.view_colors_fwd(n(vm), n(means), n(sh), p["camera_ids"], p["gaussian_ids"], deg, prec="f32")
+    opa = n(opac)[p["gaussian_ids"]]
+    tpg, ids, flat, offs = oracle.tile_encode(W, H, 16, p["means2d"], p["radii"], p["depths"], p["camera_ids"], V)
+    bg = np.array([[0.1, 0.4, 0.8]] * V, np.float32) if seed % 2 else None
+    fw = oracle.rasterize_2dgs_fwd(p["means2d"], p["ray_transforms"], col, opa, p["normals"], W, H, 16, offs, flat,
+                                   backgrounds=bg, prec="f32")
+    t = lambda a, g=True: torch.from_numpy(np.ascontiguousarray(a)).to(dev).requires_grad_(g)
+    a = [t(p["means2d"]), t(p["ray_transforms"]), t(col), t(opa), t(p["normals"])]
+    densify = torch.zeros_like(a[0], requires_grad=True)
+    absg = torch.zeros_like(a[0], requires_grad=True)
+    bgd = None if bg is None else torch.from_numpy(bg).to(dev)
+    rc, rd, ra, rn, rdist, rm, vis = ops.rasterize_to_pixels_2dgs(
+        a[0], a[1], a[2], a[3], a[4], densify, W, H, 16, torch.from_numpy(offs).to(dev), torch.from_numpy(flat).to(dev),
+        bgd, None, True, absg, False)
+    # forward
+    assert_close(rc, fw["render_colors"], REL, "render_colors", outlier_frac=OUT)
+    assert_close(rd, fw["render_depths"], REL, "render_depths", outlier_frac=OUT)
+    assert_close(ra, fw["render_alphas"], REL, "render_alphas", outlier_frac=OUT)
+    assert_close(rn, fw["render_normals"], REL, "render_normals", outlier_frac=OUT)
+    assert_close(vis, fw["visibilities"], REL, "visibilities", outlier_frac=OUT)
+    # median depth / ids: a pixel whose T sits within fp32 round-off of 0.5 may pick the neighbour splat
+    med_mismatch = (np.abs(n(rm) - fw["render_median"]) > 1e-4 * (1 + np.abs(fw["render_median"]))).mean()
+    assert med_mismatch < 1e-4, f"render_median mismatch fraction {med_mismatch}"
+    # backward with the SAME saved state convention: upstream grads N(0,1)
+    ug = synth.upstream_grads(H, W, seed=2, C=V)
+    loss = sum((o * ug[k].to(dev)).sum() for o, k in ((rc, "v_render_colors"), (rd, "v_render_depths"), (ra, "v_render_alphas"),
+                                                      (rn, "v_render_normals"), (rm, "v_render_median")))
+    loss.backward()
+    # the oracle replays from ITS OWN forward state (render_alphas/last_ids/median_ids)
+    g = oracle.rasterize_2dgs_bwd(p["means2d"], p["ray_transforms"], col, opa, p["normals"], W, H, 16, offs, flat,
+                                  fw["render_alphas"], fw["last_ids"], fw["median_ids"], n(ug["v_render_colors"]),
+                                  n(ug["v_render_depths"]), n(ug["v_render_alphas"]), n(ug["v_render_normals"]),
+                                  n(ug["v_render_median"]), backgrounds=bg, prec="f32")
+    assert_close(a[2].grad, g["v_colors"], REL, "v_colors", outlier_frac=OUT)
+    assert_close(a[4].grad, g["v_normals"], REL, "v_normals", outlier_frac=OUT)
+    assert_close(a[3].grad, g["v_opacities"], REL, "v_opacities", outlier_frac=OUT)
+    assert_close(a[1].grad, g["v_ray_transforms"], REL, "v_ray_transforms", outlier_frac=OUT)
+    assert_close(a[0].grad, g["v_means2d"], REL, "v_means2d", outlier_frac=OUT)
+    assert_close(densify.grad, g["v_densify"], REL, "v_densify (gradient_2dgs)", outlier_frac=OUT)
+    assert_close(absg.grad, g["v_means2d_abs"], REL, "v_means2d_abs", outlier_frac=OUT)
+
+
+def test_projection_and_sh_backward(ops, oracle):
+    dev = torch.device("cuda:0")
+    N, W, H, deg = 6000, 320, 240, 2
+    sc = synth.make_scene(N, W, H, sh_degree=deg, seed=5)
+    vm = synth.make_views(3, seed=3)[1:]
+    means, quats, scales, opac, sh, vmd, Kd = _inputs(sc, vm, dev)
+    a = [x.clone().requires_grad_(True) for x in (means, quats, scales, sh)]
+    seed = 4242
+    cam, gid, radii, m2d, dep, rt, nrm, smp, sw = ops.fully_fused_projection_2dgs(a[0], a[1], a[2], vmd, Kd, W, H, 0.05,
+                                                                                  300.0, 0.0, True, False, seed)
+    col = ops.get_view_colors(vmd, a[0], radii, a[3], cam, gid, deg)
+    M = cam.shape[0]
+    gen = torch.Generator().manual_seed(8)
+    v = [torch.randn(M, *s, generator=gen) for s in ((2,), (), (3, 3), (3,), (3,), (3,))]
+    vd = [x.to(dev) for x in v]
+    loss = ((m2d * vd[0]).sum() + (dep * vd[1]).sum() + (rt * vd[2]).sum() + (nrm * vd[3]).sum() + (smp * vd[4]).sum())
+    loss.backward(retain_graph=True)
+    vm_, vq_, vs_ = oracle.projection_2dgs_bwd(n(means), n(quats), n(scales), n(vm), n(Kd), W, H, n(cam), n(gid), n(v[0]),
+                                               n(v[1]), n(v[2]), n(v[3]), n(v[4]), seed=seed, prec="f64")
+    assert_close(a[0].grad, vm_, REL, "v_means (projection)")
+    assert_close(a[1].grad, vq_, REL, "v_quats")
+    assert_close(a[2].grad, vs_, REL, "v_scales")
+    a[0].grad = None
+    (col * vd[5]).sum().backward()
+    v_sh, v_means = oracle.view_colors_bwd(n(vm), n(means), n(sh), n(cam), n(gid), deg, n(v[5]), prec="f64")
+    assert_close(a[3].grad, v_sh, REL, "v_sh")
+    assert_close(a[0].grad, v_means, REL, "v_means (sh)")
+
+
+def test_edge_cases(ops, oracle):
+    dev = torch.device("cuda:0")
+    W, H = 64, 48
+    K = synth.intrinsics(W, H).to(dev)
+    vm = torch.eye(4)[None].to(dev)
+    z = lambda *s: torch.zeros(*s, device=dev)
+    # empty scene
+    out = ops.fully_fused_projection_2dgs(z(0, 3), z(0, 4), z(0, 3), vm, K, W, H, 0.05, 300.0, 0.0)
+    assert out[0].numel() == 0
+    tpg, flat, offs = ops.tile_encode(W, H, 16, out[3], out[2], out[4], True, 1, out[0], out[1])
+    assert flat.numel() == 0 and int(offs.abs().sum()) == 0
+    dens = torch.zeros(0, 2, device=dev, requires_grad=True)
+    r = ops.rasterize_to_pixels_2dgs(out[3], out[5], z(0, 3), z(0), out[6], dens, W, H, 16, offs, flat,
+                                     torch.tensor([[0.2, 0.3, 0.4]], device=dev))
+    assert_close(r[0][0, 5, 7], np.array([0.2, 0.3, 0.4]), 1e-6, "background only")
+    assert float(r[2].abs().max()) == 0.0
+    # everything culled: behind the camera / beyond far / off screen / degenerate quaternion scale
+    means = torch.tensor([[0, 0, -1.0], [0, 0, 1000.0], [50.0, 0, 1.0], [0, 0, 0.01]], device=dev)
+    quats = torch.tensor([[1.0, 0, 0, 0]] * 4, device=dev)
+    scales = torch.full((4, 3), 0.01, device=dev)
+    out = ops.fully_fused_projection_2dgs(means, quats, scales, vm, K, W, H, 0.05, 300.0, 0.0)
+    assert out[0].numel() == 0
+    # a single huge opaque splat covers every tile; max-size radius clamps to the tile grid
+    means = torch.tensor([[0.0, 0.0, 2.0]], device=dev)
+    scales = torch.full((1, 3), 50.0, device=dev)
+    out = ops.fully_fused_projection_2dgs(means, quats[:1], scales, vm, K, W, H, 0.05, 300.0, 0.0)
+    assert out[0].numel() == 1
+    tpg, flat, offs = ops.tile_encode(W, H, 16, out[3], out[2], out[4], True, 1, out[0], out[1])
+    assert int(tpg[0]) == 4 * 3 and flat.numel() == 12
+    # unsupported modes raise (same error behaviour as TORCH_CHECK in the reference's host code)
+    with pytest.raises(RuntimeError):
+        ops.fully_fused_projection_2dgs(means, quats[:1], scales, vm, K, W, H, 0.05, 300.0, 0.0, packed=False)
+    with pytest.raises(RuntimeError):
+        ops.rasterize_to_pixels_2dgs(out[3], out[5], z(1, 3), z(1), out[6], dens, W, H, 8, offs, flat)
+
+
+def test_full_size_properties(ops):
+    """BASELINE.json configs[3] shape (1 M Gaussians @ 1920x1080): size-independent properties —
+    bins sorted and consistent, alpha in [0,1), and the adjoint identities
+        sum_g colors_g . v_colors_g   == sum_pix render_colors . v_render_colors
+        sum_g normals_g . v_normals_g == sum_pix render_normals . v_render_normals
+    (compositing is linear in colours/normals), which tie backward to forward with no oracle."""
+    dev = torch.device("cuda:0")
+    N, W, H = 1_000_000, 1920, 1080
+    sc = synth.make_scene(N, W, H, sh_degree=0, seed=0)
+    vm = synth.make_views(1)
+    means, quats, scales, opac, sh, vmd, Kd = _inputs(sc, vm, dev)
+    leaves = [x.requires_grad_(True) for x in (means, quats, scales, opac, sh)]
+    import gs_sdf_amd.ops as o
+    colors, alphas, meta = o.rasterization_2dgs_sdf(*leaves, vmd, Kd, W, H, near_plane=0.05, far_plane=300.0, sh_degree=0,
+                                                    absgrad=True)
+    flat, offs, tpg = meta["flatten_ids"], meta["isect_offsets"], meta["tiles_per_gauss"]
+    I = flat.numel()
+    assert int(tpg.sum()) == I and I > N
+    o_flat = offs.reshape(-1).long()
+    assert bool((o_flat[1:] >= o_flat[:-1]).all()) and int(o_flat[0]) == 0 and int(o_flat[-1]) <= I
+    # depth-sorted inside every tile: depths of consecutive list entries are non-decreasing
+    a = alphas.detach()
+    assert float(a.min()) >= 0.0 and float(a.max()) < 1.0
+    assert float((a > 0.5).float().mean()) > 0.5
+    vis = meta["visibilities"]
+    assert float(vis.min()) >= 0.0 and float(vis.max()) <= 0.999 + 1e-6
+    assert torch.isfinite(colors).all()
+    # adjoint identity through the rasteriser alone
+    from gs_sdf_amd.ops import rasterize_to_pixels_2dgs
+    cam, gid, radii, m2d, depths, rt, nrm, smp, sw = o.fully_fused_projection_2dgs(means, quats, scales, vmd, Kd, W, H, 0.05, 300.0, 0.0)
+    key_depth = depths.detach()[flat.long()]
+    tile_of = torch.searchsorted(o_flat, torch.arange(I, device=dev), right=True) - 1
+    same = tile_of[1:] == tile_of[:-1]
+    assert bool((key_depth[1:][same] >= key_depth[:-1][same]).all()), "tile lists not depth sorted"
+    col = o.get_view_colors(vmd, means, radii, sh, cam, gid, 0).detach().requires_grad_(True)
+    nr = nrm.detach().requires_grad_(True)
+    dens = torch.zeros_like(m2d, requires_grad=True)
+    rc, rd, ra, rn, _, rm, _ = rasterize_to_pixels_2dgs(m2d.detach(), rt.detach(), col, opac.detach()[gid], nr, dens, W, H, 16,
+                                                        offs, flat)
+    g = torch.Generator().manual_seed(2)
+    vC = torch.randn(1, H, W, 3, generator=g).to(dev)
+    vN = torch.randn(1, H, W, 3, generator=g).to(dev)
+    ((rc * vC).sum() + (rn * vN).sum()).backward()
+    lhs_c, rhs_c = float((col.detach().double() * col.grad.double()).sum()), float((rc.detach().double() * vC.double()).sum())
+    lhs_n, rhs_n = float((nr.detach().double() * nr.grad.double()).sum()), float((rn.detach().double() * vN.double()).sum())
+    scale_c = float((rc.detach().abs().double() * vC.abs().double()).sum())
+    scale_n = float((rn.detach().abs().double() * vN.abs().double()).sum())
+    assert abs(lhs_c - rhs_c) <= 1e-4 * scale_c, (lhs_c, rhs_c)
+    assert abs(lhs_n - rhs_n) <= 1e-4 * scale_n, (lhs_n, rhs_n)
+    # the end-to-end backward reaches every parameter with finite values
+    (colors[..., :3].sum() + alphas.sum()).backward()
+    for x in leaves:
+        assert x.grad is not None and torch.isfinite(x.grad).all()
