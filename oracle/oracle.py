@@ -193,3 +193,94 @@ def set_threads(n):
         C.CDLL("libgomp.so.1").omp_set_num_threads(C.c_int(n))
     except OSError:
         pass
+
+
+# ----------------------------------------------------------------------------------------------
+# S1 hash grid / S2 MLP / SDF head / K1 KNN   (oracle/sdf_oracle.c)
+# ----------------------------------------------------------------------------------------------
+GRID_DEFAULT = dict(n_levels=16, n_feat=2, log2_hashmap=19, base_res=32, per_level_scale=2.0)
+
+
+def grid_offsets(cfg=GRID_DEFAULT):
+    offs = np.zeros(cfg["n_levels"] + 1, np.int64)
+    f = _lib("sdf", "f32").orc_grid_offsets
+    f.restype = C.c_int64
+    total = f(C.c_int(cfg["n_levels"]), C.c_int(cfg["n_feat"]), C.c_int(cfg["log2_hashmap"]), C.c_int(cfg["base_res"]),
+              C.c_float(cfg["per_level_scale"]), _p(offs))
+    return offs, int(total)
+
+
+def _gargs(cfg):
+    return (C.c_int(cfg["n_levels"]), C.c_int(cfg["n_feat"]), C.c_int(cfg["log2_hashmap"]), C.c_int(cfg["base_res"]),
+            C.c_float(cfg["per_level_scale"]))
+
+
+def grid_fwd(x, table, cfg=GRID_DEFAULT, want_jac=False, prec="f32"):
+    dt = _dt(prec)
+    x, table = _c(x, dt), _c(table, dt)
+    offs, _ = grid_offsets(cfg)
+    B, D = x.shape[0], cfg["n_levels"] * cfg["n_feat"]
+    feat = np.zeros((B, D), dt)
+    jac = np.zeros((B, D, 3), dt) if want_jac else None
+    _lib("sdf", prec).orc_grid_fwd(C.c_int64(B), *_gargs(cfg), _p(offs), _p(x), _p(table), _p(feat), _p(jac))
+    return (feat, jac) if want_jac else feat
+
+
+def grid_bwd(x, table, v_feat, cfg=GRID_DEFAULT, prec="f32"):
+    dt = _dt(prec)
+    x, table, v_feat = _c(x, dt), _c(table, dt), _c(v_feat, dt)
+    offs, _ = grid_offsets(cfg)
+    v_table = np.zeros(table.shape, np.float64); v_x = np.zeros_like(x)
+    _lib("sdf", prec).orc_grid_bwd(C.c_int64(x.shape[0]), *_gargs(cfg), _p(offs), _p(x), _p(table), _p(v_feat),
+                                   _p(v_table), _p(v_x))
+    return v_table, v_x
+
+
+def grid_bwd_bwd(x, table, v_feat, vv_x, cfg=GRID_DEFAULT, prec="f32"):
+    dt = _dt(prec)
+    x, table, v_feat, vv_x = _c(x, dt), _c(table, dt), _c(v_feat, dt), _c(vv_x, dt)
+    offs, _ = grid_offsets(cfg)
+    g_vfeat = np.zeros_like(v_feat); g_table = np.zeros(table.shape, np.float64); g_x = np.zeros_like(x)
+    _lib("sdf", prec).orc_grid_bwd_bwd(C.c_int64(x.shape[0]), *_gargs(cfg), _p(offs), _p(x), _p(table), _p(v_feat),
+                                       _p(vv_x), _p(g_vfeat), _p(g_table), _p(g_x))
+    return g_vfeat, g_table, g_x
+
+
+def mlp_fwd(x, dims, weights, biases=None, want_acts=False, prec="f32"):
+    dt = _dt(prec)
+    x, weights, biases = _c(x, dt), _c(weights, dt), _c(biases, dt)
+    dims_a = np.asarray(dims, np.int32)
+    B, nl = x.shape[0], len(dims) - 1
+    out = np.zeros((B, dims[-1]), dt)
+    acts = np.zeros((B, int(sum(dims[1:-1]))), dt) if want_acts else None
+    _lib("sdf", prec).orc_mlp_fwd(C.c_int64(B), C.c_int(nl), _p(dims_a), _p(weights), _p(biases), _p(x), _p(out), _p(acts))
+    return (out, acts) if want_acts else out
+
+
+def mlp_bwd(x, dims, weights, biases, v_out, prec="f32"):
+    dt = _dt(prec)
+    x, weights, biases, v_out = _c(x, dt), _c(weights, dt), _c(biases, dt), _c(v_out, dt)
+    dims_a = np.asarray(dims, np.int32)
+    B, nl = x.shape[0], len(dims) - 1
+    v_in = np.zeros_like(x); v_w = np.zeros(weights.shape, np.float64)
+    v_b = np.zeros(biases.shape, np.float64) if biases is not None else None
+    _lib("sdf", prec).orc_mlp_bwd(C.c_int64(B), C.c_int(nl), _p(dims_a), _p(weights), _p(biases), _p(x), _p(v_out),
+                                  _p(v_in), _p(v_w), _p(v_b))
+    return v_in, v_w, v_b
+
+
+def sdf_head(out, inv_bce_sigma, prec="f32"):
+    dt = _dt(prec)
+    out = _c(out, dt)
+    B = out.shape[0]
+    sdf = np.zeros(B, dt); isig = np.zeros(B, dt)
+    _lib("sdf", prec).orc_sdf_head(C.c_int64(B), _r(inv_bce_sigma, prec), _p(out), _p(sdf), _p(isig))
+    return sdf, isig
+
+
+def knn_mean_dist2(pts, prec="f32"):
+    dt = _dt(prec)
+    pts = _c(pts, dt)
+    out = np.zeros(pts.shape[0], dt)
+    _lib("sdf", prec).orc_knn_mean_dist2(C.c_int64(pts.shape[0]), _p(pts), _p(out))
+    return out
