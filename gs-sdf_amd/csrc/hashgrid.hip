@@ -1,0 +1,281 @@
+// hashgrid.hip — S1 / S1' / S1'': multiresolution hash-grid encoding, forward, backward and
+// double backward (the latter is what torch::autograd::grad(create_graph=true) needs for the
+// reference's analytic eikonal term).
+// Replaces tiny-cuda-nn's GridEncoding behind TCNNEncoding::forward
+// (/root/reference/include/neural_net/encoding_map.cpp:15-26 config, :59 call;
+//  second order requested at /root/reference/include/neural_net/local_map.cpp:151-172).
+// Semantics: SPEC A.7 — Hash grid, 3-D, F=2, Linear interpolation, pos = fma(scale,x,0.5),
+// dense index while the stride fits the level's table else prime hash, index % table size.
+//
+// MI355X mapping: one lane per (point, level) with the 16 levels of a point in the 16 consecutive
+// lanes of one DPP row (wave64 = 4 points x 16 levels):
+//   * the 32 output features of a point are 128 contiguous bytes written by one row (coalesced),
+//   * the per-point reductions over levels (d/dx, double-backward d/dx) are DPP row_shr adds —
+//     no atomics, no LDS,
+//   * the only scattered traffic is the 8 x 8-byte corner gathers (and the matching fp32 atomics
+//     of the table gradient), which is the algorithm's compulsory random access; the 61 MB fp32
+//     table is resident in the 256 MiB Infinity Cache.
+#include "common.h"
+
+namespace gsdf {
+
+static constexpr int HG_MAX_LEVELS = 16;
+static constexpr int HG_THREADS = 256;  // 16 points x 16 levels
+
+struct HgLevels {
+  float scale[HG_MAX_LEVELS];
+  uint32_t res[HG_MAX_LEVELS];
+  uint32_t hsize[HG_MAX_LEVELS];
+  uint32_t offset[HG_MAX_LEVELS];  // in entries
+  int n_levels;
+};
+
+static float level_scale_host(int l, float per_level_scale, int base_res) {
+  return exp2f((float)l * log2f(per_level_scale)) * (float)base_res - 1.0f;
+}
+
+static int64_t build_levels(int n_levels, int log2_hashmap, int base_res, float per_level_scale, HgLevels *lv,
+                            int64_t *offsets_out) {
+  int64_t off = 0;
+  for (int l = 0; l < n_levels; ++l) {
+    const float scale = level_scale_host(l, per_level_scale, base_res);
+    const uint32_t res = (uint32_t)ceilf(scale) + 1u;
+    const double dense = pow((double)res, 3.0);
+    const uint64_t max_params = 0xFFFFFFFFu / 2;
+    uint64_t p = dense > (double)max_params ? max_params : (uint64_t)res * res * res;
+    p = (p + 7) / 8 * 8;
+    const uint64_t cap = 1ull << log2_hashmap;
+    if (p > cap) p = cap;
+    if (lv) { lv->scale[l] = scale; lv->res[l] = res; lv->hsize[l] = (uint32_t)p; lv->offset[l] = (uint32_t)off; }
+    if (offsets_out) offsets_out[l] = off;
+    off += (int64_t)p;
+  }
+  if (lv) lv->n_levels = n_levels;
+  if (offsets_out) offsets_out[n_levels] = off;
+  return off;
+}
+
+__device__ __forceinline__ uint32_t grid_index(uint32_t hsize, uint32_t res, uint32_t gx, uint32_t gy, uint32_t gz) {
+  // dense index while the stride still fits the table (tiny-cuda-nn grid_index), else coherent prime hash
+  uint32_t stride = 1, index = 0;
+  if (stride <= hsize) { index += gx * stride; stride *= res; }
+  if (stride <= hsize) { index += gy * stride; stride *= res; }
+  if (stride <= hsize) { index += gz * stride; stride *= res; }
+  if (hsize < stride) index = gx ^ (gy * 2654435761u) ^ (gz * 805459861u);
+  // table sizes are powers of two for every level of the reference configuration (32^3, 64^3, 2^19)
+  return (hsize & (hsize - 1u)) == 0u ? (index & (hsize - 1u)) : (index % hsize);
+}
+
+struct Cell {
+  uint32_t g0[3];
+  float fr[3];
+  float scale;
+  uint32_t res, hsize;
+  const float2 *base;
+};
+
+__device__ __forceinline__ bool load_cell(const HgLevels &lv, int level, const float *__restrict__ x, int64_t b,
+                                          const float *__restrict__ table, Cell &c) {
+  c.scale = lv.scale[level];
+  c.res = lv.res[level];
+  c.hsize = lv.hsize[level];
+  c.base = reinterpret_cast<const float2 *>(table) + lv.offset[level];
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    const float pos = fmaf(c.scale, x[3 * b + d], 0.5f);
+    const float fl = floorf(pos);
+    c.g0[d] = (uint32_t)(int32_t)fl;
+    c.fr[d] = pos - fl;
+  }
+  return true;
+}
+
+// sums `v` over the 16 lanes of a DPP row; the total is valid in the row's last lane (lane & 15 == 15)
+__device__ __forceinline__ float row_sum_to_lane15(float v) {
+  v += dpp_mov<0x111>(v);
+  v += dpp_mov<0x112>(v);
+  v += dpp_mov<0x114>(v);
+  v += dpp_mov<0x118>(v);
+  return v;
+}
+
+__global__ void __launch_bounds__(HG_THREADS)
+    hashgrid_fwd_kernel(int64_t B, HgLevels lv, const float *__restrict__ x, const float *__restrict__ table,
+                        float *__restrict__ feat) {
+  const int level = threadIdx.x & 15;
+  const int64_t b = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+  if (b >= B || level >= lv.n_levels) return;
+  Cell c;
+  load_cell(lv, level, x, b, table, c);
+  float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int hx = k & 1, hy = (k >> 1) & 1, hz = k >> 2;
+    const uint32_t idx = grid_index(c.hsize, c.res, c.g0[0] + hx, c.g0[1] + hy, c.g0[2] + hz);
+    const float w = (hx ? c.fr[0] : 1.f - c.fr[0]) * (hy ? c.fr[1] : 1.f - c.fr[1]) * (hz ? c.fr[2] : 1.f - c.fr[2]);
+    const float2 v = c.base[idx];
+    a0 += w * v.x;
+    a1 += w * v.y;
+  }
+  *reinterpret_cast<float2 *>(feat + (b * lv.n_levels + level) * 2) = make_float2(a0, a1);
+}
+
+template <bool WANT_TABLE, bool WANT_X>
+__global__ void __launch_bounds__(HG_THREADS)
+    hashgrid_bwd_kernel(int64_t B, HgLevels lv, const float *__restrict__ x, const float *__restrict__ table,
+                        const float *__restrict__ v_feat, float *__restrict__ v_table, float *__restrict__ v_x) {
+  const int level = threadIdx.x & 15;
+  const int64_t b = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+  const bool live = b < B && level < lv.n_levels;
+  float gx = 0.f, gy = 0.f, gz = 0.f;
+  if (live) {
+    Cell c;
+    load_cell(lv, level, x, b, table, c);
+    const float2 vf = *reinterpret_cast<const float2 *>(v_feat + (b * lv.n_levels + level) * 2);
+    float2 *vt = reinterpret_cast<float2 *>(v_table) + lv.offset[level];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int hx = k & 1, hy = (k >> 1) & 1, hz = k >> 2;
+      const uint32_t idx = grid_index(c.hsize, c.res, c.g0[0] + hx, c.g0[1] + hy, c.g0[2] + hz);
+      const float wx = hx ? c.fr[0] : 1.f - c.fr[0], wy = hy ? c.fr[1] : 1.f - c.fr[1], wz = hz ? c.fr[2] : 1.f - c.fr[2];
+      if (WANT_TABLE) {
+        const float w = wx * wy * wz;
+        atomicAdd(&vt[idx].x, w * vf.x);
+        atomicAdd(&vt[idx].y, w * vf.y);
+      }
+      if (WANT_X) {
+        const float2 v = c.base[idx];
+        const float t = vf.x * v.x + vf.y * v.y;
+        gx += (hx ? 1.f : -1.f) * wy * wz * t;
+        gy += (hy ? 1.f : -1.f) * wx * wz * t;
+        gz += (hz ? 1.f : -1.f) * wx * wy * t;
+      }
+    }
+    gx *= c.scale; gy *= c.scale; gz *= c.scale;
+  }
+  if (WANT_X) {
+    gx = row_sum_to_lane15(gx); gy = row_sum_to_lane15(gy); gz = row_sum_to_lane15(gz);
+    if (level == 15 && b < B) { v_x[3 * b] = gx; v_x[3 * b + 1] = gy; v_x[3 * b + 2] = gz; }
+  }
+}
+
+// double backward of v_x = J(x,table)^T v_feat: inputs vv_x (the gradient arriving at v_x)
+template <bool WANT_VFEAT, bool WANT_TABLE, bool WANT_X>
+__global__ void __launch_bounds__(HG_THREADS)
+    hashgrid_bwd_bwd_kernel(int64_t B, HgLevels lv, const float *__restrict__ x, const float *__restrict__ table,
+                            const float *__restrict__ v_feat, const float *__restrict__ vv_x,
+                            float *__restrict__ g_vfeat, float *__restrict__ g_table, float *__restrict__ g_x) {
+  const int level = threadIdx.x & 15;
+  const int64_t b = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+  const bool live = b < B && level < lv.n_levels;
+  float ox = 0.f, oy = 0.f, oz = 0.f;
+  if (live) {
+    Cell c;
+    load_cell(lv, level, x, b, table, c);
+    const float2 vf = *reinterpret_cast<const float2 *>(v_feat + (b * lv.n_levels + level) * 2);
+    const float vx = vv_x[3 * b], vy = vv_x[3 * b + 1], vz = vv_x[3 * b + 2];
+    float2 *gt = reinterpret_cast<float2 *>(g_table) + lv.offset[level];
+    float gv0 = 0.f, gv1 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int hx = k & 1, hy = (k >> 1) & 1, hz = k >> 2;
+      const uint32_t idx = grid_index(c.hsize, c.res, c.g0[0] + hx, c.g0[1] + hy, c.g0[2] + hz);
+      const float wx = hx ? c.fr[0] : 1.f - c.fr[0], wy = hy ? c.fr[1] : 1.f - c.fr[1], wz = hz ? c.fr[2] : 1.f - c.fr[2];
+      const float sx = hx ? 1.f : -1.f, sy = hy ? 1.f : -1.f, sz = hz ? 1.f : -1.f;
+      // t = sum_d vv_d * scale * dw/dpos_d
+      const float t = c.scale * (vx * sx * wy * wz + vy * sy * wx * wz + vz * sz * wx * wy);
+      const float2 v = c.base[idx];
+      if (WANT_VFEAT) { gv0 += t * v.x; gv1 += t * v.y; }
+      if (WANT_TABLE) { atomicAdd(&gt[idx].x, t * vf.x); atomicAdd(&gt[idx].y, t * vf.y); }
+      if (WANT_X) {
+        const float q = vf.x * v.x + vf.y * v.y;
+        // sum_d vv_d * d2w/(dpos_d dpos_e): mixed terms only
+        ox += (vy * sy * sx * wz + vz * sz * sx * wy) * q;
+        oy += (vx * sx * sy * wz + vz * sz * sy * wx) * q;
+        oz += (vx * sx * sz * wy + vy * sy * sz * wx) * q;
+      }
+    }
+    if (WANT_VFEAT) *reinterpret_cast<float2 *>(g_vfeat + (b * lv.n_levels + level) * 2) = make_float2(gv0, gv1);
+    const float s2 = c.scale * c.scale;
+    ox *= s2; oy *= s2; oz *= s2;
+  }
+  if (WANT_X) {
+    ox = row_sum_to_lane15(ox); oy = row_sum_to_lane15(oy); oz = row_sum_to_lane15(oz);
+    if (level == 15 && b < B) { g_x[3 * b] = ox; g_x[3 * b + 1] = oy; g_x[3 * b + 2] = oz; }
+  }
+}
+
+}  // namespace gsdf
+
+using namespace gsdf;
+
+static int check_cfg(int n_levels, int n_feat, int log2_hashmap, int base_res, float per_level_scale, const char *who) {
+  GSDF_REQUIRE(n_levels >= 1 && n_levels <= HG_MAX_LEVELS, "%s: n_levels %d not in [1,16]", who, n_levels);
+  GSDF_REQUIRE(n_feat == 2, "%s: n_features_per_level %d unsupported (2 only, as the reference configures)", who, n_feat);
+  GSDF_REQUIRE(log2_hashmap >= 3 && log2_hashmap <= 30 && base_res >= 1 && per_level_scale >= 1.0f,
+               "%s: bad grid configuration", who);
+  return GSDF_OK;
+}
+
+extern "C" int64_t gsdf_hashgrid_offsets(int n_levels, int n_feat, int log2_hashmap, int base_res, float per_level_scale,
+                                         int64_t *offsets_host) {
+  if (check_cfg(n_levels, n_feat, log2_hashmap, base_res, per_level_scale, "hashgrid_offsets") != GSDF_OK) return -1;
+  return build_levels(n_levels, log2_hashmap, base_res, per_level_scale, nullptr, offsets_host);
+}
+
+extern "C" int gsdf_hashgrid_fwd(int64_t B, int n_levels, int n_feat, int log2_hashmap, int base_res,
+                                 float per_level_scale, const float *x, const float *table, float *feat,
+                                 gsdf_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  int rc = check_cfg(n_levels, n_feat, log2_hashmap, base_res, per_level_scale, "hashgrid_fwd");
+  if (rc) return rc;
+  if (B == 0) return GSDF_OK;
+  GSDF_REQUIRE(x && table && feat, "hashgrid_fwd: null buffer");
+  HgLevels lv;
+  build_levels(n_levels, log2_hashmap, base_res, per_level_scale, &lv, nullptr);
+  hashgrid_fwd_kernel<<<(unsigned)((B + 15) / 16), HG_THREADS, 0, stream>>>(B, lv, x, table, feat);
+  GSDF_CHECK_LAUNCH("hashgrid_fwd_kernel");
+  return GSDF_OK;
+}
+
+extern "C" int gsdf_hashgrid_bwd(int64_t B, int n_levels, int n_feat, int log2_hashmap, int base_res,
+                                 float per_level_scale, const float *x, const float *table, const float *v_feat,
+                                 float *v_table, float *v_x, gsdf_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  int rc = check_cfg(n_levels, n_feat, log2_hashmap, base_res, per_level_scale, "hashgrid_bwd");
+  if (rc) return rc;
+  if (B == 0 || (!v_table && !v_x)) return GSDF_OK;
+  GSDF_REQUIRE(x && table && v_feat, "hashgrid_bwd: null buffer");
+  HgLevels lv;
+  build_levels(n_levels, log2_hashmap, base_res, per_level_scale, &lv, nullptr);
+  const unsigned nb = (unsigned)((B + 15) / 16);
+  if (v_table && v_x) hashgrid_bwd_kernel<true, true><<<nb, HG_THREADS, 0, stream>>>(B, lv, x, table, v_feat, v_table, v_x);
+  else if (v_table)   hashgrid_bwd_kernel<true, false><<<nb, HG_THREADS, 0, stream>>>(B, lv, x, table, v_feat, v_table, v_x);
+  else                hashgrid_bwd_kernel<false, true><<<nb, HG_THREADS, 0, stream>>>(B, lv, x, table, v_feat, v_table, v_x);
+  GSDF_CHECK_LAUNCH("hashgrid_bwd_kernel");
+  return GSDF_OK;
+}
+
+extern "C" int gsdf_hashgrid_bwd_bwd(int64_t B, int n_levels, int n_feat, int log2_hashmap, int base_res,
+                                     float per_level_scale, const float *x, const float *table, const float *v_feat,
+                                     const float *vv_x, float *g_vfeat, float *g_table, float *g_x,
+                                     gsdf_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  int rc = check_cfg(n_levels, n_feat, log2_hashmap, base_res, per_level_scale, "hashgrid_bwd_bwd");
+  if (rc) return rc;
+  if (B == 0 || (!g_vfeat && !g_table && !g_x)) return GSDF_OK;
+  GSDF_REQUIRE(x && table && v_feat && vv_x, "hashgrid_bwd_bwd: null buffer");
+  HgLevels lv;
+  build_levels(n_levels, log2_hashmap, base_res, per_level_scale, &lv, nullptr);
+  const unsigned nb = (unsigned)((B + 15) / 16);
+#define L(A, Bq, Cq) hashgrid_bwd_bwd_kernel<A, Bq, Cq><<<nb, HG_THREADS, 0, stream>>>(B, lv, x, table, v_feat, vv_x, g_vfeat, g_table, g_x)
+  const int sel = (g_vfeat ? 4 : 0) | (g_table ? 2 : 0) | (g_x ? 1 : 0);
+  switch (sel) {
+    case 1: L(false, false, true); break;  case 2: L(false, true, false); break; case 3: L(false, true, true); break;
+    case 4: L(true, false, false); break;  case 5: L(true, false, true); break;  case 6: L(true, true, false); break;
+    default: L(true, true, true);
+  }
+#undef L
+  GSDF_CHECK_LAUNCH("hashgrid_bwd_bwd_kernel");
+  return GSDF_OK;
+}

@@ -1,0 +1,395 @@
+// mlp.hip — S2 / S2': fully fused width-64 ReLU decoder MLP on the fp32 MFMA pipe.
+// Replaces tiny-cuda-nn's FullyFusedMLP behind TCNNNetwork::forward
+// (/root/reference/include/neural_net/local_map.cpp:44-55, :94) and offers the same fused path for the
+// reference's default torch::nn::Sequential topology with biases (local_map.cpp:29-42).
+//
+// Numerics: v_mfma_f32_32x32x2_f32 — f32 in, f32 accumulate, bit-equal to an fmaf chain — because the
+// parity bar is 1e-4 on an SDF whose eikonal/curvature terms amplify error (no bf16/fp16 here).
+//
+// MI355X mapping (wave64, one 32-point tile per wave, whole network in registers):
+//   Y^T = W X^T :  A = weights [out i][k],  B = activations [k][point j],  D[out][point].
+//   D's lane layout (col = lane&31 = point, 16 regs = out rows (r&3)+8(r>>2)+4(lane>>5)) is fed straight
+//   back as the next layer's B operand by PERMUTING THE K ORDER: k-step s of the next layer pairs the
+//   neurons the two half-waves already hold in register s, and the weights are staged into LDS in that
+//   permuted order once per workgroup.  No transposes, no LDS round trip of activations, one
+//   conflict-free ds_read_b32 per MFMA.  ReLU/bias are applied on the accumulator registers.
+//   Weight gradients are a separate "tiny-MN, huge-K" MFMA GEMM (K = points) fed by coalesced row loads.
+#include "common.h"
+
+namespace gsdf {
+
+typedef float v16f __attribute__((ext_vector_type(16)));
+
+static constexpr int MLP_THREADS = 256;
+static constexpr int HID = 64;
+static constexpr int MAX_LAYERS = 8;
+
+struct MlpDesc {
+  int n_layers;           // linear layers
+  int d_in;               // 32 or 64
+  int d_out;              // <= 32
+  int w_off[MAX_LAYERS];  // float offset of layer l in the torch-layout weight blob
+  int b_off[MAX_LAYERS];
+  int lds_off[MAX_LAYERS];  // float offset of layer l in the permuted LDS image
+  int has_bias;
+};
+
+// neuron held by (register r, half h) of a 32-row D tile
+__device__ __forceinline__ int d_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+// K permutation of a 64-wide hidden operand: k-step s in [0,32) -> neuron
+__device__ __forceinline__ int perm_hidden(int s, int h) { return 32 * (s >> 4) + d_row(s & 15, h); }
+
+__device__ __forceinline__ v16f mfma32(float a, float b, v16f c) {
+  return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+// ----------------------------------------------------------------------------------------------
+// forward
+// ----------------------------------------------------------------------------------------------
+// LDS image of layer l: [o_tile][k_step][64 lanes] with value W[32*o_tile + (lane&31)][perm(k_step, lane>>5)]
+__device__ void stage_weights_fwd(const MlpDesc &d, const float *__restrict__ W, const float *__restrict__ bias,
+                                  float *lds_w, float *lds_b) {
+  for (int l = 0; l < d.n_layers; ++l) {
+    const int I = l == 0 ? d.d_in : HID;
+    const int O = l == d.n_layers - 1 ? d.d_out : HID;
+    const int otiles = l == d.n_layers - 1 ? 1 : 2;
+    const int ksteps = I / 2;
+    const float *Wl = W + d.w_off[l];
+    float *dst = lds_w + d.lds_off[l];
+    for (int e = threadIdx.x; e < otiles * ksteps * 64; e += MLP_THREADS) {
+      const int lane = e & 63, s = (e >> 6) % ksteps, t = (e >> 6) / ksteps;
+      const int h = lane >> 5, o = 32 * t + (lane & 31);
+      const int k = l == 0 ? h * ksteps + s : perm_hidden(s, h);
+      dst[e] = o < O ? Wl[o * I + k] : 0.f;
+    }
+    for (int e = threadIdx.x; e < HID; e += MLP_THREADS)
+      lds_b[l * HID + e] = (d.has_bias && e < O) ? bias[d.b_off[l] + e] : 0.f;
+  }
+}
+
+template <int D_IN>
+__global__ void __launch_bounds__(MLP_THREADS)
+    mlp_fwd_kernel(int64_t B, MlpDesc d, const float *__restrict__ W, const float *__restrict__ bias,
+                   const float *__restrict__ in, float *__restrict__ out, float *__restrict__ acts) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float *lds_b = smem;                         // [MAX_LAYERS][64]
+  float *lds_w = smem + MAX_LAYERS * HID;      // permuted weights
+  stage_weights_fwd(d, W, bias, lds_w, lds_b);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int h = lane >> 5, pl = lane & 31;
+  constexpr int K0 = D_IN / 2;
+  const int64_t n_tiles = (B + 31) / 32;
+  const int act_stride = HID * (d.n_layers - 1);
+  for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < n_tiles; tile += (int64_t)gridDim.x * 4) {
+    const int64_t p = tile * 32 + pl;
+    const bool live = p < B;
+    // B operand of layer 0: this lane's K0 input features h*K0 .. h*K0+K0-1 of point p
+    float x[K0];
+    const float4 *src = reinterpret_cast<const float4 *>(in + (live ? p : 0) * D_IN + h * K0);
+#pragma unroll
+    for (int q = 0; q < K0 / 4; ++q) {
+      const float4 v = live ? src[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+      x[4 * q] = v.x; x[4 * q + 1] = v.y; x[4 * q + 2] = v.z; x[4 * q + 3] = v.w;
+    }
+    v16f cur[2];
+    // ---- layer 0
+    {
+      const float *w = lds_w + d.lds_off[0];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        v16f acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = lds_b[32 * t + d_row(r, h)];
+#pragma unroll
+        for (int s = 0; s < K0; ++s) acc = mfma32(w[(t * K0 + s) * 64 + lane], x[s], acc);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = fmaxf(acc[r], 0.f);
+        cur[t] = acc;
+      }
+    }
+    // ---- hidden layers and output layer
+    for (int l = 1; l < d.n_layers; ++l) {
+      if (acts != nullptr && live) {  // post-ReLU activations of layer l-1, point-major rows of 64
+        float *a = acts + p * act_stride + (l - 1) * HID;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            *reinterpret_cast<float4 *>(a + 32 * t + 8 * q + 4 * h) =
+                make_float4(cur[t][4 * q], cur[t][4 * q + 1], cur[t][4 * q + 2], cur[t][4 * q + 3]);
+      }
+      const float *w = lds_w + d.lds_off[l];
+      const bool last = l == d.n_layers - 1;
+      const int otiles = last ? 1 : 2;
+      v16f nxt[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        if (t < otiles) {  // wave-uniform
+          v16f acc;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[r] = lds_b[l * HID + 32 * t + d_row(r, h)];
+#pragma unroll
+          for (int s = 0; s < 32; ++s) acc = mfma32(w[(t * 32 + s) * 64 + lane], cur[s >> 4][s & 15], acc);
+          if (!last) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = fmaxf(acc[r], 0.f);
+          }
+          nxt[t] = acc;
+        }
+      }
+      cur[0] = nxt[0];
+      if (!last) cur[1] = nxt[1];
+    }
+    if (live) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int o = d_row(r, h);
+        if (o < d.d_out) out[p * d.d_out + o] = cur[0][r];
+      }
+    }
+  }
+}
+
+// ----------------------------------------------------------------------------------------------
+// backward, data path: v_out -> v_pre of every layer (workspace) -> v_in
+// LDS image of layer l: [i_tile][k_step][64 lanes] = W_l[o = perm(k_step, lane>>5)][i = 32*i_tile + (lane&31)]
+// ----------------------------------------------------------------------------------------------
+__device__ void stage_weights_bwd(const MlpDesc &d, const float *__restrict__ W, float *lds_w) {
+  for (int l = 0; l < d.n_layers; ++l) {
+    const int I = l == 0 ? d.d_in : HID;
+    const int O = l == d.n_layers - 1 ? d.d_out : HID;
+    const int itiles = I / 32;
+    const int ksteps = l == d.n_layers - 1 ? 16 : 32;  // o padded to 32 on the last layer
+    const float *Wl = W + d.w_off[l];
+    float *dst = lds_w + d.lds_off[l];
+    for (int e = threadIdx.x; e < itiles * ksteps * 64; e += MLP_THREADS) {
+      const int lane = e & 63, s = (e >> 6) % ksteps, t = (e >> 6) / ksteps;
+      const int o = perm_hidden(s, lane >> 5), i = 32 * t + (lane & 31);
+      dst[e] = o < O ? Wl[o * I + i] : 0.f;
+    }
+  }
+}
+
+template <int D_IN>
+__global__ void __launch_bounds__(MLP_THREADS)
+    mlp_bwd_data_kernel(int64_t B, MlpDesc d, const float *__restrict__ W, const float *__restrict__ acts,
+                        const float *__restrict__ v_out, float *__restrict__ v_pre_ws, float *__restrict__ v_in) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float *lds_w = smem;
+  stage_weights_bwd(d, W, lds_w);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int h = lane >> 5, pl = lane & 31;
+  const int64_t n_tiles = (B + 31) / 32;
+  const int act_stride = HID * (d.n_layers - 1);
+  for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < n_tiles; tile += (int64_t)gridDim.x * 4) {
+    const int64_t p = tile * 32 + pl;
+    const bool live = p < B;
+    v16f g[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int o = d_row(r, h);
+      g[0][r] = (live && o < d.d_out) ? v_out[p * d.d_out + o] : 0.f;
+      g[1][r] = 0.f;
+    }
+    for (int l = d.n_layers - 1; l >= 1; --l) {
+      const float *w = lds_w + d.lds_off[l];
+      const bool last = l == d.n_layers - 1;
+      v16f ng[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        v16f acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        if (last) {
+#pragma unroll
+          for (int s = 0; s < 16; ++s) acc = mfma32(w[(t * 16 + s) * 64 + lane], g[0][s], acc);
+        } else {
+#pragma unroll
+          for (int s = 0; s < 32; ++s) acc = mfma32(w[(t * 32 + s) * 64 + lane], g[s >> 4][s & 15], acc);
+        }
+        ng[t] = acc;
+      }
+      // ReLU mask of layer l-1's output, then persist v_pre_{l-1} for the weight-gradient GEMM
+      const float *a = acts + (live ? p : 0) * act_stride + (l - 1) * HID;
+      float *vp = v_pre_ws + ((int64_t)(l - 1) * B + (live ? p : 0)) * HID;
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float4 hv = live ? *reinterpret_cast<const float4 *>(a + 32 * t + 8 * q + 4 * h) : make_float4(0, 0, 0, 0);
+          float4 o4;
+          o4.x = hv.x > 0.f ? ng[t][4 * q] : 0.f;
+          o4.y = hv.y > 0.f ? ng[t][4 * q + 1] : 0.f;
+          o4.z = hv.z > 0.f ? ng[t][4 * q + 2] : 0.f;
+          o4.w = hv.w > 0.f ? ng[t][4 * q + 3] : 0.f;
+          ng[t][4 * q] = o4.x; ng[t][4 * q + 1] = o4.y; ng[t][4 * q + 2] = o4.z; ng[t][4 * q + 3] = o4.w;
+          if (live) *reinterpret_cast<float4 *>(vp + 32 * t + 8 * q + 4 * h) = o4;
+        }
+      g[0] = ng[0]; g[1] = ng[1];
+    }
+    if (v_in != nullptr) {  // layer 0: v_in = W_0^T v_pre_0
+      const float *w = lds_w + d.lds_off[0];
+      constexpr int ITILES = D_IN / 32;
+#pragma unroll
+      for (int t = 0; t < ITILES; ++t) {
+        v16f acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 32; ++s) acc = mfma32(w[(t * 32 + s) * 64 + lane], g[s >> 4][s & 15], acc);
+        if (live) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            *reinterpret_cast<float4 *>(v_in + p * D_IN + 32 * t + 8 * q + 4 * h) =
+                make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+        }
+      }
+    }
+  }
+}
+
+// ----------------------------------------------------------------------------------------------
+// backward, weight path: v_W_l[o][i] += sum_p v_pre_l[p][o] * h_in_l[p][i]   (K = points)
+// grid (k_chunks, n_layers); wave w owns output tile (mt = w>>1, nt = w&1)
+// ----------------------------------------------------------------------------------------------
+static constexpr int WG_KCHUNK = 256;  // points per workgroup
+
+__global__ void __launch_bounds__(MLP_THREADS)
+    mlp_bwd_weights_kernel(int64_t B, MlpDesc d, const float *__restrict__ in, const float *__restrict__ acts,
+                           const float *__restrict__ v_out, const float *__restrict__ v_pre_ws,
+                           float *__restrict__ v_W, float *__restrict__ v_b) {
+  const int l = blockIdx.y;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int mt = wave >> 1, nt = wave & 1;
+  const int I = l == 0 ? d.d_in : HID;
+  const int O = l == d.n_layers - 1 ? d.d_out : HID;
+  if (32 * mt >= O || 32 * nt >= I) return;
+  const bool last = l == d.n_layers - 1;
+  const float *A = last ? v_out : v_pre_ws + (int64_t)l * B * HID;   // [p][lda]
+  const int lda = last ? d.d_out : HID;
+  const float *Hin = l == 0 ? in : acts + (l - 1) * HID;             // [p][ldh]
+  const int ldh = l == 0 ? d.d_in : HID * (d.n_layers - 1);
+  const int o = 32 * mt + (lane & 31), i = 32 * nt + (lane & 31), hh = lane >> 5;
+  const bool o_ok = o < O;
+  v16f acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  float bsum = 0.f;
+  const int64_t p0 = (int64_t)blockIdx.x * WG_KCHUNK;
+  const int64_t p1 = min(B, p0 + WG_KCHUNK);
+  for (int64_t pb = p0; pb < p1; pb += 16) {
+    float a[8], b[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      const int64_t p = pb + 2 * s + hh;
+      const bool ok = p < p1;
+      a[s] = (ok && o_ok) ? A[p * lda + o] : 0.f;
+      b[s] = ok ? Hin[p * ldh + i] : 0.f;
+    }
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      acc = mfma32(a[s], b[s], acc);
+      bsum += a[s];
+    }
+  }
+  float *vw = v_W + d.w_off[l];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int oo = 32 * mt + d_row(r, hh);
+    if (oo < O && acc[r] != 0.f) atomicAdd(vw + oo * I + i, acc[r]);
+  }
+  if (v_b != nullptr && nt == 0) {
+    bsum += __shfl_xor(bsum, 32, 64);
+    if (hh == 0 && o_ok) atomicAdd(v_b + d.b_off[l] + o, bsum);
+  }
+}
+
+static int make_desc(int n_layers, const int *dims, int has_bias, bool bwd, MlpDesc *d, size_t *lds_floats,
+                     const char *who) {
+  GSDF_REQUIRE(n_layers >= 2 && n_layers <= MAX_LAYERS, "%s: n_layers %d not in [2,%d]", who, n_layers, MAX_LAYERS);
+  GSDF_REQUIRE(dims[0] == 32 || dims[0] == 64, "%s: input width %d unsupported (32 or 64)", who, dims[0]);
+  GSDF_REQUIRE(dims[n_layers] >= 1 && dims[n_layers] <= 32, "%s: output width %d unsupported (<= 32)", who, dims[n_layers]);
+  for (int l = 1; l < n_layers; ++l)
+    GSDF_REQUIRE(dims[l] == HID, "%s: hidden width %d unsupported (64 only, as the reference configures)", who, dims[l]);
+  d->n_layers = n_layers; d->d_in = dims[0]; d->d_out = dims[n_layers]; d->has_bias = has_bias;
+  int w = 0, b = 0, lo = 0;
+  for (int l = 0; l < n_layers; ++l) {
+    d->w_off[l] = w; d->b_off[l] = b; d->lds_off[l] = lo;
+    w += dims[l] * dims[l + 1]; b += dims[l + 1];
+    const int I = dims[l];
+    const bool last = l == n_layers - 1;
+    lo += bwd ? (I / 32) * (last ? 16 : 32) * 64 : (last ? 1 : 2) * (I / 2) * 64;
+  }
+  *lds_floats = (size_t)lo + (bwd ? 0 : MAX_LAYERS * HID);
+  return GSDF_OK;
+}
+
+}  // namespace gsdf
+
+using namespace gsdf;
+
+static unsigned mlp_grid(int64_t B) {
+  const int64_t wg = (B + 127) / 128;  // 4 tiles of 32 points per workgroup
+  return (unsigned)(wg < 1 ? 1 : (wg > 1024 ? 1024 : wg));
+}
+
+extern "C" size_t gsdf_mlp_bwd_ws_bytes(int64_t B, int n_layers) {
+  return (size_t)(n_layers > 1 ? n_layers - 1 : 0) * (size_t)B * HID * sizeof(float) + 256;
+}
+
+extern "C" int gsdf_mlp_fwd(int64_t B, int n_layers, const int *dims_host, const float *weights, const float *biases,
+                            const float *in, float *out, float *acts, gsdf_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  GSDF_REQUIRE(dims_host, "mlp_fwd: null dims");
+  MlpDesc d;
+  size_t lds_floats;
+  int rc = make_desc(n_layers, dims_host, biases != nullptr, false, &d, &lds_floats, "mlp_fwd");
+  if (rc) return rc;
+  if (B == 0) return GSDF_OK;
+  GSDF_REQUIRE(weights && in && out, "mlp_fwd: null buffer");
+  const size_t lds = lds_floats * sizeof(float);
+  GSDF_REQUIRE(lds <= 160 * 1024, "mlp_fwd: %zu bytes of weights do not fit the 160 KiB LDS", lds);
+  if (d.d_in == 32) {
+    GSDF_HIP(hipFuncSetAttribute((const void *)mlp_fwd_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "mlp_fwd attr");
+    mlp_fwd_kernel<32><<<mlp_grid(B), MLP_THREADS, lds, stream>>>(B, d, weights, biases, in, out, acts);
+  } else {
+    GSDF_HIP(hipFuncSetAttribute((const void *)mlp_fwd_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "mlp_fwd attr");
+    mlp_fwd_kernel<64><<<mlp_grid(B), MLP_THREADS, lds, stream>>>(B, d, weights, biases, in, out, acts);
+  }
+  GSDF_CHECK_LAUNCH("mlp_fwd_kernel");
+  return GSDF_OK;
+}
+
+extern "C" int gsdf_mlp_bwd(int64_t B, int n_layers, const int *dims_host, const float *weights, const float *biases,
+                            const float *in, const float *acts, const float *v_out, float *v_in, float *v_weights,
+                            float *v_biases, void *ws, gsdf_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  GSDF_REQUIRE(dims_host, "mlp_bwd: null dims");
+  MlpDesc d;
+  size_t lds_floats;
+  int rc = make_desc(n_layers, dims_host, biases != nullptr, true, &d, &lds_floats, "mlp_bwd");
+  if (rc) return rc;
+  if (B == 0) return GSDF_OK;
+  GSDF_REQUIRE(weights && in && v_out && ws, "mlp_bwd: null buffer");
+  GSDF_REQUIRE(acts, "mlp_bwd: the saved activations of mlp_fwd are required");
+  const size_t lds = lds_floats * sizeof(float);
+  GSDF_REQUIRE(lds <= 160 * 1024, "mlp_bwd: %zu bytes of weights do not fit the 160 KiB LDS", lds);
+  float *v_pre = (float *)ws;
+  if (d.d_in == 32) {
+    GSDF_HIP(hipFuncSetAttribute((const void *)mlp_bwd_data_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "mlp_bwd attr");
+    mlp_bwd_data_kernel<32><<<mlp_grid(B), MLP_THREADS, lds, stream>>>(B, d, weights, acts, v_out, v_pre, v_in);
+  } else {
+    GSDF_HIP(hipFuncSetAttribute((const void *)mlp_bwd_data_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "mlp_bwd attr");
+    mlp_bwd_data_kernel<64><<<mlp_grid(B), MLP_THREADS, lds, stream>>>(B, d, weights, acts, v_out, v_pre, v_in);
+  }
+  GSDF_CHECK_LAUNCH("mlp_bwd_data_kernel");
+  if (v_weights != nullptr) {
+    dim3 grid((unsigned)((B + WG_KCHUNK - 1) / WG_KCHUNK), (unsigned)n_layers);
+    mlp_bwd_weights_kernel<<<grid, MLP_THREADS, 0, stream>>>(B, d, in, acts, v_out, v_pre, v_weights,
+                                                             biases != nullptr ? v_biases : nullptr);
+    GSDF_CHECK_LAUNCH("mlp_bwd_weights_kernel");
+  }
+  return GSDF_OK;
+}

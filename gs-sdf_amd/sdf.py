@@ -1,0 +1,269 @@
+"""Host-side mirror of the reference's SDF network interface on top of the C ABI.
+
+Mirrors, with the same names and behaviour,
+  * `TCNNEncoding` / `TCNNNetwork` of the (absent) tcnn_binding submodule as the reference uses them
+    (/root/reference/include/neural_net/encoding_map.cpp:15-26,59; local_map.cpp:44-55,94): objects with a
+    flat fp32 leaf `params_`, `forward(x)`, `get_out_dim()`; the encoding supports first AND second order
+    autograd (the reference calls torch::autograd::grad(..., create_graph=true), local_map.cpp:151-172);
+  * `LocalMap::get_sdf / get_gradient` (local_map.cpp:87-173) and the coordinate normalisation of
+    `SubMap::xyz_to_zp1_pts` (sub_map.cpp:82-97);
+  * the SDF losses of include/optimizer/loss/loss.cpp:7-11,49-90.
+"""
+import ctypes as C
+import math
+
+import torch
+
+from . import capi
+from .capi import f32, ptr
+from .ops import _timed
+
+GRID_DEFAULT = dict(otype="Grid", type="Hash", n_levels=16, n_features_per_level=2, log2_hashmap_size=19,
+                    base_resolution=32, per_level_scale=2.0, interpolation="Linear")
+
+
+def _gcfg(cfg):
+    return (int(cfg["n_levels"]), int(cfg["n_features_per_level"]), int(cfg["log2_hashmap_size"]),
+            int(cfg["base_resolution"]), float(cfg["per_level_scale"]))
+
+
+class _GridBwd(torch.autograd.Function):
+    """(v_feat, x, table) -> (v_x, v_table): the encoding's backward as a differentiable op, so that
+    grad-of-grad (eikonal on the analytic SDF gradient) works."""
+
+    @staticmethod
+    def forward(ctx, v_feat, x, table, cfg, want_table):
+        L = capi.lib()
+        B = x.shape[0]
+        v_feat = v_feat.contiguous()
+        v_x = torch.empty_like(x)
+        v_table = torch.zeros_like(table) if want_table else None
+        capi.check(_timed("hashgrid_bwd", L.gsdf_hashgrid_bwd, B, *cfg, f32(x), f32(table), f32(v_feat), f32(v_table),
+                          f32(v_x), capi.stream()), "hashgrid_bwd")
+        ctx.save_for_backward(v_feat, x, table)
+        ctx.cfg = cfg
+        if v_table is None:
+            v_table = torch.zeros(0, device=x.device)
+            ctx.mark_non_differentiable(v_table)
+        return v_x, v_table
+
+    @staticmethod
+    def backward(ctx, vv_x, _vv_table):
+        # second order w.r.t. the table gradient output is never requested by the reference
+        L = capi.lib()
+        v_feat, x, table = ctx.saved_tensors
+        B = x.shape[0]
+        need_vf, need_x, need_t = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2]
+        if vv_x is None:
+            return None, None, None, None, None
+        g_vfeat = torch.empty_like(v_feat) if need_vf else None
+        g_x = torch.empty_like(x) if need_x else None
+        g_table = torch.zeros_like(table) if need_t else None
+        capi.check(_timed("hashgrid_bwd_bwd", L.gsdf_hashgrid_bwd_bwd, B, *ctx.cfg, f32(x), f32(table), f32(v_feat),
+                          f32(vv_x.contiguous()), f32(g_vfeat), f32(g_table), f32(g_x), capi.stream()), "hashgrid_bwd_bwd")
+        return g_vfeat, g_x, g_table, None, None
+
+
+class _GridFwd(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, table, cfg):
+        L = capi.lib()
+        x, table = x.contiguous(), table.contiguous()
+        B = x.shape[0]
+        feat = torch.empty(B, cfg[0] * cfg[1], dtype=torch.float32, device=x.device)
+        capi.check(_timed("hashgrid_fwd", L.gsdf_hashgrid_fwd, B, *cfg, f32(x, "x"), f32(table, "params"), f32(feat),
+                          capi.stream()), "hashgrid_fwd")
+        ctx.save_for_backward(x, table)
+        ctx.cfg = cfg
+        return feat
+
+    @staticmethod
+    def backward(ctx, v_feat):
+        x, table = ctx.saved_tensors
+        v_x, v_table = _GridBwd.apply(v_feat, x, table, ctx.cfg, bool(ctx.needs_input_grad[1]))
+        return (v_x if ctx.needs_input_grad[0] else None), (v_table if ctx.needs_input_grad[1] else None), None
+
+
+class TCNNEncoding:
+    """tcnn_binding's TCNNEncoding as the reference uses it: `TCNNEncoding(3, encoding_config, name)`,
+    `.params_` (flat fp32 leaf, registered as an nn parameter by the caller, local_map.cpp:73-75),
+    `.forward(x)` with x in [0,1]^3, `.get_out_dim()`."""
+
+    def __init__(self, n_input_dims=3, config=None, name="encoder", device="cuda", seed=None):
+        cfg = dict(GRID_DEFAULT if config is None else config)
+        if cfg.get("otype", "Grid") != "Grid" or cfg.get("type", "Hash") != "Hash" or cfg.get("interpolation", "Linear") != "Linear":
+            raise RuntimeError("TCNNEncoding: only {otype: Grid, type: Hash, interpolation: Linear} is implemented")
+        if n_input_dims != 3:
+            raise RuntimeError("TCNNEncoding: only 3 input dims are implemented")
+        self.cfg, self.name_ = _gcfg(cfg), name
+        offs = (C.c_int64 * (self.cfg[0] + 1))()
+        total = capi.lib().gsdf_hashgrid_offsets(*self.cfg, offs)
+        if total < 0:
+            raise RuntimeError("TCNNEncoding: " + capi.lib().gsdf_last_error().decode())
+        self.offsets = list(offs)
+        g = None if seed is None else torch.Generator(device="cpu").manual_seed(seed)
+        # tiny-cuda-nn initialises grid parameters U(-1e-4, 1e-4)
+        init = (torch.rand(total * self.cfg[1], generator=g) * 2 - 1) * 1e-4
+        self.params_ = init.to(device).requires_grad_(True)
+
+    def get_out_dim(self):
+        return self.cfg[0] * self.cfg[1]
+
+    def forward(self, x):
+        if x.dim() != 2 or x.shape[1] != 3:
+            raise RuntimeError("TCNNEncoding.forward: expected [B,3]")
+        return _GridFwd.apply(x, self.params_.view(-1, self.cfg[1]), self.cfg)
+
+    __call__ = forward
+
+
+class _MlpFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weights, biases, dims):
+        L = capi.lib()
+        x, weights = x.contiguous(), weights.contiguous()
+        B, nl = x.shape[0], len(dims) - 1
+        dims_c = (C.c_int * len(dims))(*dims)
+        out = torch.empty(B, dims[-1], dtype=torch.float32, device=x.device)
+        need = any(ctx.needs_input_grad[:3])
+        acts = torch.empty(B, 64 * (nl - 1), dtype=torch.float32, device=x.device) if need else None
+        capi.check(_timed("mlp_fwd", L.gsdf_mlp_fwd, B, nl, dims_c, f32(weights, "weights"), f32(biases), f32(x, "x"),
+                          f32(out), f32(acts), capi.stream()), "mlp_fwd")
+        ctx.save_for_backward(x, weights, biases, acts)
+        ctx.dims = dims
+        return out
+
+    @staticmethod
+    def backward(ctx, v_out):
+        L = capi.lib()
+        x, weights, biases, acts = ctx.saved_tensors
+        dims = ctx.dims
+        B, nl = x.shape[0], len(dims) - 1
+        dims_c = (C.c_int * len(dims))(*dims)
+        v_in = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        v_w = torch.zeros_like(weights) if ctx.needs_input_grad[1] else None
+        v_b = torch.zeros_like(biases) if (biases is not None and ctx.needs_input_grad[2]) else None
+        ws = torch.empty(L.gsdf_mlp_bwd_ws_bytes(B, nl), dtype=torch.uint8, device=x.device)
+        capi.check(_timed("mlp_bwd", L.gsdf_mlp_bwd, B, nl, dims_c, f32(weights), f32(biases), f32(x), f32(acts),
+                          f32(v_out.contiguous()), f32(v_in), f32(v_w), f32(v_b), ptr(ws), capi.stream()), "mlp_bwd")
+        return v_in, v_w, v_b, None
+
+
+class TCNNNetwork:
+    """tcnn_binding's TCNNNetwork as the reference uses it (local_map.cpp:44-55,94): FullyFusedMLP, ReLU,
+    output activation None, `n_neurons` 64, `n_hidden_layers` h -> h+1 bias-free linear layers.  fp32 weights
+    (the reference's fork keeps fp16; DESIGN.md SPEC A.8).  `bias=True` gives the default torch decoder's topology."""
+
+    def __init__(self, n_input_dims, n_output_dims, config, name="decoder", device="cuda", bias=False, seed=None):
+        if config.get("otype", "FullyFusedMLP") != "FullyFusedMLP" or config.get("activation", "ReLU") != "ReLU" \
+                or config.get("output_activation", "None") != "None":
+            raise RuntimeError("TCNNNetwork: only FullyFusedMLP / ReLU / output_activation None is implemented")
+        h, nh = int(config["n_neurons"]), int(config["n_hidden_layers"])
+        self.dims = [int(n_input_dims)] + [h] * nh + [int(n_output_dims)]
+        self.name_ = name
+        g = None if seed is None else torch.Generator(device="cpu").manual_seed(seed)
+        ws, bs = [], []
+        for i, o in zip(self.dims[:-1], self.dims[1:]):        # Kaiming-uniform(a=sqrt(5)) like torch::nn::Linear
+            bound = 1.0 / math.sqrt(i)
+            ws.append((torch.rand(o * i, generator=g) * 2 - 1) * bound)
+            bs.append((torch.rand(o, generator=g) * 2 - 1) * bound)
+        self.params_ = torch.cat(ws).to(device).requires_grad_(True)
+        self.biases_ = torch.cat(bs).to(device).requires_grad_(True) if bias else None
+
+    def forward(self, x):
+        if x.dim() != 2 or x.shape[1] != self.dims[0]:
+            raise RuntimeError(f"TCNNNetwork.forward: expected [B,{self.dims[0]}]")
+        return _MlpFn.apply(x, self.params_, self.biases_, tuple(self.dims))
+
+    __call__ = forward
+
+
+class LocalMap:
+    """The SDF half of the reference's `LocalMap` (include/neural_net/local_map.{h,cpp}): hash-grid encoder +
+    decoder, `get_sdf`, `get_gradient` (numerical 6-point stencil or analytic via autograd)."""
+
+    def __init__(self, map_origin, map_size, bce_sigma=0.02, decoder_implementation=1, hidden_dim=64, geo_num_layer=3,
+                 device="cuda", seed=0, encoding_config=None):
+        self.pos_W_M = torch.as_tensor(map_origin, dtype=torch.float32, device=device).reshape(1, 3)
+        self.map_size_inv = 1.0 / float(map_size)
+        self.bce_isigma = 1.0 / float(bce_sigma)
+        self.encoder = TCNNEncoding(3, encoding_config, "encoder_local_map", device, seed)
+        feat = self.encoder.get_out_dim()
+        self.decoder_implementation = decoder_implementation
+        if decoder_implementation == 0:      # torch::nn::Sequential, local_map.cpp:29-42 (rocBLAS GEMMs)
+            torch.manual_seed(seed)
+            layers = [torch.nn.Linear(feat, hidden_dim), torch.nn.ReLU(True)]
+            for _ in range(geo_num_layer):
+                layers += [torch.nn.Linear(hidden_dim, hidden_dim), torch.nn.ReLU(True)]
+            layers += [torch.nn.Linear(hidden_dim, 2)]
+            self.decoder = torch.nn.Sequential(*layers).to(device)
+        elif decoder_implementation == 1:    # tcnn FullyFusedMLP, local_map.cpp:44-55
+            self.decoder = TCNNNetwork(feat, 2, dict(otype="FullyFusedMLP", activation="ReLU", output_activation="None",
+                                                     n_neurons=hidden_dim, n_hidden_layers=geo_num_layer), "decoder", device, seed=seed + 1)
+        else:                                # fused MFMA kernel with the torch decoder's topology (biases, 4 hidden matmuls)
+            self.decoder = TCNNNetwork(feat, 2, dict(n_neurons=hidden_dim, n_hidden_layers=geo_num_layer + 1), "decoder", device,
+                                       bias=True, seed=seed + 1)
+
+    def parameters(self):
+        ps = [self.encoder.params_]
+        if isinstance(self.decoder, torch.nn.Module):
+            ps += list(self.decoder.parameters())
+        else:
+            ps += [self.decoder.params_] + ([self.decoder.biases_] if self.decoder.biases_ is not None else [])
+        return ps
+
+    def xyz_to_zp1_pts(self, xyz):                 # sub_map.cpp:82-97
+        return 0.5 * ((xyz - self.pos_W_M) * (2.0 * self.map_size_inv)) + 0.5
+
+    def get_feat(self, xyz, normalized=False):
+        return self.encoder.forward(xyz if normalized else self.xyz_to_zp1_pts(xyz))
+
+    def get_sdf(self, xyz):
+        """-> [sdf [B,1], isigma [B,1]]  (local_map.cpp:87-103)"""
+        attr = self.decoder(self.get_feat(xyz))
+        sdf, raw = attr[:, 0:1], attr[:, 1:2]
+        return [sdf, 1 + torch.nn.functional.softplus(raw, beta=100) * self.bce_isigma]
+
+    def get_gradient(self, xyz, delta, sdf=None, hessian=False, numerical_grad=True):
+        """(local_map.cpp:105-173) numerical: central differences (+ diagonal Hessian); analytic: autograd."""
+        if numerical_grad:
+            offs = torch.tensor([[delta, 0, 0], [-delta, 0, 0], [0, delta, 0], [0, -delta, 0], [0, 0, delta], [0, 0, -delta]],
+                                dtype=torch.float32, device=xyz.device)[:, None, :]
+            pts = xyz[None] + offs
+            ps = self.get_sdf(pts.reshape(-1, 3))[0].view(6, xyz.shape[0], 1)
+            inv = 1.0 / delta
+            grad = 0.5 * inv * torch.cat([ps[0] - ps[1], ps[2] - ps[3], ps[4] - ps[5]], 1)
+            if hessian:
+                if sdf is None:
+                    sdf = self.get_sdf(xyz)[0]
+                hess = inv * inv * (torch.cat([ps[0] + ps[1], ps[2] + ps[3], ps[4] + ps[5]], 1) - 2 * sdf)
+                return [grad, hess]
+            return [grad]
+        with torch.enable_grad():
+            if not xyz.requires_grad or sdf is None:
+                xyz.requires_grad_(True)
+                sdf = self.get_sdf(xyz)[0]
+            grad = torch.autograd.grad([sdf], [xyz], [torch.ones_like(sdf)], retain_graph=True, create_graph=True)[0]
+            if hessian:
+                hess = torch.autograd.grad([grad], [xyz], [torch.ones_like(grad)], retain_graph=True, create_graph=True)[0]
+                return [grad, hess]
+        return [grad]
+
+
+# ---- losses (include/optimizer/loss/loss.cpp) -------------------------------------------------------------------
+def sdf_loss(pred_sdf, gt_sdf, pred_isigma):                  # loss.cpp:49-79
+    isigma = pred_isigma.clamp_max(5e2)
+    return torch.nn.functional.binary_cross_entropy_with_logits(-pred_sdf * isigma,
+                                                                torch.sigmoid(-gt_sdf * isigma).clamp(1e-7, 1 - 1e-7))
+
+
+def eikonal_loss(grad):                                        # loss.cpp:81-83
+    return (grad.norm(2, 1) - 1.0).square().mean()
+
+
+def curvate_loss(hessian):                                     # loss.cpp:85-90
+    return hessian.sum(-1).abs().mean().nan_to_num(0.0, 0.0, 0.0)
+
+
+def gs_sdf_loss(gs_sdf, weight):                               # loss.cpp:7-11
+    return 0.5 * (weight * gs_sdf.square()).sum()

@@ -138,6 +138,46 @@ int gsdf_rasterize_2dgs_bwd(int64_t n_cams, int64_t n_visible, int64_t n_isects,
                             float *v_ray_transforms, float *v_colors, float *v_opacities, float *v_normals,
                             float *v_densify, float *v_means2d_abs, gsdf_stream_t stream);
 
+
+/* ------------------------------------------------------------------------------------------
+ * S1  TCNNEncoding::forward — multiresolution hash grid (tiny-cuda-nn "Grid"/"Hash"/"Linear")
+ *     reference: include/neural_net/encoding_map.cpp:15-26 (config {n_levels 16, n_features_per_level 2,
+ *     log2_hashmap_size 19, base_resolution 32, per_level_scale 2.0}), :59 (forward);
+ *     second order (autograd::grad with create_graph) at include/neural_net/local_map.cpp:151-172.
+ * x [B,3] in [0,1]; table fp32 [n_entries, 2] (levels concatenated); feat [B, n_levels*2].
+ * n_features_per_level must be 2 and n_levels <= 16.
+ * ---------------------------------------------------------------------------------------- */
+/* host helper: entry offsets per level, offsets_host[n_levels+1]; returns total entries (-1 on error). */
+int64_t gsdf_hashgrid_offsets(int n_levels, int n_feat, int log2_hashmap, int base_res, float per_level_scale,
+                              int64_t *offsets_host);
+int gsdf_hashgrid_fwd(int64_t B, int n_levels, int n_feat, int log2_hashmap, int base_res, float per_level_scale,
+                      const float *x, const float *table, float *feat, gsdf_stream_t stream);
+/* v_table ACCUMULATES (zero it first), v_x is overwritten; either may be NULL. */
+int gsdf_hashgrid_bwd(int64_t B, int n_levels, int n_feat, int log2_hashmap, int base_res, float per_level_scale,
+                      const float *x, const float *table, const float *v_feat, float *v_table, float *v_x,
+                      gsdf_stream_t stream);
+/* Double backward of v_x = J(x,table)^T v_feat: given vv_x [B,3] returns d/d v_feat (g_vfeat, overwritten),
+ * d/d table (g_table, ACCUMULATES) and d/d x (g_x, overwritten); any may be NULL. */
+int gsdf_hashgrid_bwd_bwd(int64_t B, int n_levels, int n_feat, int log2_hashmap, int base_res,
+                          float per_level_scale, const float *x, const float *table, const float *v_feat,
+                          const float *vv_x, float *g_vfeat, float *g_table, float *g_x, gsdf_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * S2  TCNNNetwork::forward — fully fused width-64 ReLU MLP (fp32 MFMA)
+ *     reference: include/neural_net/local_map.cpp:44-55 (tcnn FullyFusedMLP, bias free), :94 (forward);
+ *     same kernel serves the default torch decoder topology with biases (local_map.cpp:29-42).
+ * dims_host[n_layers+1] (HOST ints): input 32|64, hidden 64, output <= 32.  weights: torch Linear layout,
+ * row-major [out][in] per layer, layers concatenated; biases concatenated or NULL.
+ * acts [B, 64*(n_layers-1)] (post-ReLU hidden activations) is written when non-NULL and required by bwd.
+ * ---------------------------------------------------------------------------------------- */
+int gsdf_mlp_fwd(int64_t B, int n_layers, const int *dims_host, const float *weights, const float *biases,
+                 const float *in, float *out, float *acts, gsdf_stream_t stream);
+size_t gsdf_mlp_bwd_ws_bytes(int64_t B, int n_layers);
+/* v_in [B,dims[0]] overwritten (may be NULL); v_weights / v_biases ACCUMULATE (may be NULL). */
+int gsdf_mlp_bwd(int64_t B, int n_layers, const int *dims_host, const float *weights, const float *biases,
+                 const float *in, const float *acts, const float *v_out, float *v_in, float *v_weights,
+                 float *v_biases, void *ws, gsdf_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
