@@ -35,6 +35,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="cfg3_1M_1080p", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-sdf", action="store_true", help="splat path only (no hash-grid SDF leg)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -59,8 +60,18 @@ def main():
     views = synth.make_views(200, seed=1).to(dev)
     K = sc["K"].to(dev)
     params = SplatParams.from_scene(sc, dev)
-    vp = ViewParallel(params, dist)
     ug = {k: v.to(dev) for k, v in synth.upstream_grads(H, W, seed=2).items()}
+    groups = []
+    if not args.no_sdf:
+        # hash-grid SDF (2^19 table, 16 levels x 2) + fused MFMA decoder; the reference's numerical-gradient
+        # configuration (params.cpp:396-399 forces it for the tcnn decoder); ray batch 32768 (base.yaml:24)
+        import gs_sdf_amd.sdf as sdfm
+        lm = sdfm.LocalMap([0.0, 0.0, 5.5], 16.0, bce_sigma=0.02, decoder_implementation=1, device=dev, seed=5)
+        groups.append(lm.flatten())
+        gq = torch.Generator().manual_seed(4)
+        pool = [((torch.rand(32768, 3, generator=gq) - 0.5) * 14.0 + torch.tensor([0.0, 0.0, 5.5])).to(dev) for _ in range(8)]
+        ray_sdf = [(torch.randn(32768, 1, generator=gq) * 0.02).to(dev) for _ in range(8)]
+    vp = ViewParallel(params, dist, groups)
 
     sizes = {}
 
@@ -73,6 +84,21 @@ def main():
         loss = ((colors[..., :3] * ug["v_render_colors"]).sum() + (colors[..., 3:] * ug["v_render_depths"]).sum()
                 + (alphas * ug["v_render_alphas"]).sum() + (meta["render_normal"] * ug["v_render_normals"]).sum()
                 + (meta["render_median"] * ug["v_render_median"]).sum())
+        if not args.no_sdf:
+            # per-ray SDF batch (neural_mapping.cpp:138-188): BCE on the SDF head + eikonal on the numerical gradient
+            pts, tgt = pool[i % 8], ray_sdf[i % 8]
+            s_pred, isig = lm.get_sdf(pts)
+            loss = loss + sdfm.sdf_loss(s_pred, tgt, isig)
+            grad = lm.get_gradient(pts, 0.02, s_pred, False, True)[0]
+            loss = loss + 0.1 * sdfm.eikonal_loss(grad)
+            # GS <-> SDF coupling (neural_mapping.cpp:420-462): SDF at the visible splats' samples
+            vis = meta["visibilities"].detach()
+            w_all = (meta["samples_weights"] * vis).detach()
+            ids = (vis > 0.1).squeeze(-1).nonzero().squeeze(-1)
+            if ids.numel() > 0:
+                gs_sdf = lm.get_sdf(meta["samples"].index_select(0, ids))[0]
+                loss = loss + 1e-3 * sdfm.gs_sdf_loss(gs_sdf, w_all.index_select(0, ids))
+            sizes.update(n_gs_sdf=int(ids.numel()))
         loss.backward()
         vp.all_reduce_grads()
         sizes.update(M=int(meta["gaussian_ids"].shape[0]), I=int(meta["flatten_ids"].shape[0]))
@@ -114,12 +140,14 @@ def main():
         if os.path.exists(tpath):
             traffic = json.load(open(tpath)).get(args.workload, {}).get(dom)
         out = {
-            "metric": "train iters/sec (splat raster fwd+bwd), 1M Gaussians @1080p",
+            "metric": "train iters/sec (splat raster + SDF fwd+bwd), 1M Gaussians @1080p" if not args.no_sdf
+                      else "train iters/sec (splat raster fwd+bwd only), 1M Gaussians @1080p",
             "value": args.steps * world / elapsed, "unit": "iters/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.workload}: {N} random Gaussians, {W}x{H}, sh_degree {deg}, 1 view/GPU/step, "
-                                   f"M={M} I={I} L={I / T:.0f}", "parallelism": f"view-parallel x{world}" if world > 1 else "single GPU"},
+                                   f"M={M} I={I} L={I / T:.0f}" + ("" if args.no_sdf else f"; + hash-grid SDF (2^19 x16x2, fused 64-wide MLP): 32768 ray "
+                                   f"points x7 (numerical eikonal) + {sizes.get('n_gs_sdf', 0)} splat samples"), "parallelism": f"view-parallel x{world}" if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                          "frac": achieved / 8000.0, "traffic": traffic, "algorithmic_bytes": alg[dom],
                          "avg_launch_ms": dur_ms, "step_B_splat_bytes": b_splat,
@@ -127,13 +155,14 @@ def main():
             "kernel_ms": kern,
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(sc, views[0:1].cpu(), N, W, H, deg)
+            out["cpu_baseline"] = cpu_baseline(sc, views[0:1].cpu(), N, W, H, deg,
+                                               0 if args.no_sdf else 7 * 32768 + sizes.get("n_gs_sdf", 0))
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
 
 
-def cpu_baseline(sc, view, N, W, H, deg):
+def cpu_baseline(sc, view, N, W, H, deg, n_sdf_points=0):
     """The oracle ("port": the reference has no CPU rasteriser and none of its kernels are vendored) timed on
     this box's host cores: ONE full iteration (fwd + bwd) of the same workload."""
     import numpy as np
@@ -161,10 +190,23 @@ def cpu_baseline(sc, view, N, W, H, deg):
                             g["v_means2d"].astype(np.float32), np.zeros(M, np.float32),
                             g["v_ray_transforms"].astype(np.float32), g["v_normals"].astype(np.float32))
     orc.view_colors_bwd(n(view), means, n(sc["sh"]), p["camera_ids"], p["gaussian_ids"], deg, g["v_colors"].astype(np.float32))
+    if n_sdf_points:
+        # SDF leg: hash-grid + decoder forward and backward on the same number of query points
+        rng = np.random.default_rng(4)
+        offs, total = orc.grid_offsets()
+        table = ((rng.random((total, 2), dtype=np.float32) * 2 - 1) * 1e-4).astype(np.float32)
+        dims = [32, 64, 64, 64, 2]
+        Wm = (rng.standard_normal(sum(i * o for i, o in zip(dims[:-1], dims[1:]))) * 0.1).astype(np.float32)
+        xs = rng.random((n_sdf_points, 3), dtype=np.float32)
+        feat = orc.grid_fwd(xs, table)
+        o = orc.mlp_fwd(feat, dims, Wm, None)
+        v_in, v_w, _ = orc.mlp_bwd(feat, dims, Wm, None, np.ones_like(o))
+        orc.grid_bwd(xs, table, v_in)
     dt = time.perf_counter() - t0
     return {"value": 1.0 / dt, "unit": "iters/s", "cores": cores, "kind": "port",
             "sample": f"1 full iteration (fwd+bwd) of the same workload, oracle/splat_oracle.c f32 build, OpenMP over tiles "
-                      f"on {cores} threads for compositing (projection/sort single-threaded), {dt:.1f} s"}
+                      f"on {cores} threads for compositing (projection/sort single-threaded)"
+                      + (f" + SDF oracle fwd+bwd on {n_sdf_points} query points" if n_sdf_points else "") + f", {dt:.1f} s"}
 
 
 if __name__ == "__main__":

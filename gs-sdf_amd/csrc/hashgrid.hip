@@ -120,33 +120,41 @@ __global__ void __launch_bounds__(HG_THREADS)
   *reinterpret_cast<float2 *>(feat + (b * lv.n_levels + level) * 2) = make_float2(a0, a1);
 }
 
+// ---- backward kernels: 4 lanes per (point, level) -------------------------------------------------------
+// Measured on MI355X (tools/ubench/atomic_*.hip): fp32 atomics retire ~21 G 64-byte-LINE requests/s
+// chip-wide regardless of footprint; lanes of one instruction that fall in the same line are merged.
+// One lane per (point, level) issuing 16 scalar atomics costs 16 line requests.  Here the 4 lanes
+// sub = (x-corner bit, feature) of a (point, level) issue ONE instruction per (y,z) corner pair whose
+// addresses are the 4 consecutive floats {entry(x0).f0, .f1, entry(x1).f0, .f1}: entries x0/x1 are
+// adjacent in the dense levels and, thanks to the hash's unit x-prime, for every even x0 in the hashed
+// levels -> 4 (dense) to ~6 (hashed) line requests instead of 16.  wave64 = one point x 16 levels.
+static constexpr int HGB_THREADS = 256;  // 4 points per workgroup
+
 template <bool WANT_TABLE, bool WANT_X>
-__global__ void __launch_bounds__(HG_THREADS)
+__global__ void __launch_bounds__(HGB_THREADS)
     hashgrid_bwd_kernel(int64_t B, HgLevels lv, const float *__restrict__ x, const float *__restrict__ table,
                         const float *__restrict__ v_feat, float *__restrict__ v_table, float *__restrict__ v_x) {
-  const int level = threadIdx.x & 15;
-  const int64_t b = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
-  const bool live = b < B && level < lv.n_levels;
+  const int lane = threadIdx.x & 63;
+  const int f = lane & 1, xb = (lane >> 1) & 1, level = lane >> 2;
+  const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= B) return;  // wave-uniform
   float gx = 0.f, gy = 0.f, gz = 0.f;
-  if (live) {
+  if (level < lv.n_levels) {
     Cell c;
     load_cell(lv, level, x, b, table, c);
-    const float2 vf = *reinterpret_cast<const float2 *>(v_feat + (b * lv.n_levels + level) * 2);
-    float2 *vt = reinterpret_cast<float2 *>(v_table) + lv.offset[level];
+    const float vf = v_feat[(b * lv.n_levels + level) * 2 + f];
+    float *vt = v_table + (int64_t)lv.offset[level] * 2 + f;
+    const float *tb = table + (int64_t)lv.offset[level] * 2 + f;
+    const float wx = xb ? c.fr[0] : 1.f - c.fr[0], sx = xb ? 1.f : -1.f;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const int hx = k & 1, hy = (k >> 1) & 1, hz = k >> 2;
-      const uint32_t idx = grid_index(c.hsize, c.res, c.g0[0] + hx, c.g0[1] + hy, c.g0[2] + hz);
-      const float wx = hx ? c.fr[0] : 1.f - c.fr[0], wy = hy ? c.fr[1] : 1.f - c.fr[1], wz = hz ? c.fr[2] : 1.f - c.fr[2];
-      if (WANT_TABLE) {
-        const float w = wx * wy * wz;
-        atomicAdd(&vt[idx].x, w * vf.x);
-        atomicAdd(&vt[idx].y, w * vf.y);
-      }
+    for (int k = 0; k < 4; ++k) {
+      const int hy = k & 1, hz = k >> 1;
+      const uint32_t idx = grid_index(c.hsize, c.res, c.g0[0] + xb, c.g0[1] + hy, c.g0[2] + hz);
+      const float wy = hy ? c.fr[1] : 1.f - c.fr[1], wz = hz ? c.fr[2] : 1.f - c.fr[2];
+      if (WANT_TABLE) atomicAdd(vt + 2 * (int64_t)idx, wx * wy * wz * vf);
       if (WANT_X) {
-        const float2 v = c.base[idx];
-        const float t = vf.x * v.x + vf.y * v.y;
-        gx += (hx ? 1.f : -1.f) * wy * wz * t;
+        const float t = vf * tb[2 * (int64_t)idx];
+        gx += sx * wy * wz * t;
         gy += (hy ? 1.f : -1.f) * wx * wz * t;
         gz += (hz ? 1.f : -1.f) * wx * wy * t;
       }
@@ -154,54 +162,57 @@ __global__ void __launch_bounds__(HG_THREADS)
     gx *= c.scale; gy *= c.scale; gz *= c.scale;
   }
   if (WANT_X) {
-    gx = row_sum_to_lane15(gx); gy = row_sum_to_lane15(gy); gz = row_sum_to_lane15(gz);
-    if (level == 15 && b < B) { v_x[3 * b] = gx; v_x[3 * b + 1] = gy; v_x[3 * b + 2] = gz; }
+    gx = wave_sum_to_lane63(gx); gy = wave_sum_to_lane63(gy); gz = wave_sum_to_lane63(gz);
+    if (lane == 63) { v_x[3 * b] = gx; v_x[3 * b + 1] = gy; v_x[3 * b + 2] = gz; }
   }
 }
 
 // double backward of v_x = J(x,table)^T v_feat: inputs vv_x (the gradient arriving at v_x)
 template <bool WANT_VFEAT, bool WANT_TABLE, bool WANT_X>
-__global__ void __launch_bounds__(HG_THREADS)
+__global__ void __launch_bounds__(HGB_THREADS)
     hashgrid_bwd_bwd_kernel(int64_t B, HgLevels lv, const float *__restrict__ x, const float *__restrict__ table,
                             const float *__restrict__ v_feat, const float *__restrict__ vv_x,
                             float *__restrict__ g_vfeat, float *__restrict__ g_table, float *__restrict__ g_x) {
-  const int level = threadIdx.x & 15;
-  const int64_t b = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
-  const bool live = b < B && level < lv.n_levels;
-  float ox = 0.f, oy = 0.f, oz = 0.f;
-  if (live) {
+  const int lane = threadIdx.x & 63;
+  const int f = lane & 1, xb = (lane >> 1) & 1, level = lane >> 2;
+  const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= B) return;  // wave-uniform
+  float ox = 0.f, oy = 0.f, oz = 0.f, gv = 0.f;
+  if (level < lv.n_levels) {
     Cell c;
     load_cell(lv, level, x, b, table, c);
-    const float2 vf = *reinterpret_cast<const float2 *>(v_feat + (b * lv.n_levels + level) * 2);
+    const float vf = v_feat[(b * lv.n_levels + level) * 2 + f];
     const float vx = vv_x[3 * b], vy = vv_x[3 * b + 1], vz = vv_x[3 * b + 2];
-    float2 *gt = reinterpret_cast<float2 *>(g_table) + lv.offset[level];
-    float gv0 = 0.f, gv1 = 0.f;
+    float *gt = g_table + (int64_t)lv.offset[level] * 2 + f;
+    const float *tb = table + (int64_t)lv.offset[level] * 2 + f;
+    const float wx = xb ? c.fr[0] : 1.f - c.fr[0], sx = xb ? 1.f : -1.f;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const int hx = k & 1, hy = (k >> 1) & 1, hz = k >> 2;
-      const uint32_t idx = grid_index(c.hsize, c.res, c.g0[0] + hx, c.g0[1] + hy, c.g0[2] + hz);
-      const float wx = hx ? c.fr[0] : 1.f - c.fr[0], wy = hy ? c.fr[1] : 1.f - c.fr[1], wz = hz ? c.fr[2] : 1.f - c.fr[2];
-      const float sx = hx ? 1.f : -1.f, sy = hy ? 1.f : -1.f, sz = hz ? 1.f : -1.f;
-      // t = sum_d vv_d * scale * dw/dpos_d
+    for (int k = 0; k < 4; ++k) {
+      const int hy = k & 1, hz = k >> 1;
+      const uint32_t idx = grid_index(c.hsize, c.res, c.g0[0] + xb, c.g0[1] + hy, c.g0[2] + hz);
+      const float wy = hy ? c.fr[1] : 1.f - c.fr[1], wz = hz ? c.fr[2] : 1.f - c.fr[2];
+      const float sy = hy ? 1.f : -1.f, sz = hz ? 1.f : -1.f;
       const float t = c.scale * (vx * sx * wy * wz + vy * sy * wx * wz + vz * sz * wx * wy);
-      const float2 v = c.base[idx];
-      if (WANT_VFEAT) { gv0 += t * v.x; gv1 += t * v.y; }
-      if (WANT_TABLE) { atomicAdd(&gt[idx].x, t * vf.x); atomicAdd(&gt[idx].y, t * vf.y); }
+      const float th = tb[2 * (int64_t)idx];
+      if (WANT_VFEAT) gv += t * th;
+      if (WANT_TABLE) atomicAdd(gt + 2 * (int64_t)idx, t * vf);
       if (WANT_X) {
-        const float q = vf.x * v.x + vf.y * v.y;
-        // sum_d vv_d * d2w/(dpos_d dpos_e): mixed terms only
+        const float q = vf * th;
         ox += (vy * sy * sx * wz + vz * sz * sx * wy) * q;
         oy += (vx * sx * sy * wz + vz * sz * sy * wx) * q;
         oz += (vx * sx * sz * wy + vy * sy * sz * wx) * q;
       }
     }
-    if (WANT_VFEAT) *reinterpret_cast<float2 *>(g_vfeat + (b * lv.n_levels + level) * 2) = make_float2(gv0, gv1);
     const float s2 = c.scale * c.scale;
     ox *= s2; oy *= s2; oz *= s2;
   }
+  if (WANT_VFEAT) {
+    gv += dpp_mov<0x4E>(gv);  // quad_perm [2,3,0,1]: add the other x-corner's partial (same feature)
+    if (xb == 0 && level < lv.n_levels) g_vfeat[(b * lv.n_levels + level) * 2 + f] = gv;
+  }
   if (WANT_X) {
-    ox = row_sum_to_lane15(ox); oy = row_sum_to_lane15(oy); oz = row_sum_to_lane15(oz);
-    if (level == 15 && b < B) { g_x[3 * b] = ox; g_x[3 * b + 1] = oy; g_x[3 * b + 2] = oz; }
+    ox = wave_sum_to_lane63(ox); oy = wave_sum_to_lane63(oy); oz = wave_sum_to_lane63(oz);
+    if (lane == 63) { g_x[3 * b] = ox; g_x[3 * b + 1] = oy; g_x[3 * b + 2] = oz; }
   }
 }
 
@@ -248,7 +259,7 @@ extern "C" int gsdf_hashgrid_bwd(int64_t B, int n_levels, int n_feat, int log2_h
   GSDF_REQUIRE(x && table && v_feat, "hashgrid_bwd: null buffer");
   HgLevels lv;
   build_levels(n_levels, log2_hashmap, base_res, per_level_scale, &lv, nullptr);
-  const unsigned nb = (unsigned)((B + 15) / 16);
+  const unsigned nb = (unsigned)((B + 3) / 4);
   if (v_table && v_x) hashgrid_bwd_kernel<true, true><<<nb, HG_THREADS, 0, stream>>>(B, lv, x, table, v_feat, v_table, v_x);
   else if (v_table)   hashgrid_bwd_kernel<true, false><<<nb, HG_THREADS, 0, stream>>>(B, lv, x, table, v_feat, v_table, v_x);
   else                hashgrid_bwd_kernel<false, true><<<nb, HG_THREADS, 0, stream>>>(B, lv, x, table, v_feat, v_table, v_x);
@@ -267,7 +278,7 @@ extern "C" int gsdf_hashgrid_bwd_bwd(int64_t B, int n_levels, int n_feat, int lo
   GSDF_REQUIRE(x && table && v_feat && vv_x, "hashgrid_bwd_bwd: null buffer");
   HgLevels lv;
   build_levels(n_levels, log2_hashmap, base_res, per_level_scale, &lv, nullptr);
-  const unsigned nb = (unsigned)((B + 15) / 16);
+  const unsigned nb = (unsigned)((B + 3) / 4);
 #define L(A, Bq, Cq) hashgrid_bwd_bwd_kernel<A, Bq, Cq><<<nb, HG_THREADS, 0, stream>>>(B, lv, x, table, v_feat, vv_x, g_vfeat, g_table, g_x)
   const int sel = (g_vfeat ? 4 : 0) | (g_table ? 2 : 0) | (g_x ? 1 : 0);
   switch (sel) {

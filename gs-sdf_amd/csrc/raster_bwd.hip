@@ -5,9 +5,17 @@
 //
 // Per tile: replay the depth-sorted list back-to-front from each pixel's last contributor.  The
 // per-(pixel,splat) gradient terms are reduced over the 64 lanes of a wave with DPP row shifts
-// (no LDS traffic), the wave total is added to a per-tile LDS accumulator (ds_add_f32 from one
-// lane, 4 waves -> no contention) and each staged splat is flushed to HBM with ONE global atomic
-// per field per tile (instead of one per wave).
+// (no LDS traffic) and the wave total is added to a per-tile LDS accumulator (ds_add_f32 from one
+// lane, 4 waves -> no contention).
+//
+// Flush to HBM — measured on MI355X (tools/ubench/atomic_*.hip): the fp32 atomic path retires
+// ~21 G *64-byte-line requests*/s chip-wide, independent of footprint and scope, and lanes of one
+// instruction that hit the same line are merged (16 consecutive floats -> 307 G atomics/s).  One
+// atomic per (tile, splat, field) into six separate [M,k] arrays is 17 line requests per
+// intersection (4e7 per view = 1.9 ms of the 2.7 ms kernel).  So the accumulator of one splat is a
+// single 80-byte RECORD ([M][20] floats), three records are flushed per wave instruction with the
+// 20 fields in consecutive lanes (<= 2 lines per splat), and a streaming epilogue unpacks the
+// records into the operator's six gradient tensors (+ the densification signal).
 #include "raster_common.h"
 
 namespace gsdf {
@@ -17,9 +25,28 @@ static constexpr int NACC = 20;
 //                    16-17 v_means2d, 18-19 v_means2d_abs
 struct BwdLds {
   SplatBatch s;
-  float acc[NACC][RT];
+  float acc[RT][NACC];  // one 80-byte record per staged splat
   int bin_final_max;
 };
+
+// Adds the LDS records of this wave's 64 staged splats to the global record array and clears them.
+// Three splats per instruction: lane = 20*j + k -> field k of splat slot 3*it + j.
+__device__ __forceinline__ void flush_records(BwdLds &lds, int wave, int lane, int g_mine, float *__restrict__ grec) {
+  const int j = lane / NACC, k = lane - j * NACC;
+#pragma unroll 2
+  for (int it = 0; it < 22; ++it) {
+    const int slot = 3 * it + j;                     // 0..65
+    const int g = __shfl(g_mine, slot & 63, 64);
+    if (j < 3 && slot < 64 && g >= 0) {
+      float *a = &lds.acc[wave * 64 + slot][k];
+      const float v = *a;
+      if (v != 0.f) {
+        *a = 0.f;
+        atomicAdd(grec + (int64_t)g * NACC + k, v);
+      }
+    }
+  }
+}
 
 __device__ __forceinline__ void lds_add(float *p, float v) { atomicAdd(p, v); }
 
@@ -34,10 +61,7 @@ __global__ void __launch_bounds__(RT)
                       const int32_t *__restrict__ last_ids, const int32_t *__restrict__ median_ids,
                       const float *__restrict__ v_render_colors, const float *__restrict__ v_render_depths,
                       const float *__restrict__ v_render_alphas, const float *__restrict__ v_render_normals,
-                      const float *__restrict__ v_render_median, float *__restrict__ v_means2d,
-                      float *__restrict__ v_ray_transforms, float *__restrict__ v_colors,
-                      float *__restrict__ v_opacities, float *__restrict__ v_normals,
-                      float *__restrict__ v_means2d_abs) {
+                      const float *__restrict__ v_render_median, float *__restrict__ grec) {
   __shared__ BwdLds lds;
   const int64_t tile = xcd_tile_index(total_tiles);
   if (tile >= total_tiles) return;
@@ -76,7 +100,7 @@ __global__ void __launch_bounds__(RT)
 
   if (tid == 0) lds.bin_final_max = -1;
 #pragma unroll
-  for (int k = 0; k < NACC; ++k) lds.acc[k][tid] = 0.f;
+  for (int k = 0; k < NACC; ++k) lds.acc[tid][k] = 0.f;
   __syncthreads();
   {  // tile-wide and wave-wide last contributor
     int m = bin_final;
@@ -95,28 +119,8 @@ __global__ void __launch_bounds__(RT)
   const int nb = (min(end, tile_bin_final + 1) - start + RT - 1) / RT;
   for (int b = nb - 1; b >= 0; --b) {
     __syncthreads();  // barrier A: previous batch fully consumed, its accumulators complete
-    if (g_mine >= 0) {
-      const int64_t g = g_mine;
-      float a[NACC];
-#pragma unroll
-      for (int k = 0; k < NACC; ++k) { a[k] = lds.acc[k][tid]; lds.acc[k][tid] = 0.f; }
-#pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        if (a[k] != 0.f) atomicAdd(v_colors + 3 * g + k, a[k]);
-        if (a[3 + k] != 0.f) atomicAdd(v_normals + 3 * g + k, a[3 + k]);
-      }
-      if (a[6] != 0.f) atomicAdd(v_opacities + g, a[6]);
-#pragma unroll
-      for (int k = 0; k < 9; ++k)
-        if (a[7 + k] != 0.f) atomicAdd(v_ray_transforms + 9 * g + k, a[7 + k]);
-      if (a[16] != 0.f) atomicAdd(v_means2d + 2 * g, a[16]);
-      if (a[17] != 0.f) atomicAdd(v_means2d + 2 * g + 1, a[17]);
-      if (ABSGRAD) {
-        if (a[18] != 0.f) atomicAdd(v_means2d_abs + 2 * g, a[18]);
-        if (a[19] != 0.f) atomicAdd(v_means2d_abs + 2 * g + 1, a[19]);
-      }
-      g_mine = -1;
-    }
+    flush_records(lds, wave, lane, g_mine, grec);  // wave w owns slots [64w, 64w+64)
+    g_mine = -1;
     const int32_t bstart = start + b * RT;
     const int32_t idx = bstart + tid;
     if (idx < end && idx <= tile_bin_final) {
@@ -181,7 +185,7 @@ __global__ void __launch_bounds__(RT)
       float r;
 #define RED(slot, val)                                   \
   r = wave_sum_to_lane63(val);                           \
-  if (lane == 63 && r != 0.f) lds_add(&lds.acc[slot][t], r)
+  if (lane == 63 && r != 0.f) lds_add(&lds.acc[t][slot], r)
       RED(0, g_rgb0); RED(1, g_rgb1); RED(2, g_rgb2);
       RED(3, g_n0);   RED(4, g_n1);   RED(5, g_n2);
       RED(6, g_op);
@@ -199,47 +203,43 @@ __global__ void __launch_bounds__(RT)
     }
   }
   __syncthreads();
-  if (g_mine >= 0) {
-    const int64_t g = g_mine;
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      const float c = lds.acc[k][tid], n = lds.acc[3 + k][tid];
-      if (c != 0.f) atomicAdd(v_colors + 3 * g + k, c);
-      if (n != 0.f) atomicAdd(v_normals + 3 * g + k, n);
-    }
-    const float o = lds.acc[6][tid];
-    if (o != 0.f) atomicAdd(v_opacities + g, o);
-#pragma unroll
-    for (int k = 0; k < 9; ++k) {
-      const float v = lds.acc[7 + k][tid];
-      if (v != 0.f) atomicAdd(v_ray_transforms + 9 * g + k, v);
-    }
-    const float mx = lds.acc[16][tid], my = lds.acc[17][tid];
-    if (mx != 0.f) atomicAdd(v_means2d + 2 * g, mx);
-    if (my != 0.f) atomicAdd(v_means2d + 2 * g + 1, my);
-    if (ABSGRAD) {
-      const float ax = lds.acc[18][tid], ay = lds.acc[19][tid];
-      if (ax != 0.f) atomicAdd(v_means2d_abs + 2 * g, ax);
-      if (ay != 0.f) atomicAdd(v_means2d_abs + 2 * g + 1, ay);
-    }
-  }
+  flush_records(lds, wave, lane, g_mine, grec);
 }
 
+// Streaming epilogue: unpack the 80-byte records into the operator's gradient tensors and derive the
 // densification signal (SPEC S-4, 2DGS convention consumed at neural_gaussian.cpp:660-665):
-// v_densify = (dL/dM_u.z, dL/dM_v.z) * M_w.z  — a per-splat epilogue, no extra atomics.
-__global__ void __launch_bounds__(256) densify_epilogue_kernel(int64_t M, const float *__restrict__ ray_transforms,
-                                                               const float *__restrict__ v_ray_transforms,
-                                                               float *__restrict__ v_densify) {
+// v_densify = (dL/dM_u.z, dL/dM_v.z) * M_w.z.
+__global__ void __launch_bounds__(256)
+    unpack_records_kernel(int64_t M, const float *__restrict__ grec, const float *__restrict__ ray_transforms,
+                          float *__restrict__ v_means2d, float *__restrict__ v_ray_transforms,
+                          float *__restrict__ v_colors, float *__restrict__ v_opacities, float *__restrict__ v_normals,
+                          float *__restrict__ v_densify, float *__restrict__ v_means2d_abs) {
   const int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (m >= M) return;
+  float r[NACC];
+  const float4 *src = reinterpret_cast<const float4 *>(grec + m * NACC);
+#pragma unroll
+  for (int q = 0; q < NACC / 4; ++q) {
+    const float4 v = src[q];
+    r[4 * q] = v.x; r[4 * q + 1] = v.y; r[4 * q + 2] = v.z; r[4 * q + 3] = v.w;
+  }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { v_colors[3 * m + k] = r[k]; v_normals[3 * m + k] = r[3 + k]; }
+  v_opacities[m] = r[6];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) v_ray_transforms[9 * m + k] = r[7 + k];
+  v_means2d[2 * m] = r[16]; v_means2d[2 * m + 1] = r[17];
+  if (v_means2d_abs != nullptr) { v_means2d_abs[2 * m] = r[18]; v_means2d_abs[2 * m + 1] = r[19]; }
   const float depth = ray_transforms[9 * m + 8];
-  v_densify[2 * m] = v_ray_transforms[9 * m + 2] * depth;
-  v_densify[2 * m + 1] = v_ray_transforms[9 * m + 5] * depth;
+  v_densify[2 * m] = r[7 + 2] * depth;
+  v_densify[2 * m + 1] = r[7 + 5] * depth;
 }
 
 }  // namespace gsdf
 
 using namespace gsdf;
+
+extern "C" size_t gsdf_rasterize_2dgs_bwd_ws_bytes(int64_t M) { return (size_t)(M > 0 ? M : 1) * NACC * sizeof(float) + 256; }
 
 extern "C" int gsdf_rasterize_2dgs_bwd(int64_t C, int64_t M, int64_t I, int width, int height, int tile_size,
                                        const float *means2d, const float *ray_transforms, const float *colors,
@@ -251,29 +251,24 @@ extern "C" int gsdf_rasterize_2dgs_bwd(int64_t C, int64_t M, int64_t I, int widt
                                        const float *v_render_alphas, const float *v_render_normals,
                                        const float *v_render_median, float *v_means2d, float *v_ray_transforms,
                                        float *v_colors, float *v_opacities, float *v_normals, float *v_densify,
-                                       float *v_means2d_abs, gsdf_stream_t stream_) {
+                                       float *v_means2d_abs, void *ws, gsdf_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   GSDF_REQUIRE(tile_size == TILE, "rasterize_bwd: tile_size %d unsupported (16 only)", tile_size);
   GSDF_REQUIRE(width > 0 && height > 0 && C >= 1, "rasterize_bwd: bad geometry");
   if (M == 0) return GSDF_OK;
-  GSDF_REQUIRE(v_means2d && v_ray_transforms && v_colors && v_opacities && v_normals && v_densify,
-               "rasterize_bwd: null gradient output");
+  GSDF_REQUIRE(v_means2d && v_ray_transforms && v_colors && v_opacities && v_normals && v_densify && ws,
+               "rasterize_bwd: null gradient output / workspace");
   GSDF_REQUIRE(render_alphas && last_ids && median_ids && v_render_colors && v_render_depths && v_render_alphas &&
                    v_render_normals && v_render_median && isect_offsets,
                "rasterize_bwd: null input");
   const int tw = (width + TILE - 1) / TILE, th = (height + TILE - 1) / TILE;
   const int64_t n_tiles = (int64_t)tw * th, total = n_tiles * C;
-  GSDF_HIP(hipMemsetAsync(v_means2d, 0, (size_t)M * 8, stream), "memset");
-  GSDF_HIP(hipMemsetAsync(v_ray_transforms, 0, (size_t)M * 36, stream), "memset");
-  GSDF_HIP(hipMemsetAsync(v_colors, 0, (size_t)M * 12, stream), "memset");
-  GSDF_HIP(hipMemsetAsync(v_opacities, 0, (size_t)M * 4, stream), "memset");
-  GSDF_HIP(hipMemsetAsync(v_normals, 0, (size_t)M * 12, stream), "memset");
-  if (v_means2d_abs) GSDF_HIP(hipMemsetAsync(v_means2d_abs, 0, (size_t)M * 8, stream), "memset");
+  float *grec = (float *)ws;
+  GSDF_HIP(hipMemsetAsync(grec, 0, (size_t)M * NACC * sizeof(float), stream), "rasterize_bwd memset");
   if (I > 0) {
 #define ARGS total, n_tiles, I, width, height, tw, means2d, ray_transforms, colors, opacities, normals, backgrounds, \
              masks, isect_offsets, flatten_ids, render_alphas, last_ids, median_ids, v_render_colors,               \
-             v_render_depths, v_render_alphas, v_render_normals, v_render_median, v_means2d, v_ray_transforms,      \
-             v_colors, v_opacities, v_normals, v_means2d_abs
+             v_render_depths, v_render_alphas, v_render_normals, v_render_median, grec
     if (v_means2d_abs)
       raster_bwd_kernel<true><<<xcd_grid(total), RT, 0, stream>>>(ARGS);
     else
@@ -281,8 +276,9 @@ extern "C" int gsdf_rasterize_2dgs_bwd(int64_t C, int64_t M, int64_t I, int widt
 #undef ARGS
     GSDF_CHECK_LAUNCH("raster_bwd_kernel");
   }
-  densify_epilogue_kernel<<<(unsigned)((M + 255) / 256), 256, 0, stream>>>(M, ray_transforms, v_ray_transforms,
-                                                                          v_densify);
-  GSDF_CHECK_LAUNCH("densify_epilogue_kernel");
+  unpack_records_kernel<<<(unsigned)((M + 255) / 256), 256, 0, stream>>>(M, grec, ray_transforms, v_means2d,
+                                                                       v_ray_transforms, v_colors, v_opacities,
+                                                                       v_normals, v_densify, v_means2d_abs);
+  GSDF_CHECK_LAUNCH("unpack_records_kernel");
   return GSDF_OK;
 }

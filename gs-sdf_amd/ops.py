@@ -242,11 +242,12 @@ class _Rasterize2DGS(torch.autograd.Function):
         e = lambda *s: _empty(s, torch.float32, means2d)
         v_means2d, v_rt, v_colors, v_opac, v_normals, v_dens = e(M, 2), e(M, 3, 3), e(M, 3), e(M), e(M, 3), e(M, 2)
         v_abs = e(M, 2) if ctx.absgrad else None
+        ws = torch.empty(L.gsdf_rasterize_2dgs_bwd_ws_bytes(M), dtype=torch.uint8, device=means2d.device)
         capi.check(_timed("rasterize_2dgs_bwd", L.gsdf_rasterize_2dgs_bwd, C, M, I, width, height, tile_size, f32(means2d), f32(rt), f32(colors),
                                              f32(opacities), f32(normals), f32(bg), ptr(mk), ptr(isect_offsets),
                                              ptr(flatten_ids), f32(ra), ptr(last), ptr(med), f32(v_rc), f32(v_rd), f32(v_ra),
                                              f32(v_rn), f32(v_rm), f32(v_means2d), f32(v_rt), f32(v_colors), f32(v_opac),
-                                             f32(v_normals), f32(v_dens), f32(v_abs), capi.stream()), "rasterize_2dgs_bwd")
+                                             f32(v_normals), f32(v_dens), f32(v_abs), ptr(ws), capi.stream()), "rasterize_2dgs_bwd")
         return (v_means2d, v_rt, v_colors, v_opac, v_normals, v_dens, v_abs, None, None, None, None, None, None, None)
 
 

@@ -212,6 +212,21 @@ class LocalMap:
             ps += [self.decoder.params_] + ([self.decoder.biases_] if self.decoder.biases_ is not None else [])
         return ps
 
+    def flatten(self):
+        """Moves every parameter into one flat buffer (single all-reduce message); returns a FlatGroup."""
+        from .trainer import FlatGroup, flatten_leaves
+        flat, flat_grad, views = flatten_leaves(self.parameters())
+        if isinstance(self.decoder, torch.nn.Module):
+            self.encoder.params_ = views[0]
+            for p, v in zip(self.decoder.parameters(), views[1:]):
+                p.data = v.data
+                p.grad = v.grad
+        else:
+            self.encoder.params_, self.decoder.params_ = views[0], views[1]
+            if self.decoder.biases_ is not None:
+                self.decoder.biases_ = views[2]
+        return FlatGroup(flat, flat_grad)
+
     def xyz_to_zp1_pts(self, xyz):                 # sub_map.cpp:82-97
         return 0.5 * ((xyz - self.pos_W_M) * (2.0 * self.map_size_inv)) + 0.5
 

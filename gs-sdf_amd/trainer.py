@@ -60,16 +60,46 @@ class ViewParallel:
     """Gradient synchronisation for view-parallel training.  `dist` is torch.distributed (backend nccl == RCCL
     on ROCm, gloo in the CPU tests) or None for a single process."""
 
-    def __init__(self, params, dist=None):
+    def __init__(self, params, dist=None, extra_groups=()):
         self.params, self.dist = params, dist
+        self.groups = [params] + list(extra_groups)
         self.world = dist.get_world_size() if dist is not None else 1
 
     def zero_grad(self):
-        self.params.flat_grad.zero_()
+        for g in self.groups:
+            g.flat_grad.zero_()
 
     def all_reduce_grads(self):
         if self.dist is None or self.world == 1:
             return
-        # mean over the G views of the step (effective batch G; SURVEY 8e "semantics change to report")
-        self.dist.all_reduce(self.params.flat_grad, op=self.dist.ReduceOp.SUM)
-        self.params.flat_grad.mul_(1.0 / self.world)
+        # mean over the G views of the step (effective batch G; SURVEY 8e "semantics change to report").
+        # One large message per parameter family: splats (56 B/splat) and the SDF network (61 MB table + MLP).
+        for g in self.groups:
+            self.dist.all_reduce(g.flat_grad, op=self.dist.ReduceOp.SUM)
+            g.flat_grad.mul_(1.0 / self.world)
+
+
+def flatten_leaves(tensors):
+    """Re-homes a list of leaf parameters into ONE flat buffer (+ one flat gradient buffer) and returns
+    (flat, flat_grad, views).  The views replace the original leaves (same values, same shapes)."""
+    dev = tensors[0].device
+    total = sum(t.numel() for t in tensors)
+    flat = torch.empty(total, dtype=torch.float32, device=dev)
+    flat_grad = torch.zeros(total, dtype=torch.float32, device=dev)
+    views, off = [], 0
+    for t in tensors:
+        n = t.numel()
+        v = flat[off:off + n].view(t.shape)
+        v.copy_(t.detach())
+        v.requires_grad_(True)
+        v.grad = flat_grad[off:off + n].view(t.shape)
+        views.append(v)
+        off += n
+    return flat, flat_grad, views
+
+
+class FlatGroup:
+    """Any flat (params, grads) pair that takes part in the per-step all-reduce (e.g. the SDF network)."""
+
+    def __init__(self, flat, flat_grad):
+        self.flat, self.flat_grad = flat, flat_grad

@@ -126,7 +126,9 @@ int gsdf_rasterize_2dgs_fwd(int64_t n_cams, int64_t n_visible, int64_t n_isects,
                             int32_t *last_ids /*[C,H,W]*/, int32_t *median_ids /*[C,H,W]*/,
                             float *visibilities /*[M,1], fully written*/, gsdf_stream_t stream);
 
-/* All gradient outputs are fully written (zeroed inside).  v_means2d_abs may be NULL. */
+/* All gradient outputs are fully written.  v_means2d_abs may be NULL.  ws >= *_bwd_ws_bytes(M): the kernel
+ * accumulates one packed 80-byte gradient record per splat there (line-coalesced atomics) and unpacks it. */
+size_t gsdf_rasterize_2dgs_bwd_ws_bytes(int64_t n_visible);
 int gsdf_rasterize_2dgs_bwd(int64_t n_cams, int64_t n_visible, int64_t n_isects, int width, int height,
                             int tile_size, const float *means2d, const float *ray_transforms,
                             const float *colors, const float *opacities, const float *normals,
@@ -136,7 +138,7 @@ int gsdf_rasterize_2dgs_bwd(int64_t n_cams, int64_t n_visible, int64_t n_isects,
                             const float *v_render_depths, const float *v_render_alphas,
                             const float *v_render_normals, const float *v_render_median, float *v_means2d,
                             float *v_ray_transforms, float *v_colors, float *v_opacities, float *v_normals,
-                            float *v_densify, float *v_means2d_abs, gsdf_stream_t stream);
+                            float *v_densify, float *v_means2d_abs, void *ws, gsdf_stream_t stream);
 
 
 /* ------------------------------------------------------------------------------------------
