@@ -125,11 +125,20 @@ __global__ void __launch_bounds__(RT)
     const int32_t idx = bstart + tid;
     if (idx < end && idx <= tile_bin_final) {
       g_mine = flatten_ids[idx];
-      stage_splat(lds.s, tid, g_mine, means2d, ray_transforms, colors, opacities, normals);
+      stage_splat(lds.s, tid, g_mine, means2d, ray_transforms, colors, opacities, normals, (float)(tx * TILE),
+                  (float)(ty * TILE));
     }
     __syncthreads();  // barrier B
     const int count = min(RT, min(end, tile_bin_final + 1) - bstart);
-    for (int t = min(count, wave_bin_final - bstart + 1) - 1; t >= 0; --t) {
+    // per-wave compaction (see raster_common.h quadrant_mask), back-to-front
+    const int wcount = min(count, wave_bin_final - bstart + 1);
+    for (int c0 = ((wcount - 1) >> 6) << 6; c0 >= 0 && wcount > 0; c0 -= 64) {
+      const int ti = c0 + lane;
+      unsigned long long todo = __ballot(ti < wcount && ((lds.s.qmask[ti < RT ? ti : 0] >> wave) & 1u));
+      while (todo) {
+      const int hb = 63 - __builtin_clzll(todo);
+      todo &= ~(1ull << hb);
+      const int t = c0 + hb;
       const float4 a0 = lds.s.q0[t], a1 = lds.s.q1[t], a2 = lds.s.q2[t];
       PairEval e;
       eval_pair(px, py, a0, a1, a2, e);
@@ -200,6 +209,7 @@ __global__ void __launch_bounds__(RT)
         if (ABSGRAD) { RED(18, fabsf(g_x)); RED(19, fabsf(g_y)); }
       }
 #undef RED
+      }
     }
   }
   __syncthreads();

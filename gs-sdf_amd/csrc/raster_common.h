@@ -26,19 +26,65 @@ static constexpr float FILTER_INV_SQUARE = 2.0f;
 struct SplatBatch {
   float4 q0[RT], q1[RT], q2[RT], q3[RT];
   float2 q4[RT];
+  unsigned qmask[RT];  // bit q set <=> the splat can reach wave q's 8x8 pixel quadrant (conservative)
 };
+
+// Conservative per-quadrant reach test, evaluated ONCE per (tile, splat) by the staging lane.
+// A pair contributes only if alpha = o*exp(-min(g3,g2)/2) >= 1/255, i.e. min(g3,g2) <= tau = 2 ln(255 o).
+//   {g3 <= tau}: projection of the splat disk u^2+v^2 <= tau.  Its exact screen bounding box follows from the
+//     dual conic W diag(1,1,-1/tau) W^T (same construction as the 3-sigma box of SPEC A.1): with
+//     D = (1,1,-1/tau), d = M_w.D.M_w (< 0 for an ellipse), c = (M_u.D.M_w)/d, h^2 = c^2 - (M_u.D.M_u)/d.
+//   {g2 <= tau}: screen disk of radius sqrt(tau/2) around mean2d (the low-pass branch).
+// The box is the union of both, grown by 0.3 px (fp32 cancellation in h^2 is < 0.1 px for |c| < 4096).
+// Hyperbolic / degenerate conics (d >= 0) are not culled.  Skipping an unreachable quadrant removes only
+// pairs whose alpha test would have failed, so results are unchanged.
+__device__ __forceinline__ unsigned quadrant_mask(const float *__restrict__ m, float mx, float my, float opac,
+                                                  float tile_x0, float tile_y0) {
+  const float o255 = 255.0f * opac;
+  if (!(o255 > 1.0f)) return 0u;  // alpha < 1/255 everywhere
+  const float tau = 2.0f * __logf(o255) * 1.0001f + 1e-4f;
+  const float r2 = sqrtf(0.5f * tau);
+  float x0 = mx - r2, x1 = mx + r2, y0 = my - r2, y1 = my + r2;
+  const float it = 1.0f / tau;
+  const float d = m[6] * m[6] + m[7] * m[7] - it * m[8] * m[8];
+  bool bounded = d < 0.0f;
+  if (bounded) {
+    const float id = 1.0f / d;
+    const float cx = (m[0] * m[6] + m[1] * m[7] - it * m[2] * m[8]) * id;
+    const float cy = (m[3] * m[6] + m[4] * m[7] - it * m[5] * m[8]) * id;
+    const float hx2 = cx * cx - (m[0] * m[0] + m[1] * m[1] - it * m[2] * m[2]) * id;
+    const float hy2 = cy * cy - (m[3] * m[3] + m[4] * m[4] - it * m[5] * m[5]) * id;
+    const float hx = sqrtf(fmaxf(hx2, 0.0f)), hy = sqrtf(fmaxf(hy2, 0.0f));
+    bounded = (hx == hx) && (hy == hy) && (cx == cx) && (cy == cy);  // NaN guard
+    x0 = fminf(x0, cx - hx); x1 = fmaxf(x1, cx + hx);
+    y0 = fminf(y0, cy - hy); y1 = fmaxf(y1, cy + hy);
+  }
+  if (!bounded) return 0xFu;
+  const float mg = 0.3f;
+  x0 -= mg; x1 += mg; y0 -= mg; y1 += mg;
+  unsigned mask = 0u;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float qx = tile_x0 + (float)((q & 1) * 8), qy = tile_y0 + (float)((q >> 1) * 8);
+    // pixel centres of the quadrant span [qx+0.5, qx+7.5]
+    if (x1 >= qx + 0.5f && x0 <= qx + 7.5f && y1 >= qy + 0.5f && y0 <= qy + 7.5f) mask |= 1u << q;
+  }
+  return mask;
+}
 
 __device__ __forceinline__ void stage_splat(SplatBatch &s, int slot, int g, const float *__restrict__ means2d,
                                             const float *__restrict__ ray_transforms,
                                             const float *__restrict__ colors, const float *__restrict__ opacities,
-                                            const float *__restrict__ normals) {
+                                            const float *__restrict__ normals, float tile_x0, float tile_y0) {
   const float *m = ray_transforms + 9 * (int64_t)g;
   const float2 xy = *reinterpret_cast<const float2 *>(means2d + 2 * (int64_t)g);
   const float *c = colors + 3 * (int64_t)g;
   const float *n = normals + 3 * (int64_t)g;
+  const float opac = opacities[g];
   s.q0[slot] = make_float4(m[0], m[1], m[2], xy.x);
   s.q1[slot] = make_float4(m[3], m[4], m[5], xy.y);
-  s.q2[slot] = make_float4(m[6], m[7], m[8], opacities[g]);
+  s.q2[slot] = make_float4(m[6], m[7], m[8], opac);
+  s.qmask[slot] = quadrant_mask(m, xy.x, xy.y, opac, tile_x0, tile_y0);
   s.q3[slot] = make_float4(c[0], c[1], c[2], n[0]);
   s.q4[slot] = make_float2(n[1], n[2]);
 }

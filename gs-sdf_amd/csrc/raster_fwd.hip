@@ -58,36 +58,45 @@ __global__ void __launch_bounds__(RT)
     const int32_t idx = bstart + tid;
     if (idx < end) {
       g_mine = flatten_ids[idx];
-      stage_splat(lds.s, tid, g_mine, means2d, ray_transforms, colors, opacities, normals);
+      stage_splat(lds.s, tid, g_mine, means2d, ray_transforms, colors, opacities, normals, (float)(tx * TILE),
+                  (float)(ty * TILE));
       lds.vis[tid] = 0u;
     }
     __syncthreads();  // barrier B
     const int count = min(RT, end - bstart);
     if (__ballot(!done) == 0ull) continue;  // this wave's 64 pixels are all finished
-    for (int t = 0; t < count; ++t) {
-      const float4 a0 = lds.s.q0[t], a1 = lds.s.q1[t], a2 = lds.s.q2[t];
-      PairEval e;
-      eval_pair(px, py, a0, a1, a2, e);
-      bool valid = !done && e.ok;
-      if (__ballot(valid) == 0ull) continue;
-      const float nT = T * (1.0f - e.alpha);
-      if (valid && nT <= T_EPS) {  // this pixel is finished: exclusive (the splat is not blended)
-        done = true;
-        valid = false;
+    // per-wave compaction: only the splats whose conservative box reaches this wave's quadrant are evaluated
+    for (int c0 = 0; c0 < count; c0 += 64) {
+      const int ti = c0 + lane;
+      unsigned long long todo = __ballot(ti < count && ((lds.s.qmask[ti < RT ? ti : 0] >> wave) & 1u));
+      while (todo) {
+        const int t = c0 + __builtin_ctzll(todo);  // front-to-back
+        todo &= todo - 1ull;
+        const float4 a0 = lds.s.q0[t], a1 = lds.s.q1[t], a2 = lds.s.q2[t];
+        PairEval e;
+        eval_pair(px, py, a0, a1, a2, e);
+        bool valid = !done && e.ok;
+        if (__ballot(valid) == 0ull) continue;
+        const float nT = T * (1.0f - e.alpha);
+        if (valid && nT <= T_EPS) {  // this pixel is finished: exclusive (the splat is not blended)
+          done = true;
+          valid = false;
+        }
+        const float w = valid ? e.alpha * T : 0.0f;
+        const float4 a3 = lds.s.q3[t];
+        const float2 a4 = lds.s.q4[t];
+        cr += a3.x * w; cg += a3.y * w; cb += a3.z * w;
+        nx += a3.w * w; ny += a4.x * w; nz += a4.y * w;
+        dsum += e.dep * w;
+        if (valid) {
+          if (T > 0.5f) { med = e.dep; med_idx = bstart + t; }
+          cur = bstart + t;
+          T = nT;
+        }
+        const float wmax = wave_max_to_lane63(w);
+        if (lane == 63 && wmax > 0.0f) atomicMax(&lds.vis[t], __float_as_uint(wmax));
       }
-      const float w = valid ? e.alpha * T : 0.0f;
-      const float4 a3 = lds.s.q3[t];
-      const float2 a4 = lds.s.q4[t];
-      cr += a3.x * w; cg += a3.y * w; cb += a3.z * w;
-      nx += a3.w * w; ny += a4.x * w; nz += a4.y * w;
-      dsum += e.dep * w;
-      if (valid) {
-        if (T > 0.5f) { med = e.dep; med_idx = bstart + t; }
-        cur = bstart + t;
-        T = nT;
-      }
-      const float wmax = wave_max_to_lane63(w);
-      if (lane == 63 && wmax > 0.0f) atomicMax(&lds.vis[t], __float_as_uint(wmax));
+      if (__ballot(!done) == 0ull) break;
     }
   }
   __syncthreads();
