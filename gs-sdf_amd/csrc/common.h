@@ -69,6 +69,35 @@ __device__ __forceinline__ float wave_max_to_lane63(float v) {
   return v;
 }
 
+// Transposing butterfly reduction of 16 per-lane values over a DPP row (16 lanes): at every stage each lane
+// keeps the half of the values selected by one of its lane bits and receives the partner lane's partial of
+// the same half, so the work halves per stage (8+4+2+1 adds instead of 16 x 4).  On return the lane holds
+// the ROW sum of value index m = 8*b0 + 4*b1 + 2*b2 + b3 (b_i = bit i of the lane id); the 4 rows of the
+// wave still have to be combined (the callers do it with one 4-way ds_add_f32 per lane).
+template <int CTRL_LO, int CTRL_HI, int BANK_LO, int BANK_HI>
+__device__ __forceinline__ float dpp_xchg(float v) {
+  // lanes of BANK_LO read with CTRL_LO (row_shl), lanes of BANK_HI with CTRL_HI (row_shr)
+  int t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL_LO, 0xF, BANK_LO, false);
+  t = __builtin_amdgcn_update_dpp(t, __float_as_int(v), CTRL_HI, 0xF, BANK_HI, false);
+  return __int_as_float(t);
+}
+
+__device__ __forceinline__ float row_transpose_reduce16(const float (&v)[16], int lane) {
+  const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4, b3 = lane & 8;
+  float a[8], b[4], c[2];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) a[k] = (b0 ? v[k + 8] : v[k]) + dpp_mov<0xB1>(b0 ? v[k] : v[k + 8]);  // lane ^ 1
+#pragma unroll
+  for (int k = 0; k < 4; ++k) b[k] = (b1 ? a[k + 4] : a[k]) + dpp_mov<0x4E>(b1 ? a[k] : a[k + 4]);  // lane ^ 2
+#pragma unroll
+  for (int k = 0; k < 2; ++k)
+    c[k] = (b2 ? b[k + 2] : b[k]) + dpp_xchg<0x104, 0x114, 0x5, 0xA>(b2 ? b[k] : b[k + 2]);          // lane ^ 4
+  return (b3 ? c[1] : c[0]) + dpp_xchg<0x108, 0x118, 0x3, 0xC>(b3 ? c[0] : c[1]);                     // lane ^ 8
+}
+__device__ __forceinline__ int row_transpose_index(int lane) {
+  return ((lane & 1) << 3) | ((lane & 2) << 1) | ((lane & 4) >> 1) | ((lane & 8) >> 3);
+}
+
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 
 }  // namespace gsdf

@@ -149,7 +149,7 @@ __global__ void __launch_bounds__(RT)
       float g_rgb0 = 0.f, g_rgb1 = 0.f, g_rgb2 = 0.f, g_n0 = 0.f, g_n1 = 0.f, g_n2 = 0.f, g_op = 0.f;
       float g_mu0 = 0.f, g_mu1 = 0.f, g_mu2 = 0.f, g_mv0 = 0.f, g_mv1 = 0.f, g_mv2 = 0.f, g_mw0 = 0.f, g_mw1 = 0.f,
             g_mw2 = 0.f, g_x = 0.f, g_y = 0.f;
-      bool v3 = false, v2 = false;
+      bool v2 = false;
       if (valid) {
         const float ra = 1.0f / (1.0f - e.alpha);
         T *= ra;
@@ -170,7 +170,7 @@ __global__ void __launch_bounds__(RT)
           v_sigma = -a2.w * e.vis * v_alpha;
         }
         if (e.b3) {
-          v3 = true;
+
           const float vsx = v_sigma * e.sx + v_dep * a2.x, vsy = v_sigma * e.sy + v_dep * a2.y;
           const float inv = __builtin_amdgcn_rcpf(e.zz);
           const float qx = vsx * inv, qy = vsy * inv;
@@ -190,21 +190,18 @@ __global__ void __launch_bounds__(RT)
           g_mw2 = v_dep;
         }
       }
-      const bool any3 = __ballot(v3) != 0ull, any2 = __ballot(v2) != 0ull;
+      const bool any2 = __ballot(v2) != 0ull;
       float r;
+      {  // slots 0..15 (rgb, normal, opacity, M_u, M_v, M_w): one transposing butterfly, one ds_add per lane
+        const float v16[16] = {g_rgb0, g_rgb1, g_rgb2, g_n0, g_n1, g_n2, g_op, g_mu0, g_mu1, g_mu2,
+                               g_mv0, g_mv1, g_mv2, g_mw0, g_mw1, g_mw2};
+        r = row_transpose_reduce16(v16, lane);
+        if (r != 0.f) lds_add(&lds.acc[t][row_transpose_index(lane)], r);  // 4 rows -> 4-way add on one address
+      }
 #define RED(slot, val)                                   \
   r = wave_sum_to_lane63(val);                           \
   if (lane == 63 && r != 0.f) lds_add(&lds.acc[t][slot], r)
-      RED(0, g_rgb0); RED(1, g_rgb1); RED(2, g_rgb2);
-      RED(3, g_n0);   RED(4, g_n1);   RED(5, g_n2);
-      RED(6, g_op);
-      RED(15, g_mw2);
-      if (any3) {
-        RED(7, g_mu0);  RED(8, g_mu1);  RED(9, g_mu2);
-        RED(10, g_mv0); RED(11, g_mv1); RED(12, g_mv2);
-        RED(13, g_mw0); RED(14, g_mw1);
-      }
-      if (any2) {
+      if (any2) {  // screen-space low-pass branch (rare): v_means2d (+abs)
         RED(16, g_x); RED(17, g_y);
         if (ABSGRAD) { RED(18, fabsf(g_x)); RED(19, fabsf(g_y)); }
       }
