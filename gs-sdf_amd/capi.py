@@ -31,6 +31,8 @@ _SIGS = {
     "gsdf_rasterize_2dgs_fwd": (C.c_int, [_i64, _i64, _i64, _i32, _i32, _i32] + [_vp] * 18),
     "gsdf_rasterize_2dgs_bwd_ws_bytes": (_sz, [_i64]),
     "gsdf_rasterize_2dgs_bwd": (C.c_int, [_i64, _i64, _i64, _i32, _i32, _i32] + [_vp] * 26),
+    "gsdf_render_post_fwd": (C.c_int, [_i64, _i32] + [_vp] * 8),
+    "gsdf_render_post_bwd": (C.c_int, [_i64, _i32] + [_vp] * 10),
     "gsdf_hashgrid_offsets": (_i64, [_i32, _i32, _i32, _i32, _f32, _vp]),
     "gsdf_hashgrid_fwd": (C.c_int, [_i64, _i32, _i32, _i32, _i32, _f32] + [_vp] * 4),
     "gsdf_hashgrid_bwd": (C.c_int, [_i64, _i32, _i32, _i32, _i32, _f32] + [_vp] * 6),

@@ -269,6 +269,54 @@ def rasterize_to_pixels_2dgs(means2d, ray_transforms, colors, opacities, normals
                                 backgrounds, masks, int(width), int(height), int(tile_size), isect_offsets, flatten_ids)
 
 
+class _RenderPost(torch.autograd.Function):
+    """Fused per-pixel epilogue (neural_gaussian.cpp:229-240): depth/alpha + nan_to_num, cat, normals to world."""
+
+    @staticmethod
+    def forward(ctx, rc, rd, ra, rn, viewmats, expected_depth):
+        L = capi.lib()
+        rc, rd, ra, rn, viewmats = rc.contiguous(), rd.contiguous(), ra.contiguous(), rn.contiguous(), viewmats.contiguous()
+        n_pix = ra.numel()
+        renders = torch.empty(*ra.shape[:-1], 4, dtype=torch.float32, device=ra.device)
+        nw = torch.empty_like(rn)
+        capi.check(_timed("render_post_fwd", L.gsdf_render_post_fwd, n_pix, int(expected_depth), f32(viewmats), f32(rc),
+                          f32(rd), f32(ra), f32(rn), f32(renders), f32(nw), capi.stream()), "render_post_fwd")
+        ctx.save_for_backward(rd, ra, viewmats)
+        ctx.expected_depth = int(expected_depth)
+        return renders, nw
+
+    @staticmethod
+    def backward(ctx, v_renders, v_nw):
+        L = capi.lib()
+        rd, ra, viewmats = ctx.saved_tensors
+        n_pix = ra.numel()
+        v_renders = torch.zeros(*ra.shape[:-1], 4, device=ra.device) if v_renders is None else v_renders.contiguous()
+        v_nw = torch.zeros(*ra.shape[:-1], 3, device=ra.device) if v_nw is None else v_nw.contiguous()
+        v_rc, v_rn = torch.empty(*ra.shape[:-1], 3, device=ra.device), torch.empty(*ra.shape[:-1], 3, device=ra.device)
+        v_rd, v_ra = torch.empty_like(ra), torch.empty_like(ra)
+        capi.check(_timed("render_post_bwd", L.gsdf_render_post_bwd, n_pix, ctx.expected_depth, f32(viewmats), f32(rd),
+                          f32(ra), f32(v_renders), f32(v_nw), f32(v_rc), f32(v_rd), f32(v_ra), f32(v_rn), capi.stream()),
+                   "render_post_bwd")
+        return v_rc, v_rd, v_ra, v_rn, None, None
+
+
+class _GatherRows(torch.autograd.Function):
+    """x[ids] for row ids that are unique per camera (packed mode): the backward is an index_add (atomics) instead
+    of the sort-based index_put the generic advanced-indexing backward launches."""
+
+    @staticmethod
+    def forward(ctx, x, ids):
+        ctx.save_for_backward(ids)
+        ctx.n = x.shape[0]
+        return x.index_select(0, ids)
+
+    @staticmethod
+    def backward(ctx, g):
+        (ids,) = ctx.saved_tensors
+        out = torch.zeros((ctx.n,) + tuple(g.shape[1:]), dtype=g.dtype, device=g.device)
+        return out.index_add_(0, ids, g), None
+
+
 # ------------------------------------------------------------------------------------------------
 # rasterization_2dgs_sdf: host orchestration of P1 -> P2 -> P3 -> P4 (neural_gaussian.cpp:129-271)
 # ------------------------------------------------------------------------------------------------
@@ -286,7 +334,7 @@ def rasterization_2dgs_sdf(means, quats, scales, opacities, colors, viewmats, Ks
      samples_weights) = fully_fused_projection_2dgs(means, quats, scales, viewmats, Ks, width, height, near_plane,
                                                     far_plane, radius_clip, packed, sparse_grad,
                                                     0 if center_reg else sample_seed)
-    pt_opacities = opacities[gaussian_ids]
+    pt_opacities = _GatherRows.apply(opacities, gaussian_ids)
     pt_colors = get_view_colors(viewmats, means, radii, colors, camera_ids, gaussian_ids, sh_degree)
     tiles_per_gauss, flatten_ids, isect_offsets = tile_encode(width, height, tile_size, means2d, radii, depths, packed,
                                                               C, camera_ids, gaussian_ids)
@@ -299,10 +347,9 @@ def rasterization_2dgs_sdf(means, quats, scales, opacities, colors, viewmats, Ks
     meta = {}
     if absgrad:
         meta["absgrad"] = means2d_absgrad
-    if render_mode in ("ED", "RGB+ED"):
-        render_depths = (render_depths / render_alphas).nan_to_num()
-    render_colors = torch.cat([render_colors, render_depths], -1)
-    render_normals = render_normals.matmul(torch.linalg.inv(viewmats)[0, :3, :3].t())   # to world space
+    # neural_gaussian.cpp:229-240 in one fused pass: expected depth, cat(colours, depth), normals to world space
+    render_colors, render_normals = _RenderPost.apply(render_colors, render_depths, render_alphas, render_normals,
+                                                      viewmats, render_mode in ("ED", "RGB+ED"))
     meta.update(render_normal=render_normals, render_median=render_median, normal=normals, gaussian_ids=gaussian_ids,
                 radii=radii, gradient_2dgs=densify, width=torch.tensor([width]), height=torch.tensor([height]),
                 n_cameras=torch.tensor([C]), samples=samples, samples_weights=samples_weights,

@@ -142,6 +142,20 @@ int gsdf_rasterize_2dgs_bwd(int64_t n_cams, int64_t n_visible, int64_t n_isects,
 
 
 /* ------------------------------------------------------------------------------------------
+ * a3  per-pixel epilogue of rasterization_2dgs_sdf (include/neural_gaussian/neural_gaussian.cpp:229-240):
+ *     renders [n,4] = cat(colours, expected_depth ? nan_to_num(depth/alpha) : depth);
+ *     normals_world [n,3] = normals @ inverse(viewmats)[0,:3,:3]^T   (camera 0's pose, as the reference does).
+ * viewmat0: the first 4x4 world->camera matrix (device).  n_pix = C*H*W.
+ * ---------------------------------------------------------------------------------------- */
+int gsdf_render_post_fwd(int64_t n_pix, int expected_depth, const float *viewmat0, const float *render_colors,
+                         const float *render_depths, const float *render_alphas, const float *render_normals,
+                         float *renders, float *normals_world, gsdf_stream_t stream);
+int gsdf_render_post_bwd(int64_t n_pix, int expected_depth, const float *viewmat0, const float *render_depths,
+                         const float *render_alphas, const float *v_renders, const float *v_normals_world,
+                         float *v_render_colors, float *v_render_depths, float *v_render_alphas,
+                         float *v_render_normals, gsdf_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * S1  TCNNEncoding::forward — multiresolution hash grid (tiny-cuda-nn "Grid"/"Hash"/"Linear")
  *     reference: include/neural_net/encoding_map.cpp:15-26 (config {n_levels 16, n_features_per_level 2,
  *     log2_hashmap_size 19, base_resolution 32, per_level_scale 2.0}), :59 (forward);

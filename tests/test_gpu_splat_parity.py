@@ -239,3 +239,29 @@ def test_full_size_properties(ops):
     (colors[..., :3].sum() + alphas.sum()).backward()
     for x in leaves:
         assert x.grad is not None and torch.isfinite(x.grad).all()
+
+
+def test_render_post_matches_reference_formulas(ops):
+    """The fused epilogue vs the reference's own libtorch formulas (neural_gaussian.cpp:229-240), fwd and bwd."""
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(0)
+    C, H, W = 2, 37, 53
+    rc = torch.rand(C, H, W, 3, generator=g).to(dev).requires_grad_(True)
+    rd = (torch.rand(C, H, W, 1, generator=g) * 5).to(dev)
+    ra = torch.rand(C, H, W, 1, generator=g).to(dev)
+    ra[0, :3] = 0.0; rd[0, :3] = 0.0                      # uncovered pixels: 0/0 -> nan_to_num -> 0
+    rd, ra = rd.requires_grad_(True), ra.requires_grad_(True)
+    rn = torch.randn(C, H, W, 3, generator=g).to(dev).requires_grad_(True)
+    vm = synth.make_views(3, seed=4)[1:].to(dev)
+    out, nw = ops._RenderPost.apply(rc, rd, ra, rn, vm, True)
+    ref_d = (rd / ra).nan_to_num()
+    ref = torch.cat([rc, ref_d], -1)
+    ref_n = rn.matmul(torch.linalg.inv(vm)[0, :3, :3].t())
+    assert_close(out, ref, 1e-6, "renders"); assert_close(nw, ref_n, 1e-5, "normals world")
+    v1, v2 = torch.randn_like(out), torch.randn_like(nw)
+    covered = (ra.detach() > 0).float()
+    g1 = torch.autograd.grad((out * v1).sum() + (nw * v2).sum(), (rc, rd, ra, rn))
+    g2 = torch.autograd.grad((ref * v1).sum() + (ref_n * v2).sum(), (rc, rd, ra, rn))
+    for a, b, nm in zip(g1, g2, ("v_colors", "v_depths", "v_alphas", "v_normals")):
+        b = torch.where(covered.bool().expand_as(b), b, torch.zeros_like(b)) if nm in ("v_depths", "v_alphas") else b
+        assert_close(a, b.nan_to_num(), 1e-5, nm)
