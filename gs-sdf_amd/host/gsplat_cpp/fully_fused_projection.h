@@ -1,0 +1,23 @@
+// gsplat_cpp/fully_fused_projection.h — drop-in for the reference's (absent) submodule header of the same
+// name, included at /root/reference/include/neural_gaussian/neural_gaussian.cpp:5 and called at :188-192.
+// Global namespace, same argument order; differentiable w.r.t. means, quats, scales (torch::autograd::Function
+// over the C ABI of include/gsdf_hip.h).  Only the reference's configuration is implemented: packed = true,
+// sparse_grad = false (neural_gaussian.cpp:526-530); anything else raises like TORCH_CHECK.
+#pragma once
+#include <torch/torch.h>
+
+#include <tuple>
+
+// -> camera_ids i64[M], gaussian_ids i64[M], radii i32[M], means2d [M,2], depths [M], ray_transforms [M,3,3],
+//    normals [M,3], samples [M,3], samples_weights [M,1]
+std::tuple<torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor,
+           torch::Tensor, torch::Tensor>
+fully_fused_projection_2dgs(const torch::Tensor &means, const torch::Tensor &quats, const torch::Tensor &scales,
+                            const torch::Tensor &viewmats, const torch::Tensor &Ks, int width, int height,
+                            float near_plane, float far_plane, float radius_clip, bool packed, bool sparse_grad);
+
+namespace gsplat_cpp {
+// Seed of the stochastic splat sample (`samples`, SPEC S-3).  0 (default) = splat centres with unit weights.
+// When non-zero a fresh seed is derived per call from torch's default generator, as a CUDA op would.
+void set_sample_mode(bool stochastic);
+}  // namespace gsplat_cpp

@@ -1,0 +1,52 @@
+// pytest_binding.cpp — pybind11 test harness: exposes the C++ operator layer (the functions the reference's
+// neural_gaussian.cpp / local_map.cpp call) to the parity tests, so that the libtorch path is exercised exactly
+// as the reference would call it.  Not part of the product surface.
+#include <torch/extension.h>
+
+#include "gsplat_cpp/fully_fused_projection.h"
+#include "gsplat_cpp/rasterize_to_pixels.h"
+#include "gsplat_cpp/rendering.h"
+#include "spatial.h"
+#include "tcnn_binding/tcnn_binding.h"
+
+namespace py = pybind11;
+
+PYBIND11_MODULE(_gsdf_host, m) {
+  m.def("fully_fused_projection_2dgs", &fully_fused_projection_2dgs);
+  m.def("set_sample_mode", &gsplat_cpp::set_sample_mode);
+  m.def("get_view_colors", [](const torch::Tensor &vm, const torch::Tensor &means, const torch::Tensor &radii,
+                              const torch::Tensor &colors, const torch::Tensor &cam, const torch::Tensor &gid,
+                              py::object deg) {
+    return gsplat_cpp::get_view_colors(vm, means, radii, colors, cam, gid,
+                                       deg.is_none() ? at::optional<int>() : at::optional<int>(deg.cast<int>()));
+  });
+  m.def("tile_encode", &gsplat_cpp::tile_encode);
+  m.def("rasterize_to_pixels_2dgs",
+        [](const torch::Tensor &a, const torch::Tensor &b, const torch::Tensor &c, const torch::Tensor &d,
+           const torch::Tensor &e, const torch::Tensor &f, int w, int h, int t, const torch::Tensor &offs,
+           const torch::Tensor &flat, py::object bg, py::object mk, bool packed, const torch::Tensor &absg, bool distloss) {
+          return rasterize_to_pixels_2dgs(a, b, c, d, e, f, w, h, t, offs, flat,
+                                          bg.is_none() ? at::optional<torch::Tensor>() : at::optional<torch::Tensor>(bg.cast<torch::Tensor>()),
+                                          mk.is_none() ? at::optional<torch::Tensor>() : at::optional<torch::Tensor>(mk.cast<torch::Tensor>()),
+                                          packed, absg, distloss);
+        });
+  m.def("distCUDA2", &distCUDA2);
+  py::class_<TCNNEncoding, std::shared_ptr<TCNNEncoding>>(m, "TCNNEncoding")
+      .def(py::init([](int n_levels, int n_feat, int log2_hashmap, int base_res, double pls) {
+        nlohmann::json cfg = {{"otype", "Grid"}, {"type", "Hash"}, {"n_levels", n_levels}, {"n_features_per_level", n_feat},
+                              {"log2_hashmap_size", log2_hashmap}, {"base_resolution", base_res}, {"per_level_scale", pls},
+                              {"interpolation", "Linear"}};
+        return std::make_shared<TCNNEncoding>(3, cfg, "encoder_test");
+      }))
+      .def("forward", &TCNNEncoding::forward)
+      .def("get_out_dim", &TCNNEncoding::get_out_dim)
+      .def_readwrite("params_", &TCNNEncoding::params_);
+  py::class_<TCNNNetwork, std::shared_ptr<TCNNNetwork>>(m, "TCNNNetwork")
+      .def(py::init([](int n_in, int n_out, int n_neurons, int n_hidden) {
+        nlohmann::json cfg = {{"otype", "FullyFusedMLP"}, {"activation", "ReLU"}, {"output_activation", "None"},
+                              {"n_neurons", n_neurons}, {"n_hidden_layers", n_hidden}};
+        return std::make_shared<TCNNNetwork>(n_in, n_out, cfg, "decoder_test");
+      }))
+      .def("forward", &TCNNNetwork::forward)
+      .def_readwrite("params_", &TCNNNetwork::params_);
+}

@@ -1,0 +1,39 @@
+// tcnn_binding/tcnn_binding.h — drop-in for the reference's submodule header
+// (/root/reference/include/neural_net/encoding_map.h:4, encodings/encodings.h:5, local_map.cpp:44-55).
+// `TCNNEncoding`: multiresolution hash grid (tiny-cuda-nn "Grid"/"Hash"/"Linear") with first and second order
+// autograd; `TCNNNetwork`: FullyFusedMLP (ReLU, no output activation) on the fp32 MFMA pipe.
+// `params_` is a plain fp32 leaf tensor the caller registers as an nn parameter (local_map.cpp:53-54,73-75).
+#pragma once
+#include <torch/torch.h>
+
+#include <nlohmann/json.hpp>
+#include <string>
+#include <vector>
+
+struct TCNNEncoding {
+  TCNNEncoding() = default;
+  TCNNEncoding(int n_input_dims, const nlohmann::json &config, const std::string &name) {
+    init_encoding(n_input_dims, config, name);
+  }
+  virtual ~TCNNEncoding() = default;
+
+  void init_encoding(int n_input_dims, const nlohmann::json &config, const std::string &name);
+  torch::Tensor forward(const torch::Tensor &x);
+  virtual size_t get_out_dim() const { return (size_t)n_levels_ * n_feat_; }
+
+  torch::Tensor params_;
+  std::string name_;
+  std::string otype_;
+  int n_input_dims_ = 3, n_levels_ = 16, n_feat_ = 2, log2_hashmap_ = 19, base_res_ = 16, sh_degree_ = 0;
+  float per_level_scale_ = 2.0f;
+  std::vector<int64_t> offsets_;  // entry offsets per level
+};
+
+struct TCNNNetwork {
+  TCNNNetwork(int n_input_dims, int n_output_dims, const nlohmann::json &config, const std::string &name);
+  torch::Tensor forward(const torch::Tensor &x);
+
+  torch::Tensor params_;
+  std::string name_;
+  std::vector<int> dims_;
+};

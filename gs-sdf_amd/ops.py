@@ -269,6 +269,21 @@ def rasterize_to_pixels_2dgs(means2d, ray_transforms, colors, opacities, normals
                                 backgrounds, masks, int(width), int(height), int(tile_size), isect_offsets, flatten_ids)
 
 
+@torch.no_grad()
+def distCUDA2(points):
+    """simple-knn's distCUDA2 (neural_gaussian.cpp:314): mean squared distance to the 3 nearest neighbours, [N,3] -> [N]."""
+    L = capi.lib()
+    points = points.detach().contiguous()
+    if points.dim() != 2 or points.shape[1] != 3:
+        raise RuntimeError("distCUDA2: expected [N,3]")
+    N = points.shape[0]
+    out = torch.empty(N, dtype=torch.float32, device=points.device)
+    ws = torch.empty(L.gsdf_knn_ws_bytes(N), dtype=torch.uint8, device=points.device)
+    capi.check(_timed("knn_mean_dist2", L.gsdf_knn_mean_dist2, N, f32(points, "points"), f32(out), ptr(ws), capi.stream()),
+               "distCUDA2")
+    return out
+
+
 class _RenderPost(torch.autograd.Function):
     """Fused per-pixel epilogue (neural_gaussian.cpp:229-240): depth/alpha + nan_to_num, cat, normals to world."""
 

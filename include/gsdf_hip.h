@@ -194,6 +194,13 @@ int gsdf_mlp_bwd(int64_t B, int n_layers, const int *dims_host, const float *wei
                  const float *in, const float *acts, const float *v_out, float *v_in, float *v_weights,
                  float *v_biases, void *ws, gsdf_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * K1  distCUDA2(points) (simple-knn)          reference call: include/neural_gaussian/neural_gaussian.cpp:314
+ *     out[i] = mean of the squared distances from point i to its 3 nearest neighbours (exact).
+ * ---------------------------------------------------------------------------------------- */
+size_t gsdf_knn_ws_bytes(int64_t n_points);
+int gsdf_knn_mean_dist2(int64_t n_points, const float *points, float *out, void *ws, gsdf_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

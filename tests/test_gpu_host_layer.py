@@ -1,0 +1,124 @@
+"""The C++/libtorch operator layer (gs-sdf_amd/host: reference-named headers over the C ABI) driven through its
+pybind11 harness: results must equal the Python mirror's (same kernels underneath), autograd must reach every
+differentiable input including the leaf `densify`/`means2d_absgrad` tensors and the hash grid's second order."""
+import numpy as np
+import pytest
+import torch
+
+import gs_sdf_amd.synth as synth
+from util import assert_close, assert_equal_int
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def host():
+    assert torch.cuda.is_available()
+    import gs_sdf_amd.hostlib as h
+    return h.load()
+
+
+def test_splat_operators_match_python_mirror(host):
+    import gs_sdf_amd.ops as ops
+    dev = torch.device("cuda:0")
+    N, W, H, deg = 20000, 480, 272, 2
+    sc = synth.make_scene(N, W, H, sh_degree=deg, seed=7)
+    vm = synth.make_views(2, seed=5)[1:].to(dev)
+    K = sc["K"].to(dev)
+    leaves = lambda: [t.to(dev).clone().requires_grad_(True) for t in (sc["means"], sc["quats"], sc["log_scales"].exp(),
+                                                                        torch.sigmoid(sc["logit_opacities"]), sc["sh"])]
+    res = []
+    for mod in ("cpp", "py"):
+        means, quats, scales, opac, sh = leaves()
+        if mod == "cpp":
+            o = host.fully_fused_projection_2dgs(means, quats, scales, vm, K, W, H, 0.05, 300.0, 0.0, True, False)
+        else:
+            o = ops.fully_fused_projection_2dgs(means, quats, scales, vm, K, W, H, 0.05, 300.0, 0.0, True, False)
+        cam, gid, radii, m2d, dep, rt, nrm, smp, sw = o
+        if mod == "cpp":
+            col = host.get_view_colors(vm, means, radii, sh, cam, gid, deg)
+            tpg, flat, offs = host.tile_encode(W, H, 16, m2d, radii, dep, True, 1, cam, gid)
+        else:
+            col = ops.get_view_colors(vm, means, radii, sh, cam, gid, deg)
+            tpg, flat, offs = ops.tile_encode(W, H, 16, m2d, radii, dep, True, 1, cam, gid)
+        dens = torch.zeros_like(m2d, requires_grad=True)
+        absg = torch.zeros_like(m2d, requires_grad=True)
+        bg = torch.tensor([[0.2, 0.1, 0.3]], device=dev)
+        f = host.rasterize_to_pixels_2dgs if mod == "cpp" else ops.rasterize_to_pixels_2dgs
+        rc, rd, ra, rn, rdist, rm, vis = f(m2d, rt, col, opac[gid], nrm, dens, W, H, 16, offs, flat, bg, None, True, absg, False)
+        ug = synth.upstream_grads(H, W, seed=2)
+        loss = sum((t * ug[k].to(dev)).sum() for t, k in ((rc, "v_render_colors"), (rd, "v_render_depths"), (ra, "v_render_alphas"),
+                                                          (rn, "v_render_normals"), (rm, "v_render_median"))) + (smp * 0.1).sum()
+        loss.backward()
+        res.append(dict(cam=cam, gid=gid, radii=radii, m2d=m2d, rt=rt, col=col, tpg=tpg, flat=flat, offs=offs, rc=rc, rd=rd, ra=ra,
+                        rn=rn, rm=rm, vis=vis, g_means=means.grad, g_quats=quats.grad, g_scales=scales.grad, g_opac=opac.grad,
+                        g_sh=sh.grad, g_dens=dens.grad, g_abs=absg.grad))
+    a, b = res
+    for k in ("cam", "gid", "radii", "tpg", "flat", "offs"):
+        assert_equal_int(a[k], b[k], k)
+    for k in ("m2d", "rt", "col", "rc", "rd", "ra", "rn", "rm", "vis"):
+        assert torch.equal(a[k], b[k]), f"{k}: forward differs between the C++ and Python layers (same kernels)"
+    for k in ("g_means", "g_quats", "g_scales", "g_opac", "g_sh", "g_dens", "g_abs"):
+        assert a[k] is not None and b[k] is not None, k
+        assert_close(a[k], b[k], 1e-4, k)          # atomics: accumulation order differs between runs
+    with pytest.raises(RuntimeError):
+        host.fully_fused_projection_2dgs(res[0]["m2d"], res[0]["m2d"], res[0]["m2d"], vm, K, W, H, 0.05, 300.0, 0.0, True, False)
+    with pytest.raises(RuntimeError):
+        host.tile_encode(W, H, 16, a["m2d"], a["radii"], a["m2d"][:, 0].contiguous(), False, 1, a["cam"], a["gid"])
+
+
+def test_tcnn_objects_first_and_second_order(host, oracle):
+    dev = torch.device("cuda:0")
+    cfg = dict(n_levels=16, n_feat=2, log2_hashmap=19, base_res=32, per_level_scale=2.0)
+    enc = host.TCNNEncoding(16, 2, 19, 32, 2.0)
+    assert enc.get_out_dim() == 32 and enc.params_.numel() == 15_269_888 and enc.params_.is_cuda
+    assert float(enc.params_.detach().abs().max()) <= 1e-4
+    g = torch.Generator().manual_seed(0)
+    B = 4096
+    x = torch.rand(B, 3, generator=g)
+    table = torch.rand(enc.params_.numel(), generator=g) * 2 - 1
+    enc.params_ = table.to(dev).requires_grad_(True)
+    xd = x.to(dev).requires_grad_(True)
+    feat = enc.forward(xd)
+    n = lambda t: t.detach().cpu().numpy()
+    assert_close(feat, oracle.grid_fwd(n(x), n(table).reshape(-1, 2), cfg, prec="f32"), 1e-5, "C++ TCNNEncoding.forward")
+    v = torch.randn(B, 32, generator=g)
+    vd = v.to(dev).requires_grad_(True)
+    v_x, v_t = torch.autograd.grad(feat, (xd, enc.params_), vd, create_graph=True)
+    vt_o, vx_o = oracle.grid_bwd(n(x), n(table).reshape(-1, 2), n(v), cfg, prec="f32")
+    assert_close(v_x, vx_o, 1e-4, "v_x"); assert_close(v_t.view(-1, 2), vt_o, 1e-4, "v_table")
+    vv = torch.randn(B, 3, generator=g)
+    g_v, g_t = torch.autograd.grad((v_x * vv.to(dev)).sum(), (vd, enc.params_))
+    gv_o, gt_o, _ = oracle.grid_bwd_bwd(n(x), n(table).reshape(-1, 2), n(v), n(vv), cfg, prec="f32")
+    assert_close(g_v, gv_o, 1e-4, "double backward d/dv_feat"); assert_close(g_t.view(-1, 2), gt_o, 1e-4, "double backward d/dtable")
+    net = host.TCNNNetwork(32, 2, 64, 3)
+    W = n(net.params_)
+    assert W.size == 32 * 64 + 2 * 64 * 64 + 64 * 2
+    f_in = torch.randn(B, 32, generator=g).to(dev).requires_grad_(True)
+    out = net.forward(f_in)
+    assert_close(out, oracle.mlp_fwd(n(f_in), [32, 64, 64, 64, 2], W, None, prec="f64"), 1e-4, "C++ TCNNNetwork.forward")
+    vo = torch.randn(B, 2, generator=g)
+    out.backward(vo.to(dev))
+    v_in, v_w, _ = oracle.mlp_bwd(n(f_in), [32, 64, 64, 64, 2], W, None, n(vo), prec="f64")
+    assert_close(f_in.grad, v_in, 1e-4, "mlp v_in"); assert_close(net.params_.grad, v_w, 1e-4, "mlp v_w")
+
+
+@pytest.mark.parametrize("N", [1, 2, 3, 4, 5000, 200_000])
+def test_distCUDA2(host, oracle, N):
+    import gs_sdf_amd.ops as ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(N)
+    pts = torch.rand(N, 3, generator=g) * torch.tensor([4.0, 1.0, 0.3])
+    if N >= 5000:
+        pts[: N // 4] = pts[: N // 4] * 0.01 + 0.5                      # a dense cluster + duplicates
+        pts[10] = pts[11]
+    got_cpp = host.distCUDA2(pts.to(dev))
+    got_py = ops.distCUDA2(pts.to(dev))
+    assert torch.equal(got_cpp, got_py)
+    if N <= 5000:
+        ref = oracle.knn_mean_dist2(pts.numpy(), prec="f64")
+    else:
+        from scipy.spatial import cKDTree
+        d, _ = cKDTree(pts.double().numpy()).query(pts.double().numpy(), k=4)
+        ref = (d[:, 1:] ** 2).mean(1)
+    assert_close(got_cpp, ref, 1e-4, "distCUDA2")
