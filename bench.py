@@ -43,13 +43,21 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    n_dev = torch.cuda.device_count()
+    # one process per GPU.  (GSDF_BENCH_BACKEND=gloo is a test hook: it lets N ranks share one GPU so that the
+    # multi-rank control flow can be exercised on a single-GPU box; RCCL itself refuses two ranks per device.)
+    backend = os.environ.get("GSDF_BENCH_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % max(n_dev, 1)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)   # nccl == RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)   # nccl == RCCL on ROCm
+        else:
+            dist.init_process_group(backend)
 
     import gs_sdf_amd.ops as ops
     import gs_sdf_amd.synth as synth
@@ -88,19 +96,30 @@ def main():
             # per-ray SDF batch (neural_mapping.cpp:138-188): BCE on the SDF head + eikonal on the numerical gradient
             pts, tgt = pool[i % 8], ray_sdf[i % 8]
             s_pred, isig = lm.get_sdf(pts)
-            loss = loss + sdfm.sdf_loss(s_pred, tgt, isig)
+            loss_sdf = sdfm.sdf_loss(s_pred, tgt, isig)
             grad = lm.get_gradient(pts, 0.02, s_pred, False, True)[0]
-            loss = loss + 0.1 * sdfm.eikonal_loss(grad)
+            loss_sdf = loss_sdf + 0.1 * sdfm.eikonal_loss(grad)
             # GS <-> SDF coupling (neural_mapping.cpp:420-462): SDF at the visible splats' samples
             vis = meta["visibilities"].detach()
             w_all = (meta["samples_weights"] * vis).detach()
             ids = (vis > 0.1).squeeze(-1).nonzero().squeeze(-1)
+            samples_cut = meta["samples"].detach().requires_grad_(True)      # graph cut: same maths, two backward legs
             if ids.numel() > 0:
-                gs_sdf = lm.get_sdf(meta["samples"].index_select(0, ids))[0]
-                loss = loss + 1e-3 * sdfm.gs_sdf_loss(gs_sdf, w_all.index_select(0, ids))
+                gs_sdf = lm.get_sdf(samples_cut.index_select(0, ids))[0]
+                loss_sdf = loss_sdf + 1e-3 * sdfm.gs_sdf_loss(gs_sdf, w_all.index_select(0, ids))
             sizes.update(n_gs_sdf=int(ids.numel()))
-        loss.backward()
-        vp.all_reduce_grads()
+            # leg 1: everything that touches the SDF network; its gradients are final afterwards, so their all-reduce
+            # (61 MB table + MLP) is started now and overlaps with the splat backward below
+            loss_sdf.backward()
+            vp.all_reduce_group_async(groups[0])
+            if samples_cut.grad is not None:
+                torch.autograd.backward([loss, meta["samples"]], [None, samples_cut.grad])
+            else:
+                loss.backward()
+        else:
+            loss.backward()
+        vp.all_reduce_group_async(params)
+        vp.finish()
         sizes.update(M=int(meta["gaussian_ids"].shape[0]), I=int(meta["flatten_ids"].shape[0]))
 
     for i in range(args.warmup):

@@ -31,7 +31,11 @@ def _worker(rank, world, port, out):
     for step in range(2):
         vp.zero_grad()
         _loss(params, views[(step * world + rank) % 4]).backward()
-        vp.all_reduce_grads()
+        if step == 0:
+            vp.all_reduce_grads()                       # blocking form
+        else:
+            vp.all_reduce_group_async(params)           # overlapped form used by bench.py
+            vp.finish()
     out[rank] = params.flat_grad.clone()
     dist.destroy_process_group()
 
