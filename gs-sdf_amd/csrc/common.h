@@ -58,6 +58,22 @@ __device__ __forceinline__ float wave_sum_to_lane63(float v) {
   return v;
 }
 
+// max over the wave of NON-NEGATIVE floats, done on their bit patterns with integer max: no fp canonicalisation
+// (v_max_f32 x,x,x) is emitted and the DPP operand folds into v_max_u32.  Result valid in lane 63.
+template <int CTRL, int ROW_MASK = 0xF, int BANK_MASK = 0xF, bool BOUND_CTRL = true>
+__device__ __forceinline__ unsigned dpp_mov_u(unsigned v) {
+  return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, BANK_MASK, BOUND_CTRL);
+}
+__device__ __forceinline__ unsigned wave_umax_to_lane63(unsigned v) {
+  v = max(v, dpp_mov_u<0x111>(v));
+  v = max(v, dpp_mov_u<0x112>(v));
+  v = max(v, dpp_mov_u<0x114>(v));
+  v = max(v, dpp_mov_u<0x118>(v));
+  v = max(v, dpp_mov_u<0x142, 0xA, 0xF, false>(v));
+  v = max(v, dpp_mov_u<0x143, 0xC, 0xF, false>(v));
+  return v;
+}
+
 __device__ __forceinline__ float wave_max_to_lane63(float v) {
   // values are >= 0, so shifted-in zeros (bound_ctrl) are neutral
   v = fmaxf(v, dpp_mov<0x111>(v));

@@ -7,7 +7,8 @@ namespace gsdf {
 
 struct FwdLds {
   SplatBatch s;
-  unsigned vis[RT];  // per staged splat: max blending weight over the tile's pixels (fp32 bits)
+  unsigned vis[4][RT];  // per wave, per staged splat: max blending weight over the wave's pixels (fp32 bits);
+                        // every (wave, splat) pair is visited once per batch -> plain stores, no LDS atomics
 };
 
 __global__ void __launch_bounds__(RT)
@@ -49,7 +50,7 @@ __global__ void __launch_bounds__(RT)
     // barrier A: every wave has finished reading the previous batch
     const int all_done = __syncthreads_and(done ? 1 : 0);
     if (g_mine >= 0) {
-      const unsigned v = lds.vis[tid];
+      const unsigned v = max(max(lds.vis[0][tid], lds.vis[1][tid]), max(lds.vis[2][tid], lds.vis[3][tid]));
       if (v) atomicMax(visibilities + g_mine, v);
       g_mine = -1;
     }
@@ -60,7 +61,7 @@ __global__ void __launch_bounds__(RT)
       g_mine = flatten_ids[idx];
       stage_splat(lds.s, tid, g_mine, means2d, ray_transforms, colors, opacities, normals, (float)(tx * TILE),
                   (float)(ty * TILE));
-      lds.vis[tid] = 0u;
+      lds.vis[0][tid] = 0u; lds.vis[1][tid] = 0u; lds.vis[2][tid] = 0u; lds.vis[3][tid] = 0u;
     }
     __syncthreads();  // barrier B
     const int count = min(RT, end - bstart);
@@ -93,15 +94,15 @@ __global__ void __launch_bounds__(RT)
           cur = bstart + t;
           T = nT;
         }
-        const float wmax = wave_max_to_lane63(w);
-        if (lane == 63 && wmax > 0.0f) atomicMax(&lds.vis[t], __float_as_uint(wmax));
+        const unsigned wmax = wave_umax_to_lane63(__float_as_uint(w));  // w >= 0: uint order == float order
+        if (lane == 63) lds.vis[wave][t] = wmax;
       }
       if (__ballot(!done) == 0ull) break;
     }
   }
   __syncthreads();
   if (g_mine >= 0) {
-    const unsigned v = lds.vis[tid];
+    const unsigned v = max(max(lds.vis[0][tid], lds.vis[1][tid]), max(lds.vis[2][tid], lds.vis[3][tid]));
     if (v) atomicMax(visibilities + g_mine, v);
   }
   if (inside) {
