@@ -1,0 +1,332 @@
+"""Host-side mirror of the reference's `NeuralGS` (include/neural_gaussian/neural_gaussian.{h,cpp}): parameters and
+activations, `render()`, densification statistics (`update_state`) and the refinement strategy
+(`train_callback`: grow = duplicate/split, prune, opacity reset, LR decay) including the Adam-state surgery of
+include/optimizer/optimizer_utils/optimizer_utils.cpp.  Plus the per-ray SDF sample construction of
+include/utils/utils.cpp:336-393 / neural_mapping.cpp:73-104.
+
+Everything here is host policy over torch tensors (it runs on any device); the arithmetic of `render()` goes
+through gs_sdf_amd.ops -> the C ABI.  Citations are /root/reference/<file>:<line>.
+"""
+import math
+from dataclasses import dataclass
+
+import torch
+
+from . import ops
+
+
+@dataclass
+class Cameras:                       # sensor::Cameras (include/utils/sensor_utils/cameras.hpp:43-174): pinhole intrinsics
+    fx: float
+    fy: float
+    cx: float
+    cy: float
+    width: int
+    height: int
+
+
+@dataclass
+class GSConfig:                      # the k_* globals this class reads (config/base.yaml:37-74, params.cpp)
+    sh_degree: int = 0
+    near: float = 0.05
+    far: float = 300.0
+    use_absgrad: bool = False
+    center_reg: bool = False
+    prune_opa: float = 0.05
+    grow_grad2d: float = 0.0002
+    grow_scale3d: float = 0.01
+    grow_scale2d: float = 0.05
+    prune_scale3d: float = 0.1
+    refine_scale2d_stop_iter: int = 0
+    refine_start_iter: int = 500
+    refine_every: int = 100
+    reset_every: int = 3000
+    sh_degree_interval: int = 1000
+    pause_refine_after_reset: int = 0
+    lr_end: float = 1e-4
+    detach_sdf_grad: bool = False
+
+
+def normalized_quat_to_rotmat(q):   # include/utils/utils.cpp:538-558 (w,x,y,z)
+    w, x, y, z = q.unbind(-1)
+    return torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y),
+                        2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x),
+                        2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)], -1).reshape(-1, 3, 3)
+
+
+class NeuralGS:
+    """Parameter names, groups and learning rates follow neural_gaussian.cpp:426-453 (all Adam eps 1e-15)."""
+
+    PARAMS = ("offsets_", "scaling_", "quaternion_", "opacity_", "features_dc_", "features_rest_")
+
+    def __init__(self, anchors, scaling, quaternion, opacity, features_dc, features_rest, cfg=None, spatial_scale=1.0,
+                 num_train_data=1):
+        self.cfg = cfg or GSConfig()
+        self.anchors_ = anchors.detach().clone()                       # registered without grad in the reference
+        mk = lambda t: t.detach().clone().requires_grad_(True)
+        self.offsets_ = mk(torch.zeros_like(anchors))
+        self.scaling_, self.quaternion_, self.opacity_ = mk(scaling), mk(quaternion), mk(opacity.reshape(-1))
+        self.features_dc_, self.features_rest_ = mk(features_dc), mk(features_rest)
+        self.spatial_scale_ = min(float(spatial_scale), 2.0)
+        self.original_spatial_scale_ = float(spatial_scale)
+        self.sh_degree_to_use_ = 0
+        self.num_train_data_ = num_train_data
+        self.state = {}
+        self.gs_param_start_idx = 0
+        self.key_for_gradient = "gradient_2dgs"
+
+    # ---- optimizer (neural_gaussian.cpp:434-453; neural_mapping.cpp:855-858 appends the groups after the SDF ones)
+    def param_groups(self):
+        s = self.spatial_scale_
+        lrs = (1.6e-4 * s, 5e-3, 1e-3, 5e-2, 2.5e-3, 2.5e-3 / 20)
+        return [dict(params=[getattr(self, n)], lr=lr, eps=1e-15) for n, lr in zip(self.PARAMS, lrs)]
+
+    def make_optimizer(self, sdf_groups=()):
+        groups = list(sdf_groups) + self.param_groups()
+        self.gs_param_start_idx = len(list(sdf_groups))
+        return torch.optim.Adam(groups, eps=1e-15)
+
+    # ---- activations (neural_gaussian.cpp:463-492)
+    def get_xyz(self):
+        return (self.anchors_ + self.offsets_).view(-1, 3)
+
+    def get_scale(self):
+        return torch.exp(self.scaling_).view(-1, 3)
+
+    def get_opacity(self, training=True):
+        return torch.sigmoid(self.opacity_)
+
+    def generate_gaussian(self, training=True):
+        return (self.get_xyz(), self.quaternion_.view(-1, 4), self.get_scale(), self.get_opacity(training),
+                torch.cat([self.features_dc_, self.features_rest_], 1))
+
+    # ---- render (neural_gaussian.cpp:495-566)
+    def render(self, pose_cam2world, camera, training=False, bck_color=0, sample_seed=0):
+        dev = self.anchors_.device
+        K = torch.tensor([[camera.fx, 0.0, camera.cx], [0.0, camera.fy, camera.cy], [0.0, 0.0, 1.0]], device=dev)[None]
+        rot, pos = pose_cam2world[:, :3].to(dev), pose_cam2world[:, 3:4].to(dev)
+        w2c = torch.cat([torch.cat([rot.t(), -rot.t() @ pos], 1), torch.tensor([[0.0, 0.0, 0.0, 1.0]], device=dev)], 0)[None]
+        xyz, quat, scales, opacity, sh = self.generate_gaussian(training)
+        renders, alphas, info = ops.rasterization_2dgs_sdf(
+            xyz, quat, scales, opacity, sh, w2c.contiguous(), K, camera.width, camera.height, "RGB+ED", self.cfg.near, self.cfg.far,
+            0.0, self.sh_degree_to_use_, True, 16, None, False, self.cfg.use_absgrad, False, self.cfg.center_reg, sample_seed)
+        color, depth = renders[..., 0:3][0], renders[..., 3:4][0]
+        out = {}
+        if bck_color == 2:
+            out["color"] = color + (1.0 - alphas[0]) * torch.rand(camera.height, camera.width, 3, device=dev)
+        elif bck_color == 1:
+            out["color"] = color + (1.0 - alphas[0])
+        else:
+            out["color"] = color
+        out.update(depth=depth, alpha=alphas, xyz=xyz)
+        out.update(info)
+        if out[self.key_for_gradient].requires_grad:
+            out[self.key_for_gradient].retain_grad()
+        return out
+
+    # ---- densification statistics (neural_gaussian.cpp:626-680)
+    def update_state(self, info):
+        grads = (info["absgrad"] if self.cfg.use_absgrad else info[self.key_for_gradient]).grad.clone()
+        n_cameras, width, height = int(info["n_cameras"]), int(info["width"]), int(info["height"])
+        dev, n = grads.device, self.anchors_.shape[0]
+        for k in ("grad2d", "count", "vis") + (("radii",) if self.cfg.refine_scale2d_stop_iter > 0 else ()):
+            if k not in self.state:
+                self.state[k] = torch.zeros(n, device=dev)
+        gs_ids = info["gaussian_ids"]
+        grads[:, 0] *= width * 0.5 * n_cameras
+        grads[:, 1] *= height * 0.5 * n_cameras
+        self.state["grad2d"].index_add_(0, gs_ids, grads.norm(2, -1))
+        gs_vis = info["visibilities"].reshape(-1)
+        self.state["vis"][gs_ids] = torch.maximum(self.state["vis"].index_select(0, gs_ids), gs_vis)
+        self.state["count"].index_add_(0, gs_ids, torch.ones_like(gs_ids, dtype=torch.float32))
+        if self.cfg.refine_scale2d_stop_iter > 0:
+            self.state["radii"][gs_ids] = torch.maximum(self.state["radii"].index_select(0, gs_ids),
+                                                        info["radii"] / float(max(width, height)))
+
+    def zero_state(self):
+        self.state["grad2d"].zero_()
+        self.state["count"].zero_()
+        if self.cfg.refine_scale2d_stop_iter > 0:
+            self.state["radii"].zero_()
+
+    # ---- Adam-state surgery (optimizer_utils.cpp:5-165): keep the moments of surviving rows, zeros for new rows
+    def _swap(self, optimizer, name, new_tensor, moments):
+        old = getattr(self, name)
+        new_tensor = new_tensor.detach().requires_grad_(True)
+        setattr(self, name, new_tensor)
+        if optimizer is None:
+            return
+        gi = self.gs_param_start_idx + self.PARAMS.index(name)
+        group = optimizer.param_groups[gi]
+        st = optimizer.state.pop(old, None)
+        group["params"][0] = new_tensor
+        if st is not None:
+            st["exp_avg"], st["exp_avg_sq"] = moments(st["exp_avg"]), moments(st["exp_avg_sq"])
+            optimizer.state[new_tensor] = st
+
+    def _apply(self, optimizer, keep_idx, ext):
+        """rows kept (index tensor or None = all) followed by the extension rows `ext[name]` (or nothing)."""
+        for name in self.PARAMS:
+            old = getattr(self, name).detach()
+            base = old if keep_idx is None else old.index_select(0, keep_idx)
+            e = ext.get(name) if ext else None
+            new = base if e is None else torch.cat([base, e], 0)
+            self._swap(optimizer, name, new, lambda m, e=e: (
+                (m if keep_idx is None else m.index_select(0, keep_idx)) if e is None else
+                torch.cat([m if keep_idx is None else m.index_select(0, keep_idx), torch.zeros_like(e)], 0)))
+
+    # ---- grow (neural_gaussian.cpp:690-827)
+    def grow_gs(self, it, optimizer):
+        cfg = self.cfg
+        grads = self.state["grad2d"] / self.state["count"].clamp_min(1)
+        is_grad_high = grads > cfg.grow_grad2d
+        is_small = self.get_scale()[:, :2].max(-1).values <= cfg.grow_scale3d * self.spatial_scale_
+        is_dupli = is_grad_high & is_small
+        is_split = is_grad_high & ~is_small
+        if it < cfg.refine_scale2d_stop_iter:
+            is_split |= self.state["radii"] > cfg.grow_scale2d
+        n_dupli = self.duplicate(optimizer, is_dupli)
+        is_split = torch.cat([is_split, torch.zeros(n_dupli, dtype=torch.bool, device=is_split.device)])
+        n_split = self.split(optimizer, is_split)
+        return n_dupli, n_split
+
+    def duplicate(self, optimizer, is_dupli):
+        n = int(is_dupli.sum())
+        if n > 0:
+            idx = is_dupli.nonzero().squeeze(-1)
+            self.anchors_ = torch.cat([self.anchors_, self.anchors_.index_select(0, idx)], 0)
+            self._apply(optimizer, None, {p: getattr(self, p).detach().index_select(0, idx) for p in self.PARAMS})
+            for k in self.state:
+                self.state[k] = torch.cat([self.state[k], self.state[k].index_select(0, idx)])
+        return n
+
+    def split(self, optimizer, is_split, generator=None):
+        n = int(is_split.sum())
+        if n > 0:
+            K = 2
+            sel, rest = is_split.nonzero().squeeze(-1), (~is_split).nonzero().squeeze(-1)
+            scales = self.get_scale().detach().index_select(0, sel)
+            scales = torch.cat([scales[:, :2], torch.zeros(n, 1, device=scales.device)], 1)
+            sample_scales = scales[None] * torch.randn(K, n, 3, device=scales.device, generator=generator)
+            quats = torch.nn.functional.normalize(self.quaternion_.detach().index_select(0, sel), dim=-1)
+            rot = normalized_quat_to_rotmat(quats)
+            split_offsets = (torch.einsum("nij,nj,bnj->bni", rot, scales, sample_scales)
+                             + self.offsets_.detach().index_select(0, sel)[None]).reshape(-1, 3)
+            ext = dict(offsets_=split_offsets, scaling_=torch.log(scales / 1.6).repeat(K, 1),
+                       quaternion_=self.quaternion_.detach().index_select(0, sel).repeat(K, 1),
+                       opacity_=self.opacity_.detach().index_select(0, sel).repeat(K),
+                       features_dc_=self.features_dc_.detach().index_select(0, sel).repeat(K, 1, 1),
+                       features_rest_=self.features_rest_.detach().index_select(0, sel).repeat(K, 1, 1))
+            self.anchors_ = torch.cat([self.anchors_.index_select(0, rest), self.anchors_.index_select(0, sel).repeat(K, 1)], 0)
+            self._apply(optimizer, rest, ext)
+            for k in self.state:
+                self.state[k] = torch.cat([self.state[k].index_select(0, rest), self.state[k].index_select(0, sel).repeat(K)])
+        return n
+
+    # ---- prune (neural_gaussian.cpp:829-916)
+    def _prune(self, optimizer, is_prune):
+        n = int(is_prune.sum())
+        if n > 0:
+            valid = (~is_prune).nonzero().squeeze(-1)
+            self.anchors_ = self.anchors_.index_select(0, valid)
+            self._apply(optimizer, valid, None)
+            for k in self.state:
+                self.state[k] = self.state[k].index_select(0, valid)
+        return n
+
+    def prune_gs(self, it, optimizer, prune_opa_only=False):
+        is_prune = self.get_opacity().detach() < self.cfg.prune_opa
+        scale = self.get_scale().detach()[:, :2]
+        is_prune |= scale.min(-1).values < 1e-4
+        if not prune_opa_only and it > self.cfg.reset_every:
+            is_prune |= scale.max(-1).values > self.cfg.prune_scale3d * self.original_spatial_scale_
+        return self._prune(optimizer, is_prune)
+
+    def prune_invisible_gs(self, it, optimizer):
+        if it > 0 and it % self.num_train_data_ == 0 and "vis" in self.state:
+            is_prune = self.state["vis"] < 1e-4
+            self.state["vis"].zero_()
+            return self._prune(optimizer, is_prune)
+        return 0
+
+    def prune_nan_gs(self, optimizer):
+        is_prune = (self.offsets_.detach().isnan().any(-1) | self.scaling_.detach().isnan().any(-1)
+                    | self.quaternion_.detach().isnan().any(-1))
+        return self._prune(optimizer, is_prune)
+
+    def reset_opacity(self, optimizer):       # neural_gaussian.cpp:918-926
+        cap = math.log(self.cfg.prune_opa * 2.0 / (1.0 - self.cfg.prune_opa * 2.0))
+        new = self.opacity_.detach().clamp_max(cap)
+        self._swap(optimizer, "opacity_", new, lambda m: torch.zeros_like(m))
+
+    # ---- per-iteration callback (neural_gaussian.cpp:568-624)
+    @torch.no_grad()
+    def train_callback(self, it, total_iter, optimizer, info):
+        cfg = self.cfg
+        refine_stop = total_iter // 2
+        log = {}
+        if info:
+            if it >= refine_stop:
+                return log
+            self.update_state(info)
+            log["nan"] = self.prune_nan_gs(optimizer)
+            log["invisible"] = self.prune_invisible_gs(it, optimizer)
+            self.sh_degree_to_use_ = min(cfg.sh_degree, it // cfg.sh_degree_interval)
+            if 0 < it < refine_stop:
+                if it > cfg.refine_start_iter and it % cfg.refine_every == 0 and (it % cfg.reset_every) >= cfg.pause_refine_after_reset:
+                    log["dupli"], log["split"] = self.grow_gs(it, optimizer)
+                    log["pruned"] = self.prune_gs(it, optimizer)
+                    self.zero_state()
+                if it % cfg.reset_every == 0:
+                    self.reset_opacity(optimizer)
+                    log["reset_opacity"] = True
+        if optimizer is not None:               # exponential LR decay of the position group (:608-623)
+            r = it / total_iter
+            lr0, lr1 = 1.6e-4 * self.spatial_scale_, 1.6e-6 * self.spatial_scale_
+            lr = math.exp(math.log(lr0) * (1 - r) + math.log(lr1) * r)
+            optimizer.param_groups[self.gs_param_start_idx]["lr"] = lr
+            sdf_lr = 0.0 if cfg.detach_sdf_grad else min(lr, cfg.lr_end)
+            for i in range(self.gs_param_start_idx):
+                optimizer.param_groups[i]["lr"] = sdf_lr
+        return log
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# per-ray SDF batch construction (a16): utils.cpp:336-393, neural_mapping.cpp:73-104 (without the octree voxel sample,
+# which belongs to the kaolin_wisp_cpp replacement, SURVEY 8f "next #2")
+# ------------------------------------------------------------------------------------------------------------------
+def sample_surface_pts(origin, direction, depth, surface_sample_num, std, generator=None):
+    n = origin.shape[0]
+    ray_sdf = torch.randn(n, surface_sample_num, 1, device=origin.device, generator=generator) * std
+    end = origin + direction * depth
+    xyz = (end[:, None] - direction[:, None] * ray_sdf).reshape(-1, 3)
+    ridx = torch.arange(n, device=origin.device)[:, None].repeat(1, surface_sample_num).reshape(-1)
+    return xyz, ray_sdf.reshape(-1, 1), ridx
+
+
+def sample_free_pts(origin, direction, depth, sample_num, generator=None):
+    n = origin.shape[0]
+    steps = torch.arange(sample_num, device=origin.device, dtype=torch.float32)[None].repeat(n, 1)
+    steps = (steps + torch.rand(n, sample_num, device=origin.device, generator=generator)) / sample_num
+    ridx = torch.arange(n, device=origin.device)[:, None].repeat(1, sample_num).reshape(-1)
+    d = depth.index_select(0, ridx) * steps.reshape(-1, 1)
+    xyz = origin.index_select(0, ridx) + direction.index_select(0, ridx) * d
+    return xyz, depth.index_select(0, ridx) - d, ridx
+
+
+def sample_rays(origin, direction, depth, sample_std, truncated_dis, surface_sample_num=3, free_sample_num=3,
+                inrange=None, generator=None):
+    """-> xyz [B,3], ray_sdf [B,1], ridx [B]: free-space + near-surface + end-point samples, SDF targets truncated to
+    +-truncated_dis, filtered by `inrange(xyz) -> bool mask` (SubMap::get_inrange_mask)."""
+    fx, fs, fr = sample_free_pts(origin, direction, depth, free_sample_num, generator)
+    sx, ss, sr = sample_surface_pts(origin, direction, depth, surface_sample_num, sample_std, generator)
+    xyz, sdf, ridx = torch.cat([fx, sx]), torch.cat([fs, ss]), torch.cat([fr, sr])
+    sdf = torch.where(sdf.abs() > truncated_dis, sdf.sign() * truncated_dis, sdf)
+    n = origin.shape[0]
+    xyz = torch.cat([xyz, origin + direction * depth])
+    sdf = torch.cat([sdf, torch.zeros(n, 1, device=origin.device)])
+    ridx = torch.cat([ridx, torch.arange(n, device=origin.device)])
+    if inrange is not None:
+        keep = inrange(xyz).reshape(-1).nonzero().squeeze(-1)
+        xyz, sdf, ridx = xyz.index_select(0, keep), sdf.index_select(0, keep), ridx.index_select(0, keep)
+    return xyz, sdf, ridx

