@@ -330,3 +330,44 @@ def sample_rays(origin, direction, depth, sample_std, truncated_dis, surface_sam
         keep = inrange(xyz).reshape(-1).nonzero().squeeze(-1)
         xyz, sdf, ridx = xyz.index_select(0, keep), sdf.index_select(0, keep), ridx.index_select(0, keep)
     return xyz, sdf, ridx
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# SDF-aided splat initialisation (a17): neural_gaussian.cpp:19-127
+# ------------------------------------------------------------------------------------------------------------------
+def rotation_6d_to_matrix(r6):       # include/utils/utils.cpp:693-719 (Gram-Schmidt, columns b1,b2,b3)
+    a1, a2 = r6[..., 0:3], r6[..., 3:6]
+    b1 = torch.nn.functional.normalize(a1, dim=-1)
+    b2 = torch.nn.functional.normalize(a2 - (b1 * a2).sum(-1, keepdim=True) * b1, dim=-1)
+    return torch.stack([b1, b2, torch.cross(b1, b2, dim=-1)], -1)
+
+
+@torch.no_grad()
+def init_gs_with_sdf(local_map, xyzs, mesh_res, init_opa=False, batch_size=50 * 32768):
+    """Splat orientation from the SDF: normal = grad, in-plane axis = diagonal-Hessian direction, rotation ->
+    axis-angle -> quaternion (w,x,y,z); optional opacity exp(-sdf^2 * isigma).  Batched like the reference
+    (k_vis_batch_pt_num = 50 * batch_pt_num, params.cpp:360)."""
+    n = xyzs.shape[0]
+    grad, curv = torch.empty(n, 3, device=xyzs.device), torch.empty(n, 3, device=xyzs.device)
+    quat = torch.empty(n, 4, device=xyzs.device)
+    opa = torch.empty(n, device=xyzs.device) if init_opa else None
+    for s in range(0, n, batch_size):
+        x = xyzs[s:s + batch_size]
+        g, h = local_map.get_gradient(x, mesh_res, None, True, True)
+        c = torch.nn.functional.normalize(g, dim=-1)
+        basis = torch.nn.functional.normalize(h, dim=-1)
+        rot = rotation_6d_to_matrix(torch.cat([c, basis], -1))
+        rot = torch.stack([rot[..., 1], rot[..., 2], rot[..., 0]], -1)
+        trace = rot[:, 0, 0] + rot[:, 1, 1] + rot[:, 2, 2]
+        angle = torch.acos((trace[:, None] - 1.0) * 0.5)
+        axis = torch.stack([rot[:, 2, 1] - rot[:, 1, 2], rot[:, 0, 2] - rot[:, 2, 0], rot[:, 1, 0] - rot[:, 0, 1]], -1) / (2.0 * torch.sin(angle))
+        axis = torch.nn.functional.normalize(axis, dim=-1)
+        q = torch.cat([torch.cos(angle * 0.5), torch.sin(angle * 0.5) * axis], -1).nan_to_num()
+        grad[s:s + batch_size], curv[s:s + batch_size], quat[s:s + batch_size] = g, h, q
+        if init_opa:
+            sdf, isig = local_map.get_sdf(x)
+            opa[s:s + batch_size] = torch.exp(-sdf.square() * isig).squeeze(-1)
+    out = dict(quaternion=quat, grad=grad, curv_dom=curv)
+    if init_opa:
+        out["opacity"] = opa
+    return out

@@ -54,3 +54,34 @@ def test_render_keys_and_short_training_run():
     # before the first refinement the parameters are only moved by Adam: the loss must go down
     assert sum(losses[8:12]) < 0.9 * sum(losses[:4]), (losses[:4], losses[8:12])
     assert lm.encoder.params_.grad is not None and float(lm.encoder.params_.grad.abs().sum()) > 0
+
+
+def test_init_gs_with_sdf_orients_splats_along_the_sdf_normal():
+    """On an analytic SDF (a plane + mild curvature, served through the LocalMap interface) the initial quaternion must
+    rotate the splat's local z axis onto the SDF gradient (neural_gaussian.cpp:19-127)."""
+    from gs_sdf_amd.neural_gs import init_gs_with_sdf, normalized_quat_to_rotmat
+    dev = torch.device("cuda:0")
+    nrm = torch.nn.functional.normalize(torch.tensor([0.3, -0.5, 0.8], device=dev), dim=0)
+
+    class AnalyticMap:
+        def get_sdf(self, x):
+            s = (x * nrm).sum(-1, keepdim=True) - 0.2 + 0.05 * (x[:, 0:1] ** 2)
+            return [s, torch.full_like(s, 50.0)]
+
+        def get_gradient(self, x, delta, sdf=None, hessian=False, numerical_grad=True):
+            offs = torch.eye(3, device=x.device) * delta
+            sp = torch.stack([self.get_sdf(x + offs[d])[0] for d in range(3)], 0)
+            sm = torch.stack([self.get_sdf(x - offs[d])[0] for d in range(3)], 0)
+            g = 0.5 / delta * torch.cat([sp[0] - sm[0], sp[1] - sm[1], sp[2] - sm[2]], 1)
+            h = torch.cat([sp[d] + sm[d] - 2 * self.get_sdf(x)[0] for d in range(3)], 1) / delta ** 2
+            return [g, h]
+
+    x = torch.rand(5000, 3, device=dev) - 0.5
+    out = init_gs_with_sdf(AnalyticMap(), x, 0.01, init_opa=True, batch_size=2048)
+    R = normalized_quat_to_rotmat(out["quaternion"])
+    z_axis = R[:, :, 2]
+    g = torch.nn.functional.normalize(out["grad"], dim=-1)
+    assert float((z_axis * g).sum(-1).abs().min()) > 0.999
+    assert torch.allclose(out["quaternion"].norm(dim=-1), torch.ones(5000, device=dev), atol=1e-4)
+    s = AnalyticMap().get_sdf(x)[0]
+    assert torch.allclose(out["opacity"], torch.exp(-s.square() * 50.0).squeeze(-1))
