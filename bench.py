@@ -1,9 +1,10 @@
 #!/usr/bin/env python
 """bench.py — train iters/s of the GS-SDF hot path on MI355X (BASELINE.json metric).
 
-One "step" = one training iteration of the splat path on one view: activations (exp/sigmoid, a2) ->
-projection (P1) -> SH colours (P2) -> tile binning (P3) -> compositing (P4) -> synthetic loss on every
-rasteriser output -> backward (P4', P2', P1') [-> RCCL all-reduce of the dense parameter grads when N>1].
+One "step" = one training iteration on one view: activations (exp/sigmoid, a2) -> projection (P1) -> SH colours (P2)
+-> tile binning (P3) -> compositing (P4) -> synthetic loss on every rasteriser output; hash-grid SDF leg (per-ray batch
+with numerical eikonal + GS<->SDF coupling on the visible splats); backward of everything (P4', P2', P1', S1', S2')
+[-> RCCL all-reduce of the flat gradient buffers when N>1] -> fused Adam step on all parameters.
 Workload at N=1: BASELINE.json configs[3] shape, "Synthetic 1M Gaussians, 1920x1080" (SURVEY 8d inputs).
 N>1: view-parallel (rank r renders view step*N+r), weak scaling, value = views/s of the job.
 
@@ -61,7 +62,7 @@ def main():
 
     import gs_sdf_amd.ops as ops
     import gs_sdf_amd.synth as synth
-    from gs_sdf_amd.trainer import SplatParams, ViewParallel
+    from gs_sdf_amd.trainer import FusedAdam, SplatParams, ViewParallel
 
     N, W, H, deg, replica = WORKLOADS[args.workload]
     sc = synth.make_scene(N, W, H, sh_degree=deg, seed=0, replica=replica)
@@ -80,6 +81,13 @@ def main():
         pool = [((torch.rand(32768, 3, generator=gq) - 0.5) * 14.0 + torch.tensor([0.0, 0.0, 5.5])).to(dev) for _ in range(8)]
         ray_sdf = [(torch.randn(32768, 1, generator=gq) * 0.02).to(dev) for _ in range(8)]
     vp = ViewParallel(params, dist, groups)
+    # optimizer: fused Adam over the flat buffers, the reference's groups / learning rates (neural_gaussian.cpp:434-453;
+    # SDF groups at min(xyz_lr, lr_end) during the joint stage, :619-623), eps 1e-15
+    adam = FusedAdam(eps=1e-15)
+    lrs = dict(offsets=1.6e-4, scaling=5e-3, quaternion=1e-3, opacity=5e-2, features_dc=2.5e-3, features_rest=2.5e-3 / 20)
+    adam.add_group(params.flat, params.flat_grad, [(params.views[k].numel(), lrs[k]) for k in params.views])
+    for gsdf_group in groups:
+        adam.add_group(gsdf_group.flat, gsdf_group.flat_grad, [(gsdf_group.flat.numel(), 1e-4)])
 
     sizes = {}
 
@@ -120,6 +128,7 @@ def main():
             loss.backward()
         vp.all_reduce_group_async(params)
         vp.finish()
+        adam.step()
         sizes.update(M=int(meta["gaussian_ids"].shape[0]), I=int(meta["flatten_ids"].shape[0]))
 
     for i in range(args.warmup):

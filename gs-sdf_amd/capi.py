@@ -40,6 +40,7 @@ _SIGS = {
     "gsdf_mlp_fwd": (C.c_int, [_i64, _i32] + [_vp] * 7),
     "gsdf_mlp_bwd_ws_bytes": (_sz, [_i64, _i32]),
     "gsdf_mlp_bwd": (C.c_int, [_i64, _i32] + [_vp] * 11),
+    "gsdf_adam_step": (C.c_int, [_i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _f32, _i64, _vp]),
     "gsdf_knn_ws_bytes": (_sz, [_i64]),
     "gsdf_knn_mean_dist2": (C.c_int, [_i64] + [_vp] * 4),
 }

@@ -118,3 +118,38 @@ class FlatGroup:
 
     def __init__(self, flat, flat_grad):
         self.flat, self.flat_grad = flat, flat_grad
+
+
+class FusedAdam:
+    """torch.optim.Adam semantics over flat (params, grads) groups, ONE HIP launch per group
+    (include/gsdf_hip.h: gsdf_adam_step).  `segments` = [(n_elements, lr), ...] in buffer order, e.g. the reference's
+    six splat groups with their learning rates (neural_gaussian.cpp:434-453)."""
+
+    def __init__(self, betas=(0.9, 0.999), eps=1e-15):
+        self.betas, self.eps, self.groups, self.t = betas, eps, [], 0
+
+    def add_group(self, flat, flat_grad, segments):
+        import ctypes as C
+        begins, off = [], 0
+        for n, _ in segments:
+            begins.append(off)
+            off += n
+        assert off == flat.numel(), (off, flat.numel())
+        self.groups.append(dict(flat=flat, grad=flat_grad, m=torch.zeros_like(flat), v=torch.zeros_like(flat),
+                                begins=(C.c_int64 * len(begins))(*begins), lrs=[lr for _, lr in segments]))
+        return len(self.groups) - 1
+
+    def set_lr(self, group, segment, lr):
+        self.groups[group]["lrs"][segment] = float(lr)
+
+    @torch.no_grad()
+    def step(self):
+        import ctypes as C
+        from . import capi
+        L = capi.lib()
+        self.t += 1
+        for g in self.groups:
+            lrs = (C.c_float * len(g["lrs"]))(*g["lrs"])
+            capi.check(L.gsdf_adam_step(g["flat"].numel(), len(g["lrs"]), g["begins"], lrs, capi.f32(g["flat"]), capi.f32(g["grad"]),
+                                        capi.f32(g["m"]), capi.f32(g["v"]), self.betas[0], self.betas[1], self.eps, self.t,
+                                        capi.stream()), "adam_step")

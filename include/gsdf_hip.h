@@ -201,6 +201,17 @@ int gsdf_mlp_bwd(int64_t B, int n_layers, const int *dims_host, const float *wei
 size_t gsdf_knn_ws_bytes(int64_t n_points);
 int gsdf_knn_mean_dist2(int64_t n_points, const float *points, float *out, void *ws, gsdf_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * O1  fused Adam step over a flat parameter buffer (torch.optim.Adam semantics, no amsgrad / weight decay):
+ *     replaces the unfused libtorch Adam of include/neural_mapping/neural_mapping.cpp:466-469 (groups and learning
+ *     rates: include/neural_gaussian/neural_gaussian.cpp:434-453).  Segments = parameter groups laid out back to
+ *     back in the flat buffer: seg_begin_host[k] (element offset, sorted, [0] == 0) and seg_lr_host[k] (HOST arrays).
+ *     `step` counts from 1 (bias correction).  params / exp_avg / exp_avg_sq are updated in place.
+ * ---------------------------------------------------------------------------------------- */
+int gsdf_adam_step(int64_t n, int n_segments, const int64_t *seg_begin_host, const float *seg_lr_host, float *params,
+                   const float *grads, float *exp_avg, float *exp_avg_sq, float beta1, float beta2, float eps,
+                   int64_t step, gsdf_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -173,3 +173,25 @@ def test_analytic_eikonal_double_backward_matches_oracle(sdf, oracle):
     # points with |g| ~ 1, and fine-level table entries are touched by single points -> 2e-3 here; the
     # operator-level double backward is held to 1e-4 in test_hashgrid_fwd_bwd_bwdbwd.
     assert_close(lm.encoder.params_.grad.view(-1, 2), gt, 2e-3, "d eikonal / d table (double backward)")
+
+
+def test_fused_adam_matches_torch_adam():
+    """gsdf_adam_step over a flat buffer with per-segment learning rates == torch.optim.Adam with the same groups."""
+    from gs_sdf_amd.trainer import FusedAdam
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(0)
+    sizes, lrs = [1003, 4096, 7, 250_001], [1.6e-4, 5e-3, 5e-2, 1e-3]
+    n = sum(sizes)
+    flat = torch.randn(n, generator=g).to(dev)
+    flat_grad = torch.zeros(n, device=dev)
+    ref_params = [torch.nn.Parameter(t.clone()) for t in flat.split(sizes)]
+    ref = torch.optim.Adam([dict(params=[p], lr=lr) for p, lr in zip(ref_params, lrs)], eps=1e-15)
+    opt = FusedAdam(eps=1e-15)
+    opt.add_group(flat, flat_grad, list(zip(sizes, lrs)))
+    for it in range(6):
+        grad = torch.randn(n, generator=g).to(dev) * (10.0 ** (it - 3))
+        flat_grad.copy_(grad)
+        for p, gg in zip(ref_params, grad.split(sizes)):
+            p.grad = gg.clone()
+        ref.step(); opt.step()
+        assert_close(flat, torch.cat([p.detach() for p in ref_params]), 1e-6, f"params after step {it + 1}")
