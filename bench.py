@@ -147,6 +147,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     kern = ops.TIMERS.summary_ms()
+    calls = ops.TIMERS.calls()
     ops.TIMERS.disable()
     if dist is not None:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
@@ -157,9 +158,17 @@ def main():
         M, I = sizes["M"], sizes["I"]
         P, T = W * H, ((W + 15) // 16) * ((H + 15) // 16)
         Kb = (deg + 1) ** 2
-        # algorithmic bytes per launch
+        # algorithmic bytes per launch.  The dominant kernel is the one with the
+        # largest total time per step (average launch x launches per step).
         alg = {"rasterize_2dgs_bwd": 80 * I + 48 * P + 88 * M, "rasterize_2dgs_fwd": 80 * I + 48 * P}
-        dom = max(alg, key=lambda k: kern.get(k, 0.0))
+        if not args.no_sdf:
+            # S1 per query point: fwd 12 + 1024 (16 levels x 8 corners x 8 B) + 128; bwd 8 + 128 + 1024 scatter; averaged
+            # over the launches of a step (32768 ray points, 6 x 32768 stencil points, the visible splat samples)
+            pts = (7 * 32768 + sizes.get("n_gs_sdf", 0)) / 3.0
+            alg["hashgrid_bwd"] = int(1160 * pts)
+            alg["hashgrid_fwd"] = int(1164 * pts)
+        per_step = {k: kern.get(k, 0.0) * calls.get(k, 0) / args.steps for k in alg}
+        dom = max(alg, key=lambda k: per_step[k])
         dur_ms = kern.get(dom, float("nan"))
         achieved = alg[dom] / (dur_ms * 1e-3) / 1e9
         b_splat = (80 + 12 * Kb) * N + (364 + 12 * Kb) * M + 204 * I + 96 * P + 4 * T
@@ -178,7 +187,8 @@ def main():
                                    f"points x7 (numerical eikonal) + {sizes.get('n_gs_sdf', 0)} splat samples"), "parallelism": f"view-parallel x{world}" if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                          "frac": achieved / 8000.0, "traffic": traffic, "algorithmic_bytes": alg[dom],
-                         "avg_launch_ms": dur_ms, "step_B_splat_bytes": b_splat,
+                         "avg_launch_ms": dur_ms, "launches_per_step": calls.get(dom, 0) / args.steps,
+                         "ms_per_step_by_kernel": {k: round(v, 4) for k, v in per_step.items()}, "step_B_splat_bytes": b_splat,
                          "step_hbm_frac": b_splat / (elapsed / args.steps) / 8e12},
             "kernel_ms": kern,
         }

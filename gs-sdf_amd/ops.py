@@ -41,6 +41,9 @@ class _Timers:
         torch.cuda.synchronize()
         return {k: sum(a.elapsed_time(b) for a, b in v) / len(v) for k, v in self.ev.items()}
 
+    def calls(self):
+        return {k: len(v) for k, v in self.ev.items()}
+
 
 TIMERS = _Timers()
 
