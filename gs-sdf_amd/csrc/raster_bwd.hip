@@ -20,18 +20,36 @@
 
 namespace gsdf {
 
-static constexpr int NACC = 20;
-// accumulator slots: 0-2 v_rgb, 3-5 v_normal, 6 v_opacity, 7-9 v_Mu, 10-12 v_Mv, 13-15 v_Mw,
-//                    16-17 v_means2d, 18-19 v_means2d_abs
+static constexpr int NACC = 21;
+// Per-splat gradient record.  The cross-product chain of z = h_u x h_v is NOT differentiated per pixel: the record
+// accumulates the moments of v_z about the splat's own centre,
+//     V0 = sum v_z,   Vx = sum (p_x - mean2d.x) v_z,   Vy = sum (p_y - mean2d.y) v_z,
+// (z is affine in the pixel, so these nine numbers carry everything) plus vD = sum v_dep / z.z for the depth
+// D / z.z; the streaming epilogue turns them into dL/dM_u, dL/dM_v, dL/dM_w once per splat.
+// slots: 0-2 v_rgb, 3-5 v_normal, 6 v_opacity, 7-9 V0, 10-12 Vx, 13-15 Vy, 16 vD, 17 v_Mw.z (low-pass branch depth),
+//        18-19 v_means2d, 20 unused ; v_means2d_abs lives in a second record array (only with absgrad)
 struct BwdLds {
   SplatBatch s;
-  float acc[RT][NACC];  // one 80-byte record per staged splat
+  float acc[RT][NACC];  // one 84-byte record per staged splat
+  float acc_abs[RT][2];
   int bin_final_max;
 };
 
 // Adds the LDS records of this wave's 64 staged splats to the global record array and clears them.
-// Three splats per instruction: lane = 20*j + k -> field k of splat slot 3*it + j.
-__device__ __forceinline__ void flush_records(BwdLds &lds, int wave, int lane, int g_mine, float *__restrict__ grec) {
+// Three splats per instruction: lane = 21*j + k -> field k of splat slot 3*it + j.
+template <bool ABSGRAD>
+__device__ __forceinline__ void flush_records(BwdLds &lds, int wave, int lane, int g_mine, float *__restrict__ grec,
+                                              float *__restrict__ grec_abs) {
+  if (ABSGRAD) {
+    const int slot = wave * 64 + lane;
+    if (g_mine >= 0) {
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const float v = lds.acc_abs[slot][k];
+        if (v != 0.f) { lds.acc_abs[slot][k] = 0.f; atomicAdd(grec_abs + 2 * (int64_t)g_mine + k, v); }
+      }
+    }
+  }
   const int j = lane / NACC, k = lane - j * NACC;
 #pragma unroll 2
   for (int it = 0; it < 22; ++it) {
@@ -61,7 +79,8 @@ __global__ void __launch_bounds__(RT)
                       const int32_t *__restrict__ last_ids, const int32_t *__restrict__ median_ids,
                       const float *__restrict__ v_render_colors, const float *__restrict__ v_render_depths,
                       const float *__restrict__ v_render_alphas, const float *__restrict__ v_render_normals,
-                      const float *__restrict__ v_render_median, float *__restrict__ grec) {
+                      const float *__restrict__ v_render_median, float *__restrict__ grec,
+                      float *__restrict__ grec_abs) {
   __shared__ BwdLds lds;
   const int64_t tile = xcd_tile_index(total_tiles);
   if (tile >= total_tiles) return;
@@ -75,6 +94,7 @@ __global__ void __launch_bounds__(RT)
   const bool inside = x < W && y < H;
   const int64_t pid = (cam * H + y) * (int64_t)W + x;
   const float px = (float)x + 0.5f, py = (float)y + 0.5f;
+  const float lx = (float)((wave & 1) * 8 + (lane & 7)), ly = (float)((wave >> 1) * 8 + (lane >> 3));
 
   const int32_t start = isect_offsets[tile];
   const int32_t end = (tile == total_tiles - 1) ? (int32_t)I : isect_offsets[tile + 1];
@@ -101,6 +121,7 @@ __global__ void __launch_bounds__(RT)
   if (tid == 0) lds.bin_final_max = -1;
 #pragma unroll
   for (int k = 0; k < NACC; ++k) lds.acc[tid][k] = 0.f;
+  lds.acc_abs[tid][0] = 0.f; lds.acc_abs[tid][1] = 0.f;
   __syncthreads();
   {  // tile-wide and wave-wide last contributor
     int m = bin_final;
@@ -119,7 +140,7 @@ __global__ void __launch_bounds__(RT)
   const int nb = (min(end, tile_bin_final + 1) - start + RT - 1) / RT;
   for (int b = nb - 1; b >= 0; --b) {
     __syncthreads();  // barrier A: previous batch fully consumed, its accumulators complete
-    flush_records(lds, wave, lane, g_mine, grec);  // wave w owns slots [64w, 64w+64)
+    flush_records<ABSGRAD>(lds, wave, lane, g_mine, grec, grec_abs);  // wave w owns slots [64w, 64w+64)
     g_mine = -1;
     const int32_t bstart = start + b * RT;
     const int32_t idx = bstart + tid;
@@ -139,16 +160,15 @@ __global__ void __launch_bounds__(RT)
       const int hb = 63 - __builtin_clzll(todo);
       todo &= ~(1ull << hb);
       const int t = c0 + hb;
-      const float4 a0 = lds.s.q0[t], a1 = lds.s.q1[t], a2 = lds.s.q2[t];
+      const float4 a0 = lds.s.q0[t], a1 = lds.s.q1[t], a2 = lds.s.q2[t], a3 = lds.s.q3[t];
       PairEval e;
-      eval_pair(px, py, a0, a1, a2, e);
+      eval_pair(lx, ly, px, py, a0, a1, a2, a3.x, a3.y, e);
       const bool valid = inside && (bstart + t <= bin_final) && e.ok;
       if (__ballot(valid) == 0ull) continue;
-      const float4 a3 = lds.s.q3[t];
-      const float2 a4 = lds.s.q4[t];
+      const float4 a4 = lds.s.q4[t];
+      const float cR = a3.z, cG = a3.w, cB = a4.x, nX = a4.y, nY = a4.z, nZ = a4.w;
       float g_rgb0 = 0.f, g_rgb1 = 0.f, g_rgb2 = 0.f, g_n0 = 0.f, g_n1 = 0.f, g_n2 = 0.f, g_op = 0.f;
-      float g_mu0 = 0.f, g_mu1 = 0.f, g_mu2 = 0.f, g_mv0 = 0.f, g_mv1 = 0.f, g_mv2 = 0.f, g_mw0 = 0.f, g_mw1 = 0.f,
-            g_mw2 = 0.f, g_x = 0.f, g_y = 0.f;
+      float vzx = 0.f, vzy = 0.f, vzz = 0.f, g_D = 0.f, g_mwz = 0.f, g_x = 0.f, g_y = 0.f;
       bool v2 = false;
       if (valid) {
         const float ra = 1.0f / (1.0f - e.alpha);
@@ -156,13 +176,13 @@ __global__ void __launch_bounds__(RT)
         const float fac = e.alpha * T;
         g_rgb0 = fac * vCr; g_rgb1 = fac * vCg; g_rgb2 = fac * vCb;
         g_n0 = fac * vNx; g_n1 = fac * vNy; g_n2 = fac * vNz;
-        float v_alpha = (a3.x * T - bCr * ra) * vCr + (a3.y * T - bCg * ra) * vCg + (a3.z * T - bCb * ra) * vCb;
-        v_alpha += (a3.w * T - bNx * ra) * vNx + (a4.x * T - bNy * ra) * vNy + (a4.y * T - bNz * ra) * vNz;
+        float v_alpha = (cR * T - bCr * ra) * vCr + (cG * T - bCg * ra) * vCg + (cB * T - bCb * ra) * vCb;
+        v_alpha += (nX * T - bNx * ra) * vNx + (nY * T - bNy * ra) * vNy + (nZ * T - bNz * ra) * vNz;
         v_alpha += (e.dep * T - bD * ra) * vD;
         v_alpha += T_final * ra * (vA - bgdot);
         const float v_dep = fac * vD + ((bstart + t) == med_idx ? vMed : 0.f);
-        bCr += a3.x * fac; bCg += a3.y * fac; bCb += a3.z * fac;
-        bNx += a3.w * fac; bNy += a4.x * fac; bNz += a4.y * fac;
+        bCr += cR * fac; bCg += cG * fac; bCb += cB * fac;
+        bNx += nX * fac; bNy += nY * fac; bNz += nZ * fac;
         bD += e.dep * fac;
         float v_sigma = 0.f;
         if (!e.clamped) {
@@ -170,83 +190,108 @@ __global__ void __launch_bounds__(RT)
           v_sigma = -a2.w * e.vis * v_alpha;
         }
         if (e.b3) {
-
-          const float vsx = v_sigma * e.sx + v_dep * a2.x, vsy = v_sigma * e.sy + v_dep * a2.y;
-          const float inv = __builtin_amdgcn_rcpf(e.zz);
-          const float qx = vsx * inv, qy = vsy * inv;
-          const float vzx = qx, vzy = qy, vzz = -(qx * e.sx + qy * e.sy);
-          // z = hu x hv  ->  v_hu = hv x v_z,  v_hv = v_z x hu
-          const float vhux = e.hvy * vzz - e.hvz * vzy, vhuy = e.hvz * vzx - e.hvx * vzz, vhuz = e.hvx * vzy - e.hvy * vzx;
-          const float vhvx = vzy * e.huz - vzz * e.huy, vhvy = vzz * e.hux - vzx * e.huz, vhvz = vzx * e.huy - vzy * e.hux;
-          g_mu0 = -vhux; g_mu1 = -vhuy; g_mu2 = -vhuz;
-          g_mv0 = -vhvx; g_mv1 = -vhvy; g_mv2 = -vhvz;
-          g_mw0 = px * vhux + py * vhvx + v_dep * e.sx;
-          g_mw1 = px * vhuy + py * vhvy + v_dep * e.sy;
-          g_mw2 = px * vhuz + py * vhvz + v_dep;
+          // sigma = (zx^2 + zy^2) / (2 zz^2),  dep = D / zz
+          const float q = v_sigma * e.inv;
+          vzx = q * e.sx; vzy = q * e.sy;
+          g_D = v_dep * e.inv;
+          vzz = -(vzx * e.sx + vzy * e.sy) - g_D * e.dep;
         } else {
           v2 = true;
           g_x = v_sigma * FILTER_INV_SQUARE * e.dx;
           g_y = v_sigma * FILTER_INV_SQUARE * e.dy;
-          g_mw2 = v_dep;
+          g_mwz = v_dep;
         }
       }
       const bool any2 = __ballot(v2) != 0ull;
       float r;
-      {  // slots 0..15 (rgb, normal, opacity, M_u, M_v, M_w): one transposing butterfly, one ds_add per lane
-        const float v16[16] = {g_rgb0, g_rgb1, g_rgb2, g_n0, g_n1, g_n2, g_op, g_mu0, g_mu1, g_mu2,
-                               g_mv0, g_mv1, g_mv2, g_mw0, g_mw1, g_mw2};
+      {  // slots 0..15 (rgb, normal, opacity, V0, Vx, Vy): one transposing butterfly, one ds_add per lane
+        const float mxp = -e.dx, myp = -e.dy;  // pixel offset from the splat centre
+        const float v16[16] = {g_rgb0, g_rgb1, g_rgb2, g_n0, g_n1, g_n2, g_op, vzx, vzy, vzz,
+                               mxp * vzx, mxp * vzy, mxp * vzz, myp * vzx, myp * vzy, myp * vzz};
         r = row_transpose_reduce16(v16, lane);
         if (r != 0.f) lds_add(&lds.acc[t][row_transpose_index(lane)], r);  // 4 rows -> 4-way add on one address
       }
 #define RED(slot, val)                                   \
   r = wave_sum_to_lane63(val);                           \
   if (lane == 63 && r != 0.f) lds_add(&lds.acc[t][slot], r)
-      if (any2) {  // screen-space low-pass branch (rare): v_means2d (+abs)
-        RED(16, g_x); RED(17, g_y);
-        if (ABSGRAD) { RED(18, fabsf(g_x)); RED(19, fabsf(g_y)); }
+      RED(16, g_D);
+      if (any2) {  // screen-space low-pass branch (rare): v_means2d (+abs), centre-depth gradient
+        RED(17, g_mwz); RED(18, g_x); RED(19, g_y);
+        if (ABSGRAD) {
+          r = wave_sum_to_lane63(fabsf(g_x)); if (lane == 63 && r != 0.f) lds_add(&lds.acc_abs[t][0], r);
+          r = wave_sum_to_lane63(fabsf(g_y)); if (lane == 63 && r != 0.f) lds_add(&lds.acc_abs[t][1], r);
+        }
       }
 #undef RED
       }
     }
   }
   __syncthreads();
-  flush_records(lds, wave, lane, g_mine, grec);
+  flush_records<ABSGRAD>(lds, wave, lane, g_mine, grec, grec_abs);
 }
 
 // Streaming epilogue: unpack the 80-byte records into the operator's gradient tensors and derive the
 // densification signal (SPEC S-4, 2DGS convention consumed at neural_gaussian.cpp:660-665):
 // v_densify = (dL/dM_u.z, dL/dM_v.z) * M_w.z.
 __global__ void __launch_bounds__(256)
-    unpack_records_kernel(int64_t M, const float *__restrict__ grec, const float *__restrict__ ray_transforms,
+    unpack_records_kernel(int64_t M, const float *__restrict__ grec, const float *__restrict__ grec_abs,
+                          const float *__restrict__ means2d, const float *__restrict__ ray_transforms,
                           float *__restrict__ v_means2d, float *__restrict__ v_ray_transforms,
                           float *__restrict__ v_colors, float *__restrict__ v_opacities, float *__restrict__ v_normals,
                           float *__restrict__ v_densify, float *__restrict__ v_means2d_abs) {
   const int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (m >= M) return;
   float r[NACC];
-  const float4 *src = reinterpret_cast<const float4 *>(grec + m * NACC);
 #pragma unroll
-  for (int q = 0; q < NACC / 4; ++q) {
-    const float4 v = src[q];
-    r[4 * q] = v.x; r[4 * q + 1] = v.y; r[4 * q + 2] = v.z; r[4 * q + 3] = v.w;
-  }
+  for (int k = 0; k < NACC; ++k) r[k] = grec[m * NACC + k];
 #pragma unroll
   for (int k = 0; k < 3; ++k) { v_colors[3 * m + k] = r[k]; v_normals[3 * m + k] = r[3 + k]; }
   v_opacities[m] = r[6];
+  v_means2d[2 * m] = r[18]; v_means2d[2 * m + 1] = r[19];
+  if (v_means2d_abs != nullptr) { v_means2d_abs[2 * m] = grec_abs[2 * m]; v_means2d_abs[2 * m + 1] = grec_abs[2 * m + 1]; }
+  // moments -> dL/dM.  With h_u = m_x M_w - M_u, h_v = m_y M_w - M_v evaluated at the splat centre (m_x, m_y):
+  //   v_hu = h_v x V0 + M_w x Vy,   v_hv = V0 x h_u + Vx x M_w,
+  //   dL/dM_u = -v_hu + vD (M_v x M_w),   dL/dM_v = -v_hv + vD (M_w x M_u),
+  //   dL/dM_w = m_x v_hu + m_y v_hv + h_v x Vx + Vy x h_u + vD (M_u x M_v) + (0, 0, v_Mw.z)
+  const float *Mr = ray_transforms + 9 * m;
+  const float mu[3] = {Mr[0], Mr[1], Mr[2]}, mv[3] = {Mr[3], Mr[4], Mr[5]}, mw[3] = {Mr[6], Mr[7], Mr[8]};
+  const float mx = means2d[2 * m], my = means2d[2 * m + 1];
+  const float hu[3] = {mx * mw[0] - mu[0], mx * mw[1] - mu[1], mx * mw[2] - mu[2]};
+  const float hv[3] = {my * mw[0] - mv[0], my * mw[1] - mv[1], my * mw[2] - mv[2]};
+  const float *V0 = r + 7, *Vx = r + 10, *Vy = r + 13;
+  const float vD = r[16];
+#define CROSS(o, a, b) o[0] = a[1] * b[2] - a[2] * b[1]; o[1] = a[2] * b[0] - a[0] * b[2]; o[2] = a[0] * b[1] - a[1] * b[0]
+  float t1[3], t2[3], vhu[3], vhv[3], AvW[3], BwU[3], CuV[3], t3[3], t4[3];
+  CROSS(t1, hv, V0); CROSS(t2, mw, Vy);
+  CROSS(t3, V0, hu); CROSS(t4, Vx, mw);
 #pragma unroll
-  for (int k = 0; k < 9; ++k) v_ray_transforms[9 * m + k] = r[7 + k];
-  v_means2d[2 * m] = r[16]; v_means2d[2 * m + 1] = r[17];
-  if (v_means2d_abs != nullptr) { v_means2d_abs[2 * m] = r[18]; v_means2d_abs[2 * m + 1] = r[19]; }
-  const float depth = ray_transforms[9 * m + 8];
-  v_densify[2 * m] = r[7 + 2] * depth;
-  v_densify[2 * m + 1] = r[7 + 5] * depth;
+  for (int k = 0; k < 3; ++k) { vhu[k] = t1[k] + t2[k]; vhv[k] = t3[k] + t4[k]; }
+  CROSS(AvW, mv, mw); CROSS(BwU, mw, mu); CROSS(CuV, mu, mv);
+  CROSS(t1, hv, Vx); CROSS(t2, Vy, hu);
+#undef CROSS
+  float gmu[3], gmv[3], gmw[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    gmu[k] = -vhu[k] + vD * AvW[k];
+    gmv[k] = -vhv[k] + vD * BwU[k];
+    gmw[k] = mx * vhu[k] + my * vhv[k] + t1[k] + t2[k] + vD * CuV[k];
+  }
+  gmw[2] += r[17];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    v_ray_transforms[9 * m + k] = gmu[k]; v_ray_transforms[9 * m + 3 + k] = gmv[k]; v_ray_transforms[9 * m + 6 + k] = gmw[k];
+  }
+  v_densify[2 * m] = gmu[2] * mw[2];
+  v_densify[2 * m + 1] = gmv[2] * mw[2];
 }
 
 }  // namespace gsdf
 
 using namespace gsdf;
 
-extern "C" size_t gsdf_rasterize_2dgs_bwd_ws_bytes(int64_t M) { return (size_t)(M > 0 ? M : 1) * NACC * sizeof(float) + 256; }
+extern "C" size_t gsdf_rasterize_2dgs_bwd_ws_bytes(int64_t M) {
+  return align_up((size_t)(M > 0 ? M : 1) * NACC * sizeof(float), 256) + align_up((size_t)(M > 0 ? M : 1) * 2 * sizeof(float), 256) + 256;
+}
 
 extern "C" int gsdf_rasterize_2dgs_bwd(int64_t C, int64_t M, int64_t I, int width, int height, int tile_size,
                                        const float *means2d, const float *ray_transforms, const float *colors,
@@ -271,11 +316,13 @@ extern "C" int gsdf_rasterize_2dgs_bwd(int64_t C, int64_t M, int64_t I, int widt
   const int tw = (width + TILE - 1) / TILE, th = (height + TILE - 1) / TILE;
   const int64_t n_tiles = (int64_t)tw * th, total = n_tiles * C;
   float *grec = (float *)ws;
+  float *grec_abs = (float *)((char *)ws + align_up((size_t)M * NACC * sizeof(float), 256));
   GSDF_HIP(hipMemsetAsync(grec, 0, (size_t)M * NACC * sizeof(float), stream), "rasterize_bwd memset");
+  if (v_means2d_abs) GSDF_HIP(hipMemsetAsync(grec_abs, 0, (size_t)M * 2 * sizeof(float), stream), "rasterize_bwd memset");
   if (I > 0) {
 #define ARGS total, n_tiles, I, width, height, tw, means2d, ray_transforms, colors, opacities, normals, backgrounds, \
              masks, isect_offsets, flatten_ids, render_alphas, last_ids, median_ids, v_render_colors,               \
-             v_render_depths, v_render_alphas, v_render_normals, v_render_median, grec
+             v_render_depths, v_render_alphas, v_render_normals, v_render_median, grec, grec_abs
     if (v_means2d_abs)
       raster_bwd_kernel<true><<<xcd_grid(total), RT, 0, stream>>>(ARGS);
     else
@@ -283,7 +330,7 @@ extern "C" int gsdf_rasterize_2dgs_bwd(int64_t C, int64_t M, int64_t I, int widt
 #undef ARGS
     GSDF_CHECK_LAUNCH("raster_bwd_kernel");
   }
-  unpack_records_kernel<<<(unsigned)((M + 255) / 256), 256, 0, stream>>>(M, grec, ray_transforms, v_means2d,
+  unpack_records_kernel<<<(unsigned)((M + 255) / 256), 256, 0, stream>>>(M, grec, grec_abs, means2d, ray_transforms, v_means2d,
                                                                        v_ray_transforms, v_colors, v_opacities,
                                                                        v_normals, v_densify, v_means2d_abs);
   GSDF_CHECK_LAUNCH("unpack_records_kernel");

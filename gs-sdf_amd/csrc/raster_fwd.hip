@@ -34,6 +34,7 @@ __global__ void __launch_bounds__(RT)
   const bool inside = x < W && y < H;
   const int64_t pid = (cam * H + y) * (int64_t)W + x;
   const float px = (float)x + 0.5f, py = (float)y + 0.5f;
+  const float lx = (float)((wave & 1) * 8 + (lane & 7)), ly = (float)((wave >> 1) * 8 + (lane >> 3));
 
   int32_t start = isect_offsets[tile];
   int32_t end = (tile == total_tiles - 1) ? (int32_t)I : isect_offsets[tile + 1];
@@ -73,9 +74,9 @@ __global__ void __launch_bounds__(RT)
       while (todo) {
         const int t = c0 + __builtin_ctzll(todo);  // front-to-back
         todo &= todo - 1ull;
-        const float4 a0 = lds.s.q0[t], a1 = lds.s.q1[t], a2 = lds.s.q2[t];
+        const float4 a0 = lds.s.q0[t], a1 = lds.s.q1[t], a2 = lds.s.q2[t], a3 = lds.s.q3[t];
         PairEval e;
-        eval_pair(px, py, a0, a1, a2, e);
+        eval_pair(lx, ly, px, py, a0, a1, a2, a3.x, a3.y, e);
         bool valid = !done && e.ok;
         if (__ballot(valid) == 0ull) continue;
         const float nT = T * (1.0f - e.alpha);
@@ -84,10 +85,9 @@ __global__ void __launch_bounds__(RT)
           valid = false;
         }
         const float w = valid ? e.alpha * T : 0.0f;
-        const float4 a3 = lds.s.q3[t];
-        const float2 a4 = lds.s.q4[t];
-        cr += a3.x * w; cg += a3.y * w; cb += a3.z * w;
-        nx += a3.w * w; ny += a4.x * w; nz += a4.y * w;
+        const float4 a4 = lds.s.q4[t];
+        cr += a3.z * w; cg += a3.w * w; cb += a4.x * w;
+        nx += a4.y * w; ny += a4.z * w; nz += a4.w * w;
         dsum += e.dep * w;
         if (valid) {
           if (T > 0.5f) { med = e.dep; med_idx = bstart + t; }
