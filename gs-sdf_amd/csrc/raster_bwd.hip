@@ -20,29 +20,31 @@
 
 namespace gsdf {
 
-static constexpr int NACC = 21;
+static constexpr int NACC = 20;
+static constexpr int BWD_BATCH = 240;  // staged splats per batch: keeps the workgroup at <= 40 KiB of LDS (4 workgroups per CU)
 // Per-splat gradient record.  The cross-product chain of z = h_u x h_v is NOT differentiated per pixel: the record
 // accumulates the moments of v_z about the splat's own centre,
 //     V0 = sum v_z,   Vx = sum (p_x - mean2d.x) v_z,   Vy = sum (p_y - mean2d.y) v_z,
 // (z is affine in the pixel, so these nine numbers carry everything) plus vD = sum v_dep / z.z for the depth
 // D / z.z; the streaming epilogue turns them into dL/dM_u, dL/dM_v, dL/dM_w once per splat.
 // slots: 0-2 v_rgb, 3-5 v_normal, 6 v_opacity, 7-9 V0, 10-12 Vx, 13-15 Vy, 16 vD, 17 v_Mw.z (low-pass branch depth),
-//        18-19 v_means2d, 20 unused ; v_means2d_abs lives in a second record array (only with absgrad)
+//        18-19 v_means2d ; v_means2d_abs lives in a second record array (only with absgrad)
+template <bool ABSGRAD>
 struct BwdLds {
   SplatBatch s;
-  float acc[RT][NACC];  // one 84-byte record per staged splat
-  float acc_abs[RT][2];
+  float acc[BWD_BATCH][NACC];  // one 80-byte record per staged splat
+  float acc_abs[ABSGRAD ? BWD_BATCH : 1][2];
   int bin_final_max;
 };
 
 // Adds the LDS records of this wave's 64 staged splats to the global record array and clears them.
-// Three splats per instruction: lane = 21*j + k -> field k of splat slot 3*it + j.
+// Three splats per instruction: lane = 20*j + k -> field k of splat slot 3*it + j.
 template <bool ABSGRAD>
-__device__ __forceinline__ void flush_records(BwdLds &lds, int wave, int lane, int g_mine, float *__restrict__ grec,
+__device__ __forceinline__ void flush_records(BwdLds<ABSGRAD> &lds, int wave, int lane, int g_mine, float *__restrict__ grec,
                                               float *__restrict__ grec_abs) {
   if (ABSGRAD) {
     const int slot = wave * 64 + lane;
-    if (g_mine >= 0) {
+    if (g_mine >= 0 && slot < BWD_BATCH) {
 #pragma unroll
       for (int k = 0; k < 2; ++k) {
         const float v = lds.acc_abs[slot][k];
@@ -81,7 +83,7 @@ __global__ void __launch_bounds__(RT)
                       const float *__restrict__ v_render_alphas, const float *__restrict__ v_render_normals,
                       const float *__restrict__ v_render_median, float *__restrict__ grec,
                       float *__restrict__ grec_abs) {
-  __shared__ BwdLds lds;
+  __shared__ BwdLds<ABSGRAD> lds;
   const int64_t tile = xcd_tile_index(total_tiles);
   if (tile >= total_tiles) return;
   if (masks != nullptr && !masks[tile]) return;
@@ -119,9 +121,11 @@ __global__ void __launch_bounds__(RT)
   float bCr = 0.f, bCg = 0.f, bCb = 0.f, bNx = 0.f, bNy = 0.f, bNz = 0.f, bD = 0.f;
 
   if (tid == 0) lds.bin_final_max = -1;
+  if (tid < BWD_BATCH) {
 #pragma unroll
-  for (int k = 0; k < NACC; ++k) lds.acc[tid][k] = 0.f;
-  lds.acc_abs[tid][0] = 0.f; lds.acc_abs[tid][1] = 0.f;
+    for (int k = 0; k < NACC; ++k) lds.acc[tid][k] = 0.f;
+    if (ABSGRAD) { lds.acc_abs[tid][0] = 0.f; lds.acc_abs[tid][1] = 0.f; }
+  }
   __syncthreads();
   {  // tile-wide and wave-wide last contributor
     int m = bin_final;
@@ -137,20 +141,20 @@ __global__ void __launch_bounds__(RT)
   if (tile_bin_final < start) return;
 
   int g_mine = -1;
-  const int nb = (min(end, tile_bin_final + 1) - start + RT - 1) / RT;
+  const int nb = (min(end, tile_bin_final + 1) - start + BWD_BATCH - 1) / BWD_BATCH;
   for (int b = nb - 1; b >= 0; --b) {
     __syncthreads();  // barrier A: previous batch fully consumed, its accumulators complete
     flush_records<ABSGRAD>(lds, wave, lane, g_mine, grec, grec_abs);  // wave w owns slots [64w, 64w+64)
     g_mine = -1;
-    const int32_t bstart = start + b * RT;
+    const int32_t bstart = start + b * BWD_BATCH;
     const int32_t idx = bstart + tid;
-    if (idx < end && idx <= tile_bin_final) {
+    if (tid < BWD_BATCH && idx < end && idx <= tile_bin_final) {
       g_mine = flatten_ids[idx];
       stage_splat(lds.s, tid, g_mine, means2d, ray_transforms, colors, opacities, normals, (float)(tx * TILE),
                   (float)(ty * TILE));
     }
     __syncthreads();  // barrier B
-    const int count = min(RT, min(end, tile_bin_final + 1) - bstart);
+    const int count = min(BWD_BATCH, min(end, tile_bin_final + 1) - bstart);
     // per-wave compaction (see raster_common.h quadrant_mask), back-to-front
     const int wcount = min(count, wave_bin_final - bstart + 1);
     for (int c0 = ((wcount - 1) >> 6) << 6; c0 >= 0 && wcount > 0; c0 -= 64) {

@@ -31,7 +31,7 @@ static constexpr float FILTER_INV_SQUARE = 2.0f;
 //   q3 = (D, M_w.z, r, g)            q4 = (b, n.x, n.y, n.z)
 struct SplatBatch {
   float4 q0[RT], q1[RT], q2[RT], q3[RT], q4[RT];
-  unsigned qmask[RT];  // bit q set <=> the splat can reach wave q's 8x8 pixel quadrant (conservative)
+  unsigned char qmask[RT];  // bit q set <=> the splat can reach wave q's 8x8 pixel quadrant (conservative)
 };
 
 // Conservative per-quadrant reach test, evaluated ONCE per (tile, splat) by the staging lane.
@@ -101,7 +101,7 @@ __device__ __forceinline__ void stage_splat(SplatBatch &s, int slot, int g, cons
   s.q2[slot] = make_float4(cx, cy, cz, opac);
   s.q3[slot] = make_float4(D, mw2, c[0], c[1]);
   s.q4[slot] = make_float4(c[2], n[0], n[1], n[2]);
-  s.qmask[slot] = quadrant_mask(m, xy.x, xy.y, opac, tile_x0, tile_y0);
+  s.qmask[slot] = (unsigned char)quadrant_mask(m, xy.x, xy.y, opac, tile_x0, tile_y0);
 }
 
 // XCD-aware tile assignment: workgroup b runs on XCD (b % 8); give each XCD one contiguous band
