@@ -7,14 +7,14 @@
 // Semantics: SPEC A.7 — Hash grid, 3-D, F=2, Linear interpolation, pos = fma(scale,x,0.5),
 // dense index while the stride fits the level's table else prime hash, index % table size.
 //
-// MI355X mapping: one lane per (point, level) with the 16 levels of a point in the 16 consecutive
-// lanes of one DPP row (wave64 = 4 points x 16 levels):
-//   * the 32 output features of a point are 128 contiguous bytes written by one row (coalesced),
-//   * the per-point reductions over levels (d/dx, double-backward d/dx) are DPP row_shr adds —
-//     no atomics, no LDS,
-//   * the only scattered traffic is the 8 x 8-byte corner gathers (and the matching fp32 atomics
-//     of the table gradient), which is the algorithm's compulsory random access; the 61 MB fp32
-//     table is resident in the 256 MiB Infinity Cache.
+// MI355X mapping: wave64 = one point x 16 levels x 4 lanes, the 4 lanes of a (point, level) being
+// (x-corner bit, feature):
+//   * every memory instruction of a (y,z) corner pair touches 4 consecutive floats (16 B) whenever the two
+//     x-neighbour entries are adjacent (always in the dense levels, for even x0 in the hashed levels);
+//   * the 32 output features of a point are 128 contiguous bytes written by one wave (coalesced);
+//   * the per-point reductions over levels (d/dx, double-backward d/dx) are DPP adds, no atomics, no LDS;
+//   * the only scattered traffic is the corner gathers and the matching fp32 atomics of the table gradient,
+//     the algorithm's compulsory random access; the 61 MB fp32 table is resident in the 256 MiB Infinity Cache.
 #include "common.h"
 
 namespace gsdf {
@@ -99,25 +99,32 @@ __device__ __forceinline__ float row_sum_to_lane15(float v) {
   return v;
 }
 
+// forward: 4 lanes per (point, level) = (x-corner bit, feature), like the backward kernels below: the 4 lanes of a
+// (y,z) corner pair read 4 consecutive floats {entry(x0).f0,.f1, entry(x1).f0,.f1} -> one 16-byte segment per group
+// instead of two 8-byte gathers in different instructions; the two x partials are combined with one quad DPP.
 __global__ void __launch_bounds__(HG_THREADS)
     hashgrid_fwd_kernel(int64_t B, HgLevels lv, const float *__restrict__ x, const float *__restrict__ table,
                         float *__restrict__ feat) {
-  const int level = threadIdx.x & 15;
-  const int64_t b = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
-  if (b >= B || level >= lv.n_levels) return;
-  Cell c;
-  load_cell(lv, level, x, b, table, c);
-  float a0 = 0.f, a1 = 0.f;
+  const int lane = threadIdx.x & 63;
+  const int f = lane & 1, xb = (lane >> 1) & 1, level = lane >> 2;
+  const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= B) return;  // wave-uniform
+  float acc = 0.f;
+  if (level < lv.n_levels) {
+    Cell c;
+    load_cell(lv, level, x, b, table, c);
+    const float *tb = table + (int64_t)lv.offset[level] * 2 + f;
+    const float wx = xb ? c.fr[0] : 1.f - c.fr[0];
 #pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    const int hx = k & 1, hy = (k >> 1) & 1, hz = k >> 2;
-    const uint32_t idx = grid_index(c.hsize, c.res, c.g0[0] + hx, c.g0[1] + hy, c.g0[2] + hz);
-    const float w = (hx ? c.fr[0] : 1.f - c.fr[0]) * (hy ? c.fr[1] : 1.f - c.fr[1]) * (hz ? c.fr[2] : 1.f - c.fr[2]);
-    const float2 v = c.base[idx];
-    a0 += w * v.x;
-    a1 += w * v.y;
+    for (int k = 0; k < 4; ++k) {
+      const int hy = k & 1, hz = k >> 1;
+      const uint32_t idx = grid_index(c.hsize, c.res, c.g0[0] + xb, c.g0[1] + hy, c.g0[2] + hz);
+      const float w = wx * (hy ? c.fr[1] : 1.f - c.fr[1]) * (hz ? c.fr[2] : 1.f - c.fr[2]);
+      acc += w * tb[2 * (int64_t)idx];
+    }
   }
-  *reinterpret_cast<float2 *>(feat + (b * lv.n_levels + level) * 2) = make_float2(a0, a1);
+  acc += dpp_mov<0x4E>(acc);  // quad_perm [2,3,0,1]: add the other x-corner's partial (same feature)
+  if (xb == 0 && level < lv.n_levels) feat[(b * lv.n_levels + level) * 2 + f] = acc;
 }
 
 // ---- backward kernels: 4 lanes per (point, level) -------------------------------------------------------
@@ -244,7 +251,7 @@ extern "C" int gsdf_hashgrid_fwd(int64_t B, int n_levels, int n_feat, int log2_h
   GSDF_REQUIRE(x && table && feat, "hashgrid_fwd: null buffer");
   HgLevels lv;
   build_levels(n_levels, log2_hashmap, base_res, per_level_scale, &lv, nullptr);
-  hashgrid_fwd_kernel<<<(unsigned)((B + 15) / 16), HG_THREADS, 0, stream>>>(B, lv, x, table, feat);
+  hashgrid_fwd_kernel<<<(unsigned)((B + 3) / 4), HG_THREADS, 0, stream>>>(B, lv, x, table, feat);
   GSDF_CHECK_LAUNCH("hashgrid_fwd_kernel");
   return GSDF_OK;
 }
