@@ -76,7 +76,7 @@ def main():
         # configuration (params.cpp:396-399 forces it for the tcnn decoder); ray batch 32768 (base.yaml:24)
         import gs_sdf_amd.sdf as sdfm
         lm = sdfm.LocalMap([0.0, 0.0, 5.5], 16.0, bce_sigma=0.02, decoder_implementation=1, device=dev, seed=5)
-        groups.append(lm.flatten())
+        groups.append(lm.flatten(accumulate_table_grad_in_place=True))
         gq = torch.Generator().manual_seed(4)
         pool = [((torch.rand(32768, 3, generator=gq) - 0.5) * 14.0 + torch.tensor([0.0, 0.0, 5.5])).to(dev) for _ in range(8)]
         ray_sdf = [(torch.randn(32768, 1, generator=gq) * 0.02).to(dev) for _ in range(8)]

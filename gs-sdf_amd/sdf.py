@@ -32,11 +32,22 @@ class _GridBwd(torch.autograd.Function):
     grad-of-grad (eikonal on the analytic SDF gradient) works."""
 
     @staticmethod
-    def forward(ctx, v_feat, x, table, cfg, want_table):
+    def forward(ctx, v_feat, x, table, cfg, want_table, grad_sink=None):
         L = capi.lib()
         B = x.shape[0]
         v_feat = v_feat.contiguous()
         v_x = torch.empty_like(x)
+        if want_table and grad_sink is not None:
+            # accumulate straight into the parameter's (pre-zeroed) gradient buffer: the kernel's atomics already
+            # ACCUMULATE, so the 61 MB zero-fill + the autograd add per call disappear; autograd sees no table grad
+            v_table, want_table = grad_sink.view(table.shape), False
+            capi.check(_timed("hashgrid_bwd", L.gsdf_hashgrid_bwd, B, *cfg, f32(x), f32(table), f32(v_feat), f32(v_table),
+                              f32(v_x), capi.stream()), "hashgrid_bwd")
+            ctx.save_for_backward(v_feat, x, table)
+            ctx.cfg = cfg
+            v_table = torch.zeros(0, device=x.device)
+            ctx.mark_non_differentiable(v_table)
+            return v_x, v_table
         v_table = torch.zeros_like(table) if want_table else None
         capi.check(_timed("hashgrid_bwd", L.gsdf_hashgrid_bwd, B, *cfg, f32(x), f32(table), f32(v_feat), f32(v_table),
                           f32(v_x), capi.stream()), "hashgrid_bwd")
@@ -55,18 +66,18 @@ class _GridBwd(torch.autograd.Function):
         B = x.shape[0]
         need_vf, need_x, need_t = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2]
         if vv_x is None:
-            return None, None, None, None, None
+            return None, None, None, None, None, None
         g_vfeat = torch.empty_like(v_feat) if need_vf else None
         g_x = torch.empty_like(x) if need_x else None
         g_table = torch.zeros_like(table) if need_t else None
         capi.check(_timed("hashgrid_bwd_bwd", L.gsdf_hashgrid_bwd_bwd, B, *ctx.cfg, f32(x), f32(table), f32(v_feat),
                           f32(vv_x.contiguous()), f32(g_vfeat), f32(g_table), f32(g_x), capi.stream()), "hashgrid_bwd_bwd")
-        return g_vfeat, g_x, g_table, None, None
+        return g_vfeat, g_x, g_table, None, None, None
 
 
 class _GridFwd(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, table, cfg):
+    def forward(ctx, x, table, cfg, grad_sink=None):
         L = capi.lib()
         x, table = x.contiguous(), table.contiguous()
         B = x.shape[0]
@@ -75,13 +86,15 @@ class _GridFwd(torch.autograd.Function):
                           capi.stream()), "hashgrid_fwd")
         ctx.save_for_backward(x, table)
         ctx.cfg = cfg
+        ctx.grad_sink = grad_sink
         return feat
 
     @staticmethod
     def backward(ctx, v_feat):
         x, table = ctx.saved_tensors
-        v_x, v_table = _GridBwd.apply(v_feat, x, table, ctx.cfg, bool(ctx.needs_input_grad[1]))
-        return (v_x if ctx.needs_input_grad[0] else None), (v_table if ctx.needs_input_grad[1] else None), None
+        v_x, v_table = _GridBwd.apply(v_feat, x, table, ctx.cfg, bool(ctx.needs_input_grad[1]), ctx.grad_sink)
+        want_t = ctx.needs_input_grad[1] and ctx.grad_sink is None
+        return (v_x if ctx.needs_input_grad[0] else None), (v_table if want_t else None), None, None
 
 
 class TCNNEncoding:
@@ -105,6 +118,9 @@ class TCNNEncoding:
         # tiny-cuda-nn initialises grid parameters U(-1e-4, 1e-4)
         init = (torch.rand(total * self.cfg[1], generator=g) * 2 - 1) * 1e-4
         self.params_ = init.to(device).requires_grad_(True)
+        # optional: a pre-zeroed buffer shaped like params_ into which the table gradient is accumulated IN PLACE
+        # (first order only) instead of being returned to autograd; set by LocalMap.flatten() for the trainer
+        self.grad_sink = None
 
     def get_out_dim(self):
         return self.cfg[0] * self.cfg[1]
@@ -112,7 +128,7 @@ class TCNNEncoding:
     def forward(self, x):
         if x.dim() != 2 or x.shape[1] != 3:
             raise RuntimeError("TCNNEncoding.forward: expected [B,3]")
-        return _GridFwd.apply(x, self.params_.view(-1, self.cfg[1]), self.cfg)
+        return _GridFwd.apply(x, self.params_.view(-1, self.cfg[1]), self.cfg, self.grad_sink)
 
     __call__ = forward
 
@@ -212,7 +228,7 @@ class LocalMap:
             ps += [self.decoder.params_] + ([self.decoder.biases_] if self.decoder.biases_ is not None else [])
         return ps
 
-    def flatten(self):
+    def flatten(self, accumulate_table_grad_in_place=False):
         """Moves every parameter into one flat buffer (single all-reduce message); returns a FlatGroup."""
         from .trainer import FlatGroup, flatten_leaves
         flat, flat_grad, views = flatten_leaves(self.parameters())
@@ -225,6 +241,8 @@ class LocalMap:
             self.encoder.params_, self.decoder.params_ = views[0], views[1]
             if self.decoder.biases_ is not None:
                 self.decoder.biases_ = views[2]
+        if accumulate_table_grad_in_place:
+            self.encoder.grad_sink = self.encoder.params_.grad
         return FlatGroup(flat, flat_grad)
 
     def xyz_to_zp1_pts(self, xyz):                 # sub_map.cpp:82-97

@@ -195,3 +195,20 @@ def test_fused_adam_matches_torch_adam():
             p.grad = gg.clone()
         ref.step(); opt.step()
         assert_close(flat, torch.cat([p.detach() for p in ref_params]), 1e-6, f"params after step {it + 1}")
+
+
+def test_in_place_table_gradient_accumulation_equals_autograd(sdf):
+    """LocalMap.flatten(accumulate_table_grad_in_place=True) (trainer fast path) gives the same parameter gradients as
+    plain autograd accumulation over several get_sdf calls."""
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(3)
+    xs = [((torch.rand(n, 3, generator=g) - 0.5) * 1.5).to(dev) for n in (3000, 5000)]
+    grads = []
+    for inplace in (False, True):
+        lm = sdf.LocalMap([0.0, 0.0, 0.0], 2.0, decoder_implementation=1, device=dev, seed=7)
+        grp = lm.flatten(accumulate_table_grad_in_place=inplace)
+        loss = sum((lm.get_sdf(x)[0] ** 2).sum() for x in xs)
+        loss.backward()
+        grads.append(grp.flat_grad.clone())
+    assert float(grads[0].abs().sum()) > 0
+    assert_close(grads[1], grads[0], 1e-5, "flat gradient (in-place sink vs autograd)")
