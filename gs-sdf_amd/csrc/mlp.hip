@@ -56,11 +56,17 @@ __device__ void stage_weights_fwd(const MlpDesc &d, const float *__restrict__ W,
     const int ksteps = I / 2;
     const float *Wl = W + d.w_off[l];
     float *dst = lds_w + d.lds_off[l];
-    for (int e = threadIdx.x; e < otiles * ksteps * 64; e += MLP_THREADS) {
-      const int lane = e & 63, s = (e >> 6) % ksteps, t = (e >> 6) / ksteps;
-      const int h = lane >> 5, o = 32 * t + (lane & 31);
-      const int k = l == 0 ? h * ksteps + s : perm_hidden(s, h);
-      dst[e] = o < O ? Wl[o * I + k] : 0.f;
+    // four consecutive k-steps of one half-wave are four CONSECUTIVE input neurons (both for the natural order of
+    // layer 0 and for perm_hidden), so every lane fetches one float4 of its weight row and scatters it into the
+    // image with 4 conflict-free ds_write_b32 (lanes = 32 consecutive output rows)
+    const int sq_n = ksteps / 4;
+    for (int u = threadIdx.x; u < otiles * sq_n * 64; u += MLP_THREADS) {
+      const int ol = u & 31, h = (u >> 5) & 1, sq = (u >> 6) % sq_n, t = (u >> 6) / sq_n;
+      const int o = 32 * t + ol;
+      const int k0 = l == 0 ? h * ksteps + 4 * sq : perm_hidden(4 * sq, h);
+      const float4 v = o < O ? *reinterpret_cast<const float4 *>(Wl + o * I + k0) : make_float4(0.f, 0.f, 0.f, 0.f);
+      float *d4 = dst + (t * ksteps + 4 * sq) * 64 + 32 * h + ol;
+      d4[0] = v.x; d4[64] = v.y; d4[128] = v.z; d4[192] = v.w;
     }
     for (int e = threadIdx.x; e < HID; e += MLP_THREADS)
       lds_b[l * HID + e] = (d.has_bias && e < O) ? bias[d.b_off[l] + e] : 0.f;
@@ -101,8 +107,11 @@ __global__ void __launch_bounds__(MLP_THREADS)
         v16f acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = lds_b[32 * t + d_row(r, h)];
+        float aw[K0];
 #pragma unroll
-        for (int s = 0; s < K0; ++s) acc = mfma32(w[(t * K0 + s) * 64 + lane], x[s], acc);
+        for (int s = 0; s < K0; ++s) aw[s] = w[(t * K0 + s) * 64 + lane];
+#pragma unroll
+        for (int s = 0; s < K0; ++s) acc = mfma32(aw[s], x[s], acc);
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = fmaxf(acc[r], 0.f);
         cur[t] = acc;
@@ -129,8 +138,11 @@ __global__ void __launch_bounds__(MLP_THREADS)
           v16f acc;
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[r] = lds_b[l * HID + 32 * t + d_row(r, h)];
+          float aw[32];  // all A operands of this tile first: the 32 dependent MFMAs then issue back to back
 #pragma unroll
-          for (int s = 0; s < 32; ++s) acc = mfma32(w[(t * 32 + s) * 64 + lane], cur[s >> 4][s & 15], acc);
+          for (int s = 0; s < 32; ++s) aw[s] = w[(t * 32 + s) * 64 + lane];
+#pragma unroll
+          for (int s = 0; s < 32; ++s) acc = mfma32(aw[s], cur[s >> 4][s & 15], acc);
           if (!last) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = fmaxf(acc[r], 0.f);
@@ -203,11 +215,17 @@ __global__ void __launch_bounds__(MLP_THREADS)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
         if (last) {
+          float aw[16];
 #pragma unroll
-          for (int s = 0; s < 16; ++s) acc = mfma32(w[(t * 16 + s) * 64 + lane], g[0][s], acc);
+          for (int s = 0; s < 16; ++s) aw[s] = w[(t * 16 + s) * 64 + lane];
+#pragma unroll
+          for (int s = 0; s < 16; ++s) acc = mfma32(aw[s], g[0][s], acc);
         } else {
+          float aw[32];
 #pragma unroll
-          for (int s = 0; s < 32; ++s) acc = mfma32(w[(t * 32 + s) * 64 + lane], g[s >> 4][s & 15], acc);
+          for (int s = 0; s < 32; ++s) aw[s] = w[(t * 32 + s) * 64 + lane];
+#pragma unroll
+          for (int s = 0; s < 32; ++s) acc = mfma32(aw[s], g[s >> 4][s & 15], acc);
         }
         ng[t] = acc;
       }
@@ -237,8 +255,11 @@ __global__ void __launch_bounds__(MLP_THREADS)
         v16f acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        float aw[32];
 #pragma unroll
-        for (int s = 0; s < 32; ++s) acc = mfma32(w[(t * 32 + s) * 64 + lane], g[s >> 4][s & 15], acc);
+        for (int s = 0; s < 32; ++s) aw[s] = w[(t * 32 + s) * 64 + lane];
+#pragma unroll
+        for (int s = 0; s < 32; ++s) acc = mfma32(aw[s], g[s >> 4][s & 15], acc);
         if (live) {
 #pragma unroll
           for (int q = 0; q < 4; ++q)
@@ -332,7 +353,7 @@ using namespace gsdf;
 
 static unsigned mlp_grid(int64_t B) {
   const int64_t wg = (B + 127) / 128;  // 4 tiles of 32 points per workgroup
-  return (unsigned)(wg < 1 ? 1 : (wg > 1024 ? 1024 : wg));
+  return (unsigned)(wg < 1 ? 1 : (wg > 512 ? 512 : wg));
 }
 
 extern "C" size_t gsdf_mlp_bwd_ws_bytes(int64_t B, int n_layers) {
