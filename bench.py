@@ -70,6 +70,7 @@ def main():
     K = sc["K"].to(dev)
     params = SplatParams.from_scene(sc, dev)
     ug = {k: v.to(dev) for k, v in synth.upstream_grads(H, W, seed=2).items()}
+    target = torch.rand(H, W, 3, generator=torch.Generator().manual_seed(3)).to(dev)    # target image U(0,1) seed 3
     groups = []
     if not args.no_sdf:
         # hash-grid SDF (2^19 table, 16 levels x 2) + fused MFMA decoder; the reference's numerical-gradient
@@ -97,9 +98,11 @@ def main():
         xyz, quat, scales, opacity, sh = params.activated()
         colors, alphas, meta = ops.rasterization_2dgs_sdf(xyz, quat, scales, opacity, sh, view, K, W, H, near_plane=0.05,
                                                           far_plane=300.0, sh_degree=deg, center_reg=True)
-        loss = ((colors[..., :3] * ug["v_render_colors"]).sum() + (colors[..., 3:] * ug["v_render_depths"]).sum()
-                + (alphas * ug["v_render_alphas"]).sum() + (meta["render_normal"] * ug["v_render_normals"]).sum()
-                + (meta["render_median"] * ug["v_render_median"]).sum())
+        # colour: the reference's photometric loss 0.8 L1 + 0.2 D-SSIM (neural_mapping.cpp:237-240), fused HIP kernel;
+        # depth / alpha / normal / median: op-level N(0,1) upstream gradients so that every backward path is live
+        loss = (ops.l1_dssim_loss(colors[0, ..., :3], target, 0.8, 0.2) + 1e-6 * (colors[..., 3:] * ug["v_render_depths"]).sum()
+                + 1e-6 * ((alphas * ug["v_render_alphas"]).sum() + (meta["render_normal"] * ug["v_render_normals"]).sum()
+                          + (meta["render_median"] * ug["v_render_median"]).sum()))
         if not args.no_sdf:
             # per-ray SDF batch (neural_mapping.cpp:138-188): BCE on the SDF head + eikonal on the numerical gradient
             pts, tgt = pool[i % 8], ray_sdf[i % 8]

@@ -272,6 +272,53 @@ def rasterize_to_pixels_2dgs(means2d, ray_transforms, colors, opacities, normals
                                 backgrounds, masks, int(width), int(height), int(tile_size), isect_offsets, flatten_ids)
 
 
+def ssim_window(window_size=11, sigma=1.5):
+    """The reference's 1-D window (loss_utils.cpp:6-14): exp(-floor((x - window_size)/2)^2 / (2 sigma^2)), normalised —
+    NOT the symmetric Gaussian; reproduced verbatim."""
+    import math
+    g = [math.exp(-(math.floor((x - window_size) / 2.0) ** 2) / (2.0 * sigma * sigma)) for x in range(window_size)]
+    s = sum(g)
+    return [v / s for v in g]
+
+
+class _L1DSSIM(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, img, gt, w_l1, w_ssim):
+        import ctypes as C
+        L = capi.lib()
+        img, gt = img.contiguous(), gt.contiguous()
+        H, W = img.shape[0], img.shape[1]
+        win = (C.c_float * 11)(*ssim_window())
+        sums = torch.empty(2, dtype=torch.float32, device=img.device)
+        maps = torch.empty(3, H, W, 3, dtype=torch.float32, device=img.device) if ctx.needs_input_grad[0] else None
+        capi.check(_timed("l1_dssim_fwd", L.gsdf_l1_dssim_fwd, H, W, f32(img, "image"), f32(gt, "gt"), win, f32(sums),
+                          f32(maps), capi.stream()), "l1_dssim_fwd")
+        ctx.save_for_backward(img, gt, maps)
+        ctx.w = (float(w_l1), float(w_ssim))
+        n = 3.0 * H * W
+        return w_l1 * sums[0] / n + w_ssim * (1.0 - sums[1] / n)
+
+    @staticmethod
+    def backward(ctx, v_loss):
+        import ctypes as C
+        L = capi.lib()
+        img, gt, maps = ctx.saved_tensors
+        H, W = img.shape[0], img.shape[1]
+        win = (C.c_float * 11)(*ssim_window())
+        v_img = torch.empty_like(img)
+        capi.check(_timed("l1_dssim_bwd", L.gsdf_l1_dssim_bwd, H, W, f32(img), f32(gt), win, f32(maps),
+                          f32(v_loss.contiguous().reshape(1)), ctx.w[0], ctx.w[1], f32(v_img), capi.stream()), "l1_dssim_bwd")
+        return v_img, None, None, None
+
+
+def l1_dssim_loss(render_color, gt_color, rgb_weight=0.8, dssim_weight=0.2):
+    """k_rgb_weight * loss::rgb_loss + k_dssim_weight * loss::dssim_loss on [H,W,3] images (neural_mapping.cpp:237-240,
+    weights config/base.yaml:35-36), one fused HIP kernel each way."""
+    if render_color.dim() != 3 or render_color.shape[2] != 3 or render_color.shape != gt_color.shape:
+        raise RuntimeError("l1_dssim_loss: expected two [H,W,3] images")
+    return _L1DSSIM.apply(render_color, gt_color, rgb_weight, dssim_weight)
+
+
 @torch.no_grad()
 def distCUDA2(points):
     """simple-knn's distCUDA2 (neural_gaussian.cpp:314): mean squared distance to the 3 nearest neighbours, [N,3] -> [N]."""

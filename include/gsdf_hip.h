@@ -212,6 +212,21 @@ int gsdf_adam_step(int64_t n, int n_segments, const int64_t *seg_begin_host, con
                    const float *grads, float *exp_avg, float *exp_avg_sq, float beta1, float beta2, float eps,
                    int64_t step, gsdf_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * O2  fused photometric loss  L = w_l1 * mean|I-G| + w_ssim * (1 - mean SSIM(I,G))  on [H,W,3] images:
+ *     loss::rgb_loss + loss::dssim_loss (include/optimizer/loss/loss.cpp:22-47) with loss_utils::ssim
+ *     (include/optimizer/loss_utils/loss_utils.cpp:71-117; 11-tap window of loss_utils.cpp:6-14 passed by the host,
+ *     zero padding 5, C1 = 0.01^2, C2 = 0.03^2), called at include/neural_mapping/neural_mapping.cpp:237-240.
+ * fwd: sums[2] (device) = { sum |I-G|, sum SSIM } over the 3*H*W pixel-channels; maps [3,H,W,3] (device, may be
+ *      NULL for evaluation) keeps dSSIM/d(mu1, E[x^2], E[xy]) for the backward.
+ * bwd: v_img [H,W,3] = dL/dI given the upstream scalar gradient v_loss (device pointer).
+ * ---------------------------------------------------------------------------------------- */
+int gsdf_l1_dssim_fwd(int height, int width, const float *img, const float *gt, const float *window11_host,
+                      float *sums, float *maps, gsdf_stream_t stream);
+int gsdf_l1_dssim_bwd(int height, int width, const float *img, const float *gt, const float *window11_host,
+                      const float *maps, const float *v_loss, float w_l1, float w_ssim, float *v_img,
+                      gsdf_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

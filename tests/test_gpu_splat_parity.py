@@ -265,3 +265,53 @@ def test_render_post_matches_reference_formulas(ops):
     for a, b, nm in zip(g1, g2, ("v_colors", "v_depths", "v_alphas", "v_normals")):
         b = torch.where(covered.bool().expand_as(b), b, torch.zeros_like(b)) if nm in ("v_depths", "v_alphas") else b
         assert_close(a, b.nan_to_num(), 1e-5, nm)
+
+
+def test_long_tile_lists_cfg4_like_shape(ops):
+    """BASELINE.json configs[4]-like shape (FAST-LIVO2: 640x512, SH degree 3, millions of splats -> tile lists of
+    several thousand entries, many LDS batches per tile): finite outputs, sorted bins, adjoint identity."""
+    dev = torch.device("cuda:0")
+    N, W, H, deg = 1_000_000, 640, 512, 3
+    sc = synth.make_scene(N, W, H, sh_degree=deg, seed=4, sigma_px=(0.5, 3.0))
+    vm = synth.make_views(2, seed=9)[1:]
+    means, quats, scales, opac, sh, vmd, Kd = _inputs(sc, vm, dev)
+    leaves = [x.requires_grad_(True) for x in (means, quats, scales, opac, sh)]
+    colors, alphas, meta = ops.rasterization_2dgs_sdf(*leaves, vmd, Kd, W, H, near_plane=0.05, far_plane=300.0, sh_degree=deg)
+    I, T = meta["flatten_ids"].numel(), meta["isect_offsets"].numel()
+    assert I / T > 1500, f"mean list length {I / T:.0f} too short for this test"
+    g = torch.Generator().manual_seed(1)
+    vC = torch.randn(1, H, W, 4, generator=g).to(dev)
+    ((colors * vC).sum() + alphas.sum()).backward()
+    for x in leaves:
+        assert x.grad is not None and torch.isfinite(x.grad).all()
+    assert torch.isfinite(colors).all() and float(alphas.max()) < 1.0
+    # compositing is linear in the colours: sum_g c_g . dL/dc_g == sum_pix C . dL/dC  (SH degree 3 colours are affine
+    # in the coefficients, so the identity is checked on the rasteriser inputs)
+    cam, gid, radii, m2d, depths, rt, nrm, smp, sw = ops.fully_fused_projection_2dgs(means.detach(), quats.detach(), scales.detach(), vmd, Kd, W, H, 0.05, 300.0, 0.0)
+    col = ops.get_view_colors(vmd, means.detach(), radii, sh.detach(), cam, gid, deg).requires_grad_(True)
+    dens = torch.zeros_like(m2d, requires_grad=True)
+    rc = ops.rasterize_to_pixels_2dgs(m2d, rt, col, opac.detach()[gid], nrm, dens, W, H, 16, meta["isect_offsets"], meta["flatten_ids"])[0]
+    (rc * vC[..., :3]).sum().backward()
+    lhs = float((col.detach().double() * col.grad.double()).sum()); rhs = float((rc.detach().double() * vC[..., :3].double()).sum())
+    assert abs(lhs - rhs) <= 1e-4 * float((rc.detach().abs().double() * vC[..., :3].abs().double()).sum())
+
+
+@pytest.mark.parametrize("H,W", [(64, 64), (77, 130), (540, 960)])
+def test_fused_l1_dssim_loss_matches_reference_formulas(ops, H, W):
+    """Fused HIP loss vs the torch-fp64 transcription of the reference's own libtorch formulas (oracle/image_loss_ref.py)."""
+    from oracle import image_loss_ref as ref
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(H)
+    img = torch.rand(H, W, 3, generator=g) * 1.2 - 0.1         # renders are not clamped in training
+    gt = torch.rand(H, W, 3, generator=g)
+    a = img.to(dev).requires_grad_(True)
+    loss = ops.l1_dssim_loss(a, gt.to(dev), 0.8, 0.2)
+    (loss * 3.0).backward()
+    b = img.double().requires_grad_(True)
+    loss_ref = ref.l1_dssim_loss(b, gt.double(), 0.8, 0.2)
+    (loss_ref * 3.0).backward()
+    assert abs(float(loss) - float(loss_ref)) <= 1e-5 * abs(float(loss_ref))
+    assert_close(a.grad, b.grad, 1e-4, "dL/dimage")
+    assert abs(sum(ops.ssim_window()) - 1.0) < 1e-12 and ops.ssim_window()[0] != ops.ssim_window()[-1]   # asymmetric quirk kept
+    with torch.no_grad():
+        assert abs(float(ops.l1_dssim_loss(a.detach(), gt.to(dev))) - float(loss_ref)) <= 1e-5 * abs(float(loss_ref))
