@@ -42,6 +42,8 @@ _SIGS = {
     "gsdf_mlp_bwd": (C.c_int, [_i64, _i32] + [_vp] * 11),
     "gsdf_l1_dssim_fwd": (C.c_int, [_i32, _i32] + [_vp] * 6),
     "gsdf_l1_dssim_bwd": (C.c_int, [_i32, _i32] + [_vp] * 5 + [_f32, _f32, _vp, _vp]),
+    "gsdf_normal_consistency_fwd": (C.c_int, [_i32, _i32] + [_vp] * 7),
+    "gsdf_normal_consistency_bwd": (C.c_int, [_i32, _i32] + [_vp] * 9),
     "gsdf_adam_step": (C.c_int, [_i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _f32, _i64, _vp]),
     "gsdf_knn_ws_bytes": (_sz, [_i64]),
     "gsdf_knn_mean_dist2": (C.c_int, [_i64] + [_vp] * 4),

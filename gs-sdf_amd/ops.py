@@ -319,6 +319,42 @@ def l1_dssim_loss(render_color, gt_color, rgb_weight=0.8, dssim_weight=0.2):
     return _L1DSSIM.apply(render_color, gt_color, rgb_weight, dssim_weight)
 
 
+class _NormalConsistency(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, depth, alpha, render_normal, intr, pose):
+        import ctypes as C
+        L = capi.lib()
+        depth, alpha, rn = depth.contiguous(), alpha.detach().contiguous(), render_normal.contiguous()
+        H, W = depth.shape[0], depth.shape[1]
+        ci, cp = (C.c_float * 4)(*intr), (C.c_float * 12)(*pose)
+        loss = torch.empty(1, dtype=torch.float32, device=depth.device)
+        capi.check(_timed("normal_consistency_fwd", L.gsdf_normal_consistency_fwd, H, W, ci, cp, f32(depth, "depth"), f32(alpha),
+                          f32(rn), f32(loss), capi.stream()), "normal_consistency_fwd")
+        ctx.save_for_backward(depth, alpha, rn)
+        ctx.cam = (intr, pose)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, v_loss):
+        import ctypes as C
+        L = capi.lib()
+        depth, alpha, rn = ctx.saved_tensors
+        H, W = depth.shape[0], depth.shape[1]
+        ci, cp = (C.c_float * 4)(*ctx.cam[0]), (C.c_float * 12)(*ctx.cam[1])
+        v_depth, v_rn = torch.empty_like(depth), torch.empty_like(rn)
+        capi.check(_timed("normal_consistency_bwd", L.gsdf_normal_consistency_bwd, H, W, ci, cp, f32(depth), f32(alpha), f32(rn),
+                          f32(v_loss.contiguous().reshape(1)), f32(v_depth), f32(v_rn), capi.stream()), "normal_consistency_bwd")
+        return v_depth, None, v_rn, None, None
+
+
+def normal_consistency_loss(depth, alpha, render_normal, fx, fy, cx, cy, pose_cam2world):
+    """mean(alpha^2 - nan_to_num((depth_to_normal(depth) * alpha) . render_normal)) with alpha detached
+    (neural_mapping.cpp:243-266; cameras.hpp:176-226).  depth, alpha [H,W,1]; render_normal [H,W,3] (world);
+    pose_cam2world [3,4] (host values are baked into the launch)."""
+    pose = [float(v) for v in pose_cam2world.detach().cpu().reshape(-1)[:12]]
+    return _NormalConsistency.apply(depth, alpha, render_normal, (float(fx), float(fy), float(cx), float(cy)), tuple(pose))
+
+
 @torch.no_grad()
 def distCUDA2(points):
     """simple-knn's distCUDA2 (neural_gaussian.cpp:314): mean squared distance to the 3 nearest neighbours, [N,3] -> [N]."""

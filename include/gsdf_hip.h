@@ -227,6 +227,21 @@ int gsdf_l1_dssim_bwd(int height, int width, const float *img, const float *gt, 
                       const float *maps, const float *v_loss, float w_l1, float w_ssim, float *v_img,
                       gsdf_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * O3  fused depth->normal + normal-consistency loss
+ *     sensor::depth_to_normal (include/utils/sensor_utils/cameras.hpp:176-226) and
+ *     normal_error = mean(alpha^2 - nan_to_num((n_depth * alpha) . render_normal)) (include/neural_mapping/neural_mapping.cpp:243-266).
+ * intrinsics4_host = {fx, fy, cx, cy}, pose_c2w_host = row-major [3,4] camera->world (HOST arrays);
+ * depth [H,W,1], alpha [H,W,1] (treated as constant, the reference detaches it), render_normal [H,W,3] (world).
+ * fwd: loss[1] (device).  bwd: v_depth [H,W,1], v_render_normal [H,W,3] given the upstream scalar v_loss (device).
+ * ---------------------------------------------------------------------------------------- */
+int gsdf_normal_consistency_fwd(int height, int width, const float *intrinsics4_host, const float *pose_c2w_host,
+                                const float *depth, const float *alpha, const float *render_normal, float *loss,
+                                gsdf_stream_t stream);
+int gsdf_normal_consistency_bwd(int height, int width, const float *intrinsics4_host, const float *pose_c2w_host,
+                                const float *depth, const float *alpha, const float *render_normal, const float *v_loss,
+                                float *v_depth, float *v_render_normal, gsdf_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -29,3 +29,25 @@ def l1_dssim_loss(render, gt, rgb_weight=0.8, dssim_weight=0.2):
     rgb = (render - gt).abs().mean()
     dssim = 1.0 - ssim(render.permute(2, 0, 1)[None], gt.permute(2, 0, 1)[None])
     return rgb_weight * rgb + dssim_weight * dssim
+
+
+def depth_to_normal(fx, fy, cx, cy, pose, depth):
+    """sensor::depth_to_normal, /root/reference/include/utils/sensor_utils/cameras.hpp:15-29 (zdir, pixel offset 0.5),
+    :176-226 (back-projection, central differences, cross product, zero border)."""
+    H, W = depth.shape[0], depth.shape[1]
+    v, u = torch.meshgrid(torch.arange(H, dtype=depth.dtype) + 0.5, torch.arange(W, dtype=depth.dtype) + 0.5, indexing="ij")
+    zdir = torch.stack([(u - cx) / fx, (v - cy) / fy, torch.ones_like(u)], -1)
+    rot, pos = pose[:, :3], pose[:, 3]
+    pts = zdir @ rot.t() * depth + pos
+    out = torch.zeros_like(pts)
+    dx = pts[2:, 1:-1] - pts[:-2, 1:-1]
+    dy = pts[1:-1, 2:] - pts[1:-1, :-2]
+    out[1:-1, 1:-1] = torch.nn.functional.normalize(torch.cross(dx, dy, dim=-1), dim=-1)
+    return out
+
+
+def normal_consistency_loss(fx, fy, cx, cy, pose, depth, alpha, render_normal):
+    """/root/reference/include/neural_mapping/neural_mapping.cpp:243-266"""
+    a = alpha.detach()
+    dn = depth_to_normal(fx, fy, cx, cy, pose, depth) * a
+    return (a.square().squeeze(-1) - (dn * render_normal).sum(-1).nan_to_num()).mean()

@@ -315,3 +315,29 @@ def test_fused_l1_dssim_loss_matches_reference_formulas(ops, H, W):
     assert abs(sum(ops.ssim_window()) - 1.0) < 1e-12 and ops.ssim_window()[0] != ops.ssim_window()[-1]   # asymmetric quirk kept
     with torch.no_grad():
         assert abs(float(ops.l1_dssim_loss(a.detach(), gt.to(dev))) - float(loss_ref)) <= 1e-5 * abs(float(loss_ref))
+
+
+@pytest.mark.parametrize("H,W", [(48, 64), (37, 53), (272, 480)])
+def test_fused_normal_consistency_loss(ops, H, W):
+    """Fused depth->normal + consistency loss vs the torch-fp64 transcription of cameras.hpp:176-226 /
+    neural_mapping.cpp:243-266 (oracle/image_loss_ref.py), forward and both gradients."""
+    from oracle import image_loss_ref as ref
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(W)
+    yy, xx = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(W, dtype=torch.float32), indexing="ij")
+    depth = (3.0 + 0.01 * xx + 0.02 * yy + 0.3 * torch.sin(xx / 7.0) + 0.05 * torch.rand(H, W, generator=g))[..., None]
+    alpha = torch.rand(H, W, 1, generator=g)
+    rn = torch.nn.functional.normalize(torch.randn(H, W, 3, generator=g), dim=-1)
+    pose = torch.linalg.inv(synth.make_views(3, seed=1)[2])[:3, :4].contiguous()
+    fx, fy, cx, cy = 0.8 * W, 0.75 * W, (W - 1) / 2.0, (H - 1) / 2.0
+    d1, r1 = depth.to(dev).requires_grad_(True), rn.to(dev).requires_grad_(True)
+    loss = ops.normal_consistency_loss(d1, alpha.to(dev), r1, fx, fy, cx, cy, pose)
+    (2.0 * loss).backward()
+    d2, r2 = depth.double().requires_grad_(True), rn.double().requires_grad_(True)
+    lref = ref.normal_consistency_loss(fx, fy, cx, cy, pose.double(), d2, alpha.double(), r2)
+    (2.0 * lref).backward()
+    assert abs(float(loss) - float(lref)) <= 1e-5 * max(abs(float(lref)), 1e-3)
+    # the depth normal is a cross product of DIFFERENCES of fp32 back-projected points (|P| ~ 5, |dP| ~ 1e-2): the
+    # cancellation costs ~2.5 digits in any fp32 evaluation (the reference's libtorch ops included), hence 1e-3 here
+    assert_close(r1.grad, r2.grad, 1e-3, "dL/d render_normal")
+    assert_close(d1.grad, d2.grad, 1e-3, "dL/d depth")
