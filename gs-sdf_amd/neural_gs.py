@@ -371,3 +371,55 @@ def init_gs_with_sdf(local_map, xyzs, mesh_res, init_opa=False, batch_size=50 * 
     if init_opa:
         out["opacity"] = opa
     return out
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# gs.ply checkpoint (3DGS-compatible binary PLY): NeuralGS::export_gs_to_ply / load_ply_to_gs, neural_gaussian.cpp:928-1188
+# ------------------------------------------------------------------------------------------------------------------
+def export_gs_to_ply(gs, path):
+    """vertex properties (float32, binary little endian): x y z, f_dc_*, f_rest_* (channel-major, transpose(1,2).flatten(1)),
+    opacity (logit), scale_0..2 (log; the third is log(1e-6) for 3DGS viewers), rot_0..3 (w,x,y,z)."""
+    import numpy as np
+    xyz = gs.get_xyz().detach().cpu().float().numpy()
+    n = xyz.shape[0]
+    f_dc = gs.features_dc_.detach().transpose(1, 2).flatten(1).cpu().float().numpy()
+    f_rest = gs.features_rest_.detach().transpose(1, 2).flatten(1).cpu().float().numpy() if gs.cfg.sh_degree > 0 else np.zeros((n, 0), np.float32)
+    opa = gs.opacity_.detach().cpu().float().numpy().reshape(n, 1)
+    scale = gs.scaling_.detach().cpu().float().numpy().copy()
+    scale[:, 2] = math.log(1e-6)
+    rot = gs.quaternion_.detach().cpu().float().numpy()
+    names = (["x", "y", "z"] + [f"f_dc_{i}" for i in range(f_dc.shape[1])] + [f"f_rest_{i}" for i in range(f_rest.shape[1])]
+             + ["opacity", "scale_0", "scale_1", "scale_2", "rot_0", "rot_1", "rot_2", "rot_3"])
+    data = np.concatenate([xyz, f_dc, f_rest, opa, scale, rot], 1).astype("<f4")
+    header = "ply\nformat binary_little_endian 1.0\nelement vertex %d\n" % n + "".join(f"property float {k}\n" for k in names) + "end_header\n"
+    with open(path, "wb") as f:
+        f.write(header.encode("ascii"))
+        f.write(data.tobytes())
+
+
+def load_ply_to_gs(path, cfg=None, device="cpu", spatial_scale=1.0):
+    """Inverse of export_gs_to_ply (anchors = xyz, offsets = 0, as the reference's loader does)."""
+    import numpy as np
+    with open(path, "rb") as f:
+        names, n = [], 0
+        while True:
+            line = f.readline().decode("ascii").strip()
+            if line.startswith("element vertex"):
+                n = int(line.split()[-1])
+            elif line.startswith("property float"):
+                names.append(line.split()[-1])
+            elif line.startswith("format") and "binary_little_endian" not in line:
+                raise RuntimeError("load_ply_to_gs: only binary_little_endian PLY is supported")
+            elif line == "end_header":
+                break
+        data = np.frombuffer(f.read(n * len(names) * 4), dtype="<f4").reshape(n, len(names))
+    col = {k: i for i, k in enumerate(names)}
+    t = lambda keys: torch.from_numpy(np.ascontiguousarray(data[:, [col[k] for k in keys]])).to(device)
+    n_dc = sum(k.startswith("f_dc_") for k in names)
+    n_rest = sum(k.startswith("f_rest_") for k in names)
+    f_dc = t([f"f_dc_{i}" for i in range(n_dc)]).reshape(n, 3, -1).transpose(1, 2).contiguous()
+    f_rest = (t([f"f_rest_{i}" for i in range(n_rest)]).reshape(n, 3, -1).transpose(1, 2).contiguous() if n_rest
+              else torch.zeros(n, 0, 3, device=device))
+    cfg = cfg or GSConfig(sh_degree=int(round(math.sqrt(1 + n_rest // 3))) - 1)
+    return NeuralGS(t(["x", "y", "z"]), t(["scale_0", "scale_1", "scale_2"]), t(["rot_0", "rot_1", "rot_2", "rot_3"]),
+                    t(["opacity"]).reshape(-1), f_dc, f_rest, cfg, spatial_scale)

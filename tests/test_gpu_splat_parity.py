@@ -4,6 +4,8 @@
 Bar (BASELINE.json north_star): tile/bin index tensors BIT-EXACT; floating outputs and gradients
 within 1e-4 relative (fp32; see tests/util.py for the precise statement).
 """
+import math
+
 import numpy as np
 import pytest
 import torch
@@ -341,3 +343,49 @@ def test_fused_normal_consistency_loss(ops, H, W):
     # cancellation costs ~2.5 digits in any fp32 evaluation (the reference's libtorch ops included), hence 1e-3 here
     assert_close(r1.grad, r2.grad, 1e-3, "dL/d render_normal")
     assert_close(d1.grad, d2.grad, 1e-3, "dL/d depth")
+
+
+def test_pathological_splats_keep_parity(ops, oracle):
+    """Huge, edge-on and near-plane splats (hyperbolic screen conics, radii of thousands of pixels, opacity at the
+    1/255 threshold): the per-quadrant culling mask must stay conservative and the affine-z evaluation accurate."""
+    dev = torch.device("cuda:0")
+    W, H, N = 160, 112, 1500
+    g = torch.Generator().manual_seed(12)
+    sc = synth.make_scene(N, W, H, sh_degree=0, seed=12, sigma_px=(0.3, 2.0))
+    sc["log_scales"][:300] += math.log(60.0)                            # enormous splats
+    sc["means"][300:600, 2] = 0.06 + 0.3 * torch.rand(300, generator=g)  # just behind the near plane (0.05)
+    sc["means"][300:600, :2] *= 0.02
+    q = sc["quats"]
+    q[600:900] = torch.tensor([0.7071, 0.7071, 0.0, 0.0]) + 0.01 * torch.randn(300, 4, generator=g)   # nearly edge-on
+    sc["logit_opacities"][900:1200] = torch.logit(torch.full((300,), 1.0 / 255.0) + 0.002 * torch.rand(300, generator=g))
+    vm = synth.make_views(2, seed=3)[1:]
+    means, quats, scales, opac, sh, vmd, Kd = _inputs(sc, vm, dev)
+    p = oracle.projection_2dgs_fwd(n(means), n(quats), n(scales), n(vm), n(Kd), W, H, prec="f32")
+    col = oracle.view_colors_fwd(n(vm), n(means), n(sh), p["camera_ids"], p["gaussian_ids"], 0, prec="f32")
+    opa = n(opac)[p["gaussian_ids"]]
+    tpg, ids, flat, offs = oracle.tile_encode(W, H, 16, p["means2d"], p["radii"], p["depths"], p["camera_ids"], 1)
+    out = ops.fully_fused_projection_2dgs(means, quats, scales, vmd, Kd, W, H, 0.05, 300.0, 0.0)
+    assert_equal_int(out[2], p["radii"], "radii"); assert_equal_int(out[1], p["gaussian_ids"], "gaussian_ids")
+    tpg_g, flat_g, offs_g = ops.tile_encode(W, H, 16, out[3], out[2], out[4], True, 1, out[0], out[1])
+    assert_equal_int(flat_g, flat, "flatten_ids"); assert_equal_int(offs_g, offs, "isect_offsets")
+    assert int(p["radii"].max()) > 1000 and flat.shape[0] > 20 * offs.size
+    ug = synth.upstream_grads(H, W, seed=2)
+    ref = {}
+    for prec in ("f32", "f64"):
+        fw = oracle.rasterize_2dgs_fwd(p["means2d"], p["ray_transforms"], col, opa, p["normals"], W, H, 16, offs, flat, prec=prec)
+        gr = oracle.rasterize_2dgs_bwd(p["means2d"], p["ray_transforms"], col, opa, p["normals"], W, H, 16, offs, flat,
+                                       fw["render_alphas"], fw["last_ids"], fw["median_ids"], n(ug["v_render_colors"]),
+                                       n(ug["v_render_depths"]), n(ug["v_render_alphas"]), n(ug["v_render_normals"]),
+                                       n(ug["v_render_median"]), prec=prec)
+        ref[prec] = {**fw, **gr}
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev).requires_grad_(True)
+    a = [t(p["means2d"]), t(p["ray_transforms"]), t(col), t(opa), t(p["normals"])]
+    dens = torch.zeros_like(a[0], requires_grad=True)
+    rc, rd, ra, rn, _, rm, vis = ops.rasterize_to_pixels_2dgs(a[0], a[1], a[2], a[3], a[4], dens, W, H, 16, torch.from_numpy(offs).to(dev),
+                                                             torch.from_numpy(flat).to(dev))
+    chk = lambda got, key: assert_parity(got, ref["f64"][key], ref["f32"][key], REL, key)
+    chk(rc, "render_colors"); chk(ra, "render_alphas"); chk(rn, "render_normals"); chk(rd, "render_depths"); chk(vis, "visibilities")
+    loss = sum((o * ug[k].to(dev)).sum() for o, k in ((rc, "v_render_colors"), (rd, "v_render_depths"), (ra, "v_render_alphas"),
+                                                      (rn, "v_render_normals"), (rm, "v_render_median")))
+    loss.backward()
+    chk(a[2].grad, "v_colors"); chk(a[3].grad, "v_opacities"); chk(a[1].grad, "v_ray_transforms"); chk(dens.grad, "v_densify")

@@ -128,3 +128,24 @@ def test_ray_sampler():
     keep = lambda p: p[:, 0] > 0
     x2, s2, r2 = sample_rays(o, d, depth, 0.02, 0.06, 3, 3, inrange=keep, generator=g)
     assert bool((x2[:, 0] > 0).all()) and x2.shape[0] < R * 7
+
+
+def test_ply_checkpoint_round_trip(tmp_path):
+    from gs_sdf_amd.neural_gs import export_gs_to_ply, load_ply_to_gs
+    g = torch.Generator().manual_seed(5)
+    n = 37
+    gs = NeuralGS(torch.randn(n, 3, generator=g), torch.randn(n, 3, generator=g), torch.randn(n, 4, generator=g),
+                  torch.randn(n, generator=g), torch.rand(n, 1, 3, generator=g), torch.randn(n, 15, 3, generator=g), GSConfig(sh_degree=3))
+    with torch.no_grad():
+        gs.offsets_ += 0.1
+    p = tmp_path / "gs.ply"
+    export_gs_to_ply(gs, p)
+    head = open(p, "rb").read(2000).split(b"end_header")[0].decode()
+    assert "format binary_little_endian 1.0" in head and f"element vertex {n}" in head
+    assert head.count("property float") == 3 + 3 + 45 + 1 + 3 + 4           # 3DGS layout
+    gs2 = load_ply_to_gs(p)
+    assert gs2.cfg.sh_degree == 3
+    assert torch.allclose(gs2.get_xyz(), gs.get_xyz()) and torch.equal(gs2.quaternion_, gs.quaternion_)
+    assert torch.equal(gs2.features_dc_, gs.features_dc_) and torch.equal(gs2.features_rest_, gs.features_rest_)
+    assert torch.equal(gs2.opacity_, gs.opacity_) and torch.equal(gs2.scaling_[:, :2], gs.scaling_[:, :2])
+    assert torch.allclose(gs2.scaling_[:, 2], torch.full((n,), math.log(1e-6)))
