@@ -37,6 +37,10 @@ def main():
     ap.add_argument("--workload", default="cfg3_1M_1080p", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sdf", action="store_true", help="splat path only (no hash-grid SDF leg)")
+    ap.add_argument("--scatter-xcds", type=int, default=2, help="XCDs reserved for the hash-grid backward (overlap mode)")
+    ap.add_argument("--dump-grads", default=None, help="test hook: run ONE step without the optimizer update, save the flat "
+                                                        "gradient buffers to this file and exit")
+    ap.add_argument("--no-overlap", action="store_true", help="issue the SDF leg on the same HIP stream as the splat leg")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -62,7 +66,7 @@ def main():
 
     import gs_sdf_amd.ops as ops
     import gs_sdf_amd.synth as synth
-    from gs_sdf_amd.trainer import FusedAdam, SplatParams, ViewParallel
+    from gs_sdf_amd.trainer import FusedAdam, GradGate, SplatParams, ViewParallel
 
     N, W, H, deg, replica = WORKLOADS[args.workload]
     sc = synth.make_scene(N, W, H, sh_degree=deg, seed=0, replica=replica)
@@ -92,48 +96,97 @@ def main():
 
     sizes = {}
 
-    def step(i):
+    # Two HIP streams: the SDF leg (hash grid + MLP; bound by the memory-side fp32 atomic units) runs beside the splat
+    # leg (rasteriser; bound by VALU issue).  The legs are the reference's own two loss groups (neural_mapping.cpp:138-188
+    # and :420-462 against :195-300); they meet only where the gradient of the splat sample points enters the projection
+    # backward (trainer.join_grad).  --no-overlap issues the identical work on one stream.
+    # The hash-grid scatter (backward) kernel gets XCDs of its own (default 2 of 8) and both legs stay off them: beside
+    # it, any kernel that shares an XCD with it finishes only when it does (gs_sdf_amd/streams.py has the measurements).
+    overlap = not args.no_sdf and not args.no_overlap
+    main = torch.cuda.current_stream()
+    side = main
+    if overlap:
+        from gs_sdf_amd.streams import xcd_partition_streams
+        (main, side), lm.encoder.scatter_stream = xcd_partition_streams(args.scatter_xcds, 2)
+        main.wait_stream(torch.cuda.current_stream())
+        torch.cuda.set_stream(main)
+    gate = GradGate()
+
+    host = [] if os.environ.get("GSDF_BENCH_HOST_TIMES") else None   # debugging aid: host-side issue times per segment
+
+    def stamp(tag):
+        if host is not None:
+            host.append((tag, time.perf_counter()))
+
+    def step(i, update=True):
+        stamp("begin")
         view = views[(i * world + rank) % views.shape[0]][None]
         vp.zero_grad()
+        begin = main.record_event()
+        if not args.no_sdf:
+            # per-ray SDF batch (neural_mapping.cpp:138-188): BCE on the SDF head + eikonal on the numerical gradient.
+            # Independent of the render: forward and backward on the side stream, beside projection / binning / compositing.
+            side.wait_event(begin)                        # parameters of step i-1 are final, gradients are zeroed
+            with torch.cuda.stream(side):
+                pts, tgt = pool[i % 8], ray_sdf[i % 8]
+                lm.ray_loss(pts, tgt, 0.02, 0.1).backward()
+        stamp("ray leg issued")
         xyz, quat, scales, opacity, sh = params.activated()
         colors, alphas, meta = ops.rasterization_2dgs_sdf(xyz, quat, scales, opacity, sh, view, K, W, H, near_plane=0.05,
-                                                          far_plane=300.0, sh_degree=deg, center_reg=True)
-        # colour: the reference's photometric loss 0.8 L1 + 0.2 D-SSIM (neural_mapping.cpp:237-240), fused HIP kernel;
-        # depth / alpha / normal / median: op-level N(0,1) upstream gradients so that every backward path is live
-        loss = (ops.l1_dssim_loss(colors[0, ..., :3], target, 0.8, 0.2) + 1e-6 * (colors[..., 3:] * ug["v_render_depths"]).sum()
-                + 1e-6 * ((alphas * ug["v_render_alphas"]).sum() + (meta["render_normal"] * ug["v_render_normals"]).sum()
-                          + (meta["render_median"] * ug["v_render_median"]).sum()))
+                                                          far_plane=300.0, sh_degree=deg, center_reg=True, samples_gate=gate)
         if not args.no_sdf:
-            # per-ray SDF batch (neural_mapping.cpp:138-188): BCE on the SDF head + eikonal on the numerical gradient
-            pts, tgt = pool[i % 8], ray_sdf[i % 8]
-            s_pred, isig = lm.get_sdf(pts)
-            loss_sdf = sdfm.sdf_loss(s_pred, tgt, isig)
-            grad = lm.get_gradient(pts, 0.02, s_pred, False, True)[0]
-            loss_sdf = loss_sdf + 0.1 * sdfm.eikonal_loss(grad)
-            # GS <-> SDF coupling (neural_mapping.cpp:420-462): SDF at the visible splats' samples
+            # GS <-> SDF coupling (neural_mapping.cpp:420-462): SDF at the visible splats' samples.  This leg is the
+            # step's critical path (compositing -> visible set -> encoder -> decoder -> scatter), so it is issued first.
+            stamp("render issued (2 syncs)")
             vis = meta["visibilities"].detach()
             w_all = (meta["samples_weights"] * vis).detach()
             ids = (vis > 0.1).squeeze(-1).nonzero().squeeze(-1)
-            samples_cut = meta["samples"].detach().requires_grad_(True)      # graph cut: same maths, two backward legs
-            if ids.numel() > 0:
-                gs_sdf = lm.get_sdf(samples_cut.index_select(0, ids))[0]
-                loss_sdf = loss_sdf + 1e-3 * sdfm.gs_sdf_loss(gs_sdf, w_all.index_select(0, ids))
+            stamp("visible set (sync)")
+            fwd_done = main.record_event()
+            samples = meta["samples"]                                 # already behind join_grad(gate)
+            samples_cut = samples.detach().requires_grad_(True)      # graph cut: same maths, two backward legs
             sizes.update(n_gs_sdf=int(ids.numel()))
-            # leg 1: everything that touches the SDF network; its gradients are final afterwards, so their all-reduce
-            # (61 MB table + MLP) is started now and overlaps with the splat backward below
-            loss_sdf.backward()
-            vp.all_reduce_group_async(groups[0])
+            side.wait_event(fwd_done)
+            with torch.cuda.stream(side):
+                if ids.numel() > 0:
+                    gs_sdf = lm.get_sdf(samples_cut.index_select(0, ids))[0]
+                    (1e-3 * sdfm.gs_sdf_loss(gs_sdf, w_all.index_select(0, ids))).backward()
+                # the SDF network's gradients are final: their all-reduce (61 MB table + MLP) starts now and overlaps
+                # with the splat backward below
+                vp.all_reduce_group_async(groups[0])
+                gate.event = side.record_event() if side is not main else None
+            stamp("samples leg issued")
+        # colour: the reference's photometric loss 0.8 L1 + 0.2 D-SSIM (neural_mapping.cpp:237-240), fused HIP kernel;
+        # depth / alpha / normal / median: op-level N(0,1) upstream gradients so that every backward path is live
+        loss = (ops.l1_dssim_loss(meta["color"][0], target, 0.8, 0.2) + 1e-6 * (meta["depth"] * ug["v_render_depths"]).sum()
+                + 1e-6 * ((alphas * ug["v_render_alphas"]).sum() + (meta["render_normal"] * ug["v_render_normals"]).sum()
+                          + (meta["render_median"] * ug["v_render_median"]).sum()))
+        stamp("loss issued")
+        if not args.no_sdf:
             if samples_cut.grad is not None:
-                torch.autograd.backward([loss, meta["samples"]], [None, samples_cut.grad])
+                torch.autograd.backward([loss, samples], [None, samples_cut.grad])
             else:
                 loss.backward()
+            main.wait_stream(side)
         else:
             loss.backward()
+        stamp("backward issued")
         vp.all_reduce_group_async(params)
         vp.finish()
-        adam.step()
+        if update:
+            adam.step()
+        stamp("adam issued")
         sizes.update(M=int(meta["gaussian_ids"].shape[0]), I=int(meta["flatten_ids"].shape[0]))
 
+    if args.dump_grads:
+        step(0, update=False)
+        torch.cuda.synchronize()
+        if rank == 0:
+            torch.save({"splat": params.flat_grad.cpu(), "sdf": [g.flat_grad.cpu() for g in groups], "sizes": dict(sizes)},
+                       args.dump_grads)
+        if dist is not None:
+            dist.destroy_process_group()
+        return
     for i in range(args.warmup):
         step(i)
     torch.cuda.synchronize()
@@ -141,6 +194,8 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     ops.TIMERS.enable()
+    if host is not None:
+        host.clear()
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(args.warmup + i)
@@ -149,6 +204,14 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    if host is not None and rank == 0:
+        import collections
+        acc, n = collections.OrderedDict(), 0
+        for (ta, a), (tb, b) in zip(host[:-1], host[1:]):
+            if tb != "begin":
+                acc[tb] = acc.get(tb, 0.0) + (b - a)
+            n += tb == "adam issued"
+        print("host ms/step: " + ", ".join(f"{k} {v / n * 1e3:.2f}" for k, v in acc.items()), file=sys.stderr, flush=True)
     kern = ops.TIMERS.summary_ms()
     calls = ops.TIMERS.calls()
     ops.TIMERS.disable()
@@ -166,8 +229,8 @@ def main():
         alg = {"rasterize_2dgs_bwd": 80 * I + 48 * P + 88 * M, "rasterize_2dgs_fwd": 80 * I + 48 * P}
         if not args.no_sdf:
             # S1 per query point: fwd 12 + 1024 (16 levels x 8 corners x 8 B) + 128; bwd 8 + 128 + 1024 scatter; averaged
-            # over the launches of a step (32768 ray points, 6 x 32768 stencil points, the visible splat samples)
-            pts = (7 * 32768 + sizes.get("n_gs_sdf", 0)) / 3.0
+            # over the launches of a step (7 x 32768 ray + stencil points in one launch, the visible splat samples in another)
+            pts = (7 * 32768 + sizes.get("n_gs_sdf", 0)) / max(1.0, calls.get("hashgrid_bwd", 0) / args.steps)
             alg["hashgrid_bwd"] = int(1160 * pts)
             alg["hashgrid_fwd"] = int(1164 * pts)
         per_step = {k: kern.get(k, 0.0) * calls.get(k, 0) / args.steps for k in alg}

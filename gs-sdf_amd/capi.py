@@ -31,8 +31,8 @@ _SIGS = {
     "gsdf_rasterize_2dgs_fwd": (C.c_int, [_i64, _i64, _i64, _i32, _i32, _i32] + [_vp] * 18),
     "gsdf_rasterize_2dgs_bwd_ws_bytes": (_sz, [_i64]),
     "gsdf_rasterize_2dgs_bwd": (C.c_int, [_i64, _i64, _i64, _i32, _i32, _i32] + [_vp] * 26),
-    "gsdf_render_post_fwd": (C.c_int, [_i64, _i32] + [_vp] * 8),
-    "gsdf_render_post_bwd": (C.c_int, [_i64, _i32] + [_vp] * 10),
+    "gsdf_render_post_fwd": (C.c_int, [_i64, _i32] + [_vp] * 10),
+    "gsdf_render_post_bwd": (C.c_int, [_i64, _i32] + [_vp] * 12),
     "gsdf_hashgrid_offsets": (_i64, [_i32, _i32, _i32, _i32, _f32, _vp]),
     "gsdf_hashgrid_fwd": (C.c_int, [_i64, _i32, _i32, _i32, _i32, _f32] + [_vp] * 4),
     "gsdf_hashgrid_bwd": (C.c_int, [_i64, _i32, _i32, _i32, _i32, _f32] + [_vp] * 6),
@@ -44,6 +44,8 @@ _SIGS = {
     "gsdf_l1_dssim_bwd": (C.c_int, [_i32, _i32] + [_vp] * 5 + [_f32, _f32, _vp, _vp]),
     "gsdf_normal_consistency_fwd": (C.c_int, [_i32, _i32] + [_vp] * 7),
     "gsdf_normal_consistency_bwd": (C.c_int, [_i32, _i32] + [_vp] * 9),
+    "gsdf_sdf_query_points": (C.c_int, [_i64, _i32, _vp, _f32, _vp, _f32, _vp, _vp]),
+    "gsdf_sdf_ray_loss": (C.c_int, [_i64, _i32, _vp, _i32, _vp, _f32, _f32, _f32, _vp, _vp, _vp]),
     "gsdf_adam_step": (C.c_int, [_i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _f32, _i64, _vp]),
     "gsdf_knn_ws_bytes": (_sz, [_i64]),
     "gsdf_knn_mean_dist2": (C.c_int, [_i64] + [_vp] * 4),

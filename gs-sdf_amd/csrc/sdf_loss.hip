@@ -1,0 +1,115 @@
+// sdf_loss.hip — S3: the per-ray SDF batch's two elementwise ends, fused.
+//   query points: world points (+ the 6 central-difference stencil points of LocalMap::get_gradient,
+//                 /root/reference/include/neural_net/local_map.cpp:110-131) -> unit-cube encoder inputs
+//                 (SubMap::xyz_to_zp1_pts, /root/reference/include/neural_net/sub_map.cpp:82-97)
+//   ray loss:     loss::sdf_loss (BCE with logits against the sigmoid-squashed target, isigma clamped at 5e2) on the
+//                 base points + w_eik * loss::eikonal_loss of the numerical gradient
+//                 (/root/reference/include/optimizer/loss.cpp:49-83; isigma = 1 + softplus(raw, beta 100) * bce_isigma,
+//                 local_map.cpp:87-103), value AND gradient w.r.t. the decoder output in one pass.
+// In the reference these are ~50 eager libtorch kernels forward and as many backward; they are pure launch latency.
+#include "common.h"
+
+namespace gsdf {
+
+__global__ void __launch_bounds__(256)
+    sdf_query_points_kernel(int64_t n, int K, const float *__restrict__ xyz, float delta, float px, float py, float pz,
+                            float inv, float *__restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n * K) return;
+  const int64_t k = i / n, j = i - k * n;  // row 0..n-1: base points; then stencil-major (+x,-x,+y,-y,+z,-z)
+  float x[3] = {xyz[3 * j], xyz[3 * j + 1], xyz[3 * j + 2]};
+  if (k > 0) {
+    const int axis = (int)(k - 1) >> 1;
+    x[axis] = x[axis] + (((k - 1) & 1) ? -delta : delta);
+  }
+  const float p[3] = {px, py, pz};
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const float m = ((x[c] - p[c]) * 2.0f) * inv;  // scale_to_m1p1
+    out[3 * i + c] = 0.5f * m + 0.5f;
+  }
+}
+
+__device__ __forceinline__ float sigmoidf(float x) { return 1.0f / (1.0f + __expf(-x)); }
+
+__global__ void __launch_bounds__(256)
+    sdf_ray_loss_kernel(int64_t n, int stencil, const float *__restrict__ attr, int ld, const float *__restrict__ gt,
+                        float bce_isigma, float delta, float w_eik, float *__restrict__ loss,
+                        float *__restrict__ v_attr) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  float contrib = 0.f;
+  if (i < n) {
+    const float inv_n = 1.0f / (float)n;
+    const float s = attr[i * ld], raw = attr[i * ld + 1], g = gt[i];
+    // isigma = min(1 + softplus(raw, beta = 100, threshold = 20) * bce_isigma, 500)
+    const float br = 100.0f * raw;
+    const float sp = br > 20.0f ? raw : log1pf(expf(br)) * 0.01f;
+    const float dsp = br > 20.0f ? 1.0f : sigmoidf(br);
+    const float is0 = 1.0f + sp * bce_isigma;
+    const float is = fminf(is0, 500.0f);
+    const float dis_draw = is0 <= 500.0f ? dsp * bce_isigma : 0.0f;
+    const float x = -s * is, u = -g * is;
+    const float t0 = sigmoidf(u);
+    const float t = fminf(fmaxf(t0, 1e-7f), 1.0f - 1e-7f);
+    const float dt_du = (t0 >= 1e-7f && t0 <= 1.0f - 1e-7f) ? t0 * (1.0f - t0) : 0.0f;
+    // bce = (1 - t) x + softplus(-x)
+    const float bce = (1.0f - t) * x + fmaxf(-x, 0.0f) + log1pf(expf(-fabsf(x)));
+    const float dx = sigmoidf(x) - t, dt = -x;
+    const float d_is = dx * (-s) + dt * dt_du * (-g);
+    contrib = bce * inv_n;
+    v_attr[i * ld] = dx * (-is) * inv_n;
+    v_attr[i * ld + 1] = d_is * dis_draw * inv_n;
+    for (int c = 2; c < ld; ++c) v_attr[i * ld + c] = 0.f;
+    if (stencil) {
+      float ps[6];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) ps[k] = attr[(n + k * n + i) * ld];
+      const float h = 0.5f * (1.0f / delta);
+      const float gx = h * (ps[0] - ps[1]), gy = h * (ps[2] - ps[3]), gz = h * (ps[4] - ps[5]);
+      const float nrm = sqrtf(gx * gx + gy * gy + gz * gz);
+      const float e = nrm - 1.0f;
+      contrib += w_eik * e * e * inv_n;
+      const float k0 = nrm > 0.f ? w_eik * 2.0f * e / nrm * h * inv_n : 0.f;  // torch's norm backward: 0 at the origin
+      const float d[3] = {k0 * gx, k0 * gy, k0 * gz};
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        const int64_t r = (n + k * n + i) * ld;
+        v_attr[r] = (k & 1) ? -d[k >> 1] : d[k >> 1];
+        for (int c = 1; c < ld; ++c) v_attr[r + c] = 0.f;
+      }
+    }
+  }
+  // block sum -> one atomic per wave
+  const float ws = wave_sum_to_lane63(contrib);
+  if ((threadIdx.x & 63) == 63 && ws != 0.f) atomicAdd(loss, ws);
+}
+
+}  // namespace gsdf
+
+using namespace gsdf;
+
+extern "C" int gsdf_sdf_query_points(int64_t n, int stencil, const float *xyz, float delta, const float *origin_host,
+                                     float map_size_inv, float *out, gsdf_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  GSDF_REQUIRE(n >= 0 && origin_host, "sdf_query_points: bad arguments");
+  if (n == 0) return GSDF_OK;
+  GSDF_REQUIRE(xyz && out, "sdf_query_points: null buffer");
+  const int K = stencil ? 7 : 1;
+  sdf_query_points_kernel<<<(unsigned)((n * K + 255) / 256), 256, 0, stream>>>(n, K, xyz, delta, origin_host[0],
+                                                                                origin_host[1], origin_host[2],
+                                                                                map_size_inv, out);
+  GSDF_CHECK_LAUNCH("sdf_query_points_kernel");
+  return GSDF_OK;
+}
+
+extern "C" int gsdf_sdf_ray_loss(int64_t n, int stencil, const float *attr, int ld, const float *gt_sdf, float bce_isigma,
+                                 float delta, float w_eik, float *loss, float *v_attr, gsdf_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  GSDF_REQUIRE(n > 0 && ld >= 2 && attr && gt_sdf && loss && v_attr, "sdf_ray_loss: bad arguments");
+  GSDF_REQUIRE(!stencil || delta > 0.f, "sdf_ray_loss: delta must be positive");
+  GSDF_HIP(hipMemsetAsync(loss, 0, 4, stream), "sdf_ray_loss memset");
+  sdf_ray_loss_kernel<<<(unsigned)((n + 255) / 256), 256, 0, stream>>>(n, stencil, attr, ld, gt_sdf, bce_isigma, delta,
+                                                                       w_eik, loss, v_attr);
+  GSDF_CHECK_LAUNCH("sdf_ray_loss_kernel");
+  return GSDF_OK;
+}

@@ -110,7 +110,7 @@ class NeuralGS:
         renders, alphas, info = ops.rasterization_2dgs_sdf(
             xyz, quat, scales, opacity, sh, w2c.contiguous(), K, camera.width, camera.height, "RGB+ED", self.cfg.near, self.cfg.far,
             0.0, self.sh_degree_to_use_, True, 16, None, False, self.cfg.use_absgrad, False, self.cfg.center_reg, sample_seed)
-        color, depth = renders[..., 0:3][0], renders[..., 3:4][0]
+        color, depth = info.pop("color")[0], info.pop("depth")[0]     # = renders[...,0:3][0], renders[...,3:4][0]
         out = {}
         if bck_color == 2:
             out["color"] = color + (1.0 - alphas[0]) * torch.rand(camera.height, camera.width, 3, device=dev)

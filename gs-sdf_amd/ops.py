@@ -371,7 +371,9 @@ def distCUDA2(points):
 
 
 class _RenderPost(torch.autograd.Function):
-    """Fused per-pixel epilogue (neural_gaussian.cpp:229-240): depth/alpha + nan_to_num, cat, normals to world."""
+    """Fused per-pixel epilogue (neural_gaussian.cpp:229-240): depth/alpha + nan_to_num, cat, normals to world.
+    Also emits the two slices NeuralGS::render takes of the result (colour [.,3], depth [.,1], :533-543) so that callers
+    need no slicing kernels (and no zero-fill + add in their backward)."""
 
     @staticmethod
     def forward(ctx, rc, rd, ra, rn, viewmats, expected_depth):
@@ -379,25 +381,25 @@ class _RenderPost(torch.autograd.Function):
         rc, rd, ra, rn, viewmats = rc.contiguous(), rd.contiguous(), ra.contiguous(), rn.contiguous(), viewmats.contiguous()
         n_pix = ra.numel()
         renders = torch.empty(*ra.shape[:-1], 4, dtype=torch.float32, device=ra.device)
-        nw = torch.empty_like(rn)
+        nw, color3, depth1 = torch.empty_like(rn), torch.empty_like(rc), torch.empty_like(rd)
         capi.check(_timed("render_post_fwd", L.gsdf_render_post_fwd, n_pix, int(expected_depth), f32(viewmats), f32(rc),
-                          f32(rd), f32(ra), f32(rn), f32(renders), f32(nw), capi.stream()), "render_post_fwd")
+                          f32(rd), f32(ra), f32(rn), f32(renders), f32(nw), f32(color3), f32(depth1), capi.stream()),
+                   "render_post_fwd")
         ctx.save_for_backward(rd, ra, viewmats)
         ctx.expected_depth = int(expected_depth)
-        return renders, nw
+        return renders, nw, color3, depth1
 
     @staticmethod
-    def backward(ctx, v_renders, v_nw):
+    def backward(ctx, v_renders, v_nw, v_c3, v_d1):
         L = capi.lib()
         rd, ra, viewmats = ctx.saved_tensors
         n_pix = ra.numel()
-        v_renders = torch.zeros(*ra.shape[:-1], 4, device=ra.device) if v_renders is None else v_renders.contiguous()
-        v_nw = torch.zeros(*ra.shape[:-1], 3, device=ra.device) if v_nw is None else v_nw.contiguous()
+        c = lambda g: None if g is None else g.contiguous()
         v_rc, v_rn = torch.empty(*ra.shape[:-1], 3, device=ra.device), torch.empty(*ra.shape[:-1], 3, device=ra.device)
         v_rd, v_ra = torch.empty_like(ra), torch.empty_like(ra)
         capi.check(_timed("render_post_bwd", L.gsdf_render_post_bwd, n_pix, ctx.expected_depth, f32(viewmats), f32(rd),
-                          f32(ra), f32(v_renders), f32(v_nw), f32(v_rc), f32(v_rd), f32(v_ra), f32(v_rn), capi.stream()),
-                   "render_post_bwd")
+                          f32(ra), f32(c(v_renders)), f32(c(v_nw)), f32(c(v_c3)), f32(c(v_d1)), f32(v_rc), f32(v_rd), f32(v_ra),
+                          f32(v_rn), capi.stream()), "render_post_bwd")
         return v_rc, v_rd, v_ra, v_rn, None, None
 
 
@@ -424,8 +426,11 @@ class _GatherRows(torch.autograd.Function):
 def rasterization_2dgs_sdf(means, quats, scales, opacities, colors, viewmats, Ks, width, height, render_mode="RGB+ED",
                            near_plane=0.01, far_plane=1e10, radius_clip=0.0, sh_degree=None, packed=True, tile_size=16,
                            backgrounds=None, sparse_grad=False, absgrad=False, distloss=False, center_reg=False,
-                           sample_seed=0):
-    """Mirror of the reference's `rasterization_2dgs_sdf` -> (render_colors [C,H,W,4], render_alphas, meta)."""
+                           sample_seed=0, samples_gate=None):
+    """Mirror of the reference's `rasterization_2dgs_sdf` -> (render_colors [C,H,W,4], render_alphas, meta).
+    `samples_gate` (a trainer.GradGate, not in the reference): meta["samples"] passes through trainer.join_grad HERE, i.e.
+    before the binning / compositing nodes are created, so that in the backward pass its gradient is consumed (and the
+    gate's event waited for) only after the compositing backward has been issued."""
     if render_mode not in ("RGB", "D", "ED", "RGB+D", "RGB+ED"):
         raise RuntimeError("Invalid render_mode")
     N, C = means.shape[0], viewmats.shape[0]
@@ -435,6 +440,11 @@ def rasterization_2dgs_sdf(means, quats, scales, opacities, colors, viewmats, Ks
      samples_weights) = fully_fused_projection_2dgs(means, quats, scales, viewmats, Ks, width, height, near_plane,
                                                     far_plane, radius_clip, packed, sparse_grad,
                                                     0 if center_reg else sample_seed)
+    if center_reg:
+        samples, samples_weights = means.index_select(0, gaussian_ids), torch.ones_like(samples_weights)
+    if samples_gate is not None:
+        from .trainer import join_grad
+        samples = join_grad(samples, samples_gate)
     pt_opacities = _GatherRows.apply(opacities, gaussian_ids)
     pt_colors = get_view_colors(viewmats, means, radii, colors, camera_ids, gaussian_ids, sh_degree)
     tiles_per_gauss, flatten_ids, isect_offsets = tile_encode(width, height, tile_size, means2d, radii, depths, packed,
@@ -449,15 +459,13 @@ def rasterization_2dgs_sdf(means, quats, scales, opacities, colors, viewmats, Ks
     if absgrad:
         meta["absgrad"] = means2d_absgrad
     # neural_gaussian.cpp:229-240 in one fused pass: expected depth, cat(colours, depth), normals to world space
-    render_colors, render_normals = _RenderPost.apply(render_colors, render_depths, render_alphas, render_normals,
-                                                      viewmats, render_mode in ("ED", "RGB+ED"))
+    render_colors, render_normals, color3, depth1 = _RenderPost.apply(render_colors, render_depths, render_alphas,
+                                                                      render_normals, viewmats, render_mode in ("ED", "RGB+ED"))
+    meta.update(color=color3, depth=depth1)      # the slices renders[...,0:3] / [...,3:4] of neural_gaussian.cpp:533-543
     meta.update(render_normal=render_normals, render_median=render_median, normal=normals, gaussian_ids=gaussian_ids,
                 radii=radii, gradient_2dgs=densify, width=torch.tensor([width]), height=torch.tensor([height]),
                 n_cameras=torch.tensor([C]), samples=samples, samples_weights=samples_weights,
                 samples_opacities=pt_opacities, visibilities=visibilities,
                 # extras (not in the reference's meta): sizes that fix the roofline byte count
                 tiles_per_gauss=tiles_per_gauss, flatten_ids=flatten_ids, isect_offsets=isect_offsets)
-    if center_reg:
-        meta["samples"] = means.index_select(0, gaussian_ids)
-        meta["samples_weights"] = torch.ones_like(samples_weights)
     return render_colors, render_alphas, meta

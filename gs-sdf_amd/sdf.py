@@ -17,6 +17,7 @@ import torch
 from . import capi
 from .capi import f32, ptr
 from .ops import _timed
+from .streams import launch_on
 
 GRID_DEFAULT = dict(otype="Grid", type="Hash", n_levels=16, n_features_per_level=2, log2_hashmap_size=19,
                     base_resolution=32, per_level_scale=2.0, interpolation="Linear")
@@ -32,7 +33,7 @@ class _GridBwd(torch.autograd.Function):
     grad-of-grad (eikonal on the analytic SDF gradient) works."""
 
     @staticmethod
-    def forward(ctx, v_feat, x, table, cfg, want_table, grad_sink=None):
+    def forward(ctx, v_feat, x, table, cfg, want_table, grad_sink=None, scatter_stream=None):
         L = capi.lib()
         B = x.shape[0]
         v_feat = v_feat.contiguous()
@@ -41,16 +42,18 @@ class _GridBwd(torch.autograd.Function):
             # accumulate straight into the parameter's (pre-zeroed) gradient buffer: the kernel's atomics already
             # ACCUMULATE, so the 61 MB zero-fill + the autograd add per call disappear; autograd sees no table grad
             v_table, want_table = grad_sink.view(table.shape), False
-            capi.check(_timed("hashgrid_bwd", L.gsdf_hashgrid_bwd, B, *cfg, f32(x), f32(table), f32(v_feat), f32(v_table),
-                              f32(v_x), capi.stream()), "hashgrid_bwd")
+            capi.check(launch_on(scatter_stream, lambda: _timed(
+                "hashgrid_bwd", L.gsdf_hashgrid_bwd, B, *cfg, f32(x), f32(table), f32(v_feat), f32(v_table), f32(v_x),
+                capi.stream())), "hashgrid_bwd")
             ctx.save_for_backward(v_feat, x, table)
             ctx.cfg = cfg
             v_table = torch.zeros(0, device=x.device)
             ctx.mark_non_differentiable(v_table)
             return v_x, v_table
         v_table = torch.zeros_like(table) if want_table else None
-        capi.check(_timed("hashgrid_bwd", L.gsdf_hashgrid_bwd, B, *cfg, f32(x), f32(table), f32(v_feat), f32(v_table),
-                          f32(v_x), capi.stream()), "hashgrid_bwd")
+        capi.check(launch_on(scatter_stream, lambda: _timed(
+            "hashgrid_bwd", L.gsdf_hashgrid_bwd, B, *cfg, f32(x), f32(table), f32(v_feat), f32(v_table), f32(v_x),
+            capi.stream())), "hashgrid_bwd")
         ctx.save_for_backward(v_feat, x, table)
         ctx.cfg = cfg
         if v_table is None:
@@ -66,18 +69,18 @@ class _GridBwd(torch.autograd.Function):
         B = x.shape[0]
         need_vf, need_x, need_t = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2]
         if vv_x is None:
-            return None, None, None, None, None, None
+            return None, None, None, None, None, None, None
         g_vfeat = torch.empty_like(v_feat) if need_vf else None
         g_x = torch.empty_like(x) if need_x else None
         g_table = torch.zeros_like(table) if need_t else None
         capi.check(_timed("hashgrid_bwd_bwd", L.gsdf_hashgrid_bwd_bwd, B, *ctx.cfg, f32(x), f32(table), f32(v_feat),
                           f32(vv_x.contiguous()), f32(g_vfeat), f32(g_table), f32(g_x), capi.stream()), "hashgrid_bwd_bwd")
-        return g_vfeat, g_x, g_table, None, None, None
+        return g_vfeat, g_x, g_table, None, None, None, None
 
 
 class _GridFwd(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, table, cfg, grad_sink=None):
+    def forward(ctx, x, table, cfg, grad_sink=None, scatter_stream=None):
         L = capi.lib()
         x, table = x.contiguous(), table.contiguous()
         B = x.shape[0]
@@ -86,15 +89,16 @@ class _GridFwd(torch.autograd.Function):
                           capi.stream()), "hashgrid_fwd")
         ctx.save_for_backward(x, table)
         ctx.cfg = cfg
-        ctx.grad_sink = grad_sink
+        ctx.grad_sink, ctx.scatter_stream = grad_sink, scatter_stream
         return feat
 
     @staticmethod
     def backward(ctx, v_feat):
         x, table = ctx.saved_tensors
-        v_x, v_table = _GridBwd.apply(v_feat, x, table, ctx.cfg, bool(ctx.needs_input_grad[1]), ctx.grad_sink)
+        v_x, v_table = _GridBwd.apply(v_feat, x, table, ctx.cfg, bool(ctx.needs_input_grad[1]), ctx.grad_sink,
+                                      ctx.scatter_stream)
         want_t = ctx.needs_input_grad[1] and ctx.grad_sink is None
-        return (v_x if ctx.needs_input_grad[0] else None), (v_table if want_t else None), None, None
+        return (v_x if ctx.needs_input_grad[0] else None), (v_table if want_t else None), None, None, None
 
 
 class TCNNEncoding:
@@ -121,6 +125,9 @@ class TCNNEncoding:
         # optional: a pre-zeroed buffer shaped like params_ into which the table gradient is accumulated IN PLACE
         # (first order only) instead of being returned to autograd; set by LocalMap.flatten() for the trainer
         self.grad_sink = None
+        # optional: a CU-masked HIP stream (streams.cu_masked_stream) for the scatter (backward) kernel, so that the
+        # atomic-bound kernel does not clog the memory pipelines of the CUs another stream is computing on
+        self.scatter_stream = None
 
     def get_out_dim(self):
         return self.cfg[0] * self.cfg[1]
@@ -128,7 +135,7 @@ class TCNNEncoding:
     def forward(self, x):
         if x.dim() != 2 or x.shape[1] != 3:
             raise RuntimeError("TCNNEncoding.forward: expected [B,3]")
-        return _GridFwd.apply(x, self.params_.view(-1, self.cfg[1]), self.cfg, self.grad_sink)
+        return _GridFwd.apply(x, self.params_.view(-1, self.cfg[1]), self.cfg, self.grad_sink, self.scatter_stream)
 
     __call__ = forward
 
@@ -194,6 +201,50 @@ class TCNNNetwork:
     __call__ = forward
 
 
+class _QueryPoints(torch.autograd.Function):
+    """world points -> unit-cube encoder inputs (+ the 6 central-difference stencil points), one launch
+    (include/gsdf_hip.h: gsdf_sdf_query_points).  The backward is a plain (twice differentiable) torch expression."""
+
+    @staticmethod
+    def forward(ctx, xyz, origin, map_size_inv, delta):
+        xyz = xyz.contiguous()
+        n, K = xyz.shape[0], (1 if delta is None else 7)
+        out = torch.empty(K * n, 3, dtype=torch.float32, device=xyz.device)
+        org = (C.c_float * 3)(*origin)
+        capi.check(_timed("sdf_query_points", capi.lib().gsdf_sdf_query_points, n, int(K == 7), f32(xyz),
+                          float(delta or 0.0), org, float(map_size_inv), f32(out), capi.stream()), "sdf_query_points")
+        ctx.n, ctx.K, ctx.c = n, K, float(map_size_inv)
+        return out
+
+    @staticmethod
+    def backward(ctx, v):
+        g = v if ctx.K == 1 else v.view(ctx.K, ctx.n, 3).sum(0)
+        return g * ctx.c, None, None, None                  # d out / d xyz = 0.5 * 2 * map_size_inv
+
+
+class _SdfRayLoss(torch.autograd.Function):
+    """loss::sdf_loss + w_eik * loss::eikonal_loss of the numerical gradient, value and gradient in one launch
+    (include/gsdf_hip.h: gsdf_sdf_ray_loss)."""
+
+    @staticmethod
+    def forward(ctx, attr, gt_sdf, bce_isigma, delta, w_eik, n):
+        attr, gt_sdf = attr.contiguous(), gt_sdf.contiguous()
+        stencil = attr.shape[0] == 7 * n
+        assert stencil or attr.shape[0] == n
+        loss = torch.empty((), dtype=torch.float32, device=attr.device)
+        v_attr = torch.empty_like(attr)
+        capi.check(_timed("sdf_ray_loss", capi.lib().gsdf_sdf_ray_loss, n, int(stencil), f32(attr), attr.shape[1],
+                          f32(gt_sdf), float(bce_isigma), float(delta or 0.0), float(w_eik), f32(loss), f32(v_attr),
+                          capi.stream()), "sdf_ray_loss")
+        ctx.save_for_backward(v_attr)
+        return loss
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, v_loss):
+        return ctx.saved_tensors[0] * v_loss, None, None, None, None, None
+
+
 class LocalMap:
     """The SDF half of the reference's `LocalMap` (include/neural_net/local_map.{h,cpp}): hash-grid encoder +
     decoder, `get_sdf`, `get_gradient` (numerical 6-point stencil or analytic via autograd)."""
@@ -202,6 +253,7 @@ class LocalMap:
                  device="cuda", seed=0, encoding_config=None):
         self.pos_W_M = torch.as_tensor(map_origin, dtype=torch.float32, device=device).reshape(1, 3)
         self.map_size_inv = 1.0 / float(map_size)
+        self._origin = [float(v) for v in map_origin]
         self.bce_isigma = 1.0 / float(bce_sigma)
         self.encoder = TCNNEncoding(3, encoding_config, "encoder_local_map", device, seed)
         feat = self.encoder.get_out_dim()
@@ -248,8 +300,19 @@ class LocalMap:
     def xyz_to_zp1_pts(self, xyz):                 # sub_map.cpp:82-97
         return 0.5 * ((xyz - self.pos_W_M) * (2.0 * self.map_size_inv)) + 0.5
 
+    def query_points(self, xyz, delta=None):
+        """xyz_to_zp1_pts (bit-identical) in one launch; with `delta` also the 6 stencil points of get_gradient:
+        rows [0,n) base, then (+x,-x,+y,-y,+z,-z) x n."""
+        return _QueryPoints.apply(xyz, self._origin, self.map_size_inv, delta)
+
     def get_feat(self, xyz, normalized=False):
-        return self.encoder.forward(xyz if normalized else self.xyz_to_zp1_pts(xyz))
+        return self.encoder.forward(xyz if normalized else self.query_points(xyz))
+
+    def ray_loss(self, xyz, gt_sdf, delta, w_eik):
+        """sdf_loss(get_sdf(xyz)) + w_eik * eikonal_loss(get_gradient(xyz, delta, numerical)) of the per-ray batch
+        (neural_mapping.cpp:138-188) as ONE encoder launch, ONE decoder launch and ONE loss launch over the 7n points."""
+        attr = self.decoder(self.encoder.forward(self.query_points(xyz, delta)))
+        return _SdfRayLoss.apply(attr, gt_sdf, self.bce_isigma, delta, w_eik, xyz.shape[0])
 
     def get_sdf(self, xyz):
         """-> [sdf [B,1], isigma [B,1]]  (local_map.cpp:87-103)"""

@@ -94,6 +94,36 @@ class ViewParallel:
             g.flat_grad.mul_(1.0 / self.world)
 
 
+class GradGate:
+    """Carries the HIP event that marks 'the gradient that flows in here is complete' from the stream that
+    produces it to the stream that consumes it (see join_grad)."""
+
+    def __init__(self):
+        self.event = None
+
+
+class _JoinGrad(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gate):
+        ctx.gate = gate
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        if ctx.gate.event is not None:
+            torch.cuda.current_stream().wait_event(ctx.gate.event)     # device-side wait, the host does not block
+            ctx.gate.event = None
+        return g, None
+
+
+def join_grad(x, gate):
+    """Identity on `x`.  In the backward pass the stream that consumes x's gradient first waits (on the device) for
+    `gate.event`.  Used to run the SDF leg of a training step (hash grid + MLP, bound by the memory-side atomic units) on
+    a second HIP stream concurrently with the splat rasteriser (bound by VALU issue): the two legs only meet where the
+    gradient of the splat sample points enters the projection backward, and this node sits exactly there."""
+    return _JoinGrad.apply(x, gate)
+
+
 def flatten_leaves(tensors):
     """Re-homes a list of leaf parameters into ONE flat buffer (+ one flat gradient buffer) and returns
     (flat, flat_grad, views).  The views replace the original leaves (same values, same shapes)."""

@@ -149,10 +149,13 @@ int gsdf_rasterize_2dgs_bwd(int64_t n_cams, int64_t n_visible, int64_t n_isects,
  * ---------------------------------------------------------------------------------------- */
 int gsdf_render_post_fwd(int64_t n_pix, int expected_depth, const float *viewmat0, const float *render_colors,
                          const float *render_depths, const float *render_alphas, const float *render_normals,
-                         float *renders, float *normals_world, gsdf_stream_t stream);
+                         float *renders, float *normals_world, float *color3 /*[n,3] or NULL*/,
+                         float *depth1 /*[n,1] or NULL: the two slices the caller takes of `renders`, :533-543*/,
+                         gsdf_stream_t stream);
+/* any of the four upstream gradients may be NULL (treated as zero) */
 int gsdf_render_post_bwd(int64_t n_pix, int expected_depth, const float *viewmat0, const float *render_depths,
                          const float *render_alphas, const float *v_renders, const float *v_normals_world,
-                         float *v_render_colors, float *v_render_depths, float *v_render_alphas,
+                         const float *v_color3, const float *v_depth1, float *v_render_colors, float *v_render_depths, float *v_render_alphas,
                          float *v_render_normals, gsdf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
@@ -211,6 +214,23 @@ int gsdf_knn_mean_dist2(int64_t n_points, const float *points, float *out, void 
 int gsdf_adam_step(int64_t n, int n_segments, const int64_t *seg_begin_host, const float *seg_lr_host, float *params,
                    const float *grads, float *exp_avg, float *exp_avg_sq, float beta1, float beta2, float eps,
                    int64_t step, gsdf_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * S3  the per-ray SDF batch's elementwise ends (replace ~100 eager libtorch kernels per step):
+ *   gsdf_sdf_query_points: world points -> unit-cube encoder inputs, out = 0.5*(((x - origin)*2)*map_size_inv) + 0.5
+ *     (SubMap::xyz_to_zp1_pts, include/neural_net/sub_map.cpp:82-97); with stencil != 0 the output holds 7n rows: the n
+ *     base points, then the 6 central-difference points x +/- delta e_axis of LocalMap::get_gradient in its order
+ *     (+x,-x,+y,-y,+z,-z; include/neural_net/local_map.cpp:110-124), each block n rows.  origin_host: 3 HOST floats.
+ *   gsdf_sdf_ray_loss: attr [(stencil?7:1)*n, ld] = decoder output (col 0 sdf, col 1 raw isigma) on those rows.
+ *     loss[0] = mean_n BCEWithLogits(-sdf*is, clamp(sigmoid(-gt*is),1e-7,1-1e-7)),  is = min(1+softplus_100(raw)*bce_isigma, 5e2)
+ *               (loss::sdf_loss, include/optimizer/loss.cpp:49-79; isigma: local_map.cpp:87-103)
+ *             + w_eik * mean_n (|g|-1)^2,  g = (sdf(+d) - sdf(-d)) / (2 delta)   (loss::eikonal_loss, loss.cpp:81-83)
+ *     v_attr [same shape] = d loss[0] / d attr (every column written).
+ * ---------------------------------------------------------------------------------------- */
+int gsdf_sdf_query_points(int64_t n, int stencil, const float *xyz, float delta, const float *origin_host,
+                          float map_size_inv, float *out, gsdf_stream_t stream);
+int gsdf_sdf_ray_loss(int64_t n, int stencil, const float *attr, int ld, const float *gt_sdf, float bce_isigma,
+                      float delta, float w_eik, float *loss, float *v_attr, gsdf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * O2  fused photometric loss  L = w_l1 * mean|I-G| + w_ssim * (1 - mean SSIM(I,G))  on [H,W,3] images:

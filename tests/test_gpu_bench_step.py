@@ -1,0 +1,51 @@
+"""The training step bench.py measures, as a black box: the two-stream / XCD-partitioned issue order must give the same
+gradients as the single-stream order, and the multi-rank control flow must run (2 ranks sharing the one GPU over gloo;
+RCCL itself needs one device per rank, the driver's 8-GPU run covers it)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+from util import assert_close
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench(args, env=None, launcher=()):
+    e = dict(os.environ)
+    e.update(env or {})
+    cmd = [sys.executable, *launcher, os.path.join(ROOT, "bench.py"), *args]
+    r = subprocess.run(cmd, cwd=ROOT, env=e, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    return r.stdout
+
+
+@pytest.mark.parametrize("workload", ["cfg0_10k_256", "cfg1_replica_300k"])
+def test_overlapped_step_gives_the_single_stream_gradients(tmp_path, workload):
+    out = {}
+    for mode, flags in (("serial", ["--no-overlap"]), ("overlap", []), ("overlap3", ["--scatter-xcds", "3"])):
+        path = str(tmp_path / f"{mode}.pt")
+        _bench(["--workload", workload, "--dump-grads", path, *flags])
+        out[mode] = torch.load(path)
+    ref = out["serial"]
+    assert ref["sizes"]["n_gs_sdf"] > 0 and float(ref["splat"].abs().sum()) > 0 and float(ref["sdf"][0].abs().sum()) > 0
+    for mode in ("overlap", "overlap3"):
+        got = out[mode]
+        assert got["sizes"] == ref["sizes"]
+        # identical kernels on identical inputs; only the order of the fp32 atomic accumulations differs
+        assert_close(got["splat"], ref["splat"], 1e-4, f"{mode}: splat gradients")
+        assert_close(got["sdf"][0], ref["sdf"][0], 1e-4, f"{mode}: SDF network gradients")
+
+
+def test_two_ranks_view_parallel_step_runs():
+    launcher = ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                "--master-port", "29531"]
+    txt = _bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--workload", "cfg0_10k_256", "--no-cpu-baseline"],
+                 env={"GSDF_BENCH_BACKEND": "gloo"}, launcher=launcher)
+    line = [l for l in txt.splitlines() if l.startswith("{")][-1]
+    j = json.loads(line)
+    assert j["n_gpus"] == 2 and j["value"] > 0 and j["scaling"] == "weak"

@@ -212,3 +212,76 @@ def test_in_place_table_gradient_accumulation_equals_autograd(sdf):
         grads.append(grp.flat_grad.clone())
     assert float(grads[0].abs().sum()) > 0
     assert_close(grads[1], grads[0], 1e-5, "flat gradient (in-place sink vs autograd)")
+
+
+def test_query_points_bit_identical_to_the_reference_expression(sdf):
+    """gsdf_sdf_query_points == 0.5 * ((xyz - pos) * 2 * map_size_inv) + 0.5 (sub_map.cpp:82-97) bit for bit, and
+    its stencil rows == that expression on xyz[None] + offsets (local_map.cpp:112-124); gradient = torch's."""
+    dev = torch.device("cuda:0")
+    lm = sdf.LocalMap([0.5, -1.0, 0.25], 12.0, decoder_implementation=1, device=dev, seed=2)
+    xyz = ((torch.rand(4099, 3, generator=torch.Generator().manual_seed(1)) - 0.5) * 11.0).to(dev).requires_grad_(True)
+    ref = lambda p: 0.5 * ((p - lm.pos_W_M) * 2 * lm.map_size_inv) + 0.5
+    assert torch.equal(lm.query_points(xyz), ref(xyz)) and torch.equal(lm.query_points(xyz), lm.xyz_to_zp1_pts(xyz))
+    d = 0.013
+    offs = torch.tensor([[d, 0, 0], [-d, 0, 0], [0, d, 0], [0, -d, 0], [0, 0, d], [0, 0, -d]], device=dev)[:, None, :]
+    want = torch.cat([ref(xyz), ref((xyz[None] + offs).view(-1, 3))], 0)
+    got = lm.query_points(xyz, d)
+    assert torch.equal(got, want)
+    v = torch.randn_like(want)
+    assert_close(torch.autograd.grad((got * v).sum(), xyz)[0], torch.autograd.grad((want * v).sum(), xyz)[0], 1e-6, "v_xyz")
+
+
+@pytest.mark.parametrize("n", [1, 777, 32768])
+def test_fused_ray_loss_matches_the_reference_composition(sdf, n):
+    """LocalMap.ray_loss (one encoder / decoder / loss launch over the 7n points) == loss::sdf_loss(get_sdf) +
+    w * loss::eikonal_loss(get_gradient numerical) composed from the mirrored torch expressions (loss.cpp:49-83,
+    local_map.cpp:87-131): value and every parameter gradient."""
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(11)
+    xyz = ((torch.rand(n, 3, generator=g) - 0.5) * 6.0).to(dev)
+    gt = (torch.randn(n, 1, generator=g) * 0.05).to(dev)
+    gt[::5] *= 20.0                                            # some targets saturate the 1e-7 clamp
+    out = []
+    for fused in (False, True):
+        lm = sdf.LocalMap([0.1, 0.2, -0.3], 8.0, bce_sigma=0.02, decoder_implementation=1, device=dev, seed=9)
+        with torch.no_grad():                                  # make the isigma head / its 5e2 clamp live
+            lm.decoder.params_.mul_(4.0)
+        if fused:
+            loss = lm.ray_loss(xyz, gt, 0.02, 0.1)
+        else:
+            s, isig = lm.get_sdf(xyz)
+            loss = sdf.sdf_loss(s, gt, isig) + 0.1 * sdf.eikonal_loss(lm.get_gradient(xyz, 0.02, s, False, True)[0])
+        grads = torch.autograd.grad(loss, lm.parameters())
+        out.append((loss.detach(), grads))
+    assert_close(out[1][0], out[0][0], 1e-5, "ray loss value")
+    for a, b, name in zip(out[1][1], out[0][1], ("table", "mlp")):
+        assert float(b.abs().max()) > 0
+        assert_close(a, b, 2e-4, f"ray loss gradient wrt {name}")
+
+
+def test_fused_ray_loss_elementwise_against_fp64_torch(sdf):
+    """gsdf_sdf_ray_loss alone on synthetic decoder outputs, against the fp64 torch expressions: covers softplus beyond
+    its threshold, the isigma clamp, saturated targets and a zero numerical gradient (norm backward = 0)."""
+    dev = torch.device("cuda:0")
+    n = 5000
+    g = torch.Generator().manual_seed(5)
+    attr = torch.randn(7 * n, 2, generator=g) * torch.tensor([0.2, 0.3])
+    attr[:50, 1] = 0.5                                         # softplus threshold branch, isigma > 5e2 -> clamped
+    attr[n:, 1] = 7.0                                          # stencil rows' raw column must not matter
+    for k in range(6):
+        attr[n + k * n + 100: n + k * n + 110, 0] = 0.25       # zero gradient points
+    gt = torch.randn(n, 1, generator=g) * 0.05
+    gt[:20] = 1.0                                              # sigmoid(-gt*isigma) underflows the 1e-7 clamp
+    a64 = attr.double().requires_grad_(True)
+    s, raw = a64[:n, 0:1], a64[:n, 1:2]
+    isig = (1 + torch.nn.functional.softplus(raw, beta=100) * 50.0)
+    ps = a64[n:, 0:1].view(6, n, 1)
+    grad = 0.5 / 0.02 * torch.cat([ps[0] - ps[1], ps[2] - ps[3], ps[4] - ps[5]], 1)
+    want = sdf.sdf_loss(s, gt.double(), isig) + 0.1 * sdf.eikonal_loss(grad)
+    v_want = torch.autograd.grad(want, a64)[0]
+    a32 = attr.to(dev).requires_grad_(True)
+    got = sdf._SdfRayLoss.apply(a32, gt.to(dev), 50.0, 0.02, 0.1, n)
+    v_got = torch.autograd.grad(got * 3.0, a32)[0]
+    assert_close(got, want.float().to(dev), 1e-5, "loss")
+    assert_close(v_got, 3.0 * v_want.float().to(dev), 1e-4, "d loss / d attr")
+    assert float(v_got[n:, 1].abs().max()) == 0.0

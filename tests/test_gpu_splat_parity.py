@@ -255,14 +255,16 @@ def test_render_post_matches_reference_formulas(ops):
     rd, ra = rd.requires_grad_(True), ra.requires_grad_(True)
     rn = torch.randn(C, H, W, 3, generator=g).to(dev).requires_grad_(True)
     vm = synth.make_views(3, seed=4)[1:].to(dev)
-    out, nw = ops._RenderPost.apply(rc, rd, ra, rn, vm, True)
+    out, nw, c3, d1 = ops._RenderPost.apply(rc, rd, ra, rn, vm, True)
+    assert torch.equal(c3, out[..., :3]) and torch.equal(d1, out[..., 3:])
     ref_d = (rd / ra).nan_to_num()
     ref = torch.cat([rc, ref_d], -1)
     ref_n = rn.matmul(torch.linalg.inv(vm)[0, :3, :3].t())
     assert_close(out, ref, 1e-6, "renders"); assert_close(nw, ref_n, 1e-5, "normals world")
     v1, v2 = torch.randn_like(out), torch.randn_like(nw)
     covered = (ra.detach() > 0).float()
-    g1 = torch.autograd.grad((out * v1).sum() + (nw * v2).sum(), (rc, rd, ra, rn))
+    g1 = torch.autograd.grad((out[..., :2] * v1[..., :2]).sum() + (c3[..., 2:] * v1[..., 2:3]).sum() + (d1 * v1[..., 3:]).sum()
+                             + (nw * v2).sum(), (rc, rd, ra, rn))
     g2 = torch.autograd.grad((ref * v1).sum() + (ref_n * v2).sum(), (rc, rd, ra, rn))
     for a, b, nm in zip(g1, g2, ("v_colors", "v_depths", "v_alphas", "v_normals")):
         b = torch.where(covered.bool().expand_as(b), b, torch.zeros_like(b)) if nm in ("v_depths", "v_alphas") else b
