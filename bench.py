@@ -88,29 +88,40 @@ def main():
     vp = ViewParallel(params, dist, groups)
     # optimizer: fused Adam over the flat buffers, the reference's groups / learning rates (neural_gaussian.cpp:434-453;
     # SDF groups at min(xyz_lr, lr_end) during the joint stage, :619-623), eps 1e-15
-    adam = FusedAdam(eps=1e-15)
+    adam, adam_sdf = FusedAdam(eps=1e-15), FusedAdam(eps=1e-15)       # one per leg: each steps on its leg's stream
     lrs = dict(offsets=1.6e-4, scaling=5e-3, quaternion=1e-3, opacity=5e-2, features_dc=2.5e-3, features_rest=2.5e-3 / 20)
     adam.add_group(params.flat, params.flat_grad, [(params.views[k].numel(), lrs[k]) for k in params.views])
     for gsdf_group in groups:
-        adam.add_group(gsdf_group.flat, gsdf_group.flat_grad, [(gsdf_group.flat.numel(), 1e-4)])
+        adam_sdf.add_group(gsdf_group.flat, gsdf_group.flat_grad, [(gsdf_group.flat.numel(), 1e-4)])
 
     sizes = {}
 
-    # Two HIP streams: the SDF leg (hash grid + MLP; bound by the memory-side fp32 atomic units) runs beside the splat
-    # leg (rasteriser; bound by VALU issue).  The legs are the reference's own two loss groups (neural_mapping.cpp:138-188
-    # and :420-462 against :195-300); they meet only where the gradient of the splat sample points enters the projection
-    # backward (trainer.join_grad).  --no-overlap issues the identical work on one stream.
-    # The hash-grid scatter (backward) kernel gets XCDs of its own (default 2 of 8) and both legs stay off them: beside
-    # it, any kernel that shares an XCD with it finishes only when it does (gs_sdf_amd/streams.py has the measurements).
+    # Two legs on two HIP streams.  The SDF leg (hash grid + MLP; its scatter is bound by the memory-side fp32 atomic units)
+    # runs beside the splat leg (rasteriser; bound by VALU issue).  They are the reference's own loss groups
+    # (neural_mapping.cpp:138-188 and :420-462 against :195-300) and touch in two places only: the visible splats' sample
+    # points go splat -> SDF after compositing, and their gradient comes back SDF -> splat where it enters the projection
+    # backward (trainer.join_grad).  Each leg owns its parameters, gradients and optimizer, so step i+1's splat leg does
+    # not wait for step i's hash-grid scatter.  --no-overlap issues the identical work on one stream.
+    # The hash-grid scatter kernel gets XCDs of its own (default 2 of 8) and both legs stay off them: beside it, any
+    # kernel that shares an XCD with it finishes only when it does (gs_sdf_amd/streams.py has the measurements).
     overlap = not args.no_sdf and not args.no_overlap
     main = torch.cuda.current_stream()
-    side = main
+    side = scatter = main
     if overlap:
         from gs_sdf_amd.streams import xcd_partition_streams
-        (main, side), lm.encoder.scatter_stream = xcd_partition_streams(args.scatter_xcds, 2)
+        (main, side), scatter = xcd_partition_streams(args.scatter_xcds, 2)
+        lm.encoder.scatter_stream = scatter
         main.wait_stream(torch.cuda.current_stream())
         torch.cuda.set_stream(main)
     gate = GradGate()
+
+    def release_streams():
+        if overlap:
+            from gs_sdf_amd.streams import destroy_all
+            torch.cuda.synchronize()
+            lm.encoder.scatter_stream = None
+            torch.cuda.set_stream(torch.cuda.default_stream())
+            destroy_all()
 
     host = [] if os.environ.get("GSDF_BENCH_HOST_TIMES") else None   # debugging aid: host-side issue times per segment
 
@@ -121,12 +132,9 @@ def main():
     def step(i, update=True):
         stamp("begin")
         view = views[(i * world + rank) % views.shape[0]][None]
-        vp.zero_grad()
-        begin = main.record_event()
         if not args.no_sdf:
             # per-ray SDF batch (neural_mapping.cpp:138-188): BCE on the SDF head + eikonal on the numerical gradient.
-            # Independent of the render: forward and backward on the side stream, beside projection / binning / compositing.
-            side.wait_event(begin)                        # parameters of step i-1 are final, gradients are zeroed
+            # Independent of the render: forward and backward beside projection / binning / compositing.
             with torch.cuda.stream(side):
                 pts, tgt = pool[i % 8], ray_sdf[i % 8]
                 lm.ray_loss(pts, tgt, 0.02, 0.1).backward()
@@ -135,8 +143,8 @@ def main():
         colors, alphas, meta = ops.rasterization_2dgs_sdf(xyz, quat, scales, opacity, sh, view, K, W, H, near_plane=0.05,
                                                           far_plane=300.0, sh_degree=deg, center_reg=True, samples_gate=gate)
         if not args.no_sdf:
-            # GS <-> SDF coupling (neural_mapping.cpp:420-462): SDF at the visible splats' samples.  This leg is the
-            # step's critical path (compositing -> visible set -> encoder -> decoder -> scatter), so it is issued first.
+            # GS <-> SDF coupling (neural_mapping.cpp:420-462): SDF at the visible splats' samples.  This is the longest
+            # dependency chain of the step (compositing -> visible set -> encoder -> decoder -> back), so it is issued first.
             stamp("render issued (2 syncs)")
             vis = meta["visibilities"].detach()
             w_all = (meta["samples_weights"] * vis).detach()
@@ -147,14 +155,14 @@ def main():
             samples_cut = samples.detach().requires_grad_(True)      # graph cut: same maths, two backward legs
             sizes.update(n_gs_sdf=int(ids.numel()))
             side.wait_event(fwd_done)
+            if side is not main:
+                for t in (samples_cut, w_all, ids):     # allocated on `main`, read by kernels on `side`: keep the blocks
+                    t.record_stream(side)               # out of main's allocator until side has passed this point
             with torch.cuda.stream(side):
                 if ids.numel() > 0:
-                    gs_sdf = lm.get_sdf(samples_cut.index_select(0, ids))[0]
+                    gs_sdf = lm.get_sdf(samples_cut.index_select(0, ids), with_isigma=False)[0]
                     (1e-3 * sdfm.gs_sdf_loss(gs_sdf, w_all.index_select(0, ids))).backward()
-                # the SDF network's gradients are final: their all-reduce (61 MB table + MLP) starts now and overlaps
-                # with the splat backward below
-                vp.all_reduce_group_async(groups[0])
-                gate.event = side.record_event() if side is not main else None
+                gate.event = side.record_event() if side is not main else None     # d loss / d samples is complete
             stamp("samples leg issued")
         # colour: the reference's photometric loss 0.8 L1 + 0.2 D-SSIM (neural_mapping.cpp:237-240), fused HIP kernel;
         # depth / alpha / normal / median: op-level N(0,1) upstream gradients so that every backward path is live
@@ -162,28 +170,37 @@ def main():
                 + 1e-6 * ((alphas * ug["v_render_alphas"]).sum() + (meta["render_normal"] * ug["v_render_normals"]).sum()
                           + (meta["render_median"] * ug["v_render_median"]).sum()))
         stamp("loss issued")
-        if not args.no_sdf:
-            if samples_cut.grad is not None:
-                torch.autograd.backward([loss, samples], [None, samples_cut.grad])
-            else:
-                loss.backward()
-            main.wait_stream(side)
+        if not args.no_sdf and samples_cut.grad is not None:
+            if side is not main:
+                samples_cut.grad.record_stream(main)    # allocated on `side`, read by the projection backward on `main`
+            torch.autograd.backward([loss, samples], [None, samples_cut.grad])
         else:
             loss.backward()
         stamp("backward issued")
-        vp.all_reduce_group_async(params)
-        vp.finish()
+        vp.all_reduce_group(params)
         if update:
             adam.step()
-        stamp("adam issued")
+            params.flat_grad.zero_()
+        if not args.no_sdf:
+            # the SDF network's gradients are final once the scatter stream has drained: all-reduce (61 MB table + MLP)
+            # and optimizer step of this leg on its own stream, beside the splat leg
+            with torch.cuda.stream(side):
+                side.wait_stream(scatter)
+                vp.all_reduce_group(groups[0])
+                if update:
+                    adam_sdf.step()
+                    groups[0].flat_grad.zero_()
+        stamp("optimizers issued")
         sizes.update(M=int(meta["gaussian_ids"].shape[0]), I=int(meta["flatten_ids"].shape[0]))
 
+    vp.zero_grad()
     if args.dump_grads:
         step(0, update=False)
         torch.cuda.synchronize()
         if rank == 0:
             torch.save({"splat": params.flat_grad.cpu(), "sdf": [g.flat_grad.cpu() for g in groups], "sizes": dict(sizes)},
                        args.dump_grads)
+        release_streams()
         if dist is not None:
             dist.destroy_process_group()
         return
@@ -210,7 +227,7 @@ def main():
         for (ta, a), (tb, b) in zip(host[:-1], host[1:]):
             if tb != "begin":
                 acc[tb] = acc.get(tb, 0.0) + (b - a)
-            n += tb == "adam issued"
+            n += tb == "optimizers issued"
         print("host ms/step: " + ", ".join(f"{k} {v / n * 1e3:.2f}" for k, v in acc.items()), file=sys.stderr, flush=True)
     kern = ops.TIMERS.summary_ms()
     calls = ops.TIMERS.calls()
@@ -262,6 +279,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(sc, views[0:1].cpu(), N, W, H, deg,
                                                0 if args.no_sdf else 7 * 32768 + sizes.get("n_gs_sdf", 0))
         print(json.dumps(out), flush=True)
+    release_streams()
     if dist is not None:
         dist.destroy_process_group()
 

@@ -33,32 +33,46 @@ class _GridBwd(torch.autograd.Function):
     grad-of-grad (eikonal on the analytic SDF gradient) works."""
 
     @staticmethod
-    def forward(ctx, v_feat, x, table, cfg, want_table, grad_sink=None, scatter_stream=None):
+    def forward(ctx, v_feat, x, table, cfg, want_table, grad_sink=None, scatter_stream=None, want_x=True):
         L = capi.lib()
         B = x.shape[0]
         v_feat = v_feat.contiguous()
-        v_x = torch.empty_like(x)
+        v_x = torch.empty_like(x) if want_x else None
+        empty = lambda: torch.zeros(0, device=x.device)
+
+        def launch(vt, vx):
+            capi.check(_timed("hashgrid_bwd" if vt is not None else "hashgrid_bwd_input", L.gsdf_hashgrid_bwd, B, *cfg,
+                              f32(x), f32(table), f32(v_feat), f32(vt), f32(vx), capi.stream()), "hashgrid_bwd")
+
         if want_table and grad_sink is not None:
             # accumulate straight into the parameter's (pre-zeroed) gradient buffer: the kernel's atomics already
             # ACCUMULATE, so the 61 MB zero-fill + the autograd add per call disappear; autograd sees no table grad
-            v_table, want_table = grad_sink.view(table.shape), False
-            capi.check(launch_on(scatter_stream, lambda: _timed(
-                "hashgrid_bwd", L.gsdf_hashgrid_bwd, B, *cfg, f32(x), f32(table), f32(v_feat), f32(v_table), f32(v_x),
-                capi.stream())), "hashgrid_bwd")
-            ctx.save_for_backward(v_feat, x, table)
-            ctx.cfg = cfg
-            v_table = torch.zeros(0, device=x.device)
-            ctx.mark_non_differentiable(v_table)
-            return v_x, v_table
-        v_table = torch.zeros_like(table) if want_table else None
-        capi.check(launch_on(scatter_stream, lambda: _timed(
-            "hashgrid_bwd", L.gsdf_hashgrid_bwd, B, *cfg, f32(x), f32(table), f32(v_feat), f32(v_table), f32(v_x),
-            capi.stream())), "hashgrid_bwd")
+            v_table = grad_sink.view(table.shape)
+            if scatter_stream is None:
+                launch(v_table, v_x)
+            else:
+                # the input gradient (no atomics) here; the scatter (atomics only) ASYNCHRONOUSLY on its own stream:
+                # whoever consumes the table gradient waits for `scatter_stream`
+                if want_x:
+                    launch(None, v_x)
+                scatter_stream.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(scatter_stream):
+                    launch(v_table, None)
+                v_feat.record_stream(scatter_stream)
+                x.record_stream(scatter_stream)
+            v_table = None
+        else:
+            v_table = torch.zeros_like(table) if want_table else None
+            if v_table is not None or v_x is not None:
+                launch_on(scatter_stream, lambda: launch(v_table, v_x))
         ctx.save_for_backward(v_feat, x, table)
         ctx.cfg = cfg
         if v_table is None:
-            v_table = torch.zeros(0, device=x.device)
+            v_table = empty()
             ctx.mark_non_differentiable(v_table)
+        if v_x is None:
+            v_x = empty()
+            ctx.mark_non_differentiable(v_x)
         return v_x, v_table
 
     @staticmethod
@@ -69,13 +83,13 @@ class _GridBwd(torch.autograd.Function):
         B = x.shape[0]
         need_vf, need_x, need_t = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2]
         if vv_x is None:
-            return None, None, None, None, None, None, None
+            return None, None, None, None, None, None, None, None
         g_vfeat = torch.empty_like(v_feat) if need_vf else None
         g_x = torch.empty_like(x) if need_x else None
         g_table = torch.zeros_like(table) if need_t else None
         capi.check(_timed("hashgrid_bwd_bwd", L.gsdf_hashgrid_bwd_bwd, B, *ctx.cfg, f32(x), f32(table), f32(v_feat),
                           f32(vv_x.contiguous()), f32(g_vfeat), f32(g_table), f32(g_x), capi.stream()), "hashgrid_bwd_bwd")
-        return g_vfeat, g_x, g_table, None, None, None, None
+        return g_vfeat, g_x, g_table, None, None, None, None, None
 
 
 class _GridFwd(torch.autograd.Function):
@@ -96,7 +110,7 @@ class _GridFwd(torch.autograd.Function):
     def backward(ctx, v_feat):
         x, table = ctx.saved_tensors
         v_x, v_table = _GridBwd.apply(v_feat, x, table, ctx.cfg, bool(ctx.needs_input_grad[1]), ctx.grad_sink,
-                                      ctx.scatter_stream)
+                                      ctx.scatter_stream, bool(ctx.needs_input_grad[0]))
         want_t = ctx.needs_input_grad[1] and ctx.grad_sink is None
         return (v_x if ctx.needs_input_grad[0] else None), (v_table if want_t else None), None, None, None
 
@@ -125,8 +139,10 @@ class TCNNEncoding:
         # optional: a pre-zeroed buffer shaped like params_ into which the table gradient is accumulated IN PLACE
         # (first order only) instead of being returned to autograd; set by LocalMap.flatten() for the trainer
         self.grad_sink = None
-        # optional: a CU-masked HIP stream (streams.cu_masked_stream) for the scatter (backward) kernel, so that the
-        # atomic-bound kernel does not clog the memory pipelines of the CUs another stream is computing on
+        # optional: a HIP stream on XCDs of its own (streams.xcd_partition_streams) for the scatter (table-gradient)
+        # kernel.  With grad_sink set the scatter is launched there ASYNCHRONOUSLY (the input gradient is computed by a
+        # separate launch on the current stream): the table gradient in grad_sink is complete only once that stream
+        # has been waited for.
         self.scatter_stream = None
 
     def get_out_dim(self):
@@ -314,9 +330,12 @@ class LocalMap:
         attr = self.decoder(self.encoder.forward(self.query_points(xyz, delta)))
         return _SdfRayLoss.apply(attr, gt_sdf, self.bce_isigma, delta, w_eik, xyz.shape[0])
 
-    def get_sdf(self, xyz):
-        """-> [sdf [B,1], isigma [B,1]]  (local_map.cpp:87-103)"""
+    def get_sdf(self, xyz, with_isigma=True):
+        """-> [sdf [B,1], isigma [B,1]]  (local_map.cpp:87-103); with_isigma=False (not in the reference) returns [sdf]
+        only and skips the three elementwise launches of the isigma head for callers that drop it."""
         attr = self.decoder(self.get_feat(xyz))
+        if not with_isigma:
+            return [attr[:, 0:1]]
         sdf, raw = attr[:, 0:1], attr[:, 1:2]
         return [sdf, 1 + torch.nn.functional.softplus(raw, beta=100) * self.bce_isigma]
 

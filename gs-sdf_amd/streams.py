@@ -48,6 +48,17 @@ def xcd_partition_streams(scatter_xcds=2, n_compute_streams=2, device=None):
     return [_masked_stream(hi, total, device) for _ in range(n_compute_streams)], _masked_stream(lo, total, device)
 
 
+def destroy_all():
+    """Synchronises the device and destroys every stream created here.  Call it after the last use (and after
+    torch.cuda.set_stream() has been pointed back at a torch-owned stream): a CU-masked stream that is still alive when
+    the process runs its exit handlers crashes rocprofv3's finalizer."""
+    torch.cuda.synchronize()
+    hip = C.CDLL("libamdhip64.so")
+    while _KEEP:
+        handle, _ = _KEEP.pop()
+        hip.hipStreamDestroy(handle)
+
+
 def launch_on(stream, fn):
     """Runs `fn()` (kernel launches) on `stream`, ordered after the current stream's work so far; the current stream then
     waits for it.  stream=None: plain call."""

@@ -84,6 +84,15 @@ class ViewParallel:
             group.flat_grad.mul_(1.0 / self.world)
         self._pending = []
 
+    def all_reduce_group(self, group):
+        """Mean of ONE parameter family's gradients over the ranks, on the CURRENT stream (RCCL's internal stream is
+        ordered after it and the current stream after RCCL): called from the stream of the leg that owns the family, so
+        that the other leg's kernels keep running beside the collective."""
+        if self.dist is None or self.world == 1:
+            return
+        self.dist.all_reduce(group.flat_grad, op=self.dist.ReduceOp.SUM)
+        group.flat_grad.mul_(1.0 / self.world)
+
     def all_reduce_grads(self):
         if self.dist is None or self.world == 1:
             return
