@@ -1,18 +1,16 @@
 """Print the device timeline of the LAST training step found in a rocprofv3 --kernel-trace CSV (run on the GPU box):
 start offset, duration, queue/stream and short kernel name, so that stream overlap and idle gaps are visible.
-Usage: trace_timeline.py <dir> <out.txt> [adam-kernel-substring]"""
+Usage: trace_timeline.py <dir> <out.txt> [once-per-step-kernel-substring]"""
 import csv, glob, os, sys
 
 d, out = sys.argv[1], sys.argv[2]
-marker = sys.argv[3] if len(sys.argv) > 3 else "adam_kernel"
+marker = sys.argv[3] if len(sys.argv) > 3 else "proj_cull_kernel"
 rows = []
 for f in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
     rows += list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-ends = [i for i, r in enumerate(rows) if marker in r["Kernel_Name"]]
-# a step ends with the last adam launch of a run of adam launches
-step_ends = [i for k, i in enumerate(ends) if k + 1 == len(ends) or ends[k + 1] != i + 1]
-a, b = step_ends[-3] + 1, step_ends[-2] + 1
+marks = [i for i, r in enumerate(rows) if marker in r["Kernel_Name"]]      # one launch per step
+a, b = marks[-3], marks[-2]
 t0 = int(rows[a]["Start_Timestamp"])
 busy = 0
 with open(out, "w") as fo:
