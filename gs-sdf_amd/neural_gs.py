@@ -423,3 +423,23 @@ def load_ply_to_gs(path, cfg=None, device="cpu", spatial_scale=1.0):
     cfg = cfg or GSConfig(sh_degree=int(round(math.sqrt(1 + n_rest // 3))) - 1)
     return NeuralGS(t(["x", "y", "z"]), t(["scale_0", "scale_1", "scale_2"]), t(["rot_0", "rot_1", "rot_2", "rot_3"]),
                     t(["opacity"]).reshape(-1), f_dc, f_rest, cfg, spatial_scale)
+
+
+def sample_ray_batch(local_map, origin, direction, depth, sample_std, truncated_dis, surface_sample_num=3, free_sample_num=3,
+                     sample_free=True, generator=None):
+    """NeuralSLAM::sample (neural_mapping.cpp:73-104) with the occupancy structure: per ray one sample in every occupied
+    voxel it crosses (LocalMap::sample, octree ray march) [+ free-space samples], the near-surface samples, SDF targets
+    truncated to +-truncated_dis, the ray end points, all filtered to the map's inner cube.
+    -> DepthSamples(xyz [B,3], ray_sdf [B,1], ridx [B], direction, origin, depth)."""
+    from .sdf import DepthSamples
+    n = origin.shape[0]
+    rays = DepthSamples(origin=origin, direction=direction, depth=depth, xyz=origin + direction * depth,
+                        ray_sdf=torch.zeros(n, 1, device=origin.device), ridx=torch.arange(n, device=origin.device))
+    pts = local_map.sample(rays, 1, sample_free, free_sample_num, generator)
+    sx, ss, sr = sample_surface_pts(origin, direction, depth, surface_sample_num, sample_std, generator)
+    surf = rays.index_select(sr)
+    surf.xyz, surf.ray_sdf, surf.depth = sx, ss, surf.depth - ss
+    pts = pts.cat(surf)
+    pts.ray_sdf = torch.where(pts.ray_sdf.abs() > truncated_dis, pts.ray_sdf.sign() * truncated_dis, pts.ray_sdf)
+    pts = pts.cat(rays)
+    return pts.index_select(local_map.get_inrange_mask(pts.xyz).nonzero().reshape(-1))

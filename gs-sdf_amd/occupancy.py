@@ -1,0 +1,120 @@
+"""Host-side mirror of the occupancy acceleration structure the reference takes from its (absent) kaolin_wisp_cpp
+submodule, on top of the C ABI (include/gsdf_hip.h, section A1):
+
+  spc_ops.quantize_points / points_to_neighbors / quantized_points_to_fpoints   sub_map.cpp:26-31, neural_mapping.cpp:757-758
+  from_quantized_points(qpts, level) -> OctreeAS                                sub_map.cpp:33-34
+  OctreeAS.query(xyz, level).pidx, .raymarch(origin, dir, "voxel", n), .get_quantized_points()
+                                                  sub_map.cpp:79, local_map.cpp:467-476,514, neural_mapping.cpp:755
+
+`OctreeAS` here is a dense bit pyramid in HBM (csrc/occupancy.hip), not a pointer octree; `pidx` carries only what the
+reference reads from it (`> -1`): 0 for occupied, -1 for free.  Semantics: DESIGN.md SPEC A.9.
+"""
+import collections
+
+import torch
+
+from . import capi
+from .capi import f32, ptr
+
+QueryResult = collections.namedtuple("QueryResult", "pidx")
+RaymarchResult = collections.namedtuple("RaymarchResult", "ridx samples depth_samples")
+
+
+class spc_ops:
+    @staticmethod
+    def quantize_points(x, level):
+        """[-1,1] floats -> int16 voxel coordinates at `level`."""
+        res = 2 ** level
+        return torch.floor(res * (x + 1.0) / 2.0).clamp(0, res - 1).to(torch.int16)
+
+    @staticmethod
+    def points_to_neighbors(qpts):
+        """[n,3] -> [n,27,3]: the 3x3x3 neighbourhood (x fastest), NOT clamped (the caller clamps, sub_map.cpp:31)."""
+        r = torch.arange(-1, 2, device=qpts.device, dtype=qpts.dtype)
+        offs = torch.stack(torch.meshgrid(r, r, r, indexing="ij"), -1).reshape(27, 3).flip(-1)
+        return qpts[:, None, :] + offs[None]
+
+    @staticmethod
+    def points_to_corners(qpts):
+        """[n,3] -> [n,8,3]: the 8 corners of each voxel (x fastest)."""
+        r = torch.arange(0, 2, device=qpts.device, dtype=qpts.dtype)
+        offs = torch.stack(torch.meshgrid(r, r, r, indexing="ij"), -1).reshape(8, 3).flip(-1)
+        return qpts[:, None, :] + offs[None]
+
+    @staticmethod
+    def quantized_points_to_fpoints(qpts, level):
+        """voxel coordinates -> the voxel's minimum corner in [-1,1] (kaolin's convention)."""
+        return qpts.to(torch.float32) * (2.0 / 2 ** level) - 1.0
+
+
+class OctreeAS:
+    def __init__(self, level, grid):
+        self.level, self.grid = int(level), grid
+
+    @property
+    def max_level(self):
+        return self.level
+
+    @classmethod
+    def from_points(cls, xyz_m1p1, level, dilate27=False):
+        """quantize_points -> unique -> (points_to_neighbors, clamp) -> from_quantized_points in one build
+        (SubMap::update_octree_as, sub_map.cpp:22-35)."""
+        L = capi.lib()
+        nbytes = L.gsdf_occ_bytes(int(level))
+        if nbytes == 0:
+            raise RuntimeError(f"OctreeAS: level {level} outside [1,12]")
+        xyz = xyz_m1p1.contiguous().float()
+        grid = torch.empty(nbytes // 4, dtype=torch.int32, device=xyz.device)
+        capi.check(L.gsdf_occ_build(int(level), xyz.shape[0], f32(xyz), int(bool(dilate27)), ptr(grid), capi.stream()),
+                   "occ_build")
+        return cls(level, grid)
+
+    def query(self, xyz_m1p1, level=-1):
+        """-> QueryResult(pidx int64 [n]): 0 where the cell at `level` (default: finest) is occupied, else -1."""
+        xyz = xyz_m1p1.contiguous().float()
+        mask = torch.empty(xyz.shape[0], dtype=torch.uint8, device=xyz.device)
+        capi.check(capi.lib().gsdf_occ_query(self.level, -1 if level is None else int(level), xyz.shape[0], f32(xyz),
+                                             ptr(self.grid), ptr(mask), capi.stream()), "occ_query")
+        return QueryResult(mask.to(torch.int64) - 1)
+
+    def get_quantized_points(self):
+        """-> int16 [V,3] occupied finest-level voxels (x-fastest linear order)."""
+        L = capi.lib()
+        n_words = max(1, 8 ** self.level // 32)
+        counts = torch.empty(n_words, dtype=torch.int32, device=self.grid.device)
+        capi.check(L.gsdf_occ_voxel_counts(self.level, ptr(self.grid), ptr(counts), capi.stream()), "occ_voxel_counts")
+        incl = torch.cumsum(counts, 0, dtype=torch.int64)
+        total = int(incl[-1].item())
+        offs = (incl - counts).contiguous()
+        vox = torch.empty(total, 3, dtype=torch.int16, device=self.grid.device)
+        if total:
+            capi.check(L.gsdf_occ_voxel_list(self.level, ptr(self.grid), ptr(offs), ptr(vox), capi.stream()), "occ_voxel_list")
+        return vox
+
+    def raymarch(self, origins_m1p1, dirs, raymarch_type="voxel", num_samples=1):
+        """-> RaymarchResult(ridx int64 [S], samples [S,3], depth_samples [S,1]): `num_samples` stratified midpoints in
+        every occupied finest-level voxel a ray crosses, rays in order, front to back (LocalMap::sample, :467-476)."""
+        if raymarch_type != "voxel":
+            raise RuntimeError("OctreeAS.raymarch: only the 'voxel' mode the reference uses is implemented")
+        L = capi.lib()
+        o, d = origins_m1p1.contiguous().float(), dirs.contiguous().float()
+        n = o.shape[0]
+        counts = torch.empty(n, dtype=torch.int32, device=o.device)
+        capi.check(L.gsdf_occ_raymarch_count(self.level, n, f32(o), f32(d), ptr(self.grid), ptr(counts), capi.stream()),
+                   "occ_raymarch_count")
+        incl = torch.cumsum(counts, 0, dtype=torch.int64)
+        total = int(incl[-1].item()) * int(num_samples) if n else 0
+        offs = (incl - counts).contiguous()
+        ridx = torch.empty(total, dtype=torch.int32, device=o.device)
+        samples = torch.empty(total, 3, dtype=torch.float32, device=o.device)
+        depth = torch.empty(total, 1, dtype=torch.float32, device=o.device)
+        if total:
+            capi.check(L.gsdf_occ_raymarch_fill(self.level, n, f32(o), f32(d), ptr(self.grid), ptr(offs), int(num_samples),
+                                                ptr(ridx), f32(samples), f32(depth), capi.stream()), "occ_raymarch_fill")
+        return RaymarchResult(ridx.to(torch.int64), samples, depth)
+
+
+def from_quantized_points(qpts, level):
+    """kaolin_wisp_cpp's factory (sub_map.cpp:33-34): builds from int voxel coordinates (their centres are re-quantised)."""
+    centres = (qpts.to(torch.float32) + 0.5) * (2.0 / 2 ** level) - 1.0
+    return OctreeAS.from_points(centres, level, dilate27=False)

@@ -261,6 +261,25 @@ class _SdfRayLoss(torch.autograd.Function):
         return ctx.saved_tensors[0] * v_loss, None, None, None, None, None
 
 
+class DepthSamples:
+    """utils::DepthSamples (include/utils/utils.h): a batch of per-ray records; every field is [n, ...] or None."""
+    FIELDS = ("origin", "direction", "depth", "xyz", "ray_sdf", "ridx")
+
+    def __init__(self, **kw):
+        for f in self.FIELDS:
+            setattr(self, f, kw.get(f))
+
+    def size(self, dim=0):
+        return next(getattr(self, f) for f in self.FIELDS if getattr(self, f) is not None).shape[dim]
+
+    def index_select(self, idx):
+        return DepthSamples(**{f: (None if getattr(self, f) is None else getattr(self, f).index_select(0, idx)) for f in self.FIELDS})
+
+    def cat(self, other):
+        return DepthSamples(**{f: (None if getattr(self, f) is None or getattr(other, f) is None
+                                   else torch.cat([getattr(self, f), getattr(other, f)], 0)) for f in self.FIELDS})
+
+
 class LocalMap:
     """The SDF half of the reference's `LocalMap` (include/neural_net/local_map.{h,cpp}): hash-grid encoder +
     decoder, `get_sdf`, `get_gradient` (numerical 6-point stencil or analytic via autograd)."""
@@ -312,6 +331,70 @@ class LocalMap:
         if accumulate_table_grad_in_place:
             self.encoder.grad_sink = self.encoder.params_.grad
         return FlatGroup(flat, flat_grad)
+
+    # ---- occupancy structure: SubMap (sub_map.cpp:7-80) + LocalMap::sample / filter_sample (local_map.cpp:449-516) ------
+    def set_bounds(self, inner_map_size, leaf_size):
+        """The k_* globals of params.cpp:243-256: cube of side inner_map_size around the origin, octree level
+        ceil(log2((inner + 2 leaf) / leaf)), map_size = 2^level * leaf (must equal this map's map_size)."""
+        self.leaf_size = float(leaf_size)
+        self.octree_level = int(math.ceil(math.log2((inner_map_size + 2 * leaf_size) / leaf_size)))
+        want = (2 ** self.octree_level) * leaf_size
+        if abs(want * self.map_size_inv - 1.0) > 1e-6:
+            raise RuntimeError(f"LocalMap.set_bounds: map_size must be 2^level * leaf_size = {want}")
+        half = torch.full((1, 3), 0.5 * float(inner_map_size), device=self.pos_W_M.device)
+        self.xyz_min_W, self.xyz_max_W = self.pos_W_M - half, self.pos_W_M + half
+        self.acc_struct_occ = None
+
+    def xyz_to_m1p1_pts(self, xyz):                # sub_map.cpp:82-93
+        return (xyz - self.pos_W_M) * 2 * self.map_size_inv
+
+    def m1p1_pts_to_xyz(self, pts):
+        return pts * 0.5 * (1.0 / self.map_size_inv) + self.pos_W_M
+
+    def scale_from_m1p1(self, t):
+        return t * 0.5 * (1.0 / self.map_size_inv)
+
+    def update_octree_as(self, xyz, is_prior=False):
+        """quantize -> unique -> (27-neighbour dilation unless is_prior) -> occupancy structure (sub_map.cpp:22-35)."""
+        from .occupancy import OctreeAS
+        self.acc_struct_occ = OctreeAS.from_points(self.xyz_to_m1p1_pts(xyz), self.octree_level, dilate27=not is_prior)
+
+    def get_valid_mask(self, xyz, level=-1):       # sub_map.cpp:76-80
+        return self.acc_struct_occ.query(self.xyz_to_m1p1_pts(xyz), level).pidx > -1
+
+    def get_inrange_mask(self, xyz, padding=0.0):  # sub_map.cpp:37-45
+        return ((xyz < self.xyz_max_W - padding - 1e-6) & (xyz > self.xyz_min_W + padding + 1e-6)).all(1)
+
+    def get_intersect_point(self, points, rays, padding=0.0):   # sub_map.cpp:47-74 -> (z_nears, z_fars, mask_intersect)
+        tmp = torch.where(rays == 0, rays + 1e-6, rays)
+        a, b = (self.xyz_min_W + padding - points) / tmp, (self.xyz_max_W - padding - points) / tmp
+        z_nears, z_fars = torch.minimum(a, b).max(1).values, torch.maximum(a, b).min(1).values
+        return z_nears, z_fars, z_nears < z_fars
+
+    def sample(self, rays, voxel_sample_num, sample_free, free_sample_num=3, generator=None):
+        """LocalMap::sample (local_map.cpp:449-509): `voxel_sample_num` points in every occupied voxel each ray crosses
+        (SDF target = ray depth - sample depth), optionally the stratified free-space samples, keeping what lies in
+        front of the surface.  `rays` / result: DepthSamples."""
+        from .neural_gs import sample_free_pts
+        if voxel_sample_num < 1:
+            return DepthSamples(xyz=rays.xyz, ray_sdf=torch.zeros_like(rays.depth), direction=rays.direction, ridx=rays.ridx)
+        rm = self.acc_struct_occ.raymarch(self.xyz_to_m1p1_pts(rays.origin).contiguous(), rays.direction.contiguous(),
+                                          "voxel", voxel_sample_num)
+        out = rays.index_select(rm.ridx)
+        out.ridx = rm.ridx
+        out.xyz = self.m1p1_pts_to_xyz(rm.samples)
+        d = self.scale_from_m1p1(rm.depth_samples)
+        out.ray_sdf, out.depth = out.depth - d, d
+        if sample_free:
+            fx, fs, fr = sample_free_pts(rays.origin, rays.direction, rays.depth, free_sample_num, generator)
+            free = rays.index_select(fr)
+            free.xyz, free.ray_sdf, free.ridx, free.depth = fx, fs, rays.ridx.index_select(0, fr), free.depth - fs
+            out = out.cat(free)
+        return out.index_select((out.ray_sdf > 0).reshape(-1).nonzero().reshape(-1))
+
+    def filter_sample(self, samples):              # local_map.cpp:511-516
+        keep = (self.acc_struct_occ.query(self.xyz_to_m1p1_pts(samples.xyz)).pidx > -1).nonzero().reshape(-1)
+        return samples.index_select(keep)
 
     def xyz_to_zp1_pts(self, xyz):                 # sub_map.cpp:82-97
         return 0.5 * ((xyz - self.pos_W_M) * (2.0 * self.map_size_inv)) + 0.5

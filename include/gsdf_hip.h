@@ -233,6 +233,38 @@ int gsdf_sdf_ray_loss(int64_t n, int stencil, const float *attr, int ld, const f
                       float delta, float w_eik, float *loss, float *v_attr, gsdf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * A1  occupancy acceleration structure: replaces the OctreeAS of the absent kaolin_wisp_cpp submodule as the reference's
+ *     call sites use it (SubMap::update_octree_as include/neural_net/sub_map.cpp:22-35; get_valid_mask :76-80;
+ *     LocalMap::sample / filter_sample include/neural_net/local_map.cpp:449-516; get_quantized_points
+ *     include/neural_mapping/neural_mapping.cpp:755-758).  Coordinates are kaolin's: the map cube is [-1,1]^3,
+ *     q = clamp(floor(2^level (x+1)/2), 0, 2^level-1).  `grid` = caller-owned device buffer of gsdf_occ_bytes(level)
+ *     bytes: a bit pyramid (level l: 2^(3l) bits, x fastest, uint32 words; levels 0..level back to back; parent = OR of
+ *     its 8 children).  level in [1,12].  Semantics: DESIGN.md SPEC A.9.
+ *   build:     clears the pyramid, sets the level-`level` voxel of every point (dilate27 != 0: and its 26 neighbours,
+ *              clamped to the cube = points_to_neighbors(...).clamp(0,res-1)), then the coarser levels.
+ *   query:     mask[i] = 1 iff xyz_i is inside [-1,1]^3 and its cell at query_level (<0: level) is occupied
+ *              (= query(xyz, level).pidx > -1).
+ *   voxel_counts / voxel_list: two-phase get_quantized_points(): word_counts[w] = popcount of the w-th word of the
+ *              finest level (2^(3 level)/32 words); the caller scans them (exclusive, int64) and passes word_offsets;
+ *              voxels[V,3] int16 (x,y,z) in x-fastest order.
+ *   raymarch:  two-phase "voxel" ray march.  count: counts[r] = number of occupied finest-level voxels ray r
+ *              (origin + t*dir, t >= 0) crosses, front to back.  fill: voxel_offsets = exclusive scan of counts (int64);
+ *              for the v-th voxel of ray r and k < num_samples, row j = (voxel_offsets[r]+v)*num_samples + k:
+ *              ridx[j] = r, depth_samples[j] = t_in + (t_out-t_in)(k+1/2)/num_samples, samples[j] = origin + t*dir.
+ * ---------------------------------------------------------------------------------------- */
+size_t gsdf_occ_bytes(int level);
+int gsdf_occ_build(int level, int64_t n_points, const float *xyz_m1p1, int dilate27, void *grid, gsdf_stream_t stream);
+int gsdf_occ_query(int level, int query_level, int64_t n, const float *xyz_m1p1, const void *grid, uint8_t *mask,
+                   gsdf_stream_t stream);
+int gsdf_occ_voxel_counts(int level, const void *grid, int32_t *word_counts, gsdf_stream_t stream);
+int gsdf_occ_voxel_list(int level, const void *grid, const int64_t *word_offsets, int16_t *voxels, gsdf_stream_t stream);
+int gsdf_occ_raymarch_count(int level, int64_t n_rays, const float *origins_m1p1, const float *dirs, const void *grid,
+                            int32_t *counts, gsdf_stream_t stream);
+int gsdf_occ_raymarch_fill(int level, int64_t n_rays, const float *origins_m1p1, const float *dirs, const void *grid,
+                           const int64_t *voxel_offsets, int num_samples, int32_t *ridx, float *samples,
+                           float *depth_samples, gsdf_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * O2  fused photometric loss  L = w_l1 * mean|I-G| + w_ssim * (1 - mean SSIM(I,G))  on [H,W,3] images:
  *     loss::rgb_loss + loss::dssim_loss (include/optimizer/loss/loss.cpp:22-47) with loss_utils::ssim
  *     (include/optimizer/loss_utils/loss_utils.cpp:71-117; 11-tap window of loss_utils.cpp:6-14 passed by the host,

@@ -21,6 +21,8 @@ def build(force=False):
     """Compile the C restatement with gcc (oracle/Makefile)."""
     kinds = [k for k in ("splat", "sdf") if os.path.exists(os.path.join(_HERE, f"{k}_oracle.c"))]
     targets = [f"_build/liborc_{k}_{p}.so" for k in kinds for p in ("f32", "f64")]
+    if os.path.exists(os.path.join(_HERE, "occ_oracle.c")):
+        targets.append("_build/liborc_occ.so")
     subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []) + targets)
 
 
@@ -284,3 +286,55 @@ def knn_mean_dist2(pts, prec="f32"):
     out = np.zeros(pts.shape[0], dt)
     _lib("sdf", prec).orc_knn_mean_dist2(C.c_int64(pts.shape[0]), _p(pts), _p(out))
     return out
+
+
+# ----------------------------------------------------------------------------------------------
+# A1 occupancy structure (oracle/occ_oracle.c; fp32 only)
+# ----------------------------------------------------------------------------------------------
+def _occ():
+    if "occ" not in _LIBS:
+        path = os.path.join(_BUILD, "liborc_occ.so")
+        if not os.path.exists(path):
+            build()
+        lib = C.CDLL(path)
+        lib.orc_occ_words.restype = C.c_int64
+        lib.orc_occ_list.restype = C.c_int64
+        _LIBS["occ"] = lib
+    return _LIBS["occ"]
+
+
+def occ_build(level, xyz, dilate27):
+    lib = _occ()
+    xyz = _c(xyz, np.float32).reshape(-1, 3)
+    grid = np.zeros(lib.orc_occ_words(C.c_int(level)), np.uint32)
+    lib.orc_occ_build(C.c_int(level), C.c_int64(xyz.shape[0]), _p(xyz), C.c_int(int(dilate27)), _p(grid))
+    return grid
+
+
+def occ_query(level, grid, xyz, query_level=-1):
+    xyz = _c(xyz, np.float32).reshape(-1, 3)
+    mask = np.zeros(xyz.shape[0], np.uint8)
+    _occ().orc_occ_query(C.c_int(level), C.c_int(query_level), C.c_int64(xyz.shape[0]), _p(xyz), _p(grid), _p(mask))
+    return mask
+
+
+def occ_list(level, grid):
+    lib = _occ()
+    n = lib.orc_occ_list(C.c_int(level), _p(grid), None)
+    out = np.zeros((n, 3), np.int16)
+    lib.orc_occ_list(C.c_int(level), _p(grid), _p(out))
+    return out
+
+
+def occ_raymarch(level, grid, origins, dirs, num_samples=1):
+    lib = _occ()
+    o, d = _c(origins, np.float32).reshape(-1, 3), _c(dirs, np.float32).reshape(-1, 3)
+    n = o.shape[0]
+    counts = np.zeros(n, np.int32)
+    lib.orc_occ_raymarch_count(C.c_int(level), C.c_int64(n), _p(o), _p(d), _p(grid), _p(counts))
+    offs = np.concatenate([[0], np.cumsum(counts.astype(np.int64))[:-1]]).astype(np.int64) if n else np.zeros(0, np.int64)
+    S = int(counts.sum()) * num_samples
+    ridx, samples, depth = np.zeros(S, np.int32), np.zeros((S, 3), np.float32), np.zeros((S, 1), np.float32)
+    lib.orc_occ_raymarch_fill(C.c_int(level), C.c_int64(n), _p(o), _p(d), _p(grid), _p(offs), _p(counts), C.c_int(num_samples),
+                              _p(ridx), _p(samples), _p(depth))
+    return counts, ridx, samples, depth

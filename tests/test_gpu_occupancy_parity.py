@@ -1,0 +1,122 @@
+"""A1 occupancy structure (csrc/occupancy.hip) against oracle/occ_oracle.c through the C ABI: the pyramid words, query
+masks, voxel lists, ray-march counts and ray ids are integer outputs -> bit-exact; the sample depths / positions are the
+same fp32 expressions evaluated without contraction on both sides -> compared exactly as well."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+dev = torch.device("cuda:0")
+
+
+def _scene(L, n_pts, seed):
+    rng = np.random.default_rng(seed)
+    # points on a sphere shell + a plane, some outside the cube
+    u = rng.standard_normal((n_pts, 3))
+    shell = 0.6 * u / np.linalg.norm(u, axis=1, keepdims=True) + 0.02 * rng.standard_normal((n_pts, 3))
+    plane = np.stack([rng.random(n_pts) * 2.4 - 1.2, rng.random(n_pts) * 2.4 - 1.2, np.full(n_pts, -0.7)], 1)
+    return np.concatenate([shell, plane]).astype(np.float32)
+
+
+@pytest.mark.parametrize("L,n_pts,dilate", [(3, 50, True), (6, 2000, True), (9, 200_000, True), (9, 100_000, False), (10, 400_000, True)])
+def test_build_query_list_bit_exact(L, n_pts, dilate):
+    from gs_sdf_amd.occupancy import OctreeAS
+    pts = _scene(L, n_pts, L)
+    ref = orc.occ_build(L, pts, dilate)
+    acc = OctreeAS.from_points(torch.from_numpy(pts).to(dev), L, dilate27=dilate)
+    got = acc.grid.cpu().numpy().view(np.uint32)
+    assert got.shape == ref.shape and np.array_equal(got, ref)
+    rng = np.random.default_rng(99)
+    q = (rng.random((100_000, 3)) * 2.2 - 1.1).astype(np.float32)
+    q[: min(1000, len(pts))] = pts[:1000]
+    for level in (-1, L, max(L - 3, 0), 0):
+        m = acc.query(torch.from_numpy(q).to(dev), level).pidx.cpu().numpy()
+        assert set(np.unique(m)) <= {-1, 0}
+        assert np.array_equal(m > -1, orc.occ_query(L, ref, q, level).astype(bool)), level
+    if L <= 9:
+        assert np.array_equal(acc.get_quantized_points().cpu().numpy(), orc.occ_list(L, ref))
+
+
+@pytest.mark.parametrize("L,n_pts,n_rays,ns", [(4, 40, 500, 1), (7, 5000, 4000, 3), (9, 200_000, 32768, 1), (10, 300_000, 8192, 2)])
+def test_voxel_raymarch_bit_exact(L, n_pts, n_rays, ns):
+    from gs_sdf_amd.occupancy import OctreeAS
+    pts = _scene(L, n_pts, 20 + L)
+    ref = orc.occ_build(L, pts, True)
+    acc = OctreeAS.from_points(torch.from_numpy(pts).to(dev), L, dilate27=True)
+    rng = np.random.default_rng(7)
+    o = (rng.random((n_rays, 3)) * 2.6 - 1.3).astype(np.float32)
+    o[: n_rays // 2] *= 0.3                                              # half of the sensors inside the shell
+    d = rng.standard_normal((n_rays, 3)).astype(np.float32)
+    d[:50, 0] = 0.0
+    d[:25, 1] = 0.0
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    d[-1] = 0.0                                                          # degenerate direction: no samples
+    counts, ridx, samples, depth = orc.occ_raymarch(L, ref, o, d, ns)
+    rm = acc.raymarch(torch.from_numpy(o).to(dev), torch.from_numpy(d).to(dev), "voxel", ns)
+    assert counts.sum() > n_rays // 4
+    assert rm.ridx.dtype == torch.int64 and np.array_equal(rm.ridx.cpu().numpy(), ridx.astype(np.int64))
+    assert np.array_equal(rm.depth_samples.cpu().numpy(), depth)
+    assert np.array_equal(rm.samples.cpu().numpy(), samples)
+
+
+def test_empty_inputs_and_errors():
+    from gs_sdf_amd.occupancy import OctreeAS
+    acc = OctreeAS.from_points(torch.zeros(0, 3, device=dev), 5)
+    assert int(acc.grid.abs().sum()) == 0 and acc.get_quantized_points().shape == (0, 3)
+    rm = acc.raymarch(torch.zeros(4, 3, device=dev), torch.ones(4, 3, device=dev), "voxel", 2)
+    assert rm.ridx.numel() == 0 and rm.samples.shape == (0, 3) and rm.depth_samples.shape == (0, 1)
+    assert acc.query(torch.zeros(0, 3, device=dev)).pidx.numel() == 0
+    with pytest.raises(RuntimeError):
+        OctreeAS.from_points(torch.zeros(1, 3, device=dev), 13)
+    with pytest.raises(RuntimeError):
+        acc.query(torch.zeros(1, 3, device=dev), 6)
+    with pytest.raises(RuntimeError):
+        acc.raymarch(torch.zeros(1, 3, device=dev), torch.ones(1, 3, device=dev), "ray", 2)
+    with pytest.raises(RuntimeError):
+        OctreeAS.from_points(torch.zeros(1, 3), 5)                        # CPU tensor: no fallback
+
+
+def test_local_map_sampler_matches_composition_of_oracle_pieces():
+    """SubMap::update_octree_as / get_valid_mask / LocalMap::sample (voxel ray march, SDF target = depth - sample depth,
+    keep ray_sdf > 0) against the same composition on the oracle's outputs."""
+    import gs_sdf_amd.sdf as sdfm
+    from gs_sdf_amd.neural_gs import sample_ray_batch
+    leaf, inner = 0.05, 12.0
+    level = int(np.ceil(np.log2((inner + 2 * leaf) / leaf)))
+    lm = sdfm.LocalMap([0.5, -0.25, 1.0], (2 ** level) * leaf, device=dev, seed=0)
+    lm.set_bounds(inner, leaf)
+    assert lm.octree_level == level == 8
+    rng = np.random.default_rng(3)
+    u = rng.standard_normal((60_000, 3))
+    surf = (4.0 * u / np.linalg.norm(u, axis=1, keepdims=True) + np.array([0.5, -0.25, 1.0])).astype(np.float32)
+    lm.update_octree_as(torch.from_numpy(surf).to(dev))
+    m1p1 = lm.xyz_to_m1p1_pts(torch.from_numpy(surf).to(dev)).cpu().numpy()
+    ref = orc.occ_build(level, m1p1, True)
+    assert np.array_equal(lm.acc_struct_occ.grid.cpu().numpy().view(np.uint32), ref)
+    assert bool(lm.get_valid_mask(torch.from_numpy(surf).to(dev)).all())
+    # rays from the centre outwards with the true depth of the sphere
+    n = 5000
+    dirs = rng.standard_normal((n, 3)).astype(np.float32)
+    dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+    origin = torch.tensor([[0.5, -0.25, 1.0]], device=dev).repeat(n, 1)
+    depth = torch.full((n, 1), 4.0, device=dev)
+    rays = sdfm.DepthSamples(origin=origin, direction=torch.from_numpy(dirs).to(dev), depth=depth,
+                             xyz=origin + torch.from_numpy(dirs).to(dev) * depth, ray_sdf=torch.zeros(n, 1, device=dev),
+                             ridx=torch.arange(n, device=dev))
+    got = lm.sample(rays, 1, False)
+    counts, ridx, samples, dep = orc.occ_raymarch(level, ref, lm.xyz_to_m1p1_pts(origin).cpu().numpy(), dirs, 1)
+    d_w = dep * np.float32(0.5) * np.float32(1.0 / lm.map_size_inv)
+    keep = (4.0 - d_w[:, 0]) > 0
+    assert keep.sum() > n and np.array_equal(got.ridx.cpu().numpy(), ridx[keep].astype(np.int64))
+    np.testing.assert_allclose(got.ray_sdf.cpu().numpy()[:, 0], (4.0 - d_w[:, 0])[keep], rtol=0, atol=1e-5)
+    np.testing.assert_allclose(got.xyz.cpu().numpy(), (samples * 0.5 / lm.map_size_inv + np.array([0.5, -0.25, 1.0]))[keep], atol=1e-4)
+    assert float(got.ray_sdf.min()) > 0 and float(got.ray_sdf.max()) < 3 * leaf * 2     # samples hug the surface shell
+    # the full per-ray batch of NeuralSLAM::sample
+    g = torch.Generator(device=dev).manual_seed(0)
+    batch = sample_ray_batch(lm, origin, torch.from_numpy(dirs).to(dev), depth, 0.05, 0.15, 3, 3, True, g)
+    assert batch.xyz.shape[0] == batch.ray_sdf.shape[0] == batch.ridx.shape[0] > 7 * n
+    assert float(batch.ray_sdf.abs().max()) <= 0.15 + 1e-6 and bool(lm.get_inrange_mask(batch.xyz).all())
+    kept = lm.filter_sample(batch)
+    assert 0 < kept.xyz.shape[0] < batch.xyz.shape[0]
