@@ -106,11 +106,14 @@ def main():
     # kernel that shares an XCD with it finishes only when it does (gs_sdf_amd/streams.py has the measurements).
     overlap = not args.no_sdf and not args.no_overlap
     main = torch.cuda.current_stream()
-    side = scatter = main
+    side = scatter = aux = main
+    if not args.no_sdf:
+        lm.encoder.save_jacobian = True      # d/dx of the sample points from the forward's Jacobian (first order only)
     if overlap:
         from gs_sdf_amd.streams import xcd_partition_streams
-        (main, side), scatter = xcd_partition_streams(args.scatter_xcds, 2)
+        (main, side, aux), scatter = xcd_partition_streams(args.scatter_xcds, 3)
         lm.encoder.scatter_stream = scatter
+        lm.decoder.aux_stream = aux          # decoder weight gradients: off the chain that leads back to the splat leg
         main.wait_stream(torch.cuda.current_stream())
         torch.cuda.set_stream(main)
     gate = GradGate()
@@ -119,7 +122,7 @@ def main():
         if overlap:
             from gs_sdf_amd.streams import destroy_all
             torch.cuda.synchronize()
-            lm.encoder.scatter_stream = None
+            lm.encoder.scatter_stream = lm.decoder.aux_stream = None
             torch.cuda.set_stream(torch.cuda.default_stream())
             destroy_all()
 
@@ -177,6 +180,8 @@ def main():
         else:
             loss.backward()
         stamp("backward issued")
+        if world > 1:
+            main.wait_stream(scatter)      # RCCL's workgroups land on every XCD: do not run them beside the scatter
         vp.all_reduce_group(params)
         if update:
             adam.step()
@@ -186,6 +191,7 @@ def main():
             # and optimizer step of this leg on its own stream, beside the splat leg
             with torch.cuda.stream(side):
                 side.wait_stream(scatter)
+                side.wait_stream(aux)
                 vp.all_reduce_group(groups[0])
                 if update:
                     adam_sdf.step()

@@ -35,11 +35,14 @@ _SIGS = {
     "gsdf_render_post_bwd": (C.c_int, [_i64, _i32] + [_vp] * 12),
     "gsdf_hashgrid_offsets": (_i64, [_i32, _i32, _i32, _i32, _f32, _vp]),
     "gsdf_hashgrid_fwd": (C.c_int, [_i64, _i32, _i32, _i32, _i32, _f32] + [_vp] * 4),
+    "gsdf_hashgrid_fwd_jac": (C.c_int, [_i64, _i32, _i32, _i32, _i32, _f32] + [_vp] * 5),
+    "gsdf_hashgrid_bwd_jac": (C.c_int, [_i64, _i32, _i32] + [_vp] * 4),
     "gsdf_hashgrid_bwd": (C.c_int, [_i64, _i32, _i32, _i32, _i32, _f32] + [_vp] * 6),
     "gsdf_hashgrid_bwd_bwd": (C.c_int, [_i64, _i32, _i32, _i32, _i32, _f32] + [_vp] * 8),
     "gsdf_mlp_fwd": (C.c_int, [_i64, _i32] + [_vp] * 7),
     "gsdf_mlp_bwd_ws_bytes": (_sz, [_i64, _i32]),
     "gsdf_mlp_bwd": (C.c_int, [_i64, _i32] + [_vp] * 11),
+    "gsdf_mlp_bwd_weights": (C.c_int, [_i64, _i32, _vp, _i32] + [_vp] * 7),
     "gsdf_l1_dssim_fwd": (C.c_int, [_i32, _i32] + [_vp] * 6),
     "gsdf_l1_dssim_bwd": (C.c_int, [_i32, _i32] + [_vp] * 5 + [_f32, _f32, _vp, _vp]),
     "gsdf_normal_consistency_fwd": (C.c_int, [_i32, _i32] + [_vp] * 7),

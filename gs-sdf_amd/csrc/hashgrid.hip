@@ -102,29 +102,62 @@ __device__ __forceinline__ float row_sum_to_lane15(float v) {
 // forward: 4 lanes per (point, level) = (x-corner bit, feature), like the backward kernels below: the 4 lanes of a
 // (y,z) corner pair read 4 consecutive floats {entry(x0).f0,.f1, entry(x1).f0,.f1} -> one 16-byte segment per group
 // instead of two 8-byte gathers in different instructions; the two x partials are combined with one quad DPP.
+// JAC: also stores d feat / d x (jac[b][level*2+f][0..2], 384 B per point) so that the first-order input gradient is
+// a dense 32x3 contraction per point later (hashgrid_bwd_jac_kernel) instead of a second pass over the table.
+template <bool JAC>
 __global__ void __launch_bounds__(HG_THREADS)
     hashgrid_fwd_kernel(int64_t B, HgLevels lv, const float *__restrict__ x, const float *__restrict__ table,
-                        float *__restrict__ feat) {
+                        float *__restrict__ feat, float *__restrict__ jac) {
   const int lane = threadIdx.x & 63;
   const int f = lane & 1, xb = (lane >> 1) & 1, level = lane >> 2;
   const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (b >= B) return;  // wave-uniform
-  float acc = 0.f;
+  float acc = 0.f, jx = 0.f, jy = 0.f, jz = 0.f;
   if (level < lv.n_levels) {
     Cell c;
     load_cell(lv, level, x, b, table, c);
     const float *tb = table + (int64_t)lv.offset[level] * 2 + f;
-    const float wx = xb ? c.fr[0] : 1.f - c.fr[0];
+    const float wx = xb ? c.fr[0] : 1.f - c.fr[0], sx = xb ? 1.f : -1.f;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int hy = k & 1, hz = k >> 1;
       const uint32_t idx = grid_index(c.hsize, c.res, c.g0[0] + xb, c.g0[1] + hy, c.g0[2] + hz);
-      const float w = wx * (hy ? c.fr[1] : 1.f - c.fr[1]) * (hz ? c.fr[2] : 1.f - c.fr[2]);
-      acc += w * tb[2 * (int64_t)idx];
+      const float wy = hy ? c.fr[1] : 1.f - c.fr[1], wz = hz ? c.fr[2] : 1.f - c.fr[2];
+      const float t = tb[2 * (int64_t)idx];
+      acc += wx * wy * wz * t;
+      if (JAC) {
+        jx += sx * wy * wz * t;
+        jy += (hy ? 1.f : -1.f) * wx * wz * t;
+        jz += (hz ? 1.f : -1.f) * wx * wy * t;
+      }
     }
+    if (JAC) { jx *= c.scale; jy *= c.scale; jz *= c.scale; }
   }
   acc += dpp_mov<0x4E>(acc);  // quad_perm [2,3,0,1]: add the other x-corner's partial (same feature)
-  if (xb == 0 && level < lv.n_levels) feat[(b * lv.n_levels + level) * 2 + f] = acc;
+  if (JAC) { jx += dpp_mov<0x4E>(jx); jy += dpp_mov<0x4E>(jy); jz += dpp_mov<0x4E>(jz); }
+  if (xb == 0 && level < lv.n_levels) {
+    const int64_t o = (b * lv.n_levels + level) * 2 + f;
+    feat[o] = acc;
+    if (JAC) { jac[3 * o] = jx; jac[3 * o + 1] = jy; jac[3 * o + 2] = jz; }
+  }
+}
+
+// v_x[b] = sum_k v_feat[b][k] * jac[b][k][:]  (k < n_out <= 32): half a wave per point, DPP row reduction
+__global__ void __launch_bounds__(256)
+    hashgrid_bwd_jac_kernel(int64_t B, int n_out, const float *__restrict__ jac, const float *__restrict__ v_feat,
+                            float *__restrict__ v_x) {
+  const int lane = threadIdx.x & 63, k = lane & 31;
+  const int64_t b = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 2 + (lane >> 5);
+  float gx = 0.f, gy = 0.f, gz = 0.f;
+  if (b < B && k < n_out) {
+    const float vf = v_feat[b * n_out + k];
+    const float *j = jac + (b * n_out + k) * 3;
+    gx = vf * j[0]; gy = vf * j[1]; gz = vf * j[2];
+  }
+  // sum over the 32 lanes of a half wave: 16-lane rows, then row_bcast15 into rows 1 and 3 -> lanes 31 and 63
+  gx = row_sum_to_lane15(gx); gy = row_sum_to_lane15(gy); gz = row_sum_to_lane15(gz);
+  gx += dpp_mov<0x142, 0xA, 0xF, false>(gx); gy += dpp_mov<0x142, 0xA, 0xF, false>(gy); gz += dpp_mov<0x142, 0xA, 0xF, false>(gz);
+  if (k == 31 && b < B) { v_x[3 * b] = gx; v_x[3 * b + 1] = gy; v_x[3 * b + 2] = gz; }
 }
 
 // ---- backward kernels: 4 lanes per (point, level) -------------------------------------------------------
@@ -251,8 +284,34 @@ extern "C" int gsdf_hashgrid_fwd(int64_t B, int n_levels, int n_feat, int log2_h
   GSDF_REQUIRE(x && table && feat, "hashgrid_fwd: null buffer");
   HgLevels lv;
   build_levels(n_levels, log2_hashmap, base_res, per_level_scale, &lv, nullptr);
-  hashgrid_fwd_kernel<<<(unsigned)((B + 3) / 4), HG_THREADS, 0, stream>>>(B, lv, x, table, feat);
+  hashgrid_fwd_kernel<false><<<(unsigned)((B + 3) / 4), HG_THREADS, 0, stream>>>(B, lv, x, table, feat, nullptr);
   GSDF_CHECK_LAUNCH("hashgrid_fwd_kernel");
+  return GSDF_OK;
+}
+
+extern "C" int gsdf_hashgrid_fwd_jac(int64_t B, int n_levels, int n_feat, int log2_hashmap, int base_res,
+                                     float per_level_scale, const float *x, const float *table, float *feat, float *jac,
+                                     gsdf_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  int rc = check_cfg(n_levels, n_feat, log2_hashmap, base_res, per_level_scale, "hashgrid_fwd_jac");
+  if (rc) return rc;
+  if (B == 0) return GSDF_OK;
+  GSDF_REQUIRE(x && table && feat && jac, "hashgrid_fwd_jac: null buffer");
+  HgLevels lv;
+  build_levels(n_levels, log2_hashmap, base_res, per_level_scale, &lv, nullptr);
+  hashgrid_fwd_kernel<true><<<(unsigned)((B + 3) / 4), HG_THREADS, 0, stream>>>(B, lv, x, table, feat, jac);
+  GSDF_CHECK_LAUNCH("hashgrid_fwd_kernel<jac>");
+  return GSDF_OK;
+}
+
+extern "C" int gsdf_hashgrid_bwd_jac(int64_t B, int n_levels, int n_feat, const float *jac, const float *v_feat,
+                                     float *v_x, gsdf_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  GSDF_REQUIRE(n_levels >= 1 && n_feat >= 1 && n_levels * n_feat <= 32, "hashgrid_bwd_jac: n_levels*n_feat must be <= 32");
+  if (B == 0) return GSDF_OK;
+  GSDF_REQUIRE(jac && v_feat && v_x, "hashgrid_bwd_jac: null buffer");
+  hashgrid_bwd_jac_kernel<<<(unsigned)((B + 7) / 8), 256, 0, stream>>>(B, n_levels * n_feat, jac, v_feat, v_x);
+  GSDF_CHECK_LAUNCH("hashgrid_bwd_jac_kernel");
   return GSDF_OK;
 }
 

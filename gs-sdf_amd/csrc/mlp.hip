@@ -414,3 +414,22 @@ extern "C" int gsdf_mlp_bwd(int64_t B, int n_layers, const int *dims_host, const
   }
   return GSDF_OK;
 }
+
+extern "C" int gsdf_mlp_bwd_weights(int64_t B, int n_layers, const int *dims_host, int has_biases, const float *in,
+                                    const float *acts, const float *v_out, const void *ws, float *v_weights,
+                                    float *v_biases, gsdf_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  GSDF_REQUIRE(dims_host, "mlp_bwd_weights: null dims");
+  MlpDesc d;
+  size_t lds_floats;
+  int rc = make_desc(n_layers, dims_host, has_biases != 0, true, &d, &lds_floats, "mlp_bwd_weights");
+  if (rc) return rc;
+  if (B == 0) return GSDF_OK;
+  GSDF_REQUIRE(in && acts && v_out && ws && v_weights, "mlp_bwd_weights: null buffer");
+  GSDF_REQUIRE(!has_biases || v_biases, "mlp_bwd_weights: null v_biases");
+  dim3 grid((unsigned)((B + WG_KCHUNK - 1) / WG_KCHUNK), (unsigned)n_layers);
+  mlp_bwd_weights_kernel<<<grid, MLP_THREADS, 0, stream>>>(B, d, in, acts, v_out, (const float *)ws, v_weights,
+                                                           has_biases ? v_biases : nullptr);
+  GSDF_CHECK_LAUNCH("mlp_bwd_weights_kernel");
+  return GSDF_OK;
+}

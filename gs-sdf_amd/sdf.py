@@ -94,25 +94,40 @@ class _GridBwd(torch.autograd.Function):
 
 class _GridFwd(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, table, cfg, grad_sink=None, scatter_stream=None):
+    def forward(ctx, x, table, cfg, grad_sink=None, scatter_stream=None, save_jacobian=False):
         L = capi.lib()
         x, table = x.contiguous(), table.contiguous()
         B = x.shape[0]
         feat = torch.empty(B, cfg[0] * cfg[1], dtype=torch.float32, device=x.device)
-        capi.check(_timed("hashgrid_fwd", L.gsdf_hashgrid_fwd, B, *cfg, f32(x, "x"), f32(table, "params"), f32(feat),
-                          capi.stream()), "hashgrid_fwd")
-        ctx.save_for_backward(x, table)
+        jac = None
+        if save_jacobian and ctx.needs_input_grad[0] and cfg[0] * cfg[1] <= 32:
+            jac = torch.empty(B, cfg[0] * cfg[1], 3, dtype=torch.float32, device=x.device)
+            capi.check(_timed("hashgrid_fwd", L.gsdf_hashgrid_fwd_jac, B, *cfg, f32(x, "x"), f32(table, "params"), f32(feat),
+                              f32(jac), capi.stream()), "hashgrid_fwd_jac")
+        else:
+            capi.check(_timed("hashgrid_fwd", L.gsdf_hashgrid_fwd, B, *cfg, f32(x, "x"), f32(table, "params"), f32(feat),
+                              capi.stream()), "hashgrid_fwd")
+        ctx.save_for_backward(x, table, jac)
         ctx.cfg = cfg
         ctx.grad_sink, ctx.scatter_stream = grad_sink, scatter_stream
         return feat
 
     @staticmethod
     def backward(ctx, v_feat):
-        x, table = ctx.saved_tensors
-        v_x, v_table = _GridBwd.apply(v_feat, x, table, ctx.cfg, bool(ctx.needs_input_grad[1]), ctx.grad_sink,
-                                      ctx.scatter_stream, bool(ctx.needs_input_grad[0]))
+        x, table, jac = ctx.saved_tensors
+        want_x, v_x = bool(ctx.needs_input_grad[0]), None
+        if jac is not None and want_x and not torch.is_grad_enabled():
+            # first-order fast path: d/dx from the Jacobian saved by the forward, only the scatter touches the table
+            v_feat = v_feat.contiguous()
+            v_x = torch.empty_like(x)
+            capi.check(_timed("hashgrid_bwd_input", capi.lib().gsdf_hashgrid_bwd_jac, x.shape[0], ctx.cfg[0], ctx.cfg[1],
+                              f32(jac), f32(v_feat), f32(v_x), capi.stream()), "hashgrid_bwd_jac")
+            want_x = False
+        g_x, v_table = _GridBwd.apply(v_feat, x, table, ctx.cfg, bool(ctx.needs_input_grad[1]), ctx.grad_sink,
+                                      ctx.scatter_stream, want_x)
+        v_x = g_x if want_x else v_x
         want_t = ctx.needs_input_grad[1] and ctx.grad_sink is None
-        return (v_x if ctx.needs_input_grad[0] else None), (v_table if want_t else None), None, None, None
+        return v_x, (v_table if want_t else None), None, None, None, None
 
 
 class TCNNEncoding:
@@ -144,6 +159,9 @@ class TCNNEncoding:
         # separate launch on the current stream): the table gradient in grad_sink is complete only once that stream
         # has been waited for.
         self.scatter_stream = None
+        # optional: the forward also stores d feat / d x (384 B per point) whenever x requires grad, and a first-order
+        # backward (no create_graph) then gets d/dx from it instead of re-walking the table
+        self.save_jacobian = False
 
     def get_out_dim(self):
         return self.cfg[0] * self.cfg[1]
@@ -151,14 +169,15 @@ class TCNNEncoding:
     def forward(self, x):
         if x.dim() != 2 or x.shape[1] != 3:
             raise RuntimeError("TCNNEncoding.forward: expected [B,3]")
-        return _GridFwd.apply(x, self.params_.view(-1, self.cfg[1]), self.cfg, self.grad_sink, self.scatter_stream)
+        return _GridFwd.apply(x, self.params_.view(-1, self.cfg[1]), self.cfg, self.grad_sink, self.scatter_stream,
+                              self.save_jacobian)
 
     __call__ = forward
 
 
 class _MlpFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weights, biases, dims):
+    def forward(ctx, x, weights, biases, dims, sinks=None, aux_stream=None):
         L = capi.lib()
         x, weights = x.contiguous(), weights.contiguous()
         B, nl = x.shape[0], len(dims) - 1
@@ -169,7 +188,7 @@ class _MlpFn(torch.autograd.Function):
         capi.check(_timed("mlp_fwd", L.gsdf_mlp_fwd, B, nl, dims_c, f32(weights, "weights"), f32(biases), f32(x, "x"),
                           f32(out), f32(acts), capi.stream()), "mlp_fwd")
         ctx.save_for_backward(x, weights, biases, acts)
-        ctx.dims = dims
+        ctx.dims, ctx.sinks, ctx.aux_stream = dims, sinks, aux_stream
         return out
 
     @staticmethod
@@ -179,13 +198,35 @@ class _MlpFn(torch.autograd.Function):
         dims = ctx.dims
         B, nl = x.shape[0], len(dims) - 1
         dims_c = (C.c_int * len(dims))(*dims)
+        v_out = v_out.contiguous()
         v_in = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        ws = torch.empty(L.gsdf_mlp_bwd_ws_bytes(B, nl), dtype=torch.uint8, device=x.device)
+        if ctx.sinks is not None and ctx.needs_input_grad[1]:
+            # trainer fast path: the parameter gradients ACCUMULATE straight into the flat gradient buffer (no zero-fill,
+            # no autograd add), and their kernel runs on `aux_stream` so that d/d input — what the rest of the backward
+            # pass waits for — is not queued behind it.  The gradients are complete once aux_stream has been waited for.
+            w_sink, b_sink = ctx.sinks
+            capi.check(_timed("mlp_bwd_data", L.gsdf_mlp_bwd, B, nl, dims_c, f32(weights), f32(biases), f32(x), f32(acts),
+                              f32(v_out), f32(v_in), None, None, ptr(ws), capi.stream()), "mlp_bwd")
+
+            def weights_half():
+                capi.check(_timed("mlp_bwd_weights", L.gsdf_mlp_bwd_weights, B, nl, dims_c, int(biases is not None), f32(x),
+                                  f32(acts), f32(v_out), ptr(ws), f32(w_sink), f32(b_sink), capi.stream()), "mlp_bwd_weights")
+            aux = ctx.aux_stream
+            if aux is None:
+                weights_half()
+            else:
+                aux.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(aux):
+                    weights_half()
+                for t in (x, acts, v_out, ws):
+                    t.record_stream(aux)
+            return v_in, None, None, None, None, None
         v_w = torch.zeros_like(weights) if ctx.needs_input_grad[1] else None
         v_b = torch.zeros_like(biases) if (biases is not None and ctx.needs_input_grad[2]) else None
-        ws = torch.empty(L.gsdf_mlp_bwd_ws_bytes(B, nl), dtype=torch.uint8, device=x.device)
         capi.check(_timed("mlp_bwd", L.gsdf_mlp_bwd, B, nl, dims_c, f32(weights), f32(biases), f32(x), f32(acts),
-                          f32(v_out.contiguous()), f32(v_in), f32(v_w), f32(v_b), ptr(ws), capi.stream()), "mlp_bwd")
-        return v_in, v_w, v_b, None
+                          f32(v_out), f32(v_in), f32(v_w), f32(v_b), ptr(ws), capi.stream()), "mlp_bwd")
+        return v_in, v_w, v_b, None, None, None
 
 
 class TCNNNetwork:
@@ -208,11 +249,14 @@ class TCNNNetwork:
             bs.append((torch.rand(o, generator=g) * 2 - 1) * bound)
         self.params_ = torch.cat(ws).to(device).requires_grad_(True)
         self.biases_ = torch.cat(bs).to(device).requires_grad_(True) if bias else None
+        # optional (set by LocalMap.flatten): pre-zeroed buffers shaped like params_ / biases_ into which the parameter
+        # gradients are accumulated IN PLACE, and a stream for that half of the backward (see _MlpFn.backward)
+        self.grad_sinks, self.aux_stream = None, None
 
     def forward(self, x):
         if x.dim() != 2 or x.shape[1] != self.dims[0]:
             raise RuntimeError(f"TCNNNetwork.forward: expected [B,{self.dims[0]}]")
-        return _MlpFn.apply(x, self.params_, self.biases_, tuple(self.dims))
+        return _MlpFn.apply(x, self.params_, self.biases_, tuple(self.dims), self.grad_sinks, self.aux_stream)
 
     __call__ = forward
 
@@ -330,6 +374,9 @@ class LocalMap:
                 self.decoder.biases_ = views[2]
         if accumulate_table_grad_in_place:
             self.encoder.grad_sink = self.encoder.params_.grad
+            if not isinstance(self.decoder, torch.nn.Module):
+                self.decoder.grad_sinks = (self.decoder.params_.grad,
+                                           None if self.decoder.biases_ is None else self.decoder.biases_.grad)
         return FlatGroup(flat, flat_grad)
 
     # ---- occupancy structure: SubMap (sub_map.cpp:7-80) + LocalMap::sample / filter_sample (local_map.cpp:449-516) ------

@@ -171,6 +171,12 @@ int64_t gsdf_hashgrid_offsets(int n_levels, int n_feat, int log2_hashmap, int ba
                               int64_t *offsets_host);
 int gsdf_hashgrid_fwd(int64_t B, int n_levels, int n_feat, int log2_hashmap, int base_res, float per_level_scale,
                       const float *x, const float *table, float *feat, gsdf_stream_t stream);
+/* First-order fast path for d/dx: the forward also stores jac [B, n_levels*n_feat, 3] = d feat / d x (384 B per point at
+ * 16x2), and v_x[b] = sum_k v_feat[b][k] * jac[b][k] is then a dense contraction (no second pass over the table). */
+int gsdf_hashgrid_fwd_jac(int64_t B, int n_levels, int n_feat, int log2_hashmap, int base_res, float per_level_scale,
+                          const float *x, const float *table, float *feat, float *jac, gsdf_stream_t stream);
+int gsdf_hashgrid_bwd_jac(int64_t B, int n_levels, int n_feat, const float *jac, const float *v_feat, float *v_x,
+                          gsdf_stream_t stream);
 /* v_table ACCUMULATES (zero it first), v_x is overwritten; either may be NULL. */
 int gsdf_hashgrid_bwd(int64_t B, int n_levels, int n_feat, int log2_hashmap, int base_res, float per_level_scale,
                       const float *x, const float *table, const float *v_feat, float *v_table, float *v_x,
@@ -196,6 +202,11 @@ size_t gsdf_mlp_bwd_ws_bytes(int64_t B, int n_layers);
 int gsdf_mlp_bwd(int64_t B, int n_layers, const int *dims_host, const float *weights, const float *biases,
                  const float *in, const float *acts, const float *v_out, float *v_in, float *v_weights,
                  float *v_biases, void *ws, gsdf_stream_t stream);
+/* The weight-gradient half alone, for callers that run it on another stream: `ws` must hold the result of a preceding
+ * gsdf_mlp_bwd(..., v_weights = NULL, ..., ws) on the same arguments.  v_weights / v_biases ACCUMULATE. */
+int gsdf_mlp_bwd_weights(int64_t B, int n_layers, const int *dims_host, int has_biases, const float *in,
+                         const float *acts, const float *v_out, const void *ws, float *v_weights, float *v_biases,
+                         gsdf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * K1  distCUDA2(points) (simple-knn)          reference call: include/neural_gaussian/neural_gaussian.cpp:314

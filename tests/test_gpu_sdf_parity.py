@@ -285,3 +285,31 @@ def test_fused_ray_loss_elementwise_against_fp64_torch(sdf):
     assert_close(got, want.float().to(dev), 1e-5, "loss")
     assert_close(v_got, 3.0 * v_want.float().to(dev), 1e-4, "d loss / d attr")
     assert float(v_got[n:, 1].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("B", [1, 7, 4099])
+def test_saved_jacobian_input_gradient_equals_table_walk(sdf, B):
+    """TCNNEncoding.save_jacobian: d/dx from the Jacobian stored by the forward == the backward kernel's d/dx, and the
+    second-order path (create_graph) is untouched by the option."""
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(B)
+    x0 = torch.rand(B, 3, generator=g).to(dev)
+    v = torch.randn(B, 32, generator=g).to(dev)
+    out = {}
+    for jac in (False, True):
+        enc = sdf.TCNNEncoding(3, None, "enc", dev, seed=3)
+        with torch.no_grad():
+            enc.params_.mul_(1e3)
+        enc.save_jacobian = jac
+        x = x0.clone().requires_grad_(True)
+        f = enc.forward(x)
+        gx, gt = torch.autograd.grad((f * v).sum(), (x, enc.params_))
+        x2 = x0.clone().requires_grad_(True)
+        f2 = enc.forward(x2)
+        g1 = torch.autograd.grad((f2 * v).sum(), x2, create_graph=True)[0]
+        gg = torch.autograd.grad((g1 ** 2).sum(), enc.params_)[0]
+        out[jac] = (f.detach(), gx, gt, gg)
+    assert torch.equal(out[True][0], out[False][0])
+    assert_close(out[True][1], out[False][1], 1e-5, "d/dx (jacobian vs table walk)")
+    assert_close(out[True][2], out[False][2], 1e-5, "table gradient")
+    assert_close(out[True][3], out[False][3], 1e-5, "second-order table gradient")
