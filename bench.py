@@ -277,7 +277,12 @@ def main():
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                          "frac": achieved / 8000.0, "traffic": traffic, "algorithmic_bytes": alg[dom],
                          "avg_launch_ms": dur_ms, "launches_per_step": calls.get(dom, 0) / args.steps,
-                         "ms_per_step_by_kernel": {k: round(v, 4) for k, v in per_step.items()}, "step_B_splat_bytes": b_splat,
+                         "ms_per_step_by_kernel": {k: round(v, 4) for k, v in per_step.items()},
+                         # the same figure for the other large kernels (the scatter runs beside the rest of the step on
+                         # XCDs of its own; the compositing backward is the largest kernel on the splat leg)
+                         "others": {k: {"achieved": alg[k] / (kern[k] * 1e-3) / 1e9, "frac": alg[k] / (kern[k] * 1e-3) / 8e12,
+                                        "avg_launch_ms": kern[k]} for k in alg if k != dom and kern.get(k)},
+                         "step_B_splat_bytes": b_splat,
                          "step_hbm_frac": b_splat / (elapsed / args.steps) / 8e12},
             "kernel_ms": kern,
         }
