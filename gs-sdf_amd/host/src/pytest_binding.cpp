@@ -6,6 +6,9 @@
 #include "gsplat_cpp/fully_fused_projection.h"
 #include "gsplat_cpp/rasterize_to_pixels.h"
 #include "gsplat_cpp/rendering.h"
+#include "kaolin/csrc/render/spc/raytrace.h"
+#include "kaolin_wisp_cpp/octree_as/octree_as.h"
+#include "kaolin_wisp_cpp/spc_ops/spc_ops.h"
 #include "spatial.h"
 #include "tcnn_binding/tcnn_binding.h"
 
@@ -31,6 +34,23 @@ PYBIND11_MODULE(_gsdf_host, m) {
                                           packed, absg, distloss);
         });
   m.def("distCUDA2", &distCUDA2);
+  m.def("quantize_points", &spc_ops::quantize_points);
+  m.def("points_to_neighbors", &spc_ops::points_to_neighbors);
+  m.def("points_to_corners", &spc_ops::points_to_corners);
+  m.def("quantized_points_to_fpoints", &spc_ops::quantized_points_to_fpoints);
+  m.def("mark_pack_boundaries", &kaolin::mark_pack_boundaries_cuda);
+  py::class_<OctreeAS, std::shared_ptr<OctreeAS>>(m, "OctreeAS")
+      .def_static("from_quantized_points", [](const torch::Tensor &q, int level) {
+        return std::shared_ptr<OctreeAS>(from_quantized_points(q, level));          // as sub_map.cpp:33-34
+      })
+      .def("query", [](const OctreeAS &a, const torch::Tensor &x, int level) { return a.query(x, level).pidx; },
+           py::arg("xyz"), py::arg("level") = -1)
+      .def("raymarch", [](const OctreeAS &a, const torch::Tensor &o, const torch::Tensor &d, const std::string &t, int n) {
+        auto r = a.raymarch(o, d, t, n);
+        return std::make_tuple(r.ridx, r.samples, r.depth_samples);
+      })
+      .def("get_quantized_points", &OctreeAS::get_quantized_points)
+      .def_readonly("grid_", &OctreeAS::grid_);
   py::class_<TCNNEncoding, std::shared_ptr<TCNNEncoding>>(m, "TCNNEncoding")
       .def(py::init([](int n_levels, int n_feat, int log2_hashmap, int base_res, double pls) {
         nlohmann::json cfg = {{"otype", "Grid"}, {"type", "Hash"}, {"n_levels", n_levels}, {"n_features_per_level", n_feat},

@@ -443,3 +443,9 @@ def sample_ray_batch(local_map, origin, direction, depth, sample_std, truncated_
     pts.ray_sdf = torch.where(pts.ray_sdf.abs() > truncated_dis, pts.ray_sdf.sign() * truncated_dis, pts.ray_sdf)
     pts = pts.cat(rays)
     return pts.index_select(local_map.get_inrange_mask(pts.xyz).nonzero().reshape(-1))
+
+
+def isotropic_loss(scale, gaussian_ids):
+    """neural_mapping.cpp:267-276: mean |s - mean(s)| over the two in-plane scales of the visible splats."""
+    s = scale.index_select(0, gaussian_ids)[..., 0:2]
+    return (s - s.mean(-1, True)).abs().mean()

@@ -122,3 +122,42 @@ def test_distCUDA2(host, oracle, N):
         d, _ = cKDTree(pts.double().numpy()).query(pts.double().numpy(), k=4)
         ref = (d[:, 1:] ** 2).mean(1)
     assert_close(got_cpp, ref, 1e-4, "distCUDA2")
+
+
+def test_octree_as_cpp_matches_python_mirror_and_oracle(host, oracle):
+    """kaolin_wisp_cpp drop-in headers (spc_ops.h, octree_as.h) driven the way sub_map.cpp:22-35 / local_map.cpp:467-476
+    do: quantize -> unique -> neighbours -> clamp -> from_quantized_points; query; voxel ray march."""
+    from gs_sdf_amd.occupancy import OctreeAS, spc_ops
+    dev = torch.device("cuda:0")
+    L = 7
+    rng = np.random.default_rng(5)
+    u = rng.standard_normal((20000, 3))
+    pts = (0.55 * u / np.linalg.norm(u, axis=1, keepdims=True)).astype(np.float32)
+    x = torch.from_numpy(pts).to(dev)
+    q = host.quantize_points(x, L)
+    assert q.dtype == torch.int16 and torch.equal(q, spc_ops.quantize_points(x, L))
+    q = torch.unique(q.contiguous(), dim=0)
+    nb = host.points_to_neighbors(q)
+    assert nb.shape == (q.shape[0], 27, 3) and torch.equal(nb, spc_ops.points_to_neighbors(q))
+    assert torch.equal(host.points_to_corners(q), spc_ops.points_to_corners(q))
+    qn = nb.view(-1, 3).clamp(0, 2 ** L - 1)
+    acc = host.OctreeAS.from_quantized_points(qn, L)
+    ref = oracle.occ_build(L, pts, True)                            # same set of voxels: dilated quantised points
+    assert np.array_equal(acc.grid_.cpu().numpy().view(np.uint32), ref)
+    py = OctreeAS.from_points(x, L, dilate27=True)
+    assert torch.equal(acc.grid_, py.grid)
+    qp = (torch.rand(50000, 3, generator=torch.Generator().manual_seed(1)) * 2.2 - 1.1).to(dev)
+    for level in (-1, 4):
+        assert torch.equal(acc.query(qp, level), py.query(qp, level).pidx)
+    vox = acc.get_quantized_points()
+    assert torch.equal(vox, py.get_quantized_points()) and vox.dtype == torch.int16
+    assert torch.equal(host.quantized_points_to_fpoints(vox, L), spc_ops.quantized_points_to_fpoints(vox, L))
+    o = (torch.rand(3000, 3, generator=torch.Generator().manual_seed(2)) * 0.4 - 0.2).to(dev)
+    d = torch.nn.functional.normalize(torch.randn(3000, 3, generator=torch.Generator().manual_seed(3)), dim=1).to(dev)
+    ridx, samples, depth = acc.raymarch(o, d, "voxel", 2)
+    r2 = py.raymarch(o, d, "voxel", 2)
+    assert ridx.numel() > 6000 and torch.equal(ridx, r2.ridx) and torch.equal(samples, r2.samples) and torch.equal(depth, r2.depth_samples)
+    first = host.mark_pack_boundaries(ridx)
+    assert int(first.sum()) == int(torch.unique(ridx).numel()) and bool(first[0])
+    with pytest.raises(RuntimeError):
+        acc.raymarch(o, d, "ray", 2)
