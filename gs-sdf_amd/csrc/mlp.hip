@@ -14,6 +14,8 @@
 //   permuted order once per workgroup.  No transposes, no LDS round trip of activations, one
 //   conflict-free ds_read_b32 per MFMA.  ReLU/bias are applied on the accumulator registers.
 //   Weight gradients are a separate "tiny-MN, huge-K" MFMA GEMM (K = points) fed by coalesced row loads.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace gsdf {
@@ -352,8 +354,9 @@ static int make_desc(int n_layers, const int *dims, int has_bias, bool bwd, MlpD
 using namespace gsdf;
 
 static unsigned mlp_grid(int64_t B) {
+  static const int64_t cap = [] { const char *e = getenv("GSDF_MLP_MAX_WG"); return e ? (int64_t)atoi(e) : (int64_t)512; }();
   const int64_t wg = (B + 127) / 128;  // 4 tiles of 32 points per workgroup
-  return (unsigned)(wg < 1 ? 1 : (wg > 512 ? 512 : wg));
+  return (unsigned)(wg < 1 ? 1 : (wg > cap ? cap : wg));
 }
 
 extern "C" size_t gsdf_mlp_bwd_ws_bytes(int64_t B, int n_layers) {
