@@ -82,6 +82,10 @@ def main():
         import gs_sdf_amd.sdf as sdfm
         lm = sdfm.LocalMap([0.0, 0.0, 5.5], 16.0, bce_sigma=0.02, decoder_implementation=1, device=dev, seed=5)
         groups.append(lm.flatten(accumulate_table_grad_in_place=True))
+        # occupancy structure of the map (SubMap::update_octree_as, sub_map.cpp:22-35): leaf 1/16 m -> level 8 in the 16 m
+        # cube, built from the splat centres (the reference builds it from the depth point cloud the splats start from)
+        lm.set_bounds(16.0 - 2 * 0.0625, 0.0625)
+        lm.update_octree_as(params.anchors)
         gq = torch.Generator().manual_seed(4)
         pool = [((torch.rand(32768, 3, generator=gq) - 0.5) * 14.0 + torch.tensor([0.0, 0.0, 5.5])).to(dev) for _ in range(8)]
         ray_sdf = [(torch.randn(32768, 1, generator=gq) * 0.02).to(dev) for _ in range(8)]
@@ -151,7 +155,8 @@ def main():
             stamp("render issued (2 syncs)")
             vis = meta["visibilities"].detach()
             w_all = (meta["samples_weights"] * vis).detach()
-            ids = (vis > 0.1).squeeze(-1).nonzero().squeeze(-1)
+            valid = lm.get_valid_mask(meta["samples"].detach()) & (vis > 0.1).squeeze(-1)      # neural_mapping.cpp:430-432
+            ids = valid.nonzero().squeeze(-1)
             stamp("visible set (sync)")
             fwd_done = main.record_event()
             samples = meta["samples"]                                 # already behind join_grad(gate)

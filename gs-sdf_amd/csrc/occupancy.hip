@@ -98,13 +98,16 @@ __global__ void __launch_bounds__(256) occ_reduce_kernel(int l, OccLevels lv, ui
   }
 }
 
+// AFFINE: xyz are world coordinates, mapped to the cube frame as SubMap::xyz_to_m1p1_pts does, ((x - origin) * 2) * inv
+template <bool AFFINE>
 __global__ void __launch_bounds__(256)
-    occ_query_kernel(int l, OccLevels lv, int64_t n, const float *__restrict__ xyz, const uint32_t *__restrict__ grid,
-                     uint8_t *__restrict__ mask) {
+    occ_query_kernel(int l, OccLevels lv, int64_t n, const float *__restrict__ xyz, float ox, float oy, float oz, float inv,
+                     const uint32_t *__restrict__ grid, uint8_t *__restrict__ mask) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   const int res = 1 << l;
-  const float x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
+  float x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
+  if (AFFINE) { x = ((x - ox) * 2.0f) * inv; y = ((y - oy) * 2.0f) * inv; z = ((z - oz) * 2.0f) * inv; }
   const bool in = x >= -1.0f && x <= 1.0f && y >= -1.0f && y <= 1.0f && z >= -1.0f && z <= 1.0f;
   mask[i] = (uint8_t)(in && occ_bit(grid, lv, l, occ_quantize(x, res), occ_quantize(y, res), occ_quantize(z, res)));
 }
@@ -272,9 +275,24 @@ extern "C" int gsdf_occ_query(int level, int query_level, int64_t n, const float
   GSDF_REQUIRE(l >= 0 && l <= level, "occ_query: query level %d outside [0,%d]", l, level);
   if (n == 0) return GSDF_OK;
   GSDF_REQUIRE(n > 0 && xyz_m1p1 && grid && mask, "occ_query: bad arguments");
-  occ_query_kernel<<<(unsigned)((n + 255) / 256), 256, 0, stream>>>(l, make_levels(level), n, xyz_m1p1,
-                                                                    (const uint32_t *)grid, mask);
+  occ_query_kernel<false><<<(unsigned)((n + 255) / 256), 256, 0, stream>>>(l, make_levels(level), n, xyz_m1p1, 0.f, 0.f, 0.f,
+                                                                           1.f, (const uint32_t *)grid, mask);
   GSDF_CHECK_LAUNCH("occ_query_kernel");
+  return GSDF_OK;
+}
+
+extern "C" int gsdf_occ_query_world(int level, int query_level, int64_t n, const float *xyz_world, const float *origin_host,
+                                    float map_size_inv, const void *grid, uint8_t *mask, gsdf_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (int rc = check_level(level, "occ_query_world")) return rc;
+  const int l = query_level < 0 ? level : query_level;
+  GSDF_REQUIRE(l >= 0 && l <= level, "occ_query_world: query level %d outside [0,%d]", l, level);
+  if (n == 0) return GSDF_OK;
+  GSDF_REQUIRE(n > 0 && xyz_world && origin_host && grid && mask, "occ_query_world: bad arguments");
+  occ_query_kernel<true><<<(unsigned)((n + 255) / 256), 256, 0, stream>>>(l, make_levels(level), n, xyz_world, origin_host[0],
+                                                                          origin_host[1], origin_host[2], map_size_inv,
+                                                                          (const uint32_t *)grid, mask);
+  GSDF_CHECK_LAUNCH("occ_query_kernel<world>");
   return GSDF_OK;
 }
 

@@ -77,6 +77,16 @@ class OctreeAS:
                                              ptr(self.grid), ptr(mask), capi.stream()), "occ_query")
         return QueryResult(mask.to(torch.int64) - 1)
 
+    def query_world_mask(self, xyz_world, origin, map_size_inv, level=-1):
+        """bool [n]: `query(((xyz - origin) * 2) * map_size_inv, level).pidx > -1` in one launch (SubMap::get_valid_mask)."""
+        import ctypes as C
+        xyz = xyz_world.contiguous().float()
+        mask = torch.empty(xyz.shape[0], dtype=torch.bool, device=xyz.device)
+        capi.check(capi.lib().gsdf_occ_query_world(self.level, -1 if level is None else int(level), xyz.shape[0], f32(xyz),
+                                                   (C.c_float * 3)(*origin), float(map_size_inv), ptr(self.grid),
+                                                   ptr(mask), capi.stream()), "occ_query_world")
+        return mask
+
     def get_quantized_points(self):
         """-> int16 [V,3] occupied finest-level voxels (x-fastest linear order)."""
         L = capi.lib()

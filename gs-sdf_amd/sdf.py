@@ -406,8 +406,8 @@ class LocalMap:
         from .occupancy import OctreeAS
         self.acc_struct_occ = OctreeAS.from_points(self.xyz_to_m1p1_pts(xyz), self.octree_level, dilate27=not is_prior)
 
-    def get_valid_mask(self, xyz, level=-1):       # sub_map.cpp:76-80
-        return self.acc_struct_occ.query(self.xyz_to_m1p1_pts(xyz), level).pidx > -1
+    def get_valid_mask(self, xyz, level=-1):       # sub_map.cpp:76-80 (normalisation + query + "> -1" in one launch)
+        return self.acc_struct_occ.query_world_mask(xyz, self._origin, self.map_size_inv, level)
 
     def get_inrange_mask(self, xyz, padding=0.0):  # sub_map.cpp:37-45
         return ((xyz < self.xyz_max_W - padding - 1e-6) & (xyz > self.xyz_min_W + padding + 1e-6)).all(1)

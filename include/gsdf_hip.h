@@ -267,6 +267,9 @@ size_t gsdf_occ_bytes(int level);
 int gsdf_occ_build(int level, int64_t n_points, const float *xyz_m1p1, int dilate27, void *grid, gsdf_stream_t stream);
 int gsdf_occ_query(int level, int query_level, int64_t n, const float *xyz_m1p1, const void *grid, uint8_t *mask,
                    gsdf_stream_t stream);
+/* query with the SubMap::xyz_to_m1p1_pts transform ((x - origin) * 2) * map_size_inv folded in (origin_host: 3 HOST floats) */
+int gsdf_occ_query_world(int level, int query_level, int64_t n, const float *xyz_world, const float *origin_host,
+                         float map_size_inv, const void *grid, uint8_t *mask, gsdf_stream_t stream);
 int gsdf_occ_voxel_counts(int level, const void *grid, int32_t *word_counts, gsdf_stream_t stream);
 int gsdf_occ_voxel_list(int level, const void *grid, const int64_t *word_offsets, int16_t *voxels, gsdf_stream_t stream);
 int gsdf_occ_raymarch_count(int level, int64_t n_rays, const float *origins_m1p1, const float *dirs, const void *grid,

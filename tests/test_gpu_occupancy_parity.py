@@ -96,6 +96,11 @@ def test_local_map_sampler_matches_composition_of_oracle_pieces():
     ref = orc.occ_build(level, m1p1, True)
     assert np.array_equal(lm.acc_struct_occ.grid.cpu().numpy().view(np.uint32), ref)
     assert bool(lm.get_valid_mask(torch.from_numpy(surf).to(dev)).all())
+    probe = (torch.rand(200_000, 3, generator=torch.Generator().manual_seed(9)) * 30.0 - 15.0).to(dev)
+    for ql in (-1, 5):
+        composed = lm.acc_struct_occ.query(lm.xyz_to_m1p1_pts(probe), ql).pidx > -1
+        fused = lm.get_valid_mask(probe, ql)
+        assert fused.dtype == torch.bool and torch.equal(fused, composed) and 0 < int(fused.sum()) < probe.shape[0]
     # rays from the centre outwards with the true depth of the sphere
     n = 5000
     dirs = rng.standard_normal((n, 3)).astype(np.float32)
