@@ -41,6 +41,18 @@ __device__ __forceinline__ int d_row(int r, int h) { return (r & 3) + 8 * (r >> 
 // K permutation of a 64-wide hidden operand: k-step s in [0,32) -> neuron
 __device__ __forceinline__ int perm_hidden(int s, int h) { return 32 * (s >> 4) + d_row(s & 15, h); }
 
+// "Register image" layout of the tensors that only travel between these kernels (saved activations, v_pre):
+// [slot][tile of 32 points][half t][lane 0..63][r 0..15] holds neuron 32 t + d_row(r, lane >> 5) of point 32 tile + (lane & 31),
+// i.e. exactly the 16 accumulator registers of a lane.  A wave stores / loads its D tile as 64 lanes x 64 contiguous
+// bytes (4 KiB per instruction group) instead of 32 scattered 16-byte pieces per instruction, and the weight-gradient
+// GEMM reads operand rows as two 64-byte runs.  Rows are padded to whole tiles: gsdf_mlp_acts_floats().
+__device__ __forceinline__ int64_t img_off(int64_t slot, int64_t n_tiles, int64_t tile, int t, int lane) {
+  return ((((slot * n_tiles + tile) * 2 + t) * 64 + lane) * 16);
+}
+// the lane/register that holds neuron-in-tile j (0..31) of a point: lane half = (j >> 2) & 1, r = (j & 3) + 4 (j >> 3)
+__device__ __forceinline__ int img_half_of(int j) { return (j >> 2) & 1; }
+__device__ __forceinline__ int img_reg_of(int j) { return (j & 3) + 4 * (j >> 3); }
+
 __device__ __forceinline__ v16f mfma32(float a, float b, v16f c) {
   return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
@@ -88,7 +100,6 @@ __global__ void __launch_bounds__(MLP_THREADS)
   const int h = lane >> 5, pl = lane & 31;
   constexpr int K0 = D_IN / 2;
   const int64_t n_tiles = (B + 31) / 32;
-  const int act_stride = HID * (d.n_layers - 1);
   for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < n_tiles; tile += (int64_t)gridDim.x * 4) {
     const int64_t p = tile * 32 + pl;
     const bool live = p < B;
@@ -121,14 +132,14 @@ __global__ void __launch_bounds__(MLP_THREADS)
     }
     // ---- hidden layers and output layer
     for (int l = 1; l < d.n_layers; ++l) {
-      if (acts != nullptr && live) {  // post-ReLU activations of layer l-1, point-major rows of 64
-        float *a = acts + p * act_stride + (l - 1) * HID;
+      if (acts != nullptr) {  // post-ReLU activations of layer l-1 as a register image (dead lanes of the last tile too)
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < 2; ++t) {
+          float4 *a = reinterpret_cast<float4 *>(acts + img_off(l - 1, n_tiles, tile, t, lane));
 #pragma unroll
           for (int q = 0; q < 4; ++q)
-            *reinterpret_cast<float4 *>(a + 32 * t + 8 * q + 4 * h) =
-                make_float4(cur[t][4 * q], cur[t][4 * q + 1], cur[t][4 * q + 2], cur[t][4 * q + 3]);
+            a[q] = make_float4(cur[t][4 * q], cur[t][4 * q + 1], cur[t][4 * q + 2], cur[t][4 * q + 3]);
+        }
       }
       const float *w = lds_w + d.lds_off[l];
       const bool last = l == d.n_layers - 1;
@@ -196,7 +207,6 @@ __global__ void __launch_bounds__(MLP_THREADS)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int h = lane >> 5, pl = lane & 31;
   const int64_t n_tiles = (B + 31) / 32;
-  const int act_stride = HID * (d.n_layers - 1);
   for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < n_tiles; tile += (int64_t)gridDim.x * 4) {
     const int64_t p = tile * 32 + pl;
     const bool live = p < B;
@@ -210,6 +220,15 @@ __global__ void __launch_bounds__(MLP_THREADS)
     for (int l = d.n_layers - 1; l >= 1; --l) {
       const float *w = lds_w + d.lds_off[l];
       const bool last = l == d.n_layers - 1;
+      // the ReLU mask of layer l-1 (its saved activations) does not depend on the MFMAs below: issue its loads first so
+      // that their latency hides behind the 32-64 MFMAs of this layer
+      float4 hv[2][4];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const float4 *a = reinterpret_cast<const float4 *>(acts + img_off(l - 1, n_tiles, tile, t, lane));
+#pragma unroll
+        for (int q = 0; q < 4; ++q) hv[t][q] = a[q];
+      }
       v16f ng[2];
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
@@ -232,21 +251,20 @@ __global__ void __launch_bounds__(MLP_THREADS)
         ng[t] = acc;
       }
       // ReLU mask of layer l-1's output, then persist v_pre_{l-1} for the weight-gradient GEMM
-      const float *a = acts + (live ? p : 0) * act_stride + (l - 1) * HID;
-      float *vp = v_pre_ws + ((int64_t)(l - 1) * B + (live ? p : 0)) * HID;
 #pragma unroll
-      for (int t = 0; t < 2; ++t)
+      for (int t = 0; t < 2; ++t) {
+        float4 *vp = reinterpret_cast<float4 *>(v_pre_ws + img_off(l - 1, n_tiles, tile, t, lane));
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const float4 hv = live ? *reinterpret_cast<const float4 *>(a + 32 * t + 8 * q + 4 * h) : make_float4(0, 0, 0, 0);
-          float4 o4;
-          o4.x = hv.x > 0.f ? ng[t][4 * q] : 0.f;
-          o4.y = hv.y > 0.f ? ng[t][4 * q + 1] : 0.f;
-          o4.z = hv.z > 0.f ? ng[t][4 * q + 2] : 0.f;
-          o4.w = hv.w > 0.f ? ng[t][4 * q + 3] : 0.f;
+          float4 o4;   // dead lanes carry g = 0 all the way down: their image rows are zeros
+          o4.x = hv[t][q].x > 0.f ? ng[t][4 * q] : 0.f;
+          o4.y = hv[t][q].y > 0.f ? ng[t][4 * q + 1] : 0.f;
+          o4.z = hv[t][q].z > 0.f ? ng[t][4 * q + 2] : 0.f;
+          o4.w = hv[t][q].w > 0.f ? ng[t][4 * q + 3] : 0.f;
           ng[t][4 * q] = o4.x; ng[t][4 * q + 1] = o4.y; ng[t][4 * q + 2] = o4.z; ng[t][4 * q + 3] = o4.w;
-          if (live) *reinterpret_cast<float4 *>(vp + 32 * t + 8 * q + 4 * h) = o4;
+          vp[q] = o4;
         }
+      }
       g[0] = ng[0]; g[1] = ng[1];
     }
     if (v_in != nullptr) {  // layer 0: v_in = W_0^T v_pre_0
@@ -277,7 +295,7 @@ __global__ void __launch_bounds__(MLP_THREADS)
 // backward, weight path: v_W_l[o][i] += sum_p v_pre_l[p][o] * h_in_l[p][i]   (K = points)
 // grid (k_chunks, n_layers); wave w owns output tile (mt = w>>1, nt = w&1)
 // ----------------------------------------------------------------------------------------------
-static constexpr int WG_KCHUNK = 256;  // points per workgroup
+static constexpr int WG_KCHUNK = 512;  // points per workgroup (one round of weight atomics per chunk)
 
 __global__ void __launch_bounds__(MLP_THREADS)
     mlp_bwd_weights_kernel(int64_t B, MlpDesc d, const float *__restrict__ in, const float *__restrict__ acts,
@@ -290,11 +308,15 @@ __global__ void __launch_bounds__(MLP_THREADS)
   const int O = l == d.n_layers - 1 ? d.d_out : HID;
   if (32 * mt >= O || 32 * nt >= I) return;
   const bool last = l == d.n_layers - 1;
-  const float *A = last ? v_out : v_pre_ws + (int64_t)l * B * HID;   // [p][lda]
-  const int lda = last ? d.d_out : HID;
-  const float *Hin = l == 0 ? in : acts + (l - 1) * HID;             // [p][ldh]
-  const int ldh = l == 0 ? d.d_in : HID * (d.n_layers - 1);
-  const int o = 32 * mt + (lane & 31), i = 32 * nt + (lane & 31), hh = lane >> 5;
+  const int64_t n_tiles = (B + 31) / 32;
+  const int n = lane & 31, hh = lane >> 5;
+  // A operand (rows = output neurons): v_out rows [p][d_out] for the last layer, else the v_pre image of slot l.
+  // B operand (cols = input neurons): the network input rows [p][d_in] for layer 0, else the activation image of slot l-1.
+  // For an image operand lane n serves neuron pi(n) = d_row(n & 15, n >> 4) of its 32-neuron tile: the 32 neurons of a
+  // point are then two runs of 16 consecutive floats (the registers of the point's two lanes in the image).
+  const bool a_img = !last, b_img = l != 0;
+  const int o = 32 * mt + (a_img ? d_row(n & 15, n >> 4) : n);   // output neuron this lane supplies as A row n
+  const int i = 32 * nt + (b_img ? d_row(n & 15, n >> 4) : n);   // input neuron this lane supplies as B column n
   const bool o_ok = o < O;
   v16f acc;
 #pragma unroll
@@ -302,25 +324,43 @@ __global__ void __launch_bounds__(MLP_THREADS)
   float bsum = 0.f;
   const int64_t p0 = (int64_t)blockIdx.x * WG_KCHUNK;
   const int64_t p1 = min(B, p0 + WG_KCHUNK);
-  for (int64_t pb = p0; pb < p1; pb += 16) {
-    float a[8], b[8];
+  // Operand addresses of a 16-point group pb..pb+15 (pb is a multiple of 16): base(pb) + s * stride, s = 0..7, so that the
+  // 8 loads of a group are one base computation + immediate offsets.  Image: the group lies in one tile,
+  // element = tile base + ((pb & 31) + 2 s + hh) * 16 (+ 512 for the neuron's second lane, + register n & 15).
+  const float *a0 = a_img ? v_pre_ws + img_off(l, n_tiles, 0, mt, 32 * (n >> 4) + hh) + (n & 15) : v_out + (int64_t)hh * d.d_out + o;
+  const float *b0 = b_img ? acts + img_off(l - 1, n_tiles, 0, nt, 32 * (n >> 4) + hh) + (n & 15) : in + (int64_t)hh * d.d_in + i;
+  const int a_stride = a_img ? 32 : 2 * d.d_out, b_stride = b_img ? 32 : 2 * d.d_in;
+  auto load16 = [&](int64_t pb, float (&ra)[8], float (&rb)[8]) {
+    const int64_t img_base = (pb >> 5) * 2048 + (pb & 31) * 16;
+    const float *ap = a0 + (a_img ? img_base : pb * d.d_out);
+    const float *bp = b0 + (b_img ? img_base : pb * d.d_in);
+    const int64_t left = p1 - pb - hh;   // point pb + 2 s + hh is valid while 2 s < left
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
-      const int64_t p = pb + 2 * s + hh;
-      const bool ok = p < p1;
-      a[s] = (ok && o_ok) ? A[p * lda + o] : 0.f;
-      b[s] = ok ? Hin[p * ldh + i] : 0.f;
+      const bool ok = 2 * s < left;
+      ra[s] = (ok && o_ok) ? ap[s * a_stride] : 0.f;
+      rb[s] = ok ? bp[s * b_stride] : 0.f;
     }
+  };
+  // software pipeline: the operands of the next 16 points are in flight while the 8 MFMAs of the current ones issue
+  float a[8], b[8], na[8], nb[8];
+  load16(p0, a, b);
+  for (int64_t pb = p0; pb < p1; pb += 16) {
+    load16(pb + 16, na, nb);   // past p1: predicated off, zeros
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
       acc = mfma32(a[s], b[s], acc);
       bsum += a[s];
     }
+#pragma unroll
+    for (int s = 0; s < 8; ++s) { a[s] = na[s]; b[s] = nb[s]; }
   }
+  // D[m][n']: row m = d_row(r, hh) is the A row supplied by lane m, column n' = this lane's B column
   float *vw = v_W + d.w_off[l];
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
-    const int oo = 32 * mt + d_row(r, hh);
+    const int m = d_row(r, hh);
+    const int oo = 32 * mt + (a_img ? d_row(m & 15, m >> 4) : m);
     if (oo < O && acc[r] != 0.f) atomicAdd(vw + oo * I + i, acc[r]);
   }
   if (v_b != nullptr && nt == 0) {
@@ -359,8 +399,11 @@ static unsigned mlp_grid(int64_t B) {
   return (unsigned)(wg < 1 ? 1 : (wg > cap ? cap : wg));
 }
 
+extern "C" size_t gsdf_mlp_acts_floats(int64_t B, int n_layers) {   // register images, rows padded to whole 32-point tiles
+  return (size_t)(n_layers > 1 ? n_layers - 1 : 0) * (size_t)((B + 31) / 32 * 32) * HID;
+}
 extern "C" size_t gsdf_mlp_bwd_ws_bytes(int64_t B, int n_layers) {
-  return (size_t)(n_layers > 1 ? n_layers - 1 : 0) * (size_t)B * HID * sizeof(float) + 256;
+  return gsdf_mlp_acts_floats(B, n_layers) * sizeof(float) + 256;
 }
 
 extern "C" int gsdf_mlp_fwd(int64_t B, int n_layers, const int *dims_host, const float *weights, const float *biases,

@@ -86,7 +86,7 @@ struct MlpFn : public torch::autograd::Function<MlpFn> {
     const int64_t B = x.size(0);
     Tensor out = empty_like_opts(x, {B, dims.back()}, torch::kFloat32);
     const bool need = x.requires_grad() || w.requires_grad();
-    Tensor acts = need ? empty_like_opts(x, {B, 64 * (nl - 1)}, torch::kFloat32) : Tensor();
+    Tensor acts = need ? empty_like_opts(x, {(int64_t)gsdf_mlp_acts_floats(B, nl)}, torch::kFloat32) : Tensor();
     check(gsdf_mlp_fwd(B, nl, dims.data(), fp(w), nullptr, fp(x), fpm(out), fpm(acts), cur_stream()), "TCNNNetwork forward");
     ctx->save_for_backward({x, w, acts});
     ctx->saved_data["dims"] = dims64;

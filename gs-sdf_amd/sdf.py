@@ -184,7 +184,7 @@ class _MlpFn(torch.autograd.Function):
         dims_c = (C.c_int * len(dims))(*dims)
         out = torch.empty(B, dims[-1], dtype=torch.float32, device=x.device)
         need = any(ctx.needs_input_grad[:3])
-        acts = torch.empty(B, 64 * (nl - 1), dtype=torch.float32, device=x.device) if need else None
+        acts = torch.empty(L.gsdf_mlp_acts_floats(B, nl), dtype=torch.float32, device=x.device) if need else None
         capi.check(_timed("mlp_fwd", L.gsdf_mlp_fwd, B, nl, dims_c, f32(weights, "weights"), f32(biases), f32(x, "x"),
                           f32(out), f32(acts), capi.stream()), "mlp_fwd")
         ctx.save_for_backward(x, weights, biases, acts)

@@ -193,10 +193,12 @@ int gsdf_hashgrid_bwd_bwd(int64_t B, int n_levels, int n_feat, int log2_hashmap,
  *     same kernel serves the default torch decoder topology with biases (local_map.cpp:29-42).
  * dims_host[n_layers+1] (HOST ints): input 32|64, hidden 64, output <= 32.  weights: torch Linear layout,
  * row-major [out][in] per layer, layers concatenated; biases concatenated or NULL.
- * acts [B, 64*(n_layers-1)] (post-ReLU hidden activations) is written when non-NULL and required by bwd.
+ * acts (gsdf_mlp_acts_floats(B, n_layers) floats; post-ReLU hidden activations in an OPAQUE tile layout that only
+ * gsdf_mlp_bwd* read) is written when non-NULL and required by bwd.
  * ---------------------------------------------------------------------------------------- */
 int gsdf_mlp_fwd(int64_t B, int n_layers, const int *dims_host, const float *weights, const float *biases,
                  const float *in, float *out, float *acts, gsdf_stream_t stream);
+size_t gsdf_mlp_acts_floats(int64_t B, int n_layers);
 size_t gsdf_mlp_bwd_ws_bytes(int64_t B, int n_layers);
 /* v_in [B,dims[0]] overwritten (may be NULL); v_weights / v_biases ACCUMULATE (may be NULL). */
 int gsdf_mlp_bwd(int64_t B, int n_layers, const int *dims_host, const float *weights, const float *biases,
