@@ -128,3 +128,38 @@ def from_quantized_points(qpts, level):
     """kaolin_wisp_cpp's factory (sub_map.cpp:33-34): builds from int voxel coordinates (their centres are re-quantised)."""
     centres = (qpts.to(torch.float32) + 0.5) * (2.0 / 2 ** level) - 1.0
     return OctreeAS.from_points(centres, level, dilate27=False)
+
+
+def write_points_ply(path, xyz):
+    """ply_utils::export_to_ply of a bare point set: binary little-endian PLY, float x y z."""
+    import numpy as np
+    pts = xyz.detach().cpu().float().numpy().astype("<f4")
+    with open(path, "wb") as f:
+        f.write(("ply\nformat binary_little_endian 1.0\nelement vertex %d\nproperty float x\nproperty float y\n"
+                 "property float z\nend_header\n" % pts.shape[0]).encode("ascii"))
+        f.write(np.ascontiguousarray(pts).tobytes())
+
+
+def read_points_ply(path, device="cpu"):
+    """-> {"xyz": [n,3]} from a binary little-endian PLY whose vertex element starts with float x y z
+    (ply_utils::read_ply_file_to_map_tensor as neural_mapping.cpp:1369-1373 uses it)."""
+    import numpy as np
+    with open(path, "rb") as f:
+        names, n, fmt = [], 0, None
+        while True:
+            line = f.readline().decode("ascii").strip()
+            if line.startswith("format"):
+                fmt = line.split()[1]
+            elif line.startswith("element vertex"):
+                n = int(line.split()[2])
+            elif line.startswith("property"):
+                parts = line.split()
+                if parts[1] != "float":
+                    raise RuntimeError("read_points_ply: only float properties are supported")
+                names.append(parts[2])
+            elif line == "end_header":
+                break
+        if fmt != "binary_little_endian" or names[:3] != ["x", "y", "z"]:
+            raise RuntimeError("read_points_ply: expected binary_little_endian with leading x y z")
+        data = np.frombuffer(f.read(n * len(names) * 4), dtype="<f4").reshape(n, len(names))
+    return {"xyz": torch.from_numpy(np.array(data[:, :3], dtype=np.float32)).to(device)}

@@ -439,6 +439,17 @@ class LocalMap:
             out = out.cat(free)
         return out.index_select((out.ray_sdf > 0).reshape(-1).nonzero().reshape(-1))
 
+    def export_as_occ_prior(self, path):
+        """as_occ_prior.ply (neural_mapping.cpp:755-762): the occupied voxels' minimum corners in world coordinates."""
+        from .occupancy import spc_ops, write_points_ply
+        vox = self.acc_struct_occ.get_quantized_points()
+        write_points_ply(path, self.m1p1_pts_to_xyz(spc_ops.quantized_points_to_fpoints(vox, self.octree_level)))
+
+    def load_as_occ_prior(self, path):
+        """checkpoint load (neural_mapping.cpp:1367-1373): update_octree_as(xyz, is_prior=true)."""
+        from .occupancy import read_points_ply
+        self.update_octree_as(read_points_ply(path, self.pos_W_M.device)["xyz"], is_prior=True)
+
     def filter_sample(self, samples):              # local_map.cpp:511-516
         keep = (self.acc_struct_occ.query(self.xyz_to_m1p1_pts(samples.xyz)).pidx > -1).nonzero().reshape(-1)
         return samples.index_select(keep)

@@ -125,3 +125,25 @@ def test_local_map_sampler_matches_composition_of_oracle_pieces():
     assert float(batch.ray_sdf.abs().max()) <= 0.15 + 1e-6 and bool(lm.get_inrange_mask(batch.xyz).all())
     kept = lm.filter_sample(batch)
     assert 0 < kept.xyz.shape[0] < batch.xyz.shape[0]
+
+
+def test_as_occ_prior_ply_round_trip(tmp_path):
+    """export (voxel minimum corners, neural_mapping.cpp:755-762) -> load with is_prior (:1367-1373) rebuilds the same
+    structure; the map size is a power of two times the leaf, so the corner coordinates are exact in fp32."""
+    import gs_sdf_amd.sdf as sdfm
+    lm = sdfm.LocalMap([1.0, -2.0, 0.5], 256 * 0.0625, device=dev, seed=0)
+    lm.set_bounds(16.0 - 0.125, 0.0625)
+    g = torch.Generator().manual_seed(4)
+    pts = ((torch.rand(50_000, 3, generator=g) - 0.5) * 12.0 + torch.tensor([1.0, -2.0, 0.5])).to(dev)
+    lm.update_octree_as(pts)
+    before = lm.acc_struct_occ.grid.clone()
+    path = str(tmp_path / "as_occ_prior.ply")
+    lm.export_as_occ_prior(path)
+    lm.acc_struct_occ = None
+    lm.load_as_occ_prior(path)
+    assert torch.equal(lm.acc_struct_occ.grid, before)
+    # voxel corners sit exactly on cell boundaries: move them to the centres for a robust second check
+    from gs_sdf_amd.occupancy import read_points_ply
+    xyz = read_points_ply(path, dev)["xyz"]
+    assert xyz.shape[0] == int(lm.acc_struct_occ.get_quantized_points().shape[0])
+    assert bool(lm.get_valid_mask(xyz + 0.5 * 0.0625).all())
