@@ -84,6 +84,24 @@ __global__ void __launch_bounds__(256)
   if ((threadIdx.x & 63) == 63 && ws != 0.f) atomicAdd(loss, ws);
 }
 
+// loss::gs_sdf_loss (/root/reference/include/optimizer/loss.cpp:7-11): 0.5 * sum_i w_i * sdf_i^2, with the row gather of
+// the weights (neural_mapping.cpp:436-437) folded in: w_i = weights[ids[i]] (ids == nullptr: w_i = weights[i]).
+__global__ void __launch_bounds__(256)
+    gs_sdf_loss_kernel(int64_t n, const float *__restrict__ attr, int ld, const float *__restrict__ weights,
+                       const int64_t *__restrict__ ids, float scale, float *__restrict__ loss, float *__restrict__ v_attr) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  float contrib = 0.f;
+  if (i < n) {
+    const float s = attr[i * ld];
+    const float w = weights[ids != nullptr ? ids[i] : i];
+    contrib = 0.5f * scale * w * s * s;
+    v_attr[i * ld] = scale * w * s;
+    for (int c = 1; c < ld; ++c) v_attr[i * ld + c] = 0.f;
+  }
+  const float ws = wave_sum_to_lane63(contrib);
+  if ((threadIdx.x & 63) == 63 && ws != 0.f) atomicAdd(loss, ws);
+}
+
 }  // namespace gsdf
 
 using namespace gsdf;
@@ -111,5 +129,17 @@ extern "C" int gsdf_sdf_ray_loss(int64_t n, int stencil, const float *attr, int 
   sdf_ray_loss_kernel<<<(unsigned)((n + 255) / 256), 256, 0, stream>>>(n, stencil, attr, ld, gt_sdf, bce_isigma, delta,
                                                                        w_eik, loss, v_attr);
   GSDF_CHECK_LAUNCH("sdf_ray_loss_kernel");
+  return GSDF_OK;
+}
+
+extern "C" int gsdf_gs_sdf_loss(int64_t n, const float *attr, int ld, const float *weights, const int64_t *ids, float scale,
+                                float *loss, float *v_attr, gsdf_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  GSDF_REQUIRE(n >= 0 && ld >= 1 && loss, "gs_sdf_loss: bad arguments");
+  GSDF_HIP(hipMemsetAsync(loss, 0, 4, stream), "gs_sdf_loss memset");
+  if (n == 0) return GSDF_OK;
+  GSDF_REQUIRE(attr && weights && v_attr, "gs_sdf_loss: null buffer");
+  gs_sdf_loss_kernel<<<(unsigned)((n + 255) / 256), 256, 0, stream>>>(n, attr, ld, weights, ids, scale, loss, v_attr);
+  GSDF_CHECK_LAUNCH("gs_sdf_loss_kernel");
   return GSDF_OK;
 }

@@ -324,6 +324,26 @@ class DepthSamples:
                                    else torch.cat([getattr(self, f), getattr(other, f)], 0)) for f in self.FIELDS})
 
 
+class _GsSdfLoss(torch.autograd.Function):
+    """scale * loss::gs_sdf_loss(attr[:, 0:1], weights[ids]) : value and gradient in one launch (gsdf_gs_sdf_loss)."""
+
+    @staticmethod
+    def forward(ctx, attr, weights, ids, scale):
+        attr, weights = attr.contiguous(), weights.contiguous().reshape(-1)
+        loss = torch.empty((), dtype=torch.float32, device=attr.device)
+        v_attr = torch.empty_like(attr)
+        capi.check(_timed("gs_sdf_loss", capi.lib().gsdf_gs_sdf_loss, attr.shape[0], f32(attr), attr.shape[1], f32(weights),
+                          ptr(None if ids is None else ids.contiguous(), torch.int64), float(scale), f32(loss), f32(v_attr),
+                          capi.stream()), "gs_sdf_loss")
+        ctx.save_for_backward(v_attr)
+        return loss
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, v_loss):
+        return ctx.saved_tensors[0] * v_loss, None, None, None
+
+
 class LocalMap:
     """The SDF half of the reference's `LocalMap` (include/neural_net/local_map.{h,cpp}): hash-grid encoder +
     decoder, `get_sdf`, `get_gradient` (numerical 6-point stencil or analytic via autograd)."""
@@ -464,6 +484,12 @@ class LocalMap:
 
     def get_feat(self, xyz, normalized=False):
         return self.encoder.forward(xyz if normalized else self.query_points(xyz))
+
+    def gs_sdf_loss(self, xyz, weights, ids=None, scale=1.0):
+        """scale * loss::gs_sdf_loss(get_sdf(xyz)[0], weights[ids]) (neural_mapping.cpp:436-462) with the decoder output
+        consumed by ONE loss launch (no slicing / square / mul / sum kernels, forward or backward)."""
+        attr = self.decoder(self.encoder.forward(self.query_points(xyz)))
+        return _GsSdfLoss.apply(attr, weights, ids, scale)
 
     def ray_loss(self, xyz, gt_sdf, delta, w_eik):
         """sdf_loss(get_sdf(xyz)) + w_eik * eikonal_loss(get_gradient(xyz, delta, numerical)) of the per-ray batch

@@ -242,6 +242,10 @@ int gsdf_adam_step(int64_t n, int n_segments, const int64_t *seg_begin_host, con
  * ---------------------------------------------------------------------------------------- */
 int gsdf_sdf_query_points(int64_t n, int stencil, const float *xyz, float delta, const float *origin_host,
                           float map_size_inv, float *out, gsdf_stream_t stream);
+ /*  gsdf_gs_sdf_loss: loss[0] = scale * 0.5 * sum_i w_i * attr[i][0]^2 (loss::gs_sdf_loss, loss.cpp:7-11), w_i =
+ *     weights[ids[i]] (the row selection of neural_mapping.cpp:436-437; ids NULL: weights[i]); v_attr = d loss / d attr. */
+int gsdf_gs_sdf_loss(int64_t n, const float *attr, int ld, const float *weights, const int64_t *ids, float scale,
+                     float *loss, float *v_attr, gsdf_stream_t stream);
 int gsdf_sdf_ray_loss(int64_t n, int stencil, const float *attr, int ld, const float *gt_sdf, float bce_isigma,
                       float delta, float w_eik, float *loss, float *v_attr, gsdf_stream_t stream);
 

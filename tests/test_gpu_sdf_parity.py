@@ -313,3 +313,27 @@ def test_saved_jacobian_input_gradient_equals_table_walk(sdf, B):
     assert_close(out[True][1], out[False][1], 1e-5, "d/dx (jacobian vs table walk)")
     assert_close(out[True][2], out[False][2], 1e-5, "table gradient")
     assert_close(out[True][3], out[False][3], 1e-5, "second-order table gradient")
+
+
+def test_fused_gs_sdf_loss_matches_the_reference_composition(sdf):
+    """LocalMap.gs_sdf_loss == scale * loss::gs_sdf_loss(get_sdf(x)[0], w[ids]) (loss.cpp:7-11, neural_mapping.cpp:436-462):
+    value, parameter gradients and the gradient w.r.t. the sample points."""
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(2)
+    M, n = 9000, 4000
+    pts = ((torch.rand(M, 3, generator=g) - 0.5) * 6.0).to(dev)
+    w_all = torch.rand(M, 1, generator=g).to(dev)
+    ids = torch.randperm(M, generator=g)[:n].sort().values.to(dev)
+    out = []
+    for fused in (False, True):
+        lm = sdf.LocalMap([0.1, 0.2, -0.3], 8.0, decoder_implementation=1, device=dev, seed=9)
+        with torch.no_grad():
+            lm.encoder.params_.mul_(1e3)
+        x = pts.clone().requires_grad_(True)
+        xs = x.index_select(0, ids)
+        loss = lm.gs_sdf_loss(xs, w_all, ids, 1e-3) if fused else 1e-3 * sdf.gs_sdf_loss(lm.get_sdf(xs)[0], w_all.index_select(0, ids))
+        out.append((loss.detach(), torch.autograd.grad(loss, [x] + lm.parameters())))
+    assert_close(out[1][0], out[0][0], 1e-5, "gs_sdf loss value")
+    for a, b, name in zip(out[1][1], out[0][1], ("points", "table", "mlp")):
+        assert float(b.abs().max()) > 0
+        assert_close(a, b, 2e-4, f"gs_sdf loss gradient wrt {name}")
