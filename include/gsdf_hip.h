@@ -285,6 +285,21 @@ int gsdf_occ_raymarch_fill(int level, int64_t n_rays, const float *origins_m1p1,
                            float *depth_samples, gsdf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * M1  marching cubes on a dense scalar grid [res_x][res_y][res_z] (x slowest): replaces mc::marching_cubes of the
+ *     reference's in-tree CUDA mesher (include/mesher/cumcubes/src/cumcubes_kernel.cu:7-282, include/cumcubes.hpp:10-19).
+ *     inside <=> value > thresh; one vertex per grid edge whose end points straddle thresh, at index + (thresh-d0)/(d1-d0)
+ *     along the edge, mapped to world as v * (upper-lower)/res + lower; faces index the vertices (int32, 0-based).
+ *     Two-phase: count -> n_vert[c] (0..3 edges owned by cell c) and n_tri[c] (0..5) per cell, c = (x*res_y + y)*res_z + z;
+ *     the caller scans both (exclusive, int64) and allocates; emit writes vertices [V,3] (by cell, then axis x,y,z) and
+ *     faces [F,3] (by cell, then table order).  The triangle table is derived (tools/gen_mc_table.py), watertight.
+ * ---------------------------------------------------------------------------------------- */
+int gsdf_mc_count(int res_x, int res_y, int res_z, const float *grid, float thresh, int32_t *n_vert, int32_t *n_tri,
+                  gsdf_stream_t stream);
+int gsdf_mc_emit(int res_x, int res_y, int res_z, const float *grid, float thresh, const int64_t *v_offsets,
+                 const int64_t *t_offsets, const float *lower_host, const float *upper_host, float *vertices,
+                 int32_t *faces, gsdf_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * O2  fused photometric loss  L = w_l1 * mean|I-G| + w_ssim * (1 - mean SSIM(I,G))  on [H,W,3] images:
  *     loss::rgb_loss + loss::dssim_loss (include/optimizer/loss/loss.cpp:22-47) with loss_utils::ssim
  *     (include/optimizer/loss_utils/loss_utils.cpp:71-117; 11-tap window of loss_utils.cpp:6-14 passed by the host,
