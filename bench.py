@@ -66,7 +66,7 @@ def main():
 
     import gs_sdf_amd.ops as ops
     import gs_sdf_amd.synth as synth
-    from gs_sdf_amd.trainer import FusedAdam, GradGate, SplatParams, ViewParallel
+    from gs_sdf_amd.trainer import FusedAdam, GradGate, SplatParams, ViewParallel, inject_grads
 
     N, W, H, deg, replica = WORKLOADS[args.workload]
     sc = synth.make_scene(N, W, H, sh_degree=deg, seed=0, replica=replica)
@@ -74,6 +74,7 @@ def main():
     K = sc["K"].to(dev)
     params = SplatParams.from_scene(sc, dev)
     ug = {k: v.to(dev) for k, v in synth.upstream_grads(H, W, seed=2).items()}
+    ug6 = {k: (1e-6 * v).contiguous() for k, v in ug.items()}       # the 1e-6 N(0,1) op-level upstream gradients, fixed
     target = torch.rand(H, W, 3, generator=torch.Generator().manual_seed(3)).to(dev)    # target image U(0,1) seed 3
     groups = []
     if not args.no_sdf:
@@ -172,10 +173,10 @@ def main():
                 gate.event = side.record_event() if side is not main else None     # d loss / d samples is complete
             stamp("samples leg issued")
         # colour: the reference's photometric loss 0.8 L1 + 0.2 D-SSIM (neural_mapping.cpp:237-240), fused HIP kernel;
-        # depth / alpha / normal / median: op-level N(0,1) upstream gradients so that every backward path is live
-        loss = (ops.l1_dssim_loss(meta["color"][0], target, 0.8, 0.2) + 1e-6 * (meta["depth"] * ug["v_render_depths"]).sum()
-                + 1e-6 * ((alphas * ug["v_render_alphas"]).sum() + (meta["render_normal"] * ug["v_render_normals"]).sum()
-                          + (meta["render_median"] * ug["v_render_median"]).sum()))
+        # depth / alpha / normal / median: op-level 1e-6 N(0,1) upstream gradients so that every backward path is live
+        loss = ops.l1_dssim_loss(meta["color"][0], target, 0.8, 0.2) + inject_grads(
+            [(meta["depth"], ug6["v_render_depths"]), (alphas, ug6["v_render_alphas"]),
+             (meta["render_normal"], ug6["v_render_normals"]), (meta["render_median"], ug6["v_render_median"])])
         stamp("loss issued")
         if not args.no_sdf and samples_cut.grad is not None:
             if side is not main:

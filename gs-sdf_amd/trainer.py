@@ -103,6 +103,30 @@ class ViewParallel:
             g.flat_grad.mul_(1.0 / self.world)
 
 
+class _InjectGrads(torch.autograd.Function):
+    """sum_k <x_k, g_k> as ONE autograd node whose backward hands the fixed upstream gradients g_k straight to the
+    producers of x_k (no per-term mul / sum / expand kernels).  Benchmark plumbing: op-level upstream gradients on the
+    render outputs that the photometric loss does not touch."""
+
+    @staticmethod
+    def forward(ctx, n, *tensors_and_grads):
+        xs, gs = tensors_and_grads[:n], tensors_and_grads[n:]
+        ctx.gs = gs
+        return torch.zeros((), dtype=xs[0].dtype, device=xs[0].device)     # the value is not used by anything
+
+    @staticmethod
+    def backward(ctx, v):
+        # v is 1 for a loss that is a plain sum of terms (asserted by the caller's test, not here: no host sync)
+        return (None,) + tuple(ctx.gs) + (None,) * len(ctx.gs)
+
+
+def inject_grads(pairs):
+    """pairs = [(tensor, upstream_gradient), ...] -> scalar 0 whose backward delivers the given gradients (times the
+    incoming gradient, which must be 1: add the result to the loss unscaled)."""
+    xs, gs = [p[0] for p in pairs], [p[1] for p in pairs]
+    return _InjectGrads.apply(len(xs), *xs, *gs)
+
+
 class GradGate:
     """Carries the HIP event that marks 'the gradient that flows in here is complete' from the stream that
     produces it to the stream that consumes it (see join_grad)."""
