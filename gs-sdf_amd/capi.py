@@ -61,6 +61,8 @@ _SIGS = {
     "gsdf_occ_raymarch_fill": (C.c_int, [_i32, _i64, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp]),
     "gsdf_mc_count": (C.c_int, [_i32, _i32, _i32, _vp, _f32, _vp, _vp, _vp]),
     "gsdf_mc_emit": (C.c_int, [_i32, _i32, _i32, _vp, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "gsdf_splat_activations_fwd": (C.c_int, [_i64] + [_vp] * 8),
+    "gsdf_splat_activations_bwd": (C.c_int, [_i64] + [_vp] * 9),
     "gsdf_adam_step": (C.c_int, [_i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _f32, _i64, _vp]),
     "gsdf_knn_ws_bytes": (_sz, [_i64]),
     "gsdf_knn_mean_dist2": (C.c_int, [_i64] + [_vp] * 4),

@@ -11,6 +11,36 @@ flatten/unflatten copies are needed.  The reference has no multi-GPU path at all
 import torch
 
 
+class _Activate(torch.autograd.Function):
+    """(offsets, scaling, opacity) -> (xyz, scales, opacities) in one launch; the backward accumulates straight into the
+    three parameters' gradient buffers (`sinks`, views of the flat gradient buffer) and returns no gradient to autograd."""
+
+    @staticmethod
+    def forward(ctx, anchors, offsets, scaling, opacity, sinks):
+        from . import capi
+        n = anchors.shape[0]
+        xyz, scales = torch.empty_like(anchors), torch.empty_like(scaling)
+        opac = torch.empty(n, dtype=torch.float32, device=anchors.device)
+        capi.check(capi.lib().gsdf_splat_activations_fwd(n, capi.f32(anchors), capi.f32(offsets), capi.f32(scaling),
+                                                         capi.f32(opacity), capi.f32(xyz), capi.f32(scales), capi.f32(opac),
+                                                         capi.stream()), "splat_activations_fwd")
+        ctx.save_for_backward(scales, opac)
+        ctx.sinks = sinks
+        return xyz, scales, opac
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, v_xyz, v_scales, v_opac):
+        from . import capi
+        scales, opac = ctx.saved_tensors
+        c = lambda g: None if g is None else g.contiguous()
+        g_off, g_sc, g_op = ctx.sinks
+        capi.check(capi.lib().gsdf_splat_activations_bwd(opac.shape[0], capi.f32(scales), capi.f32(opac), capi.f32(c(v_xyz)),
+                                                         capi.f32(c(v_scales)), capi.f32(c(v_opac)), capi.f32(g_off),
+                                                         capi.f32(g_sc), capi.f32(g_op), capi.stream()), "splat_activations_bwd")
+        return None, None, None, None, None
+
+
 class SplatParams:
     FIELDS = (("offsets", 3), ("scaling", 3), ("quaternion", 4), ("opacity", 1), ("features_dc", 3), ("features_rest", None))
 
@@ -45,9 +75,14 @@ class SplatParams:
         """generate_gaussian(): xyz = anchors+offsets, scales = exp, opacity = sigmoid, sh = cat(dc, rest)."""
         v = self.views
         N = self.anchors.shape[0]
-        xyz = self.anchors + v["offsets"]
-        scales = torch.exp(v["scaling"])
-        opacity = torch.sigmoid(v["opacity"]).reshape(N)
+        if self.anchors.is_cuda and torch.is_grad_enabled():
+            # one launch forward, one backward that accumulates into the flat gradient buffer (include/gsdf_hip.h, a2)
+            xyz, scales, opacity = _Activate.apply(self.anchors, v["offsets"], v["scaling"], v["opacity"],
+                                                   (v["offsets"].grad, v["scaling"].grad, v["opacity"].grad))
+        else:       # host tensors: only the CPU tests of the collective plumbing (gloo) come through here
+            xyz = self.anchors + v["offsets"]
+            scales = torch.exp(v["scaling"])
+            opacity = torch.sigmoid(v["opacity"]).reshape(N)
         dc = v["features_dc"].reshape(N, 1, 3)
         sh = dc if self.n_rest == 0 else torch.cat([dc, v["features_rest"].reshape(N, self.n_rest, 3)], 1)
         return xyz, v["quaternion"], scales, opacity, sh

@@ -300,6 +300,19 @@ int gsdf_mc_emit(int res_x, int res_y, int res_z, const float *grid, float thres
                  int32_t *faces, gsdf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * a2  splat parameter activations (NeuralGS::generate_gaussian / get_xyz / get_scale / get_opacity,
+ *     include/neural_gaussian/neural_gaussian.cpp:463-492): xyz = anchors + offsets, scales = exp(log_scales),
+ *     opacities = sigmoid(logit_opacities).  bwd ACCUMULATES into g_offsets / g_log_scales / g_logit_opacities (the
+ *     parameter-gradient buffers); any of the three upstream gradients may be NULL (treated as zero).
+ * ---------------------------------------------------------------------------------------- */
+int gsdf_splat_activations_fwd(int64_t n, const float *anchors, const float *offsets, const float *log_scales,
+                               const float *logit_opacities, float *xyz, float *scales, float *opacities,
+                               gsdf_stream_t stream);
+int gsdf_splat_activations_bwd(int64_t n, const float *scales, const float *opacities, const float *v_xyz,
+                               const float *v_scales, const float *v_opacities, float *g_offsets, float *g_log_scales,
+                               float *g_logit_opacities, gsdf_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * O2  fused photometric loss  L = w_l1 * mean|I-G| + w_ssim * (1 - mean SSIM(I,G))  on [H,W,3] images:
  *     loss::rgb_loss + loss::dssim_loss (include/optimizer/loss/loss.cpp:22-47) with loss_utils::ssim
  *     (include/optimizer/loss_utils/loss_utils.cpp:71-117; 11-tap window of loss_utils.cpp:6-14 passed by the host,

@@ -391,3 +391,28 @@ def test_pathological_splats_keep_parity(ops, oracle):
                                                       (rn, "v_render_normals"), (rm, "v_render_median")))
     loss.backward()
     chk(a[2].grad, "v_colors"); chk(a[3].grad, "v_opacities"); chk(a[1].grad, "v_ray_transforms"); chk(dens.grad, "v_densify")
+
+
+def test_fused_splat_activations_match_torch(ops):
+    """trainer.SplatParams.activated(): the fused activation kernel (xyz = anchors + offsets, exp, sigmoid) and its
+    in-place accumulating backward against the libtorch expressions of neural_gaussian.cpp:463-492."""
+    from gs_sdf_amd.trainer import SplatParams
+    dev = torch.device("cuda:0")
+    sc = synth.make_scene(5001, 64, 64, sh_degree=1, seed=3)
+    params = SplatParams.from_scene(sc, dev)
+    with torch.no_grad():
+        params.views["offsets"].normal_(0, 0.01)
+    params.flat_grad.fill_(0.25)                                   # the backward ACCUMULATES
+    xyz, quat, scales, opac, sh = params.activated()
+    v = params.views
+    assert torch.equal(xyz, params.anchors + v["offsets"])
+    assert_close(scales, torch.exp(v["scaling"]), 1e-6, "scales")
+    assert_close(opac, torch.sigmoid(v["opacity"]).reshape(-1), 1e-6, "opacities")
+    g = torch.Generator().manual_seed(0)
+    w = [torch.randn(t.shape, generator=g).to(dev) for t in (xyz, scales, opac)]
+    ((xyz * w[0]).sum() + (scales * w[1]).sum() + (opac * w[2]).sum()).backward()
+    o = torch.sigmoid(v["opacity"].detach()).reshape(-1)
+    assert_close(v["offsets"].grad, 0.25 + w[0], 1e-6, "d/d offsets")
+    assert_close(v["scaling"].grad, 0.25 + w[1] * torch.exp(v["scaling"].detach()), 1e-6, "d/d log-scales")
+    assert_close(v["opacity"].grad.reshape(-1), 0.25 + w[2] * o * (1 - o), 1e-6, "d/d logit-opacities")
+    assert float((v["quaternion"].grad - 0.25).abs().max()) == 0.0
