@@ -416,3 +416,22 @@ def test_fused_splat_activations_match_torch(ops):
     assert_close(v["scaling"].grad, 0.25 + w[1] * torch.exp(v["scaling"].detach()), 1e-6, "d/d log-scales")
     assert_close(v["opacity"].grad.reshape(-1), 0.25 + w[2] * o * (1 - o), 1e-6, "d/d logit-opacities")
     assert float((v["quaternion"].grad - 0.25).abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("N,W,H", [(9000, 40, 24), (30000, 64, 64)])
+def test_binning_long_tile_lists_bit_exact(ops, oracle, N, W, H):
+    """Very long tile lists (thousands of entries per tile) with many exactly equal depths: the tie order must be the stable
+    radix sort's (emission order == increasing splat index within a tile)."""
+    dev = torch.device("cuda:0")
+    sc = synth.make_scene(N, W, H, sh_degree=0, seed=12, sigma_px=(2.0, 9.0))
+    vm = synth.make_views(2, seed=4)[1:]
+    means, quats, scales, opac, sh, vmd, Kd = _inputs(sc, vm, dev)
+    cam, gid, radii, m2d, dep, rt, nrm, smp, sw = ops.fully_fused_projection_2dgs(means, quats, scales, vmd, Kd, W, H, 0.05,
+                                                                                  300.0, 0.0, True, False, 0)
+    dep = (torch.round(dep * 2) / 2).contiguous()                   # quantised depths: many exact ties inside a tile
+    tpg, flat, offs, ids = ops.tile_encode(W, H, 16, m2d, radii, dep, True, 1, cam, gid, return_isect_ids=True)
+    tpg_r, ids_r, flat_r, offs_r = oracle.tile_encode(W, H, 16, n(m2d), n(radii), n(dep), n(cam), 1)
+    counts = np.diff(np.concatenate([offs_r.reshape(-1), [flat_r.shape[0]]]))
+    assert counts.max() > 4096 and len(np.unique(n(dep))) < n(dep).shape[0] // 4
+    assert_equal_int(tpg, tpg_r, "tiles_per_gauss"); assert_equal_int(offs, offs_r, "isect_offsets")
+    assert_equal_int(ids, ids_r, "isect_ids"); assert_equal_int(flat, flat_r, "flatten_ids")
