@@ -16,16 +16,17 @@ class _Timers:
     """Optional per-operator device timing with HIP events on the launch stream (bench.py's roofline leg)."""
 
     def __init__(self):
-        self.on, self.ev = False, {}
+        self.on, self.ev, self.only = False, {}, None
 
-    def enable(self):
-        self.on, self.ev = True, {}
+    def enable(self, only=None):
+        """only: optional set of operator names to time (two events per launch cost ~10 us of host time each)."""
+        self.on, self.ev, self.only = True, {}, (None if only is None else set(only))
 
     def disable(self):
         self.on = False
 
     def start(self, name):
-        if not self.on:
+        if not self.on or (self.only is not None and name not in self.only):
             return None
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
