@@ -177,7 +177,7 @@ def main():
                     t.record_stream(side)               # out of main's allocator until side has passed this point
             with torch.cuda.stream(side):
                 if ids.numel() > 0:
-                    lm.gs_sdf_loss(samples_cut.index_select(0, ids), w_all, ids, 1e-3).backward()
+                    lm.gs_sdf_coupling(samples_cut, ids, w_all, 1e-3).backward()
                 gate.event = side.record_event() if side is not main else None     # d loss / d samples is complete
             stamp("samples leg issued")
         # colour: the reference's photometric loss 0.8 L1 + 0.2 D-SSIM (neural_mapping.cpp:237-240), fused HIP kernel;

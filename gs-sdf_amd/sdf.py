@@ -344,6 +344,95 @@ class _GsSdfLoss(torch.autograd.Function):
         return ctx.saved_tensors[0] * v_loss, None, None, None
 
 
+class _CouplingLeg(torch.autograd.Function):
+    """The GS<->SDF coupling term as ONE autograd node (trainer fast path; same kernels, same order, same results as
+    LocalMap.gs_sdf_loss on the composed operators): forward = row gather, query points, encoder (+ Jacobian), decoder,
+    loss; backward = decoder data / weight gradients, d/dx from the Jacobian, table scatter, row scatter.  Saves the
+    host time of ~10 autograd nodes per step, which sits on the step's critical path (the splat leg's backward is issued
+    after this leg).  Requires the in-place gradient sinks of LocalMap.flatten(accumulate_table_grad_in_place=True)."""
+
+    @staticmethod
+    def forward(ctx, samples, ids, weights, lm, scale):
+        L = capi.lib()
+        enc, dec = lm.encoder, lm.decoder
+        cfg, dims = enc.cfg, tuple(dec.dims)
+        xs = samples.index_select(0, ids)
+        n = xs.shape[0]
+        dev = xs.device
+        x01 = torch.empty(n, 3, dtype=torch.float32, device=dev)
+        capi.check(L.gsdf_sdf_query_points(n, 0, f32(xs), 0.0, (C.c_float * 3)(*lm._origin), float(lm.map_size_inv), f32(x01),
+                                           capi.stream()), "sdf_query_points")
+        table = enc.params_.view(-1, cfg[1])
+        nf = cfg[0] * cfg[1]
+        feat = torch.empty(n, nf, dtype=torch.float32, device=dev)
+        jac = torch.empty(n, nf, 3, dtype=torch.float32, device=dev)
+        capi.check(_timed("hashgrid_fwd", L.gsdf_hashgrid_fwd_jac, n, *cfg, f32(x01), f32(table), f32(feat), f32(jac),
+                          capi.stream()), "hashgrid_fwd_jac")
+        nl = len(dims) - 1
+        dims_c = (C.c_int * len(dims))(*dims)
+        attr = torch.empty(n, dims[-1], dtype=torch.float32, device=dev)
+        acts = torch.empty(L.gsdf_mlp_acts_floats(n, nl), dtype=torch.float32, device=dev)
+        capi.check(_timed("mlp_fwd", L.gsdf_mlp_fwd, n, nl, dims_c, f32(dec.params_), f32(dec.biases_), f32(feat), f32(attr),
+                          f32(acts), capi.stream()), "mlp_fwd")
+        loss = torch.empty((), dtype=torch.float32, device=dev)
+        v_attr = torch.empty_like(attr)
+        capi.check(_timed("gs_sdf_loss", L.gsdf_gs_sdf_loss, n, f32(attr), attr.shape[1], f32(weights.reshape(-1)), ptr(ids, torch.int64),
+                          float(scale), f32(loss), f32(v_attr), capi.stream()), "gs_sdf_loss")
+        ctx.save_for_backward(ids, x01, feat, jac, acts, v_attr)
+        ctx.lm, ctx.n_rows = lm, samples.shape[0]
+        return loss
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, v_loss):
+        L = capi.lib()
+        ids, x01, feat, jac, acts, v_attr = ctx.saved_tensors
+        lm = ctx.lm
+        enc, dec = lm.encoder, lm.decoder
+        cfg, dims = enc.cfg, tuple(dec.dims)
+        n, nl = x01.shape[0], len(dims) - 1
+        dims_c = (C.c_int * len(dims))(*dims)
+        v_out = v_attr * v_loss
+        v_feat = torch.empty_like(feat)
+        ws = torch.empty(L.gsdf_mlp_bwd_ws_bytes(n, nl), dtype=torch.uint8, device=x01.device)
+        capi.check(_timed("mlp_bwd_data", L.gsdf_mlp_bwd, n, nl, dims_c, f32(dec.params_), f32(dec.biases_), f32(feat), f32(acts),
+                          f32(v_out), f32(v_feat), None, None, ptr(ws), capi.stream()), "mlp_bwd")
+        w_sink, b_sink = dec.grad_sinks
+        cur = torch.cuda.current_stream()
+
+        def weights_half():
+            capi.check(_timed("mlp_bwd_weights", L.gsdf_mlp_bwd_weights, n, nl, dims_c, int(dec.biases_ is not None), f32(feat),
+                              f32(acts), f32(v_out), ptr(ws), f32(w_sink), f32(b_sink), capi.stream()), "mlp_bwd_weights")
+        if dec.aux_stream is None:
+            weights_half()
+        else:
+            dec.aux_stream.wait_stream(cur)
+            with torch.cuda.stream(dec.aux_stream):
+                weights_half()
+            for t in (feat, acts, v_out, ws):
+                t.record_stream(dec.aux_stream)
+        v_x = torch.empty_like(x01)
+        capi.check(_timed("hashgrid_bwd_input", L.gsdf_hashgrid_bwd_jac, n, cfg[0], cfg[1], f32(jac), f32(v_feat), f32(v_x),
+                          capi.stream()), "hashgrid_bwd_jac")
+        table = enc.params_.view(-1, cfg[1])
+        sink = enc.grad_sink.view(table.shape)
+
+        def scatter():
+            capi.check(_timed("hashgrid_bwd", L.gsdf_hashgrid_bwd, n, *cfg, f32(x01), f32(table), f32(v_feat), f32(sink), None,
+                              capi.stream()), "hashgrid_bwd")
+        if enc.scatter_stream is None:
+            scatter()
+        else:
+            enc.scatter_stream.wait_stream(cur)
+            with torch.cuda.stream(enc.scatter_stream):
+                scatter()
+            v_feat.record_stream(enc.scatter_stream)
+            x01.record_stream(enc.scatter_stream)
+        v_samples = torch.zeros(ctx.n_rows, 3, dtype=torch.float32, device=x01.device)
+        v_samples.index_add_(0, ids, v_x * float(lm.map_size_inv))          # d x01 / d xyz = 0.5 * 2 * map_size_inv
+        return v_samples, None, None, None, None
+
+
 class LocalMap:
     """The SDF half of the reference's `LocalMap` (include/neural_net/local_map.{h,cpp}): hash-grid encoder +
     decoder, `get_sdf`, `get_gradient` (numerical 6-point stencil or analytic via autograd)."""
@@ -490,6 +579,12 @@ class LocalMap:
         consumed by ONE loss launch (no slicing / square / mul / sum kernels, forward or backward)."""
         attr = self.decoder(self.encoder.forward(self.query_points(xyz)))
         return _GsSdfLoss.apply(attr, weights, ids, scale)
+
+    def gs_sdf_coupling(self, samples, ids, weights, scale=1.0):
+        """= gs_sdf_loss(samples[ids], weights, ids, scale), as a single autograd node (see _CouplingLeg)."""
+        if self.encoder.grad_sink is None or getattr(self.decoder, "grad_sinks", None) is None:
+            raise RuntimeError("gs_sdf_coupling needs LocalMap.flatten(accumulate_table_grad_in_place=True) with the fused decoder")
+        return _CouplingLeg.apply(samples, ids, weights, self, scale)
 
     def ray_loss(self, xyz, gt_sdf, delta, w_eik):
         """sdf_loss(get_sdf(xyz)) + w_eik * eikonal_loss(get_gradient(xyz, delta, numerical)) of the per-ray batch

@@ -337,3 +337,30 @@ def test_fused_gs_sdf_loss_matches_the_reference_composition(sdf):
     for a, b, name in zip(out[1][1], out[0][1], ("points", "table", "mlp")):
         assert float(b.abs().max()) > 0
         assert_close(a, b, 2e-4, f"gs_sdf loss gradient wrt {name}")
+
+
+def test_single_node_coupling_leg_equals_composed_operators(sdf):
+    """LocalMap.gs_sdf_coupling (one autograd node, in-place gradient sinks) == LocalMap.gs_sdf_loss on the composed
+    operators: loss, d/d samples and the flat parameter gradients."""
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(6)
+    M, n = 7000, 3100
+    pts = ((torch.rand(M, 3, generator=g) - 0.5) * 6.0).to(dev)
+    w_all = torch.rand(M, 1, generator=g).to(dev)
+    ids = torch.randperm(M, generator=g)[:n].sort().values.to(dev)
+    out = []
+    for fused in (False, True):
+        lm = sdf.LocalMap([0.1, 0.2, -0.3], 8.0, decoder_implementation=1, device=dev, seed=9)
+        with torch.no_grad():
+            lm.encoder.params_.mul_(1e3)
+        grp = lm.flatten(accumulate_table_grad_in_place=True)
+        lm.encoder.save_jacobian = True
+        x = pts.clone().requires_grad_(True)
+        loss = lm.gs_sdf_coupling(x, ids, w_all, 1e-3) if fused else lm.gs_sdf_loss(x.index_select(0, ids), w_all, ids, 1e-3)
+        loss.backward()
+        out.append((loss.detach(), x.grad.clone(), grp.flat_grad.clone()))
+    assert_close(out[1][0], out[0][0], 1e-6, "loss")
+    assert_close(out[1][1], out[0][1], 1e-5, "d/d samples")
+    assert_close(out[1][2], out[0][2], 1e-5, "flat parameter gradients")
+    with pytest.raises(RuntimeError):
+        sdf.LocalMap([0, 0, 0], 2.0, decoder_implementation=1, device=dev).gs_sdf_coupling(pts, ids, w_all)
