@@ -1,41 +1,37 @@
-"""Experiment (GPU box): does restricting the atomic-bound hash-grid backward to a CU subset (hipExtStreamCreateWithCUMask)
-keep its speed while leaving the rest of the chip usable by memory-bound kernels running beside it?"""
-import ctypes as C, sys, time
+"""Experiment (run on the GPU box): what does the atomic-bound hash-grid scatter do to kernels that run beside it on another
+stream, and which CU mask (hipExtStreamCreateWithCUMask) cures it?  This is the measurement behind gs_sdf_amd/streams.py.
+
+For each configuration three "victim" jobs (4 x 256 MB copies, L1 + D-SSIM forward + backward at 1080p, a 2.5 M-key
+radix sort) are timed alone and beside one scatter launch of 458 K points:
+  * unmasked side stream                       -> the victim finishes when the scatter finishes
+  * strided CU mask (every XCD shared)         -> same
+  * whole-XCD partition (scatter on the first k XCDs, victims on the rest) -> victims run at full speed
+Usage: python tools/exp_cumask.py"""
+import ctypes as C
+import sys
+
 import torch
+
 sys.path.insert(0, ".")
-import gs_sdf_amd.sdf as sdfm
+import gs_sdf_amd.ops as ops          # noqa: E402
+import gs_sdf_amd.sdf as sdfm         # noqa: E402
 
 hip = C.CDLL("libamdhip64.so")
 dev = torch.device("cuda:0")
+ALL = (1 << 256) - 1
 
 
 def masked_stream(bits):
     words = (C.c_uint32 * 8)(*[(bits >> (32 * i)) & 0xFFFFFFFF for i in range(8)])
     s = C.c_void_p()
-    rc = hip.hipExtStreamCreateWithCUMask(C.byref(s), 8, words)
-    assert rc == 0, rc
+    assert hip.hipExtStreamCreateWithCUMask(C.byref(s), 8, words) == 0
     return torch.cuda.ExternalStream(s.value)
 
 
-def pattern(n, kind):
-    if kind == "first":
-        return (1 << n) - 1
-    step = 256 // n
-    return sum(1 << i for i in range(0, 256, step))
-
-
 lm = sdfm.LocalMap([0.0, 0.0, 0.0], 2.0, decoder_implementation=1, device=dev, seed=1)
-grp = lm.flatten(accumulate_table_grad_in_place=True)
+lm.flatten(accumulate_table_grad_in_place=True)
 x = torch.rand(458000, 3, device=dev)
-big_a, big_b = torch.rand(64 << 20, device=dev), torch.empty(64 << 20, device=dev)   # 256 MB copy = 512 MB traffic
-
-
-def hg_bwd_job():
-    f = lm.encoder.forward(x)
-    return f
-
-
-import gs_sdf_amd.ops as ops
+big_a, big_b = torch.rand(64 << 20, device=dev), torch.empty(64 << 20, device=dev)
 img = torch.rand(1080, 1920, 3, device=dev, requires_grad=True)
 tgt = torch.rand(1080, 1920, 3, device=dev)
 keys = torch.randint(0, 1 << 40, (2_500_000,), device=dev)
@@ -66,7 +62,7 @@ def run(side, label):
         c0.record(); job(); c1.record(); torch.cuda.synchronize()
         alone = c0.elapsed_time(c1)
         best = (1e9, 1e9)
-        for it in range(3):
+        for _ in range(3):
             with torch.cuda.stream(side):
                 f = lm.encoder.forward(x)
                 g = torch.ones_like(f)
@@ -78,65 +74,16 @@ def run(side, label):
             c0.record(); job(); c1.record()
             torch.cuda.synchronize()
             best = min(best, (c0.elapsed_time(c1), e0.elapsed_time(e1)))
-        out.append(f"{name}: {alone:6.3f} -> {best[0]:6.3f} (bwd {best[1]:5.2f})")
-    print(f"{label:>22} | " + " | ".join(out), flush=True)
+        out.append(f"{name}: {alone:6.3f} -> {best[0]:6.3f} ms (scatter {best[1]:5.2f})")
+    print(f"{label:>28} | " + " | ".join(out), flush=True)
 
 
-ALL = (1 << 256) - 1
-for n in (32, 64, 128):
-    lo = (1 << n) - 1
-    torch.cuda.set_stream(masked_stream(ALL ^ lo))
-    run(masked_stream(lo), f"side first {n}, main rest")
-for n in (32, 64):
-    m = pattern(n, "strided")
-    torch.cuda.set_stream(masked_stream(ALL ^ m))
-    run(masked_stream(m), f"side strided {n}, main rest")
-sys.exit(0)
-
-
-def run_old(side, label):
-    main = torch.cuda.current_stream()
-    # build graph once per iteration on the side stream; time only the backward kernel with events
-    res = []
-    for it in range(4):
-        with torch.cuda.stream(side):
-            f = lm.encoder.forward(x)
-            g = torch.ones_like(f)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            f.backward(g)
-            e1.record()
-        torch.cuda.synchronize()
-        res.append(e0.elapsed_time(e1))
-    alone = min(res)
-    # concurrent: copy on main while backward on side
-    res2 = []
-    for it in range(4):
-        with torch.cuda.stream(side):
-            f = lm.encoder.forward(x)
-            g = torch.ones_like(f)
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        with torch.cuda.stream(side):
-            e0.record(); f.backward(g); e1.record()
-        c0.record()
-        for _ in range(4):
-            big_b.copy_(big_a)
-        c1.record()
-        torch.cuda.synchronize()
-        res2.append((e0.elapsed_time(e1), c0.elapsed_time(c1) / 4))
-    print(f"{label:>22}: hashgrid_bwd alone {alone:7.3f} ms | beside copies: bwd {min(r[0] for r in res2):7.3f} ms, 256MB copy {min(r[1] for r in res2):7.3f} ms", flush=True)
-
-
-c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-big_b.copy_(big_a); torch.cuda.synchronize()
-c0.record()
-for _ in range(4):
-    big_b.copy_(big_a)
-c1.record(); torch.cuda.synchronize()
-print(f"256MB copy alone: {c0.elapsed_time(c1) / 4:.3f} ms")
+torch.cuda.set_stream(torch.cuda.Stream())          # not the null stream: masked streams are blocking streams
 run(torch.cuda.Stream(), "unmasked side stream")
-for n in (128, 64, 32, 16):
-    for kind in ("first", "strided"):
-        run(masked_stream(pattern(n, kind)), f"{n} CUs {kind}")
+strided = sum(1 << i for i in range(0, 256, 8))
+torch.cuda.set_stream(masked_stream(ALL ^ strided))
+run(masked_stream(strided), "strided 32 CUs, main rest")
+for n_xcd in (1, 2, 4):
+    lo = (1 << (32 * n_xcd)) - 1
+    torch.cuda.set_stream(masked_stream(ALL ^ lo))
+    run(masked_stream(lo), f"scatter on {n_xcd} XCD(s), main rest")
