@@ -3,6 +3,7 @@
 // as the reference would call it.  Not part of the product surface.
 #include <torch/extension.h>
 
+#include "cumcubes/cumcubes_wrapper.h"
 #include "gsplat_cpp/fully_fused_projection.h"
 #include "gsplat_cpp/rasterize_to_pixels.h"
 #include "gsplat_cpp/rendering.h"
@@ -34,6 +35,10 @@ PYBIND11_MODULE(_gsdf_host, m) {
                                           packed, absg, distloss);
         });
   m.def("distCUDA2", &distCUDA2);
+  m.def("marching_cubes", [](const torch::Tensor &grid, float thresh, std::vector<float> lower, std::vector<float> upper) {
+    TORCH_CHECK(lower.size() == 3 && upper.size() == 3, "marching_cubes: lower / upper need 3 entries");
+    return mc::marching_cubes_wrapper(grid, thresh, lower.data(), upper.data());       // as cumcubes.cpp:9-27 calls it
+  });
   m.def("quantize_points", &spc_ops::quantize_points);
   m.def("points_to_neighbors", &spc_ops::points_to_neighbors);
   m.def("points_to_corners", &spc_ops::points_to_corners);

@@ -35,24 +35,18 @@ def marching_cubes(density_grid, thresh, lower, upper):
 
 
 def save_mesh_as_ply(path, vertices, faces, colors=None):
-    """binary little-endian PLY: float x y z (+ uchar red green blue per vertex), faces as uchar-count int32 lists."""
+    """The file mc::save_mesh_as_ply writes (cumcubes.cpp:29-79): binary little-endian PLY, vertices float x y z + uchar
+    red green blue (white when `colors` is None), faces as `property list int int vertex_index` (count 3 as int32)."""
     import numpy as np
     v = vertices.detach().cpu().float().numpy().astype("<f4")
     f = faces.detach().cpu().numpy().astype("<i4")
+    c = np.full((v.shape[0], 3), 255, np.uint8) if colors is None else colors.detach().cpu().numpy().astype(np.uint8)
     header = ["ply", "format binary_little_endian 1.0", f"element vertex {v.shape[0]}", "property float x", "property float y",
-              "property float z"]
-    if colors is not None:
-        header += ["property uchar red", "property uchar green", "property uchar blue"]
-    header += [f"element face {f.shape[0]}", "property list uchar int vertex_indices", "end_header"]
+              "property float z", "property uchar red", "property uchar green", "property uchar blue",
+              f"element face {f.shape[0]}", "property list int int vertex_index", "end_header"]
     with open(path, "wb") as fh:
         fh.write(("\n".join(header) + "\n").encode("ascii"))
-        if colors is None:
-            fh.write(np.ascontiguousarray(v).tobytes())
-        else:
-            c = colors.detach().cpu().numpy().astype(np.uint8)
-            rec = np.zeros(v.shape[0], dtype=[("p", "<f4", 3), ("c", "u1", 3)])
-            rec["p"], rec["c"] = v, c
-            fh.write(rec.tobytes())
-        fr = np.zeros(f.shape[0], dtype=[("n", "u1"), ("i", "<i4", 3)])
-        fr["n"], fr["i"] = 3, f
-        fh.write(fr.tobytes())
+        rec = np.zeros(v.shape[0], dtype=[("p", "<f4", 3), ("c", "u1", 3)])
+        rec["p"], rec["c"] = v, c
+        fh.write(rec.tobytes())
+        fh.write(np.concatenate([np.full((f.shape[0], 1), 3, "<i4"), f], 1).astype("<i4").tobytes())

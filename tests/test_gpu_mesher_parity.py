@@ -42,7 +42,7 @@ def test_empty_surface_and_ply_export(tmp_path):
     raw = open(path, "rb").read()
     head, body = raw.split(b"end_header\n", 1)
     assert b"element vertex %d" % v.shape[0] in head and b"element face %d" % f.shape[0] in head
-    assert len(body) == v.shape[0] * 15 + f.shape[0] * 13
+    assert len(body) == v.shape[0] * 15 + f.shape[0] * 16 and b"property list int int vertex_index" in head
     with pytest.raises(RuntimeError):
         marching_cubes(torch.ones(8, 8, device=dev), 0.0, [0] * 3, [1] * 3)
     with pytest.raises(RuntimeError):
@@ -62,3 +62,14 @@ def test_sdf_network_meshing_slice():
         sdf = lm.get_sdf(pts)[0].reshape(res, res, res) + (pts.norm(dim=1) - 1.0).reshape(res, res, res)
     v, f = marching_cubes(sdf, 0.0, [-1.5] * 3, [1.5 + 3.0 / (res - 1)] * 3)
     assert f.shape[0] > 2000 and float((v.norm(dim=1) - 1.0).abs().max()) < 0.05
+
+
+def test_cpp_marching_cubes_wrapper_matches_python_mirror():
+    """mc::marching_cubes_wrapper of the C++ operator layer (what the reference's cumcubes.cpp:9-27 calls)."""
+    import gs_sdf_amd.hostlib as h
+    from gs_sdf_amd.mesher import marching_cubes
+    host = h.load()
+    g = torch.from_numpy(_sphere(40)).to(dev)
+    v, f = marching_cubes(g, 0.0, [-1, -1, -1], [1, 1, 1])
+    v2, f2 = host.marching_cubes(g, 0.0, [-1.0, -1.0, -1.0], [1.0, 1.0, 1.0])
+    assert torch.equal(v, v2) and torch.equal(f, f2) and f2.dtype == torch.int32
