@@ -117,7 +117,11 @@ def main():
         lm.encoder.save_jacobian = True      # d/dx of the sample points from the forward's Jacobian (first order only)
     if overlap:
         from gs_sdf_amd.streams import xcd_partition_streams
-        (main, side, aux), scatter = xcd_partition_streams(args.scatter_xcds, 3)
+        try:
+            (main, side, aux), scatter = xcd_partition_streams(args.scatter_xcds, 3)
+        except Exception as e:      # CU masks unavailable: same schedule on ordinary HIP streams (slower, still correct)
+            print(f"[bench] XCD-partitioned streams unavailable ({e}); using unmasked streams", file=sys.stderr, flush=True)
+            main, side, aux, scatter = (torch.cuda.Stream() for _ in range(4))
         lm.encoder.scatter_stream = scatter
         lm.decoder.aux_stream = aux          # decoder weight gradients: off the chain that leads back to the splat leg
         main.wait_stream(torch.cuda.current_stream())
