@@ -49,6 +49,11 @@ __device__ __forceinline__ int perm_hidden(int s, int h) { return 32 * (s >> 4) 
 __device__ __forceinline__ int64_t img_off(int64_t slot, int64_t n_tiles, int64_t tile, int t, int lane) {
   return ((((slot * n_tiles + tile) * 2 + t) * 64 + lane) * 16);
 }
+// ReLU masks (bit r of a uint16 = accumulator register r of that lane was > 0): stored behind the images in the same
+// buffer, [slot][tile][t][lane]; the data-gradient kernel reads 2 B per lane instead of the 64 B of activations.
+__device__ __forceinline__ int64_t mask_off(int64_t slot, int64_t n_tiles, int64_t tile, int t, int lane) {
+  return ((slot * n_tiles + tile) * 2 + t) * 64 + lane;
+}
 // the lane/register that holds neuron-in-tile j (0..31) of a point: lane half = (j >> 2) & 1, r = (j & 3) + 4 (j >> 3)
 __device__ __forceinline__ int img_half_of(int j) { return (j >> 2) & 1; }
 __device__ __forceinline__ int img_reg_of(int j) { return (j & 3) + 4 * (j >> 3); }
@@ -100,6 +105,7 @@ __global__ void __launch_bounds__(MLP_THREADS)
   const int h = lane >> 5, pl = lane & 31;
   constexpr int K0 = D_IN / 2;
   const int64_t n_tiles = (B + 31) / 32;
+  uint16_t *masks = acts == nullptr ? nullptr : reinterpret_cast<uint16_t *>(acts + img_off(d.n_layers - 1, n_tiles, 0, 0, 0));
   for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < n_tiles; tile += (int64_t)gridDim.x * 4) {
     const int64_t p = tile * 32 + pl;
     const bool live = p < B;
@@ -136,9 +142,13 @@ __global__ void __launch_bounds__(MLP_THREADS)
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
           float4 *a = reinterpret_cast<float4 *>(acts + img_off(l - 1, n_tiles, tile, t, lane));
+          unsigned m = 0;
 #pragma unroll
           for (int q = 0; q < 4; ++q)
             a[q] = make_float4(cur[t][4 * q], cur[t][4 * q + 1], cur[t][4 * q + 2], cur[t][4 * q + 3]);
+#pragma unroll
+          for (int r = 0; r < 16; ++r) m |= (cur[t][r] > 0.f ? 1u : 0u) << r;
+          masks[mask_off(l - 1, n_tiles, tile, t, lane)] = (uint16_t)m;
         }
       }
       const float *w = lds_w + d.lds_off[l];
@@ -207,6 +217,7 @@ __global__ void __launch_bounds__(MLP_THREADS)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int h = lane >> 5, pl = lane & 31;
   const int64_t n_tiles = (B + 31) / 32;
+  const uint16_t *masks = reinterpret_cast<const uint16_t *>(acts + img_off(d.n_layers - 1, n_tiles, 0, 0, 0));
   for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < n_tiles; tile += (int64_t)gridDim.x * 4) {
     const int64_t p = tile * 32 + pl;
     const bool live = p < B;
@@ -222,13 +233,9 @@ __global__ void __launch_bounds__(MLP_THREADS)
       const bool last = l == d.n_layers - 1;
       // the ReLU mask of layer l-1 (its saved activations) does not depend on the MFMAs below: issue its loads first so
       // that their latency hides behind the 32-64 MFMAs of this layer
-      float4 hv[2][4];
+      unsigned hm[2];
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        const float4 *a = reinterpret_cast<const float4 *>(acts + img_off(l - 1, n_tiles, tile, t, lane));
-#pragma unroll
-        for (int q = 0; q < 4; ++q) hv[t][q] = a[q];
-      }
+      for (int t = 0; t < 2; ++t) hm[t] = masks[mask_off(l - 1, n_tiles, tile, t, lane)];
       v16f ng[2];
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
@@ -257,10 +264,10 @@ __global__ void __launch_bounds__(MLP_THREADS)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           float4 o4;   // dead lanes carry g = 0 all the way down: their image rows are zeros
-          o4.x = hv[t][q].x > 0.f ? ng[t][4 * q] : 0.f;
-          o4.y = hv[t][q].y > 0.f ? ng[t][4 * q + 1] : 0.f;
-          o4.z = hv[t][q].z > 0.f ? ng[t][4 * q + 2] : 0.f;
-          o4.w = hv[t][q].w > 0.f ? ng[t][4 * q + 3] : 0.f;
+          o4.x = (hm[t] >> (4 * q)) & 1u ? ng[t][4 * q] : 0.f;
+          o4.y = (hm[t] >> (4 * q + 1)) & 1u ? ng[t][4 * q + 1] : 0.f;
+          o4.z = (hm[t] >> (4 * q + 2)) & 1u ? ng[t][4 * q + 2] : 0.f;
+          o4.w = (hm[t] >> (4 * q + 3)) & 1u ? ng[t][4 * q + 3] : 0.f;
           ng[t][4 * q] = o4.x; ng[t][4 * q + 1] = o4.y; ng[t][4 * q + 2] = o4.z; ng[t][4 * q + 3] = o4.w;
           vp[q] = o4;
         }
@@ -399,11 +406,14 @@ static unsigned mlp_grid(int64_t B) {
   return (unsigned)(wg < 1 ? 1 : (wg > cap ? cap : wg));
 }
 
-extern "C" size_t gsdf_mlp_acts_floats(int64_t B, int n_layers) {   // register images, rows padded to whole 32-point tiles
+static size_t image_floats(int64_t B, int n_layers) {   // register images, rows padded to whole 32-point tiles
   return (size_t)(n_layers > 1 ? n_layers - 1 : 0) * (size_t)((B + 31) / 32 * 32) * HID;
 }
+extern "C" size_t gsdf_mlp_acts_floats(int64_t B, int n_layers) {   // images + the uint16 ReLU masks (1/32 of the images)
+  return image_floats(B, n_layers) + image_floats(B, n_layers) / 32 + 64;
+}
 extern "C" size_t gsdf_mlp_bwd_ws_bytes(int64_t B, int n_layers) {
-  return gsdf_mlp_acts_floats(B, n_layers) * sizeof(float) + 256;
+  return image_floats(B, n_layers) * sizeof(float) + 256;
 }
 
 extern "C" int gsdf_mlp_fwd(int64_t B, int n_layers, const int *dims_host, const float *weights, const float *biases,
