@@ -41,6 +41,7 @@ def main():
     ap.add_argument("--dump-grads", default=None, help="test hook: run ONE step without the optimizer update, save the flat "
                                                         "gradient buffers to this file and exit")
     ap.add_argument("--ray-leg-on-scatter-xcds", type=int, default=1, help="run the per-ray SDF leg on the scatter stream's XCDs")
+    ap.add_argument("--ray-weights-aux", type=int, default=1, help="decoder weight gradients of the ray leg on the aux stream")
     ap.add_argument("--no-overlap", action="store_true", help="issue the SDF leg on the same HIP stream as the splat leg")
     args = ap.parse_args()
 
@@ -119,6 +120,9 @@ def main():
         from gs_sdf_amd.streams import xcd_partition_streams
         try:
             (main, side, aux), scatter = xcd_partition_streams(args.scatter_xcds, 3)
+            # the compositing kernels map tile bands to XCDs for L2 locality: tell them how many XCDs their queue has
+            # (read once, at their first launch)
+            os.environ["GSDF_XCDS"] = str(8 - args.scatter_xcds)
         except Exception as e:      # CU masks unavailable: same schedule on ordinary HIP streams (slower, still correct)
             print(f"[bench] XCD-partitioned streams unavailable ({e}); using unmasked streams", file=sys.stderr, flush=True)
             main, side, aux, scatter = (torch.cuda.Stream() for _ in range(4))
@@ -153,7 +157,7 @@ def main():
             ray_stream = scatter if args.ray_leg_on_scatter_xcds else side
             if ray_stream is not side:
                 ray_stream.wait_stream(side)              # the SDF parameters of step i-1 (Adam ran on `side`)
-            aux_saved, lm.decoder.aux_stream = lm.decoder.aux_stream, (None if ray_stream is scatter else lm.decoder.aux_stream)
+            aux_saved, lm.decoder.aux_stream = lm.decoder.aux_stream, (None if (ray_stream is scatter and not args.ray_weights_aux) else lm.decoder.aux_stream)
             with torch.cuda.stream(ray_stream):
                 pts, tgt = pool[i % 8], ray_sdf[i % 8]
                 lm.ray_loss(pts, tgt, 0.02, 0.1).backward()

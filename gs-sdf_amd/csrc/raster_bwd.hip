@@ -72,7 +72,7 @@ __device__ __forceinline__ void lds_add(float *p, float v) { atomicAdd(p, v); }
 
 template <bool ABSGRAD>
 __global__ void __launch_bounds__(RT)
-    raster_bwd_kernel(int64_t total_tiles, int64_t n_tiles, int64_t I, int W, int H, int tw,
+    raster_bwd_kernel(int n_xcd, int64_t total_tiles, int64_t n_tiles, int64_t I, int W, int H, int tw,
                       const float *__restrict__ means2d, const float *__restrict__ ray_transforms,
                       const float *__restrict__ colors, const float *__restrict__ opacities,
                       const float *__restrict__ normals, const float *__restrict__ backgrounds,
@@ -84,7 +84,7 @@ __global__ void __launch_bounds__(RT)
                       const float *__restrict__ v_render_median, float *__restrict__ grec,
                       float *__restrict__ grec_abs) {
   __shared__ BwdLds<ABSGRAD> lds;
-  const int64_t tile = xcd_tile_index(total_tiles);
+  const int64_t tile = xcd_tile_index(total_tiles, n_xcd);
   if (tile >= total_tiles) return;
   if (masks != nullptr && !masks[tile]) return;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -324,7 +324,7 @@ extern "C" int gsdf_rasterize_2dgs_bwd(int64_t C, int64_t M, int64_t I, int widt
   GSDF_HIP(hipMemsetAsync(grec, 0, (size_t)M * NACC * sizeof(float), stream), "rasterize_bwd memset");
   if (v_means2d_abs) GSDF_HIP(hipMemsetAsync(grec_abs, 0, (size_t)M * 2 * sizeof(float), stream), "rasterize_bwd memset");
   if (I > 0) {
-#define ARGS total, n_tiles, I, width, height, tw, means2d, ray_transforms, colors, opacities, normals, backgrounds, \
+#define ARGS xcd_count(), total, n_tiles, I, width, height, tw, means2d, ray_transforms, colors, opacities, normals, backgrounds, \
              masks, isect_offsets, flatten_ids, render_alphas, last_ids, median_ids, v_render_colors,               \
              v_render_depths, v_render_alphas, v_render_normals, v_render_median, grec, grec_abs
     if (v_means2d_abs)

@@ -9,6 +9,8 @@
 // gathered from the packed per-splat arrays); every lane then reads the same LDS address
 // (broadcast, conflict-free ds_read_b128).
 #pragma once
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace gsdf {
@@ -106,12 +108,18 @@ __device__ __forceinline__ void stage_splat(SplatBatch &s, int slot, int g, cons
 
 // XCD-aware tile assignment: workgroup b runs on XCD (b % 8); give each XCD one contiguous band
 // of tiles so that the splats shared by neighbouring tiles stay in that XCD's 4 MiB L2.
-__device__ __forceinline__ int64_t xcd_tile_index(int64_t total_tiles) {
+// n_xcd = number of XCDs the launching queue may use (8, or fewer under a CU mask: workgroups are then dealt round-robin
+// over the enabled XCDs only).
+__device__ __forceinline__ int64_t xcd_tile_index(int64_t total_tiles, int n_xcd) {
   const int64_t b = blockIdx.x;
-  const int64_t chunk = gridDim.x / 8;
-  return (b & 7) * chunk + (b >> 3);
+  const int64_t chunk = gridDim.x / n_xcd;
+  return (b % n_xcd) * chunk + (b / n_xcd);
 }
-static inline unsigned xcd_grid(int64_t total_tiles) { return (unsigned)(((total_tiles + 7) / 8) * 8); }
+static inline int xcd_count() {   // GSDF_XCDS: XCDs of the stream the compositing kernels are launched on (default 8)
+  static const int n = [] { const char *e = getenv("GSDF_XCDS"); const int v = e ? atoi(e) : 8; return v >= 1 && v <= 8 ? v : 8; }();
+  return n;
+}
+static inline unsigned xcd_grid(int64_t total_tiles) { const int n = xcd_count(); return (unsigned)(((total_tiles + n - 1) / n) * n); }
 
 struct PairEval {
   float zx, zy, zz, inv;

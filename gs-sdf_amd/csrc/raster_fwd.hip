@@ -12,7 +12,7 @@ struct FwdLds {
 };
 
 __global__ void __launch_bounds__(RT)
-    raster_fwd_kernel(int64_t total_tiles, int64_t n_tiles, int64_t I, int W, int H, int tw,
+    raster_fwd_kernel(int n_xcd, int64_t total_tiles, int64_t n_tiles, int64_t I, int W, int H, int tw,
                       const float *__restrict__ means2d, const float *__restrict__ ray_transforms,
                       const float *__restrict__ colors, const float *__restrict__ opacities,
                       const float *__restrict__ normals, const float *__restrict__ backgrounds,
@@ -23,7 +23,7 @@ __global__ void __launch_bounds__(RT)
                       int32_t *__restrict__ last_ids, int32_t *__restrict__ median_ids,
                       unsigned *__restrict__ visibilities) {
   __shared__ FwdLds lds;
-  const int64_t tile = xcd_tile_index(total_tiles);
+  const int64_t tile = xcd_tile_index(total_tiles, n_xcd);
   if (tile >= total_tiles) return;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int64_t cam = tile / n_tiles;
@@ -144,7 +144,7 @@ extern "C" int gsdf_rasterize_2dgs_fwd(int64_t C, int64_t M, int64_t I, int widt
   const int tw = (width + TILE - 1) / TILE, th = (height + TILE - 1) / TILE;
   const int64_t n_tiles = (int64_t)tw * th, total = n_tiles * C;
   if (M > 0) GSDF_HIP(hipMemsetAsync(visibilities, 0, (size_t)M * 4, stream), "rasterize_fwd memset");
-  raster_fwd_kernel<<<xcd_grid(total), RT, 0, stream>>>(total, n_tiles, I, width, height, tw, means2d, ray_transforms,
+  raster_fwd_kernel<<<xcd_grid(total), RT, 0, stream>>>(xcd_count(), total, n_tiles, I, width, height, tw, means2d, ray_transforms,
                                                         colors, opacities, normals, backgrounds, masks, isect_offsets,
                                                         flatten_ids, render_colors, render_depths, render_alphas,
                                                         render_normals, render_median, last_ids, median_ids,
