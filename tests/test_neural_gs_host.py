@@ -149,3 +149,18 @@ def test_ply_checkpoint_round_trip(tmp_path):
     assert torch.equal(gs2.features_dc_, gs.features_dc_) and torch.equal(gs2.features_rest_, gs.features_rest_)
     assert torch.equal(gs2.opacity_, gs.opacity_) and torch.equal(gs2.scaling_[:, :2], gs.scaling_[:, :2])
     assert torch.allclose(gs2.scaling_[:, 2], torch.full((n,), math.log(1e-6)))
+
+
+def test_inject_grads_and_join_grad_are_plain_autograd_plumbing():
+    """trainer.inject_grads delivers fixed upstream gradients through one node; trainer.join_grad is the identity (its
+    event wait only exists on the GPU)."""
+    import torch
+    from gs_sdf_amd.trainer import GradGate, inject_grads, join_grad
+    a = torch.randn(5, 3, requires_grad=True)
+    b = torch.randn(7, requires_grad=True)
+    ga, gb = torch.randn(5, 3), torch.randn(7)
+    gate = GradGate()
+    loss = (join_grad(a, gate) ** 2).sum() + inject_grads([(a, ga), (b, gb)])
+    assert float(inject_grads([(a, ga)])) == 0.0
+    loss.backward()
+    assert torch.allclose(a.grad, 2 * a.detach() + ga) and torch.equal(b.grad, gb)
