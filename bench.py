@@ -312,6 +312,7 @@ def main():
                                         "avg_launch_ms": kern[k]} for k in alg if k != dom and kern.get(k)},
                          "step_B_splat_bytes": b_splat,
                          "step_hbm_frac": b_splat / (elapsed / args.steps) / 8e12},
+            "params_finite": bool(torch.isfinite(params.flat).all()) and all(bool(torch.isfinite(g.flat).all()) for g in groups),
             "hbm_gb": {"allocated_peak": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
                        "reserved": round(torch.cuda.memory_reserved() / 2 ** 30, 2)},
             "kernel_ms": kern_all, "kernel_ms_note": "average launch duration per operator over 10 extra steps after the timed region",
