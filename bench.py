@@ -120,9 +120,6 @@ def main():
         from gs_sdf_amd.streams import xcd_partition_streams
         try:
             (main, side, aux), scatter = xcd_partition_streams(args.scatter_xcds, 3)
-            # the compositing kernels map tile bands to XCDs for L2 locality: tell them how many XCDs their queue has
-            # (read once, at their first launch)
-            os.environ["GSDF_XCDS"] = str(8 - args.scatter_xcds)
         except Exception as e:      # CU masks unavailable: same schedule on ordinary HIP streams (slower, still correct)
             print(f"[bench] XCD-partitioned streams unavailable ({e}); using unmasked streams", file=sys.stderr, flush=True)
             main, side, aux, scatter = (torch.cuda.Stream() for _ in range(4))

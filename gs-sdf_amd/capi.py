@@ -63,6 +63,7 @@ _SIGS = {
     "gsdf_mc_emit": (C.c_int, [_i32, _i32, _i32, _vp, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gsdf_splat_activations_fwd": (C.c_int, [_i64] + [_vp] * 8),
     "gsdf_splat_activations_bwd": (C.c_int, [_i64] + [_vp] * 9),
+    "gsdf_stream_set_xcds": (C.c_int, [_vp, _i32]),
     "gsdf_adam_step": (C.c_int, [_i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _f32, _i64, _vp]),
     "gsdf_knn_ws_bytes": (_sz, [_i64]),
     "gsdf_knn_mean_dist2": (C.c_int, [_i64] + [_vp] * 4),

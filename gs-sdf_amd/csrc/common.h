@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #include "gsdf_hip.h"
 
@@ -113,6 +114,11 @@ __device__ __forceinline__ float row_transpose_reduce16(const float (&v)[16], in
 __device__ __forceinline__ int row_transpose_index(int lane) {
   return ((lane & 1) << 3) | ((lane & 2) << 1) | ((lane & 4) >> 1) | ((lane & 8) >> 3);
 }
+
+// Number of XCDs the queue behind `stream` may use: 8, or what the caller registered with gsdf_stream_set_xcds for a
+// CU-masked stream (workgroups are dealt round-robin over the enabled XCDs only).  A locality hint for the XCD-aware
+// kernels (tile bands of the compositing kernels, level groups of the hash-grid forward), never a correctness input.
+int xcd_count(hipStream_t stream);
 
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 

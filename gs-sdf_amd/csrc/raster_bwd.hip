@@ -324,13 +324,14 @@ extern "C" int gsdf_rasterize_2dgs_bwd(int64_t C, int64_t M, int64_t I, int widt
   GSDF_HIP(hipMemsetAsync(grec, 0, (size_t)M * NACC * sizeof(float), stream), "rasterize_bwd memset");
   if (v_means2d_abs) GSDF_HIP(hipMemsetAsync(grec_abs, 0, (size_t)M * 2 * sizeof(float), stream), "rasterize_bwd memset");
   if (I > 0) {
-#define ARGS xcd_count(), total, n_tiles, I, width, height, tw, means2d, ray_transforms, colors, opacities, normals, backgrounds, \
+    const int n_xcd = xcd_count(stream);
+#define ARGS n_xcd, total, n_tiles, I, width, height, tw, means2d, ray_transforms, colors, opacities, normals, backgrounds, \
              masks, isect_offsets, flatten_ids, render_alphas, last_ids, median_ids, v_render_colors,               \
              v_render_depths, v_render_alphas, v_render_normals, v_render_median, grec, grec_abs
     if (v_means2d_abs)
-      raster_bwd_kernel<true><<<xcd_grid(total), RT, 0, stream>>>(ARGS);
+      raster_bwd_kernel<true><<<xcd_grid(total, n_xcd), RT, 0, stream>>>(ARGS);
     else
-      raster_bwd_kernel<false><<<xcd_grid(total), RT, 0, stream>>>(ARGS);
+      raster_bwd_kernel<false><<<xcd_grid(total, n_xcd), RT, 0, stream>>>(ARGS);
 #undef ARGS
     GSDF_CHECK_LAUNCH("raster_bwd_kernel");
   }

@@ -115,11 +115,7 @@ __device__ __forceinline__ int64_t xcd_tile_index(int64_t total_tiles, int n_xcd
   const int64_t chunk = gridDim.x / n_xcd;
   return (b % n_xcd) * chunk + (b / n_xcd);
 }
-static inline int xcd_count() {   // GSDF_XCDS: XCDs of the stream the compositing kernels are launched on (default 8)
-  static const int n = [] { const char *e = getenv("GSDF_XCDS"); const int v = e ? atoi(e) : 8; return v >= 1 && v <= 8 ? v : 8; }();
-  return n;
-}
-static inline unsigned xcd_grid(int64_t total_tiles) { const int n = xcd_count(); return (unsigned)(((total_tiles + n - 1) / n) * n); }
+static inline unsigned xcd_grid(int64_t total_tiles, int n) { return (unsigned)(((total_tiles + n - 1) / n) * n); }
 
 struct PairEval {
   float zx, zy, zz, inv;

@@ -144,7 +144,8 @@ extern "C" int gsdf_rasterize_2dgs_fwd(int64_t C, int64_t M, int64_t I, int widt
   const int tw = (width + TILE - 1) / TILE, th = (height + TILE - 1) / TILE;
   const int64_t n_tiles = (int64_t)tw * th, total = n_tiles * C;
   if (M > 0) GSDF_HIP(hipMemsetAsync(visibilities, 0, (size_t)M * 4, stream), "rasterize_fwd memset");
-  raster_fwd_kernel<<<xcd_grid(total), RT, 0, stream>>>(xcd_count(), total, n_tiles, I, width, height, tw, means2d, ray_transforms,
+  const int n_xcd = xcd_count(stream);
+  raster_fwd_kernel<<<xcd_grid(total, n_xcd), RT, 0, stream>>>(n_xcd, total, n_tiles, I, width, height, tw, means2d, ray_transforms,
                                                         colors, opacities, normals, backgrounds, masks, isect_offsets,
                                                         flatten_ids, render_colors, render_depths, render_alphas,
                                                         render_normals, render_median, last_ids, median_ids,

@@ -32,6 +32,10 @@ def _masked_stream(bits, total, device):
         raise RuntimeError(f"hipExtStreamCreateWithCUMask failed with error {rc}")
     st = torch.cuda.ExternalStream(handle.value, device=device)
     _KEEP.append((handle, st))
+    # tell the XCD-aware kernels how many XCDs this queue has (include/gsdf_hip.h: gsdf_stream_set_xcds)
+    from . import capi
+    n_xcds = sum(1 for k in range(N_XCD) if (bits >> (k * (total // N_XCD))) & ((1 << (total // N_XCD)) - 1))
+    capi.check(capi.lib().gsdf_stream_set_xcds(C.c_void_p(handle.value), n_xcds), "stream_set_xcds")
     return st
 
 
@@ -54,8 +58,10 @@ def destroy_all():
     the process runs its exit handlers crashes rocprofv3's finalizer."""
     torch.cuda.synchronize()
     hip = C.CDLL("libamdhip64.so")
+    from . import capi
     while _KEEP:
         handle, _ = _KEEP.pop()
+        capi.lib().gsdf_stream_set_xcds(C.c_void_p(handle.value), 0)
         hip.hipStreamDestroy(handle)
 
 

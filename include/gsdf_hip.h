@@ -313,6 +313,14 @@ int gsdf_splat_activations_bwd(int64_t n, const float *scales, const float *opac
                                float *g_logit_opacities, gsdf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Hint for the XCD-aware kernels (compositing: one band of tiles per XCD; hash-grid forward: one group of levels per
+ * XCD): how many XCDs the queue behind `stream` can use.  Default 8; a caller that launches on a CU-masked stream
+ * (hipExtStreamCreateWithCUMask) registers the number of XCDs its mask leaves enabled; 0 forgets the stream.
+ * Locality only: results do not depend on it.
+ * ---------------------------------------------------------------------------------------- */
+int gsdf_stream_set_xcds(gsdf_stream_t stream, int n_xcds);
+
+/* ------------------------------------------------------------------------------------------
  * O2  fused photometric loss  L = w_l1 * mean|I-G| + w_ssim * (1 - mean SSIM(I,G))  on [H,W,3] images:
  *     loss::rgb_loss + loss::dssim_loss (include/optimizer/loss/loss.cpp:22-47) with loss_utils::ssim
  *     (include/optimizer/loss_utils/loss_utils.cpp:71-117; 11-tap window of loss_utils.cpp:6-14 passed by the host,

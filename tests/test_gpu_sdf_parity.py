@@ -364,3 +364,28 @@ def test_single_node_coupling_leg_equals_composed_operators(sdf):
     assert_close(out[1][2], out[0][2], 1e-5, "flat parameter gradients")
     with pytest.raises(RuntimeError):
         sdf.LocalMap([0, 0, 0], 2.0, decoder_implementation=1, device=dev).gs_sdf_coupling(pts, ids, w_all)
+
+
+@pytest.mark.parametrize("jac", [False, True])
+def test_xcd_partitioned_forward_is_bit_identical_to_the_plain_kernel(sdf, jac):
+    """Batches >= 65536 points take the XCD-partitioned forward (each XCD owns a group of levels); smaller ones the plain
+    kernel.  Same arithmetic per (point, level): features, Jacobian-based d/dx and table gradients must agree exactly."""
+    dev = torch.device("cuda:0")
+    B = 200_003
+    x0 = torch.rand(B, 3, generator=torch.Generator().manual_seed(5)).to(dev)
+    enc = sdf.TCNNEncoding(3, None, "enc", dev, seed=3)
+    with torch.no_grad():
+        enc.params_.mul_(1e3)
+    enc.save_jacobian = jac
+    v = torch.randn(B, 32, generator=torch.Generator().manual_seed(6)).to(dev)
+    xb = x0.clone().requires_grad_(True)
+    big = enc.forward(xb)
+    gx_big = torch.autograd.grad((big * v).sum(), xb)[0]
+    parts, gparts = [], []
+    for s in range(0, B, 50_000):
+        xs = x0[s:s + 50_000].clone().requires_grad_(True)
+        f = enc.forward(xs)
+        parts.append(f.detach())
+        gparts.append(torch.autograd.grad((f * v[s:s + 50_000]).sum(), xs)[0])
+    assert torch.equal(big.detach(), torch.cat(parts))
+    assert torch.equal(gx_big, torch.cat(gparts))
