@@ -307,6 +307,13 @@ def main():
                          # XCDs of its own; the compositing backward is the largest kernel on the splat leg)
                          "others": {k: {"achieved": alg[k] / (kern[k] * 1e-3) / 1e9, "frac": alg[k] / (kern[k] * 1e-3) / 8e12,
                                         "avg_launch_ms": kern[k]} for k in alg if k != dom and kern.get(k)},
+                         # the scatter is bound by the memory-side fp32 atomic units, not by HBM bytes: cache-line requests per
+                         # launch (16 levels x 4 (y,z) corner pairs x 9/8 lines: the two x-neighbours share a 64 B line unless
+                         # x0 % 8 == 7) against the measured chip-wide ceiling (tools/ubench/atomic_rate.hip)
+                         "atomic_line_rate": (None if dom != "hashgrid_bwd" else {
+                             "achieved_G_per_s": 72.0 * (alg[dom] / 1160.0) / (dur_ms * 1e-3) / 1e9, "ceiling_G_per_s": 21.0,
+                             "frac": 72.0 * (alg[dom] / 1160.0) / (dur_ms * 1e-3) / 21e9,
+                             "note": "kernel confined to 2 of 8 XCDs in the two-leg step"}),
                          "step_B_splat_bytes": b_splat,
                          "step_hbm_frac": b_splat / (elapsed / args.steps) / 8e12},
             "params_finite": bool(torch.isfinite(params.flat).all()) and all(bool(torch.isfinite(g.flat).all()) for g in groups),
