@@ -128,6 +128,26 @@ class ViewParallel:
         self.dist.all_reduce(group.flat_grad, op=self.dist.ReduceOp.SUM)
         group.flat_grad.mul_(1.0 / self.world)
 
+    def sync_refine_state(self, state):
+        """The second, small collective of view-parallel training: before a refine step every rank must
+        hold the SAME densification statistics so that duplicate / split / prune take identical decisions everywhere
+        (the reference accumulates them in NeuralGS::update_state, neural_gaussian.cpp:626-680): `grad2d` and `count` are
+        summed over the ranks' views, `vis` and `radii` are max-merged.  Two messages: one SUM, one MAX."""
+        if self.dist is None or self.world == 1:
+            return
+        sums = [k for k in ("grad2d", "count") if k in state]
+        maxs = [k for k in ("vis", "radii") if k in state]
+        for keys, op in ((sums, self.dist.ReduceOp.SUM), (maxs, self.dist.ReduceOp.MAX)):
+            if not keys:
+                continue
+            buf = torch.cat([state[k].reshape(-1) for k in keys])
+            self.dist.all_reduce(buf, op=op)
+            off = 0
+            for k in keys:
+                n = state[k].numel()
+                state[k].copy_(buf[off:off + n].view_as(state[k]))
+                off += n
+
     def all_reduce_grads(self):
         if self.dist is None or self.world == 1:
             return

@@ -58,3 +58,33 @@ def test_all_reduce_matches_single_process():
     assert sum(p.numel() for p in params.parameters()) == params.flat_grad.numel()
     for p in params.parameters():
         assert p.grad.data_ptr() >= params.flat_grad.data_ptr()
+
+
+def _refine_worker(rank, world, port, out):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = torch.Generator().manual_seed(100 + rank)                 # every rank saw different views
+    n = 1000
+    state = dict(grad2d=torch.rand(n, generator=g), count=torch.randint(0, 5, (n,), generator=g).float(),
+                 vis=torch.rand(n, generator=g), radii=torch.rand(n, generator=g))
+    before = {k: v.clone() for k, v in state.items()}
+    ViewParallel(None, dist).sync_refine_state(state)
+    out[rank] = (before, {k: v.clone() for k, v in state.items()})
+    dist.destroy_process_group()
+
+
+def test_refine_statistics_are_merged_identically_on_every_rank():
+    """SURVEY 8e, second collective: grad2d / count summed, vis / radii max-merged, so that the densification masks
+    (grad2d / count > threshold, vis < threshold) come out identical on all ranks."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    out = mp.Manager().dict()
+    mp.spawn(_refine_worker, args=(2, port, out), nprocs=2, join=True)
+    (b0, a0), (b1, a1) = out[0], out[1]
+    for k in ("grad2d", "count"):
+        assert torch.equal(a0[k], a1[k]) and torch.allclose(a0[k], b0[k] + b1[k])
+    for k in ("vis", "radii"):
+        assert torch.equal(a0[k], a1[k]) and torch.equal(a0[k], torch.maximum(b0[k], b1[k]))
+    grow0 = (a0["grad2d"] / a0["count"].clamp_min(1)) > 0.2
+    grow1 = (a1["grad2d"] / a1["count"].clamp_min(1)) > 0.2
+    assert torch.equal(grow0, grow1) and 0 < int(grow0.sum()) < grow0.numel()
