@@ -261,7 +261,10 @@ class NeuralGS:
 
     # ---- per-iteration callback (neural_gaussian.cpp:568-624)
     @torch.no_grad()
-    def train_callback(self, it, total_iter, optimizer, info):
+    def train_callback(self, it, total_iter, optimizer, info, view_parallel=None):
+        """`view_parallel` (trainer.ViewParallel, not in the reference, which is single-GPU): before every decision that
+        changes the splat set the ranks merge their densification statistics (sum / max) so that all of them take it
+        identically (parameters are identical after the gradient all-reduce, so NaN pruning needs no exchange)."""
         cfg = self.cfg
         refine_stop = total_iter // 2
         log = {}
@@ -269,6 +272,10 @@ class NeuralGS:
             if it >= refine_stop:
                 return log
             self.update_state(info)
+            refine_now = (0 < it < refine_stop and it > cfg.refine_start_iter and it % cfg.refine_every == 0
+                          and (it % cfg.reset_every) >= cfg.pause_refine_after_reset)
+            if view_parallel is not None and (refine_now or (it > 0 and it % self.num_train_data_ == 0)):
+                view_parallel.sync_refine_state(self.state)
             log["nan"] = self.prune_nan_gs(optimizer)
             log["invisible"] = self.prune_invisible_gs(it, optimizer)
             self.sh_degree_to_use_ = min(cfg.sh_degree, it // cfg.sh_degree_interval)
