@@ -275,7 +275,8 @@ class NeuralGS:
             refine_now = (0 < it < refine_stop and it > cfg.refine_start_iter and it % cfg.refine_every == 0
                           and (it % cfg.reset_every) >= cfg.pause_refine_after_reset)
             if view_parallel is not None and (refine_now or (it > 0 and it % self.num_train_data_ == 0)):
-                view_parallel.sync_refine_state(self.state)
+                # grad2d / count are reset right after a refine step (zero_state), so that is the only place to sum them
+                view_parallel.sync_refine_state(self.state, sums=refine_now, maxs=True)
             log["nan"] = self.prune_nan_gs(optimizer)
             log["invisible"] = self.prune_invisible_gs(it, optimizer)
             self.sh_degree_to_use_ = min(cfg.sh_degree, it // cfg.sh_degree_interval)

@@ -128,16 +128,18 @@ class ViewParallel:
         self.dist.all_reduce(group.flat_grad, op=self.dist.ReduceOp.SUM)
         group.flat_grad.mul_(1.0 / self.world)
 
-    def sync_refine_state(self, state):
+    def sync_refine_state(self, state, sums=True, maxs=True):
         """The second, small collective of view-parallel training: before a refine step every rank must
         hold the SAME densification statistics so that duplicate / split / prune take identical decisions everywhere
         (the reference accumulates them in NeuralGS::update_state, neural_gaussian.cpp:626-680): `grad2d` and `count` are
-        summed over the ranks' views, `vis` and `radii` are max-merged.  Two messages: one SUM, one MAX."""
+        summed over the ranks' views, `vis` and `radii` are max-merged.  Two messages: one SUM, one MAX.
+        The SUM must only be taken right before the statistics are consumed AND reset (a sum of sums would count twice);
+        the MAX is idempotent and can be taken at any time."""
         if self.dist is None or self.world == 1:
             return
-        sums = [k for k in ("grad2d", "count") if k in state]
-        maxs = [k for k in ("vis", "radii") if k in state]
-        for keys, op in ((sums, self.dist.ReduceOp.SUM), (maxs, self.dist.ReduceOp.MAX)):
+        sum_keys = [k for k in ("grad2d", "count") if k in state] if sums else []
+        max_keys = [k for k in ("vis", "radii") if k in state] if maxs else []
+        for keys, op in ((sum_keys, self.dist.ReduceOp.SUM), (max_keys, self.dist.ReduceOp.MAX)):
             if not keys:
                 continue
             buf = torch.cat([state[k].reshape(-1) for k in keys])
