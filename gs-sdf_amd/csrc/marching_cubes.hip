@@ -41,9 +41,11 @@ __device__ __forceinline__ int mc_mask(const McDims &d, const float *__restrict_
   if (g[mc_lin(d, x, y + 1, z + 1)] > thresh) mask |= 128;
   return mask;
 }
+__device__ __forceinline__ int mc_edge(uint64_t packed, int k) { return (int)((packed >> (4 * k)) & 0xFull); }  // 15: end
 __device__ __forceinline__ int mc_tri_count(int mask) {
+  const uint64_t w = MC_TRI_PACKED[mask];
   int n = 0;
-  while (n < 15 && MC_TRI_TABLE[mask][n] >= 0) n += 3;
+  while (n < 15 && mc_edge(w, n) != 15) n += 3;
   return n / 3;
 }
 
@@ -92,8 +94,9 @@ __global__ void __launch_bounds__(256)
   if (x < d.rx - 1 && y < d.ry - 1 && z < d.rz - 1) {
     const int mask = mc_mask(d, g, thresh, x, y, z);
     int64_t f = t_off[c];
-    for (int k = 0; k < 15 && MC_TRI_TABLE[mask][k] >= 0; ++k) {
-      const int e = MC_TRI_TABLE[mask][k];
+    const uint64_t tri = MC_TRI_PACKED[mask];
+    for (int k = 0; k < 15 && mc_edge(tri, k) != 15; ++k) {
+      const int e = mc_edge(tri, k);
       const int ox = x + MC_EDGE_OWNER[e][0], oy = y + MC_EDGE_OWNER[e][1], oz = z + MC_EDGE_OWNER[e][2];
       const int axis = MC_EDGE_OWNER[e][3];
       const int o_own = mc_owned(d, g, thresh, ox, oy, oz);

@@ -25,14 +25,15 @@ def test_table_invariants():
             for e in ((a, b), (b, c), (c, a)):
                 assert e not in d
                 d[e] = 1
-    # the committed header is what the generator produces
+    # the committed header is what the generator produces (one packed 64-bit word per mask, nibble 0xF = end)
+    import re
     hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gs-sdf_amd", "csrc", "mc_table.h")).read()
-    rows = [l for l in hdr.splitlines() if l.strip().startswith("{")]
-    assert len(rows) == 256
-    for m, row in enumerate(rows):
-        vals = [int(v) for v in row.strip().strip("{},").split(",")]
+    words = [int(w, 16) for w in re.findall(r"0x([0-9A-F]{16})ull", hdr)]
+    assert len(words) == 256
+    for m, w in enumerate(words):
         flat = [e for t in gen.triangulate(m) for e in t]
-        assert vals == flat + [-1] * (16 - len(flat))
+        nib = [(w >> (4 * k)) & 0xF for k in range(16)]
+        assert nib == flat + [15] * (16 - len(flat))
 
 
 def _edges_manifold(faces):
