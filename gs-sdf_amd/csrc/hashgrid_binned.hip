@@ -1,0 +1,418 @@
+// hashgrid_binned.hip — S1': the table gradient of the hash-grid encoding WITHOUT global atomics.
+// Same result as gsdf_hashgrid_bwd(..., v_table, v_x = NULL) (replaces tiny-cuda-nn's GridEncoding backward behind
+// TCNNEncoding, /root/reference/include/neural_net/encoding_map.cpp:15-26,59), for the large batches of the joint
+// iteration (7 x (ray points + visible splat samples) ~ 3 M query points, neural_mapping.cpp:106-136,448-451).
+//
+// Why: fp32 global atomics retire ~21 G requests/s chip-wide on MI355X whatever the footprint, scope or XCD placement
+// (tools/ubench/atomic_rate.hip, atomic_xcd.hip): they are executed memory-side.  A query point makes 16 levels x 8
+// corners = 128 contributions to random places of a 61 MB table, i.e. ~72 requests -> 3 M points cost >= 10 ms.
+// Plain traffic is an order of magnitude cheaper, so the scatter becomes a one-digit MSD radix sort + LDS accumulation:
+//
+//   count  : per (level, table tile of 8192 entries = 64 KB) how many contributions arrive          (LDS histograms)
+//   plan   : exclusive scan of the bucket sizes; work items of <= ITEM_MAX records for the last pass (one workgroup)
+//   emit   : every contribution becomes a 12-byte record {entry within tile, g0, g1}; a workgroup sorts the records of
+//            its 256 points x 2 levels by bucket in LDS and appends each run to its bucket with ONE reservation per
+//            (workgroup, bucket) and fully coalesced stores
+//   apply  : one workgroup per item: the tile lives in LDS (64 KB) as 64-BIT FIXED POINT, records stream in coalesced,
+//            ds_add_u64, then the tile is added to the gradient with plain coalesced read-modify-writes (the tile has
+//            exactly one owner; only buckets that were split into several items fall back to atomics, 16 floats per
+//            request).  Fixed point because ds_add_f32 retires ~0.3 lanes/clock/CU on gfx950 — 18x slower than the
+//            integer LDS atomics (tools/ubench/lds_atomic.hip: 0.2 T/s against 3.6 T/s chip-wide); the scale is a power
+//            of two per level, 2^41 / 2^ceil(log2 max|v_feat|), so a tile's sum is EXACT up to 2^-41 of the largest
+//            contribution per record and independent of the order of the records (bit-reproducible, unlike atomics).
+//
+// Traffic: 12 B written + 12 B read per contribution = 3 KB per query point, all of it coalesced.
+// The order in which records are summed is not fixed (like the atomic kernel's); results agree to fp32 rounding.
+#include "hashgrid_common.h"
+
+namespace gsdf {
+
+static constexpr int BIN_TILE_LOG2 = 12;               // 4096 entries x 2 x int64 = 64 KB of LDS
+static constexpr int BIN_TILE = 1 << BIN_TILE_LOG2;
+static constexpr int BIN_PTS = 256;                    // points per emit workgroup
+static constexpr int BIN_G = 2;                        // levels per emit workgroup (16 B of v_feat per point)
+static constexpr int BIN_MAX_LOCAL = 256;              // buckets one emit workgroup can address
+static constexpr int BIN_REC = BIN_PTS * BIN_G * 8;    // records staged per emit workgroup (48 KB)
+static constexpr int64_t BIN_ITEM_MAX = 512 * 1024;    // records per apply work item
+static constexpr int BIN_APPLY_THREADS = 512;
+static_assert(BIN_PTS == BIN_MAX_LOCAL, "the emit kernel scans its local histogram with one thread per bucket");
+
+struct BinPlan {
+  int tile_base[HG_MAX_LEVELS + 1];  // first bucket of each level; [n_levels] = number of buckets
+  int n_groups;                      // level groups of BIN_G levels
+};
+
+struct __attribute__((packed, aligned(4))) BinRecord {
+  uint32_t key;  // entry index within the tile
+  float g0, g1;
+};
+
+struct BinItem {
+  int64_t begin, end;  // record range
+  int32_t bucket, shared;  // shared != 0: the bucket has several items -> atomics when the tile is flushed
+};
+
+static bool make_plan(const HgLevels &lv, BinPlan *bp) {
+  int t = 0;
+  for (int l = 0; l < lv.n_levels; ++l) {
+    bp->tile_base[l] = t;
+    t += (int)((lv.hsize[l] + BIN_TILE - 1) >> BIN_TILE_LOG2);
+  }
+  for (int l = lv.n_levels; l <= HG_MAX_LEVELS; ++l) bp->tile_base[l] = t;
+  bp->n_groups = (lv.n_levels + BIN_G - 1) / BIN_G;
+  for (int g = 0; g < bp->n_groups; ++g) {
+    const int l0 = g * BIN_G, l1 = l0 + BIN_G < lv.n_levels ? l0 + BIN_G : lv.n_levels;
+    if (bp->tile_base[l1] - bp->tile_base[l0] > BIN_MAX_LOCAL) return false;
+  }
+  return t <= 4096;
+}
+
+// workspace layout (all 256-byte aligned): counts u32[nb] + lmax u32[16] | cursor u32[nb] | start i64[nb+1] | n_items u32 (+pad) |
+// items BinItem[max_items] | records BinRecord[B * n_levels * 8]
+struct BinWs {
+  uint32_t *counts, *lmax, *cursor, *n_items;
+  int64_t *start;
+  BinItem *items;
+  BinRecord *records;
+  int64_t max_items;
+  size_t bytes;
+};
+
+static BinWs carve(void *ws, int64_t B, int n_levels, int nb) {
+  BinWs w;
+  char *p = (char *)ws;
+  size_t o = 0;
+  auto take = [&](size_t n) { char *q = p ? p + o : nullptr; o = align_up(o + n, 256); return q; };
+  w.counts = (uint32_t *)take(sizeof(uint32_t) * (nb + HG_MAX_LEVELS));
+  w.lmax = p ? w.counts + nb : nullptr;
+  w.cursor = (uint32_t *)take(sizeof(uint32_t) * nb);
+  w.start = (int64_t *)take(sizeof(int64_t) * (nb + 1));
+  w.n_items = (uint32_t *)take(256);
+  const int64_t total = B * n_levels * 8;
+  w.max_items = total / BIN_ITEM_MAX + nb + 1;
+  w.items = (BinItem *)take(sizeof(BinItem) * (size_t)w.max_items);
+  w.records = (BinRecord *)take(sizeof(BinRecord) * (size_t)total);
+  w.bytes = o;
+  return w;
+}
+
+// The 8 corner contributions of (point b, level): entry indices and weight * v_feat.
+struct Corner8 {
+  uint32_t idx[8];
+  float w[8];
+};
+__device__ __forceinline__ void corners_of(const HgLevels &lv, int level, float px, float py, float pz, Corner8 &c) {
+  const float scale = lv.scale[level];
+  const uint32_t res = lv.res[level], hsize = lv.hsize[level];
+  uint32_t g0[3];
+  float fr[3];
+  const float xin[3] = {px, py, pz};
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    const float pos = fmaf(scale, xin[d], 0.5f);
+    const float fl = floorf(pos);
+    g0[d] = (uint32_t)(int32_t)fl;
+    fr[d] = pos - fl;
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int hx = k & 1, hy = (k >> 1) & 1, hz = k >> 2;
+    c.idx[k] = grid_index(hsize, res, g0[0] + hx, g0[1] + hy, g0[2] + hz);
+    // same association as hashgrid_bwd_kernel: (wx * wy) * wz
+    const float wx = hx ? fr[0] : 1.f - fr[0], wy = hy ? fr[1] : 1.f - fr[1], wz = hz ? fr[2] : 1.f - fr[2];
+    c.w[k] = wx * wy * wz;
+  }
+}
+
+// ---- level maxima of |v_feat| (bit patterns of non-negative floats: unsigned max) -------------------------------------
+// corner weights are <= 1, so this bounds every contribution of the level; it fixes the apply pass's fixed point
+__global__ void __launch_bounds__(256)
+    bin_vmax_kernel(int64_t n2, int n_levels, const float2 *__restrict__ v_feat, uint32_t *__restrict__ lmax) {
+  __shared__ uint32_t s_max[HG_MAX_LEVELS];
+  if (threadIdx.x < HG_MAX_LEVELS) s_max[threadIdx.x] = 0u;
+  __syncthreads();
+  // element i of the [B, n_levels] array of feature pairs belongs to level i % n_levels; the stride is a multiple of
+  // n_levels, so a lane keeps its level and needs ONE LDS atomic at the end
+  const int64_t stride = (int64_t)gridDim.x * 256 / n_levels * n_levels;
+  const int64_t i0 = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  float m = 0.f;
+  if (i0 < stride)
+    for (int64_t i = i0; i < n2; i += stride) {
+      const float2 v = v_feat[i];
+      m = fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y)));
+    }
+  if (m > 0.f) atomicMax(&s_max[(int)(i0 % n_levels)], __float_as_uint(m));
+  __syncthreads();
+  if (threadIdx.x < HG_MAX_LEVELS && s_max[threadIdx.x]) atomicMax(&lmax[threadIdx.x], s_max[threadIdx.x]);
+}
+
+// ---- count ------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(BIN_PTS)
+    bin_count_kernel(int64_t B, HgLevels lv, BinPlan bp, const float *__restrict__ x, uint32_t *__restrict__ counts) {
+  __shared__ uint32_t s_hist[BIN_MAX_LOCAL];
+  const int grp = blockIdx.x % bp.n_groups;
+  const int64_t chunk = blockIdx.x / bp.n_groups;
+  const int l0 = grp * BIN_G, l1 = min(l0 + BIN_G, lv.n_levels);
+  const int b0 = bp.tile_base[l0], nloc = bp.tile_base[l1] - b0;
+  for (int i = threadIdx.x; i < nloc; i += BIN_PTS) s_hist[i] = 0;
+  __syncthreads();
+  // 4 x 256 points per workgroup: fewer global atomics per bucket
+  for (int rep = 0; rep < 4; ++rep) {
+    const int64_t b = (chunk * 4 + rep) * BIN_PTS + threadIdx.x;
+    if (b < B) {
+      const float px = x[3 * b], py = x[3 * b + 1], pz = x[3 * b + 2];
+      for (int level = l0; level < l1; ++level) {
+        Corner8 c;
+        corners_of(lv, level, px, py, pz, c);
+        const int lb = bp.tile_base[level] - b0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) atomicAdd(&s_hist[lb + (int)(c.idx[k] >> BIN_TILE_LOG2)], 1u);
+      }
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < nloc; i += BIN_PTS)
+    if (s_hist[i]) atomicAdd(&counts[b0 + i], s_hist[i]);
+}
+
+// ---- plan: one workgroup ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024)
+    bin_plan_kernel(int nb, const uint32_t *__restrict__ counts, uint32_t *__restrict__ cursor,
+                    int64_t *__restrict__ start, BinItem *__restrict__ items, uint32_t *__restrict__ n_items) {
+  __shared__ int64_t s_rec[1024];
+  __shared__ int32_t s_it[1024];
+  __shared__ int64_t s_rec_base;
+  __shared__ int32_t s_it_base;
+  if (threadIdx.x == 0) { s_rec_base = 0; s_it_base = 0; }
+  __syncthreads();
+  for (int base = 0; base < nb; base += 1024) {
+    const int b = base + threadIdx.x;
+    const int64_t cnt = b < nb ? (int64_t)counts[b] : 0;
+    const int32_t nit = cnt > 0 ? (int32_t)((cnt + BIN_ITEM_MAX - 1) / BIN_ITEM_MAX) : 0;
+    s_rec[threadIdx.x] = cnt;
+    s_it[threadIdx.x] = nit;
+    __syncthreads();
+    for (int s = 1; s < 1024; s <<= 1) {  // inclusive Hillis-Steele scan
+      const int64_t a = threadIdx.x >= s ? s_rec[threadIdx.x - s] : 0;
+      const int32_t c = threadIdx.x >= s ? s_it[threadIdx.x - s] : 0;
+      __syncthreads();
+      s_rec[threadIdx.x] += a;
+      s_it[threadIdx.x] += c;
+      __syncthreads();
+    }
+    const int64_t rec0 = s_rec_base + s_rec[threadIdx.x] - cnt;
+    const int32_t it0 = s_it_base + s_it[threadIdx.x] - nit;
+    if (b < nb) {
+      start[b] = rec0;
+      cursor[b] = 0;
+      for (int32_t i = 0; i < nit; ++i) {
+        BinItem it;
+        it.begin = rec0 + (int64_t)i * BIN_ITEM_MAX;
+        it.end = min(rec0 + cnt, it.begin + BIN_ITEM_MAX);
+        it.bucket = b;
+        it.shared = nit > 1;
+        items[it0 + i] = it;
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x == 1023) { s_rec_base += s_rec[1023]; s_it_base += s_it[1023]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { start[nb] = s_rec_base; *n_items = (uint32_t)s_it_base; }
+}
+
+// ---- emit -------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(BIN_PTS)
+    bin_emit_kernel(int64_t B, HgLevels lv, BinPlan bp, const float *__restrict__ x, const float *__restrict__ v_feat,
+                    const int64_t *__restrict__ start, uint32_t *__restrict__ cursor, BinRecord *__restrict__ records) {
+  __shared__ uint32_t s_key[BIN_REC];
+  __shared__ float s_g0[BIN_REC], s_g1[BIN_REC];
+  __shared__ uint32_t s_hist[BIN_MAX_LOCAL], s_off[BIN_MAX_LOCAL];
+  __shared__ int64_t s_dst[BIN_MAX_LOCAL];
+  const int grp = blockIdx.x % bp.n_groups;
+  const int64_t chunk = blockIdx.x / bp.n_groups;
+  const int l0 = grp * BIN_G, l1 = min(l0 + BIN_G, lv.n_levels);
+  const int b0 = bp.tile_base[l0], nloc = bp.tile_base[l1] - b0;
+  const int t = threadIdx.x;
+  if (t < BIN_MAX_LOCAL) s_hist[t] = 0;
+  __syncthreads();
+  const int64_t b = chunk * BIN_PTS + t;
+  // pass 1: contributions in registers, slot within the workgroup's bucket run from an LDS counter
+  uint32_t key[BIN_G * 8], slot[BIN_G * 8];
+  float g0[BIN_G * 8], g1[BIN_G * 8];
+  if (b < B) {
+    const float px = x[3 * b], py = x[3 * b + 1], pz = x[3 * b + 2];
+#pragma unroll
+    for (int g = 0; g < BIN_G; ++g) {
+      const int level = l0 + g;
+      if (level < l1) {
+        Corner8 c;
+        corners_of(lv, level, px, py, pz, c);
+        const float2 vf = *reinterpret_cast<const float2 *>(v_feat + (b * lv.n_levels + level) * 2);
+        const int lb = bp.tile_base[level] - b0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const uint32_t bucket = (uint32_t)lb + (c.idx[k] >> BIN_TILE_LOG2);
+          key[g * 8 + k] = (c.idx[k] & (BIN_TILE - 1)) | (bucket << 16);
+          slot[g * 8 + k] = atomicAdd(&s_hist[bucket], 1u);
+          g0[g * 8 + k] = c.w[k] * vf.x;
+          g1[g * 8 + k] = c.w[k] * vf.y;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // reserve the runs in the global buckets; exclusive scan of the local histogram
+  const uint32_t mine = t < nloc ? s_hist[t] : 0u;
+  if (t < nloc && mine) s_dst[t] = start[b0 + t] + (int64_t)atomicAdd(&cursor[b0 + t], mine);
+  s_off[t] = mine;
+  __syncthreads();
+  for (int s = 1; s < BIN_MAX_LOCAL; s <<= 1) {
+    const uint32_t a = t >= s ? s_off[t - s] : 0u;
+    __syncthreads();
+    s_off[t] += a;
+    __syncthreads();
+  }
+  const uint32_t n_rec = s_off[BIN_MAX_LOCAL - 1];
+  __syncthreads();
+  s_off[t] -= mine;  // inclusive -> exclusive
+  __syncthreads();
+  // pass 2: records to their sorted position in LDS
+  if (b < B) {
+#pragma unroll
+    for (int g = 0; g < BIN_G; ++g)
+      if (l0 + g < l1) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const uint32_t bucket = key[g * 8 + k] >> 16;
+          const uint32_t p = s_off[bucket] + slot[g * 8 + k];
+          s_key[p] = key[g * 8 + k];      // entry within tile | local bucket << 16
+          s_g0[p] = g0[g * 8 + k];
+          s_g1[p] = g1[g * 8 + k];
+        }
+      }
+  }
+  __syncthreads();
+  // pass 3: runs to the global buckets; consecutive lanes write consecutive 12-byte records
+  for (uint32_t p = t; p < n_rec; p += BIN_PTS) {
+    const uint32_t kb = s_key[p], bucket = kb >> 16;
+    BinRecord r;
+    r.key = kb & 0xFFFFu;
+    r.g0 = s_g0[p];
+    r.g1 = s_g1[p];
+    records[s_dst[bucket] + (int64_t)(p - s_off[bucket])] = r;
+  }
+}
+
+// ---- apply ------------------------------------------------------------------------------------------------------
+static constexpr int BIN_FIX_BITS = 41;   // 2^41 * 2^ceil(log2 max) * 2^19 records per item < 2^62: no overflow
+__device__ __forceinline__ long long to_fixed(float g, double scale) {
+  // round(g * scale) through the 1.5 * 2^52 magic number: exact for |g * scale| < 2^51
+  return __double_as_longlong(fma((double)g, scale, 6755399441055744.0)) - 0x4338000000000000LL;
+}
+
+__global__ void __launch_bounds__(BIN_APPLY_THREADS)
+    bin_apply_kernel(HgLevels lv, BinPlan bp, const BinItem *__restrict__ items, const uint32_t *__restrict__ n_items,
+                     const uint32_t *__restrict__ lmax, const BinRecord *__restrict__ records, float *__restrict__ v_table) {
+  __shared__ unsigned long long s_tile[2 * BIN_TILE];
+  if (blockIdx.x >= *n_items) return;
+  const BinItem it = items[blockIdx.x];
+  // bucket -> (level, tile)
+  int level = 0;
+  while (level + 1 < lv.n_levels && bp.tile_base[level + 1] <= it.bucket) ++level;
+  const uint32_t mx = lmax[level];
+  if (mx == 0u) return;                            // every contribution of this level is zero
+  const int e = (int)(mx >> 23) - 126;             // |g| < 2^e
+  const double scale = ldexp(1.0, BIN_FIX_BITS - e), inv = ldexp(1.0, e - BIN_FIX_BITS);
+  for (int i = threadIdx.x; i < 2 * BIN_TILE; i += BIN_APPLY_THREADS) s_tile[i] = 0ull;
+  __syncthreads();
+  const int64_t n = it.end - it.begin;
+  const BinRecord *rec = records + it.begin;
+  int64_t i = threadIdx.x;
+  for (; i + 3 * BIN_APPLY_THREADS < n; i += 4 * BIN_APPLY_THREADS) {  // 4 loads in flight per lane
+    BinRecord r[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) r[u] = rec[i + u * BIN_APPLY_THREADS];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      atomicAdd(&s_tile[2 * r[u].key], (unsigned long long)to_fixed(r[u].g0, scale));
+      atomicAdd(&s_tile[2 * r[u].key + 1], (unsigned long long)to_fixed(r[u].g1, scale));
+    }
+  }
+  for (; i < n; i += BIN_APPLY_THREADS) {
+    const BinRecord r = rec[i];
+    atomicAdd(&s_tile[2 * r.key], (unsigned long long)to_fixed(r.g0, scale));
+    atomicAdd(&s_tile[2 * r.key + 1], (unsigned long long)to_fixed(r.g1, scale));
+  }
+  __syncthreads();
+  const int tile = it.bucket - bp.tile_base[level];
+  const int64_t e0 = (int64_t)tile << BIN_TILE_LOG2;
+  const int n_ent = (int)min((int64_t)BIN_TILE, (int64_t)lv.hsize[level] - e0);
+  float *dst = v_table + ((int64_t)lv.offset[level] + e0) * 2;
+  auto val = [&](int j) { return (float)((double)(long long)s_tile[j] * inv); };
+  if (!it.shared) {
+    // hsize is a multiple of 8 entries and level offsets are too: 16-byte aligned float4 read-modify-writes
+    for (int j = threadIdx.x; j < n_ent / 2; j += BIN_APPLY_THREADS) {
+      float4 d = reinterpret_cast<float4 *>(dst)[j];
+      d.x += val(4 * j); d.y += val(4 * j + 1); d.z += val(4 * j + 2); d.w += val(4 * j + 3);
+      reinterpret_cast<float4 *>(dst)[j] = d;
+    }
+  } else {
+    for (int j = threadIdx.x; j < 2 * n_ent; j += BIN_APPLY_THREADS) {
+      const float s = val(j);
+      if (s != 0.f) atomicAdd(dst + j, s);
+    }
+  }
+}
+
+}  // namespace gsdf
+
+using namespace gsdf;
+
+static int binned_setup(int64_t B, int n_levels, int n_feat, int log2_hashmap, int base_res, float per_level_scale,
+                        HgLevels *lv, BinPlan *bp) {
+  if (n_levels < 1 || n_levels > HG_MAX_LEVELS || n_feat != 2 || log2_hashmap < 3 || log2_hashmap > 30 || base_res < 1 ||
+      per_level_scale < 1.0f || B < 0)
+    return -1;
+  build_levels(n_levels, log2_hashmap, base_res, per_level_scale, lv, nullptr);
+  return make_plan(*lv, bp) ? 0 : -2;
+}
+
+extern "C" size_t gsdf_hashgrid_bwd_binned_ws_bytes(int64_t B, int n_levels, int n_feat, int log2_hashmap, int base_res,
+                                                    float per_level_scale) {
+  HgLevels lv;
+  BinPlan bp;
+  if (binned_setup(B, n_levels, n_feat, log2_hashmap, base_res, per_level_scale, &lv, &bp) != 0) return 0;
+  return carve(nullptr, B, n_levels, bp.tile_base[n_levels]).bytes;
+}
+
+extern "C" int gsdf_hashgrid_bwd_binned(int64_t B, int n_levels, int n_feat, int log2_hashmap, int base_res,
+                                        float per_level_scale, const float *x, const float *v_feat, float *v_table,
+                                        void *ws, size_t ws_bytes, gsdf_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  HgLevels lv;
+  BinPlan bp;
+  const int rc = binned_setup(B, n_levels, n_feat, log2_hashmap, base_res, per_level_scale, &lv, &bp);
+  GSDF_REQUIRE(rc != -1, "hashgrid_bwd_binned: bad grid configuration");
+  GSDF_REQUIRE(rc == 0, "hashgrid_bwd_binned: table too large for the binned scatter (use gsdf_hashgrid_bwd)");
+  if (B == 0) return GSDF_OK;
+  GSDF_REQUIRE(x && v_feat && v_table && ws, "hashgrid_bwd_binned: null buffer");
+  GSDF_REQUIRE(((uintptr_t)v_table & 15) == 0 && ((uintptr_t)ws & 255) == 0, "hashgrid_bwd_binned: v_table must be 16-byte and ws 256-byte aligned");
+  const int nb = bp.tile_base[n_levels];
+  const BinWs w = carve(ws, B, n_levels, nb);
+  GSDF_REQUIRE(ws_bytes >= w.bytes, "hashgrid_bwd_binned: workspace too small (%zu < %zu)", ws_bytes, w.bytes);
+  GSDF_HIP(hipMemsetAsync(w.counts, 0, sizeof(uint32_t) * (nb + HG_MAX_LEVELS), stream), "hashgrid_bwd_binned memset");
+  const int64_t chunks4 = (B + 4 * BIN_PTS - 1) / (4 * BIN_PTS), chunks = (B + BIN_PTS - 1) / BIN_PTS;
+  GSDF_REQUIRE(chunks * bp.n_groups < (int64_t)1 << 31, "hashgrid_bwd_binned: batch too large");
+  bin_vmax_kernel<<<1024, 256, 0, stream>>>(B * n_levels, n_levels, reinterpret_cast<const float2 *>(v_feat), w.lmax);
+  GSDF_CHECK_LAUNCH("bin_vmax_kernel");
+  bin_count_kernel<<<(unsigned)(chunks4 * bp.n_groups), BIN_PTS, 0, stream>>>(B, lv, bp, x, w.counts);
+  GSDF_CHECK_LAUNCH("bin_count_kernel");
+  bin_plan_kernel<<<1, 1024, 0, stream>>>(nb, w.counts, w.cursor, w.start, w.items, w.n_items);
+  GSDF_CHECK_LAUNCH("bin_plan_kernel");
+  bin_emit_kernel<<<(unsigned)(chunks * bp.n_groups), BIN_PTS, 0, stream>>>(B, lv, bp, x, v_feat, w.start, w.cursor, w.records);
+  GSDF_CHECK_LAUNCH("bin_emit_kernel");
+  bin_apply_kernel<<<(unsigned)w.max_items, BIN_APPLY_THREADS, 0, stream>>>(lv, bp, w.items, w.n_items, w.lmax, w.records, v_table);
+  GSDF_CHECK_LAUNCH("bin_apply_kernel");
+  return GSDF_OK;
+}

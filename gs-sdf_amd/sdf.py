@@ -11,6 +11,7 @@ Mirrors, with the same names and behaviour,
 """
 import ctypes as C
 import math
+import os
 
 import torch
 
@@ -28,6 +29,29 @@ def _gcfg(cfg):
             int(cfg["base_resolution"]), float(cfg["per_level_scale"]))
 
 
+BINNED_MIN_POINTS = 65536     # below this the atomic scatter kernel is faster than the four binned passes
+
+
+def scatter_table_grad(B, cfg, x, table, v_feat, v_table, v_x=None):
+    """v_table += (d feat / d table)^T v_feat [and v_x = (d feat / d x)^T v_feat].  Large batches take the binned scatter
+    (include/gsdf_hip.h: gsdf_hashgrid_bwd_binned, no global atomics); GSDF_HASHGRID_BINNED=0/1 forces one path (tests)."""
+    L = capi.lib()
+    mode = os.environ.get("GSDF_HASHGRID_BINNED", "auto")
+    nbytes = 0
+    if v_table is not None and mode != "0" and (mode == "1" or B >= BINNED_MIN_POINTS):
+        nbytes = L.gsdf_hashgrid_bwd_binned_ws_bytes(B, *cfg)
+    if nbytes:
+        if v_x is not None:
+            capi.check(_timed("hashgrid_bwd_input", L.gsdf_hashgrid_bwd, B, *cfg, f32(x), f32(table), f32(v_feat), None,
+                              f32(v_x), capi.stream()), "hashgrid_bwd")
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+        capi.check(_timed("hashgrid_bwd", L.gsdf_hashgrid_bwd_binned, B, *cfg, f32(x), f32(v_feat), f32(v_table), ptr(ws),
+                          nbytes, capi.stream()), "hashgrid_bwd_binned")
+    else:
+        capi.check(_timed("hashgrid_bwd" if v_table is not None else "hashgrid_bwd_input", L.gsdf_hashgrid_bwd, B, *cfg,
+                          f32(x), f32(table), f32(v_feat), f32(v_table), f32(v_x), capi.stream()), "hashgrid_bwd")
+
+
 class _GridBwd(torch.autograd.Function):
     """(v_feat, x, table) -> (v_x, v_table): the encoding's backward as a differentiable op, so that
     grad-of-grad (eikonal on the analytic SDF gradient) works."""
@@ -41,8 +65,7 @@ class _GridBwd(torch.autograd.Function):
         empty = lambda: torch.zeros(0, device=x.device)
 
         def launch(vt, vx):
-            capi.check(_timed("hashgrid_bwd" if vt is not None else "hashgrid_bwd_input", L.gsdf_hashgrid_bwd, B, *cfg,
-                              f32(x), f32(table), f32(v_feat), f32(vt), f32(vx), capi.stream()), "hashgrid_bwd")
+            scatter_table_grad(B, cfg, x, table, v_feat, vt, vx)
 
         if want_table and grad_sink is not None:
             # accumulate straight into the parameter's (pre-zeroed) gradient buffer: the kernel's atomics already
@@ -418,8 +441,7 @@ class _CouplingLeg(torch.autograd.Function):
         sink = enc.grad_sink.view(table.shape)
 
         def scatter():
-            capi.check(_timed("hashgrid_bwd", L.gsdf_hashgrid_bwd, n, *cfg, f32(x01), f32(table), f32(v_feat), f32(sink), None,
-                              capi.stream()), "hashgrid_bwd")
+            scatter_table_grad(n, cfg, x01, table, v_feat, sink)
         if enc.scatter_stream is None:
             scatter()
         else:

@@ -181,6 +181,20 @@ int gsdf_hashgrid_bwd_jac(int64_t B, int n_levels, int n_feat, const float *jac,
 int gsdf_hashgrid_bwd(int64_t B, int n_levels, int n_feat, int log2_hashmap, int base_res, float per_level_scale,
                       const float *x, const float *table, const float *v_feat, float *v_table, float *v_x,
                       gsdf_stream_t stream);
+/* The table gradient alone, without global atomics (count -> plan -> emit 12-byte records bucketed by 64 KB table tile ->
+ * accumulate each tile in LDS): the scatter of the joint iteration's large batches (7 x (ray points + visible splat
+ * samples), neural_mapping.cpp:106-136,448-451).  v_table ACCUMULATES and must not be written by anything else while
+ * the call runs (tiles are added with plain read-modify-writes).  ws: gsdf_hashgrid_bwd_binned_ws_bytes(...) bytes,
+ * 256-byte aligned; that function returns 0 for grids whose levels have more than 128 tiles of 4096 entries
+ * (log2_hashmap_size > 19), for which only gsdf_hashgrid_bwd exists.  Each tile's sum is accumulated in 64-bit fixed
+ * point (exact to 2^-41 of the level's largest |v_feat| per contribution, independent of the order of the
+ * contributions), then rounded to fp32 once: results agree with gsdf_hashgrid_bwd's to fp32 summation error and are
+ * bit-reproducible from run to run unless a tile receives more than 2^19 contributions. */
+size_t gsdf_hashgrid_bwd_binned_ws_bytes(int64_t B, int n_levels, int n_feat, int log2_hashmap, int base_res,
+                                         float per_level_scale);
+int gsdf_hashgrid_bwd_binned(int64_t B, int n_levels, int n_feat, int log2_hashmap, int base_res, float per_level_scale,
+                             const float *x, const float *v_feat, float *v_table, void *ws, size_t ws_bytes,
+                             gsdf_stream_t stream);
 /* Double backward of v_x = J(x,table)^T v_feat: given vv_x [B,3] returns d/d v_feat (g_vfeat, overwritten),
  * d/d table (g_table, ACCUMULATES) and d/d x (g_x, overwritten); any may be NULL. */
 int gsdf_hashgrid_bwd_bwd(int64_t B, int n_levels, int n_feat, int log2_hashmap, int base_res,
