@@ -11,6 +11,7 @@ N>1: view-parallel (rank r renders view step*N+r), weak scaling, valu
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline`.
 """
 import argparse
+import contextlib
 import json
 import os
 import sys
@@ -37,12 +38,17 @@ def main():
     ap.add_argument("--workload", default="cfg3_1M_1080p", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sdf", action="store_true", help="splat path only (no hash-grid SDF leg)")
-    ap.add_argument("--scatter-xcds", type=int, default=2, help="XCDs reserved for the hash-grid backward (overlap mode)")
+    ap.add_argument("--scatter-xcds", type=int, default=0, help="XCDs reserved for the hash-grid backward (overlap mode); 0 = no CU "
+                                                                "masks, every stream sees the whole chip (the binned scatter is "
+                                                                "bandwidth-bound, not atomic-bound: it wants all XCDs)")
     ap.add_argument("--dump-grads", default=None, help="test hook: run ONE step without the optimizer update, save the flat "
                                                         "gradient buffers to this file and exit")
     ap.add_argument("--ray-leg-on-scatter-xcds", type=int, default=1, help="run the per-ray SDF leg on the scatter stream's XCDs")
     ap.add_argument("--ray-weights-aux", type=int, default=1, help="decoder weight gradients of the ray leg on the aux stream")
     ap.add_argument("--no-overlap", action="store_true", help="issue the SDF leg on the same HIP stream as the splat leg")
+    ap.add_argument("--light-step", action="store_true", help="round-1 step: no GS-sample eikonal regulariser, no per-iteration "
+                                                               "update_state (NOT the reference's joint iteration)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the second (light-step) timing loop")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -69,6 +75,7 @@ def main():
     import gs_sdf_amd.ops as ops
     import gs_sdf_amd.synth as synth
     from gs_sdf_amd.trainer import FusedAdam, GradGate, SplatParams, ViewParallel, inject_grads
+    from gs_sdf_amd.neural_gs import update_densify_state
 
     N, W, H, deg, replica = WORKLOADS[args.workload]
     sc = synth.make_scene(N, W, H, sh_degree=deg, seed=0, replica=replica)
@@ -101,7 +108,7 @@ def main():
     for gsdf_group in groups:
         adam_sdf.add_group(gsdf_group.flat, gsdf_group.flat_grad, [(gsdf_group.flat.numel(), 1e-4)])
 
-    sizes = {}
+    sizes, hist = {}, {}
 
     # Two legs on two HIP streams.  The SDF leg (hash grid + MLP; its scatter is bound by the memory-side fp32 atomic units)
     # runs beside the splat leg (rasteriser; bound by VALU issue).  They are the reference's own loss groups
@@ -118,10 +125,13 @@ def main():
         lm.encoder.save_jacobian = True      # d/dx of the sample points from the forward's Jacobian (first order only)
     if overlap:
         from gs_sdf_amd.streams import xcd_partition_streams
-        try:
-            (main, side, aux), scatter = xcd_partition_streams(args.scatter_xcds, 3)
-        except Exception as e:      # CU masks unavailable: same schedule on ordinary HIP streams (slower, still correct)
-            print(f"[bench] XCD-partitioned streams unavailable ({e}); using unmasked streams", file=sys.stderr, flush=True)
+        if args.scatter_xcds > 0:
+            try:
+                (main, side, aux), scatter = xcd_partition_streams(args.scatter_xcds, 3)
+            except Exception as e:      # CU masks unavailable: same schedule on ordinary HIP streams
+                print(f"[bench] XCD-partitioned streams unavailable ({e}); using unmasked streams", file=sys.stderr, flush=True)
+                main, side, aux, scatter = (torch.cuda.Stream() for _ in range(4))
+        else:
             main, side, aux, scatter = (torch.cuda.Stream() for _ in range(4))
         lm.encoder.scatter_stream = scatter
         lm.decoder.aux_stream = aux          # decoder weight gradients: off the chain that leads back to the splat leg
@@ -143,6 +153,9 @@ def main():
         if host is not None:
             host.append((tag, time.perf_counter()))
 
+    gs_state = {}
+    state = {"light": args.light_step}
+
     def step(i, update=True):
         stamp("begin")
         view = views[(i * world + rank) % views.shape[0]][None]
@@ -157,16 +170,24 @@ def main():
             aux_saved, lm.decoder.aux_stream = lm.decoder.aux_stream, (None if (ray_stream is scatter and not args.ray_weights_aux) else lm.decoder.aux_stream)
             with torch.cuda.stream(ray_stream):
                 pts, tgt = pool[i % 8], ray_sdf[i % 8]
-                lm.ray_loss(pts, tgt, 0.02, 0.1).backward()
+                with sdfm.grad_sinks_armed():
+                    lm.ray_loss(pts, tgt, 0.02, 0.1).backward()
             lm.decoder.aux_stream = aux_saved
         stamp("ray leg issued")
         xyz, quat, scales, opacity, sh = params.activated()
         colors, alphas, meta = ops.rasterization_2dgs_sdf(xyz, quat, scales, opacity, sh, view, K, W, H, near_plane=0.05,
                                                           far_plane=300.0, sh_degree=deg, center_reg=True, samples_gate=gate)
+        # colour: the reference's photometric loss 0.8 L1 + 0.2 D-SSIM (neural_mapping.cpp:237-240), fused HIP kernel;
+        # depth / alpha / normal / median: op-level 1e-6 N(0,1) upstream gradients so that every backward path is live.
+        # Issued BEFORE the coupling leg: its kernels only need the render, and the host spends ~1 ms issuing that leg.
+        loss = ops.l1_dssim_loss(meta["color"][0], target, 0.8, 0.2) + inject_grads(
+            [(meta["depth"], ug6["v_render_depths"]), (alphas, ug6["v_render_alphas"]),
+             (meta["render_normal"], ug6["v_render_normals"]), (meta["render_median"], ug6["v_render_median"])])
+        stamp("render + loss issued (2 syncs)")
         if not args.no_sdf:
-            # GS <-> SDF coupling (neural_mapping.cpp:420-462): SDF at the visible splats' samples.  This is the longest
-            # dependency chain of the step (compositing -> visible set -> encoder -> decoder -> back), so it is issued first.
-            stamp("render issued (2 syncs)")
+            # GS <-> SDF coupling (neural_mapping.cpp:420-462): SDF at the visible splats' samples: gs_sdf_loss on the base
+            # points + (full step) the eikonal regulariser on the numerical gradient at the same points, i.e. 6 more
+            # encoder / decoder evaluations per sample (sdf_regularization(gs_samples.detach(), ...), :448-451 -> :106-136)
             vis = meta["visibilities"].detach()
             w_all = (meta["samples_weights"] * vis).detach()
             valid = lm.get_valid_mask(meta["samples"].detach()) & (vis > 0.1).squeeze(-1)      # neural_mapping.cpp:430-432
@@ -182,21 +203,23 @@ def main():
                     t.record_stream(side)               # out of main's allocator until side has passed this point
             with torch.cuda.stream(side):
                 if ids.numel() > 0:
-                    lm.gs_sdf_coupling(samples_cut, ids, w_all, 1e-3).backward()
+                    light = state["light"]
+                    cl = lm.gs_sdf_coupling(samples_cut, ids, w_all, 1e-3, None if light else 0.02, 0.0 if light else 0.1)
+                    with sdfm.grad_sinks_armed():
+                        cl.backward()
                 gate.event = side.record_event() if side is not main else None     # d loss / d samples is complete
             stamp("samples leg issued")
-        # colour: the reference's photometric loss 0.8 L1 + 0.2 D-SSIM (neural_mapping.cpp:237-240), fused HIP kernel;
-        # depth / alpha / normal / median: op-level 1e-6 N(0,1) upstream gradients so that every backward path is live
-        loss = ops.l1_dssim_loss(meta["color"][0], target, 0.8, 0.2) + inject_grads(
-            [(meta["depth"], ug6["v_render_depths"]), (alphas, ug6["v_render_alphas"]),
-             (meta["render_normal"], ug6["v_render_normals"]), (meta["render_median"], ug6["v_render_median"])])
-        stamp("loss issued")
-        if not args.no_sdf and samples_cut.grad is not None:
-            if side is not main:
-                samples_cut.grad.record_stream(main)    # allocated on `side`, read by the projection backward on `main`
-            torch.autograd.backward([loss, samples], [None, samples_cut.grad])
-        else:
-            loss.backward()
+        with (sdfm.grad_sinks_armed() if not args.no_sdf else contextlib.nullcontext()):
+            if not args.no_sdf and samples_cut.grad is not None:
+                if side is not main:
+                    samples_cut.grad.record_stream(main)    # allocated on `side`, read by the projection backward on `main`
+                torch.autograd.backward([loss, samples], [None, samples_cut.grad])
+            else:
+                loss.backward()
+        if not state["light"]:
+            # per-iteration train_callback -> NeuralGS::update_state (neural_mapping.cpp:486, neural_gaussian.cpp:626-680):
+            # densification statistics from the compositing backward's `densify` gradient, one fused launch
+            update_densify_state(gs_state, meta, N)
         stamp("backward issued")
         if world > 1:
             main.wait_stream(scatter)      # RCCL's workgroups land on every XCD: do not run them beside the scatter
@@ -216,6 +239,8 @@ def main():
                     groups[0].flat_grad.zero_()
         stamp("optimizers issued")
         sizes.update(M=int(meta["gaussian_ids"].shape[0]), I=int(meta["flatten_ids"].shape[0]))
+        for k in ("M", "I", "n_gs_sdf"):
+            hist.setdefault(k, []).append(sizes.get(k, 0))
 
     vp.zero_grad()
     if args.dump_grads:
@@ -236,18 +261,28 @@ def main():
     torch.cuda.synchronize()
     # HIP-event timing of the roofline kernels over the timed region (the full per-operator table comes from a short
     # separate pass below: two events per launch on all ~25 operators cost ~2 % of the step in host time)
-    ROOF = {"hashgrid_bwd", "hashgrid_fwd", "rasterize_2dgs_fwd", "rasterize_2dgs_bwd"}
-    ops.TIMERS.enable(only=ROOF)
-    if host is not None:
-        host.clear()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(args.warmup + i)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+    ROOF = {"hashgrid_bwd", "hashgrid_fwd", "rasterize_2dgs_fwd", "rasterize_2dgs_bwd", "mlp_fwd", "mlp_bwd_data", "mlp_bwd_weights"}
+
+    def timed(n_steps, first):
+        hist.clear()
+        ops.TIMERS.enable(only=ROOF)
+        if host is not None:
+            host.clear()
+        t0 = time.perf_counter()
+        for i in range(n_steps):
+            step(first + i)
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([el], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el, ops.TIMERS.summary_ms("median"), ops.TIMERS.summary_ms("mean"), ops.TIMERS.calls(), {k: sum(v) / len(v) for k, v in hist.items()}
+
+    elapsed, kern, kern_mean, calls, avg = timed(args.steps, args.warmup)
     if host is not None and rank == 0:
         import collections
         acc, n = collections.OrderedDict(), 0
@@ -256,90 +291,139 @@ def main():
                 acc[tb] = acc.get(tb, 0.0) + (b - a)
             n += tb == "optimizers issued"
         print("host ms/step: " + ", ".join(f"{k} {v / n * 1e3:.2f}" for k, v in acc.items()), file=sys.stderr, flush=True)
-    kern = ops.TIMERS.summary_ms()
-    calls = ops.TIMERS.calls()
     ops.TIMERS.enable()                       # every operator, outside the timed region
+    nxt = args.warmup + args.steps
     for i in range(min(10, args.steps)):
-        step(args.warmup + args.steps + i)
-    kern_all = ops.TIMERS.summary_ms()
+        step(nxt + i)
+    nxt += min(10, args.steps)
+    kern_all = ops.TIMERS.summary_ms("median")
     ops.TIMERS.disable()
-    if dist is not None:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    secondary = None
+    if not state["light"] and not args.no_sdf and not args.no_secondary and world == 1:
+        # second, clearly named line: the lighter step round 1 timed (no GS-sample eikonal, no update_state)
+        state["light"] = True
+        n2 = max(5, min(args.steps, 30))
+        for i in range(5):
+            step(nxt + i)
+        torch.cuda.synchronize()
+        el2, _, _, _, avg2 = timed(n2, nxt + 5)
+        secondary = {"name": "light step of round 1: WITHOUT the GS-sample eikonal regulariser (neural_mapping.cpp:448-451) and "
+                             "WITHOUT the per-iteration update_state; not the reference's joint iteration",
+                     "value": n2 / el2, "unit": "iters/s", "ms_per_step": el2 / n2 * 1e3, "steps": n2,
+                     "sdf_points_per_step": 7 * 32768 + avg2.get("n_gs_sdf", 0)}
+        state["light"] = False
+        ops.TIMERS.disable()
 
     if rank == 0:
-        M, I = sizes["M"], sizes["I"]
+        M, I, n_gs = avg["M"], avg["I"], avg.get("n_gs_sdf", 0.0)        # means over the timed steps (views differ per step)
         P, T = W * H, ((W + 15) // 16) * ((H + 15) // 16)
         Kb = (deg + 1) ** 2
-        # algorithmic bytes per launch.  The dominant kernel is the one with the
-        # largest total time per step (average launch x launches per step).
+        stencil = 1 if state["light"] else 7
+        sdf_pts = 0 if args.no_sdf else 7 * 32768 + stencil * n_gs
+        # algorithmic bytes / flops per launch.  The dominant kernel is the one with the
+        # largest total time per step (median launch x launches per step).
         alg = {"rasterize_2dgs_bwd": 80 * I + 48 * P + 88 * M, "rasterize_2dgs_fwd": 80 * I + 48 * P}
+        flops = {}
         if not args.no_sdf:
-            # S1 per query point: fwd 12 + 1024 (16 levels x 8 corners x 8 B) + 128; bwd 8 + 128 + 1024 scatter; averaged
-            # over the launches of a step (7 x 32768 ray + stencil points in one launch, the visible splat samples in another)
-            pts = (7 * 32768 + sizes.get("n_gs_sdf", 0)) / max(1.0, calls.get("hashgrid_bwd", 0) / args.steps)
-            alg["hashgrid_bwd"] = int(1160 * pts)
-            alg["hashgrid_fwd"] = int(1164 * pts)
-        per_step = {k: kern.get(k, 0.0) * calls.get(k, 0) / args.steps for k in alg}
-        dom = max(alg, key=lambda k: per_step[k])
+            # S1 per query point: fwd 12 + 1024 (16 levels x 8 corners x 8 B) + 128; bwd 8 + 128 + 1024 scatter; S2: 10368
+            # multiply-adds per point and pass (32x64 + 2 x 64x64 + 64x2); per launch = per step / launches per step
+            # (the 7 x 32768 ray + stencil points in one launch, the visible splat samples and their stencil in another)
+            per_launch = lambda k: sdf_pts / max(1.0, calls.get(k, 0) / args.steps)
+            alg["hashgrid_bwd"] = 1160 * per_launch("hashgrid_bwd")
+            alg["hashgrid_fwd"] = 1164 * per_launch("hashgrid_fwd")
+            for k in ("mlp_fwd", "mlp_bwd_data", "mlp_bwd_weights"):
+                flops[k] = 2 * 10368 * per_launch(k)
+        per_step = {k: kern.get(k, 0.0) * calls.get(k, 0) / args.steps for k in list(alg) + list(flops)}
+        dom = max(per_step, key=lambda k: per_step[k])
         dur_ms = kern.get(dom, float("nan"))
-        achieved = alg[dom] / (dur_ms * 1e-3) / 1e9
+
+        def roof(k):
+            if k in alg:
+                a = alg[k] / (kern[k] * 1e-3) / 1e9
+                return {"bound": "hbm", "achieved": a, "peak": 8000.0, "unit": "GB/s", "frac": a / 8000.0,
+                        "algorithmic_bytes": int(alg[k])}
+            a = flops[k] / (kern[k] * 1e-3) / 1e12
+            return {"bound": "mfma", "achieved": a, "peak": 157.3, "unit": "TFLOP/s", "frac": a / 157.3,
+                    "algorithmic_flops": int(flops[k])}
         b_splat = (80 + 12 * Kb) * N + (364 + 12 * Kb) * M + 204 * I + 96 * P + 4 * T
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tpath):
             traffic = json.load(open(tpath)).get(args.workload, {}).get(dom)
+        vpath = os.path.join(ROOT, "profiles", "valu_insts.json")
+        valu = json.load(open(vpath)).get(args.workload) if os.path.exists(vpath) else None
+        terms = ("0.8 L1 + 0.2 D-SSIM on colour, 1e-6 N(0,1) op-level gradients on depth/alpha/normal/median" +
+                 ("" if args.no_sdf else "; per-ray SDF batch: BCE sdf_loss + 0.1 eikonal (numerical gradient, 6-point stencil) on 32768 points"
+                  "; GS<->SDF: 1e-3 gs_sdf_loss on the visible splats' samples (visibility > 0.1, occupancy-valid)" +
+                  ("" if state["light"] else " + 0.1 eikonal on the same samples (numerical gradient: 6 more encoder/decoder "
+                   "evaluations per sample, neural_mapping.cpp:448-451)") + "; decoder_implementation 1 (fused MLP; the reference forces "
+                  "numerical_grad with it, params.cpp:396-399)") +
+                 ("" if state["light"] else "; per-iteration update_state (neural_gaussian.cpp:626-680)") + "; fused Adam on all parameters")
         out = {
             "metric": "train iters/sec (splat raster + SDF fwd+bwd), 1M Gaussians @1080p" if not args.no_sdf
                       else "train iters/sec (splat raster fwd+bwd only), 1M Gaussians @1080p",
             "value": args.steps * world / elapsed, "unit": "iters/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{args.workload}: {N} random Gaussians, {W}x{H}, sh_degree {deg}, 1 view/GPU/step, "
-                                   f"M={M} I={I} L={I / T:.0f}" + ("" if args.no_sdf else f"; + hash-grid SDF (2^19 x16x2, fused 64-wide MLP): 32768 ray "
-                                   f"points x7 (numerical eikonal) + {sizes.get('n_gs_sdf', 0)} splat samples"), "parallelism": f"view-parallel x{world}" if world > 1 else "single GPU"},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                         "frac": achieved / 8000.0, "traffic": traffic, "algorithmic_bytes": alg[dom],
-                         "avg_launch_ms": dur_ms, "launches_per_step": calls.get(dom, 0) / args.steps,
-                         "ms_per_step_by_kernel": {k: round(v, 4) for k, v in per_step.items()},
-                         # the same figure for the other large kernels (the scatter runs beside the rest of the step on
-                         # XCDs of its own; the compositing backward is the largest kernel on the splat leg)
-                         "others": {k: {"achieved": alg[k] / (kern[k] * 1e-3) / 1e9, "frac": alg[k] / (kern[k] * 1e-3) / 8e12,
-                                        "avg_launch_ms": kern[k]} for k in alg if k != dom and kern.get(k)},
-                         # the scatter is bound by the memory-side fp32 atomic units, not by HBM bytes: cache-line requests per
-                         # launch (16 levels x 4 (y,z) corner pairs x 9/8 lines: the two x-neighbours share a 64 B line unless
-                         # x0 % 8 == 7) against the measured chip-wide ceiling (tools/ubench/atomic_rate.hip)
-                         "atomic_line_rate": (None if dom != "hashgrid_bwd" else {
-                             "achieved_G_per_s": 72.0 * (alg[dom] / 1160.0) / (dur_ms * 1e-3) / 1e9, "ceiling_G_per_s": 21.0,
-                             "frac": 72.0 * (alg[dom] / 1160.0) / (dur_ms * 1e-3) / 21e9,
-                             "note": "kernel confined to 2 of 8 XCDs in the two-leg step"}),
-                         "step_B_splat_bytes": b_splat,
-                         "step_hbm_frac": b_splat / (elapsed / args.steps) / 8e12},
+            "config": {"workload": f"{args.workload}: {N} random Gaussians, {W}x{H}, sh_degree {deg}, 1 view/GPU/step; means over the timed "
+                                   f"steps: M={M:.0f} I={I:.0f} L={I / T:.0f}" + ("" if args.no_sdf else f"; hash-grid SDF (2^19 x16x2, fused "
+                                   f"64-wide MLP) evaluated at {sdf_pts:.0f} points/step = 7 x 32768 ray + {stencil} x {n_gs:.0f} splat samples"),
+                       "step": ("LIGHT (--light-step): " if state["light"] else "reference joint iteration (neural_mapping.cpp:400-486): ") + terms,
+                       "parallelism": f"view-parallel x{world}" if world > 1 else "single GPU"},
+            "roofline": dict(roof(dom), kernel=dom, traffic=traffic, avg_launch_ms=dur_ms, mean_launch_ms=kern_mean.get(dom),
+                             launches_per_step=calls.get(dom, 0) / args.steps, timing="median over the timed steps (HIP events)",
+                             ms_per_step_by_kernel={k: round(v, 4) for k, v in per_step.items()},
+                             # the same figure for the other large kernels
+                             others={k: dict(roof(k), avg_launch_ms=kern[k]) for k in per_step if k != dom and kern.get(k)},
+                             # compositing kernels: VALU-issue side (they are bound by instruction issue, not HBM): wave64 VALU
+                             # instructions per launch from profiles/valu_insts.json (rocprofv3 SQ_INSTS_VALU) against the issue
+                             # peak 1024 SIMDs x 1 wave-instruction / 4 cycles... see DESIGN.md 5
+                             valu=(None if not valu else {k: {"insts_per_launch": v, "issue_peak_G_per_s": 1024 * 2.4 / 1.0,
+                                                              "frac_of_issue_peak": v / (kern[k] * 1e-3) / (1024 * 2.4e9)}
+                                                          for k, v in valu.items() if kern.get(k)}),
+                             step_B_splat_bytes=int(b_splat), step_hbm_frac=b_splat / (elapsed / args.steps) / 8e12),
             "params_finite": bool(torch.isfinite(params.flat).all()) and all(bool(torch.isfinite(g.flat).all()) for g in groups),
             "hbm_gb": {"allocated_peak": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
                        "reserved": round(torch.cuda.memory_reserved() / 2 ** 30, 2)},
-            "kernel_ms": kern_all, "kernel_ms_note": "average launch duration per operator over 10 extra steps after the timed region",
+            "kernel_ms": kern_all, "kernel_ms_note": "median launch duration per operator over 10 extra steps after the timed region",
         }
+        if secondary:
+            out["secondary"] = secondary
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(sc, views[0:1].cpu(), N, W, H, deg,
-                                               0 if args.no_sdf else 7 * 32768 + sizes.get("n_gs_sdf", 0))
+            out["cpu_baseline"] = cpu_baseline(sc, views, params, N, W, H, deg, 0 if args.no_sdf else int(sdf_pts), dev)
         print(json.dumps(out), flush=True)
     release_streams()
     if dist is not None:
         dist.destroy_process_group()
 
 
-def cpu_baseline(sc, view, N, W, H, deg, n_sdf_points=0):
-    """The oracle ("port": the reference has no CPU rasteriser and none of its kernels are vendored) timed on
-    this box's host cores: ONE full iteration (fwd + bwd) of the same workload."""
+def _err_stats(got, ref):
+    """max scaled error (|got-ref| / max(|ref|, mean|ref|)), relative L2, fraction of elements above 1e-4."""
     import numpy as np
+    got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64)
+    if ref.size == 0:
+        return {"n": 0}
+    floor = np.abs(ref).mean() + 1e-30
+    e = np.abs(got - ref) / np.maximum(np.abs(ref), floor)
+    return {"n": int(ref.size), "worst": float(e.max()), "rel_l2": float(np.linalg.norm(got - ref) / (np.linalg.norm(ref) + 1e-30)),
+            "frac_above_1e-4": float((e > 1e-4).mean())}
+
+
+def cpu_baseline(sc, views, params, N, W, H, deg, n_sdf_points, dev):
+    """The oracle ("port": the reference has no CPU rasteriser and none of its kernels are vendored) timed on this box's
+    host cores on a BOUNDED sample of the step: the splat half of ONE iteration in full (projection, SH, binning,
+    compositing forward + backward, projection / SH backward at the workload's own size) + the SDF half (hash grid +
+    decoder forward and backward) on at most 300 000 of the step's query points, scaled linearly to all of them.
+    The oracle's outputs are then compared with the HIP path's on the same inputs (the parity leg of the bench line)."""
+    import numpy as np
+    import gs_sdf_amd.ops as ops
+    import gs_sdf_amd.synth as synth
     from oracle import oracle as orc
     orc.build()
     cores = os.cpu_count() or 1
     orc.set_threads(cores)
     n = lambda t: t.detach().cpu().numpy()
-    import gs_sdf_amd.synth as synth
+    view = views[0:1].cpu()
     means, quats = n(sc["means"]), n(sc["quats"])
     t0 = time.perf_counter()
     scales, opac = np.exp(n(sc["log_scales"])), 1.0 / (1.0 + np.exp(-n(sc["logit_opacities"])))
@@ -354,27 +438,58 @@ def cpu_baseline(sc, view, N, W, H, deg, n_sdf_points=0):
                                n(ug["v_render_depths"]), n(ug["v_render_alphas"]), n(ug["v_render_normals"]),
                                n(ug["v_render_median"]), absgrad=False)
     M = p["gaussian_ids"].shape[0]
-    orc.projection_2dgs_bwd(means, quats, scales, n(view), n(sc["K"]), W, H, p["camera_ids"], p["gaussian_ids"],
-                            g["v_means2d"].astype(np.float32), np.zeros(M, np.float32),
-                            g["v_ray_transforms"].astype(np.float32), g["v_normals"].astype(np.float32))
+    pb = orc.projection_2dgs_bwd(means, quats, scales, n(view), n(sc["K"]), W, H, p["camera_ids"], p["gaussian_ids"],
+                                 g["v_means2d"].astype(np.float32), np.zeros(M, np.float32),
+                                 g["v_ray_transforms"].astype(np.float32), g["v_normals"].astype(np.float32))
     orc.view_colors_bwd(n(view), means, n(sc["sh"]), p["camera_ids"], p["gaussian_ids"], deg, g["v_colors"].astype(np.float32))
+    t_splat = time.perf_counter() - t0
+    t_sdf, n_s = 0.0, 0
     if n_sdf_points:
-        # SDF leg: hash-grid + decoder forward and backward on the same number of query points
+        # SDF leg: hash-grid + decoder forward and backward on a bounded sample of the step's query points
+        n_s = min(n_sdf_points, 300_000)
         rng = np.random.default_rng(4)
-        offs, total = orc.grid_offsets()
+        _, total = orc.grid_offsets()
         table = ((rng.random((total, 2), dtype=np.float32) * 2 - 1) * 1e-4).astype(np.float32)
         dims = [32, 64, 64, 64, 2]
         Wm = (rng.standard_normal(sum(i * o for i, o in zip(dims[:-1], dims[1:]))) * 0.1).astype(np.float32)
-        xs = rng.random((n_sdf_points, 3), dtype=np.float32)
+        xs = rng.random((n_s, 3), dtype=np.float32)
+        t1 = time.perf_counter()
         feat = orc.grid_fwd(xs, table)
         o = orc.mlp_fwd(feat, dims, Wm, None)
         v_in, v_w, _ = orc.mlp_bwd(feat, dims, Wm, None, np.ones_like(o))
         orc.grid_bwd(xs, table, v_in)
-    dt = time.perf_counter() - t0
+        t_sdf = (time.perf_counter() - t1) * (n_sdf_points / n_s)
+    dt = t_splat + t_sdf
+    # ---- parity leg: the HIP operators on the same inputs against what the oracle just computed ------------------------
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    leaves = [t(a).requires_grad_(True) for a in (means, quats, scales, opac, n(sc["sh"]))]
+    colors, alphas, meta = ops.rasterization_2dgs_sdf(*leaves, view.to(dev), sc["K"].to(dev), W, H, "RGB+D", 0.05, 300.0, 0.0, deg)
+    ugd = {k: v.to(dev) for k, v in ug.items()}
+    # RGB+D keeps the accumulated depth (the oracle's render_depths); normals go back to the camera frame for the comparison
+    R = view[0, :3, :3].to(dev)
+    rn_cam = meta["render_normal"] @ R.t()
+    loss = ((colors[..., :3] * ugd["v_render_colors"]).sum() + (colors[..., 3:4] * ugd["v_render_depths"]).sum()
+            + (alphas * ugd["v_render_alphas"]).sum() + (rn_cam * ugd["v_render_normals"]).sum()
+            + (meta["render_median"] * ugd["v_render_median"]).sum())
+    loss.backward()
+    torch.cuda.synchronize()
+    par = {"integer_outputs_bit_exact": bool(np.array_equal(n(meta["gaussian_ids"]), p["gaussian_ids"]) and np.array_equal(n(meta["radii"]), p["radii"])
+                                             and np.array_equal(n(meta["flatten_ids"]), flat) and np.array_equal(n(meta["isect_offsets"]), offs)
+                                             and np.array_equal(n(meta["tiles_per_gauss"]), tpg)),
+           "render_colors": _err_stats(n(colors[..., :3]), fw["render_colors"]), "render_depths": _err_stats(n(colors[..., 3:4]), fw["render_depths"]),
+           "render_alphas": _err_stats(n(alphas), fw["render_alphas"]), "render_normals": _err_stats(n(rn_cam), fw["render_normals"]),
+           "visibilities": _err_stats(n(meta["visibilities"]), fw["visibilities"]),
+           "v_densify": _err_stats(n(meta["gradient_2dgs"].grad), g["v_densify"]),
+           "v_quats (through projection bwd)": _err_stats(n(leaves[1].grad), pb[1]), "v_scales": _err_stats(n(leaves[2].grad), pb[2]),
+           "note": "HIP path vs the oracle's fp32 build on the bench workload's first view (ids / radii / bins bit-exact; floats: max "
+                   "scaled error, relative L2, fraction of elements above 1e-4); tests/test_gpu_baseline_shapes.py gates the same "
+                   "comparison against the fp64 build"}
     return {"value": 1.0 / dt, "unit": "iters/s", "cores": cores, "kind": "port",
-            "sample": f"1 full iteration (fwd+bwd) of the same workload, oracle/splat_oracle.c f32 build, OpenMP over tiles "
-                      f"on {cores} threads for compositing (projection/sort single-threaded)"
-                      + (f" + SDF oracle fwd+bwd on {n_sdf_points} query points" if n_sdf_points else "") + f", {dt:.1f} s"}
+            "sample": f"splat half of 1 iteration in full (oracle/splat_oracle.c f32 build, OpenMP over tiles on {cores} threads for "
+                      f"compositing, projection/sort single-threaded): {t_splat:.1f} s" +
+                      (f"; SDF half (oracle/sdf_oracle.c fwd+bwd) on {n_s} of the step's {n_sdf_points} query points, scaled linearly: "
+                       f"{t_sdf:.1f} s" if n_sdf_points else ""),
+            "parity": par}
 
 
 if __name__ == "__main__":

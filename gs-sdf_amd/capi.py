@@ -36,6 +36,7 @@ _SIGS = {
     "gsdf_hashgrid_offsets": (_i64, [_i32, _i32, _i32, _i32, _f32, _vp]),
     "gsdf_hashgrid_fwd": (C.c_int, [_i64, _i32, _i32, _i32, _i32, _f32] + [_vp] * 4),
     "gsdf_hashgrid_fwd_jac": (C.c_int, [_i64, _i32, _i32, _i32, _i32, _f32] + [_vp] * 5),
+    "gsdf_hashgrid_fwd_jac_rows": (C.c_int, [_i64, _i64, _i32, _i32, _i32, _i32, _f32] + [_vp] * 5),
     "gsdf_hashgrid_bwd_jac": (C.c_int, [_i64, _i32, _i32] + [_vp] * 4),
     "gsdf_hashgrid_bwd": (C.c_int, [_i64, _i32, _i32, _i32, _i32, _f32] + [_vp] * 6),
     "gsdf_hashgrid_bwd_binned_ws_bytes": (_sz, [_i64, _i32, _i32, _i32, _i32, _f32]),
@@ -52,6 +53,7 @@ _SIGS = {
     "gsdf_normal_consistency_bwd": (C.c_int, [_i32, _i32] + [_vp] * 9),
     "gsdf_sdf_query_points": (C.c_int, [_i64, _i32, _vp, _f32, _vp, _f32, _vp, _vp]),
     "gsdf_gs_sdf_loss": (C.c_int, [_i64, _vp, _i32, _vp, _vp, _f32, _vp, _vp, _vp]),
+    "gsdf_gs_sdf_eik_loss": (C.c_int, [_i64, _i32, _vp, _i32, _vp, _vp, _f32, _f32, _f32, _vp, _vp, _vp]),
     "gsdf_sdf_ray_loss": (C.c_int, [_i64, _i32, _vp, _i32, _vp, _f32, _f32, _f32, _vp, _vp, _vp]),
     "gsdf_occ_bytes": (_sz, [_i32]),
     "gsdf_occ_build": (C.c_int, [_i32, _i64, _vp, _i32, _vp, _vp]),
@@ -65,6 +67,7 @@ _SIGS = {
     "gsdf_mc_emit": (C.c_int, [_i32, _i32, _i32, _vp, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gsdf_splat_activations_fwd": (C.c_int, [_i64] + [_vp] * 8),
     "gsdf_splat_activations_bwd": (C.c_int, [_i64] + [_vp] * 9),
+    "gsdf_densify_stats": (C.c_int, [_i64, _i64, _i32, _i32, _i32] + [_vp] * 9),
     "gsdf_stream_set_xcds": (C.c_int, [_vp, _i32]),
     "gsdf_adam_step": (C.c_int, [_i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _f32, _i64, _vp]),
     "gsdf_knn_ws_bytes": (_sz, [_i64]),

@@ -35,8 +35,8 @@ __device__ __forceinline__ float row_sum_to_lane15(float v) {
 // a dense 32x3 contraction per point later (hashgrid_bwd_jac_kernel) instead of a second pass over the table.
 template <bool JAC>
 __global__ void __launch_bounds__(HG_THREADS)
-    hashgrid_fwd_kernel(int64_t B, HgLevels lv, const float *__restrict__ x, const float *__restrict__ table,
-                        float *__restrict__ feat, float *__restrict__ jac) {
+    hashgrid_fwd_kernel(int64_t B, int64_t jac_rows, HgLevels lv, const float *__restrict__ x,
+                        const float *__restrict__ table, float *__restrict__ feat, float *__restrict__ jac) {
   const int lane = threadIdx.x & 63;
   const int f = lane & 1, xb = (lane >> 1) & 1, level = lane >> 2;
   const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -67,7 +67,7 @@ __global__ void __launch_bounds__(HG_THREADS)
   if (xb == 0 && level < lv.n_levels) {
     const int64_t o = (b * lv.n_levels + level) * 2 + f;
     feat[o] = acc;
-    if (JAC) { jac[3 * o] = jx; jac[3 * o + 1] = jy; jac[3 * o + 2] = jz; }
+    if (JAC && b < jac_rows) { jac[3 * o] = jx; jac[3 * o + 1] = jy; jac[3 * o + 2] = jz; }
   }
 }
 
@@ -100,8 +100,9 @@ struct XcdLevels {
 };
 template <bool JAC>
 __global__ void __launch_bounds__(HG_THREADS)
-    hashgrid_fwd_xcd_kernel(int64_t B, HgLevels lv, XcdLevels xl, int n_xcd, const float *__restrict__ x,
-                            const float *__restrict__ table, float *__restrict__ feat, float *__restrict__ jac) {
+    hashgrid_fwd_xcd_kernel(int64_t B, int64_t jac_rows, HgLevels lv, XcdLevels xl, int n_xcd,
+                            const float *__restrict__ x, const float *__restrict__ table, float *__restrict__ feat,
+                            float *__restrict__ jac) {
   const int xcd = blockIdx.x % n_xcd;
   const int64_t chunk = blockIdx.x / n_xcd;
   const int l0 = xl.begin[xcd], nl = xl.count[xcd];
@@ -137,7 +138,7 @@ __global__ void __launch_bounds__(HG_THREADS)
   if (xb == 0 && live) {
     const int64_t o = (b * lv.n_levels + level) * 2 + f;
     feat[o] = acc;
-    if (JAC) { jac[3 * o] = jx; jac[3 * o + 1] = jy; jac[3 * o + 2] = jz; }
+    if (JAC && b < jac_rows) { jac[3 * o] = jx; jac[3 * o + 1] = jy; jac[3 * o + 2] = jz; }
   }
 }
 
@@ -158,8 +159,8 @@ static bool make_xcd_levels(int n_levels, int n_xcd, XcdLevels *xl, int *max_nl)
 }
 
 template <bool JAC>
-static void launch_fwd(int64_t B, const HgLevels &lv, int n_levels, const float *x, const float *table, float *feat,
-                       float *jac, hipStream_t stream) {
+static void launch_fwd(int64_t B, int64_t jac_rows, const HgLevels &lv, int n_levels, const float *x, const float *table,
+                       float *feat, float *jac, hipStream_t stream) {
   XcdLevels xl;
   int max_nl = 0;
   const int n_xcd = xcd_count(stream);
@@ -169,9 +170,9 @@ static void launch_fwd(int64_t B, const HgLevels &lv, int n_levels, const float 
   if (!off && n_xcd == 8 && B >= 65536 && make_xcd_levels(n_levels, n_xcd, &xl, &max_nl)) {
     const int ppw_min = 16 / max_nl;
     const int64_t chunks = (B + 4 * ppw_min - 1) / (4 * ppw_min);
-    hashgrid_fwd_xcd_kernel<JAC><<<(unsigned)(chunks * n_xcd), HG_THREADS, 0, stream>>>(B, lv, xl, n_xcd, x, table, feat, jac);
+    hashgrid_fwd_xcd_kernel<JAC><<<(unsigned)(chunks * n_xcd), HG_THREADS, 0, stream>>>(B, jac_rows, lv, xl, n_xcd, x, table, feat, jac);
   } else {
-    hashgrid_fwd_kernel<JAC><<<(unsigned)((B + 3) / 4), HG_THREADS, 0, stream>>>(B, lv, x, table, feat, jac);
+    hashgrid_fwd_kernel<JAC><<<(unsigned)((B + 3) / 4), HG_THREADS, 0, stream>>>(B, jac_rows, lv, x, table, feat, jac);
   }
 }
 
@@ -299,24 +300,32 @@ extern "C" int gsdf_hashgrid_fwd(int64_t B, int n_levels, int n_feat, int log2_h
   GSDF_REQUIRE(x && table && feat, "hashgrid_fwd: null buffer");
   HgLevels lv;
   build_levels(n_levels, log2_hashmap, base_res, per_level_scale, &lv, nullptr);
-  launch_fwd<false>(B, lv, n_levels, x, table, feat, nullptr, stream);
+  launch_fwd<false>(B, 0, lv, n_levels, x, table, feat, nullptr, stream);
   GSDF_CHECK_LAUNCH("hashgrid_fwd_kernel");
+  return GSDF_OK;
+}
+
+extern "C" int gsdf_hashgrid_fwd_jac_rows(int64_t B, int64_t jac_rows, int n_levels, int n_feat, int log2_hashmap,
+                                          int base_res, float per_level_scale, const float *x, const float *table,
+                                          float *feat, float *jac, gsdf_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  int rc = check_cfg(n_levels, n_feat, log2_hashmap, base_res, per_level_scale, "hashgrid_fwd_jac");
+  if (rc) return rc;
+  if (B == 0) return GSDF_OK;
+  GSDF_REQUIRE(jac_rows >= 0 && jac_rows <= B, "hashgrid_fwd_jac: jac_rows must be in [0, B]");
+  GSDF_REQUIRE(x && table && feat && (jac || jac_rows == 0), "hashgrid_fwd_jac: null buffer");
+  HgLevels lv;
+  build_levels(n_levels, log2_hashmap, base_res, per_level_scale, &lv, nullptr);
+  if (jac_rows > 0) launch_fwd<true>(B, jac_rows, lv, n_levels, x, table, feat, jac, stream);
+  else launch_fwd<false>(B, 0, lv, n_levels, x, table, feat, nullptr, stream);
+  GSDF_CHECK_LAUNCH("hashgrid_fwd_kernel<jac>");
   return GSDF_OK;
 }
 
 extern "C" int gsdf_hashgrid_fwd_jac(int64_t B, int n_levels, int n_feat, int log2_hashmap, int base_res,
                                      float per_level_scale, const float *x, const float *table, float *feat, float *jac,
-                                     gsdf_stream_t stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
-  int rc = check_cfg(n_levels, n_feat, log2_hashmap, base_res, per_level_scale, "hashgrid_fwd_jac");
-  if (rc) return rc;
-  if (B == 0) return GSDF_OK;
-  GSDF_REQUIRE(x && table && feat && jac, "hashgrid_fwd_jac: null buffer");
-  HgLevels lv;
-  build_levels(n_levels, log2_hashmap, base_res, per_level_scale, &lv, nullptr);
-  launch_fwd<true>(B, lv, n_levels, x, table, feat, jac, stream);
-  GSDF_CHECK_LAUNCH("hashgrid_fwd_kernel<jac>");
-  return GSDF_OK;
+                                     gsdf_stream_t stream) {
+  return gsdf_hashgrid_fwd_jac_rows(B, B, n_levels, n_feat, log2_hashmap, base_res, per_level_scale, x, table, feat, jac, stream);
 }
 
 extern "C" int gsdf_hashgrid_bwd_jac(int64_t B, int n_levels, int n_feat, const float *jac, const float *v_feat,

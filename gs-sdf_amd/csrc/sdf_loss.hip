@@ -86,9 +86,14 @@ __global__ void __launch_bounds__(256)
 
 // loss::gs_sdf_loss (/root/reference/include/optimizer/loss.cpp:7-11): 0.5 * sum_i w_i * sdf_i^2, with the row gather of
 // the weights (neural_mapping.cpp:436-437) folded in: w_i = weights[ids[i]] (ids == nullptr: w_i = weights[i]).
+// stencil != 0: attr holds 7n rows (base points, then the 6 central-difference blocks of gsdf_sdf_query_points) and the
+// eikonal regulariser of the visible splats' samples is added: w_eik * mean_i (|g_i| - 1)^2 with the numerical gradient
+// g (NeuralSLAM::sdf_regularization on gs_samples, neural_mapping.cpp:448-451 -> :106-116; LocalMap::get_gradient
+// local_map.cpp:110-131; loss::eikonal_loss loss.cpp:81-83).
 __global__ void __launch_bounds__(256)
-    gs_sdf_loss_kernel(int64_t n, const float *__restrict__ attr, int ld, const float *__restrict__ weights,
-                       const int64_t *__restrict__ ids, float scale, float *__restrict__ loss, float *__restrict__ v_attr) {
+    gs_sdf_loss_kernel(int64_t n, int stencil, const float *__restrict__ attr, int ld, const float *__restrict__ weights,
+                       const int64_t *__restrict__ ids, float scale, float delta, float w_eik, float *__restrict__ loss,
+                       float *__restrict__ v_attr) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   float contrib = 0.f;
   if (i < n) {
@@ -97,6 +102,25 @@ __global__ void __launch_bounds__(256)
     contrib = 0.5f * scale * w * s * s;
     v_attr[i * ld] = scale * w * s;
     for (int c = 1; c < ld; ++c) v_attr[i * ld + c] = 0.f;
+    if (stencil) {
+      const float inv_n = 1.0f / (float)n;
+      float ps[6];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) ps[k] = attr[(n + k * n + i) * ld];
+      const float h = 0.5f * (1.0f / delta);
+      const float gx = h * (ps[0] - ps[1]), gy = h * (ps[2] - ps[3]), gz = h * (ps[4] - ps[5]);
+      const float nrm = sqrtf(gx * gx + gy * gy + gz * gz);
+      const float e = nrm - 1.0f;
+      contrib += w_eik * e * e * inv_n;
+      const float k0 = nrm > 0.f ? w_eik * 2.0f * e / nrm * h * inv_n : 0.f;  // torch's norm backward: 0 at the origin
+      const float d[3] = {k0 * gx, k0 * gy, k0 * gz};
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        const int64_t r = (n + k * n + i) * ld;
+        v_attr[r] = (k & 1) ? -d[k >> 1] : d[k >> 1];
+        for (int c = 1; c < ld; ++c) v_attr[r + c] = 0.f;
+      }
+    }
   }
   const float ws = wave_sum_to_lane63(contrib);
   if ((threadIdx.x & 63) == 63 && ws != 0.f) atomicAdd(loss, ws);
@@ -132,14 +156,22 @@ extern "C" int gsdf_sdf_ray_loss(int64_t n, int stencil, const float *attr, int 
   return GSDF_OK;
 }
 
-extern "C" int gsdf_gs_sdf_loss(int64_t n, const float *attr, int ld, const float *weights, const int64_t *ids, float scale,
-                                float *loss, float *v_attr, gsdf_stream_t stream_) {
+extern "C" int gsdf_gs_sdf_eik_loss(int64_t n, int stencil, const float *attr, int ld, const float *weights,
+                                    const int64_t *ids, float scale, float delta, float w_eik, float *loss,
+                                    float *v_attr, gsdf_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   GSDF_REQUIRE(n >= 0 && ld >= 1 && loss, "gs_sdf_loss: bad arguments");
+  GSDF_REQUIRE(!stencil || delta > 0.f, "gs_sdf_loss: delta must be positive");
   GSDF_HIP(hipMemsetAsync(loss, 0, 4, stream), "gs_sdf_loss memset");
   if (n == 0) return GSDF_OK;
   GSDF_REQUIRE(attr && weights && v_attr, "gs_sdf_loss: null buffer");
-  gs_sdf_loss_kernel<<<(unsigned)((n + 255) / 256), 256, 0, stream>>>(n, attr, ld, weights, ids, scale, loss, v_attr);
+  gs_sdf_loss_kernel<<<(unsigned)((n + 255) / 256), 256, 0, stream>>>(n, stencil, attr, ld, weights, ids, scale, delta,
+                                                                      w_eik, loss, v_attr);
   GSDF_CHECK_LAUNCH("gs_sdf_loss_kernel");
   return GSDF_OK;
+}
+
+extern "C" int gsdf_gs_sdf_loss(int64_t n, const float *attr, int ld, const float *weights, const int64_t *ids, float scale,
+                                float *loss, float *v_attr, gsdf_stream_t stream) {
+  return gsdf_gs_sdf_eik_loss(n, 0, attr, ld, weights, ids, scale, 0.f, 0.f, loss, v_attr, stream);
 }

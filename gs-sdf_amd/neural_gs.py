@@ -54,6 +54,37 @@ def normalized_quat_to_rotmat(q):   # include/utils/utils.cpp:538-558 (w,x,y,z)
                         2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)], -1).reshape(-1, 3, 3)
 
 
+def update_densify_state(state, info, n, use_absgrad=False, want_radii=False, key_for_gradient="gradient_2dgs"):
+    """NeuralGS::update_state (neural_gaussian.cpp:626-680) on a state dict: grad2d / count accumulate, vis / radii take
+    the maximum.  Device tensors: ONE launch (include/gsdf_hip.h: gsdf_densify_stats) instead of the reference's ~12
+    eager kernels; host tensors (the CPU tests of the refinement policy): the reference's torch expressions."""
+    src = info["absgrad"] if use_absgrad else info[key_for_gradient]
+    n_cameras, width, height = int(info["n_cameras"]), int(info["width"]), int(info["height"])
+    dev = src.device
+    for k in ("grad2d", "count", "vis") + (("radii",) if want_radii else ()):
+        if k not in state:
+            state[k] = torch.zeros(n, device=dev)
+    gs_ids = info["gaussian_ids"]
+    if src.is_cuda:
+        from . import capi
+        capi.check(capi.lib().gsdf_densify_stats(
+            gs_ids.shape[0], n, n_cameras, width, height, capi.f32(src.grad.contiguous(), "densify gradient"),
+            capi.ptr(gs_ids.contiguous(), torch.int64), capi.f32(info["visibilities"].reshape(-1).contiguous()),
+            capi.ptr(info["radii"].contiguous(), torch.int32) if want_radii else None, capi.f32(state["grad2d"]),
+            capi.f32(state["count"]), capi.f32(state["vis"]), capi.f32(state["radii"]) if want_radii else None, capi.stream()),
+            "densify_stats")
+        return
+    grads = src.grad.clone()
+    grads[:, 0] *= width * 0.5 * n_cameras
+    grads[:, 1] *= height * 0.5 * n_cameras
+    state["grad2d"].index_add_(0, gs_ids, grads.norm(2, -1))
+    gs_vis = info["visibilities"].reshape(-1)
+    state["vis"][gs_ids] = torch.maximum(state["vis"].index_select(0, gs_ids), gs_vis)
+    state["count"].index_add_(0, gs_ids, torch.ones_like(gs_ids, dtype=torch.float32))
+    if want_radii:
+        state["radii"][gs_ids] = torch.maximum(state["radii"].index_select(0, gs_ids), info["radii"] / float(max(width, height)))
+
+
 class NeuralGS:
     """Parameter names, groups and learning rates follow neural_gaussian.cpp:426-453 (all Adam eps 1e-15)."""
 
@@ -126,22 +157,8 @@ class NeuralGS:
 
     # ---- densification statistics (neural_gaussian.cpp:626-680)
     def update_state(self, info):
-        grads = (info["absgrad"] if self.cfg.use_absgrad else info[self.key_for_gradient]).grad.clone()
-        n_cameras, width, height = int(info["n_cameras"]), int(info["width"]), int(info["height"])
-        dev, n = grads.device, self.anchors_.shape[0]
-        for k in ("grad2d", "count", "vis") + (("radii",) if self.cfg.refine_scale2d_stop_iter > 0 else ()):
-            if k not in self.state:
-                self.state[k] = torch.zeros(n, device=dev)
-        gs_ids = info["gaussian_ids"]
-        grads[:, 0] *= width * 0.5 * n_cameras
-        grads[:, 1] *= height * 0.5 * n_cameras
-        self.state["grad2d"].index_add_(0, gs_ids, grads.norm(2, -1))
-        gs_vis = info["visibilities"].reshape(-1)
-        self.state["vis"][gs_ids] = torch.maximum(self.state["vis"].index_select(0, gs_ids), gs_vis)
-        self.state["count"].index_add_(0, gs_ids, torch.ones_like(gs_ids, dtype=torch.float32))
-        if self.cfg.refine_scale2d_stop_iter > 0:
-            self.state["radii"][gs_ids] = torch.maximum(self.state["radii"].index_select(0, gs_ids),
-                                                        info["radii"] / float(max(width, height)))
+        update_densify_state(self.state, info, self.anchors_.shape[0], self.cfg.use_absgrad,
+                             self.cfg.refine_scale2d_stop_iter > 0, self.key_for_gradient)
 
     def zero_state(self):
         self.state["grad2d"].zero_()
@@ -176,7 +193,7 @@ class NeuralGS:
                 torch.cat([m if keep_idx is None else m.index_select(0, keep_idx), torch.zeros_like(e)], 0)))
 
     # ---- grow (neural_gaussian.cpp:690-827)
-    def grow_gs(self, it, optimizer):
+    def grow_gs(self, it, optimizer, generator=None):
         cfg = self.cfg
         grads = self.state["grad2d"] / self.state["count"].clamp_min(1)
         is_grad_high = grads > cfg.grow_grad2d
@@ -187,7 +204,7 @@ class NeuralGS:
             is_split |= self.state["radii"] > cfg.grow_scale2d
         n_dupli = self.duplicate(optimizer, is_dupli)
         is_split = torch.cat([is_split, torch.zeros(n_dupli, dtype=torch.bool, device=is_split.device)])
-        n_split = self.split(optimizer, is_split)
+        n_split = self.split(optimizer, is_split, generator)
         return n_dupli, n_split
 
     def duplicate(self, optimizer, is_dupli):
@@ -282,7 +299,13 @@ class NeuralGS:
             self.sh_degree_to_use_ = min(cfg.sh_degree, it // cfg.sh_degree_interval)
             if 0 < it < refine_stop:
                 if it > cfg.refine_start_iter and it % cfg.refine_every == 0 and (it % cfg.reset_every) >= cfg.pause_refine_after_reset:
-                    log["dupli"], log["split"] = self.grow_gs(it, optimizer)
+                    gen = None
+                    if view_parallel is not None:
+                        # replicas must draw the SAME split offsets (neural_gaussian.cpp:781 uses the global RNG of its
+                        # single process): ranks render different views and consume different amounts of randomness, so
+                        # the generator is seeded from the iteration alone
+                        gen = torch.Generator(device=self.anchors_.device).manual_seed(0x5EED0000 + int(it))
+                    log["dupli"], log["split"] = self.grow_gs(it, optimizer, gen)
                     log["pruned"] = self.prune_gs(it, optimizer)
                     self.zero_state()
                 if it % cfg.reset_every == 0:

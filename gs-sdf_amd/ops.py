@@ -38,9 +38,14 @@ class _Timers:
         if b is not None:
             b.record()
 
-    def summary_ms(self):
+    def summary_ms(self, stat="mean"):
         torch.cuda.synchronize()
-        return {k: sum(a.elapsed_time(b) for a, b in v) / len(v) for k, v in self.ev.items()}
+        out = {}
+        for k, v in self.ev.items():
+            ts = sorted(a.elapsed_time(b) for a, b in v)
+            out[k] = (ts[len(ts) // 2] if len(ts) % 2 else 0.5 * (ts[len(ts) // 2 - 1] + ts[len(ts) // 2])) if stat == "median" \
+                else sum(ts) / len(ts)
+        return out
 
     def calls(self):
         return {k: len(v) for k, v in self.ev.items()}

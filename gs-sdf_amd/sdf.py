@@ -29,6 +29,30 @@ def _gcfg(cfg):
             int(cfg["base_resolution"]), float(cfg["per_level_scale"]))
 
 
+class _SinkState:
+    armed = 0
+
+
+class grad_sinks_armed:
+    """Context manager around the trainer's `loss.backward()`.  The in-place gradient sinks installed by
+    LocalMap.flatten(accumulate_table_grad_in_place=True) deposit parameter gradients straight into the flat gradient
+    buffer; they do so ONLY inside this context.  Any other traversal of the graph (torch.autograd.grad w.r.t. inputs,
+    create_graph=True for the analytic eikonal term, ...) gets ordinary autograd behaviour: the parameter gradients are
+    returned to autograd and nothing is written behind its back."""
+
+    def __enter__(self):
+        _SinkState.armed += 1
+        return self
+
+    def __exit__(self, *exc):
+        _SinkState.armed -= 1
+        return False
+
+
+def _sinks_live():
+    return _SinkState.armed > 0 and not torch.is_grad_enabled()
+
+
 BINNED_MIN_POINTS = 65536     # below this the atomic scatter kernel is faster than the four binned passes
 
 
@@ -146,10 +170,11 @@ class _GridFwd(torch.autograd.Function):
             capi.check(_timed("hashgrid_bwd_input", capi.lib().gsdf_hashgrid_bwd_jac, x.shape[0], ctx.cfg[0], ctx.cfg[1],
                               f32(jac), f32(v_feat), f32(v_x), capi.stream()), "hashgrid_bwd_jac")
             want_x = False
-        g_x, v_table = _GridBwd.apply(v_feat, x, table, ctx.cfg, bool(ctx.needs_input_grad[1]), ctx.grad_sink,
-                                      ctx.scatter_stream, want_x)
+        sink = ctx.grad_sink if _sinks_live() else None
+        g_x, v_table = _GridBwd.apply(v_feat, x, table, ctx.cfg, bool(ctx.needs_input_grad[1]), sink,
+                                      ctx.scatter_stream if sink is not None else None, want_x)
         v_x = g_x if want_x else v_x
-        want_t = ctx.needs_input_grad[1] and ctx.grad_sink is None
+        want_t = ctx.needs_input_grad[1] and sink is None
         return v_x, (v_table if want_t else None), None, None, None, None
 
 
@@ -215,6 +240,7 @@ class _MlpFn(torch.autograd.Function):
         return out
 
     @staticmethod
+    @torch.autograd.function.once_differentiable      # first order only, like tcnn's FullyFusedMLP (params.cpp:396-399)
     def backward(ctx, v_out):
         L = capi.lib()
         x, weights, biases, acts = ctx.saved_tensors
@@ -224,7 +250,7 @@ class _MlpFn(torch.autograd.Function):
         v_out = v_out.contiguous()
         v_in = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         ws = torch.empty(L.gsdf_mlp_bwd_ws_bytes(B, nl), dtype=torch.uint8, device=x.device)
-        if ctx.sinks is not None and ctx.needs_input_grad[1]:
+        if ctx.sinks is not None and ctx.needs_input_grad[1] and _sinks_live():
             # trainer fast path: the parameter gradients ACCUMULATE straight into the flat gradient buffer (no zero-fill,
             # no autograd add), and their kernel runs on `aux_stream` so that d/d input — what the rest of the backward
             # pass waits for — is not queued behind it.  The gradients are complete once aux_stream has been waited for.
@@ -368,39 +394,43 @@ class _GsSdfLoss(torch.autograd.Function):
 
 
 class _CouplingLeg(torch.autograd.Function):
-    """The GS<->SDF coupling term as ONE autograd node (trainer fast path; same kernels, same order, same results as
-    LocalMap.gs_sdf_loss on the composed operators): forward = row gather, query points, encoder (+ Jacobian), decoder,
-    loss; backward = decoder data / weight gradients, d/dx from the Jacobian, table scatter, row scatter.  Saves the
-    host time of ~10 autograd nodes per step, which sits on the step's critical path (the splat leg's backward is issued
-    after this leg).  Requires the in-place gradient sinks of LocalMap.flatten(accumulate_table_grad_in_place=True)."""
+    """The GS<->SDF coupling of the joint iteration as ONE autograd node (trainer fast path; same kernels, same results
+    as the composed operators): forward = row gather, query points (+ the 6 central-difference points when `delta` is
+    given), encoder (+ Jacobian of the base rows), decoder, loss = scale * gs_sdf_loss [+ w_eik * eikonal_loss of the
+    numerical gradient: NeuralSLAM::sdf_regularization(gs_samples.detach(), ...), neural_mapping.cpp:448-451]; backward =
+    decoder data / weight gradients, d/dx of the base rows from the Jacobian, table scatter, row scatter.  Saves the
+    host time of ~10 autograd nodes per step.  Requires the in-place gradient sinks of
+    LocalMap.flatten(accumulate_table_grad_in_place=True) and grad_sinks_armed() around the backward call."""
 
     @staticmethod
-    def forward(ctx, samples, ids, weights, lm, scale):
+    def forward(ctx, samples, ids, weights, lm, scale, delta, w_eik):
         L = capi.lib()
         enc, dec = lm.encoder, lm.decoder
         cfg, dims = enc.cfg, tuple(dec.dims)
         xs = samples.index_select(0, ids)
         n = xs.shape[0]
+        K = 1 if delta is None else 7
         dev = xs.device
-        x01 = torch.empty(n, 3, dtype=torch.float32, device=dev)
-        capi.check(L.gsdf_sdf_query_points(n, 0, f32(xs), 0.0, (C.c_float * 3)(*lm._origin), float(lm.map_size_inv), f32(x01),
-                                           capi.stream()), "sdf_query_points")
+        x01 = torch.empty(K * n, 3, dtype=torch.float32, device=dev)
+        capi.check(L.gsdf_sdf_query_points(n, int(K == 7), f32(xs), float(delta or 0.0), (C.c_float * 3)(*lm._origin),
+                                           float(lm.map_size_inv), f32(x01), capi.stream()), "sdf_query_points")
         table = enc.params_.view(-1, cfg[1])
         nf = cfg[0] * cfg[1]
-        feat = torch.empty(n, nf, dtype=torch.float32, device=dev)
+        feat = torch.empty(K * n, nf, dtype=torch.float32, device=dev)
         jac = torch.empty(n, nf, 3, dtype=torch.float32, device=dev)
-        capi.check(_timed("hashgrid_fwd", L.gsdf_hashgrid_fwd_jac, n, *cfg, f32(x01), f32(table), f32(feat), f32(jac),
+        capi.check(_timed("hashgrid_fwd", L.gsdf_hashgrid_fwd_jac_rows, K * n, n, *cfg, f32(x01), f32(table), f32(feat), f32(jac),
                           capi.stream()), "hashgrid_fwd_jac")
         nl = len(dims) - 1
         dims_c = (C.c_int * len(dims))(*dims)
-        attr = torch.empty(n, dims[-1], dtype=torch.float32, device=dev)
-        acts = torch.empty(L.gsdf_mlp_acts_floats(n, nl), dtype=torch.float32, device=dev)
-        capi.check(_timed("mlp_fwd", L.gsdf_mlp_fwd, n, nl, dims_c, f32(dec.params_), f32(dec.biases_), f32(feat), f32(attr),
+        attr = torch.empty(K * n, dims[-1], dtype=torch.float32, device=dev)
+        acts = torch.empty(L.gsdf_mlp_acts_floats(K * n, nl), dtype=torch.float32, device=dev)
+        capi.check(_timed("mlp_fwd", L.gsdf_mlp_fwd, K * n, nl, dims_c, f32(dec.params_), f32(dec.biases_), f32(feat), f32(attr),
                           f32(acts), capi.stream()), "mlp_fwd")
         loss = torch.empty((), dtype=torch.float32, device=dev)
         v_attr = torch.empty_like(attr)
-        capi.check(_timed("gs_sdf_loss", L.gsdf_gs_sdf_loss, n, f32(attr), attr.shape[1], f32(weights.reshape(-1)), ptr(ids, torch.int64),
-                          float(scale), f32(loss), f32(v_attr), capi.stream()), "gs_sdf_loss")
+        capi.check(_timed("gs_sdf_loss", L.gsdf_gs_sdf_eik_loss, n, int(K == 7), f32(attr), attr.shape[1], f32(weights.reshape(-1)),
+                          ptr(ids, torch.int64), float(scale), float(delta or 0.0), float(w_eik), f32(loss), f32(v_attr),
+                          capi.stream()), "gs_sdf_loss")
         ctx.save_for_backward(ids, x01, feat, jac, acts, v_attr)
         ctx.lm, ctx.n_rows = lm, samples.shape[0]
         return loss
@@ -408,23 +438,26 @@ class _CouplingLeg(torch.autograd.Function):
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, v_loss):
+        if _SinkState.armed <= 0:
+            raise RuntimeError("gs_sdf_coupling: call backward inside `with sdf.grad_sinks_armed():` (the node accumulates "
+                               "parameter gradients in place)")
         L = capi.lib()
         ids, x01, feat, jac, acts, v_attr = ctx.saved_tensors
         lm = ctx.lm
         enc, dec = lm.encoder, lm.decoder
         cfg, dims = enc.cfg, tuple(dec.dims)
-        n, nl = x01.shape[0], len(dims) - 1
+        nq, n, nl = x01.shape[0], jac.shape[0], len(dims) - 1
         dims_c = (C.c_int * len(dims))(*dims)
         v_out = v_attr * v_loss
         v_feat = torch.empty_like(feat)
-        ws = torch.empty(L.gsdf_mlp_bwd_ws_bytes(n, nl), dtype=torch.uint8, device=x01.device)
-        capi.check(_timed("mlp_bwd_data", L.gsdf_mlp_bwd, n, nl, dims_c, f32(dec.params_), f32(dec.biases_), f32(feat), f32(acts),
+        ws = torch.empty(L.gsdf_mlp_bwd_ws_bytes(nq, nl), dtype=torch.uint8, device=x01.device)
+        capi.check(_timed("mlp_bwd_data", L.gsdf_mlp_bwd, nq, nl, dims_c, f32(dec.params_), f32(dec.biases_), f32(feat), f32(acts),
                           f32(v_out), f32(v_feat), None, None, ptr(ws), capi.stream()), "mlp_bwd")
         w_sink, b_sink = dec.grad_sinks
         cur = torch.cuda.current_stream()
 
         def weights_half():
-            capi.check(_timed("mlp_bwd_weights", L.gsdf_mlp_bwd_weights, n, nl, dims_c, int(dec.biases_ is not None), f32(feat),
+            capi.check(_timed("mlp_bwd_weights", L.gsdf_mlp_bwd_weights, nq, nl, dims_c, int(dec.biases_ is not None), f32(feat),
                               f32(acts), f32(v_out), ptr(ws), f32(w_sink), f32(b_sink), capi.stream()), "mlp_bwd_weights")
         if dec.aux_stream is None:
             weights_half()
@@ -434,14 +467,15 @@ class _CouplingLeg(torch.autograd.Function):
                 weights_half()
             for t in (feat, acts, v_out, ws):
                 t.record_stream(dec.aux_stream)
-        v_x = torch.empty_like(x01)
+        # d/dx of the base rows only: the stencil rows are evaluated at gs_samples.detach() (neural_mapping.cpp:449)
+        v_x = torch.empty(n, 3, dtype=torch.float32, device=x01.device)
         capi.check(_timed("hashgrid_bwd_input", L.gsdf_hashgrid_bwd_jac, n, cfg[0], cfg[1], f32(jac), f32(v_feat), f32(v_x),
                           capi.stream()), "hashgrid_bwd_jac")
         table = enc.params_.view(-1, cfg[1])
         sink = enc.grad_sink.view(table.shape)
 
         def scatter():
-            scatter_table_grad(n, cfg, x01, table, v_feat, sink)
+            scatter_table_grad(nq, cfg, x01, table, v_feat, sink)
         if enc.scatter_stream is None:
             scatter()
         else:
@@ -452,7 +486,7 @@ class _CouplingLeg(torch.autograd.Function):
             x01.record_stream(enc.scatter_stream)
         v_samples = torch.zeros(ctx.n_rows, 3, dtype=torch.float32, device=x01.device)
         v_samples.index_add_(0, ids, v_x * float(lm.map_size_inv))          # d x01 / d xyz = 0.5 * 2 * map_size_inv
-        return v_samples, None, None, None, None
+        return v_samples, None, None, None, None, None, None
 
 
 class LocalMap:
@@ -602,11 +636,13 @@ class LocalMap:
         attr = self.decoder(self.encoder.forward(self.query_points(xyz)))
         return _GsSdfLoss.apply(attr, weights, ids, scale)
 
-    def gs_sdf_coupling(self, samples, ids, weights, scale=1.0):
-        """= gs_sdf_loss(samples[ids], weights, ids, scale), as a single autograd node (see _CouplingLeg)."""
+    def gs_sdf_coupling(self, samples, ids, weights, scale=1.0, delta=None, w_eik=0.0):
+        """= gs_sdf_loss(samples[ids], weights, ids, scale) [+ w_eik * eikonal_loss(get_gradient(samples[ids].detach(), delta,
+        numerical)) when `delta` is given: the GS-sample regulariser of the joint iteration, neural_mapping.cpp:448-451], as
+        a single autograd node (see _CouplingLeg)."""
         if self.encoder.grad_sink is None or getattr(self.decoder, "grad_sinks", None) is None:
             raise RuntimeError("gs_sdf_coupling needs LocalMap.flatten(accumulate_table_grad_in_place=True) with the fused decoder")
-        return _CouplingLeg.apply(samples, ids, weights, self, scale)
+        return _CouplingLeg.apply(samples, ids, weights, self, scale, delta, w_eik)
 
     def ray_loss(self, xyz, gt_sdf, delta, w_eik):
         """sdf_loss(get_sdf(xyz)) + w_eik * eikonal_loss(get_gradient(xyz, delta, numerical)) of the per-ray batch

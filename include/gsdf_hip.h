@@ -175,6 +175,11 @@ int gsdf_hashgrid_fwd(int64_t B, int n_levels, int n_feat, int log2_hashmap, int
  * 16x2), and v_x[b] = sum_k v_feat[b][k] * jac[b][k] is then a dense contraction (no second pass over the table). */
 int gsdf_hashgrid_fwd_jac(int64_t B, int n_levels, int n_feat, int log2_hashmap, int base_res, float per_level_scale,
                           const float *x, const float *table, float *feat, float *jac, gsdf_stream_t stream);
+/* The same with the Jacobian of the first jac_rows rows only (jac [jac_rows, n_levels*n_feat, 3]): a batch whose tail is
+ * the central-difference stencil of its head needs d/dx of the head alone (neural_mapping.cpp:436-451). */
+int gsdf_hashgrid_fwd_jac_rows(int64_t B, int64_t jac_rows, int n_levels, int n_feat, int log2_hashmap, int base_res,
+                               float per_level_scale, const float *x, const float *table, float *feat, float *jac,
+                               gsdf_stream_t stream);
 int gsdf_hashgrid_bwd_jac(int64_t B, int n_levels, int n_feat, const float *jac, const float *v_feat, float *v_x,
                           gsdf_stream_t stream);
 /* v_table ACCUMULATES (zero it first), v_x is overwritten; either may be NULL. */
@@ -260,6 +265,11 @@ int gsdf_sdf_query_points(int64_t n, int stencil, const float *xyz, float delta,
  *     weights[ids[i]] (the row selection of neural_mapping.cpp:436-437; ids NULL: weights[i]); v_attr = d loss / d attr. */
 int gsdf_gs_sdf_loss(int64_t n, const float *attr, int ld, const float *weights, const int64_t *ids, float scale,
                      float *loss, float *v_attr, gsdf_stream_t stream);
+/*  gsdf_gs_sdf_eik_loss: the same with stencil != 0 on attr [7n, ld] (rows as gsdf_sdf_query_points writes them): adds the
+ *     eikonal regulariser of the visible splats' samples, w_eik * mean_n (|g|-1)^2 with the central-difference gradient g
+ *     (NeuralSLAM::sdf_regularization(gs_samples.detach(), ...), neural_mapping.cpp:448-451 -> :106-116). */
+int gsdf_gs_sdf_eik_loss(int64_t n, int stencil, const float *attr, int ld, const float *weights, const int64_t *ids,
+                         float scale, float delta, float w_eik, float *loss, float *v_attr, gsdf_stream_t stream);
 int gsdf_sdf_ray_loss(int64_t n, int stencil, const float *attr, int ld, const float *gt_sdf, float bce_isigma,
                       float delta, float w_eik, float *loss, float *v_attr, gsdf_stream_t stream);
 
@@ -325,6 +335,17 @@ int gsdf_splat_activations_fwd(int64_t n, const float *anchors, const float *off
 int gsdf_splat_activations_bwd(int64_t n, const float *scales, const float *opacities, const float *v_xyz,
                                const float *v_scales, const float *v_opacities, float *g_offsets, float *g_log_scales,
                                float *g_logit_opacities, gsdf_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * a8  NeuralGS::update_state (include/neural_gaussian/neural_gaussian.cpp:626-680) in one launch: the densification
+ *     statistics after every backward pass.  grad [M,2] = .grad() of the `densify` (or `absgrad`) leaf, scaled by
+ *     (W/2*C, H/2*C) and L2-normed (:660-665); grad2d/count [N] accumulate; vis/radii [N] take the maximum
+ *     (radii_px int32 [M] / max(W,H); radii and radii_px may both be NULL = criterion off, :675-679).
+ *     n_cameras == 1: rows have unique ids (packed projection) and are updated with plain read-modify-writes.
+ * ---------------------------------------------------------------------------------------- */
+int gsdf_densify_stats(int64_t M, int64_t N, int n_cameras, int width, int height, const float *grad,
+                       const int64_t *gaussian_ids, const float *visibilities, const int32_t *radii_px, float *grad2d,
+                       float *count, float *vis, float *radii, gsdf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Hint for the XCD-aware kernels (compositing: one band of tiles per XCD; hash-grid forward: one group of levels per
