@@ -1,0 +1,140 @@
+"""Oracle-vs-HIP parity AT THE BASELINE SHAPES (BASELINE.json configs[1..4]; SURVEY.md 8: cfg1/2 Replica room2 300 k @ 1200x680
+with the Replica intrinsics of replica_parser.hpp:75-80, cfg3 1 M @ 1920x1080, cfg4 FAST-LIVO2-like 3 M @ 640x512 with
+sh_degree 3 = K 16), through the C ABI.
+
+Integer tensors (visible set, radii, tile keys, bins, offsets) must be BIT-EXACT against the oracle; so are the projection's
+float outputs (same operation order, no FMA contraction).  The compositing outputs and gradients are gated by ABSOLUTE
+bounds on their error distribution against the oracle's fp64 build (tests/util.py: GATE_IMAGE / GATE_GRAD / GATE_GRAD_LONG —
+bulk relative L2, fraction of elements above 1e-4 / 1e-3 / 1e-2), not by what the fp32 restatement achieves; the fp32 build
+of the oracle is evaluated alongside for information only.  The projection / SH backward must be within 1e-4 element-wise
+(at most 12 elements up to 1e-3).  Every measurement is written to gpurun_out/parity_r02.json (committed copy:
+profiles/parity_r02.json)."""
+import json
+import os
+import time
+
+import numpy as np
+import pytest
+import torch
+
+import gs_sdf_amd.synth as synth
+from util import (GATE_GRAD, GATE_GRAD_LONG, GATE_IMAGE, IMAGE_KEYS, assert_equal_int, gate_violations, parity_stats)
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OUT = os.path.join(ROOT, "gpurun_out", "parity_r02.json")
+
+SHAPES = {
+    # name: N, W, H, sh_degree, replica intrinsics, view index
+    "cfg1_cfg2_replica_room2_300k_1200x680": (300_000, 1200, 680, 0, True, 1),
+    "cfg3_1M_1920x1080": (1_000_000, 1920, 1080, 0, False, 1),
+    "cfg4_like_3M_640x512_K16": (3_000_000, 640, 512, 3, False, 1),
+}
+
+GRAD_KEYS = ("v_colors", "v_opacities", "v_normals", "v_means2d", "v_ray_transforms", "v_densify")
+
+
+def n(t):
+    return t.detach().cpu().numpy()
+
+
+def _stats(got, ref):
+    return parity_stats(got, ref)
+
+
+def _record(name, payload):
+    os.makedirs(os.path.dirname(OUT), exist_ok=True)
+    allr = json.load(open(OUT)) if os.path.exists(OUT) else {}
+    allr[name] = payload
+    json.dump(allr, open(OUT, "w"), indent=1, sort_keys=True)
+
+
+@pytest.mark.parametrize("name", list(SHAPES))
+def test_baseline_shape_parity(oracle, name):
+    import gs_sdf_amd.ops as ops
+    N, W, H, deg, replica, vi = SHAPES[name]
+    dev = torch.device("cuda:0")
+    oracle.set_threads(os.cpu_count() or 1)
+    sc = synth.make_scene(N, W, H, sh_degree=deg, seed=0, replica=replica)
+    vm = synth.make_views(vi + 1, seed=1)[vi:vi + 1]
+    means, quats = sc["means"], sc["quats"]
+    scales, opac = sc["log_scales"].exp(), torch.sigmoid(sc["logit_opacities"])
+    Kd = sc["K"]
+    rec = {"N": N, "W": W, "H": H, "sh_degree": deg, "replica_intrinsics": replica}
+    # ---- oracle: projection, colours, bins (fp32 build: these are bit-exact contracts) ---------------------------------
+    t0 = time.perf_counter()
+    p = oracle.projection_2dgs_fwd(n(means), n(quats), n(scales), n(vm), n(Kd), W, H, prec="f32")
+    col = oracle.view_colors_fwd(n(vm), n(means), n(sc["sh"]), p["camera_ids"], p["gaussian_ids"], deg, prec="f32")
+    tpg, ids, flat, offs = oracle.tile_encode(W, H, 16, p["means2d"], p["radii"], p["depths"], p["camera_ids"], 1)
+    opa = n(opac)[p["gaussian_ids"]]
+    rec.update(M=int(p["gaussian_ids"].shape[0]), I=int(flat.shape[0]), L=float(flat.shape[0] / offs.size))
+    # ---- HIP: the same operators through the C ABI ------------------------------------------------------------------------
+    d = lambda t: t.to(dev)
+    cam, gid, radii, m2d, dep, rt, nrm, smp, sw = ops.fully_fused_projection_2dgs(d(means), d(quats), d(scales), d(vm), d(Kd), W, H,
+                                                                                  0.05, 300.0, 0.0)
+    assert_equal_int(gid, p["gaussian_ids"], "gaussian_ids"); assert_equal_int(radii, p["radii"], "radii")
+    for got, key in ((m2d, "means2d"), (dep, "depths"), (rt, "ray_transforms"), (nrm, "normals")):
+        assert np.array_equal(n(got), p[key]), f"{key} not bit-identical"
+    colg = ops.get_view_colors(d(vm), d(means), radii, d(sc["sh"]), cam, gid, deg)
+    tpg_g, flat_g, offs_g, ids_g = ops.tile_encode(W, H, 16, m2d, radii, dep, True, 1, cam, gid, return_isect_ids=True)
+    assert_equal_int(tpg_g, tpg, "tiles_per_gauss"); assert_equal_int(ids_g, ids, "isect_ids")
+    assert_equal_int(flat_g, flat, "flatten_ids"); assert_equal_int(offs_g, offs, "isect_offsets")
+    rec["integer_tensors_bit_exact"] = True
+    rec["view_colors"] = _stats(n(colg), col)
+    assert rec["view_colors"]["worst"] <= 1e-5
+    # ---- compositing forward + backward: HIP vs the oracle's fp64 build (truth) and fp32 build (information) ------------
+    ug = synth.upstream_grads(H, W, seed=2)
+    ref = {}
+    for prec in ("f64", "f32"):
+        fw = oracle.rasterize_2dgs_fwd(p["means2d"], p["ray_transforms"], col, opa, p["normals"], W, H, 16, offs, flat, prec=prec)
+        g = oracle.rasterize_2dgs_bwd(p["means2d"], p["ray_transforms"], col, opa, p["normals"], W, H, 16, offs, flat,
+                                      fw["render_alphas"], fw["last_ids"], fw["median_ids"], n(ug["v_render_colors"]),
+                                      n(ug["v_render_depths"]), n(ug["v_render_alphas"]), n(ug["v_render_normals"]),
+                                      n(ug["v_render_median"]), prec=prec)
+        ref[prec] = {**fw, **g}
+    rec["oracle_seconds"] = round(time.perf_counter() - t0, 1)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev).requires_grad_(True)
+    a = [t(p["means2d"]), t(p["ray_transforms"]), t(col), t(opa), t(p["normals"])]
+    densify = torch.zeros_like(a[0], requires_grad=True)
+    rc, rd, ra, rn, _, rm, vis = ops.rasterize_to_pixels_2dgs(a[0], a[1], a[2], a[3], a[4], densify, W, H, 16, offs_g, flat_g)
+    loss = sum((o * ug[k].to(dev)).sum() for o, k in ((rc, "v_render_colors"), (rd, "v_render_depths"), (ra, "v_render_alphas"),
+                                                      (rn, "v_render_normals"), (rm, "v_render_median")))
+    loss.backward()
+    got = dict(render_colors=rc, render_alphas=ra, render_normals=rn, render_depths=rd, visibilities=vis, v_colors=a[2].grad,
+               v_opacities=a[3].grad, v_normals=a[4].grad, v_means2d=a[0].grad, v_ray_transforms=a[1].grad, v_densify=densify.grad)
+    failures = []
+    long_lists = rec["L"] >= 1000
+    for key in IMAGE_KEYS + GRAD_KEYS:
+        gate = GATE_IMAGE if key in IMAGE_KEYS else (GATE_GRAD_LONG if long_lists else GATE_GRAD)
+        s = _stats(n(got[key]), ref["f64"][key])
+        s["fp32_cpu_restatement_for_information"] = _stats(ref["f32"][key], ref["f64"][key])
+        s["gate"] = dict(gate)
+        rec[key] = s
+        failures += gate_violations(s, gate, key)
+    # render_median is the depth of ONE selected splat per pixel: a decision flip swaps it for a neighbour's (count only)
+    s = _stats(n(rm), ref["f64"]["render_median"])
+    rec["render_median"] = s
+    if s["above_1e4"] > max(12, 1e-4 * s["n"]):
+        failures.append(f"render_median: {s['above_1e4']} of the pixels differ")
+    # ---- projection / SH backward at the same size: HIP vs the oracle's fp64 build fed with the SAME upstream gradients ----
+    leaves = [d(x).clone().requires_grad_(True) for x in (means, quats, scales, sc["sh"])]
+    cam2, gid2, radii2, m2d2, dep2, rt2, nrm2, smp2, sw2 = ops.fully_fused_projection_2dgs(leaves[0], leaves[1], leaves[2], d(vm), d(Kd),
+                                                                                           W, H, 0.05, 300.0, 0.0)
+    col2 = ops.get_view_colors(d(vm), leaves[0], radii2, leaves[3], cam2, gid2, deg)
+    up = [a[0].grad, a[1].grad, a[4].grad, a[2].grad]                       # v_means2d, v_ray_transforms, v_normals, v_colors
+    ((m2d2 * up[0]).sum() + (rt2 * up[1]).sum() + (nrm2 * up[2]).sum() + (col2 * up[3]).sum()).backward()
+    M = p["gaussian_ids"].shape[0]
+    vm_, vq_, vs_ = oracle.projection_2dgs_bwd(n(means), n(quats), n(scales), n(vm), n(Kd), W, H, p["camera_ids"], p["gaussian_ids"],
+                                               n(up[0]), np.zeros(M, np.float32), n(up[1]), n(up[2]), None, prec="f64")
+    v_sh, v_means_sh = oracle.view_colors_bwd(n(vm), n(means), n(sc["sh"]), p["camera_ids"], p["gaussian_ids"], deg, n(up[3]), prec="f64")
+    for key, g_, r_ in (("v_means", leaves[0].grad, vm_ + v_means_sh), ("v_quats", leaves[1].grad, vq_), ("v_scales", leaves[2].grad, vs_),
+                        ("v_sh", leaves[3].grad, v_sh)):
+        s = _stats(n(g_), r_)
+        rec[key] = s
+        # fp32 against fp64 on 1e6..1e7 elements with upstream gradients spanning many decades: a handful of elements sit
+        # between 1e-4 and 3e-4 (measured worst 2.3e-4); everything else is within 1e-4
+        if s["above_1e4"] > 12 or s["worst"] > 1e-3:
+            failures.append(f"{key}: {s['above_1e4']} elements above 1e-4, worst {s['worst']:.2e}")
+    rec["passed"] = not failures
+    _record(name, rec)
+    assert not failures, "\n".join(failures)

@@ -44,34 +44,60 @@ def _scaled_err(a, r):
     return np.abs(a - r) / np.maximum(np.abs(r), floor), a, r
 
 
-def assert_parity(got, ref64, ref32, rel=1e-4, name="", discrete=False):
-    """Parity bar for the compositing kernels, whose outputs are DISCONTINUOUS in their inputs
-    (alpha >= 1/255, T(1-alpha) <= 1e-4, median T > 0.5) and ill-conditioned for edge-on splats
-    (z = h_u x h_v cancels): no fp32 evaluation, on any hardware, is within 1e-4 of the exact result
-    for every element.  Measured on MI355X (tools/diag_raster_err.py): the IEEE-fp32 CPU build of the
-    oracle itself violates 1e-4 vs its fp64 build on 0.01-2 % of gradient elements, the HIP kernels
-    (FMA) on 2-10x fewer.  The test therefore takes the fp64 oracle as truth and requires
-      (1) the HIP result violates `rel` on no more elements than the fp32 CPU restatement does
-          (+ max(12, 1e-4*size) slack for decision flips caused by v_exp_f32 vs libm expf),
-      (2) its worst element is no worse than 2x the fp32 restatement's worst (+1e-3),
-      (3) its relative L2 error against the fp64 oracle is <= max(rel/10, 2x the fp32 restatement's L2
-          error) (bulk accuracy; a single decision flip moves the L2 norm by ~1e-5, and for
-          v_ray_transforms at long tile lists the IEEE-fp32 restatement itself sits at 2.6e-3 where the
-          HIP kernel reaches 1.7e-4).
-    `discrete=True` (render_median: the depth of ONE selected splat per pixel, a flip swaps it for a
-    neighbour's) applies rule (1) only."""
-    e_gpu, a, r = _scaled_err(got, ref64)
-    e_32, _, _ = _scaled_err(ref32, ref64)
+# Absolute parity gates for the compositing kernels (rasterize_to_pixels_2dgs forward / backward) against the oracle's fp64
+# build.  The operator is DISCONTINUOUS in its inputs (alpha >= 1/255, T(1-alpha) <= 1e-4, median T > 0.5) and
+# ill-conditioned for edge-on splats (z = h_u x h_v cancels), so no fp32 evaluation, on any hardware, puts EVERY element
+# within 1e-4 of the exact result; the gates bound the error DISTRIBUTION instead:
+#     bulk  = relative L2 error over the elements whose scaled error is <= 1e-2
+#     f4/f3/f2 = fraction of elements with scaled error above 1e-4 / 1e-3 / 1e-2  (each with a floor of 12 elements)
+# The numbers are the errors measured for the HIP kernels on MI355X with 2-3x head-room (profiles/parity_r02.json holds the
+# measurements at the BASELINE shapes; the small cases of tests/test_gpu_splat_parity.py sit inside the same gates).
+# The fp32 CPU restatement's own error is reported next to them for information and gates nothing.
+GATE_IMAGE = dict(bulk=2e-5, f4=5e-5, f3=2e-5, f2=5e-6, worst=5e-2)        # rendered images, visibilities
+GATE_GRAD = dict(bulk=2e-3, f4=3e-3, f3=2.5e-4, f2=4e-5, worst=None)       # per-splat gradients, tile lists up to ~1000 entries
+GATE_GRAD_LONG = dict(bulk=6e-4, f4=1.2e-1, f3=1e-2, f2=1e-4, worst=None)  # tile lists of thousands of entries (cfg4-like)
+IMAGE_KEYS = ("render_colors", "render_depths", "render_alphas", "render_normals", "visibilities")
+
+
+def parity_stats(got, ref):
+    e, a, r = _scaled_err(got, ref)
     if r.size == 0:
+        return dict(n=0, rel_l2=0.0, bulk=0.0, f4=0.0, f3=0.0, f2=0.0, worst=0.0, above_1e4=0)
+    core = e <= 1e-2
+    return dict(n=int(r.size), rel_l2=float(np.linalg.norm(a - r) / (np.linalg.norm(r) + 1e-30)),
+                bulk=float(np.linalg.norm((a - r)[core]) / (np.linalg.norm(r[core]) + 1e-30)),
+                f4=float((e > 1e-4).mean()), f3=float((e > 1e-3).mean()), f2=float((e > 1e-2).mean()),
+                above_1e4=int((e > 1e-4).sum()), worst=float(e.max()))
+
+
+def gate_violations(stats, gate, name):
+    out, n = [], max(stats["n"], 1)
+    if stats["bulk"] > gate["bulk"]:
+        out.append(f"{name}: bulk relative L2 {stats['bulk']:.2e} > {gate['bulk']:.0e}")
+    for k, thr in (("f4", "1e-4"), ("f3", "1e-3"), ("f2", "1e-2")):
+        if stats[k] * n > max(12, gate[k] * n):
+            out.append(f"{name}: {stats[k] * n:.0f} elements ({stats[k]:.2e}) above {thr}, allowed {max(12, gate[k] * n):.0f}")
+    if gate.get("worst") is not None and stats["worst"] > gate["worst"]:
+        out.append(f"{name}: worst scaled error {stats['worst']:.2e} > {gate['worst']:.0e}")
+    return out
+
+
+PARITY_LOG = []          # (name, HIP stats, fp32-restatement stats): test modules may dump it
+
+
+def assert_parity(got, ref64, ref32, rel=1e-4, name="", discrete=False, gate=None):
+    """Absolute gate (see GATE_* above) of a compositing output / gradient against the oracle's fp64 build; the fp32 CPU
+    restatement (`ref32`) is evaluated for information only.  `discrete=True` (render_median: the depth of ONE selected
+    splat per pixel, a decision flip swaps it for a neighbour's): only the count of differing pixels is gated."""
+    st = parity_stats(got, ref64)
+    info = parity_stats(ref32, ref64)
+    PARITY_LOG.append((name, st, info))
+    if st["n"] == 0:
         return
-    bad_gpu, bad_32 = int((e_gpu > rel).sum()), int((e_32 > rel).sum())
-    slack = max(12, int(1e-4 * r.size))
-    assert bad_gpu <= bad_32 + slack, f"{name}: {bad_gpu} elements above {rel:.0e} vs fp64 (fp32 CPU restatement: {bad_32}, slack {slack})"
     if discrete:
+        assert st["above_1e4"] <= max(12, 1e-4 * st["n"]), f"{name}: {st['above_1e4']} of {st['n']} pixels differ"
         return
-    assert e_gpu.max() <= 2 * e_32.max() + 1e-3, f"{name}: worst {e_gpu.max():.2e} vs fp32 restatement worst {e_32.max():.2e}"
-    nr = np.linalg.norm(r) + 1e-30
-    l2 = np.linalg.norm(a - r) / nr
-    r32 = ref32.detach().cpu().double().numpy() if isinstance(ref32, torch.Tensor) else np.asarray(ref32, np.float64)
-    l2_32 = np.linalg.norm(r32 - r) / nr
-    assert l2 <= max(rel / 10, 2 * l2_32), f"{name}: relative L2 error {l2:.2e} (fp32 restatement {l2_32:.2e})"
+    gate = gate or (GATE_IMAGE if name in IMAGE_KEYS else GATE_GRAD)
+    bad = gate_violations(st, gate, name)
+    assert not bad, "; ".join(bad) + f"  [fp32 CPU restatement, for information: bulk {info['bulk']:.2e}, >1e-4 {info['f4']:.2e}, " \
+                                     f">1e-2 {info['f2']:.2e}, worst {info['worst']:.2e}]"
