@@ -125,7 +125,9 @@ __device__ __forceinline__ void corners_of(const HgLevels &lv, int level, float 
 }
 
 // ---- level maxima of |v_feat| (bit patterns of non-negative floats: unsigned max) -------------------------------------
-// corner weights are <= 1, so this bounds every contribution of the level; it fixes the apply pass's fixed point
+// corner weights are <= 1, so this bounds every contribution of the level; it fixes the apply pass's fixed point.
+// A reduction kernel of its own (0.1 ms at 3 M points): folding it into the emit kernel as one atomicMax per wave puts
+// ~1e6 atomics on the ONE 64-byte line that holds the 16 maxima and costs 3-12 ms of serialisation, filtered or not.
 __global__ void __launch_bounds__(256)
     bin_vmax_kernel(int64_t n2, int n_levels, const float2 *__restrict__ v_feat, uint32_t *__restrict__ lmax) {
   __shared__ uint32_t s_max[HG_MAX_LEVELS];
@@ -222,19 +224,28 @@ __global__ void __launch_bounds__(1024)
 }
 
 // ---- emit -------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v, int lane) {
+#pragma unroll
+  for (int s = 1; s < 64; s <<= 1) {
+    const uint32_t o = __shfl_up(v, s, 64);
+    if (lane >= s) v += o;
+  }
+  return v;
+}
+
 __global__ void __launch_bounds__(BIN_PTS)
     bin_emit_kernel(int64_t B, HgLevels lv, BinPlan bp, const float *__restrict__ x, const float *__restrict__ v_feat,
                     const int64_t *__restrict__ start, uint32_t *__restrict__ cursor, BinRecord *__restrict__ records) {
   __shared__ uint32_t s_key[BIN_REC];
   __shared__ float s_g0[BIN_REC], s_g1[BIN_REC];
-  __shared__ uint32_t s_hist[BIN_MAX_LOCAL], s_off[BIN_MAX_LOCAL];
+  __shared__ uint32_t s_hist[BIN_MAX_LOCAL], s_off[BIN_MAX_LOCAL], s_wtot[BIN_PTS / 64];
   __shared__ int64_t s_dst[BIN_MAX_LOCAL];
   const int grp = blockIdx.x % bp.n_groups;
   const int64_t chunk = blockIdx.x / bp.n_groups;
   const int l0 = grp * BIN_G, l1 = min(l0 + BIN_G, lv.n_levels);
   const int b0 = bp.tile_base[l0], nloc = bp.tile_base[l1] - b0;
-  const int t = threadIdx.x;
-  if (t < BIN_MAX_LOCAL) s_hist[t] = 0;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  s_hist[t] = 0;
   __syncthreads();
   const int64_t b = chunk * BIN_PTS + t;
   // pass 1: contributions in registers, slot within the workgroup's bucket run from an LDS counter
@@ -262,20 +273,22 @@ __global__ void __launch_bounds__(BIN_PTS)
     }
   }
   __syncthreads();
-  // reserve the runs in the global buckets; exclusive scan of the local histogram
+  // reserve the runs in the global buckets (the reply is only needed by pass 3: its latency hides behind the scan and
+  // pass 2); exclusive scan of the local histogram: DPP-free wave scans + one combine, 2 barriers
   const uint32_t mine = t < nloc ? s_hist[t] : 0u;
-  if (t < nloc && mine) s_dst[t] = start[b0 + t] + (int64_t)atomicAdd(&cursor[b0 + t], mine);
-  s_off[t] = mine;
+  uint32_t reserved = 0u;
+  if (mine) reserved = atomicAdd(&cursor[b0 + t], mine);
+  const uint32_t incl = wave_inclusive_scan(mine, lane);
+  if (lane == 63) s_wtot[wave] = incl;
   __syncthreads();
-  for (int s = 1; s < BIN_MAX_LOCAL; s <<= 1) {
-    const uint32_t a = t >= s ? s_off[t - s] : 0u;
-    __syncthreads();
-    s_off[t] += a;
-    __syncthreads();
+  uint32_t before = 0u, n_rec = 0u;
+#pragma unroll
+  for (int w = 0; w < BIN_PTS / 64; ++w) {
+    const uint32_t wt = s_wtot[w];
+    before += w < wave ? wt : 0u;
+    n_rec += wt;
   }
-  const uint32_t n_rec = s_off[BIN_MAX_LOCAL - 1];
-  __syncthreads();
-  s_off[t] -= mine;  // inclusive -> exclusive
+  s_off[t] = before + incl - mine;
   __syncthreads();
   // pass 2: records to their sorted position in LDS
   if (b < B) {
@@ -292,6 +305,7 @@ __global__ void __launch_bounds__(BIN_PTS)
         }
       }
   }
+  if (mine) s_dst[t] = start[b0 + t] + (int64_t)reserved;
   __syncthreads();
   // pass 3: runs to the global buckets; consecutive lanes write consecutive 12-byte records
   for (uint32_t p = t; p < n_rec; p += BIN_PTS) {
