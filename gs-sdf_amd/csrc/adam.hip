@@ -39,8 +39,11 @@ __global__ void __launch_bounds__(256)
     for (int k = 1; k < ADAM_MAX_SEG; ++k) s += (k < segs.n && e0 >= segs.begin[k]) ? 1 : 0;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      // a vector of 4 may straddle a segment boundary only if the boundary is not 4-aligned
-      const int sk = (s + 1 < segs.n && e0 + k >= segs.begin[s + 1]) ? s + 1 : s;
+      // a vector of 4 may straddle segment boundaries that are not 4-aligned, several of them when segments are shorter
+      // than 4 elements or empty (e.g. features_rest at sh_degree 0): the element's segment is the LAST one that begins
+      // at or before it
+      int sk = s;
+      while (sk + 1 < segs.n && e0 + k >= segs.begin[sk + 1]) ++sk;
       const float lr = segs.lr[sk];
       mv[k] = beta1 * mv[k] + (1.f - beta1) * gv[k];
       vv[k] = beta2 * vv[k] + (1.f - beta2) * gv[k] * gv[k];

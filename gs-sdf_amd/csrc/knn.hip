@@ -37,18 +37,37 @@ __global__ void __launch_bounds__(256) knn_bbox_kernel(int64_t N, const float *_
 }
 
 __global__ void knn_grid_kernel(int64_t N, int64_t max_cells, const int *bb, KnnGrid *g) {
-  float ext[3], vol = 1.f;
-  for (int d = 0; d < 3; ++d) { g->lo[d] = ord2f(bb[d]); ext[d] = fmaxf(ord2f(bb[3 + d]) - g->lo[d], 1e-12f); vol *= ext[d]; }
-  // cubic cells with ~2 points each, at most max_cells cells, at least 1 per axis
+  // cubic cells with ~2 points each, at most max_cells cells, at least 1 per axis.  Degenerate clouds (exactly planar
+  // or collinear: one or two extents are 0) are sized from the NON-degenerate extents only — a cell size derived from a
+  // clamped 1e-12 extent would ask for ~1e12 cells along the other axes and overflow the cell tables.
+  float ext[3], lo[3];
+  float emax = 0.f;
+  for (int d = 0; d < 3; ++d) { lo[d] = ord2f(bb[d]); ext[d] = fmaxf(ord2f(bb[3 + d]) - lo[d], 0.f); emax = fmaxf(emax, ext[d]); }
+  const float tiny = fmaxf(emax * 1e-6f, 1e-30f);
   const float target = fminf((float)max_cells, fmaxf((float)N * 0.5f, 1.f));
-  float cell = cbrtf(vol / target);
-  for (int it = 0; it < 8; ++it) {
+  float vol = 1.f;
+  int dims = 0;
+  for (int d = 0; d < 3; ++d)
+    if (ext[d] > tiny) { vol *= ext[d]; ++dims; }
+  float cell = dims == 0 ? 1.f : powf(vol / target, 1.f / (float)dims);
+  cell = fmaxf(cell, emax / 2048.f);                 // never more than 2048 cells along an axis (int overflow guard)
+  for (int it = 0; it < 64; ++it) {                  // grow until the grid fits: x1.26 per round = x2 cells per 3 rounds
     double cells = 1.0;
     for (int d = 0; d < 3; ++d) cells *= (double)((int)(ext[d] / cell) + 1);
     if (cells <= (double)max_cells) break;
     cell *= 1.26f;
   }
-  for (int d = 0; d < 3; ++d) { g->res[d] = (int)(ext[d] / cell) + 1; g->cell[d] = cell; g->inv_cell[d] = 1.f / cell; }
+  double cells = 1.0;
+  for (int d = 0; d < 3; ++d) {
+    g->lo[d] = lo[d];
+    g->res[d] = (int)(ext[d] / cell) + 1;
+    cells *= (double)g->res[d];
+    g->cell[d] = cell;
+    g->inv_cell[d] = 1.f / cell;
+  }
+  if (cells > (double)max_cells) {                   // cannot happen after 64 rounds unless max_cells < 1: one cell
+    for (int d = 0; d < 3; ++d) { g->res[d] = 1; g->cell[d] = fmaxf(emax, 1.f); g->inv_cell[d] = 1.f / g->cell[d]; }
+  }
 }
 
 __device__ __forceinline__ void cell_of(const KnnGrid &g, float x, float y, float z, int c[3]) {

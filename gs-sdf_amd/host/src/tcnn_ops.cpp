@@ -34,8 +34,18 @@ struct GridBwd : public torch::autograd::Function<GridBwd> {
     const int64_t B = x.size(0);
     Tensor v_x = torch::empty_like(x);
     Tensor v_table = want_table ? torch::zeros_like(table) : Tensor();
-    check(gsdf_hashgrid_bwd(B, c.L, c.F, c.H, c.R, c.S, fp(x), fp(table), fp(v_feat), fpm(v_table), fpm(v_x), cur_stream()),
-          "TCNNEncoding backward");
+    // large batches: the table gradient without global atomics (gsdf_hashgrid_bwd_binned), d/dx from the plain kernel
+    const size_t binned = (want_table && B >= 65536) ? gsdf_hashgrid_bwd_binned_ws_bytes(B, c.L, c.F, c.H, c.R, c.S) : 0;
+    if (binned) {
+      Tensor ws = empty_like_opts(x, {(int64_t)binned}, torch::kUInt8);
+      check(gsdf_hashgrid_bwd(B, c.L, c.F, c.H, c.R, c.S, fp(x), fp(table), fp(v_feat), nullptr, fpm(v_x), cur_stream()),
+            "TCNNEncoding backward");
+      check(gsdf_hashgrid_bwd_binned(B, c.L, c.F, c.H, c.R, c.S, fp(x), fp(v_feat), fpm(v_table), ws.data_ptr(), binned, cur_stream()),
+            "TCNNEncoding backward (binned scatter)");
+    } else {
+      check(gsdf_hashgrid_bwd(B, c.L, c.F, c.H, c.R, c.S, fp(x), fp(table), fp(v_feat), fpm(v_table), fpm(v_x), cur_stream()),
+            "TCNNEncoding backward");
+    }
     ctx->save_for_backward({v_feat, x, table});
     ctx->saved_data["cfg"] = cfgv;
     if (!want_table) {
@@ -93,6 +103,11 @@ struct MlpFn : public torch::autograd::Function<MlpFn> {
     return out;
   }
   static tensor_list backward(AutogradContext *ctx, tensor_list g) {
+    // first order only, like tcnn's FullyFusedMLP: the reference forces numerical_grad with this decoder
+    // (params.cpp:396-399).  Under create_graph the result would silently be treated as constant: refuse instead.
+    TORCH_CHECK(!(torch::GradMode::is_enabled() && g[0].defined() && g[0].requires_grad()),
+                "TCNNNetwork: double backward through the fused MLP is not implemented (use numerical_grad, as the reference "
+                "does with decoder_implementation 1)");
     auto s = ctx->get_saved_variables();
     auto dims64 = ctx->saved_data["dims"].toIntVector();
     std::vector<int> dims(dims64.begin(), dims64.end());

@@ -124,6 +124,27 @@ def test_distCUDA2(host, oracle, N):
     assert_close(got_cpp, ref, 1e-4, "distCUDA2")
 
 
+@pytest.mark.parametrize("kind", ["planar", "collinear", "single_point_cloud"])
+def test_distCUDA2_degenerate_clouds(oracle, kind):
+    """Exactly planar / collinear / coincident point sets: the uniform grid must be sized from the non-degenerate extents
+    (a cell size derived from a zero extent would ask for ~1e12 cells and overflow the cell tables)."""
+    import gs_sdf_amd.ops as ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(3)
+    N = 3000
+    pts = torch.rand(N, 3, generator=g) * torch.tensor([4.0, 2.0, 1.0])
+    if kind == "planar":
+        pts[:, 2] = 0.25
+    elif kind == "collinear":
+        pts[:, 1:] = torch.tensor([0.5, -1.0])
+    else:
+        pts[:] = torch.tensor([1.0, 2.0, 3.0])
+    got = ops.distCUDA2(pts.to(dev))
+    ref = oracle.knn_mean_dist2(pts.numpy(), prec="f64")
+    assert torch.isfinite(got).all()
+    assert_close(got, ref, 1e-4, f"distCUDA2 ({kind})")
+
+
 def test_octree_as_cpp_matches_python_mirror_and_oracle(host, oracle):
     """kaolin_wisp_cpp drop-in headers (spc_ops.h, octree_as.h) driven the way sub_map.cpp:22-35 / local_map.cpp:467-476
     do: quantize -> unique -> neighbours -> clamp -> from_quantized_points; query; voxel ray march."""
