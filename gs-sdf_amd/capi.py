@@ -63,8 +63,8 @@ _SIGS = {
     "gsdf_occ_voxel_list": (C.c_int, [_i32, _vp, _vp, _vp, _vp]),
     "gsdf_occ_raymarch_count": (C.c_int, [_i32, _i64, _vp, _vp, _vp, _vp, _vp]),
     "gsdf_occ_raymarch_fill": (C.c_int, [_i32, _i64, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp]),
-    "gsdf_mc_count": (C.c_int, [_i32, _i32, _i32, _vp, _f32, _vp, _vp, _vp]),
-    "gsdf_mc_emit": (C.c_int, [_i32, _i32, _i32, _vp, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "gsdf_mc_count": (C.c_int, [_i32, _i32, _i32, _i32, _vp, _f32, _vp, _vp, _vp]),
+    "gsdf_mc_emit": (C.c_int, [_i32, _i32, _i32, _i32, _vp, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gsdf_splat_activations_fwd": (C.c_int, [_i64] + [_vp] * 8),
     "gsdf_splat_activations_bwd": (C.c_int, [_i64] + [_vp] * 9),
     "gsdf_densify_stats": (C.c_int, [_i64, _i64, _i32, _i32, _i32] + [_vp] * 9),

@@ -8,10 +8,14 @@
 // deterministic emit (vertices ordered by cell then axis, faces by cell then table order; the reference's order is
 // whatever its atomics produce); (2) no [X,Y,Z,3] vertex-index grid (12 B/cell of traffic and memory): a face looks its
 // vertex ids up as v_offsets[owner cell] + rank of the edge's axis among the owner's crossings, recomputed from the
-// grid; (3) the triangle table is derived, not transcribed (mc_table.h, tools/gen_mc_table.py): watertight by construction.
+// grid.  Triangle table: `table` = GSDF_MC_TABLE_REFERENCE (0, default of the mirrors): the reference's own in-tree table
+// (utils.cuh:31-289 packed into mc_table_ref.h) -> the same triangles per cell as the reference's mesh;
+// GSDF_MC_TABLE_WATERTIGHT (1): the derived table of tools/gen_mc_table.py (same crossing edges in every configuration,
+// triangulation that is watertight across ambiguous faces, which the classic table is not).
 // Compiled with -ffp-contract=off: vertex positions are bit-identical to the numpy restatement (oracle/mc_oracle.py).
 #include "common.h"
 #include "mc_table.h"
+#include "mc_table_ref.h"
 
 namespace gsdf {
 
@@ -42,21 +46,22 @@ __device__ __forceinline__ int mc_mask(const McDims &d, const float *__restrict_
   return mask;
 }
 __device__ __forceinline__ int mc_edge(uint64_t packed, int k) { return (int)((packed >> (4 * k)) & 0xFull); }  // 15: end
-__device__ __forceinline__ int mc_tri_count(int mask) {
-  const uint64_t w = MC_TRI_PACKED[mask];
+__device__ __forceinline__ uint64_t mc_word(int table, int mask) { return table == 0 ? MC_TRI_PACKED_REF[mask] : MC_TRI_PACKED[mask]; }
+__device__ __forceinline__ int mc_tri_count(int table, int mask) {
+  const uint64_t w = mc_word(table, mask);
   int n = 0;
   while (n < 15 && mc_edge(w, n) != 15) n += 3;
   return n / 3;
 }
 
 __global__ void __launch_bounds__(256)
-    mc_count_kernel(McDims d, const float *__restrict__ g, float thresh, int32_t *__restrict__ n_vert,
+    mc_count_kernel(McDims d, int table, const float *__restrict__ g, float thresh, int32_t *__restrict__ n_vert,
                     int32_t *__restrict__ n_tri) {
   const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (c >= (int64_t)d.rx * d.ry * d.rz) return;
   const int z = (int)(c % d.rz), y = (int)((c / d.rz) % d.ry), x = (int)(c / ((int64_t)d.rz * d.ry));
   n_vert[c] = __popc(mc_owned(d, g, thresh, x, y, z));
-  n_tri[c] = (x < d.rx - 1 && y < d.ry - 1 && z < d.rz - 1) ? mc_tri_count(mc_mask(d, g, thresh, x, y, z)) : 0;
+  n_tri[c] = (x < d.rx - 1 && y < d.ry - 1 && z < d.rz - 1) ? mc_tri_count(table, mc_mask(d, g, thresh, x, y, z)) : 0;
 }
 
 // owner cell offset and axis of the 12 cube edges (cumcubes_kernel.cu:180-191)
@@ -65,7 +70,7 @@ __device__ __constant__ static const int8_t MC_EDGE_OWNER[12][4] = {
     {0, 1, 1, 0}, {0, 0, 1, 1}, {0, 0, 0, 2}, {1, 0, 0, 2}, {1, 1, 0, 2}, {0, 1, 0, 2}};
 
 __global__ void __launch_bounds__(256)
-    mc_emit_kernel(McDims d, const float *__restrict__ g, float thresh, const int64_t *__restrict__ v_off,
+    mc_emit_kernel(McDims d, int table, const float *__restrict__ g, float thresh, const int64_t *__restrict__ v_off,
                    const int64_t *__restrict__ t_off, float sx, float sy, float sz, float lx, float ly, float lz,
                    float *__restrict__ vertices, int32_t *__restrict__ faces) {
   const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -94,7 +99,7 @@ __global__ void __launch_bounds__(256)
   if (x < d.rx - 1 && y < d.ry - 1 && z < d.rz - 1) {
     const int mask = mc_mask(d, g, thresh, x, y, z);
     int64_t f = t_off[c];
-    const uint64_t tri = MC_TRI_PACKED[mask];
+    const uint64_t tri = mc_word(table, mask);
     for (int k = 0; k < 15 && mc_edge(tri, k) != 15; ++k) {
       const int e = mc_edge(tri, k);
       const int ox = x + MC_EDGE_OWNER[e][0], oy = y + MC_EDGE_OWNER[e][1], oz = z + MC_EDGE_OWNER[e][2];
@@ -110,29 +115,31 @@ __global__ void __launch_bounds__(256)
 
 using namespace gsdf;
 
-extern "C" int gsdf_mc_count(int res_x, int res_y, int res_z, const float *grid, float thresh, int32_t *n_vert,
+extern "C" int gsdf_mc_count(int res_x, int res_y, int res_z, int table, const float *grid, float thresh, int32_t *n_vert,
                              int32_t *n_tri, gsdf_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   GSDF_REQUIRE(res_x >= 1 && res_y >= 1 && res_z >= 1, "mc_count: bad resolution");
+  GSDF_REQUIRE(table == GSDF_MC_TABLE_REFERENCE || table == GSDF_MC_TABLE_WATERTIGHT, "mc_count: unknown triangle table %d", table);
   GSDF_REQUIRE(grid && n_vert && n_tri, "mc_count: null buffer");
   const McDims d = {res_x, res_y, res_z};
   const int64_t n = (int64_t)res_x * res_y * res_z;
-  mc_count_kernel<<<(unsigned)((n + 255) / 256), 256, 0, stream>>>(d, grid, thresh, n_vert, n_tri);
+  mc_count_kernel<<<(unsigned)((n + 255) / 256), 256, 0, stream>>>(d, table, grid, thresh, n_vert, n_tri);
   GSDF_CHECK_LAUNCH("mc_count_kernel");
   return GSDF_OK;
 }
 
-extern "C" int gsdf_mc_emit(int res_x, int res_y, int res_z, const float *grid, float thresh, const int64_t *v_offsets,
+extern "C" int gsdf_mc_emit(int res_x, int res_y, int res_z, int table, const float *grid, float thresh, const int64_t *v_offsets,
                             const int64_t *t_offsets, const float *lower_host, const float *upper_host, float *vertices,
                             int32_t *faces, gsdf_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   GSDF_REQUIRE(res_x >= 1 && res_y >= 1 && res_z >= 1, "mc_emit: bad resolution");
+  GSDF_REQUIRE(table == GSDF_MC_TABLE_REFERENCE || table == GSDF_MC_TABLE_WATERTIGHT, "mc_emit: unknown triangle table %d", table);
   GSDF_REQUIRE(grid && v_offsets && t_offsets && lower_host && upper_host, "mc_emit: null buffer");
   const McDims d = {res_x, res_y, res_z};
   const int64_t n = (int64_t)res_x * res_y * res_z;
   const float sx = (upper_host[0] - lower_host[0]) / (float)res_x, sy = (upper_host[1] - lower_host[1]) / (float)res_y,
               sz = (upper_host[2] - lower_host[2]) / (float)res_z;
-  mc_emit_kernel<<<(unsigned)((n + 255) / 256), 256, 0, stream>>>(d, grid, thresh, v_offsets, t_offsets, sx, sy, sz,
+  mc_emit_kernel<<<(unsigned)((n + 255) / 256), 256, 0, stream>>>(d, table, grid, thresh, v_offsets, t_offsets, sx, sy, sz,
                                                                   lower_host[0], lower_host[1], lower_host[2], vertices,
                                                                   faces);
   GSDF_CHECK_LAUNCH("mc_emit_kernel");

@@ -9,11 +9,19 @@ from . import capi
 from .capi import f32, ptr
 
 
-def marching_cubes(density_grid, thresh, lower, upper):
+TABLES = {"reference": 0, "watertight": 1}
+
+
+def marching_cubes(density_grid, thresh, lower, upper, table="reference"):
     """density_grid [X,Y,Z] float32 on the device -> [vertices [V,3] float32, faces [F,3] int32].  Vertices are ordered by
-    owning cell then axis, faces by cell then table order (deterministic; the reference's order comes from atomics)."""
+    owning cell then axis, faces by cell then table order (deterministic; the reference's order comes from atomics).
+    table = "reference" (default): the reference's in-tree triangle table -> the reference's triangles in every cell;
+    "watertight": the derived table (same vertices, no cracks across ambiguous faces)."""
     if density_grid.dim() != 3:
         raise RuntimeError("marching_cubes: expected a [X,Y,Z] grid")
+    if table not in TABLES:
+        raise RuntimeError(f"marching_cubes: table must be one of {sorted(TABLES)}")
+    tb = TABLES[table]
     L = capi.lib()
     g = density_grid.contiguous().float()
     rx, ry, rz = g.shape
@@ -21,7 +29,7 @@ def marching_cubes(density_grid, thresh, lower, upper):
     dev = g.device
     n_vert = torch.empty(n, dtype=torch.int32, device=dev)
     n_tri = torch.empty(n, dtype=torch.int32, device=dev)
-    capi.check(L.gsdf_mc_count(rx, ry, rz, f32(g), float(thresh), ptr(n_vert), ptr(n_tri), capi.stream()), "mc_count")
+    capi.check(L.gsdf_mc_count(rx, ry, rz, tb, f32(g), float(thresh), ptr(n_vert), ptr(n_tri), capi.stream()), "mc_count")
     v_incl, t_incl = torch.cumsum(n_vert, 0, dtype=torch.int64), torch.cumsum(n_tri, 0, dtype=torch.int64)
     V, F = (int(v) for v in torch.stack([v_incl[-1], t_incl[-1]]).tolist())        # the one host sync
     vertices = torch.empty(V, 3, dtype=torch.float32, device=dev)
@@ -29,7 +37,7 @@ def marching_cubes(density_grid, thresh, lower, upper):
     if V:
         lo, up = (C.c_float * 3)(*[float(v) for v in lower]), (C.c_float * 3)(*[float(v) for v in upper])
         v_off, t_off = (v_incl - n_vert).contiguous(), (t_incl - n_tri).contiguous()    # exclusive scans (kept alive here)
-        capi.check(L.gsdf_mc_emit(rx, ry, rz, f32(g), float(thresh), ptr(v_off), ptr(t_off), lo, up, f32(vertices),
+        capi.check(L.gsdf_mc_emit(rx, ry, rz, tb, f32(g), float(thresh), ptr(v_off), ptr(t_off), lo, up, f32(vertices),
                                   ptr(faces), capi.stream()), "mc_emit")
     return [vertices, faces]
 

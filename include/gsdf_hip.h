@@ -315,11 +315,16 @@ int gsdf_occ_raymarch_fill(int level, int64_t n_rays, const float *origins_m1p1,
  *     along the edge, mapped to world as v * (upper-lower)/res + lower; faces index the vertices (int32, 0-based).
  *     Two-phase: count -> n_vert[c] (0..3 edges owned by cell c) and n_tri[c] (0..5) per cell, c = (x*res_y + y)*res_z + z;
  *     the caller scans both (exclusive, int64) and allocates; emit writes vertices [V,3] (by cell, then axis x,y,z) and
- *     faces [F,3] (by cell, then table order).  The triangle table is derived (tools/gen_mc_table.py), watertight.
+ *     faces [F,3] (by cell, then table order).  table: GSDF_MC_TABLE_REFERENCE = the reference's in-tree triangle table
+ *     (include/mesher/cumcubes/include/utils.cuh:31-289): per cell the same triangles as the reference's mesh;
+ *     GSDF_MC_TABLE_WATERTIGHT = the derived table (tools/gen_mc_table.py): same vertices, triangulation that closes the
+ *     classic table's ambiguous-face cracks.
  * ---------------------------------------------------------------------------------------- */
-int gsdf_mc_count(int res_x, int res_y, int res_z, const float *grid, float thresh, int32_t *n_vert, int32_t *n_tri,
-                  gsdf_stream_t stream);
-int gsdf_mc_emit(int res_x, int res_y, int res_z, const float *grid, float thresh, const int64_t *v_offsets,
+#define GSDF_MC_TABLE_REFERENCE 0
+#define GSDF_MC_TABLE_WATERTIGHT 1
+int gsdf_mc_count(int res_x, int res_y, int res_z, int table, const float *grid, float thresh, int32_t *n_vert,
+                  int32_t *n_tri, gsdf_stream_t stream);
+int gsdf_mc_emit(int res_x, int res_y, int res_z, int table, const float *grid, float thresh, const int64_t *v_offsets,
                  const int64_t *t_offsets, const float *lower_host, const float *upper_host, float *vertices,
                  int32_t *faces, gsdf_stream_t stream);
 

@@ -3,11 +3,12 @@
 Follows /root/reference/include/mesher/cumcubes/src/cumcubes_kernel.cu: inside <=> value > thresh (:24,:52-59); one vertex
 per straddling grid edge, owned by the edge's lower cell, at index + (thresh - d0)/(d1 - d0) (:97-139); corner bits and
 the 12 edge -> (owner cell, axis) pairs (:169-193); world mapping vertices * (upper - lower)/res + lower (:260-274).
-Two things are NOT the reference's: the ordering of vertices and faces (the reference's comes out of global atomics and is
-not reproducible; here: by owning cell, then axis / table order) and the triangle table, which is derived by
-tools/gen_mc_table.py instead of transcribed (same crossing edges per configuration; triangulation chosen so that the
-surface is watertight).  PARITY UNPINNED for the face list: the reference's table lives in a header this repo must not
-copy and its kernel cannot run here (CUDA); the vertex set is the pinned part (it does not depend on the table).
+One thing is NOT the reference's: the ordering of vertices and faces (the reference's comes out of global atomics and is
+not reproducible; here: by owning cell, then axis / table order).  Triangle table: `table="reference"` is the reference's
+own in-tree table (include/mesher/cumcubes/include/utils.cuh:31-289), held as the golden vector
+tests/golden/mc_triangle_table_reference.npy (written by tools/gen_mc_table_ref.py from the header where it lies): with it
+the face SET of every cell is the reference's — the one place on this path where parity is PINNED by reference-held data.
+`table="watertight"` regenerates the derived table of tools/gen_mc_table.py from first principles.
 """
 import os
 import sys
@@ -19,17 +20,23 @@ from gen_mc_table import triangulate     # noqa: E402  (regenerates the table fr
 
 EDGE_OWNER = [(0, 0, 0, 0), (1, 0, 0, 1), (0, 1, 0, 0), (0, 0, 0, 1), (0, 0, 1, 0), (1, 0, 1, 1),
               (0, 1, 1, 0), (0, 0, 1, 1), (0, 0, 0, 2), (1, 0, 0, 2), (1, 1, 0, 2), (0, 1, 0, 2)]
-_TABLE = None
+_TABLES = {}
+GOLDEN = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "mc_triangle_table_reference.npy")
 
 
-def table():
-    global _TABLE
-    if _TABLE is None:
-        _TABLE = [triangulate(m) for m in range(256)]
-    return _TABLE
+def table(kind="reference"):
+    if kind not in _TABLES:
+        if kind == "watertight":
+            _TABLES[kind] = [triangulate(m) for m in range(256)]
+        elif kind == "reference":
+            ref = np.load(GOLDEN)
+            _TABLES[kind] = [[tuple(int(e) for e in ref[m][k:k + 3]) for k in range(0, 15, 3) if ref[m][k] >= 0] for m in range(256)]
+        else:
+            raise ValueError(kind)
+    return _TABLES[kind]
 
 
-def marching_cubes(grid, thresh, lower, upper):
+def marching_cubes(grid, thresh, lower, upper, table_kind="reference"):
     g = np.ascontiguousarray(grid, np.float32)
     X, Y, Z = g.shape
     thresh = np.float32(thresh)
@@ -62,7 +69,7 @@ def marching_cubes(grid, thresh, lower, upper):
     rank[..., 1] = cross[..., 0]
     rank[..., 2] = cross[..., 0].astype(np.int64) + cross[..., 1]
     out_cells, out_k, out_faces = [], [], []
-    T = table()
+    T = table(table_kind)
     for m in np.unique(mask):
         tris = T[int(m)]
         if not tris:

@@ -18,12 +18,17 @@ def _sphere(res, r=0.6):
 
 @pytest.mark.parametrize("shape,thresh,kind", [((13, 11, 9), 0.1, "random"), ((40, 40, 40), 0.0, "sphere"), ((2, 2, 2), 0.5, "random"),
                                               ((65, 33, 17), -0.2, "random"), ((128, 128, 128), 0.05, "sphere"), ((5, 1, 7), 0.0, "random")])
-def test_marching_cubes_bit_exact(shape, thresh, kind):
+@pytest.mark.parametrize("table", ["reference", "watertight"])
+def test_marching_cubes_bit_exact(shape, thresh, kind, table):
+    """table="reference": the oracle triangulates with the REFERENCE'S OWN triangle table (golden vector
+    tests/golden/mc_triangle_table_reference.npy, from include/mesher/cumcubes/include/utils.cuh:31-289): vertex array equal
+    and the face list equal cell by cell (hence the per-cell face SET equals the reference mesher's, whose order is whatever
+    its atomics produce)."""
     from gs_sdf_amd.mesher import marching_cubes
     g = _sphere(shape[0]) if kind == "sphere" else np.random.default_rng(sum(shape)).standard_normal(shape).astype(np.float32)
     lower, upper = [-1.5, 0.25, 3.0], [2.5, 4.25, 11.0]
-    v_ref, f_ref = mco.marching_cubes(g, thresh, lower, upper)
-    v, f = marching_cubes(torch.from_numpy(g).to(dev), thresh, lower, upper)
+    v_ref, f_ref = mco.marching_cubes(g, thresh, lower, upper, table)
+    v, f = marching_cubes(torch.from_numpy(g).to(dev), thresh, lower, upper, table)
     assert v.dtype == torch.float32 and f.dtype == torch.int32
     assert v.shape == v_ref.shape and f.shape == f_ref.shape and (kind != "sphere" or f.shape[0] > 1000)
     assert np.array_equal(v.cpu().numpy(), v_ref)
@@ -70,6 +75,6 @@ def test_cpp_marching_cubes_wrapper_matches_python_mirror():
     from gs_sdf_amd.mesher import marching_cubes
     host = h.load()
     g = torch.from_numpy(_sphere(40)).to(dev)
-    v, f = marching_cubes(g, 0.0, [-1, -1, -1], [1, 1, 1])
+    v, f = marching_cubes(g, 0.0, [-1, -1, -1], [1, 1, 1], "reference")          # the C++ wrapper uses the reference's table
     v2, f2 = host.marching_cubes(g, 0.0, [-1.0, -1.0, -1.0], [1.0, 1.0, 1.0])
     assert torch.equal(v, v2) and torch.equal(f, f2) and f2.dtype == torch.int32
