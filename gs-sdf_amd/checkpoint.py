@@ -1,0 +1,84 @@
+"""`local_map_checkpoint.pt`: the reference's SDF-network checkpoint (NeuralSLAM::export_checkpoint / load_checkpoint,
+/root/reference/include/neural_mapping/neural_mapping.cpp:1331-1378): `torch::save(local_map_ptr, path)` of the LocalMap
+module, i.e. a libtorch serialize archive (a TorchScript zip) whose entries are the module's registered parameters:
+
+    "encoder_local_map"   flat fp32 hash-grid table          (register_parameter, local_map.cpp:73-75; name encoding_map.cpp:25)
+    "decoder"             decoder_implementation 1: flat fp32 FullyFusedMLP weights (register_parameter, local_map.cpp:53-54)
+                          decoder_implementation 0: submodule torch::nn::Sequential "decoder" with children "0".."2L+2"
+                          (Linear / ReLU alternating, local_map.cpp:29-42) holding "weight" [out,in] and "bias" [out]
+
+The same archive is written here with torch.jit (what libtorch's OutputArchive produces and InputArchive::load_from reads),
+so `torch::load(local_map_ptr, path)` of the reference accepts it and files the reference wrote load here;
+tests/test_checkpoint_pt.py round-trips both directions through a libtorch C++ program.  The rest of a checkpoint
+directory — gs.ply (neural_gs.export_gs_to_ply) and as_occ_prior.ply (LocalMap.export_as_occ_prior) — already exists."""
+import torch
+
+
+def _layers(lm):
+    """[(weight [out,in], bias [out] or None), ...] of the decoder, whatever its implementation."""
+    dec = lm.decoder
+    if isinstance(dec, torch.nn.Module):
+        return [(m.weight.detach(), m.bias.detach()) for m in dec if isinstance(m, torch.nn.Linear)]
+    out, wo, bo = [], 0, 0
+    for i, o in zip(dec.dims[:-1], dec.dims[1:]):
+        w = dec.params_.detach()[wo:wo + i * o].view(o, i)
+        b = None if dec.biases_ is None else dec.biases_.detach()[bo:bo + o]
+        out.append((w, b))
+        wo, bo = wo + i * o, bo + o
+    return out
+
+
+def save_local_map_checkpoint(lm, path):
+    """Writes what `torch::save(local_map_ptr, path)` writes for this LocalMap (see the module docstring)."""
+    root = torch.nn.Module()
+    root.register_parameter("encoder_local_map", torch.nn.Parameter(lm.encoder.params_.detach().reshape(-1).cpu().clone()))
+    layers = _layers(lm)
+    if lm.decoder_implementation == 1:
+        if any(b is not None for _, b in layers):
+            raise RuntimeError("decoder_implementation 1 is bias free")
+        root.register_parameter("decoder", torch.nn.Parameter(torch.cat([w.reshape(-1) for w, _ in layers]).cpu().clone()))
+    else:
+        mods = []
+        for k, (w, b) in enumerate(layers):
+            lin = torch.nn.Linear(w.shape[1], w.shape[0], bias=True)
+            with torch.no_grad():
+                lin.weight.copy_(w.cpu())
+                lin.bias.copy_(torch.zeros(w.shape[0]) if b is None else b.cpu())
+            mods.append(lin)
+            if k + 1 < len(layers):
+                mods.append(torch.nn.ReLU(True))
+        root.add_module("decoder", torch.nn.Sequential(*mods))
+    torch.jit.script(root).save(str(path))
+
+
+def load_local_map_checkpoint(lm, path):
+    """`torch::load(local_map_ptr, path)`: copies the archive's parameters into this LocalMap (shapes must match)."""
+    m = torch.jit.load(str(path), map_location="cpu")
+    params = dict(m.named_parameters())
+    if "encoder_local_map" not in params:
+        raise RuntimeError(f"{path}: no 'encoder_local_map' parameter (not a LocalMap checkpoint)")
+    with torch.no_grad():
+        enc = params["encoder_local_map"]
+        if enc.numel() != lm.encoder.params_.numel():
+            raise RuntimeError(f"{path}: hash-grid table has {enc.numel()} entries, this map {lm.encoder.params_.numel()}")
+        lm.encoder.params_.copy_(enc.reshape(lm.encoder.params_.shape).to(lm.encoder.params_.device))
+        layers = _layers(lm)
+        if "decoder" in params:                                  # decoder_implementation 1: one flat parameter
+            flat = params["decoder"].reshape(-1)
+            if any(b is not None for _, b in layers) or flat.numel() != sum(w.numel() for w, _ in layers):
+                raise RuntimeError(f"{path}: flat decoder parameter does not fit this map's decoder")
+            off = 0
+            for w, _ in layers:
+                w.copy_(flat[off:off + w.numel()].view_as(w).to(w.device))
+                off += w.numel()
+        else:                                                    # Sequential: decoder.<2k>.weight / .bias
+            for k, (w, b) in enumerate(layers):
+                src_w, src_b = params.get(f"decoder.{2 * k}.weight"), params.get(f"decoder.{2 * k}.bias")
+                if src_w is None or tuple(src_w.shape) != tuple(w.shape):
+                    raise RuntimeError(f"{path}: decoder.{2 * k}.weight missing or of the wrong shape")
+                w.copy_(src_w.to(w.device))
+                if b is not None:
+                    b.copy_(src_b.to(b.device))
+                elif src_b is not None and float(src_b.abs().max()) != 0.0:
+                    raise RuntimeError(f"{path}: the checkpoint's decoder has biases, this map's decoder is bias free")
+    return lm

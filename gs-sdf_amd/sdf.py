@@ -615,6 +615,16 @@ class LocalMap:
         from .occupancy import read_points_ply
         self.update_octree_as(read_points_ply(path, self.pos_W_M.device)["xyz"], is_prior=True)
 
+    def export_checkpoint(self, path):
+        """local_map_checkpoint.pt = torch::save(local_map_ptr, path) (neural_mapping.cpp:1331-1342); gs_sdf_amd/checkpoint.py."""
+        from .checkpoint import save_local_map_checkpoint
+        save_local_map_checkpoint(self, path)
+
+    def load_checkpoint(self, path):
+        """torch::load(local_map_ptr, path) (neural_mapping.cpp:1344-1351)."""
+        from .checkpoint import load_local_map_checkpoint
+        return load_local_map_checkpoint(self, path)
+
     def filter_sample(self, samples):              # local_map.cpp:511-516
         keep = (self.acc_struct_occ.query(self.xyz_to_m1p1_pts(samples.xyz)).pidx > -1).nonzero().reshape(-1)
         return samples.index_select(keep)
