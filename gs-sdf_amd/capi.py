@@ -68,6 +68,7 @@ _SIGS = {
     "gsdf_splat_activations_fwd": (C.c_int, [_i64] + [_vp] * 8),
     "gsdf_splat_activations_bwd": (C.c_int, [_i64] + [_vp] * 9),
     "gsdf_densify_stats": (C.c_int, [_i64, _i64, _i32, _i32, _i32] + [_vp] * 9),
+    "gsdf_flat_rows_gather": (C.c_int, [_i32, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp]),
     "gsdf_stream_set_xcds": (C.c_int, [_vp, _i32]),
     "gsdf_adam_step": (C.c_int, [_i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _f32, _i64, _vp]),
     "gsdf_knn_ws_bytes": (_sz, [_i64]),

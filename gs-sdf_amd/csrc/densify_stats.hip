@@ -61,3 +61,54 @@ extern "C" int gsdf_densify_stats(int64_t M, int64_t N, int n_cameras, int width
   GSDF_CHECK_LAUNCH("densify_stats_kernel");
   return GSDF_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Row surgery on a FIELD-MAJOR flat buffer [field 0: n x w0 | field 1: n x w1 | ...] (trainer.SplatParams / FusedAdam moments):
+// dst rows 0..n_keep-1 = src rows keep[r] (keep == nullptr: identity), field by field, ONE launch for all fields.  This is the
+// index_select half of the reference's optimizer surgery at every refinement step (optimizer_utils.cpp:5-165 re-materialises
+// every parameter and both Adam moments with index_select / cat, ~40 launches); the appended rows are written by the caller.
+namespace gsdf {
+static constexpr int ROWS_MAX_FIELDS = 16;
+struct RowFields {
+  int32_t width[ROWS_MAX_FIELDS], col0[ROWS_MAX_FIELDS + 1];  // col0: first column of the field within the concatenated row
+  int n;
+};
+__global__ void __launch_bounds__(256)
+    flat_rows_gather_kernel(RowFields rf, int64_t n_src, int64_t n_dst, int64_t n_keep, const int64_t *__restrict__ keep,
+                            const float *__restrict__ src, float *__restrict__ dst) {
+  const int wt = rf.col0[rf.n];
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_keep * wt) return;
+  const int64_t r = i / wt;
+  const int c = (int)(i - r * wt);
+  int f = 0;
+  while (f + 1 < rf.n && c >= rf.col0[f + 1]) ++f;
+  const int w = rf.width[f], cc = c - rf.col0[f];
+  const int64_t sr = keep ? keep[r] : r;
+  dst[(int64_t)rf.col0[f] * n_dst + r * w + cc] = src[(int64_t)rf.col0[f] * n_src + sr * w + cc];
+}
+}  // namespace gsdf
+
+extern "C" int gsdf_flat_rows_gather(int n_fields, const int32_t *widths_host, int64_t n_src, int64_t n_dst, int64_t n_keep,
+                                     const int64_t *keep_idx, const float *src, float *dst, gsdf_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  GSDF_REQUIRE(n_fields >= 1 && n_fields <= ROWS_MAX_FIELDS && widths_host, "flat_rows_gather: 1..%d fields", ROWS_MAX_FIELDS);
+  GSDF_REQUIRE(n_src >= 0 && n_dst >= n_keep && n_keep >= 0 && (keep_idx || n_keep <= n_src), "flat_rows_gather: bad row counts");
+  RowFields rf;
+  rf.n = n_fields;
+  int c = 0;
+  for (int f = 0; f < n_fields; ++f) {
+    GSDF_REQUIRE(widths_host[f] >= 0, "flat_rows_gather: negative field width");
+    rf.width[f] = widths_host[f];
+    rf.col0[f] = c;
+    c += widths_host[f];
+  }
+  for (int f = n_fields; f <= ROWS_MAX_FIELDS; ++f) rf.col0[f] = c;
+  for (int f = n_fields; f < ROWS_MAX_FIELDS; ++f) rf.width[f] = 0;
+  const int64_t n = n_keep * c;
+  if (n == 0) return GSDF_OK;
+  GSDF_REQUIRE(src && dst, "flat_rows_gather: null buffer");
+  flat_rows_gather_kernel<<<(unsigned)((n + 255) / 256), 256, 0, stream>>>(rf, n_src, n_dst, n_keep, keep_idx, src, dst);
+  GSDF_CHECK_LAUNCH("flat_rows_gather_kernel");
+  return GSDF_OK;
+}

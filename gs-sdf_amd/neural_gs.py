@@ -315,11 +315,88 @@ class NeuralGS:
             r = it / total_iter
             lr0, lr1 = 1.6e-4 * self.spatial_scale_, 1.6e-6 * self.spatial_scale_
             lr = math.exp(math.log(lr0) * (1 - r) + math.log(lr1) * r)
-            optimizer.param_groups[self.gs_param_start_idx]["lr"] = lr
-            sdf_lr = 0.0 if cfg.detach_sdf_grad else min(lr, cfg.lr_end)
-            for i in range(self.gs_param_start_idx):
-                optimizer.param_groups[i]["lr"] = sdf_lr
+            self._set_lrs(optimizer, lr, 0.0 if cfg.detach_sdf_grad else min(lr, cfg.lr_end))
         return log
+
+    def _set_lrs(self, optimizer, xyz_lr, sdf_lr):
+        optimizer.param_groups[self.gs_param_start_idx]["lr"] = xyz_lr
+        for i in range(self.gs_param_start_idx):
+            optimizer.param_groups[i]["lr"] = sdf_lr
+
+
+class FlatNeuralGS(NeuralGS):
+    """NeuralGS over the trainer's flat buffers: the six parameters are views into ONE flat buffer (trainer.SplatParams, one
+    all-reduce message, fused activations) and the optimizer is the fused Adam (trainer.FusedAdam, one launch).  The whole
+    refinement policy of NeuralGS (grow = duplicate / split, prune, opacity reset, LR decay; neural_gaussian.cpp:568-926) runs
+    unchanged on top: only the storage primitives differ — `_apply` rebuilds the flat parameter buffer and both Adam moments
+    with one row-gather launch each (surviving rows keep their moments, new rows start from zero, optimizer_utils.cpp:5-165),
+    `_swap` (reset_opacity) writes the opacity segment in place and zeroes its moments."""
+
+    def __init__(self, anchors, scaling, quaternion, opacity, features_dc, features_rest, cfg=None, spatial_scale=1.0,
+                 num_train_data=1):
+        from .trainer import SplatParams
+        self.cfg = cfg or GSConfig()
+        n = anchors.shape[0]
+        self.params = SplatParams(anchors.detach().clone(), torch.zeros_like(anchors), scaling.detach().clone(),
+                                  quaternion.detach().clone(), opacity.detach().reshape(n).clone(),
+                                  features_dc.detach().reshape(n, -1).clone(), features_rest.detach().reshape(n, -1).clone())
+        self.spatial_scale_ = min(float(spatial_scale), 2.0)
+        self.original_spatial_scale_ = float(spatial_scale)
+        self.sh_degree_to_use_ = 0
+        self.num_train_data_ = num_train_data
+        self.state = {}
+        self.gs_param_start_idx = 0
+        self.key_for_gradient = "gradient_2dgs"
+        self.adam_group = 0
+
+    _FIELD = dict(offsets_="offsets", scaling_="scaling", quaternion_="quaternion", opacity_="opacity", features_dc_="features_dc",
+                  features_rest_="features_rest")
+
+    def _field(self, name):
+        v = self.params.views[self._FIELD[name]]
+        n = v.shape[0]
+        if name == "opacity_":
+            return v.view(n)
+        if name in ("features_dc_", "features_rest_"):
+            return v.view(n, -1, 3)
+        return v
+
+    anchors_ = property(lambda self: self.params.anchors, lambda self, v: setattr(self.params, "anchors", v.contiguous()))
+    offsets_ = property(lambda self: self._field("offsets_"))
+    scaling_ = property(lambda self: self._field("scaling_"))
+    quaternion_ = property(lambda self: self._field("quaternion_"))
+    opacity_ = property(lambda self: self._field("opacity_"))
+    features_dc_ = property(lambda self: self._field("features_dc_"))
+    features_rest_ = property(lambda self: self._field("features_rest_"))
+
+    def generate_gaussian(self, training=True):
+        return self.params.activated()            # one fused launch; gradients accumulate into the flat gradient buffer
+
+    def make_optimizer(self, sdf_groups=()):
+        from .trainer import FusedAdam
+        if sdf_groups:
+            raise RuntimeError("FlatNeuralGS.make_optimizer: the SDF network has its own FusedAdam (one per leg)")
+        opt = FusedAdam(eps=1e-15)
+        s = self.spatial_scale_
+        lrs = dict(offsets=1.6e-4 * s, scaling=5e-3, quaternion=1e-3, opacity=5e-2, features_dc=2.5e-3, features_rest=2.5e-3 / 20)
+        self.adam_group = opt.add_group(self.params.flat, self.params.flat_grad,
+                                        [(self.params.views[k].numel(), lrs[k]) for k in self.params.views])
+        return opt
+
+    def _apply(self, optimizer, keep_idx, ext):
+        e = None if not ext else {self._FIELD[k]: v for k, v in ext.items()}
+        self.params.resize(keep_idx, e, optimizer, self.adam_group)
+
+    def _swap(self, optimizer, name, new_tensor, moments):
+        """only reset_opacity comes through here: same rows, new values, fresh moments"""
+        with torch.no_grad():
+            self._field(name).copy_(new_tensor.view_as(self._field(name)))
+        if optimizer is not None:
+            optimizer.zero_segment_moments(self.adam_group, list(self.params.views).index(self._FIELD[name]))
+
+    def _set_lrs(self, optimizer, xyz_lr, sdf_lr):
+        optimizer.set_lr(self.adam_group, 0, xyz_lr)          # segment 0 = offsets (the position group)
+        self.sdf_lr = sdf_lr                                   # the SDF leg's optimizer reads it (bench / trainer loop)
 
 
 # ------------------------------------------------------------------------------------------------------------------

@@ -90,6 +90,71 @@ class SplatParams:
     def parameters(self):
         return list(self.views.values())
 
+    # ---- refinement-step surgery on the flat buffers (neural_gaussian.cpp:690-926 + optimizer_utils.cpp:5-165) -------------
+    def _bind(self, flat, flat_grad, n):
+        """views (and their .grad views) over a new pair of flat buffers holding n rows per field"""
+        widths = [v.shape[1] if v.dim() > 1 else 1 for v in self.views.values()]
+        off = 0
+        for (name, old), w in zip(list(self.views.items()), widths):
+            v = flat[off:off + n * w].view(n, w)
+            v.requires_grad_(True)
+            v.grad = flat_grad[off:off + n * w].view(n, w)
+            self.views[name] = v
+            off += n * w
+        self.flat, self.flat_grad = flat, flat_grad
+
+    @staticmethod
+    def _gather_rows(widths, n_src, n_dst, keep_idx, src, dst):
+        """dst rows [0, n_keep) of every field = src rows keep_idx (None: all n_src rows)."""
+        n_keep = n_src if keep_idx is None else int(keep_idx.numel())
+        if src.is_cuda:
+            import ctypes as C
+            from . import capi
+            capi.check(capi.lib().gsdf_flat_rows_gather(len(widths), (C.c_int32 * len(widths))(*widths), n_src, n_dst, n_keep,
+                                                        capi.ptr(None if keep_idx is None else keep_idx.contiguous(), torch.int64),
+                                                        capi.f32(src), capi.f32(dst), capi.stream()), "flat_rows_gather")
+            return
+        so = do = 0                                       # host tensors (CPU tests of the policy): the same thing in torch
+        for w in widths:
+            rows = src[so:so + n_src * w].view(n_src, w)
+            dst[do:do + n_keep * w].view(n_keep, w).copy_(rows if keep_idx is None else rows.index_select(0, keep_idx))
+            so, do = so + n_src * w, do + n_dst * w
+
+    @torch.no_grad()
+    def resize(self, keep_idx=None, ext=None, optimizer=None, group=0):
+        """The splat set becomes: rows `keep_idx` of the current one (int64 index tensor; None = all rows, in order) followed by
+        the rows of `ext` = {field: [n_ext, ...]} (None = nothing appended; every field must then be given).  The flat
+        parameter buffer, the flat gradient buffer (zeroed) and — when `optimizer` (FusedAdam) is given — both Adam moments of
+        `group` are rebuilt with ONE gather launch each: surviving rows keep their moments, appended rows start from zero
+        moments (optimizer_utils.cpp:5-165); the step count is kept, as torch::optim::Adam's per-parameter state is there."""
+        names = list(self.views)
+        widths = [self.views[k].shape[1] for k in names]
+        n_src = self.views[names[0]].shape[0]         # (the caller may already have replaced the anchors)
+        n_keep = n_src if keep_idx is None else int(keep_idx.numel())
+        n_ext = 0 if not ext else int(next(iter(ext.values())).shape[0])
+        n_dst, wt = n_keep + n_ext, sum(widths)
+        dev = self.flat.device
+        new_flat = torch.empty(n_dst * wt, dtype=torch.float32, device=dev)
+        self._gather_rows(widths, n_src, n_dst, keep_idx, self.flat, new_flat)
+        if n_ext:
+            off = 0
+            for k, w in zip(names, widths):
+                if w:
+                    new_flat[off + n_keep * w:off + n_dst * w].view(n_ext, w).copy_(ext[k].reshape(n_ext, w))
+                off += n_dst * w
+        if optimizer is not None:
+            g = optimizer.groups[group]
+            moments = []
+            for key in ("m", "v"):
+                buf = torch.zeros(n_dst * wt, dtype=torch.float32, device=dev)
+                self._gather_rows(widths, n_src, n_dst, keep_idx, g[key], buf)
+                moments.append(buf)
+        new_grad = torch.zeros(n_dst * wt, dtype=torch.float32, device=dev)
+        self._bind(new_flat, new_grad, n_dst)
+        if optimizer is not None:
+            optimizer.replace_group(group, new_flat, new_grad, moments[0], moments[1], [n_dst * w for w in widths])
+        return n_dst
+
 
 class ViewParallel:
     """Gradient synchronisation for view-parallel training.  `dist` is torch.distributed (backend nccl == RCCL
@@ -261,6 +326,25 @@ class FusedAdam:
 
     def set_lr(self, group, segment, lr):
         self.groups[group]["lrs"][segment] = float(lr)
+
+    def replace_group(self, group, flat, flat_grad, m, v, segment_sizes):
+        """New buffers for a group after a refinement step changed the number of rows (SplatParams.resize); learning rates
+        and the step count are kept."""
+        import ctypes as C
+        g = self.groups[group]
+        assert len(segment_sizes) == len(g["lrs"]) and sum(segment_sizes) == flat.numel()
+        begins, off = [], 0
+        for n in segment_sizes:
+            begins.append(off)
+            off += n
+        g.update(flat=flat, grad=flat_grad, m=m, v=v, begins=(C.c_int64 * len(begins))(*begins))
+
+    def zero_segment_moments(self, group, segment):
+        """reset_opacity (neural_gaussian.cpp:918-926): the moments of one parameter of the group start over."""
+        g = self.groups[group]
+        b = list(g["begins"]) + [g["flat"].numel()]
+        g["m"][b[segment]:b[segment + 1]].zero_()
+        g["v"][b[segment]:b[segment + 1]].zero_()
 
     @torch.no_grad()
     def step(self):

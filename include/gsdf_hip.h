@@ -351,6 +351,12 @@ int gsdf_splat_activations_bwd(int64_t n, const float *scales, const float *opac
 int gsdf_densify_stats(int64_t M, int64_t N, int n_cameras, int width, int height, const float *grad,
                        const int64_t *gaussian_ids, const float *visibilities, const int32_t *radii_px, float *grad2d,
                        float *count, float *vis, float *radii, gsdf_stream_t stream);
+/* a18 row surgery of the refinement steps on a FIELD-MAJOR flat buffer [field 0: n x w0 | field 1: n x w1 | ...] (the splat
+ *     parameters and both Adam moments): dst rows 0..n_keep-1 = src rows keep_idx[r] (NULL: the first n_keep rows), all fields
+ *     in one launch; dst has n_dst >= n_keep rows per field (the caller fills the appended rows).  Replaces the index_select
+ *     half of include/optimizer/optimizer_utils/optimizer_utils.cpp:5-165.  widths_host: n_fields HOST ints. */
+int gsdf_flat_rows_gather(int n_fields, const int32_t *widths_host, int64_t n_src, int64_t n_dst, int64_t n_keep,
+                          const int64_t *keep_idx, const float *src, float *dst, gsdf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Hint for the XCD-aware kernels (compositing: one band of tiles per XCD; hash-grid forward: one group of levels per

@@ -378,7 +378,9 @@ def test_single_node_coupling_leg_equals_composed_operators(sdf, eik):
         out.append((loss.detach(), x.grad.clone(), grp.flat_grad.clone()))
     assert_close(out[1][0], out[0][0], 1e-5, "loss")
     assert_close(out[1][1], out[0][1], 1e-5, "d/d samples")
-    assert_close(out[1][2], out[0][2], 2e-4 if eik else 1e-5, "flat parameter gradients")
+    # eikonal: differences of nearly equal SDF values times 1/(2 delta) -> the two evaluation orders (and the fp32 atomics of
+    # the table scatter, whose summation order is not fixed) differ by up to a few 1e-4 of the mean gradient magnitude
+    assert_close(out[1][2], out[0][2], 1e-3 if eik else 1e-5, "flat parameter gradients")
     with pytest.raises(RuntimeError):
         sdf.LocalMap([0, 0, 0], 2.0, decoder_implementation=1, device=dev).gs_sdf_coupling(pts, ids, w_all)
     with pytest.raises(RuntimeError):          # the node writes gradients in place: only inside grad_sinks_armed()

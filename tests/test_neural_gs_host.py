@@ -164,3 +164,66 @@ def test_inject_grads_and_join_grad_are_plain_autograd_plumbing():
     assert float(inject_grads([(a, ga)])) == 0.0
     loss.backward()
     assert torch.allclose(a.grad, 2 * a.detach() + ga) and torch.equal(b.grad, gb)
+
+
+def test_flat_neural_gs_refinement_equals_neural_gs_with_torch_adam():
+    """FlatNeuralGS (flat parameter buffer + FusedAdam-style moments, one row-gather per buffer) against NeuralGS +
+    torch.optim.Adam through the SAME sequence of duplicate / split / prune / opacity-reset operations (CPU: the host path
+    of SplatParams.resize; the GPU test runs the rendered schedule): identical parameters, anchors, statistics and Adam
+    moments after every step (optimizer_utils.cpp:5-165 semantics: kept rows keep their moments, new rows start at zero)."""
+    from gs_sdf_amd.neural_gs import FlatNeuralGS, GSConfig, NeuralGS
+    g = torch.Generator().manual_seed(0)
+    n, K = 300, 4
+    mk = lambda: (torch.randn(n, 3, generator=torch.Generator().manual_seed(1)), torch.randn(n, 3, generator=torch.Generator().manual_seed(2)) - 3.0,
+                  torch.randn(n, 4, generator=torch.Generator().manual_seed(3)), torch.randn(n, generator=torch.Generator().manual_seed(4)),
+                  torch.rand(n, 1, 3, generator=torch.Generator().manual_seed(5)), torch.randn(n, K - 1, 3, generator=torch.Generator().manual_seed(6)))
+    cfg = GSConfig(sh_degree=1)
+    a, b = NeuralGS(*mk(), cfg=cfg), FlatNeuralGS(*mk(), cfg=cfg)
+    opt_a, opt_b = a.make_optimizer(), b.make_optimizer()
+    # give both optimizers identical non-trivial moments
+    for name in NeuralGS.PARAMS:
+        p = getattr(a, name)
+        opt_a.state[p] = dict(step=torch.tensor(7.0), exp_avg=torch.randn(p.shape, generator=g), exp_avg_sq=torch.rand(p.shape, generator=g))
+    grp = opt_b.groups[b.adam_group]
+    opt_b.t = 7
+    off = 0
+    for name in NeuralGS.PARAMS:
+        st = opt_a.state[getattr(a, name)]
+        k = st["exp_avg"].numel()
+        grp["m"][off:off + k] = st["exp_avg"].reshape(-1)
+        grp["v"][off:off + k] = st["exp_avg_sq"].reshape(-1)
+        off += k
+    for gs in (a, b):
+        gs.state = dict(grad2d=torch.arange(n, dtype=torch.float32), count=torch.ones(n), vis=torch.rand(n, generator=torch.Generator().manual_seed(9)))
+
+    def check(tag):
+        assert a.anchors_.shape == b.anchors_.shape, tag
+        assert torch.equal(a.anchors_, b.anchors_), tag
+        off = 0
+        for name in NeuralGS.PARAMS:
+            pa, pb = getattr(a, name), getattr(b, name)
+            assert torch.equal(pa.detach().reshape(-1), pb.detach().reshape(-1)), (tag, name)
+            st = opt_a.state[pa]
+            k = pa.numel()
+            assert torch.equal(st["exp_avg"].reshape(-1), opt_b.groups[0]["m"][off:off + k]), (tag, name, "exp_avg")
+            assert torch.equal(st["exp_avg_sq"].reshape(-1), opt_b.groups[0]["v"][off:off + k]), (tag, name, "exp_avg_sq")
+            off += k
+        assert off == b.params.flat.numel() == b.params.flat_grad.numel()
+        for k in a.state:
+            assert torch.equal(a.state[k], b.state[k]), (tag, k)
+        for v in b.params.views.values():                  # views and their gradients live in the flat buffers
+            assert v.grad is not None and v.grad.data_ptr() >= b.params.flat_grad.data_ptr()
+
+    check("initial")
+    mask = torch.zeros(n, dtype=torch.bool); mask[5:40:3] = True
+    assert a.duplicate(opt_a, mask) == b.duplicate(opt_b, mask.clone()) > 0
+    check("duplicate")
+    m2 = torch.zeros(a.anchors_.shape[0], dtype=torch.bool); m2[::7] = True
+    assert a.split(opt_a, m2, torch.Generator().manual_seed(11)) == b.split(opt_b, m2.clone(), torch.Generator().manual_seed(11)) > 0
+    check("split")
+    m3 = torch.zeros(a.anchors_.shape[0], dtype=torch.bool); m3[3::5] = True
+    assert a._prune(opt_a, m3) == b._prune(opt_b, m3.clone()) > 0
+    check("prune")
+    a.reset_opacity(opt_a); b.reset_opacity(opt_b)
+    check("reset_opacity")
+    assert opt_b.t == 7 and int(b.anchors_.shape[0]) == int(b.params.views["offsets"].shape[0])
