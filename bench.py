@@ -49,6 +49,8 @@ def main():
     ap.add_argument("--light-step", action="store_true", help="round-1 step: no GS-sample eikonal regulariser, no per-iteration "
                                                                "update_state (NOT the reference's joint iteration)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the second (light-step) timing loop")
+    ap.add_argument("--collective", default="all_reduce", choices=["all_reduce", "reduce_scatter_all_gather"],
+                    help="N > 1: how a parameter family's flat gradient buffer is summed over the ranks")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -221,9 +223,10 @@ def main():
             # densification statistics from the compositing backward's `densify` gradient, one fused launch
             update_densify_state(gs_state, meta, N)
         stamp("backward issued")
-        if world > 1:
-            main.wait_stream(scatter)      # RCCL's workgroups land on every XCD: do not run them beside the scatter
-        vp.all_reduce_group(params)
+        # view-parallel: the splat family's gradients are final here; the SDF leg's scatter keeps running on its own stream
+        # beside the collective (no CU masks any more: the binned scatter is bandwidth-bound and shares the chip like any
+        # other kernel; round 1 serialised the two because RCCL's workgroups queued behind the scatter's atomics)
+        vp.all_reduce_group(params, args.collective)
         if update:
             adam.step()
             params.flat_grad.zero_()
@@ -233,7 +236,7 @@ def main():
             with torch.cuda.stream(side):
                 side.wait_stream(scatter)
                 side.wait_stream(aux)
-                vp.all_reduce_group(groups[0])
+                vp.all_reduce_group(groups[0], args.collective)
                 if update:
                     adam_sdf.step()
                     groups[0].flat_grad.zero_()

@@ -184,14 +184,46 @@ class ViewParallel:
             group.flat_grad.mul_(1.0 / self.world)
         self._pending = []
 
-    def all_reduce_group(self, group):
+    def all_reduce_group(self, group, collective="all_reduce", extra_sum=()):
         """Mean of ONE parameter family's gradients over the ranks, on the CURRENT stream (RCCL's internal stream is
         ordered after it and the current stream after RCCL): called from the stream of the leg that owns the family, so
-        that the other leg's kernels keep running beside the collective."""
+        that the other leg's kernels keep running beside the collective.
+
+        collective = "all_reduce": one all-reduce of the flat buffer.
+        collective = "reduce_scatter_all_gather": the same sum as an explicit reduce-scatter (every rank reduces 1/G of the
+            buffer) + all-gather; on xGMI (point-to-point links, no switch) both phases keep all 7 links of a GPU busy with
+            1/G-sized pieces, and the 1/G scaling runs on the shard only.  Results are identical to the all-reduce's up to
+            the order of the fp32 additions.
+        extra_sum: tensors summed over the ranks IN THE SAME MESSAGE (the refine statistics grad2d / count at a refinement
+            step: SURVEY 8e's second collective rides on the first); they are updated in place, unscaled."""
         if self.dist is None or self.world == 1:
             return
-        self.dist.all_reduce(group.flat_grad, op=self.dist.ReduceOp.SUM)
-        group.flat_grad.mul_(1.0 / self.world)
+        G, flat = self.world, group.flat_grad
+        extra = [t for t in extra_sum if t is not None]
+        if extra:
+            buf = torch.cat([flat] + [t.reshape(-1).to(flat.dtype) for t in extra])
+        else:
+            buf = flat
+        if collective == "reduce_scatter_all_gather":
+            n = buf.numel()
+            per = (n + G - 1) // G
+            if per * G != n:
+                buf = torch.cat([buf, buf.new_zeros(per * G - n)])
+            shard = torch.empty(per, dtype=buf.dtype, device=buf.device)
+            self.dist.reduce_scatter_tensor(shard, buf, op=self.dist.ReduceOp.SUM)
+            self.dist.all_gather_into_tensor(buf, shard)
+            buf = buf[:n]
+        elif collective == "all_reduce":
+            self.dist.all_reduce(buf, op=self.dist.ReduceOp.SUM)
+        else:
+            raise ValueError(f"unknown collective {collective!r}")
+        if buf is not flat:
+            flat.copy_(buf[:flat.numel()])
+            off = flat.numel()
+            for t in extra:
+                t.copy_(buf[off:off + t.numel()].view_as(t))
+                off += t.numel()
+        flat.mul_(1.0 / G)
 
     def sync_refine_state(self, state, sums=True, maxs=True):
         """The second, small collective of view-parallel training: before a refine step every rank must
