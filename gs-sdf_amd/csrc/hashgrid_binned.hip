@@ -424,6 +424,7 @@ extern "C" int gsdf_hashgrid_bwd_binned(int64_t B, int n_levels, int n_feat, int
   GSDF_CHECK_LAUNCH("bin_count_kernel");
   bin_plan_kernel<<<1, 1024, 0, stream>>>(nb, w.counts, w.cursor, w.start, w.items, w.n_items);
   GSDF_CHECK_LAUNCH("bin_plan_kernel");
+  // (measured and rejected: records straight from registers to their slots without the LDS sort — 2.0 ms against 1.74 ms)
   bin_emit_kernel<<<(unsigned)(chunks * bp.n_groups), BIN_PTS, 0, stream>>>(B, lv, bp, x, v_feat, w.start, w.cursor, w.records);
   GSDF_CHECK_LAUNCH("bin_emit_kernel");
   bin_apply_kernel<<<(unsigned)w.max_items, BIN_APPLY_THREADS, 0, stream>>>(lv, bp, w.items, w.n_items, w.lmax, w.records, v_table);
