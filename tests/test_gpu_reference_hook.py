@@ -1,0 +1,113 @@
+"""HOOK for pinning parity against the REAL reference submodules: the same comparisons as the oracle
+parity tests, but against a pybind11 module that exposes the reference's own operators
+(`fully_fused_projection_2dgs`, `gsplat_cpp::get_view_colors / tile_encode`, `rasterize_to_pixels_2dgs`, `TCNNEncoding`,
+`TCNNNetwork`, `distCUDA2`) — i.e. gs-sdf_amd/host/src/pytest_binding.cpp compiled against the maintainer's checkout of
+jianhengLiu/{gsplat_cpp,tcnn_binding,simple-knn} instead of this repository's drop-in headers (recipe: oracle/REF_HOOK.md).
+
+    GSDF_REFERENCE_MODULE=/path/to/_gsdf_ref<ext>.so  python -m pytest tests/test_gpu_reference_hook.py -m gpu
+
+Those submodules are not vendored in /root/reference (empty directories), so in this repository's own runs the variable is
+unset and the module under test is this repository's C++ operator layer (`_gsdf_host`): the run then only proves that the
+hook's plumbing works (C++ layer == Python mirror on the BASELINE shapes) and pins nothing to the reference."""
+import importlib.util
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import gs_sdf_amd.synth as synth
+from util import GATE_GRAD, GATE_IMAGE, assert_close, assert_equal_int, gate_violations, parity_stats
+
+pytestmark = pytest.mark.gpu
+SHAPES = [(10_000, 256, 256, 0, False), (300_000, 1200, 680, 0, True), (100_000, 640, 512, 3, False)]
+
+
+@pytest.fixture(scope="module")
+def ref():
+    path = os.environ.get("GSDF_REFERENCE_MODULE")
+    if not path:
+        import gs_sdf_amd.hostlib as h
+        return h.load(), False
+    spec = importlib.util.spec_from_file_location(os.path.basename(path).split(".")[0], path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod, True
+
+
+@pytest.mark.parametrize("N,W,H,deg,replica", SHAPES)
+def test_splat_operators_against_the_reference_module(ref, N, W, H, deg, replica):
+    import gs_sdf_amd.ops as ops
+    mod, real = ref
+    dev = torch.device("cuda:0")
+    sc = synth.make_scene(N, W, H, sh_degree=deg, seed=0, replica=replica)
+    vm = synth.make_views(2, seed=1)[1:].to(dev)
+    K = sc["K"].to(dev)
+    leaves = lambda: [t.to(dev).clone().requires_grad_(True) for t in (sc["means"], sc["quats"], sc["log_scales"].exp(),
+                                                                        torch.sigmoid(sc["logit_opacities"]), sc["sh"])]
+    ug = {k: v.to(dev) for k, v in synth.upstream_grads(H, W, seed=2).items()}
+    out = {}
+    for name, api in (("ref", mod), ("hip", ops)):
+        means, quats, scales, opac, sh = leaves()
+        cam, gid, radii, m2d, dep, rt, nrm, smp, sw = api.fully_fused_projection_2dgs(means, quats, scales, vm, K, W, H, 0.05, 300.0,
+                                                                                     0.0, True, False)
+        col = api.get_view_colors(vm, means, radii, sh, cam, gid, deg)
+        tpg, flat, offs = api.tile_encode(W, H, 16, m2d, radii, dep, True, 1, cam, gid)
+        dens = torch.zeros_like(m2d, requires_grad=True)
+        absg = torch.zeros_like(m2d)
+        rc, rd, ra, rn, _, rm, vis = api.rasterize_to_pixels_2dgs(m2d, rt, col, opac[gid], nrm, dens, W, H, 16, offs, flat, None, None,
+                                                                  True, absg, False)
+        loss = sum((t * ug[k]).sum() for t, k in ((rc, "v_render_colors"), (rd, "v_render_depths"), (ra, "v_render_alphas"),
+                                                  (rn, "v_render_normals"), (rm, "v_render_median")))
+        loss.backward()
+        out[name] = dict(ints=dict(camera_ids=cam, gaussian_ids=gid, radii=radii, tiles_per_gauss=tpg, flatten_ids=flat, isect_offsets=offs),
+                         proj=dict(means2d=m2d, depths=dep, ray_transforms=rt, normals=nrm, colors=col),
+                         img=dict(render_colors=rc, render_depths=rd, render_alphas=ra, render_normals=rn, visibilities=vis),
+                         grad=dict(v_means=means.grad, v_quats=quats.grad, v_scales=scales.grad, v_opacities=opac.grad, v_sh=sh.grad,
+                                   v_densify=dens.grad))
+    a, b = out["ref"], out["hip"]
+    for k in a["ints"]:                                         # tile / bin indices: bit-exact (north_star)
+        assert_equal_int(b["ints"][k], a["ints"][k], k)
+    for k in a["proj"]:
+        assert_close(b["proj"][k], a["proj"][k], 1e-4, k)
+    bad = []
+    for k in a["img"]:
+        bad += gate_violations(parity_stats(b["img"][k], a["img"][k]), GATE_IMAGE, k)
+    for k in a["grad"]:
+        bad += gate_violations(parity_stats(b["grad"][k], a["grad"][k]), GATE_GRAD, k)
+    assert not bad, ("against the reference's submodules: " if real else "plumbing self-check: ") + "; ".join(bad)
+
+
+def test_sdf_operators_against_the_reference_module(ref):
+    import gs_sdf_amd.ops as ops
+    import gs_sdf_amd.sdf as sdfm
+    mod, real = ref
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(0)
+    B = 32768
+    x = torch.rand(B, 3, generator=g).to(dev)
+    enc_r = mod.TCNNEncoding(16, 2, 19, 32, 2.0)
+    enc_h = sdfm.TCNNEncoding(3, None, "enc", dev, seed=0)
+    table = ((torch.rand(enc_h.params_.numel(), generator=g) * 2 - 1)).to(dev)
+    if real and enc_r.params_.dtype != torch.float32:          # tiny-cuda-nn keeps fp16 parameters: compare at its precision
+        pytest.skip("the reference's TCNNEncoding holds non-fp32 parameters: compare through tests with a matching tolerance")
+    enc_r.params_ = table.clone().requires_grad_(True)
+    enc_h.params_ = table.clone().requires_grad_(True)
+    v = torch.randn(B, 32, generator=g).to(dev)
+    res = []
+    for enc in (enc_r, enc_h):
+        xd = x.clone().requires_grad_(True)
+        f = enc.forward(xd)
+        (f * v).sum().backward()
+        res.append((f.detach(), xd.grad, enc.params_.grad))
+    assert_close(res[1][0], res[0][0], 1e-5, "hash-grid features")
+    assert_close(res[1][1], res[0][1], 1e-4, "hash-grid d/dx")
+    assert_close(res[1][2], res[0][2], 1e-4, "hash-grid d/d table")
+    net_r = mod.TCNNNetwork(32, 2, 64, 3)
+    net_h = sdfm.TCNNNetwork(32, 2, dict(n_neurons=64, n_hidden_layers=3), "dec", dev, seed=1)
+    if net_r.params_.dtype == torch.float32 and net_r.params_.numel() == net_h.params_.numel():
+        net_r.params_ = net_h.params_.detach().clone().requires_grad_(True)
+        fin = torch.randn(B, 32, generator=g).to(dev)
+        assert_close(net_h.forward(fin), net_r.forward(fin), 1e-4, "decoder output")
+    pts = torch.rand(5000, 3, generator=g).to(dev)
+    assert_close(ops.distCUDA2(pts), mod.distCUDA2(pts), 1e-4, "distCUDA2")
