@@ -25,7 +25,8 @@ sys.path.insert(0, ROOT)
 WORKLOADS = {
     # name: (N, W, H, sh_degree, replica intrinsics)
     "cfg3_1M_1080p": (1_000_000, 1920, 1080, 0, False),
-    "cfg1_replica_300k": (300_000, 1200, 680, 0, True),
+    "cfg1_replica_300k": (300_000, 1200, 680, 0, True),         # configs[1] with --no-sdf, configs[2] (joint train) without
+    "cfg4_3M_640x512_K16": (3_000_000, 640, 512, 3, False),     # configs[4] shape on ONE GPU (FAST-LIVO2: 640x512, sh_degree 3)
     "cfg0_10k_256": (10_000, 256, 256, 0, False),
 }
 

@@ -167,6 +167,8 @@ static void launch_fwd(int64_t B, int64_t jac_rows, const HgLevels &lv, int n_le
   static const bool off = [] { const char *e = getenv("GSDF_HASHGRID_XCD"); return e && e[0] == '0'; }();
   // measured: 17 % faster on a full-chip queue (2 levels = 8 MiB per XCD); no gain on a 6-XCD queue (3 levels = 12 MiB per
   // XCD, uneven groups) and none on 2 XCDs, so only full-chip queues take it
+  // (measured and rejected: two launches with ONE level = 4 MiB per XCD and launch, to fit the 4 MiB L2: 1.58 against 1.66 ms
+  // at 2.7 M points — the streaming x / feature traffic shares the L2 and the table still does not stay resident)
   if (!off && n_xcd == 8 && B >= 65536 && make_xcd_levels(n_levels, n_xcd, &xl, &max_nl)) {
     const int ppw_min = 16 / max_nl;
     const int64_t chunks = (B + 4 * ppw_min - 1) / (4 * ppw_min);

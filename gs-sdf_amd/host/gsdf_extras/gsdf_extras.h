@@ -1,0 +1,64 @@
+// gsdf_extras/gsdf_extras.h — the fused pieces of the training step that are NOT symbols of the replaced submodules, as
+// C++/libtorch operators in libgsdf_torch.so, so that the speed bench.py measures is reachable from the reference's own
+// C++ (each replaces a handful of eager libtorch kernels at the cited place; INTEGRATION.md section 5 shows the edits).
+//   l1_dssim_loss        k_rgb_weight * loss::rgb_loss + k_dssim_weight * loss::dssim_loss   neural_mapping.cpp:237-240
+//   query_points         SubMap::xyz_to_zp1_pts (+ the 6-point stencil of LocalMap::get_gradient)  sub_map.cpp:82-97, local_map.cpp:110-124
+//   sdf_ray_loss         loss::sdf_loss + w * loss::eikonal_loss(numerical gradient)          neural_mapping.cpp:138-188, loss.cpp:49-83
+//   gs_sdf_eik_loss      k_gs_sdf_weight * loss::gs_sdf_loss + k_eikonal_weight * eikonal on the splat samples   :436-457
+//   update_state         NeuralGS::update_state                                               neural_gaussian.cpp:626-680
+//   splat_activations    NeuralGS::generate_gaussian's exp / sigmoid / anchors + offsets      neural_gaussian.cpp:463-492
+//   FusedAdam            torch::optim::Adam::step over flat (parameter, gradient) buffers     neural_mapping.cpp:466-469
+#pragma once
+#include <torch/torch.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+namespace gsdf_extras {
+
+// [H,W,3] x [H,W,3] -> scalar; differentiable w.r.t. render
+torch::Tensor l1_dssim_loss(const torch::Tensor &render, const torch::Tensor &gt, double rgb_weight = 0.8, double dssim_weight = 0.2);
+
+// world points [n,3] -> unit-cube encoder inputs; with_stencil: 7n rows (base, then +x,-x,+y,-y,+z,-z blocks of n rows)
+torch::Tensor query_points(const torch::Tensor &xyz, const std::vector<float> &map_origin, double map_size_inv, bool with_stencil,
+                           double delta);
+
+// attr [(7 or 1) n, >=2] = decoder output on query_points' rows -> scalar (BCE sdf loss [+ w_eik * eikonal]); d/d attr
+torch::Tensor sdf_ray_loss(const torch::Tensor &attr, const torch::Tensor &gt_sdf, int64_t n, double bce_isigma, double delta, double w_eik);
+
+// attr [(7 or 1) n, >=1]; weights [M] (or [M,1]); ids int64 [n] (undefined: weights is [n]) -> scalar; d/d attr
+torch::Tensor gs_sdf_eik_loss(const torch::Tensor &attr, const torch::Tensor &weights, const torch::Tensor &ids, int64_t n, double scale,
+                              double delta, double w_eik);
+
+// state: "grad2d","count","vis"[,"radii"] created on first use; info as NeuralGS::render returns it
+void update_state(std::map<std::string, torch::Tensor> &state, const torch::Tensor &densify_grad, const torch::Tensor &gaussian_ids,
+                  const torch::Tensor &visibilities, const torch::Tensor &radii, int64_t n_gaussians, int n_cameras, int width,
+                  int height, bool want_radii);
+
+// (anchors, offsets, log-scales [N,3], logit-opacities [N]) -> (xyz, scales, opacities); differentiable
+std::vector<torch::Tensor> splat_activations(const torch::Tensor &anchors, const torch::Tensor &offsets, const torch::Tensor &scaling,
+                                             const torch::Tensor &opacity);
+
+// torch::optim::Adam semantics (no amsgrad / weight decay) over flat buffers, one launch per group
+class FusedAdam {
+ public:
+  FusedAdam(double beta1 = 0.9, double beta2 = 0.999, double eps = 1e-15) : b1_(beta1), b2_(beta2), eps_(eps) {}
+  // flat / flat_grad: contiguous fp32 device buffers; segments = consecutive (n_elements, lr) pieces covering the buffer
+  int add_group(const torch::Tensor &flat, const torch::Tensor &flat_grad, const std::vector<int64_t> &sizes, const std::vector<double> &lrs);
+  void set_lr(int group, int segment, double lr) { groups_.at(group).lrs.at(segment) = (float)lr; }
+  void step();
+  int64_t step_count() const { return t_; }
+
+ private:
+  struct Group {
+    torch::Tensor flat, grad, m, v;
+    std::vector<int64_t> begins;
+    std::vector<float> lrs;
+  };
+  std::vector<Group> groups_;
+  double b1_, b2_, eps_;
+  int64_t t_ = 0;
+};
+
+}  // namespace gsdf_extras

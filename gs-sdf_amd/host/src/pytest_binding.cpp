@@ -4,6 +4,7 @@
 #include <torch/extension.h>
 
 #include "cumcubes/cumcubes_wrapper.h"
+#include "gsdf_extras/gsdf_extras.h"
 #include "gsplat_cpp/fully_fused_projection.h"
 #include "gsplat_cpp/rasterize_to_pixels.h"
 #include "gsplat_cpp/rendering.h"
@@ -35,6 +36,25 @@ PYBIND11_MODULE(_gsdf_host, m) {
                                           packed, absg, distloss);
         });
   m.def("distCUDA2", &distCUDA2);
+  // fused extras (gsdf_extras/gsdf_extras.h)
+  m.def("l1_dssim_loss", &gsdf_extras::l1_dssim_loss);
+  m.def("query_points", &gsdf_extras::query_points);
+  m.def("sdf_ray_loss", &gsdf_extras::sdf_ray_loss);
+  m.def("gs_sdf_eik_loss", [](const torch::Tensor &attr, const torch::Tensor &w, py::object ids, int64_t n, double scale, double delta,
+                              double w_eik) {
+    return gsdf_extras::gs_sdf_eik_loss(attr, w, ids.is_none() ? torch::Tensor() : ids.cast<torch::Tensor>(), n, scale, delta, w_eik);
+  });
+  m.def("update_state", [](std::map<std::string, torch::Tensor> state, const torch::Tensor &g, const torch::Tensor &ids,
+                           const torch::Tensor &vis, const torch::Tensor &radii, int64_t n, int c, int w, int h, bool want_radii) {
+    gsdf_extras::update_state(state, g, ids, vis, radii, n, c, w, h, want_radii);
+    return state;
+  });
+  m.def("splat_activations", &gsdf_extras::splat_activations);
+  py::class_<gsdf_extras::FusedAdam>(m, "FusedAdam")
+      .def(py::init<double, double, double>(), py::arg("beta1") = 0.9, py::arg("beta2") = 0.999, py::arg("eps") = 1e-15)
+      .def("add_group", &gsdf_extras::FusedAdam::add_group)
+      .def("set_lr", &gsdf_extras::FusedAdam::set_lr)
+      .def("step", &gsdf_extras::FusedAdam::step);
   m.def("marching_cubes", [](const torch::Tensor &grid, float thresh, std::vector<float> lower, std::vector<float> upper) {
     TORCH_CHECK(lower.size() == 3 && upper.size() == 3, "marching_cubes: lower / upper need 3 entries");
     return mc::marching_cubes_wrapper(grid, thresh, lower.data(), upper.data());       // as cumcubes.cpp:9-27 calls it

@@ -91,6 +91,7 @@ def test_tcnn_objects_first_and_second_order(host, oracle):
     g_v, g_t = torch.autograd.grad((v_x * vv.to(dev)).sum(), (vd, enc.params_))
     gv_o, gt_o, _ = oracle.grid_bwd_bwd(n(x), n(table).reshape(-1, 2), n(v), n(vv), cfg, prec="f32")
     assert_close(g_v, gv_o, 1e-4, "double backward d/dv_feat"); assert_close(g_t.view(-1, 2), gt_o, 1e-4, "double backward d/dtable")
+    torch.manual_seed(1234)                  # the C++ constructor draws from the global generator (like torch::nn::Linear)
     net = host.TCNNNetwork(32, 2, 64, 3)
     W = n(net.params_)
     assert W.size == 32 * 64 + 2 * 64 * 64 + 64 * 2
@@ -100,7 +101,9 @@ def test_tcnn_objects_first_and_second_order(host, oracle):
     vo = torch.randn(B, 2, generator=g)
     out.backward(vo.to(dev))
     v_in, v_w, _ = oracle.mlp_bwd(n(f_in), [32, 64, 64, 64, 2], W, None, n(vo), prec="f64")
-    assert_close(f_in.grad, v_in, 1e-4, "mlp v_in"); assert_close(net.params_.grad, v_w, 1e-4, "mlp v_w")
+    # a pre-activation within fp32 rounding of 0 flips its ReLU mask against the fp64 oracle: a handful of elements
+    assert_close(f_in.grad, v_in, 1e-4, "mlp v_in", outlier_frac=1e-5, outlier_rel=5e-2)
+    assert_close(net.params_.grad, v_w, 1e-4, "mlp v_w", outlier_frac=1e-5, outlier_rel=5e-2)
 
 
 @pytest.mark.parametrize("N", [1, 2, 3, 4, 5000, 200_000])
@@ -182,3 +185,80 @@ def test_octree_as_cpp_matches_python_mirror_and_oracle(host, oracle):
     assert int(first.sum()) == int(torch.unique(ridx).numel()) and bool(first[0])
     with pytest.raises(RuntimeError):
         acc.raymarch(o, d, "ray", 2)
+
+
+def test_cpp_fused_extras_match_python_mirror(host):
+    """gsdf_extras/gsdf_extras.h (libgsdf_torch.so): the fused pieces of the training step that are not submodule symbols —
+    photometric loss, SDF query points / ray loss / GS-sample loss with eikonal, update_state, splat activations, fused
+    Adam — give the Python mirror's results (same kernels underneath), values and gradients."""
+    import gs_sdf_amd.ops as ops
+    import gs_sdf_amd.sdf as sdfm
+    from gs_sdf_amd.neural_gs import update_densify_state
+    from gs_sdf_amd.trainer import FusedAdam
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(0)
+    H, W = 72, 130
+    img = torch.rand(H, W, 3, generator=g).to(dev)
+    gt = torch.rand(H, W, 3, generator=g).to(dev)
+    a, b = img.clone().requires_grad_(True), img.clone().requires_grad_(True)
+    la, lb = host.l1_dssim_loss(a, gt, 0.8, 0.2), ops.l1_dssim_loss(b, gt, 0.8, 0.2)
+    (2.0 * la).backward(); (2.0 * lb).backward()
+    assert torch.allclose(la.detach(), lb.detach(), rtol=1e-6) and torch.allclose(a.grad, b.grad, rtol=1e-6, atol=1e-12)
+    # SDF pieces
+    n = 3000
+    xyz = ((torch.rand(n, 3, generator=g) - 0.5) * 6.0).to(dev)
+    lm = sdfm.LocalMap([0.1, 0.2, -0.3], 8.0, decoder_implementation=1, device=dev, seed=9)
+    q_py = lm.query_points(xyz, 0.02)
+    q_cpp = host.query_points(xyz, [0.1, 0.2, -0.3], 1.0 / 8.0, True, 0.02)
+    assert torch.equal(q_py, q_cpp)
+    attr = torch.randn(7 * n, 2, generator=g).to(dev)
+    gts = (torch.randn(n, 1, generator=g) * 0.05).to(dev)
+    a1, a2 = attr.clone().requires_grad_(True), attr.clone().requires_grad_(True)
+    l1 = host.sdf_ray_loss(a1, gts, n, 50.0, 0.02, 0.1)
+    l2 = sdfm._SdfRayLoss.apply(a2, gts, 50.0, 0.02, 0.1, n)
+    l1.backward(); l2.backward()
+    assert torch.allclose(l1.detach(), l2.detach(), rtol=1e-5) and torch.equal(a1.grad, a2.grad)   # the scalar is a sum of per-wave atomics
+    w_all = torch.rand(5000, generator=g).to(dev)
+    ids = torch.randperm(5000, generator=g)[:n].sort().values.to(dev)
+    a1, a2 = attr.clone().requires_grad_(True), attr.clone().requires_grad_(True)
+    l1 = host.gs_sdf_eik_loss(a1, w_all, ids, n, 1e-3, 0.02, 0.1)
+    l1.backward()
+    import ctypes as C
+    import gs_sdf_amd.capi as capi
+    loss = torch.empty((), device=dev); v = torch.empty_like(attr)
+    capi.check(capi.lib().gsdf_gs_sdf_eik_loss(n, 1, capi.f32(attr), 2, capi.f32(w_all), capi.ptr(ids, torch.int64), 1e-3, 0.02, 0.1,
+                                               capi.f32(loss), capi.f32(v), capi.stream()), "gs_sdf_eik_loss")
+    assert torch.allclose(l1.detach(), loss, rtol=1e-5) and torch.equal(a1.grad, v)
+    # update_state
+    N, M = 4000, 2500
+    gid = torch.randperm(N, generator=g)[:M].sort().values.to(dev)
+    dens = torch.zeros(M, 2, device=dev, requires_grad=True)
+    dens.grad = torch.randn(M, 2, generator=g).to(dev) * 1e-3
+    info = dict(gradient_2dgs=dens, n_cameras=torch.tensor([1]), width=torch.tensor([W]), height=torch.tensor([H]), gaussian_ids=gid,
+                visibilities=torch.rand(M, 1, generator=g).to(dev), radii=torch.randint(1, 30, (M,), generator=g, dtype=torch.int32).to(dev))
+    st_py = {}
+    update_densify_state(st_py, info, N, False, True)
+    st_cpp = host.update_state({}, dens.grad, gid, info["visibilities"], info["radii"], N, 1, W, H, True)
+    for k in ("grad2d", "count", "vis", "radii"):
+        assert torch.equal(st_py[k], st_cpp[k]), k
+    # activations + fused Adam
+    anchors, offsets = torch.randn(N, 3, generator=g).to(dev), (torch.randn(N, 3, generator=g) * 0.01).to(dev).requires_grad_(True)
+    scaling, opacity = torch.randn(N, 3, generator=g).to(dev).requires_grad_(True), torch.randn(N, generator=g).to(dev).requires_grad_(True)
+    xyz2, sc2, op2 = host.splat_activations(anchors, offsets, scaling, opacity)
+    assert torch.equal(xyz2, anchors + offsets)
+    assert_close(sc2, torch.exp(scaling), 1e-6, "scales"); assert_close(op2, torch.sigmoid(opacity), 1e-6, "opacities")
+    (xyz2.sum() + (sc2 * 2).sum() + (op2 * 3).sum()).backward()
+    assert_close(scaling.grad, 2 * torch.exp(scaling.detach()), 1e-6, "d/d log-scales")
+    o = torch.sigmoid(opacity.detach())
+    assert_close(opacity.grad, 3 * o * (1 - o), 1e-6, "d/d logit-opacity")
+    sizes, lrs = [1003, 4096, 7, 2501], [1.6e-4, 5e-3, 5e-2, 1e-3]
+    flat = torch.randn(sum(sizes), generator=g).to(dev)
+    f1, f2 = flat.clone(), flat.clone()
+    g1, g2 = torch.zeros_like(flat), torch.zeros_like(flat)
+    o1 = host.FusedAdam(0.9, 0.999, 1e-15); o1.add_group(f1, g1, sizes, lrs)
+    o2 = FusedAdam(eps=1e-15); o2.add_group(f2, g2, list(zip(sizes, lrs)))
+    for it in range(4):
+        gr = torch.randn(flat.numel(), generator=g).to(dev)
+        g1.copy_(gr); g2.copy_(gr)
+        o1.step(); o2.step()
+    assert torch.equal(f1, f2)
