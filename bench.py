@@ -337,16 +337,18 @@ def main():
             alg["hashgrid_fwd"] = 1164 * per_launch("hashgrid_fwd")
             for k in ("mlp_fwd", "mlp_bwd_data", "mlp_bwd_weights"):
                 flops[k] = 2 * 10368 * per_launch(k)
-        per_step = {k: kern.get(k, 0.0) * calls.get(k, 0) / args.steps for k in list(alg) + list(flops)}
+        # time per step of an operator = MEAN launch x launches per step (the two launches of an SDF operator differ 10x in size:
+        # 7 x 32768 ray points against ~3 M splat-sample points; `alg` is the per-launch mean to match); medians are reported too
+        per_step = {k: kern_mean.get(k, 0.0) * calls.get(k, 0) / args.steps for k in list(alg) + list(flops)}
         dom = max(per_step, key=lambda k: per_step[k])
-        dur_ms = kern.get(dom, float("nan"))
+        dur_ms = kern_mean.get(dom, float("nan"))
 
         def roof(k):
             if k in alg:
-                a = alg[k] / (kern[k] * 1e-3) / 1e9
+                a = alg[k] / (kern_mean[k] * 1e-3) / 1e9
                 return {"bound": "hbm", "achieved": a, "peak": 8000.0, "unit": "GB/s", "frac": a / 8000.0,
                         "algorithmic_bytes": int(alg[k])}
-            a = flops[k] / (kern[k] * 1e-3) / 1e12
+            a = flops[k] / (kern_mean[k] * 1e-3) / 1e12
             return {"bound": "mfma", "achieved": a, "peak": 157.3, "unit": "TFLOP/s", "frac": a / 157.3,
                     "algorithmic_flops": int(flops[k])}
         b_splat = (80 + 12 * Kb) * N + (364 + 12 * Kb) * M + 204 * I + 96 * P + 4 * T
@@ -374,17 +376,18 @@ def main():
                                    f"64-wide MLP) evaluated at {sdf_pts:.0f} points/step = 7 x 32768 ray + {stencil} x {n_gs:.0f} splat samples"),
                        "step": ("LIGHT (--light-step): " if state["light"] else "reference joint iteration (neural_mapping.cpp:400-486): ") + terms,
                        "parallelism": f"view-parallel x{world}" if world > 1 else "single GPU"},
-            "roofline": dict(roof(dom), kernel=dom, traffic=traffic, avg_launch_ms=dur_ms, mean_launch_ms=kern_mean.get(dom),
-                             launches_per_step=calls.get(dom, 0) / args.steps, timing="median over the timed steps (HIP events)",
+            "roofline": dict(roof(dom), kernel=dom, traffic=traffic, avg_launch_ms=dur_ms, median_launch_ms=kern.get(dom),
+                             launches_per_step=calls.get(dom, 0) / args.steps,
+                             timing="HIP events on the launch stream over the timed steps; mean launch (operators with unequal launches)",
                              ms_per_step_by_kernel={k: round(v, 4) for k, v in per_step.items()},
                              # the same figure for the other large kernels
-                             others={k: dict(roof(k), avg_launch_ms=kern[k]) for k in per_step if k != dom and kern.get(k)},
-                             # compositing kernels: VALU-issue side (they are bound by instruction issue, not HBM): wave64 VALU
-                             # instructions per launch from profiles/valu_insts.json (rocprofv3 SQ_INSTS_VALU) against the issue
-                             # peak 1024 SIMDs x 1 wave-instruction / 4 cycles... see DESIGN.md 5
-                             valu=(None if not valu else {k: {"insts_per_launch": v, "issue_peak_G_per_s": 1024 * 2.4 / 1.0,
-                                                              "frac_of_issue_peak": v / (kern[k] * 1e-3) / (1024 * 2.4e9)}
-                                                          for k, v in valu.items() if kern.get(k)}),
+                             others={k: dict(roof(k), avg_launch_ms=kern_mean[k], median_launch_ms=kern[k]) for k in per_step if k != dom and kern.get(k)},
+                             # compositing kernels: the VALU-issue side (they are bound by instruction issue, not by HBM): wave64
+                             # VALU instructions per launch (profiles/valu_insts.json: rocprofv3 --pmc SQ_INSTS_VALU, single stream)
+                             # over the launch time measured here, against 1024 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction
+                             valu=(None if not valu else {k: {"insts_per_launch": v, "issue_peak_G_per_s": 614.4,
+                                                              "frac_of_issue_peak": v / (kern_mean[k] * 1e-3) / 614.4e9}
+                                                          for k, v in valu.items() if kern_mean.get(k)}),
                              step_B_splat_bytes=int(b_splat), step_hbm_frac=b_splat / (elapsed / args.steps) / 8e12),
             "params_finite": bool(torch.isfinite(params.flat).all()) and all(bool(torch.isfinite(g.flat).all()) for g in groups),
             "hbm_gb": {"allocated_peak": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),

@@ -35,7 +35,7 @@ struct GridBwd : public torch::autograd::Function<GridBwd> {
     Tensor v_x = torch::empty_like(x);
     Tensor v_table = want_table ? torch::zeros_like(table) : Tensor();
     // large batches: the table gradient without global atomics (gsdf_hashgrid_bwd_binned), d/dx from the plain kernel
-    const size_t binned = (want_table && B >= 65536) ? gsdf_hashgrid_bwd_binned_ws_bytes(B, c.L, c.F, c.H, c.R, c.S) : 0;
+    const size_t binned = (want_table && B >= 24576) ? gsdf_hashgrid_bwd_binned_ws_bytes(B, c.L, c.F, c.H, c.R, c.S) : 0;
     if (binned) {
       Tensor ws = empty_like_opts(x, {(int64_t)binned}, torch::kUInt8);
       check(gsdf_hashgrid_bwd(B, c.L, c.F, c.H, c.R, c.S, fp(x), fp(table), fp(v_feat), nullptr, fpm(v_x), cur_stream()),

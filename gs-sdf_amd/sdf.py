@@ -53,7 +53,7 @@ def _sinks_live():
     return _SinkState.armed > 0 and not torch.is_grad_enabled()
 
 
-BINNED_MIN_POINTS = 65536     # below this the atomic scatter kernel is faster than the four binned passes
+BINNED_MIN_POINTS = 24576     # measured crossover on MI355X: 14 K points 0.058 (atomic) / 0.069 ms, 28 K points 0.109 / 0.084 ms
 
 
 def scatter_table_grad(B, cfg, x, table, v_feat, v_table, v_x=None):

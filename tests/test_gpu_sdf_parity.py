@@ -41,7 +41,7 @@ def _points(B, seed):
     return x, g
 
 
-@pytest.mark.parametrize("cfg,B", [(CFG, 32768), (CFG_SMALL, 1000), (CFG, 1)])
+@pytest.mark.parametrize("cfg,B", [(CFG, 32768), (CFG, 20000), (CFG_SMALL, 1000), (CFG, 1)])     # 32768: binned scatter, 20000: atomic
 def test_hashgrid_fwd_bwd_bwdbwd(sdf, oracle, cfg, B):
     dev = torch.device("cuda:0")
     enc = sdf.TCNNEncoding(3, tcfg(cfg), "enc", dev, seed=1)
