@@ -26,7 +26,7 @@ _SIGS = {
     "gsdf_view_colors_bwd": (C.c_int, [_i64, _i64, _i32] + [_vp] * 8 + [_i32, _vp]),
     "gsdf_tile_count_ws_bytes": (_sz, [_i64]),
     "gsdf_tile_count": (C.c_int, [_i64, _i32, _i32, _i32] + [_vp] * 7),
-    "gsdf_tile_encode_ws_bytes": (_sz, [_i64]),
+    "gsdf_tile_encode_ws_bytes": (_sz, [_i64, _i64]),
     "gsdf_tile_encode": (C.c_int, [_i64, _i64, _i64, _i32, _i32, _i32] + [_vp] * 10),
     "gsdf_rasterize_2dgs_fwd": (C.c_int, [_i64, _i64, _i64, _i32, _i32, _i32] + [_vp] * 18),
     "gsdf_rasterize_2dgs_bwd_ws_bytes": (_sz, [_i64]),

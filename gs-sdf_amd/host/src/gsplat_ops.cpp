@@ -205,7 +205,7 @@ std::tuple<Tensor, Tensor, Tensor> gsplat_cpp::tile_encode(int width, int height
   const int64_t I = read_i64(n_is);
   Tensor ids = empty_like_opts(means2d, {I}, torch::kInt64), flat = empty_like_opts(means2d, {I}, torch::kInt32);
   Tensor offs = empty_like_opts(means2d, {C, th, tw}, torch::kInt32);
-  Tensor ws2 = empty_like_opts(means2d, {(int64_t)gsdf_tile_encode_ws_bytes(I)}, torch::kUInt8);
+  Tensor ws2 = empty_like_opts(means2d, {(int64_t)gsdf_tile_encode_ws_bytes(M, I)}, torch::kUInt8);
   check(gsdf_tile_encode(M, C, I, width, height, tile_size, fp(means2d), M ? radii.data_ptr<int32_t>() : nullptr, fp(depths),
                          M ? camera_ids.data_ptr<int64_t>() : nullptr, cum.data_ptr<int64_t>(), ws2.data_ptr(),
                          I ? ids.data_ptr<int64_t>() : nullptr, I ? flat.data_ptr<int32_t>() : nullptr, offs.data_ptr<int32_t>(),

@@ -202,7 +202,7 @@ def tile_encode(width, height, tile_size, means2d, radii, depths, packed, C, cam
     I = _read_i64(n_is)
     isect_ids = _empty((I,), torch.int64, means2d); flatten_ids = _empty((I,), torch.int32, means2d)
     offsets = _empty((C, th, tw), torch.int32, means2d)
-    ws2 = torch.empty(L.gsdf_tile_encode_ws_bytes(I), dtype=torch.uint8, device=dev)
+    ws2 = torch.empty(L.gsdf_tile_encode_ws_bytes(M, I), dtype=torch.uint8, device=dev)
     capi.check(_timed("tile_encode", L.gsdf_tile_encode, M, C, I, width, height, tile_size, f32(means2d), ptr(radii), f32(depths),
                                   ptr(camera_ids, torch.int64), ptr(cum), ptr(ws2), ptr(isect_ids), ptr(flatten_ids),
                                   ptr(offsets), capi.stream()), "tile_encode")

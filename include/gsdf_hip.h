@@ -101,7 +101,7 @@ size_t gsdf_tile_count_ws_bytes(int64_t n_visible);
 int gsdf_tile_count(int64_t n_visible, int width, int height, int tile_size, const float *means2d,
                     const int32_t *radii, int32_t *tiles_per_gauss, int64_t *cum_tiles, void *ws,
                     int64_t *n_isects, gsdf_stream_t stream);
-size_t gsdf_tile_encode_ws_bytes(int64_t n_isects);
+size_t gsdf_tile_encode_ws_bytes(int64_t n_visible, int64_t n_isects);
 /* isect_ids i64[I] sorted keys (cam | tile | fp32 depth bits), flatten_ids i32[I],
  * isect_offsets i32[C*tile_h*tile_w]. */
 int gsdf_tile_encode(int64_t n_visible, int64_t n_cams, int64_t n_isects, int width, int height, int tile_size,
