@@ -135,7 +135,11 @@ def main():
                 print(f"[bench] XCD-partitioned streams unavailable ({e}); using unmasked streams", file=sys.stderr, flush=True)
                 main, side, aux, scatter = (torch.cuda.Stream() for _ in range(4))
         else:
-            main, side, aux, scatter = (torch.cuda.Stream() for _ in range(4))
+            # the splat leg's ~60 short kernels per step gate the start of the SDF leg (the visible set) and of the next step:
+            # a high-priority queue keeps them from waiting behind the SDF leg's multi-millisecond kernels
+            prio = int(os.environ.get("GSDF_SPLAT_STREAM_PRIORITY", "-1"))
+            main = torch.cuda.Stream(priority=prio)
+            side, aux, scatter = (torch.cuda.Stream() for _ in range(3))
         lm.encoder.scatter_stream = scatter
         lm.decoder.aux_stream = aux          # decoder weight gradients: off the chain that leads back to the splat leg
         main.wait_stream(torch.cuda.current_stream())
