@@ -41,6 +41,7 @@ _SIGS = {
     "gsdf_hashgrid_bwd": (C.c_int, [_i64, _i32, _i32, _i32, _i32, _f32] + [_vp] * 6),
     "gsdf_hashgrid_bwd_binned_ws_bytes": (_sz, [_i64, _i32, _i32, _i32, _i32, _f32]),
     "gsdf_hashgrid_bwd_binned": (C.c_int, [_i64, _i32, _i32, _i32, _i32, _f32] + [_vp] * 4 + [_sz, _vp]),
+    "gsdf_hashgrid_bwd_binned_stencil": (C.c_int, [_i64, _i64, _i32, _i32, _i32, _i32, _i32, _f32] + [_vp] * 4 + [_sz, _vp]),
     "gsdf_hashgrid_bwd_bwd": (C.c_int, [_i64, _i32, _i32, _i32, _i32, _f32] + [_vp] * 8),
     "gsdf_mlp_fwd": (C.c_int, [_i64, _i32] + [_vp] * 7),
     "gsdf_mlp_acts_floats": (_sz, [_i64, _i32]),

@@ -10,8 +10,8 @@
 //
 //   count  : per (level, table tile of 8192 entries = 64 KB) how many contributions arrive          (LDS histograms)
 //   plan   : exclusive scan of the bucket sizes; work items of <= ITEM_MAX records for the last pass (one workgroup)
-//   emit   : every contribution becomes a 12-byte record {entry within tile, g0, g1}; a workgroup sorts the records of
-//            its 256 points x 2 levels by bucket in LDS and appends each run to its bucket with ONE reservation per
+//   emit   : every contribution becomes a 12-byte record {entry within tile, g0, g1}; a workgroup (one thread per (point,
+//            level), 8 waves) sorts the records of its 256 points x 2 levels by bucket in LDS and appends each run to its bucket with ONE reservation per
 //            (workgroup, bucket) and fully coalesced stores
 //   apply  : one workgroup per item: the tile lives in LDS (64 KB) as 64-BIT FIXED POINT, records stream in coalesced,
 //            ds_add_u64, then the tile is added to the gradient with plain coalesced read-modify-writes (the tile has
@@ -124,6 +124,30 @@ __device__ __forceinline__ void corners_of(const HgLevels &lv, int level, float 
   }
 }
 
+// Stencil structure of a batch (optional): rows [0, n) are base points, rows n + k n + i (k = 0..5) the six central-
+// difference points of base i (gsdf_sdf_query_points).  At the coarse levels the seven points of a group usually lie in
+// the same grid cell, i.e. touch the same 8 entries: their contributions are then summed in registers and emitted as ONE
+// set of 8 records by the base row; a stencil row emits nothing at a level where it shares the cell of its base row.
+struct BinStencil {
+  int64_t n;           // 0: no structure
+  int merge_levels;    // levels [0, merge_levels) are checked for merging
+};
+__device__ __forceinline__ void cell_coords(const HgLevels &lv, int level, float px, float py, float pz, int32_t g[3]) {
+  const float scale = lv.scale[level];
+  g[0] = (int32_t)floorf(fmaf(scale, px, 0.5f));
+  g[1] = (int32_t)floorf(fmaf(scale, py, 0.5f));
+  g[2] = (int32_t)floorf(fmaf(scale, pz, 0.5f));
+}
+// does stencil row b (>= n) share the level's cell with its base row?
+__device__ __forceinline__ bool merged_into_base(const HgLevels &lv, int level, const BinStencil &stn, const float *__restrict__ x,
+                                                 int64_t b, float px, float py, float pz) {
+  const int64_t i = (b - stn.n) % stn.n;
+  int32_t gb[3], gs[3];
+  cell_coords(lv, level, x[3 * i], x[3 * i + 1], x[3 * i + 2], gb);
+  cell_coords(lv, level, px, py, pz, gs);
+  return gb[0] == gs[0] && gb[1] == gs[1] && gb[2] == gs[2];
+}
+
 // ---- level maxima of |v_feat| (bit patterns of non-negative floats: unsigned max) -------------------------------------
 // corner weights are <= 1, so this bounds every contribution of the level; it fixes the apply pass's fixed point.
 // A reduction kernel of its own (0.1 ms at 3 M points): folding it into the emit kernel as one atomicMax per wave puts
@@ -150,7 +174,7 @@ __global__ void __launch_bounds__(256)
 
 // ---- count ------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(BIN_PTS)
-    bin_count_kernel(int64_t B, HgLevels lv, BinPlan bp, const float *__restrict__ x, uint32_t *__restrict__ counts) {
+    bin_count_kernel(int64_t B, HgLevels lv, BinPlan bp, BinStencil stn, const float *__restrict__ x, uint32_t *__restrict__ counts) {
   __shared__ uint32_t s_hist[BIN_MAX_LOCAL];
   const int grp = blockIdx.x % bp.n_groups;
   const int64_t chunk = blockIdx.x / bp.n_groups;
@@ -164,6 +188,7 @@ __global__ void __launch_bounds__(BIN_PTS)
     if (b < B) {
       const float px = x[3 * b], py = x[3 * b + 1], pz = x[3 * b + 2];
       for (int level = l0; level < l1; ++level) {
+        if (stn.n > 0 && level < stn.merge_levels && b >= stn.n && merged_into_base(lv, level, stn, x, b, px, py, pz)) continue;
         Corner8 c;
         corners_of(lv, level, px, py, pz, c);
         const int lb = bp.tile_base[level] - b0;
@@ -233,82 +258,101 @@ __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v, int lane) {
   return v;
 }
 
-__global__ void __launch_bounds__(BIN_PTS)
-    bin_emit_kernel(int64_t B, HgLevels lv, BinPlan bp, const float *__restrict__ x, const float *__restrict__ v_feat,
-                    const int64_t *__restrict__ start, uint32_t *__restrict__ cursor, BinRecord *__restrict__ records) {
+static constexpr int BIN_EMIT_THREADS = BIN_PTS * BIN_G;   // one thread per (point, level of the group): 8 waves per workgroup
+__global__ void __launch_bounds__(BIN_EMIT_THREADS)
+    bin_emit_kernel(int64_t B, HgLevels lv, BinPlan bp, BinStencil stn, const float *__restrict__ x,
+                    const float *__restrict__ v_feat, const int64_t *__restrict__ start, uint32_t *__restrict__ cursor,
+                    BinRecord *__restrict__ records) {
   __shared__ uint32_t s_key[BIN_REC];
   __shared__ float s_g0[BIN_REC], s_g1[BIN_REC];
-  __shared__ uint32_t s_hist[BIN_MAX_LOCAL], s_off[BIN_MAX_LOCAL], s_wtot[BIN_PTS / 64];
+  __shared__ uint32_t s_hist[BIN_MAX_LOCAL], s_off[BIN_MAX_LOCAL], s_wtot[BIN_MAX_LOCAL / 64];
   __shared__ int64_t s_dst[BIN_MAX_LOCAL];
   const int grp = blockIdx.x % bp.n_groups;
   const int64_t chunk = blockIdx.x / bp.n_groups;
   const int l0 = grp * BIN_G, l1 = min(l0 + BIN_G, lv.n_levels);
   const int b0 = bp.tile_base[l0], nloc = bp.tile_base[l1] - b0;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  s_hist[t] = 0;
+  if (t < BIN_MAX_LOCAL) s_hist[t] = 0;
   __syncthreads();
-  const int64_t b = chunk * BIN_PTS + t;
-  // pass 1: contributions in registers, slot within the workgroup's bucket run from an LDS counter
-  uint32_t key[BIN_G * 8], slot[BIN_G * 8];
-  float g0[BIN_G * 8], g1[BIN_G * 8];
-  if (b < B) {
+  // thread -> (point, level): waves 0..3 take the group's first level, waves 4..7 the second (the level is wave-uniform)
+  const int64_t b = chunk * BIN_PTS + (t & (BIN_PTS - 1));
+  const int level = l0 + (t >> 8);
+  // pass 1: this (point, level)'s 8 contributions in registers, slot within the workgroup's bucket run from an LDS counter
+  uint32_t key[8], slot[8];
+  float g0[8], g1[8];
+  bool emits = false;
+  if (b < B && level < l1) {
     const float px = x[3 * b], py = x[3 * b + 1], pz = x[3 * b + 2];
+    const bool try_merge = stn.n > 0 && level < stn.merge_levels;
+    if (!(try_merge && b >= stn.n && merged_into_base(lv, level, stn, x, b, px, py, pz))) {   // else: the base row carries it
+      emits = true;
+      Corner8 c;
+      corners_of(lv, level, px, py, pz, c);
+      const float2 vf = *reinterpret_cast<const float2 *>(v_feat + (b * lv.n_levels + level) * 2);
 #pragma unroll
-    for (int g = 0; g < BIN_G; ++g) {
-      const int level = l0 + g;
-      if (level < l1) {
-        Corner8 c;
-        corners_of(lv, level, px, py, pz, c);
-        const float2 vf = *reinterpret_cast<const float2 *>(v_feat + (b * lv.n_levels + level) * 2);
-        const int lb = bp.tile_base[level] - b0;
+      for (int k = 0; k < 8; ++k) { g0[k] = c.w[k] * vf.x; g1[k] = c.w[k] * vf.y; }
+      if (try_merge && b < stn.n) {
+        // base row: add the stencil rows that share this cell (same 8 entries, their own trilinear weights), in row order
+        int32_t gb[3];
+        cell_coords(lv, level, px, py, pz, gb);
+        for (int k6 = 0; k6 < 6; ++k6) {
+          const int64_t r = stn.n + (int64_t)k6 * stn.n + b;
+          const float qx = x[3 * r], qy = x[3 * r + 1], qz = x[3 * r + 2];
+          int32_t gs[3];
+          cell_coords(lv, level, qx, qy, qz, gs);
+          if (gs[0] != gb[0] || gs[1] != gb[1] || gs[2] != gb[2]) continue;
+          Corner8 cs;
+          corners_of(lv, level, qx, qy, qz, cs);
+          const float2 vs = *reinterpret_cast<const float2 *>(v_feat + (r * lv.n_levels + level) * 2);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          const uint32_t bucket = (uint32_t)lb + (c.idx[k] >> BIN_TILE_LOG2);
-          key[g * 8 + k] = (c.idx[k] & (BIN_TILE - 1)) | (bucket << 16);
-          slot[g * 8 + k] = atomicAdd(&s_hist[bucket], 1u);
-          g0[g * 8 + k] = c.w[k] * vf.x;
-          g1[g * 8 + k] = c.w[k] * vf.y;
+          for (int k = 0; k < 8; ++k) { g0[k] += cs.w[k] * vs.x; g1[k] += cs.w[k] * vs.y; }
         }
+      }
+      const int lb = bp.tile_base[level] - b0;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const uint32_t bucket = (uint32_t)lb + (c.idx[k] >> BIN_TILE_LOG2);
+        key[k] = (c.idx[k] & (BIN_TILE - 1)) | (bucket << 16);
+        slot[k] = atomicAdd(&s_hist[bucket], 1u);
       }
     }
   }
   __syncthreads();
   // reserve the runs in the global buckets (the reply is only needed by pass 3: its latency hides behind the scan and
-  // pass 2); exclusive scan of the local histogram: DPP-free wave scans + one combine, 2 barriers
-  const uint32_t mine = t < nloc ? s_hist[t] : 0u;
-  uint32_t reserved = 0u;
-  if (mine) reserved = atomicAdd(&cursor[b0 + t], mine);
-  const uint32_t incl = wave_inclusive_scan(mine, lane);
-  if (lane == 63) s_wtot[wave] = incl;
-  __syncthreads();
-  uint32_t before = 0u, n_rec = 0u;
-#pragma unroll
-  for (int w = 0; w < BIN_PTS / 64; ++w) {
-    const uint32_t wt = s_wtot[w];
-    before += w < wave ? wt : 0u;
-    n_rec += wt;
+  // pass 2); exclusive scan of the local histogram by the first 256 threads: wave scans + one combine
+  uint32_t mine = 0u, reserved = 0u, incl = 0u;
+  if (t < BIN_MAX_LOCAL) {
+    mine = t < nloc ? s_hist[t] : 0u;
+    if (mine) reserved = atomicAdd(&cursor[b0 + t], mine);
+    incl = wave_inclusive_scan(mine, lane);
+    if (lane == 63) s_wtot[wave] = incl;
   }
-  s_off[t] = before + incl - mine;
+  __syncthreads();
+  uint32_t n_rec = 0u;
+#pragma unroll
+  for (int w = 0; w < BIN_MAX_LOCAL / 64; ++w) n_rec += s_wtot[w];
+  if (t < BIN_MAX_LOCAL) {
+    uint32_t before = 0u;
+#pragma unroll
+    for (int w = 0; w < BIN_MAX_LOCAL / 64; ++w) before += w < wave ? s_wtot[w] : 0u;
+    s_off[t] = before + incl - mine;
+  }
   __syncthreads();
   // pass 2: records to their sorted position in LDS
-  if (b < B) {
+  if (emits) {
 #pragma unroll
-    for (int g = 0; g < BIN_G; ++g)
-      if (l0 + g < l1) {
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          const uint32_t bucket = key[g * 8 + k] >> 16;
-          const uint32_t p = s_off[bucket] + slot[g * 8 + k];
-          s_key[p] = key[g * 8 + k];      // entry within tile | local bucket << 16
-          s_g0[p] = g0[g * 8 + k];
-          s_g1[p] = g1[g * 8 + k];
-        }
-      }
+    for (int k = 0; k < 8; ++k) {
+      const uint32_t bucket = key[k] >> 16;
+      const uint32_t p = s_off[bucket] + slot[k];
+      s_key[p] = key[k];      // entry within tile | local bucket << 16
+      s_g0[p] = g0[k];
+      s_g1[p] = g1[k];
+    }
   }
   if (mine) s_dst[t] = start[b0 + t] + (int64_t)reserved;
   __syncthreads();
   // pass 3: runs to the global buckets; consecutive lanes write consecutive 12-byte records
-  for (uint32_t p = t; p < n_rec; p += BIN_PTS) {
+  for (uint32_t p = t; p < n_rec; p += BIN_EMIT_THREADS) {
     const uint32_t kb = s_key[p], bucket = kb >> 16;
     BinRecord r;
     r.key = kb & 0xFFFFu;
@@ -402,8 +446,18 @@ extern "C" size_t gsdf_hashgrid_bwd_binned_ws_bytes(int64_t B, int n_levels, int
 
 extern "C" int gsdf_hashgrid_bwd_binned(int64_t B, int n_levels, int n_feat, int log2_hashmap, int base_res,
                                         float per_level_scale, const float *x, const float *v_feat, float *v_table,
-                                        void *ws, size_t ws_bytes, gsdf_stream_t stream_) {
+                                        void *ws, size_t ws_bytes, gsdf_stream_t stream) {
+  return gsdf_hashgrid_bwd_binned_stencil(B, 0, 0, n_levels, n_feat, log2_hashmap, base_res, per_level_scale, x, v_feat, v_table, ws,
+                                          ws_bytes, stream);
+}
+
+extern "C" int gsdf_hashgrid_bwd_binned_stencil(int64_t B, int64_t stencil_n, int merge_levels, int n_levels, int n_feat,
+                                                int log2_hashmap, int base_res, float per_level_scale, const float *x,
+                                                const float *v_feat, float *v_table, void *ws, size_t ws_bytes,
+                                                gsdf_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
+  GSDF_REQUIRE(stencil_n == 0 || (stencil_n > 0 && B == 7 * stencil_n), "hashgrid_bwd_binned: a stencil batch has 7 * stencil_n rows");
+  const BinStencil stn{stencil_n, stencil_n > 0 ? (merge_levels < 0 ? 0 : merge_levels) : 0};
   HgLevels lv;
   BinPlan bp;
   const int rc = binned_setup(B, n_levels, n_feat, log2_hashmap, base_res, per_level_scale, &lv, &bp);
@@ -420,12 +474,12 @@ extern "C" int gsdf_hashgrid_bwd_binned(int64_t B, int n_levels, int n_feat, int
   GSDF_REQUIRE(chunks * bp.n_groups < (int64_t)1 << 31, "hashgrid_bwd_binned: batch too large");
   bin_vmax_kernel<<<1024, 256, 0, stream>>>(B * n_levels, n_levels, reinterpret_cast<const float2 *>(v_feat), w.lmax);
   GSDF_CHECK_LAUNCH("bin_vmax_kernel");
-  bin_count_kernel<<<(unsigned)(chunks4 * bp.n_groups), BIN_PTS, 0, stream>>>(B, lv, bp, x, w.counts);
+  bin_count_kernel<<<(unsigned)(chunks4 * bp.n_groups), BIN_PTS, 0, stream>>>(B, lv, bp, stn, x, w.counts);
   GSDF_CHECK_LAUNCH("bin_count_kernel");
   bin_plan_kernel<<<1, 1024, 0, stream>>>(nb, w.counts, w.cursor, w.start, w.items, w.n_items);
   GSDF_CHECK_LAUNCH("bin_plan_kernel");
   // (measured and rejected: records straight from registers to their slots without the LDS sort — 2.0 ms against 1.74 ms)
-  bin_emit_kernel<<<(unsigned)(chunks * bp.n_groups), BIN_PTS, 0, stream>>>(B, lv, bp, x, v_feat, w.start, w.cursor, w.records);
+  bin_emit_kernel<<<(unsigned)(chunks * bp.n_groups), BIN_EMIT_THREADS, 0, stream>>>(B, lv, bp, stn, x, v_feat, w.start, w.cursor, w.records);
   GSDF_CHECK_LAUNCH("bin_emit_kernel");
   bin_apply_kernel<<<(unsigned)w.max_items, BIN_APPLY_THREADS, 0, stream>>>(lv, bp, w.items, w.n_items, w.lmax, w.records, v_table);
   GSDF_CHECK_LAUNCH("bin_apply_kernel");

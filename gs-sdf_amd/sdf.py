@@ -56,9 +56,17 @@ def _sinks_live():
 BINNED_MIN_POINTS = 24576     # measured crossover on MI355X: 14 K points 0.058 (atomic) / 0.069 ms, 28 K points 0.109 / 0.084 ms
 
 
-def scatter_table_grad(B, cfg, x, table, v_feat, v_table, v_x=None):
+def stencil_merge_levels(cfg, delta_unit):
+    """Number of coarse levels at which the +-delta stencil points of a sample usually share the sample's grid cell
+    (scale_l * delta < 1, scale_l = base_resolution * per_level_scale^l - 1): the levels the binned scatter checks for merging."""
+    n_levels, _, _, base_res, pls = cfg
+    return sum(1 for l in range(n_levels) if (base_res * pls ** l - 1.0) * float(delta_unit) < 1.0)
+
+
+def scatter_table_grad(B, cfg, x, table, v_feat, v_table, v_x=None, stencil=None):
     """v_table += (d feat / d table)^T v_feat [and v_x = (d feat / d x)^T v_feat].  Large batches take the binned scatter
-    (include/gsdf_hip.h: gsdf_hashgrid_bwd_binned, no global atomics); GSDF_HASHGRID_BINNED=0/1 forces one path (tests)."""
+    (include/gsdf_hip.h: gsdf_hashgrid_bwd_binned, no global atomics); GSDF_HASHGRID_BINNED=0/1 forces one path (tests).
+    stencil = (n, merge_levels): the batch is n base rows + 6 blocks of n central-difference rows (query_points layout)."""
     L = capi.lib()
     mode = os.environ.get("GSDF_HASHGRID_BINNED", "auto")
     nbytes = 0
@@ -69,8 +77,9 @@ def scatter_table_grad(B, cfg, x, table, v_feat, v_table, v_x=None):
             capi.check(_timed("hashgrid_bwd_input", L.gsdf_hashgrid_bwd, B, *cfg, f32(x), f32(table), f32(v_feat), None,
                               f32(v_x), capi.stream()), "hashgrid_bwd")
         ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
-        capi.check(_timed("hashgrid_bwd", L.gsdf_hashgrid_bwd_binned, B, *cfg, f32(x), f32(v_feat), f32(v_table), ptr(ws),
-                          nbytes, capi.stream()), "hashgrid_bwd_binned")
+        sn, ml = stencil if (stencil is not None and stencil[0] * 7 == B and os.environ.get("GSDF_STENCIL_MERGE", "1") != "0") else (0, 0)
+        capi.check(_timed("hashgrid_bwd", L.gsdf_hashgrid_bwd_binned_stencil, B, sn, ml, *cfg, f32(x), f32(v_feat), f32(v_table),
+                          ptr(ws), nbytes, capi.stream()), "hashgrid_bwd_binned")
     else:
         capi.check(_timed("hashgrid_bwd" if v_table is not None else "hashgrid_bwd_input", L.gsdf_hashgrid_bwd, B, *cfg,
                           f32(x), f32(table), f32(v_feat), f32(v_table), f32(v_x), capi.stream()), "hashgrid_bwd")
@@ -81,7 +90,7 @@ class _GridBwd(torch.autograd.Function):
     grad-of-grad (eikonal on the analytic SDF gradient) works."""
 
     @staticmethod
-    def forward(ctx, v_feat, x, table, cfg, want_table, grad_sink=None, scatter_stream=None, want_x=True):
+    def forward(ctx, v_feat, x, table, cfg, want_table, grad_sink=None, scatter_stream=None, want_x=True, stencil=None):
         L = capi.lib()
         B = x.shape[0]
         v_feat = v_feat.contiguous()
@@ -89,7 +98,7 @@ class _GridBwd(torch.autograd.Function):
         empty = lambda: torch.zeros(0, device=x.device)
 
         def launch(vt, vx):
-            scatter_table_grad(B, cfg, x, table, v_feat, vt, vx)
+            scatter_table_grad(B, cfg, x, table, v_feat, vt, vx, stencil)
 
         if want_table and grad_sink is not None:
             # accumulate straight into the parameter's (pre-zeroed) gradient buffer: the kernel's atomics already
@@ -130,18 +139,18 @@ class _GridBwd(torch.autograd.Function):
         B = x.shape[0]
         need_vf, need_x, need_t = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2]
         if vv_x is None:
-            return None, None, None, None, None, None, None, None
+            return None, None, None, None, None, None, None, None, None
         g_vfeat = torch.empty_like(v_feat) if need_vf else None
         g_x = torch.empty_like(x) if need_x else None
         g_table = torch.zeros_like(table) if need_t else None
         capi.check(_timed("hashgrid_bwd_bwd", L.gsdf_hashgrid_bwd_bwd, B, *ctx.cfg, f32(x), f32(table), f32(v_feat),
                           f32(vv_x.contiguous()), f32(g_vfeat), f32(g_table), f32(g_x), capi.stream()), "hashgrid_bwd_bwd")
-        return g_vfeat, g_x, g_table, None, None, None, None, None
+        return g_vfeat, g_x, g_table, None, None, None, None, None, None
 
 
 class _GridFwd(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, table, cfg, grad_sink=None, scatter_stream=None, save_jacobian=False):
+    def forward(ctx, x, table, cfg, grad_sink=None, scatter_stream=None, save_jacobian=False, stencil=None):
         L = capi.lib()
         x, table = x.contiguous(), table.contiguous()
         B = x.shape[0]
@@ -156,7 +165,7 @@ class _GridFwd(torch.autograd.Function):
                               capi.stream()), "hashgrid_fwd")
         ctx.save_for_backward(x, table, jac)
         ctx.cfg = cfg
-        ctx.grad_sink, ctx.scatter_stream = grad_sink, scatter_stream
+        ctx.grad_sink, ctx.scatter_stream, ctx.stencil = grad_sink, scatter_stream, stencil
         return feat
 
     @staticmethod
@@ -172,10 +181,10 @@ class _GridFwd(torch.autograd.Function):
             want_x = False
         sink = ctx.grad_sink if _sinks_live() else None
         g_x, v_table = _GridBwd.apply(v_feat, x, table, ctx.cfg, bool(ctx.needs_input_grad[1]), sink,
-                                      ctx.scatter_stream if sink is not None else None, want_x)
+                                      ctx.scatter_stream if sink is not None else None, want_x, ctx.stencil)
         v_x = g_x if want_x else v_x
         want_t = ctx.needs_input_grad[1] and sink is None
-        return v_x, (v_table if want_t else None), None, None, None, None
+        return v_x, (v_table if want_t else None), None, None, None, None, None
 
 
 class TCNNEncoding:
@@ -214,11 +223,14 @@ class TCNNEncoding:
     def get_out_dim(self):
         return self.cfg[0] * self.cfg[1]
 
-    def forward(self, x):
+    def forward(self, x, stencil=None):
+        """`stencil` = (n, merge_levels) (not in the reference's interface): x holds n base rows followed by the 6 blocks of
+        their central-difference points (LocalMap.query_points layout); lets the backward's binned scatter merge the rows of
+        a group that share a grid cell."""
         if x.dim() != 2 or x.shape[1] != 3:
             raise RuntimeError("TCNNEncoding.forward: expected [B,3]")
         return _GridFwd.apply(x, self.params_.view(-1, self.cfg[1]), self.cfg, self.grad_sink, self.scatter_stream,
-                              self.save_jacobian)
+                              self.save_jacobian, stencil)
 
     __call__ = forward
 
@@ -432,7 +444,7 @@ class _CouplingLeg(torch.autograd.Function):
                           ptr(ids, torch.int64), float(scale), float(delta or 0.0), float(w_eik), f32(loss), f32(v_attr),
                           capi.stream()), "gs_sdf_loss")
         ctx.save_for_backward(ids, x01, feat, jac, acts, v_attr)
-        ctx.lm, ctx.n_rows = lm, samples.shape[0]
+        ctx.lm, ctx.n_rows, ctx.delta = lm, samples.shape[0], float(delta or 0.0)
         return loss
 
     @staticmethod
@@ -474,8 +486,10 @@ class _CouplingLeg(torch.autograd.Function):
         table = enc.params_.view(-1, cfg[1])
         sink = enc.grad_sink.view(table.shape)
 
+        stencil = None if nq == n else (n, stencil_merge_levels(cfg, ctx.delta * lm.map_size_inv))
+
         def scatter():
-            scatter_table_grad(nq, cfg, x01, table, v_feat, sink)
+            scatter_table_grad(nq, cfg, x01, table, v_feat, sink, None, stencil)
         if enc.scatter_stream is None:
             scatter()
         else:
@@ -657,7 +671,8 @@ class LocalMap:
     def ray_loss(self, xyz, gt_sdf, delta, w_eik):
         """sdf_loss(get_sdf(xyz)) + w_eik * eikonal_loss(get_gradient(xyz, delta, numerical)) of the per-ray batch
         (neural_mapping.cpp:138-188) as ONE encoder launch, ONE decoder launch and ONE loss launch over the 7n points."""
-        attr = self.decoder(self.encoder.forward(self.query_points(xyz, delta)))
+        stencil = (xyz.shape[0], stencil_merge_levels(self.encoder.cfg, delta * self.map_size_inv))
+        attr = self.decoder(self.encoder.forward(self.query_points(xyz, delta), stencil))
         return _SdfRayLoss.apply(attr, gt_sdf, self.bce_isigma, delta, w_eik, xyz.shape[0])
 
     def get_sdf(self, xyz, with_isigma=True):

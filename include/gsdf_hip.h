@@ -200,6 +200,13 @@ size_t gsdf_hashgrid_bwd_binned_ws_bytes(int64_t B, int n_levels, int n_feat, in
 int gsdf_hashgrid_bwd_binned(int64_t B, int n_levels, int n_feat, int log2_hashmap, int base_res, float per_level_scale,
                              const float *x, const float *v_feat, float *v_table, void *ws, size_t ws_bytes,
                              gsdf_stream_t stream);
+/* The same for a batch with the stencil structure gsdf_sdf_query_points writes (rows [0, stencil_n) base points, then six blocks
+ * of stencil_n central-difference points; B == 7 * stencil_n): at the levels [0, merge_levels) the rows of a group that fall
+ * into the base point's grid cell touch the same 8 entries and are summed in registers before they become records (-23 % records
+ * at the reference configuration with delta = 0.02 m in a 16 m map).  Same result up to the fp32 sum of <= 7 products. */
+int gsdf_hashgrid_bwd_binned_stencil(int64_t B, int64_t stencil_n, int merge_levels, int n_levels, int n_feat, int log2_hashmap,
+                                     int base_res, float per_level_scale, const float *x, const float *v_feat, float *v_table,
+                                     void *ws, size_t ws_bytes, gsdf_stream_t stream);
 /* Double backward of v_x = J(x,table)^T v_feat: given vv_x [B,3] returns d/d v_feat (g_vfeat, overwritten),
  * d/d table (g_table, ACCUMULATES) and d/d x (g_x, overwritten); any may be NULL. */
 int gsdf_hashgrid_bwd_bwd(int64_t B, int n_levels, int n_feat, int log2_hashmap, int base_res,

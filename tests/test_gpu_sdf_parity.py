@@ -502,3 +502,42 @@ def test_encoder_backward_takes_binned_path_for_large_batches(sdf, oracle, monke
         enc.forward(x).backward(v)
         grads[mode] = enc.params_.grad.clone()
     assert_close(grads["1"], grads["0"], 1e-5, "autograd table gradient: binned vs atomic")
+
+
+@pytest.mark.parametrize("n,delta", [(12000, 0.02 / 16.0), (12000, 0.3), (5000, 1e-5)])
+def test_binned_scatter_with_stencil_merging_matches_oracle(sdf, oracle, n, delta):
+    """gsdf_hashgrid_bwd_binned_stencil: rows = n base points + their 6 central-difference points; at the coarse levels the rows
+    of a group that share the base point's cell are summed in registers before they become records.  delta = 0.00125 (the
+    joint iteration's: cells shared at levels 0-4), 0.3 (never shared), 1e-5 (shared at every level)."""
+    import gs_sdf_amd.capi as capi
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(13)
+    base = torch.rand(n, 3, generator=g) * 0.6 + 0.2
+    offs = torch.tensor([[0, 0, 0], [delta, 0, 0], [-delta, 0, 0], [0, delta, 0], [0, -delta, 0], [0, 0, delta], [0, 0, -delta]])
+    x = (base[None] + offs[:, None]).reshape(-1, 3).contiguous()
+    B = x.shape[0]
+    v = torch.randn(B, 32, generator=g)
+    c = (16, 2, 19, 32, 2.0)
+    offs_l, total = oracle.grid_offsets(CFG)
+    L = capi.lib()
+    nbytes = L.gsdf_hashgrid_bwd_binned_ws_bytes(B, *c)
+    xd, vd = x.to(dev), v.to(dev)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    ml = sdf.stencil_merge_levels(c, delta)
+    assert ml == {0.02 / 16.0: 5, 0.3: 0, 1e-5: 12}[delta]
+    got = torch.zeros(total, 2, device=dev)
+    capi.check(L.gsdf_hashgrid_bwd_binned_stencil(B, n, 16, *c, capi.f32(xd), capi.f32(vd), capi.f32(got), capi.ptr(ws), nbytes, capi.stream()), "stencil")
+    plain = torch.zeros(total, 2, device=dev)
+    capi.check(L.gsdf_hashgrid_bwd_binned(B, *c, capi.f32(xd), capi.f32(vd), capi.f32(plain), capi.ptr(ws), nbytes, capi.stream()), "plain")
+    torch.cuda.synchronize()
+    vt_o, _ = oracle.grid_bwd(n(x) if False else x.numpy(), np.zeros((total, 2), np.float32), v.numpy(), CFG, prec="f32")
+    # merged groups are summed in fp32 (<= 7 products of random sign) before the exact fixed-point accumulation: where they
+    # cancel, the element's error relative to ITSELF reaches a few 1e-5 (sparse table: the mean |ref| floor is tiny)
+    assert_close(got, vt_o, 5e-5, "stencil-merged binned scatter vs oracle")
+    assert_close(got, plain, 5e-5, "stencil-merged vs plain binned scatter")
+    again = torch.zeros(total, 2, device=dev)
+    capi.check(L.gsdf_hashgrid_bwd_binned_stencil(B, n, 16, *c, capi.f32(xd), capi.f32(vd), capi.f32(again), capi.ptr(ws), nbytes, capi.stream()), "stencil")
+    torch.cuda.synchronize()
+    assert torch.equal(got, again), "not bit-reproducible"
+    with pytest.raises(RuntimeError):
+        capi.check(L.gsdf_hashgrid_bwd_binned_stencil(B, n + 1, 5, *c, capi.f32(xd), capi.f32(vd), capi.f32(again), capi.ptr(ws), nbytes, capi.stream()), "bad")

@@ -40,5 +40,8 @@ for B in Bs:
 
     t_at = timeit(lambda: capi.check(L.gsdf_hashgrid_bwd(Bq, *cfg, capi.f32(x), capi.f32(table), capi.f32(v), capi.f32(out_a), None, capi.stream()), "a"))
     t_bin = timeit(lambda: capi.check(L.gsdf_hashgrid_bwd_binned(Bq, *cfg, capi.f32(x), capi.f32(v), capi.f32(out_b), capi.ptr(ws), nbytes, capi.stream()), "b"))
+    out_c = torch.zeros(total, 2, device=dev)
+    t_st = timeit(lambda: capi.check(L.gsdf_hashgrid_bwd_binned_stencil(Bq, n, 5, *cfg, capi.f32(x), capi.f32(v), capi.f32(out_c), capi.ptr(ws), nbytes, capi.stream()), "c"))
+    err_c = float((out_c - out_b).abs().max() / out_b.abs().mean())
     err = float((out_a - out_b).abs().max() / out_a.abs().mean())
-    print(f"B={Bq}: atomic {t_at:.3f} ms, binned {t_bin:.3f} ms (ws {nbytes / 2**30:.2f} GiB), max|diff|/mean|ref| {err:.2e}", flush=True)
+    print(f"B={Bq}: atomic {t_at:.3f} ms, binned {t_bin:.3f} ms, binned+stencil merge {t_st:.3f} ms (vs binned {err_c:.1e}) (ws {nbytes / 2**30:.2f} GiB), max|diff|/mean|ref| {err:.2e}", flush=True)
