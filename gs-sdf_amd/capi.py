@@ -37,6 +37,7 @@ _SIGS = {
     "gsdf_hashgrid_fwd": (C.c_int, [_i64, _i32, _i32, _i32, _i32, _f32] + [_vp] * 4),
     "gsdf_hashgrid_fwd_jac": (C.c_int, [_i64, _i32, _i32, _i32, _i32, _f32] + [_vp] * 5),
     "gsdf_hashgrid_fwd_jac_rows": (C.c_int, [_i64, _i64, _i32, _i32, _i32, _i32, _f32] + [_vp] * 5),
+    "gsdf_hashgrid_fwd_stencil": (C.c_int, [_i64, _i64, _i64, _i32, _i32, _i32, _i32, _f32] + [_vp] * 5),
     "gsdf_hashgrid_bwd_jac": (C.c_int, [_i64, _i32, _i32] + [_vp] * 4),
     "gsdf_hashgrid_bwd": (C.c_int, [_i64, _i32, _i32, _i32, _i32, _f32] + [_vp] * 6),
     "gsdf_hashgrid_bwd_binned_ws_bytes": (_sz, [_i64, _i32, _i32, _i32, _i32, _f32]),

@@ -158,6 +158,81 @@ static bool make_xcd_levels(int n_levels, int n_xcd, XcdLevels *xl, int *max_nl)
   return true;
 }
 
+// Stencil batches (n base rows followed by 6 blocks of n central-difference rows, LocalMap.query_points layout): the
+// 4 lanes of a (group, level) walk the group's 7 rows back to back instead of 7 workgroups far apart in time.
+//   * at the coarse levels the +-delta points fall in the base point's cell: its 4 gathered values are reused from
+//     registers (the loads of such a row are not issued at all);
+//   * at the fine levels the 7 cells are neighbours and share most of their 64-byte segments: the gathers of rows 1..6 hit
+//     the L1/L2 lines row 0 has just brought in, where the row-major kernel fetched them from the fabric 7 times.
+// The arithmetic of a row is the one of hashgrid_fwd_xcd_kernel (same operations in the same order): bit-identical features.
+template <bool JAC>
+__global__ void __launch_bounds__(HG_THREADS)
+    hashgrid_fwd_stencil_kernel(int64_t n, HgLevels lv, XcdLevels xl, int n_xcd, const float *__restrict__ x,
+                                const float *__restrict__ table, float *__restrict__ feat, float *__restrict__ jac) {
+  const int xcd = blockIdx.x % n_xcd;
+  const int64_t chunk = blockIdx.x / n_xcd;
+  const int l0 = xl.begin[xcd], nl = xl.count[xcd];
+  const int ppw = 16 / nl;  // groups per wave
+  const int lane = threadIdx.x & 63;
+  const int f = lane & 1, xb = (lane >> 1) & 1, slot = lane >> 2;
+  const int pw = slot / nl, level = l0 + slot - pw * nl;
+  const int64_t g = (chunk * 4 + (threadIdx.x >> 6)) * ppw + pw;
+  if (!(pw < ppw && g < n)) return;  // whole quads leave together: the quad DPP below stays among live lanes
+  const float scale = lv.scale[level];
+  const uint32_t res = lv.res[level], hsize = lv.hsize[level];
+  const float *tb = table + (int64_t)lv.offset[level] * 2 + f;
+  uint32_t cg[7][3];
+  float fr[7][3];
+#pragma unroll
+  for (int r = 0; r < 7; ++r) {
+    const int64_t b = g + (int64_t)r * n;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      const float pos = fmaf(scale, x[3 * b + d], 0.5f);
+      const float fl = floorf(pos);
+      cg[r][d] = (uint32_t)(int32_t)fl;
+      fr[r][d] = pos - fl;
+    }
+  }
+  float t[7][4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) t[0][k] = tb[2 * (int64_t)grid_index(hsize, res, cg[0][0] + xb, cg[0][1] + (k & 1), cg[0][2] + (k >> 1))];
+#pragma unroll
+  for (int r = 1; r < 7; ++r) {
+    const bool same = cg[r][0] == cg[0][0] && cg[r][1] == cg[0][1] && cg[r][2] == cg[0][2];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) t[r][k] = t[0][k];
+    if (!same) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) t[r][k] = tb[2 * (int64_t)grid_index(hsize, res, cg[r][0] + xb, cg[r][1] + (k & 1), cg[r][2] + (k >> 1))];
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 7; ++r) {
+    const float wx = xb ? fr[r][0] : 1.f - fr[r][0], sx = xb ? 1.f : -1.f;
+    float acc = 0.f, jx = 0.f, jy = 0.f, jz = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int hy = k & 1, hz = k >> 1;
+      const float wy = hy ? fr[r][1] : 1.f - fr[r][1], wz = hz ? fr[r][2] : 1.f - fr[r][2];
+      acc += wx * wy * wz * t[r][k];
+      if (JAC && r == 0) {
+        jx += sx * wy * wz * t[r][k];
+        jy += (hy ? 1.f : -1.f) * wx * wz * t[r][k];
+        jz += (hz ? 1.f : -1.f) * wx * wy * t[r][k];
+      }
+    }
+    acc += dpp_mov<0x4E>(acc);
+    const int64_t o = ((g + (int64_t)r * n) * lv.n_levels + level) * 2 + f;
+    if (xb == 0) feat[o] = acc;
+    if (JAC && r == 0) {
+      jx *= scale; jy *= scale; jz *= scale;
+      jx += dpp_mov<0x4E>(jx); jy += dpp_mov<0x4E>(jy); jz += dpp_mov<0x4E>(jz);
+      if (xb == 0) { jac[3 * o] = jx; jac[3 * o + 1] = jy; jac[3 * o + 2] = jz; }
+    }
+  }
+}
+
 template <bool JAC>
 static void launch_fwd(int64_t B, int64_t jac_rows, const HgLevels &lv, int n_levels, const float *x, const float *table,
                        float *feat, float *jac, hipStream_t stream) {
@@ -176,6 +251,22 @@ static void launch_fwd(int64_t B, int64_t jac_rows, const HgLevels &lv, int n_le
   } else {
     hashgrid_fwd_kernel<JAC><<<(unsigned)((B + 3) / 4), HG_THREADS, 0, stream>>>(B, jac_rows, lv, x, table, feat, jac);
   }
+}
+
+template <bool JAC>
+static void launch_fwd_stencil(int64_t n, const HgLevels &lv, int n_levels, const float *x, const float *table, float *feat,
+                               float *jac, hipStream_t stream) {
+  XcdLevels xl;
+  int max_nl = 0, n_xcd = xcd_count(stream);
+  static const bool off = [] { const char *e = getenv("GSDF_HASHGRID_XCD"); return e && e[0] == '0'; }();
+  if (off || n_xcd != 8 || 7 * n < 65536 || !make_xcd_levels(n_levels, n_xcd, &xl, &max_nl)) {
+    for (int k = 0; k < 8; ++k) { xl.begin[k] = 0; xl.count[k] = n_levels; }
+    n_xcd = 1;
+    max_nl = n_levels;
+  }
+  const int ppw_min = 16 / max_nl;
+  const int64_t chunks = (n + 4 * ppw_min - 1) / (4 * ppw_min);
+  hashgrid_fwd_stencil_kernel<JAC><<<(unsigned)(chunks * n_xcd), HG_THREADS, 0, stream>>>(n, lv, xl, n_xcd, x, table, feat, jac);
 }
 
 // ---- backward kernels: 4 lanes per (point, level) -------------------------------------------------------
@@ -321,6 +412,24 @@ extern "C" int gsdf_hashgrid_fwd_jac_rows(int64_t B, int64_t jac_rows, int n_lev
   if (jac_rows > 0) launch_fwd<true>(B, jac_rows, lv, n_levels, x, table, feat, jac, stream);
   else launch_fwd<false>(B, 0, lv, n_levels, x, table, feat, nullptr, stream);
   GSDF_CHECK_LAUNCH("hashgrid_fwd_kernel<jac>");
+  return GSDF_OK;
+}
+
+extern "C" int gsdf_hashgrid_fwd_stencil(int64_t B, int64_t stencil_n, int64_t jac_rows, int n_levels, int n_feat,
+                                         int log2_hashmap, int base_res, float per_level_scale, const float *x,
+                                         const float *table, float *feat, float *jac, gsdf_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  int rc = check_cfg(n_levels, n_feat, log2_hashmap, base_res, per_level_scale, "hashgrid_fwd_stencil");
+  if (rc) return rc;
+  GSDF_REQUIRE(stencil_n >= 0 && B == 7 * stencil_n, "hashgrid_fwd_stencil: a stencil batch has 7 * stencil_n rows");
+  GSDF_REQUIRE(jac_rows == 0 || jac_rows == stencil_n, "hashgrid_fwd_stencil: jac_rows must be 0 or stencil_n (the base rows)");
+  if (B == 0) return GSDF_OK;
+  GSDF_REQUIRE(x && table && feat && (jac || jac_rows == 0), "hashgrid_fwd_stencil: null buffer");
+  HgLevels lv;
+  build_levels(n_levels, log2_hashmap, base_res, per_level_scale, &lv, nullptr);
+  if (jac_rows > 0) launch_fwd_stencil<true>(stencil_n, lv, n_levels, x, table, feat, jac, stream);
+  else launch_fwd_stencil<false>(stencil_n, lv, n_levels, x, table, feat, nullptr, stream);
+  GSDF_CHECK_LAUNCH("hashgrid_fwd_stencil_kernel");
   return GSDF_OK;
 }
 

@@ -1,0 +1,57 @@
+// mlp_common.h — descriptors and the "register image" layouts shared by the decoder kernels (mlp.hip: fp32 MFMA,
+// mlp_split.hip: split-bf16 MFMA).
+#pragma once
+#include <stdlib.h>
+
+#include "common.h"
+
+namespace gsdf {
+
+typedef float v16f __attribute__((ext_vector_type(16)));
+
+static constexpr int MLP_THREADS = 256;
+static constexpr int HID = 64;
+static constexpr int MAX_LAYERS = 8;
+
+struct MlpDesc {
+  int n_layers;           // linear layers
+  int d_in;               // 32 or 64
+  int d_out;              // <= 32
+  int w_off[MAX_LAYERS];  // float offset of layer l in the torch-layout weight blob
+  int b_off[MAX_LAYERS];
+  int lds_off[MAX_LAYERS];  // float offset of layer l in the permuted LDS image
+  int has_bias;
+};
+
+// neuron held by (register r, half h) of a 32-row D tile
+__device__ __forceinline__ int d_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+// K permutation of a 64-wide hidden operand: k-step s in [0,32) -> neuron
+__device__ __forceinline__ int perm_hidden(int s, int h) { return 32 * (s >> 4) + d_row(s & 15, h); }
+
+// "Register image" layout of the tensors that only travel between these kernels (saved activations, v_pre):
+// [slot][tile of 32 points][half t][lane 0..63][r 0..15] holds neuron 32 t + d_row(r, lane >> 5) of point 32 tile + (lane & 31),
+// i.e. exactly the 16 accumulator registers of a lane.  A wave stores / loads its D tile as 64 lanes x 64 contiguous
+// bytes (4 KiB per instruction group) instead of 32 scattered 16-byte pieces per instruction, and the weight-gradient
+// GEMM reads operand rows as two 64-byte runs.  Rows are padded to whole tiles: gsdf_mlp_acts_floats().
+__device__ __forceinline__ int64_t img_off(int64_t slot, int64_t n_tiles, int64_t tile, int t, int lane) {
+  return ((((slot * n_tiles + tile) * 2 + t) * 64 + lane) * 16);
+}
+// ReLU masks (bit r of a uint16 = accumulator register r of that lane was > 0): stored behind the images in the same
+// buffer, [slot][tile][t][lane]; the data-gradient kernel reads 2 B per lane instead of the 64 B of activations.
+__device__ __forceinline__ int64_t mask_off(int64_t slot, int64_t n_tiles, int64_t tile, int t, int lane) {
+  return ((slot * n_tiles + tile) * 2 + t) * 64 + lane;
+}
+// the lane/register that holds neuron-in-tile j (0..31) of a point: lane half = (j >> 2) & 1, r = (j & 3) + 4 (j >> 3)
+__device__ __forceinline__ int img_half_of(int j) { return (j >> 2) & 1; }
+__device__ __forceinline__ int img_reg_of(int j) { return (j & 3) + 4 * (j >> 3); }
+
+__device__ __forceinline__ v16f mfma32(float a, float b, v16f c) {
+  return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+// mlp_split.hip: the same operators on the bf16 MFMA pipe (exact 3-term operand split, fp32 accuracy).
+// Return 1 if launched, 0 if the path does not cover the call (topology, LDS, GSDF_MLP_MFMA=f32), < 0 on error.
+int mlp_fwd_split_launch(int64_t B, const MlpDesc &d, const float *W, const float *bias, const float *in, float *out, float *acts,
+                         hipStream_t stream);
+
+}  // namespace gsdf

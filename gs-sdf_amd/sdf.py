@@ -63,6 +63,11 @@ def stencil_merge_levels(cfg, delta_unit):
     return sum(1 for l in range(n_levels) if (base_res * pls ** l - 1.0) * float(delta_unit) < 1.0)
 
 
+def _stencil_fwd(stencil, B):
+    """forward of a stencil batch (n base rows + 6 blocks of n central-difference rows) through the group-walking kernel"""
+    return stencil is not None and stencil[0] > 0 and stencil[0] * 7 == B and os.environ.get("GSDF_STENCIL_FWD", "1") != "0"
+
+
 def scatter_table_grad(B, cfg, x, table, v_feat, v_table, v_x=None, stencil=None):
     """v_table += (d feat / d table)^T v_feat [and v_x = (d feat / d x)^T v_feat].  Large batches take the binned scatter
     (include/gsdf_hip.h: gsdf_hashgrid_bwd_binned, no global atomics); GSDF_HASHGRID_BINNED=0/1 forces one path (tests).
@@ -160,6 +165,9 @@ class _GridFwd(torch.autograd.Function):
             jac = torch.empty(B, cfg[0] * cfg[1], 3, dtype=torch.float32, device=x.device)
             capi.check(_timed("hashgrid_fwd", L.gsdf_hashgrid_fwd_jac, B, *cfg, f32(x, "x"), f32(table, "params"), f32(feat),
                               f32(jac), capi.stream()), "hashgrid_fwd_jac")
+        elif _stencil_fwd(stencil, B):
+            capi.check(_timed("hashgrid_fwd", L.gsdf_hashgrid_fwd_stencil, B, stencil[0], 0, *cfg, f32(x, "x"), f32(table, "params"),
+                              f32(feat), None, capi.stream()), "hashgrid_fwd_stencil")
         else:
             capi.check(_timed("hashgrid_fwd", L.gsdf_hashgrid_fwd, B, *cfg, f32(x, "x"), f32(table, "params"), f32(feat),
                               capi.stream()), "hashgrid_fwd")
@@ -430,8 +438,12 @@ class _CouplingLeg(torch.autograd.Function):
         nf = cfg[0] * cfg[1]
         feat = torch.empty(K * n, nf, dtype=torch.float32, device=dev)
         jac = torch.empty(n, nf, 3, dtype=torch.float32, device=dev)
-        capi.check(_timed("hashgrid_fwd", L.gsdf_hashgrid_fwd_jac_rows, K * n, n, *cfg, f32(x01), f32(table), f32(feat), f32(jac),
-                          capi.stream()), "hashgrid_fwd_jac")
+        if _stencil_fwd((n, 0), K * n):
+            capi.check(_timed("hashgrid_fwd", L.gsdf_hashgrid_fwd_stencil, K * n, n, n, *cfg, f32(x01), f32(table), f32(feat), f32(jac),
+                              capi.stream()), "hashgrid_fwd_stencil")
+        else:
+            capi.check(_timed("hashgrid_fwd", L.gsdf_hashgrid_fwd_jac_rows, K * n, n, *cfg, f32(x01), f32(table), f32(feat), f32(jac),
+                              capi.stream()), "hashgrid_fwd_jac")
         nl = len(dims) - 1
         dims_c = (C.c_int * len(dims))(*dims)
         attr = torch.empty(K * n, dims[-1], dtype=torch.float32, device=dev)

@@ -180,6 +180,13 @@ int gsdf_hashgrid_fwd_jac(int64_t B, int n_levels, int n_feat, int log2_hashmap,
 int gsdf_hashgrid_fwd_jac_rows(int64_t B, int64_t jac_rows, int n_levels, int n_feat, int log2_hashmap, int base_res,
                                float per_level_scale, const float *x, const float *table, float *feat, float *jac,
                                gsdf_stream_t stream);
+/* The same for a stencil batch: x = stencil_n base rows followed by the 6 blocks of stencil_n central-difference rows
+ * (B = 7 * stencil_n; the layout LocalMap::get_gradient's numerical branch evaluates, include/neural_net/local_map.cpp:110-150,
+ * and neural_mapping.cpp:436-451).  Same features bit for bit; the 7 rows of a group are gathered together (register reuse
+ * where they share a grid cell, cache reuse where their cells are neighbours).  jac_rows = 0 or stencil_n. */
+int gsdf_hashgrid_fwd_stencil(int64_t B, int64_t stencil_n, int64_t jac_rows, int n_levels, int n_feat, int log2_hashmap,
+                              int base_res, float per_level_scale, const float *x, const float *table, float *feat,
+                              float *jac, gsdf_stream_t stream);
 int gsdf_hashgrid_bwd_jac(int64_t B, int n_levels, int n_feat, const float *jac, const float *v_feat, float *v_x,
                           gsdf_stream_t stream);
 /* v_table ACCUMULATES (zero it first), v_x is overwritten; either may be NULL. */

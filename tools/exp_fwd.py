@@ -18,4 +18,9 @@ def t(fn, reps=5):
 t_plain = t(lambda: capi.check(L.gsdf_hashgrid_fwd(Bq, *cfg, capi.f32(x), capi.f32(table), capi.f32(feat), capi.stream()), "f"))
 ref = feat.clone()
 t_jac = t(lambda: capi.check(L.gsdf_hashgrid_fwd_jac_rows(Bq, n, *cfg, capi.f32(x), capi.f32(table), capi.f32(feat), capi.f32(jac), capi.stream()), "f"))
+jref = jac.clone(); feat.zero_(); jac.zero_()
+t_st = t(lambda: capi.check(L.gsdf_hashgrid_fwd_stencil(Bq, n, n, *cfg, capi.f32(x), capi.f32(table), capi.f32(feat), capi.f32(jac), capi.stream()), "f"))
+print(f"stencil kernel: fwd+jac(n) {t_st:.3f} ms, feat equal {bool(torch.equal(ref, feat))}, jac equal {bool(torch.equal(jref, jac))}")
+t_st0 = t(lambda: capi.check(L.gsdf_hashgrid_fwd_stencil(Bq, n, 0, *cfg, capi.f32(x), capi.f32(table), capi.f32(feat), None, capi.stream()), "f"))
+print(f"stencil kernel, no jac: {t_st0:.3f} ms, feat equal {bool(torch.equal(ref, feat))}")
 print(f"B={Bq} phases={os.environ.get('GSDF_HASHGRID_PHASES','1')}: fwd {t_plain:.3f} ms, fwd+jac(n) {t_jac:.3f} ms, equal {bool(torch.equal(ref, feat))}", flush=True)

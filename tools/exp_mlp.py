@@ -4,7 +4,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import gs_sdf_amd.capi as capi
 dev = torch.device("cuda:0"); L = capi.lib()
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 2744000
-dims = [32, 64, 64, 64, 2]; nl = 4; dims_c = (C.c_int * 5)(*dims)
+dims = [32, 64, 64, 64, 64, 2] if os.environ.get("EXP_TORCH_TOPOLOGY", "1") == "1" else [32, 64, 64, 64, 2]
+nl = len(dims) - 1; dims_c = (C.c_int * len(dims))(*dims)
 g = torch.Generator().manual_seed(0)
 W = (torch.randn(sum(i * o for i, o in zip(dims[:-1], dims[1:])), generator=g) * 0.2).to(dev)
 x = torch.randn(B, 32, generator=g).to(dev); out = torch.empty(B, 2, device=dev)
@@ -19,5 +20,5 @@ f = t(lambda: capi.check(L.gsdf_mlp_fwd(B, nl, dims_c, capi.f32(W), None, capi.f
 fi = t(lambda: capi.check(L.gsdf_mlp_fwd(B, nl, dims_c, capi.f32(W), None, capi.f32(x), capi.f32(out), None, capi.stream()), "f"))
 bd = t(lambda: capi.check(L.gsdf_mlp_bwd(B, nl, dims_c, capi.f32(W), None, capi.f32(x), capi.f32(acts), capi.f32(v_out), capi.f32(v_in), None, None, capi.ptr(ws), capi.stream()), "b"))
 bw = t(lambda: capi.check(L.gsdf_mlp_bwd_weights(B, nl, dims_c, 0, capi.f32(x), capi.f32(acts), capi.f32(v_out), capi.ptr(ws), capi.f32(v_w), None, capi.stream()), "w"))
-fl = 2 * 10368 * B / 1e9
-print(f"B={B} MAX_WG={os.environ.get('GSDF_MLP_MAX_WG','768')}: fwd {f:.3f} ms ({fl/f:.0f} TF/s) fwd(no acts) {fi:.3f} bwd_data {bd:.3f} ({fl/bd:.0f}) bwd_weights {bw:.3f} ({fl/bw:.0f})", flush=True)
+fl = 2 * sum(i * o for i, o in zip(dims[:-1], dims[1:])) * B / 1e9
+print(f"B={B} dims={dims} MFMA={os.environ.get('GSDF_MLP_MFMA','bf16x3')}: fwd {f:.3f} ms ({fl/f:.0f} TF/s) fwd(no acts) {fi:.3f} bwd_data {bd:.3f} ({fl/bd:.0f}) bwd_weights {bw:.3f} ({fl/bw:.0f})", flush=True)
