@@ -269,7 +269,7 @@ def main():
     torch.cuda.synchronize()
     # HIP-event timing of the roofline kernels over the timed region (the full per-operator table comes from a short
     # separate pass below: two events per launch on all ~25 operators cost ~2 % of the step in host time)
-    ROOF = {"hashgrid_bwd", "hashgrid_fwd", "rasterize_2dgs_fwd", "rasterize_2dgs_bwd", "mlp_fwd", "mlp_bwd_data", "mlp_bwd_weights"}
+    ROOF = {"hashgrid_bwd", "hashgrid_fwd", "rasterize_2dgs_fwd", "rasterize_2dgs_bwd", "mlp_fwd", "mlp_bwd", "mlp_bwd_data", "mlp_bwd_weights"}
 
     def timed(n_steps, first):
         hist.clear()
@@ -339,13 +339,17 @@ def main():
             per_launch = lambda k: sdf_pts / max(1.0, calls.get(k, 0) / args.steps)
             alg["hashgrid_bwd"] = 1160 * per_launch("hashgrid_bwd")
             alg["hashgrid_fwd"] = 1164 * per_launch("hashgrid_fwd")
-            for k in ("mlp_fwd", "mlp_bwd_data", "mlp_bwd_weights"):
-                flops[k] = 2 * 10368 * per_launch(k)
+            # mlp_bwd = the one-pass backward (input + weight gradients: twice the forward's multiply-adds)
+            for k, passes in (("mlp_fwd", 1), ("mlp_bwd", 2), ("mlp_bwd_data", 1), ("mlp_bwd_weights", 1)):
+                if calls.get(k):
+                    flops[k] = passes * 2 * 10368 * per_launch(k)
         # time per step of an operator = MEAN launch x launches per step (the two launches of an SDF operator differ 10x in size:
         # 7 x 32768 ray points against ~3 M splat-sample points; `alg` is the per-launch mean to match); medians are reported too
         per_step = {k: kern_mean.get(k, 0.0) * calls.get(k, 0) / args.steps for k in list(alg) + list(flops)}
         dom = max(per_step, key=lambda k: per_step[k])
         dur_ms = kern_mean.get(dom, float("nan"))
+
+        split_mlp = os.environ.get("GSDF_MLP_MFMA", "bf16x3")[:1] not in "fF"
 
         def roof(k):
             if k in alg:
@@ -353,6 +357,12 @@ def main():
                 return {"bound": "hbm", "achieved": a, "peak": 8000.0, "unit": "GB/s", "frac": a / 8000.0,
                         "algorithmic_bytes": int(alg[k])}
             a = flops[k] / (kern_mean[k] * 1e-3) / 1e12
+            if split_mlp and k in ("mlp_fwd", "mlp_bwd"):
+                # csrc/mlp_split.hip: fp32 operands as three exact bf16 terms, six partial products per multiply-add on
+                # v_mfma_f32_32x32x16_bf16 -> the pipe executes 6x the algorithmic flops; priced against its dense bf16 peak
+                return {"bound": "mfma", "achieved": 6 * a, "peak": 2500.0, "unit": "TFLOP/s", "frac": 6 * a / 2500.0,
+                        "pipe": "bf16 MFMA, fp32-accurate 3-term operand split (6 products per multiply-add)",
+                        "algorithmic_flops": int(flops[k]), "fp32_equivalent_tflops": a, "fp32_mfma_peak": 157.3}
             return {"bound": "mfma", "achieved": a, "peak": 157.3, "unit": "TFLOP/s", "frac": a / 157.3,
                     "algorithmic_flops": int(flops[k])}
         b_splat = (80 + 12 * Kb) * N + (364 + 12 * Kb) * M + 204 * I + 96 * P + 4 * T

@@ -101,7 +101,7 @@ __global__ void __launch_bounds__(MLP_THREADS)
           unsigned m = 0;
 #pragma unroll
           for (int q = 0; q < 4; ++q)
-            a[q] = make_float4(cur[t][4 * q], cur[t][4 * q + 1], cur[t][4 * q + 2], cur[t][4 * q + 3]);
+            a[q * (IMG_Q / 4)] = make_float4(cur[t][4 * q], cur[t][4 * q + 1], cur[t][4 * q + 2], cur[t][4 * q + 3]);
 #pragma unroll
           for (int r = 0; r < 16; ++r) m |= (cur[t][r] > 0.f ? 1u : 0u) << r;
           masks[mask_off(l - 1, n_tiles, tile, t, lane)] = (uint16_t)m;
@@ -225,7 +225,7 @@ __global__ void __launch_bounds__(MLP_THREADS)
           o4.z = (hm[t] >> (4 * q + 2)) & 1u ? ng[t][4 * q + 2] : 0.f;
           o4.w = (hm[t] >> (4 * q + 3)) & 1u ? ng[t][4 * q + 3] : 0.f;
           ng[t][4 * q] = o4.x; ng[t][4 * q + 1] = o4.y; ng[t][4 * q + 2] = o4.z; ng[t][4 * q + 3] = o4.w;
-          vp[q] = o4;
+          vp[q * (IMG_Q / 4)] = o4;
         }
       }
       g[0] = ng[0]; g[1] = ng[1];
@@ -288,13 +288,15 @@ __global__ void __launch_bounds__(MLP_THREADS)
   const int64_t p0 = (int64_t)blockIdx.x * WG_KCHUNK;
   const int64_t p1 = min(B, p0 + WG_KCHUNK);
   // Operand addresses of a 16-point group pb..pb+15 (pb is a multiple of 16): base(pb) + s * stride, s = 0..7, so that the
-  // 8 loads of a group are one base computation + immediate offsets.  Image: the group lies in one tile,
-  // element = tile base + ((pb & 31) + 2 s + hh) * 16 (+ 512 for the neuron's second lane, + register n & 15).
-  const float *a0 = a_img ? v_pre_ws + img_off(l, n_tiles, 0, mt, 32 * (n >> 4) + hh) + (n & 15) : v_out + (int64_t)hh * d.d_out + o;
-  const float *b0 = b_img ? acts + img_off(l - 1, n_tiles, 0, nt, 32 * (n >> 4) + hh) + (n & 15) : in + (int64_t)hh * d.d_in + i;
-  const int a_stride = a_img ? 32 : 2 * d.d_out, b_stride = b_img ? 32 : 2 * d.d_in;
+  // 8 loads of a group are one base computation + immediate offsets.  Image: the group lies in one tile, neuron n of a point
+  // is register n & 15 of the point's lane in half n >> 4: element = tile base + IMG_Q ((n & 15) >> 2) + 4 lane + (n & 3)
+  // with lane = (pb & 31) + 2 s + hh + 32 (n >> 4).
+  const int img_lane0 = IMG_Q * ((n & 15) >> 2) + 4 * (32 * (n >> 4) + hh) + (n & 3);
+  const float *a0 = a_img ? v_pre_ws + img_off(l, n_tiles, 0, mt, 0) + img_lane0 : v_out + (int64_t)hh * d.d_out + o;
+  const float *b0 = b_img ? acts + img_off(l - 1, n_tiles, 0, nt, 0) + img_lane0 : in + (int64_t)hh * d.d_in + i;
+  const int a_stride = a_img ? 8 : 2 * d.d_out, b_stride = b_img ? 8 : 2 * d.d_in;
   auto load16 = [&](int64_t pb, float (&ra)[8], float (&rb)[8]) {
-    const int64_t img_base = (pb >> 5) * 2048 + (pb & 31) * 16;
+    const int64_t img_base = (pb >> 5) * 2048 + (pb & 31) * 4;
     const float *ap = a0 + (a_img ? img_base : pb * d.d_out);
     const float *bp = b0 + (b_img ? img_base : pb * d.d_in);
     const int64_t left = p1 - pb - hh;   // point pb + 2 s + hh is valid while 2 s < left
@@ -407,8 +409,13 @@ extern "C" int gsdf_mlp_bwd(int64_t B, int n_layers, const int *dims_host, const
   int rc = make_desc(n_layers, dims_host, biases != nullptr, true, &d, &lds_floats, "mlp_bwd");
   if (rc) return rc;
   if (B == 0) return GSDF_OK;
-  GSDF_REQUIRE(weights && in && v_out && ws, "mlp_bwd: null buffer");
+  GSDF_REQUIRE(weights && in && v_out, "mlp_bwd: null buffer");
   GSDF_REQUIRE(acts, "mlp_bwd: the saved activations of mlp_fwd are required");
+  if (v_weights != nullptr) {   // both gradients wanted: one pass on the bf16 pipe, v_pre never leaves the registers
+    rc = mlp_bwd_split_launch(B, d, weights, in, acts, v_out, v_in, v_weights, biases != nullptr ? v_biases : nullptr, stream);
+    if (rc != 0) return rc < 0 ? rc : GSDF_OK;
+  }
+  GSDF_REQUIRE(ws, "mlp_bwd: null workspace");
   const size_t lds = lds_floats * sizeof(float);
   GSDF_REQUIRE(lds <= 160 * 1024, "mlp_bwd: %zu bytes of weights do not fit the 160 KiB LDS", lds);
   float *v_pre = (float *)ws;

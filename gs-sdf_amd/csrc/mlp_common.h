@@ -29,12 +29,13 @@ __device__ __forceinline__ int d_row(int r, int h) { return (r & 3) + 8 * (r >> 
 __device__ __forceinline__ int perm_hidden(int s, int h) { return 32 * (s >> 4) + d_row(s & 15, h); }
 
 // "Register image" layout of the tensors that only travel between these kernels (saved activations, v_pre):
-// [slot][tile of 32 points][half t][lane 0..63][r 0..15] holds neuron 32 t + d_row(r, lane >> 5) of point 32 tile + (lane & 31),
-// i.e. exactly the 16 accumulator registers of a lane.  A wave stores / loads its D tile as 64 lanes x 64 contiguous
-// bytes (4 KiB per instruction group) instead of 32 scattered 16-byte pieces per instruction, and the weight-gradient
-// GEMM reads operand rows as two 64-byte runs.  Rows are padded to whole tiles: gsdf_mlp_acts_floats().
+// [slot][tile of 32 points][half t][q 0..3][lane 0..63][4 floats]: float4 q of a lane = its accumulator registers 4q..4q+3,
+// i.e. neurons 32 t + d_row(4 q + j, lane >> 5) of point 32 tile + (lane & 31).  A wave stores / loads a D tile with four
+// instructions of 64 lanes x 16 contiguous bytes (whole 1 KiB runs, every HBM line written by a single instruction).
+// Rows are padded to whole tiles: gsdf_mlp_acts_floats().  img_off() = address of float4 0 of `lane`; float4 q at + IMG_Q * q.
+static constexpr int IMG_Q = 256;   // floats between consecutive float4s of a lane
 __device__ __forceinline__ int64_t img_off(int64_t slot, int64_t n_tiles, int64_t tile, int t, int lane) {
-  return ((((slot * n_tiles + tile) * 2 + t) * 64 + lane) * 16);
+  return (((slot * n_tiles + tile) * 2 + t) * 1024 + lane * 4);
 }
 // ReLU masks (bit r of a uint16 = accumulator register r of that lane was > 0): stored behind the images in the same
 // buffer, [slot][tile][t][lane]; the data-gradient kernel reads 2 B per lane instead of the 64 B of activations.
@@ -53,5 +54,8 @@ __device__ __forceinline__ v16f mfma32(float a, float b, v16f c) {
 // Return 1 if launched, 0 if the path does not cover the call (topology, LDS, GSDF_MLP_MFMA=f32), < 0 on error.
 int mlp_fwd_split_launch(int64_t B, const MlpDesc &d, const float *W, const float *bias, const float *in, float *out, float *acts,
                          hipStream_t stream);
+// data and weight gradients in one pass (v_W required; v_in, v_b optional); v_W / v_b ACCUMULATE
+int mlp_bwd_split_launch(int64_t B, const MlpDesc &d, const float *W, const float *in, const float *acts, const float *v_out,
+                         float *v_in, float *v_W, float *v_b, hipStream_t stream);
 
 }  // namespace gsdf

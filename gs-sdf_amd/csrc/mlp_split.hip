@@ -76,6 +76,9 @@ __device__ __forceinline__ void mfma6(const Split8 &a, const Split8 &b, v16f &c)
 // k order of a hidden (64-wide) operand: element e of half h in k-step s  ->  neuron
 __device__ __forceinline__ int split_k_hidden(int s, int h, int e) { return 32 * (s >> 1) + d_row(8 * (s & 1) + e, h); }
 
+static bool split_enabled();
+static unsigned split_grid(int64_t B, int waves);
+
 struct SplitLds {
   int off4[MAX_LAYERS];   // uint4 offset of layer l's operand image
 };
@@ -163,7 +166,7 @@ __global__ void __launch_bounds__(SPLIT_FWD_THREADS)
           float4 *a = reinterpret_cast<float4 *>(acts + img_off(l - 1, n_tiles, tile, t, lane));
           unsigned m = 0;
 #pragma unroll
-          for (int q = 0; q < 4; ++q) a[q] = make_float4(cur[t][4 * q], cur[t][4 * q + 1], cur[t][4 * q + 2], cur[t][4 * q + 3]);
+          for (int q = 0; q < 4; ++q) a[q * (IMG_Q / 4)] = make_float4(cur[t][4 * q], cur[t][4 * q + 1], cur[t][4 * q + 2], cur[t][4 * q + 3]);
 #pragma unroll
           for (int r = 0; r < 16; ++r) m |= (cur[t][r] > 0.f ? 1u : 0u) << r;
           masks[mask_off(l - 1, n_tiles, tile, t, lane)] = (uint16_t)m;
@@ -205,6 +208,406 @@ __global__ void __launch_bounds__(SPLIT_FWD_THREADS)
       }
     }
   }
+}
+
+// ----------------------------------------------------------------------------------------------
+// backward: data path and weight path in ONE pass over the points.
+//
+// mlp.hip's backward is two kernels with the per-layer gradients v_pre (256 B per point and layer) written to HBM by the first
+// and read back, next to the saved activations, by the second: 7 GB per 3.3 M points, which is what bounds it (5 TB/s).  Here
+// a wave keeps v_pre in registers: per layer it (1) splits g = v_pre_l once, (2) accumulates dW_l += v_pre_l^T a_{l-1} over
+// its 32 points and (3) chains g <- relu'(a_{l-1}) (W_l^T g).  The weight-gradient tiles of EVERY layer (14.7 k values = 16
+// 32x32 tiles, + 2 for the biases) live in the accumulator registers of each wave for the whole kernel — 288 of the 512
+// registers a lane owns at one wave per SIMD — and leave through one round of atomics per wave at the very end.
+//
+// (2) contracts over points, which D's layout has on LANES while an MFMA operand wants them on ELEMENTS: both operands go
+// through a wave-private LDS block, written as bf16 terms with ds_write_b16 (row = neuron, 32 points + padding per row) and
+// read back as the 16-byte operands of lane = neuron (conflict-free with 80-byte rows).  The bias gradient is the same A
+// operand against a one-hot B column (column l of a shared tile collects layer l's sums).
+// ----------------------------------------------------------------------------------------------
+static constexpr int SPLIT_BWD_THREADS = 256;
+static constexpr int TR_ROW = 40;              // bf16 per row of a transposition block: 32 points + 8 of padding
+static constexpr int TR_BLOCK = 32 * TR_ROW;   // one term of a block (32 neurons), in bf16 units
+static constexpr int TR_WAVE_BYTES = 3 * TR_BLOCK * 2;
+
+// LDS image of layer l: [i_tile][k_step over o][term][64 lanes] x uint4 = the A operand of lane (row i = 32 i_tile + (lane & 31), half)
+__device__ void stage_split_bwd(const MlpDesc &d, const SplitLds &sl, const float *__restrict__ W, uint4 *lds_w, bool want_in) {
+  for (int l = want_in ? 0 : 1; l < d.n_layers; ++l) {
+    const int I = l == 0 ? d.d_in : HID;
+    const int O = l == d.n_layers - 1 ? d.d_out : HID;
+    const int itiles = I / 32;
+    const int ksteps = l == d.n_layers - 1 ? 2 : 4;   // o padded to 32 on the last layer
+    const float *Wl = W + d.w_off[l];
+    uint4 *dst = lds_w + sl.off4[l];
+    for (int u = threadIdx.x; u < itiles * ksteps * 64; u += blockDim.x) {
+      const int lane = u & 63, s = (u >> 6) % ksteps, t = (u >> 6) / ksteps;
+      const int i = 32 * t + (lane & 31), h = lane >> 5;
+      float w[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int o = split_k_hidden(s, h, e);
+        w[e] = o < O ? Wl[o * I + i] : 0.f;
+      }
+      const Split8 sp = split8(w);
+#pragma unroll
+      for (int j = 0; j < 3; ++j) dst[((t * ksteps + s) * 3 + j) * 64 + lane] = sp.s[j];
+    }
+  }
+}
+
+// the three terms of registers 8 g .. 8 g + 7 of a tile
+__device__ __forceinline__ void split8regs(const v16f &x, int g, uint32_t (&t)[3][8]) {
+#pragma unroll
+  for (int e = 0; e < 8; ++e) split3(x[8 * g + e], t[0][e], t[1][e], t[2][e]);
+}
+__device__ __forceinline__ Split8 pack8(const uint32_t (&t)[3][8]) {
+  Split8 o;
+#pragma unroll
+  for (int j = 0; j < 3; ++j)
+    o.s[j] = make_uint4(pack_top(t[j][0], t[j][1]), pack_top(t[j][2], t[j][3]), pack_top(t[j][4], t[j][5]), pack_top(t[j][6], t[j][7]));
+  return o;
+}
+// transposition block: lane (point, half) writes the rows of its registers 8 g .. 8 g + 7; NATURAL: row = 16 half + r (a slice
+// of the network input rows), else row = d_row(r, half) (an accumulator tile)
+template <bool NATURAL>
+__device__ __forceinline__ void tr_write8(uint16_t *tb, const uint32_t (&t)[3][8], int g, int lane) {
+  const int pt = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int r = 8 * g + e, row = NATURAL ? 16 * h + r : d_row(r, h);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) tb[j * TR_BLOCK + row * TR_ROW + pt] = (uint16_t)(t[j][e] >> 16);
+  }
+}
+// operand of lane (row = lane & 31, half) for k-step ks = points 16 ks + 8 half .. + 7
+__device__ __forceinline__ Split8 tr_read(const uint16_t *tb, int ks, int lane) {
+  Split8 a;
+#pragma unroll
+  for (int j = 0; j < 3; ++j)
+    a.s[j] = *reinterpret_cast<const uint4 *>(tb + j * TR_BLOCK + (lane & 31) * TR_ROW + 16 * ks + 8 * (lane >> 5));
+  return a;
+}
+// compiler-level fences: LDS executes a wave's accesses in order, the compiler only has to keep the program order of the
+// 2-byte stores and the 16-byte loads of the block (different types), and must not pile the phases' operands up in registers
+#define TR_FENCE() __asm__ volatile("" ::: "memory")
+#define PHASE_FENCE() do { if (NL >= 5) __builtin_amdgcn_sched_barrier(0); } while (0)
+
+template <int NL>
+struct BwdAcc {
+  v16f w0[2];                           // layer 0 (input width 32): [o tile]
+  v16f wh[NL > 2 ? NL - 2 : 1][2][2];   // layers 1 .. NL-2: [o tile][i tile]
+  v16f wl[2];                           // last layer (outputs padded to 32): [i tile]
+  v16f b[2];                            // bias sums: [o tile], column l = layer l
+};
+
+struct BwdCtx {
+  int64_t B, n_tiles;
+  const float *in, *acts, *v_out;
+  float *v_in;
+  const uint4 *lds_w;
+  uint16_t *tb;
+  int lane, d_out;
+};
+
+// Everything a tile's backward loads from HBM is read through branch-free code (clamped addresses + selects) so that a
+// whole tile is ONE basic block the scheduler can interleave.
+// input of layer L for a tile: the network input rows (lane (p, half) holds features 16 half + r) or the activation image L-1
+template <int L>
+__device__ __forceinline__ void load_layer_input(const BwdCtx &c, int64_t tile, v16f (&x)[2]) {
+  const int64_t tc = tile < c.n_tiles ? tile : c.n_tiles - 1;   // past the end: any valid tile, the values are never used
+  if (L == 0) {
+    const int64_t p = tc * 32 + (c.lane & 31);
+    const bool live = p < c.B;
+    const float4 *src = reinterpret_cast<const float4 *>(c.in + (live ? p : c.B - 1) * 32 + 16 * (c.lane >> 5));
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 v = src[q];
+      x[0][4 * q] = live ? v.x : 0.f; x[0][4 * q + 1] = live ? v.y : 0.f; x[0][4 * q + 2] = live ? v.z : 0.f; x[0][4 * q + 3] = live ? v.w : 0.f;
+    }
+  } else {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const float4 *a = reinterpret_cast<const float4 *>(c.acts + img_off(L - 1, c.n_tiles, tc, t, c.lane));
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 v = a[q * (IMG_Q / 4)];
+        x[t][4 * q] = v.x; x[t][4 * q + 1] = v.y; x[t][4 * q + 2] = v.z; x[t][4 * q + 3] = v.w;
+      }
+    }
+  }
+}
+
+__device__ __forceinline__ void load_v_out(const BwdCtx &c, int64_t tile, v16f &g) {
+  const int64_t p = tile * 32 + (c.lane & 31);
+  const bool live = tile < c.n_tiles && p < c.B;
+  const float *row = c.v_out + (live ? p : 0) * c.d_out;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int o = d_row(r, c.lane >> 5);
+    const bool ok = live && o < c.d_out;
+    const float v = row[ok ? o : 0];
+    g[r] = ok ? v : 0.f;
+  }
+}
+
+// terms of the MT tiles of g: packed chain operands gb (lane = point) and, through the LDS block, the dW operands at (lane =
+// output neuron)
+template <int MT>
+__device__ __forceinline__ void prep_g(const BwdCtx &c, const v16f (&g)[2], Split8 (&gb)[4], Split8 (&at)[2][2]) {
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+    for (int hg = 0; hg < 2; ++hg) {
+      uint32_t t[3][8];
+      split8regs(g[mt], hg, t);
+      gb[2 * mt + hg] = pack8(t);
+      tr_write8<false>(c.tb, t, hg, c.lane);
+    }
+    TR_FENCE();
+    at[mt][0] = tr_read(c.tb, 0, c.lane);
+    at[mt][1] = tr_read(c.tb, 1, c.lane);
+    TR_FENCE();
+  }
+}
+
+// the scheduler is told to issue `n_mfma` MFMAs with `valu` vector-ALU, `dsw` LDS-write and `dsr` LDS-read instructions
+// behind each: an MFMA occupies the matrix pipe for 32 cycles during which the wave can issue ~8 other instructions
+template <int N_MFMA, int VALU, int DSW, int DSR>
+__device__ __forceinline__ void interleave() {
+#pragma unroll
+  for (int i = 0; i < N_MFMA; ++i) {
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    if (DSR) __builtin_amdgcn_sched_group_barrier(0x100, DSR, 0);
+    if (VALU) __builtin_amdgcn_sched_group_barrier(0x002, VALU, 0);
+    if (DSW) __builtin_amdgcn_sched_group_barrier(0x200, DSW, 0);
+  }
+}
+
+// One layer of the backward of one tile, software-pipelined in two slots whose matrix work hides the vector work of the other
+// dependency chain:
+//   slot 1:  chain MFMAs  g' = W_L^T g   (operands gb)        ||  terms of the layer input x = a_{L-1} -> LDS block -> bt
+//   slot 2:  dW_L += v_pre_L^T a_{L-1} (+ bias column)         ||  g' <- relu'(a_{L-1}) g', its terms -> gb', at' (next layer)
+// In:  gb/at = terms of v_pre_L, x = a_{L-1} (loaded one layer ahead).  Out: gb/at of layer L-1, x = a_{L-2} (or, from layer 0,
+// the terms of the next tile's v_out and its first input).
+template <int NL, bool BIAS, int L>
+__device__ __forceinline__ void bwd_layer(const BwdCtx &c, const SplitLds &sl, BwdAcc<NL> &acc, int64_t tile, int64_t next_tile,
+                                          Split8 (&gb)[4], Split8 (&at)[2][2], v16f (&x)[2]) {
+  constexpr bool last = L == NL - 1, first = L == 0;
+  constexpr int MT = last ? 1 : 2;   // 32-row tiles of outputs o
+  constexpr int NT = first ? 1 : 2;  // 32-row tiles of inputs i
+  constexpr int KS = last ? 1 : 4;   // k-steps of the chain (over o; the last layer's outputs fit the first k-step)
+  constexpr int LH = first || last ? 0 : L - 1;
+  const int lane = c.lane;
+  // prefetch: the input of layer L-1, or the first input and v_out of the next tile
+  v16f xn[2], gn[2];
+  if (first) { load_layer_input<NL - 1>(c, next_tile, xn); load_v_out(c, next_tile, gn[0]); }
+  else load_layer_input<first ? 0 : L - 1>(c, tile, xn);
+
+  // ---- slot 1
+  const uint4 *w = c.lds_w + sl.off4[L];
+  v16f ng[2];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { ng[0][r] = 0.f; ng[1][r] = 0.f; }
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+    if (NT == 2) mfma6x2(lds_operand(w, s, lane), lds_operand(w, (last ? 2 : 4) + s, lane), gb[s], ng[0], ng[1]);
+    else mfma6(lds_operand(w, s, lane), gb[s], ng[0]);
+  }
+  Split8 bt[NT][2];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+    for (int hg = 0; hg < 2; ++hg) {
+      uint32_t t[3][8];
+      split8regs(x[nt], hg, t);
+      tr_write8<first>(c.tb, t, hg, lane);
+    }
+    TR_FENCE();
+    bt[nt][0] = tr_read(c.tb, 0, lane);
+    bt[nt][1] = tr_read(c.tb, 1, lane);
+    TR_FENCE();
+  }
+  // KS * NT * 6 MFMAs against NT * (64 VALU, 48 LDS writes, 6 LDS reads) + the chain's KS * NT * 3 operand reads
+  interleave<KS * NT * 6, (NT * 64 + KS * NT * 6 - 1) / (KS * NT * 6), (NT * 48 + KS * NT * 6 - 1) / (KS * NT * 6), 1>();
+  __builtin_amdgcn_sched_barrier(0);
+
+  // ---- slot 2
+  if (BIAS) {
+    const uint32_t one = (lane & 31) == L ? 0x3f803f80u : 0u;
+    const uint4 oh = make_uint4(one, one, one, one);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int j = 2; j >= 0; --j)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc.b[mt] = mfma_bf16(at[mt][ks].s[j], oh, acc.b[mt]);
+  }
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    if (last) {
+      mfma6(at[0][0], bt[nt][0], acc.wl[nt]);
+      mfma6(at[0][1], bt[nt][1], acc.wl[nt]);
+    } else if (first) {
+      mfma6x2(at[0][0], at[MT - 1][0], bt[nt][0], acc.w0[0], acc.w0[1]);
+      mfma6x2(at[0][1], at[MT - 1][1], bt[nt][1], acc.w0[0], acc.w0[1]);
+    } else {
+      mfma6x2(at[0][0], at[MT - 1][0], bt[nt][0], acc.wh[LH][0][nt], acc.wh[LH][1][nt]);
+      mfma6x2(at[0][1], at[MT - 1][1], bt[nt][1], acc.wh[LH][0][nt], acc.wh[LH][1][nt]);
+    }
+  }
+  Split8 gbn[4], atn[2][2];
+  if (!first) {
+    v16f g[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) g[t][r] = x[t][r] > 0.f ? ng[t][r] : 0.f;
+    prep_g<2>(c, g, gbn, atn);
+  } else {
+    const int64_t p = tile * 32 + (lane & 31);
+    if (c.v_in != nullptr && p < c.B) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        *reinterpret_cast<float4 *>(c.v_in + p * 32 + 8 * q + 4 * (lane >> 5)) = make_float4(ng[0][4 * q], ng[0][4 * q + 1], ng[0][4 * q + 2], ng[0][4 * q + 3]);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) gn[1][r] = 0.f;
+    prep_g<1>(c, gn, gbn, atn);   // the next tile's v_out
+  }
+  constexpr int M2 = MT * NT * 12 + (BIAS ? MT * 6 : 0);
+  constexpr int V2 = first ? 16 * 7 : 32 * 9, W2 = first ? 48 : 96;
+  interleave<M2, (V2 + M2 - 1) / M2, (W2 + M2 - 1) / M2, 1>();
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int s = 0; s < 4; ++s) gb[s] = gbn[s];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) { at[mt][0] = atn[mt][0]; at[mt][1] = atn[mt][1]; }
+  x[0] = xn[0]; x[1] = xn[1];
+}
+
+template <int NL, bool BIAS, int L>
+struct BwdLayers {
+  static __device__ __forceinline__ void run(const BwdCtx &c, const SplitLds &sl, BwdAcc<NL> &acc, int64_t tile, int64_t next_tile,
+                                             Split8 (&gb)[4], Split8 (&at)[2][2], v16f (&x)[2]) {
+    bwd_layer<NL, BIAS, L>(c, sl, acc, tile, next_tile, gb, at, x);
+    BwdLayers<NL, BIAS, L - 1>::run(c, sl, acc, tile, next_tile, gb, at, x);
+  }
+};
+template <int NL, bool BIAS>
+struct BwdLayers<NL, BIAS, -1> {
+  static __device__ __forceinline__ void run(const BwdCtx &, const SplitLds &, BwdAcc<NL> &, int64_t, int64_t, Split8 (&)[4], Split8 (&)[2][2], v16f (&)[2]) {}
+};
+
+// one round of atomics for a 32x32 tile: rows o = o0 + d_row(r, half) < O, column i = i0 + (lane & 31)
+__device__ __forceinline__ void flush_tile(const v16f &a, float *vw, int I, int O, int o0, int i0, int lane) {
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int o = o0 + d_row(r, lane >> 5);
+    if (o < O && a[r] != 0.f) atomicAdd(vw + o * I + i0 + (lane & 31), a[r]);
+  }
+}
+
+template <int NL, bool BIAS>
+__global__ void __launch_bounds__(SPLIT_BWD_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1)))
+    mlp_bwd_split_kernel(int64_t B, MlpDesc d, SplitLds sl, int lds_w4, const float *__restrict__ W, const float *__restrict__ in,
+                         const float *__restrict__ acts, const float *__restrict__ v_out, float *__restrict__ v_in,
+                         float *__restrict__ v_W, float *__restrict__ v_b) {
+  extern __shared__ __attribute__((aligned(16))) uint4 smem4[];
+  stage_split_bwd(d, sl, W, smem4, true);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  BwdCtx c;
+  c.B = B; c.n_tiles = (B + 31) / 32;
+  c.in = in; c.acts = acts; c.v_out = v_out; c.v_in = v_in;
+  c.lds_w = smem4;
+  c.tb = reinterpret_cast<uint16_t *>(smem4 + lds_w4) + wave * (TR_WAVE_BYTES / 2);
+  c.lane = lane; c.d_out = d.d_out;
+  BwdAcc<NL> acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      acc.w0[a][r] = 0.f; acc.wl[a][r] = 0.f; acc.b[a][r] = 0.f;
+#pragma unroll
+      for (int l = 0; l < (NL > 2 ? NL - 2 : 1); ++l) { acc.wh[l][a][0][r] = 0.f; acc.wh[l][a][1][r] = 0.f; }
+    }
+  }
+  constexpr int WAVES = SPLIT_BWD_THREADS / 64;
+  const int64_t stride = (int64_t)gridDim.x * WAVES;
+  int64_t tile = (int64_t)blockIdx.x * WAVES + wave;
+  v16f g[2], x[2];
+  Split8 gb[4], at[2][2];
+  load_layer_input<NL - 1>(c, tile, x);
+  load_v_out(c, tile, g[0]);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { g[1][r] = 0.f; x[1][r] = NL == 1 ? 0.f : x[1][r]; }
+  prep_g<1>(c, g, gb, at);
+#pragma unroll
+  for (int s = 2; s < 4; ++s) gb[s] = gb[0];
+  at[1][0] = at[0][0]; at[1][1] = at[0][1];
+  for (; tile < c.n_tiles; tile += stride) BwdLayers<NL, BIAS, NL - 1>::run(c, sl, acc, tile, tile + stride, gb, at, x);
+  // ---- one round of atomics per wave
+  flush_tile(acc.w0[0], v_W + d.w_off[0], 32, HID, 0, 0, lane);
+  flush_tile(acc.w0[1], v_W + d.w_off[0], 32, HID, 32, 0, lane);
+#pragma unroll
+  for (int l = 1; l < NL - 1; ++l)
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) flush_tile(acc.wh[l - 1][mt][nt], v_W + d.w_off[l], HID, HID, 32 * mt, 32 * nt, lane);
+  flush_tile(acc.wl[0], v_W + d.w_off[NL - 1], HID, d.d_out, 0, 0, lane);
+  flush_tile(acc.wl[1], v_W + d.w_off[NL - 1], HID, d.d_out, 0, 32, lane);
+  if (BIAS) {
+#pragma unroll
+    for (int l = 0; l < NL; ++l) {
+      if ((lane & 31) != l) continue;
+      const int O = l == NL - 1 ? d.d_out : HID;
+#pragma unroll
+      for (int mt = 0; mt < (l == NL - 1 ? 1 : 2); ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int o = 32 * mt + d_row(r, lane >> 5);
+          if (o < O) atomicAdd(v_b + d.b_off[l] + o, acc.b[mt][r]);
+        }
+    }
+  }
+}
+
+static bool n_tiles_zero(int64_t B) { return B <= 0; }
+
+static size_t split_bwd_lds(const MlpDesc &d, SplitLds *sl, int *lds_w4) {
+  int off = 0;
+  for (int l = 0; l < d.n_layers; ++l) {
+    sl->off4[l] = off;
+    const int I = l == 0 ? d.d_in : HID;
+    off += (I / 32) * (l == d.n_layers - 1 ? 2 : 4) * 3 * 64;
+  }
+  *lds_w4 = off;
+  return (size_t)off * 16 + (size_t)(SPLIT_BWD_THREADS / 64) * TR_WAVE_BYTES;
+}
+
+template <int NL, bool BIAS>
+static int launch_bwd_split(int64_t B, const MlpDesc &d, const SplitLds &sl, int lds_w4, size_t lds, const float *W, const float *in,
+                            const float *acts, const float *v_out, float *v_in, float *v_W, float *v_b, hipStream_t stream) {
+  GSDF_HIP(hipFuncSetAttribute((const void *)mlp_bwd_split_kernel<NL, BIAS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "mlp_bwd_split attr");
+  mlp_bwd_split_kernel<NL, BIAS><<<split_grid(B, SPLIT_BWD_THREADS / 64), SPLIT_BWD_THREADS, lds, stream>>>(B, d, sl, lds_w4, W, in, acts, v_out, v_in, v_W, v_b);
+  GSDF_CHECK_LAUNCH("mlp_bwd_split_kernel");
+  return 1;
+}
+
+int mlp_bwd_split_launch(int64_t B, const MlpDesc &d, const float *W, const float *in, const float *acts, const float *v_out,
+                         float *v_in, float *v_W, float *v_b, hipStream_t stream) {
+  if (!split_enabled() || d.d_in != 32 || d.d_out > 16 || v_W == nullptr || n_tiles_zero(B)) return 0;
+  SplitLds sl;
+  int lds_w4;
+  const size_t lds = split_bwd_lds(d, &sl, &lds_w4);
+  if (lds > 160 * 1024) return 0;
+  const bool bias = d.has_bias && v_b != nullptr;
+  if (d.n_layers == 5) return bias ? launch_bwd_split<5, true>(B, d, sl, lds_w4, lds, W, in, acts, v_out, v_in, v_W, v_b, stream)
+                                   : launch_bwd_split<5, false>(B, d, sl, lds_w4, lds, W, in, acts, v_out, v_in, v_W, v_b, stream);
+  if (d.n_layers == 4) return bias ? launch_bwd_split<4, true>(B, d, sl, lds_w4, lds, W, in, acts, v_out, v_in, v_W, v_b, stream)
+                                   : launch_bwd_split<4, false>(B, d, sl, lds_w4, lds, W, in, acts, v_out, v_in, v_W, v_b, stream);
+  return 0;
 }
 
 // LDS bytes of the forward image; 0 if the topology is not covered

@@ -243,6 +243,12 @@ class TCNNEncoding:
     __call__ = forward
 
 
+def _mlp_fused_bwd(dims):
+    """does gsdf_mlp_bwd with both gradients take the one-pass kernel (csrc/mlp_split.hip) for this topology?"""
+    return (dims[0] == 32 and len(dims) - 1 in (4, 5) and os.environ.get("GSDF_MLP_MFMA", "bf16x3")[:1] not in "fF"
+            and os.environ.get("GSDF_MLP_FUSED_BWD", "1") != "0")
+
+
 class _MlpFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weights, biases, dims, sinks=None, aux_stream=None):
@@ -269,6 +275,13 @@ class _MlpFn(torch.autograd.Function):
         dims_c = (C.c_int * len(dims))(*dims)
         v_out = v_out.contiguous()
         v_in = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        if ctx.sinks is not None and ctx.needs_input_grad[1] and _sinks_live() and _mlp_fused_bwd(dims):
+            # trainer fast path, fused: input and parameter gradients in one pass (v_pre stays in registers), the parameter
+            # gradients accumulate straight into the flat gradient buffer
+            w_sink, b_sink = ctx.sinks
+            capi.check(_timed("mlp_bwd", L.gsdf_mlp_bwd, B, nl, dims_c, f32(weights), f32(biases), f32(x), f32(acts),
+                              f32(v_out), f32(v_in), f32(w_sink), f32(b_sink), None, capi.stream()), "mlp_bwd")
+            return v_in, None, None, None, None, None
         ws = torch.empty(L.gsdf_mlp_bwd_ws_bytes(B, nl), dtype=torch.uint8, device=x.device)
         if ctx.sinks is not None and ctx.needs_input_grad[1] and _sinks_live():
             # trainer fast path: the parameter gradients ACCUMULATE straight into the flat gradient buffer (no zero-fill,
@@ -474,23 +487,27 @@ class _CouplingLeg(torch.autograd.Function):
         dims_c = (C.c_int * len(dims))(*dims)
         v_out = v_attr * v_loss
         v_feat = torch.empty_like(feat)
-        ws = torch.empty(L.gsdf_mlp_bwd_ws_bytes(nq, nl), dtype=torch.uint8, device=x01.device)
-        capi.check(_timed("mlp_bwd_data", L.gsdf_mlp_bwd, nq, nl, dims_c, f32(dec.params_), f32(dec.biases_), f32(feat), f32(acts),
-                          f32(v_out), f32(v_feat), None, None, ptr(ws), capi.stream()), "mlp_bwd")
         w_sink, b_sink = dec.grad_sinks
         cur = torch.cuda.current_stream()
-
-        def weights_half():
-            capi.check(_timed("mlp_bwd_weights", L.gsdf_mlp_bwd_weights, nq, nl, dims_c, int(dec.biases_ is not None), f32(feat),
-                              f32(acts), f32(v_out), ptr(ws), f32(w_sink), f32(b_sink), capi.stream()), "mlp_bwd_weights")
-        if dec.aux_stream is None:
-            weights_half()
+        if _mlp_fused_bwd(dims):
+            capi.check(_timed("mlp_bwd", L.gsdf_mlp_bwd, nq, nl, dims_c, f32(dec.params_), f32(dec.biases_), f32(feat), f32(acts),
+                              f32(v_out), f32(v_feat), f32(w_sink), f32(b_sink), None, capi.stream()), "mlp_bwd")
         else:
-            dec.aux_stream.wait_stream(cur)
-            with torch.cuda.stream(dec.aux_stream):
+            ws = torch.empty(L.gsdf_mlp_bwd_ws_bytes(nq, nl), dtype=torch.uint8, device=x01.device)
+            capi.check(_timed("mlp_bwd_data", L.gsdf_mlp_bwd, nq, nl, dims_c, f32(dec.params_), f32(dec.biases_), f32(feat), f32(acts),
+                              f32(v_out), f32(v_feat), None, None, ptr(ws), capi.stream()), "mlp_bwd")
+
+            def weights_half():
+                capi.check(_timed("mlp_bwd_weights", L.gsdf_mlp_bwd_weights, nq, nl, dims_c, int(dec.biases_ is not None), f32(feat),
+                                  f32(acts), f32(v_out), ptr(ws), f32(w_sink), f32(b_sink), capi.stream()), "mlp_bwd_weights")
+            if dec.aux_stream is None:
                 weights_half()
-            for t in (feat, acts, v_out, ws):
-                t.record_stream(dec.aux_stream)
+            else:
+                dec.aux_stream.wait_stream(cur)
+                with torch.cuda.stream(dec.aux_stream):
+                    weights_half()
+                for t in (feat, acts, v_out, ws):
+                    t.record_stream(dec.aux_stream)
         # d/dx of the base rows only: the stencil rows are evaluated at gs_samples.detach() (neural_mapping.cpp:449)
         v_x = torch.empty(n, 3, dtype=torch.float32, device=x01.device)
         capi.check(_timed("hashgrid_bwd_input", L.gsdf_hashgrid_bwd_jac, n, cfg[0], cfg[1], f32(jac), f32(v_feat), f32(v_x),

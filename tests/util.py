@@ -2,19 +2,6 @@ import numpy as np
 import torch
 
 
-def assert_close_rows(got, ref, rel=1e-4, name="", max_bad_rows=2):
-    """assert_close for per-point gradients of a ReLU network: the operator is discontinuous where a pre-activation crosses
-    zero, and two evaluations that round differently (fp32 MFMA, split-bf16 MFMA, fp64) may disagree on the sign of a
-    pre-activation of ~1e-8: that point's whole gradient row then differs.  At most `max_bad_rows` rows may do so."""
-    got = got.detach().cpu().double().numpy() if isinstance(got, torch.Tensor) else np.asarray(got, np.float64)
-    ref = ref.detach().cpu().double().numpy() if isinstance(ref, torch.Tensor) else np.asarray(ref, np.float64)
-    assert got.shape == ref.shape and got.ndim == 2, (name, got.shape, ref.shape)
-    floor = np.abs(ref).mean() + 1e-30
-    err = np.abs(got - ref) / np.maximum(np.abs(ref), floor)
-    bad_rows = np.flatnonzero((err > rel).any(axis=1))
-    assert len(bad_rows) <= max_bad_rows, f"{name}: {len(bad_rows)} rows above {rel:.1e} (allowed {max_bad_rows}); worst {err.max():.3e}"
-
-
 def assert_close(got, ref, rel=1e-4, name="", outlier_frac=0.0, outlier_rel=2e-2):
     """fp32 parity bar of BASELINE.json's north_star: "within 1e-4 rel".  Elementwise
     |got-ref| <= rel * max(|ref|, floor) with floor = mean|ref| of the tensor, so that elements that are
