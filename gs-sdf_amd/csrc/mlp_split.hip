@@ -17,6 +17,8 @@
 // 16 registers = neurons d_row(r, half)) is the next layer's B operand after a permutation of the K order: k-step s of
 // a 64-wide hidden operand is the 8 registers 8 (s & 1) .. + 7 of accumulator tile s >> 1 from both half-waves; the weights
 // are split once per workgroup into the same order in LDS (one conflict-free ds_read_b128 per A operand).
+#include <utility>
+
 #include "mlp_common.h"
 
 namespace gsdf {
@@ -226,9 +228,8 @@ __global__ void __launch_bounds__(SPLIT_FWD_THREADS)
 // operand against a one-hot B column (column l of a shared tile collects layer l's sums).
 // ----------------------------------------------------------------------------------------------
 static constexpr int SPLIT_BWD_THREADS = 256;
-static constexpr int TR_ROW = 40;              // bf16 per row of a transposition block: 32 points + 8 of padding
-static constexpr int TR_BLOCK = 32 * TR_ROW;   // one term of a block (32 neurons), in bf16 units
-static constexpr int TR_WAVE_BYTES = 3 * TR_BLOCK * 2;
+static constexpr int TR_BLOCK = 256;           // 8-byte chunks per term of a transposition block: 32 points x 8 neuron quads
+static constexpr int TR_WAVE_BYTES = 3 * TR_BLOCK * 8;
 
 // LDS image of layer l: [i_tile][k_step over o][term][64 lanes] x uint4 = the A operand of lane (row i = 32 i_tile + (lane & 31), half)
 __device__ void stage_split_bwd(const MlpDesc &d, const SplitLds &sl, const float *__restrict__ W, uint4 *lds_w, bool want_in) {
@@ -267,30 +268,41 @@ __device__ __forceinline__ Split8 pack8(const uint32_t (&t)[3][8]) {
     o.s[j] = make_uint4(pack_top(t[j][0], t[j][1]), pack_top(t[j][2], t[j][3]), pack_top(t[j][4], t[j][5]), pack_top(t[j][6], t[j][7]));
   return o;
 }
-// transposition block: lane (point, half) writes the rows of its registers 8 g .. 8 g + 7; NATURAL: row = 16 half + r (a slice
-// of the network input rows), else row = d_row(r, half) (an accumulator tile)
+// Transposition block (one per wave): per term 256 chunks of 8 bytes, chunk (point p, quad kq) = the bf16 terms of neurons
+// 4 kq .. 4 kq + 3 of point p.  A lane (point, half) owns whole chunks (its registers 4k .. 4k+3 are 4 consecutive neurons),
+// so it WRITES packed pairs with ds_write_b64; the consumer lane (neuron, half) READS with the gfx950 transpose read
+// ds_read_b64_tr_b16: the 16 lanes of a group each name one chunk (4 points x 4 quads) and lane c receives, for each of the
+// 4 points, the c-th of the group's 16 neurons -> 4 consecutive points of ITS neuron; two reads make one MFMA operand term.
+// Chunk placement 8 p + ((kq + (p >> 1)) & 7) keeps both sides conflict-free: the 16 consecutive points of a write group
+// fall on 16 different bank pairs, the 4 points x 8 quads of a 32-lane read group on all 32.
+__device__ __forceinline__ int tr_chunk(int p, int kq) { return 8 * p + ((kq + (p >> 1)) & 7); }
+
+// lane (point, half) writes the packed terms of its registers 8 g .. 8 g + 7 (two chunks per term).  NATURAL: the registers
+// are network-input features 16 half + r (quad 4 half + r / 4), else neurons d_row(r, half) (quad 2 (r / 4) + half)
 template <bool NATURAL>
-__device__ __forceinline__ void tr_write8(uint16_t *tb, const uint32_t (&t)[3][8], int g, int lane) {
+__device__ __forceinline__ void tr_write8(uint2 *tb, const Split8 &pk, int g, int lane) {
   const int pt = lane & 31, h = lane >> 5;
+  const int kq0 = NATURAL ? 4 * h + 2 * g : 4 * g + h, kq1 = NATURAL ? kq0 + 1 : kq0 + 2;
 #pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    const int r = 8 * g + e, row = NATURAL ? 16 * h + r : d_row(r, h);
-#pragma unroll
-    for (int j = 0; j < 3; ++j) tb[j * TR_BLOCK + row * TR_ROW + pt] = (uint16_t)(t[j][e] >> 16);
+  for (int j = 0; j < 3; ++j) {
+    tb[j * TR_BLOCK + tr_chunk(pt, kq0)] = make_uint2(pk.s[j].x, pk.s[j].y);
+    tb[j * TR_BLOCK + tr_chunk(pt, kq1)] = make_uint2(pk.s[j].z, pk.s[j].w);
   }
 }
-// operand of lane (row = lane & 31, half) for k-step ks = points 16 ks + 8 half .. + 7
-__device__ __forceinline__ Split8 tr_read(const uint16_t *tb, int ks, int lane) {
+// operand of lane (neuron = lane & 31, half) for k-step ks = points 16 ks + 8 half .. + 7
+typedef short short4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ Split8 tr_read(const uint2 *tb, int ks, int lane) {
+  const int p0 = 16 * ks + 8 * (lane >> 5) + ((lane & 15) >> 2), kq = 4 * ((lane >> 4) & 1) + (lane & 3);
   Split8 a;
 #pragma unroll
-  for (int j = 0; j < 3; ++j)
-    a.s[j] = *reinterpret_cast<const uint4 *>(tb + j * TR_BLOCK + (lane & 31) * TR_ROW + 16 * ks + 8 * (lane >> 5));
+  for (int j = 0; j < 3; ++j) {
+    typedef __attribute__((address_space(3))) short4v *lds_p;
+    const uint2 lo = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(tb + j * TR_BLOCK + tr_chunk(p0, kq))));
+    const uint2 hi = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(tb + j * TR_BLOCK + tr_chunk(p0 + 4, kq))));
+    a.s[j] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+  }
   return a;
 }
-// compiler-level fences: LDS executes a wave's accesses in order, the compiler only has to keep the program order of the
-// 2-byte stores and the 16-byte loads of the block (different types), and must not pile the phases' operands up in registers
-#define TR_FENCE() __asm__ volatile("" ::: "memory")
-#define PHASE_FENCE() do { if (NL >= 5) __builtin_amdgcn_sched_barrier(0); } while (0)
 
 template <int NL>
 struct BwdAcc {
@@ -305,7 +317,7 @@ struct BwdCtx {
   const float *in, *acts, *v_out;
   float *v_in;
   const uint4 *lds_w;
-  uint16_t *tb;
+  uint2 *tb;
   int lane, d_out;
 };
 
@@ -361,34 +373,23 @@ __device__ __forceinline__ void prep_g(const BwdCtx &c, const v16f (&g)[2], Spli
       uint32_t t[3][8];
       split8regs(g[mt], hg, t);
       gb[2 * mt + hg] = pack8(t);
-      tr_write8<false>(c.tb, t, hg, c.lane);
+      tr_write8<false>(c.tb, gb[2 * mt + hg], hg, c.lane);
     }
-    TR_FENCE();
     at[mt][0] = tr_read(c.tb, 0, c.lane);
     at[mt][1] = tr_read(c.tb, 1, c.lane);
-    TR_FENCE();
   }
 }
 
-// the scheduler is told to issue `n_mfma` MFMAs with `valu` vector-ALU, `dsw` LDS-write and `dsr` LDS-read instructions
-// behind each: an MFMA occupies the matrix pipe for 32 cycles during which the wave can issue ~8 other instructions
-template <int N_MFMA, int VALU, int DSW, int DSR>
-__device__ __forceinline__ void interleave() {
-#pragma unroll
-  for (int i = 0; i < N_MFMA; ++i) {
-    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-    if (DSR) __builtin_amdgcn_sched_group_barrier(0x100, DSR, 0);
-    if (VALU) __builtin_amdgcn_sched_group_barrier(0x002, VALU, 0);
-    if (DSW) __builtin_amdgcn_sched_group_barrier(0x200, DSW, 0);
-  }
-}
-
-// One layer of the backward of one tile, software-pipelined in two slots whose matrix work hides the vector work of the other
-// dependency chain:
-//   slot 1:  chain MFMAs  g' = W_L^T g   (operands gb)        ||  terms of the layer input x = a_{L-1} -> LDS block -> bt
-//   slot 2:  dW_L += v_pre_L^T a_{L-1} (+ bias column)         ||  g' <- relu'(a_{L-1}) g', its terms -> gb', at' (next layer)
+// One layer of the backward of one tile, in two phases ordered so that the loads of the next step are in flight early:
+//   phase 1:  chain MFMAs  g' = W_L^T g   (operands gb),  terms of the layer input x = a_{L-1} -> LDS block -> bt
+//   phase 2:  dW_L += v_pre_L^T a_{L-1} (+ bias column),   g' <- relu'(a_{L-1}) g', its terms -> gb', at' (next layer)
 // In:  gb/at = terms of v_pre_L, x = a_{L-1} (loaded one layer ahead).  Out: gb/at of layer L-1, x = a_{L-2} (or, from layer 0,
 // the terms of the next tile's v_out and its first input).
+// Measured and NOT adopted (tools/ubench/mfma_shadow.hip): zipping the vector work of one phase into the MFMA gaps
+// of the other by hand.  At one wave per SIMD only plain VALU instructions hide behind an MFMA (~5 per MFMA, and only when
+// the next MFMA on the same accumulator is >= 4 MFMAs away); LDS instructions (8-16 cycles of issue each) and
+// v_accvgpr_read (4-6) do not, and this kernel's vector work is a third LDS / accumulator traffic: the zipped stream ran
+// 1.16 ms against 1.17 ms (4 layers) and 1.96 against 1.64 ms (5 layers + biases, more live registers -> spills).
 template <int NL, bool BIAS, int L>
 __device__ __forceinline__ void bwd_layer(const BwdCtx &c, const SplitLds &sl, BwdAcc<NL> &acc, int64_t tile, int64_t next_tile,
                                           Split8 (&gb)[4], Split8 (&at)[2][2], v16f (&x)[2]) {
@@ -399,11 +400,15 @@ __device__ __forceinline__ void bwd_layer(const BwdCtx &c, const SplitLds &sl, B
   constexpr int LH = first || last ? 0 : L - 1;
   const int lane = c.lane;
   // prefetch: the input of layer L-1, or the first input and v_out of the next tile
+  // (with 5 layers' accumulators the prefetch is issued between the phases instead: 32 fewer live registers in phase 1)
   v16f xn[2], gn[2];
-  if (first) { load_layer_input<NL - 1>(c, next_tile, xn); load_v_out(c, next_tile, gn[0]); }
-  else load_layer_input<first ? 0 : L - 1>(c, tile, xn);
+  constexpr bool early = NL <= 4;
+  if (early) {
+    if (first) { load_layer_input<NL - 1>(c, next_tile, xn); load_v_out(c, next_tile, gn[0]); }
+    else load_layer_input<first ? 0 : L - 1>(c, tile, xn);
+  }
 
-  // ---- slot 1
+  // ---- phase 1
   const uint4 *w = c.lds_w + sl.off4[L];
   v16f ng[2];
 #pragma unroll
@@ -420,18 +425,25 @@ __device__ __forceinline__ void bwd_layer(const BwdCtx &c, const SplitLds &sl, B
     for (int hg = 0; hg < 2; ++hg) {
       uint32_t t[3][8];
       split8regs(x[nt], hg, t);
-      tr_write8<first>(c.tb, t, hg, lane);
+      tr_write8<first>(c.tb, pack8(t), hg, lane);
     }
-    TR_FENCE();
     bt[nt][0] = tr_read(c.tb, 0, lane);
     bt[nt][1] = tr_read(c.tb, 1, lane);
-    TR_FENCE();
   }
-  // KS * NT * 6 MFMAs against NT * (64 VALU, 48 LDS writes, 6 LDS reads) + the chain's KS * NT * 3 operand reads
-  interleave<KS * NT * 6, (NT * 64 + KS * NT * 6 - 1) / (KS * NT * 6), (NT * 48 + KS * NT * 6 - 1) / (KS * NT * 6), 1>();
+  v16f g[2];   // g' = relu'(a_{L-1}) (W_L^T g): x and the chain's accumulators end here
+  if (!first) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) g[t][r] = x[t][r] > 0.f ? ng[t][r] : 0.f;
+  }
   __builtin_amdgcn_sched_barrier(0);
+  if (!early) {
+    if (first) { load_layer_input<NL - 1>(c, next_tile, xn); load_v_out(c, next_tile, gn[0]); }
+    else load_layer_input<first ? 0 : L - 1>(c, tile, xn);
+  }
 
-  // ---- slot 2
+  // ---- phase 2
   if (BIAS) {
     const uint32_t one = (lane & 31) == L ? 0x3f803f80u : 0u;
     const uint4 oh = make_uint4(one, one, one, one);
@@ -457,11 +469,6 @@ __device__ __forceinline__ void bwd_layer(const BwdCtx &c, const SplitLds &sl, B
   }
   Split8 gbn[4], atn[2][2];
   if (!first) {
-    v16f g[2];
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) g[t][r] = x[t][r] > 0.f ? ng[t][r] : 0.f;
     prep_g<2>(c, g, gbn, atn);
   } else {
     const int64_t p = tile * 32 + (lane & 31);
@@ -474,9 +481,6 @@ __device__ __forceinline__ void bwd_layer(const BwdCtx &c, const SplitLds &sl, B
     for (int r = 0; r < 16; ++r) gn[1][r] = 0.f;
     prep_g<1>(c, gn, gbn, atn);   // the next tile's v_out
   }
-  constexpr int M2 = MT * NT * 12 + (BIAS ? MT * 6 : 0);
-  constexpr int V2 = first ? 16 * 7 : 32 * 9, W2 = first ? 48 : 96;
-  interleave<M2, (V2 + M2 - 1) / M2, (W2 + M2 - 1) / M2, 1>();
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int s = 0; s < 4; ++s) gb[s] = gbn[s];
@@ -520,7 +524,9 @@ __global__ void __launch_bounds__(SPLIT_BWD_THREADS) __attribute__((amdgpu_waves
   c.B = B; c.n_tiles = (B + 31) / 32;
   c.in = in; c.acts = acts; c.v_out = v_out; c.v_in = v_in;
   c.lds_w = smem4;
-  c.tb = reinterpret_cast<uint16_t *>(smem4 + lds_w4) + wave * (TR_WAVE_BYTES / 2);
+  // the transposition blocks are an object of their own: the compiler then knows that they never alias the weight image
+  __shared__ __attribute__((aligned(16))) uint2 tr_blocks[SPLIT_BWD_THREADS / 64][TR_WAVE_BYTES / 8];
+  c.tb = tr_blocks[wave];
   c.lane = lane; c.d_out = d.d_out;
   BwdAcc<NL> acc;
 #pragma unroll
@@ -583,7 +589,7 @@ static size_t split_bwd_lds(const MlpDesc &d, SplitLds *sl, int *lds_w4) {
     off += (I / 32) * (l == d.n_layers - 1 ? 2 : 4) * 3 * 64;
   }
   *lds_w4 = off;
-  return (size_t)off * 16 + (size_t)(SPLIT_BWD_THREADS / 64) * TR_WAVE_BYTES;
+  return (size_t)off * 16;   // dynamic part; the transposition blocks are static
 }
 
 template <int NL, bool BIAS>
@@ -601,7 +607,7 @@ int mlp_bwd_split_launch(int64_t B, const MlpDesc &d, const float *W, const floa
   SplitLds sl;
   int lds_w4;
   const size_t lds = split_bwd_lds(d, &sl, &lds_w4);
-  if (lds > 160 * 1024) return 0;
+  if (lds + (size_t)(SPLIT_BWD_THREADS / 64) * TR_WAVE_BYTES > 160 * 1024) return 0;
   const bool bias = d.has_bias && v_b != nullptr;
   if (d.n_layers == 5) return bias ? launch_bwd_split<5, true>(B, d, sl, lds_w4, lds, W, in, acts, v_out, v_in, v_W, v_b, stream)
                                    : launch_bwd_split<5, false>(B, d, sl, lds_w4, lds, W, in, acts, v_out, v_in, v_W, v_b, stream);
