@@ -400,7 +400,9 @@ def test_single_node_coupling_leg_equals_composed_operators(sdf, eik):
     assert_close(out[1][1], out[0][1], 1e-5, "d/d samples")
     # eikonal: differences of nearly equal SDF values times 1/(2 delta) -> the two evaluation orders (and the fp32 atomics of
     # the table scatter, whose summation order is not fixed) differ by up to a few 1e-4 of the mean gradient magnitude
-    assert_close(out[1][2], out[0][2], 1e-3 if eik else 1e-5, "flat parameter gradients")
+    # (without it: the decoder's weight gradients leave the one-pass backward through fp32 atomics, one round per wave, in
+    # an order that differs from launch to launch -> a few 1e-5 of the mean gradient magnitude)
+    assert_close(out[1][2], out[0][2], 1e-3 if eik else 1e-4, "flat parameter gradients")
     with pytest.raises(RuntimeError):
         sdf.LocalMap([0, 0, 0], 2.0, decoder_implementation=1, device=dev).gs_sdf_coupling(pts, ids, w_all)
     with pytest.raises(RuntimeError):          # the node writes gradients in place: only inside grad_sinks_armed()
@@ -432,7 +434,7 @@ def test_gradient_sinks_fire_only_when_armed(sdf):
     with sdf.grad_sinks_armed():
         s.sum().backward()
     assert float(plain.abs().sum()) > 0
-    assert_close(grp.flat_grad, plain, 1e-5, "armed sinks vs autograd accumulation")
+    assert_close(grp.flat_grad, plain, 1e-4, "armed sinks vs autograd accumulation")   # fp32 atomics of the weight gradients: launch-to-launch order
 
 
 @pytest.mark.parametrize("jac", [False, True])
