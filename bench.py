@@ -399,8 +399,12 @@ def main():
                              # compositing kernels: the VALU-issue side (they are bound by instruction issue, not by HBM): wave64
                              # VALU instructions per launch (profiles/valu_insts.json: rocprofv3 --pmc SQ_INSTS_VALU, single stream)
                              # over the launch time measured here, against 1024 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction
+                             # (nominal), and against the 759 G/s independent v_fma_f32 chains reach on this chip
+                             # (tools/ubench/pk_fma.hip; v_pk_fma_f32 gives only 1.07-1.14x more element-FMAs: no packed lever)
                              valu=(None if not valu else {k: {"insts_per_launch": v, "issue_peak_G_per_s": 614.4,
-                                                              "frac_of_issue_peak": v / (kern_mean[k] * 1e-3) / 614.4e9}
+                                                              "frac_of_issue_peak": v / (kern_mean[k] * 1e-3) / 614.4e9,
+                                                              "measured_fma_issue_G_per_s": 759.0,
+                                                              "frac_of_measured_fma_issue": v / (kern_mean[k] * 1e-3) / 759.0e9}
                                                           for k, v in valu.items() if kern_mean.get(k)}),
                              step_B_splat_bytes=int(b_splat), step_hbm_frac=b_splat / (elapsed / args.steps) / 8e12),
             "params_finite": bool(torch.isfinite(params.flat).all()) and all(bool(torch.isfinite(g.flat).all()) for g in groups),

@@ -595,3 +595,72 @@ def test_stencil_forward_is_bit_identical_to_the_row_major_kernels(sdf, n, delta
         capi.check(L.gsdf_hashgrid_fwd_stencil(B, n + 1, 0, *c, capi.f32(x), capi.f32(table), capi.f32(got), None, capi.stream()), "bad")
     with pytest.raises(RuntimeError):
         capi.check(L.gsdf_hashgrid_fwd_stencil(B, n, 3, *c, capi.f32(x), capi.f32(table), capi.f32(got), capi.f32(jgot), capi.stream()), "bad")
+
+
+def test_sdf_leg_at_the_joint_iteration_size(sdf, oracle):
+    """The joint iteration pushes 7 x (visible splat samples) ~ 3 M rows through encoder and decoder in one launch each
+    (neural_mapping.cpp:436-457): the persistent kernels then walk ~100 tiles per wave, the one-pass decoder backward keeps
+    its weight-gradient tiles in registers over all of them, the scatter takes the binned path with stencil merging.
+    Checked at 7 x 300 000 rows: (a) features, decoder outputs and per-row input gradients of 20 000 sampled rows against the
+    oracle (rows are independent); (b) parameter gradients by linearity — the launch over all rows against the sum of four
+    launches over its quarters (different tiles per wave, different flush grouping, different fixed-point scales)."""
+    import ctypes as C
+    import gs_sdf_amd.capi as capi
+    dev = torch.device("cuda:0")
+    L = capi.lib()
+    n_grp, delta = 300_000, 0.02 / 16.0
+    g = torch.Generator().manual_seed(41)
+    base = torch.rand(n_grp, 3, generator=g) * 0.8 + 0.1
+    offs = torch.tensor([[0, 0, 0], [delta, 0, 0], [-delta, 0, 0], [0, delta, 0], [0, -delta, 0], [0, 0, delta], [0, 0, -delta]])
+    x = (base[None] + offs[:, None]).reshape(-1, 3).contiguous()
+    B = x.shape[0]
+    c = (16, 2, 19, 32, 2.0)
+    _, total = oracle.grid_offsets(CFG)
+    table = (torch.rand(total, 2, generator=g) * 2 - 1) * 0.5
+    dims = [32, 64, 64, 64, 2]
+    nl, dims_c = len(dims) - 1, (C.c_int * len(dims))(*dims)
+    W = torch.cat([(torch.rand(o * i, generator=g) * 2 - 1) * (6.0 / i) ** 0.5 for i, o in zip(dims[:-1], dims[1:])])
+    xd, td, Wd = x.to(dev), table.to(dev), W.to(dev)
+    feat = torch.empty(B, 32, device=dev)
+    capi.check(L.gsdf_hashgrid_fwd_stencil(B, n_grp, 0, *c, capi.f32(xd), capi.f32(td), capi.f32(feat), None, capi.stream()), "fwd")
+    out = torch.empty(B, 2, device=dev)
+    acts = torch.empty(L.gsdf_mlp_acts_floats(B, nl), device=dev)
+    capi.check(L.gsdf_mlp_fwd(B, nl, dims_c, capi.f32(Wd), None, capi.f32(feat), capi.f32(out), capi.f32(acts), capi.stream()), "mlp fwd")
+    v_out = torch.randn(B, 2, generator=g).to(dev)
+    v_feat, v_w = torch.empty_like(feat), torch.zeros_like(Wd)
+    capi.check(L.gsdf_mlp_bwd(B, nl, dims_c, capi.f32(Wd), None, capi.f32(feat), capi.f32(acts), capi.f32(v_out), capi.f32(v_feat),
+                              capi.f32(v_w), None, None, capi.stream()), "mlp bwd")
+    nbytes = L.gsdf_hashgrid_bwd_binned_ws_bytes(B, *c)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    v_t = torch.zeros(total, 2, device=dev)
+    ml = sdf.stencil_merge_levels(c, delta)
+    capi.check(L.gsdf_hashgrid_bwd_binned_stencil(B, n_grp, ml, *c, capi.f32(xd), capi.f32(v_feat), capi.f32(v_t), capi.ptr(ws), nbytes, capi.stream()), "scatter")
+    torch.cuda.synchronize()
+    # (a) sampled rows
+    idx = torch.randperm(B, generator=g)[:20000].sort().values
+    f_s = n(feat[idx.to(dev)])
+    assert_close(f_s, oracle.grid_fwd(n(x[idx]), n(table), CFG, prec="f32"), 1e-5, "features of the sampled rows")
+    keep = ~_near_relu_kink(f_s, dims, n(W), None)
+    idk = idx[torch.from_numpy(keep)]
+    f_k = f_s[keep]
+    assert_close(out[idk.to(dev)], oracle.mlp_fwd(f_k, dims, n(W), None, prec="f64"), REL, "decoder outputs of the sampled rows")
+    vin_o, _, _ = oracle.mlp_bwd(f_k, dims, n(W), None, n(v_out[idk.to(dev)]), prec="f64")
+    assert_close(v_feat[idk.to(dev)], vin_o, REL, "decoder input gradients of the sampled rows")
+    # (b) linearity of the parameter gradients over the rows (quarters = whole groups: 7 x n_grp/4 rows each, re-stacked)
+    v_w_q, v_t_q = torch.zeros_like(Wd), torch.zeros(total, 2, device=dev)
+    q = n_grp // 4
+    for k in range(4):
+        rows = torch.cat([torch.arange(r * n_grp + k * q, r * n_grp + (k + 1) * q) for r in range(7)]).to(dev)
+        Bq = rows.numel()
+        fq, vq, xq = feat[rows].contiguous(), v_out[rows].contiguous(), xd[rows].contiguous()
+        oq, aq = torch.empty(Bq, 2, device=dev), torch.empty(L.gsdf_mlp_acts_floats(Bq, nl), device=dev)
+        capi.check(L.gsdf_mlp_fwd(Bq, nl, dims_c, capi.f32(Wd), None, capi.f32(fq), capi.f32(oq), capi.f32(aq), capi.stream()), "mlp fwd")
+        vfq = torch.empty_like(fq)
+        capi.check(L.gsdf_mlp_bwd(Bq, nl, dims_c, capi.f32(Wd), None, capi.f32(fq), capi.f32(aq), capi.f32(vq), capi.f32(vfq),
+                                  capi.f32(v_w_q), None, None, capi.stream()), "mlp bwd")
+        assert torch.equal(vfq, v_feat[rows]), "per-row input gradients depend on the launch size"
+        capi.check(L.gsdf_hashgrid_bwd_binned_stencil(Bq, q, ml, *c, capi.f32(xq), capi.f32(vfq), capi.f32(v_t_q), capi.ptr(ws), nbytes,
+                                                      capi.stream()), "scatter")
+    torch.cuda.synchronize()
+    assert_close(v_w, v_w_q, REL, "decoder weight gradients: all rows vs the sum over quarters")
+    assert_close(v_t, v_t_q, REL, "table gradient: all rows vs the sum over quarters")
