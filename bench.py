@@ -379,6 +379,7 @@ def main():
                    "evaluations per sample, neural_mapping.cpp:448-451)") + "; decoder_implementation 1 (fused MLP; the reference forces "
                   "numerical_grad with it, params.cpp:396-399)") +
                  ("" if state["light"] else "; per-iteration update_state (neural_gaussian.cpp:626-680)") + "; fused Adam on all parameters")
+        split_mlp_cfg = not args.no_sdf and os.environ.get("GSDF_MLP_MFMA", "bf16x3")[:1] not in "fF"
         out = {
             "metric": "train iters/sec (splat raster + SDF fwd+bwd), 1M Gaussians @1080p" if not args.no_sdf
                       else "train iters/sec (splat raster fwd+bwd only), 1M Gaussians @1080p",
@@ -389,7 +390,10 @@ def main():
                                    f"steps: M={M:.0f} I={I:.0f} L={I / T:.0f}" + ("" if args.no_sdf else f"; hash-grid SDF (2^19 x16x2, fused "
                                    f"64-wide MLP) evaluated at {sdf_pts:.0f} points/step = 7 x 32768 ray + {stencil} x {n_gs:.0f} splat samples"),
                        "step": ("LIGHT (--light-step): " if state["light"] else "reference joint iteration (neural_mapping.cpp:400-486): ") + terms,
-                       "parallelism": f"view-parallel x{world}" if world > 1 else "single GPU"},
+                       "parallelism": f"view-parallel x{world}" if world > 1 else "single GPU",
+                       "decoder_arithmetic": ("fp32 operands as 3 exact bf16 terms, 6 partial products per multiply-add on the bf16 MFMA pipe, "
+                                              "fp32 accumulate: error against fp64 equal to the fp32 MFMA's (tools/ubench/mfma_split.hip)"
+                                              if split_mlp_cfg else "fp32 MFMA")},
             "roofline": dict(roof(dom), kernel=dom, traffic=traffic, avg_launch_ms=dur_ms, median_launch_ms=kern.get(dom),
                              launches_per_step=calls.get(dom, 0) / args.steps,
                              timing="HIP events on the launch stream over the timed steps; mean launch (operators with unequal launches)",

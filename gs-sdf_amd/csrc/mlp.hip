@@ -374,6 +374,15 @@ extern "C" size_t gsdf_mlp_bwd_ws_bytes(int64_t B, int n_layers) {
   return image_floats(B, n_layers) * sizeof(float) + 256;
 }
 
+extern "C" size_t gsdf_mlp_bwd_ws_bytes_for(int64_t B, int n_layers, const int *dims_host, int want_weights) {
+  MlpDesc d;
+  size_t lds_floats;
+  if (dims_host && want_weights && make_desc(n_layers, dims_host, 0, true, &d, &lds_floats, "mlp_bwd_ws_bytes_for") == GSDF_OK &&
+      mlp_bwd_split_covers(d))
+    return 0;
+  return gsdf_mlp_bwd_ws_bytes(B, n_layers);
+}
+
 extern "C" int gsdf_mlp_fwd(int64_t B, int n_layers, const int *dims_host, const float *weights, const float *biases,
                             const float *in, float *out, float *acts, gsdf_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;

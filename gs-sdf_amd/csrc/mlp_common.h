@@ -54,6 +54,8 @@ __device__ __forceinline__ v16f mfma32(float a, float b, v16f c) {
 // Return 1 if launched, 0 if the path does not cover the call (topology, LDS, GSDF_MLP_MFMA=f32), < 0 on error.
 int mlp_fwd_split_launch(int64_t B, const MlpDesc &d, const float *W, const float *bias, const float *in, float *out, float *acts,
                          hipStream_t stream);
+// does mlp_bwd_split_launch cover this topology (both gradients requested)?
+bool mlp_bwd_split_covers(const MlpDesc &d);
 // data and weight gradients in one pass (v_W required; v_in, v_b optional); v_W / v_b ACCUMULATE
 int mlp_bwd_split_launch(int64_t B, const MlpDesc &d, const float *W, const float *in, const float *acts, const float *v_out,
                          float *v_in, float *v_W, float *v_b, hipStream_t stream);

@@ -223,9 +223,9 @@ __global__ void __launch_bounds__(SPLIT_FWD_THREADS)
 // registers a lane owns at one wave per SIMD — and leave through one round of atomics per wave at the very end.
 //
 // (2) contracts over points, which D's layout has on LANES while an MFMA operand wants them on ELEMENTS: both operands go
-// through a wave-private LDS block, written as bf16 terms with ds_write_b16 (row = neuron, 32 points + padding per row) and
-// read back as the 16-byte operands of lane = neuron (conflict-free with 80-byte rows).  The bias gradient is the same A
-// operand against a one-hot B column (column l of a shared tile collects layer l's sums).
+// through a wave-private LDS block (tr_write8 / tr_read below: packed pairs written with ds_write_b64, read back with the
+// gfx950 transpose read ds_read_b64_tr_b16).  The bias gradient is the same A operand against a one-hot B column (column l of
+// a shared tile collects layer l's sums).
 // ----------------------------------------------------------------------------------------------
 static constexpr int SPLIT_BWD_THREADS = 256;
 static constexpr int TR_BLOCK = 256;           // 8-byte chunks per term of a transposition block: 32 points x 8 neuron quads
@@ -579,8 +579,6 @@ __global__ void __launch_bounds__(SPLIT_BWD_THREADS) __attribute__((amdgpu_waves
   }
 }
 
-static bool n_tiles_zero(int64_t B) { return B <= 0; }
-
 static size_t split_bwd_lds(const MlpDesc &d, SplitLds *sl, int *lds_w4) {
   int off = 0;
   for (int l = 0; l < d.n_layers; ++l) {
@@ -601,13 +599,19 @@ static int launch_bwd_split(int64_t B, const MlpDesc &d, const SplitLds &sl, int
   return 1;
 }
 
+bool mlp_bwd_split_covers(const MlpDesc &d) {
+  if (!split_enabled() || d.d_in != 32 || d.d_out > 16 || (d.n_layers != 4 && d.n_layers != 5)) return false;
+  SplitLds sl;
+  int lds_w4;
+  return split_bwd_lds(d, &sl, &lds_w4) + (size_t)(SPLIT_BWD_THREADS / 64) * TR_WAVE_BYTES <= 160 * 1024;
+}
+
 int mlp_bwd_split_launch(int64_t B, const MlpDesc &d, const float *W, const float *in, const float *acts, const float *v_out,
                          float *v_in, float *v_W, float *v_b, hipStream_t stream) {
-  if (!split_enabled() || d.d_in != 32 || d.d_out > 16 || v_W == nullptr || n_tiles_zero(B)) return 0;
+  if (v_W == nullptr || !mlp_bwd_split_covers(d)) return 0;
   SplitLds sl;
   int lds_w4;
   const size_t lds = split_bwd_lds(d, &sl, &lds_w4);
-  if (lds + (size_t)(SPLIT_BWD_THREADS / 64) * TR_WAVE_BYTES > 160 * 1024) return 0;
   const bool bias = d.has_bias && v_b != nullptr;
   if (d.n_layers == 5) return bias ? launch_bwd_split<5, true>(B, d, sl, lds_w4, lds, W, in, acts, v_out, v_in, v_W, v_b, stream)
                                    : launch_bwd_split<5, false>(B, d, sl, lds_w4, lds, W, in, acts, v_out, v_in, v_W, v_b, stream);

@@ -116,7 +116,8 @@ struct MlpFn : public torch::autograd::Function<MlpFn> {
     Tensor v_out = f32c(g[0], "grad");
     Tensor v_in = ctx->needs_input_grad(0) ? torch::empty_like(s[0]) : Tensor();
     Tensor v_w = ctx->needs_input_grad(1) ? torch::zeros_like(s[1]) : Tensor();
-    Tensor ws = empty_like_opts(s[0], {(int64_t)gsdf_mlp_bwd_ws_bytes(B, nl)}, torch::kUInt8);
+    // 0 bytes when both gradients are requested and the one-pass backward covers the topology
+    Tensor ws = empty_like_opts(s[0], {(int64_t)gsdf_mlp_bwd_ws_bytes_for(B, nl, dims.data(), v_w.defined() ? 1 : 0)}, torch::kUInt8);
     check(gsdf_mlp_bwd(B, nl, dims.data(), fp(s[1]), nullptr, fp(s[0]), fp(s[2]), fp(v_out), fpm(v_in), fpm(v_w), nullptr,
                        ws.data_ptr(), cur_stream()),
           "TCNNNetwork backward");

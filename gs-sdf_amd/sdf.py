@@ -244,9 +244,11 @@ class TCNNEncoding:
 
 
 def _mlp_fused_bwd(dims):
-    """does gsdf_mlp_bwd with both gradients take the one-pass kernel (csrc/mlp_split.hip) for this topology?"""
-    return (dims[0] == 32 and len(dims) - 1 in (4, 5) and os.environ.get("GSDF_MLP_MFMA", "bf16x3")[:1] not in "fF"
-            and os.environ.get("GSDF_MLP_FUSED_BWD", "1") != "0")
+    """does gsdf_mlp_bwd with both gradients take the one-pass kernel (csrc/mlp_split.hip: no workspace) for this topology?"""
+    if os.environ.get("GSDF_MLP_FUSED_BWD", "1") == "0":
+        return False
+    dims_c = (C.c_int * len(dims))(*dims)
+    return capi.lib().gsdf_mlp_bwd_ws_bytes_for(1024, len(dims) - 1, dims_c, 1) == 0
 
 
 class _MlpFn(torch.autograd.Function):
