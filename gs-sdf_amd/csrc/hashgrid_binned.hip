@@ -32,7 +32,6 @@ static constexpr int BIN_TILE = 1 << BIN_TILE_LOG2;
 static constexpr int BIN_PTS = 256;                    // points per emit workgroup
 static constexpr int BIN_G = 2;                        // levels per emit workgroup (16 B of v_feat per point)
 static constexpr int BIN_MAX_LOCAL = 256;              // buckets one emit workgroup can address
-static constexpr int BIN_REC = BIN_PTS * BIN_G * 8;    // records staged per emit workgroup (48 KB)
 static constexpr int64_t BIN_ITEM_MAX = 512 * 1024;    // records per apply work item
 static constexpr int BIN_APPLY_THREADS = 512;
 static_assert(BIN_PTS == BIN_MAX_LOCAL, "the emit kernel scans its local histogram with one thread per bucket");
@@ -258,25 +257,30 @@ __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v, int lane) {
   return v;
 }
 
-static constexpr int BIN_EMIT_THREADS = BIN_PTS * BIN_G;   // one thread per (point, level of the group): 8 waves per workgroup
-__global__ void __launch_bounds__(BIN_EMIT_THREADS)
+// one thread per (point, level of the group); PTS points x G levels per workgroup = PTS * G * 8 records staged in LDS.
+// The records of a workgroup leave as one run per bucket: the fewer buckets a workgroup addresses and the more points it
+// holds, the longer the runs (PTS * G * 8 / (G * 128 tiles) records of 12 bytes)
+template <int PTS, int G>
+__global__ void __launch_bounds__(PTS * G)
     bin_emit_kernel(int64_t B, HgLevels lv, BinPlan bp, BinStencil stn, const float *__restrict__ x,
                     const float *__restrict__ v_feat, const int64_t *__restrict__ start, uint32_t *__restrict__ cursor,
                     BinRecord *__restrict__ records) {
+  constexpr int BIN_EMIT_THREADS = PTS * G, BIN_REC = PTS * G * 8;
   __shared__ uint32_t s_key[BIN_REC];
   __shared__ float s_g0[BIN_REC], s_g1[BIN_REC];
   __shared__ uint32_t s_hist[BIN_MAX_LOCAL], s_off[BIN_MAX_LOCAL], s_wtot[BIN_MAX_LOCAL / 64];
   __shared__ int64_t s_dst[BIN_MAX_LOCAL];
-  const int grp = blockIdx.x % bp.n_groups;
-  const int64_t chunk = blockIdx.x / bp.n_groups;
-  const int l0 = grp * BIN_G, l1 = min(l0 + BIN_G, lv.n_levels);
+  const int n_groups = (lv.n_levels + G - 1) / G;
+  const int grp = blockIdx.x % n_groups;
+  const int64_t chunk = blockIdx.x / n_groups;
+  const int l0 = grp * G, l1 = min(l0 + G, lv.n_levels);
   const int b0 = bp.tile_base[l0], nloc = bp.tile_base[l1] - b0;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   if (t < BIN_MAX_LOCAL) s_hist[t] = 0;
   __syncthreads();
   // thread -> (point, level): waves 0..3 take the group's first level, waves 4..7 the second (the level is wave-uniform)
-  const int64_t b = chunk * BIN_PTS + (t & (BIN_PTS - 1));
-  const int level = l0 + (t >> 8);
+  const int64_t b = chunk * PTS + (t % PTS);
+  const int level = l0 + t / PTS;
   // pass 1: this (point, level)'s 8 contributions in registers, slot within the workgroup's bucket run from an LDS counter
   uint32_t key[8], slot[8];
   float g0[8], g1[8];
@@ -479,7 +483,9 @@ extern "C" int gsdf_hashgrid_bwd_binned_stencil(int64_t B, int64_t stencil_n, in
   bin_plan_kernel<<<1, 1024, 0, stream>>>(nb, w.counts, w.cursor, w.start, w.items, w.n_items);
   GSDF_CHECK_LAUNCH("bin_plan_kernel");
   // (measured and rejected: records straight from registers to their slots without the LDS sort — 2.0 ms against 1.74 ms)
-  bin_emit_kernel<<<(unsigned)(chunks * bp.n_groups), BIN_EMIT_THREADS, 0, stream>>>(B, lv, bp, stn, x, v_feat, w.start, w.cursor, w.records);
+  // (measured and rejected: 512 points x 1 level and 1024 x 1 per workgroup, i.e. 2x / 4x longer runs per bucket: 3.15 and
+  //  3.48 ms against 2.94 ms for the whole scatter at 3.3 M points — the run length is not what bounds the emit pass)
+  bin_emit_kernel<BIN_PTS, BIN_G><<<(unsigned)(chunks * bp.n_groups), BIN_PTS * BIN_G, 0, stream>>>(B, lv, bp, stn, x, v_feat, w.start, w.cursor, w.records);
   GSDF_CHECK_LAUNCH("bin_emit_kernel");
   bin_apply_kernel<<<(unsigned)w.max_items, BIN_APPLY_THREADS, 0, stream>>>(lv, bp, w.items, w.n_items, w.lmax, w.records, v_table);
   GSDF_CHECK_LAUNCH("bin_apply_kernel");
