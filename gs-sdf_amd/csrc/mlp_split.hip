@@ -124,8 +124,8 @@ __device__ __forceinline__ Split8 lds_operand(const uint4 *img, int idx, int lan
   return a;
 }
 
-template <int D_IN>
-__global__ void __launch_bounds__(SPLIT_FWD_THREADS)
+template <int D_IN, int THREADS>
+__global__ void __launch_bounds__(THREADS)
     mlp_fwd_split_kernel(int64_t B, MlpDesc d, SplitLds sl, const float *__restrict__ W, const float *__restrict__ bias,
                          const float *__restrict__ in, float *__restrict__ out, float *__restrict__ acts) {
   extern __shared__ __attribute__((aligned(16))) uint4 smem4[];
@@ -136,7 +136,7 @@ __global__ void __launch_bounds__(SPLIT_FWD_THREADS)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int h = lane >> 5, pl = lane & 31;
   constexpr int KS0 = D_IN / 16;
-  constexpr int WAVES = SPLIT_FWD_THREADS / 64;
+  constexpr int WAVES = THREADS / 64;
   const int64_t n_tiles = (B + 31) / 32;
   uint16_t *masks = acts == nullptr ? nullptr : reinterpret_cast<uint16_t *>(acts + img_off(d.n_layers - 1, n_tiles, 0, 0, 0));
   for (int64_t tile = (int64_t)blockIdx.x * WAVES + wave; tile < n_tiles; tile += (int64_t)gridDim.x * WAVES) {
@@ -174,14 +174,13 @@ __global__ void __launch_bounds__(SPLIT_FWD_THREADS)
           masks[mask_off(l - 1, n_tiles, tile, t, lane)] = (uint16_t)m;
         }
       }
-      Split8 hb[4];
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
+      // B operand of k-step s = 8 registers of tile s >> 1, split right before its MFMAs (12 live registers instead of 48)
+      auto hb = [&](int s) {
         float x[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) x[e] = cur[s >> 1][8 * (s & 1) + e];
-        hb[s] = split8(x);
-      }
+        return split8(x);
+      };
       const uint4 *w = lds_w + sl.off4[l];
       const bool last = l == d.n_layers - 1;
       v16f acc0, acc1;
@@ -189,15 +188,19 @@ __global__ void __launch_bounds__(SPLIT_FWD_THREADS)
       for (int r = 0; r < 16; ++r) { acc0[r] = lds_b[l * HID + d_row(r, h)]; acc1[r] = lds_b[l * HID + 32 + d_row(r, h)]; }
       if (!last) {
 #pragma unroll
-        for (int s = 0; s < 4; ++s) mfma6x2(lds_operand(w, s, lane), lds_operand(w, 4 + s, lane), hb[s], acc0, acc1);
+        for (int s = 0; s < 4; ++s) {
+          mfma6x2(lds_operand(w, s, lane), lds_operand(w, 4 + s, lane), hb(s), acc0, acc1);
+          __builtin_amdgcn_sched_barrier(0);   // keeps hipcc from hoisting all four operand splits (48 registers) to the top
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) { cur[0][r] = fmaxf(acc0[r], 0.f); cur[1][r] = fmaxf(acc1[r], 0.f); }
       } else {   // one output tile: two k-steps in flight instead
         v16f accb;
 #pragma unroll
         for (int r = 0; r < 16; ++r) accb[r] = 0.f;
-        mfma6(lds_operand(w, 0, lane), hb[0], acc0); mfma6(lds_operand(w, 1, lane), hb[1], accb);
-        mfma6(lds_operand(w, 2, lane), hb[2], acc0); mfma6(lds_operand(w, 3, lane), hb[3], accb);
+        mfma6(lds_operand(w, 0, lane), hb(0), acc0); mfma6(lds_operand(w, 1, lane), hb(1), accb);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma6(lds_operand(w, 2, lane), hb(2), acc0); mfma6(lds_operand(w, 3, lane), hb(3), accb);
 #pragma unroll
         for (int r = 0; r < 16; ++r) cur[0][r] = acc0[r] + accb[r];
       }
@@ -649,13 +652,15 @@ int mlp_fwd_split_launch(int64_t B, const MlpDesc &d, const float *W, const floa
   SplitLds sl;
   const size_t lds = split_fwd_lds(d, &sl);
   if (lds > 160 * 1024) return 0;
+  // (measured: 12 and 16 waves per workgroup — 3 / 4 waves per SIMD, a few spilled registers — run 0.72 and 0.90 ms against
+  //  0.70 ms at 8; without the saved activations all three take 0.52 ms: occupancy is not what bounds this kernel)
   const unsigned grid = split_grid(B, SPLIT_FWD_THREADS / 64);
   if (d.d_in == 32) {
-    GSDF_HIP(hipFuncSetAttribute((const void *)mlp_fwd_split_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "mlp_fwd_split attr");
-    mlp_fwd_split_kernel<32><<<grid, SPLIT_FWD_THREADS, lds, stream>>>(B, d, sl, W, bias, in, out, acts);
+    GSDF_HIP(hipFuncSetAttribute((const void *)mlp_fwd_split_kernel<32, SPLIT_FWD_THREADS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "mlp_fwd_split attr");
+    mlp_fwd_split_kernel<32, SPLIT_FWD_THREADS><<<grid, SPLIT_FWD_THREADS, lds, stream>>>(B, d, sl, W, bias, in, out, acts);
   } else {
-    GSDF_HIP(hipFuncSetAttribute((const void *)mlp_fwd_split_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "mlp_fwd_split attr");
-    mlp_fwd_split_kernel<64><<<grid, SPLIT_FWD_THREADS, lds, stream>>>(B, d, sl, W, bias, in, out, acts);
+    GSDF_HIP(hipFuncSetAttribute((const void *)mlp_fwd_split_kernel<64, SPLIT_FWD_THREADS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "mlp_fwd_split attr");
+    mlp_fwd_split_kernel<64, SPLIT_FWD_THREADS><<<grid, SPLIT_FWD_THREADS, lds, stream>>>(B, d, sl, W, bias, in, out, acts);
   }
   GSDF_CHECK_LAUNCH("mlp_fwd_split_kernel");
   return 1;
