@@ -124,6 +124,23 @@ __device__ __forceinline__ Split8 lds_operand(const uint4 *img, int idx, int lan
   return a;
 }
 
+// accumulator tiles initialised with the layer's biases: registers 4k .. 4k+3 of a lane are 4 consecutive neurons (one
+// ds_read_b128 each); a bias-free network starts from zero without touching LDS
+__device__ __forceinline__ void load_bias(const float *lds_b, int l, int h, int has_bias, v16f &acc0, v16f &acc1) {
+  if (!has_bias) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+    return;
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float4 b0 = *reinterpret_cast<const float4 *>(lds_b + l * HID + 8 * k + 4 * h);
+    const float4 b1 = *reinterpret_cast<const float4 *>(lds_b + l * HID + 32 + 8 * k + 4 * h);
+    acc0[4 * k] = b0.x; acc0[4 * k + 1] = b0.y; acc0[4 * k + 2] = b0.z; acc0[4 * k + 3] = b0.w;
+    acc1[4 * k] = b1.x; acc1[4 * k + 1] = b1.y; acc1[4 * k + 2] = b1.z; acc1[4 * k + 3] = b1.w;
+  }
+}
+
 template <int D_IN, int THREADS>
 __global__ void __launch_bounds__(THREADS)
     mlp_fwd_split_kernel(int64_t B, MlpDesc d, SplitLds sl, const float *__restrict__ W, const float *__restrict__ bias,
@@ -139,23 +156,36 @@ __global__ void __launch_bounds__(THREADS)
   constexpr int WAVES = THREADS / 64;
   const int64_t n_tiles = (B + 31) / 32;
   uint16_t *masks = acts == nullptr ? nullptr : reinterpret_cast<uint16_t *>(acts + img_off(d.n_layers - 1, n_tiles, 0, 0, 0));
-  for (int64_t tile = (int64_t)blockIdx.x * WAVES + wave; tile < n_tiles; tile += (int64_t)gridDim.x * WAVES) {
+  // the input rows of a tile are loaded one tile ahead (branch-free: clamped address, dead lanes zeroed by a select)
+  float4 xin[2 * KS0];
+  auto load_rows = [&](int64_t tile) {
+    const int64_t p = tile * 32 + pl;
+    const bool ok = tile < n_tiles && p < B;
+    const float4 *src = reinterpret_cast<const float4 *>(in + (ok ? p : 0) * D_IN + 8 * h);
+#pragma unroll
+    for (int s = 0; s < KS0; ++s) {
+      const float4 u = src[4 * s], v = src[4 * s + 1];
+      xin[2 * s] = ok ? u : make_float4(0.f, 0.f, 0.f, 0.f);
+      xin[2 * s + 1] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  const int64_t tile0 = (int64_t)blockIdx.x * WAVES + wave, tstride = (int64_t)gridDim.x * WAVES;
+  load_rows(tile0);
+  for (int64_t tile = tile0; tile < n_tiles; tile += tstride) {
     const int64_t p = tile * 32 + pl;
     const bool live = p < B;
     v16f cur[2];
     {  // ---- layer 0: k-step s of this lane = input features 16 s + 8 h .. + 7
       Split8 xb[KS0];
-      const float4 *src = reinterpret_cast<const float4 *>(in + (live ? p : 0) * D_IN + 8 * h);
 #pragma unroll
       for (int s = 0; s < KS0; ++s) {
-        const float4 u = live ? src[4 * s] : make_float4(0.f, 0.f, 0.f, 0.f), v = live ? src[4 * s + 1] : make_float4(0.f, 0.f, 0.f, 0.f);
-        const float x[8] = {u.x, u.y, u.z, u.w, v.x, v.y, v.z, v.w};
+        const float x[8] = {xin[2 * s].x, xin[2 * s].y, xin[2 * s].z, xin[2 * s].w, xin[2 * s + 1].x, xin[2 * s + 1].y, xin[2 * s + 1].z, xin[2 * s + 1].w};
         xb[s] = split8(x);
       }
+      load_rows(tile + tstride);
       const uint4 *w = lds_w + sl.off4[0];
       v16f acc0, acc1;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { acc0[r] = lds_b[d_row(r, h)]; acc1[r] = lds_b[32 + d_row(r, h)]; }
+      load_bias(lds_b, 0, h, d.has_bias, acc0, acc1);
 #pragma unroll
       for (int s = 0; s < KS0; ++s) mfma6x2(lds_operand(w, s, lane), lds_operand(w, KS0 + s, lane), xb[s], acc0, acc1);
 #pragma unroll
@@ -184,13 +214,17 @@ __global__ void __launch_bounds__(THREADS)
       const uint4 *w = lds_w + sl.off4[l];
       const bool last = l == d.n_layers - 1;
       v16f acc0, acc1;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { acc0[r] = lds_b[l * HID + d_row(r, h)]; acc1[r] = lds_b[l * HID + 32 + d_row(r, h)]; }
+      load_bias(lds_b, l, h, d.has_bias, acc0, acc1);
       if (!last) {
+        // A operands one k-step ahead: their LDS latency hides behind the 12 MFMAs of the current k-step
+        Split8 a0 = lds_operand(w, 0, lane), a1 = lds_operand(w, 4, lane);
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-          mfma6x2(lds_operand(w, s, lane), lds_operand(w, 4 + s, lane), hb(s), acc0, acc1);
+          Split8 n0 = a0, n1 = a1;
+          if (s < 3) { n0 = lds_operand(w, s + 1, lane); n1 = lds_operand(w, 4 + s + 1, lane); }
+          mfma6x2(a0, a1, hb(s), acc0, acc1);
           __builtin_amdgcn_sched_barrier(0);   // keeps hipcc from hoisting all four operand splits (48 registers) to the top
+          a0 = n0; a1 = n1;
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) { cur[0][r] = fmaxf(acc0[r], 0.f); cur[1][r] = fmaxf(acc1[r], 0.f); }
