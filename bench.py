@@ -486,7 +486,7 @@ def cpu_baseline(sc, views, params, N, W, H, deg, n_sdf_points, dev):
         feat = orc.grid_fwd(xs, table)
         o = orc.mlp_fwd(feat, dims, Wm, None)
         v_in, v_w, _ = orc.mlp_bwd(feat, dims, Wm, None, np.ones_like(o))
-        orc.grid_bwd(xs, table, v_in)
+        vt_o, _ = orc.grid_bwd(xs, table, v_in)
         t_sdf = (time.perf_counter() - t1) * (n_sdf_points / n_s)
     dt = t_splat + t_sdf
     # ---- parity leg (not timed): the HIP operators on the same inputs against the oracle ---------------------------------
@@ -525,6 +525,37 @@ def cpu_baseline(sc, views, params, N, W, H, deg, n_sdf_points, dev):
            "note": "HIP path vs the oracle on the bench workload's first view: ids / radii / bins / offsets bit-exact against the fp32 "
                    "build; floats against the fp64 build (max scaled error, relative L2, fraction of elements above 1e-4; the operator is "
                    "discontinuous at alpha = 1/255 and T = 1e-4, see tests/util.py); tests/test_gpu_baseline_shapes.py gates the same comparison"}
+    if n_sdf_points:
+        # SDF half: the HIP encoder / decoder / scatter on the sample the oracle was timed on.  Features and table gradient
+        # against the fp32 build (pos = fma(scale, x, 0.5) in fp32 IS the function), decoder against the fp64 build
+        import ctypes as C
+        import gs_sdf_amd.capi as capi
+        L = capi.lib()
+        gcfg = (16, 2, 19, 32, 2.0)
+        nl, dims_c = len(dims) - 1, (C.c_int * len(dims))(*dims)
+        xd, td, Wd, fd = t(xs), t(table), t(Wm), t(feat)
+        feat_h = torch.empty(n_s, 32, device=dev)
+        capi.check(L.gsdf_hashgrid_fwd(n_s, *gcfg, capi.f32(xd), capi.f32(td), capi.f32(feat_h), capi.stream()), "hashgrid_fwd")
+        out_h = torch.empty(n_s, dims[-1], device=dev)
+        acts = torch.empty(L.gsdf_mlp_acts_floats(n_s, nl), device=dev)
+        capi.check(L.gsdf_mlp_fwd(n_s, nl, dims_c, capi.f32(Wd), None, capi.f32(fd), capi.f32(out_h), capi.f32(acts), capi.stream()), "mlp_fwd")
+        vin_h, vw_h = torch.empty_like(fd), torch.zeros_like(Wd)
+        ws = torch.empty(L.gsdf_mlp_bwd_ws_bytes_for(n_s, nl, dims_c, 1), dtype=torch.uint8, device=dev)
+        capi.check(L.gsdf_mlp_bwd(n_s, nl, dims_c, capi.f32(Wd), None, capi.f32(fd), capi.f32(acts), capi.f32(torch.ones_like(out_h)), capi.f32(vin_h),
+                                  capi.f32(vw_h), None, capi.ptr(ws) if ws.numel() else None, capi.stream()), "mlp_bwd")
+        nb = L.gsdf_hashgrid_bwd_binned_ws_bytes(n_s, *gcfg)
+        bws = torch.empty(nb, dtype=torch.uint8, device=dev)
+        vt_h = torch.zeros(table.shape[0], 2, device=dev)
+        capi.check(L.gsdf_hashgrid_bwd_binned(n_s, *gcfg, capi.f32(xd), capi.f32(t(v_in.astype(np.float32))), capi.f32(vt_h), capi.ptr(bws), nb, capi.stream()), "scatter")
+        torch.cuda.synchronize()
+        o64 = orc.mlp_fwd(feat, dims, Wm, None, prec="f64")
+        vin64, vw64, _ = orc.mlp_bwd(feat, dims, Wm, None, np.ones_like(o64), prec="f64")
+        par["sdf"] = {"hashgrid_features (vs f32 build)": _err_stats(n(feat_h), feat), "decoder_out (vs f64 build)": _err_stats(n(out_h), o64),
+                      "decoder_v_in (vs f64 build)": _err_stats(n(vin_h), vin64), "decoder_v_weights (vs f64 build)": _err_stats(n(vw_h), vw64),
+                      "table_gradient (vs f32 build)": _err_stats(n(vt_h), vt_o),
+                      "note": f"{n_s} uniformly random points, table U(-1e-4, 1e-4), 4-layer bias-free decoder; the decoder runs on the bf16 MFMA pipe with "
+                              "exact 3-term operand splits (GSDF_MLP_MFMA=f32 selects the fp32 pipe); a point whose pre-activation is within "
+                              "rounding of zero may take the other ReLU branch than the fp64 evaluation: those are the elements above 1e-4"}
     return {"value": 1.0 / dt, "unit": "iters/s", "cores": cores, "kind": "port",
             "sample": f"splat half of 1 iteration in full (oracle/splat_oracle.c f32 build, OpenMP over tiles on {cores} threads for "
                       f"compositing, projection/sort single-threaded): {t_splat:.1f} s" +
