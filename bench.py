@@ -139,7 +139,8 @@ def main():
             # a high-priority queue keeps them from waiting behind the SDF leg's multi-millisecond kernels
             prio = int(os.environ.get("GSDF_SPLAT_STREAM_PRIORITY", "-1"))
             main = torch.cuda.Stream(priority=prio)
-            side, aux, scatter = (torch.cuda.Stream() for _ in range(3))
+            sprio = int(os.environ.get("GSDF_SDF_STREAM_PRIORITY", "0"))
+            side, aux, scatter = (torch.cuda.Stream(priority=sprio) for _ in range(3))
         lm.encoder.scatter_stream = scatter
         lm.decoder.aux_stream = aux          # decoder weight gradients: off the chain that leads back to the splat leg
         main.wait_stream(torch.cuda.current_stream())

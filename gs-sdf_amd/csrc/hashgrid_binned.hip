@@ -483,6 +483,9 @@ extern "C" int gsdf_hashgrid_bwd_binned_stencil(int64_t B, int64_t stencil_n, in
   bin_plan_kernel<<<1, 1024, 0, stream>>>(nb, w.counts, w.cursor, w.start, w.items, w.n_items);
   GSDF_CHECK_LAUNCH("bin_plan_kernel");
   // (measured and rejected: records straight from registers to their slots without the LDS sort — 2.0 ms against 1.74 ms)
+  // (measured and rejected, round 2: 8192-entry tiles — 2x longer runs, 128 KB apply tiles — 3.23 ms; records staged as one
+  //  16-byte LDS entry instead of three 4-byte arrays — 64 KB per workgroup, 2 per CU — 3.35 ms; tools/ubench/store_runs.hip:
+  //  12-byte records in runs of 16 are written at 3.1 TB/s, runs of 32 at 4.6, one stream at 5.3)
   // (measured and rejected: 512 points x 1 level and 1024 x 1 per workgroup, i.e. 2x / 4x longer runs per bucket: 3.15 and
   //  3.48 ms against 2.94 ms for the whole scatter at 3.3 M points — the run length is not what bounds the emit pass)
   bin_emit_kernel<BIN_PTS, BIN_G><<<(unsigned)(chunks * bp.n_groups), BIN_PTS * BIN_G, 0, stream>>>(B, lv, bp, stn, x, v_feat, w.start, w.cursor, w.records);
