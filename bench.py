@@ -50,6 +50,11 @@ def main():
     ap.add_argument("--light-step", action="store_true", help="round-1 step: no GS-sample eikonal regulariser, no per-iteration "
                                                                "update_state (NOT the reference's joint iteration)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the second (light-step) timing loop")
+    ap.add_argument("--reference-loop", action="store_true",
+                    help="time the loop body as neural_mapping_node would run it linked against the drop-in submodules with ZERO "
+                         "source edits: the drop-in operators (rasterization_2dgs_sdf, TCNNEncoding, TCNNNetwork) composed with "
+                         "eager torch for everything the reference does in libtorch (losses, SSIM, activations, get_gradient's "
+                         "numerical branch, update_state, torch.optim.Adam), one stream.  NOT the headline; reported as a line of its own")
     ap.add_argument("--collective", default="all_reduce", choices=["all_reduce", "reduce_scatter_all_gather"],
                     help="N > 1: how a parameter family's flat gradient buffer is summed over the ranks")
     args = ap.parse_args()
@@ -88,6 +93,9 @@ def main():
     ug = {k: v.to(dev) for k, v in synth.upstream_grads(H, W, seed=2).items()}
     ug6 = {k: (1e-6 * v).contiguous() for k, v in ug.items()}       # the 1e-6 N(0,1) op-level upstream gradients, fixed
     target = torch.rand(H, W, 3, generator=torch.Generator().manual_seed(3)).to(dev)    # target image U(0,1) seed 3
+    if args.reference_loop:
+        print(json.dumps(reference_loop(args, sc, views, K, ug6, target, N, W, H, deg, dev)), flush=True)
+        return
     groups = []
     if not args.no_sdf:
         # hash-grid SDF (2^19 table, 16 levels x 2) + fused MFMA decoder; the reference's numerical-gradient
@@ -419,12 +427,100 @@ def main():
         }
         if secondary:
             out["secondary"] = secondary
+            # second clearly named line: the same joint iteration as neural_mapping_node would run it linked against the drop-in
+            # submodules with zero source edits (eager losses / Adam / numerical get_gradient around the drop-in operators)
+            try:
+                out["reference_loop_zero_edits"] = reference_loop(args, sc, views, K, ug6, target, N, W, H, deg, dev)
+            except Exception as e:      # never let the extra line take the headline down
+                out["reference_loop_zero_edits"] = {"error": repr(e)[:300]}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sc, views, params, N, W, H, deg, 0 if args.no_sdf else int(sdf_pts), dev)
         print(json.dumps(out), flush=True)
     release_streams()
     if dist is not None:
         dist.destroy_process_group()
+
+
+def reference_loop(args, sc, views, K, ug6, target, N, W, H, deg, dev):
+    """The joint iteration (neural_mapping.cpp:400-486) written the way the reference writes it, on top of the drop-in operator
+    layer only: what `neural_mapping_node` gets when it is linked against libgsdf_torch.so WITHOUT the gsdf_extras edits of
+    INTEGRATION.md section 5 (no fused losses, no fused coupling node, no fused Adam, no second stream).  Python stands in for
+    the reference's C++ here: every call below is one libtorch call there."""
+    import torch.nn.functional as F
+    import gs_sdf_amd.ops as ops
+    import gs_sdf_amd.sdf as sdfm
+    from gs_sdf_amd.neural_gs import update_densify_state
+    from gs_sdf_amd.trainer import SplatParams, inject_grads
+    params = SplatParams.from_scene(sc, dev)
+    lm = sdfm.LocalMap([0.0, 0.0, 5.5], 16.0, bce_sigma=0.02, decoder_implementation=1, device=dev, seed=5)
+    lm.set_bounds(16.0 - 2 * 0.0625, 0.0625)
+    lm.update_octree_as(params.anchors)
+    gq = torch.Generator().manual_seed(4)
+    pool = [((torch.rand(32768, 3, generator=gq) - 0.5) * 14.0 + torch.tensor([0.0, 0.0, 5.5])).to(dev) for _ in range(8)]
+    ray_sdf = [(torch.randn(32768, 1, generator=gq) * 0.02).to(dev) for _ in range(8)]
+    lrs = dict(offsets=1.6e-4, scaling=5e-3, quaternion=1e-3, opacity=5e-2, features_dc=2.5e-3, features_rest=2.5e-3 / 20)
+    opt = torch.optim.Adam([{"params": [params.views[k]], "lr": lrs[k]} for k in params.views] +
+                           [{"params": lm.parameters(), "lr": 1e-4}], eps=1e-15)
+    # loss_utils.cpp:71-117: 11x11 Gaussian window (sigma 1.5), per-channel convolutions
+    g1 = torch.exp(-((torch.arange(11, dtype=torch.float32) - 5) ** 2) / (2 * 1.5 ** 2))
+    win = (g1[:, None] * g1[None, :] / g1.sum() ** 2).to(dev)[None, None].expand(3, 1, 11, 11).contiguous()
+
+    def ssim(a, b):
+        a, b = a.permute(2, 0, 1)[None], b.permute(2, 0, 1)[None]
+        mu1, mu2 = F.conv2d(a, win, padding=5, groups=3), F.conv2d(b, win, padding=5, groups=3)
+        s1 = F.conv2d(a * a, win, padding=5, groups=3) - mu1 * mu1
+        s2 = F.conv2d(b * b, win, padding=5, groups=3) - mu2 * mu2
+        s12 = F.conv2d(a * b, win, padding=5, groups=3) - mu1 * mu2
+        return (((2 * mu1 * mu2 + 1e-4) * (2 * s12 + 9e-4)) / ((mu1 * mu1 + mu2 * mu2 + 1e-4) * (s1 + s2 + 9e-4))).mean()
+
+    gs_state, sizes = {}, []
+
+    def step(i):
+        view = views[i % views.shape[0]][None]
+        opt.zero_grad()
+        # sdf_train_batch_iter (:138-188): sdf_loss + eikonal on get_gradient's numerical branch
+        pts, tgt = pool[i % 8], ray_sdf[i % 8]
+        s, isig = lm.get_sdf(pts)
+        loss = sdfm.sdf_loss(s, tgt, isig) + 0.1 * sdfm.eikonal_loss(lm.get_gradient(pts, 0.02, s, False, True)[0])
+        # gs_train_batch_iter (:195-300): generate_gaussian() activations, render, 0.8 L1 + 0.2 D-SSIM
+        v = params.views
+        xyz, scales, opacity = params.anchors + v["offsets"], torch.exp(v["scaling"]), torch.sigmoid(v["opacity"]).reshape(N)
+        dc = v["features_dc"].reshape(N, 1, 3)
+        sh = dc if params.n_rest == 0 else torch.cat([dc, v["features_rest"].reshape(N, params.n_rest, 3)], 1)
+        colors, alphas, meta = ops.rasterization_2dgs_sdf(xyz, v["quaternion"], scales, opacity, sh, view, K, W, H, near_plane=0.05,
+                                                          far_plane=300.0, sh_degree=deg, center_reg=True)
+        img = meta["color"][0]
+        loss = loss + 0.8 * (img - target).abs().mean() + 0.2 * (1.0 - ssim(img, target)) + inject_grads(
+            [(meta["depth"], ug6["v_render_depths"]), (alphas, ug6["v_render_alphas"]),
+             (meta["render_normal"], ug6["v_render_normals"]), (meta["render_median"], ug6["v_render_median"])])
+        # GS <-> SDF (:420-462): gs_sdf_loss at the visible splats' samples + eikonal at the same (detached) samples
+        vis = meta["visibilities"].detach()
+        w_all = (meta["samples_weights"] * vis).detach()
+        valid = lm.get_valid_mask(meta["samples"].detach()) & (vis > 0.1).squeeze(-1)
+        ids = valid.nonzero().squeeze(-1)
+        if ids.numel() > 0:
+            xs = meta["samples"].index_select(0, ids)
+            loss = loss + 1e-3 * sdfm.gs_sdf_loss(lm.get_sdf(xs)[0], w_all.index_select(0, ids))
+            loss = loss + 0.1 * sdfm.eikonal_loss(lm.get_gradient(xs.detach(), 0.02, None, False, True)[0])
+        loss.backward()
+        opt.step()
+        update_densify_state(gs_state, meta, N, eager=True)
+        sizes.append(int(ids.numel()))
+
+    steps, warm = min(args.steps, 30), min(args.warmup, 5)
+    for i in range(warm):
+        step(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(warm + i)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    return {"metric": "train iters/sec, reference loop body on the drop-in operators with zero source edits (NOT the headline)",
+            "value": steps / el, "unit": "iters/s", "ms_per_step": el / steps * 1e3, "steps": steps, "warmup": warm, "n_gpus": 1,
+            "config": {"workload": args.workload, "sdf_points_per_step": 7 * 32768 + 7 * sum(sizes[-steps:]) / steps,
+                       "what": "drop-in rasterization_2dgs_sdf / TCNNEncoding / TCNNNetwork + eager torch losses, SSIM, activations, "
+                               "numerical get_gradient, update_state, torch.optim.Adam; one stream"}}
 
 
 def _err_stats(got, ref):

@@ -54,7 +54,7 @@ def normalized_quat_to_rotmat(q):   # include/utils/utils.cpp:538-558 (w,x,y,z)
                         2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)], -1).reshape(-1, 3, 3)
 
 
-def update_densify_state(state, info, n, use_absgrad=False, want_radii=False, key_for_gradient="gradient_2dgs"):
+def update_densify_state(state, info, n, use_absgrad=False, want_radii=False, key_for_gradient="gradient_2dgs", eager=False):
     """NeuralGS::update_state (neural_gaussian.cpp:626-680) on a state dict: grad2d / count accumulate, vis / radii take
     the maximum.  Device tensors: ONE launch (include/gsdf_hip.h: gsdf_densify_stats) instead of the reference's ~12
     eager kernels; host tensors (the CPU tests of the refinement policy): the reference's torch expressions."""
@@ -65,7 +65,7 @@ def update_densify_state(state, info, n, use_absgrad=False, want_radii=False, ke
         if k not in state:
             state[k] = torch.zeros(n, device=dev)
     gs_ids = info["gaussian_ids"]
-    if src.is_cuda:
+    if src.is_cuda and not eager:      # eager=True: the reference's own torch expressions on the device (bench.py --reference-loop)
         from . import capi
         capi.check(capi.lib().gsdf_densify_stats(
             gs_ids.shape[0], n, n_cameras, width, height, capi.f32(src.grad.contiguous(), "densify gradient"),
