@@ -17,8 +17,6 @@
 // 16 registers = neurons d_row(r, half)) is the next layer's B operand after a permutation of the K order: k-step s of
 // a 64-wide hidden operand is the 8 registers 8 (s & 1) .. + 7 of accumulator tile s >> 1 from both half-waves; the weights
 // are split once per workgroup into the same order in LDS (one conflict-free ds_read_b128 per A operand).
-#include <utility>
-
 #include "mlp_common.h"
 
 namespace gsdf {
