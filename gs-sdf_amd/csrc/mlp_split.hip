@@ -344,7 +344,7 @@ struct BwdAcc {
   v16f w0[2];                           // layer 0 (input width 32): [o tile]
   v16f wh[NL > 2 ? NL - 2 : 1][2][2];   // layers 1 .. NL-2: [o tile][i tile]
   v16f wl[2];                           // last layer (outputs padded to 32): [i tile]
-  v16f b[2];                            // bias sums: [o tile], column l = layer l
+  v16f b;                               // bias sums: column l = output tile 0 of layer l, column 8 + l = tile 1
 };
 
 struct BwdCtx {
@@ -479,15 +479,15 @@ __device__ __forceinline__ void bwd_layer(const BwdCtx &c, const SplitLds &sl, B
   }
 
   // ---- phase 2
-  if (BIAS) {
-    const uint32_t one = (lane & 31) == L ? 0x3f803f80u : 0u;
-    const uint4 oh = make_uint4(one, one, one, one);
+  if (BIAS) {   // ONE shared tile: column L collects the sums of output tile 0 of layer L, column 8 + L those of tile 1
+    const uint32_t one0 = (lane & 31) == L ? 0x3f803f80u : 0u, one1 = (lane & 31) == 8 + L ? 0x3f803f80u : 0u;
+    const uint4 oh[2] = {make_uint4(one0, one0, one0, one0), make_uint4(one1, one1, one1, one1)};
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
       for (int j = 2; j >= 0; --j)
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) acc.b[mt] = mfma_bf16(at[mt][ks].s[j], oh, acc.b[mt]);
+        for (int mt = 0; mt < MT; ++mt) acc.b = mfma_bf16(at[mt][ks].s[j], oh[mt], acc.b);
   }
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
@@ -568,7 +568,7 @@ __global__ void __launch_bounds__(SPLIT_BWD_THREADS) __attribute__((amdgpu_waves
   for (int r = 0; r < 16; ++r) {
 #pragma unroll
     for (int a = 0; a < 2; ++a) {
-      acc.w0[a][r] = 0.f; acc.wl[a][r] = 0.f; acc.b[a][r] = 0.f;
+      acc.w0[a][r] = 0.f; acc.wl[a][r] = 0.f; acc.b[r] = 0.f;
 #pragma unroll
       for (int l = 0; l < (NL > 2 ? NL - 2 : 1); ++l) { acc.wh[l][a][0][r] = 0.f; acc.wh[l][a][1][r] = 0.f; }
     }
@@ -601,15 +601,16 @@ __global__ void __launch_bounds__(SPLIT_BWD_THREADS) __attribute__((amdgpu_waves
   if (BIAS) {
 #pragma unroll
     for (int l = 0; l < NL; ++l) {
-      if ((lane & 31) != l) continue;
       const int O = l == NL - 1 ? d.d_out : HID;
 #pragma unroll
-      for (int mt = 0; mt < (l == NL - 1 ? 1 : 2); ++mt)
+      for (int mt = 0; mt < (l == NL - 1 ? 1 : 2); ++mt) {
+        if ((lane & 31) != 8 * mt + l) continue;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int o = 32 * mt + d_row(r, lane >> 5);
-          if (o < O) atomicAdd(v_b + d.b_off[l] + o, acc.b[mt][r]);
+          if (o < O) atomicAdd(v_b + d.b_off[l] + o, acc.b[r]);
         }
+      }
     }
   }
 }

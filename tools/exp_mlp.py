@@ -9,6 +9,9 @@ nl = len(dims) - 1; dims_c = (C.c_int * len(dims))(*dims)
 g = torch.Generator().manual_seed(0)
 W = (torch.randn(sum(i * o for i, o in zip(dims[:-1], dims[1:])), generator=g) * 0.2).to(dev)
 x = torch.randn(B, 32, generator=g).to(dev); out = torch.empty(B, 2, device=dev)
+bias = (torch.randn(sum(dims[1:]), generator=g) * 0.1).to(dev) if os.environ.get("EXP_BIAS", "0") == "1" else None
+v_b2 = torch.zeros_like(bias) if bias is not None else None
+fb_ = lambda t: capi.f32(t) if t is not None else None
 acts = torch.empty(L.gsdf_mlp_acts_floats(B, nl), device=dev); ws = torch.empty(L.gsdf_mlp_bwd_ws_bytes(B, nl), dtype=torch.uint8, device=dev)
 v_out = torch.randn(B, 2, generator=g).to(dev); v_in = torch.empty_like(x); v_w = torch.zeros_like(W)
 def t(fn, reps=5):
@@ -24,8 +27,9 @@ fl = 2 * sum(i * o for i, o in zip(dims[:-1], dims[1:])) * B / 1e9
 print(f"B={B} dims={dims} MFMA={os.environ.get('GSDF_MLP_MFMA','bf16x3')}: fwd {f:.3f} ms ({fl/f:.0f} TF/s) fwd(no acts) {fi:.3f} bwd_data {bd:.3f} ({fl/bd:.0f}) bwd_weights {bw:.3f} ({fl/bw:.0f})", flush=True)
 # one-pass backward (both gradients) against the two fp32-pipe kernels on the same saved activations
 v_w2 = torch.zeros_like(W); v_in2 = torch.empty_like(x)
-capi.check(L.gsdf_mlp_fwd(B, nl, dims_c, capi.f32(W), None, capi.f32(x), capi.f32(out), capi.f32(acts), capi.stream()), "f")
-fb = t(lambda: capi.check(L.gsdf_mlp_bwd(B, nl, dims_c, capi.f32(W), None, capi.f32(x), capi.f32(acts), capi.f32(v_out), capi.f32(v_in2), capi.f32(v_w2), None, capi.ptr(ws), capi.stream()), "b"))
+capi.check(L.gsdf_mlp_fwd(B, nl, dims_c, capi.f32(W), fb_(bias), capi.f32(x), capi.f32(out), capi.f32(acts), capi.stream()), "f")
+fb = t(lambda: capi.check(L.gsdf_mlp_bwd(B, nl, dims_c, capi.f32(W), fb_(bias), capi.f32(x), capi.f32(acts), capi.f32(v_out), capi.f32(v_in2), capi.f32(v_w2), fb_(v_b2), capi.ptr(ws), capi.stream()), "b"))
+if bias is not None: print(f"(with biases) one-pass backward {fb:.3f} ms")
 v_w2.zero_(); v_w.zero_()
 capi.check(L.gsdf_mlp_bwd(B, nl, dims_c, capi.f32(W), None, capi.f32(x), capi.f32(acts), capi.f32(v_out), capi.f32(v_in2), capi.f32(v_w2), None, capi.ptr(ws), capi.stream()), "b")
 capi.check(L.gsdf_mlp_bwd(B, nl, dims_c, capi.f32(W), None, capi.f32(x), capi.f32(acts), capi.f32(v_out), capi.f32(v_in), None, None, capi.ptr(ws), capi.stream()), "b")
