@@ -331,6 +331,10 @@ def main():
         state["light"] = False
         ops.TIMERS.disable()
 
+    if rank == 0 and os.environ.get("GSDF_BENCH_DUMP_PARAMS"):
+        # debugging / evidence hook (tools/compare_mlp_pipes.py): the parameters after warmup + steps optimizer steps
+        torch.cuda.synchronize()
+        torch.save({"splat": params.flat.detach().cpu(), "sdf": [g.flat.detach().cpu() for g in groups]}, os.environ["GSDF_BENCH_DUMP_PARAMS"])
     if rank == 0:
         M, I, n_gs = avg["M"], avg["I"], avg.get("n_gs_sdf", 0.0)        # means over the timed steps (views differ per step)
         P, T = W * H, ((W + 15) // 16) * ((H + 15) // 16)
