@@ -84,6 +84,7 @@ PYBIND11_MODULE(_gsdf_host, m) {
         return std::make_shared<TCNNEncoding>(3, cfg, "encoder_test");
       }))
       .def("forward", &TCNNEncoding::forward)
+      .def("forward_stencil", &TCNNEncoding::forward_stencil)
       .def("get_out_dim", &TCNNEncoding::get_out_dim)
       .def_readwrite("params_", &TCNNEncoding::params_);
   py::class_<TCNNNetwork, std::shared_ptr<TCNNNetwork>>(m, "TCNNNetwork")

@@ -11,18 +11,18 @@ using torch::autograd::tensor_list;
 
 namespace {
 
-struct GridCfg { int L, F, H, R; float S; };
+struct GridCfg { int L, F, H, R; float S; int64_t stencil_n = 0; int merge_levels = 0; };   // stencil_n > 0: forward_stencil batches
 GridCfg cfg_of(const c10::IValue &v) {
   auto t = v.toIntVector();
   float s;
   int32_t bits = (int32_t)t[4];
   std::memcpy(&s, &bits, 4);
-  return {(int)t[0], (int)t[1], (int)t[2], (int)t[3], s};
+  return {(int)t[0], (int)t[1], (int)t[2], (int)t[3], s, t.size() > 5 ? t[5] : 0, t.size() > 6 ? (int)t[6] : 0};
 }
 std::vector<int64_t> cfg_pack(const GridCfg &c) {
   int32_t bits;
   std::memcpy(&bits, &c.S, 4);
-  return {c.L, c.F, c.H, c.R, bits};
+  return {c.L, c.F, c.H, c.R, bits, c.stencil_n, c.merge_levels};
 }
 
 // (v_feat, x, table) -> (v_x, v_table): the encoding's backward as a differentiable op (grad of grad)
@@ -40,7 +40,8 @@ struct GridBwd : public torch::autograd::Function<GridBwd> {
       Tensor ws = empty_like_opts(x, {(int64_t)binned}, torch::kUInt8);
       check(gsdf_hashgrid_bwd(B, c.L, c.F, c.H, c.R, c.S, fp(x), fp(table), fp(v_feat), nullptr, fpm(v_x), cur_stream()),
             "TCNNEncoding backward");
-      check(gsdf_hashgrid_bwd_binned(B, c.L, c.F, c.H, c.R, c.S, fp(x), fp(v_feat), fpm(v_table), ws.data_ptr(), binned, cur_stream()),
+      check(gsdf_hashgrid_bwd_binned_stencil(B, c.stencil_n * 7 == B ? c.stencil_n : 0, c.merge_levels, c.L, c.F, c.H, c.R, c.S, fp(x),
+                                             fp(v_feat), fpm(v_table), ws.data_ptr(), binned, cur_stream()),
             "TCNNEncoding backward (binned scatter)");
     } else {
       check(gsdf_hashgrid_bwd(B, c.L, c.F, c.H, c.R, c.S, fp(x), fp(table), fp(v_feat), fpm(v_table), fpm(v_x), cur_stream()),
@@ -76,7 +77,11 @@ struct GridFwd : public torch::autograd::Function<GridFwd> {
     Tensor x = f32c(x_, "x"), table = f32c(table_, "params");
     const int64_t B = x.size(0);
     Tensor feat = empty_like_opts(x, {B, (int64_t)c.L * c.F}, torch::kFloat32);
-    check(gsdf_hashgrid_fwd(B, c.L, c.F, c.H, c.R, c.S, fp(x), fp(table), fpm(feat), cur_stream()), "TCNNEncoding forward");
+    if (c.stencil_n > 0 && c.stencil_n * 7 == B)
+      check(gsdf_hashgrid_fwd_stencil(B, c.stencil_n, 0, c.L, c.F, c.H, c.R, c.S, fp(x), fp(table), fpm(feat), nullptr, cur_stream()),
+            "TCNNEncoding forward (stencil batch)");
+    else
+      check(gsdf_hashgrid_fwd(B, c.L, c.F, c.H, c.R, c.S, fp(x), fp(table), fpm(feat), cur_stream()), "TCNNEncoding forward");
     ctx->save_for_backward({x, table});
     ctx->saved_data["cfg"] = cfgv;
     return feat;
@@ -158,6 +163,17 @@ torch::Tensor TCNNEncoding::forward(const torch::Tensor &x) {
               "(unused by the reference's training path)");
   TORCH_CHECK(x.dim() == 2 && x.size(1) == 3, "TCNNEncoding::forward: expected [B,3]");
   return GridFwd::apply(x, params_.view({-1, n_feat_}), cfg_pack({n_levels_, n_feat_, log2_hashmap_, base_res_, per_level_scale_}));
+}
+
+torch::Tensor TCNNEncoding::forward_stencil(const torch::Tensor &x, int64_t n_groups, double delta_unit) {
+  TORCH_CHECK(x.dim() == 2 && x.size(1) == 3 && n_groups >= 0 && x.size(0) == 7 * n_groups,
+              "TCNNEncoding::forward_stencil: expected [7 * n_groups, 3]");
+  GridCfg c{n_levels_, n_feat_, log2_hashmap_, base_res_, per_level_scale_};
+  c.stencil_n = n_groups;
+  // the coarse levels at which the +-delta points usually share the base point's cell: scale_l * delta < 1
+  for (int l = 0; l < n_levels_; ++l)
+    if ((base_res_ * std::pow((double)per_level_scale_, l) - 1.0) * delta_unit < 1.0) ++c.merge_levels;
+  return GridFwd::apply(x, params_.view({-1, n_feat_}), cfg_pack(c));
 }
 
 TCNNNetwork::TCNNNetwork(int n_input_dims, int n_output_dims, const nlohmann::json &config, const std::string &name)

@@ -19,6 +19,12 @@ struct TCNNEncoding {
 
   void init_encoding(int n_input_dims, const nlohmann::json &config, const std::string &name);
   torch::Tensor forward(const torch::Tensor &x);
+  // NOT in the reference's interface (used by the gsdf_extras edits of INTEGRATION.md section 5): x = n base rows followed by the
+  // 6 blocks of n central-difference rows that gsdf_extras::query_points(..., with_stencil = true) writes (LocalMap::get_gradient's
+  // numerical branch, local_map.cpp:110-150), delta_unit = the stencil offset in unit-cube coordinates.  Same features and
+  // gradients as forward(x); the 7 rows of a group are gathered together and the table-gradient scatter merges the rows that
+  // share a grid cell.
+  torch::Tensor forward_stencil(const torch::Tensor &x, int64_t n_groups, double delta_unit);
   virtual size_t get_out_dim() const { return (size_t)n_levels_ * n_feat_; }
 
   torch::Tensor params_;

@@ -106,6 +106,30 @@ def test_tcnn_objects_first_and_second_order(host, oracle):
     assert_close(net.params_.grad, v_w, 1e-4, "mlp v_w", outlier_frac=1e-5, outlier_rel=5e-2)
 
 
+def test_cpp_encoding_forward_stencil_equals_forward(host):
+    """TCNNEncoding::forward_stencil (extension for the gsdf_extras edits): same features bit for bit, same gradients as
+    forward() on the 7-row stencil batches of get_gradient's numerical branch — group-walking forward, stencil-merging scatter."""
+    dev = torch.device("cuda:0")
+    enc = host.TCNNEncoding(16, 2, 19, 32, 2.0)
+    g = torch.Generator().manual_seed(3)
+    enc.params_ = (torch.rand(enc.params_.numel(), generator=g) * 2 - 1).to(dev).requires_grad_(True)
+    n_grp, delta = 6000, 0.02 / 16.0
+    base = torch.rand(n_grp, 3, generator=g) * 0.8 + 0.1
+    offs = torch.tensor([[0, 0, 0], [delta, 0, 0], [-delta, 0, 0], [0, delta, 0], [0, -delta, 0], [0, 0, delta], [0, 0, -delta]])
+    x = (base[None] + offs[:, None]).reshape(-1, 3).contiguous().to(dev)
+    v = torch.randn(7 * n_grp, 32, generator=g).to(dev)
+    res = []
+    for stencil in (False, True):
+        xd = x.clone().requires_grad_(True)
+        feat = enc.forward_stencil(xd, n_grp, delta) if stencil else enc.forward(xd)
+        res.append((feat.detach(), torch.autograd.grad(feat, (xd, enc.params_), v)))
+    assert torch.equal(res[0][0], res[1][0])
+    assert torch.equal(res[0][1][0], res[1][1][0])                     # d/dx: the same kernel
+    assert_close(res[1][1][1], res[0][1][1], 5e-5, "table gradient, stencil-merged vs plain binned scatter")
+    with pytest.raises(RuntimeError):
+        enc.forward_stencil(x, n_grp + 1, delta)
+
+
 @pytest.mark.parametrize("N", [1, 2, 3, 4, 5000, 200_000])
 def test_distCUDA2(host, oracle, N):
     import gs_sdf_amd.ops as ops
