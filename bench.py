@@ -408,6 +408,12 @@ def main():
                                               "fp32 accumulate: error against fp64 equal to the fp32 MFMA's (tools/ubench/mfma_split.hip)"
                                               if split_mlp_cfg else "fp32 MFMA")},
             "roofline": dict(roof(dom), kernel=dom, traffic=traffic, avg_launch_ms=dur_ms, median_launch_ms=kern.get(dom),
+                             # what the kernel actually moves (PMC FETCH_SIZE + WRITE_SIZE of a single-stream run, profiles/) over its
+                             # launch time measured here: how hard it drives HBM, next to `frac` (= algorithmic bytes only).  The binned
+                             # scatter trades 2.6x more, fully coalesced, bytes for not using the 21 G/s fp32 atomic units; in the
+                             # overlapped step its launches share HBM with the other leg's kernels
+                             traffic_GBps=(None if not traffic or not dur_ms else traffic / (dur_ms * 1e-3) / 1e9),
+                             traffic_frac_of_hbm_peak=(None if not traffic or not dur_ms else traffic / (dur_ms * 1e-3) / 8e12),
                              launches_per_step=calls.get(dom, 0) / args.steps,
                              timing="HIP events on the launch stream over the timed steps; mean launch (operators with unequal launches)",
                              ms_per_step_by_kernel={k: round(v, 4) for k, v in per_step.items()},
