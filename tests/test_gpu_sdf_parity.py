@@ -90,6 +90,8 @@ def _near_relu_kink(x, dims, W, b, eps=1e-5):
                                          ([64, 64, 64, 16], True, 77),               # fp32-pipe kernels (input width 64)
                                          ([32, 64, 64, 64, 3], True, 4099),          # one-pass backward, 4 layers with biases
                                          ([32, 64, 64, 64, 64, 20], False, 1000),    # ... 5 layers, outputs in both k-steps of the last layer
+                                         ([32, 64, 64, 64, 16], False, 300),         # widest output the one-pass backward takes
+                                         ([32, 64, 64, 64, 64, 17], True, 300),      # one more: fp32-pipe backward, split forward
                                          ([32, 64, 64, 64, 2], False, 1),
                                          ([32, 64, 64, 64, 64, 2], True, 33)])
 def test_fused_mlp_fwd_bwd(sdf, oracle, dims, bias, B):
