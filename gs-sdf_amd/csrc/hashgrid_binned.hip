@@ -353,7 +353,8 @@ __global__ void __launch_bounds__(PTS * G)
       s_g1[p] = g1[k];
     }
   }
-  if (mine) s_dst[t] = start[b0 + t] + (int64_t)reserved;
+  // destination of sorted position p in bucket b: s_dst[b] + p  (s_dst already net of the bucket's first position in LDS)
+  if (mine) s_dst[t] = start[b0 + t] + (int64_t)reserved - (int64_t)s_off[t];
   __syncthreads();
   // pass 3: runs to the global buckets; consecutive lanes write consecutive 12-byte records
   for (uint32_t p = t; p < n_rec; p += BIN_EMIT_THREADS) {
@@ -362,7 +363,7 @@ __global__ void __launch_bounds__(PTS * G)
     r.key = kb & 0xFFFFu;
     r.g0 = s_g0[p];
     r.g1 = s_g1[p];
-    records[s_dst[bucket] + (int64_t)(p - s_off[bucket])] = r;
+    records[s_dst[bucket] + (int64_t)p] = r;
   }
 }
 
