@@ -5,6 +5,8 @@
 //   query_points         SubMap::xyz_to_zp1_pts (+ the 6-point stencil of LocalMap::get_gradient)  sub_map.cpp:82-97, local_map.cpp:110-124
 //   sdf_ray_loss         loss::sdf_loss + w * loss::eikonal_loss(numerical gradient)          neural_mapping.cpp:138-188, loss.cpp:49-83
 //   gs_sdf_eik_loss      k_gs_sdf_weight * loss::gs_sdf_loss + k_eikonal_weight * eikonal on the splat samples   :436-457
+//   gs_sdf_coupling      the whole GS<->SDF block as ONE autograd node: samples -> get_sdf -> gs_sdf_loss (+ eikonal on the
+//                        numerical gradient at samples.detach()), encoder / decoder gradients accumulated in place   :420-462
 //   update_state         NeuralGS::update_state                                               neural_gaussian.cpp:626-680
 //   splat_activations    NeuralGS::generate_gaussian's exp / sigmoid / anchors + offsets      neural_gaussian.cpp:463-492
 //   FusedAdam            torch::optim::Adam::step over flat (parameter, gradient) buffers     neural_mapping.cpp:466-469
@@ -14,6 +16,9 @@
 #include <map>
 #include <string>
 #include <vector>
+
+struct TCNNEncoding;
+struct TCNNNetwork;
 
 namespace gsdf_extras {
 
@@ -30,6 +35,17 @@ torch::Tensor sdf_ray_loss(const torch::Tensor &attr, const torch::Tensor &gt_sd
 // attr [(7 or 1) n, >=1]; weights [M] (or [M,1]); ids int64 [n] (undefined: weights is [n]) -> scalar; d/d attr
 torch::Tensor gs_sdf_eik_loss(const torch::Tensor &attr, const torch::Tensor &weights, const torch::Tensor &ids, int64_t n, double scale,
                               double delta, double w_eik);
+
+// The GS<->SDF coupling of the joint iteration (neural_mapping.cpp:420-462) as one node: rows `ids` of `samples` [M,3] ->
+// query_points (+ 6-point stencil when delta > 0) -> encoder (group-walking forward) -> decoder -> scale * gs_sdf_loss
+// (+ w_eik * eikonal_loss(numerical gradient at the detached samples)).  backward(): d loss / d samples is returned to autograd;
+// the encoder's table gradient and the decoder's weight gradient are ACCUMULATED IN PLACE into `table_grad` / `decoder_grad`
+// (fp32, same shapes as enc.params_ / dec.params_, e.g. views of the flat gradient buffer FusedAdam reads; zero them per
+// step) — one one-pass decoder backward, one Jacobian contraction, one binned stencil-merging scatter, no autograd adds.
+// `weights` = samples_weights * visibilities, [M] or [M,1].  Bias-free decoder (TCNNNetwork).
+torch::Tensor gs_sdf_coupling(const torch::Tensor &samples, const torch::Tensor &ids, const torch::Tensor &weights, ::TCNNEncoding &enc,
+                              ::TCNNNetwork &dec, const std::vector<float> &map_origin, double map_size_inv, double scale, double delta,
+                              double w_eik, torch::Tensor table_grad, torch::Tensor decoder_grad);
 
 // state: "grad2d","count","vis"[,"radii"] created on first use; info as NeuralGS::render returns it
 void update_state(std::map<std::string, torch::Tensor> &state, const torch::Tensor &densify_grad, const torch::Tensor &gaussian_ids,

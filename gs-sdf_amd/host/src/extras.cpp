@@ -1,5 +1,6 @@
 // extras.cpp — gsdf_extras/gsdf_extras.h over the C ABI (include/gsdf_hip.h sections O2, S3, a2, a8, O1).
 #include "gsdf_extras/gsdf_extras.h"
+#include "tcnn_binding/tcnn_binding.h"
 
 #include <cmath>
 
@@ -121,6 +122,94 @@ Tensor gs_sdf_eik_loss(const Tensor &attr_, const Tensor &weights, const Tensor 
                              (float)scale, (float)delta, (float)w_eik, fpm(loss), fpm(v_attr), cur_stream()),
         "gs_sdf_eik_loss");
   return ValueAndGrad::apply(attr_, loss, v_attr);
+}
+
+namespace {
+struct CouplingCfg { int L, F, H, R; float S; std::vector<int> dims; float origin[3]; double map_size_inv, scale, delta, w_eik; };
+// autograd contexts carry IValues only: the configuration travels as an int list + a double list
+CouplingCfg coupling_cfg(const std::vector<int64_t> &iv, const std::vector<double> &dv) {
+  CouplingCfg c;
+  c.L = (int)iv[0]; c.F = (int)iv[1]; c.H = (int)iv[2]; c.R = (int)iv[3];
+  c.dims.assign(iv.begin() + 4, iv.end());
+  c.S = (float)dv[0];
+  for (int d = 0; d < 3; ++d) c.origin[d] = (float)dv[1 + d];
+  c.map_size_inv = dv[4]; c.scale = dv[5]; c.delta = dv[6]; c.w_eik = dv[7];
+  return c;
+}
+
+// neural_mapping.cpp:420-462 as one node (Python mirror: gs_sdf_amd/sdf.py _CouplingLeg)
+struct CouplingFn : public torch::autograd::Function<CouplingFn> {
+  static Tensor forward(AutogradContext *ctx, const Tensor &samples, const Tensor &ids_, const Tensor &weights, const Tensor &table_,
+                        const Tensor &W_, Tensor table_grad, Tensor decoder_grad, std::vector<int64_t> iv, std::vector<double> dv) {
+    const CouplingCfg c = coupling_cfg(iv, dv);
+    Tensor ids = ids_.contiguous(), table = f32c(table_.detach(), "encoder params"), W = f32c(W_.detach(), "decoder params");
+    Tensor xs = f32c(samples.detach().index_select(0, ids), "samples");
+    const int64_t n = xs.size(0), K = c.delta > 0 ? 7 : 1, nq = K * n;
+    const int nf = c.L * c.F, nl = (int)c.dims.size() - 1;
+    Tensor x01 = empty_like_opts(xs, {nq, 3}, torch::kFloat32);
+    check(gsdf_sdf_query_points(n, K == 7, fp(xs), (float)c.delta, c.origin, (float)c.map_size_inv, fpm(x01), cur_stream()), "sdf_query_points");
+    Tensor feat = empty_like_opts(xs, {nq, nf}, torch::kFloat32), jac = empty_like_opts(xs, {n, nf, 3}, torch::kFloat32);
+    if (K == 7 && n > 0)
+      check(gsdf_hashgrid_fwd_stencil(nq, n, n, c.L, c.F, c.H, c.R, c.S, fp(x01), fp(table), fpm(feat), fpm(jac), cur_stream()), "hashgrid_fwd_stencil");
+    else
+      check(gsdf_hashgrid_fwd_jac_rows(nq, n, c.L, c.F, c.H, c.R, c.S, fp(x01), fp(table), fpm(feat), fpm(jac), cur_stream()), "hashgrid_fwd_jac");
+    Tensor attr = empty_like_opts(xs, {nq, (int64_t)c.dims.back()}, torch::kFloat32);
+    Tensor acts = empty_like_opts(xs, {(int64_t)gsdf_mlp_acts_floats(nq, nl)}, torch::kFloat32);
+    check(gsdf_mlp_fwd(nq, nl, c.dims.data(), fp(W), nullptr, fp(feat), fpm(attr), fpm(acts), cur_stream()), "mlp_fwd");
+    Tensor loss = empty_like_opts(xs, {}, torch::kFloat32), v_attr = torch::empty_like(attr);
+    Tensor w = f32c(weights.detach().reshape({-1}), "weights");
+    check(gsdf_gs_sdf_eik_loss(n, K == 7, fp(attr), (int)attr.size(1), fp(w), ids.data_ptr<int64_t>(), (float)c.scale, (float)c.delta,
+                               (float)c.w_eik, fpm(loss), fpm(v_attr), cur_stream()), "gs_sdf_eik_loss");
+    ctx->save_for_backward({ids, x01, feat, jac, acts, v_attr, table, W, table_grad, decoder_grad});
+    ctx->saved_data["n_rows"] = samples.size(0);
+    ctx->saved_data["iv"] = iv;
+    ctx->saved_data["dv"] = dv;
+    return loss;
+  }
+  static tensor_list backward(AutogradContext *ctx, tensor_list g) {
+    auto s = ctx->get_saved_variables();
+    const Tensor &ids = s[0], &x01 = s[1], &feat = s[2], &jac = s[3], &acts = s[4], &v_attr = s[5], &table = s[6], &W = s[7];
+    Tensor table_grad = s[8], decoder_grad = s[9];
+    const CouplingCfg c = coupling_cfg(ctx->saved_data["iv"].toIntVector(), ctx->saved_data["dv"].toDoubleVector());
+    const int64_t nq = x01.size(0), n = jac.size(0);
+    const int nl = (int)c.dims.size() - 1;
+    Tensor v_out = (v_attr * g[0]).contiguous(), v_feat = torch::empty_like(feat);
+    Tensor ws = empty_like_opts(feat, {(int64_t)gsdf_mlp_bwd_ws_bytes_for(nq, nl, c.dims.data(), 1)}, torch::kUInt8);
+    check(gsdf_mlp_bwd(nq, nl, c.dims.data(), fp(W), nullptr, fp(feat), fp(acts), fp(v_out), fpm(v_feat), fpm(decoder_grad), nullptr,
+                       ws.data_ptr(), cur_stream()), "mlp_bwd");
+    Tensor v_x = empty_like_opts(feat, {n, 3}, torch::kFloat32);
+    check(gsdf_hashgrid_bwd_jac(n, c.L, c.F, fp(jac), fp(v_feat), fpm(v_x), cur_stream()), "hashgrid_bwd_jac");
+    if (nq >= 24576) {
+      int merge = 0;
+      for (int l = 0; l < c.L; ++l)
+        if ((c.R * std::pow((double)c.S, l) - 1.0) * c.delta * c.map_size_inv < 1.0) ++merge;
+      const size_t nb = gsdf_hashgrid_bwd_binned_ws_bytes(nq, c.L, c.F, c.H, c.R, c.S);
+      Tensor bws = empty_like_opts(feat, {(int64_t)nb}, torch::kUInt8);
+      check(gsdf_hashgrid_bwd_binned_stencil(nq, nq == 7 * n ? n : 0, merge, c.L, c.F, c.H, c.R, c.S, fp(x01), fp(v_feat), fpm(table_grad),
+                                             bws.data_ptr(), nb, cur_stream()), "hashgrid_bwd_binned_stencil");
+    } else if (nq > 0) {
+      check(gsdf_hashgrid_bwd(nq, c.L, c.F, c.H, c.R, c.S, fp(x01), fp(table), fp(v_feat), fpm(table_grad), nullptr, cur_stream()), "hashgrid_bwd");
+    }
+    Tensor v_samples = torch::zeros({ctx->saved_data["n_rows"].toInt(), 3}, feat.options());
+    v_samples.index_add_(0, ids, v_x * c.map_size_inv);          // d x01 / d xyz = 0.5 * 2 * map_size_inv
+    return {v_samples, Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor()};
+  }
+};
+}  // namespace
+
+Tensor gs_sdf_coupling(const Tensor &samples, const Tensor &ids, const Tensor &weights, ::TCNNEncoding &enc, ::TCNNNetwork &dec,
+                       const std::vector<float> &origin, double map_size_inv, double scale, double delta, double w_eik, Tensor table_grad,
+                       Tensor decoder_grad) {
+  TORCH_CHECK(origin.size() == 3, "gs_sdf_coupling: map_origin needs 3 entries");
+  TORCH_CHECK(samples.dim() == 2 && samples.size(1) == 3 && ids.scalar_type() == torch::kInt64, "gs_sdf_coupling: samples [M,3], ids int64");
+  TORCH_CHECK(table_grad.defined() && table_grad.numel() == enc.params_.numel() && table_grad.is_contiguous() &&
+                  decoder_grad.defined() && decoder_grad.numel() == dec.params_.numel() && decoder_grad.is_contiguous() &&
+                  table_grad.scalar_type() == torch::kFloat32 && decoder_grad.scalar_type() == torch::kFloat32,
+              "gs_sdf_coupling: table_grad / decoder_grad must be contiguous fp32 buffers shaped like the parameters");
+  std::vector<int64_t> iv = {enc.n_levels_, enc.n_feat_, enc.log2_hashmap_, enc.base_res_};
+  iv.insert(iv.end(), dec.dims_.begin(), dec.dims_.end());
+  std::vector<double> dv = {enc.per_level_scale_, origin[0], origin[1], origin[2], map_size_inv, scale, delta, w_eik};
+  return CouplingFn::apply(samples, ids, weights, enc.params_, dec.params_, table_grad, decoder_grad, iv, dv);
 }
 
 void update_state(std::map<std::string, Tensor> &state, const Tensor &densify_grad, const Tensor &gaussian_ids, const Tensor &visibilities,

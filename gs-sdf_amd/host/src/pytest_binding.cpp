@@ -76,6 +76,12 @@ PYBIND11_MODULE(_gsdf_host, m) {
       })
       .def("get_quantized_points", &OctreeAS::get_quantized_points)
       .def_readonly("grid_", &OctreeAS::grid_);
+  m.def("gs_sdf_coupling", [](const torch::Tensor &samples, const torch::Tensor &ids, const torch::Tensor &weights,
+                              std::shared_ptr<TCNNEncoding> enc, std::shared_ptr<TCNNNetwork> dec, std::vector<float> origin,
+                              double map_size_inv, double scale, double delta, double w_eik, torch::Tensor table_grad,
+                              torch::Tensor decoder_grad) {
+    return gsdf_extras::gs_sdf_coupling(samples, ids, weights, *enc, *dec, origin, map_size_inv, scale, delta, w_eik, table_grad, decoder_grad);
+  });
   py::class_<TCNNEncoding, std::shared_ptr<TCNNEncoding>>(m, "TCNNEncoding")
       .def(py::init([](int n_levels, int n_feat, int log2_hashmap, int base_res, double pls) {
         nlohmann::json cfg = {{"otype", "Grid"}, {"type", "Hash"}, {"n_levels", n_levels}, {"n_features_per_level", n_feat},

@@ -130,6 +130,41 @@ def test_cpp_encoding_forward_stencil_equals_forward(host):
         enc.forward_stencil(x, n_grp + 1, delta)
 
 
+@pytest.mark.parametrize("delta,n", [(0.02, 4000), (0.0, 4000), (0.02, 2000)])      # 7 x 4000 rows: binned stencil scatter; 7 x 2000: atomic
+def test_cpp_gs_sdf_coupling_node_matches_python_mirror(host, delta, n):
+    """gsdf_extras::gs_sdf_coupling (the GS<->SDF block of neural_mapping.cpp:420-462 as one C++ autograd node with in-place
+    parameter-gradient accumulation) == LocalMap.gs_sdf_coupling of the Python mirror: loss, d/d samples, table and decoder gradients."""
+    import gs_sdf_amd.sdf as sdf
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(6)
+    M = 9000
+    pts = ((torch.rand(M, 3, generator=g) - 0.5) * 6.0).to(dev)
+    w_all = torch.rand(M, 1, generator=g).to(dev)
+    ids = torch.randperm(M, generator=g)[:n].sort().values.to(dev)
+    lm = sdf.LocalMap([0.1, 0.2, -0.3], 8.0, decoder_implementation=1, device=dev, seed=9)
+    with torch.no_grad():
+        lm.encoder.params_.mul_(1e3)
+    enc = host.TCNNEncoding(16, 2, 19, 32, 2.0)
+    enc.params_ = lm.encoder.params_.detach().clone()
+    dec = host.TCNNNetwork(32, 2, 64, 3)
+    dec.params_ = lm.decoder.params_.detach().clone()
+    t_grad, d_grad = torch.zeros_like(enc.params_), torch.zeros_like(dec.params_)
+    xc = pts.clone().requires_grad_(True)
+    loss_c = host.gs_sdf_coupling(xc, ids, w_all, enc, dec, [float(v) for v in lm._origin], float(lm.map_size_inv), 1e-3, delta, 0.1 if delta else 0.0,
+                                  t_grad, d_grad)
+    loss_c.backward()
+    grp = lm.flatten(accumulate_table_grad_in_place=True)
+    xp = pts.clone().requires_grad_(True)
+    loss_p = lm.gs_sdf_coupling(xp, ids, w_all, 1e-3, delta if delta else None, 0.1 if delta else 0.0)
+    with sdf.grad_sinks_armed():
+        loss_p.backward()
+    assert_close(loss_c, loss_p, 1e-5, "loss")
+    assert_close(xc.grad, xp.grad, 1e-5, "d/d samples")
+    nt = enc.params_.numel()
+    assert_close(t_grad, grp.flat_grad[:nt], 1e-4 if delta else 1e-5, "table gradient (in place)")
+    assert_close(d_grad, grp.flat_grad[nt:nt + d_grad.numel()], 1e-4, "decoder gradient (in place)")   # fp32 atomics: launch-to-launch order
+
+
 @pytest.mark.parametrize("N", [1, 2, 3, 4, 5000, 200_000])
 def test_distCUDA2(host, oracle, N):
     import gs_sdf_amd.ops as ops
