@@ -50,6 +50,9 @@ def main():
     ap.add_argument("--light-step", action="store_true", help="round-1 step: no GS-sample eikonal regulariser, no per-iteration "
                                                                "update_state (NOT the reference's joint iteration)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the second (light-step) timing loop")
+    ap.add_argument("--cpp-step", action="store_true",
+                    help="time gsdf_extras::JointIteration (the same joint iteration in C++/libtorch over libgsdf_torch.so, one stream, driven "
+                         "through the pybind test harness): the step the reference's node reaches with the INTEGRATION.md section 5 edits")
     ap.add_argument("--reference-loop", action="store_true",
                     help="time the loop body as neural_mapping_node would run it linked against the drop-in submodules with ZERO "
                          "source edits: the drop-in operators (rasterization_2dgs_sdf, TCNNEncoding, TCNNNetwork) composed with "
@@ -95,6 +98,9 @@ def main():
     target = torch.rand(H, W, 3, generator=torch.Generator().manual_seed(3)).to(dev)    # target image U(0,1) seed 3
     if args.reference_loop:
         print(json.dumps(reference_loop(args, sc, views, K, ug6, target, N, W, H, deg, dev)), flush=True)
+        return
+    if args.cpp_step:
+        print(json.dumps(cpp_step(args, sc, views, K, ug6, target, N, W, H, deg, dev)), flush=True)
         return
     groups = []
     if not args.no_sdf:
@@ -443,12 +449,57 @@ def main():
                 out["reference_loop_zero_edits"] = reference_loop(args, sc, views, K, ug6, target, N, W, H, deg, dev)
             except Exception as e:      # never let the extra line take the headline down
                 out["reference_loop_zero_edits"] = {"error": repr(e)[:300]}
+            # third line: the same joint iteration in C++/libtorch (gsdf_extras::JointIteration over libgsdf_torch.so, one stream)
+            try:
+                import copy
+                a2 = copy.copy(args)
+                a2.steps, a2.warmup, a2.dump_grads = min(args.steps, 40), min(args.warmup, 5), None
+                out["cpp_joint_iteration"] = cpp_step(a2, sc, views, K, ug6, target, N, W, H, deg, dev)
+            except Exception as e:
+                out["cpp_joint_iteration"] = {"error": repr(e)[:300]}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sc, views, params, N, W, H, deg, 0 if args.no_sdf else int(sdf_pts), dev)
         print(json.dumps(out), flush=True)
     release_streams()
     if dist is not None:
         dist.destroy_process_group()
+
+
+def cpp_step(args, sc, views, K, ug6, target, N, W, H, deg, dev):
+    """gsdf_extras::JointIteration (gs-sdf_amd/host/src/joint_step.cpp) on the bench's scene: the joint iteration in C++/libtorch,
+    same initial parameters, same views, ray batches and op-level gradients as the Python step, one HIP stream."""
+    import gs_sdf_amd.hostlib as hostlib
+    import gs_sdf_amd.sdf as sdfm
+    from gs_sdf_amd.trainer import SplatParams
+    host = hostlib.load()
+    params = SplatParams.from_scene(sc, dev)
+    lm = sdfm.LocalMap([0.0, 0.0, 5.5], 16.0, bce_sigma=0.02, decoder_implementation=1, device=dev, seed=5)
+    enc, dec = host.TCNNEncoding(16, 2, 19, 32, 2.0), host.TCNNNetwork(32, 2, 64, 3)
+    enc.params_, dec.params_ = lm.encoder.params_.detach().clone(), lm.decoder.params_.detach().clone()
+    fields = [params.views[k].detach().clone() for k in ("offsets", "scaling", "quaternion", "opacity", "features_dc", "features_rest")]
+    ji = host.JointIteration(params.anchors, fields, enc, dec, [0.0, 0.0, 5.5], 16.0, 0.02, 8, W, H, deg)   # level 8: 1/16 m leaves in 16 m
+    gq = torch.Generator().manual_seed(4)
+    pool = [((torch.rand(32768, 3, generator=gq) - 0.5) * 14.0 + torch.tensor([0.0, 0.0, 5.5])).to(dev) for _ in range(8)]
+    ray_sdf = [(torch.randn(32768, 1, generator=gq) * 0.02).to(dev) for _ in range(8)]
+    up = [ug6[k] for k in ("v_render_depths", "v_render_alphas", "v_render_normals", "v_render_median")]
+    if args.dump_grads:
+        sizes = ji.step(views[0][None], K, target, pool[0], ray_sdf[0], up, False)
+        torch.cuda.synchronize()
+        torch.save({"splat": ji.splat_flat_grad().cpu(), "sdf": [ji.sdf_flat_grad().cpu()], "sizes": dict(sizes)}, args.dump_grads)
+        return {"dumped": args.dump_grads}
+    n_sdf = []
+    for i in range(args.warmup):
+        ji.step(views[i % views.shape[0]][None], K, target, pool[i % 8], ray_sdf[i % 8], up, True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.warmup, args.warmup + args.steps):
+        n_sdf.append(ji.step(views[i % views.shape[0]][None], K, target, pool[i % 8], ray_sdf[i % 8], up, True)["n_gs_sdf"])
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    return {"metric": "train iters/sec, the joint iteration in C++/libtorch (gsdf_extras::JointIteration, one stream; NOT the headline)",
+            "value": args.steps / el, "unit": "iters/s", "ms_per_step": el / args.steps * 1e3, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": 1, "params_finite": bool(torch.isfinite(ji.splat_flat()).all() and torch.isfinite(ji.sdf_flat()).all()),
+            "config": {"workload": args.workload, "sdf_points_per_step": 7 * 32768 + 7 * sum(n_sdf) / max(1, len(n_sdf))}}
 
 
 def reference_loop(args, sc, views, K, ug6, target, N, W, H, deg, dev):

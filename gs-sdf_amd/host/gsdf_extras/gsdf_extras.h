@@ -10,10 +10,12 @@
 //   update_state         NeuralGS::update_state                                               neural_gaussian.cpp:626-680
 //   splat_activations    NeuralGS::generate_gaussian's exp / sigmoid / anchors + offsets      neural_gaussian.cpp:463-492
 //   FusedAdam            torch::optim::Adam::step over flat (parameter, gradient) buffers     neural_mapping.cpp:466-469
+//   JointIteration       the whole loop body on the above (what bench.py --cpp-step times)     neural_mapping.cpp:400-486
 #pragma once
 #include <torch/torch.h>
 
 #include <map>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -75,6 +77,50 @@ class FusedAdam {
   std::vector<Group> groups_;
   double b1_, b2_, eps_;
   int64_t t_ = 0;
+};
+
+// The loop body of NeuralSLAM::gs_train (neural_mapping.cpp:400-486) in C++ on the drop-in operators + the pieces above
+// (src/joint_step.cpp): per-ray SDF batch, render + 0.8 L1 + 0.2 D-SSIM, GS<->SDF coupling with the eikonal regulariser, backward,
+// update_state, fused Adam.  What `bench.py --cpp-step` times; one HIP stream.
+struct JointConfig {
+  int width = 0, height = 0, sh_degree = 0;
+  float near_plane = 0.05f, far_plane = 300.0f;
+  double rgb_w = 0.8, dssim_w = 0.2;                                   // neural_mapping.cpp:237-240
+  double sdf_delta = 0.02, eik_w = 0.1, gs_sdf_w = 1e-3, vis_thresh = 0.1;   // k_sample_std, k_eikonal_weight, k_gs_sdf_weight, :430-432
+  double lr_offsets = 1.6e-4, lr_scaling = 5e-3, lr_quaternion = 1e-3, lr_opacity = 5e-2, lr_features_dc = 2.5e-3,
+         lr_features_rest = 2.5e-3 / 20, lr_sdf = 1e-4;               // neural_gaussian.cpp:434-453, :619-623
+};
+
+class JointIteration {
+ public:
+  // fields = {offsets [N,3], scaling [N,3] (log), quaternion [N,4], opacity [N] (logit), features_dc [N,3], features_rest [N,3 r]};
+  // enc / dec: their params_ are MOVED into this object's flat SDF buffer (they become views of it).
+  JointIteration(const torch::Tensor &anchors, const std::vector<torch::Tensor> &fields, std::shared_ptr<::TCNNEncoding> enc,
+                 std::shared_ptr<::TCNNNetwork> dec, const std::vector<float> &map_origin, double map_size, double bce_sigma, int occ_level,
+                 const JointConfig &cfg);
+  // one iteration on view (viewmat [1,4,4], K [1,3,3]) against target [H,W,3] with the ray batch (ray_pts [n,3], ray_sdf [n,1]);
+  // upstream: {} or the op-level gradients {v_depth [1,H,W,1], v_alpha [1,H,W,1], v_normal [1,H,W,3], v_median [1,H,W,1]};
+  // update = false leaves the gradients in the flat buffers and skips the optimizers.  Returns {"M","I","n_gs_sdf"}.
+  std::map<std::string, int64_t> step(const torch::Tensor &viewmat, const torch::Tensor &K, const torch::Tensor &target,
+                                      const torch::Tensor &ray_pts, const torch::Tensor &ray_sdf, const std::vector<torch::Tensor> &upstream,
+                                      bool update = true);
+  torch::Tensor splat_flat() const { return flat_; }
+  torch::Tensor splat_flat_grad() const { return flat_grad_; }
+  torch::Tensor sdf_flat() const { return sdf_flat_; }
+  torch::Tensor sdf_flat_grad() const { return sdf_flat_grad_; }
+
+ private:
+  JointConfig cfg_;
+  std::shared_ptr<::TCNNEncoding> enc_;
+  std::shared_ptr<::TCNNNetwork> dec_;
+  std::vector<float> origin_;
+  double map_size_inv_, bce_isigma_;
+  int occ_level_;
+  int64_t n_rest_ = 0;
+  torch::Tensor anchors_, flat_, flat_grad_, sdf_flat_, sdf_flat_grad_, occ_grid_;
+  std::vector<torch::Tensor> views_;
+  std::map<std::string, torch::Tensor> state_;
+  FusedAdam adam_, adam_sdf_;
 };
 
 }  // namespace gsdf_extras

@@ -1,0 +1,185 @@
+// joint_step.cpp — gsdf_extras::JointIteration: the loop body of NeuralSLAM::gs_train
+// (/root/reference/include/neural_mapping/neural_mapping.cpp:400-486) on the drop-in operators and the fused pieces of
+// gsdf_extras, entirely in C++/libtorch: what the reference's node runs after the edits of INTEGRATION.md section 5.
+// Mirrors the step bench.py times (single-stream form): per-ray SDF batch, render + 0.8 L1 + 0.2 D-SSIM, GS<->SDF coupling with
+// the eikonal regulariser, backward, update_state, fused Adam.  The parameters live in two flat buffers (splats; SDF table +
+// decoder), every trainable tensor is a view whose .grad is a view of the matching flat gradient buffer.
+#include <cmath>
+
+#include "gsdf_extras/gsdf_extras.h"
+#include "gsplat_cpp/fully_fused_projection.h"
+#include "gsplat_cpp/rasterize_to_pixels.h"
+#include "gsplat_cpp/rendering.h"
+#include "tcnn_binding/tcnn_binding.h"
+#include "util.h"
+
+using namespace gsdf_host;
+using torch::Tensor;
+using torch::autograd::AutogradContext;
+using torch::autograd::tensor_list;
+
+namespace {
+
+// neural_gaussian.cpp:229-240 in one pass: expected depth, cat(colours, depth), normals to world space (+ the colour / depth slices)
+struct RenderPost : public torch::autograd::Function<RenderPost> {
+  static tensor_list forward(AutogradContext *ctx, const Tensor &rc_, const Tensor &rd_, const Tensor &ra_, const Tensor &rn_,
+                             const Tensor &viewmats_, bool expected_depth) {
+    Tensor rc = f32c(rc_, "render_colors"), rd = f32c(rd_, "render_depths"), ra = f32c(ra_, "render_alphas"), rn = f32c(rn_, "render_normals");
+    Tensor vm = f32c(viewmats_, "viewmats");
+    auto shp = ra.sizes().vec();
+    shp.back() = 4;
+    Tensor renders = empty_like_opts(ra, shp, torch::kFloat32), nw = torch::empty_like(rn), c3 = torch::empty_like(rc), d1 = torch::empty_like(rd);
+    check(gsdf_render_post_fwd(ra.numel(), expected_depth ? 1 : 0, fp(vm), fp(rc), fp(rd), fp(ra), fp(rn), fpm(renders), fpm(nw), fpm(c3), fpm(d1),
+                               cur_stream()), "render_post_fwd");
+    ctx->save_for_backward({rd, ra, vm});
+    ctx->saved_data["ed"] = expected_depth;
+    return {renders, nw, c3, d1};
+  }
+  static tensor_list backward(AutogradContext *ctx, tensor_list g) {
+    auto s = ctx->get_saved_variables();
+    const Tensor &rd = s[0], &ra = s[1], &vm = s[2];
+    auto shp = ra.sizes().vec();
+    shp.back() = 3;
+    Tensor v_rc = empty_like_opts(ra, shp, torch::kFloat32), v_rn = empty_like_opts(ra, shp, torch::kFloat32);
+    Tensor v_rd = torch::empty_like(ra), v_ra = torch::empty_like(ra);
+    auto opt = [](const Tensor &t) { return t.defined() ? t.contiguous() : Tensor(); };
+    Tensor g0 = opt(g[0]), g1 = opt(g[1]), g2 = opt(g[2]), g3 = opt(g[3]);
+    check(gsdf_render_post_bwd(ra.numel(), ctx->saved_data["ed"].toBool() ? 1 : 0, fp(vm), fp(rd), fp(ra), fp(g0), fp(g1), fp(g2), fp(g3),
+                               fpm(v_rc), fpm(v_rd), fpm(v_ra), fpm(v_rn), cur_stream()), "render_post_bwd");
+    return {v_rc, v_rd, v_ra, v_rn, Tensor(), Tensor()};
+  }
+};
+
+// scalar 0 whose backward delivers fixed upstream gradients to the given tensors (op-level gradients of the bench step)
+struct InjectGrads : public torch::autograd::Function<InjectGrads> {
+  static Tensor forward(AutogradContext *ctx, const Tensor &a, const Tensor &ga, const Tensor &b, const Tensor &gb, const Tensor &c, const Tensor &gc,
+                        const Tensor &d, const Tensor &gd) {
+    ctx->save_for_backward({ga, gb, gc, gd});
+    return torch::zeros({}, a.options());
+  }
+  static tensor_list backward(AutogradContext *ctx, tensor_list g) {
+    auto s = ctx->get_saved_variables();
+    return {s[0] * g[0], Tensor(), s[1] * g[0], Tensor(), s[2] * g[0], Tensor(), s[3] * g[0], Tensor()};
+  }
+};
+
+}  // namespace
+
+namespace gsdf_extras {
+
+JointIteration::JointIteration(const Tensor &anchors, const std::vector<Tensor> &fields, std::shared_ptr<::TCNNEncoding> enc,
+                               std::shared_ptr<::TCNNNetwork> dec, const std::vector<float> &map_origin, double map_size, double bce_sigma,
+                               int occ_level, const JointConfig &cfg)
+    : cfg_(cfg), enc_(std::move(enc)), dec_(std::move(dec)), origin_(map_origin), map_size_inv_(1.0 / map_size),
+      bce_isigma_(1.0 / bce_sigma), occ_level_(occ_level), adam_(0.9, 0.999, 1e-15), adam_sdf_(0.9, 0.999, 1e-15) {
+  TORCH_CHECK(fields.size() == 6, "JointIteration: fields = {offsets, scaling, quaternion, opacity, features_dc, features_rest}");
+  TORCH_CHECK(origin_.size() == 3, "JointIteration: map_origin needs 3 entries");
+  anchors_ = f32c(anchors.detach(), "anchors");
+  const int64_t N = anchors_.size(0);
+  // splat family: one flat buffer, the fields in the reference's group order (neural_gaussian.cpp:434-453)
+  int64_t total = 0;
+  for (const auto &f : fields) total += f.numel();
+  flat_ = torch::empty({total}, anchors_.options());
+  flat_grad_ = torch::zeros({total}, anchors_.options());
+  const double lrs[6] = {cfg.lr_offsets, cfg.lr_scaling, cfg.lr_quaternion, cfg.lr_opacity, cfg.lr_features_dc, cfg.lr_features_rest};
+  std::vector<int64_t> sizes;
+  std::vector<double> seg_lrs;
+  int64_t off = 0;
+  for (size_t i = 0; i < 6; ++i) {
+    const int64_t n = fields[i].numel();
+    Tensor v = flat_.slice(0, off, off + n).view(fields[i].sizes());
+    { torch::NoGradGuard ng; v.copy_(fields[i]); }
+    v.requires_grad_(true);
+    v.mutable_grad() = flat_grad_.slice(0, off, off + n).view(fields[i].sizes());
+    views_.push_back(v);
+    if (n > 0) { sizes.push_back(n); seg_lrs.push_back(lrs[i]); }
+    off += n;
+  }
+  n_rest_ = N > 0 ? fields[5].numel() / (3 * N) : 0;
+  adam_.add_group(flat_, flat_grad_, sizes, seg_lrs);
+  // SDF family: table then decoder in one flat buffer; the operators' params_ become views of it
+  const int64_t nt = enc_->params_.numel(), nd = dec_->params_.numel();
+  sdf_flat_ = torch::empty({nt + nd}, anchors_.options());
+  sdf_flat_grad_ = torch::zeros({nt + nd}, anchors_.options());
+  {
+    torch::NoGradGuard ng;
+    sdf_flat_.slice(0, 0, nt).copy_(enc_->params_.detach().reshape({-1}));
+    sdf_flat_.slice(0, nt, nt + nd).copy_(dec_->params_.detach().reshape({-1}));
+  }
+  enc_->params_ = sdf_flat_.slice(0, 0, nt);
+  enc_->params_.requires_grad_(true);
+  enc_->params_.mutable_grad() = sdf_flat_grad_.slice(0, 0, nt);
+  dec_->params_ = sdf_flat_.slice(0, nt, nt + nd);
+  dec_->params_.requires_grad_(true);
+  dec_->params_.mutable_grad() = sdf_flat_grad_.slice(0, nt, nt + nd);
+  adam_sdf_.add_group(sdf_flat_, sdf_flat_grad_, {nt + nd}, {cfg.lr_sdf});
+  // occupancy structure of the map from the splat centres (SubMap::update_octree_as, sub_map.cpp:22-35)
+  const size_t nbytes = gsdf_occ_bytes(occ_level_);
+  TORCH_CHECK(nbytes > 0, "JointIteration: occupancy level outside [1,12]");
+  occ_grid_ = torch::empty({(int64_t)(nbytes / 4)}, anchors_.options().dtype(torch::kInt32));
+  Tensor m1p1 = ((anchors_ - torch::tensor(origin_, anchors_.options())) * (2.0 * map_size_inv_)).contiguous();
+  check(gsdf_occ_build(occ_level_, N, fp(m1p1), 1, occ_grid_.data_ptr(), cur_stream()), "occ_build");
+}
+
+std::map<std::string, int64_t> JointIteration::step(const Tensor &viewmat, const Tensor &K, const Tensor &target, const Tensor &ray_pts,
+                                                    const Tensor &ray_sdf, const std::vector<Tensor> &upstream, bool update) {
+  const int W = cfg_.width, H = cfg_.height;
+  std::map<std::string, int64_t> sizes;
+  // ---- per-ray SDF batch (:138-188): BCE sdf_loss + eikonal on the numerical gradient, 7 n rows in one encoder / decoder / loss launch
+  {
+    const int64_t n = ray_pts.size(0);
+    Tensor q = query_points(ray_pts, origin_, map_size_inv_, true, cfg_.sdf_delta);
+    Tensor attr = dec_->forward(enc_->forward_stencil(q, n, cfg_.sdf_delta * map_size_inv_));
+    sdf_ray_loss(attr, ray_sdf, n, bce_isigma_, cfg_.sdf_delta, cfg_.eik_w).backward();
+  }
+  // ---- render (:195-300 -> neural_gaussian.cpp:129-271) + photometric loss
+  auto act = splat_activations(anchors_, views_[0], views_[1], views_[3].reshape({anchors_.size(0)}));
+  const int64_t N = anchors_.size(0);
+  Tensor dc = views_[4].reshape({N, 1, 3});
+  Tensor sh = n_rest_ == 0 ? dc : torch::cat({dc, views_[5].reshape({N, n_rest_, 3})}, 1);
+  auto proj = fully_fused_projection_2dgs(act[0], views_[2], act[1], viewmat, K, W, H, cfg_.near_plane, cfg_.far_plane, 0.f, true, false);
+  const Tensor &camera_ids = std::get<0>(proj), &gaussian_ids = std::get<1>(proj), &radii = std::get<2>(proj), &means2d = std::get<3>(proj);
+  const Tensor &depths = std::get<4>(proj), &ray_transforms = std::get<5>(proj), &normals = std::get<6>(proj);
+  Tensor samples = act[0].index_select(0, gaussian_ids);           // center_reg: the splat centres are the SDF samples
+  Tensor samples_weights = torch::ones_like(std::get<8>(proj));
+  Tensor pt_opac = act[2].index_select(0, gaussian_ids);
+  Tensor colors = gsplat_cpp::get_view_colors(viewmat, act[0], radii, sh, camera_ids, gaussian_ids, cfg_.sh_degree);
+  auto enc = gsplat_cpp::tile_encode(W, H, 16, means2d, radii, depths, true, viewmat.size(0), camera_ids, gaussian_ids);
+  Tensor densify = torch::zeros_like(means2d).requires_grad_(true), absgrad = torch::zeros_like(means2d);
+  auto rast = rasterize_to_pixels_2dgs(means2d, ray_transforms, colors, pt_opac, normals, densify, W, H, 16, std::get<2>(enc), std::get<1>(enc),
+                                       at::nullopt, at::nullopt, true, absgrad, false);
+  auto post = RenderPost::apply(std::get<0>(rast), std::get<1>(rast), std::get<2>(rast), std::get<3>(rast), viewmat, true);   // render_mode RGB+ED (neural_gaussian.cpp:229-234)
+  const Tensor &render_normal = post[1], &color3 = post[2], &depth1 = post[3];
+  const Tensor &alphas = std::get<2>(rast), &median = std::get<5>(rast), &vis = std::get<6>(rast);
+  Tensor loss = l1_dssim_loss(color3[0], target, cfg_.rgb_w, cfg_.dssim_w);
+  if (upstream.size() == 4) loss = loss + InjectGrads::apply(depth1, upstream[0], alphas, upstream[1], render_normal, upstream[2], median, upstream[3]);
+  // ---- GS <-> SDF coupling (:420-462) at the visible, occupancy-valid splats' samples
+  Tensor visd = vis.detach();
+  Tensor w_all = (samples_weights * visd).detach();
+  Tensor valid = torch::empty({samples.size(0)}, samples.options().dtype(torch::kBool));
+  {
+    Tensor sd = f32c(samples.detach(), "samples");
+    check(gsdf_occ_query_world(occ_level_, -1, sd.size(0), fp(sd), origin_.data(), (float)map_size_inv_, occ_grid_.data_ptr(),
+                               (uint8_t *)valid.data_ptr(), cur_stream()), "occ_query_world");
+  }
+  Tensor ids = (valid & (visd > cfg_.vis_thresh).squeeze(-1)).nonzero().squeeze(-1);
+  const int64_t nt = enc_->params_.numel(), nd = dec_->params_.numel();
+  if (ids.numel() > 0)
+    loss = loss + gs_sdf_coupling(samples, ids, w_all, *enc_, *dec_, origin_, map_size_inv_, cfg_.gs_sdf_w, cfg_.sdf_delta, cfg_.eik_w,
+                                  sdf_flat_grad_.slice(0, 0, nt), sdf_flat_grad_.slice(0, nt, nt + nd));
+  loss.backward();
+  // ---- train_callback -> update_state (:486, neural_gaussian.cpp:626-680), optimizers
+  update_state(state_, densify.grad(), gaussian_ids, vis, radii, N, (int)viewmat.size(0), W, H, false);
+  if (update) {
+    adam_.step();
+    adam_sdf_.step();
+    flat_grad_.zero_();
+    sdf_flat_grad_.zero_();
+  }
+  sizes["M"] = gaussian_ids.size(0);
+  sizes["I"] = std::get<1>(enc).size(0);
+  sizes["n_gs_sdf"] = ids.numel();
+  return sizes;
+}
+
+}  // namespace gsdf_extras

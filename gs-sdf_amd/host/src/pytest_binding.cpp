@@ -82,6 +82,21 @@ PYBIND11_MODULE(_gsdf_host, m) {
                               torch::Tensor decoder_grad) {
     return gsdf_extras::gs_sdf_coupling(samples, ids, weights, *enc, *dec, origin, map_size_inv, scale, delta, w_eik, table_grad, decoder_grad);
   });
+  py::class_<gsdf_extras::JointIteration, std::shared_ptr<gsdf_extras::JointIteration>>(m, "JointIteration")
+      .def(py::init([](const torch::Tensor &anchors, const std::vector<torch::Tensor> &fields, std::shared_ptr<TCNNEncoding> enc,
+                       std::shared_ptr<TCNNNetwork> dec, std::vector<float> origin, double map_size, double bce_sigma, int occ_level, int width,
+                       int height, int sh_degree) {
+        gsdf_extras::JointConfig cfg;
+        cfg.width = width; cfg.height = height; cfg.sh_degree = sh_degree;
+        return std::make_shared<gsdf_extras::JointIteration>(anchors, fields, enc, dec, origin, map_size, bce_sigma, occ_level, cfg);
+      }))
+      .def("step", &gsdf_extras::JointIteration::step, py::arg("viewmat"), py::arg("K"), py::arg("target"), py::arg("ray_pts"),
+           py::arg("ray_sdf"), py::arg("upstream"), py::arg("update") = true,
+           py::call_guard<py::gil_scoped_release>())       // step() runs the autograd engine
+      .def("splat_flat", &gsdf_extras::JointIteration::splat_flat)
+      .def("splat_flat_grad", &gsdf_extras::JointIteration::splat_flat_grad)
+      .def("sdf_flat", &gsdf_extras::JointIteration::sdf_flat)
+      .def("sdf_flat_grad", &gsdf_extras::JointIteration::sdf_flat_grad);
   py::class_<TCNNEncoding, std::shared_ptr<TCNNEncoding>>(m, "TCNNEncoding")
       .def(py::init([](int n_levels, int n_feat, int log2_hashmap, int base_res, double pls) {
         nlohmann::json cfg = {{"otype", "Grid"}, {"type", "Hash"}, {"n_levels", n_levels}, {"n_features_per_level", n_feat},

@@ -49,3 +49,20 @@ def test_two_ranks_view_parallel_step_runs():
     line = [l for l in txt.splitlines() if l.startswith("{")][-1]
     j = json.loads(line)
     assert j["n_gpus"] == 2 and j["value"] > 0 and j["scaling"] == "weak"
+
+
+@pytest.mark.parametrize("workload", ["cfg0_10k_256", "cfg1_replica_300k"])
+def test_cpp_joint_iteration_gives_the_python_step_gradients(tmp_path, workload):
+    """gsdf_extras::JointIteration (host/src/joint_step.cpp: the loop body of neural_mapping.cpp:400-486 in C++/libtorch on the drop-in
+    operators + gsdf_extras) against the Python step of bench.py on the same scene, view, ray batch and op-level gradients:
+    same visible set, same intersections, same flat gradients of both parameter families."""
+    out = {}
+    for mode, flags in (("python", ["--no-overlap"]), ("cpp", ["--cpp-step"])):
+        path = str(tmp_path / f"{mode}.pt")
+        _bench(["--workload", workload, "--dump-grads", path, *flags])
+        out[mode] = torch.load(path)
+    ref, got = out["python"], out["cpp"]
+    assert {k: int(v) for k, v in got["sizes"].items()} == {k: int(v) for k, v in ref["sizes"].items()}
+    assert float(ref["splat"].abs().sum()) > 0 and float(ref["sdf"][0].abs().sum()) > 0
+    assert_close(got["splat"], ref["splat"], 1e-4, "C++ step: splat gradients")
+    assert_close(got["sdf"][0], ref["sdf"][0], 1e-4, "C++ step: SDF network gradients")
