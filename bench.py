@@ -477,7 +477,8 @@ def cpp_step(args, sc, views, K, ug6, target, N, W, H, deg, dev):
     enc, dec = host.TCNNEncoding(16, 2, 19, 32, 2.0), host.TCNNNetwork(32, 2, 64, 3)
     enc.params_, dec.params_ = lm.encoder.params_.detach().clone(), lm.decoder.params_.detach().clone()
     fields = [params.views[k].detach().clone() for k in ("offsets", "scaling", "quaternion", "opacity", "features_dc", "features_rest")]
-    ji = host.JointIteration(params.anchors, fields, enc, dec, [0.0, 0.0, 5.5], 16.0, 0.02, 8, W, H, deg)   # level 8: 1/16 m leaves in 16 m
+    two = not args.no_overlap
+    ji = host.JointIteration(params.anchors, fields, enc, dec, [0.0, 0.0, 5.5], 16.0, 0.02, 8, W, H, deg, two)   # level 8: 1/16 m leaves in 16 m
     gq = torch.Generator().manual_seed(4)
     pool = [((torch.rand(32768, 3, generator=gq) - 0.5) * 14.0 + torch.tensor([0.0, 0.0, 5.5])).to(dev) for _ in range(8)]
     ray_sdf = [(torch.randn(32768, 1, generator=gq) * 0.02).to(dev) for _ in range(8)]
@@ -496,7 +497,7 @@ def cpp_step(args, sc, views, K, ug6, target, N, W, H, deg, dev):
         n_sdf.append(ji.step(views[i % views.shape[0]][None], K, target, pool[i % 8], ray_sdf[i % 8], up, True)["n_gs_sdf"])
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
-    return {"metric": "train iters/sec, the joint iteration in C++/libtorch (gsdf_extras::JointIteration, one stream; NOT the headline)",
+    return {"metric": "train iters/sec, the joint iteration in C++/libtorch (gsdf_extras::JointIteration, " + ("two streams" if two else "one stream") + "; NOT the headline)",
             "value": args.steps / el, "unit": "iters/s", "ms_per_step": el / args.steps * 1e3, "steps": args.steps, "warmup": args.warmup,
             "n_gpus": 1, "params_finite": bool(torch.isfinite(ji.splat_flat()).all() and torch.isfinite(ji.sdf_flat()).all()),
             "config": {"workload": args.workload, "sdf_points_per_step": 7 * 32768 + 7 * sum(n_sdf) / max(1, len(n_sdf))}}

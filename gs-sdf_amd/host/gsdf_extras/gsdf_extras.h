@@ -81,7 +81,7 @@ class FusedAdam {
 
 // The loop body of NeuralSLAM::gs_train (neural_mapping.cpp:400-486) in C++ on the drop-in operators + the pieces above
 // (src/joint_step.cpp): per-ray SDF batch, render + 0.8 L1 + 0.2 D-SSIM, GS<->SDF coupling with the eikonal regulariser, backward,
-// update_state, fused Adam.  What `bench.py --cpp-step` times; one HIP stream.
+// update_state, fused Adam.  What `bench.py --cpp-step` times; one HIP stream, or two (JointConfig::two_streams).
 struct JointConfig {
   int width = 0, height = 0, sh_degree = 0;
   float near_plane = 0.05f, far_plane = 300.0f;
@@ -89,10 +89,13 @@ struct JointConfig {
   double sdf_delta = 0.02, eik_w = 0.1, gs_sdf_w = 1e-3, vis_thresh = 0.1;   // k_sample_std, k_eikonal_weight, k_gs_sdf_weight, :430-432
   double lr_offsets = 1.6e-4, lr_scaling = 5e-3, lr_quaternion = 1e-3, lr_opacity = 5e-2, lr_features_dc = 2.5e-3,
          lr_features_rest = 2.5e-3 / 20, lr_sdf = 1e-4;               // neural_gaussian.cpp:434-453, :619-623
+  bool two_streams = false;   // the SDF network's work on a second HIP stream beside the splat leg (bench.py's overlapped schedule)
 };
 
+struct JointStreams;
 class JointIteration {
  public:
+  ~JointIteration();
   // fields = {offsets [N,3], scaling [N,3] (log), quaternion [N,4], opacity [N] (logit), features_dc [N,3], features_rest [N,3 r]};
   // enc / dec: their params_ are MOVED into this object's flat SDF buffer (they become views of it).
   JointIteration(const torch::Tensor &anchors, const std::vector<torch::Tensor> &fields, std::shared_ptr<::TCNNEncoding> enc,
@@ -121,6 +124,7 @@ class JointIteration {
   std::vector<torch::Tensor> views_;
   std::map<std::string, torch::Tensor> state_;
   FusedAdam adam_, adam_sdf_;
+  std::unique_ptr<JointStreams> streams_;
 };
 
 }  // namespace gsdf_extras

@@ -4,6 +4,10 @@
 // Mirrors the step bench.py times (single-stream form): per-ray SDF batch, render + 0.8 L1 + 0.2 D-SSIM, GS<->SDF coupling with
 // the eikonal regulariser, backward, update_state, fused Adam.  The parameters live in two flat buffers (splats; SDF table +
 // decoder), every trainable tensor is a view whose .grad is a view of the matching flat gradient buffer.
+#include <ATen/hip/HIPEvent.h>
+#include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>
+#include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
+
 #include <cmath>
 
 #include "gsdf_extras/gsdf_extras.h"
@@ -17,6 +21,13 @@ using namespace gsdf_host;
 using torch::Tensor;
 using torch::autograd::AutogradContext;
 using torch::autograd::tensor_list;
+
+namespace gsdf_extras {
+struct StreamGate {   // "the gradient entering at JoinGrad is complete": recorded on the producing stream
+  at::cuda::CUDAEvent event;
+  bool armed = false;
+};
+}
 
 namespace {
 
@@ -63,9 +74,35 @@ struct InjectGrads : public torch::autograd::Function<InjectGrads> {
   }
 };
 
+// identity whose backward first makes the current stream wait for an event: the gradient that enters here was produced on
+// another stream (Python mirror: trainer.join_grad / GradGate)
+struct JoinGrad : public torch::autograd::Function<JoinGrad> {
+  static Tensor forward(AutogradContext *ctx, const Tensor &x, int64_t gate_handle) {
+    ctx->saved_data["gate"] = gate_handle;
+    return x.view_as(x);
+  }
+  static tensor_list backward(AutogradContext *ctx, tensor_list g) {
+    auto *gate = reinterpret_cast<gsdf_extras::StreamGate *>(ctx->saved_data["gate"].toInt());
+    if (gate != nullptr && gate->armed) {
+      gate->event.block(c10::hip::getCurrentHIPStreamMasqueradingAsCUDA());
+      gate->armed = false;
+    }
+    return {g[0], Tensor()};
+  }
+};
+
 }  // namespace
 
 namespace gsdf_extras {
+
+struct JointStreams {
+  c10::hip::HIPStreamMasqueradingAsCUDA side = c10::hip::getStreamFromPoolMasqueradingAsCUDA();
+  at::cuda::CUDAEvent fwd_done, init_done;
+  StreamGate gate;
+  bool first = true;
+};
+
+JointIteration::~JointIteration() = default;
 
 JointIteration::JointIteration(const Tensor &anchors, const std::vector<Tensor> &fields, std::shared_ptr<::TCNNEncoding> enc,
                                std::shared_ptr<::TCNNNetwork> dec, const std::vector<float> &map_origin, double map_size, double bce_sigma,
@@ -125,8 +162,26 @@ std::map<std::string, int64_t> JointIteration::step(const Tensor &viewmat, const
                                                     const Tensor &ray_sdf, const std::vector<Tensor> &upstream, bool update) {
   const int W = cfg_.width, H = cfg_.height;
   std::map<std::string, int64_t> sizes;
+  // Two legs on two HIP streams (cfg.two_streams; the schedule of bench.py's overlapped step): the SDF network's work — ray batch,
+  // coupling node, its Adam — on `side`, the splat leg on the caller's stream; they touch at the samples (forward) and at the
+  // samples' gradient (backward, JoinGrad).
+  using StreamGuard = c10::hip::HIPStreamGuardMasqueradingAsCUDA;
+  const bool two = cfg_.two_streams;
+  auto main_stream = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA();
+  if (two && !streams_) streams_ = std::make_unique<JointStreams>();
+  if (two && streams_->first) {   // the constructor filled the flat buffers on the caller's stream
+    streams_->init_done.record(main_stream);
+    streams_->init_done.block(streams_->side);
+    streams_->first = false;
+  }
   // ---- per-ray SDF batch (:138-188): BCE sdf_loss + eikonal on the numerical gradient, 7 n rows in one encoder / decoder / loss launch
   {
+    c10::optional<StreamGuard> sg;
+    if (two) {
+      sg.emplace(streams_->side);
+      ray_pts.record_stream(streams_->side);
+      ray_sdf.record_stream(streams_->side);
+    }
     const int64_t n = ray_pts.size(0);
     Tensor q = query_points(ray_pts, origin_, map_size_inv_, true, cfg_.sdf_delta);
     Tensor attr = dec_->forward(enc_->forward_stencil(q, n, cfg_.sdf_delta * map_size_inv_));
@@ -141,6 +196,7 @@ std::map<std::string, int64_t> JointIteration::step(const Tensor &viewmat, const
   const Tensor &camera_ids = std::get<0>(proj), &gaussian_ids = std::get<1>(proj), &radii = std::get<2>(proj), &means2d = std::get<3>(proj);
   const Tensor &depths = std::get<4>(proj), &ray_transforms = std::get<5>(proj), &normals = std::get<6>(proj);
   Tensor samples = act[0].index_select(0, gaussian_ids);           // center_reg: the splat centres are the SDF samples
+  if (two) samples = JoinGrad::apply(samples, reinterpret_cast<int64_t>(&streams_->gate));   // created HERE: consumed late in the backward
   Tensor samples_weights = torch::ones_like(std::get<8>(proj));
   Tensor pt_opac = act[2].index_select(0, gaussian_ids);
   Tensor colors = gsplat_cpp::get_view_colors(viewmat, act[0], radii, sh, camera_ids, gaussian_ids, cfg_.sh_degree);
@@ -164,16 +220,38 @@ std::map<std::string, int64_t> JointIteration::step(const Tensor &viewmat, const
   }
   Tensor ids = (valid & (visd > cfg_.vis_thresh).squeeze(-1)).nonzero().squeeze(-1);
   const int64_t nt = enc_->params_.numel(), nd = dec_->params_.numel();
-  if (ids.numel() > 0)
-    loss = loss + gs_sdf_coupling(samples, ids, w_all, *enc_, *dec_, origin_, map_size_inv_, cfg_.gs_sdf_w, cfg_.sdf_delta, cfg_.eik_w,
-                                  sdf_flat_grad_.slice(0, 0, nt), sdf_flat_grad_.slice(0, nt, nt + nd));
-  loss.backward();
-  // ---- train_callback -> update_state (:486, neural_gaussian.cpp:626-680), optimizers
+  Tensor tg = sdf_flat_grad_.slice(0, 0, nt), dg = sdf_flat_grad_.slice(0, nt, nt + nd);
+  if (!two) {
+    if (ids.numel() > 0)
+      loss = loss + gs_sdf_coupling(samples, ids, w_all, *enc_, *dec_, origin_, map_size_inv_, cfg_.gs_sdf_w, cfg_.sdf_delta, cfg_.eik_w, tg, dg);
+    loss.backward();
+  } else if (ids.numel() > 0) {
+    // graph cut at the samples: the coupling leg (forward + backward) on `side`, its d loss / d samples joins the splat leg's
+    // backward where the samples' gradient is consumed
+    streams_->fwd_done.record(main_stream);
+    streams_->fwd_done.block(streams_->side);
+    Tensor samples_cut = samples.detach().requires_grad_(true);
+    for (const Tensor &t : {samples_cut, w_all, ids}) t.record_stream(streams_->side);
+    {
+      StreamGuard sg(streams_->side);
+      gs_sdf_coupling(samples_cut, ids, w_all, *enc_, *dec_, origin_, map_size_inv_, cfg_.gs_sdf_w, cfg_.sdf_delta, cfg_.eik_w, tg, dg).backward();
+      streams_->gate.event.record(streams_->side);
+      streams_->gate.armed = true;
+    }
+    Tensor gs = samples_cut.grad();
+    gs.record_stream(main_stream);
+    torch::autograd::backward({loss, samples}, {Tensor(), gs});
+  } else {
+    loss.backward();
+  }
+  // ---- train_callback -> update_state (:486, neural_gaussian.cpp:626-680), optimizers (each family on its leg's stream)
   update_state(state_, densify.grad(), gaussian_ids, vis, radii, N, (int)viewmat.size(0), W, H, false);
   if (update) {
     adam_.step();
-    adam_sdf_.step();
     flat_grad_.zero_();
+    c10::optional<StreamGuard> sg;
+    if (two) sg.emplace(streams_->side);
+    adam_sdf_.step();
     sdf_flat_grad_.zero_();
   }
   sizes["M"] = gaussian_ids.size(0);

@@ -85,9 +85,9 @@ PYBIND11_MODULE(_gsdf_host, m) {
   py::class_<gsdf_extras::JointIteration, std::shared_ptr<gsdf_extras::JointIteration>>(m, "JointIteration")
       .def(py::init([](const torch::Tensor &anchors, const std::vector<torch::Tensor> &fields, std::shared_ptr<TCNNEncoding> enc,
                        std::shared_ptr<TCNNNetwork> dec, std::vector<float> origin, double map_size, double bce_sigma, int occ_level, int width,
-                       int height, int sh_degree) {
+                       int height, int sh_degree, bool two_streams) {
         gsdf_extras::JointConfig cfg;
-        cfg.width = width; cfg.height = height; cfg.sh_degree = sh_degree;
+        cfg.width = width; cfg.height = height; cfg.sh_degree = sh_degree; cfg.two_streams = two_streams;
         return std::make_shared<gsdf_extras::JointIteration>(anchors, fields, enc, dec, origin, map_size, bce_sigma, occ_level, cfg);
       }))
       .def("step", &gsdf_extras::JointIteration::step, py::arg("viewmat"), py::arg("K"), py::arg("target"), py::arg("ray_pts"),

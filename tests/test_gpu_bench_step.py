@@ -57,12 +57,14 @@ def test_cpp_joint_iteration_gives_the_python_step_gradients(tmp_path, workload)
     operators + gsdf_extras) against the Python step of bench.py on the same scene, view, ray batch and op-level gradients:
     same visible set, same intersections, same flat gradients of both parameter families."""
     out = {}
-    for mode, flags in (("python", ["--no-overlap"]), ("cpp", ["--cpp-step"])):
-        path = str(tmp_path / f"{mode}.pt")
+    for mode, flags in (("python", ["--no-overlap"]), ("cpp one stream", ["--cpp-step", "--no-overlap"]), ("cpp two streams", ["--cpp-step"])):
+        path = str(tmp_path / f"{mode.replace(' ', '_')}.pt")
         _bench(["--workload", workload, "--dump-grads", path, *flags])
         out[mode] = torch.load(path)
-    ref, got = out["python"], out["cpp"]
-    assert {k: int(v) for k, v in got["sizes"].items()} == {k: int(v) for k, v in ref["sizes"].items()}
+    ref = out["python"]
     assert float(ref["splat"].abs().sum()) > 0 and float(ref["sdf"][0].abs().sum()) > 0
-    assert_close(got["splat"], ref["splat"], 1e-4, "C++ step: splat gradients")
-    assert_close(got["sdf"][0], ref["sdf"][0], 1e-4, "C++ step: SDF network gradients")
+    for mode in ("cpp one stream", "cpp two streams"):
+        got = out[mode]
+        assert {k: int(v) for k, v in got["sizes"].items()} == {k: int(v) for k, v in ref["sizes"].items()}
+        assert_close(got["splat"], ref["splat"], 1e-4, f"{mode}: splat gradients")
+        assert_close(got["sdf"][0], ref["sdf"][0], 1e-4, f"{mode}: SDF network gradients")
