@@ -45,9 +45,12 @@ torch::Tensor gs_sdf_eik_loss(const torch::Tensor &attr, const torch::Tensor &we
 // (fp32, same shapes as enc.params_ / dec.params_, e.g. views of the flat gradient buffer FusedAdam reads; zero them per
 // step) — one one-pass decoder backward, one Jacobian contraction, one binned stencil-merging scatter, no autograd adds.
 // `weights` = samples_weights * visibilities, [M] or [M,1].  Bias-free decoder (TCNNNetwork).
+// `samples_grad_ready` (optional, internal type): recorded on the backward's stream once d loss / d samples has been issued, before
+// the table scatter — lets a caller on another stream consume that gradient without waiting for the scatter (JointIteration).
+struct StreamGate;
 torch::Tensor gs_sdf_coupling(const torch::Tensor &samples, const torch::Tensor &ids, const torch::Tensor &weights, ::TCNNEncoding &enc,
                               ::TCNNNetwork &dec, const std::vector<float> &map_origin, double map_size_inv, double scale, double delta,
-                              double w_eik, torch::Tensor table_grad, torch::Tensor decoder_grad);
+                              double w_eik, torch::Tensor table_grad, torch::Tensor decoder_grad, StreamGate *samples_grad_ready = nullptr);
 
 // state: "grad2d","count","vis"[,"radii"] created on first use; info as NeuralGS::render returns it
 void update_state(std::map<std::string, torch::Tensor> &state, const torch::Tensor &densify_grad, const torch::Tensor &gaussian_ids,

@@ -4,6 +4,7 @@
 
 #include <cmath>
 
+#include "stream_gate.h"
 #include "util.h"
 
 using namespace gsdf_host;
@@ -140,7 +141,8 @@ CouplingCfg coupling_cfg(const std::vector<int64_t> &iv, const std::vector<doubl
 // neural_mapping.cpp:420-462 as one node (Python mirror: gs_sdf_amd/sdf.py _CouplingLeg)
 struct CouplingFn : public torch::autograd::Function<CouplingFn> {
   static Tensor forward(AutogradContext *ctx, const Tensor &samples, const Tensor &ids_, const Tensor &weights, const Tensor &table_,
-                        const Tensor &W_, Tensor table_grad, Tensor decoder_grad, std::vector<int64_t> iv, std::vector<double> dv) {
+                        const Tensor &W_, Tensor table_grad, Tensor decoder_grad, std::vector<int64_t> iv, std::vector<double> dv,
+                        int64_t gate_handle) {
     const CouplingCfg c = coupling_cfg(iv, dv);
     Tensor ids = ids_.contiguous(), table = f32c(table_.detach(), "encoder params"), W = f32c(W_.detach(), "decoder params");
     Tensor xs = f32c(samples.detach().index_select(0, ids), "samples");
@@ -162,6 +164,7 @@ struct CouplingFn : public torch::autograd::Function<CouplingFn> {
                                (float)c.w_eik, fpm(loss), fpm(v_attr), cur_stream()), "gs_sdf_eik_loss");
     ctx->save_for_backward({ids, x01, feat, jac, acts, v_attr, table, W, table_grad, decoder_grad});
     ctx->saved_data["n_rows"] = samples.size(0);
+    ctx->saved_data["gate"] = gate_handle;
     ctx->saved_data["iv"] = iv;
     ctx->saved_data["dv"] = dv;
     return loss;
@@ -179,6 +182,9 @@ struct CouplingFn : public torch::autograd::Function<CouplingFn> {
                        ws.data_ptr(), cur_stream()), "mlp_bwd");
     Tensor v_x = empty_like_opts(feat, {n, 3}, torch::kFloat32);
     check(gsdf_hashgrid_bwd_jac(n, c.L, c.F, fp(jac), fp(v_feat), fpm(v_x), cur_stream()), "hashgrid_bwd_jac");
+    Tensor v_samples = torch::zeros({ctx->saved_data["n_rows"].toInt(), 3}, feat.options());
+    v_samples.index_add_(0, ids, v_x * c.map_size_inv);          // d x01 / d xyz = 0.5 * 2 * map_size_inv
+    if (auto *gate = reinterpret_cast<gsdf_extras::StreamGate *>(ctx->saved_data["gate"].toInt())) gate->record_here();
     if (nq >= 24576) {
       int merge = 0;
       for (int l = 0; l < c.L; ++l)
@@ -190,16 +196,14 @@ struct CouplingFn : public torch::autograd::Function<CouplingFn> {
     } else if (nq > 0) {
       check(gsdf_hashgrid_bwd(nq, c.L, c.F, c.H, c.R, c.S, fp(x01), fp(table), fp(v_feat), fpm(table_grad), nullptr, cur_stream()), "hashgrid_bwd");
     }
-    Tensor v_samples = torch::zeros({ctx->saved_data["n_rows"].toInt(), 3}, feat.options());
-    v_samples.index_add_(0, ids, v_x * c.map_size_inv);          // d x01 / d xyz = 0.5 * 2 * map_size_inv
-    return {v_samples, Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor()};
+    return {v_samples, Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor()};
   }
 };
 }  // namespace
 
 Tensor gs_sdf_coupling(const Tensor &samples, const Tensor &ids, const Tensor &weights, ::TCNNEncoding &enc, ::TCNNNetwork &dec,
                        const std::vector<float> &origin, double map_size_inv, double scale, double delta, double w_eik, Tensor table_grad,
-                       Tensor decoder_grad) {
+                       Tensor decoder_grad, StreamGate *samples_grad_ready) {
   TORCH_CHECK(origin.size() == 3, "gs_sdf_coupling: map_origin needs 3 entries");
   TORCH_CHECK(samples.dim() == 2 && samples.size(1) == 3 && ids.scalar_type() == torch::kInt64, "gs_sdf_coupling: samples [M,3], ids int64");
   TORCH_CHECK(table_grad.defined() && table_grad.numel() == enc.params_.numel() && table_grad.is_contiguous() &&
@@ -209,7 +213,8 @@ Tensor gs_sdf_coupling(const Tensor &samples, const Tensor &ids, const Tensor &w
   std::vector<int64_t> iv = {enc.n_levels_, enc.n_feat_, enc.log2_hashmap_, enc.base_res_};
   iv.insert(iv.end(), dec.dims_.begin(), dec.dims_.end());
   std::vector<double> dv = {enc.per_level_scale_, origin[0], origin[1], origin[2], map_size_inv, scale, delta, w_eik};
-  return CouplingFn::apply(samples, ids, weights, enc.params_, dec.params_, table_grad, decoder_grad, iv, dv);
+  return CouplingFn::apply(samples, ids, weights, enc.params_, dec.params_, table_grad, decoder_grad, iv, dv,
+                           reinterpret_cast<int64_t>(samples_grad_ready));
 }
 
 void update_state(std::map<std::string, Tensor> &state, const Tensor &densify_grad, const Tensor &gaussian_ids, const Tensor &visibilities,

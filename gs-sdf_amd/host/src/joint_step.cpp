@@ -15,19 +15,13 @@
 #include "gsplat_cpp/rasterize_to_pixels.h"
 #include "gsplat_cpp/rendering.h"
 #include "tcnn_binding/tcnn_binding.h"
+#include "stream_gate.h"
 #include "util.h"
 
 using namespace gsdf_host;
 using torch::Tensor;
 using torch::autograd::AutogradContext;
 using torch::autograd::tensor_list;
-
-namespace gsdf_extras {
-struct StreamGate {   // "the gradient entering at JoinGrad is complete": recorded on the producing stream
-  at::cuda::CUDAEvent event;
-  bool armed = false;
-};
-}
 
 namespace {
 
@@ -234,9 +228,11 @@ std::map<std::string, int64_t> JointIteration::step(const Tensor &viewmat, const
     for (const Tensor &t : {samples_cut, w_all, ids}) t.record_stream(streams_->side);
     {
       StreamGuard sg(streams_->side);
-      gs_sdf_coupling(samples_cut, ids, w_all, *enc_, *dec_, origin_, map_size_inv_, cfg_.gs_sdf_w, cfg_.sdf_delta, cfg_.eik_w, tg, dg).backward();
-      streams_->gate.event.record(streams_->side);
-      streams_->gate.armed = true;
+      // the node records the gate as soon as d loss / d samples has been issued, BEFORE its table scatter (2-3 ms): the splat
+      // leg's backward tail and the next step's render do not wait for the scatter
+      gs_sdf_coupling(samples_cut, ids, w_all, *enc_, *dec_, origin_, map_size_inv_, cfg_.gs_sdf_w, cfg_.sdf_delta, cfg_.eik_w, tg, dg,
+                      &streams_->gate).backward();
+      if (!streams_->gate.armed) streams_->gate.record_here();
     }
     Tensor gs = samples_cut.grad();
     gs.record_stream(main_stream);
