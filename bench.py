@@ -31,6 +31,28 @@ WORKLOADS = {
 }
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: re-run this command line under torch.distributed.run with N ranks on this
+    node (127.0.0.1 rendezvous, a free port), one process per GPU.  Fails loudly when the box has fewer than N GPUs (RCCL needs
+    a device per rank; GSDF_BENCH_BACKEND=gloo is the test hook that lets ranks share a device).  Returns the exit code."""
+    import socket
+    import subprocess
+    n_dev = torch.cuda.device_count()
+    if os.environ.get("GSDF_BENCH_BACKEND", "nccl") == "nccl" and n_dev < n:
+        print(f"bench.py: --gpus {n} needs {n} visible GPUs (one process per GPU over RCCL), torch.cuda.device_count() = {n_dev}; "
+              "refusing to report a smaller job as an N-GPU number", file=sys.stderr, flush=True)
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: RCCL between processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "8")
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -62,12 +84,20 @@ def main():
                     help="N > 1: how a parameter family's flat gradient buffer is summed over the ranks")
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # invoked as `python bench.py --gpus N` (no launcher): start the N ranks ourselves, one process per GPU
+        sys.exit(spawn_ranks(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     n_dev = torch.cuda.device_count()
+    if os.environ.get("GSDF_BENCH_BACKEND", "nccl") == "nccl" and n_dev < world:
+        raise SystemExit(f"bench.py: --gpus {world} needs {world} visible GPUs (one process per GPU over RCCL), "
+                         f"torch.cuda.device_count() = {n_dev}")
     # one process per GPU.  (GSDF_BENCH_BACKEND=gloo is a test hook: it lets N ranks share one GPU so that the
     # multi-rank control flow can be exercised on a single-GPU box; RCCL itself refuses two ranks per device.)
     backend = os.environ.get("GSDF_BENCH_BACKEND", "nccl")

@@ -111,6 +111,20 @@ __device__ __forceinline__ float row_transpose_reduce16(const float (&v)[16], in
     c[k] = (b2 ? b[k + 2] : b[k]) + dpp_xchg<0x104, 0x114, 0x5, 0xA>(b2 ? b[k] : b[k + 2]);          // lane ^ 4
   return (b3 ? c[1] : c[0]) + dpp_xchg<0x108, 0x118, 0x3, 0xC>(b3 ? c[0] : c[1]);                     // lane ^ 8
 }
+// The same for 4 values over the quads of a row: on return lanes 12..15 of every row hold the ROW sum of value index
+// m = 2*b0 + b1 (other lanes hold partial sums).  6 + 3 + 2 VALU.
+__device__ __forceinline__ float row_transpose_reduce4(const float (&v)[4], int lane) {
+  const bool b0 = lane & 1, b1 = lane & 2;
+  float a[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) a[k] = (b0 ? v[k + 2] : v[k]) + dpp_mov<0xB1>(b0 ? v[k] : v[k + 2]);  // lane ^ 1
+  float r = (b1 ? a[1] : a[0]) + dpp_mov<0x4E>(b1 ? a[0] : a[1]);                                   // lane ^ 2
+  r += dpp_mov<0x114>(r);   // row_shr:4 (zero fill)
+  r += dpp_mov<0x118>(r);   // row_shr:8
+  return r;
+}
+__device__ __forceinline__ int row_transpose_index4(int lane) { return ((lane & 1) << 1) | ((lane & 2) >> 1); }
+
 __device__ __forceinline__ int row_transpose_index(int lane) {
   return ((lane & 1) << 3) | ((lane & 2) << 1) | ((lane & 4) >> 1) | ((lane & 8) >> 3);
 }

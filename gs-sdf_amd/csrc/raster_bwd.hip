@@ -20,18 +20,19 @@
 
 namespace gsdf {
 
-static constexpr int NACC = 20;
+static constexpr int NACC = 21;
 static constexpr int BWD_BATCH = 240;  // staged splats per batch: keeps the workgroup at <= 40 KiB of LDS (4 workgroups per CU)
 // Per-splat gradient record.  The cross-product chain of z = h_u x h_v is NOT differentiated per pixel: the record
 // accumulates the moments of v_z about the splat's own centre,
 //     V0 = sum v_z,   Vx = sum (p_x - mean2d.x) v_z,   Vy = sum (p_y - mean2d.y) v_z,
-// (z is affine in the pixel, so these nine numbers carry everything) plus vD = sum v_dep / z.z for the depth
-// D / z.z; the streaming epilogue turns them into dL/dM_u, dL/dM_v, dL/dM_w once per splat.
-// slots: 0-2 v_rgb, 3-5 v_normal, 6 v_opacity, 7-9 V0, 10-12 Vx, 13-15 Vy, 16 vD, 17 v_Mw.z (low-pass branch depth),
-//        18-19 v_means2d ; v_means2d_abs lives in a second record array (only with absgrad)
+// (z is affine in the pixel, so these nine numbers carry everything); the depth dep = s . M_w.xy + M_w.z reaches M_w
+// directly, (sum v_dep s.x, sum v_dep s.y, sum v_dep), and s through v_z.  The streaming epilogue turns the record into
+// dL/dM_u, dL/dM_v, dL/dM_w once per splat.
+// slots: 0-2 v_rgb, 3-5 v_normal, 6 v_opacity, 7-9 V0, 10-12 Vx, 13-15 Vy, 16-18 direct dL/dM_w of the depth (both branches in
+//        18), 19-20 v_means2d ; v_means2d_abs lives in a second record array (only with absgrad)
 template <bool ABSGRAD>
 struct BwdLds {
-  SplatBatch s;
+  SplatBatchT<BWD_BATCH, true> s;
   float acc[BWD_BATCH][NACC];  // one 80-byte record per staged splat
   float acc_abs[ABSGRAD ? BWD_BATCH : 1][2];
   int bin_final_max;
@@ -57,7 +58,7 @@ __device__ __forceinline__ void flush_records(BwdLds<ABSGRAD> &lds, int wave, in
   for (int it = 0; it < 22; ++it) {
     const int slot = 3 * it + j;                     // 0..65
     const int g = __shfl(g_mine, slot & 63, 64);
-    if (j < 3 && slot < 64 && g >= 0) {
+    if (j < 3 && slot < 64 && wave * 64 + slot < BWD_BATCH && g >= 0) {
       float *a = &lds.acc[wave * 64 + slot][k];
       const float v = *a;
       if (v != 0.f) {
@@ -82,7 +83,7 @@ __global__ void __launch_bounds__(RT)
                       const float *__restrict__ v_render_colors, const float *__restrict__ v_render_depths,
                       const float *__restrict__ v_render_alphas, const float *__restrict__ v_render_normals,
                       const float *__restrict__ v_render_median, float *__restrict__ grec,
-                      float *__restrict__ grec_abs) {
+                      float *__restrict__ grec_abs, const float *__restrict__ final_T) {
   __shared__ BwdLds<ABSGRAD> lds;
   const int64_t tile = xcd_tile_index(total_tiles, n_xcd);
   if (tile >= total_tiles) return;
@@ -106,7 +107,7 @@ __global__ void __launch_bounds__(RT)
         vMed = 0.f;
   int32_t bin_final = -1, med_idx = -1;
   if (inside) {
-    T_final = 1.0f - render_alphas[pid];
+    T_final = final_T != nullptr ? final_T[pid] : 1.0f - render_alphas[pid];
     // last_ids == 0 with no contributor is harmless: the replay re-tests every pair
     bin_final = last_ids[pid];
     med_idx = median_ids[pid];
@@ -159,20 +160,21 @@ __global__ void __launch_bounds__(RT)
     const int wcount = min(count, wave_bin_final - bstart + 1);
     for (int c0 = ((wcount - 1) >> 6) << 6; c0 >= 0 && wcount > 0; c0 -= 64) {
       const int ti = c0 + lane;
-      unsigned long long todo = __ballot(ti < wcount && ((lds.s.qmask[ti < RT ? ti : 0] >> wave) & 1u));
+      unsigned long long todo = __ballot(ti < wcount && ((lds.s.qmask[ti < BWD_BATCH ? ti : 0] >> wave) & 1u));
       while (todo) {
       const int hb = 63 - __builtin_clzll(todo);
       todo &= ~(1ull << hb);
       const int t = c0 + hb;
       const float4 a0 = lds.s.q0[t], a1 = lds.s.q1[t], a2 = lds.s.q2[t], a3 = lds.s.q3[t];
       PairEval e;
-      eval_pair(lx, ly, px, py, a0, a1, a2, a3.x, a3.y, e);
+      const float mwx = a3.x, mwy = lds.s.extra[t];
+      eval_pair<true>(lx, ly, px, py, a0, a1, a2, mwx, a3.y, e, mwy);
       const bool valid = inside && (bstart + t <= bin_final) && e.ok;
       if (__ballot(valid) == 0ull) continue;
       const float4 a4 = lds.s.q4[t];
       const float cR = a3.z, cG = a3.w, cB = a4.x, nX = a4.y, nY = a4.z, nZ = a4.w;
       float g_rgb0 = 0.f, g_rgb1 = 0.f, g_rgb2 = 0.f, g_n0 = 0.f, g_n1 = 0.f, g_n2 = 0.f, g_op = 0.f;
-      float vzx = 0.f, vzy = 0.f, vzz = 0.f, g_D = 0.f, g_mwz = 0.f, g_x = 0.f, g_y = 0.f;
+      float vzx = 0.f, vzy = 0.f, vzz = 0.f, g_dx = 0.f, g_dy = 0.f, g_mwz = 0.f, g_x = 0.f, g_y = 0.f;
       bool v2 = false;
       if (valid) {
         const float ra = 1.0f / (1.0f - e.alpha);
@@ -193,17 +195,17 @@ __global__ void __launch_bounds__(RT)
           g_op = e.vis * v_alpha;
           v_sigma = -a2.w * e.vis * v_alpha;
         }
+        g_mwz = v_dep;
         if (e.b3) {
-          // sigma = (zx^2 + zy^2) / (2 zz^2),  dep = D / zz
-          const float q = v_sigma * e.inv;
-          vzx = q * e.sx; vzy = q * e.sy;
-          g_D = v_dep * e.inv;
-          vzz = -(vzx * e.sx + vzy * e.sy) - g_D * e.dep;
+          // sigma = (s.s) / 2, dep = s . M_w.xy + M_w.z with s = z.xy / z.z:  v_s = v_sigma s + v_dep M_w.xy
+          vzx = fmaf(v_sigma, e.sx, v_dep * mwx) * e.inv;
+          vzy = fmaf(v_sigma, e.sy, v_dep * mwy) * e.inv;
+          vzz = -(vzx * e.sx + vzy * e.sy);
+          g_dx = v_dep * e.sx; g_dy = v_dep * e.sy;
         } else {
           v2 = true;
           g_x = v_sigma * FILTER_INV_SQUARE * e.dx;
           g_y = v_sigma * FILTER_INV_SQUARE * e.dy;
-          g_mwz = v_dep;
         }
       }
       const bool any2 = __ballot(v2) != 0ull;
@@ -218,9 +220,13 @@ __global__ void __launch_bounds__(RT)
 #define RED(slot, val)                                   \
   r = wave_sum_to_lane63(val);                           \
   if (lane == 63 && r != 0.f) lds_add(&lds.acc[t][slot], r)
-      RED(16, g_D);
-      if (any2) {  // screen-space low-pass branch (rare): v_means2d (+abs), centre-depth gradient
-        RED(17, g_mwz); RED(18, g_x); RED(19, g_y);
+      {  // slots 16..18 (direct dL/dM_w of the depth): 4-value butterfly, lanes 12..15 of each row hold the row sums
+        const float v4[4] = {g_dx, g_dy, g_mwz, 0.f};
+        r = row_transpose_reduce4(v4, lane);
+        if ((lane & 12) == 12 && r != 0.f) lds_add(&lds.acc[t][16 + row_transpose_index4(lane)], r);
+      }
+      if (any2) {  // screen-space low-pass branch (rare): v_means2d (+abs)
+        RED(19, g_x); RED(20, g_y);
         if (ABSGRAD) {
           r = wave_sum_to_lane63(fabsf(g_x)); if (lane == 63 && r != 0.f) lds_add(&lds.acc_abs[t][0], r);
           r = wave_sum_to_lane63(fabsf(g_y)); if (lane == 63 && r != 0.f) lds_add(&lds.acc_abs[t][1], r);
@@ -251,36 +257,33 @@ __global__ void __launch_bounds__(256)
 #pragma unroll
   for (int k = 0; k < 3; ++k) { v_colors[3 * m + k] = r[k]; v_normals[3 * m + k] = r[3 + k]; }
   v_opacities[m] = r[6];
-  v_means2d[2 * m] = r[18]; v_means2d[2 * m + 1] = r[19];
+  v_means2d[2 * m] = r[19]; v_means2d[2 * m + 1] = r[20];
   if (v_means2d_abs != nullptr) { v_means2d_abs[2 * m] = grec_abs[2 * m]; v_means2d_abs[2 * m + 1] = grec_abs[2 * m + 1]; }
   // moments -> dL/dM.  With h_u = m_x M_w - M_u, h_v = m_y M_w - M_v evaluated at the splat centre (m_x, m_y):
   //   v_hu = h_v x V0 + M_w x Vy,   v_hv = V0 x h_u + Vx x M_w,
-  //   dL/dM_u = -v_hu + vD (M_v x M_w),   dL/dM_v = -v_hv + vD (M_w x M_u),
-  //   dL/dM_w = m_x v_hu + m_y v_hv + h_v x Vx + Vy x h_u + vD (M_u x M_v) + (0, 0, v_Mw.z)
+  //   dL/dM_u = -v_hu,   dL/dM_v = -v_hv,
+  //   dL/dM_w = m_x v_hu + m_y v_hv + h_v x Vx + Vy x h_u + (sum v_dep s.x, sum v_dep s.y, sum v_dep)
   const float *Mr = ray_transforms + 9 * m;
   const float mu[3] = {Mr[0], Mr[1], Mr[2]}, mv[3] = {Mr[3], Mr[4], Mr[5]}, mw[3] = {Mr[6], Mr[7], Mr[8]};
   const float mx = means2d[2 * m], my = means2d[2 * m + 1];
-  const float hu[3] = {mx * mw[0] - mu[0], mx * mw[1] - mu[1], mx * mw[2] - mu[2]};
-  const float hv[3] = {my * mw[0] - mv[0], my * mw[1] - mv[1], my * mw[2] - mv[2]};
+  const float hu[3] = {fmaf(mx, mw[0], -mu[0]), fmaf(mx, mw[1], -mu[1]), fmaf(mx, mw[2], -mu[2])};   // one rounding each (see stage_splat)
+  const float hv[3] = {fmaf(my, mw[0], -mv[0]), fmaf(my, mw[1], -mv[1]), fmaf(my, mw[2], -mv[2])};
   const float *V0 = r + 7, *Vx = r + 10, *Vy = r + 13;
-  const float vD = r[16];
 #define CROSS(o, a, b) o[0] = a[1] * b[2] - a[2] * b[1]; o[1] = a[2] * b[0] - a[0] * b[2]; o[2] = a[0] * b[1] - a[1] * b[0]
-  float t1[3], t2[3], vhu[3], vhv[3], AvW[3], BwU[3], CuV[3], t3[3], t4[3];
+  float t1[3], t2[3], vhu[3], vhv[3], t3[3], t4[3];
   CROSS(t1, hv, V0); CROSS(t2, mw, Vy);
   CROSS(t3, V0, hu); CROSS(t4, Vx, mw);
 #pragma unroll
   for (int k = 0; k < 3; ++k) { vhu[k] = t1[k] + t2[k]; vhv[k] = t3[k] + t4[k]; }
-  CROSS(AvW, mv, mw); CROSS(BwU, mw, mu); CROSS(CuV, mu, mv);
   CROSS(t1, hv, Vx); CROSS(t2, Vy, hu);
 #undef CROSS
   float gmu[3], gmv[3], gmw[3];
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
-    gmu[k] = -vhu[k] + vD * AvW[k];
-    gmv[k] = -vhv[k] + vD * BwU[k];
-    gmw[k] = mx * vhu[k] + my * vhv[k] + t1[k] + t2[k] + vD * CuV[k];
+    gmu[k] = -vhu[k];
+    gmv[k] = -vhv[k];
+    gmw[k] = mx * vhu[k] + my * vhv[k] + t1[k] + t2[k] + r[16 + k];
   }
-  gmw[2] += r[17];
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
     v_ray_transforms[9 * m + k] = gmu[k]; v_ray_transforms[9 * m + 3 + k] = gmv[k]; v_ray_transforms[9 * m + 6 + k] = gmw[k];
@@ -307,7 +310,7 @@ extern "C" int gsdf_rasterize_2dgs_bwd(int64_t C, int64_t M, int64_t I, int widt
                                        const float *v_render_alphas, const float *v_render_normals,
                                        const float *v_render_median, float *v_means2d, float *v_ray_transforms,
                                        float *v_colors, float *v_opacities, float *v_normals, float *v_densify,
-                                       float *v_means2d_abs, void *ws, gsdf_stream_t stream_) {
+                                       float *v_means2d_abs, void *ws, const float *final_T, gsdf_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   GSDF_REQUIRE(tile_size == TILE, "rasterize_bwd: tile_size %d unsupported (16 only)", tile_size);
   GSDF_REQUIRE(width > 0 && height > 0 && C >= 1, "rasterize_bwd: bad geometry");
@@ -327,7 +330,7 @@ extern "C" int gsdf_rasterize_2dgs_bwd(int64_t C, int64_t M, int64_t I, int widt
     const int n_xcd = xcd_count(stream);
 #define ARGS n_xcd, total, n_tiles, I, width, height, tw, means2d, ray_transforms, colors, opacities, normals, backgrounds, \
              masks, isect_offsets, flatten_ids, render_alphas, last_ids, median_ids, v_render_colors,               \
-             v_render_depths, v_render_alphas, v_render_normals, v_render_median, grec, grec_abs
+             v_render_depths, v_render_alphas, v_render_normals, v_render_median, grec, grec_abs, final_T
     if (v_means2d_abs)
       raster_bwd_kernel<true><<<xcd_grid(total, n_xcd), RT, 0, stream>>>(ARGS);
     else

@@ -24,17 +24,28 @@ static constexpr float FILTER_INV_SQUARE = 2.0f;
 
 // Per (tile, splat) the staging lane precomputes the AFFINE form of the ray-splat cross product.  With
 // h_u = p_x M_w - M_u, h_v = p_y M_w - M_v the vector z = h_u x h_v is exactly affine in the pixel:
-//     z(p) = C0 + (p_x - p0_x) A + (p_y - p0_y) B,   A = M_v x M_w,  B = M_w x M_u,  C0 = z(p0)
+//     z(p) = C0 + (p_x - m_x) A + (p_y - m_y) B,   A = M_v x M_w,  B = M_w x M_u,  C0 = z(m),  m = mean2d
 // (the p_x p_y term is M_w x M_w = 0), and the intersection depth s.M_w.xy + M_w.z equals D / z.z with
-// D = z . M_w = det(M) constant per splat.  C0 is evaluated with the well-conditioned h_u x h_v formula at the
-// tile's first pixel centre p0, so per pixel only 6 FMAs remain (instead of 6 FMAs + a 9-op cross product) and
-// the depth is one multiply.  One staged splat = 5 LDS vectors (80 B) + a 4-bit quadrant mask:
+// D = z . M_w = det(M) constant per splat.  The expansion point is the splat's OWN projected centre: there h_u.z and h_v.z
+// vanish (the centre ray hits the splat at (u, v) = 0), so C0.xy is small and z.xy(p) = C0.xy + dx A.xy + dy B.xy carries no
+// cancellation — s = z.xy / z.z keeps its RELATIVE accuracy down to the pixels next to the centre, where the gradient
+// v_sigma * s is proportional to it.  (Round 2 expanded about the tile's first pixel: z.xy(p) was then the difference of
+// terms ~|C0| ~ 500 x larger, an absolute error of 5e-5 in s, i.e. 2e-3 of the whole gradient of a splat whose only
+// 3-D-branch pixel sits next to its centre.)  p - m is exact in fp32 (Sterbenz) and is needed for the low-pass term anyway,
+// so a pixel still costs 6 FMAs and the depth one multiply.  One staged splat = 5 LDS vectors (80 B) + a 4-bit quadrant mask:
 //   q0 = (A.x, A.y, A.z, mean2d.x)   q1 = (B.x, B.y, B.z, mean2d.y)   q2 = (C0.x, C0.y, C0.z, opacity)
 //   q3 = (D, M_w.z, r, g)            q4 = (b, n.x, n.y, n.z)
-struct SplatBatch {
-  float4 q0[RT], q1[RT], q2[RT], q3[RT], q4[RT];
-  unsigned char qmask[RT];  // bit q set <=> the splat can reach wave q's 8x8 pixel quadrant (conservative)
+// The forward composites the depth as D / z.z (one multiply).  The BACKWARD must not differentiate that form: d(D / z.z) splits
+// into (1 / z.z) dD/dM and -(D / z.z^2) dz.z/dM, two terms ~1e3 x larger than their sum that would be accumulated in separate
+// fp32 sums (measured: 1e-3 relative error of dL/dM on small splats).  It stages M_w.x, M_w.y instead of D (q3.x, extra) and
+// differentiates dep = s . M_w.xy + M_w.z as the specification writes it (SPEC A.5).
+template <int CAP, bool BWD>
+struct SplatBatchT {
+  float4 q0[CAP], q1[CAP], q2[CAP], q3[CAP], q4[CAP];
+  float extra[BWD ? CAP : 1];  // backward: M_w.y (q3.x = M_w.x instead of D)
+  unsigned char qmask[CAP];    // bit q set <=> the splat can reach wave q's 8x8 pixel quadrant (conservative)
 };
+using SplatBatch = SplatBatchT<RT, false>;
 
 // Conservative per-quadrant reach test, evaluated ONCE per (tile, splat) by the staging lane.
 // A pair contributes only if alpha = o*exp(-min(g3,g2)/2) >= 1/255, i.e. min(g3,g2) <= tau = 2 ln(255 o).
@@ -79,7 +90,8 @@ __device__ __forceinline__ unsigned quadrant_mask(const float *__restrict__ m, f
   return mask;
 }
 
-__device__ __forceinline__ void stage_splat(SplatBatch &s, int slot, int g, const float *__restrict__ means2d,
+template <int CAP, bool BWD>
+__device__ __forceinline__ void stage_splat(SplatBatchT<CAP, BWD> &s, int slot, int g, const float *__restrict__ means2d,
                                             const float *__restrict__ ray_transforms,
                                             const float *__restrict__ colors, const float *__restrict__ opacities,
                                             const float *__restrict__ normals, float tile_x0, float tile_y0) {
@@ -89,19 +101,22 @@ __device__ __forceinline__ void stage_splat(SplatBatch &s, int slot, int g, cons
   const float *n = normals + 3 * (int64_t)g;
   const float opac = opacities[g];
   const float mu0 = m[0], mu1 = m[1], mu2 = m[2], mv0 = m[3], mv1 = m[4], mv2 = m[5], mw0 = m[6], mw1 = m[7], mw2 = m[8];
+  // Explicit FMAs: h = p M_w - M is the cancelling step (|p M_w.z| ~ |M.z| ~ 1e3 |h.z|) and must be ONE rounding of the exact
+  // value; left to the compiler, the SLP vectoriser turns two of the six into v_pk_mul_f32 + v_pk_add_f32 (seen in the ISA).
   // A = M_v x M_w, B = M_w x M_u
-  const float ax = mv1 * mw2 - mv2 * mw1, ay = mv2 * mw0 - mv0 * mw2, az = mv0 * mw1 - mv1 * mw0;
-  const float bx = mw1 * mu2 - mw2 * mu1, by = mw2 * mu0 - mw0 * mu2, bz = mw0 * mu1 - mw1 * mu0;
-  // C0 = h_u x h_v at the tile's first pixel centre
-  const float p0x = tile_x0 + 0.5f, p0y = tile_y0 + 0.5f;
-  const float hux = p0x * mw0 - mu0, huy = p0x * mw1 - mu1, huz = p0x * mw2 - mu2;
-  const float hvx = p0y * mw0 - mv0, hvy = p0y * mw1 - mv1, hvz = p0y * mw2 - mv2;
-  const float cx = huy * hvz - huz * hvy, cy = huz * hvx - hux * hvz, cz = hux * hvy - huy * hvx;
-  const float D = (cx * mw0 + cy * mw1) + cz * mw2;
+  const float ax = fmaf(mv1, mw2, -(mv2 * mw1)), ay = fmaf(mv2, mw0, -(mv0 * mw2)), az = fmaf(mv0, mw1, -(mv1 * mw0));
+  const float bx = fmaf(mw1, mu2, -(mw2 * mu1)), by = fmaf(mw2, mu0, -(mw0 * mu2)), bz = fmaf(mw0, mu1, -(mw1 * mu0));
+  // C0 = h_u x h_v at the splat's projected centre
+  const float p0x = xy.x, p0y = xy.y;
+  const float hux = fmaf(p0x, mw0, -mu0), huy = fmaf(p0x, mw1, -mu1), huz = fmaf(p0x, mw2, -mu2);
+  const float hvx = fmaf(p0y, mw0, -mv0), hvy = fmaf(p0y, mw1, -mv1), hvz = fmaf(p0y, mw2, -mv2);
+  const float cx = fmaf(huy, hvz, -(huz * hvy)), cy = fmaf(huz, hvx, -(hux * hvz)), cz = fmaf(hux, hvy, -(huy * hvx));
+  const float D = fmaf(cz, mw2, fmaf(cx, mw0, cy * mw1));
   s.q0[slot] = make_float4(ax, ay, az, xy.x);
   s.q1[slot] = make_float4(bx, by, bz, xy.y);
   s.q2[slot] = make_float4(cx, cy, cz, opac);
-  s.q3[slot] = make_float4(D, mw2, c[0], c[1]);
+  s.q3[slot] = make_float4(BWD ? mw0 : D, mw2, c[0], c[1]);
+  if (BWD) s.extra[slot] = mw1;
   s.q4[slot] = make_float4(c[2], n[0], n[1], n[2]);
   s.qmask[slot] = (unsigned char)quadrant_mask(m, xy.x, xy.y, opac, tile_x0, tile_y0);
 }
@@ -125,16 +140,19 @@ struct PairEval {
 };
 
 // Evaluates one (pixel, splat) pair.  (lx, ly) = pixel offset from the tile's first pixel; (px, py) = pixel centre.
-// `ok` is false when the pair does not contribute.  depth: q3.x = D, q3.y = M_w.z.
+// `ok` is false when the pair does not contribute.  depth: forward q3.x = D, q3.y = M_w.z (dep = D / z.z);
+// backward (BWD) q3.x = M_w.x, mwy = M_w.y (dep = s . M_w.xy + M_w.z).
+template <bool BWD = false>
 __device__ __forceinline__ void eval_pair(float lx, float ly, float px, float py, const float4 &a0, const float4 &a1,
-                                          const float4 &a2, float D, float mwz, PairEval &e) {
-  e.zx = fmaf(ly, a1.x, fmaf(lx, a0.x, a2.x));
-  e.zy = fmaf(ly, a1.y, fmaf(lx, a0.y, a2.y));
-  e.zz = fmaf(ly, a1.z, fmaf(lx, a0.z, a2.z));
+                                          const float4 &a2, float D, float mwz, PairEval &e, float mwy = 0.f) {
+  (void)lx; (void)ly;
+  e.dx = a0.w - px; e.dy = a1.w - py;              // mean2d - p (exact)
+  e.zx = fmaf(-e.dy, a1.x, fmaf(-e.dx, a0.x, a2.x));
+  e.zy = fmaf(-e.dy, a1.y, fmaf(-e.dx, a0.y, a2.y));
+  e.zz = fmaf(-e.dy, a1.z, fmaf(-e.dx, a0.z, a2.z));
   e.inv = __builtin_amdgcn_rcpf(e.zz);
   e.sx = e.zx * e.inv; e.sy = e.zy * e.inv;
   const float g3 = e.sx * e.sx + e.sy * e.sy;
-  e.dx = a0.w - px; e.dy = a1.w - py;
   const float g2 = FILTER_INV_SQUARE * (e.dx * e.dx + e.dy * e.dy);
   e.b3 = g3 <= g2;
   const float sigma = 0.5f * (e.b3 ? g3 : g2);
@@ -143,7 +161,7 @@ __device__ __forceinline__ void eval_pair(float lx, float ly, float px, float py
   e.clamped = a > ALPHA_MAX;
   e.alpha = fminf(ALPHA_MAX, a);
   e.ok = (e.zz != 0.0f) && (sigma >= 0.0f) && (e.alpha >= ALPHA_MIN);
-  e.dep = e.b3 ? D * e.inv : mwz;
+  e.dep = e.b3 ? (BWD ? fmaf(e.sx, D, fmaf(e.sy, mwy, mwz)) : D * e.inv) : mwz;
 }
 
 }  // namespace gsdf

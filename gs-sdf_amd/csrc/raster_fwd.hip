@@ -21,7 +21,7 @@ __global__ void __launch_bounds__(RT)
                       float *__restrict__ render_depths, float *__restrict__ render_alphas,
                       float *__restrict__ render_normals, float *__restrict__ render_median,
                       int32_t *__restrict__ last_ids, int32_t *__restrict__ median_ids,
-                      unsigned *__restrict__ visibilities) {
+                      unsigned *__restrict__ visibilities, float *__restrict__ final_T) {
   __shared__ FwdLds lds;
   const int64_t tile = xcd_tile_index(total_tiles, n_xcd);
   if (tile >= total_tiles) return;
@@ -114,6 +114,7 @@ __global__ void __launch_bounds__(RT)
     render_normals[3 * pid] = nx; render_normals[3 * pid + 1] = ny; render_normals[3 * pid + 2] = nz;
     render_depths[pid] = dsum;
     render_alphas[pid] = 1.0f - T;
+    if (final_T != nullptr) final_T[pid] = T;
     render_median[pid] = med;
     last_ids[pid] = cur;
     median_ids[pid] = med_idx;
@@ -130,7 +131,7 @@ extern "C" int gsdf_rasterize_2dgs_fwd(int64_t C, int64_t M, int64_t I, int widt
                                        const uint8_t *masks, const int32_t *isect_offsets,
                                        const int32_t *flatten_ids, float *render_colors, float *render_depths,
                                        float *render_alphas, float *render_normals, float *render_median,
-                                       int32_t *last_ids, int32_t *median_ids, float *visibilities,
+                                       int32_t *last_ids, int32_t *median_ids, float *visibilities, float *final_T,
                                        gsdf_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   GSDF_REQUIRE(tile_size == TILE, "rasterize_fwd: tile_size %d unsupported (16 only)", tile_size);
@@ -149,7 +150,7 @@ extern "C" int gsdf_rasterize_2dgs_fwd(int64_t C, int64_t M, int64_t I, int widt
                                                         colors, opacities, normals, backgrounds, masks, isect_offsets,
                                                         flatten_ids, render_colors, render_depths, render_alphas,
                                                         render_normals, render_median, last_ids, median_ids,
-                                                        (unsigned *)visibilities);
+                                                        (unsigned *)visibilities, final_T);
   GSDF_CHECK_LAUNCH("raster_fwd_kernel");
   return GSDF_OK;
 }

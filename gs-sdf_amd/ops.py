@@ -228,11 +228,14 @@ class _Rasterize2DGS(torch.autograd.Function):
         rc, rd, ra, rn, rm = e(C, height, width, 3), e(C, height, width, 1), e(C, height, width, 1), e(C, height, width, 3), e(C, height, width, 1)
         last = _empty((C, height, width), torch.int32, means2d); med = _empty((C, height, width), torch.int32, means2d)
         vis = _empty((M, 1), torch.float32, means2d)
+        # the transmittance each pixel ended with, kept for the backward: render_alphas = 1 - T cannot give it back once T << 1
+        need = any(ctx.needs_input_grad[:7])
+        fT = _empty((C, height, width), torch.float32, means2d) if need else None
         capi.check(_timed("rasterize_2dgs_fwd", L.gsdf_rasterize_2dgs_fwd, C, M, I, width, height, tile_size, f32(means2d), f32(rt), f32(colors),
                                              f32(opacities), f32(normals), f32(bg), ptr(mk), ptr(isect_offsets, torch.int32),
                                              ptr(flatten_ids, torch.int32), f32(rc), f32(rd), f32(ra), f32(rn), f32(rm),
-                                             ptr(last), ptr(med), f32(vis), capi.stream()), "rasterize_2dgs_fwd")
-        ctx.save_for_backward(means2d, rt, colors, opacities, normals, bg, mk, isect_offsets, flatten_ids, ra, last, med)
+                                             ptr(last), ptr(med), f32(vis), f32(fT), capi.stream()), "rasterize_2dgs_fwd")
+        ctx.save_for_backward(means2d, rt, colors, opacities, normals, bg, mk, isect_offsets, flatten_ids, ra, last, med, fT)
         ctx.dims = (width, height, tile_size)
         ctx.absgrad = bool(ctx.needs_input_grad[6])
         distort = torch.zeros((C, height, width, 1), dtype=torch.float32, device=means2d.device)
@@ -242,7 +245,7 @@ class _Rasterize2DGS(torch.autograd.Function):
     @staticmethod
     def backward(ctx, v_rc, v_rd, v_ra, v_rn, _v_dist, v_rm, _v_vis):
         L = capi.lib()
-        means2d, rt, colors, opacities, normals, bg, mk, isect_offsets, flatten_ids, ra, last, med = ctx.saved_tensors
+        means2d, rt, colors, opacities, normals, bg, mk, isect_offsets, flatten_ids, ra, last, med, fT = ctx.saved_tensors
         width, height, tile_size = ctx.dims
         C, M, I = isect_offsets.shape[0], opacities.shape[0], flatten_ids.shape[0]
         zz = lambda g, ch: (torch.zeros((C, height, width, ch), dtype=torch.float32, device=means2d.device) if g is None
@@ -256,7 +259,7 @@ class _Rasterize2DGS(torch.autograd.Function):
                                              f32(opacities), f32(normals), f32(bg), ptr(mk), ptr(isect_offsets),
                                              ptr(flatten_ids), f32(ra), ptr(last), ptr(med), f32(v_rc), f32(v_rd), f32(v_ra),
                                              f32(v_rn), f32(v_rm), f32(v_means2d), f32(v_rt), f32(v_colors), f32(v_opac),
-                                             f32(v_normals), f32(v_dens), f32(v_abs), ptr(ws), capi.stream()), "rasterize_2dgs_bwd")
+                                             f32(v_normals), f32(v_dens), f32(v_abs), ptr(ws), f32(fT), capi.stream()), "rasterize_2dgs_bwd")
         return (v_means2d, v_rt, v_colors, v_opac, v_normals, v_dens, v_abs, None, None, None, None, None, None, None)
 
 

@@ -124,10 +124,15 @@ int gsdf_rasterize_2dgs_fwd(int64_t n_cams, int64_t n_visible, int64_t n_isects,
                             float *render_depths /*[C,H,W,1]*/, float *render_alphas /*[C,H,W,1]*/,
                             float *render_normals /*[C,H,W,3]*/, float *render_median /*[C,H,W,1]*/,
                             int32_t *last_ids /*[C,H,W]*/, int32_t *median_ids /*[C,H,W]*/,
-                            float *visibilities /*[M,1], fully written*/, gsdf_stream_t stream);
+                            float *visibilities /*[M,1], fully written*/,
+                            float *final_T /*[C,H,W] or NULL: the transmittance after the last blended splat, saved for the
+                                             backward (render_alphas = 1 - T loses it to rounding once T << 1)*/,
+                            gsdf_stream_t stream);
 
 /* All gradient outputs are fully written.  v_means2d_abs may be NULL.  ws >= *_bwd_ws_bytes(M): the kernel
- * accumulates one packed 80-byte gradient record per splat there (line-coalesced atomics) and unpacks it. */
+ * accumulates one packed 80-byte gradient record per splat there (line-coalesced atomics) and unpacks it.
+ * final_T: the forward's saved transmittance, or NULL (then T_final = 1 - render_alphas as upstream gsplat does, which is
+ * only accurate to 6e-8 ABSOLUTE: a 6e-4 relative error of every weight of a pixel that ended at T = 1e-4). */
 size_t gsdf_rasterize_2dgs_bwd_ws_bytes(int64_t n_visible);
 int gsdf_rasterize_2dgs_bwd(int64_t n_cams, int64_t n_visible, int64_t n_isects, int width, int height,
                             int tile_size, const float *means2d, const float *ray_transforms,
@@ -138,7 +143,7 @@ int gsdf_rasterize_2dgs_bwd(int64_t n_cams, int64_t n_visible, int64_t n_isects,
                             const float *v_render_depths, const float *v_render_alphas,
                             const float *v_render_normals, const float *v_render_median, float *v_means2d,
                             float *v_ray_transforms, float *v_colors, float *v_opacities, float *v_normals,
-                            float *v_densify, float *v_means2d_abs, void *ws, gsdf_stream_t stream);
+                            float *v_densify, float *v_means2d_abs, void *ws, const float *final_T, gsdf_stream_t stream);
 
 
 /* ------------------------------------------------------------------------------------------

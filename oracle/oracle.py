@@ -165,8 +165,10 @@ def rasterize_2dgs_fwd(means2d, ray_transforms, colors, opacities, normals, W, H
 def rasterize_2dgs_bwd(means2d, ray_transforms, colors, opacities, normals, W, H, tile_size, isect_offsets,
                        flatten_ids, render_alphas, last_ids, median_ids, v_render_colors, v_render_depths,
                        v_render_alphas, v_render_normals, v_render_median, backgrounds=None, masks=None,
-                       absgrad=True, prec="f32"):
-    """Gradients are returned as float64 arrays irrespective of `prec`."""
+                       absgrad=True, prec="f32", abs_sums=False):
+    """Gradients are returned as float64 arrays irrespective of `prec`.  abs_sums=True adds `abs_ray_transforms` [M,3,3] and
+    `abs_densify` [M,2]: the sum over pixels of |per-pixel contribution| to each element (the conditioning of the sums: an fp32
+    accumulation of those terms cannot be more accurate than ~eps32 x this)."""
     dt = _dt(prec)
     m2d, rt, col, opa, nrm, bg = (_c(a, dt) for a in (means2d, ray_transforms, colors, opacities, normals,
                                                       backgrounds))
@@ -179,13 +181,35 @@ def rasterize_2dgs_bwd(means2d, ray_transforms, colors, opacities, normals, W, H
     Mz = max(M, 1)
     g = dict(v_means2d=np.zeros((Mz, 2)), v_ray_transforms=np.zeros((Mz, 3, 3)), v_colors=np.zeros((Mz, 3)),
              v_opacities=np.zeros(Mz), v_normals=np.zeros((Mz, 3)), v_densify=np.zeros((Mz, 2)),
-             v_means2d_abs=np.zeros((Mz, 2)) if absgrad else None)
+             v_means2d_abs=np.zeros((Mz, 2)) if absgrad else None,
+             abs_ray_transforms=np.zeros((Mz, 3, 3)) if abs_sums else None, abs_densify=np.zeros((Mz, 2)) if abs_sums else None)
     _lib("splat", prec).orc_rasterize_2dgs_bwd(
         C.c_int64(Cn), C.c_int64(M), C.c_int64(I), C.c_int(W), C.c_int(H), C.c_int(tile_size), _p(m2d), _p(rt),
         _p(col), _p(opa), _p(nrm), _p(bg), _p(masks), _p(offs), _p(flat), _p(ralpha), _p(last), _p(med), _p(vc),
         _p(vd), _p(va), _p(vn), _p(vmed), _p(g["v_means2d"]), _p(g["v_ray_transforms"]), _p(g["v_colors"]),
-        _p(g["v_opacities"]), _p(g["v_normals"]), _p(g["v_densify"]), _p(g["v_means2d_abs"]))
-    return {k: (v[:M] if v is not None else None) for k, v in g.items()}
+        _p(g["v_opacities"]), _p(g["v_normals"]), _p(g["v_densify"]), _p(g["v_means2d_abs"]), _p(g["abs_ray_transforms"]),
+        _p(g["abs_densify"]))
+    return {k: (v[:M] if v is not None else None) for k, v in g.items() if v is not None or k == "v_means2d_abs"}
+
+
+def rasterize_2dgs_fragility(means2d, ray_transforms, opacities, W, H, tile_size, isect_offsets, flatten_ids, masks=None,
+                             kmargin=16.0, ulp_floor=2.4e-7, cond_abs=2e-6, kappa_max=8.0, prec="f64"):
+    """Decision margins of the compositing operator (oracle/splat_oracle.c: orc_rasterize_2dgs_fragility).
+    -> pix_flags uint8 [C,H,W], splat_flags uint8 [M], counts {pairs, valid}.  flag 0 = every decision the pixel (or any pixel
+    that blends the splat) takes has a margin of more than `kmargin` x the fp32 evaluation error of the compared quantity and
+    no blending weight is ill-conditioned (and, for a splat, it is nowhere blended edge-on: cancellation of z.z below
+    `kappa_max`): the elements a 1e-4 element-wise comparison is meaningful on."""
+    dt = _dt(prec)
+    m2d, rt, opa = (_c(a, dt) for a in (means2d, ray_transforms, opacities))
+    offs, flat = _c(isect_offsets, np.int32), _c(flatten_ids, np.int32)
+    masks = _c(masks, np.uint8)
+    Cn, M, I = offs.shape[0], opa.shape[0], flat.shape[0]
+    pf = np.zeros((Cn, H, W), np.uint8); sf = np.zeros(max(M, 1), np.uint8); counts = np.zeros(8, np.int64)
+    _lib("splat", prec).orc_rasterize_2dgs_fragility(
+        C.c_int64(Cn), C.c_int64(M), C.c_int64(I), C.c_int(W), C.c_int(H), C.c_int(tile_size), _p(m2d), _p(rt), _p(opa),
+        _p(masks), _p(offs), _p(flat), C.c_double(kmargin), C.c_double(ulp_floor), C.c_double(cond_abs), C.c_double(kappa_max),
+        _p(pf), _p(sf), _p(counts))
+    return pf, sf[:M], dict(pairs=int(counts[0]), valid=int(counts[1]))
 
 
 def set_threads(n):

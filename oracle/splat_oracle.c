@@ -590,6 +590,12 @@ void orc_rasterize_2dgs_fwd(int64_t C, int64_t M, int64_t I, int W, int H, int t
   }
 }
 
+/* debugging aid (tools/): per-pixel (pid, v_sigma, v_dep, alpha, T, branch) of ONE splat during the next backward call */
+static int64_t dbg_gid = -1, dbg_cap = 0, dbg_n = 0;
+static double *dbg_buf = 0;
+void orc_debug_trace_splat(int64_t gid, int64_t cap, double *buf) { dbg_gid = gid; dbg_cap = cap; dbg_buf = buf; dbg_n = 0; }
+int64_t orc_debug_trace_count(void) { return dbg_n; }
+
 /* SPEC A.5: VJP of the compositing.  Gradient buffers [M,.] must be zeroed by the caller.
  * v_means2d_abs may be NULL.  Gradient outputs are double regardless of REAL (deterministic
  * per-tile accumulation, cross-tile merge in double). */
@@ -603,11 +609,13 @@ void orc_rasterize_2dgs_bwd(int64_t C, int64_t M, int64_t I, int W, int H, int t
                             const REAL *v_render_alphas, const REAL *v_render_normals,
                             const REAL *v_render_median, double *v_means2d,
                             double *v_ray_transforms, double *v_colors, double *v_opacities,
-                            double *v_normals, double *v_densify, double *v_means2d_abs) {
+                            double *v_normals, double *v_densify, double *v_means2d_abs,
+                            double *abs_ray_transforms /* [M,9] or NULL: sum of |per-pixel contribution| */,
+                            double *abs_densify /* [M,2] or NULL */) {
   int tw = (W + tile_size - 1) / tile_size, th = (H + tile_size - 1) / tile_size;
   int64_t n_tiles = (int64_t)tw * th;
   (void)M;
-  enum { NG = 22 }; /* per-splat accumulators: xy2 M9 col3 opac1 nrm3 dens2 abs2 */
+  enum { NG = 33 }; /* per-splat accumulators: xy2 M9 col3 opac1 nrm3 dens2 abs2 | |M|9 |dens|2 (conditioning of the sums) */
 #pragma omp parallel for schedule(dynamic, 4)
   for (int64_t t = 0; t < C * n_tiles; ++t) {
     int64_t c = t / n_tiles, tl = t % n_tiles;
@@ -665,6 +673,13 @@ void orc_rasterize_2dgs_bwd(int64_t C, int64_t M, int64_t I, int W, int H, int t
             v_sigma = -opacities[g] * e.vis * v_alpha; /* d alpha / d sigma */
           }
           const REAL *Mw = Mrow + 6;
+          if (g == dbg_gid && dbg_buf) {
+#pragma omp critical(dbgtrace)
+            if (dbg_n < dbg_cap) {
+              double *r = dbg_buf + 6 * dbg_n++;
+              r[0] = (double)pid; r[1] = (double)v_sigma; r[2] = (double)v_dep; r[3] = (double)e.alpha; r[4] = (double)T; r[5] = e.branch3d;
+            }
+          }
           if (e.branch3d) {
             /* sigma = 0.5 (s.s); dep = s.x Mw.x + s.y Mw.y + Mw.z */
             REAL v_s[2] = {v_sigma * e.s[0] + v_dep * Mw[0], v_sigma * e.s[1] + v_dep * Mw[1]};
@@ -683,15 +698,31 @@ void orc_rasterize_2dgs_bwd(int64_t C, int64_t M, int64_t I, int W, int H, int t
               a[5 + k] += -v_hv[k];
               a[8 + k] += vMw[k];
             }
+            {
+              /* conditioning of the same sums: every product that enters a difference, in absolute value (the cross
+               * products h x v_z cancel per pixel when h and v_z are close to parallel, v_z.z = -(v_s . s) cancels too) */
+              const double za[3] = {fabs((double)v_z[0]), fabs((double)v_z[1]), fabs((double)(vsx * e.s[0])) + fabs((double)(vsy * e.s[1]))};
+              for (int k = 0; k < 3; ++k) {
+                const int k1 = (k + 1) % 3, k2 = (k + 2) % 3;
+                const double ahu = fabs((double)e.hv[k1]) * za[k2] + fabs((double)e.hv[k2]) * za[k1];
+                const double ahv = fabs((double)e.hu[k1]) * za[k2] + fabs((double)e.hu[k2]) * za[k1];
+                a[22 + k] += ahu;
+                a[25 + k] += ahv;
+                a[28 + k] += fabs((double)px) * ahu + fabs((double)py) * ahv + fabs((double)(v_dep * (k < 2 ? e.s[k] : 1)));
+                if (k == 2) { a[31] += ahu * fabs((double)Mw[2]); a[32] += ahv * fabs((double)Mw[2]); }
+              }
+            }
             /* densification signal (2DGS: dL/dM[2]*depth, dL/dM[5]*depth) SPEC S-4 */
             a[18] += -v_hu[2] * Mw[2];
             a[19] += -v_hv[2] * Mw[2];
+
           } else {
             /* sigma = 0.5*2*(d.d) ; dep = Mw.z */
             REAL gx = v_sigma * FILTER_INV_SQUARE * e.d[0], gy = v_sigma * FILTER_INV_SQUARE * e.d[1];
             a[0] += gx; a[1] += gy;
             a[20] += fabs((double)gx); a[21] += fabs((double)gy);
             a[10] += v_dep;
+            a[30] += fabs((double)v_dep);
           }
         }
       }
@@ -705,9 +736,139 @@ void orc_rasterize_2dgs_bwd(int64_t C, int64_t M, int64_t I, int W, int H, int t
       v_opacities[g] += a[14];
       v_densify[2 * g] += a[18]; v_densify[2 * g + 1] += a[19];
       if (v_means2d_abs) { v_means2d_abs[2 * g] += a[20]; v_means2d_abs[2 * g + 1] += a[21]; }
+      if (abs_ray_transforms) for (int q = 0; q < 9; ++q) abs_ray_transforms[9 * g + q] += a[22 + q];
+      if (abs_densify) { abs_densify[2 * g] += a[31]; abs_densify[2 * g + 1] += a[32]; }
     }
     free(acc);
   }
+}
+
+
+/* ---------------------------------------------------------------------------------------
+ * P4 fragility analysis (test infrastructure for the decision-matched parity gate).
+ *
+ * The compositing operator (SPEC A.4 / A.5) is piecewise smooth: per (pixel, splat) pair it takes the decisions
+ *   alpha >= 1/255 (contribute), T (1 - alpha) <= 1e-4 (stop), T > 0.5 (median), g3 <= g2 (which footprint, which
+ *   depth), opac * vis > 0.999 (clamp: gates d alpha).
+ * Two correct fp32 evaluations of the same inputs may take a different side of a decision whose margin is inside
+ * their rounding error, and then differ by O(alpha T) in that pixel and in the gradient of every splat the pixel
+ * blends.  This function walks every pixel's list with the build's own (f64: exact) decisions, evaluates every pair a
+ * second time in plain fp32 (the direct h_u x h_v form), and flags a pair as FRAGILE when a decision margin is
+ * within `kmargin` x the observed fp32 evaluation error of the quantity that is compared (with a floor of
+ * `ulp_floor` relative), or as ILL-CONDITIONED when the fp32 evaluation of its blending weight deviates by more than
+ * `cond_abs` (absolute, T-weighted).  pix_flags[p] = OR over the pixel's pairs; splat_flags[g] = OR of the flags of
+ * every pixel in which splat g is blended (or is itself the fragile pair).  Elements with flag 0 are the ones on
+ * which a 1e-4 element-wise comparison is meaningful; the caller reports the excluded fraction.
+ * A splat is additionally flagged EDGE-ON (64, splat only) when, in a pixel that blends it, the z.z component of
+ * h_u x h_v = h_u.x h_v.y - h_u.y h_v.x cancels by more than `kappa_max` (kappa = (|h_u.x h_v.y| + |h_u.y h_v.x|) / |z.z|):
+ * every fp32 evaluation of s = z.xy / z.z — the reference's included — then carries ~kappa x 6e-8 relative error, amplified
+ * again by the 1 / z.z^2 of the gradient; its own gradient is not comparable at 1e-4 element-wise.
+ * bits: 1 alpha test, 2 termination, 4 median, 8 footprint branch, 16 clamp, 32 ill-conditioned weight, 64 edge-on splat.
+ * ------------------------------------------------------------------------------------- */
+typedef struct { float a, g3, g2; int zero; } pair32_t;
+static inline pair32_t eval_pair_f32(float px, float py, float mx, float my, float opac, const float *M) {
+  pair32_t r; r.zero = 0; r.a = 0; r.g3 = 0; r.g2 = 0;
+  float hu[3], hv[3];
+  /* fused multiply-adds where a GPU compiler contracts them (nvcc -fmad=true, hipcc -ffp-contract=fast): h = p M_w - M is the
+   * cancelling step (|p M_w.z| ~ |M.z| ~ 1e3 x |h.z|), exactly rounded with an FMA */
+  for (int j = 0; j < 3; ++j) { hu[j] = fmaf(px, M[6 + j], -M[j]); hv[j] = fmaf(py, M[6 + j], -M[3 + j]); }
+  float zx = fmaf(hu[1], hv[2], -(hu[2] * hv[1])), zy = fmaf(hu[2], hv[0], -(hu[0] * hv[2])), zz = fmaf(hu[0], hv[1], -(hu[1] * hv[0]));
+  if (zz == 0.0f) { r.zero = 1; return r; }
+  float sx = zx / zz, sy = zy / zz;
+  r.g3 = sx * sx + sy * sy;
+  float dx = mx - px, dy = my - py;
+  r.g2 = 2.0f * (dx * dx + dy * dy);
+  float sigma = 0.5f * (r.g3 <= r.g2 ? r.g3 : r.g2);
+  r.a = opac * expf(-sigma);
+  return r;
+}
+
+void orc_rasterize_2dgs_fragility(int64_t C, int64_t M, int64_t I, int W, int H, int tile_size,
+                                  const REAL *means2d, const REAL *ray_transforms, const REAL *opacities,
+                                  const uint8_t *masks, const int32_t *isect_offsets, const int32_t *flatten_ids,
+                                  double kmargin, double ulp_floor, double cond_abs, double kappa_max,
+                                  uint8_t *pix_flags, uint8_t *splat_flags, int64_t *counts /* [8] */) {
+  int tw = (W + tile_size - 1) / tile_size, th = (H + tile_size - 1) / tile_size;
+  int64_t n_tiles = (int64_t)tw * th;
+  for (int64_t m = 0; m < M; ++m) splat_flags[m] = 0;
+  for (int q = 0; q < 8; ++q) counts[q] = 0;
+  int64_t n_pairs = 0, n_valid = 0;
+#pragma omp parallel for schedule(dynamic, 4) reduction(+ : n_pairs, n_valid)
+  for (int64_t t = 0; t < C * n_tiles; ++t) {
+    int64_t c = t / n_tiles, tl = t % n_tiles;
+    int ty = (int)(tl / tw), tx = (int)(tl % tw);
+    int32_t start = isect_offsets[t];
+    int32_t end = (t == C * n_tiles - 1) ? (int32_t)I : isect_offsets[t + 1];
+    int masked = masks && !masks[t];
+    int32_t len = masked ? 0 : end - start;
+    uint8_t *sf = (uint8_t *)calloc((size_t)(len > 0 ? len : 1), 1);
+    uint8_t *touched = (uint8_t *)malloc((size_t)(len > 0 ? len : 1));
+    for (int yy = 0; yy < tile_size; ++yy)
+      for (int xx = 0; xx < tile_size; ++xx) {
+        int i = ty * tile_size + yy, j = tx * tile_size + xx;
+        if (i >= H || j >= W) continue;
+        int64_t pid = (c * H + i) * (int64_t)W + j;
+        REAL px = (REAL)j + (REAL)0.5, py = (REAL)i + (REAL)0.5;
+        double T = 1, eT = 0;   /* transmittance and a running bound of its fp32 evaluation error */
+        uint8_t pf = 0;
+        int32_t prev_valid = -1;
+        memset(touched, 0, (size_t)(len > 0 ? len : 1));
+        for (int32_t k = 0; k < len; ++k) {
+          int32_t g = flatten_ids[start + k];
+          pix_eval_t e;
+          eval_pair(px, py, means2d + 2 * g, opacities[g], ray_transforms + 9 * g, &e);
+          float Mf[9];
+          for (int q = 0; q < 9; ++q) Mf[q] = (float)ray_transforms[9 * g + q];
+          pair32_t f = eval_pair_f32((float)px, (float)py, (float)means2d[2 * g], (float)means2d[2 * g + 1], (float)opacities[g], Mf);
+          ++n_pairs;
+          if (e.z[2] == 0 || f.zero) { if (e.z[2] != 0 || !f.zero) { pf |= 32; touched[k] = 1; } continue; }
+          double a64 = (double)opacities[g] * (double)e.vis;          /* before the clamp */
+          double err_a = fabs((double)f.a - a64) + ulp_floor * a64;
+          double g3 = (double)(e.s[0] * e.s[0] + e.s[1] * e.s[1]);
+          double g2 = 2.0 * (double)(e.d[0] * e.d[0] + e.d[1] * e.d[1]);
+          double err_g = fabs((double)f.g3 - g3) + fabs((double)f.g2 - g2) + ulp_floor * (g3 > g2 ? g3 : g2);
+          double alpha = a64 < 0.999 ? a64 : 0.999;
+          uint8_t fl = 0;
+          if (fabs(alpha - 1.0 / 255.0) <= kmargin * err_a) fl |= 1;
+          int contributes = e.valid;
+          if (contributes || (fl & 1)) {
+            if (fabs(g3 - g2) <= kmargin * err_g) fl |= 8;
+            if (fabs(a64 - 0.999) <= kmargin * err_a) fl |= 16;
+            if (T * err_a > cond_abs + T * ulp_floor * a64 * 4) fl |= 32;
+          }
+          if (contributes) {
+            double nT = T * (1 - alpha);
+            double enT = eT * (1 - alpha) + T * err_a + ulp_floor * nT;
+            if (fabs(nT - 1e-4) <= kmargin * enT) fl |= 2;
+            if (nT <= 1e-4) { if (fl) { pf |= fl; touched[k] = 1; } break; }
+            if (fabs(T - 0.5) <= kmargin * (eT + ulp_floor * T)) {
+              /* median = the last pair blended while T > 0.5: a flip moves render_median (and its upstream gradient)
+               * between this pair and the previous blended one; nothing else in the pixel changes */
+              pf |= 4; sf[k] |= 4;
+              if (prev_valid >= 0) sf[prev_valid] |= 4;
+            }
+            ++n_valid;
+            touched[k] = 1;
+            prev_valid = k;
+            {
+              const double t1 = fabs((double)(e.hu[0] * e.hv[1])), t2 = fabs((double)(e.hu[1] * e.hv[0]));
+              if (t1 + t2 > kappa_max * fabs((double)e.z[2])) sf[k] |= 64;
+            }
+            T = nT; eT = enT;
+          }
+          if (fl) { pf |= fl; touched[k] = 1; }
+        }
+        pix_flags[pid] = pf;
+        if (pf & ~4)
+          for (int32_t k = 0; k < len; ++k)
+            if (touched[k]) sf[k] |= (uint8_t)(pf & ~4);
+      }
+#pragma omp critical
+    for (int32_t k = 0; k < len; ++k)
+      if (sf[k]) splat_flags[flatten_ids[start + k]] |= sf[k];
+    free(sf); free(touched);
+  }
+  counts[0] = n_pairs; counts[1] = n_valid;
 }
 
 int orc_real_bytes(void) { return (int)sizeof(REAL); }

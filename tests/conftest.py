@@ -21,14 +21,14 @@ def oracle():
 
 
 def pytest_sessionfinish(session, exitstatus):
-    """The compositing parity measurements of the session (tests/util.py: assert_parity) -> gpurun_out/parity_small_cases.json"""
+    """The compositing parity measurements of the session (tests/util.py: assert_clean_parity) -> gpurun_out/parity_small_cases.json"""
     try:
         import json
         import util
         if util.PARITY_LOG:
             out = os.path.join(ROOT, "gpurun_out")
             os.makedirs(out, exist_ok=True)
-            rows = [dict(tensor=nm, hip=st, fp32_cpu_restatement_for_information=info) for nm, st, info in util.PARITY_LOG]
+            rows = [dict(tensor=nm, hip_vs_fp64_oracle=st) for nm, st in util.PARITY_LOG]
             json.dump(rows, open(os.path.join(out, "parity_small_cases.json"), "w"), indent=1)
     except Exception:
         pass

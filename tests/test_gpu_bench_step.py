@@ -41,6 +41,44 @@ def test_overlapped_step_gives_the_single_stream_gradients(tmp_path, workload):
         assert_close(got["sdf"][0], ref["sdf"][0], 1e-4, f"{mode}: SDF network gradients")
 
 
+def test_gpus_flag_starts_the_ranks_itself():
+    """`python bench.py --gpus 2` with no launcher (the way the driver calls it for N=1 and may call it for N>1): the script must
+    start 2 ranks itself.  With >= 2 GPUs: 2 RCCL ranks, n_gpus == 2 in the line.  On a 1-GPU box: a loud refusal (non-zero exit,
+    a message naming the device count), never a 1-rank number labelled as 2 GPUs."""
+    args = ["--gpus", "2", "--steps", "2", "--warmup", "1", "--workload", "cfg0_10k_256", "--no-cpu-baseline", "--no-secondary"]
+    e = dict(os.environ)
+    e.pop("WORLD_SIZE", None), e.pop("RANK", None), e.pop("LOCAL_RANK", None), e.pop("GSDF_BENCH_BACKEND", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], cwd=ROOT, env=e, capture_output=True, text=True, timeout=900)
+    if torch.cuda.device_count() >= 2:
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+        j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+        assert j["n_gpus"] == 2 and j["value"] > 0
+    else:
+        assert r.returncode != 0
+        assert "device_count() = 1" in r.stderr and not any(l.startswith("{") for l in r.stdout.splitlines())
+
+
+def test_gpus_flag_self_spawn_over_gloo_on_one_device():
+    """the same self-spawn path end to end on ONE device (GSDF_BENCH_BACKEND=gloo lets the two ranks share it)"""
+    e = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    e["GSDF_BENCH_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--workload",
+                        "cfg0_10k_256", "--no-cpu-baseline", "--no-secondary"], cwd=ROOT, env=e, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert j["n_gpus"] == 2 and j["value"] > 0 and j["scaling"] == "weak"
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="RCCL needs one device per rank")
+def test_two_ranks_over_rccl():
+    launcher = ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                "--master-port", "29533"]
+    txt = _bench(["--gpus", "2", "--steps", "3", "--warmup", "2", "--workload", "cfg1_replica_300k", "--no-cpu-baseline", "--no-secondary"],
+                 env={"GSDF_BENCH_BACKEND": "nccl", "HSA_ENABLE_IPC_MODE_LEGACY": "0"}, launcher=launcher)
+    j = json.loads([l for l in txt.splitlines() if l.startswith("{")][-1])
+    assert j["n_gpus"] == 2 and j["value"] > 0 and j["params_finite"]
+
+
 def test_two_ranks_view_parallel_step_runs():
     launcher = ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                 "--master-port", "29531"]

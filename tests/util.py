@@ -44,60 +44,76 @@ def _scaled_err(a, r):
     return np.abs(a - r) / np.maximum(np.abs(r), floor), a, r
 
 
-# Absolute parity gates for the compositing kernels (rasterize_to_pixels_2dgs forward / backward) against the oracle's fp64
-# build.  The operator is DISCONTINUOUS in its inputs (alpha >= 1/255, T(1-alpha) <= 1e-4, median T > 0.5) and
-# ill-conditioned for edge-on splats (z = h_u x h_v cancels), so no fp32 evaluation, on any hardware, puts EVERY element
-# within 1e-4 of the exact result; the gates bound the error DISTRIBUTION instead:
-#     bulk  = relative L2 error over the elements whose scaled error is <= 1e-2
-#     f4/f3/f2 = fraction of elements with scaled error above 1e-4 / 1e-3 / 1e-2  (each with a floor of 12 elements)
-# The numbers are the errors measured for the HIP kernels on MI355X with 2-3x head-room (profiles/parity_r02.json holds the
-# measurements at the BASELINE shapes; the small cases of tests/test_gpu_splat_parity.py sit inside the same gates).
-# The fp32 CPU restatement's own error is reported next to them for information and gates nothing.
-GATE_IMAGE = dict(bulk=2e-5, f4=5e-5, f3=2e-5, f2=5e-6, worst=5e-2)        # rendered images, visibilities
-GATE_GRAD = dict(bulk=2e-3, f4=3e-3, f3=2.5e-4, f2=4e-5, worst=None)       # per-splat gradients, tile lists up to ~1000 entries
-GATE_GRAD_LONG = dict(bulk=6e-4, f4=1.2e-1, f3=1e-2, f2=1e-4, worst=None)  # tile lists of thousands of entries (cfg4-like)
-IMAGE_KEYS = ("render_colors", "render_depths", "render_alphas", "render_normals", "visibilities")
+# ---------------------------------------------------------------------------------------------------------------------------
+# Decision-matched parity gate of the compositing kernels (rasterize_to_pixels_2dgs forward / backward) against the oracle's
+# fp64 build.  The operator is piecewise smooth: per (pixel, splat) it DECIDES alpha >= 1/255, T(1-alpha) <= 1e-4, T > 0.5
+# (median), g3 <= g2 (footprint / depth definition) and alpha clamped at 0.999.  Two correct fp32 evaluations can take
+# different sides of a decision whose margin is inside their rounding error, and then differ by O(alpha T) in that pixel and
+# in the gradient of every splat the pixel blends — that is not an arithmetic error and no tolerance separates it from one.
+# oracle.rasterize_2dgs_fragility() therefore walks every pixel's list with the fp64 decisions and flags
+#   * a PIXEL whose list holds a pair with a decision margin below 16 x the fp32 evaluation error of the compared quantity
+#     (or a blending weight whose fp32 evaluation is off by more than 2e-6 absolute, T-weighted),
+#   * a SPLAT that such a pixel blends, or that is blended EDGE-ON somewhere (z.z = h_u.x h_v.y - h_u.y h_v.x cancels by
+#     more than 8x: every fp32 evaluation, the reference's too, then has ~kappa x 6e-8 relative error in s = z.xy / z.z and
+#     kappa^2-ish in its own gradient).
+# On everything else (>= 99.9 % of the pixels, >= 95 % of the splats at the BASELINE shapes; the excluded fraction is reported
+# and bounded) the bar is north_star's: ELEMENT-WISE 1e-4 (scaled by max(|ref|, mean|ref|) of the tensor), images with no
+# exception, per-splat gradients with at most max(3, 1e-4 x rows) straggler rows, none beyond 1e-2, and a relative L2 error
+# of the whole clean set <= 1e-5.  The stragglers that exist are components of dL/dM_w that are ~100x smaller than their
+# own row (a sum of p_x v_hu + p_y v_hv terms ~1e3 x larger): their error is <= 80 x eps32 x sum|terms|
+# (tools/diag_parity_fragile.py prints that ratio).
+# ---------------------------------------------------------------------------------------------------------------------------
+IMAGE_KEYS = ("render_colors", "render_depths", "render_alphas", "render_normals", "render_median", "visibilities")
+PIXEL_KEYS = ("render_colors", "render_depths", "render_alphas", "render_normals", "render_median")
+MAX_EXCLUDED_PIXELS = 0.02      # decision-fragile pixels (measured 2e-4 .. 5e-3)
+MAX_EXCLUDED_SPLATS = 0.12      # decision-fragile or edge-on splats (measured 3 .. 4.5 %; adversarial edge-case scenes up to 10 %)
 
 
-def parity_stats(got, ref):
-    e, a, r = _scaled_err(got, ref)
-    if r.size == 0:
-        return dict(n=0, rel_l2=0.0, bulk=0.0, f4=0.0, f3=0.0, f2=0.0, worst=0.0, above_1e4=0)
-    core = e <= 1e-2
-    return dict(n=int(r.size), rel_l2=float(np.linalg.norm(a - r) / (np.linalg.norm(r) + 1e-30)),
-                bulk=float(np.linalg.norm((a - r)[core]) / (np.linalg.norm(r[core]) + 1e-30)),
-                f4=float((e > 1e-4).mean()), f3=float((e > 1e-3).mean()), f2=float((e > 1e-2).mean()),
-                above_1e4=int((e > 1e-4).sum()), worst=float(e.max()))
+def fragility(oracle, p, opa, W, H, offs, flat, masks=None, max_pixels=MAX_EXCLUDED_PIXELS, max_splats=MAX_EXCLUDED_SPLATS):
+    """(pixel_clean bool [C,H,W], splat_clean bool [M], info) of one compositing problem (see the block comment above).
+    max_pixels / max_splats bound the excluded fractions so that the gate cannot become vacuous."""
+    pf, sf, cnt = oracle.rasterize_2dgs_fragility(p["means2d"], p["ray_transforms"], opa, W, H, 16, offs, flat, masks=masks)
+    info = dict(pixels_excluded=float((pf != 0).mean()) if pf.size else 0.0, splats_excluded=float((sf != 0).mean()) if sf.size else 0.0,
+                by_flag={nm: [float(((pf & b) != 0).mean()) if pf.size else 0.0, float(((sf & b) != 0).mean()) if sf.size else 0.0]
+                         for b, nm in ((1, "alpha"), (2, "termination"), (4, "median"), (8, "branch"), (16, "clamp"), (32, "weight"), (64, "edge_on"))},
+                pairs=cnt)
+    assert info["pixels_excluded"] <= max_pixels, f"{info['pixels_excluded']:.3%} of the pixels are decision-fragile: the gate would be vacuous"
+    assert info["splats_excluded"] <= max_splats, f"{info['splats_excluded']:.3%} of the splats are excluded: the gate would be vacuous"
+    return pf == 0, sf == 0, info
 
 
-def gate_violations(stats, gate, name):
-    out, n = [], max(stats["n"], 1)
-    if stats["bulk"] > gate["bulk"]:
-        out.append(f"{name}: bulk relative L2 {stats['bulk']:.2e} > {gate['bulk']:.0e}")
-    for k, thr in (("f4", "1e-4"), ("f3", "1e-3"), ("f2", "1e-2")):
-        if stats[k] * n > max(12, gate[k] * n):
-            out.append(f"{name}: {stats[k] * n:.0f} elements ({stats[k]:.2e}) above {thr}, allowed {max(12, gate[k] * n):.0f}")
-    if gate.get("worst") is not None and stats["worst"] > gate["worst"]:
-        out.append(f"{name}: worst scaled error {stats['worst']:.2e} > {gate['worst']:.0e}")
-    return out
+def clean_parity_stats(got, ref, clean, rows_are="splats"):
+    """Scaled element-wise error of `got` against `ref` (fp64 oracle) restricted to the clean rows.
+    clean: bool over the leading dims of ref (pixels [C,H,W] or splats [M])."""
+    got = got.detach().cpu().double().numpy() if isinstance(got, torch.Tensor) else np.asarray(got, np.float64)
+    ref = ref.detach().cpu().double().numpy() if isinstance(ref, torch.Tensor) else np.asarray(ref, np.float64)
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    if ref.size == 0:
+        return dict(rows=0, clean_rows=0, rows_above_1e4=0, worst=0.0, rel_l2=0.0, all_rows_above_1e4=0, all_worst=0.0)
+    R = int(np.prod(clean.shape))
+    g2, r2, c = got.reshape(R, -1), ref.reshape(R, -1), np.asarray(clean).reshape(R)
+    floor = np.abs(r2).mean() + 1e-30
+    e = (np.abs(g2 - r2) / np.maximum(np.abs(r2), floor)).max(1)
+    ec = e[c]
+    return dict(rows=R, clean_rows=int(c.sum()), rows_above_1e4=int((ec > 1e-4).sum()), worst=float(ec.max()) if ec.size else 0.0,
+                rel_l2=float(np.linalg.norm((g2 - r2)[c]) / (np.linalg.norm(r2[c]) + 1e-30)),
+                all_rows_above_1e4=int((e > 1e-4).sum()), all_worst=float(e.max()))
 
 
-PARITY_LOG = []          # (name, HIP stats, fp32-restatement stats): test modules may dump it
+PARITY_LOG = []          # (name, stats): test modules may dump it
 
 
-def assert_parity(got, ref64, ref32, rel=1e-4, name="", discrete=False, gate=None):
-    """Absolute gate (see GATE_* above) of a compositing output / gradient against the oracle's fp64 build; the fp32 CPU
-    restatement (`ref32`) is evaluated for information only.  `discrete=True` (render_median: the depth of ONE selected
-    splat per pixel, a decision flip swaps it for a neighbour's): only the count of differing pixels is gated."""
-    st = parity_stats(got, ref64)
-    info = parity_stats(ref32, ref64)
-    PARITY_LOG.append((name, st, info))
-    if st["n"] == 0:
-        return
-    if discrete:
-        assert st["above_1e4"] <= max(12, 1e-4 * st["n"]), f"{name}: {st['above_1e4']} of {st['n']} pixels differ"
-        return
-    gate = gate or (GATE_IMAGE if name in IMAGE_KEYS else GATE_GRAD)
-    bad = gate_violations(st, gate, name)
-    assert not bad, "; ".join(bad) + f"  [fp32 CPU restatement, for information: bulk {info['bulk']:.2e}, >1e-4 {info['f4']:.2e}, " \
-                                     f">1e-2 {info['f2']:.2e}, worst {info['worst']:.2e}]"
+def assert_clean_parity(got, ref64, clean, name, rel=1e-4, stragglers=None):
+    """The decision-matched gate (block comment above): element-wise `rel` on the clean rows.  stragglers=None picks the rule
+    by tensor kind: images none, per-splat tensors max(3, 1e-4 x clean rows) rows up to 1e-2."""
+    st = clean_parity_stats(got, ref64, clean)
+    PARITY_LOG.append((name, st))
+    if st["clean_rows"] == 0:
+        return st
+    if stragglers is None:
+        stragglers = 0 if name in PIXEL_KEYS else max(3, int(1e-4 * st["clean_rows"]))
+    assert st["rows_above_1e4"] <= stragglers, (f"{name}: {st['rows_above_1e4']} of {st['clean_rows']} decision-robust rows above {rel:.0e} "
+                                                f"(allowed {stragglers}); worst {st['worst']:.2e}")
+    assert st["worst"] <= (rel if stragglers == 0 else 1e-2), f"{name}: worst decision-robust row {st['worst']:.2e}"
+    assert st["rel_l2"] <= 1e-5, f"{name}: relative L2 error over the decision-robust rows {st['rel_l2']:.2e} > 1e-5"
+    return st
