@@ -80,6 +80,9 @@ def main():
                          "source edits: the drop-in operators (rasterization_2dgs_sdf, TCNNEncoding, TCNNNetwork) composed with "
                          "eager torch for everything the reference does in libtorch (losses, SSIM, activations, get_gradient's "
                          "numerical branch, update_state, torch.optim.Adam), one stream.  NOT the headline; reported as a line of its own")
+    ap.add_argument("--splat-order", default="morton", choices=["morton", "as-given"],
+                    help="memory order of the splat set: Morton order of the centres (what the trainer keeps: NeuralGS re-sorts at "
+                         "initialisation and at refinement steps) or the synthetic scene's random order")
     ap.add_argument("--collective", default="all_reduce", choices=["all_reduce", "reduce_scatter_all_gather"],
                     help="N > 1: how a parameter family's flat gradient buffer is summed over the ranks")
     args = ap.parse_args()
@@ -122,7 +125,9 @@ def main():
     sc = synth.make_scene(N, W, H, sh_degree=deg, seed=0, replica=replica)
     views = synth.make_views(200, seed=1).to(dev)
     K = sc["K"].to(dev)
-    params = SplatParams.from_scene(sc, dev)
+    from gs_sdf_amd.trainer import morton_order
+    order = morton_order(sc["means"]) if args.splat_order == "morton" else None
+    params = SplatParams.from_scene(sc, dev, order)
     ug = {k: v.to(dev) for k, v in synth.upstream_grads(H, W, seed=2).items()}
     ug6 = {k: (1e-6 * v).contiguous() for k, v in ug.items()}       # the 1e-6 N(0,1) op-level upstream gradients, fixed
     target = torch.rand(H, W, 3, generator=torch.Generator().manual_seed(3)).to(dev)    # target image U(0,1) seed 3
@@ -309,6 +314,23 @@ def main():
     for i in range(args.warmup):
         step(i)
     torch.cuda.synchronize()
+    # Steady-state warm-up, independent of --warmup: a fresh box starts at idle clocks with a cold caching allocator, and a
+    # 5-step warm-up (50 ms) measures the ramp, not the step (round 2: the driver's 20-step run read 80 it/s where longer runs
+    # read 100-110).  Untimed steps continue until the GPU has been busy for GSDF_BENCH_MIN_WARM_S seconds (default 1.5 s, at
+    # most 300 steps); every rank takes the same number (the count is agreed through the slowest rank).
+    min_warm_s, extra_warm = float(os.environ.get("GSDF_BENCH_MIN_WARM_S", "1.5")), 0
+    t_w = time.perf_counter()
+    while extra_warm < 300:
+        go = torch.tensor([1.0 if time.perf_counter() - t_w < min_warm_s else 0.0], device=dev)
+        if dist is not None:
+            dist.all_reduce(go, op=dist.ReduceOp.MAX)
+        if float(go.item()) == 0.0:
+            break
+        for _ in range(10):
+            step(args.warmup + extra_warm)
+            extra_warm += 1
+        torch.cuda.synchronize()
+    warm_total = args.warmup + extra_warm
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
@@ -316,14 +338,23 @@ def main():
     # separate pass below: two events per launch on all ~25 operators cost ~2 % of the step in host time)
     ROOF = {"hashgrid_bwd", "hashgrid_fwd", "rasterize_2dgs_fwd", "rasterize_2dgs_bwd", "mlp_fwd", "mlp_bwd", "mlp_bwd_data", "mlp_bwd_weights"}
 
+    step_marks = []
+
     def timed(n_steps, first):
         hist.clear()
         ops.TIMERS.enable(only=ROOF)
         if host is not None:
             host.clear()
+        step_marks.clear()
         t0 = time.perf_counter()
         for i in range(n_steps):
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record(main)                      # the splat leg's stream: one mark per step where its first kernel is queued
+            step_marks.append(ev)
             step(first + i)
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record(main)
+        step_marks.append(ev)
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
@@ -335,7 +366,10 @@ def main():
             el = float(t.item())
         return el, ops.TIMERS.summary_ms("median"), ops.TIMERS.summary_ms("mean"), ops.TIMERS.calls(), {k: sum(v) / len(v) for k, v in hist.items()}
 
-    elapsed, kern, kern_mean, calls, avg = timed(args.steps, args.warmup)
+    elapsed, kern, kern_mean, calls, avg = timed(args.steps, warm_total)
+    gaps = sorted(a.elapsed_time(b) for a, b in zip(step_marks[:-1], step_marks[1:]))
+    step_dist = {"p10": gaps[len(gaps) // 10], "p50": gaps[len(gaps) // 2], "p90": gaps[(len(gaps) * 9) // 10], "max": gaps[-1],
+                 "what": "ms between consecutive steps' first kernels on the splat leg's stream (HIP events), over the timed steps"}
     if host is not None and rank == 0:
         import collections
         acc, n = collections.OrderedDict(), 0
@@ -345,7 +379,7 @@ def main():
             n += tb == "optimizers issued"
         print("host ms/step: " + ", ".join(f"{k} {v / n * 1e3:.2f}" for k, v in acc.items()), file=sys.stderr, flush=True)
     ops.TIMERS.enable()                       # every operator, outside the timed region
-    nxt = args.warmup + args.steps
+    nxt = warm_total + args.steps
     for i in range(min(10, args.steps)):
         step(nxt + i)
     nxt += min(10, args.steps)
@@ -434,12 +468,15 @@ def main():
                       else "train iters/sec (splat raster fwd+bwd only), 1M Gaussians @1080p",
             "value": args.steps * world / elapsed, "unit": "iters/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            "internal_warmup_steps": extra_warm, "step_ms_hip_events": step_dist,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.workload}: {N} random Gaussians, {W}x{H}, sh_degree {deg}, 1 view/GPU/step; means over the timed "
                                    f"steps: M={M:.0f} I={I:.0f} L={I / T:.0f}" + ("" if args.no_sdf else f"; hash-grid SDF (2^19 x16x2, fused "
                                    f"64-wide MLP) evaluated at {sdf_pts:.0f} points/step = 7 x 32768 ray + {stencil} x {n_gs:.0f} splat samples"),
                        "step": ("LIGHT (--light-step): " if state["light"] else "reference joint iteration (neural_mapping.cpp:400-486): ") + terms,
                        "parallelism": f"view-parallel x{world}" if world > 1 else "single GPU",
+                       "splat_order": ("Morton order of the centres (trainer.morton_order; kept by the trainer at initialisation and at "
+                                       "refinement steps)" if args.splat_order == "morton" else "as given (random)"),
                        "decoder_arithmetic": ("fp32 operands as 3 exact bf16 terms, 6 partial products per multiply-add on the bf16 MFMA pipe, "
                                               "fp32 accumulate: error against fp64 equal to the fp32 MFMA's (tools/ubench/mfma_split.hip)"
                                               if split_mlp_cfg else "fp32 MFMA")},
@@ -502,7 +539,8 @@ def cpp_step(args, sc, views, K, ug6, target, N, W, H, deg, dev):
     import gs_sdf_amd.sdf as sdfm
     from gs_sdf_amd.trainer import SplatParams
     host = hostlib.load()
-    params = SplatParams.from_scene(sc, dev)
+    from gs_sdf_amd.trainer import morton_order
+    params = SplatParams.from_scene(sc, dev, morton_order(sc["means"]) if args.splat_order == "morton" else None)
     lm = sdfm.LocalMap([0.0, 0.0, 5.5], 16.0, bce_sigma=0.02, decoder_implementation=1, device=dev, seed=5)
     enc, dec = host.TCNNEncoding(16, 2, 19, 32, 2.0), host.TCNNNetwork(32, 2, 64, 3)
     enc.params_, dec.params_ = lm.encoder.params_.detach().clone(), lm.decoder.params_.detach().clone()
@@ -542,8 +580,8 @@ def reference_loop(args, sc, views, K, ug6, target, N, W, H, deg, dev):
     import gs_sdf_amd.ops as ops
     import gs_sdf_amd.sdf as sdfm
     from gs_sdf_amd.neural_gs import update_densify_state
-    from gs_sdf_amd.trainer import SplatParams, inject_grads
-    params = SplatParams.from_scene(sc, dev)
+    from gs_sdf_amd.trainer import SplatParams, inject_grads, morton_order
+    params = SplatParams.from_scene(sc, dev, morton_order(sc["means"]) if args.splat_order == "morton" else None)
     lm = sdfm.LocalMap([0.0, 0.0, 5.5], 16.0, bce_sigma=0.02, decoder_implementation=1, device=dev, seed=5)
     lm.set_bounds(16.0 - 2 * 0.0625, 0.0625)
     lm.update_octree_as(params.anchors)
@@ -615,16 +653,25 @@ def reference_loop(args, sc, views, K, ug6, target, N, W, H, deg, dev):
                                "numerical get_gradient, update_state, torch.optim.Adam; one stream"}}
 
 
-def _err_stats(got, ref):
-    """max scaled error (|got-ref| / max(|ref|, mean|ref|)), relative L2, fraction of elements above 1e-4."""
+def _err_stats(got, ref, clean=None):
+    """Scaled error (|got-ref| / max(|ref|, mean|ref|)) per row: rows above 1e-4, worst, relative L2 — over all rows and, when
+    `clean` (bool over the leading dims) is given, over the decision-robust rows (oracle.rasterize_2dgs_fragility: the gate of
+    tests/util.py applies to those)."""
     import numpy as np
     got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64)
     if ref.size == 0:
         return {"n": 0}
-    floor = np.abs(ref).mean() + 1e-30
-    e = np.abs(got - ref) / np.maximum(np.abs(ref), floor)
-    return {"n": int(ref.size), "worst": float(e.max()), "rel_l2": float(np.linalg.norm(got - ref) / (np.linalg.norm(ref) + 1e-30)),
-            "frac_above_1e-4": float((e > 1e-4).mean())}
+    R = ref.shape[0] if clean is None else int(np.prod(clean.shape))
+    g2, r2 = got.reshape(R, -1), ref.reshape(R, -1)
+    floor = np.abs(r2).mean() + 1e-30
+    e = (np.abs(g2 - r2) / np.maximum(np.abs(r2), floor)).max(1)
+    out = {"rows": int(R), "worst": float(e.max()), "rel_l2": float(np.linalg.norm(g2 - r2) / (np.linalg.norm(r2) + 1e-30)),
+           "rows_above_1e-4": int((e > 1e-4).sum())}
+    if clean is not None:
+        c = np.asarray(clean).reshape(R)
+        out["decision_robust"] = {"rows": int(c.sum()), "rows_above_1e-4": int((e[c] > 1e-4).sum()), "worst": float(e[c].max()) if c.any() else 0.0,
+                                  "rel_l2": float(np.linalg.norm((g2 - r2)[c]) / (np.linalg.norm(r2[c]) + 1e-30))}
+    return out
 
 
 def cpu_baseline(sc, views, params, N, W, H, deg, n_sdf_points, dev):
@@ -691,6 +738,9 @@ def cpu_baseline(sc, views, params, N, W, H, deg, n_sdf_points, dev):
     pb64 = orc.projection_2dgs_bwd(means, quats, scales, n(view), n(sc["K"]), W, H, p["camera_ids"], p["gaussian_ids"],
                                    f64(g64["v_means2d"]), np.zeros(M, np.float64), f64(g64["v_ray_transforms"]), f64(g64["v_normals"]),
                                    prec="f64")
+    vsh64 = orc.view_colors_bwd(n(view), means, n(sc["sh"]), p["camera_ids"], p["gaussian_ids"], deg, f64(g64["v_colors"]), prec="f64")   # (v_sh, v_means)
+    vop64 = np.zeros(N)
+    np.add.at(vop64, p["gaussian_ids"], f64(g64["v_opacities"]))
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
     leaves = [t(a).requires_grad_(True) for a in (means, quats, scales, opac, n(sc["sh"]))]
     colors, alphas, meta = ops.rasterization_2dgs_sdf(*leaves, view.to(dev), sc["K"].to(dev), W, H, "RGB+D", 0.05, 300.0, 0.0, deg)
@@ -703,17 +753,28 @@ def cpu_baseline(sc, views, params, N, W, H, deg, n_sdf_points, dev):
             + (meta["render_median"] * ugd["v_render_median"]).sum())
     loss.backward()
     torch.cuda.synchronize()
+    # decision-robust pixels / splats of this compositing problem (tests/util.py: the element-wise 1e-4 gate applies to them)
+    pf, sf, _ = orc.rasterize_2dgs_fragility(p["means2d"], p["ray_transforms"], opa, W, H, 16, offs, flat)
+    pix_ok, splat_ok = pf == 0, sf == 0
+    gauss_ok = np.ones(N, bool)
+    gauss_ok[p["gaussian_ids"][~splat_ok]] = False
     par = {"integer_outputs_bit_exact": bool(np.array_equal(n(meta["gaussian_ids"]), p["gaussian_ids"]) and np.array_equal(n(meta["radii"]), p["radii"])
                                              and np.array_equal(n(meta["flatten_ids"]), flat) and np.array_equal(n(meta["isect_offsets"]), offs)
                                              and np.array_equal(n(meta["tiles_per_gauss"]), tpg)),
-           "render_colors": _err_stats(n(colors[..., :3]), fw64["render_colors"]), "render_depths": _err_stats(n(colors[..., 3:4]), fw64["render_depths"]),
-           "render_alphas": _err_stats(n(alphas), fw64["render_alphas"]), "render_normals": _err_stats(n(rn_cam), fw64["render_normals"]),
-           "visibilities": _err_stats(n(meta["visibilities"]), fw64["visibilities"]),
-           "v_densify": _err_stats(n(meta["gradient_2dgs"].grad), g64["v_densify"]),
-           "v_quats (compositing + projection backward)": _err_stats(n(leaves[1].grad), pb64[1]), "v_scales": _err_stats(n(leaves[2].grad), pb64[2]),
-           "note": "HIP path vs the oracle on the bench workload's first view: ids / radii / bins / offsets bit-exact against the fp32 "
-                   "build; floats against the fp64 build (max scaled error, relative L2, fraction of elements above 1e-4; the operator is "
-                   "discontinuous at alpha = 1/255 and T = 1e-4, see tests/util.py); tests/test_gpu_baseline_shapes.py gates the same comparison"}
+           "excluded": {"pixels": float((~pix_ok).mean()), "splats": float((~splat_ok).mean()),
+                        "what": "decision margin (alpha >= 1/255, T <= 1e-4, median, footprint branch, clamp) within 16x the fp32 evaluation error, "
+                                "or splat blended edge-on (cancellation of z.z above 8x)"},
+           "render_colors": _err_stats(n(colors[..., :3]), fw64["render_colors"], pix_ok), "render_depths": _err_stats(n(colors[..., 3:4]), fw64["render_depths"], pix_ok),
+           "render_alphas": _err_stats(n(alphas), fw64["render_alphas"], pix_ok), "render_normals": _err_stats(n(rn_cam), fw64["render_normals"], pix_ok),
+           "visibilities": _err_stats(n(meta["visibilities"]), fw64["visibilities"], splat_ok),
+           "v_densify": _err_stats(n(meta["gradient_2dgs"].grad), g64["v_densify"], splat_ok),
+           "v_means (compositing + projection + SH backward)": _err_stats(n(leaves[0].grad), pb64[0] + vsh64[1], gauss_ok),
+           "v_quats (compositing + projection backward)": _err_stats(n(leaves[1].grad), pb64[1], gauss_ok), "v_scales": _err_stats(n(leaves[2].grad), pb64[2], gauss_ok),
+           "v_opacities": _err_stats(n(leaves[3].grad), vop64, gauss_ok), "v_sh": _err_stats(n(leaves[4].grad), vsh64[0], gauss_ok),
+           "note": "HIP path vs the oracle on the bench workload's first view: ids / radii / bins / offsets bit-exact against the fp32 build; floats "
+                   "against the fp64 build, per row (pixel / splat): rows above 1e-4, worst scaled error, relative L2 — over ALL rows and over the "
+                   "decision-robust rows (oracle.rasterize_2dgs_fragility; tests/util.py gates the latter element-wise at 1e-4, "
+                   "tests/test_gpu_baseline_shapes.py runs the same comparison at every BASELINE shape)"}
     if n_sdf_points:
         # SDF half: the HIP encoder / decoder / scatter on the sample the oracle was timed on.  Features and table gradient
         # against the fp32 build (pos = fma(scale, x, 0.5) in fp32 IS the function), decoder against the fp64 build

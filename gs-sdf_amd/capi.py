@@ -50,6 +50,10 @@ _SIGS = {
     "gsdf_mlp_bwd_ws_bytes_for": (_sz, [_i64, _i32, _vp, _i32]),
     "gsdf_mlp_bwd": (C.c_int, [_i64, _i32] + [_vp] * 11),
     "gsdf_mlp_bwd_weights": (C.c_int, [_i64, _i32, _vp, _i32] + [_vp] * 7),
+    "gsdf_mlp_bwd_bwd_ws_bytes": (_sz, [_i64, _i32]),
+    "gsdf_mlp_bwd_bwd": (C.c_int, [_i64, _i32] + [_vp] * 10),
+    "gsdf_hashgrid_bwd_binned2": (C.c_int, [_i64, _i32, _i32, _i32, _i32, _f32] + [_vp] * 6 + [_sz, _vp]),
+    "gsdf_sdf_analytic_loss": (C.c_int, [_i64, _i32, _i32, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp] + [_f32] * 6 + [_vp] * 5),
     "gsdf_l1_dssim_fwd": (C.c_int, [_i32, _i32] + [_vp] * 6),
     "gsdf_l1_dssim_bwd": (C.c_int, [_i32, _i32] + [_vp] * 5 + [_f32, _f32, _vp, _vp]),
     "gsdf_normal_consistency_fwd": (C.c_int, [_i32, _i32] + [_vp] * 7),

@@ -123,6 +123,28 @@ __device__ __forceinline__ void corners_of(const HgLevels &lv, int level, float 
   }
 }
 
+// d/dx of the 8 trilinear weights contracted with vv: dw[k] = scale * sum_d vv[d] * d w_k / d pos_d  (same expression as
+// hashgrid_bwd_bwd_kernel's `t`): the weight with which v_feat2 reaches the table in the SECOND-ORDER term
+// d/d table [(J(x, table)^T v_feat2) . vv_x] of the analytic eikonal regulariser.
+__device__ __forceinline__ void corner_dweights(const HgLevels &lv, int level, float px, float py, float pz, float vx, float vy,
+                                                float vz, float (&dw)[8]) {
+  const float scale = lv.scale[level];
+  float fr[3];
+  const float xin[3] = {px, py, pz};
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    const float pos = fmaf(scale, xin[d], 0.5f);
+    fr[d] = pos - floorf(pos);
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int hx = k & 1, hy = (k >> 1) & 1, hz = k >> 2;
+    const float wx = hx ? fr[0] : 1.f - fr[0], wy = hy ? fr[1] : 1.f - fr[1], wz = hz ? fr[2] : 1.f - fr[2];
+    const float sx = hx ? 1.f : -1.f, sy = hy ? 1.f : -1.f, sz = hz ? 1.f : -1.f;
+    dw[k] = scale * (vx * sx * wy * wz + vy * sy * wx * wz + vz * sz * wx * wy);
+  }
+}
+
 // Stencil structure of a batch (optional): rows [0, n) are base points, rows n + k n + i (k = 0..5) the six central-
 // difference points of base i (gsdf_sdf_query_points).  At the coarse levels the seven points of a group usually lie in
 // the same grid cell, i.e. touch the same 8 entries: their contributions are then summed in registers and emitted as ONE
@@ -151,8 +173,10 @@ __device__ __forceinline__ bool merged_into_base(const HgLevels &lv, int level, 
 // corner weights are <= 1, so this bounds every contribution of the level; it fixes the apply pass's fixed point.
 // A reduction kernel of its own (0.1 ms at 3 M points): folding it into the emit kernel as one atomicMax per wave puts
 // ~1e6 atomics on the ONE 64-byte line that holds the 16 maxima and costs 3-12 ms of serialisation, filtered or not.
+// With a second-order term the bound of (point, level) is |v_feat| + scale_l * |vv_x|_1 * |v_feat2| (|d w / d pos| <= 1).
 __global__ void __launch_bounds__(256)
-    bin_vmax_kernel(int64_t n2, int n_levels, const float2 *__restrict__ v_feat, uint32_t *__restrict__ lmax) {
+    bin_vmax_kernel(int64_t n2, int n_levels, const float2 *__restrict__ v_feat, uint32_t *__restrict__ lmax,
+                    const float2 *__restrict__ v_feat2 = nullptr, const float *__restrict__ vv_x = nullptr, HgLevels lv = HgLevels()) {
   __shared__ uint32_t s_max[HG_MAX_LEVELS];
   if (threadIdx.x < HG_MAX_LEVELS) s_max[threadIdx.x] = 0u;
   __syncthreads();
@@ -163,8 +187,18 @@ __global__ void __launch_bounds__(256)
   float m = 0.f;
   if (i0 < stride)
     for (int64_t i = i0; i < n2; i += stride) {
-      const float2 v = v_feat[i];
-      m = fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y)));
+      float b = 0.f;
+      if (v_feat != nullptr) {
+        const float2 v = v_feat[i];
+        b = fmaxf(fabsf(v.x), fabsf(v.y));
+      }
+      if (v_feat2 != nullptr) {
+        const float2 v = v_feat2[i];
+        const int64_t pt = i / n_levels;
+        const float l1 = fabsf(vv_x[3 * pt]) + fabsf(vv_x[3 * pt + 1]) + fabsf(vv_x[3 * pt + 2]);
+        b += lv.scale[(int)(i0 % n_levels)] * l1 * fmaxf(fabsf(v.x), fabsf(v.y));
+      }
+      m = fmaxf(m, b);
     }
   if (m > 0.f) atomicMax(&s_max[(int)(i0 % n_levels)], __float_as_uint(m));
   __syncthreads();
@@ -264,7 +298,7 @@ template <int PTS, int G>
 __global__ void __launch_bounds__(PTS * G)
     bin_emit_kernel(int64_t B, HgLevels lv, BinPlan bp, BinStencil stn, const float *__restrict__ x,
                     const float *__restrict__ v_feat, const int64_t *__restrict__ start, uint32_t *__restrict__ cursor,
-                    BinRecord *__restrict__ records) {
+                    BinRecord *__restrict__ records, const float *__restrict__ v_feat2, const float *__restrict__ vv_x) {
   constexpr int BIN_EMIT_THREADS = PTS * G, BIN_REC = PTS * G * 8;
   __shared__ uint32_t s_key[BIN_REC];
   __shared__ float s_g0[BIN_REC], s_g1[BIN_REC];
@@ -292,9 +326,16 @@ __global__ void __launch_bounds__(PTS * G)
       emits = true;
       Corner8 c;
       corners_of(lv, level, px, py, pz, c);
-      const float2 vf = *reinterpret_cast<const float2 *>(v_feat + (b * lv.n_levels + level) * 2);
+      const float2 vf = v_feat != nullptr ? *reinterpret_cast<const float2 *>(v_feat + (b * lv.n_levels + level) * 2) : make_float2(0.f, 0.f);
 #pragma unroll
       for (int k = 0; k < 8; ++k) { g0[k] = c.w[k] * vf.x; g1[k] = c.w[k] * vf.y; }
+      if (v_feat2 != nullptr) {   // second-order term of the analytic eikonal regulariser (no stencil structure with it)
+        const float2 v2 = *reinterpret_cast<const float2 *>(v_feat2 + (b * lv.n_levels + level) * 2);
+        float dw[8];
+        corner_dweights(lv, level, px, py, pz, vv_x[3 * b], vv_x[3 * b + 1], vv_x[3 * b + 2], dw);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { g0[k] = fmaf(dw[k], v2.x, g0[k]); g1[k] = fmaf(dw[k], v2.y, g1[k]); }
+      }
       if (try_merge && b < stn.n) {
         // base row: add the stencil rows that share this cell (same 8 entries, their own trilinear weights), in row order
         int32_t gb[3];
@@ -456,11 +497,30 @@ extern "C" int gsdf_hashgrid_bwd_binned(int64_t B, int n_levels, int n_feat, int
                                           ws_bytes, stream);
 }
 
+static int binned_scatter(int64_t B, int64_t stencil_n, int merge_levels, int n_levels, int n_feat, int log2_hashmap, int base_res,
+                          float per_level_scale, const float *x, const float *v_feat, const float *v_feat2, const float *vv_x,
+                          float *v_table, void *ws, size_t ws_bytes, hipStream_t stream);
+
 extern "C" int gsdf_hashgrid_bwd_binned_stencil(int64_t B, int64_t stencil_n, int merge_levels, int n_levels, int n_feat,
                                                 int log2_hashmap, int base_res, float per_level_scale, const float *x,
                                                 const float *v_feat, float *v_table, void *ws, size_t ws_bytes,
                                                 gsdf_stream_t stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
+  GSDF_REQUIRE(B == 0 || v_feat, "hashgrid_bwd_binned: null v_feat");
+  return binned_scatter(B, stencil_n, merge_levels, n_levels, n_feat, log2_hashmap, base_res, per_level_scale, x, v_feat, nullptr, nullptr,
+                        v_table, ws, ws_bytes, (hipStream_t)stream_);
+}
+
+extern "C" int gsdf_hashgrid_bwd_binned2(int64_t B, int n_levels, int n_feat, int log2_hashmap, int base_res, float per_level_scale,
+                                         const float *x, const float *v_feat, const float *v_feat2, const float *vv_x, float *v_table,
+                                         void *ws, size_t ws_bytes, gsdf_stream_t stream_) {
+  GSDF_REQUIRE(B == 0 || (v_feat2 && vv_x), "hashgrid_bwd_binned2: null second-order inputs");
+  return binned_scatter(B, 0, 0, n_levels, n_feat, log2_hashmap, base_res, per_level_scale, x, v_feat, v_feat2, vv_x, v_table, ws, ws_bytes,
+                        (hipStream_t)stream_);
+}
+
+static int binned_scatter(int64_t B, int64_t stencil_n, int merge_levels, int n_levels, int n_feat, int log2_hashmap, int base_res,
+                          float per_level_scale, const float *x, const float *v_feat, const float *v_feat2, const float *vv_x,
+                          float *v_table, void *ws, size_t ws_bytes, hipStream_t stream) {
   GSDF_REQUIRE(stencil_n == 0 || (stencil_n > 0 && B == 7 * stencil_n), "hashgrid_bwd_binned: a stencil batch has 7 * stencil_n rows");
   const BinStencil stn{stencil_n, stencil_n > 0 ? (merge_levels < 0 ? 0 : merge_levels) : 0};
   HgLevels lv;
@@ -469,7 +529,7 @@ extern "C" int gsdf_hashgrid_bwd_binned_stencil(int64_t B, int64_t stencil_n, in
   GSDF_REQUIRE(rc != -1, "hashgrid_bwd_binned: bad grid configuration");
   GSDF_REQUIRE(rc == 0, "hashgrid_bwd_binned: table too large for the binned scatter (use gsdf_hashgrid_bwd)");
   if (B == 0) return GSDF_OK;
-  GSDF_REQUIRE(x && v_feat && v_table && ws, "hashgrid_bwd_binned: null buffer");
+  GSDF_REQUIRE(x && (v_feat || v_feat2) && v_table && ws, "hashgrid_bwd_binned: null buffer");
   GSDF_REQUIRE(((uintptr_t)v_table & 15) == 0 && ((uintptr_t)ws & 255) == 0, "hashgrid_bwd_binned: v_table must be 16-byte and ws 256-byte aligned");
   const int nb = bp.tile_base[n_levels];
   const BinWs w = carve(ws, B, n_levels, nb);
@@ -477,7 +537,8 @@ extern "C" int gsdf_hashgrid_bwd_binned_stencil(int64_t B, int64_t stencil_n, in
   GSDF_HIP(hipMemsetAsync(w.counts, 0, sizeof(uint32_t) * (nb + HG_MAX_LEVELS), stream), "hashgrid_bwd_binned memset");
   const int64_t chunks4 = (B + 4 * BIN_PTS - 1) / (4 * BIN_PTS), chunks = (B + BIN_PTS - 1) / BIN_PTS;
   GSDF_REQUIRE(chunks * bp.n_groups < (int64_t)1 << 31, "hashgrid_bwd_binned: batch too large");
-  bin_vmax_kernel<<<1024, 256, 0, stream>>>(B * n_levels, n_levels, reinterpret_cast<const float2 *>(v_feat), w.lmax);
+  bin_vmax_kernel<<<1024, 256, 0, stream>>>(B * n_levels, n_levels, reinterpret_cast<const float2 *>(v_feat), w.lmax,
+                                            reinterpret_cast<const float2 *>(v_feat2), vv_x, lv);
   GSDF_CHECK_LAUNCH("bin_vmax_kernel");
   bin_count_kernel<<<(unsigned)(chunks4 * bp.n_groups), BIN_PTS, 0, stream>>>(B, lv, bp, stn, x, w.counts);
   GSDF_CHECK_LAUNCH("bin_count_kernel");
@@ -489,7 +550,7 @@ extern "C" int gsdf_hashgrid_bwd_binned_stencil(int64_t B, int64_t stencil_n, in
   //  12-byte records in runs of 16 are written at 3.1 TB/s, runs of 32 at 4.6, one stream at 5.3)
   // (measured and rejected: 512 points x 1 level and 1024 x 1 per workgroup, i.e. 2x / 4x longer runs per bucket: 3.15 and
   //  3.48 ms against 2.94 ms for the whole scatter at 3.3 M points — the run length is not what bounds the emit pass)
-  bin_emit_kernel<BIN_PTS, BIN_G><<<(unsigned)(chunks * bp.n_groups), BIN_PTS * BIN_G, 0, stream>>>(B, lv, bp, stn, x, v_feat, w.start, w.cursor, w.records);
+  bin_emit_kernel<BIN_PTS, BIN_G><<<(unsigned)(chunks * bp.n_groups), BIN_PTS * BIN_G, 0, stream>>>(B, lv, bp, stn, x, v_feat, w.start, w.cursor, w.records, v_feat2, vv_x);
   GSDF_CHECK_LAUNCH("bin_emit_kernel");
   bin_apply_kernel<<<(unsigned)w.max_items, BIN_APPLY_THREADS, 0, stream>>>(lv, bp, w.items, w.n_items, w.lmax, w.records, v_table);
   GSDF_CHECK_LAUNCH("bin_apply_kernel");

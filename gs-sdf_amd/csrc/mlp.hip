@@ -48,10 +48,13 @@ __device__ void stage_weights_fwd(const MlpDesc &d, const float *__restrict__ W,
   }
 }
 
-template <int D_IN>
+// MASKED: the ReLUs are replaced by the saved masks of an earlier forward pass (`mask_acts` = that pass's acts buffer) and there
+// are no biases: y = W_{n-1} D_{n-2} ... D_0 W_0 x, the forward half of the decoder's DOUBLE backward (gsdf_mlp_bwd_bwd).
+template <int D_IN, bool MASKED = false>
 __global__ void __launch_bounds__(MLP_THREADS)
     mlp_fwd_kernel(int64_t B, MlpDesc d, const float *__restrict__ W, const float *__restrict__ bias,
-                   const float *__restrict__ in, float *__restrict__ out, float *__restrict__ acts) {
+                   const float *__restrict__ in, float *__restrict__ out, float *__restrict__ acts,
+                   const float *__restrict__ mask_acts = nullptr) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float *lds_b = smem;                         // [MAX_LAYERS][64]
   float *lds_w = smem + MAX_LAYERS * HID;      // permuted weights
@@ -62,6 +65,7 @@ __global__ void __launch_bounds__(MLP_THREADS)
   constexpr int K0 = D_IN / 2;
   const int64_t n_tiles = (B + 31) / 32;
   uint16_t *masks = acts == nullptr ? nullptr : reinterpret_cast<uint16_t *>(acts + img_off(d.n_layers - 1, n_tiles, 0, 0, 0));
+  const uint16_t *msrc = MASKED ? reinterpret_cast<const uint16_t *>(mask_acts + img_off(d.n_layers - 1, n_tiles, 0, 0, 0)) : nullptr;
   for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < n_tiles; tile += (int64_t)gridDim.x * 4) {
     const int64_t p = tile * 32 + pl;
     const bool live = p < B;
@@ -87,8 +91,14 @@ __global__ void __launch_bounds__(MLP_THREADS)
         for (int s = 0; s < K0; ++s) aw[s] = w[(t * K0 + s) * 64 + lane];
 #pragma unroll
         for (int s = 0; s < K0; ++s) acc = mfma32(aw[s], x[s], acc);
+        if (MASKED) {
+          const unsigned m = msrc[mask_off(0, n_tiles, tile, t, lane)];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = fmaxf(acc[r], 0.f);
+          for (int r = 0; r < 16; ++r) acc[r] = (m >> r) & 1u ? acc[r] : 0.f;
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[r] = fmaxf(acc[r], 0.f);
+        }
         cur[t] = acc;
       }
     }
@@ -123,8 +133,14 @@ __global__ void __launch_bounds__(MLP_THREADS)
 #pragma unroll
           for (int s = 0; s < 32; ++s) acc = mfma32(aw[s], cur[s >> 4][s & 15], acc);
           if (!last) {
+            if (MASKED) {
+              const unsigned m = msrc[mask_off(l, n_tiles, tile, t, lane)];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = fmaxf(acc[r], 0.f);
+              for (int r = 0; r < 16; ++r) acc[r] = (m >> r) & 1u ? acc[r] : 0.f;
+            } else {
+#pragma unroll
+              for (int r = 0; r < 16; ++r) acc[r] = fmaxf(acc[r], 0.f);
+            }
           }
           nxt[t] = acc;
         }
@@ -441,6 +457,46 @@ extern "C" int gsdf_mlp_bwd(int64_t B, int n_layers, const int *dims_host, const
     mlp_bwd_weights_kernel<<<grid, MLP_THREADS, 0, stream>>>(B, d, in, acts, v_out, v_pre, v_weights,
                                                              biases != nullptr ? v_biases : nullptr);
     GSDF_CHECK_LAUNCH("mlp_bwd_weights_kernel");
+  }
+  return GSDF_OK;
+}
+
+extern "C" size_t gsdf_mlp_bwd_bwd_ws_bytes(int64_t B, int n_layers) { return gsdf_mlp_acts_floats(B, n_layers) * sizeof(float) + 256; }
+
+extern "C" int gsdf_mlp_bwd_bwd(int64_t B, int n_layers, const int *dims_host, const float *weights, const float *acts,
+                                const float *v_out, const void *bwd_ws, const float *vv_in, float *g_vout, float *g_weights,
+                                void *ws, gsdf_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  GSDF_REQUIRE(dims_host, "mlp_bwd_bwd: null dims");
+  MlpDesc d;
+  size_t lds_floats;
+  int rc = make_desc(n_layers, dims_host, 0, false, &d, &lds_floats, "mlp_bwd_bwd");
+  if (rc) return rc;
+  if (B == 0) return GSDF_OK;
+  GSDF_REQUIRE(weights && acts && v_out && bwd_ws && vv_in && ws, "mlp_bwd_bwd: null buffer");
+  // (1) masked bias-free forward of vv_in: u_l = D_l W_l u_{l-1} saved as a register image in ws, last layer -> dL/d v_out
+  const size_t lds = lds_floats * sizeof(float);
+  GSDF_REQUIRE(lds <= 160 * 1024, "mlp_bwd_bwd: %zu bytes of weights do not fit the 160 KiB LDS", lds);
+  float *u_img = (float *)ws;
+  GSDF_REQUIRE(g_vout != nullptr, "mlp_bwd_bwd: g_vout [B, d_out] is required (it is the masked forward's output buffer)");
+  float *sink = g_vout;
+  if (d.d_in == 32) {
+    GSDF_HIP(hipFuncSetAttribute((const void *)mlp_fwd_kernel<32, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "mlp_bwd_bwd attr");
+    mlp_fwd_kernel<32, true><<<mlp_grid(B), MLP_THREADS, lds, stream>>>(B, d, weights, nullptr, vv_in, sink, u_img, acts);
+  } else {
+    GSDF_HIP(hipFuncSetAttribute((const void *)mlp_fwd_kernel<64, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "mlp_bwd_bwd attr");
+    mlp_fwd_kernel<64, true><<<mlp_grid(B), MLP_THREADS, lds, stream>>>(B, d, weights, nullptr, vv_in, sink, u_img, acts);
+  }
+  GSDF_CHECK_LAUNCH("mlp_fwd_kernel<masked>");
+  // (2) dL/dW_0 = delta_0 (x) vv_in, dL/dW_l = delta_l (x) u_{l-1}: the weight-gradient GEMM of the first order backward with
+  //     (network input, activations) := (vv_in, u images) and the first backward's own v_pre images / v_out as the A operand
+  if (g_weights != nullptr) {
+    MlpDesc db;
+    rc = make_desc(n_layers, dims_host, 0, true, &db, &lds_floats, "mlp_bwd_bwd");
+    if (rc) return rc;
+    dim3 grid((unsigned)((B + WG_KCHUNK - 1) / WG_KCHUNK), (unsigned)n_layers);
+    mlp_bwd_weights_kernel<<<grid, MLP_THREADS, 0, stream>>>(B, db, vv_in, u_img, v_out, (const float *)bwd_ws, g_weights, nullptr);
+    GSDF_CHECK_LAUNCH("mlp_bwd_weights_kernel<bwd_bwd>");
   }
   return GSDF_OK;
 }

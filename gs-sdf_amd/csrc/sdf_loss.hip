@@ -126,6 +126,93 @@ __global__ void __launch_bounds__(256)
   if ((threadIdx.x & 63) == 63 && ws != 0.f) atomicAdd(loss, ws);
 }
 
+
+// ---- the reference's DEFAULT regulariser: analytic SDF gradient (numerical_grad: 0, config/base.yaml:13) ------------------
+// NeuralSLAM::sdf_regularization (/root/reference/include/neural_mapping/neural_mapping.cpp:106-136) with
+// LocalMap::get_gradient's autograd branch (include/neural_net/local_map.cpp:151-172):
+//     g      = d sdf / d xyz            = map_size_inv * J(x)^T g0     (g0 = d sdf / d features, J = d features / d x)
+//     loss  += w_eik * mean_n (|g| - 1)^2                                                   (loss::eikonal_loss, loss.cpp:81-83)
+//     loss  += w_align * mean_{n,3} |g - g_num.detach()|,  g_num = central differences       (:126-134, align_weight 0.1)
+// on top of the batch's data term: mode 0 = sdf_weight * loss::sdf_loss (per-ray batch, neural_mapping.cpp:165-170), mode 1 =
+// scale * loss::gs_sdf_loss at the visible splats' samples (:436-457).  One thread per point: value, d/d decoder output,
+// vv_x = dL/d(J^T g0) (unit-cube coordinates) and u0 = J vv_x = dL/d g0 — what the double backward of the decoder
+// (gsdf_mlp_bwd_bwd) and of the encoder (gsdf_hashgrid_bwd_binned2) consume.
+template <int NF>
+__global__ void __launch_bounds__(256)
+    sdf_analytic_loss_kernel(int64_t n, int mode, int stencil, const float *__restrict__ attr, int ld, const float *__restrict__ g0,
+                             const float *__restrict__ jac, const float *__restrict__ gt, const float *__restrict__ weights,
+                             const int64_t *__restrict__ ids, float bce_isigma, float scale, float map_size_inv, float delta,
+                             float w_eik, float w_align, float *__restrict__ loss, float *__restrict__ v_attr,
+                             float *__restrict__ vv_x, float *__restrict__ u0) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  float contrib = 0.f;
+  if (i < n) {
+    const float inv_n = 1.0f / (float)n;
+    const float s = attr[i * ld];
+    if (mode == 0) {
+      const float raw = attr[i * ld + 1], g = gt[i];
+      const float br = 100.0f * raw;
+      const float sp = br > 20.0f ? raw : log1pf(expf(br)) * 0.01f;
+      const float dsp = br > 20.0f ? 1.0f : sigmoidf(br);
+      const float is0 = 1.0f + sp * bce_isigma;
+      const float is = fminf(is0, 500.0f);
+      const float dis_draw = is0 <= 500.0f ? dsp * bce_isigma : 0.0f;
+      const float x = -s * is, u = -g * is;
+      const float t0 = sigmoidf(u);
+      const float t = fminf(fmaxf(t0, 1e-7f), 1.0f - 1e-7f);
+      const float dt_du = (t0 >= 1e-7f && t0 <= 1.0f - 1e-7f) ? t0 * (1.0f - t0) : 0.0f;
+      const float bce = (1.0f - t) * x + fmaxf(-x, 0.0f) + log1pf(expf(-fabsf(x)));
+      const float dx = sigmoidf(x) - t, dt = -x;
+      const float d_is = dx * (-s) + dt * dt_du * (-g);
+      contrib = scale * bce * inv_n;
+      v_attr[i * ld] = scale * dx * (-is) * inv_n;
+      v_attr[i * ld + 1] = scale * d_is * dis_draw * inv_n;
+      for (int c = 2; c < ld; ++c) v_attr[i * ld + c] = 0.f;
+    } else {
+      const float w = weights[ids != nullptr ? ids[i] : i];
+      contrib = 0.5f * scale * w * s * s;
+      v_attr[i * ld] = scale * w * s;
+      for (int c = 1; c < ld; ++c) v_attr[i * ld + c] = 0.f;
+    }
+    // analytic gradient in world units
+    const float *J = jac + i * (int64_t)(NF * 3);
+    const float *gg = g0 + i * (int64_t)NF;
+    float ax = 0.f, ay = 0.f, az = 0.f;
+#pragma unroll 8
+    for (int f = 0; f < NF; ++f) {
+      const float q = gg[f];
+      ax = fmaf(J[3 * f], q, ax); ay = fmaf(J[3 * f + 1], q, ay); az = fmaf(J[3 * f + 2], q, az);
+    }
+    ax *= map_size_inv; ay *= map_size_inv; az *= map_size_inv;
+    const float nrm = sqrtf(ax * ax + ay * ay + az * az);
+    const float e = nrm - 1.0f;
+    contrib += w_eik * e * e * inv_n;
+    const float k0 = nrm > 0.f ? w_eik * 2.0f * e / nrm * inv_n : 0.f;    // torch's norm backward: 0 at the origin
+    float vx = k0 * ax, vy = k0 * ay, vz = k0 * az;
+    if (stencil && w_align != 0.f) {
+      float ps[6];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) ps[k] = attr[(n + k * n + i) * ld];
+      const float h = 0.5f * (1.0f / delta);
+      const float nx = h * (ps[0] - ps[1]), ny = h * (ps[2] - ps[3]), nz = h * (ps[4] - ps[5]);
+      const float c3 = w_align * inv_n * (1.0f / 3.0f);
+      const float dx_ = ax - nx, dy_ = ay - ny, dz_ = az - nz;
+      contrib += c3 * (fabsf(dx_) + fabsf(dy_) + fabsf(dz_));
+      // torch's abs backward: sign(0) = 0
+      vx += c3 * (dx_ > 0.f ? 1.f : (dx_ < 0.f ? -1.f : 0.f));
+      vy += c3 * (dy_ > 0.f ? 1.f : (dy_ < 0.f ? -1.f : 0.f));
+      vz += c3 * (dz_ > 0.f ? 1.f : (dz_ < 0.f ? -1.f : 0.f));
+    }
+    vx *= map_size_inv; vy *= map_size_inv; vz *= map_size_inv;       // dL / d (J^T g0)
+    vv_x[3 * i] = vx; vv_x[3 * i + 1] = vy; vv_x[3 * i + 2] = vz;
+    float *uo = u0 + i * (int64_t)NF;
+#pragma unroll 8
+    for (int f = 0; f < NF; ++f) uo[f] = fmaf(J[3 * f + 2], vz, fmaf(J[3 * f + 1], vy, J[3 * f] * vx));
+  }
+  const float ws = wave_sum_to_lane63(contrib);
+  if ((threadIdx.x & 63) == 63 && ws != 0.f) atomicAdd(loss, ws);
+}
+
 }  // namespace gsdf
 
 using namespace gsdf;
@@ -174,4 +261,23 @@ extern "C" int gsdf_gs_sdf_eik_loss(int64_t n, int stencil, const float *attr, i
 extern "C" int gsdf_gs_sdf_loss(int64_t n, const float *attr, int ld, const float *weights, const int64_t *ids, float scale,
                                 float *loss, float *v_attr, gsdf_stream_t stream) {
   return gsdf_gs_sdf_eik_loss(n, 0, attr, ld, weights, ids, scale, 0.f, 0.f, loss, v_attr, stream);
+}
+
+extern "C" int gsdf_sdf_analytic_loss(int64_t n, int mode, int stencil, const float *attr, int ld, const float *g0, int n_feat,
+                                      const float *jac, const float *gt_sdf, const float *weights, const int64_t *ids,
+                                      float bce_isigma, float scale, float map_size_inv, float delta, float w_eik, float w_align,
+                                      float *loss, float *v_attr, float *vv_x, float *u0, gsdf_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  GSDF_REQUIRE(n >= 0 && (mode == 0 || mode == 1) && loss, "sdf_analytic_loss: bad arguments");
+  GSDF_REQUIRE(n_feat == 32, "sdf_analytic_loss: %d encoder features unsupported (32: 16 levels x 2, as the reference configures)", n_feat);
+  GSDF_REQUIRE(ld >= (mode == 0 ? 2 : 1), "sdf_analytic_loss: decoder output too narrow");
+  GSDF_REQUIRE(!(stencil && w_align != 0.f) || delta > 0.f, "sdf_analytic_loss: delta must be positive");
+  GSDF_HIP(hipMemsetAsync(loss, 0, 4, stream), "sdf_analytic_loss memset");
+  if (n == 0) return GSDF_OK;
+  GSDF_REQUIRE(attr && g0 && jac && v_attr && vv_x && u0 && (mode == 0 ? gt_sdf != nullptr : weights != nullptr), "sdf_analytic_loss: null buffer");
+  sdf_analytic_loss_kernel<32><<<(unsigned)((n + 255) / 256), 256, 0, stream>>>(n, mode, stencil, attr, ld, g0, jac, gt_sdf, weights, ids,
+                                                                                bce_isigma, scale, map_size_inv, delta, w_eik, w_align,
+                                                                                loss, v_attr, vv_x, u0);
+  GSDF_CHECK_LAUNCH("sdf_analytic_loss_kernel");
+  return GSDF_OK;
 }

@@ -148,8 +148,19 @@ class _GridBwd(torch.autograd.Function):
         g_vfeat = torch.empty_like(v_feat) if need_vf else None
         g_x = torch.empty_like(x) if need_x else None
         g_table = torch.zeros_like(table) if need_t else None
-        capi.check(_timed("hashgrid_bwd_bwd", L.gsdf_hashgrid_bwd_bwd, B, *ctx.cfg, f32(x), f32(table), f32(v_feat),
-                          f32(vv_x.contiguous()), f32(g_vfeat), f32(g_table), f32(g_x), capi.stream()), "hashgrid_bwd_bwd")
+        vv_x = vv_x.contiguous()
+        # table part: large batches take the binned scatter's second-order form (no global atomics), like the first order
+        nbytes = 0
+        if need_t and os.environ.get("GSDF_HASHGRID_BINNED", "auto") != "0" and \
+                (os.environ.get("GSDF_HASHGRID_BINNED") == "1" or B >= BINNED_MIN_POINTS):
+            nbytes = L.gsdf_hashgrid_bwd_binned_ws_bytes(B, *ctx.cfg)
+        if nbytes:
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+            capi.check(_timed("hashgrid_bwd_bwd_table", L.gsdf_hashgrid_bwd_binned2, B, *ctx.cfg, f32(x), None, f32(v_feat), f32(vv_x),
+                              f32(g_table), ptr(ws), nbytes, capi.stream()), "hashgrid_bwd_binned2")
+        if need_vf or need_x or (need_t and not nbytes):
+            capi.check(_timed("hashgrid_bwd_bwd", L.gsdf_hashgrid_bwd_bwd, B, *ctx.cfg, f32(x), f32(table), f32(v_feat),
+                              f32(vv_x), f32(g_vfeat), f32(None if nbytes else g_table), f32(g_x), capi.stream()), "hashgrid_bwd_bwd")
         return g_vfeat, g_x, g_table, None, None, None, None, None, None
 
 
@@ -268,11 +279,18 @@ class _MlpFn(torch.autograd.Function):
         return out
 
     @staticmethod
-    @torch.autograd.function.once_differentiable      # first order only, like tcnn's FullyFusedMLP (params.cpp:396-399)
     def backward(ctx, v_out):
         L = capi.lib()
         x, weights, biases, acts = ctx.saved_tensors
         dims = ctx.dims
+        if torch.is_grad_enabled():
+            # create_graph=True (the analytic eikonal term of the reference's default configuration differentiates
+            # d sdf / d features again, local_map.cpp:151-172): the backward itself as a differentiable operator
+            v_in, v_w, v_b = _MlpBwd.apply(v_out, x, weights, biases, acts, dims, bool(ctx.needs_input_grad[1]),
+                                           biases is not None and bool(ctx.needs_input_grad[2]))
+            return (v_in if ctx.needs_input_grad[0] else None), (v_w if ctx.needs_input_grad[1] else None), \
+                   (v_b if (biases is not None and ctx.needs_input_grad[2]) else None), None, None, None
+        v_out = v_out.detach()
         B, nl = x.shape[0], len(dims) - 1
         dims_c = (C.c_int * len(dims))(*dims)
         v_out = v_out.contiguous()
@@ -311,6 +329,50 @@ class _MlpFn(torch.autograd.Function):
         capi.check(_timed("mlp_bwd", L.gsdf_mlp_bwd, B, nl, dims_c, f32(weights), f32(biases), f32(x), f32(acts),
                           f32(v_out), f32(v_in), f32(v_w), f32(v_b), ptr(ws), capi.stream()), "mlp_bwd")
         return v_in, v_w, v_b, None, None, None
+
+
+class _MlpBwd(torch.autograd.Function):
+    """(v_out, x, weights[, biases]) -> (v_in, v_weights, v_biases): the decoder's first-order backward as a differentiable
+    operator.  Its own backward (include/gsdf_hip.h: gsdf_mlp_bwd_bwd) serves dL/d v_in: a masked bias-free forward pass for
+    dL/d v_out and the weight-gradient GEMM on (vv_in, masked-forward activations) for dL/d weights; a ReLU network is piecewise
+    linear, so nothing flows to x or the biases, and second derivatives through v_weights are not offered (the reference
+    never asks for them)."""
+
+    @staticmethod
+    def forward(ctx, v_out, x, weights, biases, acts, dims, want_w, want_b):
+        L = capi.lib()
+        B, nl = x.shape[0], len(dims) - 1
+        dims_c = (C.c_int * len(dims))(*dims)
+        v_out = v_out.contiguous()
+        v_in = torch.empty_like(x)
+        ws = torch.empty(L.gsdf_mlp_bwd_ws_bytes(B, nl), dtype=torch.uint8, device=x.device)
+        # the two-kernel form: the per-layer gradients stay in `ws` for the double backward
+        capi.check(_timed("mlp_bwd_data", L.gsdf_mlp_bwd, B, nl, dims_c, f32(weights), f32(biases), f32(x), f32(acts), f32(v_out),
+                          f32(v_in), None, None, ptr(ws), capi.stream()), "mlp_bwd")
+        v_w = torch.zeros_like(weights) if want_w else torch.zeros(0, device=x.device)
+        v_b = torch.zeros_like(biases) if want_b else torch.zeros(0, device=x.device)
+        if want_w:
+            capi.check(_timed("mlp_bwd_weights", L.gsdf_mlp_bwd_weights, B, nl, dims_c, int(want_b), f32(x), f32(acts), f32(v_out),
+                              ptr(ws), f32(v_w), f32(v_b) if want_b else None, capi.stream()), "mlp_bwd_weights")
+        ctx.save_for_backward(v_out, weights, acts, ws)
+        ctx.dims = dims
+        ctx.mark_non_differentiable(v_w, v_b)
+        return v_in, v_w, v_b
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, vv_in, _vv_w, _vv_b):
+        L = capi.lib()
+        v_out, weights, acts, ws = ctx.saved_tensors
+        dims = ctx.dims
+        B, nl = vv_in.shape[0], len(dims) - 1
+        dims_c = (C.c_int * len(dims))(*dims)
+        g_vout = torch.empty_like(v_out)
+        g_w = torch.zeros_like(weights) if ctx.needs_input_grad[2] else None
+        ws2 = torch.empty(L.gsdf_mlp_bwd_bwd_ws_bytes(B, nl), dtype=torch.uint8, device=vv_in.device)
+        capi.check(_timed("mlp_bwd_bwd", L.gsdf_mlp_bwd_bwd, B, nl, dims_c, f32(weights), f32(acts), f32(v_out), ptr(ws),
+                          f32(vv_in.contiguous()), f32(g_vout), f32(g_w), ptr(ws2), capi.stream()), "mlp_bwd_bwd")
+        return (g_vout if ctx.needs_input_grad[0] else None), None, g_w, None, None, None, None, None
 
 
 class TCNNNetwork:
@@ -534,12 +596,157 @@ class _CouplingLeg(torch.autograd.Function):
         return v_samples, None, None, None, None, None, None
 
 
+class _SdfBatchAnalytic(torch.autograd.Function):
+    """One SDF batch of the reference's DEFAULT configuration (decoder_implementation 0 / numerical_grad 0, config/base.yaml:12-13)
+    as ONE autograd node on the fused kernels, first and second order:
+        data term   mode "ray": w_data * loss::sdf_loss(get_sdf(xyz), gt)                 (neural_mapping.cpp:165-170)
+                    mode "gs" : w_data * loss::gs_sdf_loss(get_sdf(samples[ids]), w[ids])  (:436-457; d/d samples returned)
+        + w_eik * loss::eikonal_loss(g),  g = autograd.grad(sdf, xyz, create_graph=True)    (local_map.cpp:151-172; in "gs" mode on
+                                                                                            samples.detach(), :448-451)
+        + w_align * mean |g - get_gradient(xyz, delta, numerical).detach()|                (neural_mapping.cpp:126-134)
+    forward : query points (+ 6 stencil rows for the align term) -> encoder (+ Jacobian of the base rows) -> decoder (activations
+              saved for the base rows only; the stencil rows are forward-only) -> decoder backward of e_0 (g0 = d sdf / d features,
+              its per-layer gradients kept) -> ONE loss launch (value, d/d decoder output, dL/d(J^T g0), dL/d g0)
+    backward: one-pass decoder backward of the data term; decoder DOUBLE backward (gsdf_mlp_bwd_bwd); ONE binned scatter that
+              carries the first-order and the second-order table gradient of every corner (gsdf_hashgrid_bwd_binned2); in "gs"
+              mode d/dx of the data term from the Jacobian.
+    Parameter gradients accumulate in place (LocalMap.flatten(accumulate_table_grad_in_place=True) + grad_sinks_armed())."""
+
+    @staticmethod
+    def forward(ctx, samples, ids, aux, lm, mode, w_data, delta, w_eik, w_align, _anchor):
+        # _anchor = the encoder's parameter tensor: makes the node part of the graph when `samples` carries no gradient (ray
+        # batch); its gradient is deposited in the sink, autograd gets None
+        L = capi.lib()
+        enc, dec = lm.encoder, lm.decoder
+        cfg, dims = enc.cfg, tuple(dec.dims)
+        xs = samples.detach().contiguous() if ids is None else samples.detach().index_select(0, ids)
+        n, dev = xs.shape[0], xs.device
+        stencil = bool(w_align != 0.0) and n > 0
+        K = 7 if stencil else 1
+        x01 = torch.empty(K * n, 3, dtype=torch.float32, device=dev)
+        capi.check(L.gsdf_sdf_query_points(n, int(stencil), f32(xs), float(delta or 0.0), (C.c_float * 3)(*lm._origin),
+                                           float(lm.map_size_inv), f32(x01), capi.stream()), "sdf_query_points")
+        table = enc.params_.view(-1, cfg[1])
+        nf, nl = cfg[0] * cfg[1], len(dims) - 1
+        dims_c = (C.c_int * len(dims))(*dims)
+        feat = torch.empty(K * n, nf, dtype=torch.float32, device=dev)
+        jac = torch.empty(n, nf, 3, dtype=torch.float32, device=dev)
+        if stencil and _stencil_fwd((n, 0), K * n):
+            capi.check(_timed("hashgrid_fwd", L.gsdf_hashgrid_fwd_stencil, K * n, n, n, *cfg, f32(x01), f32(table), f32(feat), f32(jac),
+                              capi.stream()), "hashgrid_fwd_stencil")
+        else:
+            capi.check(_timed("hashgrid_fwd", L.gsdf_hashgrid_fwd_jac_rows, K * n, n, *cfg, f32(x01), f32(table), f32(feat), f32(jac),
+                              capi.stream()), "hashgrid_fwd_jac")
+        attr = torch.empty(K * n, dims[-1], dtype=torch.float32, device=dev)
+        acts = torch.empty(L.gsdf_mlp_acts_floats(n, nl), dtype=torch.float32, device=dev)
+        fb, ab = feat[:n], attr[:n]
+        capi.check(_timed("mlp_fwd", L.gsdf_mlp_fwd, n, nl, dims_c, f32(dec.params_), f32(dec.biases_), f32(fb), f32(ab), f32(acts),
+                          capi.stream()), "mlp_fwd")
+        if stencil:   # forward-only rows: the numerical gradient of the align term is detached
+            capi.check(_timed("mlp_fwd", L.gsdf_mlp_fwd, 6 * n, nl, dims_c, f32(dec.params_), f32(dec.biases_), f32(feat[n:]), f32(attr[n:]),
+                              None, capi.stream()), "mlp_fwd")
+        # g0 = d sdf / d features: the decoder's backward of e_0, its per-layer gradients stay in `bws` for the double backward
+        e0 = torch.zeros(n, dims[-1], dtype=torch.float32, device=dev)
+        e0[:, 0] = 1.0
+        g0 = torch.empty(n, nf, dtype=torch.float32, device=dev)
+        bws = torch.empty(L.gsdf_mlp_bwd_ws_bytes(n, nl), dtype=torch.uint8, device=dev)
+        capi.check(_timed("mlp_bwd_data", L.gsdf_mlp_bwd, n, nl, dims_c, f32(dec.params_), f32(dec.biases_), f32(fb), f32(acts), f32(e0),
+                          f32(g0), None, None, ptr(bws), capi.stream()), "mlp_bwd")
+        loss = torch.empty((), dtype=torch.float32, device=dev)
+        v_attr = torch.empty(n, dims[-1], dtype=torch.float32, device=dev)
+        vv_x = torch.empty(n, 3, dtype=torch.float32, device=dev)
+        u0 = torch.empty(n, nf, dtype=torch.float32, device=dev)
+        gs = mode == "gs"
+        aux_c = aux.contiguous().reshape(-1)
+        capi.check(_timed("sdf_analytic_loss", L.gsdf_sdf_analytic_loss, n, int(gs), int(stencil), f32(attr), attr.shape[1], f32(g0), nf,
+                          f32(jac), None if gs else f32(aux_c), f32(aux_c) if gs else None,
+                          ptr(ids, torch.int64) if (gs and ids is not None) else None, float(lm.bce_isigma), float(w_data),
+                          float(lm.map_size_inv), float(delta or 0.0), float(w_eik), float(w_align), f32(loss), f32(v_attr), f32(vv_x),
+                          f32(u0), capi.stream()), "sdf_analytic_loss")
+        ctx.save_for_backward(ids, x01, feat, jac, acts, bws, e0, g0, v_attr, vv_x, u0)
+        ctx.lm, ctx.n, ctx.n_rows, ctx.gs = lm, n, samples.shape[0], gs
+        return loss
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, v_loss):
+        if _SinkState.armed <= 0:
+            raise RuntimeError("analytic SDF batch: call backward inside `with sdf.grad_sinks_armed():` (the node accumulates "
+                               "parameter gradients in place)")
+        L = capi.lib()
+        ids, x01, feat, jac, acts, bws, e0, g0, v_attr, vv_x, u0 = ctx.saved_tensors
+        lm, n = ctx.lm, ctx.n
+        enc, dec = lm.encoder, lm.decoder
+        cfg, dims = enc.cfg, tuple(dec.dims)
+        nl = len(dims) - 1
+        dims_c = (C.c_int * len(dims))(*dims)
+        dev = x01.device
+        want_x = ctx.gs and ctx.needs_input_grad[0]
+        if n == 0:
+            return (torch.zeros(ctx.n_rows, 3, device=dev) if want_x else None), None, None, None, None, None, None, None, None, None
+        fb, xb = feat[:n], x01[:n]
+        v_out = (v_attr * v_loss).contiguous()
+        v_feat = torch.empty(n, cfg[0] * cfg[1], dtype=torch.float32, device=dev)
+        w_sink, b_sink = dec.grad_sinks
+        # first order: data term through the decoder (one pass: input + parameter gradients)
+        ws = torch.empty(L.gsdf_mlp_bwd_ws_bytes_for(n, nl, dims_c, 1), dtype=torch.uint8, device=dev)
+        capi.check(_timed("mlp_bwd", L.gsdf_mlp_bwd, n, nl, dims_c, f32(dec.params_), f32(dec.biases_), f32(fb), f32(acts), f32(v_out),
+                          f32(v_feat), f32(w_sink), f32(b_sink), ptr(ws) if ws.numel() else None, capi.stream()), "mlp_bwd")
+        # second order: the regularisers reach the decoder weights through g0 = W_0^T D_0 ... e_0
+        vv_in = (u0 * v_loss).contiguous()
+        g_vout = torch.empty_like(e0)
+        ws2 = torch.empty(L.gsdf_mlp_bwd_bwd_ws_bytes(n, nl), dtype=torch.uint8, device=dev)
+        capi.check(_timed("mlp_bwd_bwd", L.gsdf_mlp_bwd_bwd, n, nl, dims_c, f32(dec.params_), f32(acts), f32(e0), ptr(bws), f32(vv_in),
+                          f32(g_vout), f32(w_sink), ptr(ws2), capi.stream()), "mlp_bwd_bwd")
+        v_samples = None
+        if want_x:   # d (data term) / d samples from the Jacobian of the base rows (the regularisers see samples.detach())
+            v_x = torch.empty(n, 3, dtype=torch.float32, device=dev)
+            capi.check(_timed("hashgrid_bwd_input", L.gsdf_hashgrid_bwd_jac, n, cfg[0], cfg[1], f32(jac), f32(v_feat), f32(v_x),
+                              capi.stream()), "hashgrid_bwd_jac")
+            v_samples = torch.zeros(ctx.n_rows, 3, dtype=torch.float32, device=dev)
+            if ids is None:
+                v_samples.copy_(v_x * float(lm.map_size_inv))
+            else:
+                v_samples.index_add_(0, ids, v_x * float(lm.map_size_inv))
+        # table: first-order (v_feat) and second-order (g0, vv_x) contributions of every corner in ONE scatter
+        table = enc.params_.view(-1, cfg[1])
+        sink = enc.grad_sink.view(table.shape)
+        vvx = (vv_x * v_loss).contiguous()
+
+        def scatter():
+            mode = os.environ.get("GSDF_HASHGRID_BINNED", "auto")
+            nbytes = L.gsdf_hashgrid_bwd_binned_ws_bytes(n, *cfg) if (mode != "0" and (mode == "1" or n >= BINNED_MIN_POINTS)) else 0
+            if nbytes:
+                bws2 = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+                capi.check(_timed("hashgrid_bwd", L.gsdf_hashgrid_bwd_binned2, n, *cfg, f32(xb), f32(v_feat), f32(g0), f32(vvx), f32(sink),
+                                  ptr(bws2), nbytes, capi.stream()), "hashgrid_bwd_binned2")
+            else:
+                capi.check(_timed("hashgrid_bwd", L.gsdf_hashgrid_bwd, n, *cfg, f32(xb), f32(table), f32(v_feat), f32(sink), None,
+                                  capi.stream()), "hashgrid_bwd")
+                capi.check(_timed("hashgrid_bwd_bwd", L.gsdf_hashgrid_bwd_bwd, n, *cfg, f32(xb), f32(table), f32(g0), f32(vvx), None,
+                                  f32(sink), None, capi.stream()), "hashgrid_bwd_bwd")
+        if enc.scatter_stream is None:
+            scatter()
+        else:
+            cur = torch.cuda.current_stream()
+            enc.scatter_stream.wait_stream(cur)
+            with torch.cuda.stream(enc.scatter_stream):
+                scatter()
+            for t in (v_feat, x01, g0, vvx):
+                t.record_stream(enc.scatter_stream)
+        return v_samples, None, None, None, None, None, None, None, None, None
+
+
 class LocalMap:
     """The SDF half of the reference's `LocalMap` (include/neural_net/local_map.{h,cpp}): hash-grid encoder +
     decoder, `get_sdf`, `get_gradient` (numerical 6-point stencil or analytic via autograd)."""
 
     def __init__(self, map_origin, map_size, bce_sigma=0.02, decoder_implementation=1, hidden_dim=64, geo_num_layer=3,
-                 device="cuda", seed=0, encoding_config=None):
+                 device="cuda", seed=0, encoding_config=None, decoder_backend="fused"):
+        """decoder_implementation as config/base.yaml:12: 0 = the torch::nn::Sequential topology (biases, geo_num_layer + 1 hidden
+        matmuls; the reference's DEFAULT), 1 = tcnn FullyFusedMLP (bias free, geo_num_layer hidden matmuls).  Both run on the
+        fused MFMA kernels, first AND second order; decoder_backend="torch" builds implementation 0 as an eager
+        torch.nn.Sequential instead (rocBLAS GEMMs: the A/B reference of the tests)."""
         self.pos_W_M = torch.as_tensor(map_origin, dtype=torch.float32, device=device).reshape(1, 3)
         self.map_size_inv = 1.0 / float(map_size)
         self._origin = [float(v) for v in map_origin]
@@ -547,7 +754,7 @@ class LocalMap:
         self.encoder = TCNNEncoding(3, encoding_config, "encoder_local_map", device, seed)
         feat = self.encoder.get_out_dim()
         self.decoder_implementation = decoder_implementation
-        if decoder_implementation == 0:      # torch::nn::Sequential, local_map.cpp:29-42 (rocBLAS GEMMs)
+        if decoder_implementation == 0 and decoder_backend == "torch":      # torch::nn::Sequential, local_map.cpp:29-42 (rocBLAS GEMMs)
             torch.manual_seed(seed)
             layers = [torch.nn.Linear(feat, hidden_dim), torch.nn.ReLU(True)]
             for _ in range(geo_num_layer):
@@ -557,7 +764,7 @@ class LocalMap:
         elif decoder_implementation == 1:    # tcnn FullyFusedMLP, local_map.cpp:44-55
             self.decoder = TCNNNetwork(feat, 2, dict(otype="FullyFusedMLP", activation="ReLU", output_activation="None",
                                                      n_neurons=hidden_dim, n_hidden_layers=geo_num_layer), "decoder", device, seed=seed + 1)
-        else:                                # fused MFMA kernel with the torch decoder's topology (biases, 4 hidden matmuls)
+        else:                                # 0 (or 2): fused MFMA kernels with the torch decoder's topology (biases, 4 hidden matmuls)
             self.decoder = TCNNNetwork(feat, 2, dict(n_neurons=hidden_dim, n_hidden_layers=geo_num_layer + 1), "decoder", device,
                                        bias=True, seed=seed + 1)
 
@@ -698,6 +905,23 @@ class LocalMap:
         if self.encoder.grad_sink is None or getattr(self.decoder, "grad_sinks", None) is None:
             raise RuntimeError("gs_sdf_coupling needs LocalMap.flatten(accumulate_table_grad_in_place=True) with the fused decoder")
         return _CouplingLeg.apply(samples, ids, weights, self, scale, delta, w_eik)
+
+    def _analytic_ready(self):
+        if self.encoder.grad_sink is None or getattr(self.decoder, "grad_sinks", None) is None:
+            raise RuntimeError("the fused analytic SDF batch needs LocalMap.flatten(accumulate_table_grad_in_place=True) with a fused decoder")
+
+    def ray_loss_analytic(self, xyz, gt_sdf, delta, w_sdf=1.0, w_eik=0.1, w_align=0.1):
+        """The per-ray batch of the reference's DEFAULT configuration (neural_mapping.cpp:138-188 with numerical_grad 0):
+        w_sdf * sdf_loss(get_sdf(xyz)) + w_eik * eikonal_loss(analytic gradient) + w_align * |analytic - numerical.detach()|.mean(),
+        one autograd node (_SdfBatchAnalytic)."""
+        self._analytic_ready()
+        return _SdfBatchAnalytic.apply(xyz, None, gt_sdf, self, "ray", w_sdf, delta, w_eik, w_align, self.encoder.params_)
+
+    def gs_sdf_coupling_analytic(self, samples, ids, weights, scale=1.0, delta=None, w_eik=0.0, w_align=0.0):
+        """The GS<->SDF block of the DEFAULT configuration (neural_mapping.cpp:420-462): scale * gs_sdf_loss(get_sdf(samples[ids]),
+        weights[ids]) + sdf_regularization(samples[ids].detach()) with the ANALYTIC gradient (eikonal + align), one autograd node."""
+        self._analytic_ready()
+        return _SdfBatchAnalytic.apply(samples, ids, weights, self, "gs", scale, delta, w_eik, w_align, self.encoder.params_)
 
     def ray_loss(self, xyz, gt_sdf, delta, w_eik):
         """sdf_loss(get_sdf(xyz)) + w_eik * eikonal_loss(get_gradient(xyz, delta, numerical)) of the per-ray batch

@@ -41,6 +41,26 @@ class _Activate(torch.autograd.Function):
         return None, None, None, None, None
 
 
+def morton_order(xyz, bits=16):
+    """Permutation that sorts points [n,3] by the Morton (Z-order) key of their position in their own bounding box,
+    `bits` bits per axis.  The splat set is kept in this order in HBM (at initialisation and whenever a refinement step
+    re-materialises it): packed visible rows, the GS<->SDF sample points and the tile lists' gathers are then spatially
+    coherent — the hash-grid gathers of neighbouring sample points hit the same L2 lines and the binned table-gradient scatter
+    emits long runs.  The reference attaches no meaning to the order of the splats (it appends and removes rows at every
+    refinement step, neural_gaussian.cpp:690-926)."""
+    lo, hi = xyz.min(0).values, xyz.max(0).values
+    q = ((xyz - lo) / (hi - lo).clamp_min(1e-20) * (2 ** bits - 1)).round().to(torch.int64).clamp_(0, 2 ** bits - 1)
+
+    def spread(x):          # 21-bit value -> every third bit of a 63-bit word
+        x = (x | (x << 32)) & 0x1F00000000FFFF
+        x = (x | (x << 16)) & 0x1F0000FF0000FF
+        x = (x | (x << 8)) & 0x100F00F00F00F00F
+        x = (x | (x << 4)) & 0x10C30C30C30C30C3
+        return (x | (x << 2)) & 0x1249249249249249
+    key = spread(q[:, 0]) | (spread(q[:, 1]) << 1) | (spread(q[:, 2]) << 2)
+    return torch.sort(key, stable=True).indices
+
+
 class SplatParams:
     FIELDS = (("offsets", 3), ("scaling", 3), ("quaternion", 4), ("opacity", 1), ("features_dc", 3), ("features_rest", None))
 
@@ -65,11 +85,13 @@ class SplatParams:
         self.n_rest = features_rest.reshape(N, -1).shape[1] // 3
 
     @classmethod
-    def from_scene(cls, sc, dev):
+    def from_scene(cls, sc, dev, order=None):
+        """order: None (rows as given) or an int64 permutation (e.g. morton_order(sc["means"])) applied to every field."""
         N = sc["means"].shape[0]
         sh = sc["sh"]
-        return cls(sc["means"].to(dev), torch.zeros(N, 3, device=dev), sc["log_scales"].to(dev), sc["quats"].to(dev),
-                   sc["logit_opacities"].to(dev), sh[:, :1].contiguous().to(dev), sh[:, 1:].contiguous().to(dev))
+        o = (lambda t: t) if order is None else (lambda t: t.index_select(0, order.to(t.device)))
+        return cls(o(sc["means"]).to(dev), torch.zeros(N, 3, device=dev), o(sc["log_scales"]).to(dev), o(sc["quats"]).to(dev),
+                   o(sc["logit_opacities"]).to(dev), o(sh[:, :1]).contiguous().to(dev), o(sh[:, 1:]).contiguous().to(dev))
 
     def activated(self):
         """generate_gaussian(): xyz = anchors+offsets, scales = exp, opacity = sigmoid, sh = cat(dc, rest)."""

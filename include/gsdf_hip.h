@@ -219,6 +219,14 @@ int gsdf_hashgrid_bwd_binned(int64_t B, int n_levels, int n_feat, int log2_hashm
 int gsdf_hashgrid_bwd_binned_stencil(int64_t B, int64_t stencil_n, int merge_levels, int n_levels, int n_feat, int log2_hashmap,
                                      int base_res, float per_level_scale, const float *x, const float *v_feat, float *v_table,
                                      void *ws, size_t ws_bytes, gsdf_stream_t stream);
+/* The binned scatter with the SECOND-ORDER term of the analytic eikonal regulariser folded in (the reference's default
+ * configuration, numerical_grad: 0): v_table += (d feat / d table)^T v_feat  [v_feat may be NULL]
+ *                                             + d/d table [ (J(x, table)^T v_feat2) . vv_x ]
+ * i.e. gsdf_hashgrid_bwd's and gsdf_hashgrid_bwd_bwd's table gradients of the same points in ONE pass without global atomics
+ * (every corner's record carries w * v_feat + (d w / d x . vv_x) * v_feat2).  v_feat2 [B, L*F], vv_x [B,3]. */
+int gsdf_hashgrid_bwd_binned2(int64_t B, int n_levels, int n_feat, int log2_hashmap, int base_res, float per_level_scale,
+                              const float *x, const float *v_feat, const float *v_feat2, const float *vv_x, float *v_table,
+                              void *ws, size_t ws_bytes, gsdf_stream_t stream);
 /* Double backward of v_x = J(x,table)^T v_feat: given vv_x [B,3] returns d/d v_feat (g_vfeat, overwritten),
  * d/d table (g_table, ACCUMULATES) and d/d x (g_x, overwritten); any may be NULL. */
 int gsdf_hashgrid_bwd_bwd(int64_t B, int n_levels, int n_feat, int log2_hashmap, int base_res,
@@ -246,6 +254,17 @@ size_t gsdf_mlp_bwd_ws_bytes_for(int64_t B, int n_layers, const int *dims_host, 
 int gsdf_mlp_bwd(int64_t B, int n_layers, const int *dims_host, const float *weights, const float *biases,
                  const float *in, const float *acts, const float *v_out, float *v_in, float *v_weights,
                  float *v_biases, void *ws, gsdf_stream_t stream);
+/* Double backward of the decoder: the analytic eikonal term of the reference's default configuration differentiates
+ * v_in = d sdf / d features (torch::autograd::grad(..., create_graph=true), include/neural_net/local_map.cpp:151-172) again.
+ * Inputs: `acts` of gsdf_mlp_fwd, and of the FIRST backward gsdf_mlp_bwd(..., v_weights = NULL, ws = bwd_ws) its upstream
+ * v_out and its workspace bwd_ws (kept by the caller); vv_in [B, dims[0]] = dL/d v_in.
+ * Outputs: g_vout [B, dims[n]] = dL/d v_out (required; overwritten) and g_weights (same layout as weights; ACCUMULATES; may be
+ * NULL).  Nothing flows to the biases or to the network input (a ReLU network is piecewise linear).
+ * ws: gsdf_mlp_bwd_bwd_ws_bytes(B, n_layers) bytes. */
+size_t gsdf_mlp_bwd_bwd_ws_bytes(int64_t B, int n_layers);
+int gsdf_mlp_bwd_bwd(int64_t B, int n_layers, const int *dims_host, const float *weights, const float *acts,
+                     const float *v_out, const void *bwd_ws, const float *vv_in, float *g_vout, float *g_weights, void *ws,
+                     gsdf_stream_t stream);
 /* The weight-gradient half alone, for callers that run it on another stream: `ws` must hold the result of a preceding
  * gsdf_mlp_bwd(..., v_weights = NULL, ..., ws) on the same arguments.  v_weights / v_biases ACCUMULATE. */
 int gsdf_mlp_bwd_weights(int64_t B, int n_layers, const int *dims_host, int has_biases, const float *in,
@@ -293,6 +312,18 @@ int gsdf_gs_sdf_loss(int64_t n, const float *attr, int ld, const float *weights,
  *     (NeuralSLAM::sdf_regularization(gs_samples.detach(), ...), neural_mapping.cpp:448-451 -> :106-116). */
 int gsdf_gs_sdf_eik_loss(int64_t n, int stencil, const float *attr, int ld, const float *weights, const int64_t *ids,
                          float scale, float delta, float w_eik, float *loss, float *v_attr, gsdf_stream_t stream);
+/*  gsdf_sdf_analytic_loss: the reference's DEFAULT SDF regulariser (numerical_grad: 0, config/base.yaml:13): eikonal on the
+ *     ANALYTIC gradient g = map_size_inv * J^T g0 (LocalMap::get_gradient's autograd branch, local_map.cpp:151-172; g0 [n,32] =
+ *     d sdf / d features from gsdf_mlp_bwd with v_out = (1, 0), jac [n,32,3] from gsdf_hashgrid_fwd_jac_rows) plus the align term
+ *     w_align * mean |g - g_num.detach()| against the central differences of the stencil rows (neural_mapping.cpp:126-134),
+ *     on top of the data term: mode 0 = scale * loss::sdf_loss against gt_sdf (per-ray batch), mode 1 = scale *
+ *     loss::gs_sdf_loss with weights[ids[i]] (GS<->SDF coupling).  attr [(stencil ? 7 : 1) n, ld].
+ *     Outputs: loss[0]; v_attr [n, ld] = d loss / d attr of the BASE rows (the stencil rows are detached); vv_x [n,3] =
+ *     d loss / d (J^T g0); u0 [n,32] = J vv_x = d loss / d g0. */
+int gsdf_sdf_analytic_loss(int64_t n, int mode, int stencil, const float *attr, int ld, const float *g0, int n_feat,
+                           const float *jac, const float *gt_sdf, const float *weights, const int64_t *ids, float bce_isigma,
+                           float scale, float map_size_inv, float delta, float w_eik, float w_align, float *loss,
+                           float *v_attr, float *vv_x, float *u0, gsdf_stream_t stream);
 int gsdf_sdf_ray_loss(int64_t n, int stencil, const float *attr, int ld, const float *gt_sdf, float bce_isigma,
                       float delta, float w_eik, float *loss, float *v_attr, gsdf_stream_t stream);
 

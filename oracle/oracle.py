@@ -295,6 +295,19 @@ def mlp_bwd(x, dims, weights, biases, v_out, prec="f32"):
     return v_in, v_w, v_b
 
 
+def mlp_bwd_bwd(x, dims, weights, biases, v_out, vv_in, prec="f32"):
+    """Double backward of the decoder (oracle/sdf_oracle.c: orc_mlp_bwd_bwd): vv_in = dL/d(v_in) of the first backward ->
+    (dL/d v_out [B, d_out], dL/d weights (float64))."""
+    dt = _dt(prec)
+    x, weights, biases, v_out, vv_in = _c(x, dt), _c(weights, dt), _c(biases, dt), _c(v_out, dt), _c(vv_in, dt)
+    dims_a = np.asarray(dims, np.int32)
+    B, nl = x.shape[0], len(dims) - 1
+    g_vout = np.zeros((B, dims[-1]), dt); g_w = np.zeros(weights.shape, np.float64)
+    _lib("sdf", prec).orc_mlp_bwd_bwd(C.c_int64(B), C.c_int(nl), _p(dims_a), _p(weights), _p(biases), _p(x), _p(v_out), _p(vv_in),
+                                      _p(g_vout), _p(g_w))
+    return g_vout, g_w
+
+
 def sdf_head(out, inv_bce_sigma, prec="f32"):
     dt = _dt(prec)
     out = _c(out, dt)

@@ -295,6 +295,74 @@ void orc_mlp_bwd(int64_t B, int n_layers, const int *dims, const REAL *weights, 
   free(h); free(g); free(g2);
 }
 
+/* Double backward of the decoder (the analytic eikonal term of the reference's DEFAULT configuration:
+ * LocalMap::get_gradient, /root/reference/include/neural_net/local_map.cpp:151-172, torch::autograd::grad(create_graph=true)
+ * through the torch::nn::Sequential of :29-42).  The first backward maps v_out to v_in = W_0^T D_0 W_1^T D_1 ... v_out
+ * (D_l = ReLU mask of layer l's output).  Given vv_in = dL/d v_in this returns
+ *   g_vout [B,dims[n]]  = dL/d v_out  = W_{n-1} D_{n-2} ... D_0 W_0 vv_in     (a masked, bias-free forward pass),
+ *   g_weights (ACCUMULATE, double): dL/dW_0 = delta_0 (x) vv_in,  dL/dW_l = delta_l (x) (D_{l-1} t_{l-1}),  t_0 = W_0 vv_in,
+ *                                   t_l = W_l D_{l-1} t_{l-1},  delta_l = the first backward's gradient at layer l's pre-activation.
+ * A ReLU network is piecewise linear: nothing flows to the network input or to the biases. */
+void orc_mlp_bwd_bwd(int64_t B, int n_layers, const int *dims, const REAL *weights, const REAL *biases, const REAL *in,
+                     const REAL *v_out, const REAL *vv_in, REAL *g_vout, double *g_weights) {
+  int maxd = 0;
+  for (int l = 0; l <= n_layers; ++l) if (dims[l] > maxd) maxd = dims[l];
+  REAL *h = (REAL *)malloc(sizeof(REAL) * (size_t)maxd * (n_layers + 1));      /* forward activations */
+  REAL *dl = (REAL *)malloc(sizeof(REAL) * (size_t)maxd * (n_layers + 1));     /* delta_l at slot l+1 (pre-activation gradients) */
+  REAL *t = (REAL *)malloc(sizeof(REAL) * maxd), *t2 = (REAL *)malloc(sizeof(REAL) * maxd);
+  for (int64_t b = 0; b < B; ++b) {
+    memcpy(h, in + b * dims[0], sizeof(REAL) * dims[0]);
+    const REAL *W = weights, *bi = biases;
+    for (int l = 0; l < n_layers; ++l) {
+      int I = dims[l], O = dims[l + 1];
+      const REAL *cur = h + (size_t)l * maxd;
+      REAL *nxt = h + (size_t)(l + 1) * maxd;
+      for (int o = 0; o < O; ++o) {
+        REAL acc = bi ? bi[o] : 0;
+        for (int i = 0; i < I; ++i) acc += W[o * I + i] * cur[i];
+        if (l < n_layers - 1 && acc < 0) acc = 0;
+        nxt[o] = acc;
+      }
+      W += (int64_t)O * I;
+      if (bi) bi += O;
+    }
+    /* first backward: delta_{n-1} = v_out, delta_{l-1} = D_{l-1} W_l^T delta_l */
+    memcpy(dl + (size_t)n_layers * maxd, v_out + b * dims[n_layers], sizeof(REAL) * dims[n_layers]);
+    int64_t woff = 0;
+    for (int l = 0; l < n_layers; ++l) woff += (int64_t)dims[l] * dims[l + 1];
+    for (int l = n_layers - 1; l >= 1; --l) {
+      int I = dims[l], O = dims[l + 1];
+      woff -= (int64_t)O * I;
+      const REAL *Wl = weights + woff, *d = dl + (size_t)(l + 1) * maxd, *hout = h + (size_t)l * maxd;
+      REAL *dn = dl + (size_t)l * maxd;
+      for (int i = 0; i < I; ++i) {
+        REAL acc = 0;
+        for (int o = 0; o < O; ++o) acc += Wl[o * I + i] * d[o];
+        dn[i] = hout[i] > 0 ? acc : 0;
+      }
+    }
+    /* second pass, forward: u = vv_in; dW_l += delta_l (x) u; u <- D_l (W_l u) */
+    memcpy(t, vv_in + b * dims[0], sizeof(REAL) * dims[0]);
+    woff = 0;
+    for (int l = 0; l < n_layers; ++l) {
+      int I = dims[l], O = dims[l + 1];
+      const REAL *Wl = weights + woff, *d = dl + (size_t)(l + 1) * maxd, *hout = h + (size_t)(l + 1) * maxd;
+      for (int o = 0; o < O; ++o) {
+        REAL acc = 0;
+        for (int i = 0; i < I; ++i) {
+          if (g_weights) g_weights[woff + (int64_t)o * I + i] += (double)(d[o] * t[i]);
+          acc += Wl[o * I + i] * t[i];
+        }
+        t2[o] = (l < n_layers - 1 && !(hout[o] > 0)) ? 0 : acc;
+      }
+      woff += (int64_t)O * I;
+      REAL *sw = t; t = t2; t2 = sw;
+    }
+    if (g_vout) memcpy(g_vout + b * dims[n_layers], t, sizeof(REAL) * dims[n_layers]);
+  }
+  free(h); free(dl); free(t); free(t2);
+}
+
 /* SDF head (local_map.cpp:97-102): out [B,2] -> sdf [B], isigma [B] ; softplus beta=100, threshold 20 (torch) */
 void orc_sdf_head(int64_t B, REAL inv_bce_sigma, const REAL *out, REAL *sdf, REAL *isigma) {
   for (int64_t b = 0; b < B; ++b) {

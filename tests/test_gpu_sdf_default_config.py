@@ -1,0 +1,129 @@
+"""The reference's SHIPPED DEFAULT SDF configuration (config/base.yaml:12-13: decoder_implementation 0 = biased 5-layer torch
+decoder, numerical_grad 0 = analytic eikonal by autograd(create_graph=True) + the align term) on the fused kernels:
+decoder double backward against the oracle (fp64), and the fused one-node batches against the SAME losses composed the way
+neural_mapping.cpp composes them on an eager torch.nn.Sequential decoder (libtorch autograd as the independent reference)."""
+import numpy as np
+import pytest
+import torch
+
+from util import assert_close
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def sdf():
+    assert torch.cuda.is_available()
+    import gs_sdf_amd.sdf as m
+    return m
+
+
+def n(t):
+    return t.detach().cpu().numpy()
+
+
+def _near_kink(x, dims, W, b, eps=1e-5):
+    h, off, boff, risky = x.astype(np.float64), 0, 0, np.zeros(len(x), bool)
+    for l in range(len(dims) - 2):
+        z = h @ W[off:off + dims[l] * dims[l + 1]].astype(np.float64).reshape(dims[l + 1], dims[l]).T
+        if b is not None:
+            z = z + b[boff:boff + dims[l + 1]]
+        off, boff = off + dims[l] * dims[l + 1], boff + dims[l + 1]
+        risky |= (np.abs(z) < eps).any(axis=1)
+        h = np.maximum(z, 0.0)
+    return risky
+
+
+@pytest.mark.parametrize("dims,bias,B", [([32, 64, 64, 64, 64, 2], True, 30000),      # the default decoder (local_map.cpp:29-42)
+                                         ([32, 64, 64, 64, 2], False, 4097),          # tcnn topology
+                                         ([64, 64, 64, 5], True, 333),
+                                         ([32, 64, 64, 64, 64, 2], True, 1)])
+def test_decoder_double_backward_matches_oracle(sdf, oracle, dims, bias, B):
+    dev = torch.device("cuda:0")
+    net = sdf.TCNNNetwork(dims[0], dims[-1], dict(n_neurons=64, n_hidden_layers=len(dims) - 2), "dec", dev, bias=bias, seed=3)
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(B, dims[0], generator=g)
+    W, b = n(net.params_), (n(net.biases_) if bias else None)
+    x = x[~torch.from_numpy(_near_kink(n(x), dims, W, b))]
+    B = x.shape[0]
+    xd = x.to(dev).requires_grad_(True)
+    out = net.forward(xd)
+    v_out = torch.randn(B, dims[-1], generator=g)
+    vd = v_out.to(dev).requires_grad_(True)
+    v_in, = torch.autograd.grad(out, xd, vd, create_graph=True)          # first backward, differentiable
+    ref_vin, _, _ = oracle.mlp_bwd(n(x), dims, W, b, n(v_out), prec="f64")
+    assert_close(v_in, ref_vin, 1e-4, "first backward v_in")
+    vv = torch.randn(B, dims[0], generator=g)
+    gs = torch.autograd.grad((v_in * vv.to(dev)).sum(), [vd, net.params_] + ([net.biases_] if bias else []), allow_unused=True)
+    g_vout, g_w = oracle.mlp_bwd_bwd(n(x), dims, W, b, n(v_out), n(vv), prec="f64")
+    assert_close(gs[0], g_vout, 1e-4, "double backward: d/d v_out")
+    assert_close(gs[1], g_w, 1e-4, "double backward: d/d weights")
+    if bias:
+        assert gs[2] is None or float(gs[2].abs().max()) == 0.0      # piecewise linear: nothing reaches the biases
+
+
+def _reference_composition(sdfm, lm_t, xs, mode, aux, w_data, delta, w_eik, w_align):
+    """neural_mapping.cpp:138-188 (ray) / :436-457 (gs) with sdf_regularization :106-136 on the eager decoder"""
+    if mode == "ray":
+        x = xs.detach().clone().requires_grad_(True)
+        s, isig = lm_t.get_sdf(x)
+        loss = w_data * sdfm.sdf_loss(s, aux, isig)
+        xr, sr = x, s
+    else:
+        s, _ = lm_t.get_sdf(xs)
+        loss = w_data * sdfm.gs_sdf_loss(s, aux)
+        xr, sr = xs.detach(), None          # sdf_regularization(gs_samples.detach(), ...): recomputes the SDF on the detached points
+    grad = lm_t.get_gradient(xr, delta, sr, False, False)[0]
+    loss = loss + w_eik * sdfm.eikonal_loss(grad)
+    if w_align:
+        num = lm_t.get_gradient(xr.detach(), delta, None, False, True)[0].detach()
+        loss = loss + w_align * (grad - num).abs().mean()
+    return loss
+
+
+@pytest.mark.parametrize("mode,nn", [("ray", 32768), ("gs", 30011), ("ray", 2000), ("gs", 1500)])     # binned and atomic table paths
+def test_fused_default_batch_matches_the_reference_composition(sdf, mode, nn):
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(21)
+    lm = sdf.LocalMap([0.1, -0.2, 0.3], 4.0, bce_sigma=0.02, decoder_implementation=0, device=dev, seed=6)
+    lm_t = sdf.LocalMap([0.1, -0.2, 0.3], 4.0, bce_sigma=0.02, decoder_implementation=0, device=dev, seed=6, decoder_backend="torch")
+    with torch.no_grad():
+        lm.encoder.params_.copy_(((torch.rand(lm.encoder.params_.numel(), generator=g) * 2 - 1) * 0.05).to(dev))
+    lm_t.encoder.params_ = lm.encoder.params_.detach().clone().requires_grad_(True)
+    lins = [m for m in lm_t.decoder if isinstance(m, torch.nn.Linear)]
+    dims = lm.decoder.dims
+    wo = bo = 0
+    with torch.no_grad():
+        for m, (i, o) in zip(lins, zip(dims[:-1], dims[1:])):
+            m.weight.copy_(lm.decoder.params_[wo:wo + i * o].view(o, i)); m.bias.copy_(lm.decoder.biases_[bo:bo + o])
+            wo, bo = wo + i * o, bo + o
+    grp = lm.flatten(accumulate_table_grad_in_place=True)
+    M = nn + 777
+    pts = ((torch.rand(M, 3, generator=g) - 0.5) * 3.6 + torch.tensor([0.1, -0.2, 0.3])).to(dev)
+    delta, w_eik, w_align = 0.02, 0.1, 0.1
+    if mode == "ray":
+        xs = pts[:nn].contiguous()
+        gt = (torch.randn(nn, 1, generator=g) * 0.05).to(dev)
+        with sdf.grad_sinks_armed():
+            loss = lm.ray_loss_analytic(xs, gt, delta, 1.0, w_eik, w_align)
+            loss.backward()
+        ref = _reference_composition(sdf, lm_t, xs, "ray", gt, 1.0, delta, w_eik, w_align)
+        ref.backward()
+    else:
+        samples = pts.clone().requires_grad_(True)
+        ids = torch.randperm(M, generator=g)[:nn].sort().values.to(dev)
+        w_all = torch.rand(M, 1, generator=g).to(dev)
+        with sdf.grad_sinks_armed():
+            loss = lm.gs_sdf_coupling_analytic(samples, ids, w_all, 1e-1, delta, w_eik, w_align)
+            loss.backward()
+        s_t = pts.clone().requires_grad_(True)
+        ref = _reference_composition(sdf, lm_t, s_t.index_select(0, ids), "gs", w_all.index_select(0, ids), 1e-1, delta, w_eik, w_align)
+        ref.backward()
+        assert_close(samples.grad, s_t.grad, 1e-4, "d loss / d samples", outlier_frac=2e-4)
+    assert abs(float(loss) - float(ref)) <= 1e-5 * abs(float(ref)) + 1e-7, (float(loss), float(ref))
+    # ReLU kinks / sign(g - g_num) flips between the fused (MFMA) and the eager (rocBLAS) decoder move single points: a few 1e-4 outliers
+    assert_close(lm.encoder.params_.grad, lm_t.encoder.params_.grad, 1e-4, "table gradient (first + second order)", outlier_frac=5e-4)
+    w_ref = torch.cat([m.weight.grad.reshape(-1) for m in lins]); b_ref = torch.cat([m.bias.grad for m in lins])
+    assert_close(lm.decoder.params_.grad, w_ref, 1e-4, "decoder weight gradient (first + second order)", outlier_frac=5e-4)
+    assert_close(lm.decoder.biases_.grad, b_ref, 1e-4, "decoder bias gradient", outlier_frac=5e-3)
+    assert float(grp.flat_grad.abs().sum()) > 0

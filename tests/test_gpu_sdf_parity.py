@@ -163,7 +163,7 @@ def test_local_map_get_sdf_and_numerical_gradient(sdf, oracle, impl):
 
 def test_analytic_eikonal_double_backward_matches_oracle(sdf, oracle):
     """Reference default (numerical_grad: 0, decoder_implementation: 0): SDF gradient by autograd through the
-    HIP encoder + torch decoder, eikonal loss on it, backward again (double backward through the encoder).
+    HIP encoder + fused decoder, eikonal loss on it, backward again (double backward through encoder AND decoder kernels).
     ReLU masks are piecewise constant, so d(eikonal)/d(table) is exactly the oracle's grid double backward."""
     dev = torch.device("cuda:0")
     lm = sdf.LocalMap([0.0, 0.0, 0.0], 2.0, decoder_implementation=0, device=dev, seed=5)
@@ -179,9 +179,9 @@ def test_analytic_eikonal_double_backward_matches_oracle(sdf, oracle):
     # oracle: J = d sdf / d feat from the decoder, grad_x = J . dfeat/dx, vv = dL/dgrad_x
     x01 = (0.5 * (n(xyz) * np.float32(2.0 / 2.0)) + 0.5).astype(np.float32)
     table = n(lm.encoder.params_).reshape(-1, 2)
-    lins = [m for m in lm.decoder if isinstance(m, torch.nn.Linear)]
-    W = np.concatenate([n(m.weight).reshape(-1) for m in lins]); b = np.concatenate([n(m.bias) for m in lins])
+    W, b = n(lm.decoder.params_), n(lm.decoder.biases_)            # decoder_implementation 0 on the fused kernels (biases)
     dims = [32, 64, 64, 64, 64, 2]
+    assert lm.decoder.dims == dims
     feat = oracle.grid_fwd(x01, table, CFG, prec="f32")
     v_out = np.zeros((B, 2)); v_out[:, 0] = 1.0
     J, _, _ = oracle.mlp_bwd(feat, dims, W, b, v_out, prec="f64")
