@@ -69,9 +69,16 @@ def main():
     ap.add_argument("--ray-leg-on-scatter-xcds", type=int, default=1, help="run the per-ray SDF leg on the scatter stream's XCDs")
     ap.add_argument("--ray-weights-aux", type=int, default=1, help="decoder weight gradients of the ray leg on the aux stream")
     ap.add_argument("--no-overlap", action="store_true", help="issue the SDF leg on the same HIP stream as the splat leg")
-    ap.add_argument("--light-step", action="store_true", help="round-1 step: no GS-sample eikonal regulariser, no per-iteration "
-                                                               "update_state (NOT the reference's joint iteration)")
-    ap.add_argument("--no-secondary", action="store_true", help="skip the second (light-step) timing loop")
+    ap.add_argument("--sdf-config", default="default", choices=["default", "tcnn"],
+                    help="default = the reference's shipped configuration (config/base.yaml:12-13: decoder_implementation 0, biased "
+                         "5-layer decoder; numerical_grad 0, eikonal on the ANALYTIC gradient by double backward + align_weight 0.1 against "
+                         "the detached numerical gradient); tcnn = decoder_implementation 1 (bias-free FullyFusedMLP, for which the "
+                         "reference forces the numerical gradient, params.cpp:396-399)")
+    ap.add_argument("--step-terms", default="reference", choices=["reference", "round2"],
+                    help="reference = every loss term of the reference's iteration (0.8 L1 + 0.2 D-SSIM, render_normal_weight 0.01 x "
+                         "depth->normal consistency, isotropic_weight 0.05, prune_nan test); round2 = the round-2 step (L1 + D-SSIM and "
+                         "1e-6 N(0,1) op-level gradients on depth / alpha / normal / median)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the extra lines (other SDF configuration, zero-edit loop, C++ step)")
     ap.add_argument("--cpp-step", action="store_true",
                     help="time gsdf_extras::JointIteration (the same joint iteration in C++/libtorch over libgsdf_torch.so, one stream, driven "
                          "through the pybind test harness): the step the reference's node reaches with the INTEGRATION.md section 5 edits")
@@ -142,7 +149,8 @@ def main():
         # hash-grid SDF (2^19 table, 16 levels x 2) + fused MFMA decoder; the reference's numerical-gradient
         # configuration (params.cpp:396-399 forces it for the tcnn decoder); ray batch 32768 (base.yaml:24)
         import gs_sdf_amd.sdf as sdfm
-        lm = sdfm.LocalMap([0.0, 0.0, 5.5], 16.0, bce_sigma=0.02, decoder_implementation=1, device=dev, seed=5)
+        lm = sdfm.LocalMap([0.0, 0.0, 5.5], 16.0, bce_sigma=0.02, decoder_implementation=0 if args.sdf_config == "default" else 1,
+                           device=dev, seed=5)
         groups.append(lm.flatten(accumulate_table_grad_in_place=True))
         # occupancy structure of the map (SubMap::update_octree_as, sub_map.cpp:22-35): leaf 1/16 m -> level 8 in the 16 m
         # cube, built from the splat centres (the reference builds it from the depth point cloud the splats start from)
@@ -196,8 +204,11 @@ def main():
         torch.cuda.set_stream(main)
     gate = GradGate()
 
+    released = []
+
     def release_streams():
-        if overlap:
+        if overlap and not released:
+            released.append(1)
             from gs_sdf_amd.streams import destroy_all
             torch.cuda.synchronize()
             lm.encoder.scatter_stream = lm.decoder.aux_stream = None
@@ -211,16 +222,20 @@ def main():
             host.append((tag, time.perf_counter()))
 
     gs_state = {}
-    state = {"light": args.light_step}
+    analytic = args.sdf_config == "default"
+    ref_terms = args.step_terms == "reference"
+    Kh = [float(v) for v in (sc["K"][0, 0, 0], sc["K"][0, 1, 1], sc["K"][0, 0, 2], sc["K"][0, 1, 2])]
+    c2w_host = [tuple(float(v) for v in torch.linalg.inv(vw.double())[:3, :4].reshape(-1)) for vw in views.cpu()]   # poses are known ahead
+    nan_total = torch.zeros(1, dtype=torch.int32, device=dev)
 
     def step(i, update=True):
         stamp("begin")
         view = views[(i * world + rank) % views.shape[0]][None]
-        if not args.no_sdf:
+        if not args.no_sdf and not analytic:
             # per-ray SDF batch (neural_mapping.cpp:138-188): BCE on the SDF head + eikonal on the numerical gradient.
             # Independent of the render.  In overlap mode the WHOLE leg (encoder, decoder, loss, backward, scatter) runs on
-            # the scatter stream's two XCDs: they would otherwise idle until the first scatter of the step, and the
-            # six XCDs of the splat leg are relieved of ~0.7 ms of kernels.
+            # the scatter stream: it would otherwise idle until the first scatter of the step.
+            # (analytic configuration: the ray batch travels with the splat samples in ONE batch, below)
             ray_stream = scatter if args.ray_leg_on_scatter_xcds else side
             if ray_stream is not side:
                 ray_stream.wait_stream(side)              # the SDF parameters of step i-1 (Adam ran on `side`)
@@ -237,9 +252,16 @@ def main():
         # colour: the reference's photometric loss 0.8 L1 + 0.2 D-SSIM (neural_mapping.cpp:237-240), fused HIP kernel;
         # depth / alpha / normal / median: op-level 1e-6 N(0,1) upstream gradients so that every backward path is live.
         # Issued BEFORE the coupling leg: its kernels only need the render, and the host spends ~1 ms issuing that leg.
-        loss = ops.l1_dssim_loss(meta["color"][0], target, 0.8, 0.2) + inject_grads(
-            [(meta["depth"], ug6["v_render_depths"]), (alphas, ug6["v_render_alphas"]),
-             (meta["render_normal"], ug6["v_render_normals"]), (meta["render_median"], ug6["v_render_median"])])
+        loss = ops.l1_dssim_loss(meta["color"][0], target, 0.8, 0.2)
+        if ref_terms:
+            # render_normal_weight x depth->normal consistency (neural_mapping.cpp:243-266, depth_type 0: expected depth; alpha
+            # detached) + isotropic_weight x isotropic regulariser of the visible splats (:268-276): one fused launch each
+            vi = (i * world + rank) % views.shape[0]
+            loss = loss + 0.01 * ops.normal_consistency_loss(meta["depth"][0], alphas[0], meta["render_normal"][0], *Kh, c2w_host[vi]) \
+                        + 0.05 * ops.isotropic_loss(scales, meta["gaussian_ids"])
+        else:
+            loss = loss + inject_grads([(meta["depth"], ug6["v_render_depths"]), (alphas, ug6["v_render_alphas"]),
+                                        (meta["render_normal"], ug6["v_render_normals"]), (meta["render_median"], ug6["v_render_median"])])
         stamp("render + loss issued (2 syncs)")
         if not args.no_sdf:
             # GS <-> SDF coupling (neural_mapping.cpp:420-462): SDF at the visible splats' samples: gs_sdf_loss on the base
@@ -259,9 +281,16 @@ def main():
                 for t in (samples_cut, w_all, ids):     # allocated on `main`, read by kernels on `side`: keep the blocks
                     t.record_stream(side)               # out of main's allocator until side has passed this point
             with torch.cuda.stream(side):
-                if ids.numel() > 0:
-                    light = state["light"]
-                    cl = lm.gs_sdf_coupling(samples_cut, ids, w_all, 1e-3, None if light else 0.02, 0.0 if light else 0.1)
+                if analytic:
+                    # the iteration's whole SDF work as ONE batch: per-ray points (sdf_loss) + visible splats' samples (gs_sdf_loss),
+                    # eikonal on the analytic gradient + align on both (neural_mapping.cpp:138-188, 420-462)
+                    has = ids.numel() > 0
+                    cl = lm.joint_sdf_loss_analytic(pool[i % 8], ray_sdf[i % 8], samples_cut if has else None, ids if has else None,
+                                                    w_all if has else None, 0.02, 1.0, 1e-3, 0.1, 0.1)
+                    with sdfm.grad_sinks_armed():
+                        cl.backward()
+                elif ids.numel() > 0:
+                    cl = lm.gs_sdf_coupling(samples_cut, ids, w_all, 1e-3, 0.02, 0.1)
                     with sdfm.grad_sinks_armed():
                         cl.backward()
                 gate.event = side.record_event() if side is not main else None     # d loss / d samples is complete
@@ -273,10 +302,9 @@ def main():
                 torch.autograd.backward([loss, samples], [None, samples_cut.grad])
             else:
                 loss.backward()
-        if not state["light"]:
-            # per-iteration train_callback -> NeuralGS::update_state (neural_mapping.cpp:486, neural_gaussian.cpp:626-680):
-            # densification statistics from the compositing backward's `densify` gradient, one fused launch
-            update_densify_state(gs_state, meta, N)
+        # per-iteration train_callback -> NeuralGS::update_state (neural_mapping.cpp:486, neural_gaussian.cpp:626-680):
+        # densification statistics from the compositing backward's `densify` gradient, one fused launch
+        update_densify_state(gs_state, meta, N)
         stamp("backward issued")
         # view-parallel: the splat family's gradients are final here; the SDF leg's scatter keeps running on its own stream
         # beside the collective (no CU masks any more: the binned scatter is bandwidth-bound and shares the chip like any
@@ -285,6 +313,9 @@ def main():
         if update:
             adam.step()
             params.flat_grad.zero_()
+            if ref_terms:   # train_callback -> prune_nan_gs's test (neural_gaussian.cpp:907-916), one launch, no host sync: the
+                v_ = params.views   # count is read after the timed region (a real trainer reads it with the next step's sizes)
+                nan_total.add_(ops.nan_rows(v_["offsets"], v_["scaling"], v_["quaternion"])[0])
         if not args.no_sdf:
             # the SDF network's gradients are final once the scatter stream has drained: all-reduce (61 MB table + MLP)
             # and optimizer step of this leg on its own stream, beside the splat leg
@@ -336,7 +367,8 @@ def main():
     torch.cuda.synchronize()
     # HIP-event timing of the roofline kernels over the timed region (the full per-operator table comes from a short
     # separate pass below: two events per launch on all ~25 operators cost ~2 % of the step in host time)
-    ROOF = {"hashgrid_bwd", "hashgrid_fwd", "rasterize_2dgs_fwd", "rasterize_2dgs_bwd", "mlp_fwd", "mlp_bwd", "mlp_bwd_data", "mlp_bwd_weights"}
+    ROOF = {"hashgrid_bwd", "hashgrid_fwd", "rasterize_2dgs_fwd", "rasterize_2dgs_bwd", "mlp_fwd", "mlp_bwd", "mlp_bwd_data", "mlp_bwd_weights",
+            "mlp_bwd_bwd"}
 
     step_marks = []
 
@@ -385,22 +417,6 @@ def main():
     nxt += min(10, args.steps)
     kern_all = ops.TIMERS.summary_ms("median")
     ops.TIMERS.disable()
-    secondary = None
-    if not state["light"] and not args.no_sdf and not args.no_secondary and world == 1:
-        # second, clearly named line: the lighter step round 1 timed (no GS-sample eikonal, no update_state)
-        state["light"] = True
-        n2 = max(5, min(args.steps, 30))
-        for i in range(5):
-            step(nxt + i)
-        torch.cuda.synchronize()
-        el2, _, _, _, avg2 = timed(n2, nxt + 5)
-        secondary = {"name": "light step of round 1: WITHOUT the GS-sample eikonal regulariser (neural_mapping.cpp:448-451) and "
-                             "WITHOUT the per-iteration update_state; not the reference's joint iteration",
-                     "value": n2 / el2, "unit": "iters/s", "ms_per_step": el2 / n2 * 1e3, "steps": n2,
-                     "sdf_points_per_step": 7 * 32768 + avg2.get("n_gs_sdf", 0)}
-        state["light"] = False
-        ops.TIMERS.disable()
-
     if rank == 0 and os.environ.get("GSDF_BENCH_DUMP_PARAMS"):
         # debugging / evidence hook (tools/compare_mlp_pipes.py): the parameters after warmup + steps optimizer steps
         torch.cuda.synchronize()
@@ -409,25 +425,27 @@ def main():
         M, I, n_gs = avg["M"], avg["I"], avg.get("n_gs_sdf", 0.0)        # means over the timed steps (views differ per step)
         P, T = W * H, ((W + 15) // 16) * ((H + 15) // 16)
         Kb = (deg + 1) ** 2
-        stencil = 1 if state["light"] else 7
-        sdf_pts = 0 if args.no_sdf else 7 * 32768 + stencil * n_gs
-        # algorithmic bytes / flops per launch.  The dominant kernel is the one with the
-        # largest total time per step (median launch x launches per step).
-        alg = {"rasterize_2dgs_bwd": 80 * I + 48 * P + 88 * M, "rasterize_2dgs_fwd": 80 * I + 48 * P}
-        flops = {}
+        base_pts = 0 if args.no_sdf else 32768 + n_gs                      # points that carry gradients (ray batch + splat samples)
+        sdf_pts = 7 * base_pts                                            # + their 6 central-difference points (forward-only when analytic)
+        # algorithmic bytes / flops per STEP of each operator, divided by its launches per step
+        # below.  The dominant kernel is the one with the largest total time per step.
+        alg_step = {"rasterize_2dgs_bwd": 80 * I + 48 * P + 88 * M, "rasterize_2dgs_fwd": 80 * I + 48 * P}
+        flops_step = {}
         if not args.no_sdf:
-            # S1 per query point: fwd 12 + 1024 (16 levels x 8 corners x 8 B) + 128; bwd 8 + 128 + 1024 scatter; S2: 10368
-            # multiply-adds per point and pass (32x64 + 2 x 64x64 + 64x2); per launch = per step / launches per step
-            # (the 7 x 32768 ray + stencil points in one launch, the visible splat samples and their stencil in another)
-            per_launch = lambda k: sdf_pts / max(1.0, calls.get(k, 0) / args.steps)
-            alg["hashgrid_bwd"] = 1160 * per_launch("hashgrid_bwd")
-            alg["hashgrid_fwd"] = 1164 * per_launch("hashgrid_fwd")
-            # mlp_bwd = the one-pass backward (input + weight gradients: twice the forward's multiply-adds)
-            for k, passes in (("mlp_fwd", 1), ("mlp_bwd", 2), ("mlp_bwd_data", 1), ("mlp_bwd_weights", 1)):
-                if calls.get(k):
-                    flops[k] = passes * 2 * 10368 * per_launch(k)
-        # time per step of an operator = MEAN launch x launches per step (the two launches of an SDF operator differ 10x in size:
-        # 7 x 32768 ray points against ~3 M splat-sample points; `alg` is the per-launch mean to match); medians are reported too
+            macs = sum(a_ * b_ for a_, b_ in zip(lm.decoder.dims[:-1], lm.decoder.dims[1:]))   # multiply-adds per point and pass
+            # S1 per query point: fwd 12 + 1024 (16 levels x 8 corners x 8 B) + 128 (+ 384 B of Jacobian per gradient-carrying
+            # point); bwd 8 + 128 + 1024 scatter (+ 128 + 12 for the second-order operands of the analytic configuration)
+            alg_step["hashgrid_fwd"] = 1164 * sdf_pts + 384 * base_pts
+            alg_step["hashgrid_bwd"] = (1300 * base_pts) if analytic else (1160 * sdf_pts)
+            bwd_pts = base_pts if analytic else sdf_pts
+            flops_step = {"mlp_fwd": 2 * macs * sdf_pts, "mlp_bwd": 2 * 2 * macs * bwd_pts,         # one-pass: data + weights
+                          "mlp_bwd_data": 2 * macs * bwd_pts, "mlp_bwd_weights": 2 * macs * bwd_pts,
+                          "mlp_bwd_bwd": 2 * 2 * macs * base_pts}                                   # masked forward + weight GEMM
+        launches = lambda k: max(1.0, calls.get(k, 0) / args.steps)
+        alg = {k: v / launches(k) for k, v in alg_step.items() if calls.get(k)}
+        flops = {k: v / launches(k) for k, v in flops_step.items() if calls.get(k)}
+        # time per step of an operator = MEAN launch x launches per step (the launches of an SDF operator differ 10x in size: the
+        # 32768-ray batch against ~0.45 M splat samples; `alg` is the per-launch mean to match); medians are reported too
         per_step = {k: kern_mean.get(k, 0.0) * calls.get(k, 0) / args.steps for k in list(alg) + list(flops)}
         dom = max(per_step, key=lambda k: per_step[k])
         dur_ms = kern_mean.get(dom, float("nan"))
@@ -455,13 +473,20 @@ def main():
             traffic = json.load(open(tpath)).get(args.workload, {}).get(dom)
         vpath = os.path.join(ROOT, "profiles", "valu_insts.json")
         valu = json.load(open(vpath)).get(args.workload) if os.path.exists(vpath) else None
-        terms = ("0.8 L1 + 0.2 D-SSIM on colour, 1e-6 N(0,1) op-level gradients on depth/alpha/normal/median" +
-                 ("" if args.no_sdf else "; per-ray SDF batch: BCE sdf_loss + 0.1 eikonal (numerical gradient, 6-point stencil) on 32768 points"
-                  "; GS<->SDF: 1e-3 gs_sdf_loss on the visible splats' samples (visibility > 0.1, occupancy-valid)" +
-                  ("" if state["light"] else " + 0.1 eikonal on the same samples (numerical gradient: 6 more encoder/decoder "
-                   "evaluations per sample, neural_mapping.cpp:448-451)") + "; decoder_implementation 1 (fused MLP; the reference forces "
-                  "numerical_grad with it, params.cpp:396-399)") +
-                 ("" if state["light"] else "; per-iteration update_state (neural_gaussian.cpp:626-680)") + "; fused Adam on all parameters")
+        terms = ("0.8 L1 + 0.2 D-SSIM on colour" +
+                 ("; 0.01 x depth->normal consistency (neural_mapping.cpp:243-266); 0.05 x isotropic regulariser of the visible splats (:268-276)"
+                  if ref_terms else "; 1e-6 N(0,1) op-level gradients on depth/alpha/normal/median (--step-terms round2)"))
+        if not args.no_sdf and analytic:
+            terms += ("; SDF configuration = the reference's DEFAULT (decoder_implementation 0: biased 5-layer decoder; numerical_grad 0): per-ray "
+                      "batch (32768 points): sdf_loss + 0.1 eikonal on the ANALYTIC gradient (double backward through decoder and hash grid) "
+                      "+ 0.1 align |analytic - numerical.detach()| (6 forward-only stencil evaluations per point); GS<->SDF: 1e-3 gs_sdf_loss "
+                      "on the visible splats' samples (visibility > 0.1, occupancy-valid) + the same eikonal / align regularisers at "
+                      "samples.detach() (neural_mapping.cpp:106-136, 420-462)")
+        elif not args.no_sdf:
+            terms += ("; SDF configuration = decoder_implementation 1 (bias-free FullyFusedMLP; the reference forces numerical_grad with it, "
+                      "params.cpp:396-399): per-ray batch: sdf_loss + 0.1 eikonal on the numerical gradient (6-point stencil, all 7 rows "
+                      "differentiated); GS<->SDF: 1e-3 gs_sdf_loss + 0.1 eikonal (numerical) at the visible splats' samples")
+        terms += "; per-iteration update_state" + (" + prune_nan test" if ref_terms else "") + " (neural_gaussian.cpp:626-680, 907-916); fused Adam on all parameters"
         split_mlp_cfg = not args.no_sdf and os.environ.get("GSDF_MLP_MFMA", "bf16x3")[:1] not in "fF"
         out = {
             "metric": "train iters/sec (splat raster + SDF fwd+bwd), 1M Gaussians @1080p" if not args.no_sdf
@@ -472,8 +497,9 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.workload}: {N} random Gaussians, {W}x{H}, sh_degree {deg}, 1 view/GPU/step; means over the timed "
                                    f"steps: M={M:.0f} I={I:.0f} L={I / T:.0f}" + ("" if args.no_sdf else f"; hash-grid SDF (2^19 x16x2, fused "
-                                   f"64-wide MLP) evaluated at {sdf_pts:.0f} points/step = 7 x 32768 ray + {stencil} x {n_gs:.0f} splat samples"),
-                       "step": ("LIGHT (--light-step): " if state["light"] else "reference joint iteration (neural_mapping.cpp:400-486): ") + terms,
+                                   f"64-wide MLP) evaluated at {sdf_pts:.0f} points/step = 7 x (32768 ray + {n_gs:.0f} splat samples)"),
+                       "sdf_config": None if args.no_sdf else args.sdf_config,
+                       "step": "reference joint iteration (neural_mapping.cpp:400-486): " + terms,
                        "parallelism": f"view-parallel x{world}" if world > 1 else "single GPU",
                        "splat_order": ("Morton order of the centres (trainer.morton_order; kept by the trainer at initialisation and at "
                                        "refinement steps)" if args.splat_order == "morton" else "as given (random)"),
@@ -504,19 +530,35 @@ def main():
                                                           for k, v in valu.items() if kern_mean.get(k)}),
                              step_B_splat_bytes=int(b_splat), step_hbm_frac=b_splat / (elapsed / args.steps) / 8e12),
             "params_finite": bool(torch.isfinite(params.flat).all()) and all(bool(torch.isfinite(g.flat).all()) for g in groups),
+            "nan_splats_seen_by_prune_test": int(nan_total.item()),
             "hbm_gb": {"allocated_peak": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
                        "reserved": round(torch.cuda.memory_reserved() / 2 ** 30, 2)},
             "kernel_ms": kern_all, "kernel_ms_note": "median launch duration per operator over 10 extra steps after the timed region",
         }
-        if secondary:
-            out["secondary"] = secondary
-            # second clearly named line: the same joint iteration as neural_mapping_node would run it linked against the drop-in
-            # submodules with zero source edits (eager losses / Adam / numerical get_gradient around the drop-in operators)
+        if world == 1 and not args.no_sdf and not args.no_secondary:
+            # (1) the OTHER SDF configuration, same step otherwise: a clearly named line of its own (own roofline), run as a
+            #     subprocess of this script so that nothing of this run's allocator / stream state leaks into it
+            import subprocess
+            other = "tcnn" if analytic else "default"
+            try:
+                cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", str(min(args.steps, 40)), "--warmup", str(args.warmup),
+                       "--workload", args.workload, "--sdf-config", other, "--step-terms", args.step_terms, "--splat-order", args.splat_order,
+                       "--no-secondary", "--no-cpu-baseline"] + (["--no-overlap"] if args.no_overlap else [])
+                release_streams()
+                r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+                j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+                out["other_sdf_config"] = {"sdf_config": other, "value": j["value"], "unit": "iters/s", "ms_per_step": j["ms_per_step"],
+                                           "steps": j["steps"], "step_ms_hip_events": j["step_ms_hip_events"], "step": j["config"]["step"],
+                                           "workload": j["config"]["workload"], "roofline": j["roofline"], "kernel_ms": j["kernel_ms"]}
+            except Exception as e:      # never let an extra line take the headline down
+                out["other_sdf_config"] = {"sdf_config": other, "error": repr(e)[:300]}
+            # (2) the joint iteration as neural_mapping_node would run it linked against the drop-in submodules with zero source
+            #     edits (eager losses / Adam / numerical get_gradient around the drop-in operators; tcnn configuration)
             try:
                 out["reference_loop_zero_edits"] = reference_loop(args, sc, views, K, ug6, target, N, W, H, deg, dev)
-            except Exception as e:      # never let the extra line take the headline down
+            except Exception as e:
                 out["reference_loop_zero_edits"] = {"error": repr(e)[:300]}
-            # third line: the same joint iteration in C++/libtorch (gsdf_extras::JointIteration over libgsdf_torch.so, one stream)
+            # (3) the joint iteration in C++/libtorch (gsdf_extras::JointIteration over libgsdf_torch.so)
             try:
                 import copy
                 a2 = copy.copy(args)
@@ -534,41 +576,66 @@ def main():
 
 def cpp_step(args, sc, views, K, ug6, target, N, W, H, deg, dev):
     """gsdf_extras::JointIteration (gs-sdf_amd/host/src/joint_step.cpp) on the bench's scene: the joint iteration in C++/libtorch,
-    same initial parameters, same views, ray batches and op-level gradients as the Python step, one HIP stream."""
+    same configuration (--sdf-config, --step-terms), initial parameters, views and ray batches as the Python step."""
     import gs_sdf_amd.hostlib as hostlib
     import gs_sdf_amd.sdf as sdfm
-    from gs_sdf_amd.trainer import SplatParams
+    from gs_sdf_amd.trainer import SplatParams, morton_order
     host = hostlib.load()
-    from gs_sdf_amd.trainer import morton_order
+    analytic, ref_terms = args.sdf_config == "default", args.step_terms == "reference"
     params = SplatParams.from_scene(sc, dev, morton_order(sc["means"]) if args.splat_order == "morton" else None)
-    lm = sdfm.LocalMap([0.0, 0.0, 5.5], 16.0, bce_sigma=0.02, decoder_implementation=1, device=dev, seed=5)
-    enc, dec = host.TCNNEncoding(16, 2, 19, 32, 2.0), host.TCNNNetwork(32, 2, 64, 3)
+    lm = sdfm.LocalMap([0.0, 0.0, 5.5], 16.0, bce_sigma=0.02, decoder_implementation=0 if analytic else 1, device=dev, seed=5)
+    enc = host.TCNNEncoding(16, 2, 19, 32, 2.0)
+    dec = host.TCNNNetwork(32, 2, 64, 4 if analytic else 3, analytic)       # default: the torch decoder's topology (biases, 4 hidden matmuls)
     enc.params_, dec.params_ = lm.encoder.params_.detach().clone(), lm.decoder.params_.detach().clone()
+    if analytic:
+        dec.biases_ = lm.decoder.biases_.detach().clone()
     fields = [params.views[k].detach().clone() for k in ("offsets", "scaling", "quaternion", "opacity", "features_dc", "features_rest")]
     two = not args.no_overlap
-    ji = host.JointIteration(params.anchors, fields, enc, dec, [0.0, 0.0, 5.5], 16.0, 0.02, 8, W, H, deg, two)   # level 8: 1/16 m leaves in 16 m
+    ji = host.JointIteration(params.anchors, fields, enc, dec, [0.0, 0.0, 5.5], 16.0, 0.02, 8, W, H, deg, two, analytic, ref_terms)   # level 8: 1/16 m leaves in 16 m
     gq = torch.Generator().manual_seed(4)
     pool = [((torch.rand(32768, 3, generator=gq) - 0.5) * 14.0 + torch.tensor([0.0, 0.0, 5.5])).to(dev) for _ in range(8)]
     ray_sdf = [(torch.randn(32768, 1, generator=gq) * 0.02).to(dev) for _ in range(8)]
-    up = [ug6[k] for k in ("v_render_depths", "v_render_alphas", "v_render_normals", "v_render_median")]
+    up = [] if ref_terms else [ug6[k] for k in ("v_render_depths", "v_render_alphas", "v_render_normals", "v_render_median")]
+    Kh = [float(v) for v in (sc["K"][0, 0, 0], sc["K"][0, 1, 1], sc["K"][0, 0, 2], sc["K"][0, 1, 2])]
+    cams = [Kh + [float(v) for v in torch.linalg.inv(vw.double())[:3, :4].reshape(-1)] for vw in views.cpu()]      # host values, known ahead
+    nv = views.shape[0]
     if args.dump_grads:
-        sizes = ji.step(views[0][None], K, target, pool[0], ray_sdf[0], up, False)
+        sizes = ji.step(views[0][None], K, target, pool[0], ray_sdf[0], up, False, cams[0])
         torch.cuda.synchronize()
         torch.save({"splat": ji.splat_flat_grad().cpu(), "sdf": [ji.sdf_flat_grad().cpu()], "sizes": dict(sizes)}, args.dump_grads)
         return {"dumped": args.dump_grads}
     n_sdf = []
     for i in range(args.warmup):
-        ji.step(views[i % views.shape[0]][None], K, target, pool[i % 8], ray_sdf[i % 8], up, True)
+        ji.step(views[i % nv][None], K, target, pool[i % 8], ray_sdf[i % 8], up, True, cams[i % nv])
     torch.cuda.synchronize()
+    t_w, i = time.perf_counter(), args.warmup
+    while time.perf_counter() - t_w < float(os.environ.get("GSDF_BENCH_MIN_WARM_S", "1.5")) and i < args.warmup + 300:     # steady state, as the Python step
+        ji.step(views[i % nv][None], K, target, pool[i % 8], ray_sdf[i % 8], up, True, cams[i % nv])
+        i += 1
+        if i % 10 == 0:
+            torch.cuda.synchronize()
+    torch.cuda.synchronize()
+    first = i
+    marks = []
     t0 = time.perf_counter()
-    for i in range(args.warmup, args.warmup + args.steps):
-        n_sdf.append(ji.step(views[i % views.shape[0]][None], K, target, pool[i % 8], ray_sdf[i % 8], up, True)["n_gs_sdf"])
+    for i in range(first, first + args.steps):
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        marks.append(ev)
+        n_sdf.append(ji.step(views[i % nv][None], K, target, pool[i % 8], ray_sdf[i % 8], up, True, cams[i % nv])["n_gs_sdf"])
+    ev = torch.cuda.Event(enable_timing=True)
+    ev.record()
+    marks.append(ev)
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
-    return {"metric": "train iters/sec, the joint iteration in C++/libtorch (gsdf_extras::JointIteration, " + ("two streams" if two else "one stream") + "; NOT the headline)",
+    gaps = sorted(a.elapsed_time(b) for a, b in zip(marks[:-1], marks[1:]))
+    return {"metric": "train iters/sec, the joint iteration in C++/libtorch (gsdf_extras::JointIteration, " + ("two streams" if two else "one stream") + ")",
             "value": args.steps / el, "unit": "iters/s", "ms_per_step": el / args.steps * 1e3, "steps": args.steps, "warmup": args.warmup,
-            "n_gpus": 1, "params_finite": bool(torch.isfinite(ji.splat_flat()).all() and torch.isfinite(ji.sdf_flat()).all()),
-            "config": {"workload": args.workload, "sdf_points_per_step": 7 * 32768 + 7 * sum(n_sdf) / max(1, len(n_sdf))}}
+            "internal_warmup_steps": first - args.warmup, "n_gpus": 1, "sdf_config": args.sdf_config, "step_terms": args.step_terms,
+            "step_ms_hip_events": {"p10": gaps[len(gaps) // 10], "p50": gaps[len(gaps) // 2], "p90": gaps[(len(gaps) * 9) // 10], "max": gaps[-1]},
+            "params_finite": bool(torch.isfinite(ji.splat_flat()).all() and torch.isfinite(ji.sdf_flat()).all()),
+            "nan_splats_seen_by_prune_test": int(ji.nan_splats_seen().item()),
+            "config": {"workload": args.workload, "sdf_points_per_step": 7 * (32768 + sum(n_sdf) / max(1, len(n_sdf)))}}
 
 
 def reference_loop(args, sc, views, K, ug6, target, N, W, H, deg, dev):

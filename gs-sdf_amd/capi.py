@@ -53,7 +53,7 @@ _SIGS = {
     "gsdf_mlp_bwd_bwd_ws_bytes": (_sz, [_i64, _i32]),
     "gsdf_mlp_bwd_bwd": (C.c_int, [_i64, _i32] + [_vp] * 10),
     "gsdf_hashgrid_bwd_binned2": (C.c_int, [_i64, _i32, _i32, _i32, _i32, _f32] + [_vp] * 6 + [_sz, _vp]),
-    "gsdf_sdf_analytic_loss": (C.c_int, [_i64, _i32, _i32, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp] + [_f32] * 6 + [_vp] * 5),
+    "gsdf_sdf_analytic_loss": (C.c_int, [_i64, _i64, _i32, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp] + [_f32] * 7 + [_vp] * 5),
     "gsdf_l1_dssim_fwd": (C.c_int, [_i32, _i32] + [_vp] * 6),
     "gsdf_l1_dssim_bwd": (C.c_int, [_i32, _i32] + [_vp] * 5 + [_f32, _f32, _vp, _vp]),
     "gsdf_normal_consistency_fwd": (C.c_int, [_i32, _i32] + [_vp] * 7),
@@ -74,6 +74,9 @@ _SIGS = {
     "gsdf_mc_emit": (C.c_int, [_i32, _i32, _i32, _i32, _vp, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gsdf_splat_activations_fwd": (C.c_int, [_i64] + [_vp] * 8),
     "gsdf_splat_activations_bwd": (C.c_int, [_i64] + [_vp] * 9),
+    "gsdf_isotropic_loss_fwd": (C.c_int, [_i64, _vp, _vp, _vp, _vp]),
+    "gsdf_isotropic_loss_bwd": (C.c_int, [_i64, _vp, _vp, _vp, _vp, _vp]),
+    "gsdf_nan_rows": (C.c_int, [_i64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gsdf_densify_stats": (C.c_int, [_i64, _i64, _i32, _i32, _i32] + [_vp] * 9),
     "gsdf_flat_rows_gather": (C.c_int, [_i32, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp]),
     "gsdf_stream_set_xcds": (C.c_int, [_vp, _i32]),

@@ -38,6 +38,56 @@ __global__ void __launch_bounds__(256)
   }
 }
 
+// ---- isotropic regulariser of the visible splats (neural_mapping.cpp:268-276): scale = get_scale()[gaussian_ids][:, 0:2];
+// loss = (scale - scale.mean(-1, keepdim)).abs().mean() = sum_m |s_u - s_v| / (2 M).  One launch each way instead of ~12.
+__global__ void __launch_bounds__(256)
+    isotropic_fwd_kernel(int64_t M, const float *__restrict__ scales, const int64_t *__restrict__ ids, float inv_2m,
+                         float *__restrict__ loss) {
+  __shared__ float s_part[4];
+  float c = 0.f;
+  // capped grid + grid-stride loop: atomics on ONE address serialise (~88 per microsecond)
+  for (int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x; m < M; m += (int64_t)gridDim.x * 256) {
+    const int64_t g = ids[m];
+    c += fabsf(scales[3 * g] - scales[3 * g + 1]) * inv_2m;
+  }
+  const float ws = wave_sum_to_lane63(c);
+  if ((threadIdx.x & 63) == 63) s_part[threadIdx.x >> 6] = ws;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float t = (s_part[0] + s_part[1]) + (s_part[2] + s_part[3]);
+    if (t != 0.f) atomicAdd(loss, t);
+  }
+}
+
+__global__ void __launch_bounds__(256)
+    isotropic_bwd_kernel(int64_t M, const float *__restrict__ scales, const int64_t *__restrict__ ids, float inv_2m,
+                         const float *__restrict__ v_loss, float *__restrict__ v_scales) {
+  const int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (m >= M) return;
+  const int64_t g = ids[m];
+  const float d = scales[3 * g] - scales[3 * g + 1];
+  const float s = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);      // torch's abs backward: sign(0) = 0
+  const float v = s * inv_2m * v_loss[0];
+  if (v != 0.f) { atomicAdd(v_scales + 3 * g, v); atomicAdd(v_scales + 3 * g + 1, -v); }   // ids repeat when C > 1
+}
+
+// ---- NeuralGS::prune_nan_gs's test (neural_gaussian.cpp:907-916): rows with a NaN in offsets / scaling / quaternion
+__global__ void __launch_bounds__(256)
+    nan_rows_kernel(int64_t n, const float *__restrict__ offsets, const float *__restrict__ scaling,
+                    const float *__restrict__ quaternion, int32_t *__restrict__ count, uint8_t *__restrict__ mask) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  bool bad = false;
+  if (i < n) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) bad |= (offsets[3 * i + k] != offsets[3 * i + k]) | (scaling[3 * i + k] != scaling[3 * i + k]);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) bad |= quaternion[4 * i + k] != quaternion[4 * i + k];
+    if (mask != nullptr) mask[i] = bad ? 1 : 0;
+  }
+  const unsigned long long b = __ballot(bad);
+  if ((threadIdx.x & 63) == 0 && b) atomicAdd(count, (int32_t)__popcll(b));
+}
+
 }  // namespace gsdf
 
 using namespace gsdf;
@@ -65,5 +115,39 @@ extern "C" int gsdf_splat_activations_bwd(int64_t n, const float *scales, const 
   splat_act_bwd_kernel<<<(unsigned)((n + 255) / 256), 256, 0, stream>>>(n, scales, opacities, v_xyz, v_scales, v_opacities,
                                                                          g_offsets, g_log_scales, g_logit_opacities);
   GSDF_CHECK_LAUNCH("splat_act_bwd_kernel");
+  return GSDF_OK;
+}
+
+extern "C" int gsdf_isotropic_loss_fwd(int64_t M, const float *scales, const int64_t *gaussian_ids, float *loss, gsdf_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  GSDF_REQUIRE(M >= 0 && loss, "isotropic_loss_fwd: bad arguments");
+  GSDF_HIP(hipMemsetAsync(loss, 0, 4, stream), "isotropic_loss memset");
+  if (M == 0) return GSDF_OK;
+  GSDF_REQUIRE(scales && gaussian_ids, "isotropic_loss_fwd: null buffer");
+  const int64_t blocks = (M + 255) / 256;
+  isotropic_fwd_kernel<<<(unsigned)(blocks > 512 ? 512 : blocks), 256, 0, stream>>>(M, scales, gaussian_ids, 0.5f / (float)M, loss);
+  GSDF_CHECK_LAUNCH("isotropic_fwd_kernel");
+  return GSDF_OK;
+}
+
+extern "C" int gsdf_isotropic_loss_bwd(int64_t M, const float *scales, const int64_t *gaussian_ids, const float *v_loss, float *v_scales,
+                                       gsdf_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (M == 0) return GSDF_OK;
+  GSDF_REQUIRE(M > 0 && scales && gaussian_ids && v_loss && v_scales, "isotropic_loss_bwd: bad arguments");
+  isotropic_bwd_kernel<<<(unsigned)((M + 255) / 256), 256, 0, stream>>>(M, scales, gaussian_ids, 0.5f / (float)M, v_loss, v_scales);
+  GSDF_CHECK_LAUNCH("isotropic_bwd_kernel");
+  return GSDF_OK;
+}
+
+extern "C" int gsdf_nan_rows(int64_t n, const float *offsets, const float *scaling, const float *quaternion, int32_t *count,
+                             uint8_t *mask, gsdf_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  GSDF_REQUIRE(n >= 0 && count, "nan_rows: bad arguments");
+  GSDF_HIP(hipMemsetAsync(count, 0, 4, stream), "nan_rows memset");
+  if (n == 0) return GSDF_OK;
+  GSDF_REQUIRE(offsets && scaling && quaternion, "nan_rows: null buffer");
+  nan_rows_kernel<<<(unsigned)((n + 255) / 256), 256, 0, stream>>>(n, offsets, scaling, quaternion, count, mask);
+  GSDF_CHECK_LAUNCH("nan_rows_kernel");
   return GSDF_OK;
 }

@@ -630,7 +630,13 @@ template <int NL, bool BIAS>
 static int launch_bwd_split(int64_t B, const MlpDesc &d, const SplitLds &sl, int lds_w4, size_t lds, const float *W, const float *in,
                             const float *acts, const float *v_out, float *v_in, float *v_W, float *v_b, hipStream_t stream) {
   GSDF_HIP(hipFuncSetAttribute((const void *)mlp_bwd_split_kernel<NL, BIAS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "mlp_bwd_split attr");
-  mlp_bwd_split_kernel<NL, BIAS><<<split_grid(B, SPLIT_BWD_THREADS / 64), SPLIT_BWD_THREADS, lds, stream>>>(B, d, sl, lds_w4, W, in, acts, v_out, v_in, v_W, v_b);
+  // every wave leaves through one round of atomics over ALL weight gradients (~14.5 K): a wave must own enough 32-point tiles
+  // to amortise it (measured: 32768 points on 256 workgroups = 1 tile per wave took 0.37 ms, all of it the flush)
+  constexpr int waves = SPLIT_BWD_THREADS / 64, min_tiles_per_wave = 8;
+  unsigned grid = split_grid(B, waves);
+  const int64_t want = ((B + 31) / 32 + (int64_t)waves * min_tiles_per_wave - 1) / ((int64_t)waves * min_tiles_per_wave);
+  if ((int64_t)grid > want) grid = (unsigned)(want < 1 ? 1 : want);
+  mlp_bwd_split_kernel<NL, BIAS><<<grid, SPLIT_BWD_THREADS, lds, stream>>>(B, d, sl, lds_w4, W, in, acts, v_out, v_in, v_W, v_b);
   GSDF_CHECK_LAUNCH("mlp_bwd_split_kernel");
   return 1;
 }

@@ -32,6 +32,19 @@ __global__ void __launch_bounds__(256)
 
 __device__ __forceinline__ float sigmoidf(float x) { return 1.0f / (1.0f + __expf(-x)); }
 
+// 256-thread block sum -> ONE atomic per block on the loss value (atomics on one address serialise at ~88 per microsecond:
+// one per wave cost 0.1 ms at 4.5e5 points)
+__device__ __forceinline__ void block_sum_to_loss(float contrib, float *__restrict__ loss) {
+  __shared__ float s_part[4];
+  const float ws = wave_sum_to_lane63(contrib);
+  if ((threadIdx.x & 63) == 63) s_part[threadIdx.x >> 6] = ws;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float t = (s_part[0] + s_part[1]) + (s_part[2] + s_part[3]);
+    if (t != 0.f) atomicAdd(loss, t);
+  }
+}
+
 __global__ void __launch_bounds__(256)
     sdf_ray_loss_kernel(int64_t n, int stencil, const float *__restrict__ attr, int ld, const float *__restrict__ gt,
                         float bce_isigma, float delta, float w_eik, float *__restrict__ loss,
@@ -79,9 +92,7 @@ __global__ void __launch_bounds__(256)
       }
     }
   }
-  // block sum -> one atomic per wave
-  const float ws = wave_sum_to_lane63(contrib);
-  if ((threadIdx.x & 63) == 63 && ws != 0.f) atomicAdd(loss, ws);
+  block_sum_to_loss(contrib, loss);
 }
 
 // loss::gs_sdf_loss (/root/reference/include/optimizer/loss.cpp:7-11): 0.5 * sum_i w_i * sdf_i^2, with the row gather of
@@ -122,8 +133,7 @@ __global__ void __launch_bounds__(256)
       }
     }
   }
-  const float ws = wave_sum_to_lane63(contrib);
-  if ((threadIdx.x & 63) == 63 && ws != 0.f) atomicAdd(loss, ws);
+  block_sum_to_loss(contrib, loss);
 }
 
 
@@ -139,17 +149,21 @@ __global__ void __launch_bounds__(256)
 // (gsdf_mlp_bwd_bwd) and of the encoder (gsdf_hashgrid_bwd_binned2) consume.
 template <int NF>
 __global__ void __launch_bounds__(256)
-    sdf_analytic_loss_kernel(int64_t n, int mode, int stencil, const float *__restrict__ attr, int ld, const float *__restrict__ g0,
+    sdf_analytic_loss_kernel(int64_t n, int64_t n_ray, int stencil, const float *__restrict__ attr, int ld, const float *__restrict__ g0,
                              const float *__restrict__ jac, const float *__restrict__ gt, const float *__restrict__ weights,
-                             const int64_t *__restrict__ ids, float bce_isigma, float scale, float map_size_inv, float delta,
+                             const int64_t *__restrict__ ids, float bce_isigma, float w_sdf, float w_gs, float map_size_inv, float delta,
                              float w_eik, float w_align, float *__restrict__ loss, float *__restrict__ v_attr,
                              float *__restrict__ vv_x, float *__restrict__ u0) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  __shared__ float s_part[4];
   float contrib = 0.f;
-  if (i < n) {
-    const float inv_n = 1.0f / (float)n;
+  // capped grid + grid-stride loop: the value is ONE address, and atomics on one line serialise at ~88 per microsecond
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    // rows [0, n_ray): per-ray batch (mean over n_ray); rows [n_ray, n): splat samples (mean over n - n_ray): the two
+    // sdf_regularization calls of the iteration normalise separately (neural_mapping.cpp:183-186, :448-451)
+    const bool ray = i < n_ray;
+    const float inv_n = 1.0f / (float)(ray ? n_ray : n - n_ray);
     const float s = attr[i * ld];
-    if (mode == 0) {
+    if (ray) {
       const float raw = attr[i * ld + 1], g = gt[i];
       const float br = 100.0f * raw;
       const float sp = br > 20.0f ? raw : log1pf(expf(br)) * 0.01f;
@@ -164,14 +178,15 @@ __global__ void __launch_bounds__(256)
       const float bce = (1.0f - t) * x + fmaxf(-x, 0.0f) + log1pf(expf(-fabsf(x)));
       const float dx = sigmoidf(x) - t, dt = -x;
       const float d_is = dx * (-s) + dt * dt_du * (-g);
-      contrib = scale * bce * inv_n;
-      v_attr[i * ld] = scale * dx * (-is) * inv_n;
-      v_attr[i * ld + 1] = scale * d_is * dis_draw * inv_n;
+      contrib += w_sdf * bce * inv_n;
+      v_attr[i * ld] = w_sdf * dx * (-is) * inv_n;
+      v_attr[i * ld + 1] = w_sdf * d_is * dis_draw * inv_n;
       for (int c = 2; c < ld; ++c) v_attr[i * ld + c] = 0.f;
     } else {
-      const float w = weights[ids != nullptr ? ids[i] : i];
-      contrib = 0.5f * scale * w * s * s;
-      v_attr[i * ld] = scale * w * s;
+      const int64_t j = i - n_ray;
+      const float w = weights[ids != nullptr ? ids[j] : j];
+      contrib += 0.5f * w_gs * w * s * s;
+      v_attr[i * ld] = w_gs * w * s;
       for (int c = 1; c < ld; ++c) v_attr[i * ld + c] = 0.f;
     }
     // analytic gradient in world units
@@ -210,7 +225,12 @@ __global__ void __launch_bounds__(256)
     for (int f = 0; f < NF; ++f) uo[f] = fmaf(J[3 * f + 2], vz, fmaf(J[3 * f + 1], vy, J[3 * f] * vx));
   }
   const float ws = wave_sum_to_lane63(contrib);
-  if ((threadIdx.x & 63) == 63 && ws != 0.f) atomicAdd(loss, ws);
+  if ((threadIdx.x & 63) == 63) s_part[threadIdx.x >> 6] = ws;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float t = (s_part[0] + s_part[1]) + (s_part[2] + s_part[3]);
+    if (t != 0.f) atomicAdd(loss, t);
+  }
 }
 
 }  // namespace gsdf
@@ -263,21 +283,22 @@ extern "C" int gsdf_gs_sdf_loss(int64_t n, const float *attr, int ld, const floa
   return gsdf_gs_sdf_eik_loss(n, 0, attr, ld, weights, ids, scale, 0.f, 0.f, loss, v_attr, stream);
 }
 
-extern "C" int gsdf_sdf_analytic_loss(int64_t n, int mode, int stencil, const float *attr, int ld, const float *g0, int n_feat,
+extern "C" int gsdf_sdf_analytic_loss(int64_t n, int64_t n_ray, int stencil, const float *attr, int ld, const float *g0, int n_feat,
                                       const float *jac, const float *gt_sdf, const float *weights, const int64_t *ids,
-                                      float bce_isigma, float scale, float map_size_inv, float delta, float w_eik, float w_align,
-                                      float *loss, float *v_attr, float *vv_x, float *u0, gsdf_stream_t stream_) {
+                                      float bce_isigma, float w_sdf, float w_gs, float map_size_inv, float delta, float w_eik,
+                                      float w_align, float *loss, float *v_attr, float *vv_x, float *u0, gsdf_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  GSDF_REQUIRE(n >= 0 && (mode == 0 || mode == 1) && loss, "sdf_analytic_loss: bad arguments");
+  GSDF_REQUIRE(n >= 0 && n_ray >= 0 && n_ray <= n && loss, "sdf_analytic_loss: bad arguments");
   GSDF_REQUIRE(n_feat == 32, "sdf_analytic_loss: %d encoder features unsupported (32: 16 levels x 2, as the reference configures)", n_feat);
-  GSDF_REQUIRE(ld >= (mode == 0 ? 2 : 1), "sdf_analytic_loss: decoder output too narrow");
+  GSDF_REQUIRE(ld >= (n_ray > 0 ? 2 : 1), "sdf_analytic_loss: decoder output too narrow");
   GSDF_REQUIRE(!(stencil && w_align != 0.f) || delta > 0.f, "sdf_analytic_loss: delta must be positive");
   GSDF_HIP(hipMemsetAsync(loss, 0, 4, stream), "sdf_analytic_loss memset");
   if (n == 0) return GSDF_OK;
-  GSDF_REQUIRE(attr && g0 && jac && v_attr && vv_x && u0 && (mode == 0 ? gt_sdf != nullptr : weights != nullptr), "sdf_analytic_loss: null buffer");
-  sdf_analytic_loss_kernel<32><<<(unsigned)((n + 255) / 256), 256, 0, stream>>>(n, mode, stencil, attr, ld, g0, jac, gt_sdf, weights, ids,
-                                                                                bce_isigma, scale, map_size_inv, delta, w_eik, w_align,
-                                                                                loss, v_attr, vv_x, u0);
+  GSDF_REQUIRE(attr && g0 && jac && v_attr && vv_x && u0 && (n_ray == 0 || gt_sdf) && (n_ray == n || weights), "sdf_analytic_loss: null buffer");
+  const int64_t blocks = (n + 255) / 256;
+  sdf_analytic_loss_kernel<32><<<(unsigned)(blocks > 1024 ? 1024 : blocks), 256, 0, stream>>>(n, n_ray, stencil, attr, ld, g0, jac, gt_sdf, weights,
+                                                                                           ids, bce_isigma, w_sdf, w_gs, map_size_inv, delta,
+                                                                                           w_eik, w_align, loss, v_attr, vv_x, u0);
   GSDF_CHECK_LAUNCH("sdf_analytic_loss_kernel");
   return GSDF_OK;
 }

@@ -24,6 +24,8 @@ struct TCNNNetwork;
 
 namespace gsdf_extras {
 
+struct StreamGate;   // internal (src/stream_gate.h): "the tensor produced on another stream is complete"
+
 // [H,W,3] x [H,W,3] -> scalar; differentiable w.r.t. render
 torch::Tensor l1_dssim_loss(const torch::Tensor &render, const torch::Tensor &gt, double rgb_weight = 0.8, double dssim_weight = 0.2);
 
@@ -47,10 +49,35 @@ torch::Tensor gs_sdf_eik_loss(const torch::Tensor &attr, const torch::Tensor &we
 // `weights` = samples_weights * visibilities, [M] or [M,1].  Bias-free decoder (TCNNNetwork).
 // `samples_grad_ready` (optional, internal type): recorded on the backward's stream once d loss / d samples has been issued, before
 // the table scatter — lets a caller on another stream consume that gradient without waiting for the scatter (JointIteration).
-struct StreamGate;
 torch::Tensor gs_sdf_coupling(const torch::Tensor &samples, const torch::Tensor &ids, const torch::Tensor &weights, ::TCNNEncoding &enc,
                               ::TCNNNetwork &dec, const std::vector<float> &map_origin, double map_size_inv, double scale, double delta,
                               double w_eik, torch::Tensor table_grad, torch::Tensor decoder_grad, StreamGate *samples_grad_ready = nullptr);
+
+// ---- the reference's DEFAULT SDF configuration (config/base.yaml:12-13: decoder_implementation 0, numerical_grad 0) -----------
+// The SDF work of one joint iteration as ONE autograd node (Python mirror: gs_sdf_amd/sdf.py _SdfBatchAnalytic): one batch holds
+//   rows [0, n_ray)  the per-ray batch:  w_sdf * loss::sdf_loss(get_sdf(ray_xyz), gt_sdf)                       neural_mapping.cpp:165-170
+//   rows [n_ray, n)  samples[ids]:       w_gs * loss::gs_sdf_loss(get_sdf(samples[ids]), weights[ids])          :436-457
+//   each set: + w_eik * eikonal_loss(ANALYTIC gradient, autograd::grad(create_graph = true), local_map.cpp:151-172; the splat samples
+//             detached, :448-451) + w_align * mean |analytic - numerical.detach()| (6 forward-only stencil rows, :126-134).
+// Either part may be empty (undefined tensor).  d loss / d samples is returned to autograd; the encoder's table gradient and the decoder's
+// weight / bias gradients are ACCUMULATED IN PLACE into table_grad / decoder_grad / bias_grad (views of the flat gradient buffer):
+// one-pass decoder backward, decoder double backward (gsdf_mlp_bwd_bwd), ONE binned scatter carrying the first- and second-order
+// table gradient (gsdf_hashgrid_bwd_binned2).  dec may carry biases (config "bias": true = the torch decoder's topology).
+torch::Tensor joint_sdf_loss_analytic(const torch::Tensor &ray_xyz, const torch::Tensor &gt_sdf, const torch::Tensor &samples,
+                                      const torch::Tensor &ids, const torch::Tensor &weights, ::TCNNEncoding &enc, ::TCNNNetwork &dec,
+                                      const std::vector<float> &map_origin, double map_size_inv, double bce_isigma, double w_sdf, double w_gs,
+                                      double delta, double w_eik, double w_align, torch::Tensor table_grad, torch::Tensor decoder_grad,
+                                      torch::Tensor bias_grad, StreamGate *samples_grad_ready = nullptr);
+
+// render_normal_weight's term (neural_mapping.cpp:243-266): mean(alpha^2 - nan_to_num((depth_to_normal(depth) * alpha) . render_normal)),
+// alpha detached.  depth [H,W,1], alpha [H,W,1], render_normal [H,W,3] (world); intrinsics {fx, fy, cx, cy} and the camera->world pose
+// (row-major [3,4]) as HOST values (the trainer knows its poses: no device->host copy per iteration).
+torch::Tensor normal_consistency_loss(const torch::Tensor &depth, const torch::Tensor &alpha, const torch::Tensor &render_normal,
+                                      const std::vector<float> &intrinsics4, const std::vector<float> &pose_c2w);
+// isotropic_weight's term (neural_mapping.cpp:268-276) on the activated scales [N,3] of the visible splats gaussian_ids [M]
+torch::Tensor isotropic_loss(const torch::Tensor &scales, const torch::Tensor &gaussian_ids);
+// NeuralGS::prune_nan_gs's test (neural_gaussian.cpp:907-916): int32 device scalar [1] = splats with a NaN; mask (optional out) bool [N]
+torch::Tensor nan_rows(const torch::Tensor &offsets, const torch::Tensor &scaling, const torch::Tensor &quaternion, torch::Tensor *mask = nullptr);
 
 // state: "grad2d","count","vis"[,"radii"] created on first use; info as NeuralGS::render returns it
 void update_state(std::map<std::string, torch::Tensor> &state, const torch::Tensor &densify_grad, const torch::Tensor &gaussian_ids,
@@ -90,6 +117,15 @@ struct JointConfig {
   float near_plane = 0.05f, far_plane = 300.0f;
   double rgb_w = 0.8, dssim_w = 0.2;                                   // neural_mapping.cpp:237-240
   double sdf_delta = 0.02, eik_w = 0.1, gs_sdf_w = 1e-3, vis_thresh = 0.1;   // k_sample_std, k_eikonal_weight, k_gs_sdf_weight, :430-432
+  double sdf_w = 1.0, align_w = 0.1;                                   // k_sdf_weight, k_align_weight (config/base.yaml:27-30)
+  // analytic = the reference's DEFAULT SDF configuration (numerical_grad: 0): eikonal on the analytic gradient + align term, the per-ray
+  // batch and the splat samples in ONE fused batch (joint_sdf_loss_analytic); false = the numerical-gradient configuration the
+  // reference forces with the tcnn decoder (params.cpp:396-399)
+  bool analytic = true;
+  // reference_terms: render_normal_weight x depth->normal consistency + isotropic_weight x isotropic regulariser + prune_nan test
+  // (neural_mapping.cpp:243-276, neural_gaussian.cpp:907-916); false: `upstream` op-level gradients instead (the round-2 step)
+  bool reference_terms = true;
+  double normal_w = 0.01, isotropic_w = 0.05;                          // config/base.yaml:43-44
   double lr_offsets = 1.6e-4, lr_scaling = 5e-3, lr_quaternion = 1e-3, lr_opacity = 5e-2, lr_features_dc = 2.5e-3,
          lr_features_rest = 2.5e-3 / 20, lr_sdf = 1e-4;               // neural_gaussian.cpp:434-453, :619-623
   bool two_streams = false;   // the SDF network's work on a second HIP stream beside the splat leg (bench.py's overlapped schedule)
@@ -105,15 +141,22 @@ class JointIteration {
                  std::shared_ptr<::TCNNNetwork> dec, const std::vector<float> &map_origin, double map_size, double bce_sigma, int occ_level,
                  const JointConfig &cfg);
   // one iteration on view (viewmat [1,4,4], K [1,3,3]) against target [H,W,3] with the ray batch (ray_pts [n,3], ray_sdf [n,1]);
-  // upstream: {} or the op-level gradients {v_depth [1,H,W,1], v_alpha [1,H,W,1], v_normal [1,H,W,3], v_median [1,H,W,1]};
+  // upstream: {} or the op-level gradients {v_depth [1,H,W,1], v_alpha [1,H,W,1], v_normal [1,H,W,3], v_median [1,H,W,1]} (used when
+  // !cfg.reference_terms); cam_host: {} or {fx, fy, cx, cy, camera->world pose row-major [3,4]} as HOST values for the normal-consistency
+  // term (a trainer knows its poses; when empty they are read back from viewmat / K: one device->host copy);
   // update = false leaves the gradients in the flat buffers and skips the optimizers.  Returns {"M","I","n_gs_sdf"}.
+  // STREAM CONTRACT: inputs must have been produced on the caller's current stream (or be complete); with two_streams the second
+  // stream waits for the caller's stream at entry, and the SDF family's update is complete on the caller's stream only after
+  // sync() — the accessors sdf_flat() / sdf_flat_grad() call it.
   std::map<std::string, int64_t> step(const torch::Tensor &viewmat, const torch::Tensor &K, const torch::Tensor &target,
                                       const torch::Tensor &ray_pts, const torch::Tensor &ray_sdf, const std::vector<torch::Tensor> &upstream,
-                                      bool update = true);
+                                      bool update = true, const std::vector<float> &cam_host = {});
+  void sync();   // the caller's current stream waits for everything this object has issued on its second stream
   torch::Tensor splat_flat() const { return flat_; }
   torch::Tensor splat_flat_grad() const { return flat_grad_; }
-  torch::Tensor sdf_flat() const { return sdf_flat_; }
-  torch::Tensor sdf_flat_grad() const { return sdf_flat_grad_; }
+  torch::Tensor sdf_flat() { sync(); return sdf_flat_; }
+  torch::Tensor sdf_flat_grad() { sync(); return sdf_flat_grad_; }
+  torch::Tensor nan_splats_seen() const { return nan_total_; }   // int32 device scalar: sum of the per-iteration prune_nan counts
 
  private:
   JointConfig cfg_;
@@ -123,7 +166,8 @@ class JointIteration {
   double map_size_inv_, bce_isigma_;
   int occ_level_;
   int64_t n_rest_ = 0;
-  torch::Tensor anchors_, flat_, flat_grad_, sdf_flat_, sdf_flat_grad_, occ_grid_;
+  torch::Tensor anchors_, flat_, flat_grad_, sdf_flat_, sdf_flat_grad_, occ_grid_, nan_total_;
+  int64_t n_table_ = 0, n_dec_ = 0, n_bias_ = 0;
   std::vector<torch::Tensor> views_;
   std::map<std::string, torch::Tensor> state_;
   FusedAdam adam_, adam_sdf_;

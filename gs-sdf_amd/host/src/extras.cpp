@@ -162,7 +162,11 @@ struct CouplingFn : public torch::autograd::Function<CouplingFn> {
     Tensor w = f32c(weights.detach().reshape({-1}), "weights");
     check(gsdf_gs_sdf_eik_loss(n, K == 7, fp(attr), (int)attr.size(1), fp(w), ids.data_ptr<int64_t>(), (float)c.scale, (float)c.delta,
                                (float)c.w_eik, fpm(loss), fpm(v_attr), cur_stream()), "gs_sdf_eik_loss");
-    ctx->save_for_backward({ids, x01, feat, jac, acts, v_attr, table, W, table_grad, decoder_grad});
+    // the two in-place gradient sinks travel OUTSIDE save_for_backward: they are views of the flat gradient buffer, which other
+    // nodes of the same backward pass legitimately write before this one runs (autograd's saved-tensor version check would throw)
+    ctx->save_for_backward({ids, x01, feat, jac, acts, v_attr, table, W});
+    ctx->saved_data["table_grad"] = table_grad;
+    ctx->saved_data["decoder_grad"] = decoder_grad;
     ctx->saved_data["n_rows"] = samples.size(0);
     ctx->saved_data["gate"] = gate_handle;
     ctx->saved_data["iv"] = iv;
@@ -172,7 +176,7 @@ struct CouplingFn : public torch::autograd::Function<CouplingFn> {
   static tensor_list backward(AutogradContext *ctx, tensor_list g) {
     auto s = ctx->get_saved_variables();
     const Tensor &ids = s[0], &x01 = s[1], &feat = s[2], &jac = s[3], &acts = s[4], &v_attr = s[5], &table = s[6], &W = s[7];
-    Tensor table_grad = s[8], decoder_grad = s[9];
+    Tensor table_grad = ctx->saved_data["table_grad"].toTensor(), decoder_grad = ctx->saved_data["decoder_grad"].toTensor();
     const CouplingCfg c = coupling_cfg(ctx->saved_data["iv"].toIntVector(), ctx->saved_data["dv"].toDoubleVector());
     const int64_t nq = x01.size(0), n = jac.size(0);
     const int nl = (int)c.dims.size() - 1;
@@ -185,11 +189,13 @@ struct CouplingFn : public torch::autograd::Function<CouplingFn> {
     Tensor v_samples = torch::zeros({ctx->saved_data["n_rows"].toInt(), 3}, feat.options());
     v_samples.index_add_(0, ids, v_x * c.map_size_inv);          // d x01 / d xyz = 0.5 * 2 * map_size_inv
     if (auto *gate = reinterpret_cast<gsdf_extras::StreamGate *>(ctx->saved_data["gate"].toInt())) gate->record_here();
-    if (nq >= 24576) {
+    // the binned scatter does not cover every grid (log2_hashmap_size >= 20, more than 4096 tiles: ws_bytes == 0): those take
+    // the atomic kernel, like TCNNEncoding's own backward and the Python mirror
+    const size_t nb = nq >= 24576 ? gsdf_hashgrid_bwd_binned_ws_bytes(nq, c.L, c.F, c.H, c.R, c.S) : 0;
+    if (nb > 0) {
       int merge = 0;
       for (int l = 0; l < c.L; ++l)
         if ((c.R * std::pow((double)c.S, l) - 1.0) * c.delta * c.map_size_inv < 1.0) ++merge;
-      const size_t nb = gsdf_hashgrid_bwd_binned_ws_bytes(nq, c.L, c.F, c.H, c.R, c.S);
       Tensor bws = empty_like_opts(feat, {(int64_t)nb}, torch::kUInt8);
       check(gsdf_hashgrid_bwd_binned_stencil(nq, nq == 7 * n ? n : 0, merge, c.L, c.F, c.H, c.R, c.S, fp(x01), fp(v_feat), fpm(table_grad),
                                              bws.data_ptr(), nb, cur_stream()), "hashgrid_bwd_binned_stencil");
@@ -200,6 +206,214 @@ struct CouplingFn : public torch::autograd::Function<CouplingFn> {
   }
 };
 }  // namespace
+
+namespace {
+// Python mirror: gs_sdf_amd/sdf.py _SdfBatchAnalytic (same kernels, same order)
+struct AnalyticFn : public torch::autograd::Function<AnalyticFn> {
+  static Tensor forward(AutogradContext *ctx, const Tensor &ray_xyz, const Tensor &gt_sdf, const Tensor &samples, const Tensor &ids_,
+                        const Tensor &weights, const Tensor &table_, const Tensor &W_, const Tensor &bias_, Tensor table_grad, Tensor decoder_grad,
+                        Tensor bias_grad, std::vector<int64_t> iv, std::vector<double> dv, int64_t gate_handle) {
+    // iv = {L, F, H, R, dims...}; dv = {S, origin x3, map_size_inv, bce_isigma, w_sdf, w_gs, delta, w_eik, w_align}
+    const int L = (int)iv[0], F = (int)iv[1], H = (int)iv[2], R = (int)iv[3];
+    const std::vector<int> dims(iv.begin() + 4, iv.end());
+    const float S = (float)dv[0];
+    const float origin[3] = {(float)dv[1], (float)dv[2], (float)dv[3]};
+    const double map_size_inv = dv[4], bce_isigma = dv[5], w_sdf = dv[6], w_gs = dv[7], delta = dv[8], w_eik = dv[9], w_align = dv[10];
+    Tensor table = f32c(table_.detach(), "encoder params"), W = f32c(W_.detach(), "decoder params");
+    Tensor bias = (bias_.defined() && bias_.numel() > 0) ? f32c(bias_.detach(), "decoder biases") : Tensor();
+    std::vector<Tensor> parts;
+    int64_t n_ray = 0;
+    if (ray_xyz.defined() && ray_xyz.numel() > 0) { parts.push_back(f32c(ray_xyz.detach().reshape({-1, 3}), "ray_xyz")); n_ray = parts[0].size(0); }
+    Tensor ids = (ids_.defined() && ids_.numel() > 0) ? ids_.contiguous() : Tensor();
+    if (samples.defined() && samples.numel() > 0) parts.push_back(ids.defined() ? samples.detach().index_select(0, ids) : f32c(samples.detach().reshape({-1, 3}), "samples"));
+    TORCH_CHECK(!parts.empty(), "joint_sdf_loss_analytic: no points");
+    Tensor xs = parts.size() == 1 ? parts[0].contiguous() : torch::cat(parts, 0);
+    const int64_t n = xs.size(0);
+    const bool stencil = w_align != 0.0 && n > 0;
+    const int64_t K = stencil ? 7 : 1, nq = K * n;
+    const int nf = L * F, nl = (int)dims.size() - 1;
+    Tensor x01 = empty_like_opts(xs, {nq, 3}, torch::kFloat32);
+    check(gsdf_sdf_query_points(n, stencil ? 1 : 0, fp(xs), (float)delta, origin, (float)map_size_inv, fpm(x01), cur_stream()), "sdf_query_points");
+    Tensor feat = empty_like_opts(xs, {nq, nf}, torch::kFloat32), jac = empty_like_opts(xs, {n, nf, 3}, torch::kFloat32);
+    if (stencil)
+      check(gsdf_hashgrid_fwd_stencil(nq, n, n, L, F, H, R, S, fp(x01), fp(table), fpm(feat), fpm(jac), cur_stream()), "hashgrid_fwd_stencil");
+    else
+      check(gsdf_hashgrid_fwd_jac_rows(nq, n, L, F, H, R, S, fp(x01), fp(table), fpm(feat), fpm(jac), cur_stream()), "hashgrid_fwd_jac");
+    const int64_t d_out = dims.back();
+    Tensor attr = empty_like_opts(xs, {nq, d_out}, torch::kFloat32);
+    Tensor acts = empty_like_opts(xs, {(int64_t)gsdf_mlp_acts_floats(n, nl)}, torch::kFloat32);
+    check(gsdf_mlp_fwd(n, nl, dims.data(), fp(W), fp(bias), fp(feat), fpm(attr), fpm(acts), cur_stream()), "mlp_fwd");
+    if (stencil)   // forward-only rows: the numerical gradient of the align term is detached
+      check(gsdf_mlp_fwd(6 * n, nl, dims.data(), fp(W), fp(bias), fp(feat) + n * nf, fpm(attr) + n * d_out, nullptr, cur_stream()), "mlp_fwd");
+    // g0 = d sdf / d features: the decoder's backward of e_0; its per-layer gradients stay in `bws` for the double backward
+    Tensor e0 = zeros_like_opts(xs, {n, d_out}, torch::kFloat32);
+    e0.select(1, 0).fill_(1.0f);
+    Tensor g0 = empty_like_opts(xs, {n, nf}, torch::kFloat32);
+    Tensor bws = empty_like_opts(xs, {(int64_t)gsdf_mlp_bwd_ws_bytes(n, nl)}, torch::kUInt8);
+    check(gsdf_mlp_bwd(n, nl, dims.data(), fp(W), fp(bias), fp(feat), fp(acts), fp(e0), fpm(g0), nullptr, nullptr, bws.data_ptr(), cur_stream()), "mlp_bwd");
+    Tensor loss = empty_like_opts(xs, {}, torch::kFloat32), v_attr = empty_like_opts(xs, {n, d_out}, torch::kFloat32);
+    Tensor vv_x = empty_like_opts(xs, {n, 3}, torch::kFloat32), u0 = empty_like_opts(xs, {n, nf}, torch::kFloat32);
+    Tensor gt = n_ray > 0 ? f32c(gt_sdf.detach().reshape({-1}), "gt_sdf") : Tensor();
+    Tensor w = n > n_ray ? f32c(weights.detach().reshape({-1}), "weights") : Tensor();
+    check(gsdf_sdf_analytic_loss(n, n_ray, stencil ? 1 : 0, fp(attr), (int)d_out, fp(g0), nf, fp(jac), fp(gt), fp(w),
+                                 (n > n_ray && ids.defined()) ? ids.data_ptr<int64_t>() : nullptr, (float)bce_isigma, (float)w_sdf, (float)w_gs,
+                                 (float)map_size_inv, (float)delta, (float)w_eik, (float)w_align, fpm(loss), fpm(v_attr), fpm(vv_x), fpm(u0),
+                                 cur_stream()), "sdf_analytic_loss");
+    // (tensors that travel to backward without autograd's saved-tensor version check: the in-place gradient sinks)
+    ctx->save_for_backward({ids.defined() ? ids : torch::zeros({0}, xs.options().dtype(torch::kInt64)), x01, feat, jac, acts, bws, e0, g0, v_attr, vv_x, u0,
+                            table, W, bias.defined() ? bias : torch::zeros({0}, xs.options())});
+    ctx->saved_data["table_grad"] = table_grad;
+    ctx->saved_data["decoder_grad"] = decoder_grad;
+    ctx->saved_data["bias_grad"] = bias_grad.defined() ? bias_grad : torch::zeros({0}, xs.options());
+    ctx->saved_data["n"] = n; ctx->saved_data["n_ray"] = n_ray;
+    ctx->saved_data["n_rows"] = (samples.defined() && samples.numel() > 0) ? samples.size(0) : (int64_t)0;
+    ctx->saved_data["has_ids"] = ids.defined();
+    ctx->saved_data["gate"] = gate_handle;
+    ctx->saved_data["iv"] = iv; ctx->saved_data["dv"] = dv;
+    return loss;
+  }
+  static tensor_list backward(AutogradContext *ctx, tensor_list g) {
+    auto s = ctx->get_saved_variables();
+    const Tensor &ids = s[0], &x01 = s[1], &feat = s[2], &jac = s[3], &acts = s[4], &bws = s[5], &e0 = s[6], &g0 = s[7], &v_attr = s[8];
+    const Tensor &vv_x = s[9], &u0 = s[10], &table = s[11], &W = s[12];
+    Tensor bias = s[13].numel() ? s[13] : Tensor();
+    Tensor table_grad = ctx->saved_data["table_grad"].toTensor(), decoder_grad = ctx->saved_data["decoder_grad"].toTensor();
+    Tensor bias_grad = ctx->saved_data["bias_grad"].toTensor();
+    auto iv = ctx->saved_data["iv"].toIntVector();
+    auto dv = ctx->saved_data["dv"].toDoubleVector();
+    const int L = (int)iv[0], F = (int)iv[1], H = (int)iv[2], R = (int)iv[3];
+    const std::vector<int> dims(iv.begin() + 4, iv.end());
+    const float S = (float)dv[0];
+    const double map_size_inv = dv[4];
+    const int64_t n = ctx->saved_data["n"].toInt(), n_ray = ctx->saved_data["n_ray"].toInt(), n_rows = ctx->saved_data["n_rows"].toInt();
+    const int nf = L * F, nl = (int)dims.size() - 1;
+    tensor_list out(14);
+    if (n == 0) return out;
+    Tensor v_out = (v_attr * g[0]).contiguous(), v_feat = empty_like_opts(feat, {n, nf}, torch::kFloat32);
+    // first order: data terms through the decoder (one pass: input + parameter gradients)
+    Tensor ws = empty_like_opts(feat, {(int64_t)gsdf_mlp_bwd_ws_bytes_for(n, nl, dims.data(), 1)}, torch::kUInt8);
+    check(gsdf_mlp_bwd(n, nl, dims.data(), fp(W), fp(bias), fp(feat), fp(acts), fp(v_out), fpm(v_feat), fpm(decoder_grad),
+                       bias.defined() ? fpm(bias_grad) : nullptr, ws.data_ptr(), cur_stream()), "mlp_bwd");
+    // second order: the regularisers reach the decoder weights through g0 = W_0^T D_0 ... e_0
+    Tensor vv_in = (u0 * g[0]).contiguous(), g_vout = torch::empty_like(e0);
+    Tensor ws2 = empty_like_opts(feat, {(int64_t)gsdf_mlp_bwd_bwd_ws_bytes(n, nl)}, torch::kUInt8);
+    check(gsdf_mlp_bwd_bwd(n, nl, dims.data(), fp(W), fp(acts), fp(e0), bws.data_ptr(), fp(vv_in), fpm(g_vout), fpm(decoder_grad), ws2.data_ptr(),
+                           cur_stream()), "mlp_bwd_bwd");
+    if (ctx->needs_input_grad(2) && n > n_ray) {   // d (data term) / d samples from the Jacobian of the splat rows
+      const int64_t ng = n - n_ray;
+      Tensor v_x = empty_like_opts(feat, {ng, 3}, torch::kFloat32);
+      check(gsdf_hashgrid_bwd_jac(ng, L, F, fp(jac) + n_ray * nf * 3, fp(v_feat) + n_ray * nf, fpm(v_x), cur_stream()), "hashgrid_bwd_jac");
+      Tensor v_samples = torch::zeros({n_rows, 3}, feat.options());
+      if (ctx->saved_data["has_ids"].toBool()) v_samples.index_add_(0, ids, v_x * map_size_inv);
+      else v_samples.copy_(v_x * map_size_inv);
+      out[2] = v_samples;
+    }
+    if (auto *gate = reinterpret_cast<gsdf_extras::StreamGate *>(ctx->saved_data["gate"].toInt())) gate->record_here();
+    // table: first-order (v_feat) and second-order (g0, vv_x) contributions of every corner in ONE scatter
+    Tensor vvx = (vv_x * g[0]).contiguous();
+    const size_t nb = n >= 24576 ? gsdf_hashgrid_bwd_binned_ws_bytes(n, L, F, H, R, S) : 0;
+    if (nb > 0) {
+      Tensor bws2 = empty_like_opts(feat, {(int64_t)nb}, torch::kUInt8);
+      check(gsdf_hashgrid_bwd_binned2(n, L, F, H, R, S, fp(x01), fp(v_feat), fp(g0), fp(vvx), fpm(table_grad), bws2.data_ptr(), nb, cur_stream()),
+            "hashgrid_bwd_binned2");
+    } else {
+      check(gsdf_hashgrid_bwd(n, L, F, H, R, S, fp(x01), fp(table), fp(v_feat), fpm(table_grad), nullptr, cur_stream()), "hashgrid_bwd");
+      check(gsdf_hashgrid_bwd_bwd(n, L, F, H, R, S, fp(x01), fp(table), fp(g0), fp(vvx), nullptr, fpm(table_grad), nullptr, cur_stream()),
+            "hashgrid_bwd_bwd");
+    }
+    return out;
+  }
+};
+
+struct NormalConsistencyFn : public torch::autograd::Function<NormalConsistencyFn> {
+  static Tensor forward(AutogradContext *ctx, const Tensor &depth_, const Tensor &alpha_, const Tensor &rn_, std::vector<double> cam) {
+    Tensor depth = f32c(depth_, "depth"), alpha = f32c(alpha_.detach(), "alpha"), rn = f32c(rn_, "render_normal");
+    const int H = (int)depth.size(0), W = (int)depth.size(1);
+    float intr[4], pose[12];
+    for (int k = 0; k < 4; ++k) intr[k] = (float)cam[k];
+    for (int k = 0; k < 12; ++k) pose[k] = (float)cam[4 + k];
+    Tensor loss = empty_like_opts(depth, {1}, torch::kFloat32);
+    check(gsdf_normal_consistency_fwd(H, W, intr, pose, fp(depth), fp(alpha), fp(rn), fpm(loss), cur_stream()), "normal_consistency_fwd");
+    ctx->save_for_backward({depth, alpha, rn});
+    ctx->saved_data["cam"] = cam;
+    return loss[0];
+  }
+  static tensor_list backward(AutogradContext *ctx, tensor_list g) {
+    auto s = ctx->get_saved_variables();
+    auto cam = ctx->saved_data["cam"].toDoubleVector();
+    const int H = (int)s[0].size(0), W = (int)s[0].size(1);
+    float intr[4], pose[12];
+    for (int k = 0; k < 4; ++k) intr[k] = (float)cam[k];
+    for (int k = 0; k < 12; ++k) pose[k] = (float)cam[4 + k];
+    Tensor v_depth = torch::empty_like(s[0]), v_rn = torch::empty_like(s[2]);
+    Tensor v = f32c(g[0].reshape({1}), "grad");
+    check(gsdf_normal_consistency_bwd(H, W, intr, pose, fp(s[0]), fp(s[1]), fp(s[2]), fp(v), fpm(v_depth), fpm(v_rn), cur_stream()),
+          "normal_consistency_bwd");
+    return {v_depth, Tensor(), v_rn, Tensor()};
+  }
+};
+
+struct IsotropicFn : public torch::autograd::Function<IsotropicFn> {
+  static Tensor forward(AutogradContext *ctx, const Tensor &scales_, const Tensor &ids_) {
+    Tensor scales = f32c(scales_, "scales"), ids = ids_.contiguous();
+    Tensor loss = empty_like_opts(scales, {}, torch::kFloat32);
+    check(gsdf_isotropic_loss_fwd(ids.size(0), fp(scales), ids.data_ptr<int64_t>(), fpm(loss), cur_stream()), "isotropic_loss_fwd");
+    ctx->save_for_backward({scales, ids});
+    return loss;
+  }
+  static tensor_list backward(AutogradContext *ctx, tensor_list g) {
+    auto s = ctx->get_saved_variables();
+    Tensor v_scales = torch::zeros_like(s[0]);
+    Tensor v = f32c(g[0].reshape({1}), "grad");
+    check(gsdf_isotropic_loss_bwd(s[1].size(0), fp(s[0]), s[1].data_ptr<int64_t>(), fp(v), fpm(v_scales), cur_stream()), "isotropic_loss_bwd");
+    return {v_scales, Tensor()};
+  }
+};
+}  // namespace
+
+Tensor joint_sdf_loss_analytic(const Tensor &ray_xyz, const Tensor &gt_sdf, const Tensor &samples, const Tensor &ids, const Tensor &weights,
+                               ::TCNNEncoding &enc, ::TCNNNetwork &dec, const std::vector<float> &origin, double map_size_inv, double bce_isigma,
+                               double w_sdf, double w_gs, double delta, double w_eik, double w_align, Tensor table_grad, Tensor decoder_grad,
+                               Tensor bias_grad, StreamGate *samples_grad_ready) {
+  TORCH_CHECK(origin.size() == 3, "joint_sdf_loss_analytic: map_origin needs 3 entries");
+  TORCH_CHECK(table_grad.defined() && table_grad.numel() == enc.params_.numel() && table_grad.is_contiguous() && decoder_grad.defined() &&
+                  decoder_grad.numel() == dec.params_.numel() && decoder_grad.is_contiguous() &&
+                  (!dec.biases_.defined() || (bias_grad.defined() && bias_grad.numel() == dec.biases_.numel() && bias_grad.is_contiguous())),
+              "joint_sdf_loss_analytic: table_grad / decoder_grad / bias_grad must be contiguous fp32 buffers shaped like the parameters");
+  std::vector<int64_t> iv = {enc.n_levels_, enc.n_feat_, enc.log2_hashmap_, enc.base_res_};
+  iv.insert(iv.end(), dec.dims_.begin(), dec.dims_.end());
+  std::vector<double> dv = {enc.per_level_scale_, origin[0], origin[1], origin[2], map_size_inv, bce_isigma, w_sdf, w_gs, delta, w_eik, w_align};
+  // autograd::Function::apply wants defined tensors: an empty tensor stands for "absent"
+  const auto opt = enc.params_.options().requires_grad(false);
+  auto e = [&](const Tensor &t) { return t.defined() ? t : torch::empty({0}, opt); };
+  return AnalyticFn::apply(e(ray_xyz), e(gt_sdf), e(samples), ids.defined() ? ids : torch::empty({0}, opt.dtype(torch::kInt64)), e(weights), enc.params_,
+                           dec.params_, e(dec.biases_), table_grad, decoder_grad, e(bias_grad), iv, dv, reinterpret_cast<int64_t>(samples_grad_ready));
+}
+
+Tensor normal_consistency_loss(const Tensor &depth, const Tensor &alpha, const Tensor &render_normal, const std::vector<float> &intrinsics4,
+                               const std::vector<float> &pose_c2w) {
+  TORCH_CHECK(intrinsics4.size() == 4 && pose_c2w.size() >= 12, "normal_consistency_loss: intrinsics {fx,fy,cx,cy} and a [3,4] pose expected");
+  TORCH_CHECK(depth.dim() == 3 && depth.size(2) == 1 && render_normal.dim() == 3 && render_normal.size(2) == 3, "normal_consistency_loss: [H,W,1] depth / alpha, [H,W,3] normals");
+  std::vector<double> cam(intrinsics4.begin(), intrinsics4.end());
+  cam.insert(cam.end(), pose_c2w.begin(), pose_c2w.begin() + 12);
+  return NormalConsistencyFn::apply(depth, alpha, render_normal, cam);
+}
+
+Tensor isotropic_loss(const Tensor &scales, const Tensor &gaussian_ids) {
+  TORCH_CHECK(scales.dim() == 2 && scales.size(1) == 3 && gaussian_ids.scalar_type() == torch::kInt64, "isotropic_loss: scales [N,3], gaussian_ids int64");
+  return IsotropicFn::apply(scales, gaussian_ids);
+}
+
+Tensor nan_rows(const Tensor &offsets, const Tensor &scaling, const Tensor &quaternion, Tensor *mask) {
+  torch::NoGradGuard ng;
+  Tensor o = f32c(offsets.detach(), "offsets"), sc = f32c(scaling.detach(), "scaling"), q = f32c(quaternion.detach(), "quaternion");
+  const int64_t n = o.size(0);
+  Tensor count = empty_like_opts(o, {1}, torch::kInt32);
+  Tensor m = mask ? empty_like_opts(o, {n}, torch::kBool) : Tensor();
+  check(gsdf_nan_rows(n, fp(o), fp(sc), fp(q), count.data_ptr<int32_t>(), mask ? (uint8_t *)m.data_ptr() : nullptr, cur_stream()), "nan_rows");
+  if (mask) *mask = m;
+  return count;
+}
 
 Tensor gs_sdf_coupling(const Tensor &samples, const Tensor &ids, const Tensor &weights, ::TCNNEncoding &enc, ::TCNNNetwork &dec,
                        const std::vector<float> &origin, double map_size_inv, double scale, double delta, double w_eik, Tensor table_grad,

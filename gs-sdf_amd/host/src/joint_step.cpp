@@ -91,9 +91,9 @@ namespace gsdf_extras {
 
 struct JointStreams {
   c10::hip::HIPStreamMasqueradingAsCUDA side = c10::hip::getStreamFromPoolMasqueradingAsCUDA();
-  at::cuda::CUDAEvent fwd_done, init_done;
+  at::cuda::CUDAEvent fwd_done, entry, side_done;
   StreamGate gate;
-  bool first = true;
+  bool side_pending = false;
 };
 
 JointIteration::~JointIteration() = default;
@@ -128,22 +128,27 @@ JointIteration::JointIteration(const Tensor &anchors, const std::vector<Tensor> 
   }
   n_rest_ = N > 0 ? fields[5].numel() / (3 * N) : 0;
   adam_.add_group(flat_, flat_grad_, sizes, seg_lrs);
-  // SDF family: table then decoder in one flat buffer; the operators' params_ become views of it
-  const int64_t nt = enc_->params_.numel(), nd = dec_->params_.numel();
-  sdf_flat_ = torch::empty({nt + nd}, anchors_.options());
-  sdf_flat_grad_ = torch::zeros({nt + nd}, anchors_.options());
+  // SDF family: table, decoder weights (, decoder biases) in one flat buffer; the operators' params_ become views of it
+  n_table_ = enc_->params_.numel(); n_dec_ = dec_->params_.numel(); n_bias_ = dec_->biases_.defined() ? dec_->biases_.numel() : 0;
+  const int64_t nt = n_table_, nd = n_dec_, nb = n_bias_;
+  sdf_flat_ = torch::empty({nt + nd + nb}, anchors_.options());
+  sdf_flat_grad_ = torch::zeros({nt + nd + nb}, anchors_.options());
   {
     torch::NoGradGuard ng;
     sdf_flat_.slice(0, 0, nt).copy_(enc_->params_.detach().reshape({-1}));
     sdf_flat_.slice(0, nt, nt + nd).copy_(dec_->params_.detach().reshape({-1}));
+    if (nb) sdf_flat_.slice(0, nt + nd, nt + nd + nb).copy_(dec_->biases_.detach().reshape({-1}));
   }
-  enc_->params_ = sdf_flat_.slice(0, 0, nt);
-  enc_->params_.requires_grad_(true);
-  enc_->params_.mutable_grad() = sdf_flat_grad_.slice(0, 0, nt);
-  dec_->params_ = sdf_flat_.slice(0, nt, nt + nd);
-  dec_->params_.requires_grad_(true);
-  dec_->params_.mutable_grad() = sdf_flat_grad_.slice(0, nt, nt + nd);
-  adam_sdf_.add_group(sdf_flat_, sdf_flat_grad_, {nt + nd}, {cfg.lr_sdf});
+  auto bind = [&](Tensor &p, int64_t a, int64_t b) {
+    p = sdf_flat_.slice(0, a, b);
+    p.requires_grad_(true);
+    p.mutable_grad() = sdf_flat_grad_.slice(0, a, b);
+  };
+  bind(enc_->params_, 0, nt);
+  bind(dec_->params_, nt, nt + nd);
+  if (nb) bind(dec_->biases_, nt + nd, nt + nd + nb);
+  adam_sdf_.add_group(sdf_flat_, sdf_flat_grad_, {nt + nd + nb}, {cfg.lr_sdf});
+  nan_total_ = torch::zeros({1}, anchors_.options().dtype(torch::kInt32));
   // occupancy structure of the map from the splat centres (SubMap::update_octree_as, sub_map.cpp:22-35)
   const size_t nbytes = gsdf_occ_bytes(occ_level_);
   TORCH_CHECK(nbytes > 0, "JointIteration: occupancy level outside [1,12]");
@@ -152,8 +157,16 @@ JointIteration::JointIteration(const Tensor &anchors, const std::vector<Tensor> 
   check(gsdf_occ_build(occ_level_, N, fp(m1p1), 1, occ_grid_.data_ptr(), cur_stream()), "occ_build");
 }
 
+void JointIteration::sync() {
+  if (streams_ && streams_->side_pending) {
+    streams_->side_done.block(c10::hip::getCurrentHIPStreamMasqueradingAsCUDA());
+    streams_->side_pending = false;
+  }
+}
+
 std::map<std::string, int64_t> JointIteration::step(const Tensor &viewmat, const Tensor &K, const Tensor &target, const Tensor &ray_pts,
-                                                    const Tensor &ray_sdf, const std::vector<Tensor> &upstream, bool update) {
+                                                    const Tensor &ray_sdf, const std::vector<Tensor> &upstream, bool update,
+                                                    const std::vector<float> &cam_host) {
   const int W = cfg_.width, H = cfg_.height;
   std::map<std::string, int64_t> sizes;
   // Two legs on two HIP streams (cfg.two_streams; the schedule of bench.py's overlapped step): the SDF network's work — ray batch,
@@ -163,13 +176,19 @@ std::map<std::string, int64_t> JointIteration::step(const Tensor &viewmat, const
   const bool two = cfg_.two_streams;
   auto main_stream = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA();
   if (two && !streams_) streams_ = std::make_unique<JointStreams>();
-  if (two && streams_->first) {   // the constructor filled the flat buffers on the caller's stream
-    streams_->init_done.record(main_stream);
-    streams_->init_done.block(streams_->side);
-    streams_->first = false;
+  if (two) {
+    // every step: whatever the caller produced on its stream (the ray batch, the constructor's copies, a parameter edit) is
+    // ordered before the second stream's work
+    streams_->entry.record(main_stream);
+    streams_->entry.block(streams_->side);
   }
-  // ---- per-ray SDF batch (:138-188): BCE sdf_loss + eikonal on the numerical gradient, 7 n rows in one encoder / decoder / loss launch
-  {
+  const int64_t N = anchors_.size(0);
+  const int64_t nt = n_table_, nd = n_dec_, nb = n_bias_;
+  Tensor tg = sdf_flat_grad_.slice(0, 0, nt), dg = sdf_flat_grad_.slice(0, nt, nt + nd);
+  Tensor bg = nb ? sdf_flat_grad_.slice(0, nt + nd, nt + nd + nb) : Tensor();
+  if (!cfg_.analytic) {
+    // ---- per-ray SDF batch (:138-188), numerical configuration: BCE sdf_loss + eikonal on the numerical gradient, 7 n rows in one
+    //      encoder / decoder / loss launch (independent of the render: issued first)
     c10::optional<StreamGuard> sg;
     if (two) {
       sg.emplace(streams_->side);
@@ -182,8 +201,7 @@ std::map<std::string, int64_t> JointIteration::step(const Tensor &viewmat, const
     sdf_ray_loss(attr, ray_sdf, n, bce_isigma_, cfg_.sdf_delta, cfg_.eik_w).backward();
   }
   // ---- render (:195-300 -> neural_gaussian.cpp:129-271) + photometric loss
-  auto act = splat_activations(anchors_, views_[0], views_[1], views_[3].reshape({anchors_.size(0)}));
-  const int64_t N = anchors_.size(0);
+  auto act = splat_activations(anchors_, views_[0], views_[1], views_[3].reshape({N}));
   Tensor dc = views_[4].reshape({N, 1, 3});
   Tensor sh = n_rest_ == 0 ? dc : torch::cat({dc, views_[5].reshape({N, n_rest_, 3})}, 1);
   auto proj = fully_fused_projection_2dgs(act[0], views_[2], act[1], viewmat, K, W, H, cfg_.near_plane, cfg_.far_plane, 0.f, true, false);
@@ -202,7 +220,23 @@ std::map<std::string, int64_t> JointIteration::step(const Tensor &viewmat, const
   const Tensor &render_normal = post[1], &color3 = post[2], &depth1 = post[3];
   const Tensor &alphas = std::get<2>(rast), &median = std::get<5>(rast), &vis = std::get<6>(rast);
   Tensor loss = l1_dssim_loss(color3[0], target, cfg_.rgb_w, cfg_.dssim_w);
-  if (upstream.size() == 4) loss = loss + InjectGrads::apply(depth1, upstream[0], alphas, upstream[1], render_normal, upstream[2], median, upstream[3]);
+  if (cfg_.reference_terms) {
+    // render_normal_weight x depth->normal consistency (:243-266; depth_type 0: the expected depth) + isotropic_weight x isotropic
+    // regulariser of the visible splats (:268-276), one launch each
+    std::vector<float> intr, pose;
+    if (cam_host.size() >= 16) {
+      intr.assign(cam_host.begin(), cam_host.begin() + 4);
+      pose.assign(cam_host.begin() + 4, cam_host.begin() + 16);
+    } else {   // read the camera back (one device->host copy)
+      Tensor Kc = K[0].detach().to(torch::kCPU), c2w = torch::linalg_inv(viewmat[0].detach().to(torch::kCPU).to(torch::kFloat64)).to(torch::kFloat32).contiguous();
+      intr = {Kc[0][0].item<float>(), Kc[1][1].item<float>(), Kc[0][2].item<float>(), Kc[1][2].item<float>()};
+      pose.assign(c2w.data_ptr<float>(), c2w.data_ptr<float>() + 12);
+    }
+    loss = loss + cfg_.normal_w * normal_consistency_loss(depth1[0], alphas[0], render_normal[0], intr, pose) +
+           cfg_.isotropic_w * isotropic_loss(act[1], gaussian_ids);
+  } else if (upstream.size() == 4) {
+    loss = loss + InjectGrads::apply(depth1, upstream[0], alphas, upstream[1], render_normal, upstream[2], median, upstream[3]);
+  }
   // ---- GS <-> SDF coupling (:420-462) at the visible, occupancy-valid splats' samples
   Tensor visd = vis.detach();
   Tensor w_all = (samples_weights * visd).detach();
@@ -213,30 +247,41 @@ std::map<std::string, int64_t> JointIteration::step(const Tensor &viewmat, const
                                (uint8_t *)valid.data_ptr(), cur_stream()), "occ_query_world");
   }
   Tensor ids = (valid & (visd > cfg_.vis_thresh).squeeze(-1)).nonzero().squeeze(-1);
-  const int64_t nt = enc_->params_.numel(), nd = dec_->params_.numel();
-  Tensor tg = sdf_flat_grad_.slice(0, 0, nt), dg = sdf_flat_grad_.slice(0, nt, nt + nd);
+  const bool has = ids.numel() > 0;
+  // the SDF work that depends on the render: numerical configuration = the coupling node; analytic (default) configuration = the
+  // WHOLE SDF batch of the iteration (per-ray points + splat samples) in one node
+  auto sdf_node = [&](const Tensor &smp, StreamGate *gate) -> Tensor {
+    if (cfg_.analytic)
+      return joint_sdf_loss_analytic(ray_pts, ray_sdf, has ? smp : Tensor(), has ? ids : Tensor(), has ? w_all : Tensor(), *enc_, *dec_, origin_,
+                                     map_size_inv_, bce_isigma_, cfg_.sdf_w, cfg_.gs_sdf_w, cfg_.sdf_delta, cfg_.eik_w, cfg_.align_w, tg, dg, bg, gate);
+    return gs_sdf_coupling(smp, ids, w_all, *enc_, *dec_, origin_, map_size_inv_, cfg_.gs_sdf_w, cfg_.sdf_delta, cfg_.eik_w, tg, dg, gate);
+  };
+  const bool sdf_work = cfg_.analytic || has;
   if (!two) {
-    if (ids.numel() > 0)
-      loss = loss + gs_sdf_coupling(samples, ids, w_all, *enc_, *dec_, origin_, map_size_inv_, cfg_.gs_sdf_w, cfg_.sdf_delta, cfg_.eik_w, tg, dg);
+    if (sdf_work) loss = loss + sdf_node(samples, nullptr);
     loss.backward();
-  } else if (ids.numel() > 0) {
-    // graph cut at the samples: the coupling leg (forward + backward) on `side`, its d loss / d samples joins the splat leg's
+  } else if (sdf_work) {
+    // graph cut at the samples: the SDF leg (forward + backward) on `side`, its d loss / d samples joins the splat leg's
     // backward where the samples' gradient is consumed
     streams_->fwd_done.record(main_stream);
     streams_->fwd_done.block(streams_->side);
     Tensor samples_cut = samples.detach().requires_grad_(true);
     for (const Tensor &t : {samples_cut, w_all, ids}) t.record_stream(streams_->side);
+    if (cfg_.analytic) { ray_pts.record_stream(streams_->side); ray_sdf.record_stream(streams_->side); }
     {
       StreamGuard sg(streams_->side);
-      // the node records the gate as soon as d loss / d samples has been issued, BEFORE its table scatter (2-3 ms): the splat
-      // leg's backward tail and the next step's render do not wait for the scatter
-      gs_sdf_coupling(samples_cut, ids, w_all, *enc_, *dec_, origin_, map_size_inv_, cfg_.gs_sdf_w, cfg_.sdf_delta, cfg_.eik_w, tg, dg,
-                      &streams_->gate).backward();
+      // the node records the gate as soon as d loss / d samples has been issued, BEFORE its table scatter: the splat leg's backward
+      // tail and the next step's render do not wait for the scatter
+      sdf_node(samples_cut, &streams_->gate).backward();
       if (!streams_->gate.armed) streams_->gate.record_here();
     }
     Tensor gs = samples_cut.grad();
-    gs.record_stream(main_stream);
-    torch::autograd::backward({loss, samples}, {Tensor(), gs});
+    if (gs.defined()) {
+      gs.record_stream(main_stream);
+      torch::autograd::backward({loss, samples}, {Tensor(), gs});
+    } else {
+      loss.backward();
+    }
   } else {
     loss.backward();
   }
@@ -245,10 +290,15 @@ std::map<std::string, int64_t> JointIteration::step(const Tensor &viewmat, const
   if (update) {
     adam_.step();
     flat_grad_.zero_();
+    if (cfg_.reference_terms) nan_total_.add_(nan_rows(views_[0], views_[1], views_[2]));   // prune_nan_gs's test, no host sync
     c10::optional<StreamGuard> sg;
     if (two) sg.emplace(streams_->side);
     adam_sdf_.step();
     sdf_flat_grad_.zero_();
+  }
+  if (two) {   // what the caller's stream has to wait for before it touches the SDF family (sync())
+    streams_->side_done.record(streams_->side);
+    streams_->side_pending = true;
   }
   sizes["M"] = gaussian_ids.size(0);
   sizes["I"] = std::get<1>(enc).size(0);

@@ -85,18 +85,23 @@ PYBIND11_MODULE(_gsdf_host, m) {
   py::class_<gsdf_extras::JointIteration, std::shared_ptr<gsdf_extras::JointIteration>>(m, "JointIteration")
       .def(py::init([](const torch::Tensor &anchors, const std::vector<torch::Tensor> &fields, std::shared_ptr<TCNNEncoding> enc,
                        std::shared_ptr<TCNNNetwork> dec, std::vector<float> origin, double map_size, double bce_sigma, int occ_level, int width,
-                       int height, int sh_degree, bool two_streams) {
+                       int height, int sh_degree, bool two_streams, bool analytic, bool reference_terms) {
         gsdf_extras::JointConfig cfg;
         cfg.width = width; cfg.height = height; cfg.sh_degree = sh_degree; cfg.two_streams = two_streams;
+        cfg.analytic = analytic; cfg.reference_terms = reference_terms;
         return std::make_shared<gsdf_extras::JointIteration>(anchors, fields, enc, dec, origin, map_size, bce_sigma, occ_level, cfg);
-      }))
+      }), py::arg("anchors"), py::arg("fields"), py::arg("enc"), py::arg("dec"), py::arg("origin"), py::arg("map_size"), py::arg("bce_sigma"),
+           py::arg("occ_level"), py::arg("width"), py::arg("height"), py::arg("sh_degree"), py::arg("two_streams"), py::arg("analytic") = true,
+           py::arg("reference_terms") = true)
       .def("step", &gsdf_extras::JointIteration::step, py::arg("viewmat"), py::arg("K"), py::arg("target"), py::arg("ray_pts"),
-           py::arg("ray_sdf"), py::arg("upstream"), py::arg("update") = true,
+           py::arg("ray_sdf"), py::arg("upstream"), py::arg("update") = true, py::arg("cam_host") = std::vector<float>(),
            py::call_guard<py::gil_scoped_release>())       // step() runs the autograd engine
+      .def("sync", &gsdf_extras::JointIteration::sync)
       .def("splat_flat", &gsdf_extras::JointIteration::splat_flat)
       .def("splat_flat_grad", &gsdf_extras::JointIteration::splat_flat_grad)
       .def("sdf_flat", &gsdf_extras::JointIteration::sdf_flat)
-      .def("sdf_flat_grad", &gsdf_extras::JointIteration::sdf_flat_grad);
+      .def("sdf_flat_grad", &gsdf_extras::JointIteration::sdf_flat_grad)
+      .def("nan_splats_seen", &gsdf_extras::JointIteration::nan_splats_seen);
   py::class_<TCNNEncoding, std::shared_ptr<TCNNEncoding>>(m, "TCNNEncoding")
       .def(py::init([](int n_levels, int n_feat, int log2_hashmap, int base_res, double pls) {
         nlohmann::json cfg = {{"otype", "Grid"}, {"type", "Hash"}, {"n_levels", n_levels}, {"n_features_per_level", n_feat},
@@ -109,11 +114,22 @@ PYBIND11_MODULE(_gsdf_host, m) {
       .def("get_out_dim", &TCNNEncoding::get_out_dim)
       .def_readwrite("params_", &TCNNEncoding::params_);
   py::class_<TCNNNetwork, std::shared_ptr<TCNNNetwork>>(m, "TCNNNetwork")
-      .def(py::init([](int n_in, int n_out, int n_neurons, int n_hidden) {
+      .def(py::init([](int n_in, int n_out, int n_neurons, int n_hidden, bool bias) {
         nlohmann::json cfg = {{"otype", "FullyFusedMLP"}, {"activation", "ReLU"}, {"output_activation", "None"},
-                              {"n_neurons", n_neurons}, {"n_hidden_layers", n_hidden}};
+                              {"n_neurons", n_neurons}, {"n_hidden_layers", n_hidden}, {"bias", bias}};
         return std::make_shared<TCNNNetwork>(n_in, n_out, cfg, "decoder_test");
-      }))
+      }), py::arg("n_in"), py::arg("n_out"), py::arg("n_neurons"), py::arg("n_hidden"), py::arg("bias") = false)
       .def("forward", &TCNNNetwork::forward)
-      .def_readwrite("params_", &TCNNNetwork::params_);
+      .def_readwrite("params_", &TCNNNetwork::params_)
+      .def_readwrite("biases_", &TCNNNetwork::biases_);
+  m.def("joint_sdf_loss_analytic", [](py::object ray_xyz, py::object gt, py::object samples, py::object ids, py::object weights,
+                                      std::shared_ptr<TCNNEncoding> enc, std::shared_ptr<TCNNNetwork> dec, std::vector<float> origin,
+                                      double map_size_inv, double bce_isigma, double w_sdf, double w_gs, double delta, double w_eik, double w_align,
+                                      torch::Tensor table_grad, torch::Tensor decoder_grad, py::object bias_grad) {
+    auto t = [](const py::object &o) { return o.is_none() ? torch::Tensor() : o.cast<torch::Tensor>(); };
+    return gsdf_extras::joint_sdf_loss_analytic(t(ray_xyz), t(gt), t(samples), t(ids), t(weights), *enc, *dec, origin, map_size_inv, bce_isigma,
+                                                w_sdf, w_gs, delta, w_eik, w_align, table_grad, decoder_grad, t(bias_grad));
+  });
+  m.def("normal_consistency_loss", &gsdf_extras::normal_consistency_loss);
+  m.def("isotropic_loss", &gsdf_extras::isotropic_loss);
 }

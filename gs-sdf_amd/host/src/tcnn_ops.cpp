@@ -64,9 +64,20 @@ struct GridBwd : public torch::autograd::Function<GridBwd> {
     Tensor g_vfeat = ctx->needs_input_grad(0) ? torch::empty_like(v_feat) : Tensor();
     Tensor g_x = ctx->needs_input_grad(1) ? torch::empty_like(x) : Tensor();
     Tensor g_table = ctx->needs_input_grad(2) ? torch::zeros_like(table) : Tensor();
-    check(gsdf_hashgrid_bwd_bwd(x.size(0), c.L, c.F, c.H, c.R, c.S, fp(x), fp(table), fp(v_feat), fp(vv), fpm(g_vfeat),
-                                fpm(g_table), fpm(g_x), cur_stream()),
-          "TCNNEncoding double backward");
+    const int64_t B = x.size(0);
+    // large batches: the table part of the double backward through the binned scatter's second-order form (no global atomics)
+    const size_t binned = (g_table.defined() && B >= 24576) ? gsdf_hashgrid_bwd_binned_ws_bytes(B, c.L, c.F, c.H, c.R, c.S) : 0;
+    if (binned) {
+      Tensor ws = empty_like_opts(x, {(int64_t)binned}, torch::kUInt8);
+      check(gsdf_hashgrid_bwd_binned2(B, c.L, c.F, c.H, c.R, c.S, fp(x), nullptr, fp(v_feat), fp(vv), fpm(g_table), ws.data_ptr(), binned,
+                                      cur_stream()), "TCNNEncoding double backward (binned scatter)");
+    }
+    if (g_vfeat.defined() || g_x.defined() || (g_table.defined() && !binned)) {
+      Tensor none;
+      check(gsdf_hashgrid_bwd_bwd(B, c.L, c.F, c.H, c.R, c.S, fp(x), fp(table), fp(v_feat), fp(vv), fpm(g_vfeat),
+                                  binned ? nullptr : fpm(g_table), fpm(g_x), cur_stream()),
+            "TCNNEncoding double backward");
+    }
     return {g_vfeat, g_x, g_table, Tensor(), Tensor()};
   }
 };
@@ -93,40 +104,88 @@ struct GridFwd : public torch::autograd::Function<GridFwd> {
   }
 };
 
+std::vector<int> to_int(const std::vector<int64_t> &v) { return std::vector<int>(v.begin(), v.end()); }
+
+// (v_out, x, w[, b], acts) -> (v_in, v_w, v_b): the decoder's first-order backward as a differentiable operator; its own backward
+// is gsdf_mlp_bwd_bwd (masked bias-free forward for dL/d v_out + the weight-gradient GEMM on (vv_in, masked activations)).
+struct MlpBwd : public torch::autograd::Function<MlpBwd> {
+  static tensor_list forward(AutogradContext *ctx, const Tensor &v_out_, const Tensor &x, const Tensor &w, const Tensor &b_, const Tensor &acts,
+                             std::vector<int64_t> dims64, bool want_w, bool want_b) {
+    const Tensor b = b_.numel() > 0 ? b_ : Tensor();
+    const std::vector<int> dims = to_int(dims64);
+    const int nl = (int)dims.size() - 1;
+    const int64_t B = x.size(0);
+    Tensor v_out = f32c(v_out_, "grad");
+    Tensor v_in = torch::empty_like(x);
+    Tensor ws = empty_like_opts(x, {(int64_t)gsdf_mlp_bwd_ws_bytes(B, nl)}, torch::kUInt8);
+    // the two-kernel form: the per-layer gradients stay in `ws` for the double backward
+    check(gsdf_mlp_bwd(B, nl, dims.data(), fp(w), fp(b), fp(x), fp(acts), fp(v_out), fpm(v_in), nullptr, nullptr, ws.data_ptr(), cur_stream()),
+          "TCNNNetwork backward");
+    Tensor v_w = want_w ? torch::zeros_like(w) : torch::zeros({0}, x.options());
+    Tensor v_b = (want_b && b.defined()) ? torch::zeros_like(b) : torch::zeros({0}, x.options());
+    if (want_w)
+      check(gsdf_mlp_bwd_weights(B, nl, dims.data(), (want_b && b.defined()) ? 1 : 0, fp(x), fp(acts), fp(v_out), ws.data_ptr(), fpm(v_w),
+                                 (want_b && b.defined()) ? fpm(v_b) : nullptr, cur_stream()), "TCNNNetwork backward (weights)");
+    ctx->save_for_backward({v_out, w, acts, ws});
+    ctx->saved_data["dims"] = dims64;
+    ctx->mark_non_differentiable({v_w, v_b});
+    return {v_in, v_w, v_b};
+  }
+  static tensor_list backward(AutogradContext *ctx, tensor_list g) {
+    auto s = ctx->get_saved_variables();
+    const Tensor &v_out = s[0], &w = s[1], &acts = s[2], &ws = s[3];
+    const std::vector<int> dims = to_int(ctx->saved_data["dims"].toIntVector());
+    const int nl = (int)dims.size() - 1;
+    if (!g[0].defined()) return {Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor()};
+    Tensor vv_in = f32c(g[0], "vv_in");
+    const int64_t B = vv_in.size(0);
+    Tensor g_vout = torch::empty_like(v_out);
+    Tensor g_w = ctx->needs_input_grad(2) ? torch::zeros_like(w) : Tensor();
+    Tensor ws2 = empty_like_opts(vv_in, {(int64_t)gsdf_mlp_bwd_bwd_ws_bytes(B, nl)}, torch::kUInt8);
+    check(gsdf_mlp_bwd_bwd(B, nl, dims.data(), fp(w), fp(acts), fp(v_out), ws.data_ptr(), fp(vv_in), fpm(g_vout), fpm(g_w), ws2.data_ptr(),
+                           cur_stream()), "TCNNNetwork double backward");
+    return {ctx->needs_input_grad(0) ? g_vout : Tensor(), Tensor(), g_w, Tensor(), Tensor(), Tensor(), Tensor(), Tensor()};
+  }
+};
+
 struct MlpFn : public torch::autograd::Function<MlpFn> {
-  static Tensor forward(AutogradContext *ctx, const Tensor &x_, const Tensor &w_, std::vector<int64_t> dims64) {
+  static Tensor forward(AutogradContext *ctx, const Tensor &x_, const Tensor &w_, const Tensor &b_, std::vector<int64_t> dims64) {
     Tensor x = f32c(x_, "x"), w = f32c(w_, "params");
-    std::vector<int> dims(dims64.begin(), dims64.end());
+    Tensor b = (b_.defined() && b_.numel() > 0) ? f32c(b_, "biases") : Tensor();     // an empty tensor stands for "no biases"
+    const std::vector<int> dims = to_int(dims64);
     const int nl = (int)dims.size() - 1;
     const int64_t B = x.size(0);
     Tensor out = empty_like_opts(x, {B, dims.back()}, torch::kFloat32);
-    const bool need = x.requires_grad() || w.requires_grad();
+    const bool need = x.requires_grad() || w.requires_grad() || (b.defined() && b.requires_grad());
     Tensor acts = need ? empty_like_opts(x, {(int64_t)gsdf_mlp_acts_floats(B, nl)}, torch::kFloat32) : Tensor();
-    check(gsdf_mlp_fwd(B, nl, dims.data(), fp(w), nullptr, fp(x), fpm(out), fpm(acts), cur_stream()), "TCNNNetwork forward");
-    ctx->save_for_backward({x, w, acts});
+    check(gsdf_mlp_fwd(B, nl, dims.data(), fp(w), fp(b), fp(x), fpm(out), fpm(acts), cur_stream()), "TCNNNetwork forward");
+    ctx->save_for_backward({x, w, acts.defined() ? acts : torch::empty({0}, x.options()), b.defined() ? b : torch::empty({0}, x.options())});
     ctx->saved_data["dims"] = dims64;
     return out;
   }
   static tensor_list backward(AutogradContext *ctx, tensor_list g) {
-    // first order only, like tcnn's FullyFusedMLP: the reference forces numerical_grad with this decoder
-    // (params.cpp:396-399).  Under create_graph the result would silently be treated as constant: refuse instead.
-    TORCH_CHECK(!(torch::GradMode::is_enabled() && g[0].defined() && g[0].requires_grad()),
-                "TCNNNetwork: double backward through the fused MLP is not implemented (use numerical_grad, as the reference "
-                "does with decoder_implementation 1)");
     auto s = ctx->get_saved_variables();
+    const Tensor &x = s[0], &w = s[1], &acts = s[2];
+    const Tensor b = s[3].numel() > 0 ? s[3] : Tensor();
     auto dims64 = ctx->saved_data["dims"].toIntVector();
-    std::vector<int> dims(dims64.begin(), dims64.end());
+    const bool want_w = ctx->needs_input_grad(1), want_b = b.defined() && ctx->needs_input_grad(2);
+    if (torch::GradMode::is_enabled()) {
+      // create_graph = true (LocalMap::get_gradient's analytic branch, local_map.cpp:151-172): the backward as a differentiable op
+      auto o = MlpBwd::apply(g[0], x, w, b.defined() ? b : torch::empty({0}, x.options()), acts, dims64, want_w, want_b);
+      return {ctx->needs_input_grad(0) ? o[0] : Tensor(), want_w ? o[1] : Tensor(), want_b ? o[2] : Tensor(), Tensor()};
+    }
+    const std::vector<int> dims = to_int(dims64);
     const int nl = (int)dims.size() - 1;
-    const int64_t B = s[0].size(0);
+    const int64_t B = x.size(0);
     Tensor v_out = f32c(g[0], "grad");
-    Tensor v_in = ctx->needs_input_grad(0) ? torch::empty_like(s[0]) : Tensor();
-    Tensor v_w = ctx->needs_input_grad(1) ? torch::zeros_like(s[1]) : Tensor();
+    Tensor v_in = ctx->needs_input_grad(0) ? torch::empty_like(x) : Tensor();
+    Tensor v_w = want_w ? torch::zeros_like(w) : Tensor();
+    Tensor v_b = want_b ? torch::zeros_like(b) : Tensor();
     // 0 bytes when both gradients are requested and the one-pass backward covers the topology
-    Tensor ws = empty_like_opts(s[0], {(int64_t)gsdf_mlp_bwd_ws_bytes_for(B, nl, dims.data(), v_w.defined() ? 1 : 0)}, torch::kUInt8);
-    check(gsdf_mlp_bwd(B, nl, dims.data(), fp(s[1]), nullptr, fp(s[0]), fp(s[2]), fp(v_out), fpm(v_in), fpm(v_w), nullptr,
-                       ws.data_ptr(), cur_stream()),
+    Tensor ws = empty_like_opts(x, {(int64_t)gsdf_mlp_bwd_ws_bytes_for(B, nl, dims.data(), v_w.defined() ? 1 : 0)}, torch::kUInt8);
+    check(gsdf_mlp_bwd(B, nl, dims.data(), fp(w), fp(b), fp(x), fp(acts), fp(v_out), fpm(v_in), fpm(v_w), fpm(v_b), ws.data_ptr(), cur_stream()),
           "TCNNNetwork backward");
-    return {v_in, v_w, Tensor()};
+    return {v_in, v_w, v_b, Tensor()};
   }
 };
 }  // namespace
@@ -194,9 +253,17 @@ TCNNNetwork::TCNNNetwork(int n_input_dims, int n_output_dims, const nlohmann::js
   params_ = torch::cat(ws);
   if (torch::cuda::is_available()) params_ = params_.to(torch::kCUDA);
   params_.set_requires_grad(true);
+  if (config.value("bias", false)) {   // torch::nn::Linear's bias initialisation: U(-1/sqrt(fan_in), 1/sqrt(fan_in))
+    std::vector<Tensor> bs;
+    for (size_t l = 0; l + 1 < dims_.size(); ++l)
+      bs.push_back((torch::rand({(int64_t)dims_[l + 1]}) * 2.0f - 1.0f) * (1.0f / std::sqrt((float)dims_[l])));
+    biases_ = torch::cat(bs);
+    if (torch::cuda::is_available()) biases_ = biases_.to(torch::kCUDA);
+    biases_.set_requires_grad(true);
+  }
 }
 
 torch::Tensor TCNNNetwork::forward(const torch::Tensor &x) {
   TORCH_CHECK(x.dim() == 2 && x.size(1) == dims_[0], "TCNNNetwork::forward: expected [B,", dims_[0], "]");
-  return MlpFn::apply(x, params_, std::vector<int64_t>(dims_.begin(), dims_.end()));
+  return MlpFn::apply(x, params_, biases_.defined() ? biases_ : torch::empty({0}, params_.options()), std::vector<int64_t>(dims_.begin(), dims_.end()));
 }

@@ -1,7 +1,7 @@
 // tcnn_binding/tcnn_binding.h — drop-in for the reference's submodule header
 // (/root/reference/include/neural_net/encoding_map.h:4, encodings/encodings.h:5, local_map.cpp:44-55).
 // `TCNNEncoding`: multiresolution hash grid (tiny-cuda-nn "Grid"/"Hash"/"Linear") with first and second order
-// autograd; `TCNNNetwork`: FullyFusedMLP (ReLU, no output activation) on the fp32 MFMA pipe.
+// autograd; `TCNNNetwork`: FullyFusedMLP (ReLU, no output activation) on the MFMA pipes, first and second order.
 // `params_` is a plain fp32 leaf tensor the caller registers as an nn parameter (local_map.cpp:53-54,73-75).
 #pragma once
 #include <torch/torch.h>
@@ -35,11 +35,15 @@ struct TCNNEncoding {
   std::vector<int64_t> offsets_;  // entry offsets per level
 };
 
+// First AND second order autograd (the analytic eikonal term of the reference's default configuration differentiates
+// d sdf / d features again, local_map.cpp:151-172).  Config key "bias": true (NOT in tiny-cuda-nn; default false) adds per-layer
+// biases `biases_` — the topology of the reference's torch::nn::Sequential decoder (local_map.cpp:29-42) on the fused kernels.
 struct TCNNNetwork {
   TCNNNetwork(int n_input_dims, int n_output_dims, const nlohmann::json &config, const std::string &name);
   torch::Tensor forward(const torch::Tensor &x);
 
   torch::Tensor params_;
+  torch::Tensor biases_;   // undefined for the bias-free FullyFusedMLP
   std::string name_;
   std::vector<int> dims_;
 };

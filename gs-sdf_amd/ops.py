@@ -359,9 +359,50 @@ class _NormalConsistency(torch.autograd.Function):
 def normal_consistency_loss(depth, alpha, render_normal, fx, fy, cx, cy, pose_cam2world):
     """mean(alpha^2 - nan_to_num((depth_to_normal(depth) * alpha) . render_normal)) with alpha detached
     (neural_mapping.cpp:243-266; cameras.hpp:176-226).  depth, alpha [H,W,1]; render_normal [H,W,3] (world);
-    pose_cam2world [3,4] (host values are baked into the launch)."""
-    pose = [float(v) for v in pose_cam2world.detach().cpu().reshape(-1)[:12]]
+    pose_cam2world [3,4] tensor or 12 host floats (row-major; the values are baked into the launch)."""
+    # a tensor costs a device->host copy per call; a trainer that knows its poses ahead passes the 12 host floats
+    pose = [float(v) for v in (pose_cam2world.detach().cpu().reshape(-1)[:12] if torch.is_tensor(pose_cam2world) else pose_cam2world)]
     return _NormalConsistency.apply(depth, alpha, render_normal, (float(fx), float(fy), float(cx), float(cy)), tuple(pose))
+
+
+class _Isotropic(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, scales, gaussian_ids):
+        L = capi.lib()
+        scales, ids = scales.contiguous(), gaussian_ids.contiguous()
+        loss = torch.empty((), dtype=torch.float32, device=scales.device)
+        capi.check(_timed("isotropic_loss", L.gsdf_isotropic_loss_fwd, ids.shape[0], f32(scales), ptr(ids, torch.int64), f32(loss),
+                          capi.stream()), "isotropic_loss_fwd")
+        ctx.save_for_backward(scales, ids)
+        return loss
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, v_loss):
+        scales, ids = ctx.saved_tensors
+        v_scales = torch.zeros_like(scales)
+        capi.check(_timed("isotropic_loss_bwd", capi.lib().gsdf_isotropic_loss_bwd, ids.shape[0], f32(scales), ptr(ids, torch.int64),
+                          f32(v_loss.contiguous().reshape(1)), f32(v_scales), capi.stream()), "isotropic_loss_bwd")
+        return v_scales, None
+
+
+def isotropic_loss(scales, gaussian_ids):
+    """(scale - scale.mean(-1, True)).abs().mean() with scale = scales[gaussian_ids][:, 0:2] (neural_mapping.cpp:268-276);
+    scales [N,3] (activated), gaussian_ids int64 [M]."""
+    if scales.dim() != 2 or scales.shape[1] != 3:
+        raise RuntimeError("isotropic_loss: scales must be [N,3]")
+    return _Isotropic.apply(scales, gaussian_ids)
+
+
+@torch.no_grad()
+def nan_rows(offsets, scaling, quaternion, want_mask=False):
+    """prune_nan_gs's test (neural_gaussian.cpp:907-916) in one launch -> (count int32 device scalar [1], mask bool [N] or None)."""
+    n = offsets.shape[0]
+    count = torch.empty(1, dtype=torch.int32, device=offsets.device)
+    mask = torch.empty(n, dtype=torch.uint8, device=offsets.device) if want_mask else None
+    capi.check(_timed("nan_rows", capi.lib().gsdf_nan_rows, n, f32(offsets.contiguous()), f32(scaling.contiguous()),
+                      f32(quaternion.contiguous()), ptr(count), ptr(mask), capi.stream()), "nan_rows")
+    return count, (None if mask is None else mask.bool())
 
 
 @torch.no_grad()

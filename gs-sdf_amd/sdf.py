@@ -597,29 +597,35 @@ class _CouplingLeg(torch.autograd.Function):
 
 
 class _SdfBatchAnalytic(torch.autograd.Function):
-    """One SDF batch of the reference's DEFAULT configuration (decoder_implementation 0 / numerical_grad 0, config/base.yaml:12-13)
-    as ONE autograd node on the fused kernels, first and second order:
-        data term   mode "ray": w_data * loss::sdf_loss(get_sdf(xyz), gt)                 (neural_mapping.cpp:165-170)
-                    mode "gs" : w_data * loss::gs_sdf_loss(get_sdf(samples[ids]), w[ids])  (:436-457; d/d samples returned)
-        + w_eik * loss::eikonal_loss(g),  g = autograd.grad(sdf, xyz, create_graph=True)    (local_map.cpp:151-172; in "gs" mode on
-                                                                                            samples.detach(), :448-451)
-        + w_align * mean |g - get_gradient(xyz, delta, numerical).detach()|                (neural_mapping.cpp:126-134)
+    """The SDF work of one joint iteration in the reference's DEFAULT configuration (decoder_implementation 0 / numerical_grad 0,
+    config/base.yaml:12-13) as ONE autograd node on the fused kernels, first and second order.  One batch holds both point sets:
+        rows [0, n_ray)  per-ray batch:   w_sdf * loss::sdf_loss(get_sdf(xyz), gt)                     (neural_mapping.cpp:165-170)
+        rows [n_ray, n)  splat samples:   w_gs * loss::gs_sdf_loss(get_sdf(samples[ids]), w[ids])      (:436-457; d/d samples returned)
+        each set:  + w_eik * loss::eikonal_loss(g),  g = autograd.grad(sdf, xyz, create_graph=True)     (local_map.cpp:151-172; the splat
+                                                                                                         samples detached, :448-451)
+                   + w_align * mean |g - get_gradient(xyz, delta, numerical).detach()|                 (neural_mapping.cpp:126-134)
     forward : query points (+ 6 stencil rows for the align term) -> encoder (+ Jacobian of the base rows) -> decoder (activations
               saved for the base rows only; the stencil rows are forward-only) -> decoder backward of e_0 (g0 = d sdf / d features,
               its per-layer gradients kept) -> ONE loss launch (value, d/d decoder output, dL/d(J^T g0), dL/d g0)
-    backward: one-pass decoder backward of the data term; decoder DOUBLE backward (gsdf_mlp_bwd_bwd); ONE binned scatter that
-              carries the first-order and the second-order table gradient of every corner (gsdf_hashgrid_bwd_binned2); in "gs"
-              mode d/dx of the data term from the Jacobian.
+    backward: one-pass decoder backward of the data terms; decoder DOUBLE backward (gsdf_mlp_bwd_bwd); ONE binned scatter that
+              carries the first-order and the second-order table gradient of every corner (gsdf_hashgrid_bwd_binned2); d/dx of
+              the splat samples' data term from the Jacobian.
     Parameter gradients accumulate in place (LocalMap.flatten(accumulate_table_grad_in_place=True) + grad_sinks_armed())."""
 
     @staticmethod
-    def forward(ctx, samples, ids, aux, lm, mode, w_data, delta, w_eik, w_align, _anchor):
-        # _anchor = the encoder's parameter tensor: makes the node part of the graph when `samples` carries no gradient (ray
-        # batch); its gradient is deposited in the sink, autograd gets None
+    def forward(ctx, ray_xyz, gt_sdf, samples, ids, weights, lm, w_sdf, w_gs, delta, w_eik, w_align, _anchor):
+        # _anchor = the encoder's parameter tensor: makes the node part of the graph when no input carries a gradient (ray
+        # batch alone); its gradient is deposited in the sink, autograd gets None
         L = capi.lib()
         enc, dec = lm.encoder, lm.decoder
         cfg, dims = enc.cfg, tuple(dec.dims)
-        xs = samples.detach().contiguous() if ids is None else samples.detach().index_select(0, ids)
+        parts = []
+        if ray_xyz is not None and ray_xyz.shape[0] > 0:
+            parts.append(ray_xyz.detach().reshape(-1, 3))
+        n_ray = parts[0].shape[0] if parts else 0
+        if samples is not None:
+            parts.append(samples.detach().reshape(-1, 3) if ids is None else samples.detach().index_select(0, ids))
+        xs = (parts[0] if len(parts) == 1 else torch.cat(parts, 0)).contiguous()
         n, dev = xs.shape[0], xs.device
         stencil = bool(w_align != 0.0) and n > 0
         K = 7 if stencil else 1
@@ -656,15 +662,15 @@ class _SdfBatchAnalytic(torch.autograd.Function):
         v_attr = torch.empty(n, dims[-1], dtype=torch.float32, device=dev)
         vv_x = torch.empty(n, 3, dtype=torch.float32, device=dev)
         u0 = torch.empty(n, nf, dtype=torch.float32, device=dev)
-        gs = mode == "gs"
-        aux_c = aux.contiguous().reshape(-1)
-        capi.check(_timed("sdf_analytic_loss", L.gsdf_sdf_analytic_loss, n, int(gs), int(stencil), f32(attr), attr.shape[1], f32(g0), nf,
-                          f32(jac), None if gs else f32(aux_c), f32(aux_c) if gs else None,
-                          ptr(ids, torch.int64) if (gs and ids is not None) else None, float(lm.bce_isigma), float(w_data),
-                          float(lm.map_size_inv), float(delta or 0.0), float(w_eik), float(w_align), f32(loss), f32(v_attr), f32(vv_x),
-                          f32(u0), capi.stream()), "sdf_analytic_loss")
+        gt_c = None if n_ray == 0 else gt_sdf.contiguous().reshape(-1)
+        w_c = None if n == n_ray else weights.contiguous().reshape(-1)
+        capi.check(_timed("sdf_analytic_loss", L.gsdf_sdf_analytic_loss, n, n_ray, int(stencil), f32(attr), attr.shape[1], f32(g0), nf,
+                          f32(jac), f32(gt_c), f32(w_c), ptr(ids, torch.int64) if (n > n_ray and ids is not None) else None,
+                          float(lm.bce_isigma), float(w_sdf), float(w_gs), float(lm.map_size_inv), float(delta or 0.0), float(w_eik),
+                          float(w_align), f32(loss), f32(v_attr), f32(vv_x), f32(u0), capi.stream()), "sdf_analytic_loss")
         ctx.save_for_backward(ids, x01, feat, jac, acts, bws, e0, g0, v_attr, vv_x, u0)
-        ctx.lm, ctx.n, ctx.n_rows, ctx.gs = lm, n, samples.shape[0], gs
+        ctx.lm, ctx.n, ctx.n_ray = lm, n, n_ray
+        ctx.n_rows = 0 if samples is None else samples.shape[0]
         return loss
 
     @staticmethod
@@ -675,20 +681,21 @@ class _SdfBatchAnalytic(torch.autograd.Function):
                                "parameter gradients in place)")
         L = capi.lib()
         ids, x01, feat, jac, acts, bws, e0, g0, v_attr, vv_x, u0 = ctx.saved_tensors
-        lm, n = ctx.lm, ctx.n
+        lm, n, n_ray = ctx.lm, ctx.n, ctx.n_ray
         enc, dec = lm.encoder, lm.decoder
         cfg, dims = enc.cfg, tuple(dec.dims)
         nl = len(dims) - 1
         dims_c = (C.c_int * len(dims))(*dims)
         dev = x01.device
-        want_x = ctx.gs and ctx.needs_input_grad[0]
+        want_x = ctx.needs_input_grad[2] and n > n_ray
+        none = (None,) * 9
         if n == 0:
-            return (torch.zeros(ctx.n_rows, 3, device=dev) if want_x else None), None, None, None, None, None, None, None, None, None
+            return (None, None, (torch.zeros(ctx.n_rows, 3, device=dev) if ctx.needs_input_grad[2] else None)) + none
         fb, xb = feat[:n], x01[:n]
         v_out = (v_attr * v_loss).contiguous()
         v_feat = torch.empty(n, cfg[0] * cfg[1], dtype=torch.float32, device=dev)
         w_sink, b_sink = dec.grad_sinks
-        # first order: data term through the decoder (one pass: input + parameter gradients)
+        # first order: data terms through the decoder (one pass: input + parameter gradients)
         ws = torch.empty(L.gsdf_mlp_bwd_ws_bytes_for(n, nl, dims_c, 1), dtype=torch.uint8, device=dev)
         capi.check(_timed("mlp_bwd", L.gsdf_mlp_bwd, n, nl, dims_c, f32(dec.params_), f32(dec.biases_), f32(fb), f32(acts), f32(v_out),
                           f32(v_feat), f32(w_sink), f32(b_sink), ptr(ws) if ws.numel() else None, capi.stream()), "mlp_bwd")
@@ -699,9 +706,10 @@ class _SdfBatchAnalytic(torch.autograd.Function):
         capi.check(_timed("mlp_bwd_bwd", L.gsdf_mlp_bwd_bwd, n, nl, dims_c, f32(dec.params_), f32(acts), f32(e0), ptr(bws), f32(vv_in),
                           f32(g_vout), f32(w_sink), ptr(ws2), capi.stream()), "mlp_bwd_bwd")
         v_samples = None
-        if want_x:   # d (data term) / d samples from the Jacobian of the base rows (the regularisers see samples.detach())
-            v_x = torch.empty(n, 3, dtype=torch.float32, device=dev)
-            capi.check(_timed("hashgrid_bwd_input", L.gsdf_hashgrid_bwd_jac, n, cfg[0], cfg[1], f32(jac), f32(v_feat), f32(v_x),
+        if want_x:   # d (data term) / d samples from the Jacobian of the splat rows (the regularisers see samples.detach())
+            ng = n - n_ray
+            v_x = torch.empty(ng, 3, dtype=torch.float32, device=dev)
+            capi.check(_timed("hashgrid_bwd_input", L.gsdf_hashgrid_bwd_jac, ng, cfg[0], cfg[1], f32(jac[n_ray:]), f32(v_feat[n_ray:]), f32(v_x),
                               capi.stream()), "hashgrid_bwd_jac")
             v_samples = torch.zeros(ctx.n_rows, 3, dtype=torch.float32, device=dev)
             if ids is None:
@@ -734,7 +742,7 @@ class _SdfBatchAnalytic(torch.autograd.Function):
                 scatter()
             for t in (v_feat, x01, g0, vvx):
                 t.record_stream(enc.scatter_stream)
-        return v_samples, None, None, None, None, None, None, None, None, None
+        return (None, None, v_samples) + none
 
 
 class LocalMap:
@@ -914,14 +922,20 @@ class LocalMap:
         """The per-ray batch of the reference's DEFAULT configuration (neural_mapping.cpp:138-188 with numerical_grad 0):
         w_sdf * sdf_loss(get_sdf(xyz)) + w_eik * eikonal_loss(analytic gradient) + w_align * |analytic - numerical.detach()|.mean(),
         one autograd node (_SdfBatchAnalytic)."""
-        self._analytic_ready()
-        return _SdfBatchAnalytic.apply(xyz, None, gt_sdf, self, "ray", w_sdf, delta, w_eik, w_align, self.encoder.params_)
+        return self.joint_sdf_loss_analytic(xyz, gt_sdf, None, None, None, delta, w_sdf, 0.0, w_eik, w_align)
 
     def gs_sdf_coupling_analytic(self, samples, ids, weights, scale=1.0, delta=None, w_eik=0.0, w_align=0.0):
         """The GS<->SDF block of the DEFAULT configuration (neural_mapping.cpp:420-462): scale * gs_sdf_loss(get_sdf(samples[ids]),
         weights[ids]) + sdf_regularization(samples[ids].detach()) with the ANALYTIC gradient (eikonal + align), one autograd node."""
+        return self.joint_sdf_loss_analytic(None, None, samples, ids, weights, delta, 0.0, scale, w_eik, w_align)
+
+    def joint_sdf_loss_analytic(self, ray_xyz, gt_sdf, samples, ids, weights, delta, w_sdf=1.0, w_gs=1e-3, w_eik=0.1, w_align=0.1):
+        """ray_loss_analytic(ray_xyz, gt_sdf) + gs_sdf_coupling_analytic(samples, ids, weights) as ONE batch through the encoder /
+        decoder / scatter (the SDF work of a whole joint iteration in ~12 launches); either part may be None."""
         self._analytic_ready()
-        return _SdfBatchAnalytic.apply(samples, ids, weights, self, "gs", scale, delta, w_eik, w_align, self.encoder.params_)
+        if ray_xyz is None and samples is None:
+            raise RuntimeError("joint_sdf_loss_analytic: no points")
+        return _SdfBatchAnalytic.apply(ray_xyz, gt_sdf, samples, ids, weights, self, w_sdf, w_gs, delta, w_eik, w_align, self.encoder.params_)
 
     def ray_loss(self, xyz, gt_sdf, delta, w_eik):
         """sdf_loss(get_sdf(xyz)) + w_eik * eikonal_loss(get_gradient(xyz, delta, numerical)) of the per-ray batch

@@ -316,13 +316,15 @@ int gsdf_gs_sdf_eik_loss(int64_t n, int stencil, const float *attr, int ld, cons
  *     ANALYTIC gradient g = map_size_inv * J^T g0 (LocalMap::get_gradient's autograd branch, local_map.cpp:151-172; g0 [n,32] =
  *     d sdf / d features from gsdf_mlp_bwd with v_out = (1, 0), jac [n,32,3] from gsdf_hashgrid_fwd_jac_rows) plus the align term
  *     w_align * mean |g - g_num.detach()| against the central differences of the stencil rows (neural_mapping.cpp:126-134),
- *     on top of the data term: mode 0 = scale * loss::sdf_loss against gt_sdf (per-ray batch), mode 1 = scale *
- *     loss::gs_sdf_loss with weights[ids[i]] (GS<->SDF coupling).  attr [(stencil ? 7 : 1) n, ld].
+ *     on top of the data terms of ONE batch that holds both of the iteration's point sets: rows [0, n_ray) = the per-ray batch,
+ *     w_sdf * loss::sdf_loss against gt_sdf [n_ray]; rows [n_ray, n) = the visible splats' samples, w_gs * loss::gs_sdf_loss with
+ *     weights[ids[i - n_ray]] (ids NULL: weights[i - n_ray]).  The regularisers are means over each set separately, as the two
+ *     sdf_regularization calls of the iteration are (neural_mapping.cpp:183-186, 448-451).  attr [(stencil ? 7 : 1) n, ld].
  *     Outputs: loss[0]; v_attr [n, ld] = d loss / d attr of the BASE rows (the stencil rows are detached); vv_x [n,3] =
  *     d loss / d (J^T g0); u0 [n,32] = J vv_x = d loss / d g0. */
-int gsdf_sdf_analytic_loss(int64_t n, int mode, int stencil, const float *attr, int ld, const float *g0, int n_feat,
+int gsdf_sdf_analytic_loss(int64_t n, int64_t n_ray, int stencil, const float *attr, int ld, const float *g0, int n_feat,
                            const float *jac, const float *gt_sdf, const float *weights, const int64_t *ids, float bce_isigma,
-                           float scale, float map_size_inv, float delta, float w_eik, float w_align, float *loss,
+                           float w_sdf, float w_gs, float map_size_inv, float delta, float w_eik, float w_align, float *loss,
                            float *v_attr, float *vv_x, float *u0, gsdf_stream_t stream);
 int gsdf_sdf_ray_loss(int64_t n, int stencil, const float *attr, int ld, const float *gt_sdf, float bce_isigma,
                       float delta, float w_eik, float *loss, float *v_attr, gsdf_stream_t stream);
@@ -394,6 +396,17 @@ int gsdf_splat_activations_fwd(int64_t n, const float *anchors, const float *off
 int gsdf_splat_activations_bwd(int64_t n, const float *scales, const float *opacities, const float *v_xyz,
                                const float *v_scales, const float *v_opacities, float *g_offsets, float *g_log_scales,
                                float *g_logit_opacities, gsdf_stream_t stream);
+
+/* isotropic regulariser of the visible splats (include/neural_mapping/neural_mapping.cpp:268-276):
+ *     loss[0] = mean over [M,2] of |scale - mean(scale, -1)| with scale = scales[gaussian_ids][:, 0:2]  (= sum |s_u - s_v| / 2M);
+ *     bwd ACCUMULATES v_loss[0] * d loss / d scales into v_scales [N,3]. */
+int gsdf_isotropic_loss_fwd(int64_t n_visible, const float *scales, const int64_t *gaussian_ids, float *loss, gsdf_stream_t stream);
+int gsdf_isotropic_loss_bwd(int64_t n_visible, const float *scales, const int64_t *gaussian_ids, const float *v_loss, float *v_scales,
+                            gsdf_stream_t stream);
+/* NeuralGS::prune_nan_gs's per-iteration test (include/neural_gaussian/neural_gaussian.cpp:907-916): count[0] = number of splats
+ * with a NaN in offsets [n,3] / scaling [n,3] / quaternion [n,4]; mask u8 [n] (optional) marks them. */
+int gsdf_nan_rows(int64_t n, const float *offsets, const float *scaling, const float *quaternion, int32_t *count, uint8_t *mask,
+                  gsdf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * a8  NeuralGS::update_state (include/neural_gaussian/neural_gaussian.cpp:626-680) in one launch: the densification

@@ -24,12 +24,12 @@ def _bench(args, env=None, launcher=()):
     return r.stdout
 
 
-@pytest.mark.parametrize("workload", ["cfg0_10k_256", "cfg1_replica_300k"])
-def test_overlapped_step_gives_the_single_stream_gradients(tmp_path, workload):
+@pytest.mark.parametrize("workload,cfg", [("cfg0_10k_256", "default"), ("cfg1_replica_300k", "default"), ("cfg1_replica_300k", "tcnn")])
+def test_overlapped_step_gives_the_single_stream_gradients(tmp_path, workload, cfg):
     out = {}
     for mode, flags in (("serial", ["--no-overlap"]), ("overlap", []), ("overlap3", ["--scatter-xcds", "3"])):
         path = str(tmp_path / f"{mode}.pt")
-        _bench(["--workload", workload, "--dump-grads", path, *flags])
+        _bench(["--workload", workload, "--dump-grads", path, "--sdf-config", cfg, *flags])
         out[mode] = torch.load(path)
     ref = out["serial"]
     assert ref["sizes"]["n_gs_sdf"] > 0 and float(ref["splat"].abs().sum()) > 0 and float(ref["sdf"][0].abs().sum()) > 0
@@ -89,15 +89,18 @@ def test_two_ranks_view_parallel_step_runs():
     assert j["n_gpus"] == 2 and j["value"] > 0 and j["scaling"] == "weak"
 
 
-@pytest.mark.parametrize("workload", ["cfg0_10k_256", "cfg1_replica_300k"])
-def test_cpp_joint_iteration_gives_the_python_step_gradients(tmp_path, workload):
+@pytest.mark.parametrize("workload,cfg", [("cfg0_10k_256", ["--sdf-config", "default", "--step-terms", "reference"]),
+                                          ("cfg1_replica_300k", ["--sdf-config", "default", "--step-terms", "reference"]),
+                                          ("cfg1_replica_300k", ["--sdf-config", "tcnn", "--step-terms", "round2"])])
+def test_cpp_joint_iteration_gives_the_python_step_gradients(tmp_path, workload, cfg):
     """gsdf_extras::JointIteration (host/src/joint_step.cpp: the loop body of neural_mapping.cpp:400-486 in C++/libtorch on the drop-in
-    operators + gsdf_extras) against the Python step of bench.py on the same scene, view, ray batch and op-level gradients:
+    operators + gsdf_extras) against the Python step of bench.py on the same scene, view, ray batch and loss terms — the reference's
+    default configuration (analytic eikonal + align, normal consistency, isotropic) and the tcnn / numerical one:
     same visible set, same intersections, same flat gradients of both parameter families."""
     out = {}
     for mode, flags in (("python", ["--no-overlap"]), ("cpp one stream", ["--cpp-step", "--no-overlap"]), ("cpp two streams", ["--cpp-step"])):
         path = str(tmp_path / f"{mode.replace(' ', '_')}.pt")
-        _bench(["--workload", workload, "--dump-grads", path, *flags])
+        _bench(["--workload", workload, "--dump-grads", path, *cfg, *flags])
         out[mode] = torch.load(path)
     ref = out["python"]
     assert float(ref["splat"].abs().sum()) > 0 and float(ref["sdf"][0].abs().sum()) > 0

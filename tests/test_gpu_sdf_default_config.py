@@ -127,3 +127,31 @@ def test_fused_default_batch_matches_the_reference_composition(sdf, mode, nn):
     assert_close(lm.decoder.params_.grad, w_ref, 1e-4, "decoder weight gradient (first + second order)", outlier_frac=5e-4)
     assert_close(lm.decoder.biases_.grad, b_ref, 1e-4, "decoder bias gradient", outlier_frac=5e-3)
     assert float(grp.flat_grad.abs().sum()) > 0
+
+
+def test_merged_batch_equals_the_two_batches(sdf):
+    """joint_sdf_loss_analytic(ray, samples) = ray_loss_analytic + gs_sdf_coupling_analytic (one encoder / decoder / scatter
+    pass instead of two): same loss, same parameter gradients, same d/d samples."""
+    dev = torch.device("cuda:0")
+    res = []
+    for merged in (False, True):
+        lm = sdf.LocalMap([0.1, -0.2, 0.3], 4.0, bce_sigma=0.02, decoder_implementation=0, device=dev, seed=6)
+        with torch.no_grad():
+            lm.encoder.params_.copy_(((torch.rand(lm.encoder.params_.numel(), generator=torch.Generator().manual_seed(1)) * 2 - 1) * 0.05).to(dev))
+        grp = lm.flatten(accumulate_table_grad_in_place=True)
+        gg = torch.Generator().manual_seed(9)
+        ray = ((torch.rand(30000, 3, generator=gg) - 0.5) * 3.6).to(dev)
+        gt = (torch.randn(30000, 1, generator=gg) * 0.05).to(dev)
+        samples = ((torch.rand(50000, 3, generator=gg) - 0.5) * 3.6).to(dev).requires_grad_(True)
+        ids = torch.randperm(50000, generator=gg)[:41000].sort().values.to(dev)
+        w = torch.rand(50000, 1, generator=gg).to(dev)
+        with sdf.grad_sinks_armed():
+            if merged:
+                loss = lm.joint_sdf_loss_analytic(ray, gt, samples, ids, w, 0.02, 1.0, 1e-2, 0.1, 0.1)
+            else:
+                loss = lm.ray_loss_analytic(ray, gt, 0.02, 1.0, 0.1, 0.1) + lm.gs_sdf_coupling_analytic(samples, ids, w, 1e-2, 0.02, 0.1, 0.1)
+            loss.backward()
+        res.append((float(loss.detach()), grp.flat_grad.clone(), samples.grad.clone()))
+    assert abs(res[0][0] - res[1][0]) <= 1e-6 * abs(res[0][0])
+    assert_close(res[1][1], res[0][1], 1e-5, "flat SDF gradient, merged batch vs two batches")
+    assert_close(res[1][2], res[0][2], 1e-6, "d loss / d samples")
