@@ -79,6 +79,10 @@ def main():
                          "depth->normal consistency, isotropic_weight 0.05, prune_nan test); round2 = the round-2 step (L1 + D-SSIM and "
                          "1e-6 N(0,1) op-level gradients on depth / alpha / normal / median)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the extra lines (other SDF configuration, zero-edit loop, C++ step)")
+    ap.add_argument("--step-impl", default="cpp", choices=["cpp", "python"],
+                    help="who issues the step: cpp = gsdf_extras::JointIteration (C++/libtorch over libgsdf_torch.so: the host language of the "
+                         "reference, the step its node reaches with the INTEGRATION.md section 5 edits; THE HEADLINE), python = the Python "
+                         "mirror of the same operators (tests, and the secondary line `python_mirror_step`)")
     ap.add_argument("--cpp-step", action="store_true",
                     help="time gsdf_extras::JointIteration (the same joint iteration in C++/libtorch over libgsdf_torch.so, one stream, driven "
                          "through the pybind test harness): the step the reference's node reaches with the INTEGRATION.md section 5 edits")
@@ -144,8 +148,18 @@ def main():
     if args.cpp_step:
         print(json.dumps(cpp_step(args, sc, views, K, ug6, target, N, W, H, deg, dev)), flush=True)
         return
+    impl = "python" if (args.no_sdf or args.scatter_xcds > 0) else args.step_impl     # the splat-only / CU-mask experiments exist in the mirror only
+    ji = None
+    if impl == "cpp":
+        ji, cpp_pool, cpp_ray_sdf, cpp_cams, dec_dims = make_cpp_iteration(args, sc, params, dev, W, H, deg, views)
+        cpp_up = [] if args.step_terms == "reference" else [ug6[k] for k in ("v_render_depths", "v_render_alphas", "v_render_normals", "v_render_median")]
+        if dist is not None:      # view-parallel: one collective per parameter family, on the stream its optimizer runs on
+            def _mean_over_ranks(g):
+                dist.all_reduce(g)
+                g.mul_(1.0 / world)
+            ji.set_grad_hooks(_mean_over_ranks, _mean_over_ranks)
     groups = []
-    if not args.no_sdf:
+    if not args.no_sdf and impl == "python":
         # hash-grid SDF (2^19 table, 16 levels x 2) + fused MFMA decoder; the reference's numerical-gradient
         # configuration (params.cpp:396-399 forces it for the tcnn decoder); ray batch 32768 (base.yaml:24)
         import gs_sdf_amd.sdf as sdfm
@@ -178,10 +192,10 @@ def main():
     # not wait for step i's hash-grid scatter.  --no-overlap issues the identical work on one stream.
     # The hash-grid scatter kernel gets XCDs of its own (default 2 of 8) and both legs stay off them: beside it, any
     # kernel that shares an XCD with it finishes only when it does (gs_sdf_amd/streams.py has the measurements).
-    overlap = not args.no_sdf and not args.no_overlap
+    overlap = not args.no_sdf and not args.no_overlap and impl == "python"
     main = torch.cuda.current_stream()
     side = scatter = aux = main
-    if not args.no_sdf:
+    if not args.no_sdf and impl == "python":
         lm.encoder.save_jacobian = True      # d/dx of the sample points from the forward's Jacobian (first order only)
     if overlap:
         from gs_sdf_amd.streams import xcd_partition_streams
@@ -230,6 +244,13 @@ def main():
 
     def step(i, update=True):
         stamp("begin")
+        if impl == "cpp":
+            vi = (i * world + rank) % views.shape[0]
+            sz = ji.step(views[vi][None], K, target, cpp_pool[i % 8], cpp_ray_sdf[i % 8], cpp_up, update, cpp_cams[vi])
+            for k in ("M", "I", "n_gs_sdf"):
+                hist.setdefault(k, []).append(int(sz[k]))
+            sizes.update({k: int(v) for k, v in sz.items()})
+            return
         view = views[(i * world + rank) % views.shape[0]][None]
         if not args.no_sdf and not analytic:
             # per-ray SDF batch (neural_mapping.cpp:138-188): BCE on the SDF head + eikonal on the numerical gradient.
@@ -336,7 +357,8 @@ def main():
         step(0, update=False)
         torch.cuda.synchronize()
         if rank == 0:
-            torch.save({"splat": params.flat_grad.cpu(), "sdf": [g.flat_grad.cpu() for g in groups], "sizes": dict(sizes)},
+            torch.save({"splat": (ji.splat_flat_grad() if ji is not None else params.flat_grad).cpu(),
+                        "sdf": [ji.sdf_flat_grad().cpu()] if ji is not None else [g.flat_grad.cpu() for g in groups], "sizes": dict(sizes)},
                        args.dump_grads)
         release_streams()
         if dist is not None:
@@ -372,9 +394,27 @@ def main():
 
     step_marks = []
 
+    import gs_sdf_amd.capi as capi
+    roof_cabi = sorted(k for k, v in CABI_OPS.items() if v in ROOF)
+
+    def timers_begin(only_roof):
+        if impl == "cpp":
+            capi.timing_begin(roof_cabi if only_roof else None)
+        else:
+            ops.TIMERS.enable(only=ROOF if only_roof else None)
+
+    def timers_end():
+        """-> (median, mean, calls) per operator"""
+        if impl == "cpp":
+            torch.cuda.synchronize()
+            return cabi_timing_to_ops(capi.timing_end())
+        r = ops.TIMERS.summary_ms("median"), ops.TIMERS.summary_ms("mean"), ops.TIMERS.calls()
+        ops.TIMERS.disable()
+        return r
+
     def timed(n_steps, first):
         hist.clear()
-        ops.TIMERS.enable(only=ROOF)
+        timers_begin(True)
         if host is not None:
             host.clear()
         step_marks.clear()
@@ -396,7 +436,8 @@ def main():
             t = torch.tensor([el], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = float(t.item())
-        return el, ops.TIMERS.summary_ms("median"), ops.TIMERS.summary_ms("mean"), ops.TIMERS.calls(), {k: sum(v) / len(v) for k, v in hist.items()}
+        med_, mean_, calls_ = timers_end()
+        return el, med_, mean_, calls_, {k: sum(v) / len(v) for k, v in hist.items()}
 
     elapsed, kern, kern_mean, calls, avg = timed(args.steps, warm_total)
     gaps = sorted(a.elapsed_time(b) for a, b in zip(step_marks[:-1], step_marks[1:]))
@@ -410,13 +451,12 @@ def main():
                 acc[tb] = acc.get(tb, 0.0) + (b - a)
             n += tb == "optimizers issued"
         print("host ms/step: " + ", ".join(f"{k} {v / n * 1e3:.2f}" for k, v in acc.items()), file=sys.stderr, flush=True)
-    ops.TIMERS.enable()                       # every operator, outside the timed region
+    timers_begin(False)                       # every operator, outside the timed region
     nxt = warm_total + args.steps
     for i in range(min(10, args.steps)):
         step(nxt + i)
     nxt += min(10, args.steps)
-    kern_all = ops.TIMERS.summary_ms("median")
-    ops.TIMERS.disable()
+    kern_all = timers_end()[0]
     if rank == 0 and os.environ.get("GSDF_BENCH_DUMP_PARAMS"):
         # debugging / evidence hook (tools/compare_mlp_pipes.py): the parameters after warmup + steps optimizer steps
         torch.cuda.synchronize()
@@ -432,7 +472,8 @@ def main():
         alg_step = {"rasterize_2dgs_bwd": 80 * I + 48 * P + 88 * M, "rasterize_2dgs_fwd": 80 * I + 48 * P}
         flops_step = {}
         if not args.no_sdf:
-            macs = sum(a_ * b_ for a_, b_ in zip(lm.decoder.dims[:-1], lm.decoder.dims[1:]))   # multiply-adds per point and pass
+            dd = dec_dims if impl == "cpp" else lm.decoder.dims
+            macs = sum(a_ * b_ for a_, b_ in zip(dd[:-1], dd[1:]))                             # multiply-adds per point and pass
             # S1 per query point: fwd 12 + 1024 (16 levels x 8 corners x 8 B) + 128 (+ 384 B of Jacobian per gradient-carrying
             # point); bwd 8 + 128 + 1024 scatter (+ 128 + 12 for the second-order operands of the analytic configuration)
             alg_step["hashgrid_fwd"] = 1164 * sdf_pts + 384 * base_pts
@@ -499,6 +540,10 @@ def main():
                                    f"steps: M={M:.0f} I={I:.0f} L={I / T:.0f}" + ("" if args.no_sdf else f"; hash-grid SDF (2^19 x16x2, fused "
                                    f"64-wide MLP) evaluated at {sdf_pts:.0f} points/step = 7 x (32768 ray + {n_gs:.0f} splat samples)"),
                        "sdf_config": None if args.no_sdf else args.sdf_config,
+                       "step_impl": ("C++/libtorch: gsdf_extras::JointIteration (gs-sdf_amd/host/src/joint_step.cpp) over libgsdf_torch.so -> C ABI -> "
+                                     "libgsdf_hip.so; " + ("two HIP streams" if not args.no_overlap else "one HIP stream") + "; driven per step through "
+                                     "the pybind harness" if impl == "cpp" else "Python mirror (gs_sdf_amd.ops / sdf over ctypes -> C ABI), "
+                                     + ("four HIP streams" if overlap else "one HIP stream")),
                        "step": "reference joint iteration (neural_mapping.cpp:400-486): " + terms,
                        "parallelism": f"view-parallel x{world}" if world > 1 else "single GPU",
                        "splat_order": ("Morton order of the centres (trainer.morton_order; kept by the trainer at initialisation and at "
@@ -514,7 +559,10 @@ def main():
                              traffic_GBps=(None if not traffic or not dur_ms else traffic / (dur_ms * 1e-3) / 1e9),
                              traffic_frac_of_hbm_peak=(None if not traffic or not dur_ms else traffic / (dur_ms * 1e-3) / 8e12),
                              launches_per_step=calls.get(dom, 0) / args.steps,
-                             timing="HIP events on the launch stream over the timed steps; mean launch (operators with unequal launches)",
+                             timing=("HIP events on the launch stream over the timed steps (" + ("gsdf_timing_begin/_end inside the C ABI: one event "
+                                     "pair around everything an entry point launches" if impl == "cpp" else "ops.TIMERS") + "); mean launch "
+                                     "(operators with unequal launches); kernels of the two legs share the chip, so a launch's duration includes "
+                                     "the slowdown from its neighbours — profiles/ holds the one-stream rocprofv3 stats"),
                              ms_per_step_by_kernel={k: round(v, 4) for k, v in per_step.items()},
                              # the same figure for the other large kernels
                              others={k: dict(roof(k), avg_launch_ms=kern_mean[k], median_launch_ms=kern[k]) for k in per_step if k != dom and kern.get(k)},
@@ -529,8 +577,9 @@ def main():
                                                               "frac_of_measured_fma_issue": v / (kern_mean[k] * 1e-3) / 759.0e9}
                                                           for k, v in valu.items() if kern_mean.get(k)}),
                              step_B_splat_bytes=int(b_splat), step_hbm_frac=b_splat / (elapsed / args.steps) / 8e12),
-            "params_finite": bool(torch.isfinite(params.flat).all()) and all(bool(torch.isfinite(g.flat).all()) for g in groups),
-            "nan_splats_seen_by_prune_test": int(nan_total.item()),
+            "params_finite": (bool(torch.isfinite(ji.splat_flat()).all() and torch.isfinite(ji.sdf_flat()).all()) if ji is not None else
+                              bool(torch.isfinite(params.flat).all()) and all(bool(torch.isfinite(g.flat).all()) for g in groups)),
+            "nan_splats_seen_by_prune_test": int((ji.nan_splats_seen() if ji is not None else nan_total).item()),
             "hbm_gb": {"allocated_peak": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
                        "reserved": round(torch.cuda.memory_reserved() / 2 ** 30, 2)},
             "kernel_ms": kern_all, "kernel_ms_note": "median launch duration per operator over 10 extra steps after the timed region",
@@ -558,20 +607,68 @@ def main():
                 out["reference_loop_zero_edits"] = reference_loop(args, sc, views, K, ug6, target, N, W, H, deg, dev)
             except Exception as e:
                 out["reference_loop_zero_edits"] = {"error": repr(e)[:300]}
-            # (3) the joint iteration in C++/libtorch (gsdf_extras::JointIteration over libgsdf_torch.so)
+            # (3) the other host implementation of the same step (Python mirror when the headline is the C++ step, and vice versa)
             try:
-                import copy
-                a2 = copy.copy(args)
-                a2.steps, a2.warmup, a2.dump_grads = min(args.steps, 40), min(args.warmup, 5), None
-                out["cpp_joint_iteration"] = cpp_step(a2, sc, views, K, ug6, target, N, W, H, deg, dev)
+                other_impl = "python" if impl == "cpp" else "cpp"
+                cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", str(min(args.steps, 40)), "--warmup", str(args.warmup),
+                       "--workload", args.workload, "--sdf-config", args.sdf_config, "--step-terms", args.step_terms, "--splat-order", args.splat_order,
+                       "--step-impl", other_impl, "--no-secondary", "--no-cpu-baseline"] + (["--no-overlap"] if args.no_overlap else [])
+                r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+                j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+                out["python_mirror_step" if other_impl == "python" else "cpp_joint_iteration"] = {
+                    "value": j["value"], "unit": "iters/s", "ms_per_step": j["ms_per_step"], "steps": j["steps"],
+                    "step_ms_hip_events": j["step_ms_hip_events"], "step_impl": j["config"]["step_impl"]}
             except Exception as e:
-                out["cpp_joint_iteration"] = {"error": repr(e)[:300]}
+                out["python_mirror_step" if impl == "cpp" else "cpp_joint_iteration"] = {"error": repr(e)[:300]}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sc, views, params, N, W, H, deg, 0 if args.no_sdf else int(sdf_pts), dev)
         print(json.dumps(out), flush=True)
     release_streams()
     if dist is not None:
         dist.destroy_process_group()
+
+
+# C-ABI entry points -> operator names of the roofline / kernel_ms tables (gsdf_timing_begin / _end time whole entry points)
+CABI_OPS = {"gsdf_hashgrid_fwd": "hashgrid_fwd", "gsdf_hashgrid_fwd_stencil": "hashgrid_fwd", "gsdf_hashgrid_fwd_jac_rows": "hashgrid_fwd",
+            "gsdf_hashgrid_fwd_jac": "hashgrid_fwd", "gsdf_hashgrid_bwd_binned2": "hashgrid_bwd", "gsdf_hashgrid_bwd_binned_stencil": "hashgrid_bwd",
+            "gsdf_hashgrid_bwd": "hashgrid_bwd", "gsdf_hashgrid_bwd_jac": "hashgrid_bwd_input", "gsdf_hashgrid_bwd_bwd": "hashgrid_bwd_bwd",
+            "gsdf_mlp_fwd": "mlp_fwd", "gsdf_mlp_bwd": "mlp_bwd", "gsdf_mlp_bwd_data": "mlp_bwd_data", "gsdf_mlp_bwd_weights": "mlp_bwd_weights",
+            "gsdf_mlp_bwd_bwd": "mlp_bwd_bwd", "gsdf_rasterize_2dgs_fwd": "rasterize_2dgs_fwd", "gsdf_rasterize_2dgs_bwd": "rasterize_2dgs_bwd"}
+
+
+def cabi_timing_to_ops(rep):
+    """gs_sdf_amd.capi.timing_end() report -> (median, mean, calls) per operator name (entry points of one operator merged)."""
+    med, mean, calls, tot = {}, {}, {}, {}
+    for name, r in rep.items():
+        op = CABI_OPS.get(name, name[5:] if name.startswith("gsdf_") else name)
+        calls[op] = calls.get(op, 0) + r["calls"]
+        tot[op] = tot.get(op, 0.0) + r["total_ms"]
+        med[op] = max(med.get(op, 0.0), r["median_ms"])        # merged entry points: the larger launch's median
+    for op in calls:
+        mean[op] = tot[op] / max(1, calls[op])
+    return med, mean, calls
+
+
+def make_cpp_iteration(args, sc, params, dev, W, H, deg, views):
+    """gsdf_extras::JointIteration on the bench's scene (same initial parameters as the Python step) + its per-step inputs."""
+    import gs_sdf_amd.hostlib as hostlib
+    import gs_sdf_amd.sdf as sdfm
+    host = hostlib.load()
+    analytic, ref_terms = args.sdf_config == "default", args.step_terms == "reference"
+    lm = sdfm.LocalMap([0.0, 0.0, 5.5], 16.0, bce_sigma=0.02, decoder_implementation=0 if analytic else 1, device=dev, seed=5)
+    enc = host.TCNNEncoding(16, 2, 19, 32, 2.0)
+    dec = host.TCNNNetwork(32, 2, 64, 4 if analytic else 3, analytic)       # default: the torch decoder's topology (biases, 4 hidden matmuls)
+    enc.params_, dec.params_ = lm.encoder.params_.detach().clone(), lm.decoder.params_.detach().clone()
+    if analytic:
+        dec.biases_ = lm.decoder.biases_.detach().clone()
+    fields = [params.views[k].detach().clone() for k in ("offsets", "scaling", "quaternion", "opacity", "features_dc", "features_rest")]
+    ji = host.JointIteration(params.anchors, fields, enc, dec, [0.0, 0.0, 5.5], 16.0, 0.02, 8, W, H, deg, not args.no_overlap, analytic, ref_terms)   # level 8: 1/16 m leaves in 16 m
+    gq = torch.Generator().manual_seed(4)
+    pool = [((torch.rand(32768, 3, generator=gq) - 0.5) * 14.0 + torch.tensor([0.0, 0.0, 5.5])).to(dev) for _ in range(8)]
+    ray_sdf = [(torch.randn(32768, 1, generator=gq) * 0.02).to(dev) for _ in range(8)]
+    Kh = [float(v) for v in (sc["K"][0, 0, 0], sc["K"][0, 1, 1], sc["K"][0, 0, 2], sc["K"][0, 1, 2])]
+    cams = [Kh + [float(v) for v in torch.linalg.inv(vw.double())[:3, :4].reshape(-1)] for vw in views.cpu()]      # host values, known ahead
+    return ji, pool, ray_sdf, cams, list(lm.decoder.dims)
 
 
 def cpp_step(args, sc, views, K, ug6, target, N, W, H, deg, dev):

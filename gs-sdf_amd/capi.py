@@ -18,6 +18,8 @@ _i64, _i32, _f32, _u64, _vp, _sz = C.c_int64, C.c_int, C.c_float, C.c_uint64, C.
 _SIGS = {
     "gsdf_abi_version": (C.c_int, []),
     "gsdf_last_error": (C.c_char_p, []),
+    "gsdf_timing_begin": (C.c_int, [C.c_char_p]),
+    "gsdf_timing_end": (_sz, [C.c_char_p, _sz]),
     "gsdf_projection_2dgs_ws_bytes": (_sz, [_i64, _i64]),
     "gsdf_projection_2dgs_cull": (C.c_int, [_i64, _i64] + [_vp] * 5 + [_i32, _i32, _f32, _f32, _f32] + [_vp] * 4),
     "gsdf_projection_2dgs_fill": (C.c_int, [_i64, _i64] + [_vp] * 5 + [_i32, _i32, _u64, _vp, _vp, _i64] + [_vp] * 10),
@@ -100,6 +102,28 @@ def lib():
             f.restype, f.argtypes = res, args
         _lib = l
     return _lib
+
+
+def timing_begin(only=None):
+    """Per-entry-point device timing of the C ABI (include/gsdf_hip.h: gsdf_timing_begin), whoever calls it (Python mirror or the C++
+    operator layer): `only` = iterable of entry-point names or None for all."""
+    check(lib().gsdf_timing_begin(None if only is None else ",".join(only).encode()), "timing_begin")
+
+
+def timing_end():
+    """-> {entry point: dict(calls, total_ms, mean_ms, min_ms, max_ms, median_ms)}; stops the timing."""
+    buf = C.create_string_buffer(1 << 16)      # one line per entry point: ~100 lines of < 100 bytes at most
+    lib().gsdf_timing_end(buf, len(buf))
+    return _parse_timing(buf.value.decode())
+
+
+def _parse_timing(txt):
+    out = {}
+    for line in txt.splitlines():
+        name, calls, total, mn, mx, med = line.split()
+        out[name] = dict(calls=int(calls), total_ms=float(total), mean_ms=float(total) / max(1, int(calls)), min_ms=float(mn), max_ms=float(mx),
+                         median_ms=float(med))
+    return out
 
 
 def exported_symbols():

@@ -96,6 +96,7 @@ extern "C" int gsdf_splat_activations_fwd(int64_t n, const float *anchors, const
                                           const float *logit_opacities, float *xyz, float *scales, float *opacities,
                                           gsdf_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
+  GSDF_TIMED("gsdf_splat_activations_fwd");
   if (n == 0) return GSDF_OK;
   GSDF_REQUIRE(n > 0 && anchors && offsets && log_scales && logit_opacities && xyz && scales && opacities,
                "splat_activations_fwd: bad arguments");
@@ -109,6 +110,7 @@ extern "C" int gsdf_splat_activations_bwd(int64_t n, const float *scales, const 
                                           const float *v_scales, const float *v_opacities, float *g_offsets,
                                           float *g_log_scales, float *g_logit_opacities, gsdf_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
+  GSDF_TIMED("gsdf_splat_activations_bwd");
   if (n == 0) return GSDF_OK;
   GSDF_REQUIRE(n > 0 && scales && opacities && g_offsets && g_log_scales && g_logit_opacities,
                "splat_activations_bwd: bad arguments");
@@ -120,6 +122,7 @@ extern "C" int gsdf_splat_activations_bwd(int64_t n, const float *scales, const 
 
 extern "C" int gsdf_isotropic_loss_fwd(int64_t M, const float *scales, const int64_t *gaussian_ids, float *loss, gsdf_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
+  GSDF_TIMED("gsdf_isotropic_loss_fwd");
   GSDF_REQUIRE(M >= 0 && loss, "isotropic_loss_fwd: bad arguments");
   GSDF_HIP(hipMemsetAsync(loss, 0, 4, stream), "isotropic_loss memset");
   if (M == 0) return GSDF_OK;
@@ -133,6 +136,7 @@ extern "C" int gsdf_isotropic_loss_fwd(int64_t M, const float *scales, const int
 extern "C" int gsdf_isotropic_loss_bwd(int64_t M, const float *scales, const int64_t *gaussian_ids, const float *v_loss, float *v_scales,
                                        gsdf_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
+  GSDF_TIMED("gsdf_isotropic_loss_bwd");
   if (M == 0) return GSDF_OK;
   GSDF_REQUIRE(M > 0 && scales && gaussian_ids && v_loss && v_scales, "isotropic_loss_bwd: bad arguments");
   isotropic_bwd_kernel<<<(unsigned)((M + 255) / 256), 256, 0, stream>>>(M, scales, gaussian_ids, 0.5f / (float)M, v_loss, v_scales);
@@ -143,6 +147,7 @@ extern "C" int gsdf_isotropic_loss_bwd(int64_t M, const float *scales, const int
 extern "C" int gsdf_nan_rows(int64_t n, const float *offsets, const float *scaling, const float *quaternion, int32_t *count,
                              uint8_t *mask, gsdf_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
+  GSDF_TIMED("gsdf_nan_rows");
   GSDF_REQUIRE(n >= 0 && count, "nan_rows: bad arguments");
   GSDF_HIP(hipMemsetAsync(count, 0, 4, stream), "nan_rows memset");
   if (n == 0) return GSDF_OK;

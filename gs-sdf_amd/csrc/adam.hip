@@ -70,6 +70,7 @@ extern "C" int gsdf_adam_step(int64_t n, int n_segments, const int64_t *seg_begi
                               float *params, const float *grads, float *exp_avg, float *exp_avg_sq, float beta1,
                               float beta2, float eps, int64_t step, gsdf_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
+  GSDF_TIMED("gsdf_adam_step");
   GSDF_REQUIRE(n >= 0 && n_segments >= 1 && n_segments <= ADAM_MAX_SEG, "adam_step: %d segments not in [1,%d]", n_segments,
                ADAM_MAX_SEG);
   GSDF_REQUIRE(step >= 1, "adam_step: step counts from 1");

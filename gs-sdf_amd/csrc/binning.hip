@@ -140,6 +140,7 @@ extern "C" int gsdf_tile_count(int64_t M, int width, int height, int tile_size, 
                                const int32_t *radii, int32_t *tiles_per_gauss, int64_t *cum_tiles, void *ws,
                                int64_t *n_isects, gsdf_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
+  GSDF_TIMED("gsdf_tile_count");
   GSDF_REQUIRE(tile_size > 0 && width > 0 && height > 0, "tile_count: bad geometry");
   GSDF_REQUIRE(n_isects && ws, "tile_count: null workspace / n_isects");
   const int tw = (width + tile_size - 1) / tile_size, th = (height + tile_size - 1) / tile_size;
@@ -192,6 +193,7 @@ extern "C" int gsdf_tile_encode(int64_t M, int64_t C, int64_t I, int width, int 
                                 const int64_t *camera_ids, const int64_t *cum_tiles, void *ws, int64_t *isect_ids,
                                 int32_t *flatten_ids, int32_t *isect_offsets, gsdf_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
+  GSDF_TIMED("gsdf_tile_encode");
   GSDF_REQUIRE(tile_size > 0 && width > 0 && height > 0 && C >= 1, "tile_encode: bad geometry");
   GSDF_REQUIRE(isect_offsets, "tile_encode: null isect_offsets");
   const int tw = (width + tile_size - 1) / tile_size, th = (height + tile_size - 1) / tile_size;

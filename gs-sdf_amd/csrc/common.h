@@ -129,6 +129,24 @@ __device__ __forceinline__ int row_transpose_index(int lane) {
   return ((lane & 1) << 3) | ((lane & 2) << 1) | ((lane & 4) >> 1) | ((lane & 8) >> 3);
 }
 
+// Optional per-entry-point device timing (gsdf_timing_begin / gsdf_timing_end, include/gsdf_hip.h): a HIP event pair on the
+// call's own stream around everything the entry point launches.  Off (one relaxed load) unless a caller switched it on.
+bool timing_wants(const char *name);
+void timing_push(const char *name, hipEvent_t a, hipEvent_t b);
+struct TimedScope {
+  hipEvent_t a = nullptr, b = nullptr;
+  hipStream_t s;
+  const char *n;
+  TimedScope(const char *name, hipStream_t st) : s(st), n(name) {
+    if (timing_wants(name) && hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess) (void)hipEventRecord(a, st);
+    else a = nullptr;
+  }
+  ~TimedScope() {
+    if (a != nullptr) { (void)hipEventRecord(b, s); timing_push(n, a, b); }
+  }
+};
+#define GSDF_TIMED(name) gsdf::TimedScope timed_scope_(name, stream)
+
 // Number of XCDs the queue behind `stream` may use: 8, or what the caller registered with gsdf_stream_set_xcds for a
 // CU-masked stream (workgroups are dealt round-robin over the enabled XCDs only).  A locality hint for the XCD-aware
 // kernels (tile bands of the compositing kernels, level groups of the hash-grid forward), never a correctness input.

@@ -46,6 +46,7 @@ extern "C" int gsdf_densify_stats(int64_t M, int64_t N, int n_cameras, int width
                                   const int64_t *gaussian_ids, const float *visibilities, const int32_t *radii_px,
                                   float *grad2d, float *count, float *vis, float *radii, gsdf_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
+  GSDF_TIMED("gsdf_densify_stats");
   GSDF_REQUIRE(M >= 0 && N >= 0 && n_cameras >= 1 && width > 0 && height > 0, "densify_stats: bad arguments");
   if (M == 0) return GSDF_OK;
   GSDF_REQUIRE(grad && gaussian_ids && visibilities && grad2d && count && vis, "densify_stats: null buffer");
@@ -92,6 +93,7 @@ __global__ void __launch_bounds__(256)
 extern "C" int gsdf_flat_rows_gather(int n_fields, const int32_t *widths_host, int64_t n_src, int64_t n_dst, int64_t n_keep,
                                      const int64_t *keep_idx, const float *src, float *dst, gsdf_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
+  GSDF_TIMED("gsdf_flat_rows_gather");
   GSDF_REQUIRE(n_fields >= 1 && n_fields <= ROWS_MAX_FIELDS && widths_host, "flat_rows_gather: 1..%d fields", ROWS_MAX_FIELDS);
   GSDF_REQUIRE(n_src >= 0 && n_dst >= n_keep && n_keep >= 0 && (keep_idx || n_keep <= n_src), "flat_rows_gather: bad row counts");
   RowFields rf;

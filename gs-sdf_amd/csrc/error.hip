@@ -1,9 +1,15 @@
 // error.hip — thread-local error string + ABI version of libgsdf_hip.so.
 #include <stdarg.h>
 #include <stdio.h>
+#include <string.h>
 
+#include <algorithm>
+#include <atomic>
+#include <map>
 #include <mutex>
+#include <string>
 #include <unordered_map>
+#include <vector>
 
 #include "common.h"
 
@@ -14,6 +20,24 @@ int xcd_count(hipStream_t stream) {
   std::lock_guard<std::mutex> lock(g_xcd_mutex);
   const auto it = g_stream_xcds.find((void *)stream);
   return it == g_stream_xcds.end() ? 8 : it->second;
+}
+
+// ---- per-entry-point timing ------------------------------------------------------------------------------------------------
+static std::atomic<int> g_timing_on{0};
+static std::mutex g_timing_mutex;
+static std::vector<std::string> g_timing_only;
+struct TimedCall { const char *name; hipEvent_t a, b; };
+static std::vector<TimedCall> g_timed;
+bool timing_wants(const char *name) {
+  if (!g_timing_on.load(std::memory_order_relaxed)) return false;
+  std::lock_guard<std::mutex> lock(g_timing_mutex);
+  if (g_timing_only.empty()) return true;
+  for (const auto &n : g_timing_only) if (n == name) return true;
+  return false;
+}
+void timing_push(const char *name, hipEvent_t a, hipEvent_t b) {
+  std::lock_guard<std::mutex> lock(g_timing_mutex);
+  g_timed.push_back({name, a, b});
 }
 
 static thread_local char g_err[512] = "";
@@ -34,4 +58,54 @@ extern "C" int gsdf_stream_set_xcds(gsdf_stream_t stream, int n_xcds) {
   if (n_xcds == 0) gsdf::g_stream_xcds.erase((void *)stream);
   else gsdf::g_stream_xcds[(void *)stream] = n_xcds;
   return GSDF_OK;
+}
+
+extern "C" int gsdf_timing_begin(const char *only_csv) {
+  std::lock_guard<std::mutex> lock(gsdf::g_timing_mutex);
+  for (auto &c : gsdf::g_timed) { (void)hipEventDestroy(c.a); (void)hipEventDestroy(c.b); }
+  gsdf::g_timed.clear();
+  gsdf::g_timing_only.clear();
+  if (only_csv != nullptr) {
+    std::string cur;
+    for (const char *p = only_csv;; ++p) {
+      if (*p == ',' || *p == 0) { if (!cur.empty()) gsdf::g_timing_only.push_back(cur); cur.clear(); if (*p == 0) break; }
+      else if (*p != ' ') cur.push_back(*p);
+    }
+  }
+  gsdf::g_timing_on.store(1);
+  return GSDF_OK;
+}
+
+extern "C" size_t gsdf_timing_end(char *buf, size_t cap) {
+  gsdf::g_timing_on.store(0);
+  std::vector<gsdf::TimedCall> calls;
+  {
+    std::lock_guard<std::mutex> lock(gsdf::g_timing_mutex);
+    calls.swap(gsdf::g_timed);
+  }
+  struct Agg { long n = 0; double sum = 0, mn = 1e30, mx = 0; std::vector<float> all; };
+  std::map<std::string, Agg> agg;
+  for (auto &c : calls) {
+    float ms = 0.f;
+    if (hipEventSynchronize(c.b) == hipSuccess && hipEventElapsedTime(&ms, c.a, c.b) == hipSuccess) {
+      Agg &g = agg[c.name];
+      g.n++; g.sum += ms; g.mn = ms < g.mn ? ms : g.mn; g.mx = ms > g.mx ? ms : g.mx; g.all.push_back(ms);
+    }
+    (void)hipEventDestroy(c.a); (void)hipEventDestroy(c.b);
+  }
+  std::string out;
+  char line[256];
+  for (auto &kv : agg) {
+    std::vector<float> &v = kv.second.all;
+    std::sort(v.begin(), v.end());
+    const double med = v.empty() ? 0.0 : (v.size() % 2 ? v[v.size() / 2] : 0.5 * (v[v.size() / 2 - 1] + v[v.size() / 2]));
+    snprintf(line, sizeof(line), "%s %ld %.6f %.6f %.6f %.6f\n", kv.first.c_str(), kv.second.n, kv.second.sum, kv.second.mn, kv.second.mx, med);
+    out += line;
+  }
+  if (buf != nullptr && cap > 0) {
+    const size_t n = out.size() < cap - 1 ? out.size() : cap - 1;
+    memcpy(buf, out.data(), n);
+    buf[n] = 0;
+  }
+  return out.size() + 1;
 }

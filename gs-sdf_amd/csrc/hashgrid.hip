@@ -387,6 +387,7 @@ extern "C" int gsdf_hashgrid_fwd(int64_t B, int n_levels, int n_feat, int log2_h
                                  float per_level_scale, const float *x, const float *table, float *feat,
                                  gsdf_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
+  GSDF_TIMED("gsdf_hashgrid_fwd");
   int rc = check_cfg(n_levels, n_feat, log2_hashmap, base_res, per_level_scale, "hashgrid_fwd");
   if (rc) return rc;
   if (B == 0) return GSDF_OK;
@@ -402,6 +403,7 @@ extern "C" int gsdf_hashgrid_fwd_jac_rows(int64_t B, int64_t jac_rows, int n_lev
                                           int base_res, float per_level_scale, const float *x, const float *table,
                                           float *feat, float *jac, gsdf_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
+  GSDF_TIMED("gsdf_hashgrid_fwd_jac_rows");
   int rc = check_cfg(n_levels, n_feat, log2_hashmap, base_res, per_level_scale, "hashgrid_fwd_jac");
   if (rc) return rc;
   if (B == 0) return GSDF_OK;
@@ -419,6 +421,7 @@ extern "C" int gsdf_hashgrid_fwd_stencil(int64_t B, int64_t stencil_n, int64_t j
                                          int log2_hashmap, int base_res, float per_level_scale, const float *x,
                                          const float *table, float *feat, float *jac, gsdf_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
+  GSDF_TIMED("gsdf_hashgrid_fwd_stencil");
   int rc = check_cfg(n_levels, n_feat, log2_hashmap, base_res, per_level_scale, "hashgrid_fwd_stencil");
   if (rc) return rc;
   GSDF_REQUIRE(stencil_n >= 0 && B == 7 * stencil_n, "hashgrid_fwd_stencil: a stencil batch has 7 * stencil_n rows");
@@ -442,6 +445,7 @@ extern "C" int gsdf_hashgrid_fwd_jac(int64_t B, int n_levels, int n_feat, int lo
 extern "C" int gsdf_hashgrid_bwd_jac(int64_t B, int n_levels, int n_feat, const float *jac, const float *v_feat,
                                      float *v_x, gsdf_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
+  GSDF_TIMED("gsdf_hashgrid_bwd_jac");
   GSDF_REQUIRE(n_levels >= 1 && n_feat >= 1 && n_levels * n_feat <= 32, "hashgrid_bwd_jac: n_levels*n_feat must be <= 32");
   if (B == 0) return GSDF_OK;
   GSDF_REQUIRE(jac && v_feat && v_x, "hashgrid_bwd_jac: null buffer");
@@ -454,6 +458,7 @@ extern "C" int gsdf_hashgrid_bwd(int64_t B, int n_levels, int n_feat, int log2_h
                                  float per_level_scale, const float *x, const float *table, const float *v_feat,
                                  float *v_table, float *v_x, gsdf_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
+  GSDF_TIMED("gsdf_hashgrid_bwd");
   int rc = check_cfg(n_levels, n_feat, log2_hashmap, base_res, per_level_scale, "hashgrid_bwd");
   if (rc) return rc;
   if (B == 0 || (!v_table && !v_x)) return GSDF_OK;
@@ -473,6 +478,7 @@ extern "C" int gsdf_hashgrid_bwd_bwd(int64_t B, int n_levels, int n_feat, int lo
                                      const float *vv_x, float *g_vfeat, float *g_table, float *g_x,
                                      gsdf_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
+  GSDF_TIMED("gsdf_hashgrid_bwd_bwd");
   int rc = check_cfg(n_levels, n_feat, log2_hashmap, base_res, per_level_scale, "hashgrid_bwd_bwd");
   if (rc) return rc;
   if (B == 0 || (!g_vfeat && !g_table && !g_x)) return GSDF_OK;

@@ -506,6 +506,8 @@ extern "C" int gsdf_hashgrid_bwd_binned_stencil(int64_t B, int64_t stencil_n, in
                                                 const float *v_feat, float *v_table, void *ws, size_t ws_bytes,
                                                 gsdf_stream_t stream_) {
   GSDF_REQUIRE(B == 0 || v_feat, "hashgrid_bwd_binned: null v_feat");
+  hipStream_t stream = (hipStream_t)stream_;
+  GSDF_TIMED("gsdf_hashgrid_bwd_binned_stencil");
   return binned_scatter(B, stencil_n, merge_levels, n_levels, n_feat, log2_hashmap, base_res, per_level_scale, x, v_feat, nullptr, nullptr,
                         v_table, ws, ws_bytes, (hipStream_t)stream_);
 }
@@ -514,6 +516,8 @@ extern "C" int gsdf_hashgrid_bwd_binned2(int64_t B, int n_levels, int n_feat, in
                                          const float *x, const float *v_feat, const float *v_feat2, const float *vv_x, float *v_table,
                                          void *ws, size_t ws_bytes, gsdf_stream_t stream_) {
   GSDF_REQUIRE(B == 0 || (v_feat2 && vv_x), "hashgrid_bwd_binned2: null second-order inputs");
+  hipStream_t stream = (hipStream_t)stream_;
+  GSDF_TIMED("gsdf_hashgrid_bwd_binned2");
   return binned_scatter(B, 0, 0, n_levels, n_feat, log2_hashmap, base_res, per_level_scale, x, v_feat, v_feat2, vv_x, v_table, ws, ws_bytes,
                         (hipStream_t)stream_);
 }

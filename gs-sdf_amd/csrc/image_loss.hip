@@ -174,6 +174,7 @@ using namespace gsdf;
 extern "C" int gsdf_l1_dssim_fwd(int height, int width, const float *img, const float *gt, const float *window11_host,
                                  float *sums, float *maps, gsdf_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
+  GSDF_TIMED("gsdf_l1_dssim_fwd");
   GSDF_REQUIRE(height > 0 && width > 0, "l1_dssim_fwd: bad image size");
   GSDF_REQUIRE(img && gt && window11_host && sums, "l1_dssim_fwd: null buffer");
   Win11 w;
@@ -189,6 +190,7 @@ extern "C" int gsdf_l1_dssim_bwd(int height, int width, const float *img, const 
                                  const float *maps, const float *v_loss, float w_l1, float w_ssim, float *v_img,
                                  gsdf_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
+  GSDF_TIMED("gsdf_l1_dssim_bwd");
   GSDF_REQUIRE(height > 0 && width > 0, "l1_dssim_bwd: bad image size");
   GSDF_REQUIRE(img && gt && window11_host && maps && v_loss && v_img, "l1_dssim_bwd: null buffer");
   Win11 w;

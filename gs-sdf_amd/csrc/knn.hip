@@ -179,6 +179,7 @@ extern "C" size_t gsdf_knn_ws_bytes(int64_t N) {
 
 extern "C" int gsdf_knn_mean_dist2(int64_t N, const float *points, float *out, void *ws, gsdf_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
+  GSDF_TIMED("gsdf_knn_mean_dist2");
   if (N <= 0) return GSDF_OK;
   GSDF_REQUIRE(points && out && ws, "knn_mean_dist2: null buffer");
   GSDF_REQUIRE(N < (1LL << 31), "knn_mean_dist2: too many points");

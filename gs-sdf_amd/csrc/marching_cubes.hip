@@ -118,6 +118,7 @@ using namespace gsdf;
 extern "C" int gsdf_mc_count(int res_x, int res_y, int res_z, int table, const float *grid, float thresh, int32_t *n_vert,
                              int32_t *n_tri, gsdf_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
+  GSDF_TIMED("gsdf_mc_count");
   GSDF_REQUIRE(res_x >= 1 && res_y >= 1 && res_z >= 1, "mc_count: bad resolution");
   GSDF_REQUIRE(table == GSDF_MC_TABLE_REFERENCE || table == GSDF_MC_TABLE_WATERTIGHT, "mc_count: unknown triangle table %d", table);
   GSDF_REQUIRE(grid && n_vert && n_tri, "mc_count: null buffer");
@@ -132,6 +133,7 @@ extern "C" int gsdf_mc_emit(int res_x, int res_y, int res_z, int table, const fl
                             const int64_t *t_offsets, const float *lower_host, const float *upper_host, float *vertices,
                             int32_t *faces, gsdf_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
+  GSDF_TIMED("gsdf_mc_emit");
   GSDF_REQUIRE(res_x >= 1 && res_y >= 1 && res_z >= 1, "mc_emit: bad resolution");
   GSDF_REQUIRE(table == GSDF_MC_TABLE_REFERENCE || table == GSDF_MC_TABLE_WATERTIGHT, "mc_emit: unknown triangle table %d", table);
   GSDF_REQUIRE(grid && v_offsets && t_offsets && lower_host && upper_host, "mc_emit: null buffer");

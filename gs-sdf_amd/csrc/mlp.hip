@@ -402,6 +402,7 @@ extern "C" size_t gsdf_mlp_bwd_ws_bytes_for(int64_t B, int n_layers, const int *
 extern "C" int gsdf_mlp_fwd(int64_t B, int n_layers, const int *dims_host, const float *weights, const float *biases,
                             const float *in, float *out, float *acts, gsdf_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
+  GSDF_TIMED("gsdf_mlp_fwd");
   GSDF_REQUIRE(dims_host, "mlp_fwd: null dims");
   MlpDesc d;
   size_t lds_floats;
@@ -428,6 +429,7 @@ extern "C" int gsdf_mlp_bwd(int64_t B, int n_layers, const int *dims_host, const
                             const float *in, const float *acts, const float *v_out, float *v_in, float *v_weights,
                             float *v_biases, void *ws, gsdf_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
+  GSDF_TIMED(v_weights != nullptr ? "gsdf_mlp_bwd" : "gsdf_mlp_bwd_data");   // both gradients (one pass) / input gradient only
   GSDF_REQUIRE(dims_host, "mlp_bwd: null dims");
   MlpDesc d;
   size_t lds_floats;
@@ -467,6 +469,7 @@ extern "C" int gsdf_mlp_bwd_bwd(int64_t B, int n_layers, const int *dims_host, c
                                 const float *v_out, const void *bwd_ws, const float *vv_in, float *g_vout, float *g_weights,
                                 void *ws, gsdf_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
+  GSDF_TIMED("gsdf_mlp_bwd_bwd");
   GSDF_REQUIRE(dims_host, "mlp_bwd_bwd: null dims");
   MlpDesc d;
   size_t lds_floats;
@@ -505,6 +508,7 @@ extern "C" int gsdf_mlp_bwd_weights(int64_t B, int n_layers, const int *dims_hos
                                     const float *acts, const float *v_out, const void *ws, float *v_weights,
                                     float *v_biases, gsdf_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
+  GSDF_TIMED("gsdf_mlp_bwd_weights");
   GSDF_REQUIRE(dims_host, "mlp_bwd_weights: null dims");
   MlpDesc d;
   size_t lds_floats;

@@ -151,6 +151,7 @@ extern "C" int gsdf_normal_consistency_fwd(int height, int width, const float *i
                                            const float *depth, const float *alpha, const float *render_normal, float *loss,
                                            gsdf_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
+  GSDF_TIMED("gsdf_normal_consistency_fwd");
   GSDF_REQUIRE(height > 2 && width > 2, "normal_consistency_fwd: image must be at least 3x3");
   GSDF_REQUIRE(intrinsics4_host && pose_c2w_host && depth && alpha && render_normal && loss, "normal_consistency_fwd: null buffer");
   NlCam cam;
@@ -166,6 +167,7 @@ extern "C" int gsdf_normal_consistency_bwd(int height, int width, const float *i
                                            const float *depth, const float *alpha, const float *render_normal,
                                            const float *v_loss, float *v_depth, float *v_render_normal, gsdf_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
+  GSDF_TIMED("gsdf_normal_consistency_bwd");
   GSDF_REQUIRE(height > 2 && width > 2, "normal_consistency_bwd: image must be at least 3x3");
   GSDF_REQUIRE(intrinsics4_host && pose_c2w_host && depth && alpha && render_normal && v_loss && v_depth && v_render_normal,
                "normal_consistency_bwd: null buffer");

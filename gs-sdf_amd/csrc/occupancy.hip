@@ -249,6 +249,7 @@ extern "C" size_t gsdf_occ_bytes(int level) {
 extern "C" int gsdf_occ_build(int level, int64_t n_points, const float *xyz_m1p1, int dilate27, void *grid,
                               gsdf_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
+  GSDF_TIMED("gsdf_occ_build");
   if (int rc = check_level(level, "occ_build")) return rc;
   GSDF_REQUIRE(grid && (n_points == 0 || xyz_m1p1) && n_points >= 0, "occ_build: bad arguments");
   const OccLevels lv = make_levels(level);
@@ -270,6 +271,7 @@ extern "C" int gsdf_occ_build(int level, int64_t n_points, const float *xyz_m1p1
 extern "C" int gsdf_occ_query(int level, int query_level, int64_t n, const float *xyz_m1p1, const void *grid,
                               uint8_t *mask, gsdf_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
+  GSDF_TIMED("gsdf_occ_query");
   if (int rc = check_level(level, "occ_query")) return rc;
   const int l = query_level < 0 ? level : query_level;
   GSDF_REQUIRE(l >= 0 && l <= level, "occ_query: query level %d outside [0,%d]", l, level);
@@ -284,6 +286,7 @@ extern "C" int gsdf_occ_query(int level, int query_level, int64_t n, const float
 extern "C" int gsdf_occ_query_world(int level, int query_level, int64_t n, const float *xyz_world, const float *origin_host,
                                     float map_size_inv, const void *grid, uint8_t *mask, gsdf_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
+  GSDF_TIMED("gsdf_occ_query_world");
   if (int rc = check_level(level, "occ_query_world")) return rc;
   const int l = query_level < 0 ? level : query_level;
   GSDF_REQUIRE(l >= 0 && l <= level, "occ_query_world: query level %d outside [0,%d]", l, level);
@@ -298,6 +301,7 @@ extern "C" int gsdf_occ_query_world(int level, int query_level, int64_t n, const
 
 extern "C" int gsdf_occ_voxel_counts(int level, const void *grid, int32_t *word_counts, gsdf_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
+  GSDF_TIMED("gsdf_occ_voxel_counts");
   if (int rc = check_level(level, "occ_voxel_counts")) return rc;
   GSDF_REQUIRE(grid && word_counts, "occ_voxel_counts: null buffer");
   const int64_t nw = occ_level_words(level);
@@ -310,6 +314,7 @@ extern "C" int gsdf_occ_voxel_counts(int level, const void *grid, int32_t *word_
 extern "C" int gsdf_occ_voxel_list(int level, const void *grid, const int64_t *word_offsets, int16_t *voxels,
                                    gsdf_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
+  GSDF_TIMED("gsdf_occ_voxel_list");
   if (int rc = check_level(level, "occ_voxel_list")) return rc;
   GSDF_REQUIRE(grid && word_offsets && voxels, "occ_voxel_list: null buffer");
   const int64_t nw = occ_level_words(level);
@@ -323,6 +328,7 @@ extern "C" int gsdf_occ_voxel_list(int level, const void *grid, const int64_t *w
 extern "C" int gsdf_occ_raymarch_count(int level, int64_t n_rays, const float *origins_m1p1, const float *dirs,
                                        const void *grid, int32_t *counts, gsdf_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
+  GSDF_TIMED("gsdf_occ_raymarch_count");
   if (int rc = check_level(level, "occ_raymarch_count")) return rc;
   if (n_rays == 0) return GSDF_OK;
   GSDF_REQUIRE(n_rays > 0 && origins_m1p1 && dirs && grid && counts, "occ_raymarch_count: bad arguments");
@@ -337,6 +343,7 @@ extern "C" int gsdf_occ_raymarch_fill(int level, int64_t n_rays, const float *or
                                       const void *grid, const int64_t *voxel_offsets, int num_samples, int32_t *ridx,
                                       float *samples, float *depth_samples, gsdf_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
+  GSDF_TIMED("gsdf_occ_raymarch_fill");
   if (int rc = check_level(level, "occ_raymarch_fill")) return rc;
   if (n_rays == 0) return GSDF_OK;
   GSDF_REQUIRE(n_rays > 0 && num_samples >= 1 && origins_m1p1 && dirs && grid && voxel_offsets && ridx && samples &&

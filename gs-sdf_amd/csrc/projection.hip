@@ -213,6 +213,7 @@ extern "C" int gsdf_projection_2dgs_cull(int64_t N, int64_t C, const float *mean
                                          int height, float near_plane, float far_plane, float radius_clip,
                                          int32_t *radii_dense, void *ws, int64_t *n_visible, gsdf_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
+  GSDF_TIMED("gsdf_projection_2dgs_cull");
   GSDF_REQUIRE(N >= 0 && C >= 1, "projection_cull: bad sizes N=%ld C=%ld", (long)N, (long)C);
   GSDF_REQUIRE(width > 0 && height > 0, "projection_cull: bad image size %dx%d", width, height);
   GSDF_REQUIRE(n_visible && ws, "projection_cull: null workspace / n_visible");
@@ -236,6 +237,7 @@ extern "C" int gsdf_projection_2dgs_fill(int64_t N, int64_t C, const float *mean
                                          float *ray_transforms, float *normals, float *samples,
                                          float *samples_weights, gsdf_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
+  GSDF_TIMED("gsdf_projection_2dgs_fill");
   const int64_t pairs = N * C, nb = (pairs + PT - 1) / PT;
   if (pairs == 0 || n_visible == 0) return GSDF_OK;
   GSDF_REQUIRE(camera_ids && gaussian_ids && radii && means2d && depths && ray_transforms && normals && samples &&
@@ -258,6 +260,7 @@ extern "C" int gsdf_projection_2dgs_bwd(int64_t N, int64_t C, int64_t M, const f
                                         const float *v_samples, float *v_means, float *v_quats, float *v_scales,
                                         gsdf_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
+  GSDF_TIMED("gsdf_projection_2dgs_bwd");
   if (M == 0) return GSDF_OK;
   GSDF_REQUIRE(v_means2d && v_depths && v_ray_transforms && v_normals && v_means && v_quats && v_scales,
                "projection_bwd: null gradient buffer");

@@ -312,6 +312,7 @@ extern "C" int gsdf_rasterize_2dgs_bwd(int64_t C, int64_t M, int64_t I, int widt
                                        float *v_colors, float *v_opacities, float *v_normals, float *v_densify,
                                        float *v_means2d_abs, void *ws, const float *final_T, gsdf_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
+  GSDF_TIMED("gsdf_rasterize_2dgs_bwd");
   GSDF_REQUIRE(tile_size == TILE, "rasterize_bwd: tile_size %d unsupported (16 only)", tile_size);
   GSDF_REQUIRE(width > 0 && height > 0 && C >= 1, "rasterize_bwd: bad geometry");
   if (M == 0) return GSDF_OK;

@@ -134,6 +134,7 @@ extern "C" int gsdf_rasterize_2dgs_fwd(int64_t C, int64_t M, int64_t I, int widt
                                        int32_t *last_ids, int32_t *median_ids, float *visibilities, float *final_T,
                                        gsdf_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
+  GSDF_TIMED("gsdf_rasterize_2dgs_fwd");
   GSDF_REQUIRE(tile_size == TILE, "rasterize_fwd: tile_size %d unsupported (16 only)", tile_size);
   GSDF_REQUIRE(width > 0 && height > 0 && C >= 1, "rasterize_fwd: bad geometry");
   GSDF_REQUIRE(render_colors && render_depths && render_alphas && render_normals && render_median && last_ids &&

@@ -85,6 +85,7 @@ extern "C" int gsdf_render_post_fwd(int64_t n_pix, int expected_depth, const flo
                                     const float *render_normals, float *renders, float *normals_world, float *color3,
                                     float *depth1, gsdf_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
+  GSDF_TIMED("gsdf_render_post_fwd");
   if (n_pix == 0) return GSDF_OK;
   GSDF_REQUIRE(viewmat0 && render_colors && render_depths && render_alphas && render_normals && renders && normals_world,
                "render_post_fwd: null buffer");
@@ -101,6 +102,7 @@ extern "C" int gsdf_render_post_bwd(int64_t n_pix, int expected_depth, const flo
                                     const float *v_color3, const float *v_depth1, float *v_render_colors, float *v_render_depths, float *v_render_alphas,
                                     float *v_render_normals, gsdf_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
+  GSDF_TIMED("gsdf_render_post_bwd");
   if (n_pix == 0) return GSDF_OK;
   GSDF_REQUIRE(viewmat0 && render_depths && render_alphas && v_render_colors && v_render_depths && v_render_alphas &&
                    v_render_normals,

@@ -240,6 +240,7 @@ using namespace gsdf;
 extern "C" int gsdf_sdf_query_points(int64_t n, int stencil, const float *xyz, float delta, const float *origin_host,
                                      float map_size_inv, float *out, gsdf_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
+  GSDF_TIMED("gsdf_sdf_query_points");
   GSDF_REQUIRE(n >= 0 && origin_host, "sdf_query_points: bad arguments");
   if (n == 0) return GSDF_OK;
   GSDF_REQUIRE(xyz && out, "sdf_query_points: null buffer");
@@ -254,6 +255,7 @@ extern "C" int gsdf_sdf_query_points(int64_t n, int stencil, const float *xyz, f
 extern "C" int gsdf_sdf_ray_loss(int64_t n, int stencil, const float *attr, int ld, const float *gt_sdf, float bce_isigma,
                                  float delta, float w_eik, float *loss, float *v_attr, gsdf_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
+  GSDF_TIMED("gsdf_sdf_ray_loss");
   GSDF_REQUIRE(n > 0 && ld >= 2 && attr && gt_sdf && loss && v_attr, "sdf_ray_loss: bad arguments");
   GSDF_REQUIRE(!stencil || delta > 0.f, "sdf_ray_loss: delta must be positive");
   GSDF_HIP(hipMemsetAsync(loss, 0, 4, stream), "sdf_ray_loss memset");
@@ -267,6 +269,7 @@ extern "C" int gsdf_gs_sdf_eik_loss(int64_t n, int stencil, const float *attr, i
                                     const int64_t *ids, float scale, float delta, float w_eik, float *loss,
                                     float *v_attr, gsdf_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
+  GSDF_TIMED("gsdf_gs_sdf_eik_loss");
   GSDF_REQUIRE(n >= 0 && ld >= 1 && loss, "gs_sdf_loss: bad arguments");
   GSDF_REQUIRE(!stencil || delta > 0.f, "gs_sdf_loss: delta must be positive");
   GSDF_HIP(hipMemsetAsync(loss, 0, 4, stream), "gs_sdf_loss memset");
@@ -288,6 +291,7 @@ extern "C" int gsdf_sdf_analytic_loss(int64_t n, int64_t n_ray, int stencil, con
                                       float bce_isigma, float w_sdf, float w_gs, float map_size_inv, float delta, float w_eik,
                                       float w_align, float *loss, float *v_attr, float *vv_x, float *u0, gsdf_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
+  GSDF_TIMED("gsdf_sdf_analytic_loss");
   GSDF_REQUIRE(n >= 0 && n_ray >= 0 && n_ray <= n && loss, "sdf_analytic_loss: bad arguments");
   GSDF_REQUIRE(n_feat == 32, "sdf_analytic_loss: %d encoder features unsupported (32: 16 levels x 2, as the reference configures)", n_feat);
   GSDF_REQUIRE(ld >= (n_ray > 0 ? 2 : 1), "sdf_analytic_loss: decoder output too narrow");

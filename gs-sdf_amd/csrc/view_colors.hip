@@ -173,6 +173,7 @@ extern "C" int gsdf_view_colors_fwd(int64_t M, int64_t K, int sh_degree, const f
                                     const float *sh_coeffs, const int64_t *camera_ids, const int64_t *gaussian_ids,
                                     float *colors, gsdf_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
+  GSDF_TIMED("gsdf_view_colors_fwd");
   GSDF_REQUIRE(sh_degree >= 0 && sh_degree <= 3, "view_colors: sh_degree %d not in [0,3]", sh_degree);
   GSDF_REQUIRE((sh_degree + 1) * (sh_degree + 1) <= K, "view_colors: degree %d needs %d bases, have %ld", sh_degree,
                (sh_degree + 1) * (sh_degree + 1), (long)K);
@@ -190,6 +191,7 @@ extern "C" int gsdf_view_colors_bwd(int64_t M, int64_t K, int sh_degree, const f
                                     const float *v_colors, float *v_sh, float *v_means, int unique_gaussians,
                                     gsdf_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
+  GSDF_TIMED("gsdf_view_colors_bwd");
   GSDF_REQUIRE(sh_degree >= 0 && sh_degree <= 3, "view_colors_bwd: sh_degree %d not in [0,3]", sh_degree);
   GSDF_REQUIRE((sh_degree + 1) * (sh_degree + 1) <= K, "view_colors_bwd: degree %d needs more than %ld bases",
                sh_degree, (long)K);

@@ -14,6 +14,7 @@
 #pragma once
 #include <torch/torch.h>
 
+#include <functional>
 #include <map>
 #include <memory>
 #include <string>
@@ -152,6 +153,11 @@ class JointIteration {
                                       const torch::Tensor &ray_pts, const torch::Tensor &ray_sdf, const std::vector<torch::Tensor> &upstream,
                                       bool update = true, const std::vector<float> &cam_host = {});
   void sync();   // the caller's current stream waits for everything this object has issued on its second stream
+  // View-parallel training (the reference is single-GPU): called with the family's flat gradient buffer after the backward
+  // pass and before that family's optimizer step, on the stream the family's optimizer runs on — e.g. an RCCL all-reduce + 1/G scale.
+  void set_grad_hooks(std::function<void(torch::Tensor)> splat_hook, std::function<void(torch::Tensor)> sdf_hook) {
+    splat_hook_ = std::move(splat_hook); sdf_hook_ = std::move(sdf_hook);
+  }
   torch::Tensor splat_flat() const { return flat_; }
   torch::Tensor splat_flat_grad() const { return flat_grad_; }
   torch::Tensor sdf_flat() { sync(); return sdf_flat_; }
@@ -172,6 +178,7 @@ class JointIteration {
   std::map<std::string, torch::Tensor> state_;
   FusedAdam adam_, adam_sdf_;
   std::unique_ptr<JointStreams> streams_;
+  std::function<void(torch::Tensor)> splat_hook_, sdf_hook_;
 };
 
 }  // namespace gsdf_extras

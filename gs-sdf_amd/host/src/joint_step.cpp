@@ -287,14 +287,20 @@ std::map<std::string, int64_t> JointIteration::step(const Tensor &viewmat, const
   }
   // ---- train_callback -> update_state (:486, neural_gaussian.cpp:626-680), optimizers (each family on its leg's stream)
   update_state(state_, densify.grad(), gaussian_ids, vis, radii, N, (int)viewmat.size(0), W, H, false);
+  if (splat_hook_) splat_hook_(flat_grad_);            // view-parallel: the splat family's gradients are final here
   if (update) {
     adam_.step();
     flat_grad_.zero_();
     if (cfg_.reference_terms) nan_total_.add_(nan_rows(views_[0], views_[1], views_[2]));   // prune_nan_gs's test, no host sync
+  }
+  {
     c10::optional<StreamGuard> sg;
     if (two) sg.emplace(streams_->side);
-    adam_sdf_.step();
-    sdf_flat_grad_.zero_();
+    if (sdf_hook_) sdf_hook_(sdf_flat_grad_);          // ... and the SDF family's, on its own stream (after its scatter)
+    if (update) {
+      adam_sdf_.step();
+      sdf_flat_grad_.zero_();
+    }
   }
   if (two) {   // what the caller's stream has to wait for before it touches the SDF family (sync())
     streams_->side_done.record(streams_->side);

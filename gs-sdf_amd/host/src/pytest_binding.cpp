@@ -2,6 +2,7 @@
 // neural_gaussian.cpp / local_map.cpp call) to the parity tests, so that the libtorch path is exercised exactly
 // as the reference would call it.  Not part of the product surface.
 #include <torch/extension.h>
+#include <pybind11/functional.h>
 
 #include "cumcubes/cumcubes_wrapper.h"
 #include "gsdf_extras/gsdf_extras.h"
@@ -97,6 +98,7 @@ PYBIND11_MODULE(_gsdf_host, m) {
            py::arg("ray_sdf"), py::arg("upstream"), py::arg("update") = true, py::arg("cam_host") = std::vector<float>(),
            py::call_guard<py::gil_scoped_release>())       // step() runs the autograd engine
       .def("sync", &gsdf_extras::JointIteration::sync)
+      .def("set_grad_hooks", &gsdf_extras::JointIteration::set_grad_hooks)
       .def("splat_flat", &gsdf_extras::JointIteration::splat_flat)
       .def("splat_flat_grad", &gsdf_extras::JointIteration::splat_flat_grad)
       .def("sdf_flat", &gsdf_extras::JointIteration::sdf_flat)

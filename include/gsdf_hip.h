@@ -40,6 +40,15 @@ const char *gsdf_last_error(void);
 /* ABI version; bumped on any signature change. */
 int gsdf_abi_version(void);
 
+/* Optional per-entry-point device timing (bench.py's roofline leg, for callers in any language): between gsdf_timing_begin and
+ * gsdf_timing_end every timed entry point records a HIP event pair on ITS OWN stream around everything it launches (an operator
+ * such as gsdf_hashgrid_bwd_binned2 is several kernels).  only_csv: NULL = all, else a comma-separated list of entry-point names.
+ * gsdf_timing_end stops collecting, waits for the recorded events and writes one line per entry point,
+ * "name calls total_ms min_ms max_ms median_ms\n", into buf (NUL-terminated, truncated to cap); returns the bytes the full report needs.
+ * ~10 us of host time per timed call; nothing is recorded (one atomic load per call) while timing is off. */
+int gsdf_timing_begin(const char *only_csv);
+size_t gsdf_timing_end(char *buf, size_t cap);
+
 /* ------------------------------------------------------------------------------------------
  * P1  fully_fused_projection_2dgs(means, quats, scales, viewmats, Ks, W, H, near, far,
  *                                 radius_clip, packed=true, sparse_grad=false)
