@@ -33,6 +33,7 @@ _SIGS = {
     "gsdf_rasterize_2dgs_fwd": (C.c_int, [_i64, _i64, _i64, _i32, _i32, _i32] + [_vp] * 19),
     "gsdf_rasterize_2dgs_bwd_ws_bytes": (_sz, [_i64]),
     "gsdf_rasterize_2dgs_bwd": (C.c_int, [_i64, _i64, _i64, _i32, _i32, _i32] + [_vp] * 27),
+    "gsdf_raster_set_counters": (C.c_int, [_vp]),
     "gsdf_render_post_fwd": (C.c_int, [_i64, _i32] + [_vp] * 10),
     "gsdf_render_post_bwd": (C.c_int, [_i64, _i32] + [_vp] * 12),
     "gsdf_hashgrid_offsets": (_i64, [_i32, _i32, _i32, _i32, _f32, _vp]),

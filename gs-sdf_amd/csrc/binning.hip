@@ -11,10 +11,8 @@
 // M ~ I/3), (2) the intersections are emitted in that order, (3) two stable 7-bit passes over the I (tile, splat) pairs by
 // (camera, tile) index finish the job: within a tile the entries keep the depth order, ties in emission order (= increasing
 // packed row), exactly the stable sort of SPEC A.3.  ~2.7x fewer bytes than six passes over 12-byte (key, value) pairs.
-// GSDF_BINNING_SORT=rocprim selects rocPRIM's device radix sort on the 64-bit keys (the round-1 path, kept for A/B runs).
+// (Round 1 sorted the 64-bit keys with rocPRIM; no library sort is left on any path.)
 #include <cstring>
-
-#include <rocprim/device/device_radix_sort.hpp>
 
 #include "radix.h"
 #include "scan.h"
@@ -48,30 +46,6 @@ __global__ void __launch_bounds__(BT) tile_count_kernel(int64_t M, int tile_size
     cnt = (y1 - y0) * (x1 - x0);
   }
   tiles_per_gauss[m] = cnt;
-}
-
-__global__ void __launch_bounds__(BT)
-    tile_emit_kernel(int64_t M, int tile_size, int tw, int th, int tile_bits, const float *__restrict__ means2d,
-                     const int32_t *__restrict__ radii, const float *__restrict__ depths,
-                     const int64_t *__restrict__ camera_ids, const int64_t *__restrict__ cum_tiles,
-                     uint64_t *__restrict__ keys, int32_t *__restrict__ vals) {
-  const int64_t m = (int64_t)blockIdx.x * BT + threadIdx.x;
-  if (m >= M) return;
-  const int32_t r = radii[m];
-  if (r <= 0) return;
-  const float2 xy = *reinterpret_cast<const float2 *>(means2d + 2 * m);
-  int x0, y0, x1, y1;
-  tile_rect(xy.x, xy.y, r, tile_size, tw, th, x0, y0, x1, y1);
-  int64_t pos = (m == 0) ? 0 : cum_tiles[m - 1];
-  const uint64_t hi = ((uint64_t)camera_ids[m]) << (32 + tile_bits);
-  const uint64_t lo = (uint64_t)__float_as_uint(depths[m]);
-  for (int y = y0; y < y1; ++y)
-    for (int x = x0; x < x1; ++x) {
-      const uint64_t tile_id = (uint64_t)y * tw + x;
-      keys[pos] = hi | (tile_id << 32) | lo;
-      vals[pos] = (int32_t)m;
-      ++pos;
-    }
 }
 
 // ---- depth-first pipeline ---------------------------------------------------------------------------------------
@@ -123,13 +97,6 @@ static inline int bits_for(int64_t n) {  // floor(log2(n)) + 1
   return b + 1;
 }
 
-static size_t sort_temp_bytes(int64_t I) {
-  size_t bytes = 0;
-  (void)rocprim::radix_sort_pairs<rocprim::default_config, uint64_t *, uint64_t *, int32_t *, int32_t *>(
-      nullptr, bytes, nullptr, nullptr, nullptr, nullptr, (size_t)I, 0, 64, (hipStream_t)0);
-  return bytes;
-}
-
 }  // namespace gsdf
 
 using namespace gsdf;
@@ -151,11 +118,6 @@ extern "C" int gsdf_tile_count(int64_t M, int width, int height, int tile_size, 
     GSDF_CHECK_LAUNCH("tile_count_kernel");
   }
   return scan_inclusive_i32_i64(tiles_per_gauss, cum_tiles, M, ws, n_isects, stream);
-}
-
-static bool use_rocprim() {
-  static const bool v = [] { const char *e = getenv("GSDF_BINNING_SORT"); return e && strcmp(e, "rocprim") == 0; }();
-  return v;
 }
 
 // workspace of the depth-first pipeline
@@ -183,9 +145,7 @@ static BinWs2 carve2(void *ws, int64_t M, int64_t I) {
 
 extern "C" size_t gsdf_tile_encode_ws_bytes(int64_t M, int64_t I) {
   if (I <= 0) return 256;
-  const size_t a = align_up((size_t)I * 8, 256) + align_up((size_t)I * 4, 256) + align_up(sort_temp_bytes(I), 256) + 256;   // rocPRIM path
-  const size_t b = carve2(nullptr, M, I).bytes;
-  return a > b ? a : b;
+  return carve2(nullptr, M, I).bytes;
 }
 
 extern "C" int gsdf_tile_encode(int64_t M, int64_t C, int64_t I, int width, int height, int tile_size,
@@ -207,20 +167,8 @@ extern "C" int gsdf_tile_encode(int64_t M, int64_t C, int64_t I, int width, int 
                "tile_encode: null buffer");
   const int tile_bits = bits_for(n_tiles), cam_bits = bits_for(C);
   GSDF_REQUIRE(32 + tile_bits + cam_bits <= 64, "tile_encode: key needs %d bits", 32 + tile_bits + cam_bits);
-  if (use_rocprim() || total_tiles >= (1LL << 32) || M >= (1LL << 32)) {
-    char *p = (char *)ws;
-    uint64_t *keys = (uint64_t *)p; p += align_up((size_t)I * 8, 256);
-    int32_t *vals = (int32_t *)p;   p += align_up((size_t)I * 4, 256);
-    void *temp = p;
-    size_t temp_bytes = sort_temp_bytes(I);
-    tile_emit_kernel<<<(unsigned)((M + BT - 1) / BT), BT, 0, stream>>>(M, tile_size, tw, th, tile_bits, means2d, radii,
-                                                                       depths, camera_ids, cum_tiles, keys, vals);
-    GSDF_CHECK_LAUNCH("tile_emit_kernel");
-    GSDF_HIP((rocprim::radix_sort_pairs<rocprim::default_config>(temp, temp_bytes, keys, (uint64_t *)isect_ids, vals,
-                                                                 flatten_ids, (size_t)I, 0u,
-                                                                 (unsigned)(32 + tile_bits + cam_bits), stream)),
-             "radix_sort_pairs");
-  } else {
+  GSDF_REQUIRE(total_tiles < (1LL << 32) && M < (1LL << 32), "tile_encode: more than 2^32 tiles or visible splats");
+  {
     const BinWs2 w = carve2(ws, M, I);
     const unsigned gm = (unsigned)((M + BT - 1) / BT);
     // (1) the M rows by the raw fp32 depth bits: 3 stable 11-bit passes (bits 0-10, 11-21, 22-32): depths -> B -> A -> B.  The

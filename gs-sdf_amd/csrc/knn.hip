@@ -2,13 +2,12 @@
 // Replaces the reference's (absent) simple-knn submodule, call site
 // /root/reference/include/neural_gaussian/neural_gaussian.cpp:314 (initial splat scale; init-time only).
 // Exact, like simple-knn (Morton sort + box search there); here: uniform grid sized to ~2 points per cell,
-// points sorted by cell id (integer radix sort, HBM-bound), then one lane per point walks Chebyshev shells of
-// cells until the 3rd-best distance is closer than the unexplored region.
+// points sorted by cell id (two stable 11-bit passes of the hand-written radix sort of the tile binning, radix.hip: cell ids
+// are < 2^22), then one lane per point walks Chebyshev shells of cells until the 3rd-best distance is closer than the
+// unexplored region.
 #include <cstring>
 
-#include <rocprim/device/device_radix_sort.hpp>
-
-#include "common.h"
+#include "radix.h"
 
 namespace gsdf {
 
@@ -159,12 +158,7 @@ static int64_t knn_max_cells(int64_t N) {
   int64_t c = N < 4096 ? 4096 : N;
   return c > (1 << 22) ? (1 << 22) : c;
 }
-static size_t knn_sort_temp(int64_t N) {
-  size_t bytes = 0;
-  (void)rocprim::radix_sort_pairs<rocprim::default_config, uint32_t *, uint32_t *, int32_t *, int32_t *>(
-      nullptr, bytes, nullptr, nullptr, nullptr, nullptr, (size_t)N, 0, 32, (hipStream_t)0);
-  return bytes;
-}
+static size_t knn_sort_temp(int64_t N) { return radix_ws_bytes(N); }
 
 }  // namespace gsdf
 
@@ -202,11 +196,15 @@ extern "C" int gsdf_knn_mean_dist2(int64_t N, const float *points, float *out, v
   knn_grid_kernel<<<1, 1, 0, stream>>>(N, mc, bb, grid);
   knn_cellid_kernel<<<nb, 256, 0, stream>>>(N, points, grid, keys, vals);
   GSDF_CHECK_LAUNCH("knn prep kernels");
-  GSDF_HIP((rocprim::radix_sort_pairs<rocprim::default_config>(temp, temp_bytes, keys, keys2, vals, vals2, (size_t)N, 0u, 32u, stream)),
-           "knn radix_sort_pairs");
+  // cell ids < max_cells <= 2^22: two stable passes, keys -> keys2 -> keys (values: row numbers from the first pass's iota hook)
+  (void)temp_bytes;
+  RadixHooks h0{true, nullptr, nullptr, nullptr, nullptr, 1, 0};
+  int rc = radix_pass(N, 0, 11, keys, nullptr, keys2, (uint32_t *)vals2, (uint32_t *)temp, &h0, stream);
+  if (!rc) rc = radix_pass(N, 11, 11, keys2, (const uint32_t *)vals2, keys, (uint32_t *)vals, (uint32_t *)temp, nullptr, stream);
+  if (rc) return rc;
   GSDF_HIP(hipMemsetAsync(cstart, 0, (size_t)mc * 4, stream), "knn memset");
   GSDF_HIP(hipMemsetAsync(cend, 0, (size_t)mc * 4, stream), "knn memset");
-  knn_gather_kernel<<<nb, 256, 0, stream>>>(N, points, keys2, vals2, sorted, cstart, cend);
+  knn_gather_kernel<<<nb, 256, 0, stream>>>(N, points, keys, vals, sorted, cstart, cend);
   knn_search_kernel<<<nb, 256, 0, stream>>>(N, sorted, cstart, cend, grid, out);
   GSDF_CHECK_LAUNCH("knn_search_kernel");
   return GSDF_OK;

@@ -71,7 +71,9 @@ __device__ __forceinline__ void flush_records(BwdLds<ABSGRAD> &lds, int wave, in
 
 __device__ __forceinline__ void lds_add(float *p, float v) { atomicAdd(p, v); }
 
-template <bool ABSGRAD>
+// COUNT: diagnostic instantiation (gsdf_raster_set_counters): counters[4] += (wave, splat) visits, [5] += lanes of those visits whose
+// pixel replays the splat's list position, [6] += lanes that blended the pair (pass the alpha test again).
+template <bool ABSGRAD, bool COUNT = false>
 __global__ void __launch_bounds__(RT)
     raster_bwd_kernel(int n_xcd, int64_t total_tiles, int64_t n_tiles, int64_t I, int W, int H, int tw,
                       const float *__restrict__ means2d, const float *__restrict__ ray_transforms,
@@ -83,8 +85,9 @@ __global__ void __launch_bounds__(RT)
                       const float *__restrict__ v_render_colors, const float *__restrict__ v_render_depths,
                       const float *__restrict__ v_render_alphas, const float *__restrict__ v_render_normals,
                       const float *__restrict__ v_render_median, float *__restrict__ grec,
-                      float *__restrict__ grec_abs, const float *__restrict__ final_T) {
+                      float *__restrict__ grec_abs, const float *__restrict__ final_T, unsigned long long *__restrict__ counters = nullptr) {
   __shared__ BwdLds<ABSGRAD> lds;
+  unsigned long long c_visit = 0, c_live = 0, c_valid = 0;
   const int64_t tile = xcd_tile_index(total_tiles, n_xcd);
   if (tile >= total_tiles) return;
   if (masks != nullptr && !masks[tile]) return;
@@ -170,6 +173,7 @@ __global__ void __launch_bounds__(RT)
       const float mwx = a3.x, mwy = lds.s.extra[t];
       eval_pair<true>(lx, ly, px, py, a0, a1, a2, mwx, a3.y, e, mwy);
       const bool valid = inside && (bstart + t <= bin_final) && e.ok;
+      if (COUNT) { c_visit += 1; c_live += __popcll(__ballot(inside && (bstart + t <= bin_final))); c_valid += __popcll(__ballot(valid)); }
       if (__ballot(valid) == 0ull) continue;
       const float4 a4 = lds.s.q4[t];
       const float cR = a3.z, cG = a3.w, cB = a4.x, nX = a4.y, nY = a4.z, nZ = a4.w;
@@ -238,6 +242,7 @@ __global__ void __launch_bounds__(RT)
   }
   __syncthreads();
   flush_records<ABSGRAD>(lds, wave, lane, g_mine, grec, grec_abs);
+  if (COUNT && lane == 0) { atomicAdd(counters + 4, c_visit); atomicAdd(counters + 5, c_live); atomicAdd(counters + 6, c_valid); }
 }
 
 // Streaming epilogue: unpack the 80-byte records into the operator's gradient tensors and derive the
@@ -294,6 +299,9 @@ __global__ void __launch_bounds__(256)
 
 }  // namespace gsdf
 
+namespace gsdf {
+extern unsigned long long *g_raster_counters;
+}
 using namespace gsdf;
 
 extern "C" size_t gsdf_rasterize_2dgs_bwd_ws_bytes(int64_t M) {
@@ -332,7 +340,9 @@ extern "C" int gsdf_rasterize_2dgs_bwd(int64_t C, int64_t M, int64_t I, int widt
 #define ARGS n_xcd, total, n_tiles, I, width, height, tw, means2d, ray_transforms, colors, opacities, normals, backgrounds, \
              masks, isect_offsets, flatten_ids, render_alphas, last_ids, median_ids, v_render_colors,               \
              v_render_depths, v_render_alphas, v_render_normals, v_render_median, grec, grec_abs, final_T
-    if (v_means2d_abs)
+    if (g_raster_counters != nullptr)
+      raster_bwd_kernel<false, true><<<xcd_grid(total, n_xcd), RT, 0, stream>>>(ARGS, g_raster_counters);   // (absgrad accumulation is not counted)
+    else if (v_means2d_abs)
       raster_bwd_kernel<true><<<xcd_grid(total, n_xcd), RT, 0, stream>>>(ARGS);
     else
       raster_bwd_kernel<false><<<xcd_grid(total, n_xcd), RT, 0, stream>>>(ARGS);

@@ -90,6 +90,45 @@ __device__ __forceinline__ unsigned quadrant_mask(const float *__restrict__ m, f
   return mask;
 }
 
+// The same conservative box against the tile's sixteen 4x4-pixel sub-blocks (bit 4 q + s: quadrant q, sub-block s = 2 (y >> 2 & 1) +
+// (x >> 2 & 1) within it) and against its sixteen 8x2 strips (bit 4 q + r, r = row pair within the quadrant): diagnostics of
+// tools/exp_raster_pairs.py (how many iterations a wave would need if each of its four 16-lane rows followed its own list).
+__device__ __forceinline__ void subblock_masks(const float *__restrict__ m, float mx, float my, float opac, float tile_x0, float tile_y0,
+                                               unsigned &m4x4, unsigned &m8x2) {
+  m4x4 = 0u; m8x2 = 0u;
+  const float o255 = 255.0f * opac;
+  if (!(o255 > 1.0f)) return;
+  const float tau = 2.0f * __logf(o255) * 1.0001f + 1e-4f;
+  const float r2 = sqrtf(0.5f * tau);
+  float x0 = mx - r2, x1 = mx + r2, y0 = my - r2, y1 = my + r2;
+  const float it = 1.0f / tau;
+  const float d = m[6] * m[6] + m[7] * m[7] - it * m[8] * m[8];
+  bool bounded = d < 0.0f;
+  if (bounded) {
+    const float id = 1.0f / d;
+    const float cx = (m[0] * m[6] + m[1] * m[7] - it * m[2] * m[8]) * id;
+    const float cy = (m[3] * m[6] + m[4] * m[7] - it * m[5] * m[8]) * id;
+    const float hx2 = cx * cx - (m[0] * m[0] + m[1] * m[1] - it * m[2] * m[2]) * id;
+    const float hy2 = cy * cy - (m[3] * m[3] + m[4] * m[4] - it * m[5] * m[5]) * id;
+    const float hx = sqrtf(fmaxf(hx2, 0.0f)), hy = sqrtf(fmaxf(hy2, 0.0f));
+    bounded = (hx == hx) && (hy == hy) && (cx == cx) && (cy == cy);
+    x0 = fminf(x0, cx - hx); x1 = fmaxf(x1, cx + hx);
+    y0 = fminf(y0, cy - hy); y1 = fmaxf(y1, cy + hy);
+  }
+  if (!bounded) { m4x4 = 0xFFFFu; m8x2 = 0xFFFFu; return; }
+  const float mg = 0.3f;
+  x0 -= mg; x1 += mg; y0 -= mg; y1 += mg;
+  for (int q = 0; q < 4; ++q) {
+    const float qx = tile_x0 + (float)((q & 1) * 8), qy = tile_y0 + (float)((q >> 1) * 8);
+    for (int s = 0; s < 4; ++s) {
+      const float sx = qx + (float)((s & 1) * 4), sy = qy + (float)((s >> 1) * 4);
+      if (x1 >= sx + 0.5f && x0 <= sx + 3.5f && y1 >= sy + 0.5f && y0 <= sy + 3.5f) m4x4 |= 1u << (4 * q + s);
+      const float ry = qy + (float)(2 * s);
+      if (x1 >= qx + 0.5f && x0 <= qx + 7.5f && y1 >= ry + 0.5f && y0 <= ry + 1.5f) m8x2 |= 1u << (4 * q + s);
+    }
+  }
+}
+
 template <int CAP, bool BWD>
 __device__ __forceinline__ void stage_splat(SplatBatchT<CAP, BWD> &s, int slot, int g, const float *__restrict__ means2d,
                                             const float *__restrict__ ray_transforms,

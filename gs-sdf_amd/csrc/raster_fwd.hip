@@ -7,10 +7,14 @@ namespace gsdf {
 
 struct FwdLds {
   SplatBatch s;
+  unsigned short dbg4x4[RT], dbg8x2[RT];   // COUNT build only: per staged splat, reach masks at 4x4 / 8x2 granularity
   unsigned vis[4][RT];  // per wave, per staged splat: max blending weight over the wave's pixels (fp32 bits);
                         // every (wave, splat) pair is visited once per batch -> plain stores, no LDS atomics
 };
 
+// COUNT: diagnostic instantiation (gsdf_raster_set_counters): per launch, counters[0] += (wave, splat) visits after the quadrant
+// mask, [1] += lanes of those visits whose pixel is still live, [2] += lanes that pass the alpha test, [3] += lanes that blend.
+template <bool COUNT>
 __global__ void __launch_bounds__(RT)
     raster_fwd_kernel(int n_xcd, int64_t total_tiles, int64_t n_tiles, int64_t I, int W, int H, int tw,
                       const float *__restrict__ means2d, const float *__restrict__ ray_transforms,
@@ -21,8 +25,9 @@ __global__ void __launch_bounds__(RT)
                       float *__restrict__ render_depths, float *__restrict__ render_alphas,
                       float *__restrict__ render_normals, float *__restrict__ render_median,
                       int32_t *__restrict__ last_ids, int32_t *__restrict__ median_ids,
-                      unsigned *__restrict__ visibilities, float *__restrict__ final_T) {
+                      unsigned *__restrict__ visibilities, float *__restrict__ final_T, unsigned long long *__restrict__ counters) {
   __shared__ FwdLds lds;
+  unsigned long long c_visit = 0, c_live = 0, c_ok = 0, c_blend = 0, c_empty = 0, c_r4 = 0, c_r8 = 0, c_union = 0;
   const int64_t tile = xcd_tile_index(total_tiles, n_xcd);
   if (tile >= total_tiles) return;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -63,6 +68,12 @@ __global__ void __launch_bounds__(RT)
       stage_splat(lds.s, tid, g_mine, means2d, ray_transforms, colors, opacities, normals, (float)(tx * TILE),
                   (float)(ty * TILE));
       lds.vis[0][tid] = 0u; lds.vis[1][tid] = 0u; lds.vis[2][tid] = 0u; lds.vis[3][tid] = 0u;
+      if (COUNT) {
+        unsigned a4, a8;
+        const float2 xy = *reinterpret_cast<const float2 *>(means2d + 2 * (int64_t)g_mine);
+        subblock_masks(ray_transforms + 9 * (int64_t)g_mine, xy.x, xy.y, opacities[g_mine], (float)(tx * TILE), (float)(ty * TILE), a4, a8);
+        lds.dbg4x4[tid] = (unsigned short)a4; lds.dbg8x2[tid] = (unsigned short)a8;
+      }
     }
     __syncthreads();  // barrier B
     const int count = min(RT, end - bstart);
@@ -71,6 +82,14 @@ __global__ void __launch_bounds__(RT)
     for (int c0 = 0; c0 < count; c0 += 64) {
       const int ti = c0 + lane;
       unsigned long long todo = __ballot(ti < count && ((lds.s.qmask[ti < RT ? ti : 0] >> wave) & 1u));
+      if (COUNT) {   // iterations this chunk would take if each 16-lane row of the wave followed its own list
+        int r4 = 0, r8 = 0;
+        for (int sb = 0; sb < 4; ++sb) {
+          r4 = max(r4, (int)__popcll(__ballot(ti < count && ((lds.dbg4x4[ti < RT ? ti : 0] >> (4 * wave + sb)) & 1u))));
+          r8 = max(r8, (int)__popcll(__ballot(ti < count && ((lds.dbg8x2[ti < RT ? ti : 0] >> (4 * wave + sb)) & 1u))));
+        }
+        c_r4 += r4; c_r8 += r8; c_union += __popcll(todo);
+      }
       while (todo) {
         const int t = c0 + __builtin_ctzll(todo);  // front-to-back
         todo &= todo - 1ull;
@@ -78,12 +97,14 @@ __global__ void __launch_bounds__(RT)
         PairEval e;
         eval_pair(lx, ly, px, py, a0, a1, a2, a3.x, a3.y, e);
         bool valid = !done && e.ok;
+        if (COUNT) { c_visit += 1; c_live += __popcll(__ballot(!done)); c_ok += __popcll(__ballot(valid)); c_empty += __ballot(valid) == 0ull; }
         if (__ballot(valid) == 0ull) continue;
         const float nT = T * (1.0f - e.alpha);
         if (valid && nT <= T_EPS) {  // this pixel is finished: exclusive (the splat is not blended)
           done = true;
           valid = false;
         }
+        if (COUNT) c_blend += __popcll(__ballot(valid));
         const float w = valid ? e.alpha * T : 0.0f;
         const float4 a4 = lds.s.q4[t];
         cr += a3.z * w; cg += a3.w * w; cb += a4.x * w;
@@ -101,6 +122,10 @@ __global__ void __launch_bounds__(RT)
     }
   }
   __syncthreads();
+  if (COUNT && lane == 0) {
+    atomicAdd(counters + 0, c_visit); atomicAdd(counters + 1, c_live); atomicAdd(counters + 2, c_ok); atomicAdd(counters + 3, c_blend);
+    atomicAdd(counters + 7, c_empty); atomicAdd(counters + 8, c_union); atomicAdd(counters + 9, c_r4); atomicAdd(counters + 10, c_r8);
+  }
   if (g_mine >= 0) {
     const unsigned v = max(max(lds.vis[0][tid], lds.vis[1][tid]), max(lds.vis[2][tid], lds.vis[3][tid]));
     if (v) atomicMax(visibilities + g_mine, v);
@@ -123,7 +148,15 @@ __global__ void __launch_bounds__(RT)
 
 }  // namespace gsdf
 
+namespace gsdf {
+unsigned long long *g_raster_counters = nullptr;   // device pointer to 8 x u64, or null (the normal, uninstrumented kernels)
+}
 using namespace gsdf;
+
+extern "C" int gsdf_raster_set_counters(unsigned long long *dev_counters) {
+  g_raster_counters = dev_counters;
+  return GSDF_OK;
+}
 
 extern "C" int gsdf_rasterize_2dgs_fwd(int64_t C, int64_t M, int64_t I, int width, int height, int tile_size,
                                        const float *means2d, const float *ray_transforms, const float *colors,
@@ -147,11 +180,12 @@ extern "C" int gsdf_rasterize_2dgs_fwd(int64_t C, int64_t M, int64_t I, int widt
   const int64_t n_tiles = (int64_t)tw * th, total = n_tiles * C;
   if (M > 0) GSDF_HIP(hipMemsetAsync(visibilities, 0, (size_t)M * 4, stream), "rasterize_fwd memset");
   const int n_xcd = xcd_count(stream);
-  raster_fwd_kernel<<<xcd_grid(total, n_xcd), RT, 0, stream>>>(n_xcd, total, n_tiles, I, width, height, tw, means2d, ray_transforms,
-                                                        colors, opacities, normals, backgrounds, masks, isect_offsets,
-                                                        flatten_ids, render_colors, render_depths, render_alphas,
-                                                        render_normals, render_median, last_ids, median_ids,
-                                                        (unsigned *)visibilities, final_T);
+#define FWD_ARGS n_xcd, total, n_tiles, I, width, height, tw, means2d, ray_transforms, colors, opacities, normals, backgrounds, masks, isect_offsets, \
+                 flatten_ids, render_colors, render_depths, render_alphas, render_normals, render_median, last_ids, median_ids,          \
+                 (unsigned *)visibilities, final_T, g_raster_counters
+  if (g_raster_counters != nullptr) raster_fwd_kernel<true><<<xcd_grid(total, n_xcd), RT, 0, stream>>>(FWD_ARGS);
+  else raster_fwd_kernel<false><<<xcd_grid(total, n_xcd), RT, 0, stream>>>(FWD_ARGS);
+#undef FWD_ARGS
   GSDF_CHECK_LAUNCH("raster_fwd_kernel");
   return GSDF_OK;
 }

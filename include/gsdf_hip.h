@@ -138,6 +138,12 @@ int gsdf_rasterize_2dgs_fwd(int64_t n_cams, int64_t n_visible, int64_t n_isects,
                                              backward (render_alphas = 1 - T loses it to rounding once T << 1)*/,
                             gsdf_stream_t stream);
 
+/* Diagnostic: with a device pointer to 16 zero-initialised uint64 registered, the compositing entry points launch instrumented
+ * instantiations that ADD per launch: [0] (wave, splat) visits after the per-quadrant reach mask, [1] lanes of those visits whose
+ * pixel is still live, [2] lanes passing the alpha test, [3] lanes that blend (forward); [4] visits, [5] lanes replaying, [6] lanes
+ * blending (backward); [7] forward visits in which no lane passed the alpha test; [8..10] what-if iteration counts of tools/exp_raster_pairs.py.  NULL switches back to the normal kernels.  (How much of the evaluated (pixel, splat) work is useful.) */
+int gsdf_raster_set_counters(unsigned long long *dev_counters);
+
 /* All gradient outputs are fully written.  v_means2d_abs may be NULL.  ws >= *_bwd_ws_bytes(M): the kernel
  * accumulates one packed 80-byte gradient record per splat there (line-coalesced atomics) and unpacks it.
  * final_T: the forward's saved transmittance, or NULL (then T_final = 1 - render_alphas as upstream gsplat does, which is

@@ -1,0 +1,36 @@
+"""Experiment (run on the GPU box): how much of the compositing kernels' evaluated (pixel, splat) work is useful.
+Instrumented instantiations (gsdf_raster_set_counters) at the bench workload's shape.  Usage: python tools/exp_raster_pairs.py [workload]"""
+import json, os, sys
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import gs_sdf_amd.capi as capi, gs_sdf_amd.ops as ops, gs_sdf_amd.synth as synth
+sys.path.insert(0, ROOT)
+from bench import WORKLOADS
+dev = torch.device("cuda:0")
+name = sys.argv[1] if len(sys.argv) > 1 else "cfg3_1M_1080p"
+N, W, H, deg, replica = WORKLOADS[name]
+sc = synth.make_scene(N, W, H, sh_degree=deg, seed=0, replica=replica)
+vm = synth.make_views(2, seed=1)[1:2].to(dev)
+leaves = [t.to(dev).requires_grad_(True) for t in (sc["means"], sc["quats"], sc["log_scales"].exp(), torch.sigmoid(sc["logit_opacities"]), sc["sh"])]
+cnt = torch.zeros(16, dtype=torch.int64, device=dev)
+capi.check(capi.lib().gsdf_raster_set_counters(capi.ptr(cnt)), "set_counters")
+colors, alphas, meta = ops.rasterization_2dgs_sdf(*leaves, vm, sc["K"].to(dev), W, H, near_plane=0.05, far_plane=300.0, sh_degree=deg)
+ug = {k: v.to(dev) for k, v in synth.upstream_grads(H, W, seed=2).items()}
+((colors[..., :3] * ug["v_render_colors"]).sum() + (alphas * ug["v_render_alphas"]).sum() + (meta["render_normal"] * ug["v_render_normals"]).sum()).backward()
+torch.cuda.synchronize()
+capi.lib().gsdf_raster_set_counters(None)
+c = cnt.cpu().tolist()
+I, M, P = int(meta["flatten_ids"].shape[0]), int(meta["gaussian_ids"].shape[0]), W * H
+out = dict(workload=name, M=M, I=I, P=P, staged_tile_splat_pairs=I, all_pairs_without_culling=I * 256,
+           fwd=dict(wave_visits=c[0], lanes_evaluated=c[0] * 64, lanes_live=c[1], lanes_alpha_ok=c[2], lanes_blended=c[3],
+                    visits_kept_by_quadrant_mask=c[0] / (4.0 * I), useful_of_evaluated=c[3] / max(1, c[0] * 64), alpha_ok_of_live=c[2] / max(1, c[1]),
+                    visits_with_no_useful_lane=c[7], fraction_of_visits_with_no_useful_lane=c[7] / max(1, c[0]),
+                    mean_useful_lanes_in_a_useful_visit=c[2] / max(1, c[0] - c[7]),
+                    if_each_16_lane_row_followed_its_own_list=dict(union_visits_all_pixels_live=c[8], iterations_4x4_subblocks=c[9],
+                                                                    iterations_8x2_strips=c[10])),
+           bwd=dict(wave_visits=c[4], lanes_evaluated=c[4] * 64, lanes_replaying=c[5], lanes_blended=c[6],
+                    useful_of_evaluated=c[6] / max(1, c[4] * 64)))
+print(json.dumps(out, indent=1))
+os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+json.dump(out, open(os.path.join(ROOT, "gpurun_out", f"raster_pairs_{name}.json"), "w"), indent=1)
