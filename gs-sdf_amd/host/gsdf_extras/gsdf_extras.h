@@ -9,6 +9,7 @@
 //                        numerical gradient at samples.detach()), encoder / decoder gradients accumulated in place   :420-462
 //   update_state         NeuralGS::update_state                                               neural_gaussian.cpp:626-680
 //   splat_activations    NeuralGS::generate_gaussian's exp / sigmoid / anchors + offsets      neural_gaussian.cpp:463-492
+//   render_post          expected depth, cat(colours, depth), normals to world space          neural_gaussian.cpp:229-240
 //   FusedAdam            torch::optim::Adam::step over flat (parameter, gradient) buffers     neural_mapping.cpp:466-469
 //   JointIteration       the whole loop body on the above (what bench.py --cpp-step times)     neural_mapping.cpp:400-486
 #pragma once
@@ -84,6 +85,12 @@ torch::Tensor nan_rows(const torch::Tensor &offsets, const torch::Tensor &scalin
 void update_state(std::map<std::string, torch::Tensor> &state, const torch::Tensor &densify_grad, const torch::Tensor &gaussian_ids,
                   const torch::Tensor &visibilities, const torch::Tensor &radii, int64_t n_gaussians, int n_cameras, int width,
                   int height, bool want_radii);
+
+// rasterization_2dgs_sdf's tail (neural_gaussian.cpp:229-240) in one pass, differentiable: expected depth (render_depths / alphas when
+// expected_depth), cat(colours, depth), normals rotated to world space -> {renders [C,H,W,4], render_normals_world [C,H,W,3],
+// colours [C,H,W,3], depth [C,H,W,1]} (the last two = the slices NeuralGS::render takes, :533-543)
+std::vector<torch::Tensor> render_post(const torch::Tensor &render_colors, const torch::Tensor &render_depths, const torch::Tensor &render_alphas,
+                                       const torch::Tensor &render_normals, const torch::Tensor &viewmats, bool expected_depth);
 
 // (anchors, offsets, log-scales [N,3], logit-opacities [N]) -> (xyz, scales, opacities); differentiable
 std::vector<torch::Tensor> splat_activations(const torch::Tensor &anchors, const torch::Tensor &offsets, const torch::Tensor &scaling,

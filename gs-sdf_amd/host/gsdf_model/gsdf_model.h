@@ -1,0 +1,171 @@
+// gsdf_model/gsdf_model.h — the reference's host MODEL classes on the MI355X operator layer, in C++/libtorch:
+//   gsdf_model::LocalMap  = SubMap + EncodingMap + LocalMap of /root/reference/include/neural_net/{sub_map,encoding_map,local_map}.{h,cpp}
+//   gsdf_model::NeuralGS  = NeuralGS of /root/reference/include/neural_gaussian/neural_gaussian.{h,cpp}
+// Same public members, argument meaning and behaviour (every method cites the lines it follows); what differs is what is
+// UNDER them — the hand-written HIP operators behind gsplat_cpp/*.h, tcnn_binding/tcnn_binding.h, spatial.h,
+// kaolin_wisp_cpp/* (this repository's drop-in headers) and the fused pieces of gsdf_extras — and where the configuration comes
+// from: the reference reads ~110 mutable globals `k_*` (include/params/params.h) that its YAML loader fills; these classes take
+// the values they use as plain structs (MapConfig / GSConfig, defaults = config/base.yaml), so that the model can be built and
+// tested without the reference's OpenCV / PCL / ROS control plane (out of scope).
+// The trainer (`neural_mapping.cpp`) keeps calling `local_map_ptr->get_sdf(...)`, `neural_gs_ptr->render(...)`,
+// `neural_gs_ptr->train_callback(...)` exactly as it does today: INTEGRATION.md section 6 lists the two-line edits.
+#pragma once
+#include <torch/torch.h>
+
+#include <filesystem>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "kaolin_wisp_cpp/octree_as/octree_as.h"
+#include "tcnn_binding/tcnn_binding.h"
+
+namespace gsdf_model {
+
+// sensor::Cameras (include/utils/sensor_utils/cameras.hpp:43-174): the pinhole fields the hot path reads
+struct Cameras {
+  float fx = 0, fy = 0, cx = 0, cy = 0;
+  int width = 0, height = 0;
+};
+
+// utils::DepthSamples (include/utils/ray_utils/ray_utils.h:10-142): a batch of per-ray records, every field [n, ...] or undefined
+struct DepthSamples {
+  torch::Tensor origin, direction, depth, xyz, ray_sdf, ridx, pred_sdf, pred_isigma;
+  int64_t size(int dim = 0) const;
+  DepthSamples index_select(const torch::Tensor &idx) const;
+  DepthSamples cat(const DepthSamples &other) const;
+};
+
+// the k_* globals LocalMap / SubMap / EncodingMap read (params.cpp:189-263, config/base.yaml:7-31)
+struct MapConfig {
+  float leaf_size = 0.0625f;
+  float inner_map_size = 15.875f;       // k_inner_map_size; octree level = ceil(log2((inner + 2 leaf) / leaf)), map_size = 2^level * leaf
+  float bce_sigma = 0.02f;              // k_bce_isigma = 1 / bce_sigma
+  int decoder_implementation = 0;       // 0: torch decoder topology (biases, geo_num_layer + 1 hidden matmuls), 1: tcnn FullyFusedMLP
+  int hidden_dim = 64, geo_num_layer = 3;
+  int n_levels = 16, n_features_per_level = 2, log2_hashmap_size = 19, base_resolution = 32;
+  float per_level_scale = 2.0f;
+  int free_sample_num = 3;
+  int octree_level() const;
+  float map_size() const;
+};
+
+struct LocalMap : torch::nn::Module {
+  typedef std::shared_ptr<LocalMap> Ptr;
+  // pos_W_M [1,3]: the map origin in world coordinates (SubMap::SubMap, sub_map.cpp:7-20; LocalMap::LocalMap, local_map.cpp:16-56)
+  LocalMap(const torch::Tensor &pos_W_M, const MapConfig &cfg);
+
+  MapConfig cfg_;
+  torch::Tensor pos_W_M_, xyz_max_W_, xyz_min_W_;
+  std::shared_ptr<OctreeAS> p_acc_strcut_occ_;
+  std::shared_ptr<TCNNEncoding> p_encoder_tcnn_;   // EncodingMap::p_encoder_tcnn_ (encoding_map.cpp:15-26), parameter "encoder_local_map"
+  std::shared_ptr<TCNNNetwork> p_decoder_tcnn_;    // parameter "decoder" (+ "decoder_bias" for decoder_implementation 0)
+  float map_size_inv_ = 0.f;
+
+  // ---- SubMap (sub_map.cpp)
+  void update_octree_as(const torch::Tensor &xyz, bool is_prior = false);                 // :22-35
+  torch::Tensor get_inrange_mask(const torch::Tensor &xyz, float padding = 0.f) const;     // :37-45
+  void get_intersect_point(const torch::Tensor &points, const torch::Tensor &rays, torch::Tensor &z_nears, torch::Tensor &z_fars,
+                           torch::Tensor &mask_intersect, float padding = 0.f) const;      // :47-74
+  torch::Tensor get_valid_mask(const torch::Tensor &xyz, int level = -1);                  // :76-80
+  torch::Tensor xyz_to_m1p1_pts(const torch::Tensor &xyz) const;                           // :82-93
+  torch::Tensor m1p1_pts_to_xyz(const torch::Tensor &pts) const;
+  torch::Tensor scale_from_m1p1(const torch::Tensor &t) const;
+  torch::Tensor xyz_to_zp1_pts(const torch::Tensor &xyz) const;                            // :95-97
+  // ---- LocalMap (local_map.cpp)
+  void freeze_net();                                                                       // :58-70
+  void unfreeze_net();
+  torch::Tensor get_feat(const torch::Tensor &xyz, int encoding_type = 0, bool normalized = false);   // :77-85
+  std::vector<torch::Tensor> get_sdf(const torch::Tensor &xyz);                            // :87-103 -> {sdf [B,1], isigma [B,1]}
+  std::vector<torch::Tensor> get_gradient(const torch::Tensor &xyz, float delta = 0.01f, torch::Tensor sdf = torch::Tensor(),
+                                          bool hessian = false, bool numerical_grad = true);   // :105-173
+  DepthSamples sample(const DepthSamples &samples, int voxel_sample_num = 1, bool sample_free = true);   // :449-509
+  DepthSamples filter_sample(const DepthSamples &samples);                                 // :511-516
+};
+
+// the k_* globals NeuralGS reads (config/base.yaml:37-74)
+struct GSConfig {
+  int sh_degree = 0;
+  float near = 0.05f, far = 300.0f;
+  bool use_absgrad = false, center_reg = false, geo_init = true, detach_sdf_grad = false;
+  float prune_opa = 0.05f, grow_grad2d = 0.0002f, grow_scale3d = 0.01f, grow_scale2d = 0.05f, prune_scale3d = 0.1f;
+  int refine_scale2d_stop_iter = 0, refine_start_iter = 500, refine_every = 100, reset_every = 3000, sh_degree_interval = 1000;
+  int pause_refine_after_reset = 0;
+  float lr_end = 1e-4f;
+  int64_t vis_batch_pt_num = 50 * 32768;   // k_vis_batch_pt_num (params.cpp:360)
+};
+
+struct NeuralGS : torch::nn::Module {
+  typedef std::shared_ptr<NeuralGS> Ptr;
+  // SDF-aided initialisation from a point set (neural_gaussian.cpp:273-454, without the mesh / sky-sphere variants that need the
+  // mesher and the data loader): scale from distCUDA2, rotation (and opacity) from the SDF when sdf_enable && cfg.geo_init
+  NeuralGS(const LocalMap::Ptr &local_map_ptr, const torch::Tensor &points, int num_train_data, float spatial_scale, bool sdf_enable,
+           const GSConfig &cfg);
+  // from explicit parameter tensors (tests, checkpoints): scaling = log-scales, opacity = logits
+  NeuralGS(const LocalMap::Ptr &local_map_ptr, const torch::Tensor &anchors, const torch::Tensor &scaling, const torch::Tensor &quaternion,
+           const torch::Tensor &opacity, const torch::Tensor &features_dc, const torch::Tensor &features_rest, int num_train_data,
+           float spatial_scale, const GSConfig &cfg);
+
+  LocalMap::Ptr local_map_ptr_;
+  GSConfig cfg_;
+  float spatial_scale_ = 1.f, original_spatial_scale_ = 1.f;
+  bool sdf_enable_ = false;
+  std::vector<torch::optim::OptimizerParamGroup> optimizer_params_groups_;
+  int gs_param_start_idx = 0;
+  torch::Tensor anchors_, offsets_, scaling_, quaternion_, opacity_, features_dc_, features_rest_;
+  int sh_degree_to_use_ = 0;
+  std::string key_for_gradient = "gradient_2dgs";
+  int pause_refine_after_reset = 0;
+  int num_train_data_ = 1;
+  std::mutex render_mutex_;
+  std::map<std::string, torch::Tensor> state;
+
+  torch::Tensor get_xyz();                                           // :463-465
+  torch::Tensor get_scale();                                         // :467-469
+  torch::Tensor get_opacity(bool training = false);                  // :471-478
+  // :495-566 -> {"color" [H,W,3], "depth" [H,W,1], "alpha" [1,H,W,1], "render_normal", "render_median", "normal", "gaussian_ids", "radii",
+  //             "gradient_2dgs", "samples", "samples_weights", "samples_opacities", "visibilities", "xyz", "width", "height", "n_cameras"}
+  std::map<std::string, torch::Tensor> render(const torch::Tensor &pose_cam2world, const Cameras &camera, bool training = false,
+                                              int bck_color = 0);
+  void train_callback(int iter, int total_iter, const std::shared_ptr<torch::optim::Adam> &p_optimizer,
+                      std::map<std::string, torch::Tensor> &info);   // :568-624
+  void export_gs_to_ply(const std::filesystem::path &output_path);   // :928-1039
+  void load_ply_to_gs(const std::filesystem::path &input_path);      // :1041-1188
+  void freeze_structure();
+  void unfreeze_structure();
+  // the six parameter groups in the reference's order and learning rates (:434-453), built by the constructors
+  void build_param_groups();
+
+  // (public here, private in the reference: exercised one by one by the tests)
+  void update_state(std::map<std::string, torch::Tensor> &info);     // :626-680
+  void zero_state();
+  std::pair<int, int> grow_gs(int iter, const std::shared_ptr<torch::optim::Adam> &p);          // :690-738
+  int duplicate(const std::shared_ptr<torch::optim::Adam> &p, const torch::Tensor &is_dupli);   // :740-765
+  int split(const std::shared_ptr<torch::optim::Adam> &p, const torch::Tensor &is_split);       // :767-827
+  int prune_gs(const std::shared_ptr<torch::optim::Adam> &p, const torch::Tensor &is_prune);    // :829-854
+  int prune_gs(int iter, const std::shared_ptr<torch::optim::Adam> &p, bool prune_opa_only = false);   // :856-890
+  int prune_invisible_gs(int iter, const std::shared_ptr<torch::optim::Adam> &p);               // :892-905
+  int prune_nan_gs(int iter, const std::shared_ptr<torch::optim::Adam> &p);                     // :907-916
+  void reset_opacity(const std::shared_ptr<torch::optim::Adam> &p);                             // :918-926
+
+ private:
+  std::vector<torch::Tensor *> params();   // offsets_, scaling_, quaternion_, opacity_, features_dc_, features_rest_
+  // rows `keep_idx` (undefined = all) of every parameter followed by the rows of ext[k] (empty = none); Adam moments follow
+  // (surviving rows keep theirs, new rows start from zero: include/optimizer/optimizer_utils/optimizer_utils.cpp:5-165)
+  void apply_rows(const std::shared_ptr<torch::optim::Adam> &p, const torch::Tensor &keep_idx, const std::vector<torch::Tensor> &ext);
+};
+
+// neural_gaussian.cpp:19-127: splat rotation (and optionally opacity) from the SDF's gradient and diagonal Hessian
+std::map<std::string, torch::Tensor> init_gs_with_sdf(LocalMap &local_map, const torch::Tensor &xyzs, float mesh_res, bool init_opa,
+                                                      int64_t batch_size);
+
+// neural_gaussian.cpp:129-271 on the drop-in operators -> (render_colors [C,H,W,4], render_alphas [C,H,W,1], meta)
+std::tuple<torch::Tensor, torch::Tensor, std::map<std::string, torch::Tensor>>
+rasterization_2dgs_sdf(const torch::Tensor &means, const torch::Tensor &quats, const torch::Tensor &scales, const torch::Tensor &opacities,
+                       const torch::Tensor &colors, const torch::Tensor &viewmats, const torch::Tensor &Ks, int width, int height,
+                       const std::string &render_mode, float near_plane, float far_plane, float radius_clip, at::optional<int> sh_degree,
+                       bool absgrad, bool center_reg);
+
+}  // namespace gsdf_model

@@ -89,6 +89,11 @@ struct JoinGrad : public torch::autograd::Function<JoinGrad> {
 
 namespace gsdf_extras {
 
+std::vector<Tensor> render_post(const Tensor &render_colors, const Tensor &render_depths, const Tensor &render_alphas, const Tensor &render_normals,
+                                const Tensor &viewmats, bool expected_depth) {
+  return RenderPost::apply(render_colors, render_depths, render_alphas, render_normals, viewmats, expected_depth);
+}
+
 struct JointStreams {
   c10::hip::HIPStreamMasqueradingAsCUDA side = c10::hip::getStreamFromPoolMasqueradingAsCUDA();
   at::cuda::CUDAEvent fwd_done, entry, side_done;

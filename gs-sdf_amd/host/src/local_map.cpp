@@ -1,0 +1,203 @@
+// local_map.cpp — gsdf_model::LocalMap: SubMap + EncodingMap + LocalMap of the reference
+// (/root/reference/include/neural_net/{sub_map,encoding_map,local_map}.{h,cpp}) on the drop-in operator layer.
+// Python mirror: gs_sdf_amd/sdf.py (class LocalMap); the two are compared in tests/test_gpu_cpp_model.py.
+#include <cmath>
+
+#include "gsdf_extras/gsdf_extras.h"
+#include "gsdf_model/gsdf_model.h"
+#include "kaolin_wisp_cpp/spc_ops/spc_ops.h"
+#include "util.h"
+
+using torch::Tensor;
+
+namespace gsdf_model {
+
+// ---- DepthSamples (ray_utils.h:10-142) ---------------------------------------------------------------------------------
+namespace {
+template <typename F>
+DepthSamples map_fields(const DepthSamples &s, F f) {
+  DepthSamples o;
+  auto g = [&](const Tensor &t) { return t.defined() ? f(t) : Tensor(); };
+  o.origin = g(s.origin); o.direction = g(s.direction); o.depth = g(s.depth); o.xyz = g(s.xyz); o.ray_sdf = g(s.ray_sdf); o.ridx = g(s.ridx);
+  o.pred_sdf = g(s.pred_sdf); o.pred_isigma = g(s.pred_isigma);
+  return o;
+}
+}  // namespace
+
+int64_t DepthSamples::size(int dim) const {
+  for (const Tensor *t : {&xyz, &origin, &direction, &depth, &ray_sdf, &ridx})
+    if (t->defined()) return t->size(dim);
+  return 0;
+}
+DepthSamples DepthSamples::index_select(const Tensor &idx) const {
+  return map_fields(*this, [&](const Tensor &t) { return t.index_select(0, idx); });
+}
+DepthSamples DepthSamples::cat(const DepthSamples &other) const {
+  DepthSamples o;
+  auto c = [](const Tensor &a, const Tensor &b) { return (a.defined() && b.defined()) ? torch::cat({a, b}, 0) : Tensor(); };
+  o.origin = c(origin, other.origin); o.direction = c(direction, other.direction); o.depth = c(depth, other.depth); o.xyz = c(xyz, other.xyz);
+  o.ray_sdf = c(ray_sdf, other.ray_sdf); o.ridx = c(ridx, other.ridx); o.pred_sdf = c(pred_sdf, other.pred_sdf);
+  o.pred_isigma = c(pred_isigma, other.pred_isigma);
+  return o;
+}
+
+// ---- MapConfig: params.cpp:243-256 ---------------------------------------------------------------------------------------
+int MapConfig::octree_level() const { return (int)std::ceil(std::log2((inner_map_size + 2.f * leaf_size) / leaf_size)); }
+float MapConfig::map_size() const { return std::pow(2.f, (float)octree_level()) * leaf_size; }
+
+// ---- construction: sub_map.cpp:7-20, encoding_map.cpp:6-30, local_map.cpp:16-56 --------------------------------------------
+LocalMap::LocalMap(const Tensor &pos_W_M, const MapConfig &cfg) : cfg_(cfg) {
+  TORCH_CHECK(torch::cuda::is_available(), "gsdf_model::LocalMap: no HIP device (this path has no CPU fallback)");
+  pos_W_M_ = pos_W_M.view({1, 3}).to(torch::kCUDA).to(torch::kFloat32);
+  const float half = 0.5f * cfg.inner_map_size;
+  xyz_min_W_ = pos_W_M_ - half;
+  xyz_max_W_ = pos_W_M_ + half;
+  map_size_inv_ = 1.0f / cfg.map_size();
+  // encoder: the tcnn "Grid"/"Hash" configuration of encoding_map.cpp:15-23
+  nlohmann::json enc_cfg = {{"otype", "Grid"}, {"type", "Hash"}, {"n_levels", cfg.n_levels}, {"n_features_per_level", cfg.n_features_per_level},
+                            {"log2_hashmap_size", cfg.log2_hashmap_size}, {"base_resolution", cfg.base_resolution},
+                            {"per_level_scale", cfg.per_level_scale}, {"interpolation", "Linear"}};
+  p_encoder_tcnn_ = std::make_shared<TCNNEncoding>(3, enc_cfg, "encoder_local_map");
+  p_encoder_tcnn_->params_ = register_parameter(p_encoder_tcnn_->name_, p_encoder_tcnn_->params_, true);   // local_map.cpp:73-75
+  const int feat = (int)p_encoder_tcnn_->get_out_dim();
+  // decoder: implementation 0 = Linear(feat, h) + ReLU, geo_num_layer x [Linear(h, h) + ReLU], Linear(h, 2) with biases
+  // (local_map.cpp:29-42), on the fused kernels; implementation 1 = tcnn FullyFusedMLP with geo_num_layer hidden layers (:44-55)
+  const bool torch_topology = cfg.decoder_implementation == 0;
+  nlohmann::json net_cfg = {{"otype", "FullyFusedMLP"}, {"activation", "ReLU"}, {"output_activation", "None"}, {"n_neurons", cfg.hidden_dim},
+                            {"n_hidden_layers", cfg.geo_num_layer + (torch_topology ? 1 : 0)}, {"bias", torch_topology}};
+  p_decoder_tcnn_ = std::make_shared<TCNNNetwork>(feat, 2, net_cfg, "decoder");
+  p_decoder_tcnn_->params_ = register_parameter(p_decoder_tcnn_->name_, p_decoder_tcnn_->params_, true);
+  if (p_decoder_tcnn_->biases_.defined()) p_decoder_tcnn_->biases_ = register_parameter("decoder_bias", p_decoder_tcnn_->biases_, true);
+}
+
+// ---- SubMap ----------------------------------------------------------------------------------------------------------------
+Tensor LocalMap::xyz_to_m1p1_pts(const Tensor &xyz) const { return (xyz - pos_W_M_) * 2 * map_size_inv_; }
+Tensor LocalMap::m1p1_pts_to_xyz(const Tensor &pts) const { return scale_from_m1p1(pts) + pos_W_M_; }
+Tensor LocalMap::scale_from_m1p1(const Tensor &t) const { return t * 0.5 * (1.0 / map_size_inv_); }
+Tensor LocalMap::xyz_to_zp1_pts(const Tensor &xyz) const { return 0.5f * xyz_to_m1p1_pts(xyz) + 0.5f; }
+
+void LocalMap::update_octree_as(const Tensor &xyz, bool is_prior) {
+  torch::NoGradGuard ng;
+  const int level = cfg_.octree_level();
+  Tensor qpts = spc_ops::quantize_points(xyz_to_m1p1_pts(xyz.to(pos_W_M_.device())), level);
+  qpts = std::get<0>(torch::unique_dim(qpts.contiguous(), 0));
+  if (!is_prior) qpts = spc_ops::points_to_neighbors(qpts).view({-1, 3}).clamp(0, (1 << level) - 1);
+  p_acc_strcut_occ_ = std::shared_ptr<OctreeAS>(from_quantized_points(qpts, level));
+}
+
+Tensor LocalMap::get_inrange_mask(const Tensor &xyz, float padding) const {
+  return ((xyz < (xyz_max_W_ - padding - 1e-6).to(xyz.device())) & (xyz > (xyz_min_W_ + padding + 1e-6).to(xyz.device()))).all(1);
+}
+
+void LocalMap::get_intersect_point(const Tensor &points, const Tensor &rays, Tensor &z_nears, Tensor &z_fars, Tensor &mask_intersect,
+                                   float padding) const {
+  // parallel rays are nudged off zero so that the slab test stays finite; they fail the near < far check below
+  Tensor tmp = torch::where(rays == 0, rays + 1e-6, rays);
+  Tensor a = (xyz_min_W_ + padding - points) / tmp, b = (xyz_max_W_ - padding - points) / tmp;
+  z_nears = std::get<0>(torch::max(torch::minimum(a, b), 1));
+  z_fars = std::get<0>(torch::min(torch::maximum(a, b), 1));
+  mask_intersect = z_nears < z_fars;
+}
+
+Tensor LocalMap::get_valid_mask(const Tensor &xyz, int level) {
+  TORCH_CHECK(p_acc_strcut_occ_ != nullptr, "LocalMap::get_valid_mask: update_octree_as has not been called");
+  return p_acc_strcut_occ_->query(xyz_to_m1p1_pts(xyz), level).pidx > -1;
+}
+
+// ---- LocalMap --------------------------------------------------------------------------------------------------------------
+void LocalMap::freeze_net() {
+  p_encoder_tcnn_->params_.requires_grad_(false);
+  p_decoder_tcnn_->params_.requires_grad_(false);
+  if (p_decoder_tcnn_->biases_.defined()) p_decoder_tcnn_->biases_.requires_grad_(false);
+}
+void LocalMap::unfreeze_net() {
+  p_encoder_tcnn_->params_.requires_grad_(true);
+  p_decoder_tcnn_->params_.requires_grad_(true);
+  if (p_decoder_tcnn_->biases_.defined()) p_decoder_tcnn_->biases_.requires_grad_(true);
+}
+
+Tensor LocalMap::get_feat(const Tensor &xyz, int encoding_type, bool normalized) {
+  (void)encoding_type;   // the reference has a single encoder type
+  return p_encoder_tcnn_->forward(normalized ? xyz : xyz_to_zp1_pts(xyz));
+}
+
+std::vector<Tensor> LocalMap::get_sdf(const Tensor &xyz) {
+  Tensor attr = p_decoder_tcnn_->forward(get_feat(xyz, 0, false));
+  auto parts = torch::split(attr, {1, 1}, -1);   // sdf, raw isigma
+  return {parts[0], 1 + torch::softplus(parts[1], /*beta=*/100) * (1.0 / cfg_.bce_sigma)};
+}
+
+std::vector<Tensor> LocalMap::get_gradient(const Tensor &xyz_, float delta, Tensor sdf, bool hessian, bool numerical_grad) {
+  if (numerical_grad) {
+    // central differences on the 6-point stencil (+x,-x,+y,-y,+z,-z), [6,n,3] -> one get_sdf over 6n points
+    Tensor offs = torch::tensor({{{delta, 0.f, 0.f}}, {{-delta, 0.f, 0.f}}, {{0.f, delta, 0.f}}, {{0.f, -delta, 0.f}}, {{0.f, 0.f, delta}}, {{0.f, 0.f, -delta}}},
+                                xyz_.options().requires_grad(false));
+    Tensor ps = get_sdf((xyz_.unsqueeze(0) + offs).view({-1, 3}))[0].view({6, xyz_.size(0), 1});
+    const double inv = 1.0 / delta;
+    Tensor grad = 0.5 * inv * torch::cat({ps[0] - ps[1], ps[2] - ps[3], ps[4] - ps[5]}, 1);
+    if (!hessian) return {grad};
+    if (!sdf.defined()) sdf = get_sdf(xyz_)[0];
+    Tensor hess = inv * inv * (torch::cat({ps[0] + ps[1], ps[2] + ps[3], ps[4] + ps[5]}, 1) - 2 * sdf);
+    return {grad, hess};
+  }
+  // analytic: torch::autograd::grad(create_graph = true) through the fused decoder and the hash grid (both second order)
+  const bool grad_mode = torch::GradMode::is_enabled();
+  torch::GradMode::set_enabled(true);
+  Tensor xyz = xyz_;
+  if (!xyz.requires_grad() || !sdf.defined()) {
+    xyz.requires_grad_(true);
+    sdf = get_sdf(xyz)[0];
+  }
+  Tensor g = torch::autograd::grad({sdf}, {xyz}, {torch::ones_like(sdf)}, true, true)[0];
+  std::vector<Tensor> out = {g};
+  if (hessian) out.push_back(torch::autograd::grad({g}, {xyz}, {torch::ones_like(g)}, true, true)[0]);
+  torch::GradMode::set_enabled(grad_mode);
+  return out;
+}
+
+namespace {
+// utils::sample_free_pts (include/utils/utils.cpp:366-393): stratified, jittered samples in [0, depth) of every ray
+DepthSamples sample_free_pts(const DepthSamples &rays, int sample_num) {
+  const int64_t n = rays.origin.size(0);
+  Tensor steps = torch::arange(sample_num, rays.origin.options()).unsqueeze(0).repeat({n, 1});
+  steps = (steps + torch::rand({n, sample_num}, rays.origin.options())) / (double)sample_num;
+  Tensor ridx = torch::arange(n, rays.origin.options().dtype(torch::kInt64)).unsqueeze(1).repeat({1, sample_num}).reshape({-1});
+  DepthSamples out = rays.index_select(ridx);
+  Tensor d = out.depth * steps.reshape({-1, 1});
+  out.xyz = out.origin + out.direction * d;
+  out.ray_sdf = out.depth - d;
+  out.depth = d;
+  out.ridx = rays.ridx.defined() ? rays.ridx.index_select(0, ridx) : ridx;
+  return out;
+}
+}  // namespace
+
+DepthSamples LocalMap::sample(const DepthSamples &samples_in, int voxel_sample_num, bool sample_free) {
+  DepthSamples samples;
+  if (voxel_sample_num < 1) {
+    samples.xyz = samples_in.xyz;
+    samples.ray_sdf = torch::zeros_like(samples_in.depth);
+    samples.direction = samples_in.direction;
+    samples.ridx = samples_in.ridx;
+    return samples;
+  }
+  TORCH_CHECK(p_acc_strcut_occ_ != nullptr, "LocalMap::sample: update_octree_as has not been called");
+  // one sample per occupied voxel a ray crosses (octree ray march in the [-1,1] frame), SDF target = ray depth - sample depth
+  auto rm = p_acc_strcut_occ_->raymarch(xyz_to_m1p1_pts(samples_in.origin).contiguous(), samples_in.direction.contiguous(), "voxel", voxel_sample_num);
+  samples = samples_in.index_select(rm.ridx);
+  samples.ridx = rm.ridx;
+  samples.xyz = m1p1_pts_to_xyz(rm.samples);
+  Tensor d = scale_from_m1p1(rm.depth_samples);
+  samples.ray_sdf = samples.depth - d;
+  samples.depth = d;
+  if (sample_free) samples = samples.cat(sample_free_pts(samples_in, cfg_.free_sample_num));
+  // keep what lies in front of the surface
+  return samples.index_select((samples.ray_sdf > 0).reshape({-1}).nonzero().reshape({-1}));
+}
+
+DepthSamples LocalMap::filter_sample(const DepthSamples &samples) {
+  TORCH_CHECK(p_acc_strcut_occ_ != nullptr, "LocalMap::filter_sample: update_octree_as has not been called");
+  return samples.index_select((p_acc_strcut_occ_->query(xyz_to_m1p1_pts(samples.xyz)).pidx > -1).nonzero().reshape({-1}));
+}
+
+}  // namespace gsdf_model

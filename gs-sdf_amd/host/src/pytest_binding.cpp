@@ -6,6 +6,7 @@
 
 #include "cumcubes/cumcubes_wrapper.h"
 #include "gsdf_extras/gsdf_extras.h"
+#include "gsdf_model/gsdf_model.h"
 #include "gsplat_cpp/fully_fused_projection.h"
 #include "gsplat_cpp/rasterize_to_pixels.h"
 #include "gsplat_cpp/rendering.h"
@@ -134,4 +135,175 @@ PYBIND11_MODULE(_gsdf_host, m) {
   });
   m.def("normal_consistency_loss", &gsdf_extras::normal_consistency_loss);
   m.def("isotropic_loss", &gsdf_extras::isotropic_loss);
+  m.def("render_post", &gsdf_extras::render_post);
+
+  // ---- gsdf_model: the reference's model classes (tests/test_gpu_cpp_model.py compares them with the Python mirror) ----------------
+  namespace gm = gsdf_model;
+  auto opt_t = [](const py::object &o) { return o.is_none() ? torch::Tensor() : o.cast<torch::Tensor>(); };
+  auto to_samples = [opt_t](const py::dict &d) {
+    gm::DepthSamples s;
+    auto g = [&](const char *k) { return d.contains(k) ? opt_t(d[k]) : torch::Tensor(); };
+    s.origin = g("origin"); s.direction = g("direction"); s.depth = g("depth"); s.xyz = g("xyz"); s.ray_sdf = g("ray_sdf"); s.ridx = g("ridx");
+    return s;
+  };
+  auto from_samples = [](const gm::DepthSamples &s) {
+    py::dict d;
+    auto p = [&](const char *k, const torch::Tensor &t) { if (t.defined()) d[k] = t; };
+    p("origin", s.origin); p("direction", s.direction); p("depth", s.depth); p("xyz", s.xyz); p("ray_sdf", s.ray_sdf); p("ridx", s.ridx);
+    return d;
+  };
+  py::class_<gm::MapConfig>(m, "MapConfig")
+      .def(py::init<>())
+      .def_readwrite("leaf_size", &gm::MapConfig::leaf_size)
+      .def_readwrite("inner_map_size", &gm::MapConfig::inner_map_size)
+      .def_readwrite("bce_sigma", &gm::MapConfig::bce_sigma)
+      .def_readwrite("decoder_implementation", &gm::MapConfig::decoder_implementation)
+      .def_readwrite("hidden_dim", &gm::MapConfig::hidden_dim)
+      .def_readwrite("geo_num_layer", &gm::MapConfig::geo_num_layer)
+      .def_readwrite("n_levels", &gm::MapConfig::n_levels)
+      .def_readwrite("n_features_per_level", &gm::MapConfig::n_features_per_level)
+      .def_readwrite("log2_hashmap_size", &gm::MapConfig::log2_hashmap_size)
+      .def_readwrite("base_resolution", &gm::MapConfig::base_resolution)
+      .def_readwrite("per_level_scale", &gm::MapConfig::per_level_scale)
+      .def_readwrite("free_sample_num", &gm::MapConfig::free_sample_num)
+      .def("octree_level", &gm::MapConfig::octree_level)
+      .def("map_size", &gm::MapConfig::map_size);
+  py::class_<gm::LocalMap, std::shared_ptr<gm::LocalMap>>(m, "LocalMap")
+      .def(py::init([](const torch::Tensor &pos, const gm::MapConfig &cfg) { return std::make_shared<gm::LocalMap>(pos, cfg); }))
+      .def_readonly("map_size_inv_", &gm::LocalMap::map_size_inv_)
+      .def_readonly("pos_W_M_", &gm::LocalMap::pos_W_M_)
+      .def_readonly("xyz_min_W_", &gm::LocalMap::xyz_min_W_)
+      .def_readonly("xyz_max_W_", &gm::LocalMap::xyz_max_W_)
+      .def_property_readonly("encoder", [](gm::LocalMap &l) { return l.p_encoder_tcnn_; })
+      .def_property_readonly("decoder", [](gm::LocalMap &l) { return l.p_decoder_tcnn_; })
+      .def("named_parameters", [](gm::LocalMap &l) {
+        std::map<std::string, torch::Tensor> out;
+        for (auto &kv : l.named_parameters()) out[kv.key()] = kv.value();
+        return out;
+      })
+      .def("update_octree_as", &gm::LocalMap::update_octree_as, py::arg("xyz"), py::arg("is_prior") = false)
+      .def("get_inrange_mask", &gm::LocalMap::get_inrange_mask, py::arg("xyz"), py::arg("padding") = 0.f)
+      .def("get_intersect_point", [](gm::LocalMap &l, const torch::Tensor &pts, const torch::Tensor &rays, float padding) {
+        torch::Tensor a, b, c;
+        l.get_intersect_point(pts, rays, a, b, c, padding);
+        return std::make_tuple(a, b, c);
+      }, py::arg("points"), py::arg("rays"), py::arg("padding") = 0.f)
+      .def("get_valid_mask", &gm::LocalMap::get_valid_mask, py::arg("xyz"), py::arg("level") = -1)
+      .def("xyz_to_m1p1_pts", &gm::LocalMap::xyz_to_m1p1_pts)
+      .def("m1p1_pts_to_xyz", &gm::LocalMap::m1p1_pts_to_xyz)
+      .def("xyz_to_zp1_pts", &gm::LocalMap::xyz_to_zp1_pts)
+      .def("freeze_net", &gm::LocalMap::freeze_net)
+      .def("unfreeze_net", &gm::LocalMap::unfreeze_net)
+      .def("get_feat", &gm::LocalMap::get_feat, py::arg("xyz"), py::arg("encoding_type") = 0, py::arg("normalized") = false)
+      .def("get_sdf", &gm::LocalMap::get_sdf)
+      .def("get_gradient", [opt_t](gm::LocalMap &l, const torch::Tensor &xyz, float delta, py::object sdf, bool hessian, bool numerical) {
+        return l.get_gradient(xyz, delta, opt_t(sdf), hessian, numerical);
+      }, py::arg("xyz"), py::arg("delta") = 0.01f, py::arg("sdf") = py::none(), py::arg("hessian") = false, py::arg("numerical_grad") = true)
+      .def("sample", [to_samples, from_samples](gm::LocalMap &l, const py::dict &s, int n, bool sample_free) {
+        return from_samples(l.sample(to_samples(s), n, sample_free));
+      }, py::arg("samples"), py::arg("voxel_sample_num") = 1, py::arg("sample_free") = true)
+      .def("filter_sample", [to_samples, from_samples](gm::LocalMap &l, const py::dict &s) { return from_samples(l.filter_sample(to_samples(s))); });
+  py::class_<gm::GSConfig>(m, "GSConfig")
+      .def(py::init<>())
+      .def_readwrite("sh_degree", &gm::GSConfig::sh_degree)
+      .def_readwrite("near", &gm::GSConfig::near)
+      .def_readwrite("far", &gm::GSConfig::far)
+      .def_readwrite("use_absgrad", &gm::GSConfig::use_absgrad)
+      .def_readwrite("center_reg", &gm::GSConfig::center_reg)
+      .def_readwrite("geo_init", &gm::GSConfig::geo_init)
+      .def_readwrite("detach_sdf_grad", &gm::GSConfig::detach_sdf_grad)
+      .def_readwrite("prune_opa", &gm::GSConfig::prune_opa)
+      .def_readwrite("grow_grad2d", &gm::GSConfig::grow_grad2d)
+      .def_readwrite("grow_scale3d", &gm::GSConfig::grow_scale3d)
+      .def_readwrite("grow_scale2d", &gm::GSConfig::grow_scale2d)
+      .def_readwrite("prune_scale3d", &gm::GSConfig::prune_scale3d)
+      .def_readwrite("refine_scale2d_stop_iter", &gm::GSConfig::refine_scale2d_stop_iter)
+      .def_readwrite("refine_start_iter", &gm::GSConfig::refine_start_iter)
+      .def_readwrite("refine_every", &gm::GSConfig::refine_every)
+      .def_readwrite("reset_every", &gm::GSConfig::reset_every)
+      .def_readwrite("sh_degree_interval", &gm::GSConfig::sh_degree_interval)
+      .def_readwrite("pause_refine_after_reset", &gm::GSConfig::pause_refine_after_reset)
+      .def_readwrite("lr_end", &gm::GSConfig::lr_end)
+      .def_readwrite("vis_batch_pt_num", &gm::GSConfig::vis_batch_pt_num);
+  // torch::optim::Adam over (SDF groups, splat groups) as NeuralSLAM builds it (neural_mapping.cpp:846-858)
+  struct AdamBox { std::shared_ptr<torch::optim::Adam> p; };
+  py::class_<AdamBox>(m, "Adam")
+      .def("step", [](AdamBox &a) { a.p->step(); })
+      .def("zero_grad", [](AdamBox &a) { a.p->zero_grad(); })
+      .def("n_groups", [](AdamBox &a) { return a.p->param_groups().size(); })
+      .def("lr", [](AdamBox &a, int g) { return a.p->param_groups().at(g).options().get_lr(); })
+      .def("param", [](AdamBox &a, int g) { return a.p->param_groups().at(g).params().at(0); })
+      .def("moments", [](AdamBox &a, int g) {
+        auto &t = a.p->param_groups().at(g).params().at(0);
+        auto it = a.p->state().find(t.unsafeGetTensorImpl());
+        if (it == a.p->state().end()) return std::vector<torch::Tensor>{};
+        auto &st = static_cast<torch::optim::AdamParamState &>(*it->second);
+        return std::vector<torch::Tensor>{st.exp_avg(), st.exp_avg_sq()};
+      });
+  py::class_<gm::NeuralGS, std::shared_ptr<gm::NeuralGS>>(m, "NeuralGS")
+      .def(py::init([](py::object lm, const torch::Tensor &anchors, const torch::Tensor &scaling, const torch::Tensor &quat, const torch::Tensor &opa,
+                       const torch::Tensor &dc, const torch::Tensor &rest, int num_train_data, float spatial_scale, const gm::GSConfig &cfg) {
+        auto l = lm.is_none() ? gm::LocalMap::Ptr() : lm.cast<gm::LocalMap::Ptr>();
+        return std::make_shared<gm::NeuralGS>(l, anchors, scaling, quat, opa, dc, rest, num_train_data, spatial_scale, cfg);
+      }))
+      .def_static("from_points", [](py::object lm, const torch::Tensor &points, int num_train_data, float spatial_scale, bool sdf_enable, const gm::GSConfig &cfg) {
+        auto l = lm.is_none() ? gm::LocalMap::Ptr() : lm.cast<gm::LocalMap::Ptr>();
+        return std::make_shared<gm::NeuralGS>(l, points, num_train_data, spatial_scale, sdf_enable, cfg);
+      })
+      .def_readonly("anchors_", &gm::NeuralGS::anchors_)
+      .def_readonly("offsets_", &gm::NeuralGS::offsets_)
+      .def_readonly("scaling_", &gm::NeuralGS::scaling_)
+      .def_readonly("quaternion_", &gm::NeuralGS::quaternion_)
+      .def_readonly("opacity_", &gm::NeuralGS::opacity_)
+      .def_readonly("features_dc_", &gm::NeuralGS::features_dc_)
+      .def_readonly("features_rest_", &gm::NeuralGS::features_rest_)
+      .def_readwrite("sh_degree_to_use_", &gm::NeuralGS::sh_degree_to_use_)
+      .def_readwrite("gs_param_start_idx", &gm::NeuralGS::gs_param_start_idx)
+      .def_readonly("spatial_scale_", &gm::NeuralGS::spatial_scale_)
+      .def_readwrite("state", &gm::NeuralGS::state)
+      .def("named_parameters", [](gm::NeuralGS &g) {
+        std::map<std::string, torch::Tensor> out;
+        for (auto &kv : g.named_parameters()) out[kv.key()] = kv.value();
+        return out;
+      })
+      .def("get_xyz", &gm::NeuralGS::get_xyz)
+      .def("get_scale", &gm::NeuralGS::get_scale)
+      .def("get_opacity", &gm::NeuralGS::get_opacity, py::arg("training") = false)
+      .def("make_optimizer", [](gm::NeuralGS &g, py::object lm, double sdf_lr) {
+        std::vector<torch::optim::OptimizerParamGroup> groups;
+        if (!lm.is_none()) {
+          auto l = lm.cast<gm::LocalMap::Ptr>();
+          for (auto &t : l->parameters()) {
+            auto o = std::make_unique<torch::optim::AdamOptions>(sdf_lr);
+            o->eps(1e-15);
+            groups.emplace_back(std::vector<torch::Tensor>{t}, std::move(o));
+          }
+        }
+        g.gs_param_start_idx = (int)groups.size();
+        for (auto &grp : g.optimizer_params_groups_) groups.push_back(grp);
+        AdamBox box;
+        box.p = std::make_shared<torch::optim::Adam>(groups, torch::optim::AdamOptions(1e-3).eps(1e-15));
+        return box;
+      }, py::arg("local_map") = py::none(), py::arg("sdf_lr") = 1e-3)
+      .def("render", [](gm::NeuralGS &g, const torch::Tensor &pose, float fx, float fy, float cx, float cy, int w, int h, bool training, int bck) {
+        gm::Cameras cam;
+        cam.fx = fx; cam.fy = fy; cam.cx = cx; cam.cy = cy; cam.width = w; cam.height = h;
+        return g.render(pose, cam, training, bck);
+      }, py::arg("pose_cam2world"), py::arg("fx"), py::arg("fy"), py::arg("cx"), py::arg("cy"), py::arg("width"), py::arg("height"),
+           py::arg("training") = false, py::arg("bck_color") = 0)
+      .def("train_callback", [](gm::NeuralGS &g, int iter, int total, AdamBox &a, std::map<std::string, torch::Tensor> info) {
+        g.train_callback(iter, total, a.p, info);
+      })
+      .def("update_state", [](gm::NeuralGS &g, std::map<std::string, torch::Tensor> info) { g.update_state(info); })
+      .def("grow_gs", [](gm::NeuralGS &g, int iter, AdamBox &a) { return g.grow_gs(iter, a.p); })
+      .def("prune_gs", [](gm::NeuralGS &g, int iter, AdamBox &a, bool opa_only) { return g.prune_gs(iter, a.p, opa_only); },
+           py::arg("iter"), py::arg("optimizer"), py::arg("prune_opa_only") = false)
+      .def("prune_nan_gs", [](gm::NeuralGS &g, int iter, AdamBox &a) { return g.prune_nan_gs(iter, a.p); })
+      .def("prune_invisible_gs", [](gm::NeuralGS &g, int iter, AdamBox &a) { return g.prune_invisible_gs(iter, a.p); })
+      .def("reset_opacity", [](gm::NeuralGS &g, AdamBox &a) { g.reset_opacity(a.p); })
+      .def("export_gs_to_ply", [](gm::NeuralGS &g, const std::string &p) { g.export_gs_to_ply(p); })
+      .def("load_ply_to_gs", [](gm::NeuralGS &g, const std::string &p) { g.load_ply_to_gs(p); });
+  m.def("init_gs_with_sdf", [](gm::LocalMap::Ptr lm, const torch::Tensor &xyz, float mesh_res, bool init_opa, int64_t batch) {
+    return gm::init_gs_with_sdf(*lm, xyz, mesh_res, init_opa, batch);
+  });
 }

@@ -1,0 +1,290 @@
+"""gsdf_model::LocalMap / gsdf_model::NeuralGS (gs-sdf_amd/host/gsdf_model/gsdf_model.h: the reference's C++ model classes on the
+drop-in operators) against the Python mirror (gs_sdf_amd.sdf.LocalMap, gs_sdf_amd.neural_gs.NeuralGS), which the other GPU tests pin
+to the oracle.  Both run the same kernels, so forward values must agree to rounding of the host-side arithmetic, the discrete
+decisions (refinement: who is duplicated / split / pruned, Adam moments of the survivors) exactly."""
+import math
+
+import pytest
+import torch
+
+import gs_sdf_amd.synth as synth
+from util import assert_close, assert_equal_int
+
+pytestmark = pytest.mark.gpu
+
+GRID = dict(n_levels=16, n_features_per_level=2, log2_hashmap_size=19, base_resolution=32, per_level_scale=2.0)
+
+
+@pytest.fixture(scope="module")
+def host():
+    assert torch.cuda.is_available()
+    import gs_sdf_amd.hostlib as h
+    return h.load()
+
+
+def make_maps(host, decoder_implementation, origin=(0.0, 0.0, 5.5), inner=15.0, leaf=0.25):
+    """the C++ LocalMap and the Python mirror with the C++ one's parameters"""
+    import gs_sdf_amd.sdf as sdfm
+    dev = torch.device("cuda:0")
+    cfg = host.MapConfig()
+    cfg.leaf_size, cfg.inner_map_size, cfg.decoder_implementation = leaf, inner, decoder_implementation
+    for k, v in GRID.items():
+        setattr(cfg, k, v)
+    torch.manual_seed(11)
+    cm = host.LocalMap(torch.tensor(origin), cfg)
+    enc = dict(otype="Grid", type="Hash", interpolation="Linear", **GRID)
+    pm = sdfm.LocalMap(list(origin), cfg.map_size(), decoder_implementation=decoder_implementation, device=dev, seed=1, encoding_config=enc)
+    pm.set_bounds(inner, leaf)
+    with torch.no_grad():
+        pm.encoder.params_.copy_(cm.encoder.params_)
+        pm.decoder.params_.copy_(cm.decoder.params_)
+        if decoder_implementation == 0:
+            pm.decoder.biases_.copy_(cm.decoder.biases_)
+        # the random initialisation of a hash grid is ~1e-4: scale the table so that the SDF has curvature to compare
+        for t in (cm.encoder.params_, pm.encoder.params_):
+            t.mul_(200.0)
+    return cm, pm, cfg
+
+
+@pytest.mark.parametrize("impl", [0, 1])
+def test_local_map_queries_match_python_mirror(host, impl):
+    dev = torch.device("cuda:0")
+    cm, pm, cfg = make_maps(host, impl)
+    assert cfg.octree_level() == pm.octree_level and abs(cfg.map_size() * pm.map_size_inv - 1) < 1e-6
+    names = set(cm.named_parameters())
+    assert names == ({"encoder_local_map", "decoder", "decoder_bias"} if impl == 0 else {"encoder_local_map", "decoder"})
+    g = torch.Generator(device=dev).manual_seed(3)
+    xyz = (torch.rand(30000, 3, device=dev, generator=g) - 0.5) * 14.0 + torch.tensor([0.0, 0.0, 5.5], device=dev)
+    assert_close(cm.xyz_to_zp1_pts(xyz), pm.xyz_to_zp1_pts(xyz), 1e-6, "xyz_to_zp1_pts")
+    cs, ps = cm.get_sdf(xyz), pm.get_sdf(xyz)
+    assert_close(cs[0], ps[0], 1e-5, "sdf")
+    assert_close(cs[1], ps[1], 1e-5, "isigma")
+    # numerical gradient + diagonal Hessian (local_map.cpp:110-150)
+    cg, pg = cm.get_gradient(xyz, 0.02, None, True, True), pm.get_gradient(xyz, 0.02, None, True, True)
+    assert_close(cg[0], pg[0], 1e-4, "numerical gradient")
+    assert_close(cg[1], pg[1], 1e-3, "numerical hessian")      # second difference / delta^2: 2500 x the forward's rounding
+    # analytic gradient through the fused decoder + hash grid, then once more through both (eikonal loss -> parameters)
+    grads = []
+    for m in (cm, pm):
+        x = xyz[:8000].clone().requires_grad_(True)
+        ga = m.get_gradient(x, 0.02, None, False, False)[0]
+        loss = ((ga.norm(dim=-1) - 1.0) ** 2).mean()
+        table = m.encoder.params_
+        (gt,) = torch.autograd.grad(loss, [table])
+        grads.append((ga.detach(), gt))
+    assert_close(grads[0][0], grads[1][0], 1e-5, "analytic gradient")
+    assert_close(grads[0][1], grads[1][1], 1e-4, "d eikonal / d table")
+    assert_close(grads[0][0], pg[0][:8000], 5e-2, "analytic vs numerical", outlier_frac=0.05, outlier_rel=1.0)
+
+
+def test_local_map_occupancy_and_sampling_match_python_mirror(host):
+    from gs_sdf_amd.sdf import DepthSamples
+    dev = torch.device("cuda:0")
+    cm, pm, cfg = make_maps(host, 1)
+    g = torch.Generator(device=dev).manual_seed(5)
+    # a wall of points in front of the sensor
+    n = 4000
+    origin = torch.tensor([0.0, 0.0, 5.5], device=dev).expand(n, 3).contiguous()
+    direction = torch.nn.functional.normalize(torch.randn(n, 3, device=dev, generator=g) * torch.tensor([0.5, 0.5, 0.1], device=dev)
+                                              + torch.tensor([0.0, 0.0, 1.0], device=dev), dim=-1)
+    depth = 3.0 + torch.rand(n, 1, device=dev, generator=g)
+    pts = origin + direction * depth
+    for is_prior in (False, True):
+        cm.update_octree_as(pts, is_prior)
+        pm.update_octree_as(pts, is_prior)
+        q = pts + (torch.rand(n, 3, device=dev, generator=g) - 0.5) * 1.5
+        assert_equal_int(cm.get_valid_mask(q).to(torch.int32), pm.get_valid_mask(q).to(torch.int32), "valid mask")
+    assert_equal_int(cm.get_inrange_mask(q * 2.0, 0.1).to(torch.int32), pm.get_inrange_mask(q * 2.0, 0.1).to(torch.int32), "inrange")
+    zc, zp = cm.get_intersect_point(origin, direction, 0.1), pm.get_intersect_point(origin, direction, 0.1)
+    for a, b, nm in zip(zc, zp, ("z_near", "z_far", "mask")):
+        assert torch.equal(a, b), nm
+    rays = dict(origin=origin, direction=direction, depth=depth, xyz=pts, ray_sdf=torch.zeros(n, 1, device=dev),
+                ridx=torch.arange(n, device=dev))
+    # voxel samples (deterministic part) ...
+    sc = cm.sample(rays, 1, False)
+    sp = pm.sample(DepthSamples(**rays), 1, False)
+    assert sc["xyz"].shape[0] > n // 2
+    assert_equal_int(sc["ridx"], sp.ridx, "sample ridx")
+    assert_close(sc["xyz"], sp.xyz, 1e-6, "sample xyz")
+    assert_close(sc["ray_sdf"], sp.ray_sdf, 1e-6, "sample ray_sdf")
+    assert_close(sc["depth"], sp.depth, 1e-6, "sample depth")
+    # ... with the stratified free-space samples: the same global RNG stream in both
+    torch.manual_seed(77)
+    sc = cm.sample(rays, 1, True)
+    torch.manual_seed(77)
+    sp = pm.sample(DepthSamples(**rays), 1, True, cfg.free_sample_num)
+    assert sc["xyz"].shape == sp.xyz.shape
+    assert_close(sc["xyz"], sp.xyz, 1e-6, "sample(+free) xyz")
+    assert_close(sc["ray_sdf"], sp.ray_sdf, 1e-6, "sample(+free) ray_sdf")
+    assert bool((sc["ray_sdf"] > 0).all())
+    fc, fp = cm.filter_sample(dict(xyz=q, ridx=torch.arange(n, device=dev))), pm.filter_sample(DepthSamples(xyz=q, ridx=torch.arange(n, device=dev)))
+    assert_equal_int(fc["ridx"], fp.ridx, "filter_sample")
+
+
+def scene_models(host, N=6000, W=320, H=192, deg=1, **cfg_kw):
+    from gs_sdf_amd.neural_gs import Cameras, GSConfig, NeuralGS
+    dev = torch.device("cuda:0")
+    sc = synth.make_scene(N, W, H, sh_degree=deg, seed=3)
+    K = sc["K"][0]
+    cam = Cameras(float(K[0, 0]), float(K[1, 1]), float(K[0, 2]), float(K[1, 2]), W, H)
+    pcfg = GSConfig(sh_degree=deg, **cfg_kw)
+    ccfg = host.GSConfig()
+    ccfg.sh_degree = deg
+    for k, v in cfg_kw.items():
+        setattr(ccfg, k, v)
+    args = [sc[k].to(dev) for k in ("means", "log_scales", "quats", "logit_opacities")] + [sc["sh"][:, :1].to(dev), sc["sh"][:, 1:].to(dev)]
+    pg = NeuralGS(*args, pcfg, spatial_scale=1.0, num_train_data=4)
+    cg = host.NeuralGS(None, *args, 4, 1.0, ccfg)
+    poses = [torch.linalg.inv(v)[:3, :4].contiguous() for v in synth.make_views(4, seed=2)]
+    return cg, pg, cam, poses
+
+
+def crender(cg, pose, cam, bck=0):
+    return cg.render(pose, cam.fx, cam.fy, cam.cx, cam.cy, cam.width, cam.height, True, bck)
+
+
+PFIELDS = ("offsets_", "scaling_", "quaternion_", "opacity_", "features_dc_", "features_rest_")
+
+
+def test_neural_gs_render_and_gradients_match_python_mirror(host):
+    cg, pg, cam, poses = scene_models(host, center_reg=True)
+    assert set(cg.named_parameters()) == {"anchors", "offsets", "scaling", "quaternion", "opacity", "features_dc", "features_rest"}
+    pg.sh_degree_to_use_ = cg.sh_degree_to_use_ = 1
+    rc, rp = crender(cg, poses[1], cam), pg.render(poses[1], cam, True)
+    for k in ("color", "depth", "alpha", "render_normal", "render_median", "normal", "gaussian_ids", "radii", "gradient_2dgs", "width",
+              "height", "n_cameras", "samples", "samples_weights", "samples_opacities", "visibilities", "xyz"):
+        assert k in rc, k
+        a, b = rc[k], rp[k]
+        assert a.shape == b.shape, (k, a.shape, b.shape)
+        if a.dtype in (torch.int32, torch.int64):
+            assert_equal_int(a, b.to(a.device), k)
+        else:
+            assert_close(a, b.to(a.device), 1e-5, k)   # same kernels; the activations are fused in C++, three eager kernels in the mirror
+    tgt = torch.rand_like(rc["color"])
+    w_n = torch.randn_like(rc["render_normal"])
+    for r in (rc, rp):
+        loss = ((r["color"] - tgt).abs().mean() + 0.1 * r["depth"].mean() + 0.05 * (r["render_normal"] * w_n).mean()
+                + 0.02 * r["alpha"].mean() + 1e-3 * (r["samples"] * r["samples_weights"]).sum())
+        loss.backward()
+    for f in PFIELDS:
+        a, b = getattr(cg, f).grad, getattr(pg, f).grad
+        assert a is not None and b is not None, f
+        assert_close(a, b, 1e-5, "d/d" + f)
+    assert_close(rc["gradient_2dgs"].grad, rp["gradient_2dgs"].grad, 1e-5, "densify gradient")
+    # densification statistics
+    cg.update_state(rc)
+    pg.update_state(rp)
+    st = cg.state
+    for k in ("grad2d", "count", "vis"):
+        assert_close(st[k], pg.state[k], 1e-6, "state " + k)
+    # white / random backgrounds
+    with torch.no_grad():
+        a1 = crender(cg, poses[0], cam, 1)
+        b1 = pg.render(poses[0], cam, True, 1)
+        assert_close(a1["color"], b1["color"], 1e-5, "white background")
+        torch.manual_seed(5); a2 = crender(cg, poses[0], cam, 2)
+        torch.manual_seed(5); b2 = pg.render(poses[0], cam, True, 2)
+        assert_close(a2["color"], b2["color"], 1e-5, "random background")
+
+
+def test_neural_gs_stochastic_samples_lie_on_the_splats(host):
+    """center_reg = false (the reference's default): the SDF samples are drawn on every visible splat's disc"""
+    cg, pg, cam, poses = scene_models(host, center_reg=False)
+    r = crender(cg, poses[0], cam)
+    ids = r["gaussian_ids"]
+    xyz, scale = r["xyz"].detach().index_select(0, ids), cg.get_scale().detach().index_select(0, ids)
+    d = (r["samples"].detach() - xyz).norm(dim=-1)
+    assert float(d.max()) > 0 and bool((d <= 3.5 * scale[:, :2].max(-1).values + 1e-6).all())
+    assert bool((r["samples_weights"] > 0).all()) and bool((r["samples_weights"] <= 1.0 + 1e-6).all())
+    (r["samples"].sum()).backward()
+    assert float(cg.offsets_.grad.abs().sum()) > 0 and float(cg.scaling_.grad.abs().sum()) > 0
+
+
+def test_neural_gs_training_schedule_matches_python_mirror(host):
+    """30 iterations of render -> L1 -> backward -> Adam -> train_callback with refinement every 4 iterations from 9 on and an
+    opacity reset at 20: the two implementations must take every discrete decision identically (same splat count after every
+    iteration) and carry the same parameters and Adam moments."""
+    kw = dict(refine_start_iter=8, refine_every=4, reset_every=20, grow_grad2d=2e-7, center_reg=True, sh_degree_interval=10)
+    cg, pg, cam, poses = scene_models(host, **kw)
+    copt, popt = cg.make_optimizer(), pg.make_optimizer()
+    assert copt.n_groups() == 6 and cg.gs_param_start_idx == 0
+    with torch.no_grad():
+        target = [pg.render(p, cam)["color"].detach() * 0.5 + 0.25 for p in poses]
+    sizes = []
+    for it in range(1, 31):
+        copt.zero_grad(); popt.zero_grad()
+        rc, rp = crender(cg, poses[it % 4], cam), pg.render(poses[it % 4], cam, True)
+        (rc["color"] - target[it % 4]).abs().mean().backward()
+        (rp["color"] - target[it % 4]).abs().mean().backward()
+        copt.step(); popt.step()
+        torch.manual_seed(1000 + it); cg.train_callback(it, 100, copt, rc)
+        torch.manual_seed(1000 + it); pg.train_callback(it, 100, popt, rp)
+        assert cg.anchors_.shape[0] == pg.anchors_.shape[0], (it, cg.anchors_.shape[0], pg.anchors_.shape[0])
+        assert cg.sh_degree_to_use_ == pg.sh_degree_to_use_
+        sizes.append(cg.anchors_.shape[0])
+        assert abs(copt.lr(0) - popt.param_groups[0]["lr"]) < 1e-9 * max(1.0, popt.param_groups[0]["lr"]) + 1e-12
+    assert len(set(sizes)) > 2, sizes
+    assert torch.equal(cg.anchors_, pg.anchors_)
+    fin = lambda t: torch.nan_to_num(t, neginf=-1e4)       # split children: log(0) in the unused third scale (as the reference)
+    for k, f in enumerate(PFIELDS):
+        a, b = getattr(cg, f).detach(), getattr(pg, f).detach()
+        assert a.shape == b.shape, f
+        assert_close(fin(a), fin(b), 1e-4, f, outlier_frac=1e-3, outlier_rel=1.0)
+        assert copt.param(k).data_ptr() == getattr(cg, f).data_ptr(), f + ": the optimizer does not hold the live tensor"
+        mc = copt.moments(k)
+        ms = popt.state[getattr(pg, f)]
+        assert_close(mc[0], ms["exp_avg"], 1e-4, f + " exp_avg", outlier_frac=1e-3, outlier_rel=1.0)
+        assert_close(mc[1], ms["exp_avg_sq"], 1e-4, f + " exp_avg_sq", outlier_frac=1e-3, outlier_rel=1.0)
+    named = cg.named_parameters()
+    assert named["offsets"].data_ptr() == cg.offsets_.data_ptr() and named["anchors"].shape == cg.anchors_.shape
+
+
+def test_neural_gs_ply_roundtrip_between_cpp_and_python(host, tmp_path):
+    from gs_sdf_amd.neural_gs import export_gs_to_ply, load_ply_to_gs
+    cg, pg, cam, poses = scene_models(host, N=3000)
+    p1, p2 = str(tmp_path / "cpp.ply"), str(tmp_path / "py.ply")
+    cg.export_gs_to_ply(p1)
+    export_gs_to_ply(pg, p2)
+    assert open(p1, "rb").read() == open(p2, "rb").read()
+    back = load_ply_to_gs(p1, device="cuda:0")
+    cg.load_ply_to_gs(p2)
+    assert cg.sh_degree_to_use_ == 1
+    for f in ("anchors_",) + PFIELDS:
+        a, b = getattr(cg, f).detach(), getattr(back, f).detach()
+        if f == "scaling_":
+            a, b = a[:, :2], b[:, :2]
+        assert torch.equal(a.reshape(b.shape), b), f
+    with torch.no_grad():
+        r = crender(cg, poses[0], cam)
+    assert torch.isfinite(r["color"]).all()
+
+
+def test_neural_gs_sdf_aided_initialisation(host):
+    """NeuralGS(points) with k_geo_init: scale from the 3-nearest-neighbour distance, rotation and opacity from the SDF
+    (neural_gaussian.cpp:312-326) = the Python mirror's init_gs_with_sdf on the same map."""
+    from gs_sdf_amd.neural_gs import init_gs_with_sdf
+    import gs_sdf_amd.ops as ops
+    dev = torch.device("cuda:0")
+    cm, pm, cfg = make_maps(host, 0)
+    g = torch.Generator(device=dev).manual_seed(9)
+    pts = (torch.rand(20000, 3, device=dev, generator=g) - 0.5) * 10.0 + torch.tensor([0.0, 0.0, 5.5], device=dev)
+    gcfg = host.GSConfig()
+    gcfg.vis_batch_pt_num = 8192                    # several batches
+    gs = host.NeuralGS.from_points(cm, pts, 4, 3.0, True, gcfg)
+    ref = init_gs_with_sdf(pm, pts, 0.5 * cfg.leaf_size, True, 8192)
+    keep = ~(ref["quaternion"].isnan().any(-1) | ref["opacity"].isnan())
+    assert gs.anchors_.shape[0] == int(keep.sum())
+    assert abs(gs.spatial_scale_ - 2.0) < 1e-6
+    # the rotation is built from normalised finite differences: compare the frames the quaternions encode, loosely
+    q_c, q_p = gs.quaternion_.detach(), ref["quaternion"][keep]
+    dot = (torch.nn.functional.normalize(q_c, dim=-1) * torch.nn.functional.normalize(q_p, dim=-1)).sum(-1).abs()
+    assert float((dot > 0.999).float().mean()) > 0.99
+    assert_close(gs.opacity_.detach(), ref["opacity"][keep], 1e-3, "opacity", outlier_frac=0.01, outlier_rel=1.0)
+    d2 = ops.distCUDA2(pts).clamp_min(1e-6)
+    assert_close(gs.scaling_.detach(), d2.sqrt().log()[keep, None].repeat(1, 3), 1e-6, "scaling")
+    # without the SDF: random rotations, opacity 0.1
+    gcfg.geo_init = False
+    gs2 = host.NeuralGS.from_points(None, pts, 4, 1.0, False, gcfg)
+    assert_close(gs2.opacity_.detach(), torch.full((20000,), math.log(0.1 / 0.9), device=dev), 1e-6, "logit(0.1)")
+    assert_close(gs2.quaternion_.detach().norm(dim=-1), torch.ones(20000, device=dev), 1e-5, "unit quaternions")
+    assert gs2.features_rest_.shape == (20000, 0, 3)
