@@ -91,9 +91,13 @@ def main():
                          "source edits: the drop-in operators (rasterization_2dgs_sdf, TCNNEncoding, TCNNNetwork) composed with "
                          "eager torch for everything the reference does in libtorch (losses, SSIM, activations, get_gradient's "
                          "numerical branch, update_state, torch.optim.Adam), one stream.  NOT the headline; reported as a line of its own")
-    ap.add_argument("--splat-order", default="morton", choices=["morton", "as-given"],
-                    help="memory order of the splat set: Morton order of the centres (what the trainer keeps: NeuralGS re-sorts at "
-                         "initialisation and at refinement steps) or the synthetic scene's random order")
+    ap.add_argument("--sample-mode", default="center", choices=["center", "stochastic"],
+                    help="SDF samples of the visible splats: center = k_center_reg 1 (splat centres, weight 1: the fully specified mode the "
+                         "parity / benchmark runs use, SURVEY appendix A.1); stochastic = the reference's default (center_reg absent from "
+                         "config/base.yaml): one random point on every visible splat's disc, weight exp(-|eps|^2/2)")
+    ap.add_argument("--splat-order", default="as-given", choices=["morton", "as-given"],
+                    help="memory order of the splat set: the synthetic scene's random order, or Morton order of the centres "
+                         "(trainer.morton_order; measured: no gain, the fine hash-grid levels scatter either way, DESIGN.md section 11)")
     ap.add_argument("--collective", default="all_reduce", choices=["all_reduce", "reduce_scatter_all_gather"],
                     help="N > 1: how a parameter family's flat gradient buffer is summed over the ranks")
     args = ap.parse_args()
@@ -216,6 +220,15 @@ def main():
         lm.decoder.aux_stream = aux          # decoder weight gradients: off the chain that leads back to the splat leg
         main.wait_stream(torch.cuda.current_stream())
         torch.cuda.set_stream(main)
+    elif impl == "cpp" and not args.no_overlap:
+        # JointIteration issues the splat leg on the caller's stream and the SDF network's work on a pool stream of its own.  A
+        # high-priority queue for the splat leg (what the mirror's four-stream schedule uses) was measured SLOWER here: 141.5 / 142.2
+        # against 149.8 it/s, cfg3, 40 steps — the SDF leg is the longer one in this schedule and loses more than the splat leg gains
+        prio = int(os.environ.get("GSDF_CPP_SPLAT_STREAM_PRIORITY", "0"))
+        if prio != 0:
+            main = torch.cuda.Stream(priority=prio)
+            main.wait_stream(torch.cuda.current_stream())
+            torch.cuda.set_stream(main)
     gate = GradGate()
 
     released = []
@@ -269,7 +282,8 @@ def main():
         stamp("ray leg issued")
         xyz, quat, scales, opacity, sh = params.activated()
         colors, alphas, meta = ops.rasterization_2dgs_sdf(xyz, quat, scales, opacity, sh, view, K, W, H, near_plane=0.05,
-                                                          far_plane=300.0, sh_degree=deg, center_reg=True, samples_gate=gate)
+                                                          far_plane=300.0, sh_degree=deg, center_reg=(args.sample_mode == "center"),
+                                                          sample_seed=1 + i, samples_gate=gate)
         # colour: the reference's photometric loss 0.8 L1 + 0.2 D-SSIM (neural_mapping.cpp:237-240), fused HIP kernel;
         # depth / alpha / normal / median: op-level 1e-6 N(0,1) upstream gradients so that every backward path is live.
         # Issued BEFORE the coupling leg: its kernels only need the render, and the host spends ~1 ms issuing that leg.
@@ -546,8 +560,10 @@ def main():
                                      + ("four HIP streams" if overlap else "one HIP stream")),
                        "step": "reference joint iteration (neural_mapping.cpp:400-486): " + terms,
                        "parallelism": f"view-parallel x{world}" if world > 1 else "single GPU",
-                       "splat_order": ("Morton order of the centres (trainer.morton_order; kept by the trainer at initialisation and at "
-                                       "refinement steps)" if args.splat_order == "morton" else "as given (random)"),
+                       "splat_order": "Morton order of the centres (trainer.morton_order)" if args.splat_order == "morton" else "as given (random)",
+                       "sample_mode": ("center_reg = 1: SDF samples = splat centres, weight 1" if args.sample_mode == "center" else
+                                       "stochastic (the reference's default, center_reg absent): one random point per visible splat's disc, "
+                                       "weight exp(-|eps|^2/2)"),
                        "decoder_arithmetic": ("fp32 operands as 3 exact bf16 terms, 6 partial products per multiply-add on the bf16 MFMA pipe, "
                                               "fp32 accumulate: error against fp64 equal to the fp32 MFMA's (tools/ubench/mfma_split.hip)"
                                               if split_mlp_cfg else "fp32 MFMA")},
@@ -592,7 +608,7 @@ def main():
             try:
                 cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", str(min(args.steps, 40)), "--warmup", str(args.warmup),
                        "--workload", args.workload, "--sdf-config", other, "--step-terms", args.step_terms, "--splat-order", args.splat_order,
-                       "--no-secondary", "--no-cpu-baseline"] + (["--no-overlap"] if args.no_overlap else [])
+                       "--sample-mode", args.sample_mode, "--no-secondary", "--no-cpu-baseline"] + (["--no-overlap"] if args.no_overlap else [])
                 release_streams()
                 r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
                 j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
@@ -612,7 +628,7 @@ def main():
                 other_impl = "python" if impl == "cpp" else "cpp"
                 cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", str(min(args.steps, 40)), "--warmup", str(args.warmup),
                        "--workload", args.workload, "--sdf-config", args.sdf_config, "--step-terms", args.step_terms, "--splat-order", args.splat_order,
-                       "--step-impl", other_impl, "--no-secondary", "--no-cpu-baseline"] + (["--no-overlap"] if args.no_overlap else [])
+                       "--step-impl", other_impl, "--sample-mode", args.sample_mode, "--no-secondary", "--no-cpu-baseline"] + (["--no-overlap"] if args.no_overlap else [])
                 r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
                 j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
                 out["python_mirror_step" if other_impl == "python" else "cpp_joint_iteration"] = {
@@ -620,6 +636,19 @@ def main():
                     "step_ms_hip_events": j["step_ms_hip_events"], "step_impl": j["config"]["step_impl"]}
             except Exception as e:
                 out["python_mirror_step" if impl == "cpp" else "cpp_joint_iteration"] = {"error": repr(e)[:300]}
+            # (4) the other SDF-sample mode (the reference's default draws one stochastic point per visible splat; the headline uses the
+            #     fully specified center_reg = 1 mode of the parity runs)
+            try:
+                other_mode = "stochastic" if args.sample_mode == "center" else "center"
+                cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", str(min(args.steps, 40)), "--warmup", str(args.warmup),
+                       "--workload", args.workload, "--sdf-config", args.sdf_config, "--step-terms", args.step_terms, "--splat-order", args.splat_order,
+                       "--step-impl", impl, "--sample-mode", other_mode, "--no-secondary", "--no-cpu-baseline"] + (["--no-overlap"] if args.no_overlap else [])
+                r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+                j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+                out["other_sample_mode"] = {"sample_mode": j["config"]["sample_mode"], "value": j["value"], "unit": "iters/s",
+                                            "ms_per_step": j["ms_per_step"], "steps": j["steps"], "step_ms_hip_events": j["step_ms_hip_events"]}
+            except Exception as e:
+                out["other_sample_mode"] = {"error": repr(e)[:300]}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sc, views, params, N, W, H, deg, 0 if args.no_sdf else int(sdf_pts), dev)
         print(json.dumps(out), flush=True)
@@ -662,7 +691,8 @@ def make_cpp_iteration(args, sc, params, dev, W, H, deg, views):
     if analytic:
         dec.biases_ = lm.decoder.biases_.detach().clone()
     fields = [params.views[k].detach().clone() for k in ("offsets", "scaling", "quaternion", "opacity", "features_dc", "features_rest")]
-    ji = host.JointIteration(params.anchors, fields, enc, dec, [0.0, 0.0, 5.5], 16.0, 0.02, 8, W, H, deg, not args.no_overlap, analytic, ref_terms)   # level 8: 1/16 m leaves in 16 m
+    ji = host.JointIteration(params.anchors, fields, enc, dec, [0.0, 0.0, 5.5], 16.0, 0.02, 8, W, H, deg, not args.no_overlap, analytic, ref_terms,
+                            args.sample_mode == "center")   # level 8: 1/16 m leaves in 16 m
     gq = torch.Generator().manual_seed(4)
     pool = [((torch.rand(32768, 3, generator=gq) - 0.5) * 14.0 + torch.tensor([0.0, 0.0, 5.5])).to(dev) for _ in range(8)]
     ray_sdf = [(torch.randn(32768, 1, generator=gq) * 0.02).to(dev) for _ in range(8)]
@@ -688,7 +718,8 @@ def cpp_step(args, sc, views, K, ug6, target, N, W, H, deg, dev):
         dec.biases_ = lm.decoder.biases_.detach().clone()
     fields = [params.views[k].detach().clone() for k in ("offsets", "scaling", "quaternion", "opacity", "features_dc", "features_rest")]
     two = not args.no_overlap
-    ji = host.JointIteration(params.anchors, fields, enc, dec, [0.0, 0.0, 5.5], 16.0, 0.02, 8, W, H, deg, two, analytic, ref_terms)   # level 8: 1/16 m leaves in 16 m
+    ji = host.JointIteration(params.anchors, fields, enc, dec, [0.0, 0.0, 5.5], 16.0, 0.02, 8, W, H, deg, two, analytic, ref_terms,
+                            args.sample_mode == "center")   # level 8: 1/16 m leaves in 16 m
     gq = torch.Generator().manual_seed(4)
     pool = [((torch.rand(32768, 3, generator=gq) - 0.5) * 14.0 + torch.tensor([0.0, 0.0, 5.5])).to(dev) for _ in range(8)]
     ray_sdf = [(torch.randn(32768, 1, generator=gq) * 0.02).to(dev) for _ in range(8)]

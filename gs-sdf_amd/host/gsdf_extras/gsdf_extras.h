@@ -136,6 +136,9 @@ struct JointConfig {
   double normal_w = 0.01, isotropic_w = 0.05;                          // config/base.yaml:43-44
   double lr_offsets = 1.6e-4, lr_scaling = 5e-3, lr_quaternion = 1e-3, lr_opacity = 5e-2, lr_features_dc = 2.5e-3,
          lr_features_rest = 2.5e-3 / 20, lr_sdf = 1e-4;               // neural_gaussian.cpp:434-453, :619-623
+  // center_reg (k_center_reg): the SDF samples are the splat centres with weight 1; false = the reference's DEFAULT (the key is absent from
+  // config/base.yaml -> 0): one stochastic point on every visible splat's disc, weight exp(-|eps|^2 / 2) (neural_gaussian.cpp:259-265)
+  bool center_reg = true;
   bool two_streams = false;   // the SDF network's work on a second HIP stream beside the splat leg (bench.py's overlapped schedule)
 };
 

@@ -209,12 +209,14 @@ std::map<std::string, int64_t> JointIteration::step(const Tensor &viewmat, const
   auto act = splat_activations(anchors_, views_[0], views_[1], views_[3].reshape({N}));
   Tensor dc = views_[4].reshape({N, 1, 3});
   Tensor sh = n_rest_ == 0 ? dc : torch::cat({dc, views_[5].reshape({N, n_rest_, 3})}, 1);
+  gsplat_cpp::set_sample_mode(!cfg_.center_reg);
   auto proj = fully_fused_projection_2dgs(act[0], views_[2], act[1], viewmat, K, W, H, cfg_.near_plane, cfg_.far_plane, 0.f, true, false);
   const Tensor &camera_ids = std::get<0>(proj), &gaussian_ids = std::get<1>(proj), &radii = std::get<2>(proj), &means2d = std::get<3>(proj);
   const Tensor &depths = std::get<4>(proj), &ray_transforms = std::get<5>(proj), &normals = std::get<6>(proj);
-  Tensor samples = act[0].index_select(0, gaussian_ids);           // center_reg: the splat centres are the SDF samples
+  // k_center_reg: the splat centres are the SDF samples (weight 1); otherwise the projection's stochastic points on the discs
+  Tensor samples = cfg_.center_reg ? act[0].index_select(0, gaussian_ids) : std::get<7>(proj);
   if (two) samples = JoinGrad::apply(samples, reinterpret_cast<int64_t>(&streams_->gate));   // created HERE: consumed late in the backward
-  Tensor samples_weights = torch::ones_like(std::get<8>(proj));
+  Tensor samples_weights = cfg_.center_reg ? torch::ones_like(std::get<8>(proj)) : std::get<8>(proj);
   Tensor pt_opac = act[2].index_select(0, gaussian_ids);
   Tensor colors = gsplat_cpp::get_view_colors(viewmat, act[0], radii, sh, camera_ids, gaussian_ids, cfg_.sh_degree);
   auto enc = gsplat_cpp::tile_encode(W, H, 16, means2d, radii, depths, true, viewmat.size(0), camera_ids, gaussian_ids);

@@ -29,7 +29,7 @@ def test_overlapped_step_gives_the_single_stream_gradients(tmp_path, workload, c
     out = {}
     for mode, flags in (("serial", ["--no-overlap"]), ("overlap", []), ("overlap3", ["--scatter-xcds", "3"])):
         path = str(tmp_path / f"{mode}.pt")
-        _bench(["--workload", workload, "--dump-grads", path, "--sdf-config", cfg, *flags])
+        _bench(["--workload", workload, "--dump-grads", path, "--sdf-config", cfg, "--step-impl", "python", *flags])
         out[mode] = torch.load(path)
     ref = out["serial"]
     assert ref["sizes"]["n_gs_sdf"] > 0 and float(ref["splat"].abs().sum()) > 0 and float(ref["sdf"][0].abs().sum()) > 0
@@ -98,14 +98,38 @@ def test_cpp_joint_iteration_gives_the_python_step_gradients(tmp_path, workload,
     default configuration (analytic eikonal + align, normal consistency, isotropic) and the tcnn / numerical one:
     same visible set, same intersections, same flat gradients of both parameter families."""
     out = {}
-    for mode, flags in (("python", ["--no-overlap"]), ("cpp one stream", ["--cpp-step", "--no-overlap"]), ("cpp two streams", ["--cpp-step"])):
+    for mode, flags in (("python", ["--step-impl", "python", "--no-overlap"]), ("cpp one stream", ["--step-impl", "cpp", "--no-overlap"]),
+                        ("cpp two streams", ["--step-impl", "cpp"]), ("cpp standalone loop", ["--cpp-step"])):
         path = str(tmp_path / f"{mode.replace(' ', '_')}.pt")
         _bench(["--workload", workload, "--dump-grads", path, *cfg, *flags])
         out[mode] = torch.load(path)
     ref = out["python"]
     assert float(ref["splat"].abs().sum()) > 0 and float(ref["sdf"][0].abs().sum()) > 0
-    for mode in ("cpp one stream", "cpp two streams"):
+    for mode in ("cpp one stream", "cpp two streams", "cpp standalone loop"):
         got = out[mode]
         assert {k: int(v) for k, v in got["sizes"].items()} == {k: int(v) for k, v in ref["sizes"].items()}
         assert_close(got["splat"], ref["splat"], 1e-4, f"{mode}: splat gradients")
         assert_close(got["sdf"][0], ref["sdf"][0], 1e-4, f"{mode}: SDF network gradients")
+
+
+def test_stochastic_sample_mode_step_runs_in_both_implementations(tmp_path):
+    """--sample-mode stochastic (the reference's default: center_reg absent from config/base.yaml): one random point on every visible
+    splat's disc feeds the GS<->SDF coupling.  The draws differ between the implementations (Python passes a per-step seed, the C++
+    operator draws from torch's generator), so only what does not depend on them is compared: the visible set and the intersections
+    are identical, the coupling sees samples, and the sample gradient reaches the scales / rotations of the splats."""
+    out = {}
+    for mode, flags in (("python", ["--step-impl", "python", "--no-overlap"]), ("cpp", ["--step-impl", "cpp", "--no-overlap"]),
+                        ("center", ["--step-impl", "cpp", "--no-overlap", "--sample-mode", "center"])):
+        path = str(tmp_path / f"{mode}.pt")
+        extra = [] if mode == "center" else ["--sample-mode", "stochastic"]
+        _bench(["--workload", "cfg0_10k_256", "--dump-grads", path, *extra, *flags])
+        out[mode] = torch.load(path)
+    for k in ("M", "I"):
+        assert int(out["python"]["sizes"][k]) == int(out["cpp"]["sizes"][k]) == int(out["center"]["sizes"][k])
+    for mode in ("python", "cpp"):
+        g = out[mode]
+        assert int(g["sizes"]["n_gs_sdf"]) > 0
+        assert bool(torch.isfinite(g["splat"]).all()) and bool(torch.isfinite(g["sdf"][0]).all())
+        assert float(g["splat"].abs().sum()) > 0
+    # the stochastic points move with the splat's scale: its gradient differs from the centre mode's
+    assert float((out["cpp"]["splat"] - out["center"]["splat"]).abs().max()) > 0

