@@ -226,24 +226,28 @@ std::map<std::string, int64_t> JointIteration::step(const Tensor &viewmat, const
   auto post = RenderPost::apply(std::get<0>(rast), std::get<1>(rast), std::get<2>(rast), std::get<3>(rast), viewmat, true);   // render_mode RGB+ED (neural_gaussian.cpp:229-234)
   const Tensor &render_normal = post[1], &color3 = post[2], &depth1 = post[3];
   const Tensor &alphas = std::get<2>(rast), &median = std::get<5>(rast), &vis = std::get<6>(rast);
-  Tensor loss = l1_dssim_loss(color3[0], target, cfg_.rgb_w, cfg_.dssim_w);
-  if (cfg_.reference_terms) {
-    // render_normal_weight x depth->normal consistency (:243-266; depth_type 0: the expected depth) + isotropic_weight x isotropic
-    // regulariser of the visible splats (:268-276), one launch each
-    std::vector<float> intr, pose;
-    if (cam_host.size() >= 16) {
-      intr.assign(cam_host.begin(), cam_host.begin() + 4);
-      pose.assign(cam_host.begin() + 4, cam_host.begin() + 16);
-    } else {   // read the camera back (one device->host copy)
-      Tensor Kc = K[0].detach().to(torch::kCPU), c2w = torch::linalg_inv(viewmat[0].detach().to(torch::kCPU).to(torch::kFloat64)).to(torch::kFloat32).contiguous();
-      intr = {Kc[0][0].item<float>(), Kc[1][1].item<float>(), Kc[0][2].item<float>(), Kc[1][2].item<float>()};
-      pose.assign(c2w.data_ptr<float>(), c2w.data_ptr<float>() + 12);
+  // the splat leg's own loss terms (everything but the GS <-> SDF coupling)
+  auto splat_loss = [&]() -> Tensor {
+    Tensor loss = l1_dssim_loss(color3[0], target, cfg_.rgb_w, cfg_.dssim_w);
+    if (cfg_.reference_terms) {
+      // render_normal_weight x depth->normal consistency (:243-266; depth_type 0: the expected depth) + isotropic_weight x isotropic
+      // regulariser of the visible splats (:268-276), one launch each
+      std::vector<float> intr, pose;
+      if (cam_host.size() >= 16) {
+        intr.assign(cam_host.begin(), cam_host.begin() + 4);
+        pose.assign(cam_host.begin() + 4, cam_host.begin() + 16);
+      } else {   // read the camera back (one device->host copy)
+        Tensor Kc = K[0].detach().to(torch::kCPU), c2w = torch::linalg_inv(viewmat[0].detach().to(torch::kCPU).to(torch::kFloat64)).to(torch::kFloat32).contiguous();
+        intr = {Kc[0][0].item<float>(), Kc[1][1].item<float>(), Kc[0][2].item<float>(), Kc[1][2].item<float>()};
+        pose.assign(c2w.data_ptr<float>(), c2w.data_ptr<float>() + 12);
+      }
+      loss = loss + cfg_.normal_w * normal_consistency_loss(depth1[0], alphas[0], render_normal[0], intr, pose) +
+             cfg_.isotropic_w * isotropic_loss(act[1], gaussian_ids);
+    } else if (upstream.size() == 4) {
+      loss = loss + InjectGrads::apply(depth1, upstream[0], alphas, upstream[1], render_normal, upstream[2], median, upstream[3]);
     }
-    loss = loss + cfg_.normal_w * normal_consistency_loss(depth1[0], alphas[0], render_normal[0], intr, pose) +
-           cfg_.isotropic_w * isotropic_loss(act[1], gaussian_ids);
-  } else if (upstream.size() == 4) {
-    loss = loss + InjectGrads::apply(depth1, upstream[0], alphas, upstream[1], render_normal, upstream[2], median, upstream[3]);
-  }
+    return loss;
+  };
   // ---- GS <-> SDF coupling (:420-462) at the visible, occupancy-valid splats' samples
   Tensor visd = vis.detach();
   Tensor w_all = (samples_weights * visd).detach();
@@ -264,10 +268,40 @@ std::map<std::string, int64_t> JointIteration::step(const Tensor &viewmat, const
     return gs_sdf_coupling(smp, ids, w_all, *enc_, *dec_, origin_, map_size_inv_, cfg_.gs_sdf_w, cfg_.sdf_delta, cfg_.eik_w, tg, dg, gate);
   };
   const bool sdf_work = cfg_.analytic || has;
+  // two streams, schedule A (default): SDF forward on `side` FIRST, then the splat leg's losses and its whole backward on the caller's
+  // stream (beside the hash-grid forward: VALU-bound compositing backward next to a gather-bound kernel), then the SDF backward on
+  // `side`, and last the samples' gradient through the few nodes between the samples and the splat parameters.  The splat leg's
+  // stream no longer idles while the host issues the SDF leg, and the compositing backward is off the tail of the step.
+  // Schedule B (GSDF_JOINT_SCHEDULE=B, the round-2 order): SDF forward + backward, then one backward over {loss, samples}.
+  static const bool schedule_a = [] { const char *e = getenv("GSDF_JOINT_SCHEDULE"); return !(e && (e[0] == 'B' || e[0] == 'b')); }();
   if (!two) {
+    Tensor loss = splat_loss();
     if (sdf_work) loss = loss + sdf_node(samples, nullptr);
     loss.backward();
+  } else if (sdf_work && schedule_a) {
+    streams_->fwd_done.record(main_stream);
+    streams_->fwd_done.block(streams_->side);
+    Tensor samples_cut = samples.detach().requires_grad_(true);
+    for (const Tensor &t : {samples_cut, w_all, ids}) t.record_stream(streams_->side);
+    if (cfg_.analytic) { ray_pts.record_stream(streams_->side); ray_sdf.record_stream(streams_->side); }
+    Tensor sdf_loss;
+    {
+      StreamGuard sg(streams_->side);
+      sdf_loss = sdf_node(samples_cut, &streams_->gate);
+    }
+    splat_loss().backward({}, /*retain_graph=*/true);   // the nodes between the samples and the parameters are walked again below
+    {
+      StreamGuard sg(streams_->side);
+      sdf_loss.backward();
+      if (!streams_->gate.armed) streams_->gate.record_here();
+    }
+    Tensor gs = samples_cut.grad();
+    if (gs.defined()) {
+      gs.record_stream(main_stream);
+      samples.backward(gs);   // JoinGrad (created with the samples) makes the caller's stream wait for the gate first
+    }
   } else if (sdf_work) {
+    Tensor loss = splat_loss();
     // graph cut at the samples: the SDF leg (forward + backward) on `side`, its d loss / d samples joins the splat leg's
     // backward where the samples' gradient is consumed
     streams_->fwd_done.record(main_stream);
@@ -290,7 +324,7 @@ std::map<std::string, int64_t> JointIteration::step(const Tensor &viewmat, const
       loss.backward();
     }
   } else {
-    loss.backward();
+    splat_loss().backward();
   }
   // ---- train_callback -> update_state (:486, neural_gaussian.cpp:626-680), optimizers (each family on its leg's stream)
   update_state(state_, densify.grad(), gaussian_ids, vis, radii, N, (int)viewmat.size(0), W, H, false);
