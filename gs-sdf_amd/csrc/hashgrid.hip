@@ -17,6 +17,9 @@
 //     the algorithm's compulsory random access; the 61 MB fp32 table is resident in the 256 MiB Infinity Cache.
 #include "hashgrid_common.h"
 
+#include <cstring>
+#include <string>
+
 namespace gsdf {
 
 // sums `v` over the 16 lanes of a DPP row; the total is valid in the row's last lane (lane & 15 == 15)
@@ -158,6 +161,15 @@ static bool make_xcd_levels(int n_levels, int n_xcd, XcdLevels *xl, int *max_nl)
   return true;
 }
 
+// Level slots of an XCD for the stencil kernel: slot j of XCD k = level lvl[k][j], walked for every chunk (mode 0) or for the chunks
+// with chunk % m == r (mode = m << 4 | r).  A hashed level costs the same for every point, a coarse one much less (shared cells, dense
+// table), and workgroups are dealt to the XCDs strictly in turn, so the XCD with the most expensive slots sets the pace of all:
+// two XCDs can SHARE a level (one takes the even chunks, the other the odd ones) to even the load out.
+struct XcdSlots {
+  unsigned char lvl[8][16], mode[8][16];
+  int count[8];
+};
+
 // Stencil batches (n base rows followed by 6 blocks of n central-difference rows, LocalMap.query_points layout): the
 // 4 lanes of a (group, level) walk the group's 7 rows back to back instead of 7 workgroups far apart in time.
 //   * at the coarse levels the +-delta points fall in the base point's cell: its 4 gathered values are reused from
@@ -167,17 +179,19 @@ static bool make_xcd_levels(int n_levels, int n_xcd, XcdLevels *xl, int *max_nl)
 // The arithmetic of a row is the one of hashgrid_fwd_xcd_kernel (same operations in the same order): bit-identical features.
 template <bool JAC>
 __global__ void __launch_bounds__(HG_THREADS)
-    hashgrid_fwd_stencil_kernel(int64_t n, HgLevels lv, XcdLevels xl, int n_xcd, const float *__restrict__ x,
+    hashgrid_fwd_stencil_kernel(int64_t n, HgLevels lv, XcdSlots xl, int n_xcd, int ppw, const float *__restrict__ x,
                                 const float *__restrict__ table, float *__restrict__ feat, float *__restrict__ jac) {
   const int xcd = blockIdx.x % n_xcd;
   const int64_t chunk = blockIdx.x / n_xcd;
-  const int l0 = xl.begin[xcd], nl = xl.count[xcd];
-  const int ppw = 16 / nl;  // groups per wave
+  const int nl = xl.count[xcd];
   const int lane = threadIdx.x & 63;
   const int f = lane & 1, xb = (lane >> 1) & 1, slot = lane >> 2;
-  const int pw = slot / nl, level = l0 + slot - pw * nl;
+  // ppw groups per wave (the same for every XCD: a chunk is the same 4 ppw groups everywhere), each against the XCD's nl <= 16 / ppw slots
+  const int nls = 16 / ppw, pw = slot / nls, ls = slot - pw * nls;   // a group's level slots on neighbouring quads: its features leave in 8 nls byte runs
   const int64_t g = (chunk * 4 + (threadIdx.x >> 6)) * ppw + pw;
-  if (!(pw < ppw && g < n)) return;  // whole quads leave together: the quad DPP below stays among live lanes
+  if (!(pw < ppw && ls < nl && g < n)) return;  // whole quads leave together: the quad DPP below stays among live lanes
+  const int level = xl.lvl[xcd][ls], mode = xl.mode[xcd][ls];
+  if (mode != 0 && (int)(chunk % (mode >> 4)) != (mode & 15)) return;
   const float scale = lv.scale[level];
   const uint32_t res = lv.res[level], hsize = lv.hsize[level];
   const float *tb = table + (int64_t)lv.offset[level] * 2 + f;
@@ -253,20 +267,76 @@ static void launch_fwd(int64_t B, int64_t jac_rows, const HgLevels &lv, int n_le
   }
 }
 
+// slots of the stencil kernel.  Default for 16 levels on 8 XCDs: contiguous pairs (the round-2 map).  GSDF_HASHGRID_MAP overrides it
+// for experiments: XCDs separated by ';', slots by ',', a slot = level or level%m=r (only the chunks with chunk % m == r), e.g.
+// "0,1;2,3;4,5%2=0;5%2=1,6;..."
+static bool make_stencil_slots(int n_levels, int n_xcd, XcdSlots *xs, int *ppw) {
+  *xs = XcdSlots{};
+  int max_nl = 0;
+  static const std::string env_map = [] { const char *e = getenv("GSDF_HASHGRID_MAP"); return std::string(e ? e : ""); }();
+  // 16 levels (base 32, x2: the reference's grid, config/base.yaml) on 8 XCDs, measured (tools/exp_hgmaps.sh, 494 k points): the four
+  // coarse levels together cost two hashed ones (their +-delta rows share the base row's cell, tables of 0.3-4 MiB), level 4 three
+  // quarters of one; the ten levels 6..15 are dealt in thirds, five thirds per XCD: 1.77 ms against 1.97 ms for contiguous pairs
+  // (0.93 / 1.00 at 250 k, 2.81 / 3.27 at 800 k).  Quarters (3-4 tables per L2) and halves with 3 slots measured slower.
+  static const std::string tuned16 = "0,1,2,3;4,5;6,7%3=0,7%3=1;7%3=2,8,9%3=0;9%3=1,9%3=2,10;11,12%3=0,12%3=1;12%3=2,13,14%3=0;14%3=1,14%3=2,15";
+  const std::string &env = !env_map.empty() ? env_map : (n_levels == 16 && n_xcd == 8 && env_map != "contiguous") ? tuned16 : env_map;
+  if (!env.empty() && env != "contiguous" && n_xcd == 8) {
+    int k = 0;
+    size_t i = 0;
+    while (k < 8) {
+      size_t j = env.find(';', i);
+      std::string part = env.substr(i, j == std::string::npos ? std::string::npos : j - i);
+      size_t a = 0;
+      while (a < part.size()) {
+        size_t c = part.find(',', a);
+        std::string tok = part.substr(a, c == std::string::npos ? std::string::npos : c - a);
+        if (!tok.empty() && xs->count[k] < 16) {
+          const int lvl = atoi(tok.c_str());
+          if (lvl < 0 || lvl >= n_levels) return false;
+          xs->lvl[k][xs->count[k]] = (unsigned char)lvl;
+          const size_t pc = tok.find('%');   // "level%m=r": only the chunks with chunk % m == r
+          int m = 0, r = 0;
+          if (pc != std::string::npos) { m = atoi(tok.c_str() + pc + 1); const size_t eq = tok.find('=', pc); r = eq == std::string::npos ? 0 : atoi(tok.c_str() + eq + 1); }
+          if (m < 0 || m > 15 || r < 0 || r > 15 || (m > 0 && r >= m)) return false;
+          xs->mode[k][xs->count[k]] = (unsigned char)(m > 1 ? (m << 4) | r : 0);
+          xs->count[k]++;
+        }
+        if (c == std::string::npos) break;
+        a = c + 1;
+      }
+      ++k;
+      if (j == std::string::npos) break;
+      i = j + 1;
+    }
+    for (int q = 0; q < 8; ++q) max_nl = xs->count[q] > max_nl ? xs->count[q] : max_nl;
+    if (max_nl == 0) return false;
+  } else {
+    XcdLevels xl;
+    if (!make_xcd_levels(n_levels, n_xcd, &xl, &max_nl)) return false;
+    for (int k = 0; k < n_xcd; ++k) {
+      xs->count[k] = xl.count[k];
+      for (int j = 0; j < xl.count[k]; ++j) xs->lvl[k][j] = (unsigned char)(xl.begin[k] + j);
+    }
+  }
+  *ppw = 16 / max_nl;
+  return *ppw >= 1;
+}
+
 template <bool JAC>
 static void launch_fwd_stencil(int64_t n, const HgLevels &lv, int n_levels, const float *x, const float *table, float *feat,
                                float *jac, hipStream_t stream) {
-  XcdLevels xl;
-  int max_nl = 0, n_xcd = xcd_count(stream);
+  XcdSlots xs;
+  int ppw = 1, n_xcd = xcd_count(stream);
   static const bool off = [] { const char *e = getenv("GSDF_HASHGRID_XCD"); return e && e[0] == '0'; }();
-  if (off || n_xcd != 8 || 7 * n < 65536 || !make_xcd_levels(n_levels, n_xcd, &xl, &max_nl)) {
-    for (int k = 0; k < 8; ++k) { xl.begin[k] = 0; xl.count[k] = n_levels; }
+  if (off || n_xcd != 8 || 7 * n < 65536 || !make_stencil_slots(n_levels, n_xcd, &xs, &ppw)) {
+    xs = XcdSlots{};
+    xs.count[0] = n_levels;
+    for (int j = 0; j < n_levels; ++j) xs.lvl[0][j] = (unsigned char)j;
     n_xcd = 1;
-    max_nl = n_levels;
+    ppw = 1;
   }
-  const int ppw_min = 16 / max_nl;
-  const int64_t chunks = (n + 4 * ppw_min - 1) / (4 * ppw_min);
-  hashgrid_fwd_stencil_kernel<JAC><<<(unsigned)(chunks * n_xcd), HG_THREADS, 0, stream>>>(n, lv, xl, n_xcd, x, table, feat, jac);
+  const int64_t chunks = (n + 4 * ppw - 1) / (4 * ppw);
+  hashgrid_fwd_stencil_kernel<JAC><<<(unsigned)(chunks * n_xcd), HG_THREADS, 0, stream>>>(n, lv, xs, n_xcd, ppw, x, table, feat, jac);
 }
 
 // ---- backward kernels: 4 lanes per (point, level) -------------------------------------------------------
