@@ -1,5 +1,5 @@
-"""Experiment (GPU box): tile binning, hand-written depth-first sort vs rocPRIM on the 64-bit keys (run twice with
-GSDF_BINNING_SORT unset / =rocprim).  Usage: python tools/exp_binning.py"""
+"""Experiment (GPU box): times the tile binning (hand-written depth-first radix sort; the rocPRIM path it was compared with in round 2
+has been removed).  Usage: python tools/exp_binning.py"""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import gs_sdf_amd.ops as ops, gs_sdf_amd.synth as synth
