@@ -8,10 +8,19 @@ module, i.e. a libtorch serialize archive (a TorchScript zip) whose entries are 
                           (Linear / ReLU alternating, local_map.cpp:29-42) holding "weight" [out,in] and "bias" [out]
 
 The same archive is written here with torch.jit (what libtorch's OutputArchive produces and InputArchive::load_from reads),
-so `torch::load(local_map_ptr, path)` of the reference accepts it and files the reference wrote load here;
-tests/test_checkpoint_pt.py round-trips both directions through a libtorch C++ program.  The rest of a checkpoint
-directory — gs.ply (neural_gs.export_gs_to_ply) and as_occ_prior.ply (LocalMap.export_as_occ_prior) — already exists."""
+so `torch::load(local_map_ptr, path)` of a reference build LINKED AGAINST THE DROP-IN `tcnn_binding` accepts it and files such a
+build wrote load here; tests/test_checkpoint_pt.py round-trips both directions through a libtorch C++ program.
+
+Flat "decoder" layouts (decoder_implementation 1).  The drop-in TCNNNetwork keeps the weights UNPADDED, [out, in] row-major layer
+after layer (last layer 2 x 64).  Upstream tiny-cuda-nn's FullyFusedMLP pads the output width to a multiple of 16 (last layer
+16 x 64; rows >= n_out are dead): a checkpoint of that size is accepted on load (the real rows are taken) and
+`save_local_map_checkpoint(..., pad_tcnn_output=True)` writes it.  Not checked against an upstream build (none is available here):
+its parameter dtype (fp16 when tiny-cuda-nn is built with half precision) and the hash table's layout.
+The rest of a checkpoint directory — gs.ply (neural_gs.export_gs_to_ply) and as_occ_prior.ply (LocalMap.export_as_occ_prior) —
+already exists."""
 import torch
+
+TCNN_OUT_PAD = 16      # tiny-cuda-nn FullyFusedMLP: padded_output_width = next_multiple(n_output_dims, 16)
 
 
 def _layers(lm):
@@ -28,15 +37,20 @@ def _layers(lm):
     return out
 
 
-def save_local_map_checkpoint(lm, path):
-    """Writes what `torch::save(local_map_ptr, path)` writes for this LocalMap (see the module docstring)."""
+def save_local_map_checkpoint(lm, path, pad_tcnn_output=False):
+    """Writes what `torch::save(local_map_ptr, path)` writes for this LocalMap (see the module docstring); pad_tcnn_output: the
+    flat decoder parameter in upstream tiny-cuda-nn's layout (last layer padded to 16 output rows with zeros)."""
     root = torch.nn.Module()
     root.register_parameter("encoder_local_map", torch.nn.Parameter(lm.encoder.params_.detach().reshape(-1).cpu().clone()))
     layers = _layers(lm)
     if lm.decoder_implementation == 1:
         if any(b is not None for _, b in layers):
             raise RuntimeError("decoder_implementation 1 is bias free")
-        root.register_parameter("decoder", torch.nn.Parameter(torch.cat([w.reshape(-1) for w, _ in layers]).cpu().clone()))
+        ws = [w.cpu() for w, _ in layers]
+        if pad_tcnn_output and ws[-1].shape[0] % TCNN_OUT_PAD:
+            pad = TCNN_OUT_PAD - ws[-1].shape[0] % TCNN_OUT_PAD
+            ws[-1] = torch.cat([ws[-1], torch.zeros(pad, ws[-1].shape[1])], 0)
+        root.register_parameter("decoder", torch.nn.Parameter(torch.cat([w.reshape(-1) for w in ws]).clone()))
     else:
         mods = []
         for k, (w, b) in enumerate(layers):
@@ -64,13 +78,23 @@ def load_local_map_checkpoint(lm, path):
         lm.encoder.params_.copy_(enc.reshape(lm.encoder.params_.shape).to(lm.encoder.params_.device))
         layers = _layers(lm)
         if "decoder" in params:                                  # decoder_implementation 1: one flat parameter
-            flat = params["decoder"].reshape(-1)
-            if any(b is not None for _, b in layers) or flat.numel() != sum(w.numel() for w, _ in layers):
-                raise RuntimeError(f"{path}: flat decoder parameter does not fit this map's decoder")
+            flat = params["decoder"].reshape(-1).float()
+            n_plain = sum(w.numel() for w, _ in layers)
+            last = layers[-1][0]
+            rows_padded = -(-last.shape[0] // TCNN_OUT_PAD) * TCNN_OUT_PAD
+            n_padded = n_plain - last.numel() + rows_padded * last.shape[1]
+            if any(b is not None for _, b in layers) or flat.numel() not in (n_plain, n_padded):
+                raise RuntimeError(f"{path}: flat decoder parameter ({flat.numel()} values) does not fit this map's decoder "
+                                   f"({n_plain} unpadded / {n_padded} in tiny-cuda-nn's padded layout)")
+            padded = flat.numel() == n_padded and n_padded != n_plain
             off = 0
-            for w, _ in layers:
-                w.copy_(flat[off:off + w.numel()].view_as(w).to(w.device))
-                off += w.numel()
+            for k, (w, _) in enumerate(layers):
+                if padded and k + 1 == len(layers):               # upstream layout: [rows_padded, in], the real rows first
+                    w.copy_(flat[off:off + rows_padded * w.shape[1]].view(rows_padded, w.shape[1])[:w.shape[0]].to(w.device))
+                    off += rows_padded * w.shape[1]
+                else:
+                    w.copy_(flat[off:off + w.numel()].view_as(w).to(w.device))
+                    off += w.numel()
         else:                                                    # Sequential: decoder.<2k>.weight / .bias
             for k, (w, b) in enumerate(layers):
                 src_w, src_b = params.get(f"decoder.{2 * k}.weight"), params.get(f"decoder.{2 * k}.bias")

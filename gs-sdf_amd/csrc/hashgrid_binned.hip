@@ -22,6 +22,10 @@
 //            contribution per record and independent of the order of the records (bit-reproducible, unlike atomics).
 //
 // Traffic: 12 B written + 12 B read per contribution = 3 KB per query point, all of it coalesced.
+// Workspace: sized for the worst case, 12 B x 8 corners x n_levels per point (1.5 KB per point: 0.75 GB for the step's 0.49 M base rows,
+// 5 GB for a 3.3 M-row stencil batch before merging) — gsdf_hashgrid_bwd_binned_ws_bytes; a caller that cannot afford it passes the
+// batch to gsdf_hashgrid_bwd (atomics, no workspace), which is what the host layers do when the size query returns 0.
+// Non-finite contributions: bin_vmax marks the level, bin_apply writes NaN into the level's touched tiles (nothing is silently dropped).
 // The order in which records are summed is not fixed (like the atomic kernel's); results agree to fp32 rounding.
 #include "hashgrid_common.h"
 
@@ -185,6 +189,7 @@ __global__ void __launch_bounds__(256)
   const int64_t stride = (int64_t)gridDim.x * 256 / n_levels * n_levels;
   const int64_t i0 = (int64_t)blockIdx.x * 256 + threadIdx.x;
   float m = 0.f;
+  bool bad = false;   // a NaN / Inf contribution: fmaxf would drop the NaN and the fixed-point conversion would turn it into finite garbage
   if (i0 < stride)
     for (int64_t i = i0; i < n2; i += stride) {
       float b = 0.f;
@@ -198,9 +203,11 @@ __global__ void __launch_bounds__(256)
         const float l1 = fabsf(vv_x[3 * pt]) + fabsf(vv_x[3 * pt + 1]) + fabsf(vv_x[3 * pt + 2]);
         b += lv.scale[(int)(i0 % n_levels)] * l1 * fmaxf(fabsf(v.x), fabsf(v.y));
       }
+      bad |= !(b < __builtin_inff());
       m = fmaxf(m, b);
     }
-  if (m > 0.f) atomicMax(&s_max[(int)(i0 % n_levels)], __float_as_uint(m));
+  if (bad) atomicMax(&s_max[(int)(i0 % n_levels)], 0x7FC00000u);   // above every finite pattern: the level is marked non-finite
+  else if (m > 0.f) atomicMax(&s_max[(int)(i0 % n_levels)], __float_as_uint(m));
   __syncthreads();
   if (threadIdx.x < HG_MAX_LEVELS && s_max[threadIdx.x]) atomicMax(&lmax[threadIdx.x], s_max[threadIdx.x]);
 }
@@ -426,6 +433,17 @@ __global__ void __launch_bounds__(BIN_APPLY_THREADS)
   while (level + 1 < lv.n_levels && bp.tile_base[level + 1] <= it.bucket) ++level;
   const uint32_t mx = lmax[level];
   if (mx == 0u) return;                            // every contribution of this level is zero
+  if (mx >= 0x7F800000u) {
+    // a non-finite contribution somewhere in this level (bin_vmax): no fixed-point scale exists.  The level's touched tiles are
+    // poisoned with NaN so that the caller's NaN checks trip, as they would after the atomic kernel (which poisons only the entries the
+    // offending point reaches)
+    const int tile_p = it.bucket - bp.tile_base[level];
+    const int64_t e0p = (int64_t)tile_p << BIN_TILE_LOG2;
+    const int n_entp = (int)min((int64_t)BIN_TILE, (int64_t)lv.hsize[level] - e0p);
+    float *dstp = v_table + ((int64_t)lv.offset[level] + e0p) * 2;
+    for (int j = threadIdx.x; j < 2 * n_entp; j += BIN_APPLY_THREADS) dstp[j] = __builtin_nanf("");
+    return;
+  }
   const int e = (int)(mx >> 23) - 126;             // |g| < 2^e
   const double scale = ldexp(1.0, BIN_FIX_BITS - e), inv = ldexp(1.0, e - BIN_FIX_BITS);
   for (int i = threadIdx.x; i < 2 * BIN_TILE; i += BIN_APPLY_THREADS) s_tile[i] = 0ull;

@@ -84,3 +84,24 @@ def test_python_archive_loads_in_libtorch_and_back(helper, tmp_path, impl):
     bad.encoder.params_ = torch.zeros(N_TABLE + 8)
     with pytest.raises(RuntimeError):
         load_local_map_checkpoint(bad, p2)
+
+
+def test_tcnn_padded_decoder_layout_is_accepted_and_written(tmp_path):
+    """Upstream tiny-cuda-nn's FullyFusedMLP pads the output width to 16: the flat "decoder" of such a checkpoint is 16 x 64 in its last
+    layer.  load takes the real rows; pad_tcnn_output=True writes that layout."""
+    from gs_sdf_amd.checkpoint import _layers, load_local_map_checkpoint, save_local_map_checkpoint
+    lm = _fake_local_map(1, 7)
+    n_plain = lm.decoder.params_.numel()
+    p = tmp_path / "padded.pt"
+    save_local_map_checkpoint(lm, p, pad_tcnn_output=True)
+    flat = dict(torch.jit.load(str(p)).named_parameters())["decoder"]
+    assert flat.numel() == n_plain - 2 * 64 + 16 * 64
+    tail = flat[-16 * 64:].view(16, 64)
+    assert torch.equal(tail[:2], _layers(lm)[-1][0]) and float(tail[2:].abs().max()) == 0.0
+    back = load_local_map_checkpoint(_fake_local_map(1, 8), p)
+    assert torch.equal(back.decoder.params_, lm.decoder.params_)
+    # a size that is neither layout is refused with both sizes named
+    bad = _fake_local_map(1, 9)
+    bad.decoder = types.SimpleNamespace(dims=[32, 64, 64, 2], params_=torch.zeros(32 * 64 + 64 * 64 + 128), biases_=None)
+    with pytest.raises(RuntimeError, match="padded layout"):
+        load_local_map_checkpoint(bad, p)

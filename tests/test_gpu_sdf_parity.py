@@ -666,3 +666,31 @@ def test_sdf_leg_at_the_joint_iteration_size(sdf, oracle):
     torch.cuda.synchronize()
     assert_close(v_w, v_w_q, REL, "decoder weight gradients: all rows vs the sum over quarters")
     assert_close(v_t, v_t_q, REL, "table gradient: all rows vs the sum over quarters")
+
+
+@pytest.mark.parametrize("bad", [float("nan"), float("inf")])
+def test_hashgrid_binned_scatter_propagates_non_finite_gradients(sdf, oracle, bad):
+    """A NaN / Inf upstream gradient must not become finite garbage (fmaxf drops NaN, the fixed-point conversion of a non-finite value is
+    arbitrary): the level it belongs to comes out non-finite where it was touched, the other levels are exact."""
+    import gs_sdf_amd.capi as capi
+    dev = torch.device("cuda:0")
+    B, cfg = 40000, CFG
+    g = torch.Generator().manual_seed(5)
+    x = torch.rand(B, 3, generator=g)
+    v = torch.randn(B, cfg["n_levels"] * 2, generator=g)
+    v[1234, 2 * 7 + 1] = bad                                   # one feature of level 7 of one point
+    offs, total = oracle.grid_offsets(cfg)
+    c = (cfg["n_levels"], 2, cfg["log2_hashmap"], cfg["base_res"], cfg["per_level_scale"])
+    L = capi.lib()
+    nbytes = L.gsdf_hashgrid_bwd_binned_ws_bytes(B, *c)
+    got = torch.zeros(total, 2, device=dev)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    capi.check(L.gsdf_hashgrid_bwd_binned(B, *c, capi.f32(x.to(dev)), capi.f32(v.to(dev)), capi.f32(got), capi.ptr(ws), nbytes, capi.stream()), "binned")
+    torch.cuda.synchronize()
+    lvl = got[offs[7]:offs[8]]
+    assert not bool(torch.isfinite(lvl).all()), "the non-finite contribution vanished"
+    clean = v.clone()
+    clean[1234, 2 * 7 + 1] = 0.0
+    ref, _ = oracle.grid_bwd(n(x), np.zeros((total, 2), np.float32), n(clean), cfg, prec="f32")
+    for l in (0, 6, 8, 15):
+        assert_close(got[offs[l]:offs[l + 1]], ref[offs[l]:offs[l + 1]], 1e-5, f"level {l} beside the poisoned one")
