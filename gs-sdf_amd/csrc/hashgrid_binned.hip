@@ -196,12 +196,14 @@ __global__ void __launch_bounds__(256)
       if (v_feat != nullptr) {
         const float2 v = v_feat[i];
         b = fmaxf(fabsf(v.x), fabsf(v.y));
+        bad |= !(fabsf(v.x) < __builtin_inff()) || !(fabsf(v.y) < __builtin_inff());   // (fmaxf returns the other operand for a NaN)
       }
       if (v_feat2 != nullptr) {
         const float2 v = v_feat2[i];
         const int64_t pt = i / n_levels;
         const float l1 = fabsf(vv_x[3 * pt]) + fabsf(vv_x[3 * pt + 1]) + fabsf(vv_x[3 * pt + 2]);
         b += lv.scale[(int)(i0 % n_levels)] * l1 * fmaxf(fabsf(v.x), fabsf(v.y));
+        bad |= !(fabsf(v.x) < __builtin_inff()) || !(fabsf(v.y) < __builtin_inff()) || !(l1 < __builtin_inff());
       }
       bad |= !(b < __builtin_inff());
       m = fmaxf(m, b);

@@ -20,4 +20,15 @@ namespace gsplat_cpp {
 // Seed of the stochastic splat sample (`samples`, SPEC S-3).  0 (default) = splat centres with unit weights.
 // When non-zero a fresh seed is derived per call from torch's default generator, as a CUDA op would.
 void set_sample_mode(bool stochastic);
+bool get_sample_mode();
+// sets the mode for a scope and restores the caller's on exit (the mode is process-wide state)
+struct SampleModeGuard {
+  explicit SampleModeGuard(bool stochastic) : prev_(get_sample_mode()) { set_sample_mode(stochastic); }
+  ~SampleModeGuard() { set_sample_mode(prev_); }
+  SampleModeGuard(const SampleModeGuard &) = delete;
+  SampleModeGuard &operator=(const SampleModeGuard &) = delete;
+
+ private:
+  bool prev_;
+};
 }  // namespace gsplat_cpp

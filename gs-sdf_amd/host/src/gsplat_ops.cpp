@@ -163,6 +163,7 @@ struct Rasterize2DGS : public torch::autograd::Function<Rasterize2DGS> {
 }  // namespace
 
 void gsplat_cpp::set_sample_mode(bool stochastic) { g_stochastic_samples = stochastic; }
+bool gsplat_cpp::get_sample_mode() { return g_stochastic_samples; }
 
 std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor>
 fully_fused_projection_2dgs(const Tensor &means, const Tensor &quats, const Tensor &scales, const Tensor &viewmats,

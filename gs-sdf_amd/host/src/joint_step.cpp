@@ -209,7 +209,7 @@ std::map<std::string, int64_t> JointIteration::step(const Tensor &viewmat, const
   auto act = splat_activations(anchors_, views_[0], views_[1], views_[3].reshape({N}));
   Tensor dc = views_[4].reshape({N, 1, 3});
   Tensor sh = n_rest_ == 0 ? dc : torch::cat({dc, views_[5].reshape({N, n_rest_, 3})}, 1);
-  gsplat_cpp::set_sample_mode(!cfg_.center_reg);
+  gsplat_cpp::SampleModeGuard sample_mode(!cfg_.center_reg);
   auto proj = fully_fused_projection_2dgs(act[0], views_[2], act[1], viewmat, K, W, H, cfg_.near_plane, cfg_.far_plane, 0.f, true, false);
   const Tensor &camera_ids = std::get<0>(proj), &gaussian_ids = std::get<1>(proj), &radii = std::get<2>(proj), &means2d = std::get<3>(proj);
   const Tensor &depths = std::get<4>(proj), &ray_transforms = std::get<5>(proj), &normals = std::get<6>(proj);
