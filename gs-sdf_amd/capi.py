@@ -51,6 +51,7 @@ _SIGS = {
     "gsdf_mlp_acts_floats": (_sz, [_i64, _i32]),
     "gsdf_mlp_bwd_ws_bytes": (_sz, [_i64, _i32]),
     "gsdf_mlp_bwd_ws_bytes_for": (_sz, [_i64, _i32, _vp, _i32]),
+    "gsdf_mlp_bwd_is_one_pass": (_i32, [_i32, _vp]),
     "gsdf_mlp_bwd": (C.c_int, [_i64, _i32] + [_vp] * 11),
     "gsdf_mlp_bwd_weights": (C.c_int, [_i64, _i32, _vp, _i32] + [_vp] * 7),
     "gsdf_mlp_bwd_bwd_ws_bytes": (_sz, [_i64, _i32]),

@@ -387,7 +387,9 @@ extern "C" size_t gsdf_mlp_acts_floats(int64_t B, int n_layers) {   // images + 
   return image_floats(B, n_layers) + image_floats(B, n_layers) / 32 + 64;
 }
 extern "C" size_t gsdf_mlp_bwd_ws_bytes(int64_t B, int n_layers) {
-  return image_floats(B, n_layers) * sizeof(float) + 256;
+  // the per-layer gradient images of the two-kernel path, or the per-wave partial weight gradients of the one-pass path
+  const size_t img = image_floats(B, n_layers) * sizeof(float) + 256, part = mlp_bwd_split_ws_bytes_bound(B, n_layers);
+  return img > part ? img : part;
 }
 
 extern "C" size_t gsdf_mlp_bwd_ws_bytes_for(int64_t B, int n_layers, const int *dims_host, int want_weights) {
@@ -395,8 +397,14 @@ extern "C" size_t gsdf_mlp_bwd_ws_bytes_for(int64_t B, int n_layers, const int *
   size_t lds_floats;
   if (dims_host && want_weights && make_desc(n_layers, dims_host, 0, true, &d, &lds_floats, "mlp_bwd_ws_bytes_for") == GSDF_OK &&
       mlp_bwd_split_covers(d))
-    return 0;
+    return mlp_bwd_split_ws_bytes_bound(B, n_layers);   // one-pass path: partial weight gradients only (with or without biases)
   return gsdf_mlp_bwd_ws_bytes(B, n_layers);
+}
+
+extern "C" int gsdf_mlp_bwd_is_one_pass(int n_layers, const int *dims_host) {
+  MlpDesc d;
+  size_t lds_floats;
+  return dims_host && make_desc(n_layers, dims_host, 0, true, &d, &lds_floats, "mlp_bwd_is_one_pass") == GSDF_OK && mlp_bwd_split_covers(d) ? 1 : 0;
 }
 
 extern "C" int gsdf_mlp_fwd(int64_t B, int n_layers, const int *dims_host, const float *weights, const float *biases,
@@ -439,7 +447,7 @@ extern "C" int gsdf_mlp_bwd(int64_t B, int n_layers, const int *dims_host, const
   GSDF_REQUIRE(weights && in && v_out, "mlp_bwd: null buffer");
   GSDF_REQUIRE(acts, "mlp_bwd: the saved activations of mlp_fwd are required");
   if (v_weights != nullptr) {   // both gradients wanted: one pass on the bf16 pipe, v_pre never leaves the registers
-    rc = mlp_bwd_split_launch(B, d, weights, in, acts, v_out, v_in, v_weights, biases != nullptr ? v_biases : nullptr, stream);
+    rc = mlp_bwd_split_launch(B, d, weights, in, acts, v_out, v_in, v_weights, biases != nullptr ? v_biases : nullptr, ws, stream);
     if (rc != 0) return rc < 0 ? rc : GSDF_OK;
   }
   GSDF_REQUIRE(ws, "mlp_bwd: null workspace");

@@ -537,20 +537,52 @@ struct BwdLayers<NL, BIAS, -1> {
   static __device__ __forceinline__ void run(const BwdCtx &, const SplitLds &, BwdAcc<NL> &, int64_t, int64_t, Split8 (&)[4], Split8 (&)[2][2], v16f (&)[2]) {}
 };
 
-// one round of atomics for a 32x32 tile: rows o = o0 + d_row(r, half) < O, column i = i0 + (lane & 31)
+// a 32x32 tile leaves: rows o = o0 + d_row(r, half) < O, column i = i0 + (lane & 31).  PART: plain stores into the wave's own partial
+// buffer (every element of the blob is written by exactly one tile); else one round of atomics on the gradient itself
+template <bool PART>
 __device__ __forceinline__ void flush_tile(const v16f &a, float *vw, int I, int O, int o0, int i0, int lane) {
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int o = o0 + d_row(r, lane >> 5);
-    if (o < O && a[r] != 0.f) atomicAdd(vw + o * I + i0 + (lane & 31), a[r]);
+    if (PART) { if (o < O) vw[o * I + i0 + (lane & 31)] = a[r]; }
+    else if (o < O && a[r] != 0.f) atomicAdd(vw + o * I + i0 + (lane & 31), a[r]);
   }
 }
 
-template <int NL, bool BIAS>
+// partial buffers [n_part][n_elem] -> chunk sums [RED_CHUNKS][n_elem] -> v_W / v_b (one atomic per element and launch: other launches
+// may be accumulating into the same gradient from another stream)
+static constexpr int RED_CHUNKS = 16;
+__global__ void __launch_bounds__(256) mlp_partials_sum_kernel(int n_part, int n_elem, const float *__restrict__ part, float *__restrict__ chunk) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= n_elem) return;
+  const int per = (n_part + RED_CHUNKS - 1) / RED_CHUNKS;
+  const int p0 = blockIdx.y * per, p1 = min(n_part, p0 + per);
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int p = p0;
+  for (; p + 3 < p1; p += 4) {
+    s0 += part[(int64_t)p * n_elem + e]; s1 += part[(int64_t)(p + 1) * n_elem + e];
+    s2 += part[(int64_t)(p + 2) * n_elem + e]; s3 += part[(int64_t)(p + 3) * n_elem + e];
+  }
+  for (; p < p1; ++p) s0 += part[(int64_t)p * n_elem + e];
+  chunk[(int64_t)blockIdx.y * n_elem + e] = (s0 + s1) + (s2 + s3);
+}
+__global__ void __launch_bounds__(256) mlp_partials_apply_kernel(int n_elem, int n_w, const float *__restrict__ chunk, float *__restrict__ v_W,
+                                                                 float *__restrict__ v_b) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= n_elem) return;
+  float s = 0.f;
+#pragma unroll
+  for (int c = 0; c < RED_CHUNKS; ++c) s += chunk[(int64_t)c * n_elem + e];
+  if (s == 0.f) return;
+  if (e < n_w) atomicAdd(v_W + e, s);
+  else if (v_b != nullptr) atomicAdd(v_b + (e - n_w), s);
+}
+
+template <int NL, bool BIAS, bool PART>
 __global__ void __launch_bounds__(SPLIT_BWD_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1)))
     mlp_bwd_split_kernel(int64_t B, MlpDesc d, SplitLds sl, int lds_w4, const float *__restrict__ W, const float *__restrict__ in,
                          const float *__restrict__ acts, const float *__restrict__ v_out, float *__restrict__ v_in,
-                         float *__restrict__ v_W, float *__restrict__ v_b) {
+                         float *__restrict__ v_W, float *__restrict__ v_b, int64_t part_stride) {
   extern __shared__ __attribute__((aligned(16))) uint4 smem4[];
   stage_split_bwd(d, sl, W, smem4, true);
   __syncthreads();
@@ -587,17 +619,23 @@ __global__ void __launch_bounds__(SPLIT_BWD_THREADS) __attribute__((amdgpu_waves
   for (int s = 2; s < 4; ++s) gb[s] = gb[0];
   at[1][0] = at[0][0]; at[1][1] = at[0][1];
   for (; tile < c.n_tiles; tile += stride) BwdLayers<NL, BIAS, NL - 1>::run(c, sl, acc, tile, tile + stride, gb, at, x);
-  // ---- one round of atomics per wave
-  flush_tile(acc.w0[0], v_W + d.w_off[0], 32, HID, 0, 0, lane);
-  flush_tile(acc.w0[1], v_W + d.w_off[0], 32, HID, 32, 0, lane);
+  // ---- the wave's weight-gradient tiles leave: PART = into its own partial buffer (v_W / v_b point at the buffers' base: [wave][blob]),
+  //      else one round of atomics on the gradient
+  if (PART) {
+    const int64_t mine = ((int64_t)blockIdx.x * WAVES + wave) * part_stride;
+    v_W += mine;
+    if (BIAS) v_b += mine;
+  }
+  flush_tile<PART>(acc.w0[0], v_W + d.w_off[0], 32, HID, 0, 0, lane);
+  flush_tile<PART>(acc.w0[1], v_W + d.w_off[0], 32, HID, 32, 0, lane);
 #pragma unroll
   for (int l = 1; l < NL - 1; ++l)
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-      for (int nt = 0; nt < 2; ++nt) flush_tile(acc.wh[l - 1][mt][nt], v_W + d.w_off[l], HID, HID, 32 * mt, 32 * nt, lane);
-  flush_tile(acc.wl[0], v_W + d.w_off[NL - 1], HID, d.d_out, 0, 0, lane);
-  flush_tile(acc.wl[1], v_W + d.w_off[NL - 1], HID, d.d_out, 0, 32, lane);
+      for (int nt = 0; nt < 2; ++nt) flush_tile<PART>(acc.wh[l - 1][mt][nt], v_W + d.w_off[l], HID, HID, 32 * mt, 32 * nt, lane);
+  flush_tile<PART>(acc.wl[0], v_W + d.w_off[NL - 1], HID, d.d_out, 0, 0, lane);
+  flush_tile<PART>(acc.wl[1], v_W + d.w_off[NL - 1], HID, d.d_out, 0, 32, lane);
   if (BIAS) {
 #pragma unroll
     for (int l = 0; l < NL; ++l) {
@@ -608,7 +646,7 @@ __global__ void __launch_bounds__(SPLIT_BWD_THREADS) __attribute__((amdgpu_waves
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int o = 32 * mt + d_row(r, lane >> 5);
-          if (o < O) atomicAdd(v_b + d.b_off[l] + o, acc.b[r]);
+          if (o < O) { if (PART) v_b[d.b_off[l] + o] = acc.b[r]; else atomicAdd(v_b + d.b_off[l] + o, acc.b[r]); }
         }
       }
     }
@@ -626,18 +664,56 @@ static size_t split_bwd_lds(const MlpDesc &d, SplitLds *sl, int *lds_w4) {
   return (size_t)off * 16;   // dynamic part; the transposition blocks are static
 }
 
-template <int NL, bool BIAS>
-static int launch_bwd_split(int64_t B, const MlpDesc &d, const SplitLds &sl, int lds_w4, size_t lds, const float *W, const float *in,
-                            const float *acts, const float *v_out, float *v_in, float *v_W, float *v_b, hipStream_t stream) {
-  GSDF_HIP(hipFuncSetAttribute((const void *)mlp_bwd_split_kernel<NL, BIAS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "mlp_bwd_split attr");
-  // every wave leaves through one round of atomics over ALL weight gradients (~14.5 K): a wave must own enough 32-point tiles
-  // to amortise it (measured: 32768 points on 256 workgroups = 1 tile per wave took 0.37 ms, all of it the flush)
+// grid of the one-pass backward: a wave must own enough 32-point tiles to amortise its exit (measured with the atomic exit: 32768 points
+// on 256 workgroups = 1 tile per wave took 0.37 ms, all of it the flush)
+static unsigned split_bwd_grid(int64_t B) {
   constexpr int waves = SPLIT_BWD_THREADS / 64, min_tiles_per_wave = 8;
   unsigned grid = split_grid(B, waves);
   const int64_t want = ((B + 31) / 32 + (int64_t)waves * min_tiles_per_wave - 1) / ((int64_t)waves * min_tiles_per_wave);
   if ((int64_t)grid > want) grid = (unsigned)(want < 1 ? 1 : want);
-  mlp_bwd_split_kernel<NL, BIAS><<<grid, SPLIT_BWD_THREADS, lds, stream>>>(B, d, sl, lds_w4, W, in, acts, v_out, v_in, v_W, v_b);
+  return grid;
+}
+static int blob_floats(const MlpDesc &d, int *n_w) {
+  const int O = d.d_out, nl = d.n_layers;
+  *n_w = d.w_off[nl - 1] + O * HID;
+  return *n_w + (d.has_bias ? d.b_off[nl - 1] + O : 0);
+}
+size_t mlp_bwd_split_ws_bytes(int64_t B, const MlpDesc &d) {
+  int n_w;
+  const int64_t n_elem = blob_floats(d, &n_w);
+  return (size_t)(((int64_t)split_bwd_grid(B) * (SPLIT_BWD_THREADS / 64) + RED_CHUNKS) * n_elem) * sizeof(float) + 256;
+}
+size_t mlp_bwd_split_ws_bytes_bound(int64_t B, int n_layers) {
+  const int64_t n_elem = (int64_t)n_layers * (HID * HID + HID);
+  return (size_t)(((int64_t)split_bwd_grid(B) * (SPLIT_BWD_THREADS / 64) + RED_CHUNKS) * n_elem) * sizeof(float) + 256;
+}
+
+template <int NL, bool BIAS>
+static int launch_bwd_split(int64_t B, const MlpDesc &d, const SplitLds &sl, int lds_w4, size_t lds, const float *W, const float *in,
+                            const float *acts, const float *v_out, float *v_in, float *v_W, float *v_b, void *ws, hipStream_t stream) {
+  const unsigned grid = split_bwd_grid(B);
+  static const bool atomic_exit = [] { const char *e = getenv("GSDF_MLP_BWD_EXIT"); return e && e[0] == 'a'; }();   // GSDF_MLP_BWD_EXIT=atomic: A/B
+  // beyond ~48 tiles per wave the waves drift apart and their atomic exits hide behind each other's tiles; the partial buffers then only
+  // add their two reduction launches (3.29 M points: 1.95 ms atomic, 2.05 ms partial; 0.49 M: 0.55 / 0.36; 0.1 M: 0.24 / 0.15)
+  const bool many_tiles = (B + 31) / 32 > (int64_t)grid * (SPLIT_BWD_THREADS / 64) * 48;
+  if (ws == nullptr || atomic_exit || many_tiles) {
+    GSDF_HIP(hipFuncSetAttribute((const void *)mlp_bwd_split_kernel<NL, BIAS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "mlp_bwd_split attr");
+    mlp_bwd_split_kernel<NL, BIAS, false><<<grid, SPLIT_BWD_THREADS, lds, stream>>>(B, d, sl, lds_w4, W, in, acts, v_out, v_in, v_W, v_b, 0);
+    GSDF_CHECK_LAUNCH("mlp_bwd_split_kernel");
+    return 1;
+  }
+  int n_w;
+  const int n_elem = blob_floats(d, &n_w);
+  const int n_part = (int)grid * (SPLIT_BWD_THREADS / 64);
+  float *part = (float *)(((uintptr_t)ws + 255) & ~(uintptr_t)255), *chunk = part + (int64_t)n_part * n_elem;
+  GSDF_HIP(hipFuncSetAttribute((const void *)mlp_bwd_split_kernel<NL, BIAS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "mlp_bwd_split attr");
+  mlp_bwd_split_kernel<NL, BIAS, true><<<grid, SPLIT_BWD_THREADS, lds, stream>>>(B, d, sl, lds_w4, W, in, acts, v_out, v_in, part, part + n_w, n_elem);
   GSDF_CHECK_LAUNCH("mlp_bwd_split_kernel");
+  const unsigned eb = (unsigned)((n_elem + 255) / 256);
+  mlp_partials_sum_kernel<<<dim3(eb, RED_CHUNKS), 256, 0, stream>>>(n_part, n_elem, part, chunk);
+  GSDF_CHECK_LAUNCH("mlp_partials_sum_kernel");
+  mlp_partials_apply_kernel<<<eb, 256, 0, stream>>>(n_elem, n_w, chunk, v_W, BIAS ? v_b : nullptr);
+  GSDF_CHECK_LAUNCH("mlp_partials_apply_kernel");
   return 1;
 }
 
@@ -649,16 +725,16 @@ bool mlp_bwd_split_covers(const MlpDesc &d) {
 }
 
 int mlp_bwd_split_launch(int64_t B, const MlpDesc &d, const float *W, const float *in, const float *acts, const float *v_out,
-                         float *v_in, float *v_W, float *v_b, hipStream_t stream) {
+                         float *v_in, float *v_W, float *v_b, void *ws, hipStream_t stream) {
   if (v_W == nullptr || !mlp_bwd_split_covers(d)) return 0;
   SplitLds sl;
   int lds_w4;
   const size_t lds = split_bwd_lds(d, &sl, &lds_w4);
   const bool bias = d.has_bias && v_b != nullptr;
-  if (d.n_layers == 5) return bias ? launch_bwd_split<5, true>(B, d, sl, lds_w4, lds, W, in, acts, v_out, v_in, v_W, v_b, stream)
-                                   : launch_bwd_split<5, false>(B, d, sl, lds_w4, lds, W, in, acts, v_out, v_in, v_W, v_b, stream);
-  if (d.n_layers == 4) return bias ? launch_bwd_split<4, true>(B, d, sl, lds_w4, lds, W, in, acts, v_out, v_in, v_W, v_b, stream)
-                                   : launch_bwd_split<4, false>(B, d, sl, lds_w4, lds, W, in, acts, v_out, v_in, v_W, v_b, stream);
+  if (d.n_layers == 5) return bias ? launch_bwd_split<5, true>(B, d, sl, lds_w4, lds, W, in, acts, v_out, v_in, v_W, v_b, ws, stream)
+                                   : launch_bwd_split<5, false>(B, d, sl, lds_w4, lds, W, in, acts, v_out, v_in, v_W, v_b, ws, stream);
+  if (d.n_layers == 4) return bias ? launch_bwd_split<4, true>(B, d, sl, lds_w4, lds, W, in, acts, v_out, v_in, v_W, v_b, ws, stream)
+                                   : launch_bwd_split<4, false>(B, d, sl, lds_w4, lds, W, in, acts, v_out, v_in, v_W, v_b, ws, stream);
   return 0;
 }
 

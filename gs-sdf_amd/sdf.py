@@ -255,11 +255,11 @@ class TCNNEncoding:
 
 
 def _mlp_fused_bwd(dims):
-    """does gsdf_mlp_bwd with both gradients take the one-pass kernel (csrc/mlp_split.hip: no workspace) for this topology?"""
+    """does gsdf_mlp_bwd with both gradients take the one-pass kernel (csrc/mlp_split.hip) for this topology?"""
     if os.environ.get("GSDF_MLP_FUSED_BWD", "1") == "0":
         return False
     dims_c = (C.c_int * len(dims))(*dims)
-    return capi.lib().gsdf_mlp_bwd_ws_bytes_for(1024, len(dims) - 1, dims_c, 1) == 0
+    return capi.lib().gsdf_mlp_bwd_is_one_pass(len(dims) - 1, dims_c) == 1
 
 
 class _MlpFn(torch.autograd.Function):
@@ -299,8 +299,9 @@ class _MlpFn(torch.autograd.Function):
             # trainer fast path, fused: input and parameter gradients in one pass (v_pre stays in registers), the parameter
             # gradients accumulate straight into the flat gradient buffer
             w_sink, b_sink = ctx.sinks
+            ws = torch.empty(L.gsdf_mlp_bwd_ws_bytes_for(B, nl, dims_c, 1), dtype=torch.uint8, device=x.device)   # the waves' partial weight gradients
             capi.check(_timed("mlp_bwd", L.gsdf_mlp_bwd, B, nl, dims_c, f32(weights), f32(biases), f32(x), f32(acts),
-                              f32(v_out), f32(v_in), f32(w_sink), f32(b_sink), None, capi.stream()), "mlp_bwd")
+                              f32(v_out), f32(v_in), f32(w_sink), f32(b_sink), ptr(ws), capi.stream()), "mlp_bwd")
             return v_in, None, None, None, None, None
         ws = torch.empty(L.gsdf_mlp_bwd_ws_bytes(B, nl), dtype=torch.uint8, device=x.device)
         if ctx.sinks is not None and ctx.needs_input_grad[1] and _sinks_live():
@@ -554,8 +555,9 @@ class _CouplingLeg(torch.autograd.Function):
         w_sink, b_sink = dec.grad_sinks
         cur = torch.cuda.current_stream()
         if _mlp_fused_bwd(dims):
+            ws = torch.empty(L.gsdf_mlp_bwd_ws_bytes_for(nq, nl, dims_c, 1), dtype=torch.uint8, device=x01.device)
             capi.check(_timed("mlp_bwd", L.gsdf_mlp_bwd, nq, nl, dims_c, f32(dec.params_), f32(dec.biases_), f32(feat), f32(acts),
-                              f32(v_out), f32(v_feat), f32(w_sink), f32(b_sink), None, capi.stream()), "mlp_bwd")
+                              f32(v_out), f32(v_feat), f32(w_sink), f32(b_sink), ptr(ws), capi.stream()), "mlp_bwd")
         else:
             ws = torch.empty(L.gsdf_mlp_bwd_ws_bytes(nq, nl), dtype=torch.uint8, device=x01.device)
             capi.check(_timed("mlp_bwd_data", L.gsdf_mlp_bwd, nq, nl, dims_c, f32(dec.params_), f32(dec.biases_), f32(feat), f32(acts),

@@ -261,10 +261,14 @@ int gsdf_mlp_fwd(int64_t B, int n_layers, const int *dims_host, const float *wei
                  const float *in, float *out, float *acts, gsdf_stream_t stream);
 size_t gsdf_mlp_acts_floats(int64_t B, int n_layers);
 size_t gsdf_mlp_bwd_ws_bytes(int64_t B, int n_layers);
-/* Workspace gsdf_mlp_bwd needs for THIS call: 0 when both gradients are requested and the topology takes the one-pass
- * backward (input width 32, 4 or 5 layers, <= 16 outputs: v_pre never leaves the registers, `ws` may then be NULL), else
- * gsdf_mlp_bwd_ws_bytes(B, n_layers) (the per-layer gradients travel through `ws` to gsdf_mlp_bwd_weights). */
+/* Workspace gsdf_mlp_bwd needs for THIS call.  When both gradients are requested and the topology takes the one-pass backward
+ * (input width 32, 4 or 5 layers, <= 16 outputs: v_pre never leaves the registers): the waves' partial weight gradients (plain stores,
+ * summed by two small kernels; with ws == NULL the same call still works and each wave leaves through ~14.5 K atomics instead: 0.3 ms
+ * slower per launch at 0.5 M points).  Else the per-layer gradient images that travel to gsdf_mlp_bwd_weights.
+ * gsdf_mlp_bwd_ws_bytes(B, n_layers) is an upper bound of both for callers that do not have the widths at hand. */
 size_t gsdf_mlp_bwd_ws_bytes_for(int64_t B, int n_layers, const int *dims_host, int want_weights);
+/* 1 when gsdf_mlp_bwd with both gradients takes the one-pass kernel for this topology (gsdf_mlp_bwd_weights is then never needed), else 0 */
+int gsdf_mlp_bwd_is_one_pass(int n_layers, const int *dims_host);
 /* v_in [B,dims[0]] overwritten (may be NULL); v_weights / v_biases ACCUMULATE (may be NULL). */
 int gsdf_mlp_bwd(int64_t B, int n_layers, const int *dims_host, const float *weights, const float *biases,
                  const float *in, const float *acts, const float *v_out, float *v_in, float *v_weights,
