@@ -157,6 +157,13 @@ struct NeuralGS : torch::nn::Module {
   void apply_rows(const std::shared_ptr<torch::optim::Adam> &p, const torch::Tensor &keep_idx, const std::vector<torch::Tensor> &ext);
 };
 
+// NeuralSLAM::sample (neural_mapping.cpp:73-104) + utils::sample_surface_pts (include/utils/utils.cpp:336-364): the per-ray SDF batch
+// (SURVEY 8 a16).  rays: origin / direction [R,3], depth [R,1], xyz = the ray end points.  -> one sample in every occupied voxel a ray
+// crosses [+ free_sample_num stratified free-space samples], surface_sample_num near-surface samples depth - N(0, sample_std), SDF
+// targets truncated to +-truncated_dis, the end points themselves (target 0), everything filtered to the map's inner cube.
+DepthSamples sample_rays(LocalMap &local_map, DepthSamples rays, float sample_std, float truncated_dis, int surface_sample_num = 3,
+                         bool sample_free = true);
+
 // neural_gaussian.cpp:19-127: splat rotation (and optionally opacity) from the SDF's gradient and diagonal Hessian
 std::map<std::string, torch::Tensor> init_gs_with_sdf(LocalMap &local_map, const torch::Tensor &xyzs, float mesh_res, bool init_opa,
                                                       int64_t batch_size);

@@ -200,4 +200,28 @@ DepthSamples LocalMap::filter_sample(const DepthSamples &samples) {
   return samples.index_select((p_acc_strcut_occ_->query(xyz_to_m1p1_pts(samples.xyz)).pidx > -1).nonzero().reshape({-1}));
 }
 
+DepthSamples sample_rays(LocalMap &local_map, DepthSamples rays, float sample_std, float truncated_dis, int surface_sample_num,
+                         bool sample_free) {
+  const int64_t n = rays.size(0);
+  auto dev = rays.origin.device();
+  rays.ridx = torch::arange(n, torch::TensorOptions().dtype(torch::kInt64).device(dev));
+  rays.ray_sdf = torch::zeros({n, 1}, rays.origin.options());
+  DepthSamples pts = local_map.sample(rays, 1, sample_free);
+  {   // utils::sample_surface_pts: k samples per ray at signed distance N(0, std) from the end point, along the ray
+    DepthSamples s;
+    Tensor sdf = torch::randn({n, surface_sample_num, 1}, rays.origin.options()) * sample_std;
+    auto rep = [&](const Tensor &t) { return t.unsqueeze(1).repeat({1, surface_sample_num, 1}).view({-1, t.size(1)}); };
+    s.origin = rep(rays.origin);
+    s.xyz = (rays.xyz.unsqueeze(1) - rays.direction.unsqueeze(1) * sdf).view({-1, 3});
+    s.direction = rep(rays.direction);
+    s.ridx = rays.ridx.unsqueeze(1).repeat({1, surface_sample_num}).view({-1});
+    s.depth = rep(rays.depth);
+    s.ray_sdf = sdf.view({-1, 1});
+    pts = pts.cat(s);
+  }
+  pts.ray_sdf = torch::where(pts.ray_sdf.abs() > truncated_dis, pts.ray_sdf.sign() * truncated_dis, pts.ray_sdf);
+  pts = pts.cat(rays);
+  return pts.index_select(local_map.get_inrange_mask(pts.xyz).nonzero().reshape({-1}));
+}
+
 }  // namespace gsdf_model

@@ -118,6 +118,18 @@ def test_local_map_occupancy_and_sampling_match_python_mirror(host):
     assert bool((sc["ray_sdf"] > 0).all())
     fc, fp = cm.filter_sample(dict(xyz=q, ridx=torch.arange(n, device=dev))), pm.filter_sample(DepthSamples(xyz=q, ridx=torch.arange(n, device=dev)))
     assert_equal_int(fc["ridx"], fp.ridx, "filter_sample")
+    # the whole per-ray SDF batch (NeuralSLAM::sample, neural_mapping.cpp:73-104): voxel + free + near-surface + end-point samples,
+    # truncated targets, inner-cube filter; same RNG stream in both
+    from gs_sdf_amd.neural_gs import sample_ray_batch
+    torch.manual_seed(123)
+    bc = host.sample_rays(cm, dict(origin=origin, direction=direction, depth=depth, xyz=pts), 0.02, 0.1875, 3, True)
+    torch.manual_seed(123)
+    bp = sample_ray_batch(pm, origin, direction, depth, 0.02, 0.1875, 3, cfg.free_sample_num, True)
+    assert bc["xyz"].shape == bp.xyz.shape and bc["xyz"].shape[0] > 6 * n
+    assert_equal_int(bc["ridx"], bp.ridx, "ray batch ridx")
+    assert_close(bc["xyz"], bp.xyz, 1e-6, "ray batch xyz")
+    assert_close(bc["ray_sdf"], bp.ray_sdf, 1e-6, "ray batch ray_sdf")
+    assert float(bc["ray_sdf"].abs().max()) <= 0.1875 + 1e-7
 
 
 def scene_models(host, N=6000, W=320, H=192, deg=1, **cfg_kw):
