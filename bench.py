@@ -303,9 +303,9 @@ def main():
             # points + (full step) the eikonal regulariser on the numerical gradient at the same points, i.e. 6 more
             # encoder / decoder evaluations per sample (sdf_regularization(gs_samples.detach(), ...), :448-451 -> :106-136)
             vis = meta["visibilities"].detach()
-            w_all = (meta["samples_weights"] * vis).detach()
-            valid = lm.get_valid_mask(meta["samples"].detach()) & (vis > 0.1).squeeze(-1)      # neural_mapping.cpp:430-432
-            ids = valid.nonzero().squeeze(-1)
+            # samples_weights * visibilities, get_valid_mask(samples) & (visibilities > 0.1), nonzero (neural_mapping.cpp:423-437): 3 launches
+            ids, w_all = lm.acc_struct_occ.visible_set(meta["samples"], vis, meta["samples_weights"], 0.1, lm._origin, lm.map_size_inv)
+            w_all = w_all[:, None]
             stamp("visible set (sync)")
             fwd_done = main.record_event()
             samples = meta["samples"]                                 # already behind join_grad(gate)

@@ -70,6 +70,8 @@ _SIGS = {
     "gsdf_occ_build": (C.c_int, [_i32, _i64, _vp, _i32, _vp, _vp]),
     "gsdf_occ_query": (C.c_int, [_i32, _i32, _i64, _vp, _vp, _vp, _vp]),
     "gsdf_occ_query_world": (C.c_int, [_i32, _i32, _i64, _vp, _vp, _f32, _vp, _vp, _vp]),
+    "gsdf_visible_set_ws_bytes": (_sz, [_i64]),
+    "gsdf_visible_set": (C.c_int, [_i32, _i32, _i64, _vp, _vp, _f32, _vp, _vp, _vp, _f32, _vp, _vp, _vp, _vp, _vp]),
     "gsdf_occ_voxel_counts": (C.c_int, [_i32, _vp, _vp, _vp]),
     "gsdf_occ_voxel_list": (C.c_int, [_i32, _vp, _vp, _vp, _vp]),
     "gsdf_occ_raymarch_count": (C.c_int, [_i32, _i64, _vp, _vp, _vp, _vp, _vp]),

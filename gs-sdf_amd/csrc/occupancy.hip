@@ -112,6 +112,87 @@ __global__ void __launch_bounds__(256)
   mask[i] = (uint8_t)(in && occ_bit(grid, lv, l, occ_quantize(x, res), occ_quantize(y, res), occ_quantize(z, res)));
 }
 
+// ---- the visible, occupancy-valid set of the joint iteration (neural_mapping.cpp:423-437) ---------------------------------------
+// flag(i) = visibilities[i] > thr  &&  sample i inside an occupied level-l voxel;  w_all[i] = samples_weights[i] * visibilities[i];
+// ids = the flagged rows in increasing order (what nonzero() returns).  Three launches: flags + weights + per-workgroup counts,
+// one-workgroup scan of the counts (+ total), ordered write with ballot ranks.  Replaces mul, compare, and, nonzero (a hipcub
+// reduction, a read-back, a rocPRIM partition) = 10 libtorch launches on the chain between the compositing forward and the SDF leg.
+static constexpr int VS_ROWS = 1024;   // rows per workgroup (256 lanes x 4)
+__global__ void __launch_bounds__(256)
+    visible_flags_kernel(int l, OccLevels lv, int64_t n, const float *__restrict__ xyz, float ox, float oy, float oz, float inv,
+                         const uint32_t *__restrict__ grid, const float *__restrict__ vis, const float *__restrict__ sw, float thr,
+                         float *__restrict__ w_all, uint8_t *__restrict__ flags, int32_t *__restrict__ counts) {
+  __shared__ int s_cnt[4];
+  const int res = 1 << l;
+  int c = 0;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int64_t i = (int64_t)blockIdx.x * VS_ROWS + q * 256 + threadIdx.x;
+    if (i >= n) continue;
+    const float v = vis[i];
+    w_all[i] = sw[i] * v;
+    const float x = ((xyz[3 * i] - ox) * 2.0f) * inv, y = ((xyz[3 * i + 1] - oy) * 2.0f) * inv, z = ((xyz[3 * i + 2] - oz) * 2.0f) * inv;
+    const bool in = x >= -1.0f && x <= 1.0f && y >= -1.0f && y <= 1.0f && z >= -1.0f && z <= 1.0f;
+    const bool f = v > thr && in && occ_bit(grid, lv, l, occ_quantize(x, res), occ_quantize(y, res), occ_quantize(z, res));
+    flags[i] = (uint8_t)f;
+    c += f ? 1 : 0;
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) c += __shfl_xor(c, d, 64);
+  if ((threadIdx.x & 63) == 0) s_cnt[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) counts[blockIdx.x] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+}
+// exclusive scan of nblk counts in place, total -> *total (one workgroup of 1024 lanes, any nblk)
+__global__ void __launch_bounds__(1024) visible_scan_kernel(int nblk, int32_t *__restrict__ counts, int64_t *__restrict__ total) {
+  __shared__ int s_w[16];
+  __shared__ int s_carry;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (threadIdx.x == 0) s_carry = 0;
+  __syncthreads();
+  for (int base = 0; base < nblk; base += 1024) {
+    const int i = base + threadIdx.x;
+    const int v = i < nblk ? counts[i] : 0;
+    int incl = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(incl, d, 64); if (lane >= d) incl += o; }
+    if (lane == 63) s_w[wave] = incl;
+    __syncthreads();
+    int before = s_carry;
+    for (int w = 0; w < wave; ++w) before += s_w[w];
+    if (i < nblk) counts[i] = before + incl - v;
+    __syncthreads();
+    if (threadIdx.x == 1023) s_carry = before + incl;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *total = s_carry;
+}
+__global__ void __launch_bounds__(256)
+    visible_write_kernel(int64_t n, const uint8_t *__restrict__ flags, const int32_t *__restrict__ offsets, int64_t *__restrict__ ids) {
+  __shared__ int s_cnt[4][4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  bool f[4];
+  int rank[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {   // rows in increasing order: pass q covers rows [256 q, 256 q + 256) of the block, wave w its 64-row slice
+    const int64_t i = (int64_t)blockIdx.x * VS_ROWS + q * 256 + threadIdx.x;
+    f[q] = i < n && flags[i];
+    const unsigned long long b = __ballot(f[q]);
+    rank[q] = __popcll(b & ((1ull << lane) - 1ull));
+    if (lane == 0) s_cnt[q][wave] = __popcll(b);
+  }
+  __syncthreads();
+  int base = offsets[blockIdx.x];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    int before = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) before += w < wave ? s_cnt[q][w] : 0;
+    if (f[q]) ids[base + before + rank[q]] = (int64_t)blockIdx.x * VS_ROWS + q * 256 + threadIdx.x;
+    base += s_cnt[q][0] + s_cnt[q][1] + s_cnt[q][2] + s_cnt[q][3];
+  }
+}
+
 // occupied level-L voxels: popcount per word, then (with the exclusive scan of the counts) their coordinates
 __global__ void __launch_bounds__(256)
     occ_popc_kernel(int64_t n_words, const uint32_t *__restrict__ words, int32_t *__restrict__ counts) {
@@ -296,6 +377,33 @@ extern "C" int gsdf_occ_query_world(int level, int query_level, int64_t n, const
                                                                           origin_host[1], origin_host[2], map_size_inv,
                                                                           (const uint32_t *)grid, mask);
   GSDF_CHECK_LAUNCH("occ_query_kernel<world>");
+  return GSDF_OK;
+}
+
+extern "C" size_t gsdf_visible_set_ws_bytes(int64_t n) { return (size_t)n + 4 * (size_t)((n + VS_ROWS - 1) / VS_ROWS) + 512; }
+
+extern "C" int gsdf_visible_set(int level, int query_level, int64_t n, const float *xyz_world, const float *origin_host, float map_size_inv,
+                                const void *grid, const float *visibilities, const float *samples_weights, float vis_thresh, float *w_all,
+                                int64_t *ids, int64_t *count, void *ws, gsdf_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  GSDF_TIMED("gsdf_visible_set");
+  if (int rc = check_level(level, "visible_set")) return rc;
+  const int l = query_level < 0 ? level : query_level;
+  GSDF_REQUIRE(l >= 0 && l <= level, "visible_set: query level %d outside [0,%d]", l, level);
+  GSDF_REQUIRE(n >= 0 && count, "visible_set: bad arguments");
+  if (n == 0) { GSDF_HIP(hipMemsetAsync(count, 0, sizeof(int64_t), stream), "visible_set memset"); return GSDF_OK; }
+  GSDF_REQUIRE(xyz_world && origin_host && grid && visibilities && samples_weights && w_all && ids && ws, "visible_set: null buffer");
+  GSDF_REQUIRE(n < ((int64_t)1 << 31), "visible_set: too many rows");
+  const int nblk = (int)((n + VS_ROWS - 1) / VS_ROWS);
+  int32_t *counts = (int32_t *)(((uintptr_t)ws + 255) & ~(uintptr_t)255);
+  uint8_t *flags = (uint8_t *)(counts + nblk);
+  visible_flags_kernel<<<nblk, 256, 0, stream>>>(l, make_levels(level), n, xyz_world, origin_host[0], origin_host[1], origin_host[2], map_size_inv,
+                                                 (const uint32_t *)grid, visibilities, samples_weights, vis_thresh, w_all, flags, counts);
+  GSDF_CHECK_LAUNCH("visible_flags_kernel");
+  visible_scan_kernel<<<1, 1024, 0, stream>>>(nblk, counts, count);
+  GSDF_CHECK_LAUNCH("visible_scan_kernel");
+  visible_write_kernel<<<nblk, 256, 0, stream>>>(n, flags, counts, ids);
+  GSDF_CHECK_LAUNCH("visible_write_kernel");
   return GSDF_OK;
 }
 

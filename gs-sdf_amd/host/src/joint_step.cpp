@@ -249,15 +249,19 @@ std::map<std::string, int64_t> JointIteration::step(const Tensor &viewmat, const
     return loss;
   };
   // ---- GS <-> SDF coupling (:420-462) at the visible, occupancy-valid splats' samples
-  Tensor visd = vis.detach();
-  Tensor w_all = (samples_weights * visd).detach();
-  Tensor valid = torch::empty({samples.size(0)}, samples.options().dtype(torch::kBool));
+  // visibility > k_visible_thr, get_valid_mask(samples), samples_weights * visibilities, nonzero: three launches + one size read-back
+  Tensor visd = f32c(vis.detach(), "visibilities");
+  Tensor w_all = torch::empty({samples.size(0), 1}, samples.options().requires_grad(false));
+  Tensor ids_all = torch::empty({samples.size(0)}, samples.options().dtype(torch::kInt64).requires_grad(false));
+  Tensor n_ids = torch::empty({1}, ids_all.options());
   {
-    Tensor sd = f32c(samples.detach(), "samples");
-    check(gsdf_occ_query_world(occ_level_, -1, sd.size(0), fp(sd), origin_.data(), (float)map_size_inv_, occ_grid_.data_ptr(),
-                               (uint8_t *)valid.data_ptr(), cur_stream()), "occ_query_world");
+    Tensor sd = f32c(samples.detach(), "samples"), swd = f32c(samples_weights.detach(), "samples_weights");
+    Tensor vws = torch::empty({(int64_t)gsdf_visible_set_ws_bytes(sd.size(0))}, samples.options().dtype(torch::kUInt8).requires_grad(false));
+    check(gsdf_visible_set(occ_level_, -1, sd.size(0), fp(sd), origin_.data(), (float)map_size_inv_, occ_grid_.data_ptr(), fp(visd), fp(swd),
+                           (float)cfg_.vis_thresh, fpm(w_all), ids_all.data_ptr<int64_t>(), n_ids.data_ptr<int64_t>(), vws.data_ptr(), cur_stream()),
+          "visible_set");
   }
-  Tensor ids = (valid & (visd > cfg_.vis_thresh).squeeze(-1)).nonzero().squeeze(-1);
+  Tensor ids = ids_all.narrow(0, 0, n_ids.item<int64_t>());
   const bool has = ids.numel() > 0;
   // the SDF work that depends on the render: numerical configuration = the coupling node; analytic (default) configuration = the
   // WHOLE SDF batch of the iteration (per-ray points + splat samples) in one node

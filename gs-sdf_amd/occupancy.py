@@ -87,6 +87,24 @@ class OctreeAS:
                                                    ptr(mask), capi.stream()), "occ_query_world")
         return mask
 
+    def visible_set(self, samples_world, visibilities, samples_weights, vis_thresh, origin, map_size_inv, level=-1):
+        """The visible, occupancy-valid splat samples of the joint iteration (neural_mapping.cpp:423-437) in three launches and one
+        size read-back: -> (ids int64 [n_valid] increasing = nonzero(get_valid_mask(samples) & (visibilities > thr)),
+        w_all [M] = samples_weights * visibilities)."""
+        import ctypes as C
+        xyz = samples_world.detach().contiguous().float()
+        n = xyz.shape[0]
+        vis, sw = visibilities.detach().reshape(-1).contiguous().float(), samples_weights.detach().reshape(-1).contiguous().float()
+        w_all = torch.empty(n, device=xyz.device)
+        ids = torch.empty(n, dtype=torch.int64, device=xyz.device)
+        count = torch.empty(1, dtype=torch.int64, device=xyz.device)
+        L = capi.lib()
+        ws = torch.empty(L.gsdf_visible_set_ws_bytes(n), dtype=torch.uint8, device=xyz.device)
+        capi.check(L.gsdf_visible_set(self.level, -1 if level is None else int(level), n, f32(xyz), (C.c_float * 3)(*origin), float(map_size_inv),
+                                      ptr(self.grid), f32(vis), f32(sw), float(vis_thresh), f32(w_all), ptr(ids), ptr(count), ptr(ws),
+                                      capi.stream()), "visible_set")
+        return ids[:int(count.item())], w_all
+
     def get_quantized_points(self):
         """-> int16 [V,3] occupied finest-level voxels (x-fastest linear order)."""
         L = capi.lib()

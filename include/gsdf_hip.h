@@ -375,6 +375,14 @@ int gsdf_occ_query(int level, int query_level, int64_t n, const float *xyz_m1p1,
 /* query with the SubMap::xyz_to_m1p1_pts transform ((x - origin) * 2) * map_size_inv folded in (origin_host: 3 HOST floats) */
 int gsdf_occ_query_world(int level, int query_level, int64_t n, const float *xyz_world, const float *origin_host,
                          float map_size_inv, const void *grid, uint8_t *mask, gsdf_stream_t stream);
+/* The visible, occupancy-valid splat samples of the joint iteration (neural_mapping.cpp:423-437: samples_weights * visibilities,
+ * get_valid_mask(samples) & (visibilities > k_visible_thr), nonzero) in three launches: w_all[i] = samples_weights[i] * visibilities[i]
+ * for every row; ids[0 .. *count) = the rows with visibilities > vis_thresh whose sample lies in an occupied voxel, in increasing order;
+ * *count (device int64) = their number.  ids has room for n entries.  ws: gsdf_visible_set_ws_bytes(n). */
+size_t gsdf_visible_set_ws_bytes(int64_t n);
+int gsdf_visible_set(int level, int query_level, int64_t n, const float *xyz_world, const float *origin_host, float map_size_inv,
+                     const void *grid, const float *visibilities, const float *samples_weights, float vis_thresh, float *w_all,
+                     int64_t *ids, int64_t *count, void *ws, gsdf_stream_t stream);
 int gsdf_occ_voxel_counts(int level, const void *grid, int32_t *word_counts, gsdf_stream_t stream);
 int gsdf_occ_voxel_list(int level, const void *grid, const int64_t *word_offsets, int16_t *voxels, gsdf_stream_t stream);
 int gsdf_occ_raymarch_count(int level, int64_t n_rays, const float *origins_m1p1, const float *dirs, const void *grid,

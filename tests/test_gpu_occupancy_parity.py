@@ -147,3 +147,33 @@ def test_as_occ_prior_ply_round_trip(tmp_path):
     xyz = read_points_ply(path, dev)["xyz"]
     assert xyz.shape[0] == int(lm.acc_struct_occ.get_quantized_points().shape[0])
     assert bool(lm.get_valid_mask(xyz + 0.5 * 0.0625).all())
+
+
+@pytest.mark.parametrize("n", [0, 1, 1023, 1024, 1025, 70_001, 1_300_000])
+def test_visible_set_equals_the_reference_composition(n):
+    """gsdf_visible_set == (samples_weights * visibilities, nonzero(get_valid_mask(samples) & (visibilities > thr))) of
+    neural_mapping.cpp:423-437, bit for bit (ids in increasing order), against the oracle's occupancy query."""
+    from gs_sdf_amd.occupancy import OctreeAS
+    L, origin, inv = 7, [0.5, -0.25, 2.0], 1.0 / 12.0
+    pts = _scene(L, 20000, 5)
+    acc = OctreeAS.from_points(torch.from_numpy(pts).to(dev), L, dilate27=True)
+    g = torch.Generator().manual_seed(n)
+    m1p1 = torch.rand(n, 3, generator=g) * 2.4 - 1.2
+    world = (m1p1 / (2 * inv) + torch.tensor(origin)).to(dev)
+    vis = torch.rand(n, 1, generator=g).to(dev)
+    vis[::7] = 0.1                                                   # exactly at the threshold: not visible (strict >)
+    sw = torch.rand(n, 1, generator=g).to(dev)
+    ids, w_all = acc.visible_set(world, vis, sw, 0.1, origin, inv)
+    assert torch.equal(w_all, (sw * vis).reshape(-1))
+    mask = acc.query_world_mask(world, origin, inv) & (vis > 0.1).squeeze(-1)
+    want = mask.nonzero().squeeze(-1)
+    assert ids.dtype == torch.int64 and torch.equal(ids, want)
+    if n:
+        ref = orc.occ_query(L, acc.grid.cpu().numpy().view(np.uint32), acc_m1p1(world, origin, inv).cpu().numpy(), -1).astype(bool)
+        assert np.array_equal(acc.query_world_mask(world, origin, inv).cpu().numpy(), ref)
+        if n > 1000:
+            assert 0 < ids.numel() < n
+
+
+def acc_m1p1(world, origin, inv):
+    return ((world - torch.tensor(origin, device=world.device)) * 2.0) * inv
