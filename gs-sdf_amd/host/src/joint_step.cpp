@@ -186,6 +186,7 @@ std::map<std::string, int64_t> JointIteration::step(const Tensor &viewmat, const
     // ordered before the second stream's work
     streams_->entry.record(main_stream);
     streams_->entry.block(streams_->side);
+    streams_->gate.armed = false;   // (a step whose coupling saw no samples leaves its gate unconsumed)
   }
   const int64_t N = anchors_.size(0);
   const int64_t nt = n_table_, nd = n_dec_, nb = n_bias_;
