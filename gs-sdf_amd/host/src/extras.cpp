@@ -294,11 +294,6 @@ struct AnalyticFn : public torch::autograd::Function<AnalyticFn> {
     Tensor ws = empty_like_opts(feat, {(int64_t)gsdf_mlp_bwd_ws_bytes_for(n, nl, dims.data(), 1)}, torch::kUInt8);
     check(gsdf_mlp_bwd(n, nl, dims.data(), fp(W), fp(bias), fp(feat), fp(acts), fp(v_out), fpm(v_feat), fpm(decoder_grad),
                        bias.defined() ? fpm(bias_grad) : nullptr, ws.data_ptr(), cur_stream()), "mlp_bwd");
-    // second order: the regularisers reach the decoder weights through g0 = W_0^T D_0 ... e_0
-    Tensor vv_in = (u0 * g[0]).contiguous(), g_vout = torch::empty_like(e0);
-    Tensor ws2 = empty_like_opts(feat, {(int64_t)gsdf_mlp_bwd_bwd_ws_bytes(n, nl)}, torch::kUInt8);
-    check(gsdf_mlp_bwd_bwd(n, nl, dims.data(), fp(W), fp(acts), fp(e0), bws.data_ptr(), fp(vv_in), fpm(g_vout), fpm(decoder_grad), ws2.data_ptr(),
-                           cur_stream()), "mlp_bwd_bwd");
     if (ctx->needs_input_grad(2) && n > n_ray) {   // d (data term) / d samples from the Jacobian of the splat rows
       const int64_t ng = n - n_ray;
       Tensor v_x = empty_like_opts(feat, {ng, 3}, torch::kFloat32);
@@ -309,6 +304,12 @@ struct AnalyticFn : public torch::autograd::Function<AnalyticFn> {
       out[2] = v_samples;
     }
     if (auto *gate = reinterpret_cast<gsdf_extras::StreamGate *>(ctx->saved_data["gate"].toInt())) gate->record_here();
+    // second order: the regularisers reach the decoder weights through g0 = W_0^T D_0 ... e_0 (nobody waits for it but the optimizer:
+    // issued after the samples' gradient, which the splat leg's backward is waiting for)
+    Tensor vv_in = (u0 * g[0]).contiguous(), g_vout = torch::empty_like(e0);
+    Tensor ws2 = empty_like_opts(feat, {(int64_t)gsdf_mlp_bwd_bwd_ws_bytes(n, nl)}, torch::kUInt8);
+    check(gsdf_mlp_bwd_bwd(n, nl, dims.data(), fp(W), fp(acts), fp(e0), bws.data_ptr(), fp(vv_in), fpm(g_vout), fpm(decoder_grad), ws2.data_ptr(),
+                           cur_stream()), "mlp_bwd_bwd");
     // table: first-order (v_feat) and second-order (g0, vv_x) contributions of every corner in ONE scatter
     Tensor vvx = (vv_x * g[0]).contiguous();
     const size_t nb = n >= 24576 ? gsdf_hashgrid_bwd_binned_ws_bytes(n, L, F, H, R, S) : 0;

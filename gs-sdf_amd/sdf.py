@@ -701,12 +701,6 @@ class _SdfBatchAnalytic(torch.autograd.Function):
         ws = torch.empty(L.gsdf_mlp_bwd_ws_bytes_for(n, nl, dims_c, 1), dtype=torch.uint8, device=dev)
         capi.check(_timed("mlp_bwd", L.gsdf_mlp_bwd, n, nl, dims_c, f32(dec.params_), f32(dec.biases_), f32(fb), f32(acts), f32(v_out),
                           f32(v_feat), f32(w_sink), f32(b_sink), ptr(ws) if ws.numel() else None, capi.stream()), "mlp_bwd")
-        # second order: the regularisers reach the decoder weights through g0 = W_0^T D_0 ... e_0
-        vv_in = (u0 * v_loss).contiguous()
-        g_vout = torch.empty_like(e0)
-        ws2 = torch.empty(L.gsdf_mlp_bwd_bwd_ws_bytes(n, nl), dtype=torch.uint8, device=dev)
-        capi.check(_timed("mlp_bwd_bwd", L.gsdf_mlp_bwd_bwd, n, nl, dims_c, f32(dec.params_), f32(acts), f32(e0), ptr(bws), f32(vv_in),
-                          f32(g_vout), f32(w_sink), ptr(ws2), capi.stream()), "mlp_bwd_bwd")
         v_samples = None
         if want_x:   # d (data term) / d samples from the Jacobian of the splat rows (the regularisers see samples.detach())
             ng = n - n_ray
@@ -718,6 +712,13 @@ class _SdfBatchAnalytic(torch.autograd.Function):
                 v_samples.copy_(v_x * float(lm.map_size_inv))
             else:
                 v_samples.index_add_(0, ids, v_x * float(lm.map_size_inv))
+        # second order: the regularisers reach the decoder weights through g0 = W_0^T D_0 ... e_0 (only the optimizer waits for it:
+        # issued after the samples' gradient)
+        vv_in = (u0 * v_loss).contiguous()
+        g_vout = torch.empty_like(e0)
+        ws2 = torch.empty(L.gsdf_mlp_bwd_bwd_ws_bytes(n, nl), dtype=torch.uint8, device=dev)
+        capi.check(_timed("mlp_bwd_bwd", L.gsdf_mlp_bwd_bwd, n, nl, dims_c, f32(dec.params_), f32(acts), f32(e0), ptr(bws), f32(vv_in),
+                          f32(g_vout), f32(w_sink), ptr(ws2), capi.stream()), "mlp_bwd_bwd")
         # table: first-order (v_feat) and second-order (g0, vv_x) contributions of every corner in ONE scatter
         table = enc.params_.view(-1, cfg[1])
         sink = enc.grad_sink.view(table.shape)
