@@ -303,7 +303,15 @@ std::map<std::string, int64_t> JointIteration::step(const Tensor &viewmat, const
     Tensor gs = samples_cut.grad();
     if (gs.defined()) {
       gs.record_stream(main_stream);
-      samples.backward(gs);   // JoinGrad (created with the samples) makes the caller's stream wait for the gate first
+      if (cfg_.center_reg && views_[0].grad().defined()) {
+        // samples = (anchors + offsets)[gaussian_ids]: their gradient is a row scatter into the offsets' gradient — one launch instead of
+        // the ~12 of walking JoinGrad -> index_select -> the activation node a second time
+        torch::NoGradGuard ng;
+        if (streams_->gate.armed) { streams_->gate.event.block(main_stream); streams_->gate.armed = false; }
+        views_[0].mutable_grad().index_add_(0, gaussian_ids, gs);
+      } else {
+        samples.backward(gs);   // JoinGrad (created with the samples) makes the caller's stream wait for the gate first
+      }
     }
   } else if (sdf_work) {
     Tensor loss = splat_loss();
