@@ -173,6 +173,9 @@ class JointIteration {
   torch::Tensor sdf_flat() { sync(); return sdf_flat_; }
   torch::Tensor sdf_flat_grad() { sync(); return sdf_flat_grad_; }
   torch::Tensor nan_splats_seen() const { return nan_total_; }   // int32 device scalar: sum of the per-iteration prune_nan counts
+  // {photometric 0.8 L1 + 0.2 D-SSIM sums (2 floats: sum |I - G|, sum SSIM), normal-consistency loss, isotropic loss} of the last step of
+  // the direct splat leg (device tensors; empty before the first such step)
+  std::vector<torch::Tensor> last_losses() const { return last_losses_; }
 
  private:
   JointConfig cfg_;
@@ -189,6 +192,12 @@ class JointIteration {
   FusedAdam adam_, adam_sdf_;
   std::unique_ptr<JointStreams> streams_;
   std::function<void(torch::Tensor)> splat_hook_, sdf_hook_;
+  // the splat leg without the autograd engine (step_direct): loss weights as device scalars, a never-written zero image, scratch
+  torch::Tensor w_one_, w_normal_, w_iso_, zero_image_, scratch_;
+  std::vector<torch::Tensor> last_losses_;
+  bool direct_ok(const torch::Tensor &viewmat) const;
+  std::map<std::string, int64_t> step_direct(const torch::Tensor &viewmat, const torch::Tensor &K, const torch::Tensor &target,
+                                             const torch::Tensor &ray_pts, const torch::Tensor &ray_sdf, bool update, const std::vector<float> &cam_host);
 };
 
 }  // namespace gsdf_extras

@@ -172,6 +172,7 @@ void JointIteration::sync() {
 std::map<std::string, int64_t> JointIteration::step(const Tensor &viewmat, const Tensor &K, const Tensor &target, const Tensor &ray_pts,
                                                     const Tensor &ray_sdf, const std::vector<Tensor> &upstream, bool update,
                                                     const std::vector<float> &cam_host) {
+  if (direct_ok(viewmat)) return step_direct(viewmat, K, target, ray_pts, ray_sdf, update, cam_host);
   const int W = cfg_.width, H = cfg_.height;
   std::map<std::string, int64_t> sizes;
   // Two legs on two HIP streams (cfg.two_streams; the schedule of bench.py's overlapped step): the SDF network's work — ray batch,
@@ -362,6 +363,216 @@ std::map<std::string, int64_t> JointIteration::step(const Tensor &viewmat, const
   }
   sizes["M"] = gaussian_ids.size(0);
   sizes["I"] = std::get<1>(enc).size(0);
+  sizes["n_gs_sdf"] = ids.numel();
+  return sizes;
+}
+
+// ---- the splat leg without the autograd engine ----------------------------------------------------------------------------------
+// Same operators, same order of arithmetic as the autograd composition above (tests/test_gpu_bench_step.py compares the flat
+// gradients with the Python step's); what goes away is libtorch's glue around them.  In the autograd step the ~0.3 ms of work between
+// the compositing backward and the next render took 1.2 ms on the splat leg's stream: 13 AccumulateGrad adds, ~30 zero fills, the
+// gather / scatter nodes of index_select and cat, each a 5 us kernel that waits 30-100 us for a CU beside the SDF leg's kernels.
+// Here every backward kernel accumulates straight into its segment of the flat gradient buffer (they all += into dense outputs):
+//   xyz   <- projection backward + view-colour backward + the samples' gradient          -> offsets' segment (d xyz / d offsets = 1)
+//   quats <- projection backward                                                         -> quaternion's segment
+//   scales (activated) <- projection backward + isotropic backward -> scratch [N,3]     -> x scale (exp') -> scaling's segment
+//   opacities (per visible splat) -> scratch [N] -> x o (1 - o)                          -> opacity's segment
+//   SH coefficients <- view-colour backward                                              -> features_dc's segment (degree 0)
+bool JointIteration::direct_ok(const Tensor &viewmat) const {
+  static const bool off = [] { const char *e = getenv("GSDF_JOINT_DIRECT"); return e && e[0] == '0'; }();
+  return !off && cfg_.two_streams && cfg_.analytic && cfg_.center_reg && cfg_.reference_terms && viewmat.size(0) == 1 && !splat_hook_ && !sdf_hook_;
+}
+
+namespace {
+const float *ssim_window11() {   // the reference's gaussian(): NOT the symmetric Gaussian (loss_utils.cpp:6-14), as extras.cpp
+  static float w[11];
+  static const bool init = [] {
+    double s = 0, g[11];
+    for (int x = 0; x < 11; ++x) { g[x] = std::exp(-std::pow(std::floor((x - 11) / 2.0), 2) / (2.0 * 1.5 * 1.5)); s += g[x]; }
+    for (int x = 0; x < 11; ++x) w[x] = (float)(g[x] / s);
+    return true;
+  }();
+  (void)init;
+  return w;
+}
+}  // namespace
+
+std::map<std::string, int64_t> JointIteration::step_direct(const Tensor &viewmat_, const Tensor &K_, const Tensor &target_, const Tensor &ray_pts,
+                                                           const Tensor &ray_sdf, bool update, const std::vector<float> &cam_host) {
+  using StreamGuard = c10::hip::HIPStreamGuardMasqueradingAsCUDA;
+  torch::NoGradGuard no_grad;
+  const int W = cfg_.width, H = cfg_.height;
+  std::map<std::string, int64_t> sizes;
+  auto main_stream = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA();
+  if (!streams_) streams_ = std::make_unique<JointStreams>();
+  streams_->entry.record(main_stream);
+  streams_->entry.block(streams_->side);
+  streams_->gate.armed = false;
+  const int64_t N = anchors_.size(0);
+  const auto fopt = anchors_.options().requires_grad(false);
+  if (!w_one_.defined()) {
+    w_one_ = torch::ones({1}, fopt);
+    w_normal_ = torch::full({1}, cfg_.normal_w, fopt);
+    w_iso_ = torch::full({1}, cfg_.isotropic_w, fopt);
+    zero_image_ = torch::zeros({1, H, W, 1}, fopt);
+  }
+  if (!scratch_.defined() || scratch_.numel() != 4 * N) scratch_ = torch::empty({4 * N}, fopt);
+  Tensor viewmat = f32c(viewmat_.detach(), "viewmat"), K = f32c(K_.detach(), "K"), target = f32c(target_.detach(), "target");
+  const int64_t nt = n_table_, nd = n_dec_, nb = n_bias_;
+  Tensor tg = sdf_flat_grad_.slice(0, 0, nt), dg = sdf_flat_grad_.slice(0, nt, nt + nd);
+  Tensor bg = nb ? sdf_flat_grad_.slice(0, nt + nd, nt + nd + nb) : Tensor();
+  auto seg = [&](int k) { return views_[k].grad(); };   // the field's segment of the flat gradient buffer
+  // ---- forward: activations, projection (one size read-back), colours, binning (one read-back), compositing, epilogue
+  Tensor xyz = torch::empty({N, 3}, fopt), scales = torch::empty({N, 3}, fopt), opac = torch::empty({N}, fopt);
+  check(gsdf_splat_activations_fwd(N, fp(anchors_), fp(views_[0]), fp(views_[1]), fp(views_[3]), fpm(xyz), fpm(scales), fpm(opac), cur_stream()),
+        "splat_activations_fwd");
+  const int64_t Ksh = 1 + n_rest_;
+  Tensor sh = n_rest_ == 0 ? views_[4].detach().reshape({N, 1, 3}) : torch::cat({views_[4].detach().reshape({N, 1, 3}), views_[5].detach().reshape({N, n_rest_, 3})}, 1);
+  Tensor quats = views_[2].detach();
+  Tensor radii_dense = torch::empty({std::max<int64_t>(N, 1)}, fopt.dtype(torch::kInt32));
+  Tensor pws = torch::empty({(int64_t)gsdf_projection_2dgs_ws_bytes(N, 1)}, fopt.dtype(torch::kUInt8));
+  Tensor n_vis = torch::empty({1}, fopt.dtype(torch::kInt64));
+  check(gsdf_projection_2dgs_cull(N, 1, fp(xyz), fp(quats), fp(scales), fp(viewmat), fp(K), W, H, cfg_.near_plane, cfg_.far_plane, 0.f,
+                                  radii_dense.data_ptr<int32_t>(), pws.data_ptr(), n_vis.data_ptr<int64_t>(), cur_stream()), "projection(cull)");
+  const int64_t M = read_i64(n_vis);
+  Tensor camera_ids = torch::empty({M}, fopt.dtype(torch::kInt64)), gaussian_ids = torch::empty({M}, fopt.dtype(torch::kInt64));
+  Tensor radii = torch::empty({M}, fopt.dtype(torch::kInt32)), means2d = torch::empty({M, 2}, fopt), depths = torch::empty({M}, fopt);
+  Tensor rt = torch::empty({M, 3, 3}, fopt), normals = torch::empty({M, 3}, fopt), smp = torch::empty({M, 3}, fopt), sw = torch::empty({M, 1}, fopt);
+  check(gsdf_projection_2dgs_fill(N, 1, fp(xyz), fp(quats), fp(scales), fp(viewmat), fp(K), W, H, (uint64_t)0, radii_dense.data_ptr<int32_t>(),
+                                  pws.data_ptr(), M, M ? camera_ids.data_ptr<int64_t>() : nullptr, M ? gaussian_ids.data_ptr<int64_t>() : nullptr,
+                                  M ? radii.data_ptr<int32_t>() : nullptr, fpm(means2d), fpm(depths), fpm(rt), fpm(normals), fpm(smp), fpm(sw),
+                                  cur_stream()), "projection(fill)");
+  // k_center_reg: the SDF samples are the splat centres, weight 1 (neural_gaussian.cpp:259-262)
+  Tensor samples = xyz.index_select(0, gaussian_ids), samples_weights = torch::ones({M, 1}, fopt);
+  Tensor pt_opac = opac.index_select(0, gaussian_ids);
+  Tensor colors = torch::empty({M, 3}, fopt);
+  check(gsdf_view_colors_fwd(M, Ksh, cfg_.sh_degree, fp(viewmat), fp(xyz), fp(sh), M ? camera_ids.data_ptr<int64_t>() : nullptr,
+                             M ? gaussian_ids.data_ptr<int64_t>() : nullptr, fpm(colors), cur_stream()), "view_colors_fwd");
+  auto enc = gsplat_cpp::tile_encode(W, H, 16, means2d, radii, depths, true, 1, camera_ids, gaussian_ids);
+  Tensor flat = std::get<1>(enc).contiguous(), offs = std::get<2>(enc).contiguous();
+  const int64_t I = flat.size(0);
+  auto img = [&](int64_t ch) { return torch::empty({1, H, W, ch}, fopt); };
+  Tensor rc = img(3), rd = img(1), ra = img(1), rn = img(3), rm = img(1), vis = torch::empty({M, 1}, fopt), fT = torch::empty({1, H, W}, fopt);
+  Tensor last = torch::empty({1, H, W}, fopt.dtype(torch::kInt32)), med = torch::empty({1, H, W}, fopt.dtype(torch::kInt32));
+  check(gsdf_rasterize_2dgs_fwd(1, M, I, W, H, 16, fp(means2d), fp(rt), fp(colors), fp(pt_opac), fp(normals), nullptr, nullptr, offs.data_ptr<int32_t>(),
+                                I ? flat.data_ptr<int32_t>() : nullptr, fpm(rc), fpm(rd), fpm(ra), fpm(rn), fpm(rm), last.data_ptr<int32_t>(),
+                                med.data_ptr<int32_t>(), fpm(vis), fpm(fT), cur_stream()), "rasterize_fwd");
+  Tensor renders = img(4), nw = img(3), c3 = img(3), d1 = img(1);
+  const int64_t P = (int64_t)H * W;
+  check(gsdf_render_post_fwd(P, 1, fp(viewmat), fp(rc), fp(rd), fp(ra), fp(rn), fpm(renders), fpm(nw), fpm(c3), fpm(d1), cur_stream()), "render_post_fwd");
+  // ---- the visible, occupancy-valid samples (one size read-back), then the SDF leg's forward on the second stream
+  Tensor w_all = torch::empty({M, 1}, fopt), ids_all = torch::empty({M}, fopt.dtype(torch::kInt64)), n_ids = torch::empty({1}, fopt.dtype(torch::kInt64));
+  {
+    Tensor vws = torch::empty({(int64_t)gsdf_visible_set_ws_bytes(M)}, fopt.dtype(torch::kUInt8));
+    check(gsdf_visible_set(occ_level_, -1, M, fp(samples), origin_.data(), (float)map_size_inv_, occ_grid_.data_ptr(), fp(vis), fp(samples_weights),
+                           (float)cfg_.vis_thresh, fpm(w_all), ids_all.data_ptr<int64_t>(), n_ids.data_ptr<int64_t>(), vws.data_ptr(), cur_stream()),
+          "visible_set");
+  }
+  Tensor ids = ids_all.narrow(0, 0, n_ids.item<int64_t>());
+  const bool has = ids.numel() > 0;
+  streams_->fwd_done.record(main_stream);
+  streams_->fwd_done.block(streams_->side);
+  Tensor samples_cut = samples.detach().requires_grad_(true);
+  for (const Tensor &t : {samples_cut, w_all, ids, ray_pts, ray_sdf}) t.record_stream(streams_->side);
+  Tensor sdf_loss;
+  {
+    StreamGuard sg(streams_->side);
+    torch::AutoGradMode grad_on(true);
+    sdf_loss = joint_sdf_loss_analytic(ray_pts, ray_sdf, has ? samples_cut : Tensor(), has ? ids : Tensor(), has ? w_all : Tensor(), *enc_, *dec_, origin_,
+                                       map_size_inv_, bce_isigma_, cfg_.sdf_w, cfg_.gs_sdf_w, cfg_.sdf_delta, cfg_.eik_w, cfg_.align_w, tg, dg, bg,
+                                       &streams_->gate);
+  }
+  // ---- the splat leg's losses (values kept for the caller) and their gradients
+  std::vector<float> intr, pose;
+  if (cam_host.size() >= 16) {
+    intr.assign(cam_host.begin(), cam_host.begin() + 4);
+    pose.assign(cam_host.begin() + 4, cam_host.begin() + 16);
+  } else {   // read the camera back (one device->host copy)
+    Tensor Kc = K[0].to(torch::kCPU), c2w = torch::linalg_inv(viewmat[0].to(torch::kCPU).to(torch::kFloat64)).to(torch::kFloat32).contiguous();
+    intr = {Kc[0][0].item<float>(), Kc[1][1].item<float>(), Kc[0][2].item<float>(), Kc[1][2].item<float>()};
+    pose.assign(c2w.data_ptr<float>(), c2w.data_ptr<float>() + 12);
+  }
+  Tensor sums = torch::empty({2}, fopt), maps = torch::empty({3, H, W, 3}, fopt), l_normal = torch::empty({1}, fopt), l_iso = torch::empty({}, fopt);
+  check(gsdf_l1_dssim_fwd(H, W, fp(c3), fp(target), ssim_window11(), fpm(sums), fpm(maps), cur_stream()), "l1_dssim_fwd");
+  check(gsdf_normal_consistency_fwd(H, W, intr.data(), pose.data(), fp(d1), fp(ra), fp(nw), fpm(l_normal), cur_stream()), "normal_consistency_fwd");
+  check(gsdf_isotropic_loss_fwd(M, fp(scales), M ? gaussian_ids.data_ptr<int64_t>() : nullptr, fpm(l_iso), cur_stream()), "isotropic_loss_fwd");
+  last_losses_ = {sums, l_normal, l_iso};
+  Tensor v_c3 = img(3), v_d1 = img(1), v_nw = img(3);
+  check(gsdf_l1_dssim_bwd(H, W, fp(c3), fp(target), ssim_window11(), fp(maps), fp(w_one_), (float)cfg_.rgb_w, (float)cfg_.dssim_w, fpm(v_c3), cur_stream()),
+        "l1_dssim_bwd");
+  check(gsdf_normal_consistency_bwd(H, W, intr.data(), pose.data(), fp(d1), fp(ra), fp(nw), fp(w_normal_), fpm(v_d1), fpm(v_nw), cur_stream()),
+        "normal_consistency_bwd");
+  scratch_.zero_();
+  Tensor v_scales_act = scratch_.narrow(0, 0, 3 * N).view({N, 3}), v_opac_dense = scratch_.narrow(0, 3 * N, N);
+  check(gsdf_isotropic_loss_bwd(M, fp(scales), M ? gaussian_ids.data_ptr<int64_t>() : nullptr, fp(w_iso_), fpm(v_scales_act), cur_stream()),
+        "isotropic_loss_bwd");
+  // ---- backward through the epilogue, the compositing, the colours and the projection
+  Tensor v_rc = img(3), v_rd = img(1), v_ra = img(1), v_rn = img(3);
+  check(gsdf_render_post_bwd(P, 1, fp(viewmat), fp(rd), fp(ra), nullptr, fp(v_nw), fp(v_c3), fp(v_d1), fpm(v_rc), fpm(v_rd), fpm(v_ra), fpm(v_rn), cur_stream()),
+        "render_post_bwd");
+  Tensor v_means2d = torch::empty({M, 2}, fopt), v_rt = torch::empty({M, 3, 3}, fopt), v_colors = torch::empty({M, 3}, fopt), v_opac = torch::empty({M}, fopt);
+  Tensor v_normals = torch::empty({M, 3}, fopt), v_dens = torch::empty({M, 2}, fopt);
+  Tensor rws = torch::empty({(int64_t)gsdf_rasterize_2dgs_bwd_ws_bytes(M)}, fopt.dtype(torch::kUInt8));
+  check(gsdf_rasterize_2dgs_bwd(1, M, I, W, H, 16, fp(means2d), fp(rt), fp(colors), fp(pt_opac), fp(normals), nullptr, nullptr, offs.data_ptr<int32_t>(),
+                                I ? flat.data_ptr<int32_t>() : nullptr, fp(ra), last.data_ptr<int32_t>(), med.data_ptr<int32_t>(), fp(v_rc), fp(v_rd), fp(v_ra),
+                                fp(v_rn), fp(zero_image_), fpm(v_means2d), fpm(v_rt), fpm(v_colors), fpm(v_opac), fpm(v_normals), fpm(v_dens), nullptr,
+                                rws.data_ptr(), fp(fT), cur_stream()), "rasterize_bwd");
+  // train_callback -> update_state (neural_gaussian.cpp:626-680): needs the densify gradient only
+  update_state(state_, v_dens, gaussian_ids, vis, radii, N, 1, W, H, false);
+  Tensor v_sh_tmp;
+  float *v_sh_ptr;
+  if (n_rest_ == 0) {
+    Tensor s4 = seg(4);
+    v_sh_ptr = s4.data_ptr<float>();
+  } else {
+    v_sh_tmp = torch::zeros({N, Ksh, 3}, fopt);
+    v_sh_ptr = v_sh_tmp.data_ptr<float>();
+  }
+  Tensor g_off = seg(0), g_sc = seg(1), g_q = seg(2), g_op = seg(3);
+  check(gsdf_view_colors_bwd(M, Ksh, cfg_.sh_degree, fp(viewmat), fp(xyz), fp(sh), M ? camera_ids.data_ptr<int64_t>() : nullptr,
+                             M ? gaussian_ids.data_ptr<int64_t>() : nullptr, fp(v_colors), v_sh_ptr, fpm(g_off), 1, cur_stream()), "view_colors_bwd");
+  Tensor v_depths = torch::zeros({M}, fopt);
+  check(gsdf_projection_2dgs_bwd(N, 1, M, fp(xyz), fp(quats), fp(scales), fp(viewmat), fp(K), W, H, (uint64_t)0, M ? camera_ids.data_ptr<int64_t>() : nullptr,
+                                 M ? gaussian_ids.data_ptr<int64_t>() : nullptr, fp(v_means2d), fp(v_depths), fp(v_rt), fp(v_normals), nullptr, fpm(g_off),
+                                 fpm(g_q), fpm(v_scales_act), cur_stream()), "projection_bwd");
+  v_opac_dense.index_add_(0, gaussian_ids, v_opac);
+  check(gsdf_splat_activations_bwd(N, fp(scales), fp(opac), nullptr /* xyz: accumulated in place above */, fp(v_scales_act), fp(v_opac_dense), fpm(g_off),
+                                   fpm(g_sc), fpm(g_op), cur_stream()),
+        "splat_activations_bwd");
+  if (n_rest_ != 0) {
+    seg(4).view({N, 1, 3}).add_(v_sh_tmp.narrow(1, 0, 1));
+    seg(5).view({N, n_rest_, 3}).add_(v_sh_tmp.narrow(1, 1, n_rest_));
+  }
+  // ---- the SDF leg's backward on the second stream; its d loss / d samples is a row scatter into the offsets' gradient
+  {
+    StreamGuard sg(streams_->side);
+    torch::AutoGradMode grad_on(true);
+    sdf_loss.backward();
+    if (!streams_->gate.armed) streams_->gate.record_here();
+  }
+  Tensor gs = samples_cut.grad();
+  if (gs.defined()) {
+    gs.record_stream(main_stream);
+    if (streams_->gate.armed) { streams_->gate.event.block(main_stream); streams_->gate.armed = false; }
+    g_off.index_add_(0, gaussian_ids, gs);
+  }
+  // ---- optimizers, each family on its leg's stream
+  if (update) {
+    adam_.step();
+    flat_grad_.zero_();
+    nan_total_.add_(nan_rows(views_[0], views_[1], views_[2]));   // prune_nan_gs's test, no host sync
+  }
+  {
+    StreamGuard sg(streams_->side);
+    if (update) {
+      adam_sdf_.step();
+      sdf_flat_grad_.zero_();
+    }
+  }
+  streams_->side_done.record(streams_->side);
+  streams_->side_pending = true;
+  sizes["M"] = M;
+  sizes["I"] = I;
   sizes["n_gs_sdf"] = ids.numel();
   return sizes;
 }
