@@ -380,7 +380,7 @@ std::map<std::string, int64_t> JointIteration::step(const Tensor &viewmat, const
 //   SH coefficients <- view-colour backward                                              -> features_dc's segment (degree 0)
 bool JointIteration::direct_ok(const Tensor &viewmat) const {
   static const bool off = [] { const char *e = getenv("GSDF_JOINT_DIRECT"); return e && e[0] == '0'; }();
-  return !off && cfg_.two_streams && cfg_.analytic && cfg_.center_reg && cfg_.reference_terms && viewmat.size(0) == 1 && !splat_hook_ && !sdf_hook_;
+  return !off && cfg_.two_streams && cfg_.analytic && cfg_.center_reg && cfg_.reference_terms && viewmat.size(0) == 1;
 }
 
 namespace {
@@ -556,7 +556,8 @@ std::map<std::string, int64_t> JointIteration::step_direct(const Tensor &viewmat
     if (streams_->gate.armed) { streams_->gate.event.block(main_stream); streams_->gate.armed = false; }
     g_off.index_add_(0, gaussian_ids, gs);
   }
-  // ---- optimizers, each family on its leg's stream
+  // ---- optimizers, each family on its leg's stream (view-parallel: the family's collective first, on the same stream)
+  if (splat_hook_) splat_hook_(flat_grad_);
   if (update) {
     adam_.step();
     flat_grad_.zero_();
@@ -564,6 +565,7 @@ std::map<std::string, int64_t> JointIteration::step_direct(const Tensor &viewmat
   }
   {
     StreamGuard sg(streams_->side);
+    if (sdf_hook_) sdf_hook_(sdf_flat_grad_);
     if (update) {
       adam_sdf_.step();
       sdf_flat_grad_.zero_();
