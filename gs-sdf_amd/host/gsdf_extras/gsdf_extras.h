@@ -62,6 +62,7 @@ torch::Tensor gs_sdf_coupling(const torch::Tensor &samples, const torch::Tensor 
 //   each set: + w_eik * eikonal_loss(ANALYTIC gradient, autograd::grad(create_graph = true), local_map.cpp:151-172; the splat samples
 //             detached, :448-451) + w_align * mean |analytic - numerical.detach()| (6 forward-only stencil rows, :126-134).
 // Either part may be empty (undefined tensor).  d loss / d samples is returned to autograd; the encoder's table gradient and the decoder's
+// unit_upstream: the caller promises to call backward() on the returned loss itself (upstream gradient exactly 1): three scaling launches go.
 // weight / bias gradients are ACCUMULATED IN PLACE into table_grad / decoder_grad / bias_grad (views of the flat gradient buffer):
 // one-pass decoder backward, decoder double backward (gsdf_mlp_bwd_bwd), ONE binned scatter carrying the first- and second-order
 // table gradient (gsdf_hashgrid_bwd_binned2).  dec may carry biases (config "bias": true = the torch decoder's topology).
@@ -69,7 +70,7 @@ torch::Tensor joint_sdf_loss_analytic(const torch::Tensor &ray_xyz, const torch:
                                       const torch::Tensor &ids, const torch::Tensor &weights, ::TCNNEncoding &enc, ::TCNNNetwork &dec,
                                       const std::vector<float> &map_origin, double map_size_inv, double bce_isigma, double w_sdf, double w_gs,
                                       double delta, double w_eik, double w_align, torch::Tensor table_grad, torch::Tensor decoder_grad,
-                                      torch::Tensor bias_grad, StreamGate *samples_grad_ready = nullptr);
+                                      torch::Tensor bias_grad, StreamGate *samples_grad_ready = nullptr, bool unit_upstream = false);
 
 // render_normal_weight's term (neural_mapping.cpp:243-266): mean(alpha^2 - nan_to_num((depth_to_normal(depth) * alpha) . render_normal)),
 // alpha detached.  depth [H,W,1], alpha [H,W,1], render_normal [H,W,3] (world); intrinsics {fx, fy, cx, cy} and the camera->world pose

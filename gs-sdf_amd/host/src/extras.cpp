@@ -213,7 +213,7 @@ struct AnalyticFn : public torch::autograd::Function<AnalyticFn> {
   static Tensor forward(AutogradContext *ctx, const Tensor &ray_xyz, const Tensor &gt_sdf, const Tensor &samples, const Tensor &ids_,
                         const Tensor &weights, const Tensor &table_, const Tensor &W_, const Tensor &bias_, Tensor table_grad, Tensor decoder_grad,
                         Tensor bias_grad, std::vector<int64_t> iv, std::vector<double> dv, int64_t gate_handle) {
-    // iv = {L, F, H, R, dims...}; dv = {S, origin x3, map_size_inv, bce_isigma, w_sdf, w_gs, delta, w_eik, w_align}
+    // iv = {L, F, H, R, dims...}; dv = {S, origin x3, map_size_inv, bce_isigma, w_sdf, w_gs, delta, w_eik, w_align, unit_upstream}
     const int L = (int)iv[0], F = (int)iv[1], H = (int)iv[2], R = (int)iv[3];
     const std::vector<int> dims(iv.begin() + 4, iv.end());
     const float S = (float)dv[0];
@@ -289,7 +289,10 @@ struct AnalyticFn : public torch::autograd::Function<AnalyticFn> {
     const int nf = L * F, nl = (int)dims.size() - 1;
     tensor_list out(14);
     if (n == 0) return out;
-    Tensor v_out = (v_attr * g[0]).contiguous(), v_feat = empty_like_opts(feat, {n, nf}, torch::kFloat32);
+    // unit_upstream: the caller backwards this node's output directly (gradient exactly 1): no scaling launches
+    const bool unit = dv.size() > 11 && dv[11] != 0.0;
+    auto scaled = [&](const Tensor &t) { return unit ? t : (t * g[0]).contiguous(); };
+    Tensor v_out = scaled(v_attr), v_feat = empty_like_opts(feat, {n, nf}, torch::kFloat32);
     // first order: data terms through the decoder (one pass: input + parameter gradients)
     Tensor ws = empty_like_opts(feat, {(int64_t)gsdf_mlp_bwd_ws_bytes_for(n, nl, dims.data(), 1)}, torch::kUInt8);
     check(gsdf_mlp_bwd(n, nl, dims.data(), fp(W), fp(bias), fp(feat), fp(acts), fp(v_out), fpm(v_feat), fpm(decoder_grad),
@@ -306,12 +309,12 @@ struct AnalyticFn : public torch::autograd::Function<AnalyticFn> {
     if (auto *gate = reinterpret_cast<gsdf_extras::StreamGate *>(ctx->saved_data["gate"].toInt())) gate->record_here();
     // second order: the regularisers reach the decoder weights through g0 = W_0^T D_0 ... e_0 (nobody waits for it but the optimizer:
     // issued after the samples' gradient, which the splat leg's backward is waiting for)
-    Tensor vv_in = (u0 * g[0]).contiguous(), g_vout = torch::empty_like(e0);
+    Tensor vv_in = scaled(u0), g_vout = torch::empty_like(e0);
     Tensor ws2 = empty_like_opts(feat, {(int64_t)gsdf_mlp_bwd_bwd_ws_bytes(n, nl)}, torch::kUInt8);
     check(gsdf_mlp_bwd_bwd(n, nl, dims.data(), fp(W), fp(acts), fp(e0), bws.data_ptr(), fp(vv_in), fpm(g_vout), fpm(decoder_grad), ws2.data_ptr(),
                            cur_stream()), "mlp_bwd_bwd");
     // table: first-order (v_feat) and second-order (g0, vv_x) contributions of every corner in ONE scatter
-    Tensor vvx = (vv_x * g[0]).contiguous();
+    Tensor vvx = scaled(vv_x);
     const size_t nb = n >= 24576 ? gsdf_hashgrid_bwd_binned_ws_bytes(n, L, F, H, R, S) : 0;
     if (nb > 0) {
       Tensor bws2 = empty_like_opts(feat, {(int64_t)nb}, torch::kUInt8);
@@ -375,7 +378,7 @@ struct IsotropicFn : public torch::autograd::Function<IsotropicFn> {
 Tensor joint_sdf_loss_analytic(const Tensor &ray_xyz, const Tensor &gt_sdf, const Tensor &samples, const Tensor &ids, const Tensor &weights,
                                ::TCNNEncoding &enc, ::TCNNNetwork &dec, const std::vector<float> &origin, double map_size_inv, double bce_isigma,
                                double w_sdf, double w_gs, double delta, double w_eik, double w_align, Tensor table_grad, Tensor decoder_grad,
-                               Tensor bias_grad, StreamGate *samples_grad_ready) {
+                               Tensor bias_grad, StreamGate *samples_grad_ready, bool unit_upstream) {
   TORCH_CHECK(origin.size() == 3, "joint_sdf_loss_analytic: map_origin needs 3 entries");
   TORCH_CHECK(table_grad.defined() && table_grad.numel() == enc.params_.numel() && table_grad.is_contiguous() && decoder_grad.defined() &&
                   decoder_grad.numel() == dec.params_.numel() && decoder_grad.is_contiguous() &&
@@ -383,7 +386,8 @@ Tensor joint_sdf_loss_analytic(const Tensor &ray_xyz, const Tensor &gt_sdf, cons
               "joint_sdf_loss_analytic: table_grad / decoder_grad / bias_grad must be contiguous fp32 buffers shaped like the parameters");
   std::vector<int64_t> iv = {enc.n_levels_, enc.n_feat_, enc.log2_hashmap_, enc.base_res_};
   iv.insert(iv.end(), dec.dims_.begin(), dec.dims_.end());
-  std::vector<double> dv = {enc.per_level_scale_, origin[0], origin[1], origin[2], map_size_inv, bce_isigma, w_sdf, w_gs, delta, w_eik, w_align};
+  std::vector<double> dv = {enc.per_level_scale_, origin[0], origin[1], origin[2], map_size_inv, bce_isigma, w_sdf, w_gs, delta, w_eik, w_align,
+                            unit_upstream ? 1.0 : 0.0};
   // autograd::Function::apply wants defined tensors: an empty tensor stands for "absent"
   const auto opt = enc.params_.options().requires_grad(false);
   auto e = [&](const Tensor &t) { return t.defined() ? t : torch::empty({0}, opt); };

@@ -480,7 +480,7 @@ std::map<std::string, int64_t> JointIteration::step_direct(const Tensor &viewmat
     torch::AutoGradMode grad_on(true);
     sdf_loss = joint_sdf_loss_analytic(ray_pts, ray_sdf, has ? samples_cut : Tensor(), has ? ids : Tensor(), has ? w_all : Tensor(), *enc_, *dec_, origin_,
                                        map_size_inv_, bce_isigma_, cfg_.sdf_w, cfg_.gs_sdf_w, cfg_.sdf_delta, cfg_.eik_w, cfg_.align_w, tg, dg, bg,
-                                       &streams_->gate);
+                                       &streams_->gate, /*unit_upstream=*/true);
   }
   // ---- the splat leg's losses (values kept for the caller) and their gradients
   std::vector<float> intr, pose;
