@@ -63,6 +63,7 @@ _SIGS = {
     "gsdf_normal_consistency_fwd": (C.c_int, [_i32, _i32] + [_vp] * 7),
     "gsdf_normal_consistency_bwd": (C.c_int, [_i32, _i32] + [_vp] * 9),
     "gsdf_sdf_query_points": (C.c_int, [_i64, _i32, _vp, _f32, _vp, _f32, _vp, _vp]),
+    "gsdf_sdf_query_points2": (C.c_int, [_i64, _vp, _i64, _vp, _vp, _i32, _f32, _vp, _f32, _vp, _vp]),
     "gsdf_gs_sdf_loss": (C.c_int, [_i64, _vp, _i32, _vp, _vp, _f32, _vp, _vp, _vp]),
     "gsdf_gs_sdf_eik_loss": (C.c_int, [_i64, _i32, _vp, _i32, _vp, _vp, _f32, _f32, _f32, _vp, _vp, _vp]),
     "gsdf_sdf_ray_loss": (C.c_int, [_i64, _i32, _vp, _i32, _vp, _f32, _f32, _f32, _vp, _vp, _vp]),

@@ -30,6 +30,30 @@ __global__ void __launch_bounds__(256)
   }
 }
 
+// the same for a batch that is the concatenation of n_a rows of `a` and n_b rows of `b` (rows ids[j] of it when ids != NULL): the
+// gather and the concatenation of the joint iteration's SDF batch (ray points + visible splats' samples) happen in the load
+__global__ void __launch_bounds__(256)
+    sdf_query_points2_kernel(int64_t n_a, const float *__restrict__ a, int64_t n_b, const float *__restrict__ b,
+                             const int64_t *__restrict__ ids, int K, float delta, float px, float py, float pz, float inv,
+                             float *__restrict__ out) {
+  const int64_t n = n_a + n_b;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n * K) return;
+  const int64_t k = i / n, j = i - k * n;
+  const float *src = j < n_a ? a + 3 * j : b + 3 * (ids != nullptr ? ids[j - n_a] : j - n_a);
+  float x[3] = {src[0], src[1], src[2]};
+  if (k > 0) {
+    const int axis = (int)(k - 1) >> 1;
+    x[axis] = x[axis] + (((k - 1) & 1) ? -delta : delta);
+  }
+  const float p[3] = {px, py, pz};
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const float m = ((x[c] - p[c]) * 2.0f) * inv;  // scale_to_m1p1
+    out[3 * i + c] = 0.5f * m + 0.5f;
+  }
+}
+
 __device__ __forceinline__ float sigmoidf(float x) { return 1.0f / (1.0f + __expf(-x)); }
 
 // 256-thread block sum -> ONE atomic per block on the loss value (atomics on one address serialise at ~88 per microsecond:
@@ -249,6 +273,21 @@ extern "C" int gsdf_sdf_query_points(int64_t n, int stencil, const float *xyz, f
                                                                                 origin_host[1], origin_host[2],
                                                                                 map_size_inv, out);
   GSDF_CHECK_LAUNCH("sdf_query_points_kernel");
+  return GSDF_OK;
+}
+
+extern "C" int gsdf_sdf_query_points2(int64_t n_a, const float *xyz_a, int64_t n_b, const float *xyz_b, const int64_t *ids_b, int stencil,
+                                      float delta, const float *origin_host, float map_size_inv, float *out, gsdf_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  GSDF_TIMED("gsdf_sdf_query_points");
+  GSDF_REQUIRE(n_a >= 0 && n_b >= 0 && origin_host, "sdf_query_points2: bad arguments");
+  const int64_t n = n_a + n_b;
+  if (n == 0) return GSDF_OK;
+  GSDF_REQUIRE((n_a == 0 || xyz_a) && (n_b == 0 || xyz_b) && out, "sdf_query_points2: null buffer");
+  const int K = stencil ? 7 : 1;
+  sdf_query_points2_kernel<<<(unsigned)((n * K + 255) / 256), 256, 0, stream>>>(n_a, xyz_a, n_b, xyz_b, ids_b, K, delta, origin_host[0], origin_host[1],
+                                                                                 origin_host[2], map_size_inv, out);
+  GSDF_CHECK_LAUNCH("sdf_query_points2_kernel");
   return GSDF_OK;
 }
 

@@ -221,19 +221,21 @@ struct AnalyticFn : public torch::autograd::Function<AnalyticFn> {
     const double map_size_inv = dv[4], bce_isigma = dv[5], w_sdf = dv[6], w_gs = dv[7], delta = dv[8], w_eik = dv[9], w_align = dv[10];
     Tensor table = f32c(table_.detach(), "encoder params"), W = f32c(W_.detach(), "decoder params");
     Tensor bias = (bias_.defined() && bias_.numel() > 0) ? f32c(bias_.detach(), "decoder biases") : Tensor();
-    std::vector<Tensor> parts;
-    int64_t n_ray = 0;
-    if (ray_xyz.defined() && ray_xyz.numel() > 0) { parts.push_back(f32c(ray_xyz.detach().reshape({-1, 3}), "ray_xyz")); n_ray = parts[0].size(0); }
+    // the batch = [ray points; samples[ids]]: gathered and concatenated inside the query-points launch
+    Tensor ray, smp;
+    int64_t n_ray = 0, n_smp = 0;
+    if (ray_xyz.defined() && ray_xyz.numel() > 0) { ray = f32c(ray_xyz.detach().reshape({-1, 3}), "ray_xyz"); n_ray = ray.size(0); }
     Tensor ids = (ids_.defined() && ids_.numel() > 0) ? ids_.contiguous() : Tensor();
-    if (samples.defined() && samples.numel() > 0) parts.push_back(ids.defined() ? samples.detach().index_select(0, ids) : f32c(samples.detach().reshape({-1, 3}), "samples"));
-    TORCH_CHECK(!parts.empty(), "joint_sdf_loss_analytic: no points");
-    Tensor xs = parts.size() == 1 ? parts[0].contiguous() : torch::cat(parts, 0);
-    const int64_t n = xs.size(0);
+    if (samples.defined() && samples.numel() > 0) { smp = f32c(samples.detach().reshape({-1, 3}), "samples"); n_smp = ids.defined() ? ids.size(0) : smp.size(0); }
+    TORCH_CHECK(n_ray + n_smp > 0, "joint_sdf_loss_analytic: no points");
+    const Tensor &xs = ray.defined() ? ray : smp;   // (device / dtype donor of the buffers below)
+    const int64_t n = n_ray + n_smp;
     const bool stencil = w_align != 0.0 && n > 0;
     const int64_t K = stencil ? 7 : 1, nq = K * n;
     const int nf = L * F, nl = (int)dims.size() - 1;
     Tensor x01 = empty_like_opts(xs, {nq, 3}, torch::kFloat32);
-    check(gsdf_sdf_query_points(n, stencil ? 1 : 0, fp(xs), (float)delta, origin, (float)map_size_inv, fpm(x01), cur_stream()), "sdf_query_points");
+    check(gsdf_sdf_query_points2(n_ray, fp(ray), n_smp, fp(smp), ids.defined() ? ids.data_ptr<int64_t>() : nullptr, stencil ? 1 : 0, (float)delta, origin,
+                                 (float)map_size_inv, fpm(x01), cur_stream()), "sdf_query_points");
     Tensor feat = empty_like_opts(xs, {nq, nf}, torch::kFloat32), jac = empty_like_opts(xs, {n, nf, 3}, torch::kFloat32);
     if (stencil)
       check(gsdf_hashgrid_fwd_stencil(nq, n, n, L, F, H, R, S, fp(x01), fp(table), fpm(feat), fpm(jac), cur_stream()), "hashgrid_fwd_stencil");
@@ -246,8 +248,13 @@ struct AnalyticFn : public torch::autograd::Function<AnalyticFn> {
     if (stencil)   // forward-only rows: the numerical gradient of the align term is detached
       check(gsdf_mlp_fwd(6 * n, nl, dims.data(), fp(W), fp(bias), fp(feat) + n * nf, fpm(attr) + n * d_out, nullptr, cur_stream()), "mlp_fwd");
     // g0 = d sdf / d features: the decoder's backward of e_0; its per-layer gradients stay in `bws` for the double backward
-    Tensor e0 = zeros_like_opts(xs, {n, d_out}, torch::kFloat32);
-    e0.select(1, 0).fill_(1.0f);
+    // (constant: rows (1, 0, ..); kept between calls, re-made when the batch outgrows it)
+    static thread_local Tensor e0_cache;
+    if (!e0_cache.defined() || e0_cache.size(0) < n || e0_cache.size(1) != d_out || e0_cache.device() != xs.device()) {
+      e0_cache = zeros_like_opts(xs, {n + n / 4 + 1024, d_out}, torch::kFloat32);
+      e0_cache.select(1, 0).fill_(1.0f);
+    }
+    Tensor e0 = e0_cache.narrow(0, 0, n);
     Tensor g0 = empty_like_opts(xs, {n, nf}, torch::kFloat32);
     Tensor bws = empty_like_opts(xs, {(int64_t)gsdf_mlp_bwd_ws_bytes(n, nl)}, torch::kUInt8);
     check(gsdf_mlp_bwd(n, nl, dims.data(), fp(W), fp(bias), fp(feat), fp(acts), fp(e0), fpm(g0), nullptr, nullptr, bws.data_ptr(), cur_stream()), "mlp_bwd");

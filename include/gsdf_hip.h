@@ -322,6 +322,10 @@ int gsdf_adam_step(int64_t n, int n_segments, const int64_t *seg_begin_host, con
  * ---------------------------------------------------------------------------------------- */
 int gsdf_sdf_query_points(int64_t n, int stencil, const float *xyz, float delta, const float *origin_host,
                           float map_size_inv, float *out, gsdf_stream_t stream);
+/* The same for the batch [xyz_a (n_a rows); xyz_b[ids_b] (n_b rows; ids_b NULL: the first n_b rows)]: gather + concatenation + query_points
+ * of the joint iteration's SDF batch (per-ray points, then the visible splats' samples) in one launch. */
+int gsdf_sdf_query_points2(int64_t n_a, const float *xyz_a, int64_t n_b, const float *xyz_b, const int64_t *ids_b, int stencil, float delta,
+                           const float *origin_host, float map_size_inv, float *out, gsdf_stream_t stream);
  /*  gsdf_gs_sdf_loss: loss[0] = scale * 0.5 * sum_i w_i * attr[i][0]^2 (loss::gs_sdf_loss, loss.cpp:7-11), w_i =
  *     weights[ids[i]] (the row selection of neural_mapping.cpp:436-437; ids NULL: weights[i]); v_attr = d loss / d attr. */
 int gsdf_gs_sdf_loss(int64_t n, const float *attr, int ld, const float *weights, const int64_t *ids, float scale,
