@@ -42,6 +42,7 @@ _SIGS = {
     "gsdf_hashgrid_fwd_jac_rows": (C.c_int, [_i64, _i64, _i32, _i32, _i32, _i32, _f32] + [_vp] * 5),
     "gsdf_hashgrid_fwd_stencil": (C.c_int, [_i64, _i64, _i64, _i32, _i32, _i32, _i32, _f32] + [_vp] * 5),
     "gsdf_hashgrid_bwd_jac": (C.c_int, [_i64, _i32, _i32] + [_vp] * 4),
+    "gsdf_hashgrid_bwd_jac_scatter": (C.c_int, [_i64, _i32, _i32, _vp, _vp, _f32, _vp, _vp, _vp]),
     "gsdf_hashgrid_bwd": (C.c_int, [_i64, _i32, _i32, _i32, _i32, _f32] + [_vp] * 6),
     "gsdf_hashgrid_bwd_binned_ws_bytes": (_sz, [_i64, _i32, _i32, _i32, _i32, _f32]),
     "gsdf_hashgrid_bwd_binned": (C.c_int, [_i64, _i32, _i32, _i32, _i32, _f32] + [_vp] * 4 + [_sz, _vp]),

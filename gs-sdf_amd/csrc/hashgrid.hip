@@ -91,6 +91,26 @@ __global__ void __launch_bounds__(256)
   gx += dpp_mov<0x142, 0xA, 0xF, false>(gx); gy += dpp_mov<0x142, 0xA, 0xF, false>(gy); gz += dpp_mov<0x142, 0xA, 0xF, false>(gz);
   if (k == 31 && b < B) { v_x[3 * b] = gx; v_x[3 * b + 1] = gy; v_x[3 * b + 2] = gz; }
 }
+// the same, scaled and ADDED to row ids[b] (b when ids == NULL) of `out`: the chain rule through the world -> unit-cube map and the
+// row selection of the joint iteration's splat samples in the same launch (rows are distinct: plain read-modify-write)
+__global__ void __launch_bounds__(256)
+    hashgrid_bwd_jac_scatter_kernel(int64_t B, int n_out, const float *__restrict__ jac, const float *__restrict__ v_feat, float scale,
+                                    const int64_t *__restrict__ ids, float *__restrict__ out) {
+  const int lane = threadIdx.x & 63, k = lane & 31;
+  const int64_t b = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 2 + (lane >> 5);
+  float gx = 0.f, gy = 0.f, gz = 0.f;
+  if (b < B && k < n_out) {
+    const float vf = v_feat[b * n_out + k];
+    const float *j = jac + (b * n_out + k) * 3;
+    gx = vf * j[0]; gy = vf * j[1]; gz = vf * j[2];
+  }
+  gx = row_sum_to_lane15(gx); gy = row_sum_to_lane15(gy); gz = row_sum_to_lane15(gz);
+  gx += dpp_mov<0x142, 0xA, 0xF, false>(gx); gy += dpp_mov<0x142, 0xA, 0xF, false>(gy); gz += dpp_mov<0x142, 0xA, 0xF, false>(gz);
+  if (k == 31 && b < B) {
+    float *o = out + 3 * (ids != nullptr ? ids[b] : b);
+    o[0] += gx * scale; o[1] += gy * scale; o[2] += gz * scale;
+  }
+}
 
 // XCD-partitioned forward for large batches.  The 14 hashed levels are 4 MiB each, an XCD's L2 is 4 MiB, and a wave of the
 // kernel above touches all 16 levels: every L2 thrashes over the whole 58 MiB table (hit rate ~7 %; with a 2 MiB table
@@ -521,6 +541,18 @@ extern "C" int gsdf_hashgrid_bwd_jac(int64_t B, int n_levels, int n_feat, const 
   GSDF_REQUIRE(jac && v_feat && v_x, "hashgrid_bwd_jac: null buffer");
   hashgrid_bwd_jac_kernel<<<(unsigned)((B + 7) / 8), 256, 0, stream>>>(B, n_levels * n_feat, jac, v_feat, v_x);
   GSDF_CHECK_LAUNCH("hashgrid_bwd_jac_kernel");
+  return GSDF_OK;
+}
+
+extern "C" int gsdf_hashgrid_bwd_jac_scatter(int64_t B, int n_levels, int n_feat, const float *jac, const float *v_feat, float scale,
+                                             const int64_t *ids, float *out, gsdf_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  GSDF_TIMED("gsdf_hashgrid_bwd_jac");
+  GSDF_REQUIRE(B >= 0 && n_levels >= 1 && n_levels * n_feat <= 32, "hashgrid_bwd_jac_scatter: bad arguments");
+  if (B == 0) return GSDF_OK;
+  GSDF_REQUIRE(jac && v_feat && out, "hashgrid_bwd_jac_scatter: null buffer");
+  hashgrid_bwd_jac_scatter_kernel<<<(unsigned)((B + 7) / 8), 256, 0, stream>>>(B, n_levels * n_feat, jac, v_feat, scale, ids, out);
+  GSDF_CHECK_LAUNCH("hashgrid_bwd_jac_scatter_kernel");
   return GSDF_OK;
 }
 

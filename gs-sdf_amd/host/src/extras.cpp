@@ -306,11 +306,10 @@ struct AnalyticFn : public torch::autograd::Function<AnalyticFn> {
                        bias.defined() ? fpm(bias_grad) : nullptr, ws.data_ptr(), cur_stream()), "mlp_bwd");
     if (ctx->needs_input_grad(2) && n > n_ray) {   // d (data term) / d samples from the Jacobian of the splat rows
       const int64_t ng = n - n_ray;
-      Tensor v_x = empty_like_opts(feat, {ng, 3}, torch::kFloat32);
-      check(gsdf_hashgrid_bwd_jac(ng, L, F, fp(jac) + n_ray * nf * 3, fp(v_feat) + n_ray * nf, fpm(v_x), cur_stream()), "hashgrid_bwd_jac");
-      Tensor v_samples = torch::zeros({n_rows, 3}, feat.options());
-      if (ctx->saved_data["has_ids"].toBool()) v_samples.index_add_(0, ids, v_x * map_size_inv);
-      else v_samples.copy_(v_x * map_size_inv);
+      Tensor v_samples = torch::zeros({n_rows, 3}, feat.options());   // contraction, chain-rule scale and row scatter in one launch
+      check(gsdf_hashgrid_bwd_jac_scatter(ng, L, F, fp(jac) + n_ray * nf * 3, fp(v_feat) + n_ray * nf, (float)map_size_inv,
+                                          ctx->saved_data["has_ids"].toBool() ? ids.data_ptr<int64_t>() : nullptr, fpm(v_samples), cur_stream()),
+            "hashgrid_bwd_jac_scatter");
       out[2] = v_samples;
     }
     if (auto *gate = reinterpret_cast<gsdf_extras::StreamGate *>(ctx->saved_data["gate"].toInt())) gate->record_here();

@@ -209,6 +209,10 @@ int gsdf_hashgrid_fwd_stencil(int64_t B, int64_t stencil_n, int64_t jac_rows, in
                               float *jac, gsdf_stream_t stream);
 int gsdf_hashgrid_bwd_jac(int64_t B, int n_levels, int n_feat, const float *jac, const float *v_feat, float *v_x,
                           gsdf_stream_t stream);
+/* out[ids[b]] += scale * (J_b^T v_feat_b)  (ids NULL: row b): the same contraction with the chain-rule scale of the world -> unit-cube map
+ * and the scatter to the selected sample rows in one launch; the rows named by ids must be distinct. */
+int gsdf_hashgrid_bwd_jac_scatter(int64_t B, int n_levels, int n_feat, const float *jac, const float *v_feat, float scale, const int64_t *ids,
+                                  float *out, gsdf_stream_t stream);
 /* v_table ACCUMULATES (zero it first), v_x is overwritten; either may be NULL. */
 int gsdf_hashgrid_bwd(int64_t B, int n_levels, int n_feat, int log2_hashmap, int base_res, float per_level_scale,
                       const float *x, const float *table, const float *v_feat, float *v_table, float *v_x,
