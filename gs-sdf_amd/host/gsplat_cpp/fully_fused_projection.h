@@ -21,6 +21,8 @@ namespace gsplat_cpp {
 // When non-zero a fresh seed is derived per call from torch's default generator, as a CUDA op would.
 void set_sample_mode(bool stochastic);
 bool get_sample_mode();
+// the seed the next fully_fused_projection_2dgs call would use (0 in centre mode; a draw from torch's default CPU generator otherwise)
+uint64_t next_sample_seed();
 // sets the mode for a scope and restores the caller's on exit (the mode is process-wide state)
 struct SampleModeGuard {
   explicit SampleModeGuard(bool stochastic) : prev_(get_sample_mode()) { set_sample_mode(stochastic); }

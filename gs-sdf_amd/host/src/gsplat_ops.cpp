@@ -16,12 +16,16 @@ using torch::autograd::tensor_list;
 namespace {
 bool g_stochastic_samples = false;
 
-uint64_t next_sample_seed() {
+uint64_t next_sample_seed_impl() {
   if (!g_stochastic_samples) return 0;
+  // GSDF_SAMPLE_SEED (tests): a fixed seed instead of a draw
+  static const uint64_t fixed = [] { const char *e = getenv("GSDF_SAMPLE_SEED"); return e ? (uint64_t)strtoull(e, nullptr, 10) : (uint64_t)0; }();
+  if (fixed) return fixed;
   // one draw from torch's default CPU generator: reproducible under torch::manual_seed (neural_mapping_node.cpp:26)
   const uint64_t s = (uint64_t)torch::randint(1, std::numeric_limits<int64_t>::max(), {1}, torch::kInt64).item<int64_t>();
   return s ? s : 1;
 }
+uint64_t next_sample_seed() { return next_sample_seed_impl(); }
 
 // ------------------------------------------------------------------------------------------ P1
 struct Projection2DGS : public torch::autograd::Function<Projection2DGS> {
@@ -164,6 +168,7 @@ struct Rasterize2DGS : public torch::autograd::Function<Rasterize2DGS> {
 
 void gsplat_cpp::set_sample_mode(bool stochastic) { g_stochastic_samples = stochastic; }
 bool gsplat_cpp::get_sample_mode() { return g_stochastic_samples; }
+uint64_t gsplat_cpp::next_sample_seed() { return next_sample_seed_impl(); }
 
 std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor>
 fully_fused_projection_2dgs(const Tensor &means, const Tensor &quats, const Tensor &scales, const Tensor &viewmats,

@@ -9,6 +9,7 @@
 #include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
 
 #include <cmath>
+#include <limits>
 
 #include "gsdf_extras/gsdf_extras.h"
 #include "gsplat_cpp/fully_fused_projection.h"
@@ -380,7 +381,7 @@ std::map<std::string, int64_t> JointIteration::step(const Tensor &viewmat, const
 //   SH coefficients <- view-colour backward                                              -> features_dc's segment (degree 0)
 bool JointIteration::direct_ok(const Tensor &viewmat) const {
   static const bool off = [] { const char *e = getenv("GSDF_JOINT_DIRECT"); return e && e[0] == '0'; }();
-  return !off && cfg_.two_streams && cfg_.analytic && cfg_.center_reg && cfg_.reference_terms && viewmat.size(0) == 1;
+  return !off && cfg_.two_streams && cfg_.analytic && cfg_.reference_terms && viewmat.size(0) == 1;
 }
 
 namespace {
@@ -438,12 +439,16 @@ std::map<std::string, int64_t> JointIteration::step_direct(const Tensor &viewmat
   Tensor camera_ids = torch::empty({M}, fopt.dtype(torch::kInt64)), gaussian_ids = torch::empty({M}, fopt.dtype(torch::kInt64));
   Tensor radii = torch::empty({M}, fopt.dtype(torch::kInt32)), means2d = torch::empty({M, 2}, fopt), depths = torch::empty({M}, fopt);
   Tensor rt = torch::empty({M, 3, 3}, fopt), normals = torch::empty({M, 3}, fopt), smp = torch::empty({M, 3}, fopt), sw = torch::empty({M, 1}, fopt);
-  check(gsdf_projection_2dgs_fill(N, 1, fp(xyz), fp(quats), fp(scales), fp(viewmat), fp(K), W, H, (uint64_t)0, radii_dense.data_ptr<int32_t>(),
+  // k_center_reg: the SDF samples are the splat centres, weight 1 (neural_gaussian.cpp:259-262); else one stochastic point on every visible
+  // splat's disc (SPEC S-3), the seed drawn from torch's default CPU generator as the drop-in operator does
+  const bool center = cfg_.center_reg;
+  gsplat_cpp::SampleModeGuard sample_mode(!center);
+  const uint64_t seed = center ? 0 : gsplat_cpp::next_sample_seed();
+  check(gsdf_projection_2dgs_fill(N, 1, fp(xyz), fp(quats), fp(scales), fp(viewmat), fp(K), W, H, seed, radii_dense.data_ptr<int32_t>(),
                                   pws.data_ptr(), M, M ? camera_ids.data_ptr<int64_t>() : nullptr, M ? gaussian_ids.data_ptr<int64_t>() : nullptr,
                                   M ? radii.data_ptr<int32_t>() : nullptr, fpm(means2d), fpm(depths), fpm(rt), fpm(normals), fpm(smp), fpm(sw),
                                   cur_stream()), "projection(fill)");
-  // k_center_reg: the SDF samples are the splat centres, weight 1 (neural_gaussian.cpp:259-262)
-  Tensor samples = xyz.index_select(0, gaussian_ids), samples_weights = torch::ones({M, 1}, fopt);
+  Tensor samples = center ? xyz.index_select(0, gaussian_ids) : smp, samples_weights = center ? torch::ones({M, 1}, fopt) : sw;
   Tensor pt_opac = opac.index_select(0, gaussian_ids);
   Tensor colors = torch::empty({M, 3}, fopt);
   check(gsdf_view_colors_fwd(M, Ksh, cfg_.sh_degree, fp(viewmat), fp(xyz), fp(sh), M ? camera_ids.data_ptr<int64_t>() : nullptr,
@@ -532,18 +537,22 @@ std::map<std::string, int64_t> JointIteration::step_direct(const Tensor &viewmat
   check(gsdf_view_colors_bwd(M, Ksh, cfg_.sh_degree, fp(viewmat), fp(xyz), fp(sh), M ? camera_ids.data_ptr<int64_t>() : nullptr,
                              M ? gaussian_ids.data_ptr<int64_t>() : nullptr, fp(v_colors), v_sh_ptr, fpm(g_off), 1, cur_stream()), "view_colors_bwd");
   Tensor v_depths = torch::zeros({M}, fopt);
-  check(gsdf_projection_2dgs_bwd(N, 1, M, fp(xyz), fp(quats), fp(scales), fp(viewmat), fp(K), W, H, (uint64_t)0, M ? camera_ids.data_ptr<int64_t>() : nullptr,
-                                 M ? gaussian_ids.data_ptr<int64_t>() : nullptr, fp(v_means2d), fp(v_depths), fp(v_rt), fp(v_normals), nullptr, fpm(g_off),
-                                 fpm(g_q), fpm(v_scales_act), cur_stream()), "projection_bwd");
+  // the projection's backward (and the activations' behind it): centre mode right away — the samples' gradient is a row scatter into the
+  // offsets' gradient later; stochastic mode once that gradient has arrived (the samples are an output of the projection)
+  auto projection_and_activations_bwd = [&](const Tensor &v_samples) {
+    check(gsdf_projection_2dgs_bwd(N, 1, M, fp(xyz), fp(quats), fp(scales), fp(viewmat), fp(K), W, H, seed, M ? camera_ids.data_ptr<int64_t>() : nullptr,
+                                   M ? gaussian_ids.data_ptr<int64_t>() : nullptr, fp(v_means2d), fp(v_depths), fp(v_rt), fp(v_normals), fp(v_samples),
+                                   fpm(g_off), fpm(g_q), fpm(v_scales_act), cur_stream()), "projection_bwd");
+    check(gsdf_splat_activations_bwd(N, fp(scales), fp(opac), nullptr /* xyz: accumulated in place */, fp(v_scales_act), fp(v_opac_dense), fpm(g_off),
+                                     fpm(g_sc), fpm(g_op), cur_stream()), "splat_activations_bwd");
+  };
   v_opac_dense.index_add_(0, gaussian_ids, v_opac);
-  check(gsdf_splat_activations_bwd(N, fp(scales), fp(opac), nullptr /* xyz: accumulated in place above */, fp(v_scales_act), fp(v_opac_dense), fpm(g_off),
-                                   fpm(g_sc), fpm(g_op), cur_stream()),
-        "splat_activations_bwd");
+  if (center) projection_and_activations_bwd(Tensor());
   if (n_rest_ != 0) {
     seg(4).view({N, 1, 3}).add_(v_sh_tmp.narrow(1, 0, 1));
     seg(5).view({N, n_rest_, 3}).add_(v_sh_tmp.narrow(1, 1, n_rest_));
   }
-  // ---- the SDF leg's backward on the second stream; its d loss / d samples is a row scatter into the offsets' gradient
+  // ---- the SDF leg's backward on the second stream, then its d loss / d samples on this one
   {
     StreamGuard sg(streams_->side);
     torch::AutoGradMode grad_on(true);
@@ -552,10 +561,12 @@ std::map<std::string, int64_t> JointIteration::step_direct(const Tensor &viewmat
   }
   Tensor gs = samples_cut.grad();
   if (gs.defined()) {
+    gs = f32c(gs, "samples gradient");
     gs.record_stream(main_stream);
     if (streams_->gate.armed) { streams_->gate.event.block(main_stream); streams_->gate.armed = false; }
-    g_off.index_add_(0, gaussian_ids, gs);
+    if (center) g_off.index_add_(0, gaussian_ids, gs);
   }
+  if (!center) projection_and_activations_bwd(gs);
   // ---- optimizers, each family on its leg's stream (view-parallel: the family's collective first, on the same stream)
   if (splat_hook_) splat_hook_(flat_grad_);
   if (update) {

@@ -133,3 +133,15 @@ def test_stochastic_sample_mode_step_runs_in_both_implementations(tmp_path):
         assert float(g["splat"].abs().sum()) > 0
     # the stochastic points move with the splat's scale: its gradient differs from the centre mode's
     assert float((out["cpp"]["splat"] - out["center"]["splat"]).abs().max()) > 0
+    # the splat leg without the autograd engine (JointIteration::step_direct, what the runs above took) against the autograd composition of
+    # the same operators, with the sample seed fixed (GSDF_SAMPLE_SEED) so that both place the samples identically
+    path = str(tmp_path / "autograd.pt")
+    _bench(["--workload", "cfg0_10k_256", "--dump-grads", path, "--sample-mode", "stochastic", "--step-impl", "cpp"],
+           env={"GSDF_JOINT_DIRECT": "0", "GSDF_SAMPLE_SEED": "123456789"})
+    ref = torch.load(path)
+    path2 = str(tmp_path / "direct.pt")
+    _bench(["--workload", "cfg0_10k_256", "--dump-grads", path2, "--sample-mode", "stochastic", "--step-impl", "cpp"], env={"GSDF_SAMPLE_SEED": "123456789"})
+    got = torch.load(path2)
+    assert {k: int(v) for k, v in got["sizes"].items()} == {k: int(v) for k, v in ref["sizes"].items()}
+    assert_close(got["splat"], ref["splat"], 1e-4, "stochastic mode, direct vs autograd: splat gradients")
+    assert_close(got["sdf"][0], ref["sdf"][0], 1e-4, "stochastic mode, direct vs autograd: SDF network gradients")
