@@ -145,3 +145,54 @@ def test_stochastic_sample_mode_step_runs_in_both_implementations(tmp_path):
     assert {k: int(v) for k, v in got["sizes"].items()} == {k: int(v) for k, v in ref["sizes"].items()}
     assert_close(got["splat"], ref["splat"], 1e-4, "stochastic mode, direct vs autograd: splat gradients")
     assert_close(got["sdf"][0], ref["sdf"][0], 1e-4, "stochastic mode, direct vs autograd: SDF network gradients")
+
+
+@pytest.mark.parametrize("direct", ["1", "0"])
+def test_cpp_joint_iteration_survives_a_view_that_sees_nothing(direct):
+    """A view with every splat behind the camera: M = 0, I = 0, no visible sample.  The step must run (the SDF leg still has its per-ray batch),
+    leave the splat gradients zero apart from nothing, and keep the parameters finite — in the direct splat leg and in the autograd composition."""
+    code = r'''
+import os, sys, torch
+sys.path.insert(0, os.getcwd())
+import gs_sdf_amd.synth as synth, gs_sdf_amd.hostlib as hostlib, gs_sdf_amd.sdf as sdfm
+from gs_sdf_amd.trainer import SplatParams
+host = hostlib.load(); dev = torch.device("cuda:0")
+N, W, H = 5000, 256, 256
+sc = synth.make_scene(N, W, H, sh_degree=0, seed=0)
+params = SplatParams.from_scene(sc, dev, None)
+lm = sdfm.LocalMap([0.0, 0.0, 5.5], 16.0, bce_sigma=0.02, decoder_implementation=0, device=dev, seed=5)
+enc = host.TCNNEncoding(16, 2, 19, 32, 2.0); dec = host.TCNNNetwork(32, 2, 64, 4, True)
+enc.params_, dec.params_, dec.biases_ = lm.encoder.params_.detach().clone(), lm.decoder.params_.detach().clone(), lm.decoder.biases_.detach().clone()
+fields = [params.views[k].detach().clone() for k in ("offsets", "scaling", "quaternion", "opacity", "features_dc", "features_rest")]
+ji = host.JointIteration(params.anchors, fields, enc, dec, [0.0, 0.0, 5.5], 16.0, 0.02, 8, W, H, 0, True, True, True, True)
+view = torch.eye(4); view[0, 0] = -1.0; view[2, 2] = -1.0          # look the other way: all depths negative
+K = sc["K"].to(dev); target = torch.rand(H, W, 3).to(dev)
+pts = ((torch.rand(4096, 3) - 0.5) * 14.0 + torch.tensor([0.0, 0.0, 5.5])).to(dev); sdf = (torch.randn(4096, 1) * 0.02).to(dev)
+before = ji.splat_flat().clone()
+for i in range(2):
+    sz = ji.step(view[None].to(dev), K, target, pts, sdf, [], True, [])
+    assert int(sz["M"]) == 0 and int(sz["I"]) == 0 and int(sz["n_gs_sdf"]) == 0, dict(sz)
+torch.cuda.synchronize()
+assert torch.isfinite(ji.splat_flat()).all() and torch.isfinite(ji.sdf_flat()).all()
+assert torch.equal(ji.splat_flat(), before), "splats moved although nothing was visible"
+print("EMPTY VIEW OK")
+'''
+    e = dict(os.environ)
+    e["GSDF_JOINT_DIRECT"] = direct
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=e, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "EMPTY VIEW OK" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
+
+
+def test_direct_splat_leg_with_sh_degree_3(tmp_path):
+    """The cfg4 shape (3 M splats, 640x512, SH degree 3: 16 coefficient triples per splat): the direct splat leg splits the SH gradient into
+    the features_dc / features_rest segments itself — against the autograd composition of the same operators."""
+    out = {}
+    for mode, env in (("autograd", {"GSDF_JOINT_DIRECT": "0"}), ("direct", {})):
+        path = str(tmp_path / f"{mode}.pt")
+        _bench(["--workload", "cfg4_3M_640x512_K16", "--dump-grads", path, "--step-impl", "cpp"], env=env)
+        out[mode] = torch.load(path)
+    ref, got = out["autograd"], out["direct"]
+    assert {k: int(v) for k, v in got["sizes"].items()} == {k: int(v) for k, v in ref["sizes"].items()}
+    assert float(ref["splat"].abs().sum()) > 0
+    assert_close(got["splat"], ref["splat"], 1e-4, "direct vs autograd: splat gradients (SH degree 3)")
+    assert_close(got["sdf"][0], ref["sdf"][0], 1e-4, "direct vs autograd: SDF network gradients")
