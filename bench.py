@@ -575,7 +575,8 @@ def main():
                        "sdf_config": None if args.no_sdf else args.sdf_config,
                        "step_impl": ("C++/libtorch: gsdf_extras::JointIteration (gs-sdf_amd/host/src/joint_step.cpp) over libgsdf_torch.so -> C ABI -> "
                                      "libgsdf_hip.so; " + ("two HIP streams, the splat leg's operators called through the C ABI directly (step_direct: no autograd engine), the "
-                                                           "SDF batch one autograd node" if not args.no_overlap else "one HIP stream, autograd composition") + "; driven per step through "
+                                                           "SDF batch one autograd node" if (not args.no_overlap and analytic and ref_terms) else
+                                                          ("two HIP streams" if not args.no_overlap else "one HIP stream") + ", autograd composition") + "; driven per step through "
                                      "the pybind harness" if impl == "cpp" else "Python mirror (gs_sdf_amd.ops / sdf over ctypes -> C ABI), "
                                      + ("four HIP streams" if overlap else "one HIP stream")),
                        "step": "reference joint iteration (neural_mapping.cpp:400-486): " + terms,
