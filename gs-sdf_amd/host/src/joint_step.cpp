@@ -499,9 +499,7 @@ std::map<std::string, int64_t> JointIteration::step_direct(const Tensor &viewmat
   }
   Tensor sums = torch::empty({2}, fopt), maps = torch::empty({3, H, W, 3}, fopt), l_normal = torch::empty({1}, fopt), l_iso = torch::empty({}, fopt);
   check(gsdf_l1_dssim_fwd(H, W, fp(c3), fp(target), ssim_window11(), fpm(sums), fpm(maps), cur_stream()), "l1_dssim_fwd");
-  check(gsdf_normal_consistency_fwd(H, W, intr.data(), pose.data(), fp(d1), fp(ra), fp(nw), fpm(l_normal), cur_stream()), "normal_consistency_fwd");
-  check(gsdf_isotropic_loss_fwd(M, fp(scales), M ? gaussian_ids.data_ptr<int64_t>() : nullptr, fpm(l_iso), cur_stream()), "isotropic_loss_fwd");
-  last_losses_ = {sums, l_normal, l_iso};
+  last_losses_ = {sums, l_normal, l_iso};   // (the two loss VALUES nobody's gradient needs are computed further down, where this stream waits anyway)
   Tensor v_c3 = img(3), v_d1 = img(1), v_nw = img(3);
   check(gsdf_l1_dssim_bwd(H, W, fp(c3), fp(target), ssim_window11(), fp(maps), fp(w_one_), (float)cfg_.rgb_w, (float)cfg_.dssim_w, fpm(v_c3), cur_stream()),
         "l1_dssim_bwd");
@@ -552,6 +550,10 @@ std::map<std::string, int64_t> JointIteration::step_direct(const Tensor &viewmat
     seg(4).view({N, 1, 3}).add_(v_sh_tmp.narrow(1, 0, 1));
     seg(5).view({N, n_rest_, 3}).add_(v_sh_tmp.narrow(1, 1, n_rest_));
   }
+  // the values of the normal-consistency and isotropic losses (their backward kernels above recompute what they need): issued here, where
+  // this stream is about to wait for the SDF leg's samples' gradient
+  check(gsdf_normal_consistency_fwd(H, W, intr.data(), pose.data(), fp(d1), fp(ra), fp(nw), fpm(l_normal), cur_stream()), "normal_consistency_fwd");
+  check(gsdf_isotropic_loss_fwd(M, fp(scales), M ? gaussian_ids.data_ptr<int64_t>() : nullptr, fpm(l_iso), cur_stream()), "isotropic_loss_fwd");
   // ---- the SDF leg's backward on the second stream, then its d loss / d samples on this one
   {
     StreamGuard sg(streams_->side);
