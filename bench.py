@@ -346,8 +346,7 @@ def main():
         # other kernel; round 1 serialised the two because RCCL's workgroups queued behind the scatter's atomics)
         vp.all_reduce_group(params, args.collective)
         if update:
-            adam.step()
-            params.flat_grad.zero_()
+            adam.step(zero_grad=True)
             if ref_terms:   # train_callback -> prune_nan_gs's test (neural_gaussian.cpp:907-916), one launch, no host sync: the
                 v_ = params.views   # count is read after the timed region (a real trainer reads it with the next step's sizes)
                 nan_total.add_(ops.nan_rows(v_["offsets"], v_["scaling"], v_["quaternion"])[0])
@@ -359,8 +358,7 @@ def main():
                 side.wait_stream(aux)
                 vp.all_reduce_group(groups[0], args.collective)
                 if update:
-                    adam_sdf.step()
-                    groups[0].flat_grad.zero_()
+                    adam_sdf.step(zero_grad=True)
         stamp("optimizers issued")
         sizes.update(M=int(meta["gaussian_ids"].shape[0]), I=int(meta["flatten_ids"].shape[0]))
         for k in ("M", "I", "n_gs_sdf"):

@@ -89,6 +89,7 @@ _SIGS = {
     "gsdf_flat_rows_gather": (C.c_int, [_i32, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp]),
     "gsdf_stream_set_xcds": (C.c_int, [_vp, _i32]),
     "gsdf_adam_step": (C.c_int, [_i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _f32, _i64, _vp]),
+    "gsdf_adam_step_zero_grad": (C.c_int, [_i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _f32, _i64, _vp]),
     "gsdf_knn_ws_bytes": (_sz, [_i64]),
     "gsdf_knn_mean_dist2": (C.c_int, [_i64] + [_vp] * 4),
 }

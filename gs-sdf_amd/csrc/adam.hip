@@ -14,8 +14,9 @@ struct AdamSegs {
   int n;
 };
 
+template <bool ZERO_GRAD>
 __global__ void __launch_bounds__(256)
-    adam_kernel(int64_t n_vec4, int64_t n, AdamSegs segs, float *__restrict__ p, const float *__restrict__ g,
+    adam_kernel(int64_t n_vec4, int64_t n, AdamSegs segs, float *__restrict__ p, float *__restrict__ g,
                 float *__restrict__ m, float *__restrict__ v, float beta1, float beta2, float eps, float inv_bc1,
                 float inv_sqrt_bc2) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_vec4; i += (int64_t)gridDim.x * 256) {
@@ -54,10 +55,11 @@ __global__ void __launch_bounds__(256)
       *reinterpret_cast<float4 *>(p + e0) = make_float4(pv[0], pv[1], pv[2], pv[3]);
       *reinterpret_cast<float4 *>(m + e0) = make_float4(mv[0], mv[1], mv[2], mv[3]);
       *reinterpret_cast<float4 *>(v + e0) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+      if (ZERO_GRAD) *reinterpret_cast<float4 *>(g + e0) = make_float4(0.f, 0.f, 0.f, 0.f);   // the step's zero_grad, without a pass of its own
     } else {
 #pragma unroll
       for (int k = 0; k < 4; ++k)
-        if (e0 + k < n) { p[e0 + k] = pv[k]; m[e0 + k] = mv[k]; v[e0 + k] = vv[k]; }
+        if (e0 + k < n) { p[e0 + k] = pv[k]; m[e0 + k] = mv[k]; v[e0 + k] = vv[k]; if (ZERO_GRAD) g[e0 + k] = 0.f; }
     }
   }
 }
@@ -66,9 +68,8 @@ __global__ void __launch_bounds__(256)
 
 using namespace gsdf;
 
-extern "C" int gsdf_adam_step(int64_t n, int n_segments, const int64_t *seg_begin_host, const float *seg_lr_host,
-                              float *params, const float *grads, float *exp_avg, float *exp_avg_sq, float beta1,
-                              float beta2, float eps, int64_t step, gsdf_stream_t stream_) {
+static int adam_step_impl(int64_t n, int n_segments, const int64_t *seg_begin_host, const float *seg_lr_host, float *params, float *grads,
+                          float *exp_avg, float *exp_avg_sq, float beta1, float beta2, float eps, int64_t step, bool zero_grad, gsdf_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   GSDF_TIMED("gsdf_adam_step");
   GSDF_REQUIRE(n >= 0 && n_segments >= 1 && n_segments <= ADAM_MAX_SEG, "adam_step: %d segments not in [1,%d]", n_segments,
@@ -89,8 +90,24 @@ extern "C" int gsdf_adam_step(int64_t n, int n_segments, const int64_t *seg_begi
   const int64_t n4 = (n + 3) / 4;
   int64_t blocks = (n4 + 255) / 256;
   if (blocks > 256 * 16) blocks = 256 * 16;
-  adam_kernel<<<(unsigned)blocks, 256, 0, stream>>>(n4, n, segs, params, grads, exp_avg, exp_avg_sq, beta1, beta2, eps,
-                                                    (float)(1.0 / bc1), (float)(1.0 / sqrt(bc2)));
+  if (zero_grad)
+    adam_kernel<true><<<(unsigned)blocks, 256, 0, stream>>>(n4, n, segs, params, grads, exp_avg, exp_avg_sq, beta1, beta2, eps, (float)(1.0 / bc1),
+                                                            (float)(1.0 / sqrt(bc2)));
+  else
+    adam_kernel<false><<<(unsigned)blocks, 256, 0, stream>>>(n4, n, segs, params, grads, exp_avg, exp_avg_sq, beta1, beta2, eps, (float)(1.0 / bc1),
+                                                             (float)(1.0 / sqrt(bc2)));
   GSDF_CHECK_LAUNCH("adam_kernel");
   return GSDF_OK;
+}
+
+extern "C" int gsdf_adam_step(int64_t n, int n_segments, const int64_t *seg_begin_host, const float *seg_lr_host, float *params,
+                              const float *grads, float *exp_avg, float *exp_avg_sq, float beta1, float beta2, float eps, int64_t step,
+                              gsdf_stream_t stream) {
+  return adam_step_impl(n, n_segments, seg_begin_host, seg_lr_host, params, const_cast<float *>(grads), exp_avg, exp_avg_sq, beta1, beta2, eps, step, false,
+                        stream);
+}
+
+extern "C" int gsdf_adam_step_zero_grad(int64_t n, int n_segments, const int64_t *seg_begin_host, const float *seg_lr_host, float *params, float *grads,
+                                        float *exp_avg, float *exp_avg_sq, float beta1, float beta2, float eps, int64_t step, gsdf_stream_t stream) {
+  return adam_step_impl(n, n_segments, seg_begin_host, seg_lr_host, params, grads, exp_avg, exp_avg_sq, beta1, beta2, eps, step, true, stream);
 }

@@ -104,7 +104,7 @@ class FusedAdam {
   // flat / flat_grad: contiguous fp32 device buffers; segments = consecutive (n_elements, lr) pieces covering the buffer
   int add_group(const torch::Tensor &flat, const torch::Tensor &flat_grad, const std::vector<int64_t> &sizes, const std::vector<double> &lrs);
   void set_lr(int group, int segment, double lr) { groups_.at(group).lrs.at(segment) = (float)lr; }
-  void step();
+  void step(bool zero_grad = false);   // zero_grad: the gradient buffers are zeroed as they are consumed (no fill launches)
   int64_t step_count() const { return t_; }
 
  private:

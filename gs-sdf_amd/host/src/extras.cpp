@@ -474,12 +474,14 @@ int FusedAdam::add_group(const Tensor &flat, const Tensor &flat_grad, const std:
   return (int)groups_.size() - 1;
 }
 
-void FusedAdam::step() {
+void FusedAdam::step(bool zero_grad) {
   torch::NoGradGuard ng;
   ++t_;
   for (auto &g : groups_)
-    check(gsdf_adam_step(g.flat.numel(), (int)g.lrs.size(), g.begins.data(), g.lrs.data(), fpm(g.flat), fp(g.grad), fpm(g.m), fpm(g.v),
-                         (float)b1_, (float)b2_, (float)eps_, t_, cur_stream()),
+    check((zero_grad ? gsdf_adam_step_zero_grad(g.flat.numel(), (int)g.lrs.size(), g.begins.data(), g.lrs.data(), fpm(g.flat), fpm(g.grad), fpm(g.m),
+                                                fpm(g.v), (float)b1_, (float)b2_, (float)eps_, t_, cur_stream())
+                     : gsdf_adam_step(g.flat.numel(), (int)g.lrs.size(), g.begins.data(), g.lrs.data(), fpm(g.flat), fp(g.grad), fpm(g.m), fpm(g.v),
+                                      (float)b1_, (float)b2_, (float)eps_, t_, cur_stream())),
           "adam_step");
 }
 

@@ -25,6 +25,12 @@ using torch::autograd::AutogradContext;
 using torch::autograd::tensor_list;
 
 namespace {
+// the gradient buffers are zeroed by the Adam launch that consumes them (gsdf_adam_step_zero_grad); GSDF_ADAM_FUSED_ZERO=0: separate fills
+bool fused_zero() {
+  static const bool on = [] { const char *e = getenv("GSDF_ADAM_FUSED_ZERO"); return !(e && e[0] == '0'); }();
+  return on;
+}
+
 
 // neural_gaussian.cpp:229-240 in one pass: expected depth, cat(colours, depth), normals to world space (+ the colour / depth slices)
 struct RenderPost : public torch::autograd::Function<RenderPost> {
@@ -345,8 +351,8 @@ std::map<std::string, int64_t> JointIteration::step(const Tensor &viewmat, const
   update_state(state_, densify.grad(), gaussian_ids, vis, radii, N, (int)viewmat.size(0), W, H, false);
   if (splat_hook_) splat_hook_(flat_grad_);            // view-parallel: the splat family's gradients are final here
   if (update) {
-    adam_.step();
-    flat_grad_.zero_();
+    adam_.step(/*zero_grad=*/fused_zero());
+    if (!fused_zero()) flat_grad_.zero_();
     if (cfg_.reference_terms) nan_total_.add_(nan_rows(views_[0], views_[1], views_[2]));   // prune_nan_gs's test, no host sync
   }
   {
@@ -354,8 +360,8 @@ std::map<std::string, int64_t> JointIteration::step(const Tensor &viewmat, const
     if (two) sg.emplace(streams_->side);
     if (sdf_hook_) sdf_hook_(sdf_flat_grad_);          // ... and the SDF family's, on its own stream (after its scatter)
     if (update) {
-      adam_sdf_.step();
-      sdf_flat_grad_.zero_();
+      adam_sdf_.step(/*zero_grad=*/fused_zero());
+      if (!fused_zero()) sdf_flat_grad_.zero_();
     }
   }
   if (two) {   // what the caller's stream has to wait for before it touches the SDF family (sync())
@@ -572,16 +578,16 @@ std::map<std::string, int64_t> JointIteration::step_direct(const Tensor &viewmat
   // ---- optimizers, each family on its leg's stream (view-parallel: the family's collective first, on the same stream)
   if (splat_hook_) splat_hook_(flat_grad_);
   if (update) {
-    adam_.step();
-    flat_grad_.zero_();
+    adam_.step(/*zero_grad=*/fused_zero());
+    if (!fused_zero()) flat_grad_.zero_();
     nan_total_.add_(nan_rows(views_[0], views_[1], views_[2]));   // prune_nan_gs's test, no host sync
   }
   {
     StreamGuard sg(streams_->side);
     if (sdf_hook_) sdf_hook_(sdf_flat_grad_);
     if (update) {
-      adam_sdf_.step();
-      sdf_flat_grad_.zero_();
+      adam_sdf_.step(/*zero_grad=*/fused_zero());
+      if (!fused_zero()) sdf_flat_grad_.zero_();
     }
   }
   streams_->side_done.record(streams_->side);

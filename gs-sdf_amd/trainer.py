@@ -401,13 +401,15 @@ class FusedAdam:
         g["v"][b[segment]:b[segment + 1]].zero_()
 
     @torch.no_grad()
-    def step(self):
+    def step(self, zero_grad: bool = False):
+        """zero_grad: the gradient buffers are zeroed by the same launch that consumes them (gsdf_adam_step_zero_grad)"""
         import ctypes as C
         from . import capi
         L = capi.lib()
         self.t += 1
+        fn = L.gsdf_adam_step_zero_grad if zero_grad else L.gsdf_adam_step
         for g in self.groups:
             lrs = (C.c_float * len(g["lrs"]))(*g["lrs"])
-            capi.check(L.gsdf_adam_step(g["flat"].numel(), len(g["lrs"]), g["begins"], lrs, capi.f32(g["flat"]), capi.f32(g["grad"]),
+            capi.check(fn(g["flat"].numel(), len(g["lrs"]), g["begins"], lrs, capi.f32(g["flat"]), capi.f32(g["grad"]),
                                         capi.f32(g["m"]), capi.f32(g["v"]), self.betas[0], self.betas[1], self.eps, self.t,
                                         capi.stream()), "adam_step")

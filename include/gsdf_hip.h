@@ -311,6 +311,10 @@ int gsdf_knn_mean_dist2(int64_t n_points, const float *points, float *out, void 
 int gsdf_adam_step(int64_t n, int n_segments, const int64_t *seg_begin_host, const float *seg_lr_host, float *params,
                    const float *grads, float *exp_avg, float *exp_avg_sq, float beta1, float beta2, float eps,
                    int64_t step, gsdf_stream_t stream);
+/* the same, and the gradient buffer is zeroed as it is consumed (optimizer.zero_grad() of the next iteration, neural_mapping.cpp:466, without
+ * a pass of its own) */
+int gsdf_adam_step_zero_grad(int64_t n, int n_segments, const int64_t *seg_begin_host, const float *seg_lr_host, float *params, float *grads,
+                             float *exp_avg, float *exp_avg_sq, float beta1, float beta2, float eps, int64_t step, gsdf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * S3  the per-ray SDF batch's elementwise ends (replace ~100 eager libtorch kernels per step):

@@ -218,8 +218,10 @@ def test_fused_adam_matches_torch_adam(sizes, lrs):
         flat_grad.copy_(grad)
         for p, gg in zip(ref_params, grad.split(sizes)):
             p.grad = gg.clone()
-        ref.step(); opt.step()
+        ref.step(); opt.step(zero_grad=bool(it % 2))
         assert_close(flat, torch.cat([p.detach() for p in ref_params]), 1e-6, f"params after step {it + 1}")
+        # gsdf_adam_step_zero_grad leaves the gradient buffer zeroed (every element, the ragged tail too); gsdf_adam_step leaves it alone
+        assert torch.equal(flat_grad, torch.zeros_like(grad) if it % 2 else grad), f"gradient buffer after step {it + 1}"
 
 
 def test_in_place_table_gradient_accumulation_equals_autograd(sdf):
