@@ -1,2 +1,2 @@
-// stub for the syntax-only compile of the reference's host code (tests/test_reference_compiles_against_boundary.py)
 #pragma once
+#include "cuda_runtime_api.h"

@@ -21,7 +21,13 @@ struct Mat {
   void convertTo(Mat &, int, double = 1, double = 0) const {}
   template <class T> T *ptr(int = 0) { return nullptr; }
   size_t total() const { return 0; }
+  void setTo(double) {}
+  void setTo(double, const Mat &) {}
 };
+inline Mat operator>(const Mat &m, double) { return m; }
+inline Mat operator-(const Mat &m, double) { return m; }
+inline Mat operator/(const Mat &m, double) { return m; }
+inline Mat operator~(const Mat &m) { return m; }
 inline std::ostream &operator<<(std::ostream &o, const Mat &) { return o; }
 template <class T> struct Mat_ : Mat {
   Mat_() = default;
@@ -32,6 +38,10 @@ template <class T> struct Mat_ : Mat {
 };
 enum InterpolationFlags { INTER_LINEAR = 1 };
 enum ColormapTypes { COLORMAP_TURBO = 20 };
+enum ColorConversionCodes { COLOR_RGB2BGR = 4 };
+inline void minMaxLoc(const Mat &, double *, double *, void * = nullptr, void * = nullptr, const Mat & = Mat()) {}
+inline void applyColorMap(const Mat &, Mat &, int) {}
+inline void cvtColor(const Mat &, Mat &, int) {}
 enum { CV_32FC1 = 5, CV_32FC3 = 21, CV_8UC3 = 16, CV_16SC2 = 11, CV_32F = 5 };
 inline Mat getOptimalNewCameraMatrix(const Mat &, const Mat &, Size, double, Size = Size(), void * = nullptr, bool = false) { return Mat(); }
 inline void initUndistortRectifyMap(const Mat &, const Mat &, const Mat &, const Mat &, Size, int, Mat &, Mat &) {}
@@ -43,4 +53,9 @@ inline void initUndistortRectifyMap(const Mat &, const Mat &, const Mat &, const
 #ifndef CV_32FC1
 #define CV_32FC1 5
 #define CV_16SC2 11
+#endif
+#ifndef CV_8UC1
+#define CV_8UC1 0
+#define CV_8UC3 16
+#define CV_16UC1 2
 #endif

@@ -5,6 +5,7 @@
 namespace pcl {
 template <class P> struct PointCloud {
   std::vector<P> points;
+  unsigned width = 0, height = 0;
   using Ptr = std::shared_ptr<PointCloud<P>>;
   size_t size() const { return points.size(); }
 };
