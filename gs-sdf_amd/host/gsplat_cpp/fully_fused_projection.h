@@ -17,8 +17,9 @@ fully_fused_projection_2dgs(const torch::Tensor &means, const torch::Tensor &qua
                             float near_plane, float far_plane, float radius_clip, bool packed, bool sparse_grad);
 
 namespace gsplat_cpp {
-// Seed of the stochastic splat sample (`samples`, SPEC S-3).  0 (default) = splat centres with unit weights.
-// When non-zero a fresh seed is derived per call from torch's default generator, as a CUDA op would.
+// `samples` / `samples_weights` (SPEC S-3).  Default: stochastic, one sample on every visible splat's disc, a fresh seed per call derived
+// from torch's default generator as a CUDA op would (what the reference's default k_center_reg = 0 consumes, neural_gaussian.cpp:258-264).
+// set_sample_mode(false): splat centres with unit weights and no draw, for callers that replace the samples anyway (k_center_reg = 1).
 void set_sample_mode(bool stochastic);
 bool get_sample_mode();
 // the seed the next fully_fused_projection_2dgs call would use (0 in centre mode; a draw from torch's default CPU generator otherwise)

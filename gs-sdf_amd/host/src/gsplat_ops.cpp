@@ -14,7 +14,11 @@ using torch::autograd::AutogradContext;
 using torch::autograd::tensor_list;
 
 namespace {
-bool g_stochastic_samples = false;
+// The fork's projection always returns its stochastic samples; the reference replaces them by the centres afterwards when k_center_reg is
+// set (neural_gaussian.cpp:258-264).  So that the UNMODIFIED reference gets what it expects, stochastic is the library default; callers
+// that know they will discard the samples (gsdf_model::rasterization_2dgs_sdf, gsdf_extras::JointIteration in centre mode, the Python test
+// harness gs_sdf_amd.hostlib) switch the draw off for their scope.
+bool g_stochastic_samples = true;
 
 uint64_t next_sample_seed_impl() {
   if (!g_stochastic_samples) return 0;

@@ -18,4 +18,7 @@ def load():
     spec = importlib.util.spec_from_file_location("_gsdf_host", path)
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
+    # the library's default is the fork's behaviour (stochastic SDF samples from the projection); the Python tests compare operator outputs
+    # with deterministic mirrors, so the harness starts in centre mode and tests of the stochastic path switch it on for their scope
+    mod.set_sample_mode(False)
     return mod

@@ -321,5 +321,6 @@ def test_cpp_fused_extras_match_python_mirror(host):
     for it in range(4):
         gr = torch.randn(flat.numel(), generator=g).to(dev)
         g1.copy_(gr); g2.copy_(gr)
-        o1.step(); o2.step()
+        o1.step(bool(it % 2)); o2.step(zero_grad=bool(it % 2))      # odd steps: the launch also zeroes the gradient it consumed
+        assert torch.equal(g1, g2) and bool((g1 == 0).all()) == bool(it % 2)
     assert torch.equal(f1, f2)
