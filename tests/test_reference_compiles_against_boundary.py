@@ -7,8 +7,8 @@ on the GPU box): `g++ -fsyntax-only` of
     include/neural_gaussian/neural_gaussian.cpp   (rasterization_2dgs_sdf :129-271, NeuralGS, distCUDA2 :314)
 
 with this repository's headers standing where the un-vendored submodules' headers would be
-(gs-sdf_amd/host/{gsplat_cpp,tcnn_binding,kaolin_wisp_cpp,kaolin,spatial.h} + compat/nlohmann) and declaration-only stand-ins
-(tests/ref_compile_stubs/) for what is neither on the path nor in this image: OpenCV, PCL/Eigen, the CUDA runtime header,
+(gs-sdf_amd/host/{gsplat_cpp,tcnn_binding,kaolin_wisp_cpp,kaolin,spatial.h} + compat/nlohmann) and inert stand-ins
+(tests/ref_compile_stubs/; the same set oracle/ref_link/build.py compiles and LINKS the reference's sources with) for what is neither on the path nor in this image: OpenCV, PCL/Eigen, the CUDA runtime header,
 and the reference's other un-vendored submodules llog and ply_utils/tinyply.  Every call the reference makes into the
 replaced submodules therefore type-checks against the replacement's declarations: argument order, types, return tuples,
 member names (params_, get_out_dim, ...).  Nothing from /root/reference is copied; the sources are compiled where they lie."""
