@@ -326,3 +326,88 @@ def test_reference_photometric_loss_on_the_gpu_matches_the_fused_kernels(ref):
             out.append((loss.detach(), gx))
         assert rel(out[1][0], out[0][0]) < 1e-5
         assert rel(out[1][1], out[0][1]) < 1e-4
+
+
+def test_reference_joint_iteration_on_the_dropin_matches_gsdf_model(host, ref):
+    """The joint iteration of NeuralSLAM::gs_train (neural_mapping.cpp:400-486 — the one file of the path that cannot be compiled here: ROS,
+    tf, the data loader) sequenced in Python over the REFERENCE'S compiled pieces, in the reference's default configuration (torch decoder,
+    analytic eikonal): LocalMap::get_sdf / get_gradient / get_valid_mask, NeuralGS::render / train_callback, loss::sdf_loss /
+    eikonal_loss / rgb_loss / dssim_loss / gs_sdf_loss, one torch::optim::Adam over the SDF network's and the splats' groups.  The same
+    sequence over gsdf_model:: with this repository's mirrors of the losses must produce the same loss values, iteration by iteration,
+    and the same parameters after 10 Adam steps of both networks."""
+    import gs_sdf_amd.ops as ops
+    import gs_sdf_amd.sdf as sdfm
+    dev = torch.device("cuda:0")
+    rl, cm, cfg = make_maps(host, ref, 0)
+    n, w, h = 6000, 320, 192
+    sc = synth.make_scene(n, w, h, sh_degree=1, seed=3)
+    Kc = sc["K"][0]
+    cam = (float(Kc[0, 0]), float(Kc[1, 1]), float(Kc[0, 2]), float(Kc[1, 2]), w, h)
+    poses = [torch.linalg.inv(v)[:3, :4].contiguous() for v in synth.make_views(4, seed=2)]
+    gcfg = host.GSConfig()
+    gcfg.sh_degree, gcfg.center_reg, gcfg.refine_start_iter = 1, True, 1000
+    ref.configure(dict(sh_degree=1, near=gcfg.near, far=gcfg.far, use_absgrad=gcfg.use_absgrad, geo_init=False, mesh_init=False, sky_init=False,
+                       prune_opa=gcfg.prune_opa, grow_grad2d=gcfg.grow_grad2d, grow_scale3d=gcfg.grow_scale3d, grow_scale2d=gcfg.grow_scale2d,
+                       prune_scale3d=gcfg.prune_scale3d, refine_scale2d_stop_iter=gcfg.refine_scale2d_stop_iter, refine_start_iter=1000,
+                       refine_every=gcfg.refine_every, reset_every=gcfg.reset_every, sh_degree_interval=gcfg.sh_degree_interval, lr_end=gcfg.lr_end,
+                       detach_sdf_grad=False, vis_batch_pt_num=gcfg.vis_batch_pt_num, pause_refine=False, center_reg=True))
+    torch.manual_seed(5)
+    rg = ref.NeuralGS(rl, sc["means"].to(dev), 1000, 1.0, False)
+    with torch.no_grad():
+        rg.scaling_.copy_(sc["log_scales"].to(dev)); rg.quaternion_.copy_(sc["quats"].to(dev)); rg.opacity_.copy_(sc["logit_opacities"].to(dev))
+        rg.features_dc_.copy_(sc["sh"][:, :1].to(dev)); rg.features_rest_.copy_(sc["sh"][:, 1:].to(dev))
+    cg = host.NeuralGS(cm, rg.anchors_.detach(), rg.scaling_.detach(), rg.quaternion_.detach(), rg.opacity_.detach(), rg.features_dc_.detach(),
+                       rg.features_rest_.detach(), 1000, 1.0, gcfg)
+    rg.sh_degree_to_use_ = cg.sh_degree_to_use_ = 1
+    for m_ in (rl, cm):
+        m_.update_octree_as(rg.anchors_.detach(), False)
+    ropt, copt = rg.make_optimizer(rl, 1e-3), cg.make_optimizer(cm, 1e-3)
+    assert ropt.n_groups() == 11 + 6 and copt.n_groups() == 3 + 6          # the reference's Sequential registers 10 decoder tensors
+    host.set_sample_mode(False)
+    g = torch.Generator(device=dev).manual_seed(21)
+    pool = [(torch.rand(8192, 3, device=dev, generator=g) - 0.5) * 12.0 + torch.tensor([0.0, 0.0, 5.5], device=dev) for _ in range(4)]
+    tgt_sdf = [torch.randn(8192, 1, device=dev, generator=g) * 0.05 for _ in range(4)]
+    with torch.no_grad():
+        target = [cg.render(p, *cam, False, 0)["color"].detach() * 0.5 + 0.25 for p in poses]
+
+    def iteration(lm, gs, opt, L, it):
+        opt.zero_grad()
+        pts, ts = pool[it % 4], tgt_sdf[it % 4]
+        s, isig = lm.get_sdf(pts)
+        grad = lm.get_gradient(pts.clone(), 0.02, None, False, False)[0]                       # analytic (k_numerical_grad = 0)
+        loss = L["sdf"](s, ts, isig) + 0.1 * L["eik"](grad)                                    # :138-188
+        r = gs.render(poses[it % 4], *cam, True, 0)
+        loss = loss + L["photo"](r["color"], target[it % 4])                                   # :237-240
+        vis = r["visibilities"].detach()
+        valid = lm.get_valid_mask(r["samples"].detach()) & (vis > 0.1).squeeze(-1)            # :420-462
+        ids = valid.nonzero().squeeze(-1)
+        assert ids.numel() > 100
+        xs = r["samples"].index_select(0, ids)
+        wts = (r["samples_weights"] * vis).detach().index_select(0, ids)
+        loss = loss + 1e-3 * L["gs_sdf"](lm.get_sdf(xs)[0], wts) / ids.numel()
+        loss.backward()
+        opt.step()
+        gs.train_callback(it, 1000, opt, r)
+        return float(loss.detach()), int(ids.numel())
+
+    L_ref = dict(sdf=ref.sdf_loss, eik=ref.eikonal_loss, gs_sdf=ref.gs_sdf_loss, photo=lambda a, b: 0.8 * ref.rgb_loss(a, b) + 0.2 * ref.dssim_loss(a, b))
+    L_own = dict(sdf=sdfm.sdf_loss, eik=sdfm.eikonal_loss, gs_sdf=sdfm.gs_sdf_loss, photo=lambda a, b: ops.l1_dssim_loss(a, b, 0.8, 0.2))
+    hist = []
+    for it in range(1, 11):
+        a = iteration(rl, rg, ropt, L_ref, it)
+        b = iteration(cm, cg, copt, L_own, it)
+        hist.append((a, b))
+        assert a[1] == b[1], (it, a, b)                                                        # the same visible, occupancy-valid samples
+        assert abs(a[0] - b[0]) <= 1e-4 * abs(a[0]), (it, a, b)
+    assert hist[-1][0][0] < hist[0][0][0], hist                                                # and it trains
+
+    def bulk(x, y, tol, what):
+        d = (x.detach().double() - y.detach().double()).abs() / (y.detach().double().abs().max() + 1e-30)
+        assert float((d > tol).double().mean()) < 1e-3 and float(d.max()) < 0.2, (what, float((d > tol).double().mean()), float(d.max()))
+    rp = rl.named_parameters()
+    layers = (0, 2, 4, 6, 8)
+    bulk(cm.encoder.params_, rp["encoder_local_map"], 1e-3, "hash table after 10 steps")
+    bulk(cm.decoder.params_, torch.cat([rp[f"decoder.{i}.weight"].reshape(-1) for i in layers]), 1e-3, "decoder weights")
+    bulk(cm.decoder.biases_, torch.cat([rp[f"decoder.{i}.bias"] for i in layers]), 1e-3, "decoder biases")
+    for f in PFIELDS:
+        bulk(getattr(cg, f), getattr(rg, f), 1e-3, f)
