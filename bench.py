@@ -805,9 +805,9 @@ def reference_loop(args, sc, views, K, ug6, target, N, W, H, deg, dev):
     lrs = dict(offsets=1.6e-4, scaling=5e-3, quaternion=1e-3, opacity=5e-2, features_dc=2.5e-3, features_rest=2.5e-3 / 20)
     opt = torch.optim.Adam([{"params": [params.views[k]], "lr": lrs[k]} for k in params.views] +
                            [{"params": lm.parameters(), "lr": 1e-4}], eps=1e-15)
-    # loss_utils.cpp:71-117: 11x11 Gaussian window (sigma 1.5), per-channel convolutions
-    g1 = torch.exp(-((torch.arange(11, dtype=torch.float32) - 5) ** 2) / (2 * 1.5 ** 2))
-    win = (g1[:, None] * g1[None, :] / g1.sum() ** 2).to(dev)[None, None].expand(3, 1, 11, 11).contiguous()
+    # loss_utils.cpp:6-21, 71-117: the reference's 11-tap window (sigma 1.5, its floor((x - 11) / 2) form), per-channel convolutions
+    g1 = torch.tensor(ops.ssim_window(), dtype=torch.float32)
+    win = (g1[:, None] * g1[None, :]).to(dev)[None, None].expand(3, 1, 11, 11).contiguous()
 
     def ssim(a, b):
         a, b = a.permute(2, 0, 1)[None], b.permute(2, 0, 1)[None]
