@@ -181,9 +181,9 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
         DepthSamples in = to_samples(s);
         return from_samples(l.filter_sample(in));
       })
-      .def("meshing_", [](LocalMap &l, float res) {
-        l.meshing_(res, false);
-        return std::make_tuple(l.p_mesher_->vec_vertice_, l.p_mesher_->vec_face_);
+      .def("meshing_", [](LocalMap &l, float res) {   // local_map.cpp:329-447 with _save: the chunks' vertices / faces / colours land in the mesher
+        l.meshing_(res, true);
+        return std::make_tuple(l.p_mesher_->vec_vertice_, l.p_mesher_->vec_face_, l.p_mesher_->vec_face_attr_);
       });
 
   // ---- neural_gaussian/neural_gaussian.h

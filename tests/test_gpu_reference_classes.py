@@ -411,3 +411,46 @@ def test_reference_joint_iteration_on_the_dropin_matches_gsdf_model(host, ref):
     bulk(cm.decoder.biases_, torch.cat([rp[f"decoder.{i}.bias"] for i in layers]), 1e-3, "decoder biases")
     for f in PFIELDS:
         bulk(getattr(cg, f), getattr(rg, f), 1e-3, f)
+
+
+def test_reference_meshing_on_the_dropin(host, ref):
+    """LocalMap::meshing_ (local_map.cpp:329-447, the reference's) -> utils::meshgrid_3d, get_valid_mask, get_sdf, mc::marching_cubes
+    (the reference's cumcubes.cpp over this repository's mc::marching_cubes_wrapper), spc_ops::points_to_neighbors for the boundary
+    filter — against the same steps written with this repository's Python operators (tcnn decoder on both sides: identical SDF values,
+    so the meshes must be identical)."""
+    from gs_sdf_amd.mesher import marching_cubes
+    dev = torch.device("cuda:0")
+    rl, cm, cfg = make_maps(host, ref, 1)
+    ref.configure(dict(vis_attribute=0, vis_batch_pt_num=1 << 30, dataset_type=0))          # one chunk, grey vertices, OpenCV world
+    g = torch.Generator(device=dev).manual_seed(13)
+    pts = (torch.rand(3000, 3, device=dev, generator=g) - 0.5) * torch.tensor([6.0, 6.0, 2.0], device=dev) + torch.tensor([0.0, 0.0, 5.5], device=dev)
+    rl.update_octree_as(pts, False)
+    cm.update_octree_as(pts, False)
+    res = 0.125
+    verts, faces, colors = rl.meshing_(res)
+    assert len(verts) == 1 and faces[0].shape[0] > 1000, (len(verts), [tuple(f.shape) for f in faces])
+    v_ref, f_ref = verts[0].to(dev), faces[0].to(dev)
+    assert bool((colors[0] == 127).all())
+    # the same steps over gsdf_model / the Python operators
+    pos = cm.pos_W_M_.reshape(3)
+    lo = (cm.xyz_min_W_.reshape(3) - pos + 0.5 * cfg.leaf_size).tolist()                     # xyz_min_M_margin_ (sub_map.cpp:17-18)
+    hi = (cm.xyz_max_W_.reshape(3) - pos - 0.5 * cfg.leaf_size).tolist()
+    c = pos.tolist()
+    lower = [lo[k] + c[k] for k in range(3)]
+    ax = [torch.arange(lower[k], hi[k] + c[k] + res, res, device=dev) for k in range(3)]
+    grid = torch.stack(torch.meshgrid(*ax, indexing="ij"), -1)
+    shape = grid.shape[:3]
+    xyz = grid.reshape(-1, 3)
+    mask = cm.get_valid_mask(xyz)
+    sdf = torch.full((xyz.shape[0], 1), 1e-6, device=dev)
+    with torch.no_grad():
+        sdf[mask] = cm.get_sdf(xyz[mask])[0]
+    upper = [lower[k] + shape[k] * res for k in range(3)]
+    v, f = marching_cubes(sdf.view(*shape), 0.0, lower, upper, "reference")
+    q = (v / res).floor().to(torch.int16)
+    nb = host.points_to_neighbors(q).view(-1, 3).to(torch.float32) * res
+    ok = cm.get_valid_mask(nb).view(-1, 27).all(1)
+    keep = ok[f.view(-1).long()].view(-1, 3).all(-1).nonzero().view(-1)
+    f = f.index_select(0, keep)
+    assert v.shape == v_ref.shape and f.shape == f_ref.shape, (v.shape, v_ref.shape, f.shape, f_ref.shape)
+    assert torch.equal(v, v_ref) and torch.equal(f.to(f_ref.dtype), f_ref)
