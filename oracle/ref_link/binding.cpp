@@ -17,6 +17,7 @@
 #include "optimizer/optimizer_utils/optimizer_utils.h"
 #include "params/params.h"
 #include "utils/utils.h"
+#include "mesher/cumcubes/include/cumcubes.hpp"
 
 namespace py = pybind11;
 using torch::Tensor;
@@ -113,6 +114,10 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     cam.fx = fx; cam.fy = fy; cam.cx = cx; cam.cy = cy; cam.width = w; cam.height = h;
     return sensor::depth_to_normal(cam, pose, depth);
   });
+
+  // ---- mesher/cumcubes/include/cumcubes.hpp: the mesh file writer (host code of the reference; the kernels behind mc::marching_cubes are
+  //      this repository's, reached through LocalMap.meshing_)
+  m.def("save_mesh_as_ply", [](const std::string &path, Tensor v, Tensor f, Tensor c) { mc::save_mesh_as_ply(path, v, f, c); });
 
   // ---- optimizer/optimizer_utils/optimizer_utils.h on a torch::optim::Adam
   py::class_<AdamBox>(m, "Adam")

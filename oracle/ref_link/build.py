@@ -90,7 +90,12 @@ def load():
     import torch  # noqa: F401  (libtorch must be loaded first)
     spec = importlib.util.spec_from_file_location(NAME, p)
     mod = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(mod)
+    try:
+        spec.loader.exec_module(mod)
+    except (ImportError, OSError) as e:   # a module left over from before libgsdf_torch.so changed: rebuild (python oracle/ref_link/build.py)
+        import warnings
+        warnings.warn(f"oracle/ref_link: {os.path.basename(p)} does not load ({e}); rebuild it with python oracle/ref_link/build.py")
+        return None
     return mod
 
 

@@ -43,6 +43,9 @@ def inputs():
     inp["ray_o"] = n(20, 3) * 0.1
     inp["ray_d"] = torch.nn.functional.normalize(n(20, 3), dim=-1)
     inp["ray_depth"] = 1.0 + 3.0 * r(20, 1)
+    # a small coloured mesh for the PLY writer
+    inp["mesh_v"], inp["mesh_f"] = n(7, 3), torch.randint(0, 7, (5, 3), generator=g, dtype=torch.int32)
+    inp["mesh_c"] = torch.randint(0, 256, (7, 3), generator=g, dtype=torch.int32).to(torch.uint8)
     # Adam surgery: six parameter groups of 12 rows, gradients for 6 steps, the extension rows
     for k, sh in enumerate(ADAM_SHAPES):
         inp[f"adam_p{k}"] = n(12, *sh)
@@ -155,6 +158,11 @@ def evaluate(m, inp):
     ss = m.sample_surface_pts(rays, 3, 0.05)
     for k in ("xyz", "ray_sdf", "depth", "ridx"):
         out["surf_" + k] = _np(ss[k])
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        path = d + "/mesh.ply"
+        m.save_mesh_as_ply(path, inp["mesh_v"], inp["mesh_f"], inp["mesh_c"])
+        out["mesh_ply_bytes"] = np.frombuffer(open(path, "rb").read(), np.uint8).copy()
     for phase, snap in enumerate(adam_script(_RefAdam(m), inp)):
         for j, arr in enumerate(snap):
             out[f"adam_{phase}_{j // 3}_{'pmv'[j % 3]}"] = arr

@@ -9,6 +9,7 @@ seeded inputs in tests/golden/reference_intree.npz.  Here, on any machine:
       the product's window for gsdf_l1_dssim_* (gs_sdf_amd.ops.ssim_window),
       depth -> normal (oracle.image_loss_ref.depth_to_normal                          <- cameras.hpp:176-226),
       quaternion / 6-D rotation helpers, free-space and near-surface ray samples      <- utils.cpp:336-393, 538-558, 693-719),
+      the mesh file writer (gs_sdf_amd.mesher.save_mesh_as_ply, byte for byte           <- cumcubes.cpp:29-79),
       Adam state surgery of the NeuralGS mirror (prune / append / prune+append / replace, with Adam steps between them
                                                                                        <- optimizer_utils.cpp:5-165);
   * where the compiled module exists (this container; the GPU box through the prebuilt oracle/_ref), the stored outputs are
@@ -132,6 +133,14 @@ def test_ray_samplers_match_the_reference_draw_for_draw():
     close(xyz, OUT["surf_xyz"], 1e-6, "surface xyz")
     close(sdf, OUT["surf_ray_sdf"], 1e-6, "surface ray_sdf")
     assert np.array_equal(ridx.numpy(), OUT["surf_ridx"])
+
+
+def test_mesh_file_writer_matches_the_reference_byte_for_byte(tmp_path):
+    """mc::save_mesh_as_ply (cumcubes.cpp:29-79) against gs_sdf_amd.mesher.save_mesh_as_ply"""
+    from gs_sdf_amd.mesher import save_mesh_as_ply
+    path = str(tmp_path / "mesh.ply")
+    save_mesh_as_ply(path, INP["mesh_v"], INP["mesh_f"], INP["mesh_c"])
+    assert open(path, "rb").read() == OUT["mesh_ply_bytes"].tobytes()
 
 
 class _MirrorAdam:
