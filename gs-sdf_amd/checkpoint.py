@@ -9,7 +9,8 @@ module, i.e. a libtorch serialize archive (a TorchScript zip) whose entries are 
 
 The same archive is written here with torch.jit (what libtorch's OutputArchive produces and InputArchive::load_from reads),
 so `torch::load(local_map_ptr, path)` of a reference build LINKED AGAINST THE DROP-IN `tcnn_binding` accepts it and files such a
-build wrote load here; tests/test_checkpoint_pt.py round-trips both directions through a libtorch C++ program.
+build wrote load here; tests/test_checkpoint_pt.py round-trips both directions through a libtorch C++ program, and tests/test_reference_intree_pins.py through
+the REFERENCE'S OWN LocalMap module (compiled from /root/reference by oracle/ref_link, linked with the drop-in tcnn_binding).
 
 Flat "decoder" layouts (decoder_implementation 1).  The drop-in TCNNNetwork keeps the weights UNPADDED, [out, in] row-major layer
 after layer (last layer 2 x 64).  Upstream tiny-cuda-nn's FullyFusedMLP pads the output width to a multiple of 16 (last layer

@@ -191,6 +191,10 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
         return std::make_tuple(l.p_mesher_->vec_vertice_, l.p_mesher_->vec_face_, l.p_mesher_->vec_face_attr_);
       });
 
+  // NeuralSLAM::export_checkpoint / load_checkpoint (neural_mapping.cpp:1331-1352): torch::save / torch::load of the LocalMap module
+  m.def("save_local_map", [](LocalMap::Ptr lm, const std::string &path) { torch::save(lm, path); });
+  m.def("load_local_map", [](LocalMap::Ptr lm, const std::string &path) { torch::load(lm, path); });
+
   // ---- neural_gaussian/neural_gaussian.h
   py::class_<NeuralGS, std::shared_ptr<NeuralGS>>(m, "NeuralGS")
       .def(py::init([](py::object lm, const Tensor &points, int num_train_data, float spatial_scale, bool sdf_enable) {

@@ -199,3 +199,62 @@ def test_adam_state_surgery_matches_optimizer_utils():
     # rows that survive keep their moments, appended rows start from zero moments but share the group's step count, a replaced
     # tensor restarts its moments (the bias correction keeps counting): all visible in the reference's numbers
     assert OUT["adam_1_0_p"].shape[0] == 8 and OUT["adam_2_0_p"].shape[0] == 11 and OUT["adam_3_0_p"].shape[0] == 11 and OUT["adam_4_0_p"].shape[0] == 14
+
+
+@pytest.mark.parametrize("impl", [0, 1])
+def test_local_map_checkpoint_interchanges_with_the_references_module(tmp_path, impl):
+    """local_map_checkpoint.pt both ways with the REFERENCE'S LocalMap (its registered names, its torch::nn::Sequential decoder or the
+    flat tcnn parameter of the drop-in): torch::save(local_map_ptr) -> checkpoint.load_local_map_checkpoint, and
+    checkpoint.save_local_map_checkpoint -> torch::load(local_map_ptr) (neural_mapping.cpp:1331-1352)."""
+    import types
+    from gs_sdf_amd.checkpoint import load_local_map_checkpoint, save_local_map_checkpoint
+    m = ref_build.load()
+    if m is None:
+        pytest.skip("oracle/_ref/_gsdf_reference*.so not built (needs /root/reference: python oracle/ref_link/build.py)")
+    m.configure(dict(device="cpu", decoder_implementation=impl, n_levels=8, log2_hashmap_size=14, n_features_per_level=2, hidden_dim=64, geo_num_layer=3))
+    torch.manual_seed(17 + impl)
+    rl = m.LocalMap(torch.zeros(3))
+    rp = rl.named_parameters()
+    n_table = rp["encoder_local_map"].numel()
+    with torch.no_grad():
+        rp["encoder_local_map"].copy_(torch.randn(n_table))
+
+    def mirror(seed):   # the attributes checkpoint.py touches (the real mirror needs the HIP library), sized like the reference's map
+        g = torch.Generator().manual_seed(seed)
+        enc = types.SimpleNamespace(params_=torch.randn(n_table, generator=g))
+        if impl == 0:
+            mods = [torch.nn.Linear(16, 64), torch.nn.ReLU(True)]
+            for _ in range(3):
+                mods += [torch.nn.Linear(64, 64), torch.nn.ReLU(True)]
+            dec = torch.nn.Sequential(*mods, torch.nn.Linear(64, 2))
+        else:
+            dims = [16, 64, 64, 64, 2]
+            dec = types.SimpleNamespace(dims=dims, params_=torch.randn(sum(i * o for i, o in zip(dims[:-1], dims[1:])), generator=g), biases_=None)
+        return types.SimpleNamespace(encoder=enc, decoder=dec, decoder_implementation=impl)
+
+    def as_dict(lm):
+        d = {"encoder_local_map": lm.encoder.params_.detach()}
+        if impl == 1:
+            d["decoder"] = lm.decoder.params_.detach()
+        else:
+            for k, mod in enumerate(lm.decoder):
+                if isinstance(mod, torch.nn.Linear):
+                    d[f"decoder.{k}.weight"], d[f"decoder.{k}.bias"] = mod.weight.detach(), mod.bias.detach()
+        return d
+    # reference -> here
+    p1 = str(tmp_path / "from_reference.pt")
+    m.save_local_map(rl, p1)
+    got = as_dict(load_local_map_checkpoint(mirror(1), p1))
+    assert set(got) == set(rp)
+    for k in rp:
+        assert torch.equal(got[k].reshape(-1), rp[k].detach().reshape(-1)), k
+    # here -> reference
+    src = mirror(2)
+    p2 = str(tmp_path / "from_here.pt")
+    save_local_map_checkpoint(src, p2)
+    rl2 = m.LocalMap(torch.zeros(3))
+    m.load_local_map(rl2, p2)
+    want, rp2 = as_dict(src), rl2.named_parameters()
+    assert set(want) == set(rp2)
+    for k in want:
+        assert torch.equal(rp2[k].detach().reshape(-1), want[k].reshape(-1)), k
