@@ -21,3 +21,13 @@ inline std::tuple<at::Tensor, at::Tensor> eigh(const at::Tensor &a, c10::string_
 }  // namespace linalg
 }  // namespace torch
 #endif
+
+// neural_mapping.cpp calls c10::cuda::CUDACachingAllocator::emptyCache() before its memory reports (":301, :361, ..."); a CUDA libtorch brings
+// the declaration in through <torch/torch.h>, this image's does not.  Inert here: it only affects the reported memory figures.
+namespace c10 {
+namespace cuda {
+namespace CUDACachingAllocator {
+inline void emptyCache() {}
+}  // namespace CUDACachingAllocator
+}  // namespace cuda
+}  // namespace c10

@@ -42,6 +42,16 @@ enum ColorConversionCodes { COLOR_RGB2BGR = 4 };
 inline void minMaxLoc(const Mat &, double *, double *, void * = nullptr, void * = nullptr, const Mat & = Mat()) {}
 inline void applyColorMap(const Mat &, Mat &, int) {}
 inline void cvtColor(const Mat &, Mat &, int) {}
+inline bool imwrite(const std::string &, const Mat &) { return true; }
+inline void resize(const Mat &, Mat &, Size, double = 0, double = 0, int = 1) {}
+struct VideoWriter {
+  VideoWriter() = default;
+  VideoWriter(const std::string &, int, double, Size, bool = true) {}
+  static int fourcc(char, char, char, char) { return 0; }
+  bool isOpened() const { return false; }
+  void release() {}
+  void write(const Mat &) {}
+};
 enum { CV_32FC1 = 5, CV_32FC3 = 21, CV_8UC3 = 16, CV_16SC2 = 11, CV_32F = 5 };
 inline Mat getOptimalNewCameraMatrix(const Mat &, const Mat &, Size, double, Size = Size(), void * = nullptr, bool = false) { return Mat(); }
 inline void initUndistortRectifyMap(const Mat &, const Mat &, const Mat &, const Mat &, Size, int, Mat &, Mat &) {}

@@ -24,5 +24,6 @@ struct PlyFile {
 namespace ply_utils {
 inline tinyply::Type torch_type_to_ply_type(c10::ScalarType) { return tinyply::Type::FLOAT32; }
 inline bool export_to_ply(const std::string &, const torch::Tensor &, const torch::Tensor & = torch::Tensor(), const torch::Tensor & = torch::Tensor()) { return true; }
+inline bool read_ply_file_to_map_tensor(const std::string &, std::map<std::string, torch::Tensor> &, const torch::Device & = torch::kCPU) { return false; }
 inline bool read_ply_file_to_tensor(const std::string &, std::map<std::string, torch::Tensor> &, const torch::Device & = torch::kCPU) { return true; }
 }  // namespace ply_utils

@@ -5,10 +5,11 @@ on the GPU box): `g++ -fsyntax-only` of
     include/neural_net/sub_map.cpp         (OctreeAS build / query through kaolin_wisp_cpp, :22-35,76-80)
     include/neural_net/local_map.cpp       (LocalMap ctor, get_sdf, get_gradient, sample, meshing, :16-173,449-516)
     include/neural_gaussian/neural_gaussian.cpp   (rasterization_2dgs_sdf :129-271, NeuralGS, distCUDA2 :314)
+    include/neural_mapping/neural_mapping.cpp     (NeuralSLAM: sample :73-104, sdf / gs batch iterations :138-300, gs_train :400-486, checkpoints)
 
 with this repository's headers standing where the un-vendored submodules' headers would be
 (gs-sdf_amd/host/{gsplat_cpp,tcnn_binding,kaolin_wisp_cpp,kaolin,spatial.h} + compat/nlohmann) and inert stand-ins
-(tests/ref_compile_stubs/; the same set oracle/ref_link/build.py compiles and LINKS the reference's sources with) for what is neither on the path nor in this image: OpenCV, PCL/Eigen, the CUDA runtime header,
+(tests/ref_compile_stubs/; the same set oracle/ref_link/build.py compiles and LINKS the reference's sources with) for what is neither on the path nor in this image: OpenCV, PCL, Eigen, the CUDA runtime header,
 and the reference's other un-vendored submodules llog and ply_utils/tinyply.  Every call the reference makes into the
 replaced submodules therefore type-checks against the replacement's declarations: argument order, types, return tuples,
 member names (params_, get_out_dim, ...).  Nothing from /root/reference is copied; the sources are compiled where they lie."""
@@ -21,7 +22,10 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF = "/root/reference/include"
-FILES = ["neural_net/encoding_map.cpp", "neural_net/sub_map.cpp", "neural_net/local_map.cpp", "neural_gaussian/neural_gaussian.cpp"]
+FILES = ["neural_net/encoding_map.cpp", "neural_net/sub_map.cpp", "neural_net/local_map.cpp", "neural_gaussian/neural_gaussian.cpp",
+         # the trainer itself (NeuralSLAM::train / gs_train / sample, the loop north_star names): built without ENABLE_ROS it needs nothing but
+         # libtorch, the drop-in headers and the inert stand-ins; it is type-checked here (linking it needs the data loader: OpenCV / PCL I/O)
+         "neural_mapping/neural_mapping.cpp"]
 
 
 def _flags():
