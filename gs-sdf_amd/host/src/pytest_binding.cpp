@@ -84,6 +84,17 @@ PYBIND11_MODULE(_gsdf_host, m) {
                               torch::Tensor decoder_grad) {
     return gsdf_extras::gs_sdf_coupling(samples, ids, weights, *enc, *dec, origin, map_size_inv, scale, delta, w_eik, table_grad, decoder_grad);
   });
+  // the defaults of gsdf_extras::JointConfig (tests/test_reference_config_defaults.py holds them to the reference's config/base.yaml)
+  m.def("joint_config_defaults", [] {
+    gsdf_extras::JointConfig c;
+    py::dict d;
+    d["near"] = c.near_plane; d["far"] = c.far_plane; d["rgb_weight"] = c.rgb_w; d["dssim_weight"] = c.dssim_w; d["eikonal_weight"] = c.eik_w;
+    d["gs_sdf_weight"] = c.gs_sdf_w; d["visible_thr"] = c.vis_thresh; d["sdf_weight"] = c.sdf_w; d["align_weight"] = c.align_w;
+    d["render_normal_weight"] = c.normal_w; d["isotropic_weight"] = c.isotropic_w; d["analytic"] = c.analytic; d["reference_terms"] = c.reference_terms;
+    d["lr_end"] = c.lr_sdf;
+    d["lrs"] = std::vector<double>{c.lr_offsets, c.lr_scaling, c.lr_quaternion, c.lr_opacity, c.lr_features_dc, c.lr_features_rest};
+    return d;
+  });
   py::class_<gsdf_extras::JointIteration, std::shared_ptr<gsdf_extras::JointIteration>>(m, "JointIteration")
       .def(py::init([](const torch::Tensor &anchors, const std::vector<torch::Tensor> &fields, std::shared_ptr<TCNNEncoding> enc,
                        std::shared_ptr<TCNNNetwork> dec, std::vector<float> origin, double map_size, double bce_sigma, int occ_level, int width,

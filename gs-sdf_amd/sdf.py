@@ -752,7 +752,7 @@ class LocalMap:
     """The SDF half of the reference's `LocalMap` (include/neural_net/local_map.{h,cpp}): hash-grid encoder +
     decoder, `get_sdf`, `get_gradient` (numerical 6-point stencil or analytic via autograd)."""
 
-    def __init__(self, map_origin, map_size, bce_sigma=0.02, decoder_implementation=1, hidden_dim=64, geo_num_layer=3,
+    def __init__(self, map_origin, map_size, bce_sigma=0.02, decoder_implementation=0, hidden_dim=64, geo_num_layer=3,
                  device="cuda", seed=0, encoding_config=None, decoder_backend="fused"):
         """decoder_implementation as config/base.yaml:12: 0 = the torch::nn::Sequential topology (biases, geo_num_layer + 1 hidden
         matmuls; the reference's DEFAULT), 1 = tcnn FullyFusedMLP (bias free, geo_num_layer hidden matmuls).  Both run on the

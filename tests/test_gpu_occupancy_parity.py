@@ -85,7 +85,7 @@ def test_local_map_sampler_matches_composition_of_oracle_pieces():
     from gs_sdf_amd.neural_gs import sample_ray_batch
     leaf, inner = 0.05, 12.0
     level = int(np.ceil(np.log2((inner + 2 * leaf) / leaf)))
-    lm = sdfm.LocalMap([0.5, -0.25, 1.0], (2 ** level) * leaf, device=dev, seed=0)
+    lm = sdfm.LocalMap([0.5, -0.25, 1.0], (2 ** level) * leaf, decoder_implementation=1, device=dev, seed=0)
     lm.set_bounds(inner, leaf)
     assert lm.octree_level == level == 8
     rng = np.random.default_rng(3)
@@ -131,7 +131,7 @@ def test_as_occ_prior_ply_round_trip(tmp_path):
     """export (voxel minimum corners, neural_mapping.cpp:755-762) -> load with is_prior (:1367-1373) rebuilds the same
     structure; the map size is a power of two times the leaf, so the corner coordinates are exact in fp32."""
     import gs_sdf_amd.sdf as sdfm
-    lm = sdfm.LocalMap([1.0, -2.0, 0.5], 256 * 0.0625, device=dev, seed=0)
+    lm = sdfm.LocalMap([1.0, -2.0, 0.5], 256 * 0.0625, decoder_implementation=1, device=dev, seed=0)
     lm.set_bounds(16.0 - 0.125, 0.0625)
     g = torch.Generator().manual_seed(4)
     pts = ((torch.rand(50_000, 3, generator=g) - 0.5) * 12.0 + torch.tensor([1.0, -2.0, 0.5])).to(dev)
