@@ -201,6 +201,16 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
         auto l = lm.is_none() ? LocalMap::Ptr() : lm.cast<LocalMap::Ptr>();
         return std::make_shared<NeuralGS>(l, points, num_train_data, spatial_scale, sdf_enable);
       }))
+      // NeuralGS(local_map, gs.ply) (neural_gaussian.cpp:456-461): the reference's own loader; no kernel involved, runs on k_device = cpu too
+      .def_static("from_ply", [](py::object lm, const std::string &path) {
+        auto l = lm.is_none() ? LocalMap::Ptr() : lm.cast<LocalMap::Ptr>();
+        return std::make_shared<NeuralGS>(l, std::filesystem::path(path));
+      })
+      .def("export_gs_to_ply", [](NeuralGS &g, const std::string &path) {
+        std::filesystem::path p(path);
+        g.export_gs_to_ply(p);
+      })
+      .def("load_ply_to_gs", [](NeuralGS &g, const std::string &path) { g.load_ply_to_gs(path); })
       .def_readwrite("anchors_", &NeuralGS::anchors_)
       .def_readwrite("offsets_", &NeuralGS::offsets_)
       .def_readwrite("scaling_", &NeuralGS::scaling_)

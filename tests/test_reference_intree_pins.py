@@ -10,6 +10,7 @@ seeded inputs in tests/golden/reference_intree.npz.  Here, on any machine:
       depth -> normal (oracle.image_loss_ref.depth_to_normal                          <- cameras.hpp:176-226),
       quaternion / 6-D rotation helpers, free-space and near-surface ray samples      <- utils.cpp:336-393, 538-558, 693-719),
       the mesh file writer (gs_sdf_amd.mesher.save_mesh_as_ply, byte for byte           <- cumcubes.cpp:29-79),
+      gs.ply through the reference's own NeuralGS loader and exporter, local_map_checkpoint.pt through torch::save / load of its LocalMap,
       Adam state surgery of the NeuralGS mirror (prune / append / prune+append / replace, with Adam steps between them
                                                                                        <- optimizer_utils.cpp:5-165);
   * where the compiled module exists (this container; the GPU box through the prebuilt oracle/_ref), the stored outputs are
@@ -258,3 +259,35 @@ def test_local_map_checkpoint_interchanges_with_the_references_module(tmp_path, 
     assert set(want) == set(rp2)
     for k in want:
         assert torch.equal(rp2[k].detach().reshape(-1), want[k].reshape(-1)), k
+
+
+@pytest.mark.parametrize("deg", [0, 1, 3])
+def test_gs_ply_interchanges_with_the_references_loader_and_exporter(tmp_path, deg):
+    """gs.ply both ways with the REFERENCE'S NeuralGS::load_ply_to_gs / export_gs_to_ply (neural_gaussian.cpp:928-1188; which properties, in
+    which order, through which transposes, the log(1e-6) third scale — the container is written by a functional stand-in for tinyply,
+    tests/ref_compile_stubs/utils/ply_utils): the file the mirror writes loads into the reference's tensors, and the reference writes the
+    same bytes back."""
+    from gs_sdf_amd.neural_gs import GSConfig, NeuralGS, export_gs_to_ply, load_ply_to_gs
+    m = ref_build.load()
+    if m is None:
+        pytest.skip("oracle/_ref/_gsdf_reference*.so not built (needs /root/reference: python oracle/ref_link/build.py)")
+    m.configure(dict(device="cpu", sh_degree=deg))
+    g = torch.Generator().manual_seed(31 + deg)
+    n, nr = 257, (deg + 1) ** 2 - 1
+    gs = NeuralGS(torch.randn(n, 3, generator=g), torch.randn(n, 3, generator=g), torch.randn(n, 4, generator=g), torch.randn(n, generator=g),
+                  torch.rand(n, 1, 3, generator=g), torch.randn(n, nr, 3, generator=g), GSConfig(sh_degree=deg))
+    p1 = str(tmp_path / "mirror.ply")
+    export_gs_to_ply(gs, p1)
+    rg = m.NeuralGS.from_ply(None, p1)
+    assert rg.sh_degree_to_use_ == deg
+    assert torch.equal(rg.anchors_, gs.anchors_) and float(rg.offsets_.abs().max()) == 0.0
+    assert torch.equal(rg.features_dc_, gs.features_dc_.detach()) and tuple(rg.features_rest_.shape) == (n, nr, 3)
+    assert torch.equal(rg.features_rest_, gs.features_rest_.detach())
+    assert torch.equal(rg.opacity_, gs.opacity_.detach()) and torch.equal(rg.quaternion_, gs.quaternion_.detach())
+    assert torch.equal(rg.scaling_[:, :2], gs.scaling_.detach()[:, :2])
+    assert bool((rg.scaling_[:, 2] == torch.tensor(1e-6).log()).all())          # the exporter's third scale (3DGS viewers), :1003-1008
+    p2 = str(tmp_path / "reference.ply")
+    rg.export_gs_to_ply(p2)
+    assert open(p2, "rb").read() == open(p1, "rb").read()
+    back = load_ply_to_gs(p2)
+    assert torch.equal(back.anchors_, gs.anchors_) and torch.equal(back.features_rest_.detach(), gs.features_rest_.detach())
