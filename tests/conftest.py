@@ -13,6 +13,19 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run by the driver with -m gpu)")
 
 
+@pytest.fixture(autouse=True)
+def _flush_c_stdio():
+    """The C++ code under test (the drop-in layer, and above all the reference's own sources in oracle/_ref) prints through C stdio, which is
+    fully buffered on a pipe: without a flush inside the test its output would spill AFTER pytest's summary line.  Flushed here it is
+    captured with the test it belongs to."""
+    yield
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+
+
 @pytest.fixture(scope="session")
 def oracle():
     from oracle import oracle as orc
