@@ -869,8 +869,7 @@ def reference_loop(args, sc, views, K, ug6, target, N, W, H, deg, dev):
 
 def _err_stats(got, ref, clean=None):
     """Scaled error (|got-ref| / max(|ref|, mean|ref|)) per row: rows above 1e-4, worst, relative L2 — over all rows and, when
-    `clean` (bool over the leading dims) is given, over the decision-robust rows (oracle.rasterize_2dgs_fragility: the gate of
-    tests/util.py applies to those)."""
+    `clean` (bool over the leading dims) is given, over those rows too ("masked": the decoder's points away from a ReLU kink)."""
     import numpy as np
     got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64)
     if ref.size == 0:
@@ -883,7 +882,7 @@ def _err_stats(got, ref, clean=None):
            "rows_above_1e-4": int((e > 1e-4).sum())}
     if clean is not None:
         c = np.asarray(clean).reshape(R)
-        out["decision_robust"] = {"rows": int(c.sum()), "rows_above_1e-4": int((e[c] > 1e-4).sum()), "worst": float(e[c].max()) if c.any() else 0.0,
+        out["masked"] = {"rows": int(c.sum()), "rows_above_1e-4": int((e[c] > 1e-4).sum()), "worst": float(e[c].max()) if c.any() else 0.0,
                                   "rel_l2": float(np.linalg.norm((g2 - r2)[c]) / (np.linalg.norm(r2[c]) + 1e-30))}
     return out
 
@@ -944,18 +943,27 @@ def cpu_baseline(sc, views, params, N, W, H, deg, n_sdf_points, dev):
     # forward / backward and of the projection backward (truth: the fp32 CPU build itself is 1e-2 off on these gradients,
     # profiles/parity_r02.json)
     f64 = lambda a: np.asarray(a, np.float64)
-    fw64 = orc.rasterize_2dgs_fwd(p["means2d"], p["ray_transforms"], col, opa, p["normals"], W, H, 16, offs, flat, prec="f64")
-    g64 = orc.rasterize_2dgs_bwd(p["means2d"], p["ray_transforms"], col, opa, p["normals"], W, H, 16, offs, flat,
-                                 fw64["render_alphas"], fw64["last_ids"], fw64["median_ids"], n(ug["v_render_colors"]),
-                                 n(ug["v_render_depths"]), n(ug["v_render_alphas"]), n(ug["v_render_normals"]),
-                                 n(ug["v_render_median"]), absgrad=False, prec="f64")
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    # DECISION-MATCHED reference (tests/util.py, oracle/splat_oracle.c): the kernel's decisions in every decision-fragile pixel are
+    # traced (instrumented instantiation of the same kernel on the same inputs) and the fp64 oracle is evaluated under them: no
+    # pixel and no splat is excluded from the comparison below
+    pf, sf, _ = orc.rasterize_2dgs_fragility(p["means2d"], p["ray_transforms"], opa, W, H, 16, offs, flat)
+    rows, stride, n_rows = orc.trace_plan(pf, offs, flat.shape[0])
+    tr = ops.rasterize_fwd_instr(t(p["means2d"]), t(p["ray_transforms"]), t(col), t(opa), t(p["normals"]), W, H, t(offs), t(flat),
+                                 trace_rows=t(rows), trace_stride=stride)
+    bits = n(tr["trace_bits"])
+    fw64 = orc.rasterize_2dgs_fwd_matched(p["means2d"], p["ray_transforms"], col, opa, p["normals"], W, H, 16, offs, flat, trace_rows=rows,
+                                          trace_bits=bits, prec="f64")
+    g64 = orc.rasterize_2dgs_bwd_matched(p["means2d"], p["ray_transforms"], col, opa, p["normals"], W, H, 16, offs, flat,
+                                         fw64["render_alphas"], fw64["last_ids"], fw64["median_ids"], n(ug["v_render_colors"]),
+                                         n(ug["v_render_depths"]), n(ug["v_render_alphas"]), n(ug["v_render_normals"]),
+                                         n(ug["v_render_median"]), trace_rows=rows, trace_bits=bits, prec="f64")
     pb64 = orc.projection_2dgs_bwd(means, quats, scales, n(view), n(sc["K"]), W, H, p["camera_ids"], p["gaussian_ids"],
                                    f64(g64["v_means2d"]), np.zeros(M, np.float64), f64(g64["v_ray_transforms"]), f64(g64["v_normals"]),
                                    prec="f64")
     vsh64 = orc.view_colors_bwd(n(view), means, n(sc["sh"]), p["camera_ids"], p["gaussian_ids"], deg, f64(g64["v_colors"]), prec="f64")   # (v_sh, v_means)
     vop64 = np.zeros(N)
     np.add.at(vop64, p["gaussian_ids"], f64(g64["v_opacities"]))
-    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
     leaves = [t(a).requires_grad_(True) for a in (means, quats, scales, opac, n(sc["sh"]))]
     colors, alphas, meta = ops.rasterization_2dgs_sdf(*leaves, view.to(dev), sc["K"].to(dev), W, H, "RGB+D", 0.05, 300.0, 0.0, deg)
     ugd = {k: v.to(dev) for k, v in ug.items()}
@@ -967,28 +975,41 @@ def cpu_baseline(sc, views, params, N, W, H, deg, n_sdf_points, dev):
             + (meta["render_median"] * ugd["v_render_median"]).sum())
     loss.backward()
     torch.cuda.synchronize()
-    # decision-robust pixels / splats of this compositing problem (tests/util.py: the element-wise 1e-4 gate applies to them)
-    pf, sf, _ = orc.rasterize_2dgs_fragility(p["means2d"], p["ray_transforms"], opa, W, H, 16, offs, flat)
-    pix_ok, splat_ok = pf == 0, sf == 0
-    gauss_ok = np.ones(N, bool)
-    gauss_ok[p["gaussian_ids"][~splat_ok]] = False
+    EPS32, COND_C = 2.0 ** -24, 8.0
+
+    def matched(got, ref, bound):
+        """|got - ref| <= 1e-4 max(|ref|, mean|ref|) + COND_C eps32 bound for every element (tests/util.py: matched_stats)"""
+        got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64)
+        b = np.asarray(bound, np.float64)
+        b = b.reshape(ref.shape) if b.size == ref.size else np.broadcast_to(b.reshape(b.shape + (1,) * (ref.ndim - b.ndim)), ref.shape)
+        base = 1e-4 * np.maximum(np.abs(ref), np.abs(ref).mean() + 1e-30)
+        err = np.abs(got - ref)
+        return {"elements": int(err.size), "above_1e-4": int((err > base).sum()), "worst_over_1e-4_bar": float((err / base).max()),
+                "worst_over_tolerance": float((err / (base + COND_C * EPS32 * b)).max()),
+                "rel_l2": float(np.linalg.norm(got - ref) / (np.linalg.norm(ref) + 1e-30))}
+    pb = fw64["pix_bound"]
     par = {"integer_outputs_bit_exact": bool(np.array_equal(n(meta["gaussian_ids"]), p["gaussian_ids"]) and np.array_equal(n(meta["radii"]), p["radii"])
                                              and np.array_equal(n(meta["flatten_ids"]), flat) and np.array_equal(n(meta["isect_offsets"]), offs)
                                              and np.array_equal(n(meta["tiles_per_gauss"]), tpg)),
-           "excluded": {"pixels": float((~pix_ok).mean()), "splats": float((~splat_ok).mean()),
-                        "what": "decision margin (alpha >= 1/255, T <= 1e-4, median, footprint branch, clamp) within 16x the fp32 evaluation error, "
-                                "or splat blended edge-on (cancellation of z.z above 8x)"},
-           "render_colors": _err_stats(n(colors[..., :3]), fw64["render_colors"], pix_ok), "render_depths": _err_stats(n(colors[..., 3:4]), fw64["render_depths"], pix_ok),
-           "render_alphas": _err_stats(n(alphas), fw64["render_alphas"], pix_ok), "render_normals": _err_stats(n(rn_cam), fw64["render_normals"], pix_ok),
-           "visibilities": _err_stats(n(meta["visibilities"]), fw64["visibilities"], splat_ok),
-           "v_densify": _err_stats(n(meta["gradient_2dgs"].grad), g64["v_densify"], splat_ok),
-           "v_means (compositing + projection + SH backward)": _err_stats(n(leaves[0].grad), pb64[0] + vsh64[1], gauss_ok),
-           "v_quats (compositing + projection backward)": _err_stats(n(leaves[1].grad), pb64[1], gauss_ok), "v_scales": _err_stats(n(leaves[2].grad), pb64[2], gauss_ok),
-           "v_opacities": _err_stats(n(leaves[3].grad), vop64, gauss_ok), "v_sh": _err_stats(n(leaves[4].grad), vsh64[0], gauss_ok),
-           "note": "HIP path vs the oracle on the bench workload's first view: ids / radii / bins / offsets bit-exact against the fp32 build; floats "
-                   "against the fp64 build, per row (pixel / splat): rows above 1e-4, worst scaled error, relative L2 — over ALL rows and over the "
-                   "decision-robust rows (oracle.rasterize_2dgs_fragility; tests/util.py gates the latter element-wise at 1e-4, "
-                   "tests/test_gpu_baseline_shapes.py runs the same comparison at every BASELINE shape)"}
+           "decision_matching": {"traced_pixels": n_rows, "traced_fraction": n_rows / max(pf.size, 1), "excluded_pixels": 0, "excluded_splats": 0,
+                                 "flips (count, worst margin in fp32-evaluation errors)": fw64["flips"],
+                                 "last_ids_identical": bool(np.array_equal(n(tr["last_ids"]), fw64["last_ids"])),
+                                 "median_ids_identical": bool(np.array_equal(n(tr["median_ids"]), fw64["median_ids"])),
+                                 "instrumented_forward_bit_identical_to_the_product_kernel": bool(torch.equal(tr["render_alphas"], alphas.detach()))},
+           "render_colors": matched(n(colors[..., :3]), fw64["render_colors"], pb[..., 0]), "render_depths": matched(n(colors[..., 3:4]), fw64["render_depths"], pb[..., 1]),
+           "render_alphas": matched(n(alphas), fw64["render_alphas"], pb[..., 2]), "render_normals": matched(n(rn_cam), fw64["render_normals"], pb[..., 3]),
+           "render_median": matched(n(meta["render_median"]), fw64["render_median"], pb[..., 4]),
+           "visibilities": matched(n(meta["visibilities"]), fw64["visibilities"], fw64["vis_bound"]),
+           "v_densify": matched(n(meta["gradient_2dgs"].grad), g64["v_densify"], g64["cond"][:, orc.COND_SLICES["v_densify"]]),
+           "v_means (compositing + projection + SH backward)": _err_stats(n(leaves[0].grad), pb64[0] + vsh64[1]),
+           "v_quats (compositing + projection backward)": _err_stats(n(leaves[1].grad), pb64[1]), "v_scales": _err_stats(n(leaves[2].grad), pb64[2]),
+           "v_opacities": _err_stats(n(leaves[3].grad), vop64), "v_sh": _err_stats(n(leaves[4].grad), vsh64[0]),
+           "note": "HIP path vs the oracle on the bench workload's first view, NO pixel or splat excluded: ids / radii / bins / offsets bit-exact against "
+                   "the fp32 build; floats against the fp64 build evaluated under the kernel's own traced decisions (oracle.rasterize_2dgs_*_matched). "
+                   "Compositing outputs: every element against 1e-4 max(|ref|, mean|ref|) + 8 eps32 x the oracle's first-order conditioning bound "
+                   "(worst_over_tolerance <= 1 is the gate of tests/util.py; above_1e-4 = elements that needed the second term). End-to-end "
+                   "parameter gradients (compositing -> projection / SH backward): per row, rows above 1e-4 / worst / relative L2 over ALL rows "
+                   "(tests/test_gpu_baseline_shapes.py runs the same comparison at every BASELINE shape)"}
     if n_sdf_points:
         # SDF half: the HIP encoder / decoder / scatter on the sample the oracle was timed on.  Features and table gradient
         # against the fp32 build (pos = fma(scale, x, 0.5) in fp32 IS the function, DESIGN.md A.7), decoder against the fp64 build
@@ -1014,8 +1035,17 @@ def cpu_baseline(sc, views, params, N, W, H, deg, n_sdf_points, dev):
         torch.cuda.synchronize()
         o64 = orc.mlp_fwd(feat, dims, Wm, None, prec="f64")
         vin64, vw64, _ = orc.mlp_bwd(feat, dims, Wm, None, np.ones_like(o64), prec="f64")
+        # points with a hidden pre-activation within 1e-5 of zero may take the other ReLU branch than the fp64 evaluation (a decision, like
+        # the compositing's): the same mask as tests/test_gpu_sdf_parity.py::_near_relu_kink; both figures are printed
+        hcur, off_, away = feat.astype(np.float64), 0, np.ones(n_s, bool)
+        for l_ in range(len(dims) - 2):
+            z_ = hcur @ Wm[off_:off_ + dims[l_] * dims[l_ + 1]].astype(np.float64).reshape(dims[l_ + 1], dims[l_]).T
+            off_ += dims[l_] * dims[l_ + 1]
+            away &= ~(np.abs(z_) < 1e-5).any(axis=1)
+            hcur = np.maximum(z_, 0.0)
         par["sdf"] = {"hashgrid_features (vs f32 build)": _err_stats(n(feat_h), feat), "decoder_out (vs f64 build)": _err_stats(n(out_h), o64),
-                      "decoder_v_in (vs f64 build)": _err_stats(n(vin_h), vin64), "decoder_v_weights (vs f64 build)": _err_stats(n(vw_h), vw64),
+                      "decoder_v_in (vs f64 build)": _err_stats(n(vin_h), vin64, away), "decoder_v_weights (vs f64 build)": _err_stats(n(vw_h), vw64),
+                      "points_within_1e-5_of_a_relu_kink": int((~away).sum()),
                       "table_gradient (vs f32 build)": _err_stats(n(vt_h), vt_o),
                       "note": f"{n_s} uniformly random points, table U(-1e-4, 1e-4), 4-layer bias-free decoder; the decoder runs on the bf16 MFMA pipe with "
                               "exact 3-term operand splits (GSDF_MLP_MFMA=f32 selects the fp32 pipe); a point whose pre-activation is within "

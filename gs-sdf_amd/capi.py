@@ -15,6 +15,14 @@ _lib = None
 
 _i64, _i32, _f32, _u64, _vp, _sz = C.c_int64, C.c_int, C.c_float, C.c_uint64, C.c_void_p, C.c_size_t
 
+ABI_VERSION = 3      # include/gsdf_hip.h: GSDF_ABI_VERSION this binding was written against
+
+
+class RasterInstr(C.Structure):
+    """include/gsdf_hip.h: gsdf_raster_instr (instrumented compositing launches: counters or the decision record)."""
+    _fields_ = [("counters", C.c_void_p), ("trace_rows", C.c_void_p), ("trace_stride", C.c_int32), ("trace_bits", C.c_void_p)]
+
+
 _SIGS = {
     "gsdf_abi_version": (C.c_int, []),
     "gsdf_last_error": (C.c_char_p, []),
@@ -33,7 +41,8 @@ _SIGS = {
     "gsdf_rasterize_2dgs_fwd": (C.c_int, [_i64, _i64, _i64, _i32, _i32, _i32] + [_vp] * 19),
     "gsdf_rasterize_2dgs_bwd_ws_bytes": (_sz, [_i64]),
     "gsdf_rasterize_2dgs_bwd": (C.c_int, [_i64, _i64, _i64, _i32, _i32, _i32] + [_vp] * 27),
-    "gsdf_raster_set_counters": (C.c_int, [_vp]),
+    "gsdf_rasterize_2dgs_fwd_instr": (C.c_int, [_i64, _i64, _i64, _i32, _i32, _i32] + [_vp] * 20),
+    "gsdf_rasterize_2dgs_bwd_instr": (C.c_int, [_i64, _i64, _i64, _i32, _i32, _i32] + [_vp] * 28),
     "gsdf_render_post_fwd": (C.c_int, [_i64, _i32] + [_vp] * 10),
     "gsdf_render_post_bwd": (C.c_int, [_i64, _i32] + [_vp] * 12),
     "gsdf_hashgrid_offsets": (_i64, [_i32, _i32, _i32, _i32, _f32, _vp]),
@@ -107,6 +116,10 @@ def lib():
         for name, (res, args) in _SIGS.items():
             f = getattr(l, name)       # AttributeError if the library does not export the symbol
             f.restype, f.argtypes = res, args
+        got = l.gsdf_abi_version()
+        if got != ABI_VERSION:
+            raise RuntimeError(f"{LIB_PATH} has ABI version {got}, this binding was written against {ABI_VERSION} (include/gsdf_hip.h): "
+                               "stale library, rebuild it with __graft_entry__.build()")
         _lib = l
     return _lib
 

@@ -50,7 +50,7 @@ void set_error(const char *fmt, ...) {
 }  // namespace gsdf
 
 extern "C" const char *gsdf_last_error(void) { return gsdf::g_err; }
-extern "C" int gsdf_abi_version(void) { return 2; }
+extern "C" int gsdf_abi_version(void) { return GSDF_ABI_VERSION; }
 
 extern "C" int gsdf_stream_set_xcds(gsdf_stream_t stream, int n_xcds) {
   GSDF_REQUIRE(n_xcds >= 0 && n_xcds <= 8, "stream_set_xcds: n_xcds %d outside [0,8]", n_xcds);

@@ -71,7 +71,7 @@ __device__ __forceinline__ void flush_records(BwdLds<ABSGRAD> &lds, int wave, in
 
 __device__ __forceinline__ void lds_add(float *p, float v) { atomicAdd(p, v); }
 
-// COUNT: diagnostic instantiation (gsdf_raster_set_counters): counters[4] += (wave, splat) visits, [5] += lanes of those visits whose
+// COUNT: diagnostic instantiation (gsdf_rasterize_2dgs_bwd_instr with counters): counters[4] += (wave, splat) visits, [5] += lanes of those visits whose
 // pixel replays the splat's list position, [6] += lanes that blended the pair (pass the alpha test again).
 template <bool ABSGRAD, bool COUNT = false>
 __global__ void __launch_bounds__(RT)
@@ -299,16 +299,13 @@ __global__ void __launch_bounds__(256)
 
 }  // namespace gsdf
 
-namespace gsdf {
-extern unsigned long long *g_raster_counters;
-}
 using namespace gsdf;
 
 extern "C" size_t gsdf_rasterize_2dgs_bwd_ws_bytes(int64_t M) {
   return align_up((size_t)(M > 0 ? M : 1) * NACC * sizeof(float), 256) + align_up((size_t)(M > 0 ? M : 1) * 2 * sizeof(float), 256) + 256;
 }
 
-extern "C" int gsdf_rasterize_2dgs_bwd(int64_t C, int64_t M, int64_t I, int width, int height, int tile_size,
+static int rasterize_bwd_launch(int64_t C, int64_t M, int64_t I, int width, int height, int tile_size,
                                        const float *means2d, const float *ray_transforms, const float *colors,
                                        const float *opacities, const float *normals, const float *backgrounds,
                                        const uint8_t *masks, const int32_t *isect_offsets,
@@ -318,9 +315,7 @@ extern "C" int gsdf_rasterize_2dgs_bwd(int64_t C, int64_t M, int64_t I, int widt
                                        const float *v_render_alphas, const float *v_render_normals,
                                        const float *v_render_median, float *v_means2d, float *v_ray_transforms,
                                        float *v_colors, float *v_opacities, float *v_normals, float *v_densify,
-                                       float *v_means2d_abs, void *ws, const float *final_T, gsdf_stream_t stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
-  GSDF_TIMED("gsdf_rasterize_2dgs_bwd");
+                                       float *v_means2d_abs, void *ws, const float *final_T, unsigned long long *counters, hipStream_t stream) {
   GSDF_REQUIRE(tile_size == TILE, "rasterize_bwd: tile_size %d unsupported (16 only)", tile_size);
   GSDF_REQUIRE(width > 0 && height > 0 && C >= 1, "rasterize_bwd: bad geometry");
   if (M == 0) return GSDF_OK;
@@ -340,8 +335,10 @@ extern "C" int gsdf_rasterize_2dgs_bwd(int64_t C, int64_t M, int64_t I, int widt
 #define ARGS n_xcd, total, n_tiles, I, width, height, tw, means2d, ray_transforms, colors, opacities, normals, backgrounds, \
              masks, isect_offsets, flatten_ids, render_alphas, last_ids, median_ids, v_render_colors,               \
              v_render_depths, v_render_alphas, v_render_normals, v_render_median, grec, grec_abs, final_T
-    if (g_raster_counters != nullptr)
-      raster_bwd_kernel<false, true><<<xcd_grid(total, n_xcd), RT, 0, stream>>>(ARGS, g_raster_counters);   // (absgrad accumulation is not counted)
+    if (counters != nullptr && v_means2d_abs)
+      raster_bwd_kernel<true, true><<<xcd_grid(total, n_xcd), RT, 0, stream>>>(ARGS, counters);
+    else if (counters != nullptr)
+      raster_bwd_kernel<false, true><<<xcd_grid(total, n_xcd), RT, 0, stream>>>(ARGS, counters);
     else if (v_means2d_abs)
       raster_bwd_kernel<true><<<xcd_grid(total, n_xcd), RT, 0, stream>>>(ARGS);
     else
@@ -354,4 +351,40 @@ extern "C" int gsdf_rasterize_2dgs_bwd(int64_t C, int64_t M, int64_t I, int widt
                                                                        v_normals, v_densify, v_means2d_abs);
   GSDF_CHECK_LAUNCH("unpack_records_kernel");
   return GSDF_OK;
+}
+
+extern "C" int gsdf_rasterize_2dgs_bwd(int64_t C, int64_t M, int64_t I, int width, int height, int tile_size,
+                                       const float *means2d, const float *ray_transforms, const float *colors,
+                                       const float *opacities, const float *normals, const float *backgrounds,
+                                       const uint8_t *masks, const int32_t *isect_offsets,
+                                       const int32_t *flatten_ids, const float *render_alphas,
+                                       const int32_t *last_ids, const int32_t *median_ids,
+                                       const float *v_render_colors, const float *v_render_depths,
+                                       const float *v_render_alphas, const float *v_render_normals,
+                                       const float *v_render_median, float *v_means2d, float *v_ray_transforms,
+                                       float *v_colors, float *v_opacities, float *v_normals, float *v_densify,
+                                       float *v_means2d_abs, void *ws, const float *final_T, gsdf_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  GSDF_TIMED("gsdf_rasterize_2dgs_bwd");
+  return rasterize_bwd_launch(C, M, I, width, height, tile_size, means2d, ray_transforms, colors, opacities, normals, backgrounds, masks,
+                              isect_offsets, flatten_ids, render_alphas, last_ids, median_ids, v_render_colors, v_render_depths,
+                              v_render_alphas, v_render_normals, v_render_median, v_means2d, v_ray_transforms, v_colors, v_opacities,
+                              v_normals, v_densify, v_means2d_abs, ws, final_T, nullptr, (hipStream_t)stream_);
+}
+
+extern "C" int gsdf_rasterize_2dgs_bwd_instr(int64_t C, int64_t M, int64_t I, int width, int height, int tile_size,
+                                       const float *means2d, const float *ray_transforms, const float *colors,
+                                       const float *opacities, const float *normals, const float *backgrounds,
+                                       const uint8_t *masks, const int32_t *isect_offsets,
+                                       const int32_t *flatten_ids, const float *render_alphas,
+                                       const int32_t *last_ids, const int32_t *median_ids,
+                                       const float *v_render_colors, const float *v_render_depths,
+                                       const float *v_render_alphas, const float *v_render_normals,
+                                       const float *v_render_median, float *v_means2d, float *v_ray_transforms,
+                                       float *v_colors, float *v_opacities, float *v_normals, float *v_densify,
+                                       float *v_means2d_abs, void *ws, const float *final_T, const gsdf_raster_instr *instr, gsdf_stream_t stream_) {
+  return rasterize_bwd_launch(C, M, I, width, height, tile_size, means2d, ray_transforms, colors, opacities, normals, backgrounds, masks,
+                              isect_offsets, flatten_ids, render_alphas, last_ids, median_ids, v_render_colors, v_render_depths,
+                              v_render_alphas, v_render_normals, v_render_median, v_means2d, v_ray_transforms, v_colors, v_opacities,
+                              v_normals, v_densify, v_means2d_abs, ws, final_T, instr ? instr->counters : nullptr, (hipStream_t)stream_);
 }

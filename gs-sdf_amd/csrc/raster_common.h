@@ -191,8 +191,9 @@ __device__ __forceinline__ void eval_pair(float lx, float ly, float px, float py
   e.zz = fmaf(-e.dy, a1.z, fmaf(-e.dx, a0.z, a2.z));
   e.inv = __builtin_amdgcn_rcpf(e.zz);
   e.sx = e.zx * e.inv; e.sy = e.zy * e.inv;
-  const float g3 = e.sx * e.sx + e.sy * e.sy;
-  const float g2 = FILTER_INV_SQUARE * (e.dx * e.dx + e.dy * e.dy);
+  // explicit FMAs: every instantiation of the compositing kernels (forward, backward, instrumented) must take bit-identical decisions
+  const float g3 = fmaf(e.sx, e.sx, e.sy * e.sy);
+  const float g2 = FILTER_INV_SQUARE * fmaf(e.dx, e.dx, e.dy * e.dy);
   e.b3 = g3 <= g2;
   const float sigma = 0.5f * (e.b3 ? g3 : g2);
   e.vis = __expf(-sigma);

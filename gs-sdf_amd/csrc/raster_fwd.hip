@@ -12,9 +12,12 @@ struct FwdLds {
                         // every (wave, splat) pair is visited once per batch -> plain stores, no LDS atomics
 };
 
-// COUNT: diagnostic instantiation (gsdf_raster_set_counters): per launch, counters[0] += (wave, splat) visits after the quadrant
-// mask, [1] += lanes of those visits whose pixel is still live, [2] += lanes that pass the alpha test, [3] += lanes that blend.
-template <bool COUNT>
+// COUNT: diagnostic instantiation (gsdf_rasterize_2dgs_fwd_instr with counters): per launch, counters[0] += (wave, splat) visits after the
+// quadrant mask, [1] += lanes of those visits whose pixel is still live, [2] += lanes that pass the alpha test, [3] += lanes that blend.
+// TRACE: the decision record of the parity gate (gsdf_raster_instr.trace_*): a pixel with trace_rows[pid] >= 0 writes one byte per list
+// position it takes a decision at — bit0 blended, bit1 3-D footprint branch, bit2 alpha clamped, bit3 the pixel terminates at this pair
+// (not blended), bit4 the median is updated here; positions it skips (alpha test failed, unreachable quadrant, pixel finished) stay 0.
+template <bool COUNT, bool TRACE>
 __global__ void __launch_bounds__(RT)
     raster_fwd_kernel(int n_xcd, int64_t total_tiles, int64_t n_tiles, int64_t I, int W, int H, int tw,
                       const float *__restrict__ means2d, const float *__restrict__ ray_transforms,
@@ -25,7 +28,8 @@ __global__ void __launch_bounds__(RT)
                       float *__restrict__ render_depths, float *__restrict__ render_alphas,
                       float *__restrict__ render_normals, float *__restrict__ render_median,
                       int32_t *__restrict__ last_ids, int32_t *__restrict__ median_ids,
-                      unsigned *__restrict__ visibilities, float *__restrict__ final_T, unsigned long long *__restrict__ counters) {
+                      unsigned *__restrict__ visibilities, float *__restrict__ final_T, unsigned long long *__restrict__ counters,
+                      const int32_t *__restrict__ trace_rows, int trace_stride, uint8_t *__restrict__ trace_bits) {
   __shared__ FwdLds lds;
   unsigned long long c_visit = 0, c_live = 0, c_ok = 0, c_blend = 0, c_empty = 0, c_r4 = 0, c_r8 = 0, c_union = 0;
   const int64_t tile = xcd_tile_index(total_tiles, n_xcd);
@@ -50,6 +54,8 @@ __global__ void __launch_bounds__(RT)
   int32_t cur = 0, med_idx = 0;
   bool done = !inside;
   int g_mine = -1;
+  uint8_t *trow = nullptr;
+  if (TRACE && inside && trace_rows[pid] >= 0) trow = trace_bits + (int64_t)trace_rows[pid] * trace_stride;
 
   const int nb = (end - start + RT - 1) / RT;
   for (int b = 0; b < nb; ++b) {
@@ -100,6 +106,11 @@ __global__ void __launch_bounds__(RT)
         if (COUNT) { c_visit += 1; c_live += __popcll(__ballot(!done)); c_ok += __popcll(__ballot(valid)); c_empty += __ballot(valid) == 0ull; }
         if (__ballot(valid) == 0ull) continue;
         const float nT = T * (1.0f - e.alpha);
+        if (TRACE && trow != nullptr && valid) {
+          const int k = bstart + t - start;
+          if (k < trace_stride)
+            trow[k] = (uint8_t)((e.b3 ? 2 : 0) | (e.clamped ? 4 : 0) | (nT <= T_EPS ? 8 : (1 | (T > 0.5f ? 16 : 0))));
+        }
         if (valid && nT <= T_EPS) {  // this pixel is finished: exclusive (the splat is not blended)
           done = true;
           valid = false;
@@ -148,13 +159,42 @@ __global__ void __launch_bounds__(RT)
 
 }  // namespace gsdf
 
-namespace gsdf {
-unsigned long long *g_raster_counters = nullptr;   // device pointer to 8 x u64, or null (the normal, uninstrumented kernels)
-}
 using namespace gsdf;
 
-extern "C" int gsdf_raster_set_counters(unsigned long long *dev_counters) {
-  g_raster_counters = dev_counters;
+static int rasterize_fwd_launch(int64_t C, int64_t M, int64_t I, int width, int height, int tile_size,
+                                const float *means2d, const float *ray_transforms, const float *colors,
+                                const float *opacities, const float *normals, const float *backgrounds,
+                                const uint8_t *masks, const int32_t *isect_offsets,
+                                const int32_t *flatten_ids, float *render_colors, float *render_depths,
+                                float *render_alphas, float *render_normals, float *render_median,
+                                int32_t *last_ids, int32_t *median_ids, float *visibilities, float *final_T,
+                                const gsdf_raster_instr *instr, hipStream_t stream) {
+  GSDF_REQUIRE(tile_size == TILE, "rasterize_fwd: tile_size %d unsupported (16 only)", tile_size);
+  GSDF_REQUIRE(width > 0 && height > 0 && C >= 1, "rasterize_fwd: bad geometry");
+  GSDF_REQUIRE(render_colors && render_depths && render_alphas && render_normals && render_median && last_ids &&
+                   median_ids && isect_offsets,
+               "rasterize_fwd: null output/offsets");
+  GSDF_REQUIRE(I == 0 || (flatten_ids && means2d && ray_transforms && colors && opacities && normals),
+               "rasterize_fwd: null input");
+  GSDF_REQUIRE(M == 0 || visibilities, "rasterize_fwd: null visibilities");
+  unsigned long long *counters = instr ? instr->counters : nullptr;
+  const int32_t *trace_rows = instr ? instr->trace_rows : nullptr;
+  const int trace_stride = instr ? instr->trace_stride : 0;
+  uint8_t *trace_bits = instr ? instr->trace_bits : nullptr;
+  GSDF_REQUIRE(!(counters && trace_rows), "rasterize_fwd: counters and the decision trace are separate instrumented launches");
+  GSDF_REQUIRE(!trace_rows || (trace_bits && trace_stride > 0), "rasterize_fwd: trace_rows without trace_bits / stride");
+  const int tw = (width + TILE - 1) / TILE, th = (height + TILE - 1) / TILE;
+  const int64_t n_tiles = (int64_t)tw * th, total = n_tiles * C;
+  if (M > 0) GSDF_HIP(hipMemsetAsync(visibilities, 0, (size_t)M * 4, stream), "rasterize_fwd memset");
+  const int n_xcd = xcd_count(stream);
+#define FWD_ARGS n_xcd, total, n_tiles, I, width, height, tw, means2d, ray_transforms, colors, opacities, normals, backgrounds, masks, isect_offsets, \
+                 flatten_ids, render_colors, render_depths, render_alphas, render_normals, render_median, last_ids, median_ids,          \
+                 (unsigned *)visibilities, final_T, counters, trace_rows, trace_stride, trace_bits
+  if (counters != nullptr) raster_fwd_kernel<true, false><<<xcd_grid(total, n_xcd), RT, 0, stream>>>(FWD_ARGS);
+  else if (trace_rows != nullptr) raster_fwd_kernel<false, true><<<xcd_grid(total, n_xcd), RT, 0, stream>>>(FWD_ARGS);
+  else raster_fwd_kernel<false, false><<<xcd_grid(total, n_xcd), RT, 0, stream>>>(FWD_ARGS);
+#undef FWD_ARGS
+  GSDF_CHECK_LAUNCH("raster_fwd_kernel");
   return GSDF_OK;
 }
 
@@ -168,24 +208,20 @@ extern "C" int gsdf_rasterize_2dgs_fwd(int64_t C, int64_t M, int64_t I, int widt
                                        gsdf_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   GSDF_TIMED("gsdf_rasterize_2dgs_fwd");
-  GSDF_REQUIRE(tile_size == TILE, "rasterize_fwd: tile_size %d unsupported (16 only)", tile_size);
-  GSDF_REQUIRE(width > 0 && height > 0 && C >= 1, "rasterize_fwd: bad geometry");
-  GSDF_REQUIRE(render_colors && render_depths && render_alphas && render_normals && render_median && last_ids &&
-                   median_ids && isect_offsets,
-               "rasterize_fwd: null output/offsets");
-  GSDF_REQUIRE(I == 0 || (flatten_ids && means2d && ray_transforms && colors && opacities && normals),
-               "rasterize_fwd: null input");
-  GSDF_REQUIRE(M == 0 || visibilities, "rasterize_fwd: null visibilities");
-  const int tw = (width + TILE - 1) / TILE, th = (height + TILE - 1) / TILE;
-  const int64_t n_tiles = (int64_t)tw * th, total = n_tiles * C;
-  if (M > 0) GSDF_HIP(hipMemsetAsync(visibilities, 0, (size_t)M * 4, stream), "rasterize_fwd memset");
-  const int n_xcd = xcd_count(stream);
-#define FWD_ARGS n_xcd, total, n_tiles, I, width, height, tw, means2d, ray_transforms, colors, opacities, normals, backgrounds, masks, isect_offsets, \
-                 flatten_ids, render_colors, render_depths, render_alphas, render_normals, render_median, last_ids, median_ids,          \
-                 (unsigned *)visibilities, final_T, g_raster_counters
-  if (g_raster_counters != nullptr) raster_fwd_kernel<true><<<xcd_grid(total, n_xcd), RT, 0, stream>>>(FWD_ARGS);
-  else raster_fwd_kernel<false><<<xcd_grid(total, n_xcd), RT, 0, stream>>>(FWD_ARGS);
-#undef FWD_ARGS
-  GSDF_CHECK_LAUNCH("raster_fwd_kernel");
-  return GSDF_OK;
+  return rasterize_fwd_launch(C, M, I, width, height, tile_size, means2d, ray_transforms, colors, opacities, normals, backgrounds, masks,
+                              isect_offsets, flatten_ids, render_colors, render_depths, render_alphas, render_normals, render_median,
+                              last_ids, median_ids, visibilities, final_T, nullptr, (hipStream_t)stream_);
+}
+
+extern "C" int gsdf_rasterize_2dgs_fwd_instr(int64_t C, int64_t M, int64_t I, int width, int height, int tile_size,
+                                             const float *means2d, const float *ray_transforms, const float *colors,
+                                             const float *opacities, const float *normals, const float *backgrounds,
+                                             const uint8_t *masks, const int32_t *isect_offsets,
+                                             const int32_t *flatten_ids, float *render_colors, float *render_depths,
+                                             float *render_alphas, float *render_normals, float *render_median,
+                                             int32_t *last_ids, int32_t *median_ids, float *visibilities, float *final_T,
+                                             const gsdf_raster_instr *instr, gsdf_stream_t stream_) {
+  return rasterize_fwd_launch(C, M, I, width, height, tile_size, means2d, ray_transforms, colors, opacities, normals, backgrounds, masks,
+                              isect_offsets, flatten_ids, render_colors, render_depths, render_alphas, render_normals, render_median,
+                              last_ids, median_ids, visibilities, final_T, instr, (hipStream_t)stream_);
 }

@@ -18,10 +18,20 @@ namespace {
 // set (neural_gaussian.cpp:258-264).  So that the UNMODIFIED reference gets what it expects, stochastic is the library default; callers
 // that know they will discard the samples (gsdf_model::rasterization_2dgs_sdf, gsdf_extras::JointIteration in centre mode, the Python test
 // harness gs_sdf_amd.hostlib) switch the draw off for their scope.
-bool g_stochastic_samples = true;
+thread_local bool g_stochastic_samples = true;   // ambient mode of the reference-signature entry point only, per thread
 
-uint64_t next_sample_seed_impl() {
-  if (!g_stochastic_samples) return 0;
+// a binding built against another header version must not reach the device with shifted arguments
+const bool g_abi_checked = [] {
+  if (gsdf_abi_version() != GSDF_ABI_VERSION) {
+    fprintf(stderr, "libgsdf_torch: libgsdf_hip.so has ABI version %d, this layer was built against %d (include/gsdf_hip.h): rebuild both\n",
+            gsdf_abi_version(), GSDF_ABI_VERSION);
+    abort();
+  }
+  return true;
+}();
+
+uint64_t next_sample_seed_impl(bool stochastic) {
+  if (!stochastic) return 0;
   // GSDF_SAMPLE_SEED (tests): a fixed seed instead of a draw
   static const uint64_t fixed = [] { const char *e = getenv("GSDF_SAMPLE_SEED"); return e ? (uint64_t)strtoull(e, nullptr, 10) : (uint64_t)0; }();
   if (fixed) return fixed;
@@ -29,7 +39,6 @@ uint64_t next_sample_seed_impl() {
   const uint64_t s = (uint64_t)torch::randint(1, std::numeric_limits<int64_t>::max(), {1}, torch::kInt64).item<int64_t>();
   return s ? s : 1;
 }
-uint64_t next_sample_seed() { return next_sample_seed_impl(); }
 
 // ------------------------------------------------------------------------------------------ P1
 struct Projection2DGS : public torch::autograd::Function<Projection2DGS> {
@@ -172,12 +181,21 @@ struct Rasterize2DGS : public torch::autograd::Function<Rasterize2DGS> {
 
 void gsplat_cpp::set_sample_mode(bool stochastic) { g_stochastic_samples = stochastic; }
 bool gsplat_cpp::get_sample_mode() { return g_stochastic_samples; }
-uint64_t gsplat_cpp::next_sample_seed() { return next_sample_seed_impl(); }
+uint64_t gsplat_cpp::next_sample_seed() { return next_sample_seed_impl(g_stochastic_samples); }
+uint64_t gsplat_cpp::next_sample_seed(bool stochastic) { return next_sample_seed_impl(stochastic); }
 
 std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor>
 fully_fused_projection_2dgs(const Tensor &means, const Tensor &quats, const Tensor &scales, const Tensor &viewmats,
                             const Tensor &Ks, int width, int height, float near_plane, float far_plane, float radius_clip,
                             bool packed, bool sparse_grad) {
+  return gsplat_cpp::fully_fused_projection_2dgs(means, quats, scales, viewmats, Ks, width, height, near_plane, far_plane, radius_clip, packed,
+                                                 sparse_grad, g_stochastic_samples);
+}
+
+std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor>
+gsplat_cpp::fully_fused_projection_2dgs(const Tensor &means, const Tensor &quats, const Tensor &scales, const Tensor &viewmats,
+                                        const Tensor &Ks, int width, int height, float near_plane, float far_plane, float radius_clip,
+                                        bool packed, bool sparse_grad, bool stochastic_samples) {
   TORCH_CHECK(packed, "fully_fused_projection_2dgs: only packed=true is implemented (the reference uses packed)");
   TORCH_CHECK(!sparse_grad, "fully_fused_projection_2dgs: sparse_grad=true is not implemented (the reference passes false)");
   const int64_t N = means.size(0), C = viewmats.size(0);
@@ -186,7 +204,7 @@ fully_fused_projection_2dgs(const Tensor &means, const Tensor &quats, const Tens
   TORCH_CHECK(viewmats.sizes() == torch::IntArrayRef({C, 4, 4}) && Ks.sizes() == torch::IntArrayRef({C, 3, 3}),
               "fully_fused_projection_2dgs: invalid viewmats/Ks shape");
   auto o = Projection2DGS::apply(means, quats, scales, viewmats, Ks, (int64_t)width, (int64_t)height, (double)near_plane,
-                                 (double)far_plane, (double)radius_clip, (int64_t)next_sample_seed());
+                                 (double)far_plane, (double)radius_clip, (int64_t)next_sample_seed_impl(stochastic_samples));
   return std::make_tuple(o[0], o[1], o[2], o[3], o[4], o[5], o[6], o[7], o[8]);
 }
 

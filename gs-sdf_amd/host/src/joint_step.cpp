@@ -218,8 +218,8 @@ std::map<std::string, int64_t> JointIteration::step(const Tensor &viewmat, const
   auto act = splat_activations(anchors_, views_[0], views_[1], views_[3].reshape({N}));
   Tensor dc = views_[4].reshape({N, 1, 3});
   Tensor sh = n_rest_ == 0 ? dc : torch::cat({dc, views_[5].reshape({N, n_rest_, 3})}, 1);
-  gsplat_cpp::SampleModeGuard sample_mode(!cfg_.center_reg);
-  auto proj = fully_fused_projection_2dgs(act[0], views_[2], act[1], viewmat, K, W, H, cfg_.near_plane, cfg_.far_plane, 0.f, true, false);
+  auto proj = gsplat_cpp::fully_fused_projection_2dgs(act[0], views_[2], act[1], viewmat, K, W, H, cfg_.near_plane, cfg_.far_plane, 0.f, true, false,
+                                                      /*stochastic_samples=*/!cfg_.center_reg);
   const Tensor &camera_ids = std::get<0>(proj), &gaussian_ids = std::get<1>(proj), &radii = std::get<2>(proj), &means2d = std::get<3>(proj);
   const Tensor &depths = std::get<4>(proj), &ray_transforms = std::get<5>(proj), &normals = std::get<6>(proj);
   // k_center_reg: the splat centres are the SDF samples (weight 1); otherwise the projection's stochastic points on the discs
@@ -448,8 +448,7 @@ std::map<std::string, int64_t> JointIteration::step_direct(const Tensor &viewmat
   // k_center_reg: the SDF samples are the splat centres, weight 1 (neural_gaussian.cpp:259-262); else one stochastic point on every visible
   // splat's disc (SPEC S-3), the seed drawn from torch's default CPU generator as the drop-in operator does
   const bool center = cfg_.center_reg;
-  gsplat_cpp::SampleModeGuard sample_mode(!center);
-  const uint64_t seed = center ? 0 : gsplat_cpp::next_sample_seed();
+  const uint64_t seed = gsplat_cpp::next_sample_seed(/*stochastic=*/!center);
   check(gsdf_projection_2dgs_fill(N, 1, fp(xyz), fp(quats), fp(scales), fp(viewmat), fp(K), W, H, seed, radii_dense.data_ptr<int32_t>(),
                                   pws.data_ptr(), M, M ? camera_ids.data_ptr<int64_t>() : nullptr, M ? gaussian_ids.data_ptr<int64_t>() : nullptr,
                                   M ? radii.data_ptr<int32_t>() : nullptr, fpm(means2d), fpm(depths), fpm(rt), fpm(normals), fpm(smp), fpm(sw),

@@ -98,8 +98,9 @@ rasterization_2dgs_sdf(const Tensor &means, const Tensor &quats, const Tensor &s
               "Invalid render_mode");
   const int64_t N = means.size(0), C = viewmats.size(0);
   TORCH_CHECK(opacities.dim() == 1 && opacities.size(0) == N, "Invalid opacities shape");
-  gsplat_cpp::SampleModeGuard sample_mode(!center_reg);   // stochastic SDF samples on the splat's disc unless k_center_reg (:259-265)
-  auto proj = fully_fused_projection_2dgs(means, quats, scales, viewmats, Ks, width, height, near_plane, far_plane, radius_clip, true, false);
+  // stochastic SDF samples on the splat's disc unless k_center_reg (:259-265): the mode is this call's argument, no ambient state
+  auto proj = gsplat_cpp::fully_fused_projection_2dgs(means, quats, scales, viewmats, Ks, width, height, near_plane, far_plane, radius_clip, true, false,
+                                                      /*stochastic_samples=*/!center_reg);
   const Tensor &camera_ids = std::get<0>(proj), &gaussian_ids = std::get<1>(proj), &radii = std::get<2>(proj), &means2d = std::get<3>(proj);
   const Tensor &depths = std::get<4>(proj), &ray_transforms = std::get<5>(proj), &normals = std::get<6>(proj);
   Tensor samples = std::get<7>(proj), samples_weights = std::get<8>(proj);

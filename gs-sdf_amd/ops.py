@@ -263,6 +263,60 @@ class _Rasterize2DGS(torch.autograd.Function):
         return (v_means2d, v_rt, v_colors, v_opac, v_normals, v_dens, v_abs, None, None, None, None, None, None, None)
 
 
+def rasterize_fwd_instr(means2d, ray_transforms, colors, opacities, normals, width, height, isect_offsets, flatten_ids, backgrounds=None,
+                        masks=None, counters=None, trace_rows=None, trace_stride=0):
+    """Instrumented forward launch (include/gsdf_hip.h: gsdf_rasterize_2dgs_fwd_instr; tests / diagnostics, no autograd).
+    counters: int64 [16] device tensor the launch adds to, OR trace_rows int32 [C,H,W] + trace_stride: the decision record of the
+    parity gate (`trace_bits` uint8 [rows, stride] in the result).  -> dict of the operator's outputs (+ last_ids, median_ids, final_T)."""
+    import ctypes
+    L = capi.lib()
+    C, M, I = isect_offsets.shape[0], opacities.shape[0], flatten_ids.shape[0]
+    e = lambda *s: _empty(s, torch.float32, means2d)
+    rc, rd, ra, rn, rm = e(C, height, width, 3), e(C, height, width, 1), e(C, height, width, 1), e(C, height, width, 3), e(C, height, width, 1)
+    last = _empty((C, height, width), torch.int32, means2d); med = _empty((C, height, width), torch.int32, means2d)
+    vis, fT = _empty((M, 1), torch.float32, means2d), _empty((C, height, width), torch.float32, means2d)
+    bits = None
+    if trace_rows is not None:
+        n_rows = int(trace_rows.max().item()) + 1
+        bits = torch.zeros((max(n_rows, 1), int(trace_stride)), dtype=torch.uint8, device=means2d.device)
+    instr = capi.RasterInstr(capi.ptr(counters).value if counters is not None else None,
+                             capi.ptr(trace_rows, torch.int32).value if trace_rows is not None else None, int(trace_stride),
+                             capi.ptr(bits).value if bits is not None else None)
+    mk = None if masks is None else masks.to(torch.uint8).contiguous()
+    capi.check(L.gsdf_rasterize_2dgs_fwd_instr(C, M, I, width, height, 16, f32(means2d), f32(ray_transforms), f32(colors), f32(opacities),
+                                               f32(normals), f32(backgrounds), ptr(mk), ptr(isect_offsets, torch.int32),
+                                               ptr(flatten_ids, torch.int32), f32(rc), f32(rd), f32(ra), f32(rn), f32(rm), ptr(last), ptr(med),
+                                               f32(vis), f32(fT), ctypes.cast(ctypes.pointer(instr), ctypes.c_void_p), capi.stream()),
+               "rasterize_2dgs_fwd_instr")
+    return dict(render_colors=rc, render_depths=rd, render_alphas=ra, render_normals=rn, render_median=rm, last_ids=last, median_ids=med,
+                visibilities=vis, final_T=fT, trace_bits=bits)
+
+
+def rasterize_bwd_instr(means2d, ray_transforms, colors, opacities, normals, width, height, isect_offsets, flatten_ids, fwd, upstream,
+                        counters, backgrounds=None, masks=None, absgrad=False):
+    """Instrumented backward launch (gsdf_rasterize_2dgs_bwd_instr): `fwd` = the dict of rasterize_fwd_instr, `upstream` = dict of the
+    five v_render_* tensors.  -> dict of the operator's gradients."""
+    import ctypes
+    L = capi.lib()
+    C, M, I = isect_offsets.shape[0], opacities.shape[0], flatten_ids.shape[0]
+    e = lambda *s: _empty(s, torch.float32, means2d)
+    g = dict(v_means2d=e(M, 2), v_ray_transforms=e(M, 3, 3), v_colors=e(M, 3), v_opacities=e(M), v_normals=e(M, 3), v_densify=e(M, 2),
+             v_means2d_abs=e(M, 2) if absgrad else None)
+    ws = torch.empty(L.gsdf_rasterize_2dgs_bwd_ws_bytes(M), dtype=torch.uint8, device=means2d.device)
+    instr = capi.RasterInstr(capi.ptr(counters).value if counters is not None else None, None, 0, None)
+    mk = None if masks is None else masks.to(torch.uint8).contiguous()
+    u = lambda k: f32(upstream[k].contiguous())
+    capi.check(L.gsdf_rasterize_2dgs_bwd_instr(C, M, I, width, height, 16, f32(means2d), f32(ray_transforms), f32(colors), f32(opacities),
+                                               f32(normals), f32(backgrounds), ptr(mk), ptr(isect_offsets), ptr(flatten_ids),
+                                               f32(fwd["render_alphas"]), ptr(fwd["last_ids"]), ptr(fwd["median_ids"]),
+                                               u("v_render_colors"), u("v_render_depths"), u("v_render_alphas"), u("v_render_normals"),
+                                               u("v_render_median"), f32(g["v_means2d"]), f32(g["v_ray_transforms"]), f32(g["v_colors"]),
+                                               f32(g["v_opacities"]), f32(g["v_normals"]), f32(g["v_densify"]), f32(g["v_means2d_abs"]), ptr(ws),
+                                               f32(fwd["final_T"]), ctypes.cast(ctypes.pointer(instr), ctypes.c_void_p), capi.stream()),
+               "rasterize_2dgs_bwd_instr")
+    return g
+
+
 def rasterize_to_pixels_2dgs(means2d, ray_transforms, colors, opacities, normals, densify, width, height, tile_size,
                              isect_offsets, flatten_ids, backgrounds=None, masks=None, packed=True,
                              means2d_absgrad=None, distloss=False):

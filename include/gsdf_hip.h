@@ -37,7 +37,10 @@ extern "C" {
 typedef void *gsdf_stream_t;
 
 const char *gsdf_last_error(void);
-/* ABI version; bumped on any signature change. */
+/* ABI version; bumped on any signature change.  Every binding compares gsdf_abi_version() of the library it loaded with the
+ * GSDF_ABI_VERSION of the header it was written against and refuses to run on a mismatch (gs_sdf_amd/capi.py: lib(); the C++
+ * operator layer: gsplat_ops.cpp static initialiser): a stale libgsdf_hip.so fails at load, not on the device. */
+#define GSDF_ABI_VERSION 3
 int gsdf_abi_version(void);
 
 /* Optional per-entry-point device timing (bench.py's roofline leg, for callers in any language): between gsdf_timing_begin and
@@ -138,11 +141,31 @@ int gsdf_rasterize_2dgs_fwd(int64_t n_cams, int64_t n_visible, int64_t n_isects,
                                              backward (render_alphas = 1 - T loses it to rounding once T << 1)*/,
                             gsdf_stream_t stream);
 
-/* Diagnostic: with a device pointer to 16 zero-initialised uint64 registered, the compositing entry points launch instrumented
- * instantiations that ADD per launch: [0] (wave, splat) visits after the per-quadrant reach mask, [1] lanes of those visits whose
- * pixel is still live, [2] lanes passing the alpha test, [3] lanes that blend (forward); [4] visits, [5] lanes replaying, [6] lanes
- * blending (backward); [7] forward visits in which no lane passed the alpha test; [8..10] what-if iteration counts of tools/exp_raster_pairs.py.  NULL switches back to the normal kernels.  (How much of the evaluated (pixel, splat) work is useful.) */
-int gsdf_raster_set_counters(unsigned long long *dev_counters);
+/* Instrumented launches of the compositing kernels (tests / diagnostics; the product never passes an instr block).  No process-wide
+ * state: the instrumentation is an argument of the call.
+ *   counters: device pointer to 16 zero-initialised uint64, the launch ADDS [0] (wave, splat) visits after the per-quadrant reach mask,
+ *     [1] lanes of those visits whose pixel is still live, [2] lanes passing the alpha test, [3] lanes that blend (forward); [4] visits,
+ *     [5] lanes replaying, [6] lanes blending (backward); [7] forward visits in which no lane passed the alpha test; [8..10] what-if
+ *     iteration counts of tools/exp_raster_pairs.py.
+ *   trace_rows / trace_stride / trace_bits (forward only): the DECISION RECORD of the parity gate (tests/util.py).  trace_rows int32
+ *     [C,H,W]: row of the record of that pixel or -1; trace_bits uint8 [rows, trace_stride], zeroed by the caller: byte k of a row =
+ *     the decisions the kernel took for the pixel at position k of its tile's list: bit0 blended, bit1 3-D footprint branch (g3 <= g2),
+ *     bit2 alpha clamped at 0.999, bit3 the pixel terminates at this pair (T (1 - alpha) <= 1e-4; not blended), bit4 the median is
+ *     updated here (T > 0.5); 0 = the pair does not contribute (alpha < 1/255, or after termination).
+ * counters and the trace are separate launches (one of the two per call). */
+typedef struct gsdf_raster_instr {
+  unsigned long long *counters;
+  const int32_t *trace_rows;
+  int32_t trace_stride;
+  uint8_t *trace_bits;
+} gsdf_raster_instr;
+int gsdf_rasterize_2dgs_fwd_instr(int64_t n_cams, int64_t n_visible, int64_t n_isects, int width, int height,
+                                  int tile_size, const float *means2d, const float *ray_transforms, const float *colors,
+                                  const float *opacities, const float *normals, const float *backgrounds, const uint8_t *masks,
+                                  const int32_t *isect_offsets, const int32_t *flatten_ids, float *render_colors,
+                                  float *render_depths, float *render_alphas, float *render_normals, float *render_median,
+                                  int32_t *last_ids, int32_t *median_ids, float *visibilities, float *final_T,
+                                  const gsdf_raster_instr *instr /*host pointer*/, gsdf_stream_t stream);
 
 /* All gradient outputs are fully written.  v_means2d_abs may be NULL.  ws >= *_bwd_ws_bytes(M): the kernel
  * accumulates one packed 80-byte gradient record per splat there (line-coalesced atomics) and unpacks it.
@@ -159,6 +182,18 @@ int gsdf_rasterize_2dgs_bwd(int64_t n_cams, int64_t n_visible, int64_t n_isects,
                             const float *v_render_normals, const float *v_render_median, float *v_means2d,
                             float *v_ray_transforms, float *v_colors, float *v_opacities, float *v_normals,
                             float *v_densify, float *v_means2d_abs, void *ws, const float *final_T, gsdf_stream_t stream);
+/* the same with instr->counters (see gsdf_raster_instr; the trace is a forward-only facility) */
+int gsdf_rasterize_2dgs_bwd_instr(int64_t n_cams, int64_t n_visible, int64_t n_isects, int width, int height,
+                                  int tile_size, const float *means2d, const float *ray_transforms,
+                                  const float *colors, const float *opacities, const float *normals,
+                                  const float *backgrounds, const uint8_t *masks, const int32_t *isect_offsets,
+                                  const int32_t *flatten_ids, const float *render_alphas, const int32_t *last_ids,
+                                  const int32_t *median_ids, const float *v_render_colors,
+                                  const float *v_render_depths, const float *v_render_alphas,
+                                  const float *v_render_normals, const float *v_render_median, float *v_means2d,
+                                  float *v_ray_transforms, float *v_colors, float *v_opacities, float *v_normals,
+                                  float *v_densify, float *v_means2d_abs, void *ws, const float *final_T,
+                                  const gsdf_raster_instr *instr /*host pointer*/, gsdf_stream_t stream);
 
 
 /* ------------------------------------------------------------------------------------------

@@ -20,7 +20,7 @@ _LIBS = {}
 def build(force=False):
     """Compile the C restatement with gcc (oracle/Makefile)."""
     kinds = [k for k in ("splat", "sdf") if os.path.exists(os.path.join(_HERE, f"{k}_oracle.c"))]
-    targets = [f"_build/liborc_{k}_{p}.so" for k in kinds for p in ("f32", "f64")]
+    targets = [f"_build/liborc_{k}_{p}.so" for k in kinds for p in ("f32", "f64")] + ["_build/liborc_splat_f32fma.so"]
     if os.path.exists(os.path.join(_HERE, "occ_oracle.c")):
         targets.append("_build/liborc_occ.so")
     subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []) + targets)
@@ -37,7 +37,7 @@ def _lib(kind, prec):
 
 
 def _dt(prec):
-    return np.float32 if prec == "f32" else np.float64
+    return np.float32 if prec in ("f32", "f32fma") else np.float64
 
 
 def _p(a):
@@ -45,7 +45,7 @@ def _p(a):
 
 
 def _r(x, prec):
-    return C.c_float(x) if prec == "f32" else C.c_double(x)
+    return C.c_float(x) if prec in ("f32", "f32fma") else C.c_double(x)
 
 
 def _c(a, dt):
@@ -210,6 +210,103 @@ def rasterize_2dgs_fragility(means2d, ray_transforms, opacities, W, H, tile_size
         _p(masks), _p(offs), _p(flat), C.c_double(kmargin), C.c_double(ulp_floor), C.c_double(cond_abs), C.c_double(kappa_max),
         _p(pf), _p(sf), _p(counts))
     return pf, sf[:M], dict(pairs=int(counts[0]), valid=int(counts[1]))
+
+
+# --- decision-matched evaluation (the parity gate of tests/util.py; see the block comment in splat_oracle.c) ----------------
+ACC_DEPTH = 4.0
+TRACE_BLEND, TRACE_BRANCH3D, TRACE_CLAMPED, TRACE_STOP, TRACE_MEDIAN = 1, 2, 4, 8, 16
+FLIP_NAMES = ("alpha", "branch", "clamp", "termination", "median")
+COND_SLICES = dict(v_means2d=slice(0, 2), v_ray_transforms=slice(2, 11), v_colors=slice(11, 14), v_opacities=slice(14, 15),
+                   v_normals=slice(15, 18), v_densify=slice(18, 20), v_means2d_abs=slice(20, 22))
+PIX_BOUND_COLS = dict(render_colors=0, render_depths=1, render_alphas=2, render_normals=3, render_median=4)
+
+
+def trace_plan(pix_flags, isect_offsets, n_isects, tile_size=16):
+    """trace_rows int32 [C,H,W] (row of the decision record, -1 = not traced) and the record stride (longest tile list among the
+    traced pixels) for the pixels with a non-zero flag."""
+    Cn, H, W = pix_flags.shape
+    offs = np.asarray(isect_offsets, np.int64).reshape(-1)
+    lens = np.diff(np.concatenate([offs, [n_isects]]))
+    th, tw = (H + tile_size - 1) // tile_size, (W + tile_size - 1) // tile_size
+    sel = np.flatnonzero(pix_flags.reshape(-1))
+    rows = np.full(Cn * H * W, -1, np.int32)
+    rows[sel] = np.arange(sel.size, dtype=np.int32)
+    c, rem = np.divmod(sel, H * W)
+    y, x = np.divmod(rem, W)
+    tl = lens[(c * th + y // tile_size) * tw + x // tile_size] if sel.size else np.zeros(0, np.int64)
+    stride = int(tl.max()) if sel.size else 1
+    return rows.reshape(Cn, H, W), max(stride, 1), int(sel.size)
+
+
+def rasterize_2dgs_trace(means2d, ray_transforms, opacities, W, H, tile_size, isect_offsets, flatten_ids, trace_rows, trace_stride,
+                         masks=None, prec="f32"):
+    """Decision record of this build's own evaluation for the traced pixels: uint8 [n_rows, trace_stride]."""
+    dt = _dt(prec)
+    m2d, rt, opa = (_c(a, dt) for a in (means2d, ray_transforms, opacities))
+    offs, flat, rows = _c(isect_offsets, np.int32), _c(flatten_ids, np.int32), _c(trace_rows, np.int32)
+    masks = _c(masks, np.uint8)
+    n_rows = int(rows.max()) + 1 if rows.size else 0
+    bits = np.zeros((max(n_rows, 1), trace_stride), np.uint8)
+    _lib("splat", prec).orc_rasterize_2dgs_trace(
+        C.c_int64(offs.shape[0]), C.c_int64(opa.shape[0]), C.c_int64(flat.shape[0]), C.c_int(W), C.c_int(H), C.c_int(tile_size),
+        _p(m2d), _p(rt), _p(opa), _p(masks), _p(offs), _p(flat), _p(rows), C.c_int64(trace_stride), _p(bits))
+    return bits
+
+
+def rasterize_2dgs_fwd_matched(means2d, ray_transforms, colors, opacities, normals, W, H, tile_size, isect_offsets, flatten_ids,
+                               trace_rows=None, trace_bits=None, backgrounds=None, masks=None, ulp_floor=2.4e-7, prec="f64"):
+    """Forward under the traced decisions (None: the build's own everywhere) + first-order fp32 error bounds in eps32 units
+    (`pix_bound` [C,H,W,5] in PIX_BOUND_COLS order, `vis_bound` [M,1]) + the flips of the trace against the own decisions
+    (`flips`: name -> (count, worst margin / fp32 evaluation error))."""
+    dt = _dt(prec)
+    m2d, rt, col, opa, nrm, bg = (_c(a, dt) for a in (means2d, ray_transforms, colors, opacities, normals, backgrounds))
+    offs, flat = _c(isect_offsets, np.int32), _c(flatten_ids, np.int32)
+    masks = _c(masks, np.uint8)
+    rows = _c(trace_rows, np.int32); bits = _c(trace_bits, np.uint8)
+    stride = bits.shape[1] if bits is not None else 0
+    Cn, M, I = offs.shape[0], opa.shape[0], flat.shape[0]
+    rc = np.zeros((Cn, H, W, 3), dt); rd = np.zeros((Cn, H, W, 1), dt); ra = np.zeros((Cn, H, W, 1), dt)
+    rn = np.zeros((Cn, H, W, 3), dt); rm = np.zeros((Cn, H, W, 1), dt)
+    last = np.zeros((Cn, H, W), np.int32); med = np.zeros((Cn, H, W), np.int32)
+    vis = np.zeros((max(M, 1), 1), dt)
+    pb = np.zeros((Cn, H, W, 5)); vb = np.zeros((max(M, 1), 1)); fcnt = np.zeros(5, np.int64); fworst = np.zeros(5)
+    _lib("splat", prec).orc_rasterize_2dgs_fwd_matched(
+        C.c_int64(Cn), C.c_int64(M), C.c_int64(I), C.c_int(W), C.c_int(H), C.c_int(tile_size), _p(m2d), _p(rt), _p(col), _p(opa),
+        _p(nrm), _p(bg), _p(masks), _p(offs), _p(flat), _p(rows), C.c_int64(stride), _p(bits), C.c_double(ulp_floor), _p(rc), _p(rd),
+        _p(ra), _p(rn), _p(rm), _p(last), _p(med), _p(vis), _p(pb), _p(vb), _p(fcnt), _p(fworst))
+    return dict(render_colors=rc, render_depths=rd, render_alphas=ra, render_normals=rn, render_median=rm, last_ids=last,
+                median_ids=med, visibilities=vis[:M], pix_bound=pb, vis_bound=vb[:M],
+                flips={nm: (int(fcnt[i]), float(fworst[i])) for i, nm in enumerate(FLIP_NAMES)})
+
+
+def rasterize_2dgs_bwd_matched(means2d, ray_transforms, colors, opacities, normals, W, H, tile_size, isect_offsets, flatten_ids,
+                               render_alphas, last_ids, median_ids, v_render_colors, v_render_depths, v_render_alphas,
+                               v_render_normals, v_render_median, trace_rows=None, trace_bits=None, backgrounds=None, masks=None,
+                               prec="f64", recovers_final_T=False):
+    """VJP under the traced decisions; float64 gradients + `cond` [M,22] (first-order fp32 error bound of every gradient element
+    in eps32 units, COND_SLICES layout).  recovers_final_T: the implementation under test computes the final transmittance as
+    1 - render_alphas (absolute error eps32, i.e. 1/T relative) instead of saving it; libgsdf_hip saves it."""
+    dt = _dt(prec)
+    m2d, rt, col, opa, nrm, bg = (_c(a, dt) for a in (means2d, ray_transforms, colors, opacities, normals, backgrounds))
+    offs, flat = _c(isect_offsets, np.int32), _c(flatten_ids, np.int32)
+    masks = _c(masks, np.uint8)
+    rows = _c(trace_rows, np.int32); bits = _c(trace_bits, np.uint8)
+    stride = bits.shape[1] if bits is not None else 0
+    ralpha, last, med = _c(render_alphas, dt), _c(last_ids, np.int32), _c(median_ids, np.int32)
+    vc, vd, va, vn, vmed = (_c(a, dt) for a in (v_render_colors, v_render_depths, v_render_alphas, v_render_normals, v_render_median))
+    Cn, M, I = offs.shape[0], opa.shape[0], flat.shape[0]
+    Mz = max(M, 1)
+    g = dict(v_means2d=np.zeros((Mz, 2)), v_ray_transforms=np.zeros((Mz, 3, 3)), v_colors=np.zeros((Mz, 3)), v_opacities=np.zeros(Mz),
+             v_normals=np.zeros((Mz, 3)), v_densify=np.zeros((Mz, 2)), v_means2d_abs=np.zeros((Mz, 2)), cond=np.zeros((Mz, 44)))
+    _lib("splat", prec).orc_rasterize_2dgs_bwd_matched(
+        C.c_int64(Cn), C.c_int64(M), C.c_int64(I), C.c_int(W), C.c_int(H), C.c_int(tile_size), _p(m2d), _p(rt), _p(col), _p(opa),
+        _p(nrm), _p(bg), _p(masks), _p(offs), _p(flat), _p(rows), C.c_int64(stride), _p(bits), _p(ralpha), _p(last), _p(med), _p(vc),
+        _p(vd), _p(va), _p(vn), _p(vmed), _p(g["v_means2d"]), _p(g["v_ray_transforms"]), _p(g["v_colors"]), _p(g["v_opacities"]),
+        _p(g["v_normals"]), _p(g["v_densify"]), _p(g["v_means2d_abs"]), _p(g["cond"]), C.c_double(1.0 if recovers_final_T else 0.0))
+    out = {k: v[:M] for k, v in g.items()}
+    # root-sum-square of the per-pixel evaluation errors + the fp32 accumulation of the terms (wave tree + a few atomics: ACC_DEPTH)
+    out["cond"] = np.sqrt(out["cond"][:, :22]) + ACC_DEPTH * out["cond"][:, 22:]
+    return out
 
 
 def set_threads(n):

@@ -872,3 +872,421 @@ void orc_rasterize_2dgs_fragility(int64_t C, int64_t M, int64_t I, int W, int H,
 }
 
 int orc_real_bytes(void) { return (int)sizeof(REAL); }
+
+/* ---------------------------------------------------------------------------------------
+ * P4 DECISION-MATCHED compositing (test infrastructure; the gate of tests/util.py).
+ *
+ * orc_rasterize_2dgs_fragility() above names the pixels in which some decision of the operator has a margin inside fp32
+ * rounding.  Instead of leaving those pixels (and the splats they blend) unchecked, the implementation under test is asked for
+ * the decisions it actually took there (libgsdf_hip's gsdf_rasterize_2dgs_fwd_instr writes one byte per (traced pixel, list
+ * position): bit0 blended, bit1 3-D footprint branch, bit2 alpha clamped, bit3 the pixel terminates at this pair (not blended),
+ * bit4 the median is updated here) and the fp64 operator is evaluated UNDER THOSE DECISIONS: between two decision surfaces the
+ * operator is smooth, so the result is the exact value the implementation approximates and the 1e-4 bar applies to it.
+ * Every decision that differs from the fp64 evaluation's own is counted and its margin is reported in units of the fp32
+ * evaluation error of the compared quantity (flip_worst): a flip is legitimate only inside that noise, the caller asserts it.
+ *
+ * What is left after matching the decisions is CONDITIONING, which no implementation escapes: exp(-|s|^2/2) with s = z.xy / z.z
+ * carries kappa = (|h_u.x h_v.y| + |h_u.y h_v.x|) / |z.z| times the rounding of z.z (edge-on splats), transmittances are
+ * products of (1 - alpha) with alpha up to 0.999, per-splat gradients are sums over pixels of terms that cancel.  Both
+ * functions therefore return, next to every value, a first-order BOUND of its fp32 evaluation error in units of eps32
+ * (pix_bound / vis_bound / cond): per pair the relative error of alpha is r = 2 + 2 sigma kappa' (kappa' = kappa in the 3-D
+ * branch, 1 in the screen-space branch, r = 0 when clamped), a pixel's weights carry R = sum_j r_j max(1, alpha_j/(1-alpha_j))
+ * + (number of blended pairs), s and 1/z.z add kappa each, and every sum is bounded through the sum of the absolute values of
+ * its terms.  The gate is  |got - ref| <= 1e-4 max(|ref|, mean|ref|) + C eps32 bound  for EVERY element.
+ * ------------------------------------------------------------------------------------- */
+typedef struct {
+  int valid, stop, median, forced;
+  int branch3d, clamped;
+  REAL hu[3], hv[3], z[3], s[2], d[2], vis, alpha, dep, sigma, a_raw, g3, g2;
+  double kappa, ks, r;   /* conditioning of the pair: z.z, the vector s (relative, in norm), alpha — see the block comment */
+} mpair_t;
+
+static inline void eval_pair_matched(REAL px, REAL py, const REAL *xy, REAL opac, const REAL *M, int forced, uint8_t bits, mpair_t *e) {
+  const REAL *Mu = M, *Mv = M + 3, *Mw = M + 6;
+  e->valid = 0; e->stop = 0; e->median = 0; e->forced = forced;
+  for (int j = 0; j < 3; ++j) { e->hu[j] = px * Mw[j] - Mu[j]; e->hv[j] = py * Mw[j] - Mv[j]; }
+  e->z[0] = e->hu[1] * e->hv[2] - e->hu[2] * e->hv[1];
+  e->z[1] = e->hu[2] * e->hv[0] - e->hu[0] * e->hv[2];
+  e->z[2] = e->hu[0] * e->hv[1] - e->hu[1] * e->hv[0];
+  e->d[0] = xy[0] - px; e->d[1] = xy[1] - py;
+  e->g2 = FILTER_INV_SQUARE * (e->d[0] * e->d[0] + e->d[1] * e->d[1]);
+  if (e->z[2] == 0) { e->s[0] = e->s[1] = 0; e->g3 = (REAL)INFINITY; }
+  else { e->s[0] = e->z[0] / e->z[2]; e->s[1] = e->z[1] / e->z[2]; e->g3 = e->s[0] * e->s[0] + e->s[1] * e->s[1]; }
+  e->branch3d = forced ? ((bits >> 1) & 1) : (e->z[2] != 0 && e->g3 <= e->g2);
+  e->sigma = (REAL)0.5 * (e->branch3d ? e->g3 : e->g2);
+  e->vis = (REAL)exp(-(double)e->sigma);
+  e->a_raw = opac * e->vis;
+  e->clamped = forced ? ((bits >> 2) & 1) : (e->a_raw > ALPHA_MAX);
+  e->alpha = e->clamped ? ALPHA_MAX : e->a_raw;
+  e->dep = e->branch3d ? (e->s[0] * Mw[0] + e->s[1] * Mw[1]) + Mw[2] : Mw[2];
+  if (forced) { e->valid = (bits & 1) != 0; e->stop = (bits >> 3) & 1; e->median = (bits >> 4) & 1; }
+  else e->valid = (e->z[2] != 0) && (e->sigma >= 0) && (e->alpha >= TILE_ALPHA_MIN);
+  /* conditioning of s = z.xy / z.z in the direct form z = h_u x h_v (what the reference's kernel evaluates): every component of z is a
+   * difference of two products */
+  e->kappa = 1.0; e->ks = 1.0; e->r = e->clamped ? 0.0 : 2.0;
+  if (e->branch3d && e->z[2] != 0) {
+    const double iz = 1.0 / fabs((double)e->z[2]);
+    const double Ax = fabs((double)(e->hu[1] * e->hv[2])) + fabs((double)(e->hu[2] * e->hv[1]));
+    const double Ay = fabs((double)(e->hu[2] * e->hv[0])) + fabs((double)(e->hu[0] * e->hv[2]));
+    const double Az = fabs((double)(e->hu[0] * e->hv[1])) + fabs((double)(e->hu[1] * e->hv[0]));
+    const double sx = fabs((double)e->s[0]), sy = fabs((double)e->s[1]), sn = sqrt(sx * sx + sy * sy);
+    e->kappa = Az * iz;
+    const double dsx = Ax * iz + sx * e->kappa, dsy = Ay * iz + sy * e->kappa;   /* absolute error of s, eps units */
+    e->ks = sn > 0 ? sqrt(dsx * dsx + dsy * dsy) / sn : e->kappa;
+    if (!e->clamped) e->r = 2.0 + sx * dsx + sy * dsy;                           /* d sigma = s . ds */
+  }
+}
+
+/* pix_bound [C*H*W][5] (colors, depths, alphas, normals, median), vis_bound [M]: eps32 units, may be NULL.
+ * flip_counts [5] / flip_worst [5]: alpha test, branch, clamp, termination, median (may be NULL). */
+void orc_rasterize_2dgs_fwd_matched(int64_t C, int64_t M, int64_t I, int W, int H, int tile_size,
+                                    const REAL *means2d, const REAL *ray_transforms, const REAL *colors,
+                                    const REAL *opacities, const REAL *normals, const REAL *backgrounds,
+                                    const uint8_t *masks, const int32_t *isect_offsets, const int32_t *flatten_ids,
+                                    const int32_t *trace_rows, int64_t trace_stride, const uint8_t *trace_bits, double ulp_floor,
+                                    REAL *render_colors, REAL *render_depths, REAL *render_alphas, REAL *render_normals,
+                                    REAL *render_median, int32_t *last_ids, int32_t *median_ids, REAL *visibilities,
+                                    double *pix_bound, double *vis_bound, int64_t *flip_counts, double *flip_worst) {
+  int tw = (W + tile_size - 1) / tile_size, th = (H + tile_size - 1) / tile_size;
+  int64_t n_tiles = (int64_t)tw * th;
+  for (int64_t m = 0; m < M; ++m) { visibilities[m] = 0; if (vis_bound) vis_bound[m] = 0; }
+  int64_t fc[5] = {0, 0, 0, 0, 0};
+  double fw_[5] = {0, 0, 0, 0, 0};
+#pragma omp parallel for schedule(dynamic, 4)
+  for (int64_t t = 0; t < C * n_tiles; ++t) {
+    int64_t c = t / n_tiles, tl = t % n_tiles;
+    int ty = (int)(tl / tw), tx = (int)(tl % tw);
+    int32_t start = isect_offsets[t];
+    int32_t end = (t == C * n_tiles - 1) ? (int32_t)I : isect_offsets[t + 1];
+    int masked = masks && !masks[t];
+    int32_t len = masked ? 0 : end - start;
+    REAL *vis_local = (REAL *)calloc((size_t)(len > 0 ? len : 1), sizeof(REAL));
+    double *visb_local = (double *)calloc((size_t)(len > 0 ? len : 1), sizeof(double));
+    int64_t lfc[5] = {0, 0, 0, 0, 0};
+    double lfw[5] = {0, 0, 0, 0, 0};
+    for (int yy = 0; yy < tile_size; ++yy)
+      for (int xx = 0; xx < tile_size; ++xx) {
+        int i = ty * tile_size + yy, j = tx * tile_size + xx;
+        if (i >= H || j >= W) continue;
+        int64_t pid = (c * H + i) * (int64_t)W + j;
+        REAL px = (REAL)j + (REAL)0.5, py = (REAL)i + (REAL)0.5;
+        const int32_t row = trace_rows ? trace_rows[pid] : -1;
+        const uint8_t *bits = row >= 0 ? trace_bits + (int64_t)row * trace_stride : NULL;
+        REAL T = 1, col[3] = {0, 0, 0}, nrm[3] = {0, 0, 0}, dsum = 0, med = 0;
+        int32_t cur = 0, med_idx = 0;
+        double Racc = 0 /* sum of squares */, eT = 0, bcol = 0, bnrm = 0, bdep = 0, bmed = 0;
+        for (int32_t k = 0; k < len; ++k) {
+          int32_t g = flatten_ids[start + k];
+          mpair_t e;
+          const int forced = bits != NULL && k < trace_stride;
+          eval_pair_matched(px, py, means2d + 2 * g, opacities[g], ray_transforms + 9 * g, forced, forced ? bits[k] : 0, &e);
+          double err_a = 0, err_g = 0;
+          if (forced) {
+            /* margins of the decisions the fp64 evaluation would have taken itself, in units of the fp32 evaluation error */
+            float Mf[9];
+            for (int q = 0; q < 9; ++q) Mf[q] = (float)ray_transforms[9 * g + q];
+            pair32_t f = eval_pair_f32((float)px, (float)py, (float)means2d[2 * g], (float)means2d[2 * g + 1], (float)opacities[g], Mf);
+            const double g3o = (double)e.g3, g2o = (double)e.g2;
+            const int own_b3 = e.z[2] != 0 && g3o <= g2o;
+            const double a_own = (double)opacities[g] * exp(-0.5 * (own_b3 ? g3o : g2o));
+            err_a = fabs((double)f.a - a_own) + ulp_floor * a_own;
+            err_g = fabs((double)f.g3 - g3o) + fabs((double)f.g2 - g2o) + ulp_floor * (g3o > g2o ? g3o : g2o);
+            const double al_own = a_own < 0.999 ? a_own : 0.999;
+            const int own_valid = e.z[2] != 0 && al_own >= 1.0 / 255.0;
+            const int f_valid = e.valid || e.stop;
+            if (own_valid != f_valid) {
+              double ratio = fabs(al_own - 1.0 / 255.0) / err_a;
+              if (e.z[2] == 0 || f.zero) ratio = INFINITY;
+              lfc[0]++; if (ratio > lfw[0]) lfw[0] = ratio;
+            }
+            if (f_valid && own_valid) {
+              if (own_b3 != e.branch3d) { double ratio = fabs(g3o - g2o) / err_g; lfc[1]++; if (ratio > lfw[1]) lfw[1] = ratio; }
+              if ((a_own > 0.999) != e.clamped) { double ratio = fabs(a_own - 0.999) / err_a; lfc[2]++; if (ratio > lfw[2]) lfw[2] = ratio; }
+            }
+          }
+          if (!forced) {
+            if (!e.valid) continue;
+            if (T * (1 - e.alpha) <= T_EPS) break;
+            e.median = T > (REAL)0.5;
+          } else {
+            if (e.valid || e.stop) {
+              const double nT = (double)T * (1 - (double)e.alpha);
+              const double enT = eT * (1 - (double)e.alpha) + (double)T * err_a + ulp_floor * nT;
+              const int own_stop = nT <= 1e-4;
+              if (own_stop != e.stop) { double ratio = fabs(nT - 1e-4) / enT; lfc[3]++; if (ratio > lfw[3]) lfw[3] = ratio; }
+              if (!e.stop && (((double)T > 0.5) != e.median)) {
+                double ratio = fabs((double)T - 0.5) / (eT + ulp_floor * (double)T); lfc[4]++; if (ratio > lfw[4]) lfw[4] = ratio;
+              }
+              if (!e.stop) eT = enT;
+            }
+            if (e.stop) break;
+            if (!e.valid) continue;
+          }
+          const REAL nT = T * (1 - e.alpha);
+          REAL w = e.alpha * T;
+          const double rel = sqrt(Racc + e.r * e.r + 1.0);
+          REAL cmax = 0, nmax = 0;
+          for (int ch = 0; ch < 3; ++ch) {
+            col[ch] += colors[3 * g + ch] * w;
+            nrm[ch] += normals[3 * g + ch] * w;
+            cmax = rmax(cmax, (REAL)fabs((double)colors[3 * g + ch])); nmax = rmax(nmax, (REAL)fabs((double)normals[3 * g + ch]));
+          }
+          dsum += e.dep * w;
+          bcol += (double)w * (double)cmax * rel; bnrm += (double)w * (double)nmax * rel;
+          const double adepv = e.branch3d ? (fabs((double)(e.s[0] * ray_transforms[9 * g + 6])) + fabs((double)(e.s[1] * ray_transforms[9 * g + 7]))) * (e.ks + 1.0) +
+                                                fabs((double)ray_transforms[9 * g + 8]) : fabs((double)e.dep);   /* eps units: error of dep */
+          bdep += (double)w * (fabs((double)e.dep) * rel + adepv);
+          if (e.median) { med = e.dep; med_idx = start + k; bmed = adepv + fabs((double)e.dep); }
+          if (w > vis_local[k]) vis_local[k] = w;
+          if ((double)w * rel > visb_local[k]) visb_local[k] = (double)w * rel;
+          cur = start + k;
+          const double am = (double)e.alpha / (1 - (double)e.alpha), rm_ = e.r * (am > 1 ? am : 1);
+          Racc += rm_ * rm_ + 1.0;
+          T = nT;
+        }
+        for (int ch = 0; ch < 3; ++ch) {
+          render_colors[3 * pid + ch] = backgrounds ? col[ch] + T * backgrounds[3 * c + ch] : col[ch];
+          render_normals[3 * pid + ch] = nrm[ch];
+        }
+        render_depths[pid] = dsum;
+        render_alphas[pid] = 1 - T;
+        render_median[pid] = med;
+        last_ids[pid] = cur;
+        median_ids[pid] = med_idx;
+        if (pix_bound) {
+          double *b = pix_bound + 5 * pid;
+          double bgm = 0;
+          if (backgrounds) for (int ch = 0; ch < 3; ++ch) bgm = fmax(bgm, fabs((double)backgrounds[3 * c + ch]));
+          const double Rf = sqrt(Racc + 1.0);
+          b[0] = bcol + (double)T * Rf * bgm; b[1] = bdep; b[2] = (double)T * Rf; b[3] = bnrm; b[4] = bmed;
+        }
+      }
+#pragma omp critical
+    {
+      for (int32_t k = 0; k < len; ++k) {
+        int32_t g = flatten_ids[start + k];
+        if (vis_local[k] > visibilities[g]) visibilities[g] = vis_local[k];
+        if (vis_bound && visb_local[k] > vis_bound[g]) vis_bound[g] = visb_local[k];
+      }
+      for (int q = 0; q < 5; ++q) { fc[q] += lfc[q]; if (lfw[q] > fw_[q]) fw_[q] = lfw[q]; }
+    }
+    free(vis_local); free(visb_local);
+  }
+  if (flip_counts) for (int q = 0; q < 5; ++q) flip_counts[q] = fc[q];
+  if (flip_worst) for (int q = 0; q < 5; ++q) flip_worst[q] = fw_[q];
+}
+
+/* VJP under the same decisions.  last_ids / median_ids / render_alphas are those of orc_rasterize_2dgs_fwd_matched.
+ * Gradients [M,.] double, zeroed by the caller; cond [M][44], zeroed by the caller, may be NULL: per gradient element (layout:
+ * means2d 2, M 9, colors 3, opacity 1, normals 3, densify 2, means2d_abs 2) first the sum over pixels of (F |term|)^2 — F the
+ * pair's relative-error factor, root-sum-square model of independent roundings — then the plain sum of |term| (the fp32
+ * accumulation itself).  The caller's bound is sqrt(first) + ACC x second, in eps32 units. */
+void orc_rasterize_2dgs_bwd_matched(int64_t C, int64_t M, int64_t I, int W, int H, int tile_size,
+                                    const REAL *means2d, const REAL *ray_transforms, const REAL *colors,
+                                    const REAL *opacities, const REAL *normals, const REAL *backgrounds,
+                                    const uint8_t *masks, const int32_t *isect_offsets, const int32_t *flatten_ids,
+                                    const int32_t *trace_rows, int64_t trace_stride, const uint8_t *trace_bits,
+                                    const REAL *render_alphas, const int32_t *last_ids, const int32_t *median_ids,
+                                    const REAL *v_render_colors, const REAL *v_render_depths, const REAL *v_render_alphas,
+                                    const REAL *v_render_normals, const REAL *v_render_median, double *v_means2d,
+                                    double *v_ray_transforms, double *v_colors, double *v_opacities, double *v_normals,
+                                    double *v_densify, double *v_means2d_abs, double *cond,
+                                    double t_final_abs_err /* eps32 units: 1 for an implementation that recovers the final transmittance
+                                                              as 1 - render_alphas (upstream gsplat, this file's fp32 builds), 0 for one
+                                                              that saves it (libgsdf_hip's final_T) */) {
+  int tw = (W + tile_size - 1) / tile_size, th = (H + tile_size - 1) / tile_size;
+  int64_t n_tiles = (int64_t)tw * th;
+  (void)M;
+  enum { NG = 66 }; /* 0..21 gradients (layout of cond), 22..43 sum of (F |term|)^2, 44..65 sum of |term| */
+#pragma omp parallel for schedule(dynamic, 4)
+  for (int64_t t = 0; t < C * n_tiles; ++t) {
+    int64_t c = t / n_tiles, tl = t % n_tiles;
+    int ty = (int)(tl / tw), tx = (int)(tl % tw);
+    int32_t start = isect_offsets[t];
+    int32_t end = (t == C * n_tiles - 1) ? (int32_t)I : isect_offsets[t + 1];
+    if (masks && !masks[t]) continue;
+    int32_t len = end - start;
+    if (len <= 0) continue;
+    double *acc = (double *)calloc((size_t)len * NG, sizeof(double));
+    for (int yy = 0; yy < tile_size; ++yy)
+      for (int xx = 0; xx < tile_size; ++xx) {
+        int i = ty * tile_size + yy, j = tx * tile_size + xx;
+        if (i >= H || j >= W) continue;
+        int64_t pid = (c * H + i) * (int64_t)W + j;
+        REAL px = (REAL)j + (REAL)0.5, py = (REAL)i + (REAL)0.5;
+        const int32_t row = trace_rows ? trace_rows[pid] : -1;
+        const uint8_t *bits = row >= 0 ? trace_bits + (int64_t)row * trace_stride : NULL;
+        const REAL T_final = 1 - render_alphas[pid];
+        REAL T = T_final;
+        const int32_t bin_final = last_ids[pid], med_idx = median_ids[pid];
+        const REAL *vC = v_render_colors + 3 * pid, *vN = v_render_normals + 3 * pid;
+        const REAL vD = v_render_depths[pid], vA = v_render_alphas[pid], vMed = v_render_median[pid];
+        REAL bufC[3] = {0, 0, 0}, bufN[3] = {0, 0, 0}, bufD = 0;
+        double abufC[3] = {0, 0, 0}, abufN[3] = {0, 0, 0}, abufD = 0;
+        REAL bgdot = 0;
+        double abgdot = 0;
+        if (backgrounds) {
+          bgdot = backgrounds[3 * c] * vC[0] + backgrounds[3 * c + 1] * vC[1] + backgrounds[3 * c + 2] * vC[2];
+          abgdot = fabs((double)(backgrounds[3 * c] * vC[0])) + fabs((double)(backgrounds[3 * c + 1] * vC[1])) + fabs((double)(backgrounds[3 * c + 2] * vC[2]));
+        }
+        /* the pixel's weight conditioning R (block comment): one pass over its blended pairs */
+        double Rpix = 0;
+        if (cond && t_final_abs_err > 0) { const double q = t_final_abs_err / fmax((double)T_final, 1e-30); Rpix += q * q; }
+        if (cond)
+          for (int32_t idx = start; idx <= bin_final; ++idx) {
+            int32_t g = flatten_ids[idx];
+            mpair_t e;
+            const int k = idx - start, forced = bits != NULL && k < trace_stride;
+            eval_pair_matched(px, py, means2d + 2 * g, opacities[g], ray_transforms + 9 * g, forced, forced ? bits[k] : 0, &e);
+            if (!e.valid) continue;
+            const double am = (double)e.alpha / (1 - (double)e.alpha), rm_ = e.r * (am > 1 ? am : 1);
+            Rpix += rm_ * rm_ + 1.0;    /* sum of squares */
+          }
+        for (int32_t idx = bin_final; idx >= start; --idx) {
+          int32_t g = flatten_ids[idx];
+          mpair_t e;
+          const REAL *Mrow = ray_transforms + 9 * g;
+          const int k = idx - start, forced = bits != NULL && k < trace_stride;
+          eval_pair_matched(px, py, means2d + 2 * g, opacities[g], Mrow, forced, forced ? bits[k] : 0, &e);
+          if (!e.valid) continue;
+          double *a = acc + (size_t)(idx - start) * NG, *b = a + 22, *l = a + 44;
+#define BND(slot, F, term) do { const double t_ = (term), f_ = (F) * t_; b[slot] += f_ * f_; l[slot] += t_; } while (0)
+          const REAL ra = 1 / (1 - e.alpha);
+          T *= ra;
+          const REAL fac = e.alpha * T;
+          REAL v_alpha = 0;
+          double A = 0;   /* sum of the absolute values of v_alpha's terms */
+          for (int ch = 0; ch < 3; ++ch) {
+            a[11 + ch] += fac * vC[ch];
+            a[15 + ch] += fac * vN[ch];
+            BND(11 + ch, sqrt(Rpix), fabs((double)(fac * vC[ch])));
+            BND(15 + ch, sqrt(Rpix), fabs((double)(fac * vN[ch])));
+            v_alpha += (colors[3 * g + ch] * T - bufC[ch] * ra) * vC[ch];
+            v_alpha += (normals[3 * g + ch] * T - bufN[ch] * ra) * vN[ch];
+            A += (fabs((double)(colors[3 * g + ch] * T)) + abufC[ch] * (double)ra) * fabs((double)vC[ch]);
+            A += (fabs((double)(normals[3 * g + ch] * T)) + abufN[ch] * (double)ra) * fabs((double)vN[ch]);
+          }
+          v_alpha += (e.dep * T - bufD * ra) * vD;
+          v_alpha += T_final * ra * vA;
+          v_alpha += -T_final * ra * bgdot;
+          A += (fabs((double)(e.dep * T)) + abufD * (double)ra) * fabs((double)vD) + (double)(T_final * ra) * (fabs((double)vA) + abgdot);
+          const int is_med = (idx == med_idx);
+          REAL v_dep = fac * vD + (is_med ? vMed : 0);
+          const double adep = fabs((double)(fac * vD)) + (is_med ? fabs((double)vMed) : 0);
+          for (int ch = 0; ch < 3; ++ch) {
+            bufC[ch] += colors[3 * g + ch] * fac;
+            bufN[ch] += normals[3 * g + ch] * fac;
+            abufC[ch] += fabs((double)(colors[3 * g + ch] * fac));
+            abufN[ch] += fabs((double)(normals[3 * g + ch] * fac));
+          }
+          bufD += e.dep * fac;
+          abufD += fabs((double)(e.dep * fac));
+          REAL v_sigma = 0;
+          double asig = 0;
+          const double Fw = sqrt(Rpix + e.r * e.r + e.ks * e.ks);   /* ks: e.dep inside v_alpha carries the error of s */
+          if (!e.clamped) {
+            a[14] += e.vis * v_alpha;
+            BND(14, Fw, (double)e.vis * A);
+            v_sigma = -opacities[g] * e.vis * v_alpha;
+            asig = (double)opacities[g] * (double)e.vis * A;
+          }
+          const REAL *Mw = Mrow + 6;
+          if (e.branch3d) {
+            REAL v_s[2] = {v_sigma * e.s[0] + v_dep * Mw[0], v_sigma * e.s[1] + v_dep * Mw[1]};
+            REAL vsx = v_s[0] / e.z[2], vsy = v_s[1] / e.z[2];
+            REAL v_z[3] = {vsx, vsy, -(vsx * e.s[0] + vsy * e.s[1])};
+            REAL v_hu[3] = {e.hv[1] * v_z[2] - e.hv[2] * v_z[1], e.hv[2] * v_z[0] - e.hv[0] * v_z[2],
+                            e.hv[0] * v_z[1] - e.hv[1] * v_z[0]};
+            REAL v_hv[3] = {v_z[1] * e.hu[2] - v_z[2] * e.hu[1], v_z[2] * e.hu[0] - v_z[0] * e.hu[2],
+                            v_z[0] * e.hu[1] - v_z[1] * e.hu[0]};
+            REAL vMw[3] = {px * v_hu[0] + py * v_hv[0] + v_dep * e.s[0],
+                           px * v_hu[1] + py * v_hv[1] + v_dep * e.s[1],
+                           px * v_hu[2] + py * v_hv[2] + v_dep};
+            for (int q = 0; q < 3; ++q) { a[2 + q] += -v_hu[q]; a[5 + q] += -v_hv[q]; a[8 + q] += vMw[q]; }
+            a[18] += -v_hu[2] * Mw[2];
+            a[19] += -v_hv[2] * Mw[2];
+            if (cond) {
+              const double iz = 1.0 / fabs((double)e.z[2]);
+              const double sn = sqrt((double)e.g3);
+              const double avs[2] = {asig * sn + adep * fabs((double)Mw[0]), asig * sn + adep * fabs((double)Mw[1])};
+              const double za[3] = {avs[0] * iz, avs[1] * iz, (avs[0] + avs[1]) * iz * sn};
+              const double F = sqrt(Rpix + e.r * e.r + 4.0 * e.ks * e.ks + e.kappa * e.kappa + 16.0);
+              for (int q = 0; q < 3; ++q) {
+                const int q1 = (q + 1) % 3, q2 = (q + 2) % 3;
+                const double ahu = fabs((double)e.hv[q1]) * za[q2] + fabs((double)e.hv[q2]) * za[q1];
+                const double ahv = fabs((double)e.hu[q1]) * za[q2] + fabs((double)e.hu[q2]) * za[q1];
+                BND(2 + q, F, ahu);
+                BND(5 + q, F, ahv);
+                BND(8 + q, F, fabs((double)px) * ahu + fabs((double)py) * ahv + adep * (q < 2 ? fabs((double)e.s[q]) : 1.0));
+                if (q == 2) { BND(18, F, ahu * fabs((double)Mw[2])); BND(19, F, ahv * fabs((double)Mw[2])); }
+              }
+            }
+          } else {
+            REAL gx = v_sigma * FILTER_INV_SQUARE * e.d[0], gy = v_sigma * FILTER_INV_SQUARE * e.d[1];
+            a[0] += gx; a[1] += gy;
+            a[20] += fabs((double)gx); a[21] += fabs((double)gy);
+            a[10] += v_dep;
+            if (cond) {
+              const double F = sqrt(Rpix + e.r * e.r + 16.0);
+              const double agx = asig * 2.0 * fabs((double)e.d[0]), agy = asig * 2.0 * fabs((double)e.d[1]);
+              BND(0, F, agx); BND(1, F, agy); BND(20, F, agx); BND(21, F, agy);
+              BND(10, sqrt(Rpix + 4.0), adep);
+            }
+          }
+        }
+      }
+#pragma omp critical
+    for (int32_t k = 0; k < len; ++k) {
+      int32_t g = flatten_ids[start + k];
+      const double *a = acc + (size_t)k * NG;
+      v_means2d[2 * g] += a[0]; v_means2d[2 * g + 1] += a[1];
+      for (int q = 0; q < 9; ++q) v_ray_transforms[9 * g + q] += a[2 + q];
+      for (int q = 0; q < 3; ++q) { v_colors[3 * g + q] += a[11 + q]; v_normals[3 * g + q] += a[15 + q]; }
+      v_opacities[g] += a[14];
+      v_densify[2 * g] += a[18]; v_densify[2 * g + 1] += a[19];
+      if (v_means2d_abs) { v_means2d_abs[2 * g] += a[20]; v_means2d_abs[2 * g + 1] += a[21]; }
+      if (cond) for (int q = 0; q < 22; ++q) { cond[44 * (int64_t)g + q] += a[22 + q]; cond[44 * (int64_t)g + 22 + q] += a[44 + q]; }
+    }
+#undef BND
+    free(acc);
+  }
+}
+
+/* The decision record of THIS build's own evaluation (same byte layout as gsdf_rasterize_2dgs_fwd_instr writes): used by the
+ * CPU self-check of the decision-matched gate, where the fp32 build stands in for the implementation under test. */
+void orc_rasterize_2dgs_trace(int64_t C, int64_t M, int64_t I, int W, int H, int tile_size, const REAL *means2d,
+                              const REAL *ray_transforms, const REAL *opacities, const uint8_t *masks,
+                              const int32_t *isect_offsets, const int32_t *flatten_ids, const int32_t *trace_rows,
+                              int64_t trace_stride, uint8_t *trace_bits) {
+  int tw = (W + tile_size - 1) / tile_size, th = (H + tile_size - 1) / tile_size;
+  int64_t n_tiles = (int64_t)tw * th;
+  (void)M;
+#pragma omp parallel for schedule(dynamic, 4)
+  for (int64_t t = 0; t < C * n_tiles; ++t) {
+    int64_t c = t / n_tiles, tl = t % n_tiles;
+    int ty = (int)(tl / tw), tx = (int)(tl % tw);
+    int32_t start = isect_offsets[t];
+    int32_t end = (t == C * n_tiles - 1) ? (int32_t)I : isect_offsets[t + 1];
+    int32_t len = (masks && !masks[t]) ? 0 : end - start;
+    for (int yy = 0; yy < tile_size; ++yy)
+      for (int xx = 0; xx < tile_size; ++xx) {
+        int i = ty * tile_size + yy, j = tx * tile_size + xx;
+        if (i >= H || j >= W) continue;
+        int64_t pid = (c * H + i) * (int64_t)W + j;
+        if (trace_rows[pid] < 0) continue;
+        uint8_t *bits = trace_bits + (int64_t)trace_rows[pid] * trace_stride;
+        REAL px = (REAL)j + (REAL)0.5, py = (REAL)i + (REAL)0.5, T = 1;
+        for (int32_t k = 0; k < len && k < trace_stride; ++k) {
+          int32_t g = flatten_ids[start + k];
+          pix_eval_t e;
+          eval_pair(px, py, means2d + 2 * g, opacities[g], ray_transforms + 9 * g, &e);
+          if (!e.valid) continue;
+          uint8_t b = (uint8_t)((e.branch3d ? 2 : 0) | (e.clamped ? 4 : 0));
+          REAL nT = T * (1 - e.alpha);
+          if (nT <= T_EPS) { bits[k] = b | 8; break; }
+          bits[k] = b | 1 | (T > (REAL)0.5 ? 16 : 0);
+          T = nT;
+        }
+      }
+  }
+}

@@ -38,7 +38,17 @@ def test_library_exports_every_declared_symbol(built):
 def test_python_binding_covers_every_declared_symbol(built):
     assert set(built.exported_symbols()) == _declared()
     l = built.lib()
-    assert l.gsdf_abi_version() >= 1
+    hdr = open(os.path.join(ROOT, "include", "gsdf_hip.h")).read()
+    declared = int(re.search(r"#define\s+GSDF_ABI_VERSION\s+(\d+)", hdr).group(1))
+    assert l.gsdf_abi_version() == declared == built.ABI_VERSION
+
+
+def test_stale_library_is_refused_at_load(built, monkeypatch):
+    """A library whose gsdf_abi_version() differs from the binding's is refused before any call can reach the device."""
+    monkeypatch.setattr(built, "_lib", None)
+    monkeypatch.setattr(built, "ABI_VERSION", built.ABI_VERSION + 1)
+    with pytest.raises(RuntimeError, match="ABI version"):
+        built.lib()
 
 
 def test_missing_library_fails_loudly(built, monkeypatch):

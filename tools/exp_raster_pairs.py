@@ -1,5 +1,5 @@
 """Experiment (run on the GPU box): how much of the compositing kernels' evaluated (pixel, splat) work is useful.
-Instrumented instantiations (gsdf_raster_set_counters) at the bench workload's shape.  Usage: python tools/exp_raster_pairs.py [workload]"""
+Instrumented launches (gsdf_rasterize_2dgs_fwd_instr / _bwd_instr with counters) at the bench workload's shape.  Usage: python tools/exp_raster_pairs.py [workload]"""
 import json, os, sys
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -12,14 +12,19 @@ name = sys.argv[1] if len(sys.argv) > 1 else "cfg3_1M_1080p"
 N, W, H, deg, replica = WORKLOADS[name]
 sc = synth.make_scene(N, W, H, sh_degree=deg, seed=0, replica=replica)
 vm = synth.make_views(2, seed=1)[1:2].to(dev)
-leaves = [t.to(dev).requires_grad_(True) for t in (sc["means"], sc["quats"], sc["log_scales"].exp(), torch.sigmoid(sc["logit_opacities"]), sc["sh"])]
 cnt = torch.zeros(16, dtype=torch.int64, device=dev)
-capi.check(capi.lib().gsdf_raster_set_counters(capi.ptr(cnt)), "set_counters")
-colors, alphas, meta = ops.rasterization_2dgs_sdf(*leaves, vm, sc["K"].to(dev), W, H, near_plane=0.05, far_plane=300.0, sh_degree=deg)
-ug = {k: v.to(dev) for k, v in synth.upstream_grads(H, W, seed=2).items()}
-((colors[..., :3] * ug["v_render_colors"]).sum() + (alphas * ug["v_render_alphas"]).sum() + (meta["render_normal"] * ug["v_render_normals"]).sum()).backward()
+d = lambda t: t.to(dev)
+with torch.no_grad():
+    cam, gid, radii, m2d, dep, rt, nrm, smp, sw = ops.fully_fused_projection_2dgs(d(sc["means"]), d(sc["quats"]), d(sc["log_scales"].exp()), vm,
+                                                                                  d(sc["K"]), W, H, 0.05, 300.0, 0.0)
+    col = ops.get_view_colors(vm, d(sc["means"]), radii, d(sc["sh"]), cam, gid, deg)
+    opa = torch.sigmoid(d(sc["logit_opacities"]))[gid].contiguous()
+    tpg, flat, offs = ops.tile_encode(W, H, 16, m2d, radii, dep, True, 1, cam, gid)
+    fwd = ops.rasterize_fwd_instr(m2d, rt, col, opa, nrm, W, H, offs, flat, counters=cnt)
+    ug = {k: v.to(dev) for k, v in synth.upstream_grads(H, W, seed=2).items()}
+    ops.rasterize_bwd_instr(m2d, rt, col, opa, nrm, W, H, offs, flat, fwd, ug, cnt)
 torch.cuda.synchronize()
-capi.lib().gsdf_raster_set_counters(None)
+meta = dict(flatten_ids=flat, gaussian_ids=gid)
 c = cnt.cpu().tolist()
 I, M, P = int(meta["flatten_ids"].shape[0]), int(meta["gaussian_ids"].shape[0]), W * H
 out = dict(workload=name, M=M, I=I, P=P, staged_tile_splat_pairs=I, all_pairs_without_culling=I * 256,
