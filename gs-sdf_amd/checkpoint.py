@@ -72,38 +72,44 @@ def load_local_map_checkpoint(lm, path):
     params = dict(m.named_parameters())
     if "encoder_local_map" not in params:
         raise RuntimeError(f"{path}: no 'encoder_local_map' parameter (not a LocalMap checkpoint)")
+    enc = params["encoder_local_map"]
+    if enc.numel() != lm.encoder.params_.numel():
+        raise RuntimeError(f"{path}: hash-grid table has {enc.numel()} entries, this map {lm.encoder.params_.numel()}")
+    layers = _layers(lm)
+    # everything is validated BEFORE anything is copied: a refused checkpoint leaves the map untouched
+    copies = [(lm.encoder.params_, enc.reshape(lm.encoder.params_.shape))]
+    if "decoder" in params:                                  # decoder_implementation 1: one flat parameter
+        flat = params["decoder"].reshape(-1).float()
+        n_plain = sum(w.numel() for w, _ in layers)
+        last = layers[-1][0]
+        rows_padded = -(-last.shape[0] // TCNN_OUT_PAD) * TCNN_OUT_PAD
+        n_padded = n_plain - last.numel() + rows_padded * last.shape[1]
+        if any(b is not None for _, b in layers) or flat.numel() not in (n_plain, n_padded):
+            raise RuntimeError(f"{path}: flat decoder parameter ({flat.numel()} values) does not fit this map's decoder "
+                               f"({n_plain} unpadded / {n_padded} in tiny-cuda-nn's padded layout"
+                               + (", and this map's decoder has biases: decoder_implementation 0 expects the Sequential layout)" if any(b is not None for _, b in layers) else ")"))
+        padded = flat.numel() == n_padded and n_padded != n_plain
+        off = 0
+        for k, (w, _) in enumerate(layers):
+            if padded and k + 1 == len(layers):               # upstream layout: [rows_padded, in], the real rows first
+                copies.append((w, flat[off:off + rows_padded * w.shape[1]].view(rows_padded, w.shape[1])[:w.shape[0]]))
+                off += rows_padded * w.shape[1]
+            else:
+                copies.append((w, flat[off:off + w.numel()].view_as(w)))
+                off += w.numel()
+    else:                                                    # Sequential: decoder.<2k>.weight / .bias
+        for k, (w, b) in enumerate(layers):
+            src_w, src_b = params.get(f"decoder.{2 * k}.weight"), params.get(f"decoder.{2 * k}.bias")
+            if src_w is None or tuple(src_w.shape) != tuple(w.shape):
+                raise RuntimeError(f"{path}: decoder.{2 * k}.weight missing or of the wrong shape")
+            copies.append((w, src_w))
+            if b is not None:
+                if src_b is None or src_b.numel() != b.numel():
+                    raise RuntimeError(f"{path}: decoder.{2 * k}.bias missing or of the wrong shape")
+                copies.append((b, src_b))
+            elif src_b is not None and float(src_b.abs().max()) != 0.0:
+                raise RuntimeError(f"{path}: the checkpoint's decoder has biases, this map's decoder is bias free")
     with torch.no_grad():
-        enc = params["encoder_local_map"]
-        if enc.numel() != lm.encoder.params_.numel():
-            raise RuntimeError(f"{path}: hash-grid table has {enc.numel()} entries, this map {lm.encoder.params_.numel()}")
-        lm.encoder.params_.copy_(enc.reshape(lm.encoder.params_.shape).to(lm.encoder.params_.device))
-        layers = _layers(lm)
-        if "decoder" in params:                                  # decoder_implementation 1: one flat parameter
-            flat = params["decoder"].reshape(-1).float()
-            n_plain = sum(w.numel() for w, _ in layers)
-            last = layers[-1][0]
-            rows_padded = -(-last.shape[0] // TCNN_OUT_PAD) * TCNN_OUT_PAD
-            n_padded = n_plain - last.numel() + rows_padded * last.shape[1]
-            if any(b is not None for _, b in layers) or flat.numel() not in (n_plain, n_padded):
-                raise RuntimeError(f"{path}: flat decoder parameter ({flat.numel()} values) does not fit this map's decoder "
-                                   f"({n_plain} unpadded / {n_padded} in tiny-cuda-nn's padded layout)")
-            padded = flat.numel() == n_padded and n_padded != n_plain
-            off = 0
-            for k, (w, _) in enumerate(layers):
-                if padded and k + 1 == len(layers):               # upstream layout: [rows_padded, in], the real rows first
-                    w.copy_(flat[off:off + rows_padded * w.shape[1]].view(rows_padded, w.shape[1])[:w.shape[0]].to(w.device))
-                    off += rows_padded * w.shape[1]
-                else:
-                    w.copy_(flat[off:off + w.numel()].view_as(w).to(w.device))
-                    off += w.numel()
-        else:                                                    # Sequential: decoder.<2k>.weight / .bias
-            for k, (w, b) in enumerate(layers):
-                src_w, src_b = params.get(f"decoder.{2 * k}.weight"), params.get(f"decoder.{2 * k}.bias")
-                if src_w is None or tuple(src_w.shape) != tuple(w.shape):
-                    raise RuntimeError(f"{path}: decoder.{2 * k}.weight missing or of the wrong shape")
-                w.copy_(src_w.to(w.device))
-                if b is not None:
-                    b.copy_(src_b.to(b.device))
-                elif src_b is not None and float(src_b.abs().max()) != 0.0:
-                    raise RuntimeError(f"{path}: the checkpoint's decoder has biases, this map's decoder is bias free")
+        for dst, src in copies:
+            dst.copy_(src.to(dst.device))
     return lm

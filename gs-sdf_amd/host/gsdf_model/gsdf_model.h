@@ -83,6 +83,14 @@ struct LocalMap : torch::nn::Module {
                                           bool hessian = false, bool numerical_grad = true);   // :105-173
   DepthSamples sample(const DepthSamples &samples, int voxel_sample_num = 1, bool sample_free = true);   // :449-509
   DepthSamples filter_sample(const DepthSamples &samples);                                 // :511-516
+
+  // torch::save / torch::load of the module (neural_mapping.cpp:1334,1351) in the REFERENCE'S archive layout, so that a
+  // local_map_checkpoint.pt written here loads in the reference's LocalMap (and in gs_sdf_amd/checkpoint.py) and vice versa:
+  // "encoder_local_map" (flat table) + decoder_implementation 1: "decoder" (flat FullyFusedMLP weights); decoder_implementation 0:
+  // submodule "decoder" = torch::nn::Sequential with children "0".."2L+2", Linear layers holding "weight" [out,in] / "bias" [out]
+  // (local_map.cpp:29-42) — the flat fused-kernel parameters are sliced into / filled from that layout.
+  void save(torch::serialize::OutputArchive &archive) const override;
+  void load(torch::serialize::InputArchive &archive) override;
 };
 
 // the k_* globals NeuralGS reads (config/base.yaml:37-74)

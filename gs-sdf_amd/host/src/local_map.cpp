@@ -70,6 +70,67 @@ LocalMap::LocalMap(const Tensor &pos_W_M, const MapConfig &cfg) : cfg_(cfg) {
   if (p_decoder_tcnn_->biases_.defined()) p_decoder_tcnn_->biases_ = register_parameter("decoder_bias", p_decoder_tcnn_->biases_, true);
 }
 
+// ---- checkpoint layout (neural_mapping.cpp:1331-1378; reference module layout local_map.cpp:29-55,73-75) ------------------------
+namespace {
+// the reference's decoder_implementation 0 module, with the flat fused-kernel parameters copied in (or out)
+torch::nn::Sequential sequential_of(const TCNNNetwork &net, bool copy_in) {
+  torch::nn::Sequential seq;
+  const auto &d = net.dims_;
+  int64_t wo = 0, bo = 0;
+  torch::NoGradGuard ng;
+  for (size_t l = 0; l + 1 < d.size(); ++l) {
+    torch::nn::Linear lin(torch::nn::LinearOptions(d[l], d[l + 1]).bias(true));
+    if (copy_in) {
+      lin->weight.copy_(net.params_.detach().slice(0, wo, wo + (int64_t)d[l] * d[l + 1]).view({d[l + 1], d[l]}).cpu());
+      if (net.biases_.defined()) lin->bias.copy_(net.biases_.detach().slice(0, bo, bo + d[l + 1]).cpu());
+      else lin->bias.zero_();
+    }
+    wo += (int64_t)d[l] * d[l + 1]; bo += d[l + 1];
+    seq->push_back(lin);
+    if (l + 2 < d.size()) seq->push_back(torch::nn::ReLU(torch::nn::ReLUOptions(true)));
+  }
+  return seq;
+}
+}  // namespace
+
+void LocalMap::save(torch::serialize::OutputArchive &archive) const {
+  archive.write(p_encoder_tcnn_->name_, p_encoder_tcnn_->params_.detach().cpu());
+  if (cfg_.decoder_implementation != 0) {
+    archive.write(p_decoder_tcnn_->name_, p_decoder_tcnn_->params_.detach().cpu());
+    return;
+  }
+  torch::serialize::OutputArchive child(archive.compilation_unit());
+  sequential_of(*p_decoder_tcnn_, true)->save(child);
+  archive.write("decoder", child);
+}
+
+void LocalMap::load(torch::serialize::InputArchive &archive) {
+  torch::NoGradGuard ng;
+  // everything is read and validated BEFORE anything is copied: a refused checkpoint leaves the map untouched
+  Tensor enc;
+  TORCH_CHECK(archive.try_read(p_encoder_tcnn_->name_, enc), "LocalMap::load: no '", p_encoder_tcnn_->name_, "' parameter (not a LocalMap checkpoint)");
+  TORCH_CHECK(enc.numel() == p_encoder_tcnn_->params_.numel(), "LocalMap::load: hash-grid table has ", enc.numel(), " entries, this map ",
+              p_encoder_tcnn_->params_.numel());
+  Tensor dec_w, dec_b;
+  if (cfg_.decoder_implementation != 0) {
+    TORCH_CHECK(archive.try_read(p_decoder_tcnn_->name_, dec_w) && dec_w.numel() == p_decoder_tcnn_->params_.numel(),
+                "LocalMap::load: flat 'decoder' parameter missing or of the wrong size (decoder_implementation 1)");
+  } else {
+    torch::serialize::InputArchive child;
+    TORCH_CHECK(archive.try_read("decoder", child), "LocalMap::load: no 'decoder' submodule (decoder_implementation 0 expects the Sequential layout)");
+    auto seq = sequential_of(*p_decoder_tcnn_, false);
+    seq->load(child);   // throws on a missing / mis-shaped decoder.<2k>.weight / .bias
+    std::vector<Tensor> ws, bs;
+    for (auto &mod : seq->children())
+      if (auto *lin = mod->as<torch::nn::Linear>()) { ws.push_back(lin->weight.reshape({-1})); bs.push_back(lin->bias.reshape({-1})); }
+    dec_w = torch::cat(ws); dec_b = torch::cat(bs);
+    TORCH_CHECK(dec_w.numel() == p_decoder_tcnn_->params_.numel(), "LocalMap::load: decoder topology differs");
+  }
+  p_encoder_tcnn_->params_.copy_(enc.reshape(p_encoder_tcnn_->params_.sizes()).to(p_encoder_tcnn_->params_.device()));
+  p_decoder_tcnn_->params_.copy_(dec_w.reshape(p_decoder_tcnn_->params_.sizes()).to(p_decoder_tcnn_->params_.device()));
+  if (p_decoder_tcnn_->biases_.defined() && dec_b.defined()) p_decoder_tcnn_->biases_.copy_(dec_b.to(p_decoder_tcnn_->biases_.device()));
+}
+
 // ---- SubMap ----------------------------------------------------------------------------------------------------------------
 Tensor LocalMap::xyz_to_m1p1_pts(const Tensor &xyz) const { return (xyz - pos_W_M_) * 2 * map_size_inv_; }
 Tensor LocalMap::m1p1_pts_to_xyz(const Tensor &pts) const { return scale_from_m1p1(pts) + pos_W_M_; }

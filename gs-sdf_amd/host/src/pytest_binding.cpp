@@ -192,6 +192,8 @@ PYBIND11_MODULE(_gsdf_host, m) {
         for (auto &kv : l.named_parameters()) out[kv.key()] = kv.value();
         return out;
       })
+      .def("save_checkpoint", [](const std::shared_ptr<gm::LocalMap> &l, const std::string &path) { torch::save(l, path); })    // neural_mapping.cpp:1334
+      .def("load_checkpoint", [](std::shared_ptr<gm::LocalMap> &l, const std::string &path) { torch::load(l, path); })          // :1351
       .def("update_octree_as", &gm::LocalMap::update_octree_as, py::arg("xyz"), py::arg("is_prior") = false)
       .def("get_inrange_mask", &gm::LocalMap::get_inrange_mask, py::arg("xyz"), py::arg("padding") = 0.f)
       .def("get_intersect_point", [](gm::LocalMap &l, const torch::Tensor &pts, const torch::Tensor &rays, float padding) {

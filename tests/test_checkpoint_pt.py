@@ -105,3 +105,19 @@ def test_tcnn_padded_decoder_layout_is_accepted_and_written(tmp_path):
     bad.decoder = types.SimpleNamespace(dims=[32, 64, 64, 2], params_=torch.zeros(32 * 64 + 64 * 64 + 128), biases_=None)
     with pytest.raises(RuntimeError, match="padded layout"):
         load_local_map_checkpoint(bad, p)
+
+
+def test_refused_checkpoint_leaves_the_map_untouched(tmp_path):
+    """the decoder is validated BEFORE the encoder is copied — a checkpoint whose decoder does not fit changes nothing."""
+    from gs_sdf_amd.checkpoint import load_local_map_checkpoint, save_local_map_checkpoint
+    p = tmp_path / "impl1.pt"
+    save_local_map_checkpoint(_fake_local_map(1, 3), p)
+    lm = _fake_local_map(0, 4)                                # a biased Sequential decoder cannot take the flat tcnn parameter
+    dims = [32, 64, 64, 64, 64, 2]
+    g = torch.Generator().manual_seed(1)
+    lm.decoder = types.SimpleNamespace(dims=dims, params_=torch.randn(sum(i * o for i, o in zip(dims[:-1], dims[1:])), generator=g),
+                                       biases_=torch.randn(sum(dims[1:]), generator=g))
+    before = (lm.encoder.params_.clone(), lm.decoder.params_.clone(), lm.decoder.biases_.clone())
+    with pytest.raises(RuntimeError, match="does not fit"):
+        load_local_map_checkpoint(lm, p)
+    assert torch.equal(lm.encoder.params_, before[0]) and torch.equal(lm.decoder.params_, before[1]) and torch.equal(lm.decoder.biases_, before[2])

@@ -108,8 +108,8 @@ def test_baseline_shape_parity(oracle, name):
             failures.append(f"{key}: an element is {st['worst_over_tol']:.2f} x its tolerance ({st['worst_over_base']:.1f} x the 1e-4 bar)")
         if st["needed"] > max(8, MAX_NEEDED * st["elements"]):
             failures.append(f"{key}: {st['needed']} of {st['elements']} elements above the plain 1e-4 bar")
-        if st["rel_l2"] > 1e-5:
-            failures.append(f"{key}: relative L2 over all elements {st['rel_l2']:.2e} > 1e-5")
+        if st["rel_l2"] > 1e-5 + st["l2_allowance"]:
+            failures.append(f"{key}: relative L2 over all elements {st['rel_l2']:.2e} > 1e-5 + {st['l2_allowance']:.1e}")
     a = [None, got["v_ray_transforms"], got["v_colors"], None, got["v_normals"]]
     up0 = got["v_means2d"]
     # ---- projection / SH backward at the same size: HIP vs the oracle's fp64 build fed with the SAME upstream gradients ----

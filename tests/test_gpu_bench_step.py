@@ -194,5 +194,7 @@ def test_direct_splat_leg_with_sh_degree_3(tmp_path):
     ref, got = out["autograd"], out["direct"]
     assert {k: int(v) for k, v in got["sizes"].items()} == {k: int(v) for k, v in ref["sizes"].items()}
     assert float(ref["splat"].abs().sum()) > 0
-    assert_close(got["splat"], ref["splat"], 1e-4, "direct vs autograd: splat gradients (SH degree 3)")
+    # two separate runs of the same kernels: the compositing backward's fp32 atomics arrive in a different order, so a handful of the
+    # 1.5e8 elements (sums of hundreds of cancelling terms) may differ beyond 1e-4 — at most 12, none beyond 2e-2 (util.assert_close)
+    assert_close(got["splat"], ref["splat"], 1e-4, "direct vs autograd: splat gradients (SH degree 3)", outlier_frac=1e-9)
     assert_close(got["sdf"][0], ref["sdf"][0], 1e-4, "direct vs autograd: SDF network gradients")

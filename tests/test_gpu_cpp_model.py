@@ -310,3 +310,49 @@ def test_neural_gs_sdf_aided_initialisation(host):
     assert_close(gs2.opacity_.detach(), torch.full((20000,), math.log(0.1 / 0.9), device=dev), 1e-6, "logit(0.1)")
     assert_close(gs2.quaternion_.detach().norm(dim=-1), torch.ones(20000, device=dev), 1e-5, "unit quaternions")
     assert gs2.features_rest_.shape == (20000, 0, 3)
+
+
+@pytest.mark.parametrize("impl", [0, 1])
+def test_cpp_local_map_checkpoint_round_trips_with_the_python_mirror(host, tmp_path, impl):
+    """local_map_checkpoint.pt written by gsdf_model::LocalMap (torch::save of the module, neural_mapping.cpp:1334) is the REFERENCE'S
+    archive layout — submodule `decoder` = Sequential with decoder.<2k>.weight / .bias for decoder_implementation 0, the flat `decoder`
+    for 1 — so checkpoint.load_local_map_checkpoint reads it, and the file checkpoint.save_local_map_checkpoint writes loads back into
+    the C++ class (the flat {decoder, decoder_bias} pair it used to write loaded nowhere)."""
+    from gs_sdf_amd.checkpoint import load_local_map_checkpoint, save_local_map_checkpoint
+    cm, pm, cfg = make_maps(host, impl)
+    with torch.no_grad():
+        for t in (pm.encoder.params_, pm.decoder.params_):
+            t.add_(1.0)                                            # the mirror differs before the load
+    p1 = str(tmp_path / "from_cpp.pt")
+    cm.save_checkpoint(p1)
+    names = set(dict(torch.jit.load(p1, map_location="cpu").named_parameters()))
+    layers = range(0, 2 * (cfg.geo_num_layer + 2), 2)
+    assert names == ({"encoder_local_map"} | {f"decoder.{i}.{w}" for i in layers for w in ("weight", "bias")} if impl == 0
+                     else {"encoder_local_map", "decoder"})
+    load_local_map_checkpoint(pm, p1)
+    assert torch.equal(pm.encoder.params_.reshape(-1), cm.encoder.params_.reshape(-1)) and torch.equal(pm.decoder.params_, cm.decoder.params_)
+    if impl == 0:
+        assert torch.equal(pm.decoder.biases_, cm.decoder.biases_)
+    # Python -> C++
+    with torch.no_grad():
+        pm.encoder.params_.mul_(0.5); pm.decoder.params_.mul_(-2.0)
+        if impl == 0:
+            pm.decoder.biases_.add_(0.25)
+    p2 = str(tmp_path / "from_python.pt")
+    save_local_map_checkpoint(pm, p2)
+    cm.load_checkpoint(p2)
+    assert torch.equal(cm.encoder.params_.reshape(-1), pm.encoder.params_.reshape(-1)) and torch.equal(cm.decoder.params_, pm.decoder.params_)
+    if impl == 0:
+        assert torch.equal(cm.decoder.biases_, pm.decoder.biases_)
+    # a checkpoint of the other decoder implementation is refused and leaves the map untouched
+    other, _, _ = make_maps(host, 1 - impl)
+    p3 = str(tmp_path / "other.pt")
+    other.save_checkpoint(p3)
+    before = (cm.encoder.params_.clone(), cm.decoder.params_.clone())
+    with pytest.raises(RuntimeError):
+        cm.load_checkpoint(p3)
+    assert torch.equal(cm.encoder.params_, before[0]) and torch.equal(cm.decoder.params_, before[1])
+    before = (pm.encoder.params_.clone(), pm.decoder.params_.clone())
+    with pytest.raises(RuntimeError):
+        load_local_map_checkpoint(pm, p3)
+    assert torch.equal(pm.encoder.params_, before[0]) and torch.equal(pm.decoder.params_, before[1])

@@ -454,3 +454,31 @@ def test_reference_meshing_on_the_dropin(host, ref):
     f = f.index_select(0, keep)
     assert v.shape == v_ref.shape and f.shape == f_ref.shape, (v.shape, v_ref.shape, f.shape, f_ref.shape)
     assert torch.equal(v, v_ref) and torch.equal(f.to(f_ref.dtype), f_ref)
+
+
+@pytest.mark.parametrize("impl", [0, 1])
+def test_gsdf_model_checkpoint_loads_in_the_references_local_map_and_back(host, ref, tmp_path, impl):
+    """torch::save(gsdf_model::LocalMap) -> torch::load(the reference's LocalMap) and the other way (neural_mapping.cpp:1331-1352): the C++
+    model class writes the reference's archive layout in both decoder implementations."""
+    rl, cm, cfg = make_maps(host, ref, impl)
+    with torch.no_grad():
+        cm.encoder.params_.mul_(0.5); cm.decoder.params_.mul_(-1.5)
+        if impl == 0:
+            cm.decoder.biases_.add_(0.125)
+    p1 = str(tmp_path / "from_gsdf_model.pt")
+    cm.save_checkpoint(p1)
+    ref.load_local_map(rl, p1)
+    rp = rl.named_parameters()
+    layers = (0, 2, 4, 6, 8)
+    assert torch.equal(rp["encoder_local_map"].reshape(-1), cm.encoder.params_.reshape(-1))
+    if impl == 0:
+        assert torch.equal(torch.cat([rp[f"decoder.{i}.weight"].reshape(-1) for i in layers]), cm.decoder.params_)
+        assert torch.equal(torch.cat([rp[f"decoder.{i}.bias"] for i in layers]), cm.decoder.biases_)
+    else:
+        assert torch.equal(rp["decoder"].reshape(-1), cm.decoder.params_)
+    with torch.no_grad():
+        rp["encoder_local_map"].add_(1.0)
+    p2 = str(tmp_path / "from_reference.pt")
+    ref.save_local_map(rl, p2)
+    cm.load_checkpoint(p2)
+    assert torch.equal(cm.encoder.params_.reshape(-1), rp["encoder_local_map"].reshape(-1))

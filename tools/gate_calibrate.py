@@ -21,7 +21,7 @@ out = {}
 
 def run(name, sc, vm, W, H, deg, V, bg):
     t0 = time.time()
-    Kd = sc["K"].expand(V, 3, 3).contiguous() if sc["K"].dim() == 2 else sc["K"]
+    Kd = sc["K"].reshape(-1, 3, 3)[:1].expand(V, 3, 3).contiguous()
     p = orc.projection_2dgs_fwd(n(sc["means"]), n(sc["quats"]), n(sc["log_scales"].exp()), n(vm), n(Kd), W, H, prec="f32")
     col = orc.view_colors_fwd(n(vm), n(sc["means"]), n(sc["sh"]), p["camera_ids"], p["gaussian_ids"], deg, prec="f32")
     opa = n(torch.sigmoid(sc["logit_opacities"]))[p["gaussian_ids"]]
