@@ -95,6 +95,11 @@ def main():
                     help="SDF samples of the visible splats: center = k_center_reg 1 (splat centres, weight 1: the fully specified mode the "
                          "parity / benchmark runs use, SURVEY appendix A.1); stochastic = the reference's default (center_reg absent from "
                          "config/base.yaml): one random point on every visible splat's disc, weight exp(-|eps|^2/2)")
+    ap.add_argument("--ray-batch", default="sampled", choices=["sampled", "pool"],
+                    help="sampled (default, C++ step): the reference's per-iteration ray-batch construction inside the timed step — random rays "
+                         "gathered from a host-side depth-ray pool, H2D copy, octree ray march + free / surface / end-point samples, truncation, "
+                         "in-range filter, throttled to ~32768 points (neural_mapping.cpp:138-164, 73-104, 324-330); pool: 8 pre-generated batches "
+                         "of 32768 uniform points (rounds 1-3; what --dump-grads and the Python mirror use)")
     ap.add_argument("--splat-order", default="as-given", choices=["morton", "as-given"],
                     help="memory order of the splat set: the synthetic scene's random order, or Morton order of the centres "
                          "(trainer.morton_order; measured: no gain, the fine hash-grid levels scatter either way, DESIGN.md section 11)")
@@ -159,9 +164,16 @@ def main():
         cpp_up = [] if args.step_terms == "reference" else [ug6[k] for k in ("v_render_depths", "v_render_alphas", "v_render_normals", "v_render_median")]
         if dist is not None:      # view-parallel: one collective per parameter family, on the stream its optimizer runs on
             def _mean_over_ranks(g):
-                dist.all_reduce(g)
-                g.mul_(1.0 / world)
+                if backend == "nccl":
+                    dist.all_reduce(g, op=dist.ReduceOp.AVG)     # RCCL averages inside the collective: no second pass over the buffer
+                else:                                            # gloo (CPU-side test runs) has no AVG
+                    dist.all_reduce(g)
+                    g.mul_(1.0 / world)
             ji.set_grad_hooks(_mean_over_ranks, _mean_over_ranks)
+    batcher = None
+    if impl == "cpp" and args.ray_batch == "sampled" and not args.dump_grads:
+        import gs_sdf_amd.hostlib as hostlib
+        batcher = RayBatcher(hostlib.load(), sc, views, dev)
     groups = []
     if not args.no_sdf and impl == "python":
         # hash-grid SDF (2^19 table, 16 levels x 2) + fused MFMA decoder; the reference's numerical-gradient
@@ -259,7 +271,14 @@ def main():
         stamp("begin")
         if impl == "cpp":
             vi = (i * world + rank) % views.shape[0]
-            sz = ji.step(views[vi][None], K, target, cpp_pool[i % 8], cpp_ray_sdf[i % 8], cpp_up, update, cpp_cams[vi])
+            if batcher is not None:
+                rp, rs = batcher.take(torch.cuda.current_stream())
+            else:
+                rp, rs = cpp_pool[i % 8], cpp_ray_sdf[i % 8]
+            sz = ji.step(views[vi][None], K, target, rp, rs, cpp_up, update, cpp_cams[vi])
+            if batcher is not None:
+                batcher.issue()            # the NEXT step's batch, while this step runs (see RayBatcher)
+            hist.setdefault("n_ray_pts", []).append(int(rp.shape[0]))
             for k in ("M", "I", "n_gs_sdf"):
                 hist.setdefault(k, []).append(int(sz[k]))
             sizes.update({k: int(v) for k, v in sz.items()})
@@ -477,7 +496,8 @@ def main():
         M, I, n_gs = avg["M"], avg["I"], avg.get("n_gs_sdf", 0.0)        # means over the timed steps (views differ per step)
         P, T = W * H, ((W + 15) // 16) * ((H + 15) // 16)
         Kb = (deg + 1) ** 2
-        base_pts = 0 if args.no_sdf else 32768 + n_gs                      # points that carry gradients (ray batch + splat samples)
+        n_ray = avg.get("n_ray_pts", 32768.0)                              # the per-ray batch of the step (sampled: ~32768 by the throttle)
+        base_pts = 0 if args.no_sdf else n_ray + n_gs                      # points that carry gradients (ray batch + splat samples)
         sdf_pts = 7 * base_pts                                            # + their 6 central-difference points (forward-only when analytic)
         # algorithmic bytes / flops per STEP of each operator, divided by its launches per step
         # below.  The dominant kernel is the one with the largest total time per step.
@@ -502,24 +522,27 @@ def main():
         per_step = {k: kern_mean.get(k, 0.0) * calls.get(k, 0) / args.steps for k in list(alg) + list(flops)}
         dom = max(per_step, key=lambda k: per_step[k])
         dom_rule = "largest time per step by the in-bench HIP-event timers"
-        # The in-bench timers bracket whole entry points on their stream, so beside the other leg they also count the time a launch
-        # waits for CUs; rocprofv3's kernel trace of this same command does not.  When its summary is committed, the dominant kernel is
-        # the one IT ranks first (the contract's own cross-check), timed here as always.
-        spath = os.path.join(ROOT, "profiles", "r03_bench_cfg3_kernel_stats.csv")
-        if args.workload == "cfg3_1M_1080p" and analytic and not args.no_sdf and os.path.exists(spath):
+        # The dominant kernel is chosen from THIS run's timers (above).  Cross-check, reported next to it: the operator the newest committed
+        # rocprofv3 --kernel-trace --stats summary of the same command ranks first (profiles/rNN_bench_cfg3_kernel_stats.csv).  The in-bench
+        # timers bracket whole entry points on their stream, so beside the other leg they also count the time a launch waits for CUs;
+        # rocprofv3's kernel trace does not — when the two disagree both are in the line, the live one prices the roofline.
+        rocprof_first = None
+        import glob
+        spaths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_bench_cfg3_kernel_stats.csv")))
+        if args.workload == "cfg3_1M_1080p" and analytic and not args.no_sdf and spaths:
             import csv
             kmap = (("hashgrid_fwd", "hashgrid_fwd"), ("raster_bwd_kernel", "rasterize_2dgs_bwd"), ("raster_fwd_kernel", "rasterize_2dgs_fwd"),
                     ("mlp_bwd_split", "mlp_bwd"), ("mlp_fwd_split", "mlp_fwd"), ("bin_apply", "hashgrid_bwd"), ("bin_emit", "hashgrid_bwd"))
             share = {}
-            for row in list(csv.reader(open(spath)))[1:]:
+            for row in list(csv.reader(open(spaths[-1])))[1:]:
                 for sub, op in kmap:
                     if sub in row[0]:
                         share[op] = share.get(op, 0.0) + float(row[4])
                         break
-            top = max(share, key=lambda k: share[k]) if share else None
-            if top in per_step:
-                dom, dom_rule = top, (f"first in rocprofv3 --kernel-trace --stats of this command (profiles/r03_bench_cfg3_kernel_stats.csv: "
-                                      f"{share[top]:.1f} % of GPU time); timed live here")
+            if share:
+                top = max(share, key=lambda k: share[k])
+                rocprof_first = {"operator": top, "percent_of_gpu_time": share[top], "file": os.path.relpath(spaths[-1], ROOT),
+                                 "agrees_with_live_selection": top == dom}
         dur_ms = kern_mean.get(dom, float("nan"))
 
         split_mlp = os.environ.get("GSDF_MLP_MFMA", "bf16x3")[:1] not in "fF"
@@ -569,7 +592,15 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.workload}: {N} random Gaussians, {W}x{H}, sh_degree {deg}, 1 view/GPU/step; means over the timed "
                                    f"steps: M={M:.0f} I={I:.0f} L={I / T:.0f}" + ("" if args.no_sdf else f"; hash-grid SDF (2^19 x16x2, fused "
-                                   f"64-wide MLP) evaluated at {sdf_pts:.0f} points/step = 7 x (32768 ray + {n_gs:.0f} splat samples)"),
+                                   f"64-wide MLP) evaluated at {sdf_pts:.0f} points/step = 7 x ({n_ray:.0f} ray + {n_gs:.0f} splat samples)"),
+                       "ray_batch": (None if args.no_sdf else
+                                     ({"mode": "sampled inside the timed step, one step ahead on its own stream (bench.py: RayBatcher): random rays gathered from a "
+                                               "host-side synthetic depth pack (2 M rays: camera centre -> splat centre), H2D copy, octree ray march (1 sample per "
+                                               "occupied voxel) + 3 free + 3 near-surface samples + end point per ray, targets truncated at 3 leaves, in-range filter, "
+                                               "throttled to ~32768 points per batch (neural_mapping.cpp:138-164, 73-104, 324-330; local_map.cpp:449-509)",
+                                       "rays_per_step": sum(a for a, _ in batcher.hist[-args.steps:]) / max(1, len(batcher.hist[-args.steps:])),
+                                       "points_per_step": n_ray} if batcher is not None else
+                                      {"mode": "8 pre-generated batches of 32768 uniform points (--ray-batch pool)", "points_per_step": n_ray})),
                        "sdf_config": None if args.no_sdf else args.sdf_config,
                        "step_impl": ("C++/libtorch: gsdf_extras::JointIteration (gs-sdf_amd/host/src/joint_step.cpp) over libgsdf_torch.so -> C ABI -> "
                                      "libgsdf_hip.so; " + ("two HIP streams, the splat leg's operators called through the C ABI directly (step_direct: no autograd engine), the "
@@ -578,7 +609,9 @@ def main():
                                      "the pybind harness" if impl == "cpp" else "Python mirror (gs_sdf_amd.ops / sdf over ctypes -> C ABI), "
                                      + ("four HIP streams" if overlap else "one HIP stream")),
                        "step": "reference joint iteration (neural_mapping.cpp:400-486): " + terms,
-                       "parallelism": f"view-parallel x{world}" if world > 1 else "single GPU",
+                       "parallelism": (f"view-parallel x{world}: torch.distributed backend {dist.get_backend()} ({'RCCL' if dist.get_backend() == 'nccl' else 'host-side'}), "
+                                       f"world_size {dist.get_world_size()}, one process per GPU, gradient all-reduce (ReduceOp.{'AVG' if backend == 'nccl' else 'SUM, then 1/N'}) "
+                                       "per parameter family on the stream its optimizer runs on" if world > 1 else "single GPU"),
                        "splat_order": "Morton order of the centres (trainer.morton_order)" if args.splat_order == "morton" else "as given (random)",
                        "sample_mode": ("center_reg = 1: SDF samples = splat centres, weight 1" if args.sample_mode == "center" else
                                        "stochastic (the reference's default, center_reg absent): one random point per visible splat's disc, "
@@ -586,7 +619,7 @@ def main():
                        "decoder_arithmetic": ("fp32 operands as 3 exact bf16 terms, 6 partial products per multiply-add on the bf16 MFMA pipe, "
                                               "fp32 accumulate: error against fp64 equal to the fp32 MFMA's (tools/ubench/mfma_split.hip)"
                                               if split_mlp_cfg else "fp32 MFMA")},
-            "roofline": dict(roof(dom), kernel=dom, kernel_selection=dom_rule, traffic=traffic, avg_launch_ms=dur_ms, median_launch_ms=kern.get(dom),
+            "roofline": dict(roof(dom), kernel=dom, kernel_selection=dom_rule, committed_rocprof_ranking=rocprof_first, traffic=traffic, avg_launch_ms=dur_ms, median_launch_ms=kern.get(dom),
                              # what the kernel actually moves (PMC FETCH_SIZE + WRITE_SIZE of a single-stream run, profiles/) over its
                              # launch time measured here: how hard it drives HBM, next to `frac` (= algorithmic bytes only).  The binned
                              # scatter trades 2.6x more, fully coalesced, bytes for not using the 21 G/s fp32 atomic units; in the
@@ -695,6 +728,70 @@ def cabi_timing_to_ops(rep):
     for op in calls:
         mean[op] = tot[op] / max(1, calls[op])
     return med, mean, calls
+
+
+class RayBatcher:
+    """The reference's per-iteration SDF ray batch, built INSIDE the timed step:
+      NeuralSLAM::sdf_train_batch_iter (neural_mapping.cpp:138-164): k_batch_num random indices into the HOST-side depth pack
+        (train_depth_pack_ lives on the CPU, :145-156), gather, copy to the device;
+      NeuralSLAM::sample (:73-104) = gsdf_model::sample_rays (host/src/local_map.cpp): LocalMap::sample — octree ray march, one sample per
+        occupied voxel crossed (gsdf occ_raymarch kernels), + free_sample_num stratified samples, those in front of the surface kept
+        (local_map.cpp:449-509) — + surface_sample_num samples at depth - N(0, sample_std), targets truncated at +-truncated_dis, + the ray end
+        points, in-range filter;
+      the throttle of the training loop (:324-330): k_batch_num = min(batch_pt_num / EMA(points per ray), batch_pt_num), so that a batch
+        holds ~batch_pt_num = 32768 points.
+    The batch depends on the occupancy structure and the rays only, never on the parameters: it is issued ONE STEP AHEAD on a stream of its
+    own (a data-loader prefetch), so its size read-backs (nonzero) wait for its own small kernels, not for the training step in flight.
+    Synthetic depth pack: rays from the 200 camera centres to splat centres (every ray ends in an occupied leaf), 10000 per view."""
+
+    def __init__(self, host, sc, views, dev, batch_pt_num=32768, rays_per_view=10000, leaf=0.0625, map_size=16.0, seed=7):
+        self.host, self.dev, self.batch_pt_num = host, dev, batch_pt_num
+        cfg = host.MapConfig()
+        cfg.leaf_size, cfg.inner_map_size = leaf, map_size - 2 * leaf
+        self.lm = host.LocalMap(torch.tensor([0.0, 0.0, 5.5]), cfg)
+        self.lm.update_octree_as(sc["means"].to(dev), False)
+        g = torch.Generator().manual_seed(seed)
+        c2w = torch.linalg.inv(views.cpu().double())
+        centres = c2w[:, :3, 3].float()                                               # camera centres in the world
+        V, N = centres.shape[0], sc["means"].shape[0]
+        idx = torch.randint(0, N, (V, rays_per_view), generator=g)
+        end = sc["means"][idx.reshape(-1)]
+        org = centres[:, None, :].expand(V, rays_per_view, 3).reshape(-1, 3)
+        d = end - org
+        depth = d.norm(dim=1, keepdim=True)
+        pin = lambda t: t.contiguous().pin_memory()
+        self.pack = dict(origin=pin(org), direction=pin(d / depth), depth=pin(depth), xyz=pin(end))   # the host-side depth pack
+        self.n_rays = org.shape[0]
+        self.k_batch_num, self.pts_per_ray = batch_pt_num, 1.0                        # nsdf_train: k_batch_num = k_batch_ray_num (= batch_pt_num)
+        self.stream = torch.cuda.Stream(device=dev)
+        self.gen = torch.Generator().manual_seed(seed + 1)
+        self.sample_std, self.truncated_dis = 0.02, 3 * leaf                          # base.yaml: sample_std; truncated at 3 leaves
+        self.ready = None
+        self.hist = []
+
+    def issue(self):
+        """queues the next batch on the prefetch stream -> nothing; `take()` hands it to the step"""
+        n = int(self.k_batch_num)
+        indices = (torch.rand(n, generator=self.gen) * self.n_rays).long().clamp_(0, self.n_rays - 1)      # :141-149
+        with torch.cuda.stream(self.stream):
+            rays = {k: v.index_select(0, indices).to(self.dev, non_blocking=True) for k, v in self.pack.items()}   # :151-156
+            b = self.host.sample_rays(self.lm, rays, self.sample_std, self.truncated_dis, 3, True)
+            ev = torch.cuda.Event()
+            ev.record(self.stream)
+        pt_n = int(b["xyz"].shape[0])
+        self.pts_per_ray = self.pts_per_ray * 0.9 + (pt_n / max(n, 1)) * 0.1           # :324-327
+        self.k_batch_num = max(1, min(int(self.batch_pt_num / self.pts_per_ray), self.batch_pt_num))
+        self.hist.append((n, pt_n))
+        self.ready = (b["xyz"].contiguous(), b["ray_sdf"].contiguous(), ev)
+
+    def take(self, consumer_stream):
+        if self.ready is None:
+            self.issue()
+        xyz, rsdf, ev = self.ready
+        consumer_stream.wait_event(ev)
+        xyz.record_stream(consumer_stream); rsdf.record_stream(consumer_stream)
+        self.ready = None
+        return xyz, rsdf
 
 
 def make_cpp_iteration(args, sc, params, dev, W, H, deg, views):

@@ -449,8 +449,11 @@ extern "C" int gsdf_mlp_bwd(int64_t B, int n_layers, const int *dims_host, const
   if (v_weights != nullptr) {   // both gradients wanted: one pass on the bf16 pipe, v_pre never leaves the registers
     rc = mlp_bwd_split_launch(B, d, weights, in, acts, v_out, v_in, v_weights, biases != nullptr ? v_biases : nullptr, ws, stream);
     if (rc != 0) return rc < 0 ? rc : GSDF_OK;
+  } else if (ws == nullptr) {   // input gradient only and NOTHING saved (round 4): the chain alone on the bf16 pipe, ReLU masks instead of activations
+    rc = mlp_bwd_data_split_launch(B, d, weights, acts, v_out, v_in, stream);
+    if (rc != 0) return rc < 0 ? rc : GSDF_OK;
   }
-  GSDF_REQUIRE(ws, "mlp_bwd: null workspace");
+  GSDF_REQUIRE(ws, "mlp_bwd: null workspace (only the topologies gsdf_mlp_bwd_is_one_pass covers run without one)");
   const size_t lds = lds_floats * sizeof(float);
   GSDF_REQUIRE(lds <= 160 * 1024, "mlp_bwd: %zu bytes of weights do not fit the 160 KiB LDS", lds);
   float *v_pre = (float *)ws;
@@ -471,7 +474,9 @@ extern "C" int gsdf_mlp_bwd(int64_t B, int n_layers, const int *dims_host, const
   return GSDF_OK;
 }
 
-extern "C" size_t gsdf_mlp_bwd_bwd_ws_bytes(int64_t B, int n_layers) { return gsdf_mlp_acts_floats(B, n_layers) * sizeof(float) + 256; }
+extern "C" size_t gsdf_mlp_bwd_bwd_ws_bytes(int64_t B, int n_layers) {   // tangent images, then the per-wave partial weight gradients of the recompute path
+  return align_up(gsdf_mlp_acts_floats(B, n_layers) * sizeof(float) + 256, 256) + mlp_bwd_split_ws_bytes_bound(B, n_layers);
+}
 
 extern "C" int gsdf_mlp_bwd_bwd(int64_t B, int n_layers, const int *dims_host, const float *weights, const float *acts,
                                 const float *v_out, const void *bwd_ws, const float *vv_in, float *g_vout, float *g_weights,
@@ -484,12 +489,32 @@ extern "C" int gsdf_mlp_bwd_bwd(int64_t B, int n_layers, const int *dims_host, c
   int rc = make_desc(n_layers, dims_host, 0, false, &d, &lds_floats, "mlp_bwd_bwd");
   if (rc) return rc;
   if (B == 0) return GSDF_OK;
-  GSDF_REQUIRE(weights && acts && v_out && bwd_ws && vv_in && ws, "mlp_bwd_bwd: null buffer");
+  GSDF_REQUIRE(weights && acts && v_out && vv_in && ws, "mlp_bwd_bwd: null buffer");
+  GSDF_REQUIRE(g_vout != nullptr, "mlp_bwd_bwd: g_vout [B, d_out] is required (it is the masked forward's output buffer)");
+  if (bwd_ws == nullptr) {
+    // Round 4, no saved v_pre images: (1) the tangent pass on the bf16 pipe (masked forward of vv_in, images t_0 .. t_{n-2} into ws),
+    // (2) ONE pass that recomputes the chain v_out -> v_pre_l in registers from the ReLU masks and accumulates dL/dW_l += v_pre_l (x) t_{l-1}
+    // (mlp_split.hip: BWD_TANGENT).  Only for the topologies the one-pass backward covers (gsdf_mlp_bwd_is_one_pass).
+    MlpDesc db;
+    rc = make_desc(n_layers, dims_host, 0, true, &db, &lds_floats, "mlp_bwd_bwd");
+    if (rc) return rc;
+    GSDF_REQUIRE(mlp_bwd_split_covers(db), "mlp_bwd_bwd: bwd_ws = NULL (recompute) needs a topology gsdf_mlp_bwd_is_one_pass covers");
+    float *tangent = (float *)ws;
+    rc = mlp_fwd_masked_split_launch(B, d, weights, vv_in, g_vout, tangent, acts, stream);
+    GSDF_REQUIRE(rc != 0, "mlp_bwd_bwd: the masked forward does not cover this topology");
+    if (rc < 0) return rc;
+    if (g_weights != nullptr) {
+      void *part = (char *)ws + align_up(gsdf_mlp_acts_floats(B, n_layers) * sizeof(float) + 256, 256);
+      rc = mlp_bwd_tangent_split_launch(B, db, weights, vv_in, tangent, acts, v_out, g_weights, part, stream);
+      GSDF_REQUIRE(rc != 0, "mlp_bwd_bwd: the recompute pass does not cover this topology");
+      if (rc < 0) return rc;
+    }
+    return GSDF_OK;
+  }
   // (1) masked bias-free forward of vv_in: u_l = D_l W_l u_{l-1} saved as a register image in ws, last layer -> dL/d v_out
   const size_t lds = lds_floats * sizeof(float);
   GSDF_REQUIRE(lds <= 160 * 1024, "mlp_bwd_bwd: %zu bytes of weights do not fit the 160 KiB LDS", lds);
   float *u_img = (float *)ws;
-  GSDF_REQUIRE(g_vout != nullptr, "mlp_bwd_bwd: g_vout [B, d_out] is required (it is the masked forward's output buffer)");
   float *sink = g_vout;
   if (d.d_in == 32) {
     GSDF_HIP(hipFuncSetAttribute((const void *)mlp_fwd_kernel<32, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "mlp_bwd_bwd attr");

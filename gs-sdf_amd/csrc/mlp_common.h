@@ -61,6 +61,12 @@ bool mlp_bwd_split_covers(const MlpDesc &d);
 // of one round of ~14.5 K atomics per wave on the same 58 KB (measured 0.3 us per wave: 0.3 ms of a 0.55 ms launch at 494 K points)
 int mlp_bwd_split_launch(int64_t B, const MlpDesc &d, const float *W, const float *in, const float *acts, const float *v_out,
                          float *v_in, float *v_W, float *v_b, void *ws, hipStream_t stream);
+// round 4, the analytic configuration's e0 backward and double backward on the same pipe (mlp_split.hip: BWD_DATA / BWD_TANGENT, MASKED):
+int mlp_bwd_data_split_launch(int64_t B, const MlpDesc &d, const float *W, const float *acts, const float *v_out, float *v_in, hipStream_t stream);
+int mlp_fwd_masked_split_launch(int64_t B, const MlpDesc &d, const float *W, const float *vv_in, float *out, float *tangent, const float *mask_acts,
+                                hipStream_t stream);
+int mlp_bwd_tangent_split_launch(int64_t B, const MlpDesc &d, const float *W, const float *vv_in, const float *tangent, const float *mask_acts,
+                                 const float *v_out, float *g_W, void *ws, hipStream_t stream);
 size_t mlp_bwd_split_ws_bytes(int64_t B, const MlpDesc &d);
 size_t mlp_bwd_split_ws_bytes_bound(int64_t B, int n_layers);   // for callers that do not know the widths
 

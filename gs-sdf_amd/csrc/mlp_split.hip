@@ -139,10 +139,14 @@ __device__ __forceinline__ void load_bias(const float *lds_b, int l, int h, int 
   }
 }
 
-template <int D_IN, int THREADS>
+// MASKED: the ReLUs are replaced by the saved masks of an earlier forward pass (`mask_acts` = that pass's acts buffer), no biases:
+// y = W_{n-1} D_{n-2} ... D_0 W_0 x, the tangent pass of the decoder's DOUBLE backward (gsdf_mlp_bwd_bwd); `acts` receives the tangent
+// images t_0 .. t_{n-2} (no masks of its own).
+template <int D_IN, int THREADS, bool MASKED = false>
 __global__ void __launch_bounds__(THREADS)
     mlp_fwd_split_kernel(int64_t B, MlpDesc d, SplitLds sl, const float *__restrict__ W, const float *__restrict__ bias,
-                         const float *__restrict__ in, float *__restrict__ out, float *__restrict__ acts) {
+                         const float *__restrict__ in, float *__restrict__ out, float *__restrict__ acts,
+                         const float *__restrict__ mask_acts = nullptr) {
   extern __shared__ __attribute__((aligned(16))) uint4 smem4[];
   float *lds_b = reinterpret_cast<float *>(smem4);   // [MAX_LAYERS][64]
   uint4 *lds_w = smem4 + MAX_LAYERS * HID / 4;
@@ -154,6 +158,7 @@ __global__ void __launch_bounds__(THREADS)
   constexpr int WAVES = THREADS / 64;
   const int64_t n_tiles = (B + 31) / 32;
   uint16_t *masks = acts == nullptr ? nullptr : reinterpret_cast<uint16_t *>(acts + img_off(d.n_layers - 1, n_tiles, 0, 0, 0));
+  const uint16_t *msrc = MASKED ? reinterpret_cast<const uint16_t *>(mask_acts + img_off(d.n_layers - 1, n_tiles, 0, 0, 0)) : nullptr;
   // the input rows of a tile are loaded one tile ahead (branch-free: clamped address, dead lanes zeroed by a select)
   float4 xin[2 * KS0];
   auto load_rows = [&](int64_t tile) {
@@ -183,11 +188,16 @@ __global__ void __launch_bounds__(THREADS)
       load_rows(tile + tstride);
       const uint4 *w = lds_w + sl.off4[0];
       v16f acc0, acc1;
-      load_bias(lds_b, 0, h, d.has_bias, acc0, acc1);
+      load_bias(lds_b, 0, h, MASKED ? 0 : d.has_bias, acc0, acc1);
+      unsigned m0 = 0, m1 = 0;
+      if (MASKED) { m0 = msrc[mask_off(0, n_tiles, tile, 0, lane)]; m1 = msrc[mask_off(0, n_tiles, tile, 1, lane)]; }
 #pragma unroll
       for (int s = 0; s < KS0; ++s) mfma6x2(lds_operand(w, s, lane), lds_operand(w, KS0 + s, lane), xb[s], acc0, acc1);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { cur[0][r] = fmaxf(acc0[r], 0.f); cur[1][r] = fmaxf(acc1[r], 0.f); }
+      for (int r = 0; r < 16; ++r) {
+        cur[0][r] = MASKED ? ((m0 >> r) & 1u ? acc0[r] : 0.f) : fmaxf(acc0[r], 0.f);
+        cur[1][r] = MASKED ? ((m1 >> r) & 1u ? acc1[r] : 0.f) : fmaxf(acc1[r], 0.f);
+      }
     }
     for (int l = 1; l < d.n_layers; ++l) {
       if (acts != nullptr) {  // post-ReLU activations of layer l-1 as a register image (dead lanes of the last tile too)
@@ -197,9 +207,11 @@ __global__ void __launch_bounds__(THREADS)
           unsigned m = 0;
 #pragma unroll
           for (int q = 0; q < 4; ++q) a[q * (IMG_Q / 4)] = make_float4(cur[t][4 * q], cur[t][4 * q + 1], cur[t][4 * q + 2], cur[t][4 * q + 3]);
+          if (!MASKED) {
 #pragma unroll
-          for (int r = 0; r < 16; ++r) m |= (cur[t][r] > 0.f ? 1u : 0u) << r;
-          masks[mask_off(l - 1, n_tiles, tile, t, lane)] = (uint16_t)m;
+            for (int r = 0; r < 16; ++r) m |= (cur[t][r] > 0.f ? 1u : 0u) << r;
+            masks[mask_off(l - 1, n_tiles, tile, t, lane)] = (uint16_t)m;
+          }
         }
       }
       // B operand of k-step s = 8 registers of tile s >> 1, split right before its MFMAs (12 live registers instead of 48)
@@ -212,7 +224,9 @@ __global__ void __launch_bounds__(THREADS)
       const uint4 *w = lds_w + sl.off4[l];
       const bool last = l == d.n_layers - 1;
       v16f acc0, acc1;
-      load_bias(lds_b, l, h, d.has_bias, acc0, acc1);
+      load_bias(lds_b, l, h, MASKED ? 0 : d.has_bias, acc0, acc1);
+      unsigned m0 = 0, m1 = 0;
+      if (MASKED && !last) { m0 = msrc[mask_off(l, n_tiles, tile, 0, lane)]; m1 = msrc[mask_off(l, n_tiles, tile, 1, lane)]; }
       if (!last) {
         // A operands one k-step ahead: their LDS latency hides behind the 12 MFMAs of the current k-step
         Split8 a0 = lds_operand(w, 0, lane), a1 = lds_operand(w, 4, lane);
@@ -225,7 +239,10 @@ __global__ void __launch_bounds__(THREADS)
           a0 = n0; a1 = n1;
         }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { cur[0][r] = fmaxf(acc0[r], 0.f); cur[1][r] = fmaxf(acc1[r], 0.f); }
+        for (int r = 0; r < 16; ++r) {
+          cur[0][r] = MASKED ? ((m0 >> r) & 1u ? acc0[r] : 0.f) : fmaxf(acc0[r], 0.f);
+          cur[1][r] = MASKED ? ((m1 >> r) & 1u ? acc1[r] : 0.f) : fmaxf(acc1[r], 0.f);
+        }
       } else {   // one output tile: two k-steps in flight instead
         v16f accb;
 #pragma unroll
@@ -263,6 +280,14 @@ __global__ void __launch_bounds__(THREADS)
 // a shared tile collects layer l's sums).
 // ----------------------------------------------------------------------------------------------
 static constexpr int SPLIT_BWD_THREADS = 256;
+// Modes of the one-pass backward kernel (round 4: the analytic configuration's e0 backward and double backward on this pipe too)
+//   BWD_FULL    : v_in and the weight / bias gradients from v_out, the saved activations and the network input
+//   BWD_DATA    : v_in only (the e0 backward dsdf/dfeat before the loss): the chain alone, ReLU derivatives from the saved MASKS (2 B per
+//                 lane and tile instead of the 64 B of activations), nothing saved, no transposition, two waves per SIMD
+//   BWD_TANGENT : the double backward's weight term dL/dW_l += v_pre_l (x) t_{l-1}: the chain from v_out is RECOMPUTED in registers
+//                 (masks) and paired with the tangent images t (written by the masked forward) in place of the activations, the network
+//                 input replaced by vv_in; no v_in, no bias term
+enum { BWD_FULL = 0, BWD_DATA = 1, BWD_TANGENT = 2 };
 static constexpr int TR_BLOCK = 256;           // 8-byte chunks per term of a transposition block: 32 points x 8 neuron quads
 static constexpr int TR_WAVE_BYTES = 3 * TR_BLOCK * 8;
 
@@ -349,6 +374,7 @@ struct BwdAcc {
 
 struct BwdCtx {
   int64_t B, n_tiles;
+  const uint16_t *masks;   // modes DATA / TANGENT: the ReLU masks of the first forward
   const float *in, *acts, *v_out;
   float *v_in;
   const uint4 *lds_w;
@@ -384,6 +410,14 @@ __device__ __forceinline__ void load_layer_input(const BwdCtx &c, int64_t tile, 
   }
 }
 
+// ReLU masks of the output of layer L-1 (slot L-1) for a tile, both halves
+template <int L>
+__device__ __forceinline__ void load_masks(const BwdCtx &c, int64_t tile, unsigned (&hm)[2]) {
+  const int64_t tc = tile < c.n_tiles ? tile : c.n_tiles - 1;
+  hm[0] = c.masks[mask_off(L - 1, c.n_tiles, tc, 0, c.lane)];
+  hm[1] = c.masks[mask_off(L - 1, c.n_tiles, tc, 1, c.lane)];
+}
+
 __device__ __forceinline__ void load_v_out(const BwdCtx &c, int64_t tile, v16f &g) {
   const int64_t p = tile * 32 + (c.lane & 31);
   const bool live = tile < c.n_tiles && p < c.B;
@@ -399,7 +433,7 @@ __device__ __forceinline__ void load_v_out(const BwdCtx &c, int64_t tile, v16f &
 
 // terms of the MT tiles of g: packed chain operands gb (lane = point) and, through the LDS block, the dW operands at (lane =
 // output neuron)
-template <int MT>
+template <int MT, bool TR = true>
 __device__ __forceinline__ void prep_g(const BwdCtx &c, const v16f (&g)[2], Split8 (&gb)[4], Split8 (&at)[2][2]) {
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
@@ -408,10 +442,12 @@ __device__ __forceinline__ void prep_g(const BwdCtx &c, const v16f (&g)[2], Spli
       uint32_t t[3][8];
       split8regs(g[mt], hg, t);
       gb[2 * mt + hg] = pack8(t);
-      tr_write8<false>(c.tb, gb[2 * mt + hg], hg, c.lane);
+      if (TR) tr_write8<false>(c.tb, gb[2 * mt + hg], hg, c.lane);
     }
-    at[mt][0] = tr_read(c.tb, 0, c.lane);
-    at[mt][1] = tr_read(c.tb, 1, c.lane);
+    if (TR) {
+      at[mt][0] = tr_read(c.tb, 0, c.lane);
+      at[mt][1] = tr_read(c.tb, 1, c.lane);
+    }
   }
 }
 
@@ -425,10 +461,12 @@ __device__ __forceinline__ void prep_g(const BwdCtx &c, const v16f (&g)[2], Spli
 // the next MFMA on the same accumulator is >= 4 MFMAs away); LDS instructions (8-16 cycles of issue each) and
 // v_accvgpr_read (4-6) do not, and this kernel's vector work is a third LDS / accumulator traffic: the zipped stream ran
 // 1.16 ms against 1.17 ms (4 layers) and 1.96 against 1.64 ms (5 layers + biases, more live registers -> spills).
-template <int NL, bool BIAS, int L>
+template <int NL, bool BIAS, int L, int MODE>
 __device__ __forceinline__ void bwd_layer(const BwdCtx &c, const SplitLds &sl, BwdAcc<NL> &acc, int64_t tile, int64_t next_tile,
-                                          Split8 (&gb)[4], Split8 (&at)[2][2], v16f (&x)[2]) {
+                                          Split8 (&gb)[4], Split8 (&at)[2][2], v16f (&x)[2], unsigned (&hm)[2]) {
   constexpr bool last = L == NL - 1, first = L == 0;
+  constexpr bool DW = MODE != BWD_DATA;       // weight-gradient tiles are accumulated
+  constexpr bool MASKS = MODE != BWD_FULL;    // relu'(a_{L-1}) from the saved masks: x is not the activation (or not loaded at all)
   constexpr int MT = last ? 1 : 2;   // 32-row tiles of outputs o
   constexpr int NT = first ? 1 : 2;  // 32-row tiles of inputs i
   constexpr int KS = last ? 1 : 4;   // k-steps of the chain (over o; the last layer's outputs fit the first k-step)
@@ -437,10 +475,15 @@ __device__ __forceinline__ void bwd_layer(const BwdCtx &c, const SplitLds &sl, B
   // prefetch: the input of layer L-1, or the first input and v_out of the next tile
   // (with 5 layers' accumulators the prefetch is issued between the phases instead: 32 fewer live registers in phase 1)
   v16f xn[2], gn[2];
-  constexpr bool early = NL <= 4;
+  unsigned hmn[2] = {0u, 0u};
+  constexpr bool early = NL <= 4 || !DW;
   if (early) {
-    if (first) { load_layer_input<NL - 1>(c, next_tile, xn); load_v_out(c, next_tile, gn[0]); }
-    else load_layer_input<first ? 0 : L - 1>(c, tile, xn);
+    if (first) { if (DW) load_layer_input<NL - 1>(c, next_tile, xn); load_v_out(c, next_tile, gn[0]); }
+    else if (DW) load_layer_input<first ? 0 : L - 1>(c, tile, xn);
+  }
+  if (MASKS) {   // masks of the layer below (slot L-2), or of the next tile's top hidden layer
+    if (first) load_masks<NL - 1>(c, next_tile, hmn);
+    else if (L >= 2) load_masks<(L >= 2 ? L - 1 : 1)>(c, tile, hmn);
   }
 
   // ---- phase 1
@@ -448,29 +491,32 @@ __device__ __forceinline__ void bwd_layer(const BwdCtx &c, const SplitLds &sl, B
   v16f ng[2];
 #pragma unroll
   for (int r = 0; r < 16; ++r) { ng[0][r] = 0.f; ng[1][r] = 0.f; }
+  constexpr int KSC = (first && MODE == BWD_TANGENT) ? 0 : KS;   // the tangent pass has no use for v_in = W_0^T v_pre_0
 #pragma unroll
-  for (int s = 0; s < KS; ++s) {
+  for (int s = 0; s < KSC; ++s) {
     if (NT == 2) mfma6x2(lds_operand(w, s, lane), lds_operand(w, (last ? 2 : 4) + s, lane), gb[s], ng[0], ng[1]);
     else mfma6(lds_operand(w, s, lane), gb[s], ng[0]);
   }
   Split8 bt[NT][2];
+  if (DW) {
 #pragma unroll
-  for (int nt = 0; nt < NT; ++nt) {
+    for (int nt = 0; nt < NT; ++nt) {
 #pragma unroll
-    for (int hg = 0; hg < 2; ++hg) {
-      uint32_t t[3][8];
-      split8regs(x[nt], hg, t);
-      tr_write8<first>(c.tb, pack8(t), hg, lane);
+      for (int hg = 0; hg < 2; ++hg) {
+        uint32_t t[3][8];
+        split8regs(x[nt], hg, t);
+        tr_write8<first>(c.tb, pack8(t), hg, lane);
+      }
+      bt[nt][0] = tr_read(c.tb, 0, lane);
+      bt[nt][1] = tr_read(c.tb, 1, lane);
     }
-    bt[nt][0] = tr_read(c.tb, 0, lane);
-    bt[nt][1] = tr_read(c.tb, 1, lane);
   }
   v16f g[2];   // g' = relu'(a_{L-1}) (W_L^T g): x and the chain's accumulators end here
   if (!first) {
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) g[t][r] = x[t][r] > 0.f ? ng[t][r] : 0.f;
+      for (int r = 0; r < 16; ++r) g[t][r] = (MASKS ? ((hm[t] >> r) & 1u) != 0u : x[t][r] > 0.f) ? ng[t][r] : 0.f;
   }
   __builtin_amdgcn_sched_barrier(0);
   if (!early) {
@@ -479,7 +525,7 @@ __device__ __forceinline__ void bwd_layer(const BwdCtx &c, const SplitLds &sl, B
   }
 
   // ---- phase 2
-  if (BIAS) {   // ONE shared tile: column L collects the sums of output tile 0 of layer L, column 8 + L those of tile 1
+  if (BIAS && DW) {   // ONE shared tile: column L collects the sums of output tile 0 of layer L, column 8 + L those of tile 1
     const uint32_t one0 = (lane & 31) == L ? 0x3f803f80u : 0u, one1 = (lane & 31) == 8 + L ? 0x3f803f80u : 0u;
     const uint4 oh[2] = {make_uint4(one0, one0, one0, one0), make_uint4(one1, one1, one1, one1)};
 #pragma unroll
@@ -490,7 +536,7 @@ __device__ __forceinline__ void bwd_layer(const BwdCtx &c, const SplitLds &sl, B
         for (int mt = 0; mt < MT; ++mt) acc.b = mfma_bf16(at[mt][ks].s[j], oh[mt], acc.b);
   }
 #pragma unroll
-  for (int nt = 0; nt < NT; ++nt) {
+  for (int nt = 0; nt < (DW ? NT : 0); ++nt) {
     if (last) {
       mfma6(at[0][0], bt[nt][0], acc.wl[nt]);
       mfma6(at[0][1], bt[nt][1], acc.wl[nt]);
@@ -504,7 +550,7 @@ __device__ __forceinline__ void bwd_layer(const BwdCtx &c, const SplitLds &sl, B
   }
   Split8 gbn[4], atn[2][2];
   if (!first) {
-    prep_g<2>(c, g, gbn, atn);
+    prep_g<2, DW>(c, g, gbn, atn);
   } else {
     const int64_t p = tile * 32 + (lane & 31);
     if (c.v_in != nullptr && p < c.B) {
@@ -514,27 +560,31 @@ __device__ __forceinline__ void bwd_layer(const BwdCtx &c, const SplitLds &sl, B
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) gn[1][r] = 0.f;
-    prep_g<1>(c, gn, gbn, atn);   // the next tile's v_out
+    prep_g<1, DW>(c, gn, gbn, atn);   // the next tile's v_out
   }
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int s = 0; s < 4; ++s) gb[s] = gbn[s];
+  if (DW) {
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt) { at[mt][0] = atn[mt][0]; at[mt][1] = atn[mt][1]; }
-  x[0] = xn[0]; x[1] = xn[1];
+    for (int mt = 0; mt < 2; ++mt) { at[mt][0] = atn[mt][0]; at[mt][1] = atn[mt][1]; }
+    x[0] = xn[0]; x[1] = xn[1];
+  }
+  hm[0] = hmn[0]; hm[1] = hmn[1];
 }
 
-template <int NL, bool BIAS, int L>
+template <int NL, bool BIAS, int L, int MODE>
 struct BwdLayers {
   static __device__ __forceinline__ void run(const BwdCtx &c, const SplitLds &sl, BwdAcc<NL> &acc, int64_t tile, int64_t next_tile,
-                                             Split8 (&gb)[4], Split8 (&at)[2][2], v16f (&x)[2]) {
-    bwd_layer<NL, BIAS, L>(c, sl, acc, tile, next_tile, gb, at, x);
-    BwdLayers<NL, BIAS, L - 1>::run(c, sl, acc, tile, next_tile, gb, at, x);
+                                             Split8 (&gb)[4], Split8 (&at)[2][2], v16f (&x)[2], unsigned (&hm)[2]) {
+    bwd_layer<NL, BIAS, L, MODE>(c, sl, acc, tile, next_tile, gb, at, x, hm);
+    BwdLayers<NL, BIAS, L - 1, MODE>::run(c, sl, acc, tile, next_tile, gb, at, x, hm);
   }
 };
-template <int NL, bool BIAS>
-struct BwdLayers<NL, BIAS, -1> {
-  static __device__ __forceinline__ void run(const BwdCtx &, const SplitLds &, BwdAcc<NL> &, int64_t, int64_t, Split8 (&)[4], Split8 (&)[2][2], v16f (&)[2]) {}
+template <int NL, bool BIAS, int MODE>
+struct BwdLayers<NL, BIAS, -1, MODE> {
+  static __device__ __forceinline__ void run(const BwdCtx &, const SplitLds &, BwdAcc<NL> &, int64_t, int64_t, Split8 (&)[4], Split8 (&)[2][2], v16f (&)[2],
+                                             unsigned (&)[2]) {}
 };
 
 // a 32x32 tile leaves: rows o = o0 + d_row(r, half) < O, column i = i0 + (lane & 31).  PART: plain stores into the wave's own partial
@@ -578,22 +628,23 @@ __global__ void __launch_bounds__(256) mlp_partials_apply_kernel(int n_elem, int
   else if (v_b != nullptr) atomicAdd(v_b + (e - n_w), s);
 }
 
-template <int NL, bool BIAS, bool PART>
-__global__ void __launch_bounds__(SPLIT_BWD_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1)))
+template <int NL, bool BIAS, bool PART, int MODE = BWD_FULL, int THREADS = SPLIT_BWD_THREADS>
+__global__ void __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(THREADS / 256, THREADS / 256)))
     mlp_bwd_split_kernel(int64_t B, MlpDesc d, SplitLds sl, int lds_w4, const float *__restrict__ W, const float *__restrict__ in,
                          const float *__restrict__ acts, const float *__restrict__ v_out, float *__restrict__ v_in,
-                         float *__restrict__ v_W, float *__restrict__ v_b, int64_t part_stride) {
+                         float *__restrict__ v_W, float *__restrict__ v_b, int64_t part_stride, const float *__restrict__ mask_acts = nullptr) {
   extern __shared__ __attribute__((aligned(16))) uint4 smem4[];
-  stage_split_bwd(d, sl, W, smem4, true);
+  stage_split_bwd(d, sl, W, smem4, MODE != BWD_TANGENT);   // the tangent pass has no use for W_0^T (no v_in)
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   BwdCtx c;
   c.B = B; c.n_tiles = (B + 31) / 32;
   c.in = in; c.acts = acts; c.v_out = v_out; c.v_in = v_in;
+  c.masks = MODE != BWD_FULL ? reinterpret_cast<const uint16_t *>(mask_acts + img_off(d.n_layers - 1, c.n_tiles, 0, 0, 0)) : nullptr;
   c.lds_w = smem4;
   // the transposition blocks are an object of their own: the compiler then knows that they never alias the weight image
-  __shared__ __attribute__((aligned(16))) uint2 tr_blocks[SPLIT_BWD_THREADS / 64][TR_WAVE_BYTES / 8];
-  c.tb = tr_blocks[wave];
+  __shared__ __attribute__((aligned(16))) uint2 tr_blocks[MODE == BWD_DATA ? 1 : THREADS / 64][MODE == BWD_DATA ? 1 : TR_WAVE_BYTES / 8];
+  c.tb = tr_blocks[MODE == BWD_DATA ? 0 : wave];
   c.lane = lane; c.d_out = d.d_out;
   BwdAcc<NL> acc;
 #pragma unroll
@@ -605,20 +656,23 @@ __global__ void __launch_bounds__(SPLIT_BWD_THREADS) __attribute__((amdgpu_waves
       for (int l = 0; l < (NL > 2 ? NL - 2 : 1); ++l) { acc.wh[l][a][0][r] = 0.f; acc.wh[l][a][1][r] = 0.f; }
     }
   }
-  constexpr int WAVES = SPLIT_BWD_THREADS / 64;
+  constexpr int WAVES = THREADS / 64;
   const int64_t stride = (int64_t)gridDim.x * WAVES;
   int64_t tile = (int64_t)blockIdx.x * WAVES + wave;
   v16f g[2], x[2];
+  unsigned hm[2] = {0u, 0u};
   Split8 gb[4], at[2][2];
-  load_layer_input<NL - 1>(c, tile, x);
+  if (MODE != BWD_DATA) load_layer_input<NL - 1>(c, tile, x);
+  if (MODE != BWD_FULL) load_masks<NL - 1>(c, tile, hm);
   load_v_out(c, tile, g[0]);
 #pragma unroll
-  for (int r = 0; r < 16; ++r) { g[1][r] = 0.f; x[1][r] = NL == 1 ? 0.f : x[1][r]; }
-  prep_g<1>(c, g, gb, at);
+  for (int r = 0; r < 16; ++r) { g[1][r] = 0.f; x[1][r] = (NL == 1 || MODE == BWD_DATA) ? 0.f : x[1][r]; if (MODE == BWD_DATA) x[0][r] = 0.f; }
+  prep_g<1, MODE != BWD_DATA>(c, g, gb, at);
 #pragma unroll
   for (int s = 2; s < 4; ++s) gb[s] = gb[0];
-  at[1][0] = at[0][0]; at[1][1] = at[0][1];
-  for (; tile < c.n_tiles; tile += stride) BwdLayers<NL, BIAS, NL - 1>::run(c, sl, acc, tile, tile + stride, gb, at, x);
+  if (MODE != BWD_DATA) { at[1][0] = at[0][0]; at[1][1] = at[0][1]; }
+  for (; tile < c.n_tiles; tile += stride) BwdLayers<NL, BIAS, NL - 1, MODE>::run(c, sl, acc, tile, tile + stride, gb, at, x, hm);
+  if (MODE == BWD_DATA) return;
   // ---- the wave's weight-gradient tiles leave: PART = into its own partial buffer (v_W / v_b point at the buffers' base: [wave][blob]),
   //      else one round of atomics on the gradient
   if (PART) {
@@ -688,17 +742,18 @@ size_t mlp_bwd_split_ws_bytes_bound(int64_t B, int n_layers) {
   return (size_t)(((int64_t)split_bwd_grid(B) * (SPLIT_BWD_THREADS / 64) + RED_CHUNKS) * n_elem) * sizeof(float) + 256;
 }
 
-template <int NL, bool BIAS>
+template <int NL, bool BIAS, int MODE = BWD_FULL>
 static int launch_bwd_split(int64_t B, const MlpDesc &d, const SplitLds &sl, int lds_w4, size_t lds, const float *W, const float *in,
-                            const float *acts, const float *v_out, float *v_in, float *v_W, float *v_b, void *ws, hipStream_t stream) {
+                            const float *acts, const float *v_out, float *v_in, float *v_W, float *v_b, void *ws, hipStream_t stream,
+                            const float *mask_acts = nullptr) {
   const unsigned grid = split_bwd_grid(B);
   static const bool atomic_exit = [] { const char *e = getenv("GSDF_MLP_BWD_EXIT"); return e && e[0] == 'a'; }();   // GSDF_MLP_BWD_EXIT=atomic: A/B
   // beyond ~48 tiles per wave the waves drift apart and their atomic exits hide behind each other's tiles; the partial buffers then only
   // add their two reduction launches (3.29 M points: 1.95 ms atomic, 2.05 ms partial; 0.49 M: 0.55 / 0.36; 0.1 M: 0.24 / 0.15)
   const bool many_tiles = (B + 31) / 32 > (int64_t)grid * (SPLIT_BWD_THREADS / 64) * 48;
   if (ws == nullptr || atomic_exit || many_tiles) {
-    GSDF_HIP(hipFuncSetAttribute((const void *)mlp_bwd_split_kernel<NL, BIAS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "mlp_bwd_split attr");
-    mlp_bwd_split_kernel<NL, BIAS, false><<<grid, SPLIT_BWD_THREADS, lds, stream>>>(B, d, sl, lds_w4, W, in, acts, v_out, v_in, v_W, v_b, 0);
+    GSDF_HIP(hipFuncSetAttribute((const void *)mlp_bwd_split_kernel<NL, BIAS, false, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "mlp_bwd_split attr");
+    mlp_bwd_split_kernel<NL, BIAS, false, MODE><<<grid, SPLIT_BWD_THREADS, lds, stream>>>(B, d, sl, lds_w4, W, in, acts, v_out, v_in, v_W, v_b, 0, mask_acts);
     GSDF_CHECK_LAUNCH("mlp_bwd_split_kernel");
     return 1;
   }
@@ -706,8 +761,8 @@ static int launch_bwd_split(int64_t B, const MlpDesc &d, const SplitLds &sl, int
   const int n_elem = blob_floats(d, &n_w);
   const int n_part = (int)grid * (SPLIT_BWD_THREADS / 64);
   float *part = (float *)(((uintptr_t)ws + 255) & ~(uintptr_t)255), *chunk = part + (int64_t)n_part * n_elem;
-  GSDF_HIP(hipFuncSetAttribute((const void *)mlp_bwd_split_kernel<NL, BIAS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "mlp_bwd_split attr");
-  mlp_bwd_split_kernel<NL, BIAS, true><<<grid, SPLIT_BWD_THREADS, lds, stream>>>(B, d, sl, lds_w4, W, in, acts, v_out, v_in, part, part + n_w, n_elem);
+  GSDF_HIP(hipFuncSetAttribute((const void *)mlp_bwd_split_kernel<NL, BIAS, true, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "mlp_bwd_split attr");
+  mlp_bwd_split_kernel<NL, BIAS, true, MODE><<<grid, SPLIT_BWD_THREADS, lds, stream>>>(B, d, sl, lds_w4, W, in, acts, v_out, v_in, part, part + n_w, n_elem, mask_acts);
   GSDF_CHECK_LAUNCH("mlp_bwd_split_kernel");
   const unsigned eb = (unsigned)((n_elem + 255) / 256);
   mlp_partials_sum_kernel<<<dim3(eb, RED_CHUNKS), 256, 0, stream>>>(n_part, n_elem, part, chunk);
@@ -738,6 +793,38 @@ int mlp_bwd_split_launch(int64_t B, const MlpDesc &d, const float *W, const floa
   return 0;
 }
 
+// v_in only (the chain, masks instead of activations, nothing saved): 8 waves per workgroup, two per SIMD
+int mlp_bwd_data_split_launch(int64_t B, const MlpDesc &d, const float *W, const float *acts, const float *v_out, float *v_in, hipStream_t stream) {
+  if (v_in == nullptr || !mlp_bwd_split_covers(d)) return 0;
+  SplitLds sl;
+  int lds_w4;
+  const size_t lds = split_bwd_lds(d, &sl, &lds_w4);
+  constexpr int THREADS = 512;
+  const unsigned grid = split_grid(B, THREADS / 64);
+#define LAUNCH_DATA(NL)                                                                                                                  \
+  {                                                                                                                                      \
+    GSDF_HIP(hipFuncSetAttribute((const void *)mlp_bwd_split_kernel<NL, false, false, BWD_DATA, THREADS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), \
+             "mlp_bwd_data_split attr");                                                                                                 \
+    mlp_bwd_split_kernel<NL, false, false, BWD_DATA, THREADS><<<grid, THREADS, lds, stream>>>(B, d, sl, lds_w4, W, nullptr, nullptr, v_out, v_in, nullptr, nullptr, \
+                                                                                               0, acts);                                 \
+  }
+  if (d.n_layers == 5) LAUNCH_DATA(5) else LAUNCH_DATA(4)
+#undef LAUNCH_DATA
+  GSDF_CHECK_LAUNCH("mlp_bwd_split_kernel<data>");
+  return 1;
+}
+
+// the double backward's weight term with the chain recomputed (BWD_TANGENT): in = vv_in, tangent = the masked forward's images
+int mlp_bwd_tangent_split_launch(int64_t B, const MlpDesc &d, const float *W, const float *vv_in, const float *tangent, const float *mask_acts,
+                                 const float *v_out, float *g_W, void *ws, hipStream_t stream) {
+  if (g_W == nullptr || !mlp_bwd_split_covers(d)) return 0;
+  SplitLds sl;
+  int lds_w4;
+  const size_t lds = split_bwd_lds(d, &sl, &lds_w4);
+  if (d.n_layers == 5) return launch_bwd_split<5, false, BWD_TANGENT>(B, d, sl, lds_w4, lds, W, vv_in, tangent, v_out, nullptr, g_W, nullptr, ws, stream, mask_acts);
+  return launch_bwd_split<4, false, BWD_TANGENT>(B, d, sl, lds_w4, lds, W, vv_in, tangent, v_out, nullptr, g_W, nullptr, ws, stream, mask_acts);
+}
+
 // LDS bytes of the forward image; 0 if the topology is not covered
 static size_t split_fwd_lds(const MlpDesc &d, SplitLds *sl) {
   int off = 0;
@@ -758,6 +845,20 @@ static unsigned split_grid(int64_t B, int waves) {
   static const int64_t cap = [] { const char *e = getenv("GSDF_MLP_SPLIT_WG"); return e ? (int64_t)atoi(e) : (int64_t)256; }();   // the image fills most of a CU's LDS: one workgroup per CU
   const int64_t wg = ((B + 31) / 32 + waves - 1) / waves;
   return (unsigned)(wg < 1 ? 1 : (wg > cap ? cap : wg));
+}
+
+// the tangent pass of the double backward: masked, bias-free forward of vv_in; images of t_0 .. t_{n-2} into `tangent`
+int mlp_fwd_masked_split_launch(int64_t B, const MlpDesc &d, const float *W, const float *vv_in, float *out, float *tangent, const float *mask_acts,
+                                hipStream_t stream) {
+  if (!split_enabled() || d.d_in != 32) return 0;
+  SplitLds sl;
+  const size_t lds = split_fwd_lds(d, &sl);
+  if (lds > 160 * 1024) return 0;
+  const unsigned grid = split_grid(B, SPLIT_FWD_THREADS / 64);
+  GSDF_HIP(hipFuncSetAttribute((const void *)mlp_fwd_split_kernel<32, SPLIT_FWD_THREADS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "mlp_fwd_masked_split attr");
+  mlp_fwd_split_kernel<32, SPLIT_FWD_THREADS, true><<<grid, SPLIT_FWD_THREADS, lds, stream>>>(B, d, sl, W, nullptr, vv_in, out, tangent, mask_acts);
+  GSDF_CHECK_LAUNCH("mlp_fwd_split_kernel<masked>");
+  return 1;
 }
 
 // returns 1 if launched, 0 if this path does not cover the call (the caller falls back to the fp32 pipe), < 0 on error

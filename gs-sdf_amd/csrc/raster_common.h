@@ -129,6 +129,52 @@ __device__ __forceinline__ void subblock_masks(const float *__restrict__ m, floa
   }
 }
 
+// Reach mask at 4x4-pixel granularity (bit 4 q + s: quadrant q = wave, sub-block s = 2 (y >> 2 & 1) + (x >> 2 & 1) = the 16-lane DPP row of
+// the wave that owns those pixels): the same conservative box as quadrant_mask against the tile's sixteen sub-blocks.  Round 4: each
+// 16-lane row of a wave follows ITS OWN list of the staged splats that reach its 4x4 pixels (row lists, compositing kernels), so a visit
+// evaluates 16 pixels that the splat's box touches instead of the 64 of the whole quadrant.
+__device__ __forceinline__ unsigned subblock_mask4x4(const float *__restrict__ m, float mx, float my, float opac, float tile_x0, float tile_y0) {
+  const float o255 = 255.0f * opac;
+  if (!(o255 > 1.0f)) return 0u;
+  const float tau = 2.0f * __logf(o255) * 1.0001f + 1e-4f;
+  const float r2 = sqrtf(0.5f * tau);
+  float x0 = mx - r2, x1 = mx + r2, y0 = my - r2, y1 = my + r2;
+  const float it = 1.0f / tau;
+  const float d = m[6] * m[6] + m[7] * m[7] - it * m[8] * m[8];
+  bool bounded = d < 0.0f;
+  if (bounded) {
+    const float id = 1.0f / d;
+    const float cx = (m[0] * m[6] + m[1] * m[7] - it * m[2] * m[8]) * id;
+    const float cy = (m[3] * m[6] + m[4] * m[7] - it * m[5] * m[8]) * id;
+    const float hx2 = cx * cx - (m[0] * m[0] + m[1] * m[1] - it * m[2] * m[2]) * id;
+    const float hy2 = cy * cy - (m[3] * m[3] + m[4] * m[4] - it * m[5] * m[5]) * id;
+    const float hx = sqrtf(fmaxf(hx2, 0.0f)), hy = sqrtf(fmaxf(hy2, 0.0f));
+    bounded = (hx == hx) && (hy == hy) && (cx == cx) && (cy == cy);
+    x0 = fminf(x0, cx - hx); x1 = fmaxf(x1, cx + hx);
+    y0 = fminf(y0, cy - hy); y1 = fmaxf(y1, cy + hy);
+  }
+  if (!bounded) return 0xFFFFu;
+  const float mg = 0.3f;
+  x0 -= mg; x1 += mg; y0 -= mg; y1 += mg;
+  // columns / rows of 4 pixels: column c spans pixel centres [tile_x0 + 4c + 0.5, tile_x0 + 4c + 3.5]
+  unsigned cols = 0u, rows = 0u;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const float sx = tile_x0 + (float)(4 * c), sy = tile_y0 + (float)(4 * c);
+    if (x1 >= sx + 0.5f && x0 <= sx + 3.5f) cols |= 1u << c;
+    if (y1 >= sy + 0.5f && y0 <= sy + 3.5f) rows |= 1u << c;
+  }
+  unsigned mask = 0u;
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int sb = 0; sb < 4; ++sb) {
+      const int c = 2 * (q & 1) + (sb & 1), r = 2 * (q >> 1) + (sb >> 1);
+      if (((cols >> c) & 1u) && ((rows >> r) & 1u)) mask |= 1u << (4 * q + sb);
+    }
+  return mask;
+}
+
 template <int CAP, bool BWD>
 __device__ __forceinline__ void stage_splat(SplatBatchT<CAP, BWD> &s, int slot, int g, const float *__restrict__ means2d,
                                             const float *__restrict__ ray_transforms,
@@ -158,6 +204,28 @@ __device__ __forceinline__ void stage_splat(SplatBatchT<CAP, BWD> &s, int slot, 
   if (BWD) s.extra[slot] = mw1;
   s.q4[slot] = make_float4(c[2], n[0], n[1], n[2]);
   s.qmask[slot] = (unsigned char)quadrant_mask(m, xy.x, xy.y, opac, tile_x0, tile_y0);
+}
+
+// row sum / max over the 16 lanes of a DPP row; valid in lane 15 of each row
+__device__ __forceinline__ float row_sum_to_lane15(float v) {
+  v += dpp_mov<0x111>(v);
+  v += dpp_mov<0x112>(v);
+  v += dpp_mov<0x114>(v);
+  v += dpp_mov<0x118>(v);
+  return v;
+}
+__device__ __forceinline__ unsigned row_umax_to_lane15(unsigned v) {
+  v = max(v, dpp_mov_u<0x111>(v));
+  v = max(v, dpp_mov_u<0x112>(v));
+  v = max(v, dpp_mov_u<0x114>(v));
+  v = max(v, dpp_mov_u<0x118>(v));
+  return v;
+}
+// pixel of a lane in the row-list kernels: 16-lane row s of wave q owns the 4x4 sub-block s of quadrant q
+__device__ __forceinline__ void row_pixel(int wave, int lane, int &lx, int &ly) {
+  const int sb = lane >> 4, j = lane & 15;
+  lx = (wave & 1) * 8 + (sb & 1) * 4 + (j & 3);
+  ly = (wave >> 1) * 8 + (sb >> 1) * 4 + (j >> 2);
 }
 
 // XCD-aware tile assignment: workgroup b runs on XCD (b % 8); give each XCD one contiguous band

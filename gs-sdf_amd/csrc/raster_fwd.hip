@@ -157,6 +157,169 @@ __global__ void __launch_bounds__(RT)
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------------
+// Round 4: ROW LISTS.  The kernel above evaluates a staged splat for all 64 pixels of a wave's 8x8 quadrant although its footprint covers
+// ~14 of them (profiles/r03_raster_pair_counters_cfg3.json: 16.6 % of the evaluated lanes blend).  Here every 16-lane DPP row of a wave owns
+// one 4x4-pixel sub-block and follows ITS OWN list of the staged splats whose conservative box reaches those 16 pixels (subblock_mask4x4,
+// evaluated once per (tile, splat) by the staging lane): per batch the wave compacts four lists into LDS with ballot + mbcnt (24 VALU per 64
+// staged splats), then iterates k = 0 .. max list length; lane l reads slot list[row(l)][k], so one iteration blends up to FOUR different
+// splats.  Each pixel still sees its tile's splats in list order, so every output is bit-identical to the quadrant kernel's.  The maximum
+// blending weight per splat goes to LDS with one ds_max_u32 per row and iteration (integer LDS atomics are cheap).
+// ---------------------------------------------------------------------------------------------------------------------------------------
+struct FwdRowsLds {
+  SplatBatch s;
+  unsigned short m16[RT];        // 4x4 reach mask of the staged splat (bit 4 wave + row)
+  unsigned vis[RT];              // max blending weight over the tile's pixels (fp32 bits)
+  unsigned char list[16][RT];    // per (wave, row): slots of the staged splats that reach the row, in list order
+};
+
+template <bool COUNT, bool TRACE>
+__global__ void __launch_bounds__(RT)
+    raster_fwd_rows_kernel(int n_xcd, int64_t total_tiles, int64_t n_tiles, int64_t I, int W, int H, int tw,
+                           const float *__restrict__ means2d, const float *__restrict__ ray_transforms,
+                           const float *__restrict__ colors, const float *__restrict__ opacities,
+                           const float *__restrict__ normals, const float *__restrict__ backgrounds,
+                           const uint8_t *__restrict__ masks, const int32_t *__restrict__ isect_offsets,
+                           const int32_t *__restrict__ flatten_ids, float *__restrict__ render_colors,
+                           float *__restrict__ render_depths, float *__restrict__ render_alphas,
+                           float *__restrict__ render_normals, float *__restrict__ render_median,
+                           int32_t *__restrict__ last_ids, int32_t *__restrict__ median_ids,
+                           unsigned *__restrict__ visibilities, float *__restrict__ final_T, unsigned long long *__restrict__ counters,
+                           const int32_t *__restrict__ trace_rows, int trace_stride, uint8_t *__restrict__ trace_bits) {
+  __shared__ FwdRowsLds lds;
+  unsigned long long c_visit = 0, c_live = 0, c_ok = 0, c_blend = 0, c_empty = 0;
+  const int64_t tile = xcd_tile_index(total_tiles, n_xcd);
+  if (tile >= total_tiles) return;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, row = lane >> 4;
+  const int64_t cam = tile / n_tiles;
+  const int tl = (int)(tile - cam * n_tiles);
+  const int ty = tl / tw, tx = tl - ty * tw;
+  int plx, ply;
+  row_pixel(wave, lane, plx, ply);
+  const int x = tx * TILE + plx, y = ty * TILE + ply;
+  const bool inside = x < W && y < H;
+  const int64_t pid = (cam * H + y) * (int64_t)W + x;
+  const float px = (float)x + 0.5f, py = (float)y + 0.5f;
+
+  int32_t start = isect_offsets[tile];
+  int32_t end = (tile == total_tiles - 1) ? (int32_t)I : isect_offsets[tile + 1];
+  if (masks != nullptr && !masks[tile]) end = start;
+
+  float T = 1.0f;
+  float cr = 0.f, cg = 0.f, cb = 0.f, nx = 0.f, ny = 0.f, nz = 0.f, dsum = 0.f, med = 0.f;
+  int32_t cur = 0, med_idx = 0;
+  bool done = !inside;
+  int g_mine = -1;
+  uint8_t *trow = nullptr;
+  if (TRACE && inside && trace_rows[pid] >= 0) trow = trace_bits + (int64_t)trace_rows[pid] * trace_stride;
+  unsigned char *my_list = lds.list[wave * 4 + row];
+
+  const int nb = (end - start + RT - 1) / RT;
+  for (int b = 0; b < nb; ++b) {
+    const int all_done = __syncthreads_and(done ? 1 : 0);   // barrier A: every wave has finished reading the previous batch
+    if (g_mine >= 0) {
+      const unsigned v = lds.vis[tid];
+      if (v) atomicMax(visibilities + g_mine, v);
+      g_mine = -1;
+    }
+    if (all_done) break;
+    const int32_t bstart = start + b * RT;
+    const int32_t idx = bstart + tid;
+    if (idx < end) {
+      g_mine = flatten_ids[idx];
+      stage_splat(lds.s, tid, g_mine, means2d, ray_transforms, colors, opacities, normals, (float)(tx * TILE), (float)(ty * TILE));
+      const float2 xy = *reinterpret_cast<const float2 *>(means2d + 2 * (int64_t)g_mine);
+      lds.m16[tid] = (unsigned short)subblock_mask4x4(ray_transforms + 9 * (int64_t)g_mine, xy.x, xy.y, opacities[g_mine], (float)(tx * TILE),
+                                                        (float)(ty * TILE));
+      lds.vis[tid] = 0u;
+    }
+    __syncthreads();  // barrier B
+    const int count = min(RT, end - bstart);
+    const unsigned long long live = __ballot(!done);
+    if (live == 0ull) continue;  // this wave's 64 pixels are all finished
+    // ---- the four row lists of this wave (rows whose 16 pixels are all finished get an empty list)
+    int n0 = 0, n1 = 0, n2 = 0, n3 = 0;
+    for (int c0 = 0; c0 < count; c0 += 64) {
+      const int ti = c0 + lane;
+      const unsigned m = ti < count ? (unsigned)lds.m16[ti] >> (4 * wave) : 0u;
+#define ROW_LIST(r, n)                                                                                         \
+  {                                                                                                            \
+    const bool bit = (m >> r) & 1u;                                                                            \
+    const unsigned long long mk = __ballot(bit);                                                               \
+    if (bit) lds.list[wave * 4 + r][n + __builtin_amdgcn_mbcnt_hi((unsigned)(mk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk, 0u))] = (unsigned char)ti; \
+    n += (int)__popcll(mk);                                                                                    \
+  }
+      ROW_LIST(0, n0) ROW_LIST(1, n1) ROW_LIST(2, n2) ROW_LIST(3, n3)
+#undef ROW_LIST
+    }
+    if (((live >> 0) & 0xFFFFull) == 0ull) n0 = 0;
+    if (((live >> 16) & 0xFFFFull) == 0ull) n1 = 0;
+    if (((live >> 32) & 0xFFFFull) == 0ull) n2 = 0;
+    if (((live >> 48) & 0xFFFFull) == 0ull) n3 = 0;
+    const int n_mine = row == 0 ? n0 : (row == 1 ? n1 : (row == 2 ? n2 : n3));
+    const int kmax = max(max(n0, n1), max(n2, n3));
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // the lists are wave-private: written and read by this wave only
+    for (int k = 0; k < kmax; ++k) {
+      const bool active = k < n_mine;
+      const int t = active ? (int)my_list[k] : 0;
+      const float4 a0 = lds.s.q0[t], a1 = lds.s.q1[t], a2 = lds.s.q2[t], a3 = lds.s.q3[t];
+      PairEval e;
+      eval_pair(0.f, 0.f, px, py, a0, a1, a2, a3.x, a3.y, e);
+      bool valid = active && !done && e.ok;
+      if (COUNT) { c_visit += 1; c_live += __popcll(__ballot(active && !done)); c_ok += __popcll(__ballot(valid)); c_empty += __ballot(valid) == 0ull; }
+      if (__ballot(valid) == 0ull) continue;
+      const float nT = T * (1.0f - e.alpha);
+      if (TRACE && trow != nullptr && valid) {
+        const int kk = bstart + t - start;
+        if (kk < trace_stride)
+          trow[kk] = (uint8_t)((e.b3 ? 2 : 0) | (e.clamped ? 4 : 0) | (nT <= T_EPS ? 8 : (1 | (T > 0.5f ? 16 : 0))));
+      }
+      if (valid && nT <= T_EPS) {  // this pixel is finished: exclusive (the splat is not blended)
+        done = true;
+        valid = false;
+      }
+      if (COUNT) c_blend += __popcll(__ballot(valid));
+      const float w = valid ? e.alpha * T : 0.0f;
+      const float4 a4 = lds.s.q4[t];
+      cr += a3.z * w; cg += a3.w * w; cb += a4.x * w;
+      nx += a4.y * w; ny += a4.z * w; nz += a4.w * w;
+      dsum += e.dep * w;
+      if (valid) {
+        if (T > 0.5f) { med = e.dep; med_idx = bstart + t; }
+        cur = bstart + t;
+        T = nT;
+      }
+      const unsigned wmax = row_umax_to_lane15(__float_as_uint(w));  // w >= 0: uint order == float order
+      if ((lane & 15) == 15 && wmax) atomicMax(&lds.vis[t], wmax);
+      if ((k & 15) == 15 && __ballot(!done) == 0ull) break;
+    }
+  }
+  __syncthreads();
+  if (COUNT && lane == 0) {
+    atomicAdd(counters + 0, c_visit); atomicAdd(counters + 1, c_live); atomicAdd(counters + 2, c_ok); atomicAdd(counters + 3, c_blend);
+    atomicAdd(counters + 7, c_empty);
+  }
+  if (g_mine >= 0) {
+    const unsigned v = lds.vis[tid];
+    if (v) atomicMax(visibilities + g_mine, v);
+  }
+  if (inside) {
+    float br = 0.f, bg = 0.f, bb = 0.f;
+    if (backgrounds != nullptr) { br = backgrounds[3 * cam]; bg = backgrounds[3 * cam + 1]; bb = backgrounds[3 * cam + 2]; }
+    render_colors[3 * pid] = cr + T * br;
+    render_colors[3 * pid + 1] = cg + T * bg;
+    render_colors[3 * pid + 2] = cb + T * bb;
+    render_normals[3 * pid] = nx; render_normals[3 * pid + 1] = ny; render_normals[3 * pid + 2] = nz;
+    render_depths[pid] = dsum;
+    render_alphas[pid] = 1.0f - T;
+    if (final_T != nullptr) final_T[pid] = T;
+    render_median[pid] = med;
+    last_ids[pid] = cur;
+    median_ids[pid] = med_idx;
+  }
+}
+
 }  // namespace gsdf
 
 using namespace gsdf;
@@ -190,9 +353,17 @@ static int rasterize_fwd_launch(int64_t C, int64_t M, int64_t I, int width, int 
 #define FWD_ARGS n_xcd, total, n_tiles, I, width, height, tw, means2d, ray_transforms, colors, opacities, normals, backgrounds, masks, isect_offsets, \
                  flatten_ids, render_colors, render_depths, render_alphas, render_normals, render_median, last_ids, median_ids,          \
                  (unsigned *)visibilities, final_T, counters, trace_rows, trace_stride, trace_bits
-  if (counters != nullptr) raster_fwd_kernel<true, false><<<xcd_grid(total, n_xcd), RT, 0, stream>>>(FWD_ARGS);
-  else if (trace_rows != nullptr) raster_fwd_kernel<false, true><<<xcd_grid(total, n_xcd), RT, 0, stream>>>(FWD_ARGS);
-  else raster_fwd_kernel<false, false><<<xcd_grid(total, n_xcd), RT, 0, stream>>>(FWD_ARGS);
+  // A/B switch (measured): GSDF_RASTER_ROW_LISTS = 0 quadrant lists in both kernels, 1 row lists in both, 2 (default) backward only
+  static const bool quadrant_lists = [] { const char *e = getenv("GSDF_RASTER_ROW_LISTS"); return e == nullptr || e[0] != '1'; }();
+  if (quadrant_lists) {
+    if (counters != nullptr) raster_fwd_kernel<true, false><<<xcd_grid(total, n_xcd), RT, 0, stream>>>(FWD_ARGS);
+    else if (trace_rows != nullptr) raster_fwd_kernel<false, true><<<xcd_grid(total, n_xcd), RT, 0, stream>>>(FWD_ARGS);
+    else raster_fwd_kernel<false, false><<<xcd_grid(total, n_xcd), RT, 0, stream>>>(FWD_ARGS);
+  } else {
+    if (counters != nullptr) raster_fwd_rows_kernel<true, false><<<xcd_grid(total, n_xcd), RT, 0, stream>>>(FWD_ARGS);
+    else if (trace_rows != nullptr) raster_fwd_rows_kernel<false, true><<<xcd_grid(total, n_xcd), RT, 0, stream>>>(FWD_ARGS);
+    else raster_fwd_rows_kernel<false, false><<<xcd_grid(total, n_xcd), RT, 0, stream>>>(FWD_ARGS);
+  }
 #undef FWD_ARGS
   GSDF_CHECK_LAUNCH("raster_fwd_kernel");
   return GSDF_OK;

@@ -256,8 +256,13 @@ struct AnalyticFn : public torch::autograd::Function<AnalyticFn> {
     }
     Tensor e0 = e0_cache.narrow(0, 0, n);
     Tensor g0 = empty_like_opts(xs, {n, nf}, torch::kFloat32);
-    Tensor bws = empty_like_opts(xs, {(int64_t)gsdf_mlp_bwd_ws_bytes(n, nl)}, torch::kUInt8);
-    check(gsdf_mlp_bwd(n, nl, dims.data(), fp(W), fp(bias), fp(feat), fp(acts), fp(e0), fpm(g0), nullptr, nullptr, bws.data_ptr(), cur_stream()), "mlp_bwd");
+    // topologies of the one-pass backward (the reference's both): the lean e0 backward — the chain alone on the bf16 pipe, nothing saved; the
+    // double backward recomputes it from the ReLU masks (gsdf_mlp_bwd_bwd with bwd_ws = NULL).  Else the fp32-pipe pair with its v_pre images.
+    static const bool lean_off = [] { const char *e = getenv("GSDF_MLP_LEAN_BWD_BWD"); return e != nullptr && e[0] == '0'; }();   // A/B switch
+    const bool lean = !lean_off && gsdf_mlp_bwd_is_one_pass(nl, dims.data()) == 1;
+    Tensor bws = lean ? empty_like_opts(xs, {0}, torch::kUInt8) : empty_like_opts(xs, {(int64_t)gsdf_mlp_bwd_ws_bytes(n, nl)}, torch::kUInt8);
+    check(gsdf_mlp_bwd(n, nl, dims.data(), fp(W), fp(bias), fp(feat), fp(acts), fp(e0), fpm(g0), nullptr, nullptr, lean ? nullptr : bws.data_ptr(),
+                       cur_stream()), "mlp_bwd");
     Tensor loss = empty_like_opts(xs, {}, torch::kFloat32), v_attr = empty_like_opts(xs, {n, d_out}, torch::kFloat32);
     Tensor vv_x = empty_like_opts(xs, {n, 3}, torch::kFloat32), u0 = empty_like_opts(xs, {n, nf}, torch::kFloat32);
     Tensor gt = n_ray > 0 ? f32c(gt_sdf.detach().reshape({-1}), "gt_sdf") : Tensor();
@@ -317,8 +322,8 @@ struct AnalyticFn : public torch::autograd::Function<AnalyticFn> {
     // issued after the samples' gradient, which the splat leg's backward is waiting for)
     Tensor vv_in = scaled(u0), g_vout = torch::empty_like(e0);
     Tensor ws2 = empty_like_opts(feat, {(int64_t)gsdf_mlp_bwd_bwd_ws_bytes(n, nl)}, torch::kUInt8);
-    check(gsdf_mlp_bwd_bwd(n, nl, dims.data(), fp(W), fp(acts), fp(e0), bws.data_ptr(), fp(vv_in), fpm(g_vout), fpm(decoder_grad), ws2.data_ptr(),
-                           cur_stream()), "mlp_bwd_bwd");
+    check(gsdf_mlp_bwd_bwd(n, nl, dims.data(), fp(W), fp(acts), fp(e0), bws.numel() ? bws.data_ptr() : nullptr, fp(vv_in), fpm(g_vout), fpm(decoder_grad),
+                           ws2.data_ptr(), cur_stream()), "mlp_bwd_bwd");
     // table: first-order (v_feat) and second-order (g0, vv_x) contributions of every corner in ONE scatter
     Tensor vvx = scaled(vv_x);
     const size_t nb = n >= 24576 ? gsdf_hashgrid_bwd_binned_ws_bytes(n, L, F, H, R, S) : 0;

@@ -80,9 +80,10 @@ torch::nn::Sequential sequential_of(const TCNNNetwork &net, bool copy_in) {
   torch::NoGradGuard ng;
   for (size_t l = 0; l + 1 < d.size(); ++l) {
     torch::nn::Linear lin(torch::nn::LinearOptions(d[l], d[l + 1]).bias(true));
-    if (copy_in) {
-      lin->weight.copy_(net.params_.detach().slice(0, wo, wo + (int64_t)d[l] * d[l + 1]).view({d[l + 1], d[l]}).cpu());
-      if (net.biases_.defined()) lin->bias.copy_(net.biases_.detach().slice(0, bo, bo + d[l + 1]).cpu());
+    if (copy_in) {   // on the parameters' device, as torch::save of the reference's module keeps its tensors (torch::load restores them there)
+      lin->to(net.params_.device());
+      lin->weight.copy_(net.params_.detach().slice(0, wo, wo + (int64_t)d[l] * d[l + 1]).view({d[l + 1], d[l]}));
+      if (net.biases_.defined()) lin->bias.copy_(net.biases_.detach().slice(0, bo, bo + d[l + 1]));
       else lin->bias.zero_();
     }
     wo += (int64_t)d[l] * d[l + 1]; bo += d[l + 1];
@@ -94,9 +95,9 @@ torch::nn::Sequential sequential_of(const TCNNNetwork &net, bool copy_in) {
 }  // namespace
 
 void LocalMap::save(torch::serialize::OutputArchive &archive) const {
-  archive.write(p_encoder_tcnn_->name_, p_encoder_tcnn_->params_.detach().cpu());
+  archive.write(p_encoder_tcnn_->name_, p_encoder_tcnn_->params_.detach());
   if (cfg_.decoder_implementation != 0) {
-    archive.write(p_decoder_tcnn_->name_, p_decoder_tcnn_->params_.detach().cpu());
+    archive.write(p_decoder_tcnn_->name_, p_decoder_tcnn_->params_.detach());
     return;
   }
   torch::serialize::OutputArchive child(archive.compilation_unit());
@@ -123,7 +124,7 @@ void LocalMap::load(torch::serialize::InputArchive &archive) {
     std::vector<Tensor> ws, bs;
     for (auto &mod : seq->children())
       if (auto *lin = mod->as<torch::nn::Linear>()) { ws.push_back(lin->weight.reshape({-1})); bs.push_back(lin->bias.reshape({-1})); }
-    dec_w = torch::cat(ws); dec_b = torch::cat(bs);
+    dec_w = torch::cat(ws).detach(); dec_b = torch::cat(bs).detach();
     TORCH_CHECK(dec_w.numel() == p_decoder_tcnn_->params_.numel(), "LocalMap::load: decoder topology differs");
   }
   p_encoder_tcnn_->params_.copy_(enc.reshape(p_encoder_tcnn_->params_.sizes()).to(p_encoder_tcnn_->params_.device()));

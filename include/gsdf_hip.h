@@ -318,6 +318,9 @@ int gsdf_mlp_bwd(int64_t B, int n_layers, const int *dims_host, const float *wei
  * v_out and its workspace bwd_ws (kept by the caller); vv_in [B, dims[0]] = dL/d v_in.
  * Outputs: g_vout [B, dims[n]] = dL/d v_out (required; overwritten) and g_weights (same layout as weights; ACCUMULATES; may be
  * NULL).  Nothing flows to the biases or to the network input (a ReLU network is piecewise linear).
+ * bwd_ws = NULL (round 4; topologies gsdf_mlp_bwd_is_one_pass covers): nothing of the first backward is needed — the chain v_out -> v_pre_l
+ * is recomputed in registers from the ReLU masks inside the pass that accumulates g_weights, and the matching first backward may be the
+ * lean one (gsdf_mlp_bwd with v_weights = NULL and ws = NULL: input gradient only, nothing saved).
  * ws: gsdf_mlp_bwd_bwd_ws_bytes(B, n_layers) bytes. */
 size_t gsdf_mlp_bwd_bwd_ws_bytes(int64_t B, int n_layers);
 int gsdf_mlp_bwd_bwd(int64_t B, int n_layers, const int *dims_host, const float *weights, const float *acts,

@@ -62,6 +62,46 @@ def test_decoder_double_backward_matches_oracle(sdf, oracle, dims, bias, B):
         assert gs[2] is None or float(gs[2].abs().max()) == 0.0      # piecewise linear: nothing reaches the biases
 
 
+@pytest.mark.parametrize("dims,bias,B", [([32, 64, 64, 64, 64, 2], True, 30000), ([32, 64, 64, 64, 2], False, 4097), ([32, 64, 64, 64, 64, 2], True, 33)])
+def test_lean_e0_backward_and_recomputing_double_backward_match_oracle(sdf, oracle, dims, bias, B):
+    """Round 4: the analytic configuration's decoder passes on the bf16 pipe, through the C ABI — gsdf_mlp_bwd with v_weights = NULL and
+    ws = NULL (input gradient only: the chain from the ReLU masks, nothing saved) and gsdf_mlp_bwd_bwd with bwd_ws = NULL (masked forward +
+    ONE pass that recomputes the chain and accumulates the weight term) — against the fp64 oracle, and against the fp32-pipe pair."""
+    import ctypes as C
+    import gs_sdf_amd.capi as capi
+    from gs_sdf_amd.capi import f32, ptr
+    L = capi.lib()
+    dev = torch.device("cuda:0")
+    net = sdf.TCNNNetwork(dims[0], dims[-1], dict(n_neurons=64, n_hidden_layers=len(dims) - 2), "dec", dev, bias=bias, seed=3)
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(B, dims[0], generator=g)
+    W, b = n(net.params_), (n(net.biases_) if bias else None)
+    x = x[~torch.from_numpy(_near_kink(n(x), dims, W, b))]
+    B = x.shape[0]
+    nl, dims_c = len(dims) - 1, (C.c_int * len(dims))(*dims)
+    assert L.gsdf_mlp_bwd_is_one_pass(nl, dims_c) == 1
+    xd, v_out, vv = x.to(dev), torch.randn(B, dims[-1], generator=g).to(dev), torch.randn(B, dims[0], generator=g).to(dev)
+    out = torch.empty(B, dims[-1], device=dev)
+    acts = torch.empty(L.gsdf_mlp_acts_floats(B, nl), device=dev)
+    capi.check(L.gsdf_mlp_fwd(B, nl, dims_c, f32(net.params_), f32(net.biases_) if bias else None, f32(xd), f32(out), f32(acts), capi.stream()), "fwd")
+    v_in = torch.empty(B, dims[0], device=dev)
+    capi.check(L.gsdf_mlp_bwd(B, nl, dims_c, f32(net.params_), f32(net.biases_) if bias else None, f32(xd), f32(acts), f32(v_out), f32(v_in), None, None,
+                              None, capi.stream()), "lean bwd")
+    ref_vin, _, _ = oracle.mlp_bwd(n(x), dims, W, b, n(v_out), prec="f64")
+    assert_close(v_in, ref_vin, 1e-4, "lean first backward v_in")
+    g_vout, g_w = torch.empty(B, dims[-1], device=dev), torch.zeros_like(net.params_)
+    ws2 = torch.empty(L.gsdf_mlp_bwd_bwd_ws_bytes(B, nl), dtype=torch.uint8, device=dev)
+    capi.check(L.gsdf_mlp_bwd_bwd(B, nl, dims_c, f32(net.params_), f32(acts), f32(v_out), None, f32(vv), f32(g_vout), f32(g_w), ptr(ws2), capi.stream()),
+               "lean bwd_bwd")
+    r_gv, r_gw = oracle.mlp_bwd_bwd(n(x), dims, W, b, n(v_out), n(vv), prec="f64")
+    assert_close(g_vout, r_gv, 1e-4, "recomputing double backward: d/d v_out")
+    assert_close(g_w, r_gw, 1e-4, "recomputing double backward: d/d weights")
+    # a second call ACCUMULATES into g_weights
+    capi.check(L.gsdf_mlp_bwd_bwd(B, nl, dims_c, f32(net.params_), f32(acts), f32(v_out), None, f32(vv), f32(g_vout), f32(g_w), ptr(ws2), capi.stream()),
+               "lean bwd_bwd")
+    assert_close(g_w, 2 * r_gw, 1e-4, "recomputing double backward accumulates")
+
+
 def _reference_composition(sdfm, lm_t, xs, mode, aux, w_data, delta, w_eik, w_align):
     """neural_mapping.cpp:138-188 (ray) / :436-457 (gs) with sdf_regularization :106-136 on the eager decoder"""
     if mode == "ray":
