@@ -531,7 +531,7 @@ def main():
         spaths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_bench_cfg3_kernel_stats.csv")))
         if args.workload == "cfg3_1M_1080p" and analytic and not args.no_sdf and spaths:
             import csv
-            kmap = (("hashgrid_fwd", "hashgrid_fwd"), ("raster_bwd_kernel", "rasterize_2dgs_bwd"), ("raster_fwd_kernel", "rasterize_2dgs_fwd"),
+            kmap = (("hashgrid_fwd", "hashgrid_fwd"), ("raster_bwd_", "rasterize_2dgs_bwd"), ("raster_fwd_", "rasterize_2dgs_fwd"),
                     ("mlp_bwd_split", "mlp_bwd"), ("mlp_fwd_split", "mlp_fwd"), ("bin_apply", "hashgrid_bwd"), ("bin_emit", "hashgrid_bwd"))
             share = {}
             for row in list(csv.reader(open(spaths[-1])))[1:]:
@@ -768,6 +768,14 @@ class RayBatcher:
         self.sample_std, self.truncated_dis = 0.02, 3 * leaf                          # base.yaml: sample_std; truncated at 3 leaves
         self.ready = None
         self.hist = []
+        # the throttle starts from its steady state (the reference reaches it after ~50 iterations of :324-330; a batch of 32768 RAYS in this
+        # scene would be 3.6 M points): a calibration batch of 256 rays measures the points per ray
+        self.k_batch_num = 256
+        self.issue()
+        n0, p0 = self.hist[-1]
+        self.pts_per_ray = max(p0 / max(n0, 1), 1e-3)
+        self.k_batch_num = max(1, min(int(self.batch_pt_num / self.pts_per_ray), self.batch_pt_num))
+        self.ready, self.hist = None, []
 
     def issue(self):
         """queues the next batch on the prefetch stream -> nothing; `take()` hands it to the step"""

@@ -107,7 +107,7 @@ def load_local_map_checkpoint(lm, path):
                 if src_b is None or src_b.numel() != b.numel():
                     raise RuntimeError(f"{path}: decoder.{2 * k}.bias missing or of the wrong shape")
                 copies.append((b, src_b))
-            elif src_b is not None and float(src_b.abs().max()) != 0.0:
+            elif src_b is not None and float(src_b.detach().abs().max()) != 0.0:
                 raise RuntimeError(f"{path}: the checkpoint's decoder has biases, this map's decoder is bias free")
     with torch.no_grad():
         for dst, src in copies:

@@ -10,7 +10,7 @@
 //
 //   count  : per (level, table tile of 8192 entries = 64 KB) how many contributions arrive          (LDS histograms)
 //   plan   : exclusive scan of the bucket sizes; work items of <= ITEM_MAX records for the last pass (one workgroup)
-//   emit   : every contribution becomes a 12-byte record {entry within tile, g0, g1}; a workgroup (one thread per (point,
+//   emit   : every contribution becomes an 8-byte record {entry within tile, block-float (g0, g1)} (pack_record); a workgroup (one thread per (point,
 //            level), 8 waves) sorts the records of its 256 points x 2 levels by bucket in LDS and appends each run to its bucket with ONE reservation per
 //            (workgroup, bucket) and fully coalesced stores
 //   apply  : one workgroup per item: the tile lives in LDS (64 KB) as 64-BIT FIXED POINT, records stream in coalesced,
@@ -45,10 +45,33 @@ struct BinPlan {
   int n_groups;                      // level groups of BIN_G levels
 };
 
-struct __attribute__((packed, aligned(4))) BinRecord {
-  uint32_t key;  // entry index within the tile
-  float g0, g1;
-};
+// Round 4: 8-byte records (12 before).  A record = the entry within its tile (12 bits) + the two gradient values as a BLOCK FLOAT relative
+// to the level's largest contribution 2^e (bin_vmax): shift s = e - e_rec (6 bits; e_rec = exponent of the larger of the two) and two signed
+// 23-bit mantissas m = round(g 2^(22 - e_rec)).  The apply pass turns (s, m) into the same 2^(e - 41) fixed point it accumulated before
+// (m << (19 - s)), so the sums stay exact integer sums, independent of the order of the records (bit-reproducible); what changed is that a
+// contribution is rounded to 22 bits relative to the larger value of ITS record (2.4e-7) instead of entering with its 24: the table gradient
+// agrees with the oracle's double-precision accumulation to ~1e-6 as before (tests/test_gpu_sdf_parity.py), and the scatter moves 2/3 of
+// the bytes (records are written once and read once: 16 B per contribution instead of 24).
+typedef unsigned long long BinRecord;
+__device__ __forceinline__ BinRecord pack_record(uint32_t entry, float g0, float g1, int e_level) {
+  const float mx = fmaxf(fabsf(g0), fabsf(g1));
+  const int e_rec = (int)((__float_as_uint(mx) >> 23) & 255u) - 126;            // mx < 2^e_rec (0 -> -126: everything rounds to 0)
+  int s = e_level - e_rec;
+  s = s < 0 ? 0 : (s > 63 ? 63 : s);
+  const int up = 22 - (e_level - s);                                           // m = round(g 2^(22 - e_rec')), e_rec' = e_level - s (v_ldexp_f32: exact)
+  int m0 = (int)rintf(ldexpf(g0, up)), m1 = (int)rintf(ldexpf(g1, up));
+  m0 = max(-4194303, min(4194303, m0)); m1 = max(-4194303, min(4194303, m1));
+  return (BinRecord)(entry & 0xFFFu) | ((BinRecord)(unsigned)s << 12) | ((BinRecord)((unsigned)m0 & 0x7FFFFFu) << 18) |
+         ((BinRecord)((unsigned)m1 & 0x7FFFFFu) << 41);
+}
+__device__ __forceinline__ void unpack_record(BinRecord r, uint32_t &entry, long long &f0, long long &f1) {
+  entry = (uint32_t)r & 0xFFFu;
+  const int s = (int)((r >> 12) & 63u);
+  const long long m0 = ((long long)(r << 23)) >> 41, m1 = ((long long)r) >> 41;   // sign-extended 23-bit fields
+  // fixed point of the level: 2^(e - 41); the record's unit is 2^(e - s - 22)
+  f0 = s <= 19 ? m0 << (19 - s) : m0 >> (s - 19);
+  f1 = s <= 19 ? m1 << (19 - s) : m1 >> (s - 19);
+}
 
 struct BinItem {
   int64_t begin, end;  // record range
@@ -307,10 +330,11 @@ template <int PTS, int G>
 __global__ void __launch_bounds__(PTS * G)
     bin_emit_kernel(int64_t B, HgLevels lv, BinPlan bp, BinStencil stn, const float *__restrict__ x,
                     const float *__restrict__ v_feat, const int64_t *__restrict__ start, uint32_t *__restrict__ cursor,
-                    BinRecord *__restrict__ records, const float *__restrict__ v_feat2, const float *__restrict__ vv_x) {
+                    BinRecord *__restrict__ records, const float *__restrict__ v_feat2, const float *__restrict__ vv_x,
+                    const uint32_t *__restrict__ lmax) {
   constexpr int BIN_EMIT_THREADS = PTS * G, BIN_REC = PTS * G * 8;
-  __shared__ uint32_t s_key[BIN_REC];
-  __shared__ float s_g0[BIN_REC], s_g1[BIN_REC];
+  __shared__ BinRecord s_rec[BIN_REC];      // packed records at their sorted position
+  __shared__ unsigned char s_bkt[BIN_REC];  // their local bucket
   __shared__ uint32_t s_hist[BIN_MAX_LOCAL], s_off[BIN_MAX_LOCAL], s_wtot[BIN_MAX_LOCAL / 64];
   __shared__ int64_t s_dst[BIN_MAX_LOCAL];
   const int n_groups = (lv.n_levels + G - 1) / G;
@@ -392,38 +416,27 @@ __global__ void __launch_bounds__(PTS * G)
     s_off[t] = before + incl - mine;
   }
   __syncthreads();
-  // pass 2: records to their sorted position in LDS
+  // pass 2: packed records to their sorted position in LDS
   if (emits) {
+    const uint32_t mxl = lmax[level];
+    const int e_level = (int)(mxl >> 23) - 126;     // |g| < 2^e (a non-finite level is poisoned by the apply pass whatever is written here)
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       const uint32_t bucket = key[k] >> 16;
       const uint32_t p = s_off[bucket] + slot[k];
-      s_key[p] = key[k];      // entry within tile | local bucket << 16
-      s_g0[p] = g0[k];
-      s_g1[p] = g1[k];
+      s_rec[p] = pack_record(key[k] & 0xFFFFu, g0[k], g1[k], e_level);
+      s_bkt[p] = (unsigned char)bucket;
     }
   }
   // destination of sorted position p in bucket b: s_dst[b] + p  (s_dst already net of the bucket's first position in LDS)
   if (mine) s_dst[t] = start[b0 + t] + (int64_t)reserved - (int64_t)s_off[t];
   __syncthreads();
-  // pass 3: runs to the global buckets; consecutive lanes write consecutive 12-byte records
-  for (uint32_t p = t; p < n_rec; p += BIN_EMIT_THREADS) {
-    const uint32_t kb = s_key[p], bucket = kb >> 16;
-    BinRecord r;
-    r.key = kb & 0xFFFFu;
-    r.g0 = s_g0[p];
-    r.g1 = s_g1[p];
-    records[s_dst[bucket] + (int64_t)p] = r;
-  }
+  // pass 3: runs to the global buckets; consecutive lanes write consecutive 8-byte records
+  for (uint32_t p = t; p < n_rec; p += BIN_EMIT_THREADS) records[s_dst[s_bkt[p]] + (int64_t)p] = s_rec[p];
 }
 
 // ---- apply ------------------------------------------------------------------------------------------------------
 static constexpr int BIN_FIX_BITS = 41;   // 2^41 * 2^ceil(log2 max) * 2^19 records per item < 2^62: no overflow
-__device__ __forceinline__ long long to_fixed(float g, double scale) {
-  // round(g * scale) through the 1.5 * 2^52 magic number: exact for |g * scale| < 2^51
-  return __double_as_longlong(fma((double)g, scale, 6755399441055744.0)) - 0x4338000000000000LL;
-}
-
 __global__ void __launch_bounds__(BIN_APPLY_THREADS)
     bin_apply_kernel(HgLevels lv, BinPlan bp, const BinItem *__restrict__ items, const uint32_t *__restrict__ n_items,
                      const uint32_t *__restrict__ lmax, const BinRecord *__restrict__ records, float *__restrict__ v_table) {
@@ -447,7 +460,7 @@ __global__ void __launch_bounds__(BIN_APPLY_THREADS)
     return;
   }
   const int e = (int)(mx >> 23) - 126;             // |g| < 2^e
-  const double scale = ldexp(1.0, BIN_FIX_BITS - e), inv = ldexp(1.0, e - BIN_FIX_BITS);
+  const double inv = ldexp(1.0, e - BIN_FIX_BITS);
   for (int i = threadIdx.x; i < 2 * BIN_TILE; i += BIN_APPLY_THREADS) s_tile[i] = 0ull;
   __syncthreads();
   const int64_t n = it.end - it.begin;
@@ -459,14 +472,19 @@ __global__ void __launch_bounds__(BIN_APPLY_THREADS)
     for (int u = 0; u < 4; ++u) r[u] = rec[i + u * BIN_APPLY_THREADS];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      atomicAdd(&s_tile[2 * r[u].key], (unsigned long long)to_fixed(r[u].g0, scale));
-      atomicAdd(&s_tile[2 * r[u].key + 1], (unsigned long long)to_fixed(r[u].g1, scale));
+      uint32_t key;
+      long long f0, f1;
+      unpack_record(r[u], key, f0, f1);
+      atomicAdd(&s_tile[2 * key], (unsigned long long)f0);
+      atomicAdd(&s_tile[2 * key + 1], (unsigned long long)f1);
     }
   }
   for (; i < n; i += BIN_APPLY_THREADS) {
-    const BinRecord r = rec[i];
-    atomicAdd(&s_tile[2 * r.key], (unsigned long long)to_fixed(r.g0, scale));
-    atomicAdd(&s_tile[2 * r.key + 1], (unsigned long long)to_fixed(r.g1, scale));
+    uint32_t key;
+    long long f0, f1;
+    unpack_record(rec[i], key, f0, f1);
+    atomicAdd(&s_tile[2 * key], (unsigned long long)f0);
+    atomicAdd(&s_tile[2 * key + 1], (unsigned long long)f1);
   }
   __syncthreads();
   const int tile = it.bucket - bp.tile_base[level];
@@ -574,7 +592,7 @@ static int binned_scatter(int64_t B, int64_t stencil_n, int merge_levels, int n_
   //  12-byte records in runs of 16 are written at 3.1 TB/s, runs of 32 at 4.6, one stream at 5.3)
   // (measured and rejected: 512 points x 1 level and 1024 x 1 per workgroup, i.e. 2x / 4x longer runs per bucket: 3.15 and
   //  3.48 ms against 2.94 ms for the whole scatter at 3.3 M points — the run length is not what bounds the emit pass)
-  bin_emit_kernel<BIN_PTS, BIN_G><<<(unsigned)(chunks * bp.n_groups), BIN_PTS * BIN_G, 0, stream>>>(B, lv, bp, stn, x, v_feat, w.start, w.cursor, w.records, v_feat2, vv_x);
+  bin_emit_kernel<BIN_PTS, BIN_G><<<(unsigned)(chunks * bp.n_groups), BIN_PTS * BIN_G, 0, stream>>>(B, lv, bp, stn, x, v_feat, w.start, w.cursor, w.records, v_feat2, vv_x, w.lmax);
   GSDF_CHECK_LAUNCH("bin_emit_kernel");
   bin_apply_kernel<<<(unsigned)w.max_items, BIN_APPLY_THREADS, 0, stream>>>(lv, bp, w.items, w.n_items, w.lmax, w.records, v_table);
   GSDF_CHECK_LAUNCH("bin_apply_kernel");
