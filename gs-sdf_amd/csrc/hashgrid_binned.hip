@@ -53,6 +53,7 @@ struct BinPlan {
 // agrees with the oracle's double-precision accumulation to ~1e-6 as before (tests/test_gpu_sdf_parity.py), and the scatter moves 2/3 of
 // the bytes (records are written once and read once: 16 B per contribution instead of 24).
 typedef unsigned long long BinRecord;
+static constexpr int BIN_EXP_HEADROOM = 3;   // 2^e bounds ONE contribution; a base row that carries its six stencil rows sums up to seven
 __device__ __forceinline__ BinRecord pack_record(uint32_t entry, float g0, float g1, int e_level) {
   const float mx = fmaxf(fabsf(g0), fabsf(g1));
   const int e_rec = (int)((__float_as_uint(mx) >> 23) & 255u) - 126;            // mx < 2^e_rec (0 -> -126: everything rounds to 0)
@@ -419,7 +420,7 @@ __global__ void __launch_bounds__(PTS * G)
   // pass 2: packed records to their sorted position in LDS
   if (emits) {
     const uint32_t mxl = lmax[level];
-    const int e_level = (int)(mxl >> 23) - 126;     // |g| < 2^e (a non-finite level is poisoned by the apply pass whatever is written here)
+    const int e_level = (int)(mxl >> 23) - 126 + BIN_EXP_HEADROOM;     // |g| < 2^e (a non-finite level is poisoned by the apply pass whatever is written here)
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       const uint32_t bucket = key[k] >> 16;
@@ -459,7 +460,7 @@ __global__ void __launch_bounds__(BIN_APPLY_THREADS)
     for (int j = threadIdx.x; j < 2 * n_entp; j += BIN_APPLY_THREADS) dstp[j] = __builtin_nanf("");
     return;
   }
-  const int e = (int)(mx >> 23) - 126;             // |g| < 2^e
+  const int e = (int)(mx >> 23) - 126 + BIN_EXP_HEADROOM;   // |g| < 2^e, the exponent pack_record used
   const double inv = ldexp(1.0, e - BIN_FIX_BITS);
   for (int i = threadIdx.x; i < 2 * BIN_TILE; i += BIN_APPLY_THREADS) s_tile[i] = 0ull;
   __syncthreads();

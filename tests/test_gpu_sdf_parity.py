@@ -498,15 +498,31 @@ def test_hashgrid_binned_scatter_matches_atomic_and_oracle(sdf, oracle, cfg, B, 
     capi.check(L.gsdf_hashgrid_bwd(B, *c, capi.f32(xd), capi.f32(table), capi.f32(vd), capi.f32(atomic), None, capi.stream()), "atomic")
     torch.cuda.synchronize()
     # the atomic kernel sums in fp32 in arrival order: with ~5e5 contributions of random sign per entry (concentrated)
-    # its own rounding noise is ~1e-4 of the tensor's mean magnitude; the binned path sums exactly (fixed point)
-    assert_close(got - seed, atomic - seed, 1e-3 if concentrated else 1e-5, "binned vs atomic scatter")
+    # its own rounding noise is ~1e-4 of the tensor's mean magnitude
+    assert_close(got - seed, atomic - seed, 1e-3 if concentrated else 1e-4, "binned vs atomic scatter")
     vt_o, _ = oracle.grid_bwd(n(x), n(table.cpu()), n(v), cfg, prec="f32")     # oracle accumulates in double
-    assert_close(got - seed, vt_o, 1e-5 if B >= 100 else 1e-3, "binned scatter (accumulated onto a non-zero buffer) vs oracle")
+    # Round 4: 8-byte records.  A contribution enters the (exact, order-independent) fixed-point sum rounded to 22 bits relative to the larger
+    # value of its record, so an entry's error is bounded by 2^-23 x the sum of |contributions| of BOTH features of the entry (+ the final
+    # fp32 rounding): the oracle evaluated on |v| gives that sum.  Element-wise: within the 1e-4 bar AND within 4 x that bound.
+    vt_abs, _ = oracle.grid_bwd(n(x), n(table.cpu()), np.abs(n(v)), cfg, prec="f32")
+    bound = 4.0 * 2.0 ** -23 * vt_abs.sum(1, keepdims=True) + 2.0 ** -22 * np.abs(vt_o) + 1e-30
+    # + the resolution of the fixed point itself: 2^-38 of the level's largest |v_feat| per record (a contribution below it is dropped, as it
+    # was at 2^-41 with the 12-byte records): 2^-28 of the level maximum covers a thousand records per entry
+    vn = np.abs(n(v)).reshape(B, cfg["n_levels"], 2).max(axis=(0, 2))
+    for l in range(cfg["n_levels"]):
+        bound[offs[l]:offs[l + 1]] += 2.0 ** -28 * vn[l]
+
+    def within_record_rounding(t, what, extra=0.0):
+        e = np.abs(n(t).astype(np.float64) - vt_o)
+        worst = float((e / (bound + extra)).max())
+        assert worst <= 1.0, f"{what}: an entry is {worst:.2f} x the bound of the records' rounding"
+    assert_close(got - seed, vt_o, 1e-4 if B >= 100 else 1e-3, "binned scatter (accumulated onto a non-zero buffer) vs oracle")
     # a second call on the same workspace (stale counters / cursors must not leak)
     got2 = torch.zeros_like(seed)
     capi.check(L.gsdf_hashgrid_bwd_binned(B, *c, capi.f32(xd), capi.f32(vd), capi.f32(got2), capi.ptr(ws), nbytes, capi.stream()), "binned")
     torch.cuda.synchronize()
-    assert_close(got2, vt_o, 1e-6, "binned scatter, reused workspace")
+    assert_close(got2, vt_o, 1e-4, "binned scatter, reused workspace")
+    within_record_rounding(got2, "binned scatter, reused workspace")
     if not concentrated:       # no bucket is split (<= 2^19 records per tile): bit-reproducible
         got3 = torch.zeros_like(seed)
         capi.check(L.gsdf_hashgrid_bwd_binned(B, *c, capi.f32(xd), capi.f32(vd), capi.f32(got3), capi.ptr(ws), nbytes, capi.stream()), "binned")
@@ -527,7 +543,7 @@ def test_encoder_backward_takes_binned_path_for_large_batches(sdf, oracle, monke
         enc.params_.grad = None
         enc.forward(x).backward(v)
         grads[mode] = enc.params_.grad.clone()
-    assert_close(grads["1"], grads["0"], 1e-5, "autograd table gradient: binned vs atomic")
+    assert_close(grads["1"], grads["0"], 1e-4, "autograd table gradient: binned vs atomic")   # (8-byte records: 22-bit contributions)
 
 
 @pytest.mark.parametrize("n,delta", [(12000, 0.02 / 16.0), (12000, 0.3), (5000, 1e-5)])
