@@ -1087,7 +1087,7 @@ def cpu_baseline(sc, views, params, N, W, H, deg, n_sdf_points, dev):
             + (meta["render_median"] * ugd["v_render_median"]).sum())
     loss.backward()
     torch.cuda.synchronize()
-    EPS32, COND_C = 2.0 ** -24, 4.0
+    EPS32, COND_C = 2.0 ** -24, 2.0
 
     def matched(got, ref, bound):
         """|got - ref| <= 1e-4 max(|ref|, mean|ref|) + COND_C eps32 bound for every element (tests/util.py: matched_stats)"""
@@ -1118,7 +1118,7 @@ def cpu_baseline(sc, views, params, N, W, H, deg, n_sdf_points, dev):
            "v_opacities": _err_stats(n(leaves[3].grad), vop64), "v_sh": _err_stats(n(leaves[4].grad), vsh64[0]),
            "note": "HIP path vs the oracle on the bench workload's first view, NO pixel or splat excluded: ids / radii / bins / offsets bit-exact against "
                    "the fp32 build; floats against the fp64 build evaluated under the kernel's own traced decisions (oracle.rasterize_2dgs_*_matched). "
-                   "Compositing outputs: every element against 1e-4 max(|ref|, mean|ref|) + 4 eps32 x the oracle's first-order conditioning bound "
+                   "Compositing outputs: every element against 1e-4 max(|ref|, mean|ref|) + 2 eps32 x the oracle's first-order conditioning bound "
                    "(worst_over_tolerance <= 1 is the gate of tests/util.py; above_1e-4 = elements that needed the second term). End-to-end "
                    "parameter gradients (compositing -> projection / SH backward): per row, rows above 1e-4 / worst / relative L2 over ALL rows "
                    "(tests/test_gpu_baseline_shapes.py runs the same comparison at every BASELINE shape)"}

@@ -303,8 +303,7 @@ __global__ void __launch_bounds__(RT, 4)
                            const float *__restrict__ v_render_colors, const float *__restrict__ v_render_depths,
                            const float *__restrict__ v_render_alphas, const float *__restrict__ v_render_normals,
                            const float *__restrict__ v_render_median, float *__restrict__ grec,
-                           float *__restrict__ grec_abs, const float *__restrict__ final_T, unsigned long long *__restrict__ counters = nullptr,
-                           int dbg = 0) {
+                           float *__restrict__ grec_abs, const float *__restrict__ final_T, unsigned long long *__restrict__ counters = nullptr) {
   __shared__ BwdRowsLds<ABSGRAD> lds;
   unsigned long long c_visit = 0, c_live = 0, c_valid = 0;
   const int64_t tile = xcd_tile_index(total_tiles, n_xcd);
@@ -452,12 +451,12 @@ __global__ void __launch_bounds__(RT, 4)
         const float v16[16] = {g_rgb0, g_rgb1, g_rgb2, g_n0, g_n1, g_n2, g_op, vzx, vzy, vzz,
                                mxp * vzx, mxp * vzy, mxp * vzz, myp * vzx, myp * vzy, myp * vzz};
         r = row_transpose_reduce16(v16, lane);
-        if (r != 0.f && !(dbg & 1)) lds_add(&lds.acc[t][row_transpose_index(lane)], r);
+        if (r != 0.f) lds_add(&lds.acc[t][row_transpose_index(lane)], r);
       }
       {  // slots 16..18
         const float v4[4] = {g_dx, g_dy, g_mwz, 0.f};
         r = row_transpose_reduce4(v4, lane);
-        if ((lane & 12) == 12 && r != 0.f && !(dbg & 1)) lds_add(&lds.acc[t][16 + row_transpose_index4(lane)], r);
+        if ((lane & 12) == 12 && r != 0.f) lds_add(&lds.acc[t][16 + row_transpose_index4(lane)], r);
       }
       if (any2) {  // screen-space low-pass branch (rare)
         r = row_sum_to_lane15(g_x); if ((lane & 15) == 15 && r != 0.f) lds_add(&lds.acc[t][19], r);
@@ -581,10 +580,8 @@ static int rasterize_bwd_launch(int64_t C, int64_t M, int64_t I, int width, int 
         raster_bwd_rows_kernel<false, true><<<xcd_grid(total, n_xcd), RT, 0, stream>>>(ARGS, counters);
       else if (v_means2d_abs)
         raster_bwd_rows_kernel<true><<<xcd_grid(total, n_xcd), RT, 0, stream>>>(ARGS);
-      else {
-        static const int dbg = [] { const char *e = getenv("GSDF_RASTER_BWD_DBG"); return e ? atoi(e) : 0; }();   // EXPERIMENT (wrong results when set)
-        raster_bwd_rows_kernel<false><<<xcd_grid(total, n_xcd), RT, 0, stream>>>(ARGS, nullptr, dbg);
-      }
+      else
+        raster_bwd_rows_kernel<false><<<xcd_grid(total, n_xcd), RT, 0, stream>>>(ARGS);
     }
 #undef ARGS
     GSDF_CHECK_LAUNCH("raster_bwd_kernel");

@@ -6,7 +6,7 @@ Integer tensors (visible set, radii, tile keys, bins, offsets) must be BIT-EXACT
 float outputs (same operation order, no FMA contraction).  The compositing outputs and gradients go through the
 DECISION-MATCHED gate of tests/util.py (round 4: no excluded pixel or splat): the kernel's decisions in every decision-fragile
 pixel are traced, the oracle's fp64 build is evaluated under them, last_ids / median_ids must be identical and EVERY element of
-every image and gradient must be within 1e-4 (+ the first-order conditioning bound, needed by at most 0.2 % of a tensor's
+every image and gradient must be within 1e-4 (+ the first-order conditioning bound, needed by at most 1e-4 of a tensor's
 elements).  The projection / SH backward must be within 1e-4 element-wise (at most 12 elements up to 1e-3).  Every measurement
 is written to gpurun_out/parity_r04.json (committed copy: profiles/parity_r04.json)."""
 import json
@@ -106,7 +106,7 @@ def test_baseline_shape_parity(oracle, name):
         rec[key] = st
         if not st["finite"] or st["worst_over_tol"] > 1.0:
             failures.append(f"{key}: an element is {st['worst_over_tol']:.2f} x its tolerance ({st['worst_over_base']:.1f} x the 1e-4 bar)")
-        if st["needed"] > max(8, MAX_NEEDED * st["elements"]):
+        if st["needed"] > max(16, MAX_NEEDED * st["elements"]):
             failures.append(f"{key}: {st['needed']} of {st['elements']} elements above the plain 1e-4 bar")
         if st["rel_l2"] > 1e-5 + st["l2_allowance"]:
             failures.append(f"{key}: relative L2 over all elements {st['rel_l2']:.2e} > 1e-5 + {st['l2_allowance']:.1e}")

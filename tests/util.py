@@ -131,11 +131,13 @@ def assert_clean_parity(got, ref64, clean, name, rel=1e-4, stragglers=None):
 #     where `bound` is the oracle's first-order fp32 error bound of that element (conditioning of exp(-|s|^2/2) for edge-on
 #     splats, of the transmittance products, of the cancelling sums over pixels: splat_oracle.c block comment).  The second term
 #     is what no fp32 evaluation — the reference's included — can go below; the report says for how many elements it matters
-#     (`relaxed`: elements whose tolerance it more than doubles) and how many needed it (`needed`).
+#     (`relaxed`: elements whose tolerance it more than doubles) and how many needed it (`needed`: elements above the plain
+#     1e-4 bar — capped at MAX_NEEDED of a tensor, so that the plain bar is the gate for all but a handful of elements).
 # No straggler allowance, no excluded pixel or splat.
 # ---------------------------------------------------------------------------------------------------------------------------
 EPS32 = 2.0 ** -24
-COND_C = 4.0            # safety factor on the first-order bound (largest factor any measured element needed: 0.8, gpurun_out/gate_cal.log)
+COND_C = 2.0            # safety factor on the first-order bound (largest factor any measured element needed: 0.16 at the BASELINE shapes,
+                        # 0.78 in the adversarial scene — profiles/parity_r04.json, parity_small_cases_r04.json: c_needed)
 FLIP_MARGIN = 16.0      # a traced decision may differ from the fp64 one only within this many fp32-evaluation errors
 MATCHED_LOG = []        # (case, tensor, stats): dumped by conftest.pytest_sessionfinish
 
@@ -161,8 +163,9 @@ def matched_stats(got, ref, bound, rel=1e-4, cond_c=COND_C):
                 rel_l2=float(np.linalg.norm(g2 - r2) / (np.linalg.norm(r2) + 1e-30)), finite=bool(np.isfinite(g2).all()))
 
 
-MAX_NEEDED = 2e-3       # at most this fraction of a tensor's elements may lie above the plain 1e-4 bar at all (they must then be inside the
-                        # conditioning bound): the gate IS the plain bar on >= 99.8 % of the elements, whatever the bound says
+MAX_NEEDED = 1e-4       # at most this fraction of a tensor's elements (16 in a small tensor) may lie above the plain 1e-4 bar at all (they must
+                        # then be inside the conditioning bound): the gate IS the plain bar on >= 99.99 % of the elements, whatever the bound
+                        # says (measured: <= 1.5e-5 of the elements of any tensor at the BASELINE shapes)
 
 
 def assert_matched(got, ref, bound, name, case="", rel=1e-4, max_needed=MAX_NEEDED, max_rel_l2=1e-5):
@@ -176,7 +179,7 @@ def assert_matched(got, ref, bound, name, case="", rel=1e-4, max_needed=MAX_NEED
     assert st["rel_l2"] <= max_rel_l2 + st["l2_allowance"], (f"{name}: relative L2 error over ALL elements {st['rel_l2']:.2e} > {max_rel_l2:.0e} "
                                                              f"+ {st['l2_allowance']:.1e}")
     if max_needed is not None and st["elements"]:
-        assert st["needed"] <= max(8, max_needed * st["elements"]), (f"{name}: {st['needed']} of {st['elements']} elements are above the plain {rel:.0e} bar "
+        assert st["needed"] <= max(16, max_needed * st["elements"]), (f"{name}: {st['needed']} of {st['elements']} elements are above the plain {rel:.0e} bar "
                                                                      "(inside their conditioning bound, but too many for the bound to be the exception)")
     return st
 
