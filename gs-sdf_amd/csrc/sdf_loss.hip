@@ -171,6 +171,12 @@ __global__ void __launch_bounds__(256)
 // scale * loss::gs_sdf_loss at the visible splats' samples (:436-457).  One thread per point: value, d/d decoder output,
 // vv_x = dL/d(J^T g0) (unit-cube coordinates) and u0 = J vv_x = dL/d g0 — what the double backward of the decoder
 // (gsdf_mlp_bwd_bwd) and of the encoder (gsdf_hashgrid_bwd_binned2) consume.
+// Round 4: EIGHT lanes per point (NF = 32: four features per lane).  One lane per point read its own 384-byte Jacobian row and 128-byte
+// g0 row at a 384-byte lane stride — 64 lines per load instruction, the rows thrashing the L1 — and read the Jacobian twice (J^T g0, then
+// J vv_x).  Now a group's 8 lanes read their point's rows as 8 x 48 and 8 x 16 contiguous bytes (a wave = 8 consecutive points = 3 KB /
+// 1 KB contiguous), keep the 12 Jacobian entries of their 4 features in registers for both products, reduce the three components of
+// J^T g0 over the group with DPP and write u0 as one float4 each.  The per-point scalar work (data term, eikonal, align) is done by every
+// lane of the group on the same operands; lane 0 writes it.  0.213 -> see DESIGN 6 (the kernel now moves its algorithmic 0.75 KB per point).
 template <int NF>
 __global__ void __launch_bounds__(256)
     sdf_analytic_loss_kernel(int64_t n, int64_t n_ray, int stencil, const float *__restrict__ attr, int ld, const float *__restrict__ g0,
@@ -178,17 +184,25 @@ __global__ void __launch_bounds__(256)
                              const int64_t *__restrict__ ids, float bce_isigma, float w_sdf, float w_gs, float map_size_inv, float delta,
                              float w_eik, float w_align, float *__restrict__ loss, float *__restrict__ v_attr,
                              float *__restrict__ vv_x, float *__restrict__ u0) {
+  static_assert(NF == 32, "8 lanes x 4 features");
   __shared__ float s_part[4];
   float contrib = 0.f;
+  const int q = threadIdx.x & 7;                       // lane within the point's group: features 4q .. 4q+3
+  const int64_t gpb = 256 / 8;                         // points per workgroup and round
+  const int64_t rounds = (n + gpb * gridDim.x - 1) / (gpb * gridDim.x);
   // capped grid + grid-stride loop: the value is ONE address, and atomics on one line serialise at ~88 per microsecond
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+  for (int64_t rd = 0; rd < rounds; ++rd) {
+    const int64_t i = (rd * gridDim.x + blockIdx.x) * gpb + (threadIdx.x >> 3);
+    const bool live = i < n;                           // whole groups are live or dead together; dead groups still take part in the DPP
+    const int64_t ic = live ? i : 0;
     // rows [0, n_ray): per-ray batch (mean over n_ray); rows [n_ray, n): splat samples (mean over n - n_ray): the two
     // sdf_regularization calls of the iteration normalise separately (neural_mapping.cpp:183-186, :448-451)
-    const bool ray = i < n_ray;
+    const bool ray = ic < n_ray;
     const float inv_n = 1.0f / (float)(ray ? n_ray : n - n_ray);
-    const float s = attr[i * ld];
+    const float s = attr[ic * ld];
+    float c_pt = 0.f, va0 = 0.f, va1 = 0.f;
     if (ray) {
-      const float raw = attr[i * ld + 1], g = gt[i];
+      const float raw = attr[ic * ld + 1], g = gt[ic];
       const float br = 100.0f * raw;
       const float sp = br > 20.0f ? raw : log1pf(expf(br)) * 0.01f;
       const float dsp = br > 20.0f ? 1.0f : sigmoidf(br);
@@ -202,51 +216,64 @@ __global__ void __launch_bounds__(256)
       const float bce = (1.0f - t) * x + fmaxf(-x, 0.0f) + log1pf(expf(-fabsf(x)));
       const float dx = sigmoidf(x) - t, dt = -x;
       const float d_is = dx * (-s) + dt * dt_du * (-g);
-      contrib += w_sdf * bce * inv_n;
-      v_attr[i * ld] = w_sdf * dx * (-is) * inv_n;
-      v_attr[i * ld + 1] = w_sdf * d_is * dis_draw * inv_n;
-      for (int c = 2; c < ld; ++c) v_attr[i * ld + c] = 0.f;
+      c_pt += w_sdf * bce * inv_n;
+      va0 = w_sdf * dx * (-is) * inv_n;
+      va1 = w_sdf * d_is * dis_draw * inv_n;
     } else {
-      const int64_t j = i - n_ray;
+      const int64_t j = ic - n_ray;
       const float w = weights[ids != nullptr ? ids[j] : j];
-      contrib += 0.5f * w_gs * w * s * s;
-      v_attr[i * ld] = w_gs * w * s;
-      for (int c = 1; c < ld; ++c) v_attr[i * ld + c] = 0.f;
+      c_pt += 0.5f * w_gs * w * s * s;
+      va0 = w_gs * w * s;
     }
-    // analytic gradient in world units
-    const float *J = jac + i * (int64_t)(NF * 3);
-    const float *gg = g0 + i * (int64_t)NF;
+    // analytic gradient in world units: this lane's 4 features
+    const float4 *J4 = reinterpret_cast<const float4 *>(jac + ic * (int64_t)(NF * 3) + 12 * q);
+    const float4 j0 = J4[0], j1 = J4[1], j2 = J4[2];
+    const float4 gq = *reinterpret_cast<const float4 *>(g0 + ic * (int64_t)NF + 4 * q);
+    const float J[12] = {j0.x, j0.y, j0.z, j0.w, j1.x, j1.y, j1.z, j1.w, j2.x, j2.y, j2.z, j2.w};
+    const float gv[4] = {gq.x, gq.y, gq.z, gq.w};
     float ax = 0.f, ay = 0.f, az = 0.f;
-#pragma unroll 8
-    for (int f = 0; f < NF; ++f) {
-      const float q = gg[f];
-      ax = fmaf(J[3 * f], q, ax); ay = fmaf(J[3 * f + 1], q, ay); az = fmaf(J[3 * f + 2], q, az);
-    }
+#pragma unroll
+    for (int f = 0; f < 4; ++f) { ax = fmaf(J[3 * f], gv[f], ax); ay = fmaf(J[3 * f + 1], gv[f], ay); az = fmaf(J[3 * f + 2], gv[f], az); }
+    // sum over the 8 lanes of the group (all lanes get it): lane ^ 1, ^ 2 (quad permutes), ^ 4 (row_shl / row_shr by 4 within 8-lane halves)
+    ax += dpp_mov<0xB1>(ax); ay += dpp_mov<0xB1>(ay); az += dpp_mov<0xB1>(az);
+    ax += dpp_mov<0x4E>(ax); ay += dpp_mov<0x4E>(ay); az += dpp_mov<0x4E>(az);
+    ax += dpp_xchg<0x104, 0x114, 0x5, 0xA>(ax); ay += dpp_xchg<0x104, 0x114, 0x5, 0xA>(ay); az += dpp_xchg<0x104, 0x114, 0x5, 0xA>(az);
     ax *= map_size_inv; ay *= map_size_inv; az *= map_size_inv;
     const float nrm = sqrtf(ax * ax + ay * ay + az * az);
     const float e = nrm - 1.0f;
-    contrib += w_eik * e * e * inv_n;
+    c_pt += w_eik * e * e * inv_n;
     const float k0 = nrm > 0.f ? w_eik * 2.0f * e / nrm * inv_n : 0.f;    // torch's norm backward: 0 at the origin
     float vx = k0 * ax, vy = k0 * ay, vz = k0 * az;
     if (stencil && w_align != 0.f) {
       float ps[6];
 #pragma unroll
-      for (int k = 0; k < 6; ++k) ps[k] = attr[(n + k * n + i) * ld];
+      for (int k = 0; k < 6; ++k) ps[k] = attr[(n + k * n + ic) * ld];
       const float h = 0.5f * (1.0f / delta);
       const float nx = h * (ps[0] - ps[1]), ny = h * (ps[2] - ps[3]), nz = h * (ps[4] - ps[5]);
       const float c3 = w_align * inv_n * (1.0f / 3.0f);
       const float dx_ = ax - nx, dy_ = ay - ny, dz_ = az - nz;
-      contrib += c3 * (fabsf(dx_) + fabsf(dy_) + fabsf(dz_));
+      c_pt += c3 * (fabsf(dx_) + fabsf(dy_) + fabsf(dz_));
       // torch's abs backward: sign(0) = 0
       vx += c3 * (dx_ > 0.f ? 1.f : (dx_ < 0.f ? -1.f : 0.f));
       vy += c3 * (dy_ > 0.f ? 1.f : (dy_ < 0.f ? -1.f : 0.f));
       vz += c3 * (dz_ > 0.f ? 1.f : (dz_ < 0.f ? -1.f : 0.f));
     }
     vx *= map_size_inv; vy *= map_size_inv; vz *= map_size_inv;       // dL / d (J^T g0)
-    vv_x[3 * i] = vx; vv_x[3 * i + 1] = vy; vv_x[3 * i + 2] = vz;
-    float *uo = u0 + i * (int64_t)NF;
-#pragma unroll 8
-    for (int f = 0; f < NF; ++f) uo[f] = fmaf(J[3 * f + 2], vz, fmaf(J[3 * f + 1], vy, J[3 * f] * vx));
+    if (live) {
+      float4 uo;
+      uo.x = fmaf(J[2], vz, fmaf(J[1], vy, J[0] * vx));
+      uo.y = fmaf(J[5], vz, fmaf(J[4], vy, J[3] * vx));
+      uo.z = fmaf(J[8], vz, fmaf(J[7], vy, J[6] * vx));
+      uo.w = fmaf(J[11], vz, fmaf(J[10], vy, J[9] * vx));
+      *reinterpret_cast<float4 *>(u0 + i * (int64_t)NF + 4 * q) = uo;
+      if (q == 0) {
+        contrib += c_pt;
+        v_attr[i * ld] = va0;
+        if (ld > 1) v_attr[i * ld + 1] = va1;       // (0 for a splat-sample row)
+        for (int c = 2; c < ld; ++c) v_attr[i * ld + c] = 0.f;
+        vv_x[3 * i] = vx; vv_x[3 * i + 1] = vy; vv_x[3 * i + 2] = vz;
+      }
+    }
   }
   const float ws = wave_sum_to_lane63(contrib);
   if ((threadIdx.x & 63) == 63) s_part[threadIdx.x >> 6] = ws;
@@ -338,8 +365,8 @@ extern "C" int gsdf_sdf_analytic_loss(int64_t n, int64_t n_ray, int stencil, con
   GSDF_HIP(hipMemsetAsync(loss, 0, 4, stream), "sdf_analytic_loss memset");
   if (n == 0) return GSDF_OK;
   GSDF_REQUIRE(attr && g0 && jac && v_attr && vv_x && u0 && (n_ray == 0 || gt_sdf) && (n_ray == n || weights), "sdf_analytic_loss: null buffer");
-  const int64_t blocks = (n + 255) / 256;
-  sdf_analytic_loss_kernel<32><<<(unsigned)(blocks > 1024 ? 1024 : blocks), 256, 0, stream>>>(n, n_ray, stencil, attr, ld, g0, jac, gt_sdf, weights,
+  const int64_t blocks = (n + 31) / 32;          // 8 lanes per point
+  sdf_analytic_loss_kernel<32><<<(unsigned)(blocks > 2048 ? 2048 : blocks), 256, 0, stream>>>(n, n_ray, stencil, attr, ld, g0, jac, gt_sdf, weights,
                                                                                            ids, bce_isigma, w_sdf, w_gs, map_size_inv, delta,
                                                                                            w_eik, w_align, loss, v_attr, vv_x, u0);
   GSDF_CHECK_LAUNCH("sdf_analytic_loss_kernel");
