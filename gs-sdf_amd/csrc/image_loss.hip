@@ -29,7 +29,14 @@ __global__ void __launch_bounds__(256)
   __shared__ float sx[3][IL_H][IL_H + 1], sy[3][IL_H][IL_H + 1];
   __shared__ float row[5][IL_H][IL_T + 1];
   __shared__ float red[2][4];
-  const int x0 = blockIdx.x * IL_T, y0 = blockIdx.y * IL_T, tid = threadIdx.x;
+  const int tid = threadIdx.x;
+  // the two sums are ONE line: capped grid + tile loop, two atomics per workgroup instead of per tile (atomics on one line serialise at
+  // ~88 per microsecond, DESIGN 6.2: 4080 of them at 1080p)
+  const int tiles_x = (W + IL_T - 1) / IL_T, n_tiles = tiles_x * ((H + IL_T - 1) / IL_T);
+  float l1 = 0.f, ss = 0.f;
+  for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+  const int x0 = (tile % tiles_x) * IL_T, y0 = (tile / tiles_x) * IL_T;
+  if (tile != (int)blockIdx.x) __syncthreads();   // the previous tile's readers of sx / sy are done
   for (int e = tid; e < IL_H * IL_H * 3; e += 256) {
     const int px = e / 3, c = e - 3 * px;
     const int yy = px / IL_H, xx = px - yy * IL_H;
@@ -37,7 +44,6 @@ __global__ void __launch_bounds__(256)
     sy[c][yy][xx] = il_at(gt, H, W, y0 + yy - IL_R, x0 + xx - IL_R, c);
   }
   __syncthreads();
-  float l1 = 0.f, ss = 0.f;
   const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
   float keep[4][3][3];  // [pixel of this lane][map][channel]
 #pragma unroll
@@ -92,6 +98,7 @@ __global__ void __launch_bounds__(256)
       }
     }
   }
+  }   // tile loop
   for (int s = 32; s >= 1; s >>= 1) { l1 += __shfl_xor(l1, s, 64); ss += __shfl_xor(ss, s, 64); }
   if ((tid & 63) == 0) { red[0][tid >> 6] = l1; red[1][tid >> 6] = ss; }
   __syncthreads();
@@ -180,8 +187,8 @@ extern "C" int gsdf_l1_dssim_fwd(int height, int width, const float *img, const 
   Win11 w;
   for (int k = 0; k < 11; ++k) w.w[k] = window11_host[k];
   GSDF_HIP(hipMemsetAsync(sums, 0, 2 * sizeof(float), stream), "l1_dssim_fwd memset");
-  dim3 grid((width + IL_T - 1) / IL_T, (height + IL_T - 1) / IL_T, 1);
-  l1_dssim_fwd_kernel<<<grid, 256, 0, stream>>>(height, width, img, gt, w, sums, maps);
+  const int n_tiles = ((width + IL_T - 1) / IL_T) * ((height + IL_T - 1) / IL_T);
+  l1_dssim_fwd_kernel<<<n_tiles < 512 ? n_tiles : 512, 256, 0, stream>>>(height, width, img, gt, w, sums, maps);
   GSDF_CHECK_LAUNCH("l1_dssim_fwd_kernel");
   return GSDF_OK;
 }
