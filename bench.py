@@ -173,7 +173,7 @@ def main():
     batcher = None
     if impl == "cpp" and args.ray_batch == "sampled" and not args.dump_grads:
         import gs_sdf_amd.hostlib as hostlib
-        batcher = RayBatcher(hostlib.load(), sc, views, dev)
+        batcher = RayBatcher(hostlib.load(), sc, views, dev, seed=7 + 1009 * rank)      # every rank draws its own rays (seed xor rank)
     groups = []
     if not args.no_sdf and impl == "python":
         # hash-grid SDF (2^19 table, 16 levels x 2) + fused MFMA decoder; the reference's numerical-gradient
@@ -757,7 +757,7 @@ class RayBatcher:
         cfg.leaf_size, cfg.inner_map_size = leaf, map_size - 2 * leaf
         self.lm = host.LocalMap(torch.tensor([0.0, 0.0, 5.5]), cfg)
         self.lm.update_octree_as(sc["means"].to(dev), False)
-        g = torch.Generator().manual_seed(seed)
+        g = torch.Generator().manual_seed(7)            # the depth pack is the data set: the same on every rank; `seed` drives the draws
         c2w = torch.linalg.inv(views.cpu().double())
         centres = c2w[:, :3, 3].float()                                               # camera centres in the world
         V, N = centres.shape[0], sc["means"].shape[0]
@@ -1076,6 +1076,31 @@ def cpu_baseline(sc, views, params, N, W, H, deg, n_sdf_points, dev):
     vsh64 = orc.view_colors_bwd(n(view), means, n(sc["sh"]), p["camera_ids"], p["gaussian_ids"], deg, f64(g64["v_colors"]), prec="f64")   # (v_sh, v_means)
     vop64 = np.zeros(N)
     np.add.at(vop64, p["gaussian_ids"], f64(g64["v_opacities"]))
+    # The compositing gradients' first-order error bounds (g64["cond"], eps32 units) pushed through the LINEAR projection / SH backward, one
+    # upstream component at a time, so that every term enters with its absolute value: bound(leaf) = sum_k |J^T (e_k . bound_k)|.
+    # The end-to-end parameter gradients below are then gated like the compositing's own: 1e-4 max(|ref|, mean|ref|) + COND_C eps32 bound.
+    cnd = g64["cond"]
+    zM = lambda *sh: np.zeros((M,) + sh, np.float64)
+    b_means, b_quats, b_scales = np.zeros((N, 3)), np.zeros((N, 4)), np.zeros((N, 3))
+    for k in range(14):
+        v2d, vrt, vnr = zM(2), zM(3, 3), zM(3)
+        if k < 2:
+            v2d[:, k] = cnd[:, k]
+        elif k < 11:
+            vrt.reshape(M, 9)[:, k - 2] = cnd[:, k]
+        else:
+            vnr[:, k - 11] = cnd[:, 15 + k - 11]
+        bm_, bq_, bs_ = orc.projection_2dgs_bwd(means, quats, scales, n(view), n(sc["K"]), W, H, p["camera_ids"], p["gaussian_ids"], v2d, np.zeros(M, np.float64),
+                                                vrt, vnr, prec="f64")
+        b_means += np.abs(bm_); b_quats += np.abs(bq_); b_scales += np.abs(bs_)
+    b_sh = np.zeros(n(sc["sh"]).shape)
+    for k in range(3):
+        vc = zM(3)
+        vc[:, k] = cnd[:, 11 + k]
+        bsh_, bms_ = orc.view_colors_bwd(n(view), means, n(sc["sh"]), p["camera_ids"], p["gaussian_ids"], deg, vc, prec="f64")
+        b_sh += np.abs(bsh_); b_means += np.abs(bms_)
+    b_opac = np.zeros(N)
+    np.add.at(b_opac, p["gaussian_ids"], cnd[:, 14])
     leaves = [t(a).requires_grad_(True) for a in (means, quats, scales, opac, n(sc["sh"]))]
     colors, alphas, meta = ops.rasterization_2dgs_sdf(*leaves, view.to(dev), sc["K"].to(dev), W, H, "RGB+D", 0.05, 300.0, 0.0, deg)
     ugd = {k: v.to(dev) for k, v in ug.items()}
@@ -1113,9 +1138,9 @@ def cpu_baseline(sc, views, params, N, W, H, deg, n_sdf_points, dev):
            "render_median": matched(n(meta["render_median"]), fw64["render_median"], pb[..., 4]),
            "visibilities": matched(n(meta["visibilities"]), fw64["visibilities"], fw64["vis_bound"]),
            "v_densify": matched(n(meta["gradient_2dgs"].grad), g64["v_densify"], g64["cond"][:, orc.COND_SLICES["v_densify"]]),
-           "v_means (compositing + projection + SH backward)": _err_stats(n(leaves[0].grad), pb64[0] + vsh64[1]),
-           "v_quats (compositing + projection backward)": _err_stats(n(leaves[1].grad), pb64[1]), "v_scales": _err_stats(n(leaves[2].grad), pb64[2]),
-           "v_opacities": _err_stats(n(leaves[3].grad), vop64), "v_sh": _err_stats(n(leaves[4].grad), vsh64[0]),
+           "v_means (compositing + projection + SH backward)": matched(n(leaves[0].grad), pb64[0] + vsh64[1], b_means),
+           "v_quats (compositing + projection backward)": matched(n(leaves[1].grad), pb64[1], b_quats), "v_scales": matched(n(leaves[2].grad), pb64[2], b_scales),
+           "v_opacities": matched(n(leaves[3].grad), vop64, b_opac), "v_sh": matched(n(leaves[4].grad), vsh64[0], b_sh),
            "note": "HIP path vs the oracle on the bench workload's first view, NO pixel or splat excluded: ids / radii / bins / offsets bit-exact against "
                    "the fp32 build; floats against the fp64 build evaluated under the kernel's own traced decisions (oracle.rasterize_2dgs_*_matched). "
                    "Compositing outputs: every element against 1e-4 max(|ref|, mean|ref|) + 2 eps32 x the oracle's first-order conditioning bound "
@@ -1147,17 +1172,17 @@ def cpu_baseline(sc, views, params, N, W, H, deg, n_sdf_points, dev):
         torch.cuda.synchronize()
         o64 = orc.mlp_fwd(feat, dims, Wm, None, prec="f64")
         vin64, vw64, _ = orc.mlp_bwd(feat, dims, Wm, None, np.ones_like(o64), prec="f64")
-        # points with a hidden pre-activation within 1e-5 of zero may take the other ReLU branch than the fp64 evaluation (a decision, like
+        # points with a hidden pre-activation within 1e-5 (of the layer's rms) of zero may take the other ReLU branch than the fp64 evaluation (a decision, like
         # the compositing's): the same mask as tests/test_gpu_sdf_parity.py::_near_relu_kink; both figures are printed
         hcur, off_, away = feat.astype(np.float64), 0, np.ones(n_s, bool)
         for l_ in range(len(dims) - 2):
             z_ = hcur @ Wm[off_:off_ + dims[l_] * dims[l_ + 1]].astype(np.float64).reshape(dims[l_ + 1], dims[l_]).T
             off_ += dims[l_] * dims[l_ + 1]
-            away &= ~(np.abs(z_) < 1e-5).any(axis=1)
+            away &= ~(np.abs(z_) < 1e-5 * np.sqrt((z_ * z_).mean())).any(axis=1)      # relative to the layer's pre-activation scale (here ~1e-4: the table is U(-1e-4, 1e-4))
             hcur = np.maximum(z_, 0.0)
         par["sdf"] = {"hashgrid_features (vs f32 build)": _err_stats(n(feat_h), feat), "decoder_out (vs f64 build)": _err_stats(n(out_h), o64),
                       "decoder_v_in (vs f64 build)": _err_stats(n(vin_h), vin64, away), "decoder_v_weights (vs f64 build)": _err_stats(n(vw_h), vw64),
-                      "points_within_1e-5_of_a_relu_kink": int((~away).sum()),
+                      "points_within_1e-5_rms_of_a_relu_kink": int((~away).sum()),
                       "table_gradient (vs f32 build)": _err_stats(n(vt_h), vt_o),
                       "note": f"{n_s} uniformly random points, table U(-1e-4, 1e-4), 4-layer bias-free decoder; the decoder runs on the bf16 MFMA pipe with "
                               "exact 3-term operand splits (GSDF_MLP_MFMA=f32 selects the fp32 pipe); a point whose pre-activation is within "
