@@ -1145,8 +1145,9 @@ def cpu_baseline(sc, views, params, N, W, H, deg, n_sdf_points, dev):
                    "the fp32 build; floats against the fp64 build evaluated under the kernel's own traced decisions (oracle.rasterize_2dgs_*_matched). "
                    "Compositing outputs: every element against 1e-4 max(|ref|, mean|ref|) + 2 eps32 x the oracle's first-order conditioning bound "
                    "(worst_over_tolerance <= 1 is the gate of tests/util.py; above_1e-4 = elements that needed the second term). End-to-end "
-                   "parameter gradients (compositing -> projection / SH backward): per row, rows above 1e-4 / worst / relative L2 over ALL rows "
-                   "(tests/test_gpu_baseline_shapes.py runs the same comparison at every BASELINE shape)"}
+                   "parameter gradients (compositing -> projection / SH backward): the same element-wise comparison, the compositing bounds "
+                   "pushed through the fp64 projection / SH backward by absolute values "
+                   "(tests/test_gpu_baseline_shapes.py runs the comparison at every BASELINE shape)"}
     if n_sdf_points:
         # SDF half: the HIP encoder / decoder / scatter on the sample the oracle was timed on.  Features and table gradient
         # against the fp32 build (pos = fma(scale, x, 0.5) in fp32 IS the function), decoder against the fp64 build
