@@ -15,7 +15,7 @@ _lib = None
 
 _i64, _i32, _f32, _u64, _vp, _sz = C.c_int64, C.c_int, C.c_float, C.c_uint64, C.c_void_p, C.c_size_t
 
-ABI_VERSION = 3      # include/gsdf_hip.h: GSDF_ABI_VERSION this binding was written against
+ABI_VERSION = 4      # include/gsdf_hip.h: GSDF_ABI_VERSION this binding was written against
 
 
 class RasterInstr(C.Structure):
@@ -28,6 +28,8 @@ _SIGS = {
     "gsdf_last_error": (C.c_char_p, []),
     "gsdf_timing_begin": (C.c_int, [C.c_char_p]),
     "gsdf_timing_end": (_sz, [C.c_char_p, _sz]),
+    "gsdf_host_words_alloc": (C.c_int, [_i32, _vp, _vp]),
+    "gsdf_host_words_free": (C.c_int, [_vp]),
     "gsdf_projection_2dgs_ws_bytes": (_sz, [_i64, _i64]),
     "gsdf_projection_2dgs_cull": (C.c_int, [_i64, _i64] + [_vp] * 5 + [_i32, _i32, _f32, _f32, _f32] + [_vp] * 4),
     "gsdf_projection_2dgs_fill": (C.c_int, [_i64, _i64] + [_vp] * 5 + [_i32, _i32, _u64, _vp, _vp, _i64] + [_vp] * 10),

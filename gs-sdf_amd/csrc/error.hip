@@ -52,6 +52,30 @@ void set_error(const char *fmt, ...) {
 extern "C" const char *gsdf_last_error(void) { return gsdf::g_err; }
 extern "C" int gsdf_abi_version(void) { return GSDF_ABI_VERSION; }
 
+extern "C" int gsdf_host_words_alloc(int n_words, int64_t **host_view, int64_t **device_view) {
+  GSDF_REQUIRE(n_words > 0 && host_view && device_view, "host_words_alloc: bad arguments");
+  void *h = nullptr, *d = nullptr;
+  // coherent (fine-grained) pinned memory: device stores are not held back in the L2 until the end of the kernel
+  if (hipHostMalloc(&h, (size_t)n_words * sizeof(int64_t), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) {
+    (void)hipGetLastError();
+    GSDF_HIP(hipHostMalloc(&h, (size_t)n_words * sizeof(int64_t), hipHostMallocMapped), "host_words_alloc");
+  }
+  if (hipHostGetDevicePointer(&d, h, 0) != hipSuccess) {
+    (void)hipGetLastError();
+    (void)hipHostFree(h);
+    gsdf::set_error("host_words_alloc: no device view of the pinned words");
+    return GSDF_ERR_LAUNCH;
+  }
+  memset(h, 0, (size_t)n_words * sizeof(int64_t));
+  *host_view = (int64_t *)h;
+  *device_view = (int64_t *)d;
+  return GSDF_OK;
+}
+extern "C" int gsdf_host_words_free(int64_t *host_view) {
+  if (host_view != nullptr) GSDF_HIP(hipHostFree(host_view), "host_words_free");
+  return GSDF_OK;
+}
+
 extern "C" int gsdf_stream_set_xcds(gsdf_stream_t stream, int n_xcds) {
   GSDF_REQUIRE(n_xcds >= 0 && n_xcds <= 8, "stream_set_xcds: n_xcds %d outside [0,8]", n_xcds);
   std::lock_guard<std::mutex> lock(gsdf::g_xcd_mutex);

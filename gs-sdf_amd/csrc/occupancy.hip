@@ -165,7 +165,7 @@ __global__ void __launch_bounds__(1024) visible_scan_kernel(int nblk, int32_t *_
     if (threadIdx.x == 1023) s_carry = before + incl;
     __syncthreads();
   }
-  if (threadIdx.x == 0) *total = s_carry;
+  if (threadIdx.x == 0) { *total = s_carry; __threadfence_system(); }   // (the count may be a host-visible word: gsdf_host_words_alloc)
 }
 __global__ void __launch_bounds__(256)
     visible_write_kernel(int64_t n, const uint8_t *__restrict__ flags, const int32_t *__restrict__ offsets, int64_t *__restrict__ ids) {

@@ -60,7 +60,7 @@ __global__ void __launch_bounds__(SCAN_THREADS) scan_partials_kernel(int64_t *__
     if (i < nb) partials[i] = carry + incl - v;
     carry += tot;
   }
-  if (threadIdx.x == 0) *total = carry;
+  if (threadIdx.x == 0) { *total = carry; __threadfence_system(); }   // (the total may be a host-visible word: gsdf_host_words_alloc)
 }
 
 __global__ void __launch_bounds__(SCAN_THREADS) scan_downsweep_kernel(const int32_t *__restrict__ in, int64_t n,

@@ -106,6 +106,7 @@ struct JointStreams {
   at::cuda::CUDAEvent fwd_done, entry, side_done;
   StreamGate gate;
   bool side_pending = false;
+  std::unique_ptr<gsdf_host::HostWords> counts;   // step_direct: M, I, n_gs_sdf as host-visible words (no copy, no synchronisation)
 };
 
 JointIteration::~JointIteration() = default;
@@ -438,10 +439,22 @@ std::map<std::string, int64_t> JointIteration::step_direct(const Tensor &viewmat
   Tensor quats = views_[2].detach();
   Tensor radii_dense = torch::empty({std::max<int64_t>(N, 1)}, fopt.dtype(torch::kInt32));
   Tensor pws = torch::empty({(int64_t)gsdf_projection_2dgs_ws_bytes(N, 1)}, fopt.dtype(torch::kUInt8));
-  Tensor n_vis = torch::empty({1}, fopt.dtype(torch::kInt64));
+  // The three sizes the host needs (M, I, n_gs_sdf) arrive in host-visible words (gsdf_host_words_alloc): no copy kernel, no stream
+  // synchronisation, and what is queued between the launch and the wait runs while the host polls.  GSDF_HOST_COUNTS=0: device scalars.
+  if (gsdf_host::HostWords::enabled() && !streams_->counts) streams_->counts = std::make_unique<gsdf_host::HostWords>(4);
+  gsdf_host::HostWords *cw = gsdf_host::HostWords::enabled() ? streams_->counts.get() : nullptr;
+  Tensor dev_counts = cw ? Tensor() : torch::empty({3}, fopt.dtype(torch::kInt64));
+  auto count_ptr = [&](int i) { if (cw) { cw->arm(i); return cw->dev(i); } return dev_counts.data_ptr<int64_t>() + i; };
+  auto count_wait = [&](int i) { return cw ? cw->wait(i) : read_i64(dev_counts[i]); };
   check(gsdf_projection_2dgs_cull(N, 1, fp(xyz), fp(quats), fp(scales), fp(viewmat), fp(K), W, H, cfg_.near_plane, cfg_.far_plane, 0.f,
-                                  radii_dense.data_ptr<int32_t>(), pws.data_ptr(), n_vis.data_ptr<int64_t>(), cur_stream()), "projection(cull)");
-  const int64_t M = read_i64(n_vis);
+                                  radii_dense.data_ptr<int32_t>(), pws.data_ptr(), count_ptr(0), cur_stream()), "projection(cull)");
+  // (while the host waits for M: the zero fill of the backward's scratch, the images' allocations)
+  scratch_.zero_();
+  auto img = [&](int64_t ch) { return torch::empty({1, H, W, ch}, fopt); };
+  Tensor rc = img(3), rd = img(1), ra = img(1), rn = img(3), rm = img(1), fT = torch::empty({1, H, W}, fopt);
+  Tensor last = torch::empty({1, H, W}, fopt.dtype(torch::kInt32)), med = torch::empty({1, H, W}, fopt.dtype(torch::kInt32));
+  Tensor renders = img(4), nw = img(3), c3 = img(3), d1 = img(1);
+  const int64_t M = count_wait(0);
   Tensor camera_ids = torch::empty({M}, fopt.dtype(torch::kInt64)), gaussian_ids = torch::empty({M}, fopt.dtype(torch::kInt64));
   Tensor radii = torch::empty({M}, fopt.dtype(torch::kInt32)), means2d = torch::empty({M, 2}, fopt), depths = torch::empty({M}, fopt);
   Tensor rt = torch::empty({M, 3, 3}, fopt), normals = torch::empty({M, 3}, fopt), smp = torch::empty({M, 3}, fopt), sw = torch::empty({M, 1}, fopt);
@@ -453,34 +466,46 @@ std::map<std::string, int64_t> JointIteration::step_direct(const Tensor &viewmat
                                   pws.data_ptr(), M, M ? camera_ids.data_ptr<int64_t>() : nullptr, M ? gaussian_ids.data_ptr<int64_t>() : nullptr,
                                   M ? radii.data_ptr<int32_t>() : nullptr, fpm(means2d), fpm(depths), fpm(rt), fpm(normals), fpm(smp), fpm(sw),
                                   cur_stream()), "projection(fill)");
+  // tile binning, first half (gsplat_cpp::tile_encode's two launches, split at its size read-back): tiles per splat and their running sum
+  Tensor tpg = torch::empty({M}, fopt.dtype(torch::kInt32)), cum = torch::empty({std::max<int64_t>(M, 1)}, fopt.dtype(torch::kInt64));
+  Tensor tws = torch::empty({(int64_t)gsdf_tile_count_ws_bytes(M)}, fopt.dtype(torch::kUInt8));
+  check(gsdf_tile_count(M, W, H, 16, fp(means2d), M ? radii.data_ptr<int32_t>() : nullptr, M ? tpg.data_ptr<int32_t>() : nullptr, cum.data_ptr<int64_t>(),
+                        tws.data_ptr(), count_ptr(1), cur_stream()), "tile_encode(count)");
+  // (while the host waits for I: the gathers and the colours, which the binning does not need)
   Tensor samples = center ? xyz.index_select(0, gaussian_ids) : smp, samples_weights = center ? torch::ones({M, 1}, fopt) : sw;
   Tensor pt_opac = opac.index_select(0, gaussian_ids);
   Tensor colors = torch::empty({M, 3}, fopt);
   check(gsdf_view_colors_fwd(M, Ksh, cfg_.sh_degree, fp(viewmat), fp(xyz), fp(sh), M ? camera_ids.data_ptr<int64_t>() : nullptr,
                              M ? gaussian_ids.data_ptr<int64_t>() : nullptr, fpm(colors), cur_stream()), "view_colors_fwd");
-  auto enc = gsplat_cpp::tile_encode(W, H, 16, means2d, radii, depths, true, 1, camera_ids, gaussian_ids);
-  Tensor flat = std::get<1>(enc).contiguous(), offs = std::get<2>(enc).contiguous();
-  const int64_t I = flat.size(0);
-  auto img = [&](int64_t ch) { return torch::empty({1, H, W, ch}, fopt); };
-  Tensor rc = img(3), rd = img(1), ra = img(1), rn = img(3), rm = img(1), vis = torch::empty({M, 1}, fopt), fT = torch::empty({1, H, W}, fopt);
-  Tensor last = torch::empty({1, H, W}, fopt.dtype(torch::kInt32)), med = torch::empty({1, H, W}, fopt.dtype(torch::kInt32));
+  Tensor vis = torch::empty({M, 1}, fopt);
+  Tensor offs = torch::empty({1, (H + 15) / 16, (W + 15) / 16}, fopt.dtype(torch::kInt32));
+  const int64_t I = count_wait(1);
+  Tensor isect_ids = torch::empty({I}, fopt.dtype(torch::kInt64)), flat = torch::empty({I}, fopt.dtype(torch::kInt32));
+  {
+    Tensor ws2 = torch::empty({(int64_t)gsdf_tile_encode_ws_bytes(M, I)}, fopt.dtype(torch::kUInt8));
+    check(gsdf_tile_encode(M, 1, I, W, H, 16, fp(means2d), M ? radii.data_ptr<int32_t>() : nullptr, fp(depths), M ? camera_ids.data_ptr<int64_t>() : nullptr,
+                           cum.data_ptr<int64_t>(), ws2.data_ptr(), I ? isect_ids.data_ptr<int64_t>() : nullptr, I ? flat.data_ptr<int32_t>() : nullptr,
+                           offs.data_ptr<int32_t>(), cur_stream()), "tile_encode");
+  }
   check(gsdf_rasterize_2dgs_fwd(1, M, I, W, H, 16, fp(means2d), fp(rt), fp(colors), fp(pt_opac), fp(normals), nullptr, nullptr, offs.data_ptr<int32_t>(),
                                 I ? flat.data_ptr<int32_t>() : nullptr, fpm(rc), fpm(rd), fpm(ra), fpm(rn), fpm(rm), last.data_ptr<int32_t>(),
                                 med.data_ptr<int32_t>(), fpm(vis), fpm(fT), cur_stream()), "rasterize_fwd");
-  Tensor renders = img(4), nw = img(3), c3 = img(3), d1 = img(1);
   const int64_t P = (int64_t)H * W;
   check(gsdf_render_post_fwd(P, 1, fp(viewmat), fp(rc), fp(rd), fp(ra), fp(rn), fpm(renders), fpm(nw), fpm(c3), fpm(d1), cur_stream()), "render_post_fwd");
-  // ---- the visible, occupancy-valid samples (one size read-back), then the SDF leg's forward on the second stream
-  Tensor w_all = torch::empty({M, 1}, fopt), ids_all = torch::empty({M}, fopt.dtype(torch::kInt64)), n_ids = torch::empty({1}, fopt.dtype(torch::kInt64));
+  // ---- the visible, occupancy-valid samples (one size), then the SDF leg's forward on the second stream
+  Tensor w_all = torch::empty({M, 1}, fopt), ids_all = torch::empty({M}, fopt.dtype(torch::kInt64));
   {
     Tensor vws = torch::empty({(int64_t)gsdf_visible_set_ws_bytes(M)}, fopt.dtype(torch::kUInt8));
     check(gsdf_visible_set(occ_level_, -1, M, fp(samples), origin_.data(), (float)map_size_inv_, occ_grid_.data_ptr(), fp(vis), fp(samples_weights),
-                           (float)cfg_.vis_thresh, fpm(w_all), ids_all.data_ptr<int64_t>(), n_ids.data_ptr<int64_t>(), vws.data_ptr(), cur_stream()),
+                           (float)cfg_.vis_thresh, fpm(w_all), ids_all.data_ptr<int64_t>(), count_ptr(2), vws.data_ptr(), cur_stream()),
           "visible_set");
   }
-  Tensor ids = ids_all.narrow(0, 0, n_ids.item<int64_t>());
+  streams_->fwd_done.record(main_stream);   // the second stream waits for the visible set, not for what follows it on this one
+  // (while the host waits for n_gs_sdf: the photometric loss, which no size depends on)
+  Tensor sums = torch::empty({2}, fopt), maps = torch::empty({3, H, W, 3}, fopt), l_normal = torch::empty({1}, fopt), l_iso = torch::empty({}, fopt);
+  check(gsdf_l1_dssim_fwd(H, W, fp(c3), fp(target), ssim_window11(), fpm(sums), fpm(maps), cur_stream()), "l1_dssim_fwd");
+  Tensor ids = ids_all.narrow(0, 0, count_wait(2));
   const bool has = ids.numel() > 0;
-  streams_->fwd_done.record(main_stream);
   streams_->fwd_done.block(streams_->side);
   Tensor samples_cut = samples.detach().requires_grad_(true);
   for (const Tensor &t : {samples_cut, w_all, ids, ray_pts, ray_sdf}) t.record_stream(streams_->side);
@@ -502,15 +527,12 @@ std::map<std::string, int64_t> JointIteration::step_direct(const Tensor &viewmat
     intr = {Kc[0][0].item<float>(), Kc[1][1].item<float>(), Kc[0][2].item<float>(), Kc[1][2].item<float>()};
     pose.assign(c2w.data_ptr<float>(), c2w.data_ptr<float>() + 12);
   }
-  Tensor sums = torch::empty({2}, fopt), maps = torch::empty({3, H, W, 3}, fopt), l_normal = torch::empty({1}, fopt), l_iso = torch::empty({}, fopt);
-  check(gsdf_l1_dssim_fwd(H, W, fp(c3), fp(target), ssim_window11(), fpm(sums), fpm(maps), cur_stream()), "l1_dssim_fwd");
   last_losses_ = {sums, l_normal, l_iso};   // (the two loss VALUES nobody's gradient needs are computed further down, where this stream waits anyway)
   Tensor v_c3 = img(3), v_d1 = img(1), v_nw = img(3);
   check(gsdf_l1_dssim_bwd(H, W, fp(c3), fp(target), ssim_window11(), fp(maps), fp(w_one_), (float)cfg_.rgb_w, (float)cfg_.dssim_w, fpm(v_c3), cur_stream()),
         "l1_dssim_bwd");
   check(gsdf_normal_consistency_bwd(H, W, intr.data(), pose.data(), fp(d1), fp(ra), fp(nw), fp(w_normal_), fpm(v_d1), fpm(v_nw), cur_stream()),
         "normal_consistency_bwd");
-  scratch_.zero_();
   Tensor v_scales_act = scratch_.narrow(0, 0, 3 * N).view({N, 3}), v_opac_dense = scratch_.narrow(0, 3 * N, N);
   check(gsdf_isotropic_loss_bwd(M, fp(scales), M ? gaussian_ids.data_ptr<int64_t>() : nullptr, fp(w_iso_), fpm(v_scales_act), cur_stream()),
         "isotropic_loss_bwd");

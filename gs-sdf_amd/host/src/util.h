@@ -1,6 +1,8 @@
 // util.h — glue between libtorch tensors and the C ABI (include/gsdf_hip.h).
 #pragma once
 #include <c10/hip/HIPStream.h>
+
+#include <chrono>
 #include <torch/torch.h>
 
 #include "gsdf_hip.h"
@@ -28,5 +30,42 @@ inline torch::Tensor zeros_like_opts(const torch::Tensor &ref, at::IntArrayRef s
   return torch::zeros(shape, ref.options().dtype(dt).requires_grad(false));
 }
 inline int64_t read_i64(const torch::Tensor &dev_scalar) { return dev_scalar.item<int64_t>(); }  // the one host sync
+
+// Counts the host waits for between two launches, without a copy kernel and a stream synchronisation (include/gsdf_hip.h:
+// gsdf_host_words_alloc): words of pinned, device-mapped host memory.  arm(i) before the launch that writes word i, pass dev(i) as the
+// operator's count output, queue whatever does not depend on the count, then wait(i).  The poll falls back to a stream synchronisation
+// after ~2 ms (a store that is only made visible by the end of the queue's work still gets read).
+class HostWords {
+ public:
+  explicit HostWords(int n) : n_(n) { check(gsdf_host_words_alloc(n, &host_, &dev_), "host_words_alloc"); }
+  ~HostWords() { (void)gsdf_host_words_free(host_); }
+  HostWords(const HostWords &) = delete;
+  HostWords &operator=(const HostWords &) = delete;
+  int64_t *dev(int i) const { return dev_ + i; }
+  void arm(int i) { __atomic_store_n(host_ + i, kArmed, __ATOMIC_RELEASE); }
+  int64_t wait(int i) const {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int64_t spins = 1;; ++spins) {
+      const int64_t v = __atomic_load_n(host_ + i, __ATOMIC_ACQUIRE);
+      if (v != kArmed) return v;
+      if ((spins & 1023) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) {
+        c10::hip::getCurrentHIPStream().synchronize();
+        const int64_t w = __atomic_load_n(host_ + i, __ATOMIC_ACQUIRE);
+        TORCH_CHECK(w != kArmed, "HostWords: the count was never written");
+        return w;
+      }
+      __builtin_ia32_pause();
+    }
+  }
+  static bool enabled() {
+    static const bool on = [] { const char *e = getenv("GSDF_HOST_COUNTS"); return !(e && e[0] == '0'); }();   // GSDF_HOST_COUNTS=0: device scalars + item()
+    return on;
+  }
+
+ private:
+  static constexpr int64_t kArmed = INT64_MIN;
+  int n_;
+  int64_t *host_ = nullptr, *dev_ = nullptr;
+};
 
 }  // namespace gsdf_host

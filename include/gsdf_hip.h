@@ -40,7 +40,7 @@ const char *gsdf_last_error(void);
 /* ABI version; bumped on any signature change.  Every binding compares gsdf_abi_version() of the library it loaded with the
  * GSDF_ABI_VERSION of the header it was written against and refuses to run on a mismatch (gs_sdf_amd/capi.py: lib(); the C++
  * operator layer: gsplat_ops.cpp static initialiser): a stale libgsdf_hip.so fails at load, not on the device. */
-#define GSDF_ABI_VERSION 3
+#define GSDF_ABI_VERSION 4
 int gsdf_abi_version(void);
 
 /* Optional per-entry-point device timing (bench.py's roofline leg, for callers in any language): between gsdf_timing_begin and
@@ -51,6 +51,15 @@ int gsdf_abi_version(void);
  * ~10 us of host time per timed call; nothing is recorded (one atomic load per call) while timing is off. */
 int gsdf_timing_begin(const char *only_csv);
 size_t gsdf_timing_end(char *buf, size_t cap);
+
+/* Host-visible count words.  The packed operators hand the HOST a size between two launches (P1: visible splats, P3: intersections, the
+ * visible set of the joint iteration): a device scalar read back with a copy + a stream synchronisation costs 30-50 us of idle queue per
+ * read on this path (profiles/r04_bench_cfg3_step_timeline.txt).  Any `int64_t *` count output of this ABI (n_visible, n_isects, n_out ...)
+ * may instead point at words of pinned, device-mapped, fine-grained host memory: the kernel's store lands in host memory, the host arms the
+ * word with a sentinel before the launch and polls it — no copy kernel, no synchronisation, and whatever the host queues after the launch
+ * runs while it waits.  gsdf_host_words_alloc returns the same words under both addresses (host view, device view); free with the host view. */
+int gsdf_host_words_alloc(int n_words, int64_t **host_view, int64_t **device_view);
+int gsdf_host_words_free(int64_t *host_view);
 
 /* ------------------------------------------------------------------------------------------
  * P1  fully_fused_projection_2dgs(means, quats, scales, viewmats, Ks, W, H, near, far,
