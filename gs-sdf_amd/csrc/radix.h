@@ -8,12 +8,16 @@ namespace gsdf {
 
 static constexpr int RADIX_MAX_BITS = 11;                               // digit widths up to 11 (2048 counters per wave in LDS)
 static constexpr int RADIX_THREADS = 256;
-static constexpr int RADIX_ITEMS = 16;                                  // elements per thread
-static constexpr int RADIX_BLOCK = RADIX_THREADS * RADIX_ITEMS;         // elements per workgroup
-
-static inline int64_t radix_blocks(int64_t n) { return (n + RADIX_BLOCK - 1) / RADIX_BLOCK; }
-// scratch of one pass: the per-(digit, block) histogram matrix + the digit totals
-static inline size_t radix_ws_bytes(int64_t n) { return align_up(((size_t)(radix_blocks(n) > 0 ? radix_blocks(n) : 1) + 1) * ((size_t)4 << RADIX_MAX_BITS), 256); }
+// elements per thread: a workgroup owns 256 x items consecutive elements (radix_items(): 16 for long inputs, fewer for the inputs of
+// the binning, where a pass is a few hundred workgroups that each walk their block in `items` serial rounds)
+static constexpr int RADIX_MIN_ITEMS = 4;
+int radix_items(int64_t n);
+static inline int64_t radix_blocks(int64_t n, int items) { return (n + (int64_t)RADIX_THREADS * items - 1) / ((int64_t)RADIX_THREADS * items); }
+// scratch of one pass: the per-(digit, block) histogram matrix + the digit totals (sized for the smallest block)
+static inline size_t radix_ws_bytes(int64_t n) {
+  const int64_t nb = radix_blocks(n, RADIX_MIN_ITEMS);
+  return align_up(((size_t)(nb > 0 ? nb : 1) + 1) * ((size_t)4 << RADIX_MAX_BITS), 256);
+}
 
 // Optional work fused into a pass (all pointers may be null):
 struct RadixHooks {

@@ -17,9 +17,11 @@
 // shows the same cliff at that shape: 6.2 ms).
 #include "radix.h"
 
+#include <stdlib.h>
+
 namespace gsdf {
 
-template <int BITS>
+template <int BITS, int ITEMS>
 __global__ void __launch_bounds__(RADIX_THREADS)
     radix_hist_kernel(int64_t n, int shift, const uint32_t *__restrict__ keys, uint32_t *__restrict__ hist, int64_t nblk) {
   constexpr int BINS = 1 << BITS;
@@ -27,9 +29,9 @@ __global__ void __launch_bounds__(RADIX_THREADS)
   const int t = threadIdx.x;
   for (int d = t; d < BINS; d += RADIX_THREADS) s_h[d] = 0u;
   __syncthreads();
-  const int64_t base = (int64_t)blockIdx.x * RADIX_BLOCK;
+  const int64_t base = (int64_t)blockIdx.x * (RADIX_THREADS * ITEMS);
 #pragma unroll 4
-  for (int r = 0; r < RADIX_ITEMS; ++r) {
+  for (int r = 0; r < ITEMS; ++r) {
     const int64_t i = base + r * RADIX_THREADS + t;
     if (i < n) atomicAdd(&s_h[(keys[i] >> shift) & (BINS - 1)], 1u);
   }
@@ -65,13 +67,13 @@ __global__ void __launch_bounds__(RADIX_THREADS) radix_scan_kernel(int64_t nblk,
   if (t == 0) totals[blockIdx.x] = carry;
 }
 
-template <int BITS>
+template <int BITS, int ITEMS>
 __global__ void __launch_bounds__(RADIX_THREADS)
     radix_scatter_kernel(int64_t n, int shift, const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
                          uint32_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out, const uint32_t *__restrict__ hist,
                          const uint32_t *__restrict__ totals, int64_t nblk, RadixHooks hk) {
   constexpr int BINS = 1 << BITS;
-  constexpr int NW = RADIX_THREADS / 64, PER_WAVE = RADIX_BLOCK / NW, ROUNDS = PER_WAVE / 64;
+  constexpr int RADIX_BLOCK = RADIX_THREADS * ITEMS, NW = RADIX_THREADS / 64, PER_WAVE = RADIX_BLOCK / NW, ROUNDS = PER_WAVE / 64;
   __shared__ uint32_t s_dig[BINS];                       // digit offset + this block's offset within the digit
   __shared__ uint32_t s_cnt[NW][BINS];                   // phase 1: counts; phase 2: running slots of the wave
   __shared__ uint32_t s_w[NW];
@@ -150,19 +152,37 @@ __global__ void __launch_bounds__(RADIX_THREADS)
   }
 }
 
-template <int BITS>
+template <int BITS, int ITEMS>
 static int radix_pass_t(int64_t n, int shift, const uint32_t *keys_in, const uint32_t *vals_in, uint32_t *keys_out, uint32_t *vals_out,
                         uint32_t *hist, const RadixHooks &hk, hipStream_t stream) {
   constexpr int BINS = 1 << BITS;
-  const int64_t nblk = radix_blocks(n);
-  radix_hist_kernel<BITS><<<(unsigned)nblk, RADIX_THREADS, 0, stream>>>(n, shift, keys_in, hist, nblk);
+  const int64_t nblk = radix_blocks(n, ITEMS);
+  radix_hist_kernel<BITS, ITEMS><<<(unsigned)nblk, RADIX_THREADS, 0, stream>>>(n, shift, keys_in, hist, nblk);
   GSDF_CHECK_LAUNCH("radix_hist_kernel");
   uint32_t *totals = hist + nblk * BINS;
   radix_scan_kernel<<<BINS, RADIX_THREADS, 0, stream>>>(nblk, hist, totals);
   GSDF_CHECK_LAUNCH("radix_scan_kernel");
-  radix_scatter_kernel<BITS><<<(unsigned)nblk, RADIX_THREADS, 0, stream>>>(n, shift, keys_in, vals_in, keys_out, vals_out, hist, totals, nblk, hk);
+  radix_scatter_kernel<BITS, ITEMS><<<(unsigned)nblk, RADIX_THREADS, 0, stream>>>(n, shift, keys_in, vals_in, keys_out, vals_out, hist, totals, nblk, hk);
   GSDF_CHECK_LAUNCH("radix_scatter_kernel");
   return GSDF_OK;
+}
+template <int BITS>
+static int radix_pass_b(int64_t n, int shift, const uint32_t *keys_in, const uint32_t *vals_in, uint32_t *keys_out, uint32_t *vals_out,
+                        uint32_t *hist, const RadixHooks &hk, hipStream_t stream) {
+  switch (radix_items(n)) {
+    case 4: return radix_pass_t<BITS, 4>(n, shift, keys_in, vals_in, keys_out, vals_out, hist, hk, stream);
+    case 8: return radix_pass_t<BITS, 8>(n, shift, keys_in, vals_in, keys_out, vals_out, hist, hk, stream);
+    default: return radix_pass_t<BITS, 16>(n, shift, keys_in, vals_in, keys_out, vals_out, hist, hk, stream);
+  }
+}
+
+// GSDF_RADIX_ITEMS = 4 | 8 | 16 pins the block size (A/B); default: by the input's length
+int radix_items(int64_t n) {
+  static const int pinned = [] { const char *e = getenv("GSDF_RADIX_ITEMS"); const int v = e ? atoi(e) : 0; return (v == 4 || v == 8 || v == 16) ? v : 0; }();
+  if (pinned) return pinned;
+  // measured on the binning (tools/exp_binning.py, whole tile_encode): 300 k splats / 0.64 M intersections 0.247 (16) 0.218 (8) 0.203 ms (4);
+  // 1 M / 2.1 M: 0.357, 0.353, 0.366; 3 M / 7.1 M: 0.845, 0.881, 0.973 (and one 6.9 ms outlier at 4)
+  return n < (1 << 19) ? 4 : n < 3 * (1 << 19) ? 8 : 16;
 }
 
 int radix_pass(int64_t n, int shift, int bits, const uint32_t *keys_in, const uint32_t *vals_in, uint32_t *keys_out, uint32_t *vals_out,
@@ -171,10 +191,10 @@ int radix_pass(int64_t n, int shift, int bits, const uint32_t *keys_in, const ui
   GSDF_REQUIRE(n < (1LL << 32), "radix: too many elements");
   const RadixHooks hk = hooks ? *hooks : RadixHooks{false, nullptr, nullptr, nullptr, nullptr, 1, 0};
   switch (bits) {
-    case 6: return radix_pass_t<6>(n, shift, keys_in, vals_in, keys_out, vals_out, hist, hk, stream);
-    case 7: return radix_pass_t<7>(n, shift, keys_in, vals_in, keys_out, vals_out, hist, hk, stream);
-    case 8: return radix_pass_t<8>(n, shift, keys_in, vals_in, keys_out, vals_out, hist, hk, stream);
-    case 11: return radix_pass_t<11>(n, shift, keys_in, vals_in, keys_out, vals_out, hist, hk, stream);
+    case 6: return radix_pass_b<6>(n, shift, keys_in, vals_in, keys_out, vals_out, hist, hk, stream);
+    case 7: return radix_pass_b<7>(n, shift, keys_in, vals_in, keys_out, vals_out, hist, hk, stream);
+    case 8: return radix_pass_b<8>(n, shift, keys_in, vals_in, keys_out, vals_out, hist, hk, stream);
+    case 11: return radix_pass_b<11>(n, shift, keys_in, vals_in, keys_out, vals_out, hist, hk, stream);
     default: set_error("radix_pass: digit width %d not instantiated", bits); return GSDF_ERR_INVALID_ARG;
   }
 }

@@ -1,4 +1,4 @@
-// scan.hip — reduce / scan-of-partials / downsweep.  2048 elements per 256-thread workgroup
+// scan.hip — reduce / downsweep (two launches: a workgroup sums the block totals before it itself).  2048 elements per 256-thread workgroup
 // (8 per lane, int4 x2 loads), wave64 prefix by DPP-free shuffles over int64 (cold path: the scans
 // here touch <= a few MB, they are launch-latency bound, not bandwidth bound).
 #include "scan.h"
@@ -47,26 +47,33 @@ __global__ void __launch_bounds__(SCAN_THREADS) scan_reduce_kernel(const int32_t
   if (threadIdx.x == 0) partials[blockIdx.x] = tot;
 }
 
-// single workgroup: partials -> exclusive prefix (in place), grand total -> *total
-__global__ void __launch_bounds__(SCAN_THREADS) scan_partials_kernel(int64_t *__restrict__ partials, int64_t nb,
-                                                                     int64_t *__restrict__ total) {
-  __shared__ int64_t lds4[4];
-  int64_t carry = 0;
-  for (int64_t base = 0; base < nb; base += SCAN_THREADS) {
-    const int64_t i = base + threadIdx.x;
-    const int64_t v = i < nb ? partials[i] : 0;
-    int64_t tot;
-    const int64_t incl = block_incl_scan_i64(v, lds4, &tot);
-    if (i < nb) partials[i] = carry + incl - v;
-    carry += tot;
-  }
-  if (threadIdx.x == 0) { *total = carry; __threadfence_system(); }   // (the total may be a host-visible word: gsdf_host_words_alloc)
+// sum of v over the workgroup (every thread gets it)
+__device__ __forceinline__ int64_t block_sum_i64(int64_t v, int64_t *lds4) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+  if ((threadIdx.x & 63) == 0) lds4[threadIdx.x >> 6] = v;
+  __syncthreads();
+  const int64_t s = lds4[0] + lds4[1] + lds4[2] + lds4[3];
+  __syncthreads();
+  return s;
 }
 
+// Second (and last) launch: a workgroup forms its own exclusive prefix from the block sums before it (a few thousand words at most:
+// cheaper than a third launch for the scan of the partials); workgroup 0 sums all of them first and publishes the grand total — the
+// host may be polling that word (gsdf_host_words_alloc).
 __global__ void __launch_bounds__(SCAN_THREADS) scan_downsweep_kernel(const int32_t *__restrict__ in, int64_t n,
-                                                                      const int64_t *__restrict__ partials,
-                                                                      int64_t *__restrict__ out) {
+                                                                      const int64_t *__restrict__ partials, int64_t nb,
+                                                                      int64_t *__restrict__ out, int64_t *__restrict__ total) {
   __shared__ int64_t lds4[4];
+  if (blockIdx.x == 0) {
+    int64_t t = 0;
+    for (int64_t i = threadIdx.x; i < nb; i += SCAN_THREADS) t += partials[i];
+    t = block_sum_i64(t, lds4);
+    if (threadIdx.x == 0) { *total = t; __threadfence_system(); }
+  }
+  int64_t before = 0;
+  for (int64_t i = threadIdx.x; i < (int64_t)blockIdx.x; i += SCAN_THREADS) before += partials[i];
+  before = block_sum_i64(before, lds4);
   const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
   int32_t x[SCAN_ITEMS];
   int64_t s = 0;
@@ -76,7 +83,7 @@ __global__ void __launch_bounds__(SCAN_THREADS) scan_downsweep_kernel(const int3
     s += x[k];
   }
   const int64_t incl = block_incl_scan_i64(s, lds4, nullptr);
-  int64_t run = partials[blockIdx.x] + incl - s;
+  int64_t run = before + incl - s;
 #pragma unroll
   for (int k = 0; k < SCAN_ITEMS; ++k) {
     run += x[k];
@@ -102,9 +109,7 @@ int scan_inclusive_i32_i64(const int32_t *in, int64_t *out, int64_t n, void *ws,
   int64_t *partials = (int64_t *)ws;
   scan_reduce_kernel<<<(unsigned)nb, SCAN_THREADS, 0, stream>>>(in, n, partials);
   GSDF_CHECK_LAUNCH("scan_reduce");
-  scan_partials_kernel<<<1, SCAN_THREADS, 0, stream>>>(partials, nb, total);
-  GSDF_CHECK_LAUNCH("scan_partials");
-  scan_downsweep_kernel<<<(unsigned)nb, SCAN_THREADS, 0, stream>>>(in, n, partials, out);
+  scan_downsweep_kernel<<<(unsigned)nb, SCAN_THREADS, 0, stream>>>(in, n, partials, nb, out, total);
   GSDF_CHECK_LAUNCH("scan_downsweep");
   return GSDF_OK;
 }
