@@ -50,12 +50,12 @@ struct Projection2DGS : public torch::autograd::Function<Projection2DGS> {
     const int64_t N = means.size(0), C = viewmats.size(0);
     Tensor radii_dense = empty_like_opts(means, {std::max<int64_t>(N * C, 1)}, torch::kInt32);
     Tensor ws = empty_like_opts(means, {(int64_t)gsdf_projection_2dgs_ws_bytes(N, C)}, torch::kUInt8);
-    Tensor n_vis = empty_like_opts(means, {1}, torch::kInt64);
-    check(gsdf_projection_2dgs_cull(N, C, fp(means), fp(quats), fp(scales), fp(viewmats), fp(Ks), (int)width, (int)height,
-                                    (float)near_plane, (float)far_plane, (float)radius_clip, radii_dense.data_ptr<int32_t>(),
-                                    ws.data_ptr(), n_vis.data_ptr<int64_t>(), cur_stream()),
-          "fully_fused_projection_2dgs(cull)");
-    const int64_t M = read_i64(n_vis);
+    const int64_t M = gsdf_host::count_via_host_word(means, [&](int64_t *n_vis) {
+      check(gsdf_projection_2dgs_cull(N, C, fp(means), fp(quats), fp(scales), fp(viewmats), fp(Ks), (int)width, (int)height,
+                                      (float)near_plane, (float)far_plane, (float)radius_clip, radii_dense.data_ptr<int32_t>(),
+                                      ws.data_ptr(), n_vis, cur_stream()),
+            "fully_fused_projection_2dgs(cull)");
+    });
     Tensor camera_ids = empty_like_opts(means, {M}, torch::kInt64), gaussian_ids = empty_like_opts(means, {M}, torch::kInt64);
     Tensor radii = empty_like_opts(means, {M}, torch::kInt32), means2d = empty_like_opts(means, {M, 2}, torch::kFloat32);
     Tensor depths = empty_like_opts(means, {M}, torch::kFloat32), rt = empty_like_opts(means, {M, 3, 3}, torch::kFloat32);
@@ -228,11 +228,10 @@ std::tuple<Tensor, Tensor, Tensor> gsplat_cpp::tile_encode(int width, int height
   const int tw = (width + tile_size - 1) / tile_size, th = (height + tile_size - 1) / tile_size;
   Tensor tpg = empty_like_opts(means2d, {M}, torch::kInt32), cum = empty_like_opts(means2d, {std::max<int64_t>(M, 1)}, torch::kInt64);
   Tensor ws = empty_like_opts(means2d, {(int64_t)gsdf_tile_count_ws_bytes(M)}, torch::kUInt8);
-  Tensor n_is = empty_like_opts(means2d, {1}, torch::kInt64);
-  check(gsdf_tile_count(M, width, height, tile_size, fp(means2d), M ? radii.data_ptr<int32_t>() : nullptr,
-                        M ? tpg.data_ptr<int32_t>() : nullptr, cum.data_ptr<int64_t>(), ws.data_ptr(), n_is.data_ptr<int64_t>(),
-                        cur_stream()), "tile_encode(count)");
-  const int64_t I = read_i64(n_is);
+  const int64_t I = gsdf_host::count_via_host_word(means2d, [&](int64_t *n_is) {
+    check(gsdf_tile_count(M, width, height, tile_size, fp(means2d), M ? radii.data_ptr<int32_t>() : nullptr,
+                          M ? tpg.data_ptr<int32_t>() : nullptr, cum.data_ptr<int64_t>(), ws.data_ptr(), n_is, cur_stream()), "tile_encode(count)");
+  });
   Tensor ids = empty_like_opts(means2d, {I}, torch::kInt64), flat = empty_like_opts(means2d, {I}, torch::kInt32);
   Tensor offs = empty_like_opts(means2d, {C, th, tw}, torch::kInt32);
   Tensor ws2 = empty_like_opts(means2d, {(int64_t)gsdf_tile_encode_ws_bytes(M, I)}, torch::kUInt8);

@@ -68,4 +68,19 @@ class HostWords {
   int64_t *host_ = nullptr, *dev_ = nullptr;
 };
 
+// One count through the calling thread's own word (the operator-level functions: cull -> M -> fill, count -> I -> encode): `launch` receives
+// the pointer to pass as the operator's count output and returns after queueing it.
+template <class F>
+inline int64_t count_via_host_word(const torch::Tensor &like, F &&launch) {
+  if (!HostWords::enabled()) {
+    torch::Tensor n = torch::empty({1}, like.options().dtype(torch::kInt64).requires_grad(false));
+    launch(n.data_ptr<int64_t>());
+    return read_i64(n);
+  }
+  static thread_local HostWords *words = new HostWords(1);   // (never freed: a thread's exit may come after the HIP runtime's)
+  words->arm(0);
+  launch(words->dev(0));
+  return words->wait(0);
+}
+
 }  // namespace gsdf_host
