@@ -126,6 +126,58 @@ def lib():
     return _lib
 
 
+class HostWords:
+    """Counts the host waits for between two launches without a copy kernel and a stream synchronisation (include/gsdf_hip.h:
+    gsdf_host_words_alloc; the C++ operator layer's host/src/util.h: HostWords): arm(i), pass dev(i) as the operator's count output, wait(i)."""
+    ARMED = -(1 << 63)
+
+    def __init__(self, n=1):
+        h, d = C.POINTER(C.c_int64)(), C.POINTER(C.c_int64)()
+        check(lib().gsdf_host_words_alloc(n, C.byref(h), C.byref(d)), "host_words_alloc")
+        self._host, self._dev, self.n = h, C.cast(d, C.c_void_p).value, n
+
+    def dev(self, i=0):
+        return C.c_void_p(self._dev + 8 * i)
+
+    def arm(self, i=0):
+        self._host[i] = self.ARMED
+
+    def wait(self, i=0):
+        h = self._host
+        for _ in range(20000):          # ~2 ms of polling, then the queue is drained the ordinary way
+            v = h[i]
+            if v != self.ARMED:
+                return v
+        torch.cuda.current_stream().synchronize()
+        v = h[i]
+        if v == self.ARMED:
+            raise RuntimeError("HostWords: the count was never written")
+        return v
+
+    def __del__(self):
+        try:
+            lib().gsdf_host_words_free(self._host)
+        except Exception:
+            pass
+
+
+_words = None
+
+
+def count_via_host_word(launch, device):
+    """Runs launch(count_pointer) and returns the count it wrote: through a host-visible word (GSDF_HOST_COUNTS=0: a device scalar + item())."""
+    global _words
+    if os.environ.get("GSDF_HOST_COUNTS", "1") == "0":
+        n = torch.empty(1, dtype=torch.int64, device=device)
+        launch(C.c_void_p(n.data_ptr()))
+        return int(n.item())
+    if _words is None:
+        _words = HostWords(1)
+    _words.arm(0)
+    launch(_words.dev(0))
+    return int(_words.wait(0))
+
+
 def timing_begin(only=None):
     """Per-entry-point device timing of the C ABI (include/gsdf_hip.h: gsdf_timing_begin), whoever calls it (Python mirror or the C++
     operator layer): `only` = iterable of entry-point names or None for all."""

@@ -65,11 +65,6 @@ def _empty(shape, dtype, like):
     return torch.empty(shape, dtype=dtype, device=like.device)
 
 
-def _read_i64(dev_scalar):
-    # the one host sync per dynamic size, as in the reference (packed nnz / n_isects)
-    return int(dev_scalar.item())
-
-
 # ------------------------------------------------------------------------------------------------
 # P1  fully_fused_projection_2dgs  (neural_gaussian.cpp:188-192)
 # ------------------------------------------------------------------------------------------------
@@ -84,12 +79,10 @@ class _Projection2DGS(torch.autograd.Function):
         dev = means.device
         radii_dense = torch.empty(max(N * C, 1), dtype=torch.int32, device=dev)
         ws = torch.empty(L.gsdf_projection_2dgs_ws_bytes(N, C), dtype=torch.uint8, device=dev)
-        n_vis = torch.empty(1, dtype=torch.int64, device=dev)
-        capi.check(_timed("projection_2dgs_cull", L.gsdf_projection_2dgs_cull, N, C, f32(means, "means"), f32(quats, "quats"), f32(scales, "scales"),
-                                               f32(viewmats, "viewmats"), f32(Ks, "Ks"), width, height, near_plane,
-                                               far_plane, radius_clip, ptr(radii_dense), ptr(ws), ptr(n_vis),
-                                               capi.stream()), "projection_2dgs_cull")
-        M = _read_i64(n_vis)
+        M = capi.count_via_host_word(lambda n_vis: capi.check(
+            _timed("projection_2dgs_cull", L.gsdf_projection_2dgs_cull, N, C, f32(means, "means"), f32(quats, "quats"), f32(scales, "scales"),
+                   f32(viewmats, "viewmats"), f32(Ks, "Ks"), width, height, near_plane, far_plane, radius_clip, ptr(radii_dense), ptr(ws), n_vis,
+                   capi.stream()), "projection_2dgs_cull"), dev)
         camera_ids = _empty((M,), torch.int64, means); gaussian_ids = _empty((M,), torch.int64, means)
         radii = _empty((M,), torch.int32, means); means2d = _empty((M, 2), torch.float32, means)
         depths = _empty((M,), torch.float32, means); rt = _empty((M, 3, 3), torch.float32, means)
@@ -196,10 +189,9 @@ def tile_encode(width, height, tile_size, means2d, radii, depths, packed, C, cam
     tw, th = (width + tile_size - 1) // tile_size, (height + tile_size - 1) // tile_size
     tpg = _empty((M,), torch.int32, means2d); cum = _empty((max(M, 1),), torch.int64, means2d)
     ws = torch.empty(L.gsdf_tile_count_ws_bytes(M), dtype=torch.uint8, device=dev)
-    n_is = torch.empty(1, dtype=torch.int64, device=dev)
-    capi.check(_timed("tile_count", L.gsdf_tile_count, M, width, height, tile_size, f32(means2d), ptr(radii, torch.int32), ptr(tpg), ptr(cum),
-                                 ptr(ws), ptr(n_is), capi.stream()), "tile_count")
-    I = _read_i64(n_is)
+    I = capi.count_via_host_word(lambda n_is: capi.check(
+        _timed("tile_count", L.gsdf_tile_count, M, width, height, tile_size, f32(means2d), ptr(radii, torch.int32), ptr(tpg), ptr(cum), ptr(ws), n_is,
+               capi.stream()), "tile_count"), dev)
     isect_ids = _empty((I,), torch.int64, means2d); flatten_ids = _empty((I,), torch.int32, means2d)
     offsets = _empty((C, th, tw), torch.int32, means2d)
     ws2 = torch.empty(L.gsdf_tile_encode_ws_bytes(M, I), dtype=torch.uint8, device=dev)
