@@ -12,6 +12,7 @@ B="python $REPO/bench.py --no-cpu-baseline --no-secondary"
 rm -rf /tmp/p1 && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p1 -- $B --steps 20 --warmup 5 > $OUT/${TAG}_bench_cfg3_under_rocprof.json 2> $OUT/stats.log
 python $REPO/tools/summarize_rocprof.py /tmp/p1 $OUT/${TAG}_bench_cfg3_kernel_stats.csv > /dev/null
 python $REPO/tools/trace_timeline.py /tmp/p1 $OUT/${TAG}_bench_cfg3_step_timeline.txt > /dev/null
+[ "${2:-}" = quick ] && { ls -la $OUT; exit 0; }   # quick: the overlapped stats + timeline only
 # 2) the same work on ONE stream (kernel durations without neighbours)
 rm -rf /tmp/p2 && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p2 -- $B --steps 20 --warmup 5 --no-overlap > $OUT/${TAG}_bench_cfg3_serial_under_rocprof.json 2>> $OUT/stats.log
 python $REPO/tools/summarize_rocprof.py /tmp/p2 $OUT/${TAG}_bench_cfg3_serial_kernel_stats.csv > /dev/null
