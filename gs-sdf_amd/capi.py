@@ -15,7 +15,7 @@ _lib = None
 
 _i64, _i32, _f32, _u64, _vp, _sz = C.c_int64, C.c_int, C.c_float, C.c_uint64, C.c_void_p, C.c_size_t
 
-ABI_VERSION = 4      # include/gsdf_hip.h: GSDF_ABI_VERSION this binding was written against
+ABI_VERSION = 5      # include/gsdf_hip.h: GSDF_ABI_VERSION this binding was written against
 
 
 class RasterInstr(C.Structure):
@@ -74,6 +74,7 @@ _SIGS = {
     "gsdf_l1_dssim_bwd": (C.c_int, [_i32, _i32] + [_vp] * 5 + [_f32, _f32, _vp, _vp]),
     "gsdf_normal_consistency_fwd": (C.c_int, [_i32, _i32] + [_vp] * 7),
     "gsdf_normal_consistency_bwd": (C.c_int, [_i32, _i32] + [_vp] * 9),
+    "gsdf_normal_consistency_fwd_bwd": (C.c_int, [_i32, _i32] + [_vp] * 10),
     "gsdf_sdf_query_points": (C.c_int, [_i64, _i32, _vp, _f32, _vp, _f32, _vp, _vp]),
     "gsdf_sdf_query_points2": (C.c_int, [_i64, _vp, _i64, _vp, _vp, _i32, _f32, _vp, _f32, _vp, _vp]),
     "gsdf_gs_sdf_loss": (C.c_int, [_i64, _vp, _i32, _vp, _vp, _f32, _vp, _vp, _vp]),
@@ -95,6 +96,7 @@ _SIGS = {
     "gsdf_splat_activations_bwd": (C.c_int, [_i64] + [_vp] * 9),
     "gsdf_isotropic_loss_fwd": (C.c_int, [_i64, _vp, _vp, _vp, _vp]),
     "gsdf_isotropic_loss_bwd": (C.c_int, [_i64, _vp, _vp, _vp, _vp, _vp]),
+    "gsdf_isotropic_loss_fwd_bwd": (C.c_int, [_i64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gsdf_nan_rows": (C.c_int, [_i64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gsdf_densify_stats": (C.c_int, [_i64, _i64, _i32, _i32, _i32] + [_vp] * 9),
     "gsdf_flat_rows_gather": (C.c_int, [_i32, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp]),

@@ -71,6 +71,30 @@ __global__ void __launch_bounds__(256)
   if (v != 0.f) { atomicAdd(v_scales + 3 * g, v); atomicAdd(v_scales + 3 * g + 1, -v); }   // ids repeat when C > 1
 }
 
+// value and gradient in one launch (the joint step: no separate launch, no memset for a number only the log reads); `loss` ACCUMULATES
+__global__ void __launch_bounds__(256)
+    isotropic_fwd_bwd_kernel(int64_t M, const float *__restrict__ scales, const int64_t *__restrict__ ids, float inv_2m,
+                             const float *__restrict__ v_loss, float *__restrict__ loss, float *__restrict__ v_scales) {
+  __shared__ float s_part[4];
+  float c = 0.f;
+  const float vl = v_loss[0];
+  for (int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x; m < M; m += (int64_t)gridDim.x * 256) {
+    const int64_t g = ids[m];
+    const float d = scales[3 * g] - scales[3 * g + 1];
+    c += fabsf(d) * inv_2m;
+    const float s = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+    const float v = s * inv_2m * vl;
+    if (v != 0.f) { atomicAdd(v_scales + 3 * g, v); atomicAdd(v_scales + 3 * g + 1, -v); }
+  }
+  const float ws = wave_sum_to_lane63(c);
+  if ((threadIdx.x & 63) == 63) s_part[threadIdx.x >> 6] = ws;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float t = (s_part[0] + s_part[1]) + (s_part[2] + s_part[3]);
+    if (t != 0.f) atomicAdd(loss, t);
+  }
+}
+
 // ---- NeuralGS::prune_nan_gs's test (neural_gaussian.cpp:907-916): rows with a NaN in offsets / scaling / quaternion
 __global__ void __launch_bounds__(256)
     nan_rows_kernel(int64_t n, const float *__restrict__ offsets, const float *__restrict__ scaling,
@@ -141,6 +165,18 @@ extern "C" int gsdf_isotropic_loss_bwd(int64_t M, const float *scales, const int
   GSDF_REQUIRE(M > 0 && scales && gaussian_ids && v_loss && v_scales, "isotropic_loss_bwd: bad arguments");
   isotropic_bwd_kernel<<<(unsigned)((M + 255) / 256), 256, 0, stream>>>(M, scales, gaussian_ids, 0.5f / (float)M, v_loss, v_scales);
   GSDF_CHECK_LAUNCH("isotropic_bwd_kernel");
+  return GSDF_OK;
+}
+
+extern "C" int gsdf_isotropic_loss_fwd_bwd(int64_t M, const float *scales, const int64_t *gaussian_ids, const float *v_loss, float *loss,
+                                           float *v_scales, gsdf_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  GSDF_TIMED("gsdf_isotropic_loss_fwd_bwd");
+  if (M == 0) return GSDF_OK;
+  GSDF_REQUIRE(M > 0 && scales && gaussian_ids && v_loss && loss && v_scales, "isotropic_loss_fwd_bwd: bad arguments");
+  const int64_t blocks = (M + 255) / 256;
+  isotropic_fwd_bwd_kernel<<<(unsigned)(blocks > 1024 ? 1024 : blocks), 256, 0, stream>>>(M, scales, gaussian_ids, 0.5f / (float)M, v_loss, loss, v_scales);
+  GSDF_CHECK_LAUNCH("isotropic_fwd_bwd_kernel");
   return GSDF_OK;
 }
 

@@ -137,10 +137,23 @@ __global__ void __launch_bounds__(256)
       }
       float *vr = v_rnormal + ((int64_t)gy * W + gx) * 3;
       vr[0] = o[0]; vr[1] = o[1]; vr[2] = o[2];
+      if (sum != nullptr) {   // the value next to the gradient (gsdf_normal_consistency_fwd_bwd): the forward's term of this pixel
+        const float a = alpha[(int64_t)gy * W + gx];
+        float dot = 0.f;
+        if (gx >= 1 && gx < W - 1 && gy >= 1 && gy < H - 1) {
+          NlN nn;
+          nl_normal(P[yy + 1][xx + 2], P[yy + 3][xx + 2], P[yy + 2][xx + 1], P[yy + 2][xx + 3], nn);
+          const float *rn = rnormal + ((int64_t)gy * W + gx) * 3;
+          dot = a * (nn.n[0] * rn[0] + nn.n[1] * rn[1] + nn.n[2] * rn[2]);
+          if (dot != dot) dot = 0.f;
+          else dot = fminf(fmaxf(dot, -3.4028234663852886e38f), 3.4028234663852886e38f);
+        }
+        wg_term += a * a - dot;
+      }
     }
   }
   }   // tile loop
-  if (!BWD) {
+  if (!BWD || sum != nullptr) {
     for (int s = 32; s >= 1; s >>= 1) wg_term += __shfl_xor(wg_term, s, 64);
     if ((tid & 63) == 0) red[tid >> 6] = wg_term;
     __syncthreads();
@@ -171,6 +184,25 @@ extern "C" int gsdf_normal_consistency_fwd(int height, int width, const float *i
   const int n_tiles = ((width + NL_T - 1) / NL_T) * ((height + NL_T - 1) / NL_T);
   normal_loss_kernel<false><<<n_tiles < 1024 ? n_tiles : 1024, 256, 0, stream>>>(height, width, cam, depth, alpha, render_normal, loss, nullptr, nullptr, nullptr);
   GSDF_CHECK_LAUNCH("normal_loss_kernel<fwd>");
+  return GSDF_OK;
+}
+
+// value and gradients in one launch; `loss` ACCUMULATES (the caller zeroes it, e.g. with the buffer it lives in)
+extern "C" int gsdf_normal_consistency_fwd_bwd(int height, int width, const float *intrinsics4_host, const float *pose_c2w_host,
+                                               const float *depth, const float *alpha, const float *render_normal, const float *v_loss,
+                                               float *loss, float *v_depth, float *v_render_normal, gsdf_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  GSDF_TIMED("gsdf_normal_consistency_fwd_bwd");
+  GSDF_REQUIRE(height > 2 && width > 2, "normal_consistency_fwd_bwd: image must be at least 3x3");
+  GSDF_REQUIRE(intrinsics4_host && pose_c2w_host && depth && alpha && render_normal && v_loss && loss && v_depth && v_render_normal,
+               "normal_consistency_fwd_bwd: null buffer");
+  NlCam cam;
+  nl_cam(intrinsics4_host, pose_c2w_host, &cam);
+  const int n_tiles = ((width + NL_T - 1) / NL_T) * ((height + NL_T - 1) / NL_T);
+  // capped grid: the value is one address (one atomic per workgroup)
+  normal_loss_kernel<true><<<n_tiles < 2048 ? n_tiles : 2048, 256, 0, stream>>>(height, width, cam, depth, alpha, render_normal, loss, v_loss, v_depth,
+                                                                               v_render_normal);
+  GSDF_CHECK_LAUNCH("normal_loss_kernel<fwd+bwd>");
   return GSDF_OK;
 }
 

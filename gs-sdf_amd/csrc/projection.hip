@@ -153,7 +153,7 @@ __global__ void __launch_bounds__(PT)
     vH2[j] = cx * vMu[j] + cy * vMv[j] + vMw[j];
   }
   const float *c9 = p.Rc;
-  const float v_mc[3] = {vH0[2], vH1[2], vH2[2] + v_depths[m]};
+  const float v_mc[3] = {vH0[2], vH1[2], vH2[2] + (v_depths != nullptr ? v_depths[m] : 0.f)};
   float v_su = vH0[0] * c9[0] + vH1[0] * c9[3] + vH2[0] * c9[6];
   float v_sv = vH0[1] * c9[1] + vH1[1] * c9[4] + vH2[1] * c9[7];
   float vRc[9];
@@ -262,7 +262,7 @@ extern "C" int gsdf_projection_2dgs_bwd(int64_t N, int64_t C, int64_t M, const f
   hipStream_t stream = (hipStream_t)stream_;
   GSDF_TIMED("gsdf_projection_2dgs_bwd");
   if (M == 0) return GSDF_OK;
-  GSDF_REQUIRE(v_means2d && v_depths && v_ray_transforms && v_normals && v_means && v_quats && v_scales,
+  GSDF_REQUIRE(v_means2d && v_ray_transforms && v_normals && v_means && v_quats && v_scales,
                "projection_bwd: null gradient buffer");
   (void)N;
   const unsigned nb = (unsigned)((M + PT - 1) / PT);

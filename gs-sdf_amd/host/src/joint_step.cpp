@@ -448,8 +448,10 @@ std::map<std::string, int64_t> JointIteration::step_direct(const Tensor &viewmat
   auto count_wait = [&](int i) { return cw ? cw->wait(i) : read_i64(dev_counts[i]); };
   check(gsdf_projection_2dgs_cull(N, 1, fp(xyz), fp(quats), fp(scales), fp(viewmat), fp(K), W, H, cfg_.near_plane, cfg_.far_plane, 0.f,
                                   radii_dense.data_ptr<int32_t>(), pws.data_ptr(), count_ptr(0), cur_stream()), "projection(cull)");
-  // (while the host waits for M: the zero fill of the backward's scratch, the images' allocations)
+  // (while the host waits for M: the zero fill of the backward's scratch and of the two loss values the backward kernels accumulate, the
+  // images' allocations)
   scratch_.zero_();
+  Tensor loss_values = torch::zeros({2}, fopt);
   auto img = [&](int64_t ch) { return torch::empty({1, H, W, ch}, fopt); };
   Tensor rc = img(3), rd = img(1), ra = img(1), rn = img(3), rm = img(1), fT = torch::empty({1, H, W}, fopt);
   Tensor last = torch::empty({1, H, W}, fopt.dtype(torch::kInt32)), med = torch::empty({1, H, W}, fopt.dtype(torch::kInt32));
@@ -502,7 +504,7 @@ std::map<std::string, int64_t> JointIteration::step_direct(const Tensor &viewmat
   }
   streams_->fwd_done.record(main_stream);   // the second stream waits for the visible set, not for what follows it on this one
   // (while the host waits for n_gs_sdf: the photometric loss, which no size depends on)
-  Tensor sums = torch::empty({2}, fopt), maps = torch::empty({3, H, W, 3}, fopt), l_normal = torch::empty({1}, fopt), l_iso = torch::empty({}, fopt);
+  Tensor sums = torch::empty({2}, fopt), maps = torch::empty({3, H, W, 3}, fopt), l_normal = loss_values.narrow(0, 0, 1), l_iso = loss_values[1];
   check(gsdf_l1_dssim_fwd(H, W, fp(c3), fp(target), ssim_window11(), fpm(sums), fpm(maps), cur_stream()), "l1_dssim_fwd");
   Tensor ids = ids_all.narrow(0, 0, count_wait(2));
   const bool has = ids.numel() > 0;
@@ -527,15 +529,24 @@ std::map<std::string, int64_t> JointIteration::step_direct(const Tensor &viewmat
     intr = {Kc[0][0].item<float>(), Kc[1][1].item<float>(), Kc[0][2].item<float>(), Kc[1][2].item<float>()};
     pose.assign(c2w.data_ptr<float>(), c2w.data_ptr<float>() + 12);
   }
-  last_losses_ = {sums, l_normal, l_iso};   // (the two loss VALUES nobody's gradient needs are computed further down, where this stream waits anyway)
+  last_losses_ = {sums, l_normal, l_iso};   // (the normal-consistency and isotropic VALUES are accumulated by their gradient kernels: no launch of their own)
   Tensor v_c3 = img(3), v_d1 = img(1), v_nw = img(3);
   check(gsdf_l1_dssim_bwd(H, W, fp(c3), fp(target), ssim_window11(), fp(maps), fp(w_one_), (float)cfg_.rgb_w, (float)cfg_.dssim_w, fpm(v_c3), cur_stream()),
         "l1_dssim_bwd");
-  check(gsdf_normal_consistency_bwd(H, W, intr.data(), pose.data(), fp(d1), fp(ra), fp(nw), fp(w_normal_), fpm(v_d1), fpm(v_nw), cur_stream()),
-        "normal_consistency_bwd");
+  static const bool fused_values = [] { const char *e = getenv("GSDF_JOINT_FUSED_LOSS_VALUES"); return !(e && e[0] == '0'); }();   // 0: separate launches (A/B)
+  if (fused_values)
+    check(gsdf_normal_consistency_fwd_bwd(H, W, intr.data(), pose.data(), fp(d1), fp(ra), fp(nw), fp(w_normal_), fpm(l_normal), fpm(v_d1), fpm(v_nw),
+                                          cur_stream()), "normal_consistency_fwd_bwd");
+  else
+    check(gsdf_normal_consistency_bwd(H, W, intr.data(), pose.data(), fp(d1), fp(ra), fp(nw), fp(w_normal_), fpm(v_d1), fpm(v_nw), cur_stream()),
+          "normal_consistency_bwd");
   Tensor v_scales_act = scratch_.narrow(0, 0, 3 * N).view({N, 3}), v_opac_dense = scratch_.narrow(0, 3 * N, N);
-  check(gsdf_isotropic_loss_bwd(M, fp(scales), M ? gaussian_ids.data_ptr<int64_t>() : nullptr, fp(w_iso_), fpm(v_scales_act), cur_stream()),
-        "isotropic_loss_bwd");
+  if (fused_values)
+    check(gsdf_isotropic_loss_fwd_bwd(M, fp(scales), M ? gaussian_ids.data_ptr<int64_t>() : nullptr, fp(w_iso_), fpm(l_iso), fpm(v_scales_act), cur_stream()),
+          "isotropic_loss_fwd_bwd");
+  else
+    check(gsdf_isotropic_loss_bwd(M, fp(scales), M ? gaussian_ids.data_ptr<int64_t>() : nullptr, fp(w_iso_), fpm(v_scales_act), cur_stream()),
+          "isotropic_loss_bwd");
   // ---- backward through the epilogue, the compositing, the colours and the projection
   Tensor v_rc = img(3), v_rd = img(1), v_ra = img(1), v_rn = img(3);
   check(gsdf_render_post_bwd(P, 1, fp(viewmat), fp(rd), fp(ra), nullptr, fp(v_nw), fp(v_c3), fp(v_d1), fpm(v_rc), fpm(v_rd), fpm(v_ra), fpm(v_rn), cur_stream()),
@@ -561,12 +572,11 @@ std::map<std::string, int64_t> JointIteration::step_direct(const Tensor &viewmat
   Tensor g_off = seg(0), g_sc = seg(1), g_q = seg(2), g_op = seg(3);
   check(gsdf_view_colors_bwd(M, Ksh, cfg_.sh_degree, fp(viewmat), fp(xyz), fp(sh), M ? camera_ids.data_ptr<int64_t>() : nullptr,
                              M ? gaussian_ids.data_ptr<int64_t>() : nullptr, fp(v_colors), v_sh_ptr, fpm(g_off), 1, cur_stream()), "view_colors_bwd");
-  Tensor v_depths = torch::zeros({M}, fopt);
   // the projection's backward (and the activations' behind it): centre mode right away — the samples' gradient is a row scatter into the
   // offsets' gradient later; stochastic mode once that gradient has arrived (the samples are an output of the projection)
   auto projection_and_activations_bwd = [&](const Tensor &v_samples) {
     check(gsdf_projection_2dgs_bwd(N, 1, M, fp(xyz), fp(quats), fp(scales), fp(viewmat), fp(K), W, H, seed, M ? camera_ids.data_ptr<int64_t>() : nullptr,
-                                   M ? gaussian_ids.data_ptr<int64_t>() : nullptr, fp(v_means2d), fp(v_depths), fp(v_rt), fp(v_normals), fp(v_samples),
+                                   M ? gaussian_ids.data_ptr<int64_t>() : nullptr, fp(v_means2d), nullptr /* v_depths = 0 */, fp(v_rt), fp(v_normals), fp(v_samples),
                                    fpm(g_off), fpm(g_q), fpm(v_scales_act), cur_stream()), "projection_bwd");
     check(gsdf_splat_activations_bwd(N, fp(scales), fp(opac), nullptr /* xyz: accumulated in place */, fp(v_scales_act), fp(v_opac_dense), fpm(g_off),
                                      fpm(g_sc), fpm(g_op), cur_stream()), "splat_activations_bwd");
@@ -577,10 +587,10 @@ std::map<std::string, int64_t> JointIteration::step_direct(const Tensor &viewmat
     seg(4).view({N, 1, 3}).add_(v_sh_tmp.narrow(1, 0, 1));
     seg(5).view({N, n_rest_, 3}).add_(v_sh_tmp.narrow(1, 1, n_rest_));
   }
-  // the values of the normal-consistency and isotropic losses (their backward kernels above recompute what they need): issued here, where
-  // this stream is about to wait for the SDF leg's samples' gradient
-  check(gsdf_normal_consistency_fwd(H, W, intr.data(), pose.data(), fp(d1), fp(ra), fp(nw), fpm(l_normal), cur_stream()), "normal_consistency_fwd");
-  check(gsdf_isotropic_loss_fwd(M, fp(scales), M ? gaussian_ids.data_ptr<int64_t>() : nullptr, fpm(l_iso), cur_stream()), "isotropic_loss_fwd");
+  if (!fused_values) {   // the two values in launches of their own, where this stream is about to wait for the samples' gradient
+    check(gsdf_normal_consistency_fwd(H, W, intr.data(), pose.data(), fp(d1), fp(ra), fp(nw), fpm(l_normal), cur_stream()), "normal_consistency_fwd");
+    check(gsdf_isotropic_loss_fwd(M, fp(scales), M ? gaussian_ids.data_ptr<int64_t>() : nullptr, fpm(l_iso), cur_stream()), "isotropic_loss_fwd");
+  }
   // ---- the SDF leg's backward on the second stream, then its d loss / d samples on this one
   {
     StreamGuard sg(streams_->side);

@@ -40,7 +40,7 @@ const char *gsdf_last_error(void);
 /* ABI version; bumped on any signature change.  Every binding compares gsdf_abi_version() of the library it loaded with the
  * GSDF_ABI_VERSION of the header it was written against and refuses to run on a mismatch (gs_sdf_amd/capi.py: lib(); the C++
  * operator layer: gsplat_ops.cpp static initialiser): a stale libgsdf_hip.so fails at load, not on the device. */
-#define GSDF_ABI_VERSION 4
+#define GSDF_ABI_VERSION 5
 int gsdf_abi_version(void);
 
 /* Optional per-entry-point device timing (bench.py's roofline leg, for callers in any language): between gsdf_timing_begin and
@@ -88,7 +88,7 @@ int gsdf_projection_2dgs_fill(int64_t n_gauss, int64_t n_cams, const float *mean
                               float *means2d, float *depths, float *ray_transforms, float *normals,
                               float *samples, float *samples_weights, gsdf_stream_t stream);
 
-/* VJP (implicit via autograd in the reference).  v_samples may be NULL.  Dense outputs
+/* VJP (implicit via autograd in the reference).  v_samples and v_depths may be NULL (= zero).  Dense outputs
  * v_means [N,3], v_quats [N,4], v_scales [N,3]: ACCUMULATE (zero them first). */
 int gsdf_projection_2dgs_bwd(int64_t n_gauss, int64_t n_cams, int64_t n_visible, const float *means,
                              const float *quats, const float *scales, const float *viewmats, const float *Ks,
@@ -489,6 +489,10 @@ int gsdf_splat_activations_bwd(int64_t n, const float *scales, const float *opac
 int gsdf_isotropic_loss_fwd(int64_t n_visible, const float *scales, const int64_t *gaussian_ids, float *loss, gsdf_stream_t stream);
 int gsdf_isotropic_loss_bwd(int64_t n_visible, const float *scales, const int64_t *gaussian_ids, const float *v_loss, float *v_scales,
                             gsdf_stream_t stream);
+/* value and gradient in ONE launch (the joint iteration's step: the value is a number only the log reads — no launch and no memset of its
+ * own): `loss` [1] ACCUMULATES (the caller zeroes it, e.g. together with the buffer it lives in), v_scales as in _bwd. */
+int gsdf_isotropic_loss_fwd_bwd(int64_t n_visible, const float *scales, const int64_t *gaussian_ids, const float *v_loss, float *loss,
+                                float *v_scales, gsdf_stream_t stream);
 /* NeuralGS::prune_nan_gs's per-iteration test (include/neural_gaussian/neural_gaussian.cpp:907-916): count[0] = number of splats
  * with a NaN in offsets [n,3] / scaling [n,3] / quaternion [n,4]; mask u8 [n] (optional) marks them. */
 int gsdf_nan_rows(int64_t n, const float *offsets, const float *scaling, const float *quaternion, int32_t *count, uint8_t *mask,
@@ -548,6 +552,10 @@ int gsdf_normal_consistency_fwd(int height, int width, const float *intrinsics4_
 int gsdf_normal_consistency_bwd(int height, int width, const float *intrinsics4_host, const float *pose_c2w_host,
                                 const float *depth, const float *alpha, const float *render_normal, const float *v_loss,
                                 float *v_depth, float *v_render_normal, gsdf_stream_t stream);
+/* value and gradients in ONE launch: `loss` [1] ACCUMULATES (the caller zeroes it); v_depth / v_render_normal as in _bwd. */
+int gsdf_normal_consistency_fwd_bwd(int height, int width, const float *intrinsics4_host, const float *pose_c2w_host,
+                                    const float *depth, const float *alpha, const float *render_normal, const float *v_loss,
+                                    float *loss, float *v_depth, float *v_render_normal, gsdf_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -396,3 +396,41 @@ def test_binning_long_tile_lists_bit_exact(ops, oracle, N, W, H):
     assert counts.max() > 4096 and len(np.unique(n(dep))) < n(dep).shape[0] // 4
     assert_equal_int(tpg, tpg_r, "tiles_per_gauss"); assert_equal_int(offs, offs_r, "isect_offsets")
     assert_equal_int(ids, ids_r, "isect_ids"); assert_equal_int(flat, flat_r, "flatten_ids")
+
+
+def test_value_and_gradient_in_one_launch_match_the_separate_launches(ops):
+    """gsdf_normal_consistency_fwd_bwd / gsdf_isotropic_loss_fwd_bwd (the joint step's forms: the value ACCUMULATES into a word the caller
+    zeroed, gradients as the _bwd entry points) against the separate _fwd / _bwd launches; projection backward with v_depths = NULL."""
+    import gs_sdf_amd.capi as capi
+    L = capi.lib()
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(5)
+    H, W = 139, 211
+    yy, xx = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(W, dtype=torch.float32), indexing="ij")
+    depth = (3.0 + 0.01 * xx + 0.02 * yy + 0.3 * torch.sin(xx / 7.0) + 0.05 * torch.rand(H, W, generator=g)).to(dev).contiguous()
+    alpha = torch.rand(H, W, generator=g).to(dev)
+    rn = torch.nn.functional.normalize(torch.randn(H, W, 3, generator=g), dim=-1).to(dev).contiguous()
+    pose = torch.linalg.inv(synth.make_views(3, seed=1)[2])[:3, :4].contiguous()
+    import ctypes as C
+    intr = (C.c_float * 4)(0.8 * W, 0.75 * W, (W - 1) / 2.0, (H - 1) / 2.0)
+    pose_c = (C.c_float * 12)(*[float(v) for v in pose.reshape(-1)])
+    w = torch.full((1,), 0.37, device=dev)
+    l_sep = torch.empty(1, device=dev); vd_sep = torch.empty(H, W, device=dev); vn_sep = torch.empty(H, W, 3, device=dev)
+    capi.check(L.gsdf_normal_consistency_fwd(H, W, intr, pose_c, capi.f32(depth), capi.f32(alpha), capi.f32(rn), capi.f32(l_sep), capi.stream()), "fwd")
+    capi.check(L.gsdf_normal_consistency_bwd(H, W, intr, pose_c, capi.f32(depth), capi.f32(alpha), capi.f32(rn), capi.f32(w), capi.f32(vd_sep), capi.f32(vn_sep),
+                                             capi.stream()), "bwd")
+    l_one = torch.full((1,), 2.0, device=dev); vd_one = torch.empty(H, W, device=dev); vn_one = torch.empty(H, W, 3, device=dev)   # (accumulates on top of 2)
+    capi.check(L.gsdf_normal_consistency_fwd_bwd(H, W, intr, pose_c, capi.f32(depth), capi.f32(alpha), capi.f32(rn), capi.f32(w), capi.f32(l_one),
+                                                 capi.f32(vd_one), capi.f32(vn_one), capi.stream()), "fwd_bwd")
+    assert abs(float(l_one) - 2.0 - float(l_sep)) <= 2e-6 * max(1.0, abs(float(l_sep)))
+    assert torch.equal(vd_one, vd_sep) and torch.equal(vn_one, vn_sep)
+    # isotropic regulariser
+    N, M = 5000, 3100
+    scales = (torch.rand(N, 3, generator=g) * 0.2 + 0.01).to(dev)
+    ids = torch.randperm(N, generator=g)[:M].to(dev)
+    l_sep = torch.empty((), device=dev); v_sep = torch.zeros(N, 3, device=dev)
+    capi.check(L.gsdf_isotropic_loss_fwd(M, capi.f32(scales), capi.ptr(ids, torch.int64), capi.f32(l_sep), capi.stream()), "iso fwd")
+    capi.check(L.gsdf_isotropic_loss_bwd(M, capi.f32(scales), capi.ptr(ids, torch.int64), capi.f32(w), capi.f32(v_sep), capi.stream()), "iso bwd")
+    l_one = torch.zeros((), device=dev); v_one = torch.zeros(N, 3, device=dev)
+    capi.check(L.gsdf_isotropic_loss_fwd_bwd(M, capi.f32(scales), capi.ptr(ids, torch.int64), capi.f32(w), capi.f32(l_one), capi.f32(v_one), capi.stream()), "iso")
+    assert abs(float(l_one) - float(l_sep)) <= 2e-6 * abs(float(l_sep)) and torch.equal(v_one, v_sep)
