@@ -97,13 +97,12 @@ class OctreeAS:
         vis, sw = visibilities.detach().reshape(-1).contiguous().float(), samples_weights.detach().reshape(-1).contiguous().float()
         w_all = torch.empty(n, device=xyz.device)
         ids = torch.empty(n, dtype=torch.int64, device=xyz.device)
-        count = torch.empty(1, dtype=torch.int64, device=xyz.device)
         L = capi.lib()
         ws = torch.empty(L.gsdf_visible_set_ws_bytes(n), dtype=torch.uint8, device=xyz.device)
-        capi.check(L.gsdf_visible_set(self.level, -1 if level is None else int(level), n, f32(xyz), (C.c_float * 3)(*origin), float(map_size_inv),
-                                      ptr(self.grid), f32(vis), f32(sw), float(vis_thresh), f32(w_all), ptr(ids), ptr(count), ptr(ws),
-                                      capi.stream()), "visible_set")
-        return ids[:int(count.item())], w_all
+        n_valid = capi.count_via_host_word(lambda count: capi.check(
+            L.gsdf_visible_set(self.level, -1 if level is None else int(level), n, f32(xyz), (C.c_float * 3)(*origin), float(map_size_inv), ptr(self.grid),
+                               f32(vis), f32(sw), float(vis_thresh), f32(w_all), ptr(ids), count, ptr(ws), capi.stream()), "visible_set"), xyz.device)
+        return ids[:n_valid], w_all
 
     def get_quantized_points(self):
         """-> int16 [V,3] occupied finest-level voxels (x-fastest linear order)."""
