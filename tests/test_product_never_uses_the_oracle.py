@@ -36,12 +36,16 @@ def test_no_product_source_touches_the_oracle():
 
 
 def test_bench_uses_the_oracle_only_in_its_cpu_baseline_leg():
-    src = open(os.path.join(ROOT, "bench.py")).read()
-    funcs = [(m.start(), m.group(1)) for m in re.finditer(r"^def (\w+)\(", src, re.M)]
-    for m in re.finditer(r"^\s*(from oracle\b.*|import oracle\b.*)$", src, re.M):
-        owner = [name for pos, name in funcs if pos < m.start()][-1]
-        assert owner == "cpu_baseline", f"bench.py imports the oracle in {owner}(): {m.group(1)}"
-    assert "_gsdf_reference" not in src and "ref_link" not in src
+    """bench.py and benchlib/: the oracle is imported by benchlib/cpu_baseline.py alone (the CPU baseline + parity leg)"""
+    paths = [os.path.join(ROOT, "bench.py")] + sorted(os.path.join(ROOT, "benchlib", f) for f in os.listdir(os.path.join(ROOT, "benchlib")) if f.endswith(".py"))
+    for p in paths:
+        src = _strip_comments(p, open(p).read())
+        uses = [m.group(0).strip() for m in re.finditer(r"^\s*(from oracle\b.*|import oracle\b.*)$", src, re.M)]
+        if os.path.basename(p) == "cpu_baseline.py":
+            assert uses, "the cpu_baseline leg no longer times the oracle?"
+        else:
+            assert not uses, f"{os.path.relpath(p, ROOT)} imports the oracle: {uses}"
+        assert "_gsdf_reference" not in src and "ref_link" not in src
 
 
 def test_the_product_fails_loudly_without_its_library(monkeypatch, tmp_path):
