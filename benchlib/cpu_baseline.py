@@ -106,29 +106,21 @@ def cpu_baseline(sc, views, params, N, W, H, deg, n_sdf_points, dev):
     vsh64 = orc.view_colors_bwd(n(view), means, n(sc["sh"]), p["camera_ids"], p["gaussian_ids"], deg, f64(g64["v_colors"]), prec="f64")   # (v_sh, v_means)
     vop64 = np.zeros(N)
     np.add.at(vop64, p["gaussian_ids"], f64(g64["v_opacities"]))
-    # The compositing gradients' first-order error bounds (g64["cond"], eps32 units) pushed through the LINEAR projection / SH backward, one
-    # upstream component at a time, so that every term enters with its absolute value: bound(leaf) = sum_k |J^T (e_k . bound_k)|.
-    # The end-to-end parameter gradients below are then gated like the compositing's own: 1e-4 max(|ref|, mean|ref|) + COND_C eps32 bound.
+    # End-to-end parameter gradients: bound(leaf) = the compositing gradients' first-order error bounds (g64["cond"], eps32 units) pushed through
+    # the ABSOLUTE SHADOW of the projection / SH backward (oracle: orc_projection_2dgs_bwd_bound — every term enters with its absolute value,
+    # internal cancellations included) + the backward's own evaluation error (PROJ_COND_C eps32 x the shadow of |upstream|, the rule of
+    # tests/test_gpu_baseline_shapes.py); gated like the compositing's own: 1e-4 max(|ref|, mean|ref|) + COND_C eps32 bound
     cnd = g64["cond"]
-    zM = lambda *sh: np.zeros((M,) + sh, np.float64)
-    b_means, b_quats, b_scales = np.zeros((N, 3)), np.zeros((N, 4)), np.zeros((N, 3))
-    for k in range(14):
-        v2d, vrt, vnr = zM(2), zM(3, 3), zM(3)
-        if k < 2:
-            v2d[:, k] = cnd[:, k]
-        elif k < 11:
-            vrt.reshape(M, 9)[:, k - 2] = cnd[:, k]
-        else:
-            vnr[:, k - 11] = cnd[:, 15 + k - 11]
-        bm_, bq_, bs_ = orc.projection_2dgs_bwd(means, quats, scales, n(view), n(sc["K"]), W, H, p["camera_ids"], p["gaussian_ids"], v2d, np.zeros(M, np.float64),
-                                                vrt, vnr, prec="f64")
-        b_means += np.abs(bm_); b_quats += np.abs(bq_); b_scales += np.abs(bs_)
-    b_sh = np.zeros(n(sc["sh"]).shape)
-    for k in range(3):
-        vc = zM(3)
-        vc[:, k] = cnd[:, 11 + k]
-        bsh_, bms_ = orc.view_colors_bwd(n(view), means, n(sc["sh"]), p["camera_ids"], p["gaussian_ids"], deg, vc, prec="f64")
-        b_sh += np.abs(bsh_); b_means += np.abs(bms_)
+    PROJ_OVER_COND = 16.0 / 2.0          # PROJ_COND_C / COND_C
+    zM = np.zeros(M, np.float64)
+    pa = (means, quats, scales, n(view), n(sc["K"]), W, H, p["camera_ids"], p["gaussian_ids"])
+    b1 = orc.projection_2dgs_bwd_bound(*pa, cnd[:, 0:2], zM, cnd[:, 2:11].reshape(M, 3, 3), cnd[:, 15:18])
+    b2 = orc.projection_2dgs_bwd_bound(*pa, np.abs(f64(g64["v_means2d"])), zM, np.abs(f64(g64["v_ray_transforms"])), np.abs(f64(g64["v_normals"])))
+    s1 = orc.view_colors_bwd_bound(n(view), means, n(sc["sh"]), p["camera_ids"], p["gaussian_ids"], deg, cnd[:, 11:14])
+    s2 = orc.view_colors_bwd_bound(n(view), means, n(sc["sh"]), p["camera_ids"], p["gaussian_ids"], deg, np.abs(f64(g64["v_colors"])))
+    b_means = b1[0] + s1[1] + PROJ_OVER_COND * (b2[0] + s2[1])
+    b_quats, b_scales = b1[1] + PROJ_OVER_COND * b2[1], b1[2] + PROJ_OVER_COND * b2[2]
+    b_sh = s1[0] + PROJ_OVER_COND * s2[0]
     b_opac = np.zeros(N)
     np.add.at(b_opac, p["gaussian_ids"], cnd[:, 14])
     leaves = [t(a).requires_grad_(True) for a in (means, quats, scales, opac, n(sc["sh"]))]

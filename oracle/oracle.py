@@ -15,12 +15,13 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _BUILD = os.path.join(_HERE, "_build")
 _LIBS = {}
+F32_BUILDS = ("f32", "f32fma", "f32acc", "f32fmaacc")
 
 
 def build(force=False):
     """Compile the C restatement with gcc (oracle/Makefile)."""
     kinds = [k for k in ("splat", "sdf") if os.path.exists(os.path.join(_HERE, f"{k}_oracle.c"))]
-    targets = [f"_build/liborc_{k}_{p}.so" for k in kinds for p in ("f32", "f64")] + ["_build/liborc_splat_f32fma.so"]
+    targets = [f"_build/liborc_{k}_{p}.so" for k in kinds for p in ("f32", "f64")] + [f"_build/liborc_splat_{p}.so" for p in ("f32fma", "f32acc", "f32fmaacc")]
     if os.path.exists(os.path.join(_HERE, "occ_oracle.c")):
         targets.append("_build/liborc_occ.so")
     subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []) + targets)
@@ -37,7 +38,7 @@ def _lib(kind, prec):
 
 
 def _dt(prec):
-    return np.float32 if prec in ("f32", "f32fma") else np.float64
+    return np.float32 if prec in F32_BUILDS else np.float64
 
 
 def _p(a):
@@ -45,7 +46,7 @@ def _p(a):
 
 
 def _r(x, prec):
-    return C.c_float(x) if prec in ("f32", "f32fma") else C.c_double(x)
+    return C.c_float(x) if prec in F32_BUILDS else C.c_double(x)
 
 
 def _c(a, dt):
@@ -90,6 +91,22 @@ def projection_2dgs_bwd(means, quats, scales, viewmats, Ks, W, H, camera_ids, ga
     return vm, vq, vs
 
 
+def projection_2dgs_bwd_bound(means, quats, scales, viewmats, Ks, W, H, camera_ids, gaussian_ids, a_means2d, a_depths,
+                              a_ray_transforms, a_normals, a_samples=None, seed=0):
+    """Absolute shadow of projection_2dgs_bwd (fp64 build): sum of the absolute values of all terms entering every output, given the
+    absolute upstream gradients (or their error bounds).  -> (b_means [N,3], b_quats [N,4], b_scales [N,3])"""
+    dt = np.float64
+    means, quats, scales, viewmats, Ks = (_c(a, dt) for a in (means, quats, scales, viewmats, Ks))
+    N, Cn, M = means.shape[0], viewmats.shape[0], camera_ids.shape[0]
+    cam, gid = _c(camera_ids, np.int64), _c(gaussian_ids, np.int64)
+    a2, ad, art, an, asm = (_c(a, dt) for a in (a_means2d, a_depths, a_ray_transforms, a_normals, a_samples))
+    bm = np.zeros((N, 3), dt); bq = np.zeros((N, 4), dt); bs = np.zeros((N, 3), dt)
+    _lib("splat", "f64").orc_projection_2dgs_bwd_bound(
+        C.c_int64(N), C.c_int64(Cn), C.c_int64(M), _p(means), _p(quats), _p(scales), _p(viewmats), _p(Ks),
+        C.c_int(W), C.c_int(H), C.c_uint64(seed), _p(cam), _p(gid), _p(a2), _p(ad), _p(art), _p(an), _p(asm), _p(bm), _p(bq), _p(bs))
+    return bm, bq, bs
+
+
 # ----------------------------------------------------------------------------------------------
 # P2 view colours
 # ----------------------------------------------------------------------------------------------
@@ -114,6 +131,18 @@ def view_colors_bwd(viewmats, means, sh_coeffs, camera_ids, gaussian_ids, sh_deg
                                             _p(means), _p(sh), _p(cam), _p(gid), _p(v_colors), _p(v_sh),
                                             _p(v_means))
     return v_sh, v_means
+
+
+def view_colors_bwd_bound(viewmats, means, sh_coeffs, camera_ids, gaussian_ids, sh_degree, a_colors):
+    """absolute shadow of view_colors_bwd (fp64 build) -> (b_sh, b_means)"""
+    dt = np.float64
+    viewmats, means, sh, a_colors = _c(viewmats, dt), _c(means, dt), _c(sh_coeffs, dt), _c(a_colors, dt)
+    cam, gid = _c(camera_ids, np.int64), _c(gaussian_ids, np.int64)
+    M, K = cam.shape[0], sh.shape[1]
+    b_sh = np.zeros_like(sh); b_means = np.zeros_like(means)
+    _lib("splat", "f64").orc_view_colors_bwd_bound(C.c_int64(M), C.c_int64(K), C.c_int(sh_degree), _p(viewmats), _p(means), _p(sh), _p(cam),
+                                                   _p(gid), _p(a_colors), _p(b_sh), _p(b_means))
+    return b_sh, b_means
 
 
 # ----------------------------------------------------------------------------------------------

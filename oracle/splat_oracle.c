@@ -117,6 +117,13 @@ static void project_one(const REAL *mean, const REAL *quat, const REAL *scale, c
     c[3 + j] = (R10 * q[0 + j] + R11 * q[3 + j]) + R12 * q[6 + j];
     c[6 + j] = (R20 * q[0 + j] + R21 * q[3 + j]) + R22 * q[6 + j];
   }
+  /* the normal flip is decided here, BEFORE the radius / screen culls: the backward recomputes this function for rows that were visible in the
+   * forward, and in another precision such a row may fail a cull by a rounding — its mult must still be defined (round 5: it was read
+   * uninitialised by the f64 backward for splats whose box touches the screen edge) */
+  {
+    REAL dotv = (-c[2]) * o->mc[0] + (-c[5]) * o->mc[1] + (-c[8]) * o->mc[2];
+    o->mult = dotv > 0 ? (REAL)1 : (REAL)-1;
+  }
   const REAL su = scale[0], sv = scale[1];
   /* H rows: H[i] = (su*Rc[i][0], sv*Rc[i][1], mc[i]) */
   REAL H0[3] = {su * c[0], sv * c[1], o->mc[0]};
@@ -148,8 +155,6 @@ static void project_one(const REAL *mean, const REAL *quat, const REAL *scale, c
     return;
   if (!(radius < (REAL)2147483000.0)) return; /* int32 overflow guard (inf) */
   o->radius = radius;
-  REAL dotv = (-c[2]) * o->mc[0] + (-c[5]) * o->mc[1] + (-c[8]) * o->mc[2];
-  o->mult = dotv > 0 ? (REAL)1 : (REAL)-1;
   o->culled = 0;
 }
 
@@ -364,6 +369,93 @@ void orc_view_colors_fwd(int64_t M, int64_t K, int sh_degree, const REAL *viewma
 }
 
 /* outputs v_sh [N,K,3] and v_means [N,3] must be zeroed by the caller */
+/* First-order bound of the fp32 evaluation error of orc_projection_2dgs_bwd: the SAME expression tree evaluated on absolute values with every
+ * subtraction turned into an addition ("absolute shadow"), i.e. the sum of the absolute values of all terms that enter each output — internal
+ * cancellations (the quaternion gradient's projection orthogonal to q, the mean2d terms of v_Mw) included.  An fp32 evaluation in ANY operation
+ * order deviates from the exact value by at most (operation depth) x eps32 x this sum.  Outputs b_* are accumulated like the gradients.
+ * `a_*` = |upstream gradient| or its own error bound (the parity tests push both through). */
+void orc_projection_2dgs_bwd_bound(int64_t N, int64_t C, int64_t M, const REAL *means, const REAL *quats,
+                                   const REAL *scales, const REAL *viewmats, const REAL *Ks, int W, int H,
+                                   uint64_t seed, const int64_t *camera_ids, const int64_t *gaussian_ids,
+                                   const REAL *a_means2d, const REAL *a_depths, const REAL *a_ray_transforms, const REAL *a_normals,
+                                   const REAL *a_samples, REAL *b_means, REAL *b_quats, REAL *b_scales) {
+  (void)N; (void)C;
+#define AB(x) ((REAL)fabs((double)(x)))
+  for (int64_t m = 0; m < M; ++m) {
+    int64_t c = camera_ids[m], n = gaussian_ids[m];
+    const REAL *vm = viewmats + 16 * c, *K = Ks + 9 * c;
+    proj_t p;
+    project_one(means + 3 * n, quats + 4 * n, scales + 3 * n, vm, K, W, H, (REAL)-1e30, (REAL)1e30, (REAL)-1, &p);
+    const REAL *Mu = p.Mu, *Mv = p.Mv, *Mw = p.Mw, *f = p.f;
+    REAL vMu[3], vMv[3], vMw[3];
+    for (int j = 0; j < 3; ++j) {
+      vMu[j] = AB(a_ray_transforms[9 * m + j]);
+      vMv[j] = AB(a_ray_transforms[9 * m + 3 + j]);
+      vMw[j] = AB(a_ray_transforms[9 * m + 6 + j]);
+    }
+    REAL gx = AB(a_means2d[2 * m]), gy = AB(a_means2d[2 * m + 1]);
+    /* f = (1,1,-1) / dist, dist = Mw0^2 + Mw1^2 - Mw2^2: a cancelling sum, relative error kd x eps32 with kd = sum Mw_j^2 / |dist| (>= 1) —
+     * the recomputed FORWARD quantity every mean2d term carries; mean2d = sum_j f_j Mu_j Mw_j inherits it on the sum of its |terms| */
+    const REAL sq = Mw[0] * Mw[0] + Mw[1] * Mw[1] + Mw[2] * Mw[2];
+    const REAL kd = sq * AB(f[0]);
+    REAL am0 = 0, am1 = 0;
+    for (int j = 0; j < 3; ++j) { am0 += AB(f[j] * Mu[j] * Mw[j]); am1 += AB(f[j] * Mv[j] * Mw[j]); }
+    for (int j = 0; j < 3; ++j) {
+      vMu[j] += gx * AB(f[j] * Mw[j]) * kd;
+      vMv[j] += gy * AB(f[j] * Mw[j]) * kd;
+      vMw[j] += gx * (AB(f[j] * Mu[j]) * kd + 2 * AB(f[j] * Mw[j]) * am0 * (2 * kd)) + gy * (AB(f[j] * Mv[j]) * kd + 2 * AB(f[j] * Mw[j]) * am1 * (2 * kd));
+    }
+    const REAL fx = AB(K[0]), cx = AB(K[2]), fy = AB(K[4]), cy = AB(K[5]);
+    REAL vH0[3], vH1[3], vH2[3];
+    for (int j = 0; j < 3; ++j) {
+      vH0[j] = fx * vMu[j];
+      vH1[j] = fy * vMv[j];
+      vH2[j] = cx * vMu[j] + cy * vMv[j] + vMw[j];
+    }
+    const REAL su = AB(scales[3 * n]), sv = AB(scales[3 * n + 1]);
+    const REAL *c9 = p.Rc;
+    REAL v_mc[3] = {vH0[2], vH1[2], vH2[2] + (a_depths ? AB(a_depths[m]) : 0)};
+    REAL v_su = vH0[0] * AB(c9[0]) + vH1[0] * AB(c9[3]) + vH2[0] * AB(c9[6]);
+    REAL v_sv = vH0[1] * AB(c9[1]) + vH1[1] * AB(c9[4]) + vH2[1] * AB(c9[7]);
+    REAL vRc[9];
+    vRc[0] = su * vH0[0]; vRc[3] = su * vH1[0]; vRc[6] = su * vH2[0];
+    vRc[1] = sv * vH0[1]; vRc[4] = sv * vH1[1]; vRc[7] = sv * vH2[1];
+    vRc[2] = AB(p.mult) * AB(a_normals[3 * m]); vRc[5] = AB(p.mult) * AB(a_normals[3 * m + 1]); vRc[8] = AB(p.mult) * AB(a_normals[3 * m + 2]);
+    REAL Rv[9] = {AB(vm[0]), AB(vm[1]), AB(vm[2]), AB(vm[4]), AB(vm[5]), AB(vm[6]), AB(vm[8]), AB(vm[9]), AB(vm[10])};
+    REAL vRq[9];
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) vRq[3 * i + j] = Rv[0 + i] * vRc[0 + j] + Rv[3 + i] * vRc[3 + j] + Rv[6 + i] * vRc[6 + j];
+    REAL v_mu[3];
+    for (int i = 0; i < 3; ++i) v_mu[i] = Rv[0 + i] * v_mc[0] + Rv[3 + i] * v_mc[1] + Rv[6 + i] * v_mc[2];
+    REAL eu, ev;
+    sample_eps(seed, (uint32_t)n, &eu, &ev);
+    if (a_samples) {
+      const REAL *vs = a_samples + 3 * m;
+      for (int i = 0; i < 3; ++i) {
+        v_mu[i] += AB(vs[i]);
+        vRq[3 * i + 0] += su * AB(eu) * AB(vs[i]);
+        vRq[3 * i + 1] += sv * AB(ev) * AB(vs[i]);
+        v_su += AB(eu * p.Rq[3 * i + 0]) * AB(vs[i]);
+        v_sv += AB(ev * p.Rq[3 * i + 1]) * AB(vs[i]);
+      }
+    }
+    REAL w = AB(p.qn[0]), x = AB(p.qn[1]), y = AB(p.qn[2]), z = AB(p.qn[3]);
+    const REAL *g = vRq;
+    REAL vq[4];
+    vq[0] = 2 * (x * (g[7] + g[5]) + y * (g[2] + g[6]) + z * (g[3] + g[1]));
+    vq[1] = 2 * (2 * x * (g[4] + g[8]) + y * (g[1] + g[3]) + z * (g[2] + g[6]) + w * (g[7] + g[5]));
+    vq[2] = 2 * (x * (g[1] + g[3]) + 2 * y * (g[0] + g[8]) + z * (g[5] + g[7]) + w * (g[2] + g[6]));
+    vq[3] = 2 * (x * (g[2] + g[6]) + y * (g[5] + g[7]) + 2 * z * (g[0] + g[4]) + w * (g[3] + g[1]));
+    REAL dotq = vq[0] * w + vq[1] * x + vq[2] * y + vq[3] * z;
+    const REAL qa[4] = {w, x, y, z};
+    for (int i = 0; i < 4; ++i) b_quats[4 * n + i] += (vq[i] + dotq * qa[i]) * AB(p.inv_norm);
+    for (int i = 0; i < 3; ++i) b_means[3 * n + i] += v_mu[i];
+    b_scales[3 * n] += v_su;
+    b_scales[3 * n + 1] += v_sv;
+  }
+#undef AB
+}
+
 void orc_view_colors_bwd(int64_t M, int64_t K, int sh_degree, const REAL *viewmats, const REAL *means,
                          const REAL *sh_coeffs, const int64_t *camera_ids, const int64_t *gaussian_ids,
                          const REAL *v_colors, REAL *v_sh, REAL *v_means) {
@@ -395,6 +487,41 @@ void orc_view_colors_bwd(int64_t M, int64_t K, int sh_degree, const REAL *viewma
     REAL dot = vu[0] * u[0] + vu[1] * u[1] + vu[2] * u[2];
     for (int i = 0; i < 3; ++i) v_means[3 * n + i] += (vu[i] - dot * u[i]) * inv;
   }
+}
+
+/* absolute shadow of orc_view_colors_bwd (see orc_projection_2dgs_bwd_bound) */
+void orc_view_colors_bwd_bound(int64_t M, int64_t K, int sh_degree, const REAL *viewmats, const REAL *means,
+                               const REAL *sh_coeffs, const int64_t *camera_ids, const int64_t *gaussian_ids,
+                               const REAL *a_colors, REAL *b_sh, REAL *b_means) {
+#define AB(x) ((REAL)fabs((double)(x)))
+  for (int64_t m = 0; m < M; ++m) {
+    int64_t n = gaussian_ids[m];
+    REAL cp[3];
+    cam_pos(viewmats + 16 * camera_ids[m], cp);
+    REAL d[3] = {means[3 * n] - cp[0], means[3 * n + 1] - cp[1], means[3 * n + 2] - cp[2]};
+    REAL len = (REAL)sqrt((double)(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]));
+    REAL inv = len > 0 ? 1 / len : 0;
+    REAL u[3] = {d[0] * inv, d[1] * inv, d[2] * inv};
+    REAL b[16], db[16][3];
+    sh_basis(sh_degree, u[0], u[1], u[2], b);
+    sh_basis_grad(sh_degree, u[0], u[1], u[2], db);
+    int nb = (sh_degree + 1) * (sh_degree + 1);
+    REAL vu[3] = {0, 0, 0};
+    for (int ch = 0; ch < 3; ++ch) {
+      REAL acc = 0;
+      for (int k = 0; k < nb; ++k) acc += b[k] * sh_coeffs[(n * K + k) * 3 + ch];
+      if (!(acc + (REAL)0.5 > 0)) continue;
+      REAL g = AB(a_colors[3 * m + ch]);
+      for (int k = 0; k < nb; ++k) {
+        b_sh[(n * K + k) * 3 + ch] += g * AB(b[k]);
+        REAL cf = g * AB(sh_coeffs[(n * K + k) * 3 + ch]);
+        vu[0] += cf * AB(db[k][0]); vu[1] += cf * AB(db[k][1]); vu[2] += cf * AB(db[k][2]);
+      }
+    }
+    REAL dot = vu[0] * AB(u[0]) + vu[1] * AB(u[1]) + vu[2] * AB(u[2]);
+    for (int i = 0; i < 3; ++i) b_means[3 * n + i] += (vu[i] + dot * AB(u[i])) * inv;
+  }
+#undef AB
 }
 
 /* ---------------------------------------------------------------------------------------
@@ -1081,6 +1208,15 @@ void orc_rasterize_2dgs_fwd_matched(int64_t C, int64_t M, int64_t I, int W, int 
  * means2d 2, M 9, colors 3, opacity 1, normals 3, densify 2, means2d_abs 2) first the sum over pixels of (F |term|)^2 — F the
  * pair's relative-error factor, root-sum-square model of independent roundings — then the plain sum of |term| (the fp32
  * accumulation itself).  The caller's bound is sqrt(first) + ACC x second, in eps32 units. */
+/* Gradient accumulation of the matched backward.  Default: every term (evaluated in REAL) is summed in double, so that the f64 build is the
+ * reference and the f32 builds isolate the per-term evaluation error.  -DACC_FLOAT (the builds liborc_splat_f32acc / _f32fmaacc): the sums
+ * are fp32 as well, term after term in pixel order and tile after tile — a SECOND, fully-fp32 evaluation of the operator with an operation
+ * order unlike the HIP kernel's (wave trees + atomics), used by the parity tests as the independent leg under the conditioning bound. */
+#ifdef ACC_FLOAT
+#define ACCADD(x, v) do { (x) = (double)(float)((x) + (double)(float)(v)); } while (0)
+#else
+#define ACCADD(x, v) do { (x) += (v); } while (0)
+#endif
 void orc_rasterize_2dgs_bwd_matched(int64_t C, int64_t M, int64_t I, int W, int H, int tile_size,
                                     const REAL *means2d, const REAL *ray_transforms, const REAL *colors,
                                     const REAL *opacities, const REAL *normals, const REAL *backgrounds,
@@ -1157,8 +1293,8 @@ void orc_rasterize_2dgs_bwd_matched(int64_t C, int64_t M, int64_t I, int W, int 
           REAL v_alpha = 0;
           double A = 0;   /* sum of the absolute values of v_alpha's terms */
           for (int ch = 0; ch < 3; ++ch) {
-            a[11 + ch] += fac * vC[ch];
-            a[15 + ch] += fac * vN[ch];
+            ACCADD(a[11 + ch], fac * vC[ch]);
+            ACCADD(a[15 + ch], fac * vN[ch]);
             BND(11 + ch, sqrt(Rpix), fabs((double)(fac * vC[ch])));
             BND(15 + ch, sqrt(Rpix), fabs((double)(fac * vN[ch])));
             v_alpha += (colors[3 * g + ch] * T - bufC[ch] * ra) * vC[ch];
@@ -1185,7 +1321,7 @@ void orc_rasterize_2dgs_bwd_matched(int64_t C, int64_t M, int64_t I, int W, int 
           double asig = 0;
           const double Fw = sqrt(Rpix + e.r * e.r + e.ks * e.ks);   /* ks: e.dep inside v_alpha carries the error of s */
           if (!e.clamped) {
-            a[14] += e.vis * v_alpha;
+            ACCADD(a[14], e.vis * v_alpha);
             BND(14, Fw, (double)e.vis * A);
             v_sigma = -opacities[g] * e.vis * v_alpha;
             asig = (double)opacities[g] * (double)e.vis * A;
@@ -1202,9 +1338,9 @@ void orc_rasterize_2dgs_bwd_matched(int64_t C, int64_t M, int64_t I, int W, int 
             REAL vMw[3] = {px * v_hu[0] + py * v_hv[0] + v_dep * e.s[0],
                            px * v_hu[1] + py * v_hv[1] + v_dep * e.s[1],
                            px * v_hu[2] + py * v_hv[2] + v_dep};
-            for (int q = 0; q < 3; ++q) { a[2 + q] += -v_hu[q]; a[5 + q] += -v_hv[q]; a[8 + q] += vMw[q]; }
-            a[18] += -v_hu[2] * Mw[2];
-            a[19] += -v_hv[2] * Mw[2];
+            for (int q = 0; q < 3; ++q) { ACCADD(a[2 + q], -v_hu[q]); ACCADD(a[5 + q], -v_hv[q]); ACCADD(a[8 + q], vMw[q]); }
+            ACCADD(a[18], -v_hu[2] * Mw[2]);
+            ACCADD(a[19], -v_hv[2] * Mw[2]);
             if (cond) {
               const double iz = 1.0 / fabs((double)e.z[2]);
               const double sn = sqrt((double)e.g3);
@@ -1223,9 +1359,9 @@ void orc_rasterize_2dgs_bwd_matched(int64_t C, int64_t M, int64_t I, int W, int 
             }
           } else {
             REAL gx = v_sigma * FILTER_INV_SQUARE * e.d[0], gy = v_sigma * FILTER_INV_SQUARE * e.d[1];
-            a[0] += gx; a[1] += gy;
-            a[20] += fabs((double)gx); a[21] += fabs((double)gy);
-            a[10] += v_dep;
+            ACCADD(a[0], gx); ACCADD(a[1], gy);
+            ACCADD(a[20], fabs((double)gx)); ACCADD(a[21], fabs((double)gy));
+            ACCADD(a[10], v_dep);
             if (cond) {
               const double F = sqrt(Rpix + e.r * e.r + 16.0);
               const double agx = asig * 2.0 * fabs((double)e.d[0]), agy = asig * 2.0 * fabs((double)e.d[1]);
@@ -1239,12 +1375,12 @@ void orc_rasterize_2dgs_bwd_matched(int64_t C, int64_t M, int64_t I, int W, int 
     for (int32_t k = 0; k < len; ++k) {
       int32_t g = flatten_ids[start + k];
       const double *a = acc + (size_t)k * NG;
-      v_means2d[2 * g] += a[0]; v_means2d[2 * g + 1] += a[1];
-      for (int q = 0; q < 9; ++q) v_ray_transforms[9 * g + q] += a[2 + q];
-      for (int q = 0; q < 3; ++q) { v_colors[3 * g + q] += a[11 + q]; v_normals[3 * g + q] += a[15 + q]; }
-      v_opacities[g] += a[14];
-      v_densify[2 * g] += a[18]; v_densify[2 * g + 1] += a[19];
-      if (v_means2d_abs) { v_means2d_abs[2 * g] += a[20]; v_means2d_abs[2 * g + 1] += a[21]; }
+      ACCADD(v_means2d[2 * g], a[0]); ACCADD(v_means2d[2 * g + 1], a[1]);
+      for (int q = 0; q < 9; ++q) ACCADD(v_ray_transforms[9 * g + q], a[2 + q]);
+      for (int q = 0; q < 3; ++q) { ACCADD(v_colors[3 * g + q], a[11 + q]); ACCADD(v_normals[3 * g + q], a[15 + q]); }
+      ACCADD(v_opacities[g], a[14]);
+      ACCADD(v_densify[2 * g], a[18]); ACCADD(v_densify[2 * g + 1], a[19]);
+      if (v_means2d_abs) { ACCADD(v_means2d_abs[2 * g], a[20]); ACCADD(v_means2d_abs[2 * g + 1], a[21]); }
       if (cond) for (int q = 0; q < 22; ++q) { cond[44 * (int64_t)g + q] += a[22 + q]; cond[44 * (int64_t)g + 22 + q] += a[44 + q]; }
     }
 #undef BND
@@ -1252,6 +1388,7 @@ void orc_rasterize_2dgs_bwd_matched(int64_t C, int64_t M, int64_t I, int W, int 
   }
 }
 
+#undef ACCADD
 /* The decision record of THIS build's own evaluation (same byte layout as gsdf_rasterize_2dgs_fwd_instr writes): used by the
  * CPU self-check of the decision-matched gate, where the fp32 build stands in for the implementation under test. */
 void orc_rasterize_2dgs_trace(int64_t C, int64_t M, int64_t I, int W, int H, int tile_size, const REAL *means2d,

@@ -85,3 +85,35 @@ def test_gate_refuses_a_wrong_decision_and_a_wrong_value(oracle):
     g["last_ids"] = got["last_ids"].copy(); g["last_ids"][0, 5, 5] += 1
     with pytest.raises(AssertionError, match="last_ids"):
         util.assert_all_matched(g, ref, oracle, keys=())
+
+
+def test_independent_fp32_builds_land_as_far_from_fp64_as_the_stand_in(oracle):
+    """CPU self-check of the cross-check (tests/util.py "INDEPENDENT leg"): the stand-in implementation (f32fma build, double accumulation) and the
+    two fully-fp32 builds are three correct fp32 evaluations; wherever the stand-in leaves the plain 1e-4 bar the others must be comparably
+    far out, and a value pushed 50 x further out than any of them must be refused."""
+    N, W, H = 6000, 192, 128
+    p, col, opa, flat, offs, ug = _problem(oracle, N, W, H, 0)
+    got, trace = _standin(oracle, p, col, opa, W, H, offs, flat, ug)
+    ref = util.matched_reference(oracle, p, col, opa, W, H, offs, flat, ug, trace, recovers_final_T=True)
+    alts = util.independent_fp32_evaluations(oracle, ref, p, col, opa, W, H, offs, flat, ug)
+    for prec in util.INDEP_BUILDS:      # the builds see the same decisions: identical ids
+        assert np.array_equal(alts[prec]["last_ids"], ref["last_ids"]) and np.array_equal(alts[prec]["median_ids"], ref["median_ids"])
+    seen_needed = 0
+    for key in util.RASTER_TENSORS:
+        st = util.independent_stats(got[key], ref[key], [alts[b][key] for b in util.INDEP_BUILDS])
+        util.check_independent(st, key)
+        seen_needed += st["needed"]
+        assert st["rel_l2_alt"] < 1e-3
+    # float accumulation is really on in the builds: their gradients differ from the double-accumulating f32 build's
+    g32 = oracle.rasterize_2dgs_bwd_matched(p["means2d"], p["ray_transforms"], col, opa, p["normals"], W, H, 16, offs, flat, alts["f32acc"]["render_alphas"],
+                                            ref["last_ids"], ref["median_ids"], *(n(ug[k]) for k in UP), trace_rows=ref["trace_rows"], trace_bits=ref["trace_bits"],
+                                            prec="f32", recovers_final_T=True)
+    assert not np.array_equal(g32["v_colors"], alts["f32acc"]["v_colors"])
+    bad = np.array(got["v_ray_transforms"], np.float64).copy()
+    i = int(np.argmax(np.abs(bad - ref["v_ray_transforms"]).reshape(-1)))
+    base = 1e-4 * max(abs(ref["v_ray_transforms"].reshape(-1)[i]), np.abs(ref["v_ray_transforms"]).mean())
+    worst_alt = max(util.independent_stats(got["v_ray_transforms"], ref["v_ray_transforms"], [alts[b]["v_ray_transforms"] for b in util.INDEP_BUILDS])["worst_over_base_alt"], 1.0)
+    bad.reshape(-1)[i] = ref["v_ray_transforms"].reshape(-1)[i] + 50.0 * worst_alt * base
+    st = util.independent_stats(bad, ref["v_ray_transforms"], [alts[b]["v_ray_transforms"] for b in util.INDEP_BUILDS])
+    with pytest.raises(AssertionError, match="v_ray_transforms"):
+        util.check_independent(st, "v_ray_transforms")

@@ -274,3 +274,106 @@ def hip_matched_parity(ops, oracle, p, col, opa, W, H, offs, flat, ug, dev, case
         trace_fn(np.full(ref["last_ids"].shape, -1, np.int32), 1)
     stats = assert_all_matched(got, ref, oracle, case, rel)
     return stats, ref["info"], got, ref
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# Round 5: an INDEPENDENT leg under the conditioning bound.  The bound above comes from the same oracle that supplies the
+# reference, so by itself it is self-certified.  The cross-check: two more, fully-fp32 evaluations of the operator under the SAME
+# traced decisions — oracle builds liborc_splat_f32acc (no FMA contraction) and liborc_splat_f32fmaacc (FMA contraction), both
+# with fp32 accumulation of the gradients in pixel / tile order and the final transmittance recovered as 1 - alpha (the upstream
+# gsplat form), i.e. an operation order unlike the HIP kernel's — are compared with the fp64 reference on the same elements.
+# If a tensor of the implementation under test needed the conditioning term, another correct fp32 evaluation must land
+# comparably far from fp64: per tensor
+#     ratio_worst  = worst_over_base(impl) / max over the two builds of worst_over_base(build)
+#     ratio_needed = needed(impl) / max(needed(build))           (elements above the plain 1e-4 bar)
+#     on the impl's own needed elements: median and max of err_impl / max(err_build)   (max is reported, not gated: a single
+#     element where both builds happen to round luckily makes it arbitrarily large)
+# and the gate is ratio_worst <= INDEP_MAX_RATIO and needed(impl) <= INDEP_MAX_RATIO * max(needed(build)) + 16.
+# ---------------------------------------------------------------------------------------------------------------------------
+INDEP_BUILDS = ("f32acc", "f32fmaacc")
+INDEP_MAX_RATIO = 4.0
+INDEP_LOG = []          # (case, tensor, stats)
+
+
+def independent_fp32_evaluations(oracle, ref, p, col, opa, W, H, offs, flat, ug, backgrounds=None, masks=None):
+    """-> {build: {tensor: array}} of the two fully-fp32 oracle builds under the trace stored in `ref` (matched_reference's result)."""
+    nn = lambda a: a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else a
+    out = {}
+    for prec in INDEP_BUILDS:
+        fw = oracle.rasterize_2dgs_fwd_matched(p["means2d"], p["ray_transforms"], col, opa, p["normals"], W, H, 16, offs, flat,
+                                               trace_rows=ref["trace_rows"], trace_bits=ref["trace_bits"], backgrounds=backgrounds, masks=masks, prec=prec)
+        g = oracle.rasterize_2dgs_bwd_matched(p["means2d"], p["ray_transforms"], col, opa, p["normals"], W, H, 16, offs, flat,
+                                              fw["render_alphas"], fw["last_ids"], fw["median_ids"], nn(ug["v_render_colors"]),
+                                              nn(ug["v_render_depths"]), nn(ug["v_render_alphas"]), nn(ug["v_render_normals"]),
+                                              nn(ug["v_render_median"]), trace_rows=ref["trace_rows"], trace_bits=ref["trace_bits"],
+                                              backgrounds=backgrounds, masks=masks, prec=prec, recovers_final_T=True)
+        out[prec] = {**fw, **g}
+    return out
+
+
+def independent_stats(got, ref, alts, rel=1e-4):
+    """got / ref: arrays of one tensor (implementation under test, fp64 reference); alts: list of arrays (independent fp32 evaluations)."""
+    f = lambda a: (a.detach().cpu().double().numpy() if isinstance(a, torch.Tensor) else np.asarray(a, np.float64)).reshape(-1)
+    g, r = f(got), f(ref)
+    if r.size == 0:
+        return dict(elements=0, needed=0, needed_alt=0, worst_over_base=0.0, worst_over_base_alt=0.0, ratio_worst=0.0, ratio_needed=0.0,
+                    on_needed_median_ratio=0.0, on_needed_max_ratio=0.0, rel_l2=0.0, rel_l2_alt=0.0)
+    base = rel * np.maximum(np.abs(r), np.abs(r).mean() + 1e-30)
+    err = np.abs(g - r)
+    errs_alt = [np.abs(f(a) - r) for a in alts]
+    err_alt = np.maximum.reduce(errs_alt)
+    need = err > base
+    wob, wob_alt = float((err / base).max()), float(max((e / base).max() for e in errs_alt))
+    needed_alt = int(max((e > base).sum() for e in errs_alt))
+    on = (err[need] / np.maximum(err_alt[need], 1e-300)) if need.any() else np.zeros(0)
+    nrm = np.linalg.norm(r) + 1e-30
+    return dict(elements=int(r.size), needed=int(need.sum()), needed_alt=needed_alt, worst_over_base=wob, worst_over_base_alt=wob_alt,
+                ratio_worst=wob / max(wob_alt, 1e-30), ratio_needed=float(need.sum()) / max(needed_alt, 1),
+                on_needed_median_ratio=float(np.median(on)) if on.size else 0.0, on_needed_max_ratio=float(on.max()) if on.size else 0.0,
+                rel_l2=float(np.linalg.norm(g - r) / nrm), rel_l2_alt=float(max(np.linalg.norm(f(a) - r) for a in alts) / nrm))
+
+
+def check_independent(st, name, failures=None, max_ratio=INDEP_MAX_RATIO):
+    """the gate on one tensor's independent_stats(); collects into `failures` (list) or asserts"""
+    msgs = []
+    if st["worst_over_base"] > 1.0 and st["ratio_worst"] > max_ratio:
+        msgs.append(f"{name}: worst element is {st['worst_over_base']:.1f} x the 1e-4 bar, the independent fp32 builds' worst {st['worst_over_base_alt']:.1f} x "
+                    f"(ratio {st['ratio_worst']:.1f} > {max_ratio})")
+    if st["needed"] > max_ratio * st["needed_alt"] + 16:
+        msgs.append(f"{name}: {st['needed']} elements above the plain bar, an independent fp32 build {st['needed_alt']}")
+    if failures is None:
+        assert not msgs, "\n".join(msgs)
+    else:
+        failures.extend(msgs)
+    return not msgs
+
+
+def projection_bwd_bound(oracle, means, quats, scales, viewmats, Ks, W, H, camera_ids, gaussian_ids, sh, sh_degree,
+                         a_means2d, a_ray_transforms, a_normals, a_colors):
+    """First-order bound of the fp32 evaluation error of the projection / SH backward: the oracle's absolute shadow of the same expression
+    tree (oracle/splat_oracle.c: orc_projection_2dgs_bwd_bound, orc_view_colors_bwd_bound), fed with the absolute upstream gradients (or
+    with their own error bounds).  -> (b_means [N,3], b_quats [N,4], b_scales [N,3], b_sh [N,K,3]) = sum of |terms| per output element."""
+    M = gaussian_ids.shape[0]
+    ab = lambda a: np.abs(np.asarray(a, np.float64))
+    bm, bq, bs = oracle.projection_2dgs_bwd_bound(means, quats, scales, viewmats, Ks, W, H, camera_ids, gaussian_ids, ab(a_means2d), np.zeros(M),
+                                                  ab(a_ray_transforms), ab(a_normals))
+    bsh, bms = oracle.view_colors_bwd_bound(viewmats, means, sh, camera_ids, gaussian_ids, sh_degree, ab(a_colors))
+    return bm + bms, bq, bs, bsh
+
+
+def normal_flip_rows(means, quats, viewmats, camera_ids, gaussian_ids, normals_impl):
+    """The projection's one discrete decision: the splat normal R_c[:,2] is flipped to face the camera (mult = sign(-R_c[:,2] . mu_c)).  For an
+    edge-on splat the sign hangs on the rounding of a cancelling dot product, and the fp64 oracle may decide differently from a correct fp32
+    implementation.  -> bool [M]: rows where the implementation's normal (normals_impl [M,3]) has the OTHER sign than the fp64 evaluation's.
+    The decision-matched reference negates the upstream normal gradient of those rows (vRc[:,2] = mult * v_normals)."""
+    f = lambda a: np.asarray(a, np.float64)
+    q = f(quats)[gaussian_ids]
+    q = q / np.linalg.norm(q, axis=1, keepdims=True)
+    w, x, y, z = q.T
+    r2 = np.stack([2 * (x * z + w * y), 2 * (y * z - w * x), 1 - 2 * (x * x + y * y)], 1)        # third column of R_q
+    V = f(viewmats)[camera_ids]
+    rc2 = np.einsum("mij,mj->mi", V[:, :3, :3], r2)
+    mc = np.einsum("mij,mj->mi", V[:, :3, :3], f(means)[gaussian_ids]) + V[:, :3, 3]
+    mult64 = np.where(-(rc2 * mc).sum(1) > 0, 1.0, -1.0)
+    mult_impl = np.where((f(normals_impl) * rc2).sum(1) >= 0, 1.0, -1.0)
+    return mult64 != mult_impl
