@@ -15,7 +15,7 @@ _lib = None
 
 _i64, _i32, _f32, _u64, _vp, _sz = C.c_int64, C.c_int, C.c_float, C.c_uint64, C.c_void_p, C.c_size_t
 
-ABI_VERSION = 5      # include/gsdf_hip.h: GSDF_ABI_VERSION this binding was written against
+ABI_VERSION = 6      # include/gsdf_hip.h: GSDF_ABI_VERSION this binding was written against
 
 
 class RasterInstr(C.Structure):
@@ -90,6 +90,8 @@ _SIGS = {
     "gsdf_occ_voxel_list": (C.c_int, [_i32, _vp, _vp, _vp, _vp]),
     "gsdf_occ_raymarch_count": (C.c_int, [_i32, _i64, _vp, _vp, _vp, _vp, _vp]),
     "gsdf_occ_raymarch_fill": (C.c_int, [_i32, _i64, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp]),
+    "gsdf_ray_sampler_count": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),                      # (const gsdf_ray_sampler_args *, counts, offsets_incl, total, stream)
+    "gsdf_ray_sampler_fill": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gsdf_mc_count": (C.c_int, [_i32, _i32, _i32, _i32, _vp, _f32, _vp, _vp, _vp]),
     "gsdf_mc_emit": (C.c_int, [_i32, _i32, _i32, _i32, _vp, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gsdf_splat_activations_fwd": (C.c_int, [_i64] + [_vp] * 8),
@@ -163,21 +165,38 @@ class HostWords:
             pass
 
 
-_words = None
+class RaySamplerArgs(C.Structure):
+    """include/gsdf_hip.h: gsdf_ray_sampler_args"""
+    _fields_ = [("level", C.c_int), ("n_rays", C.c_int64), ("origin", C.c_void_p), ("direction", C.c_void_p), ("depth", C.c_void_p),
+                ("end_xyz", C.c_void_p), ("grid", C.c_void_p), ("rand_free", C.c_void_p), ("randn_surf", C.c_void_p),
+                ("free_sample_num", C.c_int), ("surface_sample_num", C.c_int), ("map_origin", C.c_float * 3), ("map_size_inv", C.c_float),
+                ("map_half", C.c_float), ("range_lo", C.c_float * 3), ("range_hi", C.c_float * 3), ("sample_std", C.c_float),
+                ("truncated_dis", C.c_float)]
 
 
-def count_via_host_word(launch, device):
-    """Runs launch(count_pointer) and returns the count it wrote: through a host-visible word (GSDF_HOST_COUNTS=0: a device scalar + item())."""
-    global _words
+_words = {}          # (thread id, device index) -> HostWords: two threads never arm the same word, one word per device
+
+
+def count_via_host_word(launch, device, upper=None):
+    """Runs launch(count_pointer) and returns the count it wrote: through a host-visible word (GSDF_HOST_COUNTS=0: a device scalar + item()).
+    `upper`: the largest plausible count (it is about to be used as an allocation size); anything outside [0, upper] raises."""
     if os.environ.get("GSDF_HOST_COUNTS", "1") == "0":
         n = torch.empty(1, dtype=torch.int64, device=device)
         launch(C.c_void_p(n.data_ptr()))
-        return int(n.item())
-    if _words is None:
-        _words = HostWords(1)
-    _words.arm(0)
-    launch(_words.dev(0))
-    return int(_words.wait(0))
+        v = int(n.item())
+    else:
+        import threading
+        dev = torch.device(device)
+        key = (threading.get_ident(), dev.index if dev.index is not None else torch.cuda.current_device())
+        w = _words.get(key)
+        if w is None:
+            w = _words[key] = HostWords(1)
+        w.arm(0)
+        launch(w.dev(0))
+        v = int(w.wait(0))
+    if v < 0 or (upper is not None and v > upper):
+        raise RuntimeError(f"count_via_host_word: implausible count {v} (expected 0..{upper})")
+    return v
 
 
 def timing_begin(only=None):

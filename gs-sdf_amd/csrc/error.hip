@@ -56,9 +56,11 @@ extern "C" int gsdf_host_words_alloc(int n_words, int64_t **host_view, int64_t *
   GSDF_REQUIRE(n_words > 0 && host_view && device_view, "host_words_alloc: bad arguments");
   void *h = nullptr, *d = nullptr;
   // coherent (fine-grained) pinned memory: device stores are not held back in the L2 until the end of the kernel
-  if (hipHostMalloc(&h, (size_t)n_words * sizeof(int64_t), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) {
+  // portable: the words are mapped on every device of the process (a multi-GPU process may launch on a device other than the one that was
+  // current at allocation time)
+  if (hipHostMalloc(&h, (size_t)n_words * sizeof(int64_t), hipHostMallocMapped | hipHostMallocCoherent | hipHostMallocPortable) != hipSuccess) {
     (void)hipGetLastError();
-    GSDF_HIP(hipHostMalloc(&h, (size_t)n_words * sizeof(int64_t), hipHostMallocMapped), "host_words_alloc");
+    GSDF_HIP(hipHostMalloc(&h, (size_t)n_words * sizeof(int64_t), hipHostMallocMapped | hipHostMallocPortable), "host_words_alloc");
   }
   if (hipHostGetDevicePointer(&d, h, 0) != hipSuccess) {
     (void)hipGetLastError();

@@ -91,7 +91,7 @@ __global__ void __launch_bounds__(SCAN_THREADS) scan_downsweep_kernel(const int3
   }
 }
 
-__global__ void scan_zero_total_kernel(int64_t *total) { *total = 0; }
+__global__ void scan_zero_total_kernel(int64_t *total) { *total = 0; __threadfence_system(); }   // the host may be polling the word
 
 size_t scan_ws_bytes(int64_t n) {
   const int64_t nb = (n + SCAN_TILE - 1) / SCAN_TILE;

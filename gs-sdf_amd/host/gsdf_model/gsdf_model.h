@@ -63,6 +63,9 @@ struct LocalMap : torch::nn::Module {
   std::shared_ptr<TCNNEncoding> p_encoder_tcnn_;   // EncodingMap::p_encoder_tcnn_ (encoding_map.cpp:15-26), parameter "encoder_local_map"
   std::shared_ptr<TCNNNetwork> p_decoder_tcnn_;    // parameter "decoder" (+ "decoder_bias" for decoder_implementation 0)
   float map_size_inv_ = 0.f;
+  // host copies of the map frame for the fused kernels' arguments (origin; the bounds get_inrange_mask tests against): read back once
+  struct HostFrame { float pos[3], lo[3], hi[3]; };
+  const HostFrame &host_frame();
 
   // ---- SubMap (sub_map.cpp)
   void update_octree_as(const torch::Tensor &xyz, bool is_prior = false);                 // :22-35
@@ -91,6 +94,10 @@ struct LocalMap : torch::nn::Module {
   // (local_map.cpp:29-42) — the flat fused-kernel parameters are sliced into / filled from that layout.
   void save(torch::serialize::OutputArchive &archive) const override;
   void load(torch::serialize::InputArchive &archive) override;
+
+ private:
+  HostFrame host_frame_{};
+  bool host_frame_valid_ = false;
 };
 
 // the k_* globals NeuralGS reads (config/base.yaml:37-74)
@@ -169,8 +176,13 @@ struct NeuralGS : torch::nn::Module {
 // (SURVEY 8 a16).  rays: origin / direction [R,3], depth [R,1], xyz = the ray end points.  -> one sample in every occupied voxel a ray
 // crosses [+ free_sample_num stratified free-space samples], surface_sample_num near-surface samples depth - N(0, sample_std), SDF
 // targets truncated to +-truncated_dis, the end points themselves (target 0), everything filtered to the map's inner cube.
+// sample_rays: three fused kernels (gsdf_ray_sampler_count / _fill) + the two torch random draws; sample_rays_composed: the reference's op
+// chain on libtorch + OctreeAS::raymarch (what LocalMap::sample composes; kept as the definition the fused path is tested against;
+// GSDF_FUSED_SAMPLER=0 routes sample_rays through it).  Same generator calls in the same order: identical draws.
 DepthSamples sample_rays(LocalMap &local_map, DepthSamples rays, float sample_std, float truncated_dis, int surface_sample_num = 3,
                          bool sample_free = true);
+DepthSamples sample_rays_composed(LocalMap &local_map, DepthSamples rays, float sample_std, float truncated_dis, int surface_sample_num = 3,
+                                  bool sample_free = true);
 
 // neural_gaussian.cpp:19-127: splat rotation (and optionally opacity) from the SDF's gradient and diagonal Hessian
 std::map<std::string, torch::Tensor> init_gs_with_sdf(LocalMap &local_map, const torch::Tensor &xyzs, float mesh_res, bool init_opa,

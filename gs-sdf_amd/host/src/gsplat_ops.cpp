@@ -55,7 +55,7 @@ struct Projection2DGS : public torch::autograd::Function<Projection2DGS> {
                                       (float)near_plane, (float)far_plane, (float)radius_clip, radii_dense.data_ptr<int32_t>(),
                                       ws.data_ptr(), n_vis, cur_stream()),
             "fully_fused_projection_2dgs(cull)");
-    });
+    }, N * C);
     Tensor camera_ids = empty_like_opts(means, {M}, torch::kInt64), gaussian_ids = empty_like_opts(means, {M}, torch::kInt64);
     Tensor radii = empty_like_opts(means, {M}, torch::kInt32), means2d = empty_like_opts(means, {M, 2}, torch::kFloat32);
     Tensor depths = empty_like_opts(means, {M}, torch::kFloat32), rt = empty_like_opts(means, {M, 3, 3}, torch::kFloat32);
@@ -231,7 +231,7 @@ std::tuple<Tensor, Tensor, Tensor> gsplat_cpp::tile_encode(int width, int height
   const int64_t I = gsdf_host::count_via_host_word(means2d, [&](int64_t *n_is) {
     check(gsdf_tile_count(M, width, height, tile_size, fp(means2d), M ? radii.data_ptr<int32_t>() : nullptr,
                           M ? tpg.data_ptr<int32_t>() : nullptr, cum.data_ptr<int64_t>(), ws.data_ptr(), n_is, cur_stream()), "tile_encode(count)");
-  });
+  }, M * (int64_t)tw * th);
   Tensor ids = empty_like_opts(means2d, {I}, torch::kInt64), flat = empty_like_opts(means2d, {I}, torch::kInt32);
   Tensor offs = empty_like_opts(means2d, {C, th, tw}, torch::kInt32);
   Tensor ws2 = empty_like_opts(means2d, {(int64_t)gsdf_tile_encode_ws_bytes(M, I)}, torch::kUInt8);

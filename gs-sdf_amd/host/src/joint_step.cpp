@@ -445,7 +445,12 @@ std::map<std::string, int64_t> JointIteration::step_direct(const Tensor &viewmat
   gsdf_host::HostWords *cw = gsdf_host::HostWords::enabled() ? streams_->counts.get() : nullptr;
   Tensor dev_counts = cw ? Tensor() : torch::empty({3}, fopt.dtype(torch::kInt64));
   auto count_ptr = [&](int i) { if (cw) { cw->arm(i); return cw->dev(i); } return dev_counts.data_ptr<int64_t>() + i; };
-  auto count_wait = [&](int i) { return cw ? cw->wait(i) : read_i64(dev_counts[i]); };
+  // a count is about to size an allocation: anything outside [0, upper] is refused (a word somebody else wrote, or none at all)
+  auto count_wait = [&](int i, int64_t upper) {
+    const int64_t v = cw ? cw->wait(i) : read_i64(dev_counts[i]);
+    TORCH_CHECK(v >= 0 && v <= upper, "JointIteration: implausible count ", v, " in word ", i, " (expected 0..", upper, ")");
+    return v;
+  };
   check(gsdf_projection_2dgs_cull(N, 1, fp(xyz), fp(quats), fp(scales), fp(viewmat), fp(K), W, H, cfg_.near_plane, cfg_.far_plane, 0.f,
                                   radii_dense.data_ptr<int32_t>(), pws.data_ptr(), count_ptr(0), cur_stream()), "projection(cull)");
   // (while the host waits for M: the zero fill of the backward's scratch and of the two loss values the backward kernels accumulate, the
@@ -456,7 +461,7 @@ std::map<std::string, int64_t> JointIteration::step_direct(const Tensor &viewmat
   Tensor rc = img(3), rd = img(1), ra = img(1), rn = img(3), rm = img(1), fT = torch::empty({1, H, W}, fopt);
   Tensor last = torch::empty({1, H, W}, fopt.dtype(torch::kInt32)), med = torch::empty({1, H, W}, fopt.dtype(torch::kInt32));
   Tensor renders = img(4), nw = img(3), c3 = img(3), d1 = img(1);
-  const int64_t M = count_wait(0);
+  const int64_t M = count_wait(0, N);
   Tensor camera_ids = torch::empty({M}, fopt.dtype(torch::kInt64)), gaussian_ids = torch::empty({M}, fopt.dtype(torch::kInt64));
   Tensor radii = torch::empty({M}, fopt.dtype(torch::kInt32)), means2d = torch::empty({M, 2}, fopt), depths = torch::empty({M}, fopt);
   Tensor rt = torch::empty({M, 3, 3}, fopt), normals = torch::empty({M, 3}, fopt), smp = torch::empty({M, 3}, fopt), sw = torch::empty({M, 1}, fopt);
@@ -481,7 +486,7 @@ std::map<std::string, int64_t> JointIteration::step_direct(const Tensor &viewmat
                              M ? gaussian_ids.data_ptr<int64_t>() : nullptr, fpm(colors), cur_stream()), "view_colors_fwd");
   Tensor vis = torch::empty({M, 1}, fopt);
   Tensor offs = torch::empty({1, (H + 15) / 16, (W + 15) / 16}, fopt.dtype(torch::kInt32));
-  const int64_t I = count_wait(1);
+  const int64_t I = count_wait(1, M * (int64_t)(((W + 15) / 16) * ((H + 15) / 16)));
   Tensor isect_ids = torch::empty({I}, fopt.dtype(torch::kInt64)), flat = torch::empty({I}, fopt.dtype(torch::kInt32));
   {
     Tensor ws2 = torch::empty({(int64_t)gsdf_tile_encode_ws_bytes(M, I)}, fopt.dtype(torch::kUInt8));
@@ -506,7 +511,7 @@ std::map<std::string, int64_t> JointIteration::step_direct(const Tensor &viewmat
   // (while the host waits for n_gs_sdf: the photometric loss, which no size depends on)
   Tensor sums = torch::empty({2}, fopt), maps = torch::empty({3, H, W, 3}, fopt), l_normal = loss_values.narrow(0, 0, 1), l_iso = loss_values[1];
   check(gsdf_l1_dssim_fwd(H, W, fp(c3), fp(target), ssim_window11(), fpm(sums), fpm(maps), cur_stream()), "l1_dssim_fwd");
-  Tensor ids = ids_all.narrow(0, 0, count_wait(2));
+  Tensor ids = ids_all.narrow(0, 0, count_wait(2, M));
   const bool has = ids.numel() > 0;
   streams_->fwd_done.block(streams_->side);
   Tensor samples_cut = samples.detach().requires_grad_(true);

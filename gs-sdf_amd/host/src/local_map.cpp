@@ -133,6 +133,16 @@ void LocalMap::load(torch::serialize::InputArchive &archive) {
 }
 
 // ---- SubMap ----------------------------------------------------------------------------------------------------------------
+const LocalMap::HostFrame &LocalMap::host_frame() {
+  if (!host_frame_valid_) {
+    // the bounds get_inrange_mask compares against (padding 0), computed by the same libtorch operations, read back once
+    Tensor v = torch::cat({pos_W_M_.reshape({-1}), (xyz_min_W_ + 0.f + 1e-6).reshape({-1}), (xyz_max_W_ - 0.f - 1e-6).reshape({-1})}).to(torch::kCPU);
+    const float *p = v.data_ptr<float>();
+    for (int k = 0; k < 3; ++k) { host_frame_.pos[k] = p[k]; host_frame_.lo[k] = p[3 + k]; host_frame_.hi[k] = p[6 + k]; }
+    host_frame_valid_ = true;
+  }
+  return host_frame_;
+}
 Tensor LocalMap::xyz_to_m1p1_pts(const Tensor &xyz) const { return (xyz - pos_W_M_) * 2 * map_size_inv_; }
 Tensor LocalMap::m1p1_pts_to_xyz(const Tensor &pts) const { return scale_from_m1p1(pts) + pos_W_M_; }
 Tensor LocalMap::scale_from_m1p1(const Tensor &t) const { return t * 0.5 * (1.0 / map_size_inv_); }
@@ -262,7 +272,7 @@ DepthSamples LocalMap::filter_sample(const DepthSamples &samples) {
   return samples.index_select((p_acc_strcut_occ_->query(xyz_to_m1p1_pts(samples.xyz)).pidx > -1).nonzero().reshape({-1}));
 }
 
-DepthSamples sample_rays(LocalMap &local_map, DepthSamples rays, float sample_std, float truncated_dis, int surface_sample_num,
+DepthSamples sample_rays_composed(LocalMap &local_map, DepthSamples rays, float sample_std, float truncated_dis, int surface_sample_num,
                          bool sample_free) {
   const int64_t n = rays.size(0);
   auto dev = rays.origin.device();
@@ -284,6 +294,51 @@ DepthSamples sample_rays(LocalMap &local_map, DepthSamples rays, float sample_st
   pts.ray_sdf = torch::where(pts.ray_sdf.abs() > truncated_dis, pts.ray_sdf.sign() * truncated_dis, pts.ray_sdf);
   pts = pts.cat(rays);
   return pts.index_select(local_map.get_inrange_mask(pts.xyz).nonzero().reshape({-1}));
+}
+
+
+// The same batch in three kernels (count per ray and segment, one-workgroup scan, fill: csrc/occupancy.hip ray_sampler_kernel) + the two
+// random draws, which stay torch's: rand [n, F] first, randn [n, S, 1] second — the generator calls of the composition above (and of the
+// reference's NeuralSLAM::sample), so both paths place every sample identically.  Rows come in the composition's order.
+DepthSamples sample_rays(LocalMap &local_map, DepthSamples rays, float sample_std, float truncated_dis, int surface_sample_num,
+                         bool sample_free) {
+  using namespace gsdf_host;
+  static const bool composed = [] { const char *e = getenv("GSDF_FUSED_SAMPLER"); return e && e[0] == '0'; }();
+  const int F = sample_free ? local_map.cfg_.free_sample_num : 0, S = surface_sample_num;
+  if (composed || F > 64 || S > 64 || F < 0 || S < 0) return sample_rays_composed(local_map, rays, sample_std, truncated_dis, surface_sample_num, sample_free);
+  torch::NoGradGuard ng;
+  TORCH_CHECK(local_map.p_acc_strcut_occ_ != nullptr, "sample_rays: update_octree_as has not been called");
+  Tensor origin = f32c(rays.origin.detach(), "rays.origin"), direction = f32c(rays.direction.detach(), "rays.direction");
+  Tensor depth = f32c(rays.depth.detach(), "rays.depth"), end = f32c(rays.xyz.detach(), "rays.xyz");
+  const int64_t n = origin.size(0);
+  TORCH_CHECK(origin.dim() == 2 && origin.size(1) == 3 && direction.sizes() == origin.sizes() && end.sizes() == origin.sizes() && depth.numel() == n,
+              "sample_rays: expected origin / direction / xyz [n,3] and depth [n,1]");
+  Tensor rf = F > 0 ? torch::rand({n, F}, origin.options()) : Tensor();
+  Tensor rs = torch::randn({n, S, 1}, origin.options());
+  gsdf_ray_sampler_args a{};
+  a.level = local_map.p_acc_strcut_occ_->max_level_;
+  a.n_rays = n;
+  a.origin = fp(origin); a.direction = fp(direction); a.depth = fp(depth); a.end_xyz = fp(end);
+  a.grid = local_map.p_acc_strcut_occ_->grid_.data_ptr();
+  a.rand_free = F > 0 ? fp(rf) : nullptr; a.randn_surf = fp(rs);
+  a.free_sample_num = F; a.surface_sample_num = S;
+  const LocalMap::HostFrame &hf = local_map.host_frame();
+  for (int k = 0; k < 3; ++k) { a.map_origin[k] = hf.pos[k]; a.range_lo[k] = hf.lo[k]; a.range_hi[k] = hf.hi[k]; }
+  a.map_size_inv = local_map.map_size_inv_;
+  a.map_half = (float)(1.0 / (double)local_map.map_size_inv_);      // scale_from_m1p1: t * 0.5 * (1.0 / map_size_inv_), the scalar rounded to fp32
+  a.sample_std = sample_std; a.truncated_dis = truncated_dis;
+  Tensor counts = empty_like_opts(origin, {4 * n}, torch::kInt32), incl = empty_like_opts(origin, {4 * n}, torch::kInt64);
+  const int64_t B = count_via_host_word(origin, [&](int64_t *total) {
+    check(gsdf_ray_sampler_count(&a, n ? counts.data_ptr<int32_t>() : nullptr, n ? incl.data_ptr<int64_t>() : nullptr, total, cur_stream()), "sample_rays (count)");
+  }, n * (int64_t)(3 * ((int64_t)1 << a.level) + F + S + 1));      // <= 3 cells per slab of the major axis + the other three segments
+  DepthSamples out;
+  out.xyz = empty_like_opts(origin, {B, 3}, torch::kFloat32); out.ray_sdf = empty_like_opts(origin, {B, 1}, torch::kFloat32);
+  out.ridx = empty_like_opts(origin, {B}, torch::kInt64); out.origin = empty_like_opts(origin, {B, 3}, torch::kFloat32);
+  out.direction = empty_like_opts(origin, {B, 3}, torch::kFloat32); out.depth = empty_like_opts(origin, {B, 1}, torch::kFloat32);
+  if (B > 0)
+    check(gsdf_ray_sampler_fill(&a, counts.data_ptr<int32_t>(), incl.data_ptr<int64_t>(), fpm(out.xyz), fpm(out.ray_sdf), out.ridx.data_ptr<int64_t>(),
+                                fpm(out.origin), fpm(out.direction), fpm(out.depth), cur_stream()), "sample_rays (fill)");
+  return out;
 }
 
 }  // namespace gsdf_model

@@ -322,6 +322,10 @@ PYBIND11_MODULE(_gsdf_host, m) {
                                                   bool sample_free) {
     return from_samples(gm::sample_rays(*lm, to_samples(rays), sample_std, truncated_dis, surface_sample_num, sample_free));
   });
+  m.def("sample_rays_composed", [to_samples, from_samples](gm::LocalMap::Ptr lm, const py::dict &rays, float sample_std, float truncated_dis,
+                                                           int surface_sample_num, bool sample_free) {
+    return from_samples(gm::sample_rays_composed(*lm, to_samples(rays), sample_std, truncated_dis, surface_sample_num, sample_free));
+  });
   m.def("init_gs_with_sdf", [](gm::LocalMap::Ptr lm, const torch::Tensor &xyz, float mesh_res, bool init_opa, int64_t batch) {
     return gm::init_gs_with_sdf(*lm, xyz, mesh_res, init_opa, batch);
   });

@@ -3,6 +3,7 @@
 #include <c10/hip/HIPStream.h>
 
 #include <chrono>
+#include <map>
 #include <torch/torch.h>
 
 #include "gsdf_hip.h"
@@ -35,6 +36,14 @@ inline int64_t read_i64(const torch::Tensor &dev_scalar) { return dev_scalar.ite
 // gsdf_host_words_alloc): words of pinned, device-mapped host memory.  arm(i) before the launch that writes word i, pass dev(i) as the
 // operator's count output, queue whatever does not depend on the count, then wait(i).  The poll falls back to a stream synchronisation
 // after ~2 ms (a store that is only made visible by the end of the queue's work still gets read).
+inline void cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+  __builtin_ia32_pause();
+#elif defined(__aarch64__)
+  __asm__ __volatile__("yield");
+#endif
+}
+
 class HostWords {
  public:
   explicit HostWords(int n) : n_(n) { check(gsdf_host_words_alloc(n, &host_, &dev_), "host_words_alloc"); }
@@ -54,7 +63,7 @@ class HostWords {
         TORCH_CHECK(w != kArmed, "HostWords: the count was never written");
         return w;
       }
-      __builtin_ia32_pause();
+      cpu_relax();
     }
   }
   static bool enabled() {
@@ -70,17 +79,28 @@ class HostWords {
 
 // One count through the calling thread's own word (the operator-level functions: cull -> M -> fill, count -> I -> encode): `launch` receives
 // the pointer to pass as the operator's count output and returns after queueing it.
+// `upper`: the largest count the caller can make sense of (it is about to be used as an allocation size): anything outside [0, upper] means the
+// word was written by someone else or not at all, and is refused instead of allocated.
 template <class F>
-inline int64_t count_via_host_word(const torch::Tensor &like, F &&launch) {
+inline int64_t count_via_host_word(const torch::Tensor &like, F &&launch, int64_t upper = INT64_MAX) {
+  int64_t v;
   if (!HostWords::enabled()) {
     torch::Tensor n = torch::empty({1}, like.options().dtype(torch::kInt64).requires_grad(false));
     launch(n.data_ptr<int64_t>());
-    return read_i64(n);
+    v = read_i64(n);
+  } else {
+    // one word per (thread, device): two threads never arm the same word, and a thread that moves between devices gets a word per device
+    // (never freed: a thread's exit may come after the HIP runtime's)
+    static thread_local std::map<int, HostWords *> words;
+    const int dev = like.is_cuda() ? (int)like.get_device() : (int)c10::hip::current_device();
+    HostWords *&w = words[dev];
+    if (w == nullptr) w = new HostWords(1);
+    w->arm(0);
+    launch(w->dev(0));
+    v = w->wait(0);
   }
-  static thread_local HostWords *words = new HostWords(1);   // (never freed: a thread's exit may come after the HIP runtime's)
-  words->arm(0);
-  launch(words->dev(0));
-  return words->wait(0);
+  TORCH_CHECK(v >= 0 && v <= upper, "count_via_host_word: implausible count ", v, " (expected 0..", upper, ")");
+  return v;
 }
 
 }  // namespace gsdf_host

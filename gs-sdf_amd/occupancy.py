@@ -101,7 +101,7 @@ class OctreeAS:
         ws = torch.empty(L.gsdf_visible_set_ws_bytes(n), dtype=torch.uint8, device=xyz.device)
         n_valid = capi.count_via_host_word(lambda count: capi.check(
             L.gsdf_visible_set(self.level, -1 if level is None else int(level), n, f32(xyz), (C.c_float * 3)(*origin), float(map_size_inv), ptr(self.grid),
-                               f32(vis), f32(sw), float(vis_thresh), f32(w_all), ptr(ids), count, ptr(ws), capi.stream()), "visible_set"), xyz.device)
+                               f32(vis), f32(sw), float(vis_thresh), f32(w_all), ptr(ids), count, ptr(ws), capi.stream()), "visible_set"), xyz.device, upper=n)
         return ids[:n_valid], w_all
 
     def get_quantized_points(self):

@@ -82,7 +82,7 @@ class _Projection2DGS(torch.autograd.Function):
         M = capi.count_via_host_word(lambda n_vis: capi.check(
             _timed("projection_2dgs_cull", L.gsdf_projection_2dgs_cull, N, C, f32(means, "means"), f32(quats, "quats"), f32(scales, "scales"),
                    f32(viewmats, "viewmats"), f32(Ks, "Ks"), width, height, near_plane, far_plane, radius_clip, ptr(radii_dense), ptr(ws), n_vis,
-                   capi.stream()), "projection_2dgs_cull"), dev)
+                   capi.stream()), "projection_2dgs_cull"), dev, upper=N * C)
         camera_ids = _empty((M,), torch.int64, means); gaussian_ids = _empty((M,), torch.int64, means)
         radii = _empty((M,), torch.int32, means); means2d = _empty((M, 2), torch.float32, means)
         depths = _empty((M,), torch.float32, means); rt = _empty((M, 3, 3), torch.float32, means)
@@ -191,7 +191,7 @@ def tile_encode(width, height, tile_size, means2d, radii, depths, packed, C, cam
     ws = torch.empty(L.gsdf_tile_count_ws_bytes(M), dtype=torch.uint8, device=dev)
     I = capi.count_via_host_word(lambda n_is: capi.check(
         _timed("tile_count", L.gsdf_tile_count, M, width, height, tile_size, f32(means2d), ptr(radii, torch.int32), ptr(tpg), ptr(cum), ptr(ws), n_is,
-               capi.stream()), "tile_count"), dev)
+               capi.stream()), "tile_count"), dev, upper=M * tw * th)
     isect_ids = _empty((I,), torch.int64, means2d); flatten_ids = _empty((I,), torch.int32, means2d)
     offsets = _empty((C, th, tw), torch.int32, means2d)
     ws2 = torch.empty(L.gsdf_tile_encode_ws_bytes(M, I), dtype=torch.uint8, device=dev)

@@ -40,7 +40,7 @@ const char *gsdf_last_error(void);
 /* ABI version; bumped on any signature change.  Every binding compares gsdf_abi_version() of the library it loaded with the
  * GSDF_ABI_VERSION of the header it was written against and refuses to run on a mismatch (gs_sdf_amd/capi.py: lib(); the C++
  * operator layer: gsplat_ops.cpp static initialiser): a stale libgsdf_hip.so fails at load, not on the device. */
-#define GSDF_ABI_VERSION 5
+#define GSDF_ABI_VERSION 6
 int gsdf_abi_version(void);
 
 /* Optional per-entry-point device timing (bench.py's roofline leg, for callers in any language): between gsdf_timing_begin and
@@ -426,6 +426,7 @@ int gsdf_sdf_ray_loss(int64_t n, int stencil, const float *attr, int ld, const f
  *              (origin + t*dir, t >= 0) crosses, front to back.  fill: voxel_offsets = exclusive scan of counts (int64);
  *              for the v-th voxel of ray r and k < num_samples, row j = (voxel_offsets[r]+v)*num_samples + k:
  *              ridx[j] = r, depth_samples[j] = t_in + (t_out-t_in)(k+1/2)/num_samples, samples[j] = origin + t*dir.
+ *              One wave per ray, one slab of the ray's major axis per lane (<= 3 cells per slab): csrc/occupancy.hip.
  * ---------------------------------------------------------------------------------------- */
 size_t gsdf_occ_bytes(int level);
 int gsdf_occ_build(int level, int64_t n_points, const float *xyz_m1p1, int dilate27, void *grid, gsdf_stream_t stream);
@@ -449,6 +450,36 @@ int gsdf_occ_raymarch_count(int level, int64_t n_rays, const float *origins_m1p1
 int gsdf_occ_raymarch_fill(int level, int64_t n_rays, const float *origins_m1p1, const float *dirs, const void *grid,
                            const int64_t *voxel_offsets, int num_samples, int32_t *ridx, float *samples,
                            float *depth_samples, gsdf_stream_t stream);
+
+/* The reference's per-ray SDF batch in two passes over the rays instead of ~60 libtorch launches:
+ *   NeuralSLAM::sample          include/neural_mapping/neural_mapping.cpp:73-104
+ *   LocalMap::sample            include/neural_net/local_map.cpp:449-509   (1 sample per occupied voxel crossed + free samples, ray_sdf > 0 kept)
+ *   utils::sample_surface_pts / sample_free_pts   include/utils/utils.cpp:336-393
+ *   SubMap::get_inrange_mask    include/neural_net/sub_map.cpp:37-45
+ * Rays: origin / direction [n,3], depth [n,1], end_xyz [n,3] in the WORLD frame.  The random numbers stay the caller's (torch's generator,
+ * drawn in the reference's order): rand_free [n, free_sample_num] U[0,1), randn_surf [n, surface_sample_num] N(0,1).  map_origin (3 host
+ * floats), map_size_inv, map_half = 1 / map_size_inv define SubMap's frames: m1p1 = ((x - origin) * 2) * map_size_inv,
+ * world = (m1p1 * 0.5) * map_half + origin.  range_lo / range_hi: get_inrange_mask keeps lo < xyz < hi (its own padded bounds).
+ * Output rows, in the reference's order: [voxel samples: rays in order, front to back | free samples, ray-major | surface samples,
+ * ray-major | ray end points], the first two segments filtered by ray_sdf > 0, targets of the first three truncated to +-truncated_dis,
+ * everything filtered by the in-range test.  Every elementwise operation is the reference's, in its order, in fp32.
+ *   count: counts [4][n] int32 (kept rows per segment and ray), offsets_incl [4 n] int64 = inclusive scan of counts, *total = rows
+ *          (total may be a host-visible word, gsdf_host_words_alloc).  Two launches.
+ *   fill:  writes the rows (xyz [B,3], ray_sdf [B,1], ridx [B] int64, origin / direction [B,3], depth [B,1]).  One launch. */
+typedef struct {
+  int level;
+  int64_t n_rays;
+  const float *origin, *direction, *depth, *end_xyz;
+  const void *grid;
+  const float *rand_free, *randn_surf;
+  int free_sample_num, surface_sample_num;
+  float map_origin[3], map_size_inv, map_half;
+  float range_lo[3], range_hi[3];
+  float sample_std, truncated_dis;
+} gsdf_ray_sampler_args;
+int gsdf_ray_sampler_count(const gsdf_ray_sampler_args *args, int32_t *counts, int64_t *offsets_incl, int64_t *total, gsdf_stream_t stream);
+int gsdf_ray_sampler_fill(const gsdf_ray_sampler_args *args, const int32_t *counts, const int64_t *offsets_incl, float *xyz, float *ray_sdf,
+                          int64_t *ridx, float *origin, float *direction, float *depth, gsdf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * M1  marching cubes on a dense scalar grid [res_x][res_y][res_z] (x slowest): replaces mc::marching_cubes of the

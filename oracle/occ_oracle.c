@@ -107,9 +107,17 @@ int64_t orc_occ_list(int L, const uint32_t *grid, int16_t *out) {
   return v;
 }
 
-#define OCC_EPS 1e-3f
-
-/* One ray.  Returns the number of occupied level-L voxels it crosses; when t_io != NULL writes their (t_in, t_out). */
+/* One ray: the occupied level-L voxels it crosses, front to back, by SLABS of the ray's major axis (DESIGN.md SPEC A.9, round 5).
+ * Grid frame: g(s) = go + u s, |u| = 1, s in [s0, s1] = the ray inside the cube [0, res]^3.  m = the axis with the largest |u| (first on
+ * ties).  Slab k (cells with c[m] = k) is crossed for s in [sa, sb] = the two planes g_m = k, k + 1, clipped to [s0, s1]; inside a slab
+ * the ray advances at most one cell along either minor axis, so the slab holds at most three cells, separated by at most one integer
+ * crossing per minor axis (t = (plane - go[a]) / u[a], clamped to the slab).  Each sub-interval of positive length is one cell: its minor
+ * coordinates are floor(g(mid)) of the sub-interval's midpoint (robust: never decided at a boundary), neighbouring sub-intervals that land
+ * in the same cell are merged.  An occupied cell reports (t_in, t_out) = its sub-interval / len.  Slabs are independent of each other:
+ * the HIP kernel (csrc/occupancy.hip: occ_march_wave) gives one slab to each lane of a wave and mirrors this arithmetic operation for
+ * operation (fp32, no contraction) -> bit-identical samples.
+ * Returns the number of voxels; when t_io != NULL writes their (t_in, t_out). */
+static inline int clampi(float v, int res) { const int c = (int)v; return c < 0 ? 0 : (c > res - 1 ? res - 1 : c); }
 static int march(int L, const float *o, const float *d, const uint32_t *grid, float *t_io) {
   const int res = 1 << L;
   const float half = 0.5f * (float)res;
@@ -131,47 +139,60 @@ static int march(int L, const float *o, const float *d, const uint32_t *grid, fl
     }
   }
   if (!(s0 < s1)) return 0;
-  const int lv[3] = {L - 6, L - 3, L};
-  float s = s0;
+  int m = 0;
+  if (fabsf(u[1]) > fabsf(u[m])) m = 1;
+  if (fabsf(u[2]) > fabsf(u[m])) m = 2;
+  const int ax[2] = {(m + 1) % 3, (m + 2) % 3};
+  const float um = u[m];
+  const int k0 = clampi(floorf(go[m] + um * s0), res), k1 = clampi(floorf(go[m] + um * s1), res);
+  const int dir = um > 0.f ? 1 : -1;
+  const int nsl = (k1 - k0) * dir + 1;
   int n = 0;
-  for (int it = 0; it < 8 * res + 64 && s < s1; ++it) {
-    const float sp = s + OCC_EPS;
-    int c[3];
-    for (int a = 0; a < 3; ++a) {
-      int v = (int)floorf(go[a] + u[a] * sp);
-      c[a] = v < 0 ? 0 : (v > res - 1 ? res - 1 : v);
-    }
-    int hit = 0;
-    float s_out = s1;
-    for (int k = 0; k < 3; ++k) {
-      const int l = lv[k];
-      if (l < 1) continue;
-      const int sh = L - l;
-      const int occ = get_bit(grid, l, c[0] >> sh, c[1] >> sh, c[2] >> sh);
-      if (occ && l < L) continue; /* descend */
-      /* empty cell at level l (skip it), or occupied voxel at level L (record it): exit distance of that cell */
-      float e = INFINITY, in = -INFINITY;
-      for (int a = 0; a < 3; ++a) {
-        if (u[a] == 0.f) continue;
-        const float lo = (float)((c[a] >> sh) << sh), hi = lo + (float)(1 << sh);
-        const float ex = ((u[a] > 0.f ? hi : lo) - go[a]) / u[a], en = ((u[a] > 0.f ? lo : hi) - go[a]) / u[a];
-        if (ex < e) e = ex;
-        if (en > in) in = en;
-      }
-      s_out = e;
-      if (occ) {
-        hit = 1;
-        if (in < s0) in = s0;
-        if (e > s1) e = s1;
-        if (e > in) {
-          if (t_io) { t_io[2 * n] = in / len; t_io[2 * n + 1] = e / len; }
-          ++n;
+  for (int i = 0; i < nsl; ++i) {
+    const int k = k0 + dir * i;
+    const float lo = (float)k, hi = lo + 1.0f;
+    float sa = ((um > 0.f ? lo : hi) - go[m]) / um, sb = ((um > 0.f ? hi : lo) - go[m]) / um;
+    if (sa < s0) sa = s0;
+    if (sb > s1) sb = s1;
+    if (!(sb > sa)) continue;
+    float tb[2];
+    for (int q = 0; q < 2; ++q) {
+      const int a = ax[q];
+      tb[q] = sb;
+      if (u[a] != 0.f) {
+        const float ia = floorf(go[a] + u[a] * sa), ib = floorf(go[a] + u[a] * sb);
+        if (ia != ib) {
+          float tt = ((u[a] > 0.f ? ia + 1.0f : ia) - go[a]) / u[a];
+          if (tt < sa) tt = sa;
+          if (tt > sb) tt = sb;
+          tb[q] = tt;
         }
       }
-      break;
     }
-    (void)hit;
-    s = s_out > sp ? s_out : sp; /* always progress */
+    const float b[4] = {sa, tb[0] < tb[1] ? tb[0] : tb[1], tb[0] < tb[1] ? tb[1] : tb[0], sb};
+    float in[3], e[3];
+    int c1[3], c2[3], valid[3];
+    for (int j = 0; j < 3; ++j) {
+      in[j] = b[j]; e[j] = b[j + 1];
+      valid[j] = e[j] > in[j];
+      const float mid = (in[j] + e[j]) * 0.5f;
+      c1[j] = clampi(floorf(go[ax[0]] + u[ax[0]] * mid), res);
+      c2[j] = clampi(floorf(go[ax[1]] + u[ax[1]] * mid), res);
+    }
+    /* merge neighbours that landed in the same cell (a breakpoint that did not separate two cells) */
+    if (valid[0] && valid[1] && c1[0] == c1[1] && c2[0] == c2[1]) { in[1] = in[0]; valid[0] = 0; }
+    {
+      const int pj = valid[1] ? 1 : 0;
+      if (valid[2] && valid[pj] && c1[pj] == c1[2] && c2[pj] == c2[2]) { in[2] = in[pj]; valid[pj] = 0; }
+    }
+    for (int j = 0; j < 3; ++j) {
+      if (!valid[j]) continue;
+      int c[3];
+      c[m] = k; c[ax[0]] = c1[j]; c[ax[1]] = c2[j];
+      if (!get_bit(grid, L, c[0], c[1], c[2])) continue;
+      if (t_io) { t_io[2 * n] = in[j] / len; t_io[2 * n + 1] = e[j] / len; }
+      ++n;
+    }
   }
   return n;
 }

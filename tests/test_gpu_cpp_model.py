@@ -356,3 +356,54 @@ def test_cpp_local_map_checkpoint_round_trips_with_the_python_mirror(host, tmp_p
     with pytest.raises(RuntimeError):
         load_local_map_checkpoint(pm, p3)
     assert torch.equal(pm.encoder.params_, before[0]) and torch.equal(pm.decoder.params_, before[1])
+
+
+@pytest.mark.parametrize("free,S,scene", [(True, 3, "wall"), (False, 3, "wall"), (True, 0, "wall"), (True, 5, "edge")])
+def test_fused_ray_sampler_is_the_composed_op_chain_row_for_row(host, free, S, scene):
+    """gsdf_model::sample_rays (three fused kernels + the two torch draws: gsdf_ray_sampler_count / _fill) against sample_rays_composed (the
+    reference's op chain NeuralSLAM::sample on libtorch + OctreeAS::raymarch, neural_mapping.cpp:73-104) under the same generator state: the
+    same rows in the same order — ridx identical, every float field bit-identical (the kernels evaluate the chain's elementwise operations in
+    its order in fp32).  `edge`: rays that start outside the map cube, miss it, run along an axis, or end outside the inner cube."""
+    dev = torch.device("cuda:0")
+    cm, pm, cfg = make_maps(host, 1)
+    g = torch.Generator(device=dev).manual_seed(21)
+    n = 3000
+    origin = torch.tensor([0.0, 0.0, 5.5], device=dev).expand(n, 3).contiguous()
+    direction = torch.nn.functional.normalize(torch.randn(n, 3, device=dev, generator=g) * torch.tensor([0.5, 0.5, 0.1], device=dev)
+                                              + torch.tensor([0.0, 0.0, 1.0], device=dev), dim=-1)
+    depth = 3.0 + torch.rand(n, 1, device=dev, generator=g)
+    if scene == "edge":
+        origin = origin.clone()
+        origin[:300] += torch.tensor([30.0, 0.0, 0.0], device=dev)              # outside the cube, most miss it
+        origin[300:600] += (torch.rand(300, 3, device=dev, generator=g) - 0.5) * 40.0
+        direction = direction.clone()
+        direction[600:700] = torch.tensor([0.0, 0.0, 1.0], device=dev)          # axis-parallel
+        direction[700:800] = torch.tensor([1.0, 0.0, 0.0], device=dev)
+        depth = depth.clone()
+        depth[800:1000] = 20.0                                                  # end points outside the inner cube
+        depth[1000:1010] = 0.0                                                  # zero-length rays: no free sample survives ray_sdf > 0
+    pts = origin + direction * depth
+    cm.update_octree_as(pts[:2000] if scene == "edge" else pts, False)
+    rays = dict(origin=origin, direction=direction, depth=depth, xyz=pts)
+    torch.manual_seed(99)
+    a = host.sample_rays(cm, rays, 0.02, 0.1875, S, free)
+    state_after_fused = torch.cuda.get_rng_state()
+    torch.manual_seed(99)
+    b = host.sample_rays_composed(cm, rays, 0.02, 0.1875, S, free)
+    assert torch.equal(state_after_fused, torch.cuda.get_rng_state()), "the two paths consume the generator differently"
+    assert sorted(a) == sorted(b) and {"origin", "direction", "depth", "xyz", "ray_sdf", "ridx"} <= set(a)
+    assert a["ridx"].shape == b["ridx"].shape and a["ridx"].shape[0] > (n if scene == "wall" else 100)
+    assert torch.equal(a["ridx"], b["ridx"]), "row order differs"
+    for k in ("xyz", "ray_sdf", "depth", "origin", "direction"):
+        assert a[k].shape == b[k].shape, k
+        assert torch.equal(a[k], b[k]), (k, float((a[k] - b[k]).abs().max()))
+    assert float(a["ray_sdf"].abs().max()) <= 0.1875 and bool(cm.get_inrange_mask(a["xyz"]).all())
+
+
+def test_fused_ray_sampler_empty_batch(host):
+    dev = torch.device("cuda:0")
+    cm, pm, cfg = make_maps(host, 1)
+    cm.update_octree_as(torch.rand(100, 3, device=dev) + torch.tensor([0.0, 0.0, 5.0], device=dev), False)
+    z = torch.zeros(0, 3, device=dev)
+    out = host.sample_rays(cm, dict(origin=z, direction=z, depth=torch.zeros(0, 1, device=dev), xyz=z), 0.02, 0.1875, 3, True)
+    assert out["xyz"].shape == (0, 3) and out["ridx"].shape == (0,) and out["ridx"].dtype == torch.int64
