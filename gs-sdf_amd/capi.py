@@ -90,6 +90,9 @@ _SIGS = {
     "gsdf_occ_voxel_list": (C.c_int, [_i32, _vp, _vp, _vp, _vp]),
     "gsdf_occ_raymarch_count": (C.c_int, [_i32, _i64, _vp, _vp, _vp, _vp, _vp]),
     "gsdf_occ_raymarch_fill": (C.c_int, [_i32, _i64, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp]),
+    "gsdf_refine_ws_bytes": (C.c_size_t, [_i64]),
+    "gsdf_refine_plan": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
+    "gsdf_refine_apply": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gsdf_ray_sampler_count": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),                      # (const gsdf_ray_sampler_args *, counts, offsets_incl, total, stream)
     "gsdf_ray_sampler_fill": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gsdf_mc_count": (C.c_int, [_i32, _i32, _i32, _i32, _vp, _f32, _vp, _vp, _vp]),

@@ -106,6 +106,13 @@ class FusedAdam {
   void set_lr(int group, int segment, double lr) { groups_.at(group).lrs.at(segment) = (float)lr; }
   void step(bool zero_grad = false);   // zero_grad: the gradient buffers are zeroed as they are consumed (no fill launches)
   int64_t step_count() const { return t_; }
+  // refinement (optimizer_utils.cpp:5-165 on flat buffers): the group's buffers are replaced by re-materialised ones of another row count;
+  // `sizes` = the new segment sizes (learning rates are kept); the step count is kept, as torch::optim::Adam's per-parameter state keeps it
+  void replace_group(int group, const torch::Tensor &flat, const torch::Tensor &flat_grad, const torch::Tensor &m, const torch::Tensor &v,
+                     const std::vector<int64_t> &sizes);
+  torch::Tensor exp_avg(int group) const { return groups_.at(group).m; }
+  torch::Tensor exp_avg_sq(int group) const { return groups_.at(group).v; }
+  void zero_segment_moments(int group, int segment);   // reset_optimizer of one parameter (reset_opacity, neural_gaussian.cpp:918-926)
 
  private:
   struct Group {
@@ -143,7 +150,19 @@ struct JointConfig {
   bool two_streams = false;   // the SDF network's work on a second HIP stream beside the splat leg (bench.py's overlapped schedule)
 };
 
+// the refinement policy's configuration: GSConfig's fields (config/base.yaml:60-74) + the scene scale NeuralGS keeps (neural_gaussian.cpp:286-290)
+struct RefineConfig {
+  float prune_opa = 0.05f, grow_grad2d = 0.0002f, grow_scale3d = 0.01f, grow_scale2d = 0.05f, prune_scale3d = 0.1f;
+  int refine_scale2d_stop_iter = 0, refine_start_iter = 500, refine_every = 100, reset_every = 3000, pause_refine_after_reset = 0;
+  float spatial_scale = 1.f, original_spatial_scale = 1.f;
+  int num_train_data = 1;
+};
+
 struct JointStreams;
+struct RefinePlanArgs;
+}  // namespace gsdf_extras
+namespace gsdf_host { class HostWords; }
+namespace gsdf_extras {
 class JointIteration {
  public:
   ~JointIteration();
@@ -169,6 +188,21 @@ class JointIteration {
   void set_grad_hooks(std::function<void(torch::Tensor)> splat_hook, std::function<void(torch::Tensor)> sdf_hook) {
     splat_hook_ = std::move(splat_hook); sdf_hook_ = std::move(sdf_hook);
   }
+  // ---- refinement on the flat buffers (csrc/refine.hip) -------------------------------------------------------------
+  // NeuralGS::train_callback's structural part (neural_gaussian.cpp:568-618) for iteration `iter` (call it after step(): update_state has run):
+  // prune_invisible_gs every num_train_data iterations; grow_gs + prune_gs + zero_state when iter > refine_start_iter, iter % refine_every == 0
+  // and (iter % reset_every) >= pause_refine_after_reset; reset_opacity every reset_every.  -> {"n_dupli","n_split","n_prune","n_invisible","N"}
+  std::map<std::string, int64_t> train_callback(int iter, int total_iter, const RefineConfig &rc);
+  // grow_gs (duplicate + split) + prune_gs + zero_state as ONE row map: two kernels over the rows, the four counts in host-visible words
+  std::map<std::string, int64_t> refine(int iter, const RefineConfig &rc);
+  int64_t prune_rows(const torch::Tensor &mask);     // rows with mask != 0 leave (prune_invisible_gs / prune_nan_gs); -> rows removed
+  void reset_opacity(const RefineConfig &rc);        // :918-926: opacity logits clamped to logit(2 prune_opa), fresh moments
+  // View-parallel: called with the densification statistics before any decision is taken (sum grad2d / count, max vis / radii over the ranks)
+  void set_refine_hook(std::function<void(std::map<std::string, torch::Tensor> &)> hook) { refine_hook_ = std::move(hook); }
+  torch::Tensor anchors() const { return anchors_; }
+  std::map<std::string, torch::Tensor> &state() { return state_; }
+  std::vector<torch::Tensor> splat_adam_moments() const { return {adam_.exp_avg(0), adam_.exp_avg_sq(0)}; }
+  int64_t n_splats() const { return anchors_.size(0); }
   torch::Tensor splat_flat() const { return flat_; }
   torch::Tensor splat_flat_grad() const { return flat_grad_; }
   torch::Tensor sdf_flat() { sync(); return sdf_flat_; }
@@ -188,11 +222,17 @@ class JointIteration {
   int64_t n_rest_ = 0;
   torch::Tensor anchors_, flat_, flat_grad_, sdf_flat_, sdf_flat_grad_, occ_grid_, nan_total_;
   int64_t n_table_ = 0, n_dec_ = 0, n_bias_ = 0;
+  std::vector<int64_t> field_cols_;                    // columns per row of the six fields (3, 3, 4, 1, 3, 3 r)
+  std::vector<std::vector<int64_t>> field_shapes_;     // their trailing shapes
+  std::unique_ptr<gsdf_host::HostWords> refine_words_;
   std::vector<torch::Tensor> views_;
   std::map<std::string, torch::Tensor> state_;
   FusedAdam adam_, adam_sdf_;
   std::unique_ptr<JointStreams> streams_;
   std::function<void(torch::Tensor)> splat_hook_, sdf_hook_;
+  std::function<void(std::map<std::string, torch::Tensor> &)> refine_hook_;
+  std::map<std::string, int64_t> apply_row_map(RefinePlanArgs &pa);   // plan -> totals -> new buffers -> apply -> rebind
+  void bind_views(const torch::Tensor &flat, const torch::Tensor &flat_grad, int64_t n);
   // the splat leg without the autograd engine (step_direct): loss weights as device scalars, a never-written zero image, scratch
   torch::Tensor w_one_, w_normal_, w_iso_, zero_image_, scratch_;
   std::vector<torch::Tensor> last_losses_;

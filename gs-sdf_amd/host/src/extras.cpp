@@ -490,4 +490,23 @@ void FusedAdam::step(bool zero_grad) {
           "adam_step");
 }
 
+void FusedAdam::replace_group(int group, const Tensor &flat, const Tensor &flat_grad, const Tensor &m, const Tensor &v, const std::vector<int64_t> &sizes) {
+  Group &g = groups_.at(group);
+  TORCH_CHECK(sizes.size() == g.lrs.size(), "FusedAdam::replace_group: ", sizes.size(), " segments, the group has ", g.lrs.size());
+  TORCH_CHECK(flat.is_cuda() && flat.is_contiguous() && flat.scalar_type() == torch::kFloat32 && flat_grad.sizes() == flat.sizes() &&
+              m.sizes() == flat.sizes() && v.sizes() == flat.sizes(), "FusedAdam::replace_group: flat fp32 device buffers of one size expected");
+  int64_t off = 0;
+  for (size_t i = 0; i < sizes.size(); ++i) { g.begins[i] = off; off += sizes[i]; }
+  TORCH_CHECK(off == flat.numel(), "FusedAdam::replace_group: segments cover ", off, " of ", flat.numel(), " elements");
+  g.flat = flat; g.grad = flat_grad; g.m = m; g.v = v;
+}
+
+void FusedAdam::zero_segment_moments(int group, int segment) {
+  Group &g = groups_.at(group);
+  const int64_t b = g.begins.at(segment), e = (size_t)segment + 1 < g.begins.size() ? g.begins[segment + 1] : g.flat.numel();
+  torch::NoGradGuard ng;
+  g.m.slice(0, b, e).zero_();
+  g.v.slice(0, b, e).zero_();
+}
+
 }  // namespace gsdf_extras

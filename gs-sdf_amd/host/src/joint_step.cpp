@@ -131,14 +131,14 @@ JointIteration::JointIteration(const Tensor &anchors, const std::vector<Tensor> 
   int64_t off = 0;
   for (size_t i = 0; i < 6; ++i) {
     const int64_t n = fields[i].numel();
-    Tensor v = flat_.slice(0, off, off + n).view(fields[i].sizes());
-    { torch::NoGradGuard ng; v.copy_(fields[i]); }
-    v.requires_grad_(true);
-    v.mutable_grad() = flat_grad_.slice(0, off, off + n).view(fields[i].sizes());
-    views_.push_back(v);
+    { torch::NoGradGuard ng; flat_.slice(0, off, off + n).copy_(fields[i].reshape({-1})); }
+    field_cols_.push_back(N > 0 ? n / N : 0);
     if (n > 0) { sizes.push_back(n); seg_lrs.push_back(lrs[i]); }
     off += n;
   }
+  field_shapes_.clear();
+  for (const auto &f : fields) { auto sh = f.sizes().vec(); field_shapes_.push_back(std::vector<int64_t>(sh.begin() + 1, sh.end())); }
+  bind_views(flat_, flat_grad_, N);
   n_rest_ = N > 0 ? fields[5].numel() / (3 * N) : 0;
   adam_.add_group(flat_, flat_grad_, sizes, seg_lrs);
   // SDF family: table, decoder weights (, decoder biases) in one flat buffer; the operators' params_ become views of it
@@ -168,6 +168,23 @@ JointIteration::JointIteration(const Tensor &anchors, const std::vector<Tensor> 
   occ_grid_ = torch::empty({(int64_t)(nbytes / 4)}, anchors_.options().dtype(torch::kInt32));
   Tensor m1p1 = ((anchors_ - torch::tensor(origin_, anchors_.options())) * (2.0 * map_size_inv_)).contiguous();
   check(gsdf_occ_build(occ_level_, N, fp(m1p1), 1, occ_grid_.data_ptr(), cur_stream()), "occ_build");
+}
+
+// the six trainable tensors as views of the flat buffer, their .grad views of the flat gradient buffer (constructor, and after every refinement)
+void JointIteration::bind_views(const Tensor &flat, const Tensor &flat_grad, int64_t n) {
+  flat_ = flat; flat_grad_ = flat_grad;
+  views_.clear();
+  int64_t off = 0;
+  for (size_t i = 0; i < 6; ++i) {
+    const int64_t cnt = n * field_cols_[i];
+    std::vector<int64_t> shape = {n};
+    shape.insert(shape.end(), field_shapes_[i].begin(), field_shapes_[i].end());
+    Tensor v = flat_.slice(0, off, off + cnt).view(shape);
+    v.requires_grad_(true);
+    v.mutable_grad() = flat_grad_.slice(0, off, off + cnt).view(shape);
+    views_.push_back(v);
+    off += cnt;
+  }
 }
 
 void JointIteration::sync() {
@@ -632,6 +649,134 @@ std::map<std::string, int64_t> JointIteration::step_direct(const Tensor &viewmat
   sizes["I"] = I;
   sizes["n_gs_sdf"] = ids.numel();
   return sizes;
+}
+
+// ---- refinement on the flat buffers (a18) ------------------------------------------------------------------------------------------------
+struct RefinePlanArgs {
+  gsdf_refine_args a{};
+  bool zero_stats = false;   // zero_state() after growing / pruning: grad2d, count (, radii) restart from zero, vis is carried
+};
+
+std::map<std::string, int64_t> JointIteration::apply_row_map(RefinePlanArgs &pa) {
+  torch::NoGradGuard ng;
+  sync();      // the SDF leg of the last step may still be running: it reads this step's samples, not the flat buffers, but its Adam shares no state with us either way
+  const int64_t N = anchors_.size(0);
+  const auto fopt = anchors_.options().requires_grad(false);
+  gsdf_refine_args &a = pa.a;
+  a.n = N;
+  a.n_rest_cols = (int)field_cols_[5];
+  a.flat = fp(flat_);
+  Tensor m_old = adam_.exp_avg(0), v_old = adam_.exp_avg_sq(0);
+  a.adam_m = fp(m_old); a.adam_v = fp(v_old);
+  a.anchors = fp(anchors_);
+  auto st = [&](const char *k) -> const float * { auto it = state_.find(k); return it == state_.end() ? nullptr : fp(it->second); };
+  a.grad2d = st("grad2d"); a.count = st("count"); a.vis = st("vis"); a.radii = st("radii");
+  Tensor counts = torch::empty({4 * std::max<int64_t>(N, 1)}, fopt.dtype(torch::kInt32)), incl = torch::empty({4 * std::max<int64_t>(N, 1)}, fopt.dtype(torch::kInt64));
+  Tensor ws = torch::empty({(int64_t)gsdf_refine_ws_bytes(N)}, fopt.dtype(torch::kUInt8));
+  // the four totals in host-visible words (the reference reads three .sum().item<int>() and runs nonzero() five times per refinement step)
+  int64_t tot[4];
+  if (gsdf_host::HostWords::enabled()) {
+    if (!refine_words_) refine_words_ = std::make_unique<gsdf_host::HostWords>(4);
+    for (int k = 0; k < 4; ++k) refine_words_->arm(k);
+    check(gsdf_refine_plan(&a, counts.data_ptr<int32_t>(), incl.data_ptr<int64_t>(), refine_words_->dev(0), ws.data_ptr(), cur_stream()), "refine_plan");
+    for (int k = 3; k >= 0; --k) tot[k] = refine_words_->wait(k);
+  } else {
+    Tensor t4 = torch::empty({4}, fopt.dtype(torch::kInt64));
+    check(gsdf_refine_plan(&a, counts.data_ptr<int32_t>(), incl.data_ptr<int64_t>(), t4.data_ptr<int64_t>(), ws.data_ptr(), cur_stream()), "refine_plan");
+    Tensor h = t4.cpu();
+    for (int k = 0; k < 4; ++k) tot[k] = h.data_ptr<int64_t>()[k];
+  }
+  for (int k = 0; k < 4; ++k) TORCH_CHECK(tot[k] >= 0 && tot[k] <= N, "JointIteration::refine: implausible total ", tot[k]);
+  const int64_t nA = tot[0], nB = tot[1], nC = tot[2], nS = tot[3], Nn = nA + nB + 2 * nC;
+  std::map<std::string, int64_t> out = {{"N_before", N}, {"N", Nn}, {"n_kept", nA}, {"n_dupli_kept", nB}, {"n_split_children_kept", 2 * nC}, {"n_split", nS}};
+  if (Nn == N && nA == N) {       // nothing moves: keep every buffer (the reference's `if (n > 0)` guards)
+    if (pa.zero_stats) for (const char *k : {"grad2d", "count", "radii"}) if (state_.count(k)) state_[k].zero_();
+    return out;
+  }
+  int64_t width = 0;
+  for (int64_t c : field_cols_) width += c;
+  Tensor randn = nS > 0 ? torch::randn({2, nS, 3}, fopt) : Tensor();      // NeuralGS::split's draw (:781), for ALL split rows
+  Tensor flat_new = torch::empty({Nn * width}, fopt), m_new = torch::empty({Nn * width}, fopt), v_new = torch::empty({Nn * width}, fopt);
+  Tensor anchors_new = torch::empty({Nn, 3}, fopt);
+  std::map<std::string, Tensor> state_new;
+  float *sp[4] = {nullptr, nullptr, nullptr, nullptr};
+  const char *keys[4] = {"grad2d", "count", "vis", "radii"};
+  for (int k = 0; k < 4; ++k) {
+    if (!state_.count(keys[k])) continue;
+    const bool zero = pa.zero_stats && k != 2;
+    state_new[keys[k]] = zero ? torch::zeros({Nn}, fopt) : torch::empty({Nn}, fopt);
+    if (!zero) sp[k] = fpm(state_new[keys[k]]);
+  }
+  check(gsdf_refine_apply(&a, counts.data_ptr<int32_t>(), incl.data_ptr<int64_t>(), tot, nS > 0 ? fp(randn) : nullptr, fpm(flat_new), fpm(m_new), fpm(v_new),
+                          fpm(anchors_new), sp, cur_stream()), "refine_apply");
+  // rebind: parameter views, gradient buffer (zero: the step that follows accumulates into it), optimizer group, anchors, statistics
+  Tensor grad_new = torch::zeros({Nn * width}, fopt);
+  anchors_ = anchors_new;
+  bind_views(flat_new, grad_new, Nn);
+  std::vector<int64_t> sizes;
+  for (int64_t c : field_cols_) if (c > 0) sizes.push_back(c * Nn);
+  adam_.replace_group(0, flat_, flat_grad_, m_new, v_new, sizes);
+  state_ = std::move(state_new);
+  return out;
+}
+
+std::map<std::string, int64_t> JointIteration::refine(int iter, const RefineConfig &rc) {
+  if (refine_hook_ && !state_.empty()) refine_hook_(state_);
+  TORCH_CHECK(state_.count("grad2d") && state_.count("count"), "JointIteration::refine: no densification statistics yet (run step() first)");
+  RefinePlanArgs pa;
+  pa.zero_stats = true;
+  pa.a.mode = 0;
+  pa.a.grow_grad2d = rc.grow_grad2d;
+  pa.a.grow_scale3d = rc.grow_scale3d * rc.spatial_scale;
+  pa.a.grow_scale2d = rc.grow_scale2d;
+  pa.a.prune_opa = rc.prune_opa;
+  pa.a.prune_scale_min = 1e-4f;
+  pa.a.prune_scale3d = rc.prune_scale3d * rc.original_spatial_scale;
+  pa.a.use_radii = iter < rc.refine_scale2d_stop_iter && state_.count("radii") ? 1 : 0;
+  pa.a.use_prune_scale3d = iter > rc.reset_every ? 1 : 0;
+  return apply_row_map(pa);
+}
+
+int64_t JointIteration::prune_rows(const Tensor &mask) {
+  TORCH_CHECK(mask.defined() && mask.numel() == anchors_.size(0), "JointIteration::prune_rows: one mask entry per splat");
+  Tensor m8 = mask.to(torch::kUInt8).contiguous();
+  RefinePlanArgs pa;
+  pa.a.mode = 1;
+  pa.a.mask = m8.data_ptr<uint8_t>();
+  auto r = apply_row_map(pa);
+  return r["N_before"] - r["N"];
+}
+
+void JointIteration::reset_opacity(const RefineConfig &rc) {
+  torch::NoGradGuard ng;
+  const double cap = std::log(rc.prune_opa * 2.0 / (1.0 - rc.prune_opa * 2.0));
+  views_[3].clamp_max_(cap);
+  // segment index of the opacity among the non-empty segments (features_rest may be empty)
+  int seg = 0;
+  for (int i = 0; i < 3; ++i) seg += field_cols_[i] > 0 ? 1 : 0;
+  adam_.zero_segment_moments(0, seg);
+}
+
+std::map<std::string, int64_t> JointIteration::train_callback(int iter, int total_iter, const RefineConfig &rc) {
+  std::map<std::string, int64_t> out = {{"N", anchors_.size(0)}};
+  if (iter >= total_iter / 2) return out;       // refine_stop_iter (:573-578)
+  // prune_nan_gs (:907-916): step() already accumulates the count without a host round trip (nan_splats_seen()); rows are removed by the caller
+  // with prune_rows() when that count moves.  prune_invisible_gs (:892-905):
+  if (iter > 0 && iter % rc.num_train_data == 0 && state_.count("vis")) {
+    if (refine_hook_) refine_hook_(state_);
+    Tensor invisible = state_["vis"] < 1e-4;
+    state_["vis"].zero_();
+    out["n_invisible"] = prune_rows(invisible);
+  }
+  if (iter > 0) {
+    if (iter > rc.refine_start_iter && iter % rc.refine_every == 0 && (iter % rc.reset_every) >= rc.pause_refine_after_reset) {
+      auto r = refine(iter, rc);
+      out.insert(r.begin(), r.end());
+    }
+    if (iter % rc.reset_every == 0) reset_opacity(rc);
+  }
+  out["N"] = anchors_.size(0);
+  return out;
 }
 
 }  // namespace gsdf_extras

@@ -115,7 +115,37 @@ PYBIND11_MODULE(_gsdf_host, m) {
       .def("splat_flat_grad", &gsdf_extras::JointIteration::splat_flat_grad)
       .def("sdf_flat", &gsdf_extras::JointIteration::sdf_flat)
       .def("sdf_flat_grad", &gsdf_extras::JointIteration::sdf_flat_grad)
-      .def("nan_splats_seen", &gsdf_extras::JointIteration::nan_splats_seen);
+      .def("nan_splats_seen", &gsdf_extras::JointIteration::nan_splats_seen)
+      .def("refine", &gsdf_extras::JointIteration::refine)
+      .def("train_callback", &gsdf_extras::JointIteration::train_callback)
+      .def("prune_rows", &gsdf_extras::JointIteration::prune_rows)
+      .def("reset_opacity", &gsdf_extras::JointIteration::reset_opacity)
+      .def("set_refine_hook", &gsdf_extras::JointIteration::set_refine_hook)
+      .def("anchors", &gsdf_extras::JointIteration::anchors)
+      .def("n_splats", &gsdf_extras::JointIteration::n_splats)
+      .def("splat_adam_moments", &gsdf_extras::JointIteration::splat_adam_moments)
+      .def("get_state", [](gsdf_extras::JointIteration &j) { return j.state(); })
+      .def("set_state", [](gsdf_extras::JointIteration &j, std::map<std::string, torch::Tensor> s) { j.state() = std::move(s); })
+      .def("set_splat_adam_moments", [](gsdf_extras::JointIteration &j, const torch::Tensor &m, const torch::Tensor &v) {
+        auto mv = j.splat_adam_moments();
+        torch::NoGradGuard ng;
+        mv[0].copy_(m); mv[1].copy_(v);
+      });
+  py::class_<gsdf_extras::RefineConfig>(m, "RefineConfig")
+      .def(py::init<>())
+      .def_readwrite("prune_opa", &gsdf_extras::RefineConfig::prune_opa)
+      .def_readwrite("grow_grad2d", &gsdf_extras::RefineConfig::grow_grad2d)
+      .def_readwrite("grow_scale3d", &gsdf_extras::RefineConfig::grow_scale3d)
+      .def_readwrite("grow_scale2d", &gsdf_extras::RefineConfig::grow_scale2d)
+      .def_readwrite("prune_scale3d", &gsdf_extras::RefineConfig::prune_scale3d)
+      .def_readwrite("refine_scale2d_stop_iter", &gsdf_extras::RefineConfig::refine_scale2d_stop_iter)
+      .def_readwrite("refine_start_iter", &gsdf_extras::RefineConfig::refine_start_iter)
+      .def_readwrite("refine_every", &gsdf_extras::RefineConfig::refine_every)
+      .def_readwrite("reset_every", &gsdf_extras::RefineConfig::reset_every)
+      .def_readwrite("pause_refine_after_reset", &gsdf_extras::RefineConfig::pause_refine_after_reset)
+      .def_readwrite("spatial_scale", &gsdf_extras::RefineConfig::spatial_scale)
+      .def_readwrite("original_spatial_scale", &gsdf_extras::RefineConfig::original_spatial_scale)
+      .def_readwrite("num_train_data", &gsdf_extras::RefineConfig::num_train_data);
   py::class_<TCNNEncoding, std::shared_ptr<TCNNEncoding>>(m, "TCNNEncoding")
       .def(py::init([](int n_levels, int n_feat, int log2_hashmap, int base_res, double pls) {
         nlohmann::json cfg = {{"otype", "Grid"}, {"type", "Hash"}, {"n_levels", n_levels}, {"n_features_per_level", n_feat},
@@ -316,6 +346,7 @@ PYBIND11_MODULE(_gsdf_host, m) {
       .def("prune_nan_gs", [](gm::NeuralGS &g, int iter, AdamBox &a) { return g.prune_nan_gs(iter, a.p); })
       .def("prune_invisible_gs", [](gm::NeuralGS &g, int iter, AdamBox &a) { return g.prune_invisible_gs(iter, a.p); })
       .def("reset_opacity", [](gm::NeuralGS &g, AdamBox &a) { g.reset_opacity(a.p); })
+      .def("zero_state", &gm::NeuralGS::zero_state)
       .def("export_gs_to_ply", [](gm::NeuralGS &g, const std::string &p) { g.export_gs_to_ply(p); })
       .def("load_ply_to_gs", [](gm::NeuralGS &g, const std::string &p) { g.load_ply_to_gs(p); });
   m.def("sample_rays", [to_samples, from_samples](gm::LocalMap::Ptr lm, const py::dict &rays, float sample_std, float truncated_dis, int surface_sample_num,

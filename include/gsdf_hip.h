@@ -546,6 +546,39 @@ int gsdf_densify_stats(int64_t M, int64_t N, int n_cameras, int width, int heigh
 int gsdf_flat_rows_gather(int n_fields, const int32_t *widths_host, int64_t n_src, int64_t n_dst, int64_t n_keep,
                           const int64_t *keep_idx, const float *src, float *dst, gsdf_stream_t stream);
 
+/* a18 one refinement step of the splat set on the field-major flat buffers [offsets n x 3 | scaling n x 3 | quaternion n x 4 | opacity n |
+ *     features_dc n x 3 | features_rest n x n_rest_cols], in two passes over the rows: NeuralGS::grow_gs (duplicate, split), prune_gs and the
+ *     Adam-state surgery under them (include/neural_gaussian/neural_gaussian.cpp:690-890; include/optimizer/optimizer_utils/
+ *     optimizer_utils.cpp:5-165) composed into one row map.  The new set is, in the reference's order: A the old rows neither split nor
+ *     pruned (moments kept) | B the unpruned copies of the duplicated rows | C, D the unpruned first / second children of the split rows
+ *     (B, C, D: zero moments).  Decisions (mode 0): grads = grad2d / max(count, 1) > grow_grad2d; small = max(exp(scaling[:2])) <=
+ *     grow_scale3d (the caller passes k_grow_scale3d * spatial_scale); duplicate = high & small; split = high & !small (| radii >
+ *     grow_scale2d when use_radii); prune = sigmoid(opacity) < prune_opa | min(exp(scaling[:2])) < prune_scale_min (| max > prune_scale3d when
+ *     use_prune_scale3d), tested on the rows AFTER growing (children: scale / 1.6).  mode 1: prune the rows with mask[i] != 0 only
+ *     (prune_invisible_gs :892-905, prune_nan_gs :907-916).
+ *   plan:  counts [4][n] int32 (A, B, C flags and the split flag), offsets_incl [4 n] int64 (their inclusive scan, segment-major),
+ *          totals [4] int64 = { nA, nB, nC, n_split } (device memory or host-visible words, gsdf_host_words_alloc).  4 launches.
+ *   apply: totals_host = the four totals as HOST values; randn [2, n_split, 3] N(0,1) (the reference's torch::randn({2, n, 3}), :781);
+ *          new buffers of n_new = nA + nB + 2 nC rows: flat_new, m_new / v_new (both or neither), anchors_new [n_new,3], state_new[4] =
+ *          grad2d, count, vis, radii images (each may be NULL; children and copies inherit the parent's values, as the reference's
+ *          cat(index_select) does — the caller zeroes what zero_state() zeroes).  1 launch. */
+typedef struct {
+  int64_t n;
+  int n_rest_cols;                         /* 3 x (SH bases - 1) */
+  int mode;                                /* 0 = grow + prune, 1 = prune by mask */
+  const float *flat, *adam_m, *adam_v;     /* adam_m / adam_v may be NULL (no optimizer state yet) */
+  const float *anchors;                    /* [n,3] */
+  const float *grad2d, *count, *vis, *radii;
+  const uint8_t *mask;                     /* mode 1 */
+  float grow_grad2d, grow_scale3d, grow_scale2d, prune_opa, prune_scale_min, prune_scale3d;
+  int use_radii, use_prune_scale3d;
+} gsdf_refine_args;
+size_t gsdf_refine_ws_bytes(int64_t n);
+int gsdf_refine_plan(const gsdf_refine_args *args, int32_t *counts, int64_t *offsets_incl, int64_t *totals, void *ws, gsdf_stream_t stream);
+int gsdf_refine_apply(const gsdf_refine_args *args, const int32_t *counts, const int64_t *offsets_incl, const int64_t *totals_host,
+                      const float *randn, float *flat_new, float *m_new, float *v_new, float *anchors_new, float *const *state_new,
+                      gsdf_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Hint for the XCD-aware kernels (compositing: one band of tiles per XCD; hash-grid forward: one group of levels per
  * XCD): how many XCDs the queue behind `stream` can use.  Default 8; a caller that launches on a CU-masked stream
