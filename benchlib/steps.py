@@ -181,4 +181,61 @@ def reference_loop(args, sc, views, K, ug6, target, N, W, H, deg, dev):
 
 
 def refine_amortised(args, sc, views, K, target, N, W, H, deg, dev):
-    raise NotImplementedError("refine_amortised: not built yet")
+    """Refinement INSIDE a measured run (SURVEY 8 row a18; NeuralGS::train_callback, neural_gaussian.cpp:568-624): the headline's step
+    (gsdf_extras::JointIteration, two streams, per-iteration ray batches) followed every iteration by JointIteration::train_callback —
+    prune_invisible_gs every num_train_data iterations, grow_gs (duplicate + split) + prune_gs + zero_state with the Adam-state surgery
+    every refine_every iterations after refine_start_iter — with the reference's thresholds (config/base.yaml:60-74) on the synthetic scene.
+    The splat count follows the policy (reported); the run stops growing at GSDF_REFINE_MAX_SPLATS (default 4 M) so that a synthetic
+    target image that keeps every gradient high cannot exhaust the box."""
+    import gs_sdf_amd.hostlib as hostlib
+    from benchlib.raybatch import RayBatcher
+    from gs_sdf_amd.trainer import SplatParams
+    host = hostlib.load()
+    params = SplatParams.from_scene(sc, dev, None)
+    ji, pool, ray_sdf, cams, _ = make_cpp_iteration(args, sc, params, dev, W, H, deg, views)
+    batcher = RayBatcher(host, sc, views, dev, seed=7)
+    rc = host.RefineConfig()
+    rc.num_train_data = int(views.shape[0])
+    steps = int(os.environ.get("GSDF_REFINE_STEPS", "1000"))
+    cap = int(os.environ.get("GSDF_REFINE_MAX_SPLATS", "4000000"))
+    total_iter = 4 * steps                        # refine_stop_iter = total_iter / 2 lies beyond the run
+    nv = views.shape[0]
+
+    def one(i):
+        rp, rs = batcher.take(torch.cuda.current_stream())
+        ji.step(views[i % nv][None], K, target, rp, rs, [], True, cams[i % nv])
+        batcher.issue()
+
+    for i in range(1, 21):                        # warm-up (no refinement below refine_start_iter anyway)
+        one(i)
+    torch.cuda.synchronize()
+    refine_ms, n_hist, events = [], [int(ji.n_splats())], []
+    t0 = time.perf_counter()
+    for i in range(21, 21 + steps):
+        one(i)
+        will_refine = i > rc.refine_start_iter and i % rc.refine_every == 0 and ji.n_splats() < cap
+        will_prune = i % rc.num_train_data == 0
+        if will_refine or will_prune:
+            torch.cuda.synchronize()              # so that the refinement step is timed alone (costs the run one drain per refinement)
+            t1 = time.perf_counter()
+            out = ji.train_callback(i, total_iter, rc)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t1) * 1e3
+            if will_refine:
+                refine_ms.append(dt)
+            events.append({"iter": i, "ms": round(dt, 3), **{k: int(v) for k, v in out.items()}})
+            n_hist.append(int(out["N"]))
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    refine_ms.sort()
+    step_ms = el / steps * 1e3
+    return {"metric": "train iters/sec over a run WITH refinement (train_callback every iteration; grow + split + prune + Adam-state surgery on the flat buffers)",
+            "value": steps / el, "unit": "iters/s", "ms_per_step": step_ms, "steps": steps, "n_gpus": 1,
+            "refine_steps": len(refine_ms), "refine_ms_median": refine_ms[len(refine_ms) // 2] if refine_ms else None,
+            "refine_ms_max": refine_ms[-1] if refine_ms else None,
+            "refine_over_normal_step": (refine_ms[len(refine_ms) // 2] / step_ms) if refine_ms else None,
+            "splats_first_last_max": [n_hist[0], n_hist[-1], max(n_hist)], "events": events[:12],
+            "config": {"refine_start_iter": rc.refine_start_iter, "refine_every": rc.refine_every, "reset_every": rc.reset_every,
+                       "num_train_data": rc.num_train_data, "grow_grad2d": rc.grow_grad2d, "prune_opa": rc.prune_opa, "max_splats": cap,
+                       "what": "a refinement step = JointIteration::train_callback alone between two device synchronisations: plan (flags + scan + 4 totals in "
+                               "host-visible words), randn, apply (every row of parameters, both Adam moments, anchors, statistics written once), rebind"}}

@@ -40,7 +40,13 @@ for counter in ("FETCH_SIZE", "WRITE_SIZE"):
     f = os.path.join(root, f"{tag}_bench_{short}_pmc_{counter}.csv")
     for op, (tot, n) in per_launch(f, counter).items():
         hbm[op] = hbm.get(op, 0.0) + tot * 1024.0 / n
-out = {op: int(v) for op, v in hbm.items()}
+# the unit counts the per-launch means belong to: the detail record bench.py wrote beside the FETCH_SIZE run (every step of that process)
+import glob
+det = {}
+for f in glob.glob(os.path.join(root, f"{tag}_bench_{short}_pmc_FETCH_SIZE.detail.json")):
+    det = json.load(open(f)).get("all_steps", {})
+out = {op: {"bytes": int(v), "sdf_points": det.get("mean_sdf_points"), "M": det.get("mean_M"), "I": det.get("mean_I"),
+            "source": f"profiles/{tag}_bench_{short}_pmc_FETCH_SIZE.csv + _WRITE_SIZE.csv"} for op, v in hbm.items()}
 out["_note"] = (f"{tag}: FETCH_SIZE + WRITE_SIZE per operator launch in bytes (KiB counters x1024, mean over the launches of the run; FETCH "
                 "uncorrected for the gfx950 x2 under-report of wide reads). Collected with bench.py --no-overlap so that one kernel "
                 "runs at a time; hashgrid_bwd = vmax + count + plan + emit + apply of the binned scatter.")
