@@ -14,7 +14,7 @@ from concurrent.futures import ThreadPoolExecutor
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "gs-sdf_amd", "csrc")
-NO_CONTRACT = {"projection", "binning", "radix", "occupancy", "marching_cubes"}      # as the Makefile builds them
+NO_CONTRACT = {"projection", "binning", "radix", "occupancy", "marching_cubes", "refine"}      # as the Makefile builds them
 PAT = re.compile(r"- \.agpr_count:\s+(\d+).*?\.group_segment_fixed_size:\s+(\d+).*?\.max_flat_workgroup_size:\s+(\d+).*?\.name:\s+(\S+).*?"
                  r"\.private_segment_fixed_size:\s+(\d+).*?\.sgpr_count:\s+(\d+).*?\.sgpr_spill_count:\s+(\d+).*?\.vgpr_count:\s+(\d+).*?"
                  r"\.vgpr_spill_count:\s+(\d+)", re.S)
