@@ -102,7 +102,9 @@ std::vector<Tensor> render_post(const Tensor &render_colors, const Tensor &rende
 }
 
 struct JointStreams {
-  c10::hip::HIPStreamMasqueradingAsCUDA side = c10::hip::getStreamFromPoolMasqueradingAsCUDA();
+  // GSDF_SDF_STREAM_HIGH_PRIORITY=1: the SDF leg's queue ahead of the splat leg's when both have workgroups waiting (experiment)
+  c10::hip::HIPStreamMasqueradingAsCUDA side = c10::hip::getStreamFromPoolMasqueradingAsCUDA(
+      [] { const char *e = getenv("GSDF_SDF_STREAM_HIGH_PRIORITY"); return e && e[0] == '1'; }());
   at::cuda::CUDAEvent fwd_done, entry, side_done;
   StreamGate gate;
   bool side_pending = false;
