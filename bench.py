@@ -167,14 +167,22 @@ def main():
     if impl == "cpp":
         ji, cpp_pool, cpp_ray_sdf, cpp_cams, dec_dims = make_cpp_iteration(args, sc, params, dev, W, H, deg, views)
         cpp_up = [] if args.step_terms == "reference" else [ug6[k] for k in ("v_render_depths", "v_render_alphas", "v_render_normals", "v_render_median")]
+        coll_events = {"splat": [], "sdf": []}
         if dist is not None:      # view-parallel: one collective per parameter family, on the stream its optimizer runs on
-            def _mean_over_ranks(g):
-                if backend == "nccl":
-                    dist.all_reduce(g, op=dist.ReduceOp.AVG)     # RCCL averages inside the collective: no second pass over the buffer
-                else:                                            # gloo (CPU-side test runs) has no AVG
-                    dist.all_reduce(g)
-                    g.mul_(1.0 / world)
-            ji.set_grad_hooks(_mean_over_ranks, _mean_over_ranks)
+            def _hook(family):
+                def mean_over_ranks(g):
+                    # issued on the CURRENT stream = the leg that owns the family (JointIteration::set_grad_hooks); timed with events on that stream
+                    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    a.record()
+                    if backend == "nccl":
+                        dist.all_reduce(g, op=dist.ReduceOp.AVG)     # RCCL averages inside the collective: no second pass over the buffer
+                    else:                                            # gloo (CPU-side test runs) has no AVG
+                        dist.all_reduce(g)
+                        g.mul_(1.0 / world)
+                    b.record()
+                    coll_events[family].append((a, b, g.numel() * 4))
+                return mean_over_ranks
+            ji.set_grad_hooks(_hook("splat"), _hook("sdf"))
     batcher = None
     if impl == "cpp" and args.ray_batch == "sampled" and not args.dump_grads:
         import gs_sdf_amd.hostlib as hostlib
@@ -540,6 +548,12 @@ def main():
             "hbm_gb": {"allocated_peak": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2), "reserved": round(torch.cuda.memory_reserved() / 2 ** 30, 2)},
             # every step this process ran (warm-up included): what one row of a rocprofv3 --stats summary of this command averages over
             "all_steps": {"steps": len(all_hist.get("M", [])), **{"mean_" + k: sum(v) / max(1, len(v)) for k, v in all_hist.items()}},
+            "collectives": (None if dist is None or impl != "cpp" else {
+                "backend": dist.get_backend(), "world_size": dist.get_world_size(),
+                **{fam: {"calls": len(ev), "bytes": ev[-1][2] if ev else 0,
+                         "mean_ms": (sum(a.elapsed_time(b) for a, b, _ in ev[-args.steps:]) / max(1, len(ev[-args.steps:]))) if ev else None}
+                   for fam, ev in coll_events.items()},
+                "what": "per-family gradient all-reduce, HIP events on the stream it was issued on (splat: the caller's stream; sdf: JointIteration's second stream)"}),
             "kernel_ms": kern_all, "kernel_ms_note": "median launch duration per operator over 10 extra steps after the timed region",
         }
         detail["all_steps"]["mean_sdf_points"] = 7 * (detail["all_steps"].get("mean_n_ray_pts", 32768.0) + detail["all_steps"].get("mean_n_gs_sdf", 0.0))

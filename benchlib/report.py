@@ -185,6 +185,11 @@ def compact_line(d):
                                 "parity": {"integer_outputs_bit_exact": p.get("integer_outputs_bit_exact"), "worst_over_tolerance": round(worst, 4),
                                            "elements_above_1e-4": above, "elements": n_el, "pinned": "unpinned (no reference kernel source or vector exists); "
                                            "oracle cross-checked by an independent fp32 build, profiles/parity_r05.json"}}
+    if d.get("collectives"):
+        c_ = d["collectives"]
+        line["collectives"] = {"backend": c_["backend"], "world_size": c_["world_size"],
+                               "splat_allreduce_ms": None if not c_["splat"]["mean_ms"] else round(c_["splat"]["mean_ms"], 3), "splat_bytes": c_["splat"]["bytes"],
+                               "sdf_allreduce_ms": None if not c_["sdf"]["mean_ms"] else round(c_["sdf"]["mean_ms"], 3), "sdf_bytes": c_["sdf"]["bytes"]}
     if d.get("secondary"):
         line["secondary"] = {k: (round(v["value"], 2) if isinstance(v, dict) and "value" in v else "error") for k, v in d["secondary"].items()}
         line["secondary_unit"] = "iters/s (each its own line above and in the detail file)"
