@@ -70,8 +70,10 @@ __device__ __forceinline__ void unpack_record(BinRecord r, uint32_t &entry, long
   const int s = (int)((r >> 12) & 63u);
   const long long m0 = ((long long)(r << 23)) >> 41, m1 = ((long long)r) >> 41;   // sign-extended 23-bit fields
   // fixed point of the level: 2^(e - 41); the record's unit is 2^(e - s - 22)
-  f0 = s <= 19 ? m0 << (19 - s) : m0 >> (s - 19);
-  f1 = s <= 19 ? m1 << (19 - s) : m1 >> (s - 19);
+  // contributions more than 2^19 below the level's maximum lose their low bits here: ROUND to nearest (an arithmetic shift alone floors toward
+  // minus infinity, a one-sided bias of up to one fixed-point unit on every small contribution)
+  f0 = s <= 19 ? m0 << (19 - s) : (m0 + (1LL << (s - 20))) >> (s - 19);
+  f1 = s <= 19 ? m1 << (19 - s) : (m1 + (1LL << (s - 20))) >> (s - 19);
 }
 
 struct BinItem {

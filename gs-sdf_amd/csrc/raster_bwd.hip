@@ -101,6 +101,7 @@ __global__ void __launch_bounds__(RT)
   const int64_t pid = (cam * H + y) * (int64_t)W + x;
   const float px = (float)x + 0.5f, py = (float)y + 0.5f;
   const float lx = (float)((wave & 1) * 8 + (lane & 7)), ly = (float)((wave >> 1) * 8 + (lane >> 3));
+  const int sub_bit = 4 * wave + 2 * ((lane >> 5) & 1) + ((lane >> 2) & 1);   // this pixel's 4x4 sub-block in SplatBatchT::m16 (8x8 row-major lanes)
 
   const int32_t start = isect_offsets[tile];
   const int32_t end = (tile == total_tiles - 1) ? (int32_t)I : isect_offsets[tile + 1];
@@ -163,7 +164,7 @@ __global__ void __launch_bounds__(RT)
     const int wcount = min(count, wave_bin_final - bstart + 1);
     for (int c0 = ((wcount - 1) >> 6) << 6; c0 >= 0 && wcount > 0; c0 -= 64) {
       const int ti = c0 + lane;
-      unsigned long long todo = __ballot(ti < wcount && ((lds.s.qmask[ti < BWD_BATCH ? ti : 0] >> wave) & 1u));
+      unsigned long long todo = __ballot(ti < wcount && ((lds.s.m16[ti < BWD_BATCH ? ti : 0] >> (4 * wave)) & 0xFu));
       while (todo) {
       const int hb = 63 - __builtin_clzll(todo);
       todo &= ~(1ull << hb);
@@ -172,7 +173,7 @@ __global__ void __launch_bounds__(RT)
       PairEval e;
       const float mwx = a3.x, mwy = lds.s.extra[t];
       eval_pair<true>(lx, ly, px, py, a0, a1, a2, mwx, a3.y, e, mwy);
-      const bool valid = inside && (bstart + t <= bin_final) && e.ok;
+      const bool valid = inside && (bstart + t <= bin_final) && e.ok && ((lds.s.m16[t] >> sub_bit) & 1u);   // as the forward
       if (COUNT) { c_visit += 1; c_live += __popcll(__ballot(inside && (bstart + t <= bin_final))); c_valid += __popcll(__ballot(valid)); }
       if (__ballot(valid) == 0ull) continue;
       const float4 a4 = lds.s.q4[t];
@@ -251,16 +252,19 @@ __global__ void __launch_bounds__(RT)
 // up to four different splats.  The reductions were row-local already (row_transpose_reduce16 / _reduce4 sum over a DPP row and the four
 // rows met in a 4-way ds_add on one address): now each row adds into the record of its own splat.
 // ---------------------------------------------------------------------------------------------------------------------------------------
-static constexpr int BWD_ROWS_BATCH = 216;   // 186 B of LDS per staged splat -> <= 40 KiB per workgroup (4 workgroups per CU)
+static constexpr int BWD_ROWS_BATCH = 216;   // 186 B of LDS per staged splat (194 with the absgrad accumulators) -> <= 40 KiB per workgroup without absgrad
+                                             // (4 workgroups per CU), 42 KiB with it (3 per CU: the launch bound below says so)
 template <bool ABSGRAD>
 struct BwdRowsLds {
   SplatBatchT<BWD_ROWS_BATCH, true> s;
   float acc[BWD_ROWS_BATCH][NACC];
   float acc_abs[ABSGRAD ? BWD_ROWS_BATCH : 1][2];
-  unsigned short m16[BWD_ROWS_BATCH];
   unsigned char list[16][BWD_ROWS_BATCH];
   int bin_final_max;
 };
+
+static_assert(sizeof(BwdRowsLds<false>) <= 40960, "raster_bwd_rows: 4 workgroups per CU need <= 40 KiB of LDS each");
+static_assert(sizeof(BwdRowsLds<true>) <= 53248, "raster_bwd_rows (absgrad): 3 workgroups per CU need <= 52 KiB of LDS each");
 
 template <bool ABSGRAD>
 __device__ __forceinline__ void flush_records_rows(BwdRowsLds<ABSGRAD> &lds, int wave, int lane, int g_mine, float *__restrict__ grec,
@@ -292,7 +296,7 @@ __device__ __forceinline__ void flush_records_rows(BwdRowsLds<ABSGRAD> &lds, int
 }
 
 template <bool ABSGRAD, bool COUNT = false>
-__global__ void __launch_bounds__(RT, 4)
+__global__ void __launch_bounds__(RT, ABSGRAD ? 3 : 4)
     raster_bwd_rows_kernel(int n_xcd, int64_t total_tiles, int64_t n_tiles, int64_t I, int W, int H, int tw,
                            const float *__restrict__ means2d, const float *__restrict__ ray_transforms,
                            const float *__restrict__ colors, const float *__restrict__ opacities,
@@ -372,9 +376,6 @@ __global__ void __launch_bounds__(RT, 4)
     if (tid < BWD_ROWS_BATCH && idx < end && idx <= tile_bin_final) {
       g_mine = flatten_ids[idx];
       stage_splat(lds.s, tid, g_mine, means2d, ray_transforms, colors, opacities, normals, (float)(tx * TILE), (float)(ty * TILE));
-      const float2 xy = *reinterpret_cast<const float2 *>(means2d + 2 * (int64_t)g_mine);
-      lds.m16[tid] = (unsigned short)subblock_mask4x4(ray_transforms + 9 * (int64_t)g_mine, xy.x, xy.y, opacities[g_mine], (float)(tx * TILE),
-                                                        (float)(ty * TILE));
     }
     __syncthreads();  // barrier B
     const int count = min(BWD_ROWS_BATCH, min(end, tile_bin_final + 1) - bstart);
@@ -384,7 +385,7 @@ __global__ void __launch_bounds__(RT, 4)
     int n0 = 0, n1 = 0, n2 = 0, n3 = 0;
     for (int c0 = 0; c0 < wcount; c0 += 64) {
       const int ti = c0 + lane;
-      const unsigned m = ti < wcount ? (unsigned)lds.m16[ti] >> (4 * wave) : 0u;
+      const unsigned m = ti < wcount ? (unsigned)lds.s.m16[ti] >> (4 * wave) : 0u;
 #define ROW_LIST(r, n, rbf)                                                                                    \
   {                                                                                                            \
     const bool bit = ((m >> r) & 1u) && (bstart + ti <= rbf);                                                  \

@@ -43,7 +43,11 @@ template <int CAP, bool BWD>
 struct SplatBatchT {
   float4 q0[CAP], q1[CAP], q2[CAP], q3[CAP], q4[CAP];
   float extra[BWD ? CAP : 1];  // backward: M_w.y (q3.x = M_w.x instead of D)
-  unsigned char qmask[CAP];    // bit q set <=> the splat can reach wave q's 8x8 pixel quadrant (conservative)
+  unsigned short m16[CAP];     // bit 4 q + s set <=> the splat's conservative box reaches the 4x4-pixel sub-block s of wave q's quadrant
+                               // (subblock_mask4x4).  EVERY compositing kernel takes its skip decisions from this one mask — a quadrant is
+                               // visited when its nibble is non-zero, a pixel blends only when its own sub-block bit is set — so that the forward
+                               // and the backward drop a pair in exactly the same pixels even where the box is not conservative (the backward
+                               // replays the forward's transmittance and must see the same blended set)
 };
 using SplatBatch = SplatBatchT<RT, false>;
 
@@ -203,7 +207,7 @@ __device__ __forceinline__ void stage_splat(SplatBatchT<CAP, BWD> &s, int slot, 
   s.q3[slot] = make_float4(BWD ? mw0 : D, mw2, c[0], c[1]);
   if (BWD) s.extra[slot] = mw1;
   s.q4[slot] = make_float4(c[2], n[0], n[1], n[2]);
-  s.qmask[slot] = (unsigned char)quadrant_mask(m, xy.x, xy.y, opac, tile_x0, tile_y0);
+  s.m16[slot] = (unsigned short)subblock_mask4x4(m, xy.x, xy.y, opac, tile_x0, tile_y0);
 }
 
 // row sum / max over the 16 lanes of a DPP row; valid in lane 15 of each row

@@ -44,6 +44,7 @@ __global__ void __launch_bounds__(RT)
   const int64_t pid = (cam * H + y) * (int64_t)W + x;
   const float px = (float)x + 0.5f, py = (float)y + 0.5f;
   const float lx = (float)((wave & 1) * 8 + (lane & 7)), ly = (float)((wave >> 1) * 8 + (lane >> 3));
+  const int sub_bit = 4 * wave + 2 * ((lane >> 5) & 1) + ((lane >> 2) & 1);   // this pixel's 4x4 sub-block in SplatBatchT::m16 (8x8 row-major lanes)
 
   int32_t start = isect_offsets[tile];
   int32_t end = (tile == total_tiles - 1) ? (int32_t)I : isect_offsets[tile + 1];
@@ -87,7 +88,7 @@ __global__ void __launch_bounds__(RT)
     // per-wave compaction: only the splats whose conservative box reaches this wave's quadrant are evaluated
     for (int c0 = 0; c0 < count; c0 += 64) {
       const int ti = c0 + lane;
-      unsigned long long todo = __ballot(ti < count && ((lds.s.qmask[ti < RT ? ti : 0] >> wave) & 1u));
+      unsigned long long todo = __ballot(ti < count && ((lds.s.m16[ti < RT ? ti : 0] >> (4 * wave)) & 0xFu));
       if (COUNT) {   // iterations this chunk would take if each 16-lane row of the wave followed its own list
         int r4 = 0, r8 = 0;
         for (int sb = 0; sb < 4; ++sb) {
@@ -102,7 +103,7 @@ __global__ void __launch_bounds__(RT)
         const float4 a0 = lds.s.q0[t], a1 = lds.s.q1[t], a2 = lds.s.q2[t], a3 = lds.s.q3[t];
         PairEval e;
         eval_pair(lx, ly, px, py, a0, a1, a2, a3.x, a3.y, e);
-        bool valid = !done && e.ok;
+        bool valid = !done && e.ok && ((lds.s.m16[t] >> sub_bit) & 1u);   // the pixel's own 4x4 sub-block is reached (the mask the backward takes its lists from)
         if (COUNT) { c_visit += 1; c_live += __popcll(__ballot(!done)); c_ok += __popcll(__ballot(valid)); c_empty += __ballot(valid) == 0ull; }
         if (__ballot(valid) == 0ull) continue;
         const float nT = T * (1.0f - e.alpha);
@@ -169,7 +170,6 @@ __global__ void __launch_bounds__(RT)
 // ---------------------------------------------------------------------------------------------------------------------------------------
 struct FwdRowsLds {
   SplatBatch s;
-  unsigned short m16[RT];        // 4x4 reach mask of the staged splat (bit 4 wave + row)
   unsigned vis[RT];              // max blending weight over the tile's pixels (fp32 bits)
   unsigned char list[16][RT];    // per (wave, row): slots of the staged splats that reach the row, in list order
 };
@@ -229,9 +229,6 @@ __global__ void __launch_bounds__(RT)
     if (idx < end) {
       g_mine = flatten_ids[idx];
       stage_splat(lds.s, tid, g_mine, means2d, ray_transforms, colors, opacities, normals, (float)(tx * TILE), (float)(ty * TILE));
-      const float2 xy = *reinterpret_cast<const float2 *>(means2d + 2 * (int64_t)g_mine);
-      lds.m16[tid] = (unsigned short)subblock_mask4x4(ray_transforms + 9 * (int64_t)g_mine, xy.x, xy.y, opacities[g_mine], (float)(tx * TILE),
-                                                        (float)(ty * TILE));
       lds.vis[tid] = 0u;
     }
     __syncthreads();  // barrier B
@@ -242,7 +239,7 @@ __global__ void __launch_bounds__(RT)
     int n0 = 0, n1 = 0, n2 = 0, n3 = 0;
     for (int c0 = 0; c0 < count; c0 += 64) {
       const int ti = c0 + lane;
-      const unsigned m = ti < count ? (unsigned)lds.m16[ti] >> (4 * wave) : 0u;
+      const unsigned m = ti < count ? (unsigned)lds.s.m16[ti] >> (4 * wave) : 0u;
 #define ROW_LIST(r, n)                                                                                         \
   {                                                                                                            \
     const bool bit = (m >> r) & 1u;                                                                            \

@@ -89,7 +89,8 @@ struct LocalMap : torch::nn::Module {
 
   // torch::save / torch::load of the module (neural_mapping.cpp:1334,1351) in the REFERENCE'S archive layout, so that a
   // local_map_checkpoint.pt written here loads in the reference's LocalMap (and in gs_sdf_amd/checkpoint.py) and vice versa:
-  // "encoder_local_map" (flat table) + decoder_implementation 1: "decoder" (flat FullyFusedMLP weights); decoder_implementation 0:
+  // "encoder_local_map" (flat table) + decoder_implementation 1: "decoder" (flat FullyFusedMLP weights: written unpadded; read unpadded or
+  // in tiny-cuda-nn's layout with the last layer padded to 16 output rows, the real rows first); decoder_implementation 0:
   // submodule "decoder" = torch::nn::Sequential with children "0".."2L+2", Linear layers holding "weight" [out,in] / "bias" [out]
   // (local_map.cpp:29-42) — the flat fused-kernel parameters are sliced into / filled from that layout.
   void save(torch::serialize::OutputArchive &archive) const override;

@@ -114,8 +114,20 @@ void LocalMap::load(torch::serialize::InputArchive &archive) {
               p_encoder_tcnn_->params_.numel());
   Tensor dec_w, dec_b;
   if (cfg_.decoder_implementation != 0) {
-    TORCH_CHECK(archive.try_read(p_decoder_tcnn_->name_, dec_w) && dec_w.numel() == p_decoder_tcnn_->params_.numel(),
-                "LocalMap::load: flat 'decoder' parameter missing or of the wrong size (decoder_implementation 1)");
+    // the flat FullyFusedMLP parameter, either unpadded (what save() writes) or in upstream tiny-cuda-nn's layout, whose last layer is padded
+    // to a multiple of 16 output rows (what a checkpoint written by the reference's own tcnn build, or by checkpoint.py with
+    // pad_tcnn_output, holds): the real rows come first, the padding is dropped
+    TORCH_CHECK(archive.try_read(p_decoder_tcnn_->name_, dec_w), "LocalMap::load: no flat 'decoder' parameter (decoder_implementation 1)");
+    const auto &d = p_decoder_tcnn_->dims_;
+    const int64_t n_plain = p_decoder_tcnn_->params_.numel(), in_last = d[d.size() - 2], out_last = d.back();
+    const int64_t rows_padded = (out_last + 15) / 16 * 16, n_padded = n_plain - out_last * in_last + rows_padded * in_last;
+    TORCH_CHECK(dec_w.numel() == n_plain || dec_w.numel() == n_padded, "LocalMap::load: flat 'decoder' parameter has ", dec_w.numel(), " entries, expected ",
+                n_plain, " (unpadded) or ", n_padded, " (tiny-cuda-nn's padded last layer)");
+    if (dec_w.numel() != n_plain) {
+      dec_w = dec_w.reshape({-1});
+      const int64_t head = n_plain - out_last * in_last;
+      dec_w = torch::cat({dec_w.slice(0, 0, head), dec_w.slice(0, head, head + rows_padded * in_last).view({rows_padded, in_last}).slice(0, 0, out_last).reshape({-1})});
+    }
   } else {
     torch::serialize::InputArchive child;
     TORCH_CHECK(archive.try_read("decoder", child), "LocalMap::load: no 'decoder' submodule (decoder_implementation 0 expects the Sequential layout)");

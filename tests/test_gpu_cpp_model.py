@@ -344,6 +344,14 @@ def test_cpp_local_map_checkpoint_round_trips_with_the_python_mirror(host, tmp_p
     assert torch.equal(cm.encoder.params_.reshape(-1), pm.encoder.params_.reshape(-1)) and torch.equal(cm.decoder.params_, pm.decoder.params_)
     if impl == 0:
         assert torch.equal(cm.decoder.biases_, pm.decoder.biases_)
+    if impl == 1:
+        # tiny-cuda-nn's own layout (last layer padded to 16 output rows; what the reference's tcnn build writes): the C++ class takes the real rows
+        with torch.no_grad():
+            pm.decoder.params_.add_(0.5)
+        p2b = str(tmp_path / "from_python_padded.pt")
+        save_local_map_checkpoint(pm, p2b, pad_tcnn_output=True)
+        cm.load_checkpoint(p2b)
+        assert torch.equal(cm.decoder.params_, pm.decoder.params_) and torch.equal(cm.encoder.params_.reshape(-1), pm.encoder.params_.reshape(-1))
     # a checkpoint of the other decoder implementation is refused and leaves the map untouched
     other, _, _ = make_maps(host, 1 - impl)
     p3 = str(tmp_path / "other.pt")
