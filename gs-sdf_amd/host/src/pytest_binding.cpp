@@ -153,6 +153,10 @@ PYBIND11_MODULE(_gsdf_host, m) {
                               {"interpolation", "Linear"}};
         return std::make_shared<TCNNEncoding>(3, cfg, "encoder_test");
       }))
+      .def_static("spherical_harmonics", [](int degree) {      // what the reference's SHEncoding constructs (encodings.h:15-22)
+        nlohmann::json cfg = {{"otype", "SphericalHarmonics"}, {"degree", degree}};
+        return std::make_shared<TCNNEncoding>(3, cfg, "sh_encoding");
+      })
       .def("forward", &TCNNEncoding::forward)
       .def("forward_stencil", &TCNNEncoding::forward_stencil)
       .def("get_out_dim", &TCNNEncoding::get_out_dim)

@@ -190,12 +190,49 @@ struct MlpFn : public torch::autograd::Function<MlpFn> {
 };
 }  // namespace
 
+// tiny-cuda-nn's SphericalHarmonics encoding (the reference's SHEncoding, include/neural_net/encodings/encodings.h:6-27: declared, never
+// evaluated by the training path): x in [0,1]^3 is the direction (d + 1) / 2; outputs the degree^2 real spherical-harmonic basis values of
+// d = 2 x - 1 in tiny-cuda-nn's order and sign convention (the basis of SPEC A.2 / csrc/view_colors.hip).  Parameter-free; composed of
+// libtorch elementwise operations (autograd of any order for free) — not a hot path, so no kernel of its own.
+static torch::Tensor sh_encoding(const torch::Tensor &x01, int degree) {
+  TORCH_CHECK(degree >= 1 && degree <= 4, "SphericalHarmonics encoding: degree must be in [1, 4], got ", degree);
+  torch::Tensor d = x01 * 2.0 - 1.0;
+  torch::Tensor x = d.select(1, 0), y = d.select(1, 1), z = d.select(1, 2);
+  std::vector<torch::Tensor> o;
+  o.push_back(torch::full_like(x, 0.28209479177387814));
+  if (degree > 1) {
+    o.push_back(-0.48860251190291987 * y);
+    o.push_back(0.48860251190291987 * z);
+    o.push_back(-0.48860251190291987 * x);
+  }
+  if (degree > 2) {
+    torch::Tensor x2 = x * x, y2 = y * y, z2 = z * z;
+    o.push_back(1.0925484305920792 * (x * y));
+    o.push_back(-1.0925484305920792 * (y * z));
+    o.push_back(0.94617469575755997 * z2 - 0.31539156525251999);
+    o.push_back(-1.0925484305920792 * (x * z));
+    o.push_back(0.54627421529603959 * x2 - 0.54627421529603959 * y2);
+    if (degree > 3) {
+      o.push_back(0.59004358992664352 * y * (-3.0 * x2 + y2));
+      o.push_back(2.8906114426405538 * (x * y) * z);
+      o.push_back(0.45704579946446572 * y * (1.0 - 5.0 * z2));
+      o.push_back(0.3731763325901154 * z * (5.0 * z2 - 3.0));
+      o.push_back(0.45704579946446572 * x * (1.0 - 5.0 * z2));
+      o.push_back(1.4453057213202769 * z * (x2 - y2));
+      o.push_back(0.59004358992664352 * x * (-x2 + 3.0 * y2));
+    }
+  }
+  return torch::stack(o, 1);
+}
+
 void TCNNEncoding::init_encoding(int n_input_dims, const nlohmann::json &config, const std::string &name) {
   name_ = name;
   n_input_dims_ = n_input_dims;
   otype_ = config.value("otype", std::string("Grid"));
-  if (otype_ == "SphericalHarmonics") {  // declared by the reference (encodings.h:6-27) but never evaluated in training
+  if (otype_ == "SphericalHarmonics") {  // declared by the reference (encodings.h:6-27) but never evaluated in training; parameter-free
     sh_degree_ = config.value("degree", 4);
+    TORCH_CHECK(n_input_dims == 3, "TCNNEncoding: the SphericalHarmonics encoding takes 3 input dims");
+    params_ = torch::empty({0});
     return;
   }
   TORCH_CHECK(otype_ == "Grid" || otype_ == "HashGrid", "TCNNEncoding: otype '", otype_, "' is not implemented");
@@ -218,9 +255,8 @@ void TCNNEncoding::init_encoding(int n_input_dims, const nlohmann::json &config,
 }
 
 torch::Tensor TCNNEncoding::forward(const torch::Tensor &x) {
-  TORCH_CHECK(otype_ != "SphericalHarmonics", "TCNNEncoding: the SphericalHarmonics encoding is declared but not implemented "
-              "(unused by the reference's training path)");
   TORCH_CHECK(x.dim() == 2 && x.size(1) == 3, "TCNNEncoding::forward: expected [B,3]");
+  if (otype_ == "SphericalHarmonics") return sh_encoding(x, sh_degree_);
   return GridFwd::apply(x, params_.view({-1, n_feat_}), cfg_pack({n_levels_, n_feat_, log2_hashmap_, base_res_, per_level_scale_}));
 }
 

@@ -324,3 +324,32 @@ def test_cpp_fused_extras_match_python_mirror(host):
         o1.step(bool(it % 2)); o2.step(zero_grad=bool(it % 2))      # odd steps: the launch also zeroes the gradient it consumed
         assert torch.equal(g1, g2) and bool((g1 == 0).all()) == bool(it % 2)
     assert torch.equal(f1, f2)
+
+
+@pytest.mark.parametrize("degree", [1, 2, 3, 4])
+def test_spherical_harmonics_encoding_is_the_view_colour_basis(host, oracle, degree):
+    """SHEncoding (the reference's include/neural_net/encodings/encodings.h:6-27: TCNNEncoding with otype SphericalHarmonics): degree^2 outputs,
+    the basis of the splat colours (SPEC A.2: oracle view_colors_fwd with one-hot coefficients evaluates it), differentiable in its input."""
+    dev = torch.device("cuda:0")
+    enc = host.TCNNEncoding.spherical_harmonics(degree)
+    assert enc.get_out_dim() == degree * degree and enc.params_.numel() == 0
+    g = torch.Generator().manual_seed(degree)
+    d = torch.nn.functional.normalize(torch.randn(500, 3, generator=g), dim=-1)
+    x = ((d + 1.0) * 0.5).to(dev).requires_grad_(True)                       # tiny-cuda-nn's convention: the input is (direction + 1) / 2
+    y = enc.forward(x)
+    assert y.shape == (500, degree * degree)
+    # oracle: colour = max(sum_k basis_k(dir) c_k + 0.5, 0) with dir = mean - camera position (camera at the origin: viewmat = I)
+    K = degree * degree
+    vm = np.eye(4, dtype=np.float32)[None]
+    cam, gid = np.zeros(500, np.int64), np.arange(500, dtype=np.int64)
+    for k in range(K):
+        sh = np.zeros((500, K, 3), np.float32)
+        sh[:, k, 0] = 1.0
+        col = oracle.view_colors_fwd(vm, d.numpy().astype(np.float32), sh, cam, gid, degree - 1, prec="f64")[:, 0]
+        want = np.maximum(y[:, k].detach().cpu().double().numpy() + 0.5, 0.0)
+        np.testing.assert_allclose(col, want, rtol=0, atol=2e-6, err_msg=f"basis {k}")
+    (gx,) = torch.autograd.grad((y * torch.arange(1, K + 1, device=dev)).sum(), x, create_graph=True)
+    assert gx.shape == x.shape and bool(torch.isfinite(gx).all())
+    if degree > 2:
+        (ggx,) = torch.autograd.grad(gx.square().sum(), x)                   # second order exists (autograd of the composition)
+        assert float(ggx.abs().sum()) > 0
