@@ -23,17 +23,23 @@ g = lambda k: vals.get(k)
 out = {"kernel": KERNEL, "counters_per_launch": vals, "query_points_per_launch": det.get("mean_sdf_points"),
        "one_stream_average_launch_ns": float(stats["AverageNs"]) if stats else None}
 if g("TCP_TCC_READ_REQ_sum") and g("TCP_TCC_READ_REQ_LATENCY_sum") and g("GRBM_GUI_ACTIVE"):
-    req, lat, cyc = g("TCP_TCC_READ_REQ_sum"), g("TCP_TCC_READ_REQ_LATENCY_sum"), g("GRBM_GUI_ACTIVE")
+    # GRBM_GUI_ACTIVE is summed over the 8 XCDs of the chip (34 M for a 1.7 ms launch at ~2.4 GHz): cycles of ONE clock domain = / 8
+    req, lat, cyc = g("TCP_TCC_READ_REQ_sum"), g("TCP_TCC_READ_REQ_LATENCY_sum"), g("GRBM_GUI_ACTIVE") / 8.0
+    out["kernel_cycles"] = cyc
     out["l1_to_l2_read_requests"] = req
     out["mean_read_latency_cycles"] = lat / req
     out["reads_in_flight_per_cu"] = lat / cyc / 256.0
     out["requests_per_query_point"] = req / det["mean_sdf_points"] if det.get("mean_sdf_points") else None
+    out["requests_per_cycle_per_cu"] = req / cyc / 256.0
+    out["reading"] = ("the L1s hold ~reads_in_flight_per_cu line requests in flight per CU for the whole launch (the vector L1's miss capacity is 64) at "
+                      "mean_read_latency_cycles each: the kernel's rate is requests = in-flight x CUs / latency (Little), not a function of occupancy; half "
+                      "of the requests miss the 4 MiB L2 of their XCD (the 14 hashed levels are 4 MiB each) and are served by the Infinity Cache")
     out["pending_stall_fraction_of_cu_cycles"] = g("TCP_PENDING_STALL_CYCLES_sum") / (cyc * 256.0) if g("TCP_PENDING_STALL_CYCLES_sum") else None
 if g("TCC_HIT_sum") is not None and g("TCC_MISS_sum"):
     out["l2_hit_rate"] = g("TCC_HIT_sum") / (g("TCC_HIT_sum") + g("TCC_MISS_sum"))
     out["fabric_read_requests"] = g("TCC_EA0_RDREQ_sum")
 if g("TA_TA_BUSY_sum") and g("GRBM_GUI_ACTIVE"):
-    out["ta_busy_fraction"] = g("TA_TA_BUSY_sum") / (g("GRBM_GUI_ACTIVE") * 256.0)
+    out["ta_busy_fraction"] = g("TA_TA_BUSY_sum") / (g("GRBM_GUI_ACTIVE") / 8.0 * 256.0)
 path = os.path.join(root, f"{tag}_hashgrid_fwd_l1_l2_counters.json")
 json.dump(out, open(path, "w"), indent=1)
 print(json.dumps(out, indent=1))
