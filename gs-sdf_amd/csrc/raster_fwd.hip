@@ -350,8 +350,10 @@ static int rasterize_fwd_launch(int64_t C, int64_t M, int64_t I, int width, int 
 #define FWD_ARGS n_xcd, total, n_tiles, I, width, height, tw, means2d, ray_transforms, colors, opacities, normals, backgrounds, masks, isect_offsets, \
                  flatten_ids, render_colors, render_depths, render_alphas, render_normals, render_median, last_ids, median_ids,          \
                  (unsigned *)visibilities, final_T, counters, trace_rows, trace_stride, trace_bits
-  // A/B switch (measured): GSDF_RASTER_ROW_LISTS = 0 quadrant lists in both kernels, 1 row lists in both, 2 (default) backward only
-  static const bool quadrant_lists = [] { const char *e = getenv("GSDF_RASTER_ROW_LISTS"); return e == nullptr || e[0] != '1'; }();
+  // A/B switch (measured): GSDF_RASTER_ROW_LISTS = 1 (default) row lists in both kernels, 0 quadrant lists in both, 2 quadrant forward +
+  // row-list backward (the round-4 default).  Every combination takes its skip decisions from the same 4x4 reach mask (SplatBatchT::m16); since the
+  // quadrant forward pays for that with a mask test per visit (0.53 against 0.43 ms at cfg3), the row-list forward is the default in round 5.
+  static const bool quadrant_lists = [] { const char *e = getenv("GSDF_RASTER_ROW_LISTS"); return e != nullptr && (e[0] == '0' || e[0] == '2'); }();
   if (quadrant_lists) {
     if (counters != nullptr) raster_fwd_kernel<true, false><<<xcd_grid(total, n_xcd), RT, 0, stream>>>(FWD_ARGS);
     else if (trace_rows != nullptr) raster_fwd_kernel<false, true><<<xcd_grid(total, n_xcd), RT, 0, stream>>>(FWD_ARGS);

@@ -35,7 +35,7 @@ if len(sys.argv) > 2 and sys.argv[2] == "child":
     sys.exit(0)
 wl = sys.argv[1] if len(sys.argv) > 1 else "cfg3_1M_1080p"
 out = {}
-VARIANTS = (("row_lists", {}), ("quadrant_lists", {"GSDF_RASTER_ROW_LISTS": "0"}), ("row_lists_again", {}))
+VARIANTS = (("row_lists", {}), ("quadrant_lists", {"GSDF_RASTER_ROW_LISTS": "0"}), ("quadrant_forward_row_backward", {"GSDF_RASTER_ROW_LISTS": "2"}), ("row_lists_again", {}))
 if os.environ.get("GSDF_EXP_VARIANTS"):
     VARIANTS = tuple((v, dict(kv.split("=") for kv in v.split(",") if kv)) for v in os.environ["GSDF_EXP_VARIANTS"].split(";"))
 for name, env in VARIANTS:
