@@ -502,6 +502,36 @@ def main():
         step(nxt + i)
     nxt += min(10, args.steps)
     kern_all = timers_end()[0]
+    # The roofline kernels ALONE on the chip: the same step on ONE stream (a second JointIteration, same scene and views), HIP events on that
+    # stream.  In the two-stream step a launch's duration includes the slowdown from the other leg's kernels running beside it (this round the
+    # hash-grid forward runs beside the compositing backward: 2.4 ms there, 1.7 ms alone, the step equally fast) — `roofline.frac` keeps the
+    # duration of the timed region, `roofline.alone` is the kernel's own rate and what the one-stream rocprofv3 summary in profiles/ must agree with.
+    alone = None
+    if impl == "cpp" and rank == 0 and world == 1 and not args.no_overlap and not args.no_sdf and not args.dump_grads:
+        import copy
+        a1 = copy.copy(args)
+        a1.no_overlap = True
+        ji1, pool1, rsdf1, cams1, _ = make_cpp_iteration(a1, sc, params, dev, W, H, deg, views)
+        h1 = {}
+
+        def step1(i):
+            vi = i % views.shape[0]
+            sz = ji1.step(views[vi][None], K, target, pool1[i % 8], rsdf1[i % 8], cpp_up, True, cpp_cams[vi])
+            for k in ("M", "I", "n_gs_sdf"):
+                h1.setdefault(k, []).append(int(sz[k]))
+        for i in range(3):
+            step1(warm_total + i)
+        torch.cuda.synchronize()
+        h1.clear()
+        n1 = min(10, args.steps)
+        capi.timing_begin(roof_cabi)
+        for i in range(n1):
+            step1(warm_total + i)
+        torch.cuda.synchronize()
+        med1, mean1, calls1 = cabi_timing_to_ops(capi.timing_end())
+        alone = {"steps": n1, "mean_ms": mean1, "calls": calls1, "avg": {k: sum(v) / len(v) for k, v in h1.items()}}
+        alone["avg"]["n_ray_pts"] = 32768.0
+        del ji1
     if rank == 0 and os.environ.get("GSDF_BENCH_DUMP_PARAMS"):
         # debugging / evidence hook (tools/compare_mlp_pipes.py): the parameters after warmup + steps optimizer steps
         torch.cuda.synchronize()
@@ -512,6 +542,15 @@ def main():
         a = report.algorithmic(avg, N, W, H, deg, analytic, args.no_sdf, (dec_dims if impl == "cpp" else lm.decoder.dims) if not args.no_sdf else None)
         split_mlp = not args.no_sdf and os.environ.get("GSDF_MLP_MFMA", "bf16x3")[:1] not in "fF"
         roof = report.roofline(a, calls, kern_mean, kern, args.steps, args.workload, analytic, args.no_sdf, split_mlp, elapsed / args.steps)
+        if alone is not None:
+            a_al = report.algorithmic(alone["avg"], N, W, H, deg, analytic, args.no_sdf, dec_dims)
+            r_al = report.roofline(a_al, alone["calls"], alone["mean_ms"], alone["mean_ms"], alone["steps"], args.workload, analytic, args.no_sdf, split_mlp, 1.0)
+            pick = lambda r: {k: r[k] for k in ("bound", "achieved", "peak", "unit", "frac", "avg_launch_ms") if k in r}
+            roof["alone"] = dict(pick(r_al) if r_al["kernel"] == roof["kernel"] else pick(r_al["others"][roof["kernel"]]), kernel=roof["kernel"],
+                                 steps=alone["steps"], sdf_points_per_step=round(a_al["sdf_pts"]),
+                                 what="the same step on ONE stream (second JointIteration, pool ray batches), HIP events on that stream: the kernel alone on the chip; "
+                                      "profiles/ holds the one-stream rocprofv3 summary it must agree with",
+                                 others={k: pick(v) for k, v in ([(r_al["kernel"], r_al)] + list(r_al["others"].items())) if k != roof["kernel"]})
         direct = impl == "cpp" and not args.no_overlap and analytic and ref_terms
         detail = {
             "metric": "train iters/sec (splat raster + SDF fwd+bwd), 1M Gaussians @1080p" if not args.no_sdf

@@ -154,4 +154,9 @@ int xcd_count(hipStream_t stream);
 
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 
+// A count the HOST may be polling (gsdf_host_words_alloc: pinned, device-mapped, fine-grained host memory): one system-scope store straight to the
+// word.  (Round 4 wrote it with a plain store + __threadfence_system(): on gfx950 that fence writes the whole L2's dirty lines back — 8-65 us
+// beside a kernel of the other leg — although the host reads nothing but the word.)
+__device__ __forceinline__ void store_host_visible(int64_t *p, int64_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+
 }  // namespace gsdf

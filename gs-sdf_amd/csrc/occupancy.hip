@@ -165,7 +165,7 @@ __global__ void __launch_bounds__(1024) visible_scan_kernel(int nblk, int32_t *_
     if (threadIdx.x == 1023) s_carry = before + incl;
     __syncthreads();
   }
-  if (threadIdx.x == 0) { *total = s_carry; __threadfence_system(); }   // (the count may be a host-visible word: gsdf_host_words_alloc)
+  if (threadIdx.x == 0) store_host_visible(total, s_carry);   // (the count may be a host-visible word: gsdf_host_words_alloc)
 }
 __global__ void __launch_bounds__(256)
     visible_write_kernel(int64_t n, const uint8_t *__restrict__ flags, const int32_t *__restrict__ offsets, int64_t *__restrict__ ids) {
@@ -530,7 +530,7 @@ __global__ void __launch_bounds__(1024)
   for (int w = 0; w < 16; ++w) { before += w < wave ? s_w[w] : 0; all += s_w[w]; }
   int64_t run = before + v - s;
   for (int64_t i = b; i < e; ++i) { run += counts[i]; incl[i] = run; }
-  if (threadIdx.x == 0) { *total = all; __threadfence_system(); }
+  if (threadIdx.x == 0) store_host_visible(total, all);
 }
 
 }  // namespace gsdf

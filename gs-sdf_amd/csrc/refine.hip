@@ -79,9 +79,8 @@ __global__ void refine_totals_kernel(int64_t n, const int64_t *__restrict__ incl
   const int k = threadIdx.x;
   if (k < 4) {
     const int64_t hi = incl[(int64_t)(k + 1) * n - 1], lo = k ? incl[(int64_t)k * n - 1] : 0;
-    totals[k] = hi - lo;
+    store_host_visible(totals + k, hi - lo);
   }
-  __threadfence_system();
 }
 
 struct RefineSrc {

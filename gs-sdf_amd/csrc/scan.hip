@@ -69,7 +69,7 @@ __global__ void __launch_bounds__(SCAN_THREADS) scan_downsweep_kernel(const int3
     int64_t t = 0;
     for (int64_t i = threadIdx.x; i < nb; i += SCAN_THREADS) t += partials[i];
     t = block_sum_i64(t, lds4);
-    if (threadIdx.x == 0) { *total = t; __threadfence_system(); }
+    if (threadIdx.x == 0) store_host_visible(total, t);
   }
   int64_t before = 0;
   for (int64_t i = threadIdx.x; i < (int64_t)blockIdx.x; i += SCAN_THREADS) before += partials[i];
@@ -91,7 +91,7 @@ __global__ void __launch_bounds__(SCAN_THREADS) scan_downsweep_kernel(const int3
   }
 }
 
-__global__ void scan_zero_total_kernel(int64_t *total) { *total = 0; __threadfence_system(); }   // the host may be polling the word
+__global__ void scan_zero_total_kernel(int64_t *total) { store_host_visible(total, 0); }   // the host may be polling the word
 
 size_t scan_ws_bytes(int64_t n) {
   const int64_t nb = (n + SCAN_TILE - 1) / SCAN_TILE;
