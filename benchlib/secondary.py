@@ -61,5 +61,6 @@ def run_all(args, impl, analytic, sc, views, K, ug6, target, N, W, H, deg, dev):
             out[name] = fn()
         except Exception as e:   # noqa: BLE001
             out[name] = {"error": repr(e)[:300]}
-        print(f"[secondary] {name} " + json.dumps(out[name]), flush=True)
+        short = {k: v for k, v in out[name].items() if k not in ("events", "config", "metric")} if isinstance(out[name], dict) else out[name]
+        print(f"[secondary] {name} " + json.dumps(short), flush=True)      # the full record is in the detail file
     return out
