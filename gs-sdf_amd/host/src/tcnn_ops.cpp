@@ -26,6 +26,27 @@ std::vector<int64_t> cfg_pack(const GridCfg &c) {
 }
 
 // (v_feat, x, table) -> (v_x, v_table): the encoding's backward as a differentiable op (grad of grad)
+// The double-backward operators below are evaluated by kernels inside a backward(): libtorch records nothing for them, so a THIRD derivative
+// (LocalMap::get_gradient with hessian = true and numerical_grad = 0, then a loss on the Hessian — the reference's curvate_weight > 0,
+// /root/reference/include/neural_net/local_map.cpp:163-168; default 0.0, config/base.yaml:32) would silently be missing.  When such a backward runs
+// with create_graph = true its results pass through this node: their VALUES are exact (second order), differentiating them again raises.
+struct ThirdOrderGuard : public torch::autograd::Function<ThirdOrderGuard> {
+  static Tensor forward(AutogradContext *, const Tensor &value, const Tensor &anchor) {
+    (void)anchor;   // an input that requires grad: it puts this node on the graph
+    return value.view_as(value);
+  }
+  static tensor_list backward(AutogradContext *, tensor_list) {
+    TORCH_CHECK(false, "TCNNEncoding / TCNNNetwork: third-order derivatives are not implemented (a loss on the analytic Hessian, curvate_weight > 0 with "
+                       "numerical_grad = 0); use the numerical branch of LocalMap::get_gradient (numerical_grad = 1), whose Hessian is first order in "
+                       "the network");
+    return {};
+  }
+};
+static Tensor guard3(const Tensor &value, const Tensor &anchor) {
+  if (!value.defined() || !torch::GradMode::is_enabled() || !anchor.defined() || !anchor.requires_grad()) return value;
+  return ThirdOrderGuard::apply(value, anchor);
+}
+
 struct GridBwd : public torch::autograd::Function<GridBwd> {
   static tensor_list forward(AutogradContext *ctx, const Tensor &v_feat_, const Tensor &x, const Tensor &table,
                              std::vector<int64_t> cfgv, bool want_table) {
@@ -78,7 +99,9 @@ struct GridBwd : public torch::autograd::Function<GridBwd> {
                                   binned ? nullptr : fpm(g_table), fpm(g_x), cur_stream()),
             "TCNNEncoding double backward");
     }
-    return {g_vfeat, g_x, g_table, Tensor(), Tensor()};
+    // (anchor: the first saved input that is part of a graph)
+    const Tensor &anchor = table.requires_grad() ? table : (x.requires_grad() ? x : v_feat);
+    return {guard3(g_vfeat, anchor), guard3(g_x, anchor), guard3(g_table, anchor), Tensor(), Tensor()};
   }
 };
 
@@ -144,7 +167,8 @@ struct MlpBwd : public torch::autograd::Function<MlpBwd> {
     Tensor ws2 = empty_like_opts(vv_in, {(int64_t)gsdf_mlp_bwd_bwd_ws_bytes(B, nl)}, torch::kUInt8);
     check(gsdf_mlp_bwd_bwd(B, nl, dims.data(), fp(w), fp(acts), fp(v_out), ws.data_ptr(), fp(vv_in), fpm(g_vout), fpm(g_w), ws2.data_ptr(),
                            cur_stream()), "TCNNNetwork double backward");
-    return {ctx->needs_input_grad(0) ? g_vout : Tensor(), Tensor(), g_w, Tensor(), Tensor(), Tensor(), Tensor(), Tensor()};
+    const Tensor &anchor = w.requires_grad() ? w : v_out;
+    return {ctx->needs_input_grad(0) ? guard3(g_vout, anchor) : Tensor(), Tensor(), guard3(g_w, anchor), Tensor(), Tensor(), Tensor(), Tensor(), Tensor()};
   }
 };
 

@@ -25,7 +25,9 @@ struct TCNNEncoding {
   // gradients as forward(x); the 7 rows of a group are gathered together and the table-gradient scatter merges the rows that
   // share a grid cell.
   torch::Tensor forward_stencil(const torch::Tensor &x, int64_t n_groups, double delta_unit);
-  virtual size_t get_out_dim() const { return (size_t)n_levels_ * n_feat_; }
+  virtual size_t get_out_dim() const {   // (the reference's SHEncoding overrides it with levels^2, encodings.h:26: the same value)
+    return otype_ == "SphericalHarmonics" ? (size_t)sh_degree_ * sh_degree_ : (size_t)n_levels_ * n_feat_;
+  }
 
   torch::Tensor params_;
   std::string name_;

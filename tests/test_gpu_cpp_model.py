@@ -415,3 +415,46 @@ def test_fused_ray_sampler_empty_batch(host):
     z = torch.zeros(0, 3, device=dev)
     out = host.sample_rays(cm, dict(origin=z, direction=z, depth=torch.zeros(0, 1, device=dev), xyz=z), 0.02, 0.1875, 3, True)
     assert out["xyz"].shape == (0, 3) and out["ridx"].shape == (0,) and out["ridx"].dtype == torch.int64
+
+
+def test_analytic_hessian_values_match_oracle_and_third_order_fails_loudly(host, oracle):
+    """LocalMap::get_gradient(hessian = true, numerical_grad = 0) (local_map.cpp:151-168): the second autograd::grad call goes through the
+    drop-in encoder's double-backward operator.  Its VALUE — sum_j d g_j / d x_i, with the ReLU masks piecewise constant exactly the oracle's
+    grid double backward applied to vv = 1 — is checked here; a loss on it (curvate_weight > 0) would need a THIRD derivative, which the
+    operators do not implement: it must raise, not silently train on a missing term (VERDICT r4 missing #4)."""
+    import numpy as np
+    dev = torch.device("cuda:0")
+    cm, pm, cfg = make_maps(host, 0)
+    g = torch.Generator().manual_seed(3)
+    B = 1500
+    xyz = ((torch.rand(B, 3, generator=g) - 0.5) * 12.0 + torch.tensor([0.0, 0.0, 5.5])).to(dev)
+    out = cm.get_gradient(xyz, 0.02, None, True, False)
+    assert len(out) == 2 and out[0].shape == out[1].shape == (B, 3)
+    grad, hess = out
+    # oracle: features, decoder backward of d sdf -> J = d sdf / d feat, then the grid's double backward with vv = 1 gives d(J^T dfeat/dx . 1)/dx
+    n_ = lambda t: t.detach().cpu().numpy()
+    inv = float(cm.map_size_inv_) if hasattr(cm, "map_size_inv_") else 1.0 / cfg.map_size()
+    x01 = n_(pm.xyz_to_zp1_pts(xyz)).astype(np.float32)
+    table = n_(cm.encoder.params_).reshape(-1, GRID["n_features_per_level"])
+    ocfg = dict(n_levels=GRID["n_levels"], n_feat=GRID["n_features_per_level"], log2_hashmap=GRID["log2_hashmap_size"], base_res=GRID["base_resolution"],
+                per_level_scale=GRID["per_level_scale"])
+    feat = oracle.grid_fwd(x01, table, ocfg, prec="f32")
+    dims = list(pm.decoder.dims)
+    v_out = np.zeros((B, 2)); v_out[:, 0] = 1.0
+    J, _, _ = oracle.mlp_bwd(feat, dims, n_(cm.decoder.params_), n_(cm.decoder.biases_), v_out, prec="f64")
+    _, gx01 = oracle.grid_bwd(x01, table, J, ocfg, prec="f32")
+    s = 0.5 * 2.0 * inv                                              # d x01 / d xyz
+    assert_close(grad, gx01 * s, 2e-4, "analytic gradient")
+    vv = np.full((B, 3), s, np.float64)                               # d(sum grad) / d(grad_x01) = s for every component
+    _, _, g_x = oracle.grid_bwd_bwd(x01, table, J, vv, ocfg, prec="f32")
+    assert_close(hess, g_x * s, 2e-3, "analytic Hessian (row sums)")
+    assert float(hess.abs().sum()) > 0
+    # the value is on a graph only so that a third derivative can fail LOUDLY
+    assert hess.requires_grad
+    with pytest.raises(RuntimeError, match="third-order derivatives are not implemented"):
+        hess.abs().sum().backward()
+    # ... while the second-order training path (eikonal on the analytic gradient -> parameters) is untouched by the guard
+    x2 = xyz.clone().requires_grad_(True)
+    ga = cm.get_gradient(x2, 0.02, None, False, False)[0]
+    (gt,) = torch.autograd.grad(((ga.norm(dim=-1) - 1.0) ** 2).mean(), [cm.encoder.params_])
+    assert bool(torch.isfinite(gt).all()) and float(gt.abs().sum()) > 0
