@@ -543,14 +543,24 @@ def main():
         split_mlp = not args.no_sdf and os.environ.get("GSDF_MLP_MFMA", "bf16x3")[:1] not in "fF"
         roof = report.roofline(a, calls, kern_mean, kern, args.steps, args.workload, analytic, args.no_sdf, split_mlp, elapsed / args.steps)
         if alone is not None:
+            # The roofline figure is the kernel's OWN rate: algorithmic bytes of a launch over its duration alone on the chip (the same step on one
+            # stream, HIP events on that stream) — what the one-stream rocprofv3 summary in profiles/ reproduces.  `in_step` keeps the timed region's
+            # figure: in the two-stream step a launch's duration includes the slowdown from the other leg's kernels beside it (the hash-grid forward
+            # runs beside the compositing backward: 2.4 ms there, 1.7 alone, the step equally fast), which says where a leg waits, not how fast a kernel is.
             a_al = report.algorithmic(alone["avg"], N, W, H, deg, analytic, args.no_sdf, dec_dims)
-            r_al = report.roofline(a_al, alone["calls"], alone["mean_ms"], alone["mean_ms"], alone["steps"], args.workload, analytic, args.no_sdf, split_mlp, 1.0)
-            pick = lambda r: {k: r[k] for k in ("bound", "achieved", "peak", "unit", "frac", "avg_launch_ms") if k in r}
-            roof["alone"] = dict(pick(r_al) if r_al["kernel"] == roof["kernel"] else pick(r_al["others"][roof["kernel"]]), kernel=roof["kernel"],
-                                 steps=alone["steps"], sdf_points_per_step=round(a_al["sdf_pts"]),
-                                 what="the same step on ONE stream (second JointIteration, pool ray batches), HIP events on that stream: the kernel alone on the chip; "
-                                      "profiles/ holds the one-stream rocprofv3 summary it must agree with",
-                                 others={k: pick(v) for k, v in ([(r_al["kernel"], r_al)] + list(r_al["others"].items())) if k != roof["kernel"]})
+            r_al = report.roofline(a_al, alone["calls"], alone["mean_ms"], alone["mean_ms"], alone["steps"], args.workload, analytic, args.no_sdf, split_mlp,
+                                   elapsed / args.steps)
+            pick = lambda r: {k: r[k] for k in ("bound", "achieved", "peak", "unit", "frac", "avg_launch_ms", "algorithmic_bytes", "algorithmic_flops") if k in r}
+            dom = roof["kernel"]
+            in_step = dict(pick(roof), sdf_points_per_step=round(a["sdf_pts"]), ms_per_step_by_kernel=roof["ms_per_step_by_kernel"],
+                           others={k: pick(v) for k, v in roof["others"].items()}, valu=roof.get("valu"),
+                           what="the timed region (two streams): HIP events on the launch stream, durations include the other leg's kernels running beside")
+            src = r_al if r_al["kernel"] == dom else dict(r_al["others"][dom], kernel=dom)
+            roof = dict(r_al, **pick(src), kernel=dom, kernel_selection=roof["kernel_selection"], launches_per_step=roof["launches_per_step"],
+                        measured=("alone: the same step on ONE stream (a second JointIteration on the same scene and views, pool ray batches), HIP events on that "
+                                  f"stream over {alone['steps']} steps after the timed region; profiles/ holds the one-stream rocprofv3 summary it agrees with"),
+                        sdf_points_per_step=round(a_al["sdf_pts"]), in_step=in_step,
+                        step_B_splat_bytes=int(a["b_splat"]), step_hbm_frac=a["b_splat"] / (elapsed / args.steps) / 8e12)
         direct = impl == "cpp" and not args.no_overlap and analytic and ref_terms
         detail = {
             "metric": "train iters/sec (splat raster + SDF fwd+bwd), 1M Gaussians @1080p" if not args.no_sdf

@@ -172,10 +172,13 @@ def compact_line(d):
                         "launches_per_step": r["launches_per_step"], "traffic": None if r["traffic"] is None else int(r["traffic"]),
                         "traffic_over_algorithmic": None if not r.get("traffic_over_algorithmic") else round(r["traffic_over_algorithmic"], 2),
                         "valu_issue_frac": None if not r.get("valu") else {k.replace("rasterize_2dgs_", ""): round(v["frac_of_issue_peak"], 3) for k, v in r["valu"].items()},
-                        "alone": None if not r.get("alone") else {"avg_launch_ms": round(r["alone"]["avg_launch_ms"], 4), "frac": round(r["alone"]["frac"], 4),
-                                                                  "sdf_points_per_step": r["alone"]["sdf_points_per_step"], "what": "same step on one stream, HIP events"},
+                        "measured": "alone (same step on one stream, HIP events)" if r.get("in_step") else "timed region",
+                        "sdf_points_per_step": r.get("sdf_points_per_step"),
+                        "in_step": None if not r.get("in_step") else {"avg_launch_ms": round(r["in_step"]["avg_launch_ms"], 4), "frac": round(r["in_step"]["frac"], 4),
+                                                                      "sdf_points_per_step": r["in_step"]["sdf_points_per_step"],
+                                                                      "what": "timed region, two streams: beside the other leg's kernels"},
                         "step_hbm_frac": round(r["step_hbm_frac"], 4),
-                        "ms_per_step_by_kernel": r["ms_per_step_by_kernel"]}
+                        "ms_per_step_by_kernel": (r["in_step"] if r.get("in_step") else r)["ms_per_step_by_kernel"]}
     cb = d.get("cpu_baseline")
     if cb:
         p = cb.get("parity", {})
