@@ -84,7 +84,7 @@ def _assert_same(ngs, opt, ji, what, offsets_tol=2e-6):
         assert torch.equal(st[k], js[k]), what + ": state " + k
 
 
-@pytest.mark.parametrize("N,deg,iter_,radii", [(20_000, 1, 600, False), (50_000, 0, 3100, False), (20_000, 2, 600, True)])
+@pytest.mark.parametrize("N,deg,iter_,radii", [(20_000, 1, 600, False), (50_000, 0, 3100, False), (20_000, 2, 600, True), (1_000_000, 0, 700, False)])
 def test_refine_is_grow_then_prune_then_zero_state(host, N, deg, iter_, radii):
     ngs, opt, ji, rc = _pair(host, N, deg, 3, iter_, radii)
     _assert_same(ngs, opt, ji, "before")
