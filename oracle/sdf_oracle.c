@@ -154,6 +154,9 @@ void orc_grid_bwd(int64_t B, int n_levels, int n_feat, int log2_hashmap, int bas
                   REAL *v_x) {
   grid_cfg_t c = {n_levels, n_feat, log2_hashmap, base_res, per_level_scale};
   const int F = n_feat;
+  /* threaded over the points (round 5: the cpu_baseline leg of bench.py times this function); the table gradient is a double sum whose order
+   * then varies by ~1e-16 relative */
+#pragma omp parallel for
   for (int64_t b = 0; b < B; ++b) {
     REAL gx[3] = {0, 0, 0};
     for (int l = 0; l < n_levels; ++l) {
@@ -163,7 +166,11 @@ void orc_grid_bwd(int64_t B, int n_levels, int n_feat, int log2_hashmap, int bas
         REAL vf = v_feat[b * n_levels * F + l * F + f];
         for (int k = 0; k < 8; ++k) {
           int64_t e = (offsets[l] + cr.idx[k]) * F + f;
-          if (v_table) v_table[e] += (double)(cr.w[k] * vf);
+          if (v_table) {
+            const double add = (double)(cr.w[k] * vf);
+#pragma omp atomic
+            v_table[e] += add;
+          }
           for (int d = 0; d < 3; ++d) gx[d] += vf * cr.scale * cr.dw[k][d] * table[e];
         }
       }
@@ -251,9 +258,15 @@ void orc_mlp_bwd(int64_t B, int n_layers, const int *dims, const REAL *weights, 
   int64_t nw = 0, nb = 0;
   for (int l = 0; l <= n_layers; ++l) if (dims[l] > maxd) maxd = dims[l];
   for (int l = 0; l < n_layers; ++l) { nw += (int64_t)dims[l] * dims[l + 1]; nb += dims[l + 1]; }
-  (void)nw; (void)nb;
+  /* threaded over the points (round 5: timed by bench.py's cpu_baseline leg): every thread accumulates its own weight / bias gradient and the
+   * partial sums are added in turn (double sums: the order changes the result by ~1e-16 relative) */
+#pragma omp parallel
+  {
   REAL *h = (REAL *)malloc(sizeof(REAL) * (size_t)maxd * (n_layers + 1));
   REAL *g = (REAL *)malloc(sizeof(REAL) * maxd), *g2 = (REAL *)malloc(sizeof(REAL) * maxd);
+  double *tw = v_weights ? (double *)calloc((size_t)nw, sizeof(double)) : NULL;
+  double *tb = (v_biases && biases) ? (double *)calloc((size_t)nb, sizeof(double)) : NULL;
+#pragma omp for
   for (int64_t b = 0; b < B; ++b) {
     memcpy(h, in + b * dims[0], sizeof(REAL) * dims[0]);
     const REAL *W = weights, *bi = biases;
@@ -282,9 +295,9 @@ void orc_mlp_bwd(int64_t B, int n_layers, const int *dims, const REAL *weights, 
         for (int o = 0; o < O; ++o) if (!(hout[o] > 0)) g[o] = 0; /* ReLU mask */
       for (int i = 0; i < I; ++i) g2[i] = 0;
       for (int o = 0; o < O; ++o) {
-        if (v_biases && biases) v_biases[boff + o] += (double)g[o];
+        if (tb) tb[boff + o] += (double)g[o];
         for (int i = 0; i < I; ++i) {
-          if (v_weights) v_weights[woff + (int64_t)o * I + i] += (double)(g[o] * hin[i]);
+          if (tw) tw[woff + (int64_t)o * I + i] += (double)(g[o] * hin[i]);
           g2[i] += Wl[o * I + i] * g[o];
         }
       }
@@ -292,7 +305,13 @@ void orc_mlp_bwd(int64_t B, int n_layers, const int *dims, const REAL *weights, 
     }
     if (v_in) memcpy(v_in + b * dims[0], g, sizeof(REAL) * dims[0]);
   }
-  free(h); free(g); free(g2);
+#pragma omp critical
+  {
+    if (tw) for (int64_t k = 0; k < nw; ++k) v_weights[k] += tw[k];
+    if (tb) for (int64_t k = 0; k < nb; ++k) v_biases[k] += tb[k];
+  }
+  free(h); free(g); free(g2); free(tw); free(tb);
+  }
 }
 
 /* Double backward of the decoder (the analytic eikonal term of the reference's DEFAULT configuration:
