@@ -197,21 +197,10 @@ struct XcdSlots {
 //   * at the fine levels the 7 cells are neighbours and share most of their 64-byte segments: the gathers of rows 1..6 hit
 //     the L1/L2 lines row 0 has just brought in, where the row-major kernel fetched them from the fabric 7 times.
 // The arithmetic of a row is the one of hashgrid_fwd_xcd_kernel (same operations in the same order): bit-identical features.
+// one chunk (4 ppw groups) of one level slot: the work of a (lane quad, chunk)
 template <bool JAC>
-__global__ void __launch_bounds__(HG_THREADS)
-    hashgrid_fwd_stencil_kernel(int64_t n, HgLevels lv, XcdSlots xl, int n_xcd, int ppw, const float *__restrict__ x,
-                                const float *__restrict__ table, float *__restrict__ feat, float *__restrict__ jac) {
-  const int xcd = blockIdx.x % n_xcd;
-  const int64_t chunk = blockIdx.x / n_xcd;
-  const int nl = xl.count[xcd];
-  const int lane = threadIdx.x & 63;
-  const int f = lane & 1, xb = (lane >> 1) & 1, slot = lane >> 2;
-  // ppw groups per wave (the same for every XCD: a chunk is the same 4 ppw groups everywhere), each against the XCD's nl <= 16 / ppw slots
-  const int nls = 16 / ppw, pw = slot / nls, ls = slot - pw * nls;   // a group's level slots on neighbouring quads: its features leave in 8 nls byte runs
-  const int64_t g = (chunk * 4 + (threadIdx.x >> 6)) * ppw + pw;
-  if (!(pw < ppw && ls < nl && g < n)) return;  // whole quads leave together: the quad DPP below stays among live lanes
-  const int level = xl.lvl[xcd][ls], mode = xl.mode[xcd][ls];
-  if (mode != 0 && (int)(chunk % (mode >> 4)) != (mode & 15)) return;
+__device__ __forceinline__ void stencil_chunk(int64_t n, const HgLevels &lv, int level, int f, int xb, int64_t g, const float *__restrict__ x,
+                                              const float *__restrict__ table, float *__restrict__ feat, float *__restrict__ jac) {
   const float scale = lv.scale[level];
   const uint32_t res = lv.res[level], hsize = lv.hsize[level];
   const float *tb = table + (int64_t)lv.offset[level] * 2 + f;
@@ -263,6 +252,34 @@ __global__ void __launch_bounds__(HG_THREADS)
       jx *= scale; jy *= scale; jz *= scale;
       jx += dpp_mov<0x4E>(jx); jy += dpp_mov<0x4E>(jy); jz += dpp_mov<0x4E>(jz);
       if (xb == 0) { jac[3 * o] = jx; jac[3 * o + 1] = jy; jac[3 * o + 2] = jz; }
+    }
+  }
+}
+
+template <bool JAC, bool RESIDENT>
+__global__ void __launch_bounds__(HG_THREADS)
+    hashgrid_fwd_stencil_kernel(int64_t n, HgLevels lv, XcdSlots xl, int n_xcd, int ppw, int64_t chunks, int64_t chunk_stride,
+                                const float *__restrict__ x, const float *__restrict__ table, float *__restrict__ feat, float *__restrict__ jac) {
+  const int xcd = blockIdx.x % n_xcd;
+  const int nl = xl.count[xcd];
+  const int lane = threadIdx.x & 63;
+  const int f = lane & 1, xb = (lane >> 1) & 1, slot = lane >> 2;
+  // ppw groups per wave (the same for every XCD: a chunk is the same 4 ppw groups everywhere), each against the XCD's nl <= 16 / ppw slots
+  const int nls = 16 / ppw, pw = slot / nls, ls = slot - pw * nls;   // a group's level slots on neighbouring quads: its features leave in 8 nls byte runs
+  if (!(pw < ppw && ls < nl)) return;  // whole quads leave together: the quad DPP of stencil_chunk stays among live lanes
+  const int level = xl.lvl[xcd][ls], mode = xl.mode[xcd][ls];
+  if (!RESIDENT) {   // one chunk per workgroup
+    const int64_t chunk = blockIdx.x / n_xcd;
+    const int64_t g = (chunk * 4 + (threadIdx.x >> 6)) * ppw + pw;
+    if (g >= n) return;
+    if (mode != 0 && (int)(chunk % (mode >> 4)) != (mode & 15)) return;
+    stencil_chunk<JAC>(n, lv, level, f, xb, g, x, table, feat, jac);
+  } else {           // a grid of chunk_stride workgroups per XCD that walks the chunks (see launch_fwd_stencil)
+    for (int64_t chunk = blockIdx.x / n_xcd; chunk < chunks; chunk += chunk_stride) {
+      const int64_t g = (chunk * 4 + (threadIdx.x >> 6)) * ppw + pw;
+      if (g >= n) break;
+      if (mode != 0 && (int)(chunk % (mode >> 4)) != (mode & 15)) continue;
+      stencil_chunk<JAC>(n, lv, level, f, xb, g, x, table, feat, jac);
     }
   }
 }
@@ -356,7 +373,17 @@ static void launch_fwd_stencil(int64_t n, const HgLevels &lv, int n_levels, cons
     ppw = 1;
   }
   const int64_t chunks = (n + 4 * ppw - 1) / (4 * ppw);
-  hashgrid_fwd_stencil_kernel<JAC><<<(unsigned)(chunks * n_xcd), HG_THREADS, 0, stream>>>(n, lv, xs, n_xcd, ppw, x, table, feat, jac);
+  // GSDF_HASHGRID_RESIDENT=w: a resident grid of w workgroups per CU (w * 32 per XCD) that walks the chunks, instead of one workgroup per chunk.
+  // The gathers are bound by the L1's miss queue, which two waves per SIMD already keep full; the wave slots and registers a full-occupancy grid
+  // would hold stay free for the kernels of the other stream.
+  static const int resident = [] { const char *e = getenv("GSDF_HASHGRID_RESIDENT"); return e ? atoi(e) : 0; }();
+  int64_t stride = chunks;
+  if (resident > 0 && n_xcd == 8 && chunks > (int64_t)resident * 32) {
+    stride = (int64_t)resident * 32;
+    if (stride % 3 == 0) ++stride;   // slots dealt by chunk % 3: every workgroup sees all three residues in turn
+  }
+  if (stride < chunks) hashgrid_fwd_stencil_kernel<JAC, true><<<(unsigned)(stride * n_xcd), HG_THREADS, 0, stream>>>(n, lv, xs, n_xcd, ppw, chunks, stride, x, table, feat, jac);
+  else hashgrid_fwd_stencil_kernel<JAC, false><<<(unsigned)(chunks * n_xcd), HG_THREADS, 0, stream>>>(n, lv, xs, n_xcd, ppw, chunks, chunks, x, table, feat, jac);
 }
 
 // ---- backward kernels: 4 lanes per (point, level) -------------------------------------------------------
