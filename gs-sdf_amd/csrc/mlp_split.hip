@@ -377,6 +377,7 @@ struct BwdCtx {
   const uint16_t *masks;   // modes DATA / TANGENT: the ReLU masks of the first forward
   const float *in, *acts, *v_out;
   float *v_in;
+  float *g_img;            // two-range backward: v_pre below the upper range's bottom layer, register image [tile][t] (written by the upper, read by the lower pass)
   const uint4 *lds_w;
   uint2 *tb;
   int lane, d_out;
@@ -431,6 +432,28 @@ __device__ __forceinline__ void load_v_out(const BwdCtx &c, int64_t tile, v16f &
   }
 }
 
+// hand-over of the two-range backward: the chain's state (v_pre of the layer below the upper range, ReLU derivative applied) as a register image
+__device__ __forceinline__ void store_g(const BwdCtx &c, int64_t tile, const v16f (&g)[2]) {
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    float4 *dst = reinterpret_cast<float4 *>(c.g_img + img_off(0, c.n_tiles, tile, t, c.lane));
+#pragma unroll
+    for (int q = 0; q < 4; ++q) dst[q * (IMG_Q / 4)] = make_float4(g[t][4 * q], g[t][4 * q + 1], g[t][4 * q + 2], g[t][4 * q + 3]);
+  }
+}
+__device__ __forceinline__ void load_g(const BwdCtx &c, int64_t tile, v16f (&g)[2]) {
+  const int64_t tc = tile < c.n_tiles ? tile : c.n_tiles - 1;   // past the end: any valid tile, the values are never used
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const float4 *src = reinterpret_cast<const float4 *>(c.g_img + img_off(0, c.n_tiles, tc, t, c.lane));
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 v = src[q * (IMG_Q / 4)];
+      g[t][4 * q] = v.x; g[t][4 * q + 1] = v.y; g[t][4 * q + 2] = v.z; g[t][4 * q + 3] = v.w;
+    }
+  }
+}
+
 // terms of the MT tiles of g: packed chain operands gb (lane = point) and, through the LDS block, the dW operands at (lane =
 // output neuron)
 template <int MT, bool TR = true>
@@ -461,10 +484,15 @@ __device__ __forceinline__ void prep_g(const BwdCtx &c, const v16f (&g)[2], Spli
 // the next MFMA on the same accumulator is >= 4 MFMAs away); LDS instructions (8-16 cycles of issue each) and
 // v_accvgpr_read (4-6) do not, and this kernel's vector work is a third LDS / accumulator traffic: the zipped stream ran
 // 1.16 ms against 1.17 ms (4 layers) and 1.96 against 1.64 ms (5 layers + biases, more live registers -> spills).
-template <int NL, bool BIAS, int L, int MODE>
+// Layer ranges (round 5): a launch runs the layers LT .. LB of every tile.  LT = NL - 1, LB = 0 is the whole backward in one launch; the
+// 5-layer instances run as TWO launches (upper range down to LB > 0, which leaves the chain's state in c.g_img; lower range from there),
+// so that a wave holds the weight-gradient tiles of its range only (7 + 11 instead of 17) and nothing spills.
+template <int NL, bool BIAS, int L, int MODE, int LT, int LB>
 __device__ __forceinline__ void bwd_layer(const BwdCtx &c, const SplitLds &sl, BwdAcc<NL> &acc, int64_t tile, int64_t next_tile,
                                           Split8 (&gb)[4], Split8 (&at)[2][2], v16f (&x)[2], unsigned (&hm)[2]) {
   constexpr bool last = L == NL - 1, first = L == 0;
+  constexpr bool bottom = L == LB;            // the range ends here: what follows is the next tile's top layer
+  constexpr bool top_is_out = LT == NL - 1;   // the range starts from v_out (else from the hand-over image)
   constexpr bool DW = MODE != BWD_DATA;       // weight-gradient tiles are accumulated
   constexpr bool MASKS = MODE != BWD_FULL;    // relu'(a_{L-1}) from the saved masks: x is not the activation (or not loaded at all)
   constexpr int MT = last ? 1 : 2;   // 32-row tiles of outputs o
@@ -476,13 +504,19 @@ __device__ __forceinline__ void bwd_layer(const BwdCtx &c, const SplitLds &sl, B
   // (with 5 layers' accumulators the prefetch is issued between the phases instead: 32 fewer live registers in phase 1)
   v16f xn[2], gn[2];
   unsigned hmn[2] = {0u, 0u};
-  constexpr bool early = NL <= 4 || !DW;
-  if (early) {
-    if (first) { if (DW) load_layer_input<NL - 1>(c, next_tile, xn); load_v_out(c, next_tile, gn[0]); }
-    else if (DW) load_layer_input<first ? 0 : L - 1>(c, tile, xn);
-  }
-  if (MASKS) {   // masks of the layer below (slot L-2), or of the next tile's top hidden layer
-    if (first) load_masks<NL - 1>(c, next_tile, hmn);
+  constexpr bool early = NL <= 4 || !DW || LT - LB + 1 < NL;
+  auto prefetch = [&] {
+    if (bottom) {
+      if (DW) load_layer_input<LT>(c, next_tile, xn);
+      if (top_is_out) load_v_out(c, next_tile, gn[0]);
+      else load_g(c, next_tile, gn);
+    } else if (DW) {
+      load_layer_input<first ? 0 : L - 1>(c, tile, xn);
+    }
+  };
+  if (early) prefetch();
+  if (MASKS) {   // masks of the layer below (slot L-2), or of the next tile's top layer
+    if (bottom) load_masks<(LT >= 1 ? LT : 1)>(c, next_tile, hmn);
     else if (L >= 2) load_masks<(L >= 2 ? L - 1 : 1)>(c, tile, hmn);
   }
 
@@ -519,10 +553,7 @@ __device__ __forceinline__ void bwd_layer(const BwdCtx &c, const SplitLds &sl, B
       for (int r = 0; r < 16; ++r) g[t][r] = (MASKS ? ((hm[t] >> r) & 1u) != 0u : x[t][r] > 0.f) ? ng[t][r] : 0.f;
   }
   __builtin_amdgcn_sched_barrier(0);
-  if (!early) {
-    if (first) { load_layer_input<NL - 1>(c, next_tile, xn); load_v_out(c, next_tile, gn[0]); }
-    else load_layer_input<first ? 0 : L - 1>(c, tile, xn);
-  }
+  if (!early) prefetch();
 
   // ---- phase 2
   if (BIAS && DW) {   // ONE shared tile: column L collects the sums of output tile 0 of layer L, column 8 + L those of tile 1
@@ -549,18 +580,26 @@ __device__ __forceinline__ void bwd_layer(const BwdCtx &c, const SplitLds &sl, B
     }
   }
   Split8 gbn[4], atn[2][2];
-  if (!first) {
+  if (!bottom) {
     prep_g<2, DW>(c, g, gbn, atn);
   } else {
-    const int64_t p = tile * 32 + (lane & 31);
-    if (c.v_in != nullptr && p < c.B) {
+    if (first) {
+      const int64_t p = tile * 32 + (lane & 31);
+      if (c.v_in != nullptr && p < c.B) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q)
-        *reinterpret_cast<float4 *>(c.v_in + p * 32 + 8 * q + 4 * (lane >> 5)) = make_float4(ng[0][4 * q], ng[0][4 * q + 1], ng[0][4 * q + 2], ng[0][4 * q + 3]);
+        for (int q = 0; q < 4; ++q)
+          *reinterpret_cast<float4 *>(c.v_in + p * 32 + 8 * q + 4 * (lane >> 5)) = make_float4(ng[0][4 * q], ng[0][4 * q + 1], ng[0][4 * q + 2], ng[0][4 * q + 3]);
+      }
+    } else {
+      store_g(c, tile, g);   // the lower range's launch continues from here
     }
+    if (top_is_out) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) gn[1][r] = 0.f;
-    prep_g<1, DW>(c, gn, gbn, atn);   // the next tile's v_out
+      for (int r = 0; r < 16; ++r) gn[1][r] = 0.f;
+      prep_g<1, DW>(c, gn, gbn, atn);   // the next tile's v_out
+    } else {
+      prep_g<2, DW>(c, gn, gbn, atn);   // the next tile's hand-over state
+    }
   }
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -573,16 +612,16 @@ __device__ __forceinline__ void bwd_layer(const BwdCtx &c, const SplitLds &sl, B
   hm[0] = hmn[0]; hm[1] = hmn[1];
 }
 
-template <int NL, bool BIAS, int L, int MODE>
+template <int NL, bool BIAS, int L, int MODE, int LT, int LB, bool DONE = (L < LB)>
 struct BwdLayers {
   static __device__ __forceinline__ void run(const BwdCtx &c, const SplitLds &sl, BwdAcc<NL> &acc, int64_t tile, int64_t next_tile,
                                              Split8 (&gb)[4], Split8 (&at)[2][2], v16f (&x)[2], unsigned (&hm)[2]) {
-    bwd_layer<NL, BIAS, L, MODE>(c, sl, acc, tile, next_tile, gb, at, x, hm);
-    BwdLayers<NL, BIAS, L - 1, MODE>::run(c, sl, acc, tile, next_tile, gb, at, x, hm);
+    bwd_layer<NL, BIAS, L, MODE, LT, LB>(c, sl, acc, tile, next_tile, gb, at, x, hm);
+    BwdLayers<NL, BIAS, L - 1, MODE, LT, LB>::run(c, sl, acc, tile, next_tile, gb, at, x, hm);
   }
 };
-template <int NL, bool BIAS, int MODE>
-struct BwdLayers<NL, BIAS, -1, MODE> {
+template <int NL, bool BIAS, int L, int MODE, int LT, int LB>
+struct BwdLayers<NL, BIAS, L, MODE, LT, LB, true> {
   static __device__ __forceinline__ void run(const BwdCtx &, const SplitLds &, BwdAcc<NL> &, int64_t, int64_t, Split8 (&)[4], Split8 (&)[2][2], v16f (&)[2],
                                              unsigned (&)[2]) {}
 };
@@ -628,18 +667,21 @@ __global__ void __launch_bounds__(256) mlp_partials_apply_kernel(int n_elem, int
   else if (v_b != nullptr) atomicAdd(v_b + (e - n_w), s);
 }
 
-template <int NL, bool BIAS, bool PART, int MODE = BWD_FULL, int THREADS = SPLIT_BWD_THREADS>
+template <int NL, bool BIAS, bool PART, int MODE = BWD_FULL, int THREADS = SPLIT_BWD_THREADS, int LT = NL - 1, int LB = 0>
 __global__ void __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(THREADS / 256, THREADS / 256)))
     mlp_bwd_split_kernel(int64_t B, MlpDesc d, SplitLds sl, int lds_w4, const float *__restrict__ W, const float *__restrict__ in,
                          const float *__restrict__ acts, const float *__restrict__ v_out, float *__restrict__ v_in,
-                         float *__restrict__ v_W, float *__restrict__ v_b, int64_t part_stride, const float *__restrict__ mask_acts = nullptr) {
+                         float *__restrict__ v_W, float *__restrict__ v_b, int64_t part_stride, const float *__restrict__ mask_acts = nullptr,
+                         float *g_img = nullptr) {
+  static_assert(LT <= NL - 1 && LB >= 0 && LB <= LT && (LT >= 1 || NL == 1), "layer range");
+  static_assert(MODE != BWD_DATA || (LT == NL - 1 && LB == 0), "the data pass has no accumulators to divide");
   extern __shared__ __attribute__((aligned(16))) uint4 smem4[];
   stage_split_bwd(d, sl, W, smem4, MODE != BWD_TANGENT);   // the tangent pass has no use for W_0^T (no v_in)
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   BwdCtx c;
   c.B = B; c.n_tiles = (B + 31) / 32;
-  c.in = in; c.acts = acts; c.v_out = v_out; c.v_in = v_in;
+  c.in = in; c.acts = acts; c.v_out = v_out; c.v_in = v_in; c.g_img = g_img;
   c.masks = MODE != BWD_FULL ? reinterpret_cast<const uint16_t *>(mask_acts + img_off(d.n_layers - 1, c.n_tiles, 0, 0, 0)) : nullptr;
   c.lds_w = smem4;
   // the transposition blocks are an object of their own: the compiler then knows that they never alias the weight image
@@ -662,16 +704,21 @@ __global__ void __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(TH
   v16f g[2], x[2];
   unsigned hm[2] = {0u, 0u};
   Split8 gb[4], at[2][2];
-  if (MODE != BWD_DATA) load_layer_input<NL - 1>(c, tile, x);
-  if (MODE != BWD_FULL) load_masks<NL - 1>(c, tile, hm);
-  load_v_out(c, tile, g[0]);
+  if (MODE != BWD_DATA) load_layer_input<LT>(c, tile, x);
+  if (MODE != BWD_FULL) load_masks<(LT >= 1 ? LT : 1)>(c, tile, hm);
+  if (LT == NL - 1) {
+    load_v_out(c, tile, g[0]);
 #pragma unroll
-  for (int r = 0; r < 16; ++r) { g[1][r] = 0.f; x[1][r] = (NL == 1 || MODE == BWD_DATA) ? 0.f : x[1][r]; if (MODE == BWD_DATA) x[0][r] = 0.f; }
-  prep_g<1, MODE != BWD_DATA>(c, g, gb, at);
+    for (int r = 0; r < 16; ++r) { g[1][r] = 0.f; x[1][r] = (NL == 1 || MODE == BWD_DATA) ? 0.f : x[1][r]; if (MODE == BWD_DATA) x[0][r] = 0.f; }
+    prep_g<1, MODE != BWD_DATA>(c, g, gb, at);
 #pragma unroll
-  for (int s = 2; s < 4; ++s) gb[s] = gb[0];
-  if (MODE != BWD_DATA) { at[1][0] = at[0][0]; at[1][1] = at[0][1]; }
-  for (; tile < c.n_tiles; tile += stride) BwdLayers<NL, BIAS, NL - 1, MODE>::run(c, sl, acc, tile, tile + stride, gb, at, x, hm);
+    for (int s = 2; s < 4; ++s) gb[s] = gb[0];
+    if (MODE != BWD_DATA) { at[1][0] = at[0][0]; at[1][1] = at[0][1]; }
+  } else {   // lower range: the chain's state as the upper range's launch left it
+    load_g(c, tile, g);
+    prep_g<2, true>(c, g, gb, at);
+  }
+  for (; tile < c.n_tiles; tile += stride) BwdLayers<NL, BIAS, LT, MODE, LT, LB>::run(c, sl, acc, tile, tile + stride, gb, at, x, hm);
   if (MODE == BWD_DATA) return;
   // ---- the wave's weight-gradient tiles leave: PART = into its own partial buffer (v_W / v_b point at the buffers' base: [wave][blob]),
   //      else one round of atomics on the gradient
@@ -680,19 +727,24 @@ __global__ void __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(TH
     v_W += mine;
     if (BIAS) v_b += mine;
   }
-  flush_tile<PART>(acc.w0[0], v_W + d.w_off[0], 32, HID, 0, 0, lane);
-  flush_tile<PART>(acc.w0[1], v_W + d.w_off[0], 32, HID, 32, 0, lane);
+  // (only the tiles of the layers LB .. LT: with PART, the two ranges' launches fill disjoint parts of the same per-wave blob)
+  if (LB == 0) {
+    flush_tile<PART>(acc.w0[0], v_W + d.w_off[0], 32, HID, 0, 0, lane);
+    flush_tile<PART>(acc.w0[1], v_W + d.w_off[0], 32, HID, 32, 0, lane);
+  }
 #pragma unroll
-  for (int l = 1; l < NL - 1; ++l)
+  for (int l = (LB > 1 ? LB : 1); l < (LT < NL - 1 ? LT + 1 : NL - 1); ++l)
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt) flush_tile<PART>(acc.wh[l - 1][mt][nt], v_W + d.w_off[l], HID, HID, 32 * mt, 32 * nt, lane);
-  flush_tile<PART>(acc.wl[0], v_W + d.w_off[NL - 1], HID, d.d_out, 0, 0, lane);
-  flush_tile<PART>(acc.wl[1], v_W + d.w_off[NL - 1], HID, d.d_out, 0, 32, lane);
+  if (LT == NL - 1) {
+    flush_tile<PART>(acc.wl[0], v_W + d.w_off[NL - 1], HID, d.d_out, 0, 0, lane);
+    flush_tile<PART>(acc.wl[1], v_W + d.w_off[NL - 1], HID, d.d_out, 0, 32, lane);
+  }
   if (BIAS) {
 #pragma unroll
-    for (int l = 0; l < NL; ++l) {
+    for (int l = LB; l <= LT; ++l) {
       const int O = l == NL - 1 ? d.d_out : HID;
 #pragma unroll
       for (int mt = 0; mt < (l == NL - 1 ? 1 : 2); ++mt) {
@@ -732,14 +784,50 @@ static int blob_floats(const MlpDesc &d, int *n_w) {
   *n_w = d.w_off[nl - 1] + O * HID;
   return *n_w + (d.has_bias ? d.b_off[nl - 1] + O : 0);
 }
+// the hand-over image of the two-range backward: 64 floats per point, rows padded to whole tiles; it sits behind the partial buffers
+static size_t g_img_bytes(int64_t B) { return (size_t)((B + 31) / 32) * 2048 * sizeof(float) + 256; }
+static size_t partials_bytes(int64_t B, int64_t n_elem) {
+  return (size_t)(((int64_t)split_bwd_grid(B) * (SPLIT_BWD_THREADS / 64) + RED_CHUNKS) * n_elem) * sizeof(float) + 256;
+}
 size_t mlp_bwd_split_ws_bytes(int64_t B, const MlpDesc &d) {
   int n_w;
   const int64_t n_elem = blob_floats(d, &n_w);
-  return (size_t)(((int64_t)split_bwd_grid(B) * (SPLIT_BWD_THREADS / 64) + RED_CHUNKS) * n_elem) * sizeof(float) + 256;
+  return partials_bytes(B, n_elem) + (d.n_layers == 5 ? g_img_bytes(B) : 0);
 }
 size_t mlp_bwd_split_ws_bytes_bound(int64_t B, int n_layers) {
   const int64_t n_elem = (int64_t)n_layers * (HID * HID + HID);
-  return (size_t)(((int64_t)split_bwd_grid(B) * (SPLIT_BWD_THREADS / 64) + RED_CHUNKS) * n_elem) * sizeof(float) + 256;
+  return partials_bytes(B, n_elem) + g_img_bytes(B);
+}
+
+// The 5-layer backward as two launches over layer ranges (bwd_layer): layers {4, 3}, then {2, 1, 0}: 7 + 11 accumulator tiles, 428 / 487
+// registers, no scratch (one launch: 17 tiles, 124-229 spilled registers).  Measured at the headline batch (0.44 M base rows): one-pass
+// backward 261 -> 216 us, recomputing pass 365 -> 303 us, step 200 -> 208 it/s.  The 4-layer net (tcnn topology: 13 tiles, 1-25 spilled)
+// stays one launch: split {3, 2} + {1, 0} it compiles without scratch too but its step gets 2 % slower (123 -> 121 it/s: 3 M rows through
+// the 256 B/row hand-over image cost more than the few spills).  GSDF_MLP_BWD_RANGES=0: one launch for every net (A/B).
+template <int NL, bool BIAS, bool PART, int MODE>
+static int launch_bwd_kernels(unsigned grid, size_t lds, float *g_img, int64_t B, const MlpDesc &d, const SplitLds &sl, int lds_w4, const float *W,
+                              const float *in, const float *acts, const float *v_out, float *v_in, float *v_W, float *v_b, int64_t part_stride,
+                              const float *mask_acts, hipStream_t stream) {
+  static const bool ranges = [] { const char *e = getenv("GSDF_MLP_BWD_RANGES"); return !(e && e[0] == '0'); }();
+  if constexpr (NL == 5) {
+    if (ranges && g_img != nullptr) {
+      constexpr int RL = 3;
+      auto upper = mlp_bwd_split_kernel<NL, BIAS, PART, MODE, SPLIT_BWD_THREADS, NL - 1, RL>;
+      auto lower = mlp_bwd_split_kernel<NL, BIAS, PART, MODE, SPLIT_BWD_THREADS, RL - 1, 0>;
+      GSDF_HIP(hipFuncSetAttribute((const void *)upper, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "mlp_bwd_split attr");
+      GSDF_HIP(hipFuncSetAttribute((const void *)lower, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "mlp_bwd_split attr");
+      upper<<<grid, SPLIT_BWD_THREADS, lds, stream>>>(B, d, sl, lds_w4, W, in, acts, v_out, v_in, v_W, v_b, part_stride, mask_acts, g_img);
+      GSDF_CHECK_LAUNCH("mlp_bwd_split_kernel (upper layers)");
+      lower<<<grid, SPLIT_BWD_THREADS, lds, stream>>>(B, d, sl, lds_w4, W, in, acts, v_out, v_in, v_W, v_b, part_stride, mask_acts, g_img);
+      GSDF_CHECK_LAUNCH("mlp_bwd_split_kernel (lower layers)");
+      return 1;
+    }
+  }
+  auto whole = mlp_bwd_split_kernel<NL, BIAS, PART, MODE>;
+  GSDF_HIP(hipFuncSetAttribute((const void *)whole, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "mlp_bwd_split attr");
+  whole<<<grid, SPLIT_BWD_THREADS, lds, stream>>>(B, d, sl, lds_w4, W, in, acts, v_out, v_in, v_W, v_b, part_stride, mask_acts, nullptr);
+  GSDF_CHECK_LAUNCH("mlp_bwd_split_kernel");
+  return 1;
 }
 
 template <int NL, bool BIAS, int MODE = BWD_FULL>
@@ -751,19 +839,15 @@ static int launch_bwd_split(int64_t B, const MlpDesc &d, const SplitLds &sl, int
   // beyond ~48 tiles per wave the waves drift apart and their atomic exits hide behind each other's tiles; the partial buffers then only
   // add their two reduction launches (3.29 M points: 1.95 ms atomic, 2.05 ms partial; 0.49 M: 0.55 / 0.36; 0.1 M: 0.24 / 0.15)
   const bool many_tiles = (B + 31) / 32 > (int64_t)grid * (SPLIT_BWD_THREADS / 64) * 48;
-  if (ws == nullptr || atomic_exit || many_tiles) {
-    GSDF_HIP(hipFuncSetAttribute((const void *)mlp_bwd_split_kernel<NL, BIAS, false, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "mlp_bwd_split attr");
-    mlp_bwd_split_kernel<NL, BIAS, false, MODE><<<grid, SPLIT_BWD_THREADS, lds, stream>>>(B, d, sl, lds_w4, W, in, acts, v_out, v_in, v_W, v_b, 0, mask_acts);
-    GSDF_CHECK_LAUNCH("mlp_bwd_split_kernel");
-    return 1;
-  }
   int n_w;
   const int n_elem = blob_floats(d, &n_w);
   const int n_part = (int)grid * (SPLIT_BWD_THREADS / 64);
-  float *part = (float *)(((uintptr_t)ws + 255) & ~(uintptr_t)255), *chunk = part + (int64_t)n_part * n_elem;
-  GSDF_HIP(hipFuncSetAttribute((const void *)mlp_bwd_split_kernel<NL, BIAS, true, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "mlp_bwd_split attr");
-  mlp_bwd_split_kernel<NL, BIAS, true, MODE><<<grid, SPLIT_BWD_THREADS, lds, stream>>>(B, d, sl, lds_w4, W, in, acts, v_out, v_in, part, part + n_w, n_elem, mask_acts);
-  GSDF_CHECK_LAUNCH("mlp_bwd_split_kernel");
+  float *part = ws != nullptr ? (float *)(((uintptr_t)ws + 255) & ~(uintptr_t)255) : nullptr, *chunk = part + (int64_t)n_part * n_elem;
+  float *g_img = (ws != nullptr && NL == 5) ? (float *)(((uintptr_t)(chunk + (int64_t)RED_CHUNKS * n_elem) + 255) & ~(uintptr_t)255) : nullptr;
+  if (ws == nullptr || atomic_exit || many_tiles)
+    return launch_bwd_kernels<NL, BIAS, false, MODE>(grid, lds, g_img, B, d, sl, lds_w4, W, in, acts, v_out, v_in, v_W, v_b, 0, mask_acts, stream);
+  int rc = launch_bwd_kernels<NL, BIAS, true, MODE>(grid, lds, g_img, B, d, sl, lds_w4, W, in, acts, v_out, v_in, part, part + n_w, n_elem, mask_acts, stream);
+  if (rc < 0) return rc;
   const unsigned eb = (unsigned)((n_elem + 255) / 256);
   mlp_partials_sum_kernel<<<dim3(eb, RED_CHUNKS), 256, 0, stream>>>(n_part, n_elem, part, chunk);
   GSDF_CHECK_LAUNCH("mlp_partials_sum_kernel");

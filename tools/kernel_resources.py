@@ -50,9 +50,9 @@ def main(path):
     with open(path, "w") as f:
         f.write("# hipcc --offload-arch=gfx950 -O3, code-object metadata (tools/kernel_resources.py); vgpr = architectural + accumulation registers per lane;\n"
                 "# waves/SIMD = what the VGPR count allows (<= 8); waves/CU = min of that x 4 SIMDs and the workgroups 160 KB of LDS hold (launch bounds as compiled)\n")
-        f.write(f"{'file':16s} {'kernel':46s} {'vgpr':>5s} {'agpr':>5s} {'sgpr':>5s} {'lds B':>7s} {'scratch B':>9s} {'vgpr spills':>11s} {'wg':>5s} {'waves/SIMD':>10s} {'waves/CU':>8s}\n")
+        f.write(f"{'file':16s} {'kernel':56s} {'vgpr':>5s} {'agpr':>5s} {'sgpr':>5s} {'lds B':>7s} {'scratch B':>9s} {'vgpr spills':>11s} {'wg':>5s} {'waves/SIMD':>10s} {'waves/CU':>8s}\n")
         for r in rows:
-            f.write(f"{r[0]:16s} {r[1][:46]:46s} {r[2]:5d} {r[3]:5d} {r[4]:5d} {r[5]:7d} {r[6]:9d} {r[7]:11d} {r[9]:5d} {r[10]:10d} {r[11]:8d}\n")
+            f.write(f"{r[0]:16s} {r[1][:56]:56s} {r[2]:5d} {r[3]:5d} {r[4]:5d} {r[5]:7d} {r[6]:9d} {r[7]:11d} {r[9]:5d} {r[10]:10d} {r[11]:8d}\n")
     print(path, len(rows), "kernels;", sum(1 for r in rows if r[7]), "with VGPR spills")
 
 
