@@ -174,8 +174,13 @@ struct FwdRowsLds {
   unsigned char list[16][RT];    // per (wave, row): slots of the staged splats that reach the row, in list order
 };
 
+// workgroups per CU the register allocation aims for (26 KB of LDS each: six fit).  Round 5: the kernel happened to compile to 96 or 100
+// registers (5 or 4 waves per SIMD) depending on unrelated edits of the staging code, 0.385 against 0.426 ms at cfg3: the occupancy is now stated
+#ifndef RASTER_FWD_ROWS_WGS
+#define RASTER_FWD_ROWS_WGS 5
+#endif
 template <bool COUNT, bool TRACE>
-__global__ void __launch_bounds__(RT)
+__global__ void __launch_bounds__(RT, RASTER_FWD_ROWS_WGS)
     raster_fwd_rows_kernel(int n_xcd, int64_t total_tiles, int64_t n_tiles, int64_t I, int W, int H, int tw,
                            const float *__restrict__ means2d, const float *__restrict__ ray_transforms,
                            const float *__restrict__ colors, const float *__restrict__ opacities,
