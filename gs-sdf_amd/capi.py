@@ -15,7 +15,7 @@ _lib = None
 
 _i64, _i32, _f32, _u64, _vp, _sz = C.c_int64, C.c_int, C.c_float, C.c_uint64, C.c_void_p, C.c_size_t
 
-ABI_VERSION = 6      # include/gsdf_hip.h: GSDF_ABI_VERSION this binding was written against
+ABI_VERSION = 7      # include/gsdf_hip.h: GSDF_ABI_VERSION this binding was written against
 
 
 class RasterInstr(C.Structure):
@@ -52,6 +52,7 @@ _SIGS = {
     "gsdf_hashgrid_fwd_jac": (C.c_int, [_i64, _i32, _i32, _i32, _i32, _f32] + [_vp] * 5),
     "gsdf_hashgrid_fwd_jac_rows": (C.c_int, [_i64, _i64, _i32, _i32, _i32, _i32, _f32] + [_vp] * 5),
     "gsdf_hashgrid_fwd_stencil": (C.c_int, [_i64, _i64, _i64, _i32, _i32, _i32, _i32, _f32] + [_vp] * 5),
+    "gsdf_hashgrid_fwd_stencil_resident": (C.c_int, [_i32]),
     "gsdf_hashgrid_bwd_jac": (C.c_int, [_i64, _i32, _i32] + [_vp] * 4),
     "gsdf_hashgrid_bwd_jac_scatter": (C.c_int, [_i64, _i32, _i32, _vp, _vp, _f32, _vp, _vp, _vp]),
     "gsdf_hashgrid_bwd": (C.c_int, [_i64, _i32, _i32, _i32, _i32, _f32] + [_vp] * 6),

@@ -257,7 +257,7 @@ __device__ __forceinline__ void stencil_chunk(int64_t n, const HgLevels &lv, int
 }
 
 template <bool JAC, bool RESIDENT>
-__global__ void __launch_bounds__(HG_THREADS)
+__global__ void __launch_bounds__(HG_THREADS, 4)   // <= 128 registers: two resident waves per SIMD leave room for two 128-register waves of another kernel
     hashgrid_fwd_stencil_kernel(int64_t n, HgLevels lv, XcdSlots xl, int n_xcd, int ppw, int64_t chunks, int64_t chunk_stride,
                                 const float *__restrict__ x, const float *__restrict__ table, float *__restrict__ feat, float *__restrict__ jac) {
   const int xcd = blockIdx.x % n_xcd;
@@ -359,6 +359,8 @@ static bool make_stencil_slots(int n_levels, int n_xcd, XcdSlots *xs, int *ppw) 
   return *ppw >= 1;
 }
 
+static thread_local int tl_stencil_resident = -1;   // -1: environment default
+
 template <bool JAC>
 static void launch_fwd_stencil(int64_t n, const HgLevels &lv, int n_levels, const float *x, const float *table, float *feat,
                                float *jac, hipStream_t stream) {
@@ -373,10 +375,12 @@ static void launch_fwd_stencil(int64_t n, const HgLevels &lv, int n_levels, cons
     ppw = 1;
   }
   const int64_t chunks = (n + 4 * ppw - 1) / (4 * ppw);
-  // GSDF_HASHGRID_RESIDENT=w: a resident grid of w workgroups per CU (w * 32 per XCD) that walks the chunks, instead of one workgroup per chunk.
-  // The gathers are bound by the L1's miss queue, which two waves per SIMD already keep full; the wave slots and registers a full-occupancy grid
-  // would hold stay free for the kernels of the other stream.
-  static const int resident = [] { const char *e = getenv("GSDF_HASHGRID_RESIDENT"); return e ? atoi(e) : 0; }();
+  // Resident grid (gsdf_hashgrid_fwd_stencil_resident(w) on this thread, or GSDF_HASHGRID_RESIDENT=w): w workgroups per CU (w * 32 per XCD)
+  // that walk the chunks, instead of one workgroup per chunk.  The gathers are bound by the L1's miss queue, which two waves per SIMD keep
+  // nearly as full as four; the wave slots and registers a full-occupancy grid would hold stay free for the kernels of another stream
+  // (the resident kernel is held to 128 registers so that two of its waves leave room for two 128-register waves per SIMD).
+  static const int resident_env = [] { const char *e = getenv("GSDF_HASHGRID_RESIDENT"); return e ? atoi(e) : 0; }();
+  const int resident = tl_stencil_resident >= 0 ? tl_stencil_resident : resident_env;   // gsdf_hashgrid_fwd_stencil_resident(): the caller's hint
   int64_t stride = chunks;
   if (resident > 0 && n_xcd == 8 && chunks > (int64_t)resident * 32) {
     stride = (int64_t)resident * 32;
@@ -492,6 +496,12 @@ static int check_cfg(int n_levels, int n_feat, int log2_hashmap, int base_res, f
   GSDF_REQUIRE(log2_hashmap >= 3 && log2_hashmap <= 30 && base_res >= 1 && per_level_scale >= 1.0f,
                "%s: bad grid configuration", who);
   return GSDF_OK;
+}
+
+extern "C" int gsdf_hashgrid_fwd_stencil_resident(int wgs_per_cu) {
+  const int before = tl_stencil_resident;
+  tl_stencil_resident = wgs_per_cu < 0 ? -1 : (wgs_per_cu > 8 ? 8 : wgs_per_cu);
+  return before;
 }
 
 extern "C" int64_t gsdf_hashgrid_offsets(int n_levels, int n_feat, int log2_hashmap, int base_res, float per_level_scale,

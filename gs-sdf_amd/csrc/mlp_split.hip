@@ -953,7 +953,8 @@ int mlp_fwd_split_launch(int64_t B, const MlpDesc &d, const float *W, const floa
   const size_t lds = split_fwd_lds(d, &sl);
   if (lds > 160 * 1024) return 0;
   // (measured: 12 and 16 waves per workgroup — 3 / 4 waves per SIMD, a few spilled registers — run 0.72 and 0.90 ms against
-  //  0.70 ms at 8; without the saved activations all three take 0.52 ms: occupancy is not what bounds this kernel)
+  //  0.70 ms at 8; without the saved activations all three take 0.52 ms: occupancy is not what bounds this kernel; round 5: 4 waves per
+  //  workgroup — one per SIMD, so that the compositing backward's waves could share the CU in the two-stream step — 203 against 209 it/s)
   const unsigned grid = split_grid(B, SPLIT_FWD_THREADS / 64);
   if (d.d_in == 32) {
     GSDF_HIP(hipFuncSetAttribute((const void *)mlp_fwd_split_kernel<32, SPLIT_FWD_THREADS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "mlp_fwd_split attr");

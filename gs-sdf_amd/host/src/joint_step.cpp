@@ -25,6 +25,16 @@ using torch::autograd::AutogradContext;
 using torch::autograd::tensor_list;
 
 namespace {
+// the stencil hash-grid forward as a resident grid while the other leg shares the chip (JointConfig::hashgrid_resident; the hint is per host thread)
+struct ResidentGridHint {
+  int before;
+  explicit ResidentGridHint(int wgs_per_cu) : before(gsdf_hashgrid_fwd_stencil_resident(wgs_per_cu)) {}
+  ~ResidentGridHint() { gsdf_hashgrid_fwd_stencil_resident(before); }
+  static int of(const gsdf_extras::JointConfig &cfg) {
+    static const int env = [] { const char *e = getenv("GSDF_JOINT_HASHGRID_RESIDENT"); return e ? atoi(e) : -1; }();   // A/B
+    return cfg.two_streams ? (env >= 0 ? env : cfg.hashgrid_resident) : -1;
+  }
+};
 // the gradient buffers are zeroed by the Adam launch that consumes them (gsdf_adam_step_zero_grad); GSDF_ADAM_FUSED_ZERO=0: separate fills
 bool fused_zero() {
   static const bool on = [] { const char *e = getenv("GSDF_ADAM_FUSED_ZERO"); return !(e && e[0] == '0'); }();
@@ -295,6 +305,7 @@ std::map<std::string, int64_t> JointIteration::step(const Tensor &viewmat, const
   // the SDF work that depends on the render: numerical configuration = the coupling node; analytic (default) configuration = the
   // WHOLE SDF batch of the iteration (per-ray points + splat samples) in one node
   auto sdf_node = [&](const Tensor &smp, StreamGate *gate) -> Tensor {
+    ResidentGridHint hint(ResidentGridHint::of(cfg_));
     if (cfg_.analytic)
       return joint_sdf_loss_analytic(ray_pts, ray_sdf, has ? smp : Tensor(), has ? ids : Tensor(), has ? w_all : Tensor(), *enc_, *dec_, origin_,
                                      map_size_inv_, bce_isigma_, cfg_.sdf_w, cfg_.gs_sdf_w, cfg_.sdf_delta, cfg_.eik_w, cfg_.align_w, tg, dg, bg, gate);
@@ -539,6 +550,7 @@ std::map<std::string, int64_t> JointIteration::step_direct(const Tensor &viewmat
   {
     StreamGuard sg(streams_->side);
     torch::AutoGradMode grad_on(true);
+    ResidentGridHint hint(ResidentGridHint::of(cfg_));
     sdf_loss = joint_sdf_loss_analytic(ray_pts, ray_sdf, has ? samples_cut : Tensor(), has ? ids : Tensor(), has ? w_all : Tensor(), *enc_, *dec_, origin_,
                                        map_size_inv_, bce_isigma_, cfg_.sdf_w, cfg_.gs_sdf_w, cfg_.sdf_delta, cfg_.eik_w, cfg_.align_w, tg, dg, bg,
                                        &streams_->gate, /*unit_upstream=*/true);

@@ -40,7 +40,7 @@ const char *gsdf_last_error(void);
 /* ABI version; bumped on any signature change.  Every binding compares gsdf_abi_version() of the library it loaded with the
  * GSDF_ABI_VERSION of the header it was written against and refuses to run on a mismatch (gs_sdf_amd/capi.py: lib(); the C++
  * operator layer: gsplat_ops.cpp static initialiser): a stale libgsdf_hip.so fails at load, not on the device. */
-#define GSDF_ABI_VERSION 6
+#define GSDF_ABI_VERSION 7
 int gsdf_abi_version(void);
 
 /* Optional per-entry-point device timing (bench.py's roofline leg, for callers in any language): between gsdf_timing_begin and
@@ -251,6 +251,14 @@ int gsdf_hashgrid_fwd_jac_rows(int64_t B, int64_t jac_rows, int n_levels, int n_
 int gsdf_hashgrid_fwd_stencil(int64_t B, int64_t stencil_n, int64_t jac_rows, int n_levels, int n_feat, int log2_hashmap,
                               int base_res, float per_level_scale, const float *x, const float *table, float *feat,
                               float *jac, gsdf_stream_t stream);
+/* Launch hint for gsdf_hashgrid_fwd_stencil on the CALLING THREAD (round 5): wgs_per_cu > 0 launches a RESIDENT grid of that many
+ * 256-thread workgroups per CU which walks the batch, instead of one workgroup per chunk; 0 = the full grid; -1 = back to the default
+ * (environment GSDF_HASHGRID_RESIDENT, else 0).  The gathers are bound by the L1's miss queue, which two waves per SIMD keep nearly as
+ * full as four: a caller that runs OTHER kernels on a second stream at the same time (gsdf_extras::JointIteration's splat leg) asks for 2,
+ * so that half of every SIMD's wave slots and registers stay free for them and the two legs really share the CUs instead of taking turns
+ * (measured at the headline workload: the launch alone 1.67 -> 2.2 ms, the two-stream step 4.91 -> 4.72 ms).  A caller with the chip to
+ * itself leaves the default.  Results are bit-identical either way.  Returns the previous value. */
+int gsdf_hashgrid_fwd_stencil_resident(int wgs_per_cu);
 int gsdf_hashgrid_bwd_jac(int64_t B, int n_levels, int n_feat, const float *jac, const float *v_feat, float *v_x,
                           gsdf_stream_t stream);
 /* out[ids[b]] += scale * (J_b^T v_feat_b)  (ids NULL: row b): the same contraction with the chain-rule scale of the world -> unit-cube map

@@ -6,7 +6,7 @@ import csv, glob, json, os, sys
 
 tag = sys.argv[1]
 root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
-KERNEL = "hashgrid_fwd_stencil_kernel<true>"
+KERNEL = "hashgrid_fwd_stencil_kernel<true, false>"   # <JAC, RESIDENT>: the default launch
 vals = {}
 for f in glob.glob(os.path.join(root, f"{tag}_bench_cfg3_pmc_*.csv")):
     for r in csv.DictReader(open(f)):

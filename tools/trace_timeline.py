@@ -10,7 +10,14 @@ for f in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
     rows += list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 marks = [i for i, r in enumerate(rows) if marker in r["Kernel_Name"]]      # one launch per step
+# the last step that used more than one queue (bench.py ends with a one-stream pass of the same step for the dominant kernel's own
+# rate: that is not the step the headline times); a one-stream trace falls back to the last complete step
 a, b = marks[-3], marks[-2]
+multi = lambda k: len({r.get("Queue_Id") for r in rows[marks[k - 1]:marks[k]]}) > 1   # noqa: E731
+for k in range(len(marks) - 2, 0, -1):
+    if multi(k) and multi(k + 1):     # not the last two-stream step either: its tail is the teardown between the passes
+        a, b = marks[k - 1], marks[k]
+        break
 t0 = int(rows[a]["Start_Timestamp"])
 busy = 0
 with open(out, "w") as fo:
