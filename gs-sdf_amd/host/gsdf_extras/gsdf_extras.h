@@ -148,7 +148,7 @@ struct JointConfig {
   // config/base.yaml -> 0): one stochastic point on every visible splat's disc, weight exp(-|eps|^2 / 2) (neural_gaussian.cpp:259-265)
   bool center_reg = true;
   bool two_streams = false;   // the SDF network's work on a second HIP stream beside the splat leg (bench.py's overlapped schedule)
-  int hashgrid_resident = 2;  // two_streams only: workgroups per CU of the stencil hash-grid forward's RESIDENT grid (gsdf_hashgrid_fwd_stencil_resident):
+  int hashgrid_resident = 2;  // two_streams + analytic only: workgroups per CU of the stencil hash-grid forward's RESIDENT grid (gsdf_hashgrid_fwd_stencil_resident):
                               // its gathers need two waves per SIMD, the rest of every CU stays free for the splat leg's kernels; 0 = the full grid
 };
 
