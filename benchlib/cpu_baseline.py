@@ -212,9 +212,9 @@ def cpu_baseline(sc, views, params, N, W, H, deg, n_sdf_points, dev):
                               "rounding of zero may take the other ReLU branch than the fp64 evaluation: those are the elements above 1e-4"}
     return {"value": 1.0 / dt, "unit": "iters/s", "cores": cores, "kind": "port",
             "sample_short": f"splat half of 1 iteration in full ({t_splat:.1f} s) + SDF half on {n_s} of {n_sdf_points} points scaled ({t_sdf:.1f} s); OpenMP over tiles, "
-                            "projection / sort single-threaded, hash grid + decoder threaded over the points",
+                            "projection threaded over the splats, sort single-threaded, hash grid + decoder threaded over the points",
             "sample": f"splat half of 1 iteration in full (oracle/splat_oracle.c f32 build, OpenMP over tiles on {cores} threads for "
-                      f"compositing, projection / sort single-threaded): {t_splat:.1f} s" +
+                      f"compositing, projection threaded over the splats, sort single-threaded): {t_splat:.1f} s" +
                       (f"; SDF half (oracle/sdf_oracle.c fwd+bwd, OpenMP over the points) on {n_s} of the step's {n_sdf_points} query points, scaled linearly: "
                        f"{t_sdf:.1f} s" if n_sdf_points else ""),
             "parity": par}

@@ -166,44 +166,56 @@ int64_t orc_projection_2dgs_fwd(int64_t N, int64_t C, const REAL *means, const R
                                 int64_t *camera_ids, int64_t *gaussian_ids, int32_t *radii,
                                 REAL *means2d, REAL *depths, REAL *ray_transforms, REAL *normals,
                                 REAL *samples, REAL *samples_weights) {
-  int64_t m = 0;
-  for (int64_t c = 0; c < C; ++c) {
-    for (int64_t n = 0; n < N; ++n) {
-      proj_t p;
-      project_one(means + 3 * n, quats + 4 * n, scales + 3 * n, viewmats + 16 * c, Ks + 9 * c, W, H,
-                  near_p, far_p, radius_clip, &p);
-      if (p.culled) continue;
-      camera_ids[m] = c; gaussian_ids[m] = n; radii[m] = (int32_t)p.radius;
-      means2d[2 * m] = p.mean2d[0]; means2d[2 * m + 1] = p.mean2d[1];
-      depths[m] = p.mc[2];
-      for (int j = 0; j < 3; ++j) {
-        ray_transforms[9 * m + j] = p.Mu[j];
-        ray_transforms[9 * m + 3 + j] = p.Mv[j];
-        ray_transforms[9 * m + 6 + j] = p.Mw[j];
-        normals[3 * m + j] = p.mult * p.Rc[3 * j + 2];
-      }
-      REAL eu, ev;
-      sample_eps(seed, (uint32_t)n, &eu, &ev);
-      for (int j = 0; j < 3; ++j)
-        samples[3 * m + j] = means[3 * n + j] + (scales[3 * n] * eu) * p.Rq[3 * j] +
-                             (scales[3 * n + 1] * ev) * p.Rq[3 * j + 1];
-      samples_weights[m] = (REAL)exp(-0.5 * (double)(eu * eu + ev * ev));
-      ++m;
-    }
+  /* Two passes so that the (camera, gaussian) pairs can be projected on all cores (the cpu_baseline leg times this on the host's cores):
+   * pass 1 marks the survivors, a serial running sum gives every survivor its row (the serial loop's order: camera-major, gaussian
+   * ascending), pass 2 projects the survivors again and writes their rows.  Per pair the arithmetic is the serial loop's. */
+  const int64_t P = C * N;
+  unsigned char *keep = (unsigned char *)malloc((size_t)(P > 0 ? P : 1));
+  int64_t *row = (int64_t *)malloc(sizeof(int64_t) * (size_t)(P + 1));
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < P; ++i) {
+    const int64_t c = i / N, n = i - c * N;
+    proj_t p;
+    project_one(means + 3 * n, quats + 4 * n, scales + 3 * n, viewmats + 16 * c, Ks + 9 * c, W, H, near_p, far_p, radius_clip, &p);
+    keep[i] = p.culled ? 0 : 1;
   }
-  return m;
+  row[0] = 0;
+  for (int64_t i = 0; i < P; ++i) row[i + 1] = row[i] + keep[i];
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < P; ++i) {
+    if (!keep[i]) continue;
+    const int64_t c = i / N, n = i - c * N, m = row[i];
+    proj_t p;
+    project_one(means + 3 * n, quats + 4 * n, scales + 3 * n, viewmats + 16 * c, Ks + 9 * c, W, H, near_p, far_p, radius_clip, &p);
+    camera_ids[m] = c; gaussian_ids[m] = n; radii[m] = (int32_t)p.radius;
+    means2d[2 * m] = p.mean2d[0]; means2d[2 * m + 1] = p.mean2d[1];
+    depths[m] = p.mc[2];
+    for (int j = 0; j < 3; ++j) {
+      ray_transforms[9 * m + j] = p.Mu[j];
+      ray_transforms[9 * m + 3 + j] = p.Mv[j];
+      ray_transforms[9 * m + 6 + j] = p.Mw[j];
+      normals[3 * m + j] = p.mult * p.Rc[3 * j + 2];
+    }
+    REAL eu, ev;
+    sample_eps(seed, (uint32_t)n, &eu, &ev);
+    for (int j = 0; j < 3; ++j)
+      samples[3 * m + j] = means[3 * n + j] + (scales[3 * n] * eu) * p.Rq[3 * j] +
+                           (scales[3 * n + 1] * ev) * p.Rq[3 * j + 1];
+    samples_weights[m] = (REAL)exp(-0.5 * (double)(eu * eu + ev * ev));
+  }
+  const int64_t total = row[P];
+  free(keep); free(row);
+  return total;
 }
 
 /* SPEC A.6: VJP of the projection.  Dense [N,.] outputs (sparse_grad=false,
  * neural_gaussian.cpp:529), accumulated over cameras. Outputs must be zeroed by the caller. */
-void orc_projection_2dgs_bwd(int64_t N, int64_t C, int64_t M, const REAL *means, const REAL *quats,
+static void projection_bwd_row(int64_t m, const REAL *means, const REAL *quats,
                              const REAL *scales, const REAL *viewmats, const REAL *Ks, int W, int H,
                              uint64_t seed, const int64_t *camera_ids, const int64_t *gaussian_ids,
                              const REAL *v_means2d, const REAL *v_depths,
                              const REAL *v_ray_transforms, const REAL *v_normals,
                              const REAL *v_samples, REAL *v_means, REAL *v_quats, REAL *v_scales) {
-  (void)N; (void)C;
-  for (int64_t m = 0; m < M; ++m) {
     int64_t c = camera_ids[m], n = gaussian_ids[m];
     const REAL *vm = viewmats + 16 * c, *K = Ks + 9 * c;
     proj_t p;
@@ -275,6 +287,35 @@ void orc_projection_2dgs_bwd(int64_t N, int64_t C, int64_t M, const REAL *means,
     for (int i = 0; i < 3; ++i) v_means[3 * n + i] += v_mu[i];
     v_scales[3 * n] += v_su;
     v_scales[3 * n + 1] += v_sv;
+}
+
+void orc_projection_2dgs_bwd(int64_t N, int64_t C, int64_t M, const REAL *means, const REAL *quats,
+                             const REAL *scales, const REAL *viewmats, const REAL *Ks, int W, int H,
+                             uint64_t seed, const int64_t *camera_ids, const int64_t *gaussian_ids,
+                             const REAL *v_means2d, const REAL *v_depths,
+                             const REAL *v_ray_transforms, const REAL *v_normals,
+                             const REAL *v_samples, REAL *v_means, REAL *v_quats, REAL *v_scales) {
+  (void)N; (void)C;
+  /* rows of one camera name distinct gaussians (the forward's output order: camera-major, gaussian ascending): they are independent and run on
+   * all cores, camera after camera, so that a gaussian's sum over the cameras is accumulated in the serial loop's order.  Any other row
+   * order takes the serial loop. */
+  int ordered = 1;
+  for (int64_t m = 1; m < M && ordered; ++m)
+    ordered = camera_ids[m] > camera_ids[m - 1] || (camera_ids[m] == camera_ids[m - 1] && gaussian_ids[m] > gaussian_ids[m - 1]);
+  if (!ordered) {
+    for (int64_t m = 0; m < M; ++m)
+      projection_bwd_row(m, means, quats, scales, viewmats, Ks, W, H, seed, camera_ids, gaussian_ids, v_means2d, v_depths, v_ray_transforms,
+                         v_normals, v_samples, v_means, v_quats, v_scales);
+    return;
+  }
+  for (int64_t a = 0; a < M;) {
+    int64_t b = a;
+    while (b < M && camera_ids[b] == camera_ids[a]) ++b;
+#pragma omp parallel for schedule(static)
+    for (int64_t m = a; m < b; ++m)
+      projection_bwd_row(m, means, quats, scales, viewmats, Ks, W, H, seed, camera_ids, gaussian_ids, v_means2d, v_depths, v_ray_transforms,
+                         v_normals, v_samples, v_means, v_quats, v_scales);
+    a = b;
   }
 }
 

@@ -206,3 +206,34 @@ def test_fronto_parallel_splat_is_isotropic(oracle):
     np.testing.assert_allclose(fw["render_alphas"][0, :, :, 0], expect, atol=1e-9)
     np.testing.assert_allclose(fw["render_normals"][0, 32, 32] / max(fw["render_alphas"][0, 32, 32, 0], 1e-9), [0, 0, -1], atol=1e-9)
     np.testing.assert_allclose(fw["render_depths"][0, 32, 32, 0] / fw["render_alphas"][0, 32, 32, 0], z, rtol=1e-6)
+
+
+def test_threaded_projection_equals_the_serial_row_loop(oracle):
+    """The projection runs on all cores (two passes forward; camera blocks backward) for the cpu_baseline leg.  Forward: rows in the serial
+    loop's order (camera-major, gaussian ascending), one thread or many.  Backward: rows handed over in any OTHER order take the serial loop;
+    with two cameras both orders add the same two terms per gaussian, so the sums must agree bit for bit."""
+    sc = synth.make_scene(4000, 160, 96, sh_degree=0, seed=5, sigma_px=(0.7, 5.0))
+    vm = synth.make_views(3, seed=2)[1:3]
+    n = lambda t: t.detach().numpy()
+    means, quats, scales, K = n(sc["means"]), n(sc["quats"]), n(sc["log_scales"].exp()), n(sc["K"]).repeat(2, 0)
+    oracle.set_threads(4)
+    p4 = oracle.projection_2dgs_fwd(means, quats, scales, n(vm), K, 160, 96)
+    oracle.set_threads(1)
+    p1 = oracle.projection_2dgs_fwd(means, quats, scales, n(vm), K, 160, 96)
+    for k in p1:
+        assert np.array_equal(p1[k], p4[k]), k
+    cam, gid = p1["camera_ids"], p1["gaussian_ids"]
+    M = len(gid)
+    assert len(set(cam.tolist())) == 2 and M > 4000
+    order = np.lexsort((gid, cam))
+    assert np.array_equal(order, np.arange(M))                       # camera-major, gaussian ascending
+    g = np.random.default_rng(0)
+    v2d, vd = g.standard_normal((M, 2)).astype(np.float32), g.standard_normal(M).astype(np.float32)
+    vrt, vn = g.standard_normal((M, 3, 3)).astype(np.float32), g.standard_normal((M, 3)).astype(np.float32)
+    oracle.set_threads(4)
+    a = oracle.projection_2dgs_bwd(means, quats, scales, n(vm), K, 160, 96, cam, gid, v2d, vd, vrt, vn)
+    r = np.arange(M)[::-1].copy()                                    # reversed rows: the serial loop
+    b = oracle.projection_2dgs_bwd(means, quats, scales, n(vm), K, 160, 96, cam[r].copy(), gid[r].copy(), v2d[r].copy(), vd[r].copy(),
+                                   vrt[r].copy(), vn[r].copy())
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
