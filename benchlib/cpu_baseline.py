@@ -40,7 +40,7 @@ def cpu_baseline(sc, views, params, N, W, H, deg, n_sdf_points, dev):
     import gs_sdf_amd.synth as synth
     from oracle import oracle as orc
     orc.build()
-    cores = os.cpu_count() or 1
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)   # the cores this process may run on
     orc.set_threads(cores)
     n = lambda t: t.detach().cpu().numpy()
     view = views[0:1].cpu()
