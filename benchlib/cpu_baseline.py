@@ -9,6 +9,24 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _usable_cores():
+    """the cores this process may really use: CPU affinity, capped by the container's CFS quota (cgroup v2 cpu.max / v1 cpu.cfs_quota_us)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, -(-int(q) // int(per))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, -(-q // per)))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def _err_stats(got, ref, clean=None):
     """Scaled error (|got-ref| / max(|ref|, mean|ref|)) per row: rows above 1e-4, worst, relative L2 — over all rows and, when
     `clean` (bool over the leading dims) is given, over those rows too ("masked": the decoder's points away from a ReLU kink)."""
@@ -40,7 +58,7 @@ def cpu_baseline(sc, views, params, N, W, H, deg, n_sdf_points, dev):
     import gs_sdf_amd.synth as synth
     from oracle import oracle as orc
     orc.build()
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)   # the cores this process may run on
+    cores = _usable_cores()
     orc.set_threads(cores)
     n = lambda t: t.detach().cpu().numpy()
     view = views[0:1].cpu()
