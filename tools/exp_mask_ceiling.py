@@ -27,6 +27,7 @@ a=[np.ascontiguousarray(v) for v in (rt[idx].reshape(P,9), m2d[idx], opac[idx], 
 lib.reach_masks4x4(C.c_int64(P),*(v.ctypes.data_as(C.c_void_p) for v in a),masks.ctypes.data_as(C.c_void_p))
 px=np.arange(16)[None,:]+0.5
 tot_set=tot_kept_blocks=tot_keep=0; tot_88=0; tot_22=0
+row_len=np.zeros((T,16),np.int64); row_len_exact=np.zeros((T,16),np.int64); quad_len=np.zeros((T,64),np.int64)
 yy,xx=np.meshgrid(np.arange(16),np.arange(16),indexing='ij')
 bit=4*(2*(yy>>3)+(xx>>3))+2*((yy>>2)&1)+((xx>>2)&1)
 for s0 in range(0,P,20000):
@@ -49,7 +50,19 @@ for s0 in range(0,P,20000):
     tot_set+=setb.sum(); tot_kept_blocks+=kb.sum(); tot_keep+=keep.sum()
     # 2x2 blocks ceiling
     k22=keep.reshape(len(ii),8,2,8,2).any(axis=(2,4)); tot_22+=k22.sum()
+    tl=tile_of[sl]
+    np.add.at(row_len,(tl[:,None].repeat(16,1),np.arange(16)[None].repeat(len(ii),0)),setb.astype(np.int64))
+    np.add.at(row_len_exact,(tl[:,None].repeat(16,1),np.arange(16)[None].repeat(len(ii),0)),kb.astype(np.int64))
+    # quad q of a wave: wave w = 8x8 quadrant (2 (y>>3) + (x>>3)), 16 quads of 2x2 pixels inside it
+    qy,qx=np.meshgrid(np.arange(8),np.arange(8),indexing='ij')
+    qid=(16*(2*(qy>>2)+(qx>>2))+4*(qy&3)+(qx&3)).reshape(-1)
+    np.add.at(quad_len,(tl[:,None].repeat(64,1),qid[None].repeat(len(ii),0)),k22.reshape(len(ii),64).astype(np.int64))
 print('kept pixels',tot_keep)
 print('mask blocks (4x4)',tot_set,'-> useful lanes',tot_keep/(16*tot_set))
 print('exact 4x4 blocks',tot_kept_blocks,'-> useful lanes ceiling',tot_keep/(16*tot_kept_blocks))
 print('exact 2x2 blocks',tot_22,'-> useful lanes ceiling',tot_keep/(4*tot_22))
+
+# wave iterations of the compositing loop (every wave runs max over its lists' lengths; batches of 256 staged splats ignored)
+rows_now=row_len.reshape(T,4,4).max(axis=2).sum(); rows_exact=row_len_exact.reshape(T,4,4).max(axis=2).sum(); quads=quad_len.reshape(T,4,16).max(axis=2).sum()
+print('wave iterations: row lists, current mask',rows_now,'| row lists, exact 4x4 mask',rows_exact,'| quad (2x2) lists, exact mask',quads)
+print('lane-iterations (64 x wave iterations) per kept pixel:',64*rows_now/tot_keep,64*rows_exact/tot_keep,64*quads/tot_keep)
