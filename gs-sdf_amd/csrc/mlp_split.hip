@@ -842,8 +842,12 @@ static int launch_bwd_split(int64_t B, const MlpDesc &d, const SplitLds &sl, int
   int n_w;
   const int n_elem = blob_floats(d, &n_w);
   const int n_part = (int)grid * (SPLIT_BWD_THREADS / 64);
-  float *part = ws != nullptr ? (float *)(((uintptr_t)ws + 255) & ~(uintptr_t)255) : nullptr, *chunk = part + (int64_t)n_part * n_elem;
-  float *g_img = (ws != nullptr && NL == 5) ? (float *)(((uintptr_t)(chunk + (int64_t)RED_CHUNKS * n_elem) + 255) & ~(uintptr_t)255) : nullptr;
+  float *part = nullptr, *chunk = nullptr, *g_img = nullptr;   // the workspace: per-wave partial blobs, their chunk sums, the two ranges' hand-over image
+  if (ws != nullptr) {
+    part = (float *)(((uintptr_t)ws + 255) & ~(uintptr_t)255);
+    chunk = part + (int64_t)n_part * n_elem;
+    if (NL == 5) g_img = (float *)(((uintptr_t)(chunk + (int64_t)RED_CHUNKS * n_elem) + 255) & ~(uintptr_t)255);
+  }
   if (ws == nullptr || atomic_exit || many_tiles)
     return launch_bwd_kernels<NL, BIAS, false, MODE>(grid, lds, g_img, B, d, sl, lds_w4, W, in, acts, v_out, v_in, v_W, v_b, 0, mask_acts, stream);
   int rc = launch_bwd_kernels<NL, BIAS, true, MODE>(grid, lds, g_img, B, d, sl, lds_w4, W, in, acts, v_out, v_in, part, part + n_w, n_elem, mask_acts, stream);
