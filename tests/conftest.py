@@ -9,6 +9,28 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
 
 
+def _usable_cores():
+    """CPU affinity capped by the container's CFS quota (the GPU boxes show 256 logical CPUs behind a 16-CPU quota: 256 OpenMP threads there
+    run the oracle several times SLOWER than 16)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, -(-int(q) // int(per))))
+    except (OSError, ValueError):
+        try:
+            q, per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()), int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, -(-q // per)))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
+os.environ.setdefault("OMP_NUM_THREADS", str(_usable_cores()))      # before any OpenMP runtime (the oracle's, torch's) starts
+os.environ["GSDF_TEST_THREADS"] = os.environ["OMP_NUM_THREADS"]
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run by the driver with -m gpu)")
 
@@ -30,6 +52,7 @@ def _flush_c_stdio():
 def oracle():
     from oracle import oracle as orc
     orc.build()
+    orc.set_threads(int(os.environ.get("OMP_NUM_THREADS", "0")) or _usable_cores())
     return orc
 
 
