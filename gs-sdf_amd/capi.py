@@ -15,7 +15,7 @@ _lib = None
 
 _i64, _i32, _f32, _u64, _vp, _sz = C.c_int64, C.c_int, C.c_float, C.c_uint64, C.c_void_p, C.c_size_t
 
-ABI_VERSION = 7      # include/gsdf_hip.h: GSDF_ABI_VERSION this binding was written against
+ABI_VERSION = 8      # include/gsdf_hip.h: GSDF_ABI_VERSION this binding was written against
 
 
 class RasterInstr(C.Structure):
@@ -40,11 +40,12 @@ _SIGS = {
     "gsdf_tile_count": (C.c_int, [_i64, _i32, _i32, _i32] + [_vp] * 7),
     "gsdf_tile_encode_ws_bytes": (_sz, [_i64, _i64]),
     "gsdf_tile_encode": (C.c_int, [_i64, _i64, _i64, _i32, _i32, _i32] + [_vp] * 10),
-    "gsdf_rasterize_2dgs_fwd": (C.c_int, [_i64, _i64, _i64, _i32, _i32, _i32] + [_vp] * 19),
-    "gsdf_rasterize_2dgs_bwd_ws_bytes": (_sz, [_i64]),
-    "gsdf_rasterize_2dgs_bwd": (C.c_int, [_i64, _i64, _i64, _i32, _i32, _i32] + [_vp] * 27),
-    "gsdf_rasterize_2dgs_fwd_instr": (C.c_int, [_i64, _i64, _i64, _i32, _i32, _i32] + [_vp] * 20),
-    "gsdf_rasterize_2dgs_bwd_instr": (C.c_int, [_i64, _i64, _i64, _i32, _i32, _i32] + [_vp] * 28),
+    "gsdf_rasterize_2dgs_fwd_ws_bytes": (_sz, [_i64, _i64]),
+    "gsdf_rasterize_2dgs_fwd": (C.c_int, [_i64, _i64, _i64, _i32, _i32, _i32] + [_vp] * 20),
+    "gsdf_rasterize_2dgs_bwd_ws_bytes": (_sz, [_i64, _i64]),
+    "gsdf_rasterize_2dgs_bwd": (C.c_int, [_i64, _i64, _i64, _i32, _i32, _i32] + [_vp] * 28),
+    "gsdf_rasterize_2dgs_fwd_instr": (C.c_int, [_i64, _i64, _i64, _i32, _i32, _i32] + [_vp] * 21),
+    "gsdf_rasterize_2dgs_bwd_instr": (C.c_int, [_i64, _i64, _i64, _i32, _i32, _i32] + [_vp] * 29),
     "gsdf_render_post_fwd": (C.c_int, [_i64, _i32] + [_vp] * 10),
     "gsdf_render_post_bwd": (C.c_int, [_i64, _i32] + [_vp] * 12),
     "gsdf_hashgrid_offsets": (_i64, [_i32, _i32, _i32, _i32, _f32, _vp]),

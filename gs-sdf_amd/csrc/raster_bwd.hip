@@ -16,7 +16,7 @@
 // single 80-byte RECORD ([M][20] floats), three records are flushed per wave instruction with the
 // 20 fields in consecutive lanes (<= 2 lines per splat), and a streaming epilogue unpacks the
 // records into the operator's six gradient tensors (+ the densification signal).
-#include "raster_common.h"
+#include "raster_quad.h"
 
 namespace gsdf {
 
@@ -474,6 +474,300 @@ __global__ void __launch_bounds__(RT, ABSGRAD ? 3 : 4)
   if (COUNT && lane == 0) { atomicAdd(counters + 4, c_visit); atomicAdd(counters + 5, c_live); atomicAdd(counters + 6, c_valid); }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------------
+// Round 6: QUAD LISTS (raster_quad.h).  Every lane quad (2x2 pixels) replays its own list of the staged splats (those whose 64-bit reach mask
+// has the quad's bit and that lie at or before the quad's last contributor), back to front.  The per-pixel gradient terms are reduced over the
+// FOUR lanes of the quad with a transposing butterfly (16 values -> 4 per lane: 36 VALU) and added to the splat's record in LDS.
+// The record is accumulated in DOUBLE: ds_add_f32 retires 0.33 lanes per clock per CU on gfx950 whatever the address pattern
+// (tools/ubench/lds_fadd_patterns.hip: linear, the row kernel's 4 records x 16 fields, 16 records x 4 fields, random — all 0.20 T lane-ops/s
+// chip-wide), ds_add_f64 7.7 (4.7 T/s): the row kernel's 20 float adds per (row, splat) were ~0.4 ms of LDS-atomic time per launch, the quad
+// kernel's 20 per (quad, splat) would be ~1.2 ms; as double adds they are ~0.05 ms, and the tile-level sum is exact to fp32.
+// ---------------------------------------------------------------------------------------------------------------------------------------
+#ifndef RASTER_BWD_QUADS_BATCH
+#define RASTER_BWD_QUADS_BATCH 116
+#endif
+#ifndef RASTER_BWD_QUADS_WGS
+#define RASTER_BWD_QUADS_WGS 4
+#endif
+static constexpr int BQB = RASTER_BWD_QUADS_BATCH;
+static constexpr int BQ_CHUNKS = (BQB + 63) / 64;
+static constexpr int NACC_D = 20;   // double fields of a record: 0-18 as NACC's 0-18, 19 padding (the 4-value butterfly's fourth output)
+template <bool ABSGRAD>
+struct BwdQuadsLds {
+  float4 q0[BQB], q1[BQB], q2[BQB], q3[BQB], q4[BQB];   // q3.x = M_w.x (the forward's record has D there)
+  float mwy[BQB];
+  unsigned long long m64[BQB];
+  double acc[BQB][NACC_D];
+  float acc2[BQB][2];                       // v_means2d of the low-pass branch (rare): float adds
+  float acc_abs[ABSGRAD ? BQB : 1][2];
+  unsigned char list[64][BQB];
+  unsigned short cmask[4][BQB];    // per wave: quad bits of the staged splats that reach the wave's quadrant (compacted, list order)
+  unsigned char cslot[4][BQB];     //           and their slots
+  int bin_final_max;
+};
+static_assert(BQB % 4 == 0 && BQB <= 256, "raster_bwd_quads: list words, byte slots");
+static_assert(sizeof(BwdQuadsLds<false>) * RASTER_BWD_QUADS_WGS <= 160 * 1024, "raster_bwd_quads: LDS per workgroup against the stated workgroups per CU");
+static_assert(sizeof(BwdQuadsLds<true>) * RASTER_BWD_QUADS_WGS <= 160 * 1024, "raster_bwd_quads (absgrad): LDS per workgroup against the stated workgroups per CU");
+
+// Adds the LDS records of this wave's slots (slot = 4 lane + wave, thread_slot) to the global record array and clears them.
+// Three splats per instruction: lane = 21 j + k -> field k of the wave's j-th slot of this round.
+template <bool ABSGRAD>
+__device__ __forceinline__ void flush_records_quads(BwdQuadsLds<ABSGRAD> &lds, int wave, int lane, int g_mine, float *__restrict__ grec,
+                                                    float *__restrict__ grec_abs) {
+  if (ABSGRAD) {
+    const int slot = 4 * lane + wave;
+    if (g_mine >= 0 && slot < BQB) {
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const float v = lds.acc_abs[slot][k];
+        if (v != 0.f) { lds.acc_abs[slot][k] = 0.f; atomicAdd(grec_abs + 2 * (int64_t)g_mine + k, v); }
+      }
+    }
+  }
+  const int j = lane / NACC, k = lane - j * NACC;
+  constexpr int PER_WAVE = (BQB + 3) / 4;          // staging lanes per wave
+#pragma unroll 2
+  for (int it = 0; it < (PER_WAVE + 2) / 3; ++it) {
+    const int sl = 3 * it + j;                     // staging lane of this wave
+    const int g = __shfl(g_mine, sl & 63, 64);
+    const int slot = 4 * sl + wave;
+    if (j < 3 && sl < PER_WAVE && slot < BQB && g >= 0) {
+      float v;
+      if (k < 19) {
+        double *a = &lds.acc[slot][k];
+        const double d = *a;
+        v = (float)d;
+        if (d != 0.0) *a = 0.0;
+      } else {
+        float *a = &lds.acc2[slot][k - 19];
+        v = *a;
+        if (v != 0.f) *a = 0.f;
+      }
+      if (v != 0.f) atomicAdd(grec + (int64_t)g * NACC + k, v);
+    }
+  }
+}
+
+template <bool ABSGRAD, bool COUNT = false>
+__global__ void __launch_bounds__(RT, RASTER_BWD_QUADS_WGS)
+    raster_bwd_quads_kernel(int n_xcd, int64_t total_tiles, int64_t n_tiles, int64_t I, int W, int H, int tw,
+                            const float4 *__restrict__ rec, const unsigned long long *__restrict__ pair_masks,
+                            const float *__restrict__ backgrounds, const uint8_t *__restrict__ masks,
+                            const int32_t *__restrict__ isect_offsets, const int32_t *__restrict__ flatten_ids,
+                            const float *__restrict__ render_alphas, const int32_t *__restrict__ last_ids,
+                            const int32_t *__restrict__ median_ids, const float *__restrict__ v_render_colors,
+                            const float *__restrict__ v_render_depths, const float *__restrict__ v_render_alphas,
+                            const float *__restrict__ v_render_normals, const float *__restrict__ v_render_median,
+                            float *__restrict__ grec, float *__restrict__ grec_abs, const float *__restrict__ final_T,
+                            unsigned long long *__restrict__ counters = nullptr) {
+  __shared__ BwdQuadsLds<ABSGRAD> lds;
+  unsigned long long c_visit = 0, c_live = 0, c_valid = 0;
+  const int64_t tile = xcd_tile_index(total_tiles, n_xcd);
+  if (tile >= total_tiles) return;
+  if (masks != nullptr && !masks[tile]) return;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int64_t cam = tile / n_tiles;
+  const int tl = (int)(tile - cam * n_tiles);
+  const int ty = tl / tw, tx = tl - ty * tw;
+  int plx, ply;
+  quad_pixel(wave, lane, plx, ply);
+  const int x = tx * TILE + plx, y = ty * TILE + ply;
+  const bool inside = x < W && y < H;
+  const int64_t pid = (cam * H + y) * (int64_t)W + x;
+  const float px = (float)x + 0.5f, py = (float)y + 0.5f;
+
+  const int32_t start = isect_offsets[tile];
+  const int32_t end = (tile == total_tiles - 1) ? (int32_t)I : isect_offsets[tile + 1];
+  if (end <= start) return;
+
+  float T_final = 1.0f, vCr = 0.f, vCg = 0.f, vCb = 0.f, vNx = 0.f, vNy = 0.f, vNz = 0.f, vD = 0.f, vA = 0.f, vMed = 0.f;
+  int32_t bin_final = -1, med_idx = -1;
+  if (inside) {
+    T_final = final_T != nullptr ? final_T[pid] : 1.0f - render_alphas[pid];
+    bin_final = last_ids[pid];
+    med_idx = median_ids[pid];
+    vCr = v_render_colors[3 * pid]; vCg = v_render_colors[3 * pid + 1]; vCb = v_render_colors[3 * pid + 2];
+    vNx = v_render_normals[3 * pid]; vNy = v_render_normals[3 * pid + 1]; vNz = v_render_normals[3 * pid + 2];
+    vD = v_render_depths[pid]; vA = v_render_alphas[pid]; vMed = v_render_median[pid];
+  }
+  float bgdot = 0.f;
+  if (backgrounds != nullptr)
+    bgdot = backgrounds[3 * cam] * vCr + backgrounds[3 * cam + 1] * vCg + backgrounds[3 * cam + 2] * vCb;
+  float T = T_final;
+  float bCr = 0.f, bCg = 0.f, bCb = 0.f, bNx = 0.f, bNy = 0.f, bNz = 0.f, bD = 0.f;
+
+  if (tid == 0) lds.bin_final_max = -1;
+  for (int i = tid; i < BQB * NACC_D; i += RT) (&lds.acc[0][0])[i] = 0.0;
+  for (int i = tid; i < BQB * 2; i += RT) { (&lds.acc2[0][0])[i] = 0.f; if (ABSGRAD) (&lds.acc_abs[0][0])[i] = 0.f; }
+  __syncthreads();
+  // last contributor of the quad (4 lanes), of the wave, of the tile
+  const int quad_bin_final = quad_imax(bin_final);
+  int wave_bin_final = quad_bin_final;
+#pragma unroll
+  for (int d = 4; d <= 32; d <<= 1) wave_bin_final = max(wave_bin_final, __shfl_xor(wave_bin_final, d, 64));
+  wave_bin_final = __builtin_amdgcn_readfirstlane(wave_bin_final);   // uniform: say so (scalar list counters below)
+  if (lane == 0) atomicMax(&lds.bin_final_max, wave_bin_final);
+  __syncthreads();
+  const int tile_bin_final = __builtin_amdgcn_readfirstlane(lds.bin_final_max);
+  if (tile_bin_final < start) return;
+  const unsigned char *my_list = lds.list[wave * 16 + (lane >> 2)];
+  const int slot = thread_slot(tid);
+  const int mbase = wave_mask_base(wave);
+  const int f0 = quad_reduce16_first(lane), f4 = 16 + quad_reduce4_index(lane);
+
+  int g_mine = -1;
+  const int last = min(end, tile_bin_final + 1);
+  const int nb = (last - start + BQB - 1) / BQB;
+  for (int b = nb - 1; b >= 0; --b) {
+    __syncthreads();  // barrier A: previous batch fully consumed, its accumulators complete
+    flush_records_quads<ABSGRAD>(lds, wave, lane, g_mine, grec, grec_abs);
+    g_mine = -1;
+    const int32_t bstart = start + b * BQB;
+    const int32_t idx = bstart + slot;
+    if (slot < BQB && idx < last) {
+      g_mine = flatten_ids[idx];
+      const float4 *r = rec + 8 * (int64_t)g_mine;
+      const float4 r3 = r[3], r5 = r[5];
+      lds.q0[slot] = r[0]; lds.q1[slot] = r[1]; lds.q2[slot] = r[2];
+      lds.q3[slot] = make_float4(r5.x, r3.y, r3.z, r3.w);
+      lds.q4[slot] = r[4];
+      lds.mwy[slot] = r5.y;
+      lds.m64[slot] = pair_masks[idx];
+    }
+    __syncthreads();  // barrier B
+    const int count = min(BQB, last - bstart);
+    const int wcount = min(count, wave_bin_final - bstart + 1);
+    if (wcount <= 0) continue;
+    // ---- step 1: the staged splats that reach a quad of this wave which still replays at this depth, compacted in list order
+    const unsigned long long replays = __ballot(quad_bin_final >= bstart);
+    const unsigned live_q = quads_any(replays);
+    int ncomp = 0;
+#pragma unroll
+    for (int c = 0; c < BQ_CHUNKS; ++c) {
+      if (64 * c < wcount) {
+        const int ti = 64 * c + lane;
+        const unsigned qb = ti < wcount ? (wave_quad_bits(lds.m64[ti], mbase) & live_q) : 0u;
+        const bool any = qb != 0u;
+        const unsigned long long mk = __ballot(any);
+        if (any) {
+          const int pos = ncomp + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk, 0u));
+          lds.cslot[wave][pos] = (unsigned char)ti;
+          lds.cmask[wave][pos] = (unsigned short)qb;
+        }
+        ncomp += (int)__popcll(mk);
+      }
+    }
+    if (ncomp == 0) continue;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    // ---- step 2: one ballot per quad and compacted chunk; a quad drops what lies behind its last contributor
+    unsigned cm[BQ_CHUNKS];
+    int cti[BQ_CHUNKS];
+#pragma unroll
+    for (int c = 0; c < BQ_CHUNKS; ++c) {
+      const int i = 64 * c + lane;
+      const bool in = 64 * c < ncomp && i < ncomp;
+      cm[c] = in ? (unsigned)lds.cmask[wave][i] : 0u;
+      cti[c] = in ? (int)lds.cslot[wave][i] : 0;
+    }
+    int nvec = 0, kmax = 0;
+    for_quads([&](auto qc) {
+      constexpr int Q = decltype(qc)::value;
+      int n = 0;
+      const int qbf = __builtin_amdgcn_readlane(quad_bin_final, 4 * Q) - bstart;   // last batch slot the quad replays
+#pragma unroll
+      for (int c = 0; c < BQ_CHUNKS; ++c) {
+        if (64 * c < ncomp) {
+          const bool bit = ((cm[c] >> Q) & 1u) && (cti[c] <= qbf);
+          const unsigned long long mk = __ballot(bit);
+          if (bit) lds.list[wave * 16 + Q][n + __builtin_amdgcn_mbcnt_hi((unsigned)(mk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk, 0u))] = (unsigned char)cti[c];
+          n += (int)__popcll(mk);
+        }
+      }
+      writelane<4 * Q>(nvec, n);
+      kmax = max(kmax, n);
+    });
+    const int n_mine = dpp_quad_i<0x00>(nvec);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    for (int k = 0; k < kmax; ++k) {      // every quad walks its own list from the back
+      const bool active = k < n_mine;
+      const int t = active ? (int)my_list[n_mine - 1 - k] : 0;
+      const float4 a0 = lds.q0[t], a1 = lds.q1[t], a2 = lds.q2[t], a3 = lds.q3[t];
+      PairEval e;
+      const float mwx = a3.x, mwy = lds.mwy[t];
+      eval_pair<true>(0.f, 0.f, px, py, a0, a1, a2, mwx, a3.y, e, mwy);
+      const bool valid = active && inside && (bstart + t <= bin_final) && e.ok;
+      if (COUNT) { c_visit += 1; c_live += __popcll(__ballot(active && inside && (bstart + t <= bin_final))); c_valid += __popcll(__ballot(valid)); }
+      const float4 a4 = lds.q4[t];
+      const float cR = a3.z, cG = a3.w, cB = a4.x, nX = a4.y, nY = a4.z, nZ = a4.w;
+      float g_rgb0 = 0.f, g_rgb1 = 0.f, g_rgb2 = 0.f, g_n0 = 0.f, g_n1 = 0.f, g_n2 = 0.f, g_op = 0.f;
+      float vzx = 0.f, vzy = 0.f, vzz = 0.f, g_dx = 0.f, g_dy = 0.f, g_mwz = 0.f, g_x = 0.f, g_y = 0.f;
+      bool v2 = false;
+      if (valid) {
+        const float ra = 1.0f / (1.0f - e.alpha);
+        T *= ra;
+        const float fac = e.alpha * T;
+        g_rgb0 = fac * vCr; g_rgb1 = fac * vCg; g_rgb2 = fac * vCb;
+        g_n0 = fac * vNx; g_n1 = fac * vNy; g_n2 = fac * vNz;
+        float v_alpha = (cR * T - bCr * ra) * vCr + (cG * T - bCg * ra) * vCg + (cB * T - bCb * ra) * vCb;
+        v_alpha += (nX * T - bNx * ra) * vNx + (nY * T - bNy * ra) * vNy + (nZ * T - bNz * ra) * vNz;
+        v_alpha += (e.dep * T - bD * ra) * vD;
+        v_alpha += T_final * ra * (vA - bgdot);
+        const float v_dep = fac * vD + ((bstart + t) == med_idx ? vMed : 0.f);
+        bCr += cR * fac; bCg += cG * fac; bCb += cB * fac;
+        bNx += nX * fac; bNy += nY * fac; bNz += nZ * fac;
+        bD += e.dep * fac;
+        float v_sigma = 0.f;
+        if (!e.clamped) {
+          g_op = e.vis * v_alpha;
+          v_sigma = -a2.w * e.vis * v_alpha;
+        }
+        g_mwz = v_dep;
+        if (e.b3) {
+          vzx = fmaf(v_sigma, e.sx, v_dep * mwx) * e.inv;
+          vzy = fmaf(v_sigma, e.sy, v_dep * mwy) * e.inv;
+          vzz = -(vzx * e.sx + vzy * e.sy);
+          g_dx = v_dep * e.sx; g_dy = v_dep * e.sy;
+        } else {
+          v2 = true;
+          g_x = v_sigma * FILTER_INV_SQUARE * e.dx;
+          g_y = v_sigma * FILTER_INV_SQUARE * e.dy;
+        }
+      }
+      const bool any2 = __ballot(v2) != 0ull;
+      int qv = (int)valid;
+      qv |= dpp_quad_i<0xB1>(qv);
+      qv |= dpp_quad_i<0x4E>(qv);
+      const bool quad_valid = qv != 0;
+      {  // slots 0..15: one transposing butterfly over the quad, four double adds per lane into the quad's own splat record
+        const float mxp = -e.dx, myp = -e.dy;
+        const float v16[16] = {g_rgb0, g_rgb1, g_rgb2, g_n0, g_n1, g_n2, g_op, vzx, vzy, vzz,
+                               mxp * vzx, mxp * vzy, mxp * vzz, myp * vzx, myp * vzy, myp * vzz};
+        float r4[4];
+        quad_transpose_reduce16(v16, lane, r4);
+        const float v4[4] = {g_dx, g_dy, g_mwz, 0.f};   // slots 16..18 (+ padding)
+        const float r1 = quad_transpose_reduce4(v4, lane);
+        if (quad_valid) {
+          double *a = &lds.acc[t][0];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) atomicAdd(a + f0 + i, (double)r4[i]);
+          atomicAdd(a + f4, (double)r1);
+        }
+      }
+      if (any2) {  // screen-space low-pass branch (rare)
+        float r = quad_sum(g_x); if ((lane & 3) == 0 && r != 0.f) lds_add(&lds.acc2[t][0], r);
+        r = quad_sum(g_y); if ((lane & 3) == 0 && r != 0.f) lds_add(&lds.acc2[t][1], r);
+        if (ABSGRAD) {
+          r = quad_sum(fabsf(g_x)); if ((lane & 3) == 0 && r != 0.f) lds_add(&lds.acc_abs[t][0], r);
+          r = quad_sum(fabsf(g_y)); if ((lane & 3) == 0 && r != 0.f) lds_add(&lds.acc_abs[t][1], r);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  flush_records_quads<ABSGRAD>(lds, wave, lane, g_mine, grec, grec_abs);
+  if (COUNT && lane == 0) { atomicAdd(counters + 4, c_visit); atomicAdd(counters + 5, c_live); atomicAdd(counters + 6, c_valid); }
+}
+
 // Streaming epilogue: unpack the 80-byte records into the operator's gradient tensors and derive the
 // densification signal (SPEC S-4, 2DGS convention consumed at neural_gaussian.cpp:660-665):
 // v_densify = (dL/dM_u.z, dL/dM_v.z) * M_w.z.
@@ -530,9 +824,11 @@ __global__ void __launch_bounds__(256)
 
 using namespace gsdf;
 
-extern "C" size_t gsdf_rasterize_2dgs_bwd_ws_bytes(int64_t M) {
+static size_t bwd_records_bytes(int64_t M) {
   return align_up((size_t)(M > 0 ? M : 1) * NACC * sizeof(float), 256) + align_up((size_t)(M > 0 ? M : 1) * 2 * sizeof(float), 256) + 256;
 }
+// gradient records + room for the pack / mask passes (used when the caller does not hand over the forward's workspace)
+extern "C" size_t gsdf_rasterize_2dgs_bwd_ws_bytes(int64_t M, int64_t I) { return bwd_records_bytes(M) + raster_pack_bytes(M, I); }
 
 static int rasterize_bwd_launch(int64_t C, int64_t M, int64_t I, int width, int height, int tile_size,
                                        const float *means2d, const float *ray_transforms, const float *colors,
@@ -544,7 +840,8 @@ static int rasterize_bwd_launch(int64_t C, int64_t M, int64_t I, int width, int 
                                        const float *v_render_alphas, const float *v_render_normals,
                                        const float *v_render_median, float *v_means2d, float *v_ray_transforms,
                                        float *v_colors, float *v_opacities, float *v_normals, float *v_densify,
-                                       float *v_means2d_abs, void *ws, const float *final_T, unsigned long long *counters, hipStream_t stream) {
+                                       float *v_means2d_abs, void *ws, const float *final_T, const void *fwd_ws, unsigned long long *counters,
+                                       hipStream_t stream) {
   GSDF_REQUIRE(tile_size == TILE, "rasterize_bwd: tile_size %d unsupported (16 only)", tile_size);
   GSDF_REQUIRE(width > 0 && height > 0 && C >= 1, "rasterize_bwd: bad geometry");
   if (M == 0) return GSDF_OK;
@@ -564,8 +861,27 @@ static int rasterize_bwd_launch(int64_t C, int64_t M, int64_t I, int width, int 
 #define ARGS n_xcd, total, n_tiles, I, width, height, tw, means2d, ray_transforms, colors, opacities, normals, backgrounds, \
              masks, isect_offsets, flatten_ids, render_alphas, last_ids, median_ids, v_render_colors,               \
              v_render_depths, v_render_alphas, v_render_normals, v_render_median, grec, grec_abs, final_T
-    static const bool quadrant_lists = [] { const char *e = getenv("GSDF_RASTER_ROW_LISTS"); return e != nullptr && e[0] == '0'; }();   // A/B switch (raster_fwd.hip)
-    if (quadrant_lists) {
+    static const int lists_mode = raster_lists_mode();
+    if (lists_mode == 0) {   // quad lists (round 6)
+      if (fwd_ws == nullptr) {   // no forward workspace handed over: run the pack + mask passes into this call's own
+        void *own = (char *)ws + bwd_records_bytes(M);
+        const int rc = raster_pack_launch(M, I, total, n_tiles, tw, means2d, ray_transforms, colors, opacities, normals, isect_offsets, flatten_ids, own, stream);
+        if (rc != GSDF_OK) return rc;
+        fwd_ws = own;
+      }
+#define QARGS n_xcd, total, n_tiles, I, width, height, tw, (const float4 *)ws_records(fwd_ws), ws_masks(fwd_ws, M), backgrounds, masks, isect_offsets, \
+              flatten_ids, render_alphas, last_ids, median_ids, v_render_colors, v_render_depths, v_render_alphas, v_render_normals,               \
+              v_render_median, grec, grec_abs, final_T
+      if (counters != nullptr && v_means2d_abs)
+        raster_bwd_quads_kernel<true, true><<<xcd_grid(total, n_xcd), RT, 0, stream>>>(QARGS, counters);
+      else if (counters != nullptr)
+        raster_bwd_quads_kernel<false, true><<<xcd_grid(total, n_xcd), RT, 0, stream>>>(QARGS, counters);
+      else if (v_means2d_abs)
+        raster_bwd_quads_kernel<true><<<xcd_grid(total, n_xcd), RT, 0, stream>>>(QARGS);
+      else
+        raster_bwd_quads_kernel<false><<<xcd_grid(total, n_xcd), RT, 0, stream>>>(QARGS);
+#undef QARGS
+    } else if (lists_mode == 2) {
       if (counters != nullptr && v_means2d_abs)
         raster_bwd_kernel<true, true><<<xcd_grid(total, n_xcd), RT, 0, stream>>>(ARGS, counters);
       else if (counters != nullptr)
@@ -604,13 +920,13 @@ extern "C" int gsdf_rasterize_2dgs_bwd(int64_t C, int64_t M, int64_t I, int widt
                                        const float *v_render_alphas, const float *v_render_normals,
                                        const float *v_render_median, float *v_means2d, float *v_ray_transforms,
                                        float *v_colors, float *v_opacities, float *v_normals, float *v_densify,
-                                       float *v_means2d_abs, void *ws, const float *final_T, gsdf_stream_t stream_) {
+                                       float *v_means2d_abs, void *ws, const float *final_T, const void *fwd_ws, gsdf_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   GSDF_TIMED("gsdf_rasterize_2dgs_bwd");
   return rasterize_bwd_launch(C, M, I, width, height, tile_size, means2d, ray_transforms, colors, opacities, normals, backgrounds, masks,
                               isect_offsets, flatten_ids, render_alphas, last_ids, median_ids, v_render_colors, v_render_depths,
                               v_render_alphas, v_render_normals, v_render_median, v_means2d, v_ray_transforms, v_colors, v_opacities,
-                              v_normals, v_densify, v_means2d_abs, ws, final_T, nullptr, (hipStream_t)stream_);
+                              v_normals, v_densify, v_means2d_abs, ws, final_T, fwd_ws, nullptr, (hipStream_t)stream_);
 }
 
 extern "C" int gsdf_rasterize_2dgs_bwd_instr(int64_t C, int64_t M, int64_t I, int width, int height, int tile_size,
@@ -623,9 +939,10 @@ extern "C" int gsdf_rasterize_2dgs_bwd_instr(int64_t C, int64_t M, int64_t I, in
                                        const float *v_render_alphas, const float *v_render_normals,
                                        const float *v_render_median, float *v_means2d, float *v_ray_transforms,
                                        float *v_colors, float *v_opacities, float *v_normals, float *v_densify,
-                                       float *v_means2d_abs, void *ws, const float *final_T, const gsdf_raster_instr *instr, gsdf_stream_t stream_) {
+                                       float *v_means2d_abs, void *ws, const float *final_T, const void *fwd_ws, const gsdf_raster_instr *instr,
+                                       gsdf_stream_t stream_) {
   return rasterize_bwd_launch(C, M, I, width, height, tile_size, means2d, ray_transforms, colors, opacities, normals, backgrounds, masks,
                               isect_offsets, flatten_ids, render_alphas, last_ids, median_ids, v_render_colors, v_render_depths,
                               v_render_alphas, v_render_normals, v_render_median, v_means2d, v_ray_transforms, v_colors, v_opacities,
-                              v_normals, v_densify, v_means2d_abs, ws, final_T, instr ? instr->counters : nullptr, (hipStream_t)stream_);
+                              v_normals, v_densify, v_means2d_abs, ws, final_T, fwd_ws, instr ? instr->counters : nullptr, (hipStream_t)stream_);
 }

@@ -100,4 +100,111 @@ GSDF_RM_FN unsigned subblock_mask4x4(const float *GSDF_RM_RESTRICT m, float mx, 
   return mask;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------------
+// Round 6: the reach mask at 2x2-PIXEL granularity (one bit per lane quad of the compositing kernels: 8 x 8 blocks per 16 x 16 tile, bit
+// 8 by + bx).  A pair contributes to a pixel p only if min(g3, g2) <= tau = 2 ln(255 o), i.e. p lies in the ELLIPSE E = {g3 <= tau} (the screen
+// projection of the splat disc u^2 + v^2 <= tau: centre c and shape S from the dual conic, as in the 4x4 mask above) or in the low-pass DISK
+// {g2 <= tau} of radius sqrt(tau / 2) about mean2d.  Instead of a box cut by a strip, every PIXEL ROW of the tile gets the exact x-interval of
+// both convex regions, and a block's bit is the OR over its two pixel rows: no waste inside the box.  The work is split:
+//   reach_params   once per visible splat (the pack pass of the compositing kernels): c, the row-interval coefficients of the ellipse inflated
+//                  by the safety margin, the inflated disk radius;
+//   reach_mask2x2  once per (tile, splat) pair (the mask pass): 16 pixel rows x two intervals.
+// Safety margin: both regions are grown by RM_MARGIN px in every direction (fp32 cancellation in c and S stays below 0.1 px for |c| < 4096, as
+// for the 4x4 mask).  The ellipse is grown as a matrix: E (+) disk(m) lies inside the ellipse of S' = (1 + e) S + (1 + 1/e) m^2 I for any e > 0
+// (Cauchy-Schwarz on the support functions); e = m / (minor semi-axis) makes S' tight across the splat, where the lanes are won.
+// ---------------------------------------------------------------------------------------------------------------------------------------
+#ifndef GSDF_RM_MARGIN
+#define GSDF_RM_MARGIN 0.1f
+#endif
+static constexpr float RM_MARGIN = GSDF_RM_MARGIN;
+// p[0] cx, p[1] cy, p[2] 1 / S'yy, p[3] S'xy / S'yy, p[4] kk = S'xx - S'xy^2 / S'yy (> 0), p[5] (disk radius + margin)^2, p[6] mean2d.x, p[7] mean2d.y;
+// kk = -1: unbounded conic or a NaN on the way (every block reached), kk = -2: alpha < 1/255 everywhere (no block reached)
+GSDF_RM_FN void reach_params(const float *GSDF_RM_RESTRICT m, float mx, float my, float opac, float *GSDF_RM_RESTRICT p) {
+  p[0] = p[1] = p[2] = p[3] = p[5] = 0.f;
+  p[4] = -2.f;
+  p[6] = mx; p[7] = my;
+  const float o255 = 255.0f * opac;
+  if (!(o255 > 1.0f)) return;
+  const float tau = 2.0f * GSDF_RM_LOGF(o255) * 1.0001f + 1e-4f;
+  const float r2 = sqrtf(0.5f * tau) + RM_MARGIN;
+  p[5] = r2 * r2;
+  p[4] = -1.f;
+  const float it = 1.0f / tau;
+  const float d = m[6] * m[6] + m[7] * m[7] - it * m[8] * m[8];
+  if (!(d < 0.0f)) return;
+  // The conic in screen coordinates RELATIVE TO mean2d: rows M_u - mx M_w, M_v - my M_w (one rounding each, fmaf).  In absolute coordinates the
+  // shape S = c c^T - (...) / d is the difference of two terms ~ |c|^2 ~ 4e6 at 1080p, i.e. +- 0.5 px^2 of fp32 rounding on a splat of 1 px^2;
+  // about mean2d the centre offset is a fraction of the splat's own size and nothing cancels.
+  const float u0 = fmaf(-mx, m[6], m[0]), u1 = fmaf(-mx, m[7], m[1]), u2 = fmaf(-mx, m[8], m[2]);
+  const float v0 = fmaf(-my, m[6], m[3]), v1 = fmaf(-my, m[7], m[4]), v2 = fmaf(-my, m[8], m[5]);
+  const float id = 1.0f / d;
+  const float cxr = (u0 * m[6] + u1 * m[7] - it * u2 * m[8]) * id;
+  const float cyr = (v0 * m[6] + v1 * m[7] - it * v2 * m[8]) * id;
+  float sxx = cxr * cxr - (u0 * u0 + u1 * u1 - it * u2 * u2) * id;
+  float syy = cyr * cyr - (v0 * v0 + v1 * v1 - it * v2 * v2) * id;
+  const float sxy = cxr * cyr - (u0 * v0 + u1 * v1 - it * u2 * v2) * id;
+  const float cx = mx + cxr, cy = my + cyr;
+  sxx = fmaxf(sxx, 0.0f); syy = fmaxf(syy, 0.0f);
+  const float tr = sxx + syy, df = sxx - syy;
+  const float lmin = fmaxf(0.5f * (tr - sqrtf(df * df + 4.0f * sxy * sxy)), 0.0f);
+  const float b = fmaxf(sqrtf(lmin), RM_MARGIN);                  // e <= 1
+  const float e = RM_MARGIN / b;
+  const float add = (1.0f + 1.0f / e) * RM_MARGIN * RM_MARGIN;
+  const float Sxx = (1.0f + e) * sxx * 1.0001f + add, Syy = (1.0f + e) * syy * 1.0001f + add, Sxy = (1.0f + e) * sxy;
+  const float isyy = 1.0f / Syy, slope = Sxy * isyy, kk = Sxx - Sxy * slope;
+  if (!((cx == cx) && (cy == cy) && (isyy == isyy) && (slope == slope) && (kk == kk)) || !(kk > 0.0f) || !(fabsf(cx) < 1e7f) || !(fabsf(cy) < 1e7f) ||
+      !(Sxx < 1e12f) || !(Syy < 1e12f))
+    return;   // NaN / overflow: keep everything
+  p[0] = cx; p[1] = cy; p[2] = isyy; p[3] = slope; p[4] = kk;
+}
+
+// bits [lo, hi] of a 16-bit pixel row for the x-interval [xa, xb] (tile-relative pixel-centre coordinates: pixel i has its centre at i + 0.5)
+GSDF_RM_FN unsigned rm_row_bits(float xa, float xb) {
+  // pixel i is inside when xa <= i + 0.5 <= xb
+  const float flo = ceilf(xa - 0.5f), fhi = floorf(xb - 0.5f);
+  if (!(flo <= fhi) || !(fhi >= 0.0f) || !(flo <= 15.0f)) return 0u;
+  const int lo = (int)fmaxf(flo, 0.0f), hi = (int)fminf(fhi, 15.0f);
+  return (2u << hi) - (1u << lo);
+}
+// 16-bit pixel-row mask -> 8-bit block mask (block bx = pixels 2 bx, 2 bx + 1)
+GSDF_RM_FN unsigned rm_fold_pairs(unsigned r) {
+  r = (r | (r >> 1)) & 0x5555u;
+  r = (r | (r >> 1)) & 0x3333u;
+  r = (r | (r >> 2)) & 0x0F0Fu;
+  r = (r | (r >> 4)) & 0x00FFu;
+  return r;
+}
+
+GSDF_RM_FN unsigned long long reach_mask2x2(const float *GSDF_RM_RESTRICT p, float tile_x0, float tile_y0) {
+  if (!(p[4] > 0.0f)) return p[4] == -2.f ? 0ull : ~0ull;
+  const float cx = p[0] - tile_x0, cy = p[1] - tile_y0, isyy = p[2], slope = p[3], kk = p[4], R2 = p[5];
+  const float dmx = p[6] - tile_x0, dmy = p[7] - tile_y0;
+  unsigned lo32 = 0u, hi32 = 0u;
+#pragma unroll
+  for (int by = 0; by < 8; ++by) {
+    unsigned rows = 0u;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const float yp = (float)(2 * by + h) + 0.5f;
+      const float dy = yp - cy;
+      const float t = 1.0f - dy * dy * isyy;
+      if (t >= 0.0f) {
+        const float w = sqrtf(kk * t), xm = cx + slope * dy;
+        rows |= rm_row_bits(xm - w, xm + w);
+      }
+      const float dyd = yp - dmy;
+      const float td = R2 - dyd * dyd;
+      if (td >= 0.0f) {
+        const float wd = sqrtf(td);
+        rows |= rm_row_bits(dmx - wd, dmx + wd);
+      }
+    }
+    const unsigned blk = rm_fold_pairs(rows);
+    if (by < 4) lo32 |= blk << (8 * by);
+    else hi32 |= blk << (8 * (by - 4));
+  }
+  return ((unsigned long long)hi32 << 32) | lo32;
+}
+
 }  // namespace gsdf

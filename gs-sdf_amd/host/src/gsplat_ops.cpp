@@ -140,12 +140,15 @@ struct Rasterize2DGS : public torch::autograd::Function<Rasterize2DGS> {
     Tensor last = empty_like_opts(means2d, {C, height, width}, torch::kInt32), med = empty_like_opts(means2d, {C, height, width}, torch::kInt32);
     // the transmittance each pixel ended with, saved for the backward (render_alphas = 1 - T cannot give it back once T << 1)
     Tensor fT = e({C, height, width});
+    // packed splat records + reach masks of the (tile, splat) pairs (csrc/raster_quad.h): written by the forward, reused by the backward
+    Tensor fws = empty_like_opts(means2d, {(int64_t)gsdf_rasterize_2dgs_fwd_ws_bytes(M, I)}, torch::kUInt8);
     check(gsdf_rasterize_2dgs_fwd(C, M, I, (int)width, (int)height, (int)tile_size, fp(means2d), fp(rt), fp(colors), fp(opac),
                                   fp(normals), fp(bg), mk.defined() ? mk.data_ptr<uint8_t>() : nullptr,
                                   offs.data_ptr<int32_t>(), I ? flat.data_ptr<int32_t>() : nullptr, fpm(rc), fpm(rd), fpm(ra),
-                                  fpm(rn), fpm(rm), last.data_ptr<int32_t>(), med.data_ptr<int32_t>(), fpm(vis), fpm(fT), cur_stream()),
+                                  fpm(rn), fpm(rm), last.data_ptr<int32_t>(), med.data_ptr<int32_t>(), fpm(vis), fpm(fT), fws.data_ptr(),
+                                  cur_stream()),
           "rasterize_to_pixels_2dgs");
-    ctx->save_for_backward({means2d, rt, colors, opac, normals, bg, mk, offs, flat, ra, last, med, fT});
+    ctx->save_for_backward({means2d, rt, colors, opac, normals, bg, mk, offs, flat, ra, last, med, fT, fws});
     ctx->saved_data["w"] = width; ctx->saved_data["h"] = height; ctx->saved_data["t"] = tile_size;
     ctx->saved_data["absgrad"] = means2d_absgrad.requires_grad();
     Tensor distort = zeros_like_opts(means2d, {C, height, width, 1}, torch::kFloat32);
@@ -157,7 +160,7 @@ struct Rasterize2DGS : public torch::autograd::Function<Rasterize2DGS> {
   static tensor_list backward(AutogradContext *ctx, tensor_list g) {
     auto s = ctx->get_saved_variables();
     const Tensor &means2d = s[0], &rt = s[1], &colors = s[2], &opac = s[3], &normals = s[4], &bg = s[5], &mk = s[6];
-    const Tensor &offs = s[7], &flat = s[8], &ra = s[9], &last = s[10], &med = s[11], &fT = s[12];
+    const Tensor &offs = s[7], &flat = s[8], &ra = s[9], &last = s[10], &med = s[11], &fT = s[12], &fws = s[13];
     const int64_t width = ctx->saved_data["w"].toInt(), height = ctx->saved_data["h"].toInt(), tile = ctx->saved_data["t"].toInt();
     const int64_t C = offs.size(0), M = opac.size(0), I = flat.size(0);
     auto z = [&](const Tensor &t, int64_t ch) {
@@ -167,12 +170,12 @@ struct Rasterize2DGS : public torch::autograd::Function<Rasterize2DGS> {
     auto e = [&](at::IntArrayRef sh) { return empty_like_opts(means2d, sh, torch::kFloat32); };
     Tensor v_means2d = e({M, 2}), v_rt = e({M, 3, 3}), v_colors = e({M, 3}), v_opac = e({M}), v_normals = e({M, 3}), v_dens = e({M, 2});
     Tensor v_abs = ctx->saved_data["absgrad"].toBool() ? e({M, 2}) : Tensor();
-    Tensor ws = empty_like_opts(means2d, {(int64_t)gsdf_rasterize_2dgs_bwd_ws_bytes(M)}, torch::kUInt8);
+    Tensor ws = empty_like_opts(means2d, {(int64_t)gsdf_rasterize_2dgs_bwd_ws_bytes(M, I)}, torch::kUInt8);
     check(gsdf_rasterize_2dgs_bwd(C, M, I, (int)width, (int)height, (int)tile, fp(means2d), fp(rt), fp(colors), fp(opac),
                                   fp(normals), fp(bg), mk.defined() ? mk.data_ptr<uint8_t>() : nullptr, offs.data_ptr<int32_t>(),
                                   I ? flat.data_ptr<int32_t>() : nullptr, fp(ra), last.data_ptr<int32_t>(), med.data_ptr<int32_t>(),
                                   fp(v_rc), fp(v_rd), fp(v_ra), fp(v_rn), fp(v_rm), fpm(v_means2d), fpm(v_rt), fpm(v_colors),
-                                  fpm(v_opac), fpm(v_normals), fpm(v_dens), fpm(v_abs), ws.data_ptr(), fp(fT), cur_stream()),
+                                  fpm(v_opac), fpm(v_normals), fpm(v_dens), fpm(v_abs), ws.data_ptr(), fp(fT), fws.data_ptr(), cur_stream()),
           "rasterize_to_pixels_2dgs(backward)");
     return {v_means2d, v_rt, v_colors, v_opac, v_normals, v_dens, v_abs, Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor()};
   }

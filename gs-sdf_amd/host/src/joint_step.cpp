@@ -526,9 +526,11 @@ std::map<std::string, int64_t> JointIteration::step_direct(const Tensor &viewmat
                            cum.data_ptr<int64_t>(), ws2.data_ptr(), I ? isect_ids.data_ptr<int64_t>() : nullptr, I ? flat.data_ptr<int32_t>() : nullptr,
                            offs.data_ptr<int32_t>(), cur_stream()), "tile_encode");
   }
+  // packed splat records + reach masks of the (tile, splat) pairs: written by the compositing forward, reused by its backward
+  Tensor raster_fws = torch::empty({(int64_t)gsdf_rasterize_2dgs_fwd_ws_bytes(M, I)}, fopt.dtype(torch::kUInt8));
   check(gsdf_rasterize_2dgs_fwd(1, M, I, W, H, 16, fp(means2d), fp(rt), fp(colors), fp(pt_opac), fp(normals), nullptr, nullptr, offs.data_ptr<int32_t>(),
                                 I ? flat.data_ptr<int32_t>() : nullptr, fpm(rc), fpm(rd), fpm(ra), fpm(rn), fpm(rm), last.data_ptr<int32_t>(),
-                                med.data_ptr<int32_t>(), fpm(vis), fpm(fT), cur_stream()), "rasterize_fwd");
+                                med.data_ptr<int32_t>(), fpm(vis), fpm(fT), raster_fws.data_ptr(), cur_stream()), "rasterize_fwd");
   const int64_t P = (int64_t)H * W;
   check(gsdf_render_post_fwd(P, 1, fp(viewmat), fp(rc), fp(rd), fp(ra), fp(rn), fpm(renders), fpm(nw), fpm(c3), fpm(d1), cur_stream()), "render_post_fwd");
   // ---- the visible, occupancy-valid samples (one size), then the SDF leg's forward on the second stream
@@ -591,11 +593,11 @@ std::map<std::string, int64_t> JointIteration::step_direct(const Tensor &viewmat
         "render_post_bwd");
   Tensor v_means2d = torch::empty({M, 2}, fopt), v_rt = torch::empty({M, 3, 3}, fopt), v_colors = torch::empty({M, 3}, fopt), v_opac = torch::empty({M}, fopt);
   Tensor v_normals = torch::empty({M, 3}, fopt), v_dens = torch::empty({M, 2}, fopt);
-  Tensor rws = torch::empty({(int64_t)gsdf_rasterize_2dgs_bwd_ws_bytes(M)}, fopt.dtype(torch::kUInt8));
+  Tensor rws = torch::empty({(int64_t)gsdf_rasterize_2dgs_bwd_ws_bytes(M, I)}, fopt.dtype(torch::kUInt8));
   check(gsdf_rasterize_2dgs_bwd(1, M, I, W, H, 16, fp(means2d), fp(rt), fp(colors), fp(pt_opac), fp(normals), nullptr, nullptr, offs.data_ptr<int32_t>(),
                                 I ? flat.data_ptr<int32_t>() : nullptr, fp(ra), last.data_ptr<int32_t>(), med.data_ptr<int32_t>(), fp(v_rc), fp(v_rd), fp(v_ra),
                                 fp(v_rn), fp(zero_image_), fpm(v_means2d), fpm(v_rt), fpm(v_colors), fpm(v_opac), fpm(v_normals), fpm(v_dens), nullptr,
-                                rws.data_ptr(), fp(fT), cur_stream()), "rasterize_bwd");
+                                rws.data_ptr(), fp(fT), raster_fws.data_ptr(), cur_stream()), "rasterize_bwd");
   // train_callback -> update_state (neural_gaussian.cpp:626-680): needs the densify gradient only
   update_state(state_, v_dens, gaussian_ids, vis, radii, N, 1, W, H, false);
   Tensor v_sh_tmp;

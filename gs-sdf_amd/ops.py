@@ -223,11 +223,13 @@ class _Rasterize2DGS(torch.autograd.Function):
         # the transmittance each pixel ended with, kept for the backward: render_alphas = 1 - T cannot give it back once T << 1
         need = any(ctx.needs_input_grad[:7])
         fT = _empty((C, height, width), torch.float32, means2d) if need else None
+        # packed splat records + reach masks of the (tile, splat) pairs: written by the forward, reused by the backward
+        fws = torch.empty(L.gsdf_rasterize_2dgs_fwd_ws_bytes(M, I), dtype=torch.uint8, device=means2d.device)
         capi.check(_timed("rasterize_2dgs_fwd", L.gsdf_rasterize_2dgs_fwd, C, M, I, width, height, tile_size, f32(means2d), f32(rt), f32(colors),
                                              f32(opacities), f32(normals), f32(bg), ptr(mk), ptr(isect_offsets, torch.int32),
                                              ptr(flatten_ids, torch.int32), f32(rc), f32(rd), f32(ra), f32(rn), f32(rm),
-                                             ptr(last), ptr(med), f32(vis), f32(fT), capi.stream()), "rasterize_2dgs_fwd")
-        ctx.save_for_backward(means2d, rt, colors, opacities, normals, bg, mk, isect_offsets, flatten_ids, ra, last, med, fT)
+                                             ptr(last), ptr(med), f32(vis), f32(fT), ptr(fws), capi.stream()), "rasterize_2dgs_fwd")
+        ctx.save_for_backward(means2d, rt, colors, opacities, normals, bg, mk, isect_offsets, flatten_ids, ra, last, med, fT, fws if need else None)
         ctx.dims = (width, height, tile_size)
         ctx.absgrad = bool(ctx.needs_input_grad[6])
         distort = torch.zeros((C, height, width, 1), dtype=torch.float32, device=means2d.device)
@@ -237,7 +239,7 @@ class _Rasterize2DGS(torch.autograd.Function):
     @staticmethod
     def backward(ctx, v_rc, v_rd, v_ra, v_rn, _v_dist, v_rm, _v_vis):
         L = capi.lib()
-        means2d, rt, colors, opacities, normals, bg, mk, isect_offsets, flatten_ids, ra, last, med, fT = ctx.saved_tensors
+        means2d, rt, colors, opacities, normals, bg, mk, isect_offsets, flatten_ids, ra, last, med, fT, fws = ctx.saved_tensors
         width, height, tile_size = ctx.dims
         C, M, I = isect_offsets.shape[0], opacities.shape[0], flatten_ids.shape[0]
         zz = lambda g, ch: (torch.zeros((C, height, width, ch), dtype=torch.float32, device=means2d.device) if g is None
@@ -246,12 +248,12 @@ class _Rasterize2DGS(torch.autograd.Function):
         e = lambda *s: _empty(s, torch.float32, means2d)
         v_means2d, v_rt, v_colors, v_opac, v_normals, v_dens = e(M, 2), e(M, 3, 3), e(M, 3), e(M), e(M, 3), e(M, 2)
         v_abs = e(M, 2) if ctx.absgrad else None
-        ws = torch.empty(L.gsdf_rasterize_2dgs_bwd_ws_bytes(M), dtype=torch.uint8, device=means2d.device)
+        ws = torch.empty(L.gsdf_rasterize_2dgs_bwd_ws_bytes(M, I), dtype=torch.uint8, device=means2d.device)
         capi.check(_timed("rasterize_2dgs_bwd", L.gsdf_rasterize_2dgs_bwd, C, M, I, width, height, tile_size, f32(means2d), f32(rt), f32(colors),
                                              f32(opacities), f32(normals), f32(bg), ptr(mk), ptr(isect_offsets),
                                              ptr(flatten_ids), f32(ra), ptr(last), ptr(med), f32(v_rc), f32(v_rd), f32(v_ra),
                                              f32(v_rn), f32(v_rm), f32(v_means2d), f32(v_rt), f32(v_colors), f32(v_opac),
-                                             f32(v_normals), f32(v_dens), f32(v_abs), ptr(ws), f32(fT), capi.stream()), "rasterize_2dgs_bwd")
+                                             f32(v_normals), f32(v_dens), f32(v_abs), ptr(ws), f32(fT), ptr(fws), capi.stream()), "rasterize_2dgs_bwd")
         return (v_means2d, v_rt, v_colors, v_opac, v_normals, v_dens, v_abs, None, None, None, None, None, None, None)
 
 
@@ -267,6 +269,7 @@ def rasterize_fwd_instr(means2d, ray_transforms, colors, opacities, normals, wid
     rc, rd, ra, rn, rm = e(C, height, width, 3), e(C, height, width, 1), e(C, height, width, 1), e(C, height, width, 3), e(C, height, width, 1)
     last = _empty((C, height, width), torch.int32, means2d); med = _empty((C, height, width), torch.int32, means2d)
     vis, fT = _empty((M, 1), torch.float32, means2d), _empty((C, height, width), torch.float32, means2d)
+    fws = torch.empty(L.gsdf_rasterize_2dgs_fwd_ws_bytes(M, I), dtype=torch.uint8, device=means2d.device)
     bits = None
     if trace_rows is not None:
         n_rows = int(trace_rows.max().item()) + 1
@@ -278,10 +281,10 @@ def rasterize_fwd_instr(means2d, ray_transforms, colors, opacities, normals, wid
     capi.check(L.gsdf_rasterize_2dgs_fwd_instr(C, M, I, width, height, 16, f32(means2d), f32(ray_transforms), f32(colors), f32(opacities),
                                                f32(normals), f32(backgrounds), ptr(mk), ptr(isect_offsets, torch.int32),
                                                ptr(flatten_ids, torch.int32), f32(rc), f32(rd), f32(ra), f32(rn), f32(rm), ptr(last), ptr(med),
-                                               f32(vis), f32(fT), ctypes.cast(ctypes.pointer(instr), ctypes.c_void_p), capi.stream()),
+                                               f32(vis), f32(fT), ptr(fws), ctypes.cast(ctypes.pointer(instr), ctypes.c_void_p), capi.stream()),
                "rasterize_2dgs_fwd_instr")
     return dict(render_colors=rc, render_depths=rd, render_alphas=ra, render_normals=rn, render_median=rm, last_ids=last, median_ids=med,
-                visibilities=vis, final_T=fT, trace_bits=bits)
+                visibilities=vis, final_T=fT, trace_bits=bits, fwd_ws=fws)
 
 
 def rasterize_bwd_instr(means2d, ray_transforms, colors, opacities, normals, width, height, isect_offsets, flatten_ids, fwd, upstream,
@@ -294,7 +297,7 @@ def rasterize_bwd_instr(means2d, ray_transforms, colors, opacities, normals, wid
     e = lambda *s: _empty(s, torch.float32, means2d)
     g = dict(v_means2d=e(M, 2), v_ray_transforms=e(M, 3, 3), v_colors=e(M, 3), v_opacities=e(M), v_normals=e(M, 3), v_densify=e(M, 2),
              v_means2d_abs=e(M, 2) if absgrad else None)
-    ws = torch.empty(L.gsdf_rasterize_2dgs_bwd_ws_bytes(M), dtype=torch.uint8, device=means2d.device)
+    ws = torch.empty(L.gsdf_rasterize_2dgs_bwd_ws_bytes(M, I), dtype=torch.uint8, device=means2d.device)
     instr = capi.RasterInstr(capi.ptr(counters).value if counters is not None else None, None, 0, None)
     mk = None if masks is None else masks.to(torch.uint8).contiguous()
     u = lambda k: f32(upstream[k].contiguous())
@@ -304,7 +307,8 @@ def rasterize_bwd_instr(means2d, ray_transforms, colors, opacities, normals, wid
                                                u("v_render_colors"), u("v_render_depths"), u("v_render_alphas"), u("v_render_normals"),
                                                u("v_render_median"), f32(g["v_means2d"]), f32(g["v_ray_transforms"]), f32(g["v_colors"]),
                                                f32(g["v_opacities"]), f32(g["v_normals"]), f32(g["v_densify"]), f32(g["v_means2d_abs"]), ptr(ws),
-                                               f32(fwd["final_T"]), ctypes.cast(ctypes.pointer(instr), ctypes.c_void_p), capi.stream()),
+                                               f32(fwd["final_T"]), ptr(fwd.get("fwd_ws")), ctypes.cast(ctypes.pointer(instr), ctypes.c_void_p),
+                                               capi.stream()),
                "rasterize_2dgs_bwd_instr")
     return g
 

@@ -40,7 +40,7 @@ const char *gsdf_last_error(void);
 /* ABI version; bumped on any signature change.  Every binding compares gsdf_abi_version() of the library it loaded with the
  * GSDF_ABI_VERSION of the header it was written against and refuses to run on a mismatch (gs_sdf_amd/capi.py: lib(); the C++
  * operator layer: gsplat_ops.cpp static initialiser): a stale libgsdf_hip.so fails at load, not on the device. */
-#define GSDF_ABI_VERSION 7
+#define GSDF_ABI_VERSION 8
 int gsdf_abi_version(void);
 
 /* Optional per-entry-point device timing (bench.py's roofline leg, for callers in any language): between gsdf_timing_begin and
@@ -136,7 +136,11 @@ int gsdf_tile_encode(int64_t n_visible, int64_t n_cams, int64_t n_isects, int wi
  *                              packed, means2d_absgrad, distloss)
  *     reference call: neural_gaussian.cpp:215-223 ; grads consumed at :626-633
  * tile_size must be 16.  backgrounds [C,3] / masks u8[C,th,tw] may be NULL.
+ * ws >= gsdf_rasterize_2dgs_fwd_ws_bytes(M, I) (ABI 8): the forward first packs every visible splat into one 128-byte record and
+ * every (tile, splat) pair into a 64-bit reach mask (csrc/raster_quad.h) and leaves both there; handing the same buffer to the
+ * backward as `fwd_ws` saves it the two passes.
  * ---------------------------------------------------------------------------------------- */
+size_t gsdf_rasterize_2dgs_fwd_ws_bytes(int64_t n_visible, int64_t n_isects);
 int gsdf_rasterize_2dgs_fwd(int64_t n_cams, int64_t n_visible, int64_t n_isects, int width, int height,
                             int tile_size, const float *means2d, const float *ray_transforms,
                             const float *colors, const float *opacities, const float *normals,
@@ -148,7 +152,7 @@ int gsdf_rasterize_2dgs_fwd(int64_t n_cams, int64_t n_visible, int64_t n_isects,
                             float *visibilities /*[M,1], fully written*/,
                             float *final_T /*[C,H,W] or NULL: the transmittance after the last blended splat, saved for the
                                              backward (render_alphas = 1 - T loses it to rounding once T << 1)*/,
-                            gsdf_stream_t stream);
+                            void *ws, gsdf_stream_t stream);
 
 /* Instrumented launches of the compositing kernels (tests / diagnostics; the product never passes an instr block).  No process-wide
  * state: the instrumentation is an argument of the call.
@@ -173,14 +177,16 @@ int gsdf_rasterize_2dgs_fwd_instr(int64_t n_cams, int64_t n_visible, int64_t n_i
                                   const float *opacities, const float *normals, const float *backgrounds, const uint8_t *masks,
                                   const int32_t *isect_offsets, const int32_t *flatten_ids, float *render_colors,
                                   float *render_depths, float *render_alphas, float *render_normals, float *render_median,
-                                  int32_t *last_ids, int32_t *median_ids, float *visibilities, float *final_T,
+                                  int32_t *last_ids, int32_t *median_ids, float *visibilities, float *final_T, void *ws,
                                   const gsdf_raster_instr *instr /*host pointer*/, gsdf_stream_t stream);
 
-/* All gradient outputs are fully written.  v_means2d_abs may be NULL.  ws >= *_bwd_ws_bytes(M): the kernel
- * accumulates one packed 80-byte gradient record per splat there (line-coalesced atomics) and unpacks it.
+/* All gradient outputs are fully written.  v_means2d_abs may be NULL.  ws >= *_bwd_ws_bytes(M, I): the kernel
+ * accumulates one packed 84-byte gradient record per splat there (line-coalesced atomics) and unpacks it.
+ * fwd_ws: the workspace the forward of the SAME inputs filled (records + reach masks), or NULL — the backward then runs the pack and
+ * mask passes into its own workspace.
  * final_T: the forward's saved transmittance, or NULL (then T_final = 1 - render_alphas as upstream gsplat does, which is
  * only accurate to 6e-8 ABSOLUTE: a 6e-4 relative error of every weight of a pixel that ended at T = 1e-4). */
-size_t gsdf_rasterize_2dgs_bwd_ws_bytes(int64_t n_visible);
+size_t gsdf_rasterize_2dgs_bwd_ws_bytes(int64_t n_visible, int64_t n_isects);
 int gsdf_rasterize_2dgs_bwd(int64_t n_cams, int64_t n_visible, int64_t n_isects, int width, int height,
                             int tile_size, const float *means2d, const float *ray_transforms,
                             const float *colors, const float *opacities, const float *normals,
@@ -190,7 +196,8 @@ int gsdf_rasterize_2dgs_bwd(int64_t n_cams, int64_t n_visible, int64_t n_isects,
                             const float *v_render_depths, const float *v_render_alphas,
                             const float *v_render_normals, const float *v_render_median, float *v_means2d,
                             float *v_ray_transforms, float *v_colors, float *v_opacities, float *v_normals,
-                            float *v_densify, float *v_means2d_abs, void *ws, const float *final_T, gsdf_stream_t stream);
+                            float *v_densify, float *v_means2d_abs, void *ws, const float *final_T, const void *fwd_ws,
+                            gsdf_stream_t stream);
 /* the same with instr->counters (see gsdf_raster_instr; the trace is a forward-only facility) */
 int gsdf_rasterize_2dgs_bwd_instr(int64_t n_cams, int64_t n_visible, int64_t n_isects, int width, int height,
                                   int tile_size, const float *means2d, const float *ray_transforms,
@@ -201,7 +208,7 @@ int gsdf_rasterize_2dgs_bwd_instr(int64_t n_cams, int64_t n_visible, int64_t n_i
                                   const float *v_render_depths, const float *v_render_alphas,
                                   const float *v_render_normals, const float *v_render_median, float *v_means2d,
                                   float *v_ray_transforms, float *v_colors, float *v_opacities, float *v_normals,
-                                  float *v_densify, float *v_means2d_abs, void *ws, const float *final_T,
+                                  float *v_densify, float *v_means2d_abs, void *ws, const float *final_T, const void *fwd_ws,
                                   const gsdf_raster_instr *instr /*host pointer*/, gsdf_stream_t stream);
 
 
