@@ -483,11 +483,18 @@ __global__ void __launch_bounds__(RT, ABSGRAD ? 3 : 4)
 // chip-wide), ds_add_f64 7.7 (4.7 T/s): the row kernel's 20 float adds per (row, splat) were ~0.4 ms of LDS-atomic time per launch, the quad
 // kernel's 20 per (quad, splat) would be ~1.2 ms; as double adds they are ~0.05 ms, and the tile-level sum is exact to fp32.
 // ---------------------------------------------------------------------------------------------------------------------------------------
+// Measured at cfg3 (tools/exp_raster_quads.py, library variants of tools/build_variants.sh; backward + unpack, ms): batch 116 at 4 workgroups per CU
+// 0.750; without the SLP vectoriser (its packed-fp32 forms cost more moves than they save: 106 -> 96 registers) 0.731; v_rcp_f32 for 1 / (1 - alpha)
+// instead of the IEEE division sequence 0.719; batch 92 at 5 workgroups per CU 0.692 (84: 0.764 — a smaller batch at the same occupancy costs more
+// than it gives); batch 76 at 6 per CU (80 registers, 27-32 spilled) 0.911.
+#ifndef RASTER_BWD_RCP
+#define RASTER_BWD_RCP(x) __builtin_amdgcn_rcpf(x)
+#endif
 #ifndef RASTER_BWD_QUADS_BATCH
-#define RASTER_BWD_QUADS_BATCH 116
+#define RASTER_BWD_QUADS_BATCH 92
 #endif
 #ifndef RASTER_BWD_QUADS_WGS
-#define RASTER_BWD_QUADS_WGS 4
+#define RASTER_BWD_QUADS_WGS 5
 #endif
 static constexpr int BQB = RASTER_BWD_QUADS_BATCH;
 static constexpr int BQ_CHUNKS = (BQB + 63) / 64;
@@ -703,7 +710,7 @@ __global__ void __launch_bounds__(RT, RASTER_BWD_QUADS_WGS)
       float vzx = 0.f, vzy = 0.f, vzz = 0.f, g_dx = 0.f, g_dy = 0.f, g_mwz = 0.f, g_x = 0.f, g_y = 0.f;
       bool v2 = false;
       if (valid) {
-        const float ra = 1.0f / (1.0f - e.alpha);
+        const float ra = RASTER_BWD_RCP(1.0f - e.alpha);
         T *= ra;
         const float fac = e.alpha * T;
         g_rgb0 = fac * vCr; g_rgb1 = fac * vCg; g_rgb2 = fac * vCb;

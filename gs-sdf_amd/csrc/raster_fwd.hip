@@ -329,11 +329,14 @@ __global__ void __launch_bounds__(RT, RASTER_FWD_ROWS_WGS)
 // them with the same operands, so every output is bit-identical to the row-list and quadrant kernels above.  Quads whose four pixels are
 // finished get no list (termination mask).
 // ---------------------------------------------------------------------------------------------------------------------------------------
+// Measured at cfg3 (tools/exp_raster_quads.py, library variants of tools/build_variants.sh; pack + mask + forward, ms): batch 192 at 5 workgroups
+// per CU 0.343, 160 at 6 0.313, 144 at 6 0.302, 128 at 7 0.299, 112 at 8 0.291, 240 at 4 0.330: the kernel is latency-bound (VALU issue 49 %, LDS
+// 26 % busy at 5 per CU), so the batch is what eight workgroups' LDS allows (62 registers: eight waves per SIMD fit).
 #ifndef RASTER_FWD_QUADS_BATCH
-#define RASTER_FWD_QUADS_BATCH 192
+#define RASTER_FWD_QUADS_BATCH 120
 #endif
 #ifndef RASTER_FWD_QUADS_WGS
-#define RASTER_FWD_QUADS_WGS 5
+#define RASTER_FWD_QUADS_WGS 8
 #endif
 static constexpr int FQB = RASTER_FWD_QUADS_BATCH;
 static constexpr int FQ_CHUNKS = (FQB + 63) / 64;

@@ -8,11 +8,13 @@
 #define GSDF_RM_FN static inline
 #define GSDF_RM_LOGF logf
 #define GSDF_RM_RSQRTF(x) (1.0f / sqrtf(x))
+#define GSDF_RM_SQRTF_FAST(x) sqrtf(x)
 #define GSDF_RM_RESTRICT
 #else
 #define GSDF_RM_FN __device__ __forceinline__
 #define GSDF_RM_LOGF __logf
 #define GSDF_RM_RSQRTF(x) rsqrtf(x)
+#define GSDF_RM_SQRTF_FAST(x) __builtin_amdgcn_sqrtf(x)   /* v_sqrt_f32, 1 ulp: the intervals carry a 1e-3 px slack */
 #define GSDF_RM_RESTRICT __restrict__
 #endif
 
@@ -159,48 +161,37 @@ GSDF_RM_FN void reach_params(const float *GSDF_RM_RESTRICT m, float mx, float my
   p[0] = cx; p[1] = cy; p[2] = isyy; p[3] = slope; p[4] = kk;
 }
 
-// bits [lo, hi] of a 16-bit pixel row for the x-interval [xa, xb] (tile-relative pixel-centre coordinates: pixel i has its centre at i + 0.5)
-GSDF_RM_FN unsigned rm_row_bits(float xa, float xb) {
-  // pixel i is inside when xa <= i + 0.5 <= xb
-  const float flo = ceilf(xa - 0.5f), fhi = floorf(xb - 0.5f);
-  if (!(flo <= fhi) || !(fhi >= 0.0f) || !(flo <= 15.0f)) return 0u;
-  const int lo = (int)fmaxf(flo, 0.0f), hi = (int)fminf(fhi, 15.0f);
-  return (2u << hi) - (1u << lo);
+// bits [lo, hi] of an 8-bit block row for the x-interval [xa, xb] (tile-relative pixel-centre coordinates: pixel i has its centre at i + 0.5, block
+// bx = pixels 2 bx, 2 bx + 1).  Pixel i is inside when xa <= i + 0.5 <= xb, i.e. ceil(xa - 0.5) <= i <= floor(xb - 0.5); both roundings are taken
+// as ONE round-to-nearest of a value moved 1e-3 px outwards (rint(xa - 1e-3) <= ceil(xa - 0.5), rint(xb - 1 + 1e-3) >= floor(xb - 0.5), ties
+// included): a pixel whose centre lies within 1e-3 px outside the interval may be kept, none inside it is dropped.  The caller passes
+// xa - 1e-3 and xb - (1 - 1e-3); an empty interval is a NaN in either bound (every comparison with it fails).
+GSDF_RM_FN unsigned rm_block_bits(float xa_m, float xb_m) {
+  const float flo = rintf(xa_m), fhi = rintf(xb_m);
+  const bool ok = (flo <= fhi) && (fhi >= 0.0f) && (flo <= 15.0f);
+  const unsigned lo = (unsigned)fmaxf(flo, 0.0f) >> 1, hi = (unsigned)fminf(fmaxf(fhi, 0.0f), 15.0f) >> 1;
+  return ok ? (2u << hi) - (1u << lo) : 0u;
 }
-// 16-bit pixel-row mask -> 8-bit block mask (block bx = pixels 2 bx, 2 bx + 1)
-GSDF_RM_FN unsigned rm_fold_pairs(unsigned r) {
-  r = (r | (r >> 1)) & 0x5555u;
-  r = (r | (r >> 1)) & 0x3333u;
-  r = (r | (r >> 2)) & 0x0F0Fu;
-  r = (r | (r >> 4)) & 0x00FFu;
-  return r;
-}
-
+// NaN-ignoring min / max (fminf / fmaxf return the other operand when one is a NaN: an empty pixel row does not widen the block row)
 GSDF_RM_FN unsigned long long reach_mask2x2(const float *GSDF_RM_RESTRICT p, float tile_x0, float tile_y0) {
   if (!(p[4] > 0.0f)) return p[4] == -2.f ? 0ull : ~0ull;
-  const float cx = p[0] - tile_x0, cy = p[1] - tile_y0, isyy = p[2], slope = p[3], kk = p[4], R2 = p[5];
-  const float dmx = p[6] - tile_x0, dmy = p[7] - tile_y0;
+  const float cy = p[1] - tile_y0, isyy = p[2], slope = p[3], kk = p[4], R2 = p[5];
+  const float dmy = p[7] - tile_y0;
+  const float cxa = (p[0] - tile_x0) - 1e-3f, cxb = (p[0] - tile_x0) - (1.0f - 1e-3f);
+  const float dxa = (p[6] - tile_x0) - 1e-3f, dxb = (p[6] - tile_x0) - (1.0f - 1e-3f);
   unsigned lo32 = 0u, hi32 = 0u;
 #pragma unroll
   for (int by = 0; by < 8; ++by) {
-    unsigned rows = 0u;
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const float yp = (float)(2 * by + h) + 0.5f;
-      const float dy = yp - cy;
-      const float t = 1.0f - dy * dy * isyy;
-      if (t >= 0.0f) {
-        const float w = sqrtf(kk * t), xm = cx + slope * dy;
-        rows |= rm_row_bits(xm - w, xm + w);
-      }
-      const float dyd = yp - dmy;
-      const float td = R2 - dyd * dyd;
-      if (td >= 0.0f) {
-        const float wd = sqrtf(td);
-        rows |= rm_row_bits(dmx - wd, dmx + wd);
-      }
-    }
-    const unsigned blk = rm_fold_pairs(rows);
+    // the block row's two pixel rows: x-interval of the ellipse (xm -+ w, w = sqrt(kk (1 - dy^2 / S'yy)); NaN when the row misses it) and of
+    // the disk; the union of two rows of one convex shape is taken as [min, max] (a superset when the rows do not overlap)
+    const float y0 = (float)(2 * by) + 0.5f, y1 = y0 + 1.0f;
+    const float e0 = y0 - cy, e1 = y1 - cy;
+    const float w0 = GSDF_RM_SQRTF_FAST(kk * (1.0f - e0 * e0 * isyy)), w1 = GSDF_RM_SQRTF_FAST(kk * (1.0f - e1 * e1 * isyy));
+    const float ea = fminf((cxa + slope * e0) - w0, (cxa + slope * e1) - w1), eb = fmaxf((cxb + slope * e0) + w0, (cxb + slope * e1) + w1);
+    const float d0 = y0 - dmy, d1 = y1 - dmy;
+    const float v0 = GSDF_RM_SQRTF_FAST(R2 - d0 * d0), v1 = GSDF_RM_SQRTF_FAST(R2 - d1 * d1);
+    const float da = dxa - fmaxf(v0, v1), db = dxb + fmaxf(v0, v1);
+    const unsigned blk = rm_block_bits(ea, eb) | rm_block_bits(da, db);
     if (by < 4) lo32 |= blk << (8 * by);
     else hi32 |= blk << (8 * (by - 4));
   }

@@ -9,6 +9,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if len(sys.argv) > 2 and sys.argv[2] == "child":
     import torch
     sys.path.insert(0, ROOT)
+    import gs_sdf_amd.capi as capi
+    if os.environ.get("GSDF_EXP_LIB"):      # compile-time variant of the library (tools/build_variants.sh), this tool only
+        capi.LIB_PATH = os.path.join(ROOT, "gs-sdf_amd", "lib", "variants", os.environ["GSDF_EXP_LIB"], "libgsdf_hip.so")
     import gs_sdf_amd.ops as ops, gs_sdf_amd.synth as synth
     from bench import WORKLOADS
     dev = torch.device("cuda:0")
@@ -52,13 +55,15 @@ wl = sys.argv[1] if len(sys.argv) > 1 else "cfg3_1M_1080p"
 out = {}
 VARIANTS = (("quads", {"GSDF_RASTER_LISTS": "quads"}), ("rows", {"GSDF_RASTER_LISTS": "rows"}), ("quads_again", {"GSDF_RASTER_LISTS": "quads"}))
 if os.environ.get("GSDF_EXP_VARIANTS"):
-    VARIANTS = tuple((v, {"GSDF_RASTER_LISTS": v.split("_")[0]}) for v in os.environ["GSDF_EXP_VARIANTS"].split(";"))
+    # "quads", "rows", or "quads@<library variant>"
+    VARIANTS = tuple((v, {"GSDF_RASTER_LISTS": v.split("@")[0].split("_")[0], **({"GSDF_EXP_LIB": v.split("@")[1]} if "@" in v else {})})
+                     for v in os.environ["GSDF_EXP_VARIANTS"].split(";"))
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
 for name, env in VARIANTS:
     e = dict(os.environ); e.update(env)
-    r = subprocess.run([sys.executable, __file__, wl, "child", f"/tmp/raster_{name}.pt"], env=e, capture_output=True, text=True)
+    r = subprocess.run([sys.executable, __file__, wl, "child", f"/tmp/raster_{name.replace('@', '_')}.pt"], env=e, capture_output=True, text=True)
     out[name] = json.loads(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 else {"error": r.stderr[-3000:]}
-    print(name, out[name], flush=True)
+    print(name, {k: (round(v, 4) if isinstance(v, float) else v) for k, v in out[name].items() if k.endswith("_ms_median") or k == "error"}, flush=True)
 names = [n for n, _ in VARIANTS if "error" not in out[n]]
 if "quads" in names and "rows" in names:
     a, b = torch.load("/tmp/raster_quads.pt"), torch.load("/tmp/raster_rows.pt")
