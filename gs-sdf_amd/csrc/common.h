@@ -59,74 +59,17 @@ __device__ __forceinline__ float wave_sum_to_lane63(float v) {
   return v;
 }
 
-// max over the wave of NON-NEGATIVE floats, done on their bit patterns with integer max: no fp canonicalisation
-// (v_max_f32 x,x,x) is emitted and the DPP operand folds into v_max_u32.  Result valid in lane 63.
 template <int CTRL, int ROW_MASK = 0xF, int BANK_MASK = 0xF, bool BOUND_CTRL = true>
 __device__ __forceinline__ unsigned dpp_mov_u(unsigned v) {
   return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, BANK_MASK, BOUND_CTRL);
 }
-__device__ __forceinline__ unsigned wave_umax_to_lane63(unsigned v) {
-  v = max(v, dpp_mov_u<0x111>(v));
-  v = max(v, dpp_mov_u<0x112>(v));
-  v = max(v, dpp_mov_u<0x114>(v));
-  v = max(v, dpp_mov_u<0x118>(v));
-  v = max(v, dpp_mov_u<0x142, 0xA, 0xF, false>(v));
-  v = max(v, dpp_mov_u<0x143, 0xC, 0xF, false>(v));
-  return v;
-}
-
-__device__ __forceinline__ float wave_max_to_lane63(float v) {
-  // values are >= 0, so shifted-in zeros (bound_ctrl) are neutral
-  v = fmaxf(v, dpp_mov<0x111>(v));
-  v = fmaxf(v, dpp_mov<0x112>(v));
-  v = fmaxf(v, dpp_mov<0x114>(v));
-  v = fmaxf(v, dpp_mov<0x118>(v));
-  v = fmaxf(v, dpp_mov<0x142, 0xA, 0xF, false>(v));
-  v = fmaxf(v, dpp_mov<0x143, 0xC, 0xF, false>(v));
-  return v;
-}
-
-// Transposing butterfly reduction of 16 per-lane values over a DPP row (16 lanes): at every stage each lane
-// keeps the half of the values selected by one of its lane bits and receives the partner lane's partial of
-// the same half, so the work halves per stage (8+4+2+1 adds instead of 16 x 4).  On return the lane holds
-// the ROW sum of value index m = 8*b0 + 4*b1 + 2*b2 + b3 (b_i = bit i of the lane id); the 4 rows of the
-// wave still have to be combined (the callers do it with one 4-way ds_add_f32 per lane).
+// lane ^ 4 / lane ^ 8 exchange inside a DPP row: two masked row shifts
 template <int CTRL_LO, int CTRL_HI, int BANK_LO, int BANK_HI>
 __device__ __forceinline__ float dpp_xchg(float v) {
   // lanes of BANK_LO read with CTRL_LO (row_shl), lanes of BANK_HI with CTRL_HI (row_shr)
   int t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL_LO, 0xF, BANK_LO, false);
   t = __builtin_amdgcn_update_dpp(t, __float_as_int(v), CTRL_HI, 0xF, BANK_HI, false);
   return __int_as_float(t);
-}
-
-__device__ __forceinline__ float row_transpose_reduce16(const float (&v)[16], int lane) {
-  const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4, b3 = lane & 8;
-  float a[8], b[4], c[2];
-#pragma unroll
-  for (int k = 0; k < 8; ++k) a[k] = (b0 ? v[k + 8] : v[k]) + dpp_mov<0xB1>(b0 ? v[k] : v[k + 8]);  // lane ^ 1
-#pragma unroll
-  for (int k = 0; k < 4; ++k) b[k] = (b1 ? a[k + 4] : a[k]) + dpp_mov<0x4E>(b1 ? a[k] : a[k + 4]);  // lane ^ 2
-#pragma unroll
-  for (int k = 0; k < 2; ++k)
-    c[k] = (b2 ? b[k + 2] : b[k]) + dpp_xchg<0x104, 0x114, 0x5, 0xA>(b2 ? b[k] : b[k + 2]);          // lane ^ 4
-  return (b3 ? c[1] : c[0]) + dpp_xchg<0x108, 0x118, 0x3, 0xC>(b3 ? c[0] : c[1]);                     // lane ^ 8
-}
-// The same for 4 values over the quads of a row: on return lanes 12..15 of every row hold the ROW sum of value index
-// m = 2*b0 + b1 (other lanes hold partial sums).  6 + 3 + 2 VALU.
-__device__ __forceinline__ float row_transpose_reduce4(const float (&v)[4], int lane) {
-  const bool b0 = lane & 1, b1 = lane & 2;
-  float a[2];
-#pragma unroll
-  for (int k = 0; k < 2; ++k) a[k] = (b0 ? v[k + 2] : v[k]) + dpp_mov<0xB1>(b0 ? v[k] : v[k + 2]);  // lane ^ 1
-  float r = (b1 ? a[1] : a[0]) + dpp_mov<0x4E>(b1 ? a[0] : a[1]);                                   // lane ^ 2
-  r += dpp_mov<0x114>(r);   // row_shr:4 (zero fill)
-  r += dpp_mov<0x118>(r);   // row_shr:8
-  return r;
-}
-__device__ __forceinline__ int row_transpose_index4(int lane) { return ((lane & 1) << 1) | ((lane & 2) >> 1); }
-
-__device__ __forceinline__ int row_transpose_index(int lane) {
-  return ((lane & 1) << 3) | ((lane & 2) << 1) | ((lane & 4) >> 1) | ((lane & 8) >> 3);
 }
 
 // Optional per-entry-point device timing (gsdf_timing_begin / gsdf_timing_end, include/gsdf_hip.h): a HIP event pair on the

@@ -3,25 +3,22 @@
 // (/root/reference/include/neural_gaussian/neural_gaussian.cpp:215-223); the gradients of the leaf
 // tensors `densify` / `means2d_absgrad` are consumed at neural_gaussian.cpp:626-633.
 //
-// Per tile: replay the depth-sorted list back-to-front from each pixel's last contributor.  The
-// per-(pixel,splat) gradient terms are reduced over the 64 lanes of a wave with DPP row shifts
-// (no LDS traffic) and the wave total is added to a per-tile LDS accumulator (ds_add_f32 from one
-// lane, 4 waves -> no contention).
+// Per tile: replay the depth-sorted list back-to-front from each pixel's last contributor; the per-(pixel, splat) gradient
+// terms are reduced over the lanes of a quad with DPP (no LDS traffic) and added to a per-tile LDS record of the splat.
 //
 // Flush to HBM — measured on MI355X (tools/ubench/atomic_*.hip): the fp32 atomic path retires
 // ~21 G *64-byte-line requests*/s chip-wide, independent of footprint and scope, and lanes of one
 // instruction that hit the same line are merged (16 consecutive floats -> 307 G atomics/s).  One
 // atomic per (tile, splat, field) into six separate [M,k] arrays is 17 line requests per
-// intersection (4e7 per view = 1.9 ms of the 2.7 ms kernel).  So the accumulator of one splat is a
-// single 80-byte RECORD ([M][20] floats), three records are flushed per wave instruction with the
-// 20 fields in consecutive lanes (<= 2 lines per splat), and a streaming epilogue unpacks the
+// intersection (4e7 per view = 1.9 ms of the first kernel's 2.7 ms).  So the accumulator of one splat is a
+// single 84-byte RECORD ([M][21] floats), three records are flushed per wave instruction with the
+// 21 fields in consecutive lanes (<= 2 lines per splat), and a streaming epilogue unpacks the
 // records into the operator's six gradient tensors (+ the densification signal).
 #include "raster_quad.h"
 
 namespace gsdf {
 
 static constexpr int NACC = 21;
-static constexpr int BWD_BATCH = 240;  // staged splats per batch: keeps the workgroup at <= 40 KiB of LDS (4 workgroups per CU)
 // Per-splat gradient record.  The cross-product chain of z = h_u x h_v is NOT differentiated per pixel: the record
 // accumulates the moments of v_z about the splat's own centre,
 //     V0 = sum v_z,   Vx = sum (p_x - mean2d.x) v_z,   Vy = sum (p_y - mean2d.y) v_z,
@@ -30,452 +27,11 @@ static constexpr int BWD_BATCH = 240;  // staged splats per batch: keeps the wor
 // dL/dM_u, dL/dM_v, dL/dM_w once per splat.
 // slots: 0-2 v_rgb, 3-5 v_normal, 6 v_opacity, 7-9 V0, 10-12 Vx, 13-15 Vy, 16-18 direct dL/dM_w of the depth (both branches in
 //        18), 19-20 v_means2d ; v_means2d_abs lives in a second record array (only with absgrad)
-template <bool ABSGRAD>
-struct BwdLds {
-  SplatBatchT<BWD_BATCH, true> s;
-  float acc[BWD_BATCH][NACC];  // one 80-byte record per staged splat
-  float acc_abs[ABSGRAD ? BWD_BATCH : 1][2];
-  int bin_final_max;
-};
-
-// Adds the LDS records of this wave's 64 staged splats to the global record array and clears them.
-// Three splats per instruction: lane = 20*j + k -> field k of splat slot 3*it + j.
-template <bool ABSGRAD>
-__device__ __forceinline__ void flush_records(BwdLds<ABSGRAD> &lds, int wave, int lane, int g_mine, float *__restrict__ grec,
-                                              float *__restrict__ grec_abs) {
-  if (ABSGRAD) {
-    const int slot = wave * 64 + lane;
-    if (g_mine >= 0 && slot < BWD_BATCH) {
-#pragma unroll
-      for (int k = 0; k < 2; ++k) {
-        const float v = lds.acc_abs[slot][k];
-        if (v != 0.f) { lds.acc_abs[slot][k] = 0.f; atomicAdd(grec_abs + 2 * (int64_t)g_mine + k, v); }
-      }
-    }
-  }
-  const int j = lane / NACC, k = lane - j * NACC;
-#pragma unroll 2
-  for (int it = 0; it < 22; ++it) {
-    const int slot = 3 * it + j;                     // 0..65
-    const int g = __shfl(g_mine, slot & 63, 64);
-    if (j < 3 && slot < 64 && wave * 64 + slot < BWD_BATCH && g >= 0) {
-      float *a = &lds.acc[wave * 64 + slot][k];
-      const float v = *a;
-      if (v != 0.f) {
-        *a = 0.f;
-        atomicAdd(grec + (int64_t)g * NACC + k, v);
-      }
-    }
-  }
-}
 
 __device__ __forceinline__ void lds_add(float *p, float v) { atomicAdd(p, v); }
 
-// COUNT: diagnostic instantiation (gsdf_rasterize_2dgs_bwd_instr with counters): counters[4] += (wave, splat) visits, [5] += lanes of those visits whose
-// pixel replays the splat's list position, [6] += lanes that blended the pair (pass the alpha test again).
-template <bool ABSGRAD, bool COUNT = false>
-__global__ void __launch_bounds__(RT)
-    raster_bwd_kernel(int n_xcd, int64_t total_tiles, int64_t n_tiles, int64_t I, int W, int H, int tw,
-                      const float *__restrict__ means2d, const float *__restrict__ ray_transforms,
-                      const float *__restrict__ colors, const float *__restrict__ opacities,
-                      const float *__restrict__ normals, const float *__restrict__ backgrounds,
-                      const uint8_t *__restrict__ masks, const int32_t *__restrict__ isect_offsets,
-                      const int32_t *__restrict__ flatten_ids, const float *__restrict__ render_alphas,
-                      const int32_t *__restrict__ last_ids, const int32_t *__restrict__ median_ids,
-                      const float *__restrict__ v_render_colors, const float *__restrict__ v_render_depths,
-                      const float *__restrict__ v_render_alphas, const float *__restrict__ v_render_normals,
-                      const float *__restrict__ v_render_median, float *__restrict__ grec,
-                      float *__restrict__ grec_abs, const float *__restrict__ final_T, unsigned long long *__restrict__ counters = nullptr) {
-  __shared__ BwdLds<ABSGRAD> lds;
-  unsigned long long c_visit = 0, c_live = 0, c_valid = 0;
-  const int64_t tile = xcd_tile_index(total_tiles, n_xcd);
-  if (tile >= total_tiles) return;
-  if (masks != nullptr && !masks[tile]) return;
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int64_t cam = tile / n_tiles;
-  const int tl = (int)(tile - cam * n_tiles);
-  const int ty = tl / tw, tx = tl - ty * tw;
-  const int x = tx * TILE + (wave & 1) * 8 + (lane & 7);
-  const int y = ty * TILE + (wave >> 1) * 8 + (lane >> 3);
-  const bool inside = x < W && y < H;
-  const int64_t pid = (cam * H + y) * (int64_t)W + x;
-  const float px = (float)x + 0.5f, py = (float)y + 0.5f;
-  const float lx = (float)((wave & 1) * 8 + (lane & 7)), ly = (float)((wave >> 1) * 8 + (lane >> 3));
-  const int sub_bit = 4 * wave + 2 * ((lane >> 5) & 1) + ((lane >> 2) & 1);   // this pixel's 4x4 sub-block in SplatBatchT::m16 (8x8 row-major lanes)
-
-  const int32_t start = isect_offsets[tile];
-  const int32_t end = (tile == total_tiles - 1) ? (int32_t)I : isect_offsets[tile + 1];
-  if (end <= start) return;
-
-  float T_final = 1.0f, vCr = 0.f, vCg = 0.f, vCb = 0.f, vNx = 0.f, vNy = 0.f, vNz = 0.f, vD = 0.f, vA = 0.f,
-        vMed = 0.f;
-  int32_t bin_final = -1, med_idx = -1;
-  if (inside) {
-    T_final = final_T != nullptr ? final_T[pid] : 1.0f - render_alphas[pid];
-    // last_ids == 0 with no contributor is harmless: the replay re-tests every pair
-    bin_final = last_ids[pid];
-    med_idx = median_ids[pid];
-    vCr = v_render_colors[3 * pid]; vCg = v_render_colors[3 * pid + 1]; vCb = v_render_colors[3 * pid + 2];
-    vNx = v_render_normals[3 * pid]; vNy = v_render_normals[3 * pid + 1]; vNz = v_render_normals[3 * pid + 2];
-    vD = v_render_depths[pid]; vA = v_render_alphas[pid]; vMed = v_render_median[pid];
-  }
-  float bgdot = 0.f;
-  if (backgrounds != nullptr)
-    bgdot = backgrounds[3 * cam] * vCr + backgrounds[3 * cam + 1] * vCg + backgrounds[3 * cam + 2] * vCb;
-  float T = T_final;
-  float bCr = 0.f, bCg = 0.f, bCb = 0.f, bNx = 0.f, bNy = 0.f, bNz = 0.f, bD = 0.f;
-
-  if (tid == 0) lds.bin_final_max = -1;
-  if (tid < BWD_BATCH) {
-#pragma unroll
-    for (int k = 0; k < NACC; ++k) lds.acc[tid][k] = 0.f;
-    if (ABSGRAD) { lds.acc_abs[tid][0] = 0.f; lds.acc_abs[tid][1] = 0.f; }
-  }
-  __syncthreads();
-  {  // tile-wide and wave-wide last contributor
-    int m = bin_final;
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) m = max(m, __shfl_xor(m, d, 64));
-    if (lane == 0) atomicMax(&lds.bin_final_max, m);
-  }
-  int wave_bin_final = bin_final;
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) wave_bin_final = max(wave_bin_final, __shfl_xor(wave_bin_final, d, 64));
-  __syncthreads();
-  const int tile_bin_final = lds.bin_final_max;
-  if (tile_bin_final < start) return;
-
-  int g_mine = -1;
-  const int nb = (min(end, tile_bin_final + 1) - start + BWD_BATCH - 1) / BWD_BATCH;
-  for (int b = nb - 1; b >= 0; --b) {
-    __syncthreads();  // barrier A: previous batch fully consumed, its accumulators complete
-    flush_records<ABSGRAD>(lds, wave, lane, g_mine, grec, grec_abs);  // wave w owns slots [64w, 64w+64)
-    g_mine = -1;
-    const int32_t bstart = start + b * BWD_BATCH;
-    const int32_t idx = bstart + tid;
-    if (tid < BWD_BATCH && idx < end && idx <= tile_bin_final) {
-      g_mine = flatten_ids[idx];
-      stage_splat(lds.s, tid, g_mine, means2d, ray_transforms, colors, opacities, normals, (float)(tx * TILE),
-                  (float)(ty * TILE));
-    }
-    __syncthreads();  // barrier B
-    const int count = min(BWD_BATCH, min(end, tile_bin_final + 1) - bstart);
-    // per-wave compaction (see raster_common.h quadrant_mask), back-to-front
-    const int wcount = min(count, wave_bin_final - bstart + 1);
-    for (int c0 = ((wcount - 1) >> 6) << 6; c0 >= 0 && wcount > 0; c0 -= 64) {
-      const int ti = c0 + lane;
-      unsigned long long todo = __ballot(ti < wcount && ((lds.s.m16[ti < BWD_BATCH ? ti : 0] >> (4 * wave)) & 0xFu));
-      while (todo) {
-      const int hb = 63 - __builtin_clzll(todo);
-      todo &= ~(1ull << hb);
-      const int t = c0 + hb;
-      const float4 a0 = lds.s.q0[t], a1 = lds.s.q1[t], a2 = lds.s.q2[t], a3 = lds.s.q3[t];
-      PairEval e;
-      const float mwx = a3.x, mwy = lds.s.extra[t];
-      eval_pair<true>(lx, ly, px, py, a0, a1, a2, mwx, a3.y, e, mwy);
-      const bool valid = inside && (bstart + t <= bin_final) && e.ok && ((lds.s.m16[t] >> sub_bit) & 1u);   // as the forward
-      if (COUNT) { c_visit += 1; c_live += __popcll(__ballot(inside && (bstart + t <= bin_final))); c_valid += __popcll(__ballot(valid)); }
-      if (__ballot(valid) == 0ull) continue;
-      const float4 a4 = lds.s.q4[t];
-      const float cR = a3.z, cG = a3.w, cB = a4.x, nX = a4.y, nY = a4.z, nZ = a4.w;
-      float g_rgb0 = 0.f, g_rgb1 = 0.f, g_rgb2 = 0.f, g_n0 = 0.f, g_n1 = 0.f, g_n2 = 0.f, g_op = 0.f;
-      float vzx = 0.f, vzy = 0.f, vzz = 0.f, g_dx = 0.f, g_dy = 0.f, g_mwz = 0.f, g_x = 0.f, g_y = 0.f;
-      bool v2 = false;
-      if (valid) {
-        const float ra = 1.0f / (1.0f - e.alpha);
-        T *= ra;
-        const float fac = e.alpha * T;
-        g_rgb0 = fac * vCr; g_rgb1 = fac * vCg; g_rgb2 = fac * vCb;
-        g_n0 = fac * vNx; g_n1 = fac * vNy; g_n2 = fac * vNz;
-        float v_alpha = (cR * T - bCr * ra) * vCr + (cG * T - bCg * ra) * vCg + (cB * T - bCb * ra) * vCb;
-        v_alpha += (nX * T - bNx * ra) * vNx + (nY * T - bNy * ra) * vNy + (nZ * T - bNz * ra) * vNz;
-        v_alpha += (e.dep * T - bD * ra) * vD;
-        v_alpha += T_final * ra * (vA - bgdot);
-        const float v_dep = fac * vD + ((bstart + t) == med_idx ? vMed : 0.f);
-        bCr += cR * fac; bCg += cG * fac; bCb += cB * fac;
-        bNx += nX * fac; bNy += nY * fac; bNz += nZ * fac;
-        bD += e.dep * fac;
-        float v_sigma = 0.f;
-        if (!e.clamped) {
-          g_op = e.vis * v_alpha;
-          v_sigma = -a2.w * e.vis * v_alpha;
-        }
-        g_mwz = v_dep;
-        if (e.b3) {
-          // sigma = (s.s) / 2, dep = s . M_w.xy + M_w.z with s = z.xy / z.z:  v_s = v_sigma s + v_dep M_w.xy
-          vzx = fmaf(v_sigma, e.sx, v_dep * mwx) * e.inv;
-          vzy = fmaf(v_sigma, e.sy, v_dep * mwy) * e.inv;
-          vzz = -(vzx * e.sx + vzy * e.sy);
-          g_dx = v_dep * e.sx; g_dy = v_dep * e.sy;
-        } else {
-          v2 = true;
-          g_x = v_sigma * FILTER_INV_SQUARE * e.dx;
-          g_y = v_sigma * FILTER_INV_SQUARE * e.dy;
-        }
-      }
-      const bool any2 = __ballot(v2) != 0ull;
-      float r;
-      {  // slots 0..15 (rgb, normal, opacity, V0, Vx, Vy): one transposing butterfly, one ds_add per lane
-        const float mxp = -e.dx, myp = -e.dy;  // pixel offset from the splat centre
-        const float v16[16] = {g_rgb0, g_rgb1, g_rgb2, g_n0, g_n1, g_n2, g_op, vzx, vzy, vzz,
-                               mxp * vzx, mxp * vzy, mxp * vzz, myp * vzx, myp * vzy, myp * vzz};
-        r = row_transpose_reduce16(v16, lane);
-        if (r != 0.f) lds_add(&lds.acc[t][row_transpose_index(lane)], r);  // 4 rows -> 4-way add on one address
-      }
-#define RED(slot, val)                                   \
-  r = wave_sum_to_lane63(val);                           \
-  if (lane == 63 && r != 0.f) lds_add(&lds.acc[t][slot], r)
-      {  // slots 16..18 (direct dL/dM_w of the depth): 4-value butterfly, lanes 12..15 of each row hold the row sums
-        const float v4[4] = {g_dx, g_dy, g_mwz, 0.f};
-        r = row_transpose_reduce4(v4, lane);
-        if ((lane & 12) == 12 && r != 0.f) lds_add(&lds.acc[t][16 + row_transpose_index4(lane)], r);
-      }
-      if (any2) {  // screen-space low-pass branch (rare): v_means2d (+abs)
-        RED(19, g_x); RED(20, g_y);
-        if (ABSGRAD) {
-          r = wave_sum_to_lane63(fabsf(g_x)); if (lane == 63 && r != 0.f) lds_add(&lds.acc_abs[t][0], r);
-          r = wave_sum_to_lane63(fabsf(g_y)); if (lane == 63 && r != 0.f) lds_add(&lds.acc_abs[t][1], r);
-        }
-      }
-#undef RED
-      }
-    }
-  }
-  __syncthreads();
-  flush_records<ABSGRAD>(lds, wave, lane, g_mine, grec, grec_abs);
-  if (COUNT && lane == 0) { atomicAdd(counters + 4, c_visit); atomicAdd(counters + 5, c_live); atomicAdd(counters + 6, c_valid); }
-}
-
 // ---------------------------------------------------------------------------------------------------------------------------------------
-// Round 4: ROW LISTS (see raster_fwd.hip).  Every 16-lane DPP row of a wave owns a 4x4-pixel sub-block and replays ITS OWN list of the
-// staged splats that reach those pixels (and that lie at or before the row's last contributor), back to front; one iteration differentiates
-// up to four different splats.  The reductions were row-local already (row_transpose_reduce16 / _reduce4 sum over a DPP row and the four
-// rows met in a 4-way ds_add on one address): now each row adds into the record of its own splat.
-// ---------------------------------------------------------------------------------------------------------------------------------------
-static constexpr int BWD_ROWS_BATCH = 216;   // 186 B of LDS per staged splat (194 with the absgrad accumulators) -> <= 40 KiB per workgroup without absgrad
-                                             // (4 workgroups per CU), 42 KiB with it (3 per CU: the launch bound below says so)
-template <bool ABSGRAD>
-struct BwdRowsLds {
-  SplatBatchT<BWD_ROWS_BATCH, true> s;
-  float acc[BWD_ROWS_BATCH][NACC];
-  float acc_abs[ABSGRAD ? BWD_ROWS_BATCH : 1][2];
-  unsigned char list[16][BWD_ROWS_BATCH];
-  int bin_final_max;
-};
-
-static_assert(sizeof(BwdRowsLds<false>) <= 40960, "raster_bwd_rows: 4 workgroups per CU need <= 40 KiB of LDS each");
-static_assert(sizeof(BwdRowsLds<true>) <= 53248, "raster_bwd_rows (absgrad): 3 workgroups per CU need <= 52 KiB of LDS each");
-
-template <bool ABSGRAD>
-__device__ __forceinline__ void flush_records_rows(BwdRowsLds<ABSGRAD> &lds, int wave, int lane, int g_mine, float *__restrict__ grec,
-                                                   float *__restrict__ grec_abs) {
-  if (ABSGRAD) {
-    const int slot = wave * 64 + lane;
-    if (g_mine >= 0 && slot < BWD_ROWS_BATCH) {
-#pragma unroll
-      for (int k = 0; k < 2; ++k) {
-        const float v = lds.acc_abs[slot][k];
-        if (v != 0.f) { lds.acc_abs[slot][k] = 0.f; atomicAdd(grec_abs + 2 * (int64_t)g_mine + k, v); }
-      }
-    }
-  }
-  const int j = lane / NACC, k = lane - j * NACC;
-#pragma unroll 2
-  for (int it = 0; it < 22; ++it) {
-    const int slot = 3 * it + j;
-    const int g = __shfl(g_mine, slot & 63, 64);
-    if (j < 3 && slot < 64 && wave * 64 + slot < BWD_ROWS_BATCH && g >= 0) {
-      float *a = &lds.acc[wave * 64 + slot][k];
-      const float v = *a;
-      if (v != 0.f) {
-        *a = 0.f;
-        atomicAdd(grec + (int64_t)g * NACC + k, v);
-      }
-    }
-  }
-}
-
-template <bool ABSGRAD, bool COUNT = false>
-__global__ void __launch_bounds__(RT, ABSGRAD ? 3 : 4)
-    raster_bwd_rows_kernel(int n_xcd, int64_t total_tiles, int64_t n_tiles, int64_t I, int W, int H, int tw,
-                           const float *__restrict__ means2d, const float *__restrict__ ray_transforms,
-                           const float *__restrict__ colors, const float *__restrict__ opacities,
-                           const float *__restrict__ normals, const float *__restrict__ backgrounds,
-                           const uint8_t *__restrict__ masks, const int32_t *__restrict__ isect_offsets,
-                           const int32_t *__restrict__ flatten_ids, const float *__restrict__ render_alphas,
-                           const int32_t *__restrict__ last_ids, const int32_t *__restrict__ median_ids,
-                           const float *__restrict__ v_render_colors, const float *__restrict__ v_render_depths,
-                           const float *__restrict__ v_render_alphas, const float *__restrict__ v_render_normals,
-                           const float *__restrict__ v_render_median, float *__restrict__ grec,
-                           float *__restrict__ grec_abs, const float *__restrict__ final_T, unsigned long long *__restrict__ counters = nullptr) {
-  __shared__ BwdRowsLds<ABSGRAD> lds;
-  unsigned long long c_visit = 0, c_live = 0, c_valid = 0;
-  const int64_t tile = xcd_tile_index(total_tiles, n_xcd);
-  if (tile >= total_tiles) return;
-  if (masks != nullptr && !masks[tile]) return;
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, row = lane >> 4;
-  const int64_t cam = tile / n_tiles;
-  const int tl = (int)(tile - cam * n_tiles);
-  const int ty = tl / tw, tx = tl - ty * tw;
-  int plx, ply;
-  row_pixel(wave, lane, plx, ply);
-  const int x = tx * TILE + plx, y = ty * TILE + ply;
-  const bool inside = x < W && y < H;
-  const int64_t pid = (cam * H + y) * (int64_t)W + x;
-  const float px = (float)x + 0.5f, py = (float)y + 0.5f;
-
-  const int32_t start = isect_offsets[tile];
-  const int32_t end = (tile == total_tiles - 1) ? (int32_t)I : isect_offsets[tile + 1];
-  if (end <= start) return;
-
-  float T_final = 1.0f, vCr = 0.f, vCg = 0.f, vCb = 0.f, vNx = 0.f, vNy = 0.f, vNz = 0.f, vD = 0.f, vA = 0.f, vMed = 0.f;
-  int32_t bin_final = -1, med_idx = -1;
-  if (inside) {
-    T_final = final_T != nullptr ? final_T[pid] : 1.0f - render_alphas[pid];
-    bin_final = last_ids[pid];
-    med_idx = median_ids[pid];
-    vCr = v_render_colors[3 * pid]; vCg = v_render_colors[3 * pid + 1]; vCb = v_render_colors[3 * pid + 2];
-    vNx = v_render_normals[3 * pid]; vNy = v_render_normals[3 * pid + 1]; vNz = v_render_normals[3 * pid + 2];
-    vD = v_render_depths[pid]; vA = v_render_alphas[pid]; vMed = v_render_median[pid];
-  }
-  float bgdot = 0.f;
-  if (backgrounds != nullptr)
-    bgdot = backgrounds[3 * cam] * vCr + backgrounds[3 * cam + 1] * vCg + backgrounds[3 * cam + 2] * vCb;
-  float T = T_final;
-  float bCr = 0.f, bCg = 0.f, bCb = 0.f, bNx = 0.f, bNy = 0.f, bNz = 0.f, bD = 0.f;
-
-  if (tid == 0) lds.bin_final_max = -1;
-  if (tid < BWD_ROWS_BATCH) {
-#pragma unroll
-    for (int k = 0; k < NACC; ++k) lds.acc[tid][k] = 0.f;
-    if (ABSGRAD) { lds.acc_abs[tid][0] = 0.f; lds.acc_abs[tid][1] = 0.f; }
-  }
-  __syncthreads();
-  // last contributor of the row (16 lanes), of the wave, of the tile
-  int row_bin_final = bin_final;
-#pragma unroll
-  for (int d = 8; d >= 1; d >>= 1) row_bin_final = max(row_bin_final, __shfl_xor(row_bin_final, d, 64));
-  int wave_bin_final = max(row_bin_final, __shfl_xor(row_bin_final, 16, 64));
-  wave_bin_final = max(wave_bin_final, __shfl_xor(wave_bin_final, 32, 64));
-  if (lane == 0) atomicMax(&lds.bin_final_max, wave_bin_final);
-  const int rbf0 = __shfl(row_bin_final, 0, 64), rbf1 = __shfl(row_bin_final, 16, 64), rbf2 = __shfl(row_bin_final, 32, 64),
-            rbf3 = __shfl(row_bin_final, 48, 64);
-  __syncthreads();
-  const int tile_bin_final = lds.bin_final_max;
-  if (tile_bin_final < start) return;
-  unsigned char *my_list = lds.list[wave * 4 + row];
-
-  int g_mine = -1;
-  const int nb = (min(end, tile_bin_final + 1) - start + BWD_ROWS_BATCH - 1) / BWD_ROWS_BATCH;
-  for (int b = nb - 1; b >= 0; --b) {
-    __syncthreads();  // barrier A: previous batch fully consumed, its accumulators complete
-    flush_records_rows<ABSGRAD>(lds, wave, lane, g_mine, grec, grec_abs);  // wave w owns slots [64w, 64w+64)
-    g_mine = -1;
-    const int32_t bstart = start + b * BWD_ROWS_BATCH;
-    const int32_t idx = bstart + tid;
-    if (tid < BWD_ROWS_BATCH && idx < end && idx <= tile_bin_final) {
-      g_mine = flatten_ids[idx];
-      stage_splat(lds.s, tid, g_mine, means2d, ray_transforms, colors, opacities, normals, (float)(tx * TILE), (float)(ty * TILE));
-    }
-    __syncthreads();  // barrier B
-    const int count = min(BWD_ROWS_BATCH, min(end, tile_bin_final + 1) - bstart);
-    const int wcount = min(count, wave_bin_final - bstart + 1);
-    if (wcount <= 0) continue;
-    // ---- the four row lists of this wave: staged splats that reach the row's 4x4 pixels and are not behind its last contributor
-    int n0 = 0, n1 = 0, n2 = 0, n3 = 0;
-    for (int c0 = 0; c0 < wcount; c0 += 64) {
-      const int ti = c0 + lane;
-      const unsigned m = ti < wcount ? (unsigned)lds.s.m16[ti] >> (4 * wave) : 0u;
-#define ROW_LIST(r, n, rbf)                                                                                    \
-  {                                                                                                            \
-    const bool bit = ((m >> r) & 1u) && (bstart + ti <= rbf);                                                  \
-    const unsigned long long mk = __ballot(bit);                                                               \
-    if (bit) lds.list[wave * 4 + r][n + __builtin_amdgcn_mbcnt_hi((unsigned)(mk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk, 0u))] = (unsigned char)ti; \
-    n += (int)__popcll(mk);                                                                                    \
-  }
-      ROW_LIST(0, n0, rbf0) ROW_LIST(1, n1, rbf1) ROW_LIST(2, n2, rbf2) ROW_LIST(3, n3, rbf3)
-#undef ROW_LIST
-    }
-    const int n_mine = row == 0 ? n0 : (row == 1 ? n1 : (row == 2 ? n2 : n3));
-    const int kmax = max(max(n0, n1), max(n2, n3));
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    for (int k = 0; k < kmax; ++k) {      // every row walks its own list from the back
-      const bool active = k < n_mine;
-      const int t = active ? (int)my_list[n_mine - 1 - k] : 0;
-      const float4 a0 = lds.s.q0[t], a1 = lds.s.q1[t], a2 = lds.s.q2[t], a3 = lds.s.q3[t];
-      PairEval e;
-      const float mwx = a3.x, mwy = lds.s.extra[t];
-      eval_pair<true>(0.f, 0.f, px, py, a0, a1, a2, mwx, a3.y, e, mwy);
-      const bool valid = active && inside && (bstart + t <= bin_final) && e.ok;
-      if (COUNT) { c_visit += 1; c_live += __popcll(__ballot(active && inside && (bstart + t <= bin_final))); c_valid += __popcll(__ballot(valid)); }
-      if (__ballot(valid) == 0ull) continue;
-      const float4 a4 = lds.s.q4[t];
-      const float cR = a3.z, cG = a3.w, cB = a4.x, nX = a4.y, nY = a4.z, nZ = a4.w;
-      float g_rgb0 = 0.f, g_rgb1 = 0.f, g_rgb2 = 0.f, g_n0 = 0.f, g_n1 = 0.f, g_n2 = 0.f, g_op = 0.f;
-      float vzx = 0.f, vzy = 0.f, vzz = 0.f, g_dx = 0.f, g_dy = 0.f, g_mwz = 0.f, g_x = 0.f, g_y = 0.f;
-      bool v2 = false;
-      if (valid) {
-        const float ra = 1.0f / (1.0f - e.alpha);
-        T *= ra;
-        const float fac = e.alpha * T;
-        g_rgb0 = fac * vCr; g_rgb1 = fac * vCg; g_rgb2 = fac * vCb;
-        g_n0 = fac * vNx; g_n1 = fac * vNy; g_n2 = fac * vNz;
-        float v_alpha = (cR * T - bCr * ra) * vCr + (cG * T - bCg * ra) * vCg + (cB * T - bCb * ra) * vCb;
-        v_alpha += (nX * T - bNx * ra) * vNx + (nY * T - bNy * ra) * vNy + (nZ * T - bNz * ra) * vNz;
-        v_alpha += (e.dep * T - bD * ra) * vD;
-        v_alpha += T_final * ra * (vA - bgdot);
-        const float v_dep = fac * vD + ((bstart + t) == med_idx ? vMed : 0.f);
-        bCr += cR * fac; bCg += cG * fac; bCb += cB * fac;
-        bNx += nX * fac; bNy += nY * fac; bNz += nZ * fac;
-        bD += e.dep * fac;
-        float v_sigma = 0.f;
-        if (!e.clamped) {
-          g_op = e.vis * v_alpha;
-          v_sigma = -a2.w * e.vis * v_alpha;
-        }
-        g_mwz = v_dep;
-        if (e.b3) {
-          vzx = fmaf(v_sigma, e.sx, v_dep * mwx) * e.inv;
-          vzy = fmaf(v_sigma, e.sy, v_dep * mwy) * e.inv;
-          vzz = -(vzx * e.sx + vzy * e.sy);
-          g_dx = v_dep * e.sx; g_dy = v_dep * e.sy;
-        } else {
-          v2 = true;
-          g_x = v_sigma * FILTER_INV_SQUARE * e.dx;
-          g_y = v_sigma * FILTER_INV_SQUARE * e.dy;
-        }
-      }
-      const bool any2 = __ballot(v2) != 0ull;
-      float r;
-      {  // slots 0..15: one transposing butterfly over the row, one ds_add per lane into the row's own splat record
-        const float mxp = -e.dx, myp = -e.dy;
-        const float v16[16] = {g_rgb0, g_rgb1, g_rgb2, g_n0, g_n1, g_n2, g_op, vzx, vzy, vzz,
-                               mxp * vzx, mxp * vzy, mxp * vzz, myp * vzx, myp * vzy, myp * vzz};
-        r = row_transpose_reduce16(v16, lane);
-        if (r != 0.f) lds_add(&lds.acc[t][row_transpose_index(lane)], r);
-      }
-      {  // slots 16..18
-        const float v4[4] = {g_dx, g_dy, g_mwz, 0.f};
-        r = row_transpose_reduce4(v4, lane);
-        if ((lane & 12) == 12 && r != 0.f) lds_add(&lds.acc[t][16 + row_transpose_index4(lane)], r);
-      }
-      if (any2) {  // screen-space low-pass branch (rare)
-        r = row_sum_to_lane15(g_x); if ((lane & 15) == 15 && r != 0.f) lds_add(&lds.acc[t][19], r);
-        r = row_sum_to_lane15(g_y); if ((lane & 15) == 15 && r != 0.f) lds_add(&lds.acc[t][20], r);
-        if (ABSGRAD) {
-          r = row_sum_to_lane15(fabsf(g_x)); if ((lane & 15) == 15 && r != 0.f) lds_add(&lds.acc_abs[t][0], r);
-          r = row_sum_to_lane15(fabsf(g_y)); if ((lane & 15) == 15 && r != 0.f) lds_add(&lds.acc_abs[t][1], r);
-        }
-      }
-    }
-  }
-  __syncthreads();
-  flush_records_rows<ABSGRAD>(lds, wave, lane, g_mine, grec, grec_abs);
-  if (COUNT && lane == 0) { atomicAdd(counters + 4, c_visit); atomicAdd(counters + 5, c_live); atomicAdd(counters + 6, c_valid); }
-}
-
-// ---------------------------------------------------------------------------------------------------------------------------------------
-// Round 6: QUAD LISTS (raster_quad.h).  Every lane quad (2x2 pixels) replays its own list of the staged splats (those whose 64-bit reach mask
+// QUAD LISTS (round 6, raster_quad.h).  Every lane quad (2x2 pixels) replays its own list of the staged splats (those whose 64-bit reach mask
 // has the quad's bit and that lie at or before the quad's last contributor), back to front.  The per-pixel gradient terms are reduced over the
 // FOUR lanes of the quad with a transposing butterfly (16 values -> 4 per lane: 36 VALU) and added to the splat's record in LDS.
 // The record is accumulated in DOUBLE: ds_add_f32 retires 0.33 lanes per clock per CU on gfx950 whatever the address pattern
@@ -865,50 +421,25 @@ static int rasterize_bwd_launch(int64_t C, int64_t M, int64_t I, int width, int 
   if (v_means2d_abs) GSDF_HIP(hipMemsetAsync(grec_abs, 0, (size_t)M * 2 * sizeof(float), stream), "rasterize_bwd memset");
   if (I > 0) {
     const int n_xcd = xcd_count(stream);
-#define ARGS n_xcd, total, n_tiles, I, width, height, tw, means2d, ray_transforms, colors, opacities, normals, backgrounds, \
-             masks, isect_offsets, flatten_ids, render_alphas, last_ids, median_ids, v_render_colors,               \
-             v_render_depths, v_render_alphas, v_render_normals, v_render_median, grec, grec_abs, final_T
-    static const int lists_mode = raster_lists_mode();
-    if (lists_mode == 0) {   // quad lists (round 6)
-      if (fwd_ws == nullptr) {   // no forward workspace handed over: run the pack + mask passes into this call's own
-        void *own = (char *)ws + bwd_records_bytes(M);
-        const int rc = raster_pack_launch(M, I, total, n_tiles, tw, means2d, ray_transforms, colors, opacities, normals, isect_offsets, flatten_ids, own, stream);
-        if (rc != GSDF_OK) return rc;
-        fwd_ws = own;
-      }
+    if (fwd_ws == nullptr) {   // no forward workspace handed over: run the pack + mask passes into this call's own
+      void *own = (char *)ws + bwd_records_bytes(M);
+      const int rc = raster_pack_launch(M, I, total, n_tiles, tw, means2d, ray_transforms, colors, opacities, normals, isect_offsets, flatten_ids, own, stream);
+      if (rc != GSDF_OK) return rc;
+      fwd_ws = own;
+    }
 #define QARGS n_xcd, total, n_tiles, I, width, height, tw, (const float4 *)ws_records(fwd_ws), ws_masks(fwd_ws, M), backgrounds, masks, isect_offsets, \
               flatten_ids, render_alphas, last_ids, median_ids, v_render_colors, v_render_depths, v_render_alphas, v_render_normals,               \
               v_render_median, grec, grec_abs, final_T
-      if (counters != nullptr && v_means2d_abs)
-        raster_bwd_quads_kernel<true, true><<<xcd_grid(total, n_xcd), RT, 0, stream>>>(QARGS, counters);
-      else if (counters != nullptr)
-        raster_bwd_quads_kernel<false, true><<<xcd_grid(total, n_xcd), RT, 0, stream>>>(QARGS, counters);
-      else if (v_means2d_abs)
-        raster_bwd_quads_kernel<true><<<xcd_grid(total, n_xcd), RT, 0, stream>>>(QARGS);
-      else
-        raster_bwd_quads_kernel<false><<<xcd_grid(total, n_xcd), RT, 0, stream>>>(QARGS);
+    if (counters != nullptr && v_means2d_abs)
+      raster_bwd_quads_kernel<true, true><<<xcd_grid(total, n_xcd), RT, 0, stream>>>(QARGS, counters);
+    else if (counters != nullptr)
+      raster_bwd_quads_kernel<false, true><<<xcd_grid(total, n_xcd), RT, 0, stream>>>(QARGS, counters);
+    else if (v_means2d_abs)
+      raster_bwd_quads_kernel<true><<<xcd_grid(total, n_xcd), RT, 0, stream>>>(QARGS);
+    else
+      raster_bwd_quads_kernel<false><<<xcd_grid(total, n_xcd), RT, 0, stream>>>(QARGS);
 #undef QARGS
-    } else if (lists_mode == 2) {
-      if (counters != nullptr && v_means2d_abs)
-        raster_bwd_kernel<true, true><<<xcd_grid(total, n_xcd), RT, 0, stream>>>(ARGS, counters);
-      else if (counters != nullptr)
-        raster_bwd_kernel<false, true><<<xcd_grid(total, n_xcd), RT, 0, stream>>>(ARGS, counters);
-      else if (v_means2d_abs)
-        raster_bwd_kernel<true><<<xcd_grid(total, n_xcd), RT, 0, stream>>>(ARGS);
-      else
-        raster_bwd_kernel<false><<<xcd_grid(total, n_xcd), RT, 0, stream>>>(ARGS);
-    } else {
-      if (counters != nullptr && v_means2d_abs)
-        raster_bwd_rows_kernel<true, true><<<xcd_grid(total, n_xcd), RT, 0, stream>>>(ARGS, counters);
-      else if (counters != nullptr)
-        raster_bwd_rows_kernel<false, true><<<xcd_grid(total, n_xcd), RT, 0, stream>>>(ARGS, counters);
-      else if (v_means2d_abs)
-        raster_bwd_rows_kernel<true><<<xcd_grid(total, n_xcd), RT, 0, stream>>>(ARGS);
-      else
-        raster_bwd_rows_kernel<false><<<xcd_grid(total, n_xcd), RT, 0, stream>>>(ARGS);
-    }
-#undef ARGS
-    GSDF_CHECK_LAUNCH("raster_bwd_kernel");
+    GSDF_CHECK_LAUNCH("raster_bwd_quads_kernel");
   }
   unpack_records_kernel<<<(unsigned)((M + 255) / 256), 256, 0, stream>>>(M, grec, grec_abs, means2d, ray_transforms, v_means2d,
                                                                        v_ray_transforms, v_colors, v_opacities,

@@ -120,12 +120,6 @@ static inline const float *ws_records(const void *ws) { return (const float *)ws
 static inline const unsigned long long *ws_masks(const void *ws, int64_t M) {
   return (const unsigned long long *)((const char *)ws + align_up((size_t)(M > 0 ? M : 1) * REC_F * sizeof(float), 256));
 }
-// TEMPORARY A/B switch of round 6: GSDF_RASTER_LISTS = quads (default) | rows | quadrants
-static inline int raster_lists_mode() {
-  const char *e = getenv("GSDF_RASTER_LISTS");
-  if (e == nullptr) return 0;
-  return e[0] == 'r' ? 1 : (e[0] == 'q' && e[3] == 'd' && e[4] == 'r' ? 2 : 0);
-}
 // pack + mask passes (raster_pack.hip)
 int raster_pack_launch(int64_t M, int64_t I, int64_t total_tiles, int64_t n_tiles, int tw, const float *means2d, const float *ray_transforms,
                        const float *colors, const float *opacities, const float *normals, const int32_t *isect_offsets,

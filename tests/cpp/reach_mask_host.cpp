@@ -5,13 +5,6 @@
 
 #include "reach_mask.h"
 
-extern "C" void reach_masks4x4(int64_t n, const float *ray_transforms /* [n, 9] */, const float *means2d /* [n, 2] */, const float *opacities,
-                               const float *tile_xy0 /* [n, 2] */, uint16_t *masks) {
-  for (int64_t i = 0; i < n; ++i)
-    masks[i] = (uint16_t)gsdf::subblock_mask4x4(ray_transforms + 9 * i, means2d[2 * i], means2d[2 * i + 1], opacities[i], tile_xy0[2 * i],
-                                                tile_xy0[2 * i + 1]);
-}
-
 // Round 6: the 2x2 mask (bit 8 by + bx) from the per-splat parameters, as the pack + mask passes of the compositing kernels compute it.
 extern "C" void reach_masks2x2(int64_t n, const float *ray_transforms /* [n, 9] */, const float *means2d /* [n, 2] */, const float *opacities,
                                const float *tile_xy0 /* [n, 2] */, uint64_t *masks) {

@@ -1,6 +1,7 @@
-"""The 4x4 reach mask of the compositing kernels (gs-sdf_amd/csrc/reach_mask.h: dual-conic box cut by the strip across the ellipse's minor axis)
-decides which 16-lane rows evaluate a (tile, splat) pair at all — in the forward AND the backward — so it must never clear the bit of a sub-block
-that holds a pixel the alpha test would keep.  The GPU parity tests see that through the decision-matched gate; here the product's own source is
+"""The 2x2 reach mask of the compositing kernels (gs-sdf_amd/csrc/reach_mask.h: reach_params once per splat + reach_mask2x2 once per (tile,
+splat) pair: exact pixel-row intervals of the alpha >= 1/255 ellipse and of the low-pass disk, grown by a safety margin) decides which lane
+quads evaluate a (tile, splat) pair at all — in the forward AND the backward — so it must never clear the bit of a 2x2 block that holds a pixel
+the alpha test would keep.  The GPU parity tests see that through the decision-matched gate; here the product's own source is
 compiled for the host and checked directly, on splats made to stress it: elongated (aspect up to 300), oblique, grazing, tiny, huge, near the
 screen border, every opacity.  Brute force in fp64 with the reference's alpha test (z = (x M_w - M_u) x (y M_w - M_v), s = z.xy / z.z,
 sigma = min(|s|^2, 2 |p - mean2d|^2) / 2, alpha = min(0.999, o e^-sigma) >= 1/255)."""
@@ -23,7 +24,7 @@ def mask_lib(tmp_path_factory):
     subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-ffp-contract=off", "-I", os.path.join(ROOT, "gs-sdf_amd", "csrc"),
                            os.path.join(ROOT, "tests", "cpp", "reach_mask_host.cpp"), "-o", str(out)])
     lib = C.CDLL(str(out))
-    lib.reach_masks4x4.restype = None
+    lib.reach_masks2x2.restype = None
     return lib
 
 
@@ -79,9 +80,9 @@ def test_no_kept_pixel_outside_the_mask(mask_lib, kind):
     assert P > 2 * M // 3
     idx = pairs[:, 0]
     txy = (pairs[:, 1:3] * 16).astype(np.float32)
-    masks = np.zeros(P, np.uint16)
+    masks = np.zeros(P, np.uint64)
     a = [np.ascontiguousarray(v) for v in (rt[idx].reshape(P, 9), m2d[idx], opac[idx], txy)]
-    mask_lib.reach_masks4x4(C.c_int64(P), *(v.ctypes.data_as(C.c_void_p) for v in a), masks.ctypes.data_as(C.c_void_p))
+    mask_lib.reach_masks2x2(C.c_int64(P), *(v.ctypes.data_as(C.c_void_p) for v in a), masks.ctypes.data_as(C.c_void_p))
     # brute force, fp64: the 256 pixel centres of every pair
     px = np.arange(16)[None, :] + 0.5
     X = (txy[:, 0:1].astype(np.float64) + px)[:, None, :].repeat(16, 1)          # [P, y, x]
@@ -97,18 +98,16 @@ def test_no_kept_pixel_outside_the_mask(mask_lib, kind):
     sigma = 0.5 * np.where(np.isfinite(g3), np.minimum(g3, g2), g2)
     alpha = np.minimum(0.999, opac[idx].astype(np.float64)[:, None, None] * np.exp(-sigma))
     keep = (z[..., 2] != 0) & (alpha >= 1.0 / 255.0) & (X < W) & (Y < H)
-    # sub-block bit of a pixel: quadrant q = 2 (y >> 3) + (x >> 3), sub-block s = 2 (y >> 2 & 1) + (x >> 2 & 1)
+    # block bit of a pixel: 8 (y >> 1) + (x >> 1)
     yy, xx = np.meshgrid(np.arange(16), np.arange(16), indexing="ij")
-    bit = 4 * (2 * (yy >> 3) + (xx >> 3)) + 2 * ((yy >> 2) & 1) + ((xx >> 2) & 1)
-    allowed = ((masks[:, None, None].astype(np.int64) >> bit[None]) & 1).astype(bool)
+    bit = (8 * (yy >> 1) + (xx >> 1)).astype(np.uint64)
+    allowed = ((masks[:, None, None] >> bit[None]) & np.uint64(1)).astype(bool)
     lost = keep & ~allowed
-    assert not lost.any(), (f"{kind}: {int(lost.sum())} kept pixels of {int(lost.any(axis=(1, 2)).sum())} pairs lie in sub-blocks the mask drops; first: "
+    assert not lost.any(), (f"{kind}: {int(lost.sum())} kept pixels of {int(lost.any(axis=(1, 2)).sum())} pairs lie in blocks the mask drops; first: "
                             f"pair {pairs[np.argmax(lost.any(axis=(1, 2)))]}")
-    # and the mask is worth having: how many of the set bits hold a kept pixel (report only), how many pairs lose bits to the strip
-    blocks_kept = np.zeros((P, 16), bool)
-    for b in range(16):
-        blocks_kept[:, b] = (keep & (bit[None] == b)).any(axis=(1, 2))
-    set_bits = ((masks[:, None].astype(np.int64) >> np.arange(16)[None]) & 1).astype(bool)
+    # and the mask is worth having: how many of the set bits hold a kept pixel
+    blocks_kept = keep.reshape(P, 8, 2, 8, 2).any(axis=(2, 4)).reshape(P, 64)
+    set_bits = ((masks[:, None] >> np.arange(64, dtype=np.uint64)[None]) & np.uint64(1)).astype(bool)
     tight = blocks_kept.sum() / max(set_bits.sum(), 1)
-    print(f"{kind}: {P} pairs, {int(keep.sum())} kept pixels, {int(set_bits.sum())} sub-blocks in the masks, {tight:.2f} of them hold a kept pixel")
+    print(f"{kind}: {P} pairs, {int(keep.sum())} kept pixels, {int(set_bits.sum())} blocks in the masks, {tight:.2f} of them hold a kept pixel")
     assert tight > (0.1 if kind == "grazing" else 0.3)      # edge-on discs: unbounded conics keep the full mask

@@ -1,6 +1,6 @@
 """Round 6: what the 2x2 reach mask (csrc/reach_mask.h: reach_params + reach_mask2x2, host build) gives the quad-list compositing kernels, on a
 cfg3-like scene scaled to 480x272 (RM_WH=W,H for another size, RM_MARGIN for another safety margin) against an fp64 brute force of the alpha test (CPU only; termination not modelled): conservativeness, useful
-lanes of the evaluated ones, wave iterations (max over a wave's 16 quad lists) beside the row-list figures.  python tools/exp_mask2x2.py"""
+lanes of the evaluated ones, wave iterations (max over a wave's 16 quad lists); round 5's row lists on its 4x4 mask: 0.32 useful, 158 856 iterations on the same scene.  python tools/exp_mask2x2.py"""
 import sys, os, ctypes as C, subprocess, numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import gs_sdf_amd.synth as synth
@@ -10,7 +10,7 @@ out = '/tmp/libreach_mask_host.so'
 MARGIN = os.environ.get("RM_MARGIN")
 subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-ffp-contract=off", "-I", ROOT + "/gs-sdf_amd/csrc", ROOT + "/tests/cpp/reach_mask_host.cpp", "-o", out]
                       + ([f"-DGSDF_RM_MARGIN={MARGIN}f"] if MARGIN else []))
-lib = C.CDLL(out); lib.reach_masks4x4.restype = None; lib.reach_masks2x2.restype = None
+lib = C.CDLL(out); lib.reach_masks2x2.restype = None
 W, H = (int(v) for v in os.environ.get("RM_WH", "480,272").split(",")); N = int(1_000_000 * (W * H) / (1920 * 1080))
 sc = synth.make_scene(N, W, H, 0, seed=0)
 n = lambda t: t.detach().numpy()
@@ -25,18 +25,16 @@ idx = np.asarray(flat)
 P = len(idx); print('pairs', P, 'M', len(pr["gaussian_ids"]), 'L', P / T)
 rt = pr["ray_transforms"].astype(np.float32); m2d = pr["means2d"].astype(np.float32); opac = opac_all[pr["gaussian_ids"]].astype(np.float32)
 txy = np.stack([(tile_of % tw) * 16, (tile_of // tw) * 16], 1).astype(np.float32)
-m4 = np.zeros(P, np.uint16); m2 = np.zeros(P, np.uint64)
+m2 = np.zeros(P, np.uint64)
 a = [np.ascontiguousarray(v) for v in (rt[idx].reshape(P, 9), m2d[idx], opac[idx], txy)]
-lib.reach_masks4x4(C.c_int64(P), *(v.ctypes.data_as(C.c_void_p) for v in a), m4.ctypes.data_as(C.c_void_p))
 lib.reach_masks2x2(C.c_int64(P), *(v.ctypes.data_as(C.c_void_p) for v in a), m2.ctypes.data_as(C.c_void_p))
 px = np.arange(16)[None, :] + 0.5
 yy, xx = np.meshgrid(np.arange(16), np.arange(16), indexing='ij')
-bit4 = 4 * (2 * (yy >> 3) + (xx >> 3)) + 2 * ((yy >> 2) & 1) + ((xx >> 2) & 1)
-tot_keep = tot_set4 = tot_set2 = tot_exact2 = lost = 0
-row_len = np.zeros((T, 16), np.int64); quad_len = np.zeros((T, 64), np.int64); quad_len_exact = np.zeros((T, 64), np.int64)
-# quad id inside a wave: wave w = 8x8 quadrant, row r = 4x4 sub-block, qq = 2x2 block inside it
+tot_keep = tot_set2 = tot_exact2 = lost = 0
+quad_len = np.zeros((T, 64), np.int64); quad_len_exact = np.zeros((T, 64), np.int64)
+# quad id inside a wave: wave w = 8x8 quadrant, quad = 2x2 block of it (row-major)
 by, bx = np.meshgrid(np.arange(8), np.arange(8), indexing='ij')
-qid = (16 * (2 * (by >> 2) + (bx >> 2)) + 4 * (2 * ((by >> 1) & 1) + ((bx >> 1) & 1)) + 2 * (by & 1) + (bx & 1)).reshape(-1)
+qid = (16 * (2 * (by >> 2) + (bx >> 2)) + 4 * (by & 3) + (bx & 3)).reshape(-1)
 for s0 in range(0, P, 20000):
     sl = slice(s0, min(P, s0 + 20000)); ii = idx[sl]; t = txy[sl]
     X = (t[:, 0:1].astype(np.float64) + px)[:, None, :].repeat(16, 1); Y = (t[:, 1:2].astype(np.float64) + px)[:, :, None].repeat(16, 2)
@@ -51,16 +49,13 @@ for s0 in range(0, P, 20000):
     keep = (z[..., 2] != 0) & (alpha >= 1 / 255) & (X < W) & (Y < H)
     k22 = keep.reshape(len(ii), 8, 2, 8, 2).any(axis=(2, 4)).reshape(len(ii), 64)
     set2 = ((m2[sl][:, None] >> np.arange(64, dtype=np.uint64)[None]) & np.uint64(1)).astype(bool)     # bit 8 by + bx
-    set4 = ((m4[sl][:, None].astype(np.int64) >> np.arange(16)[None]) & 1).astype(bool)
     lost += int((k22 & ~set2).sum())
-    tot_keep += keep.sum(); tot_set4 += set4.sum(); tot_set2 += set2.sum(); tot_exact2 += k22.sum()
+    tot_keep += keep.sum(); tot_set2 += set2.sum(); tot_exact2 += k22.sum()
     tl = tile_of[sl]
-    np.add.at(row_len, (tl[:, None].repeat(16, 1), np.arange(16)[None].repeat(len(ii), 0)), set4.astype(np.int64))
     np.add.at(quad_len, (tl[:, None].repeat(64, 1), qid[None].repeat(len(ii), 0)), set2.astype(np.int64))
     np.add.at(quad_len_exact, (tl[:, None].repeat(64, 1), qid[None].repeat(len(ii), 0)), k22.astype(np.int64))
 print('kept pixels', tot_keep, '| blocks with a kept pixel the 2x2 mask drops:', lost)
-print('4x4 mask: bits', tot_set4, 'useful lanes', tot_keep / (16 * tot_set4))
 print('2x2 mask: bits', tot_set2, 'useful lanes', tot_keep / (4 * tot_set2), '| exact 2x2:', tot_exact2, tot_keep / (4 * tot_exact2))
-rows_now = row_len.reshape(T, 4, 4).max(axis=2).sum(); quads = quad_len.reshape(T, 4, 16).max(axis=2).sum(); quads_exact = quad_len_exact.reshape(T, 4, 16).max(axis=2).sum()
-print('wave iterations: row lists (4x4 mask)', rows_now, '| quad lists, this 2x2 mask', quads, '| quad lists, exact 2x2', quads_exact)
-print('mean list length per quad', quad_len.mean(), 'per row', row_len.mean(), ' sum of quad entries per tile', quad_len.sum() / T)
+quads = quad_len.reshape(T, 4, 16).max(axis=2).sum(); quads_exact = quad_len_exact.reshape(T, 4, 16).max(axis=2).sum()
+print('wave iterations: quad lists, this 2x2 mask', quads, '| quad lists, exact 2x2', quads_exact)
+print('mean list length per quad', quad_len.mean(), ' sum of quad entries per tile', quad_len.sum() / T)

@@ -28,13 +28,11 @@ meta = dict(flatten_ids=flat, gaussian_ids=gid)
 c = cnt.cpu().tolist()
 I, M, P = int(meta["flatten_ids"].shape[0]), int(meta["gaussian_ids"].shape[0]), W * H
 out = dict(workload=name, M=M, I=I, P=P, staged_tile_splat_pairs=I, all_pairs_without_culling=I * 256,
-           fwd=dict(wave_visits=c[0], lanes_evaluated=c[0] * 64, lanes_live=c[1], lanes_alpha_ok=c[2], lanes_blended=c[3],
-                    visits_kept_by_quadrant_mask=c[0] / (4.0 * I), useful_of_evaluated=c[3] / max(1, c[0] * 64), alpha_ok_of_live=c[2] / max(1, c[1]),
+           fwd=dict(wave_iterations=c[0], lanes_evaluated=c[0] * 64, lanes_live=c[1], lanes_alpha_ok=c[2], lanes_blended=c[3],
+                    useful_of_evaluated=c[3] / max(1, c[0] * 64), alpha_ok_of_live=c[2] / max(1, c[1]),
                     visits_with_no_useful_lane=c[7], fraction_of_visits_with_no_useful_lane=c[7] / max(1, c[0]),
-                    mean_useful_lanes_in_a_useful_visit=c[2] / max(1, c[0] - c[7]),
-                    if_each_16_lane_row_followed_its_own_list=dict(union_visits_all_pixels_live=c[8], iterations_4x4_subblocks=c[9],
-                                                                    iterations_8x2_strips=c[10])),
-           bwd=dict(wave_visits=c[4], lanes_evaluated=c[4] * 64, lanes_replaying=c[5], lanes_blended=c[6],
+                    mean_useful_lanes_in_a_useful_visit=c[2] / max(1, c[0] - c[7])),
+           bwd=dict(wave_iterations=c[4], lanes_evaluated=c[4] * 64, lanes_replaying=c[5], lanes_blended=c[6],
                     useful_of_evaluated=c[6] / max(1, c[4] * 64)))
 print(json.dumps(out, indent=1))
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)

@@ -1,5 +1,6 @@
-"""Round 6: the compositing kernels on lane-quad lists against the row-list kernels of round 5, at a bench workload's shape, each variant in
-its own process (GSDF_RASTER_LISTS = quads | rows, the temporary A/B switch of csrc/raster_quad.h):
+"""Round 6: the compositing kernels (lane-quad lists) at a bench workload's shape, each variant in its own process.  A variant is the product
+library ("quads") or a compile-time variant of it ("quads@<name>", built by tools/build_variants.sh).  profiles/r06_raster_quad_vs_row_lists_cfg3.json
+is this tool's record of the quad kernels against round 5's row-list kernels (forward bit-identical), taken before those were removed:
   * kernel time of gsdf_rasterize_2dgs_fwd / _bwd over REPS launches (HIP events; the quad forward's time includes its pack + mask passes),
   * pair counters of the instrumented instantiations (wave iterations, evaluated / blending lanes),
   * the outputs themselves: the parent compares the forward images bit for bit and the gradients element-wise.
@@ -53,11 +54,10 @@ if len(sys.argv) > 2 and sys.argv[2] == "child":
 import torch
 wl = sys.argv[1] if len(sys.argv) > 1 else "cfg3_1M_1080p"
 out = {}
-VARIANTS = (("quads", {"GSDF_RASTER_LISTS": "quads"}), ("rows", {"GSDF_RASTER_LISTS": "rows"}), ("quads_again", {"GSDF_RASTER_LISTS": "quads"}))
+VARIANTS = (("quads", {}), ("quads_again", {}))
 if os.environ.get("GSDF_EXP_VARIANTS"):
     # "quads", "rows", or "quads@<library variant>"
-    VARIANTS = tuple((v, {"GSDF_RASTER_LISTS": v.split("@")[0].split("_")[0], **({"GSDF_EXP_LIB": v.split("@")[1]} if "@" in v else {})})
-                     for v in os.environ["GSDF_EXP_VARIANTS"].split(";"))
+    VARIANTS = tuple((v, ({"GSDF_EXP_LIB": v.split("@")[1]} if "@" in v else {})) for v in os.environ["GSDF_EXP_VARIANTS"].split(";"))
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
 for name, env in VARIANTS:
     e = dict(os.environ); e.update(env)
@@ -65,8 +65,8 @@ for name, env in VARIANTS:
     out[name] = json.loads(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 else {"error": r.stderr[-3000:]}
     print(name, {k: (round(v, 4) if isinstance(v, float) else v) for k, v in out[name].items() if k.endswith("_ms_median") or k == "error"}, flush=True)
 names = [n for n, _ in VARIANTS if "error" not in out[n]]
-if "quads" in names and "rows" in names:
-    a, b = torch.load("/tmp/raster_quads.pt"), torch.load("/tmp/raster_rows.pt")
+if len(names) >= 2:      # the first two variants' outputs against each other
+    a, b = torch.load(f"/tmp/raster_{names[0].replace('@', '_')}.pt"), torch.load(f"/tmp/raster_{names[1].replace('@', '_')}.pt")
     cmp = {}
     for k in a:
         x, y = a[k], b[k]
@@ -75,6 +75,6 @@ if "quads" in names and "rows" in names:
             cmp[k] = dict(max_abs_diff_over_max=float((x - y).abs().max().item() / den), frac_rel_gt_1e4=float(((x - y).abs() > 1e-4 * y.abs() + 1e-7 * den).float().mean().item()))
         else:
             cmp[k] = dict(bit_identical=bool(torch.equal(x, y)), n_diff=int((x != y).sum().item()))
-    out["quads_vs_rows"] = cmp
+    out[f"{names[0]}_vs_{names[1]}"] = cmp
     print(json.dumps(cmp, indent=1))
 json.dump(out, open(os.path.join(ROOT, "gpurun_out", f"raster_quads_{wl}.json"), "w"), indent=1)

@@ -1,9 +1,8 @@
 #!/bin/bash
 # Run ON THE GPU BOX: kernel stats + counter passes of the compositing kernels alone (tools/exp_raster_quads.py child, cfg3 shape).
-# usage: tools/prof_raster.sh <tag> [lists]      -> gpurun_out/prof_raster_<tag>/
+# usage: tools/prof_raster.sh <tag>      -> gpurun_out/prof_raster_<tag>/
 set -u
 TAG=${1:-r06}
-export GSDF_RASTER_LISTS=${2:-quads}
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/prof_raster_$TAG
 mkdir -p $OUT
