@@ -148,8 +148,10 @@ struct JointConfig {
   // config/base.yaml -> 0): one stochastic point on every visible splat's disc, weight exp(-|eps|^2 / 2) (neural_gaussian.cpp:259-265)
   bool center_reg = true;
   bool two_streams = false;   // the SDF network's work on a second HIP stream beside the splat leg (bench.py's overlapped schedule)
-  int hashgrid_resident = 2;  // two_streams + analytic only: workgroups per CU of the stencil hash-grid forward's RESIDENT grid (gsdf_hashgrid_fwd_stencil_resident):
-                              // its gathers need two waves per SIMD, the rest of every CU stays free for the splat leg's kernels; 0 = the full grid
+  int hashgrid_resident = 3;  // two_streams + analytic only: workgroups per CU of the stencil hash-grid forward's RESIDENT grid (gsdf_hashgrid_fwd_stencil_resident):
+                              // the rest of every CU stays free for the splat leg's kernels; 0 = the full grid.  Round 6 (tools/ab_lib.sh, same box, two runs
+                              // each): 2 -> 4.51 ms per step (hash-grid forward 2.11 ms beside the compositing backward), 3 -> 4.26 (1.62 ms = its time alone:
+                              // three 128-register waves + one 96-register wave of the quad-list backward fill a SIMD's file), 4 -> 4.57, 5 -> 4.48, 6 -> 4.45, 1 -> 5.8
 };
 
 // the refinement policy's configuration: GSConfig's fields (config/base.yaml:60-74) + the scene scale NeuralGS keeps (neural_gaussian.cpp:286-290)
