@@ -198,8 +198,11 @@ struct XcdSlots {
 //     the L1/L2 lines row 0 has just brought in, where the row-major kernel fetched them from the fabric 7 times.
 // The arithmetic of a row is the one of hashgrid_fwd_xcd_kernel (same operations in the same order): bit-identical features.
 // one chunk (4 ppw groups) of one level slot: the work of a (lane quad, chunk)
-template <bool JAC>
-__device__ __forceinline__ void stencil_chunk(int64_t n, const HgLevels &lv, int level, int f, int xb, int64_t g, const float *__restrict__ x,
+// IDX: the integer type of the row / feature offsets.  int32_t when 7 n rows x 16 levels x 2 features x 3 (the Jacobian's floats) stay below
+// 2^31 (any batch of the reference's iteration): the 7 rows' addresses are then one 32-bit offset each against a uniform base instead of
+// 64-bit pairs the compiler hoists out of the resident grid's chunk loop (round 5: 128 registers with 4 of them spilled).
+template <bool JAC, typename IDX>
+__device__ __forceinline__ void stencil_chunk(IDX n, const HgLevels &lv, int level, int f, int xb, IDX g, const float *__restrict__ x,
                                               const float *__restrict__ table, float *__restrict__ feat, float *__restrict__ jac) {
   const float scale = lv.scale[level];
   const uint32_t res = lv.res[level], hsize = lv.hsize[level];
@@ -208,7 +211,7 @@ __device__ __forceinline__ void stencil_chunk(int64_t n, const HgLevels &lv, int
   float fr[7][3];
 #pragma unroll
   for (int r = 0; r < 7; ++r) {
-    const int64_t b = g + (int64_t)r * n;
+    const IDX b = g + (IDX)r * n;
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
       const float pos = fmaf(scale, x[3 * b + d], 0.5f);
@@ -219,7 +222,7 @@ __device__ __forceinline__ void stencil_chunk(int64_t n, const HgLevels &lv, int
   }
   float t[7][4];
 #pragma unroll
-  for (int k = 0; k < 4; ++k) t[0][k] = tb[2 * (int64_t)grid_index(hsize, res, cg[0][0] + xb, cg[0][1] + (k & 1), cg[0][2] + (k >> 1))];
+  for (int k = 0; k < 4; ++k) t[0][k] = tb[2 * grid_index(hsize, res, cg[0][0] + xb, cg[0][1] + (k & 1), cg[0][2] + (k >> 1))];
 #pragma unroll
   for (int r = 1; r < 7; ++r) {
     const bool same = cg[r][0] == cg[0][0] && cg[r][1] == cg[0][1] && cg[r][2] == cg[0][2];
@@ -227,7 +230,7 @@ __device__ __forceinline__ void stencil_chunk(int64_t n, const HgLevels &lv, int
     for (int k = 0; k < 4; ++k) t[r][k] = t[0][k];
     if (!same) {
 #pragma unroll
-      for (int k = 0; k < 4; ++k) t[r][k] = tb[2 * (int64_t)grid_index(hsize, res, cg[r][0] + xb, cg[r][1] + (k & 1), cg[r][2] + (k >> 1))];
+      for (int k = 0; k < 4; ++k) t[r][k] = tb[2 * grid_index(hsize, res, cg[r][0] + xb, cg[r][1] + (k & 1), cg[r][2] + (k >> 1))];
     }
   }
 #pragma unroll
@@ -246,7 +249,7 @@ __device__ __forceinline__ void stencil_chunk(int64_t n, const HgLevels &lv, int
       }
     }
     acc += dpp_mov<0x4E>(acc);
-    const int64_t o = ((g + (int64_t)r * n) * lv.n_levels + level) * 2 + f;
+    const IDX o = ((g + (IDX)r * n) * (IDX)lv.n_levels + (IDX)level) * 2 + (IDX)f;
     if (xb == 0) feat[o] = acc;
     if (JAC && r == 0) {
       jx *= scale; jy *= scale; jz *= scale;
@@ -256,10 +259,11 @@ __device__ __forceinline__ void stencil_chunk(int64_t n, const HgLevels &lv, int
   }
 }
 
-template <bool JAC, bool RESIDENT>
-__global__ void __launch_bounds__(HG_THREADS, 4)   // <= 128 registers: two resident waves per SIMD leave room for two 128-register waves of another kernel
-    hashgrid_fwd_stencil_kernel(int64_t n, HgLevels lv, XcdSlots xl, int n_xcd, int ppw, int64_t chunks, int64_t chunk_stride,
+template <bool JAC, bool RESIDENT, typename IDX>
+__global__ void __launch_bounds__(HG_THREADS, 4)   // <= 128 registers: three resident waves per SIMD leave room for a 96-register wave of another kernel
+    hashgrid_fwd_stencil_kernel(int64_t n_, HgLevels lv, XcdSlots xl, int n_xcd, int ppw, int64_t chunks_, int64_t chunk_stride_,
                                 const float *__restrict__ x, const float *__restrict__ table, float *__restrict__ feat, float *__restrict__ jac) {
+  const IDX n = (IDX)n_, chunks = (IDX)chunks_, chunk_stride = (IDX)chunk_stride_;
   const int xcd = blockIdx.x % n_xcd;
   const int nl = xl.count[xcd];
   const int lane = threadIdx.x & 63;
@@ -269,17 +273,17 @@ __global__ void __launch_bounds__(HG_THREADS, 4)   // <= 128 registers: two resi
   if (!(pw < ppw && ls < nl)) return;  // whole quads leave together: the quad DPP of stencil_chunk stays among live lanes
   const int level = xl.lvl[xcd][ls], mode = xl.mode[xcd][ls];
   if (!RESIDENT) {   // one chunk per workgroup
-    const int64_t chunk = blockIdx.x / n_xcd;
-    const int64_t g = (chunk * 4 + (threadIdx.x >> 6)) * ppw + pw;
+    const IDX chunk = (IDX)(blockIdx.x / n_xcd);
+    const IDX g = (chunk * 4 + (IDX)(threadIdx.x >> 6)) * ppw + pw;
     if (g >= n) return;
     if (mode != 0 && (int)(chunk % (mode >> 4)) != (mode & 15)) return;
-    stencil_chunk<JAC>(n, lv, level, f, xb, g, x, table, feat, jac);
+    stencil_chunk<JAC, IDX>(n, lv, level, f, xb, g, x, table, feat, jac);
   } else {           // a grid of chunk_stride workgroups per XCD that walks the chunks (see launch_fwd_stencil)
-    for (int64_t chunk = blockIdx.x / n_xcd; chunk < chunks; chunk += chunk_stride) {
-      const int64_t g = (chunk * 4 + (threadIdx.x >> 6)) * ppw + pw;
+    for (IDX chunk = (IDX)(blockIdx.x / n_xcd); chunk < chunks; chunk += chunk_stride) {
+      const IDX g = (chunk * 4 + (IDX)(threadIdx.x >> 6)) * ppw + pw;
       if (g >= n) break;
       if (mode != 0 && (int)(chunk % (mode >> 4)) != (mode & 15)) continue;
-      stencil_chunk<JAC>(n, lv, level, f, xb, g, x, table, feat, jac);
+      stencil_chunk<JAC, IDX>(n, lv, level, f, xb, g, x, table, feat, jac);
     }
   }
 }
@@ -386,8 +390,11 @@ static void launch_fwd_stencil(int64_t n, const HgLevels &lv, int n_levels, cons
     stride = (int64_t)resident * 32;
     if (stride % 3 == 0) ++stride;   // slots dealt by chunk % 3: every workgroup sees all three residues in turn
   }
-  if (stride < chunks) hashgrid_fwd_stencil_kernel<JAC, true><<<(unsigned)(stride * n_xcd), HG_THREADS, 0, stream>>>(n, lv, xs, n_xcd, ppw, chunks, stride, x, table, feat, jac);
-  else hashgrid_fwd_stencil_kernel<JAC, false><<<(unsigned)(chunks * n_xcd), HG_THREADS, 0, stream>>>(n, lv, xs, n_xcd, ppw, chunks, chunks, x, table, feat, jac);
+  const bool idx32 = 7 * n * (int64_t)n_levels * 6 < (int64_t)1 << 31;
+#define STENCIL(RES, IDX, grid) hashgrid_fwd_stencil_kernel<JAC, RES, IDX><<<(unsigned)((grid) * n_xcd), HG_THREADS, 0, stream>>>(n, lv, xs, n_xcd, ppw, chunks, stride, x, table, feat, jac)
+  if (stride < chunks) { if (idx32) STENCIL(true, int32_t, stride); else STENCIL(true, int64_t, stride); }
+  else { if (idx32) STENCIL(false, int32_t, chunks); else STENCIL(false, int64_t, chunks); }
+#undef STENCIL
 }
 
 // ---- backward kernels: 4 lanes per (point, level) -------------------------------------------------------
