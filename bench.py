@@ -30,7 +30,11 @@ WORKLOADS = {
     "cfg1_replica_300k": (300_000, 1200, 680, 0, True),         # configs[1] with --no-sdf, configs[2] (joint train) without
     "cfg4_3M_640x512_K16": (3_000_000, 640, 512, 3, False),     # configs[4] shape on ONE GPU (FAST-LIVO2: 640x512, sh_degree 3)
     "cfg0_10k_256": (10_000, 256, 256, 0, False),
+    # larger footprints than the SURVEY 8d scene (projected 1-sigma 2-12 px instead of 0.5-4: ~12 M (tile, splat) pairs, L ~ 1500): the hard end
+    # for the list kernels; a secondary line, never the headline
+    "stress_1M_1080p_sigma2_12": (1_000_000, 1920, 1080, 0, False),
 }
+WORKLOAD_SIGMA_PX = {"stress_1M_1080p_sigma2_12": (2.0, 12.0)}      # synth.make_scene(sigma_px=...); default (0.5, 4.0)
 
 
 def spawn_ranks(n):
@@ -144,7 +148,7 @@ def main():
     from gs_sdf_amd.neural_gs import update_densify_state
 
     N, W, H, deg, replica = WORKLOADS[args.workload]
-    sc = synth.make_scene(N, W, H, sh_degree=deg, seed=0, replica=replica)
+    sc = synth.make_scene(N, W, H, sh_degree=deg, seed=0, replica=replica, sigma_px=WORKLOAD_SIGMA_PX.get(args.workload, (0.5, 4.0)))
     views = synth.make_views(200, seed=1).to(dev)
     K = sc["K"].to(dev)
     from gs_sdf_amd.trainer import morton_order
@@ -532,6 +536,16 @@ def main():
         alone = {"steps": n1, "mean_ms": mean1, "calls": calls1, "avg": {k: sum(v) / len(v) for k, v in h1.items()}}
         alone["avg"]["n_ray_pts"] = 32768.0
         del ji1
+    replica_checksums = None
+    if dist is not None:
+        flat_s = ji.splat_flat() if ji is not None else params.flat
+        flat_d = ji.sdf_flat() if ji is not None else (groups[0].flat if groups else flat_s[:0])
+        cs = torch.stack([flat_s.double().sum(), flat_s.double().abs().sum(), flat_d.double().sum(), flat_d.double().abs().sum()]).to(dev)
+        allcs = [torch.zeros_like(cs) for _ in range(world)]
+        dist.all_gather(allcs, cs)
+        rows = [[float(v) for v in t.cpu()] for t in allcs]
+        replica_checksums = {"what": "per rank: sum and sum |.| of the splat and of the SDF parameters (fp64) after the timed region",
+                             "per_rank": rows, "all_equal": all(r == rows[0] for r in rows)}
     if rank == 0 and os.environ.get("GSDF_BENCH_DUMP_PARAMS"):
         # debugging / evidence hook (tools/compare_mlp_pipes.py): the parameters after warmup + steps optimizer steps
         torch.cuda.synchronize()
@@ -597,6 +611,8 @@ def main():
             "hbm_gb": {"allocated_peak": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2), "reserved": round(torch.cuda.memory_reserved() / 2 ** 30, 2)},
             # every step this process ran (warm-up included): what one row of a rocprofv3 --stats summary of this command averages over
             "all_steps": {"steps": len(all_hist.get("M", [])), **{"mean_" + k: sum(v) / max(1, len(v)) for k, v in all_hist.items()}},
+            # view-parallel replicas must stay identical: a checksum of every rank's parameters after the timed region (all equal <=> replicas identical)
+            "replica_checksums": replica_checksums,
             "collectives": (None if dist is None or impl != "cpp" else {
                 "backend": dist.get_backend(), "world_size": dist.get_world_size(),
                 **{fam: {"calls": len(ev), "bytes": ev[-1][2] if ev else 0,

@@ -31,7 +31,7 @@ def cabi_timing_to_ops(rep):
 
 
 
-PROFILE_ROUND = "r05"
+PROFILE_ROUND = "r06"
 HBM_PEAK_GBPS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s
 BF16_MFMA_PEAK = 2500.0          # dense bf16 MFMA, TFLOP/s
 F32_MFMA_PEAK = 157.3
@@ -92,13 +92,14 @@ def roofline(a, calls, kern_mean, kern_med, steps, workload, analytic, no_sdf, s
     flops = {k: v / launches(k) for k, v in a["flops"].items() if calls.get(k)}
     # time per step of an operator = MEAN launch x launches per step (launches of an SDF operator differ in size; `alg` is the per-launch mean)
     per_step = {k: kern_mean.get(k, 0.0) * calls.get(k, 0) / steps for k in list(alg) + list(flops)}
+    # The dominant kernel is ranked LIVE (largest time per step by the in-bench HIP-event timers of this run); the committed one-stream rocprofv3
+    # stats of this round are the cross-check, and a disagreement is said so in the line (a committed CSV must not pick the kernel)
     live_first = max(per_step, key=lambda k: per_step[k])
     rank = committed_ranking(workload, analytic, no_sdf)
-    dom, rule = live_first, "largest time per step by the in-bench HIP-event timers"
-    if rank is not None and rank["operator"] in per_step:
-        dom = rank["operator"]
-        rule = (f"first in {rank['file']} (rocprofv3 --kernel-trace --stats of this command on one stream: {rank['percent_of_gpu_time']:.1f} % of GPU "
-                f"time); timed live here (live entry-point timers, which include CU waits beside the other leg, rank {live_first} first)")
+    dom, rule = live_first, "largest time per step by the in-bench HIP-event timers of this run"
+    if rank is not None:
+        rule += (f"; {rank['file']} (rocprofv3 --kernel-trace --stats of this command on one stream) ranks {rank['operator']} first "
+                 f"({rank['percent_of_gpu_time']:.1f} % of GPU time): " + ("agrees" if rank["operator"] == dom else "DISAGREES"))
 
     def roof(k):
         if k in alg:
@@ -166,6 +167,9 @@ def compact_line(d):
     line["config"] = {"workload": c["workload"], "step_impl": c["step_impl_short"], "sdf_config": c["sdf_config"], "sample_mode": c["sample_mode_short"],
                       "ray_batch": c["ray_batch_short"], "parallelism": c["parallelism"], "sdf_points_per_step": c["sdf_points_per_step"],
                       "M": c["M"], "I": c["I"]}
+    line["internal_warmup_steps"] = d.get("internal_warmup_steps")      # untimed steady-state steps bench.py runs on top of --warmup
+    if d.get("all_steps") and c.get("sdf_points_per_step"):
+        line["sdf_points_timed_vs_run_mean"] = [c["sdf_points_per_step"], round(d["all_steps"].get("mean_sdf_points", 0.0))]
     line["step_ms_hip_events"] = {k: round(v, 3) for k, v in d["step_ms_hip_events"].items() if k != "what"}
     line["roofline"] = {"kernel": r["kernel"], "bound": r["bound"], "achieved": round(r["achieved"], 1), "peak": r["peak"], "unit": r["unit"],
                         "frac": round(r["frac"], 4), "algorithmic_bytes": r.get("algorithmic_bytes"), "avg_launch_ms": round(r["avg_launch_ms"], 4),
@@ -189,12 +193,14 @@ def compact_line(d):
         line["cpu_baseline"] = {"value": cb["value"], "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"], "sample": cb["sample_short"],
                                 "parity": {"integer_outputs_bit_exact": p.get("integer_outputs_bit_exact"), "worst_over_tolerance": round(worst, 4),
                                            "elements_above_1e-4": above, "elements": n_el, "pinned": "unpinned (no reference kernel source or vector exists); "
-                                           "oracle cross-checked by an independent fp32 build, profiles/parity_r05.json"}}
+                                           "oracle cross-checked by an independent fp32 build, profiles/parity_r06.json"}}
     if d.get("collectives"):
         c_ = d["collectives"]
         line["collectives"] = {"backend": c_["backend"], "world_size": c_["world_size"],
                                "splat_allreduce_ms": None if not c_["splat"]["mean_ms"] else round(c_["splat"]["mean_ms"], 3), "splat_bytes": c_["splat"]["bytes"],
                                "sdf_allreduce_ms": None if not c_["sdf"]["mean_ms"] else round(c_["sdf"]["mean_ms"], 3), "sdf_bytes": c_["sdf"]["bytes"]}
+    if d.get("replica_checksums"):
+        line["replicas_identical"] = d["replica_checksums"]["all_equal"]
     if d.get("secondary"):
         line["secondary"] = {k: (round(v["value"], 2) if isinstance(v, dict) and "value" in v else "error") for k, v in d["secondary"].items()}
         line["secondary_unit"] = "iters/s (each its own line above and in the detail file)"

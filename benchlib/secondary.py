@@ -9,10 +9,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BENCH = os.path.join(ROOT, "bench.py")
 
 
-def _sub(args, extra, steps):
+def _sub(args, extra, steps, workload=None):
     """this same script in a subprocess (nothing of the caller's allocator / stream state leaks into it) -> its detail record"""
     name = f"bench_detail_secondary_{os.getpid()}.json"
-    cmd = [sys.executable, BENCH, "--gpus", "1", "--steps", str(steps), "--warmup", str(args.warmup), "--workload", args.workload,
+    cmd = [sys.executable, BENCH, "--gpus", "1", "--steps", str(steps), "--warmup", str(args.warmup), "--workload", workload or args.workload,
            "--step-terms", args.step_terms, "--splat-order", args.splat_order, "--no-secondary", "--no-cpu-baseline"] + (["--no-overlap"] if args.no_overlap else []) + extra
     env = dict(os.environ, GSDF_BENCH_DETAIL=name)
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
@@ -56,6 +56,21 @@ def run_all(args, impl, analytic, sc, views, K, ug6, target, N, W, H, deg, dev):
         # refinement inside a measured run (grow / split / prune / Adam-state surgery every refine_every steps)
         ("refine_amortised", lambda: refine_amortised(args, sc, views, K, target, N, W, H, deg, dev)),
     )
+    # the other BASELINE.json configurations and one stress workload on THIS tree (parity-test shapes; never the headline): each line carries its
+    # own dominant kernel's roofline fraction and the list sizes
+    def other(workload, extra):
+        j = _sub(args, extra + ["--sdf-config", args.sdf_config, "--sample-mode", args.sample_mode], min(args.steps, 20), workload=workload)
+        r, c = j["roofline"], j["config"]
+        return _short(j, workload=c["workload"], step_impl=c["step_impl_short"], M=c["M"], I=c["I"], L=c["L"], sdf_points_per_step=c["sdf_points_per_step"],
+                      roofline={"kernel": r["kernel"], "bound": r["bound"], "frac": round(r["frac"], 4), "avg_launch_ms": round(r["avg_launch_ms"], 4)},
+                      ms_per_step_by_kernel=(r.get("in_step") or r)["ms_per_step_by_kernel"])
+    if args.workload == "cfg3_1M_1080p":
+        jobs = jobs + (
+            ("configs1_replica_300k_splat_only", lambda: other("cfg1_replica_300k", ["--no-sdf"])),       # BASELINE.json configs[1]
+            ("configs2_replica_300k_joint", lambda: other("cfg1_replica_300k", ["--step-impl", impl])),    # configs[2]
+            ("configs4_shape_3M_640x512_K16", lambda: other("cfg4_3M_640x512_K16", ["--step-impl", impl])),  # configs[4]'s shape on one GPU
+            ("stress_1M_1080p_sigma2_12", lambda: other("stress_1M_1080p_sigma2_12", ["--step-impl", impl])),
+        )
     for name, fn in jobs:
         try:
             out[name] = fn()

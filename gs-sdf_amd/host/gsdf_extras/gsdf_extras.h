@@ -201,7 +201,9 @@ class JointIteration {
   std::map<std::string, int64_t> refine(int iter, const RefineConfig &rc);
   int64_t prune_rows(const torch::Tensor &mask);     // rows with mask != 0 leave (prune_invisible_gs / prune_nan_gs); -> rows removed
   void reset_opacity(const RefineConfig &rc);        // :918-926: opacity logits clamped to logit(2 prune_opa), fresh moments
-  // View-parallel: called with the densification statistics before any decision is taken (sum grad2d / count, max vis / radii over the ranks)
+  // View-parallel: called with the densification statistics a decision is about to consume — {"vis"} before the invisible prune, {"grad2d",
+  // "count", "radii"} before a refinement — and only those (sum grad2d / count, max vis / radii over the ranks, in place); each is zeroed by
+  // its consumer, so no accumulator is reduced twice
   void set_refine_hook(std::function<void(std::map<std::string, torch::Tensor> &)> hook) { refine_hook_ = std::move(hook); }
   torch::Tensor anchors() const { return anchors_; }
   std::map<std::string, torch::Tensor> &state() { return state_; }
@@ -235,6 +237,7 @@ class JointIteration {
   std::unique_ptr<JointStreams> streams_;
   std::function<void(torch::Tensor)> splat_hook_, sdf_hook_;
   std::function<void(std::map<std::string, torch::Tensor> &)> refine_hook_;
+  void reduce_stats(std::initializer_list<const char *> keys);   // the hook on the statistics a consumer is about to use up, and only those
   std::map<std::string, int64_t> apply_row_map(RefinePlanArgs &pa);   // plan -> totals -> new buffers -> apply -> rebind
   void bind_views(const torch::Tensor &flat, const torch::Tensor &flat_grad, int64_t n);
   // the splat leg without the autograd engine (step_direct): loss weights as device scalars, a never-written zero image, scratch

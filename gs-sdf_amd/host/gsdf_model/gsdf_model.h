@@ -99,6 +99,10 @@ struct LocalMap : torch::nn::Module {
  private:
   HostFrame host_frame_{};
   bool host_frame_valid_ = false;
+  // what the cached frame was computed from: pos_W_M_ / xyz_min_W_ / xyz_max_W_ are public and mutable (the reference assigns them), so the
+  // cache is keyed on their storage and version counters
+  const void *host_frame_ptr_[3] = {nullptr, nullptr, nullptr};
+  uint32_t host_frame_ver_[3] = {0, 0, 0};
 };
 
 // the k_* globals NeuralGS reads (config/base.yaml:37-74)

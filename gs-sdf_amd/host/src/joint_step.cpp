@@ -738,8 +738,21 @@ std::map<std::string, int64_t> JointIteration::apply_row_map(RefinePlanArgs &pa)
   return out;
 }
 
+// The view-parallel hook reduces statistics IN PLACE (sum of grad2d / count, max of vis / radii over the ranks), which is not idempotent: every
+// consumer hands it only the keys it is about to consume and zero afterwards, so no accumulator is ever reduced twice (the invisible
+// prune and the refinement of one iteration used to reduce the same map twice, and a prune alone left rank-summed grad2d / count behind).
+void JointIteration::reduce_stats(std::initializer_list<const char *> keys) {
+  if (!refine_hook_) return;
+  std::map<std::string, Tensor> sub;
+  for (const char *k : keys) {
+    auto it = state_.find(k);
+    if (it != state_.end()) sub.emplace(it->first, it->second);      // the same storage: the hook's in-place reduction lands in state_
+  }
+  if (!sub.empty()) refine_hook_(sub);
+}
+
 std::map<std::string, int64_t> JointIteration::refine(int iter, const RefineConfig &rc) {
-  if (refine_hook_ && !state_.empty()) refine_hook_(state_);
+  reduce_stats({"grad2d", "count", "radii"});
   TORCH_CHECK(state_.count("grad2d") && state_.count("count"), "JointIteration::refine: no densification statistics yet (run step() first)");
   RefinePlanArgs pa;
   pa.zero_stats = true;
@@ -777,11 +790,14 @@ void JointIteration::reset_opacity(const RefineConfig &rc) {
 
 std::map<std::string, int64_t> JointIteration::train_callback(int iter, int total_iter, const RefineConfig &rc) {
   std::map<std::string, int64_t> out = {{"N", anchors_.size(0)}};
+  TORCH_CHECK(rc.num_train_data > 0 && rc.refine_every > 0 && rc.reset_every > 0,
+              "JointIteration::train_callback: num_train_data, refine_every and reset_every are periods (> 0), got ", rc.num_train_data, ", ",
+              rc.refine_every, ", ", rc.reset_every);
   if (iter >= total_iter / 2) return out;       // refine_stop_iter (:573-578)
   // prune_nan_gs (:907-916): step() already accumulates the count without a host round trip (nan_splats_seen()); rows are removed by the caller
   // with prune_rows() when that count moves.  prune_invisible_gs (:892-905):
   if (iter > 0 && iter % rc.num_train_data == 0 && state_.count("vis")) {
-    if (refine_hook_) refine_hook_(state_);
+    reduce_stats({"vis"});
     Tensor invisible = state_["vis"] < 1e-4;
     state_["vis"].zero_();
     out["n_invisible"] = prune_rows(invisible);

@@ -146,7 +146,11 @@ void LocalMap::load(torch::serialize::InputArchive &archive) {
 
 // ---- SubMap ----------------------------------------------------------------------------------------------------------------
 const LocalMap::HostFrame &LocalMap::host_frame() {
+  const Tensor *src[3] = {&pos_W_M_, &xyz_min_W_, &xyz_max_W_};
+  for (int k = 0; k < 3; ++k)
+    if (host_frame_ptr_[k] != src[k]->data_ptr() || host_frame_ver_[k] != src[k]->_version()) host_frame_valid_ = false;
   if (!host_frame_valid_) {
+    for (int k = 0; k < 3; ++k) { host_frame_ptr_[k] = src[k]->data_ptr(); host_frame_ver_[k] = src[k]->_version(); }
     // the bounds get_inrange_mask compares against (padding 0), computed by the same libtorch operations, read back once
     Tensor v = torch::cat({pos_W_M_.reshape({-1}), (xyz_min_W_ + 0.f + 1e-6).reshape({-1}), (xyz_max_W_ - 0.f - 1e-6).reshape({-1})}).to(torch::kCPU);
     const float *p = v.data_ptr<float>();

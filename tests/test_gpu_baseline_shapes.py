@@ -64,7 +64,6 @@ def test_baseline_shape_parity(oracle, name):
     N, W, H, deg, replica, vis_, bgmask = SHAPES[name]
     Cn = len(vis_)
     dev = torch.device("cuda:0")
-    oracle.set_threads(os.cpu_count() or 1)
     sc = synth.make_scene(N, W, H, sh_degree=deg, seed=0, replica=replica)
     vm = synth.make_views(max(vis_) + 1, seed=1)[list(vis_)]
     Kd = sc["K"].expand(Cn, 3, 3).contiguous()

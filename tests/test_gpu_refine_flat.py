@@ -161,3 +161,45 @@ def test_refine_then_step_runs(host):
         assert bool(torch.isfinite(ji.splat_flat()[torch.isfinite(ji.splat_flat()) | ~ji.splat_flat().isinf()]).all())
         m, v = ji.splat_adam_moments()
         assert m.numel() == ji.splat_flat().numel() and bool(torch.isfinite(m).all()) and bool(torch.isfinite(v).all())
+
+
+def test_view_parallel_hook_reduces_every_statistic_exactly_once(host):
+    """The view-parallel hook (JointIteration::set_refine_hook) sums grad2d / count and maxes vis / radii over the ranks IN PLACE.  A fake two-rank
+    hook (identical ranks: the sums double, the maxima stay) must give the decisions of a single process whose statistics were doubled by hand —
+    also in an iteration where the invisible prune AND the refinement fire, and a prune-only iteration must not leave reduced sums behind."""
+    seen = []
+
+    def hook(state):
+        seen.append(sorted(state.keys()))
+        for k in ("grad2d", "count"):
+            if k in state:
+                state[k].mul_(2.0)
+
+    def run(it, with_hook):
+        ngs, opt, ji, rc = _pair(host, 8_000, 0, 11, it, radii=True)
+        rc.refine_every, rc.refine_start_iter = 100, 500
+        st = ji.get_state()
+        if with_hook:
+            ji.set_refine_hook(hook)
+        else:
+            st["grad2d"] = st["grad2d"] * 2.0; st["count"] = st["count"] * 2.0
+            ji.set_state(st)
+        before = {k: v.clone() for k, v in ji.get_state().items()}
+        torch.manual_seed(5)
+        out = ji.train_callback(it, 10_000, rc)
+        return out, ji, before
+
+    # 600 % 4 == 0 (invisible prune) and 600 % 100 == 0 (refinement): both consumers in one iteration
+    seen.clear()
+    out_h, ji_h, _ = run(600, True)
+    out_r, ji_r, _ = run(600, False)
+    assert seen == [["vis"], ["count", "grad2d", "radii"]], seen          # each statistic handed to the hook once, by its consumer
+    assert out_h == out_r and out_h.get("n_dupli", 0) + out_h.get("n_split", 0) > 0, (out_h, out_r)
+    assert torch.equal(ji_h.splat_flat(), ji_r.splat_flat())
+    # 604 % 4 == 0, 604 % 100 != 0: the prune alone — grad2d / count must stay the local accumulators (not reduced, not scaled)
+    seen.clear()
+    out_p, ji_p, before = run(604, True)
+    assert seen == [["vis"]] and "n_invisible" in out_p
+    keep = before["vis"] >= 1e-4
+    after = ji_p.get_state()
+    assert torch.equal(after["grad2d"], before["grad2d"][keep]) and torch.equal(after["count"], before["count"][keep])
