@@ -109,6 +109,9 @@ def main():
     ap.add_argument("--splat-order", default="as-given", choices=["morton", "as-given"],
                     help="memory order of the splat set: the synthetic scene's random order, or Morton order of the centres "
                          "(trainer.morton_order; measured: no gain, the fine hash-grid levels scatter either way, DESIGN.md section 11)")
+    ap.add_argument("--hashgrid-resident", type=int, default=-1,
+                    help="C++ step, two streams: workgroups per CU of the stencil hash-grid forward's resident grid (JointConfig::hashgrid_resident; "
+                         "-1 = its default, 0 = the full grid)")
     ap.add_argument("--collective", default="all_reduce", choices=["all_reduce", "reduce_scatter_all_gather"],
                     help="N > 1: how a parameter family's flat gradient buffer is summed over the ranks")
     args = ap.parse_args()

@@ -294,12 +294,11 @@ static void launch_fwd(int64_t B, int64_t jac_rows, const HgLevels &lv, int n_le
   XcdLevels xl;
   int max_nl = 0;
   const int n_xcd = xcd_count(stream);
-  static const bool off = [] { const char *e = getenv("GSDF_HASHGRID_XCD"); return e && e[0] == '0'; }();
   // measured: 17 % faster on a full-chip queue (2 levels = 8 MiB per XCD); no gain on a 6-XCD queue (3 levels = 12 MiB per
   // XCD, uneven groups) and none on 2 XCDs, so only full-chip queues take it
   // (measured and rejected: two launches with ONE level = 4 MiB per XCD and launch, to fit the 4 MiB L2: 1.58 against 1.66 ms
   // at 2.7 M points — the streaming x / feature traffic shares the L2 and the table still does not stay resident)
-  if (!off && n_xcd == 8 && B >= 65536 && make_xcd_levels(n_levels, n_xcd, &xl, &max_nl)) {
+  if (n_xcd == 8 && B >= 65536 && make_xcd_levels(n_levels, n_xcd, &xl, &max_nl)) {
     const int ppw_min = 16 / max_nl;
     const int64_t chunks = (B + 4 * ppw_min - 1) / (4 * ppw_min);
     hashgrid_fwd_xcd_kernel<JAC><<<(unsigned)(chunks * n_xcd), HG_THREADS, 0, stream>>>(B, jac_rows, lv, xl, n_xcd, x, table, feat, jac);
@@ -308,20 +307,19 @@ static void launch_fwd(int64_t B, int64_t jac_rows, const HgLevels &lv, int n_le
   }
 }
 
-// slots of the stencil kernel.  Default for 16 levels on 8 XCDs: contiguous pairs (the round-2 map).  GSDF_HASHGRID_MAP overrides it
-// for experiments: XCDs separated by ';', slots by ',', a slot = level or level%m=r (only the chunks with chunk % m == r), e.g.
-// "0,1;2,3;4,5%2=0;5%2=1,6;..."
+// slots of the stencil kernel.  A map is written as XCDs separated by ';', slots by ',', a slot = level or level%m=r (only the chunks with
+// chunk % m == r), e.g. "0,1;2,3;4,5%2=0;5%2=1,6;...".  16 levels on 8 XCDs take the measured map below, anything else contiguous groups.
 static bool make_stencil_slots(int n_levels, int n_xcd, XcdSlots *xs, int *ppw) {
   *xs = XcdSlots{};
   int max_nl = 0;
-  static const std::string env_map = [] { const char *e = getenv("GSDF_HASHGRID_MAP"); return std::string(e ? e : ""); }();
   // 16 levels (base 32, x2: the reference's grid, config/base.yaml) on 8 XCDs, measured (tools/exp_hgmaps.sh, 494 k points): the four
   // coarse levels together cost two hashed ones (their +-delta rows share the base row's cell, tables of 0.3-4 MiB), level 4 three
   // quarters of one; the ten levels 6..15 are dealt in thirds, five thirds per XCD: 1.77 ms against 1.97 ms for contiguous pairs
   // (0.93 / 1.00 at 250 k, 2.81 / 3.27 at 800 k).  Quarters (3-4 tables per L2) and halves with 3 slots measured slower.
   static const std::string tuned16 = "0,1,2,3;4,5;6,7%3=0,7%3=1;7%3=2,8,9%3=0;9%3=1,9%3=2,10;11,12%3=0,12%3=1;12%3=2,13,14%3=0;14%3=1,14%3=2,15";
-  const std::string &env = !env_map.empty() ? env_map : (n_levels == 16 && n_xcd == 8 && env_map != "contiguous") ? tuned16 : env_map;
-  if (!env.empty() && env != "contiguous" && n_xcd == 8) {
+  static const std::string none;
+  const std::string &env = (n_levels == 16 && n_xcd == 8) ? tuned16 : none;
+  if (!env.empty()) {
     int k = 0;
     size_t i = 0;
     while (k < 8) {
@@ -363,15 +361,14 @@ static bool make_stencil_slots(int n_levels, int n_xcd, XcdSlots *xs, int *ppw) 
   return *ppw >= 1;
 }
 
-static thread_local int tl_stencil_resident = -1;   // -1: environment default
+static thread_local int tl_stencil_resident = -1;   // <= 0: the full grid
 
 template <bool JAC>
 static void launch_fwd_stencil(int64_t n, const HgLevels &lv, int n_levels, const float *x, const float *table, float *feat,
                                float *jac, hipStream_t stream) {
   XcdSlots xs;
   int ppw = 1, n_xcd = xcd_count(stream);
-  static const bool off = [] { const char *e = getenv("GSDF_HASHGRID_XCD"); return e && e[0] == '0'; }();
-  if (off || n_xcd != 8 || 7 * n < 65536 || !make_stencil_slots(n_levels, n_xcd, &xs, &ppw)) {
+  if (n_xcd != 8 || 7 * n < 65536 || !make_stencil_slots(n_levels, n_xcd, &xs, &ppw)) {
     xs = XcdSlots{};
     xs.count[0] = n_levels;
     for (int j = 0; j < n_levels; ++j) xs.lvl[0][j] = (unsigned char)j;
@@ -379,12 +376,11 @@ static void launch_fwd_stencil(int64_t n, const HgLevels &lv, int n_levels, cons
     ppw = 1;
   }
   const int64_t chunks = (n + 4 * ppw - 1) / (4 * ppw);
-  // Resident grid (gsdf_hashgrid_fwd_stencil_resident(w) on this thread, or GSDF_HASHGRID_RESIDENT=w): w workgroups per CU (w * 32 per XCD)
+  // Resident grid (gsdf_hashgrid_fwd_stencil_resident(w) on this thread): w workgroups per CU (w * 32 per XCD)
   // that walk the chunks, instead of one workgroup per chunk.  The gathers are bound by the L1's miss queue, which two waves per SIMD keep
   // nearly as full as four; the wave slots and registers a full-occupancy grid would hold stay free for the kernels of another stream
   // (the resident kernel is held to 128 registers so that two of its waves leave room for two 128-register waves per SIMD).
-  static const int resident_env = [] { const char *e = getenv("GSDF_HASHGRID_RESIDENT"); return e ? atoi(e) : 0; }();
-  const int resident = tl_stencil_resident >= 0 ? tl_stencil_resident : resident_env;   // gsdf_hashgrid_fwd_stencil_resident(): the caller's hint
+  const int resident = tl_stencil_resident > 0 ? tl_stencil_resident : 0;   // gsdf_hashgrid_fwd_stencil_resident(): the caller's hint
   int64_t stride = chunks;
   if (resident > 0 && n_xcd == 8 && chunks > (int64_t)resident * 32) {
     stride = (int64_t)resident * 32;

@@ -375,7 +375,7 @@ static int make_desc(int n_layers, const int *dims, int has_bias, bool bwd, MlpD
 using namespace gsdf;
 
 static unsigned mlp_grid(int64_t B) {
-  static const int64_t cap = [] { const char *e = getenv("GSDF_MLP_MAX_WG"); return e ? (int64_t)atoi(e) : (int64_t)768; }();   // 3 per CU on 256 CUs, 4 per CU on a 6-XCD queue
+  const int64_t cap = 768;   // 3 per CU on 256 CUs, 4 per CU on a 6-XCD queue
   const int64_t wg = (B + 127) / 128;  // 4 tiles of 32 points per workgroup
   return (unsigned)(wg < 1 ? 1 : (wg > cap ? cap : wg));
 }

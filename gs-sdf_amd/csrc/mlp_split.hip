@@ -803,14 +803,13 @@ size_t mlp_bwd_split_ws_bytes_bound(int64_t B, int n_layers) {
 // registers, no scratch (one launch: 17 tiles, 124-229 spilled registers).  Measured at the headline batch (0.44 M base rows): one-pass
 // backward 261 -> 216 us, recomputing pass 365 -> 303 us, step 200 -> 208 it/s.  The 4-layer net (tcnn topology: 13 tiles, 1-25 spilled)
 // stays one launch: split {3, 2} + {1, 0} it compiles without scratch too but its step gets 2 % slower (123 -> 121 it/s: 3 M rows through
-// the 256 B/row hand-over image cost more than the few spills).  GSDF_MLP_BWD_RANGES=0: one launch for every net (A/B).
+// the 256 B/row hand-over image cost more than the few spills).  Without a workspace (ws == NULL) the 5-layer net runs as one launch too.
 template <int NL, bool BIAS, bool PART, int MODE>
 static int launch_bwd_kernels(unsigned grid, size_t lds, float *g_img, int64_t B, const MlpDesc &d, const SplitLds &sl, int lds_w4, const float *W,
                               const float *in, const float *acts, const float *v_out, float *v_in, float *v_W, float *v_b, int64_t part_stride,
                               const float *mask_acts, hipStream_t stream) {
-  static const bool ranges = [] { const char *e = getenv("GSDF_MLP_BWD_RANGES"); return !(e && e[0] == '0'); }();
   if constexpr (NL == 5) {
-    if (ranges && g_img != nullptr) {
+    if (g_img != nullptr) {
       constexpr int RL = 3;
       auto upper = mlp_bwd_split_kernel<NL, BIAS, PART, MODE, SPLIT_BWD_THREADS, NL - 1, RL>;
       auto lower = mlp_bwd_split_kernel<NL, BIAS, PART, MODE, SPLIT_BWD_THREADS, RL - 1, 0>;
@@ -835,7 +834,6 @@ static int launch_bwd_split(int64_t B, const MlpDesc &d, const SplitLds &sl, int
                             const float *acts, const float *v_out, float *v_in, float *v_W, float *v_b, void *ws, hipStream_t stream,
                             const float *mask_acts = nullptr) {
   const unsigned grid = split_bwd_grid(B);
-  static const bool atomic_exit = [] { const char *e = getenv("GSDF_MLP_BWD_EXIT"); return e && e[0] == 'a'; }();   // GSDF_MLP_BWD_EXIT=atomic: A/B
   // beyond ~48 tiles per wave the waves drift apart and their atomic exits hide behind each other's tiles; the partial buffers then only
   // add their two reduction launches (3.29 M points: 1.95 ms atomic, 2.05 ms partial; 0.49 M: 0.55 / 0.36; 0.1 M: 0.24 / 0.15)
   const bool many_tiles = (B + 31) / 32 > (int64_t)grid * (SPLIT_BWD_THREADS / 64) * 48;
@@ -848,7 +846,7 @@ static int launch_bwd_split(int64_t B, const MlpDesc &d, const SplitLds &sl, int
     chunk = part + (int64_t)n_part * n_elem;
     if (NL == 5) g_img = (float *)(((uintptr_t)(chunk + (int64_t)RED_CHUNKS * n_elem) + 255) & ~(uintptr_t)255);
   }
-  if (ws == nullptr || atomic_exit || many_tiles)
+  if (ws == nullptr || many_tiles)
     return launch_bwd_kernels<NL, BIAS, false, MODE>(grid, lds, g_img, B, d, sl, lds_w4, W, in, acts, v_out, v_in, v_W, v_b, 0, mask_acts, stream);
   int rc = launch_bwd_kernels<NL, BIAS, true, MODE>(grid, lds, g_img, B, d, sl, lds_w4, W, in, acts, v_out, v_in, part, part + n_w, n_elem, mask_acts, stream);
   if (rc < 0) return rc;
@@ -930,7 +928,7 @@ static bool split_enabled() {
 }
 
 static unsigned split_grid(int64_t B, int waves) {
-  static const int64_t cap = [] { const char *e = getenv("GSDF_MLP_SPLIT_WG"); return e ? (int64_t)atoi(e) : (int64_t)256; }();   // the image fills most of a CU's LDS: one workgroup per CU
+  const int64_t cap = 256;   // the image fills most of a CU's LDS: one workgroup per CU
   const int64_t wg = ((B + 31) / 32 + waves - 1) / waves;
   return (unsigned)(wg < 1 ? 1 : (wg > cap ? cap : wg));
 }

@@ -176,10 +176,8 @@ static int radix_pass_b(int64_t n, int shift, const uint32_t *keys_in, const uin
   }
 }
 
-// GSDF_RADIX_ITEMS = 4 | 8 | 16 pins the block size (A/B); default: by the input's length
+// items per thread of a pass: by the input's length
 int radix_items(int64_t n) {
-  static const int pinned = [] { const char *e = getenv("GSDF_RADIX_ITEMS"); const int v = e ? atoi(e) : 0; return (v == 4 || v == 8 || v == 16) ? v : 0; }();
-  if (pinned) return pinned;
   // measured on the binning (tools/exp_binning.py, whole tile_encode): 300 k splats / 0.64 M intersections 0.247 (16) 0.218 (8) 0.203 ms (4);
   // 1 M / 2.1 M: 0.357, 0.353, 0.366; 3 M / 7.1 M: 0.845, 0.881, 0.973 (and one 6.9 ms outlier at 4)
   return n < (1 << 19) ? 4 : n < 3 * (1 << 19) ? 8 : 16;

@@ -258,8 +258,7 @@ struct AnalyticFn : public torch::autograd::Function<AnalyticFn> {
     Tensor g0 = empty_like_opts(xs, {n, nf}, torch::kFloat32);
     // topologies of the one-pass backward (the reference's both): the lean e0 backward — the chain alone on the bf16 pipe, nothing saved; the
     // double backward recomputes it from the ReLU masks (gsdf_mlp_bwd_bwd with bwd_ws = NULL).  Else the fp32-pipe pair with its v_pre images.
-    static const bool lean_off = [] { const char *e = getenv("GSDF_MLP_LEAN_BWD_BWD"); return e != nullptr && e[0] == '0'; }();   // A/B switch
-    const bool lean = !lean_off && gsdf_mlp_bwd_is_one_pass(nl, dims.data()) == 1;
+    const bool lean = gsdf_mlp_bwd_is_one_pass(nl, dims.data()) == 1;
     Tensor bws = lean ? empty_like_opts(xs, {0}, torch::kUInt8) : empty_like_opts(xs, {(int64_t)gsdf_mlp_bwd_ws_bytes(n, nl)}, torch::kUInt8);
     check(gsdf_mlp_bwd(n, nl, dims.data(), fp(W), fp(bias), fp(feat), fp(acts), fp(e0), fpm(g0), nullptr, nullptr, lean ? nullptr : bws.data_ptr(),
                        cur_stream()), "mlp_bwd");

@@ -31,17 +31,14 @@ struct ResidentGridHint {
   explicit ResidentGridHint(int wgs_per_cu) : before(gsdf_hashgrid_fwd_stencil_resident(wgs_per_cu)) {}
   ~ResidentGridHint() { gsdf_hashgrid_fwd_stencil_resident(before); }
   static int of(const gsdf_extras::JointConfig &cfg) {
-    static const int env = [] { const char *e = getenv("GSDF_JOINT_HASHGRID_RESIDENT"); return e ? atoi(e) : -1; }();   // A/B
     // (the analytic configuration only: in the numerical one the stencil forward runs beside other kernels of its own leg and the resident
     //  grid costs 6 % of the step, 120.7 -> 113.8 it/s)
-    return cfg.two_streams && cfg.analytic ? (env >= 0 ? env : cfg.hashgrid_resident) : -1;
+    return cfg.two_streams && cfg.analytic ? cfg.hashgrid_resident : -1;
   }
 };
-// the gradient buffers are zeroed by the Adam launch that consumes them (gsdf_adam_step_zero_grad); GSDF_ADAM_FUSED_ZERO=0: separate fills
-bool fused_zero() {
-  static const bool on = [] { const char *e = getenv("GSDF_ADAM_FUSED_ZERO"); return !(e && e[0] == '0'); }();
-  return on;
-}
+// the gradient buffers are zeroed by the Adam launch that consumes them (gsdf_adam_step_zero_grad); measured equal to separate fills within noise
+// in round 4, kept because it removes the fill launches from both legs
+constexpr bool fused_zero() { return true; }
 
 
 // neural_gaussian.cpp:229-240 in one pass: expected depth, cat(colours, depth), normals to world space (+ the colour / depth slices)
@@ -114,9 +111,8 @@ std::vector<Tensor> render_post(const Tensor &render_colors, const Tensor &rende
 }
 
 struct JointStreams {
-  // GSDF_SDF_STREAM_HIGH_PRIORITY=1: the SDF leg's queue ahead of the splat leg's when both have workgroups waiting (experiment)
-  c10::hip::HIPStreamMasqueradingAsCUDA side = c10::hip::getStreamFromPoolMasqueradingAsCUDA(
-      [] { const char *e = getenv("GSDF_SDF_STREAM_HIGH_PRIORITY"); return e && e[0] == '1'; }());
+  // (a high-priority queue for the SDF leg was measured and costs 1-5 % of the step)
+  c10::hip::HIPStreamMasqueradingAsCUDA side = c10::hip::getStreamFromPoolMasqueradingAsCUDA(false);
   at::cuda::CUDAEvent fwd_done, entry, side_done;
   StreamGate gate;
   bool side_pending = false;
@@ -318,8 +314,9 @@ std::map<std::string, int64_t> JointIteration::step(const Tensor &viewmat, const
   // stream (beside the hash-grid forward: VALU-bound compositing backward next to a gather-bound kernel), then the SDF backward on
   // `side`, and last the samples' gradient through the few nodes between the samples and the splat parameters.  The splat leg's
   // stream no longer idles while the host issues the SDF leg, and the compositing backward is off the tail of the step.
-  // Schedule B (GSDF_JOINT_SCHEDULE=B, the round-2 order): SDF forward + backward, then one backward over {loss, samples}.
-  static const bool schedule_a = [] { const char *e = getenv("GSDF_JOINT_SCHEDULE"); return !(e && (e[0] == 'B' || e[0] == 'b')); }();
+  // (Schedule B, the round-2 order — SDF forward + backward, then one backward over {loss, samples} — is what the code below falls back to
+  //  when there is no SDF work.)
+  constexpr bool schedule_a = true;
   if (!two) {
     Tensor loss = splat_loss();
     if (sdf_work) loss = loss + sdf_node(samples, nullptr);
@@ -573,7 +570,7 @@ std::map<std::string, int64_t> JointIteration::step_direct(const Tensor &viewmat
   Tensor v_c3 = img(3), v_d1 = img(1), v_nw = img(3);
   check(gsdf_l1_dssim_bwd(H, W, fp(c3), fp(target), ssim_window11(), fp(maps), fp(w_one_), (float)cfg_.rgb_w, (float)cfg_.dssim_w, fpm(v_c3), cur_stream()),
         "l1_dssim_bwd");
-  static const bool fused_values = [] { const char *e = getenv("GSDF_JOINT_FUSED_LOSS_VALUES"); return !(e && e[0] == '0'); }();   // 0: separate launches (A/B)
+  constexpr bool fused_values = true;   // the two loss values come out of the fused forward + backward launches
   if (fused_values)
     check(gsdf_normal_consistency_fwd_bwd(H, W, intr.data(), pose.data(), fp(d1), fp(ra), fp(nw), fp(w_normal_), fpm(l_normal), fpm(v_d1), fpm(v_nw),
                                           cur_stream()), "normal_consistency_fwd_bwd");

@@ -98,14 +98,15 @@ PYBIND11_MODULE(_gsdf_host, m) {
   py::class_<gsdf_extras::JointIteration, std::shared_ptr<gsdf_extras::JointIteration>>(m, "JointIteration")
       .def(py::init([](const torch::Tensor &anchors, const std::vector<torch::Tensor> &fields, std::shared_ptr<TCNNEncoding> enc,
                        std::shared_ptr<TCNNNetwork> dec, std::vector<float> origin, double map_size, double bce_sigma, int occ_level, int width,
-                       int height, int sh_degree, bool two_streams, bool analytic, bool reference_terms, bool center_reg) {
+                       int height, int sh_degree, bool two_streams, bool analytic, bool reference_terms, bool center_reg, int hashgrid_resident) {
         gsdf_extras::JointConfig cfg;
         cfg.width = width; cfg.height = height; cfg.sh_degree = sh_degree; cfg.two_streams = two_streams;
         cfg.analytic = analytic; cfg.reference_terms = reference_terms; cfg.center_reg = center_reg;
+        if (hashgrid_resident >= 0) cfg.hashgrid_resident = hashgrid_resident;
         return std::make_shared<gsdf_extras::JointIteration>(anchors, fields, enc, dec, origin, map_size, bce_sigma, occ_level, cfg);
       }), py::arg("anchors"), py::arg("fields"), py::arg("enc"), py::arg("dec"), py::arg("origin"), py::arg("map_size"), py::arg("bce_sigma"),
            py::arg("occ_level"), py::arg("width"), py::arg("height"), py::arg("sh_degree"), py::arg("two_streams"), py::arg("analytic") = true,
-           py::arg("reference_terms") = true, py::arg("center_reg") = true)
+           py::arg("reference_terms") = true, py::arg("center_reg") = true, py::arg("hashgrid_resident") = -1)
       .def("step", &gsdf_extras::JointIteration::step, py::arg("viewmat"), py::arg("K"), py::arg("target"), py::arg("ray_pts"),
            py::arg("ray_sdf"), py::arg("upstream"), py::arg("update") = true, py::arg("cam_host") = std::vector<float>(),
            py::call_guard<py::gil_scoped_release>())       // step() runs the autograd engine

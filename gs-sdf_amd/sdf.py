@@ -658,8 +658,8 @@ class _SdfBatchAnalytic(torch.autograd.Function):
         e0[:, 0] = 1.0
         g0 = torch.empty(n, nf, dtype=torch.float32, device=dev)
         # topologies of the one-pass backward: the lean e0 backward (the chain alone on the bf16 pipe, nothing saved); the double backward then
-        # recomputes it from the ReLU masks (gsdf_mlp_bwd_bwd with bwd_ws = NULL).  GSDF_MLP_LEAN_BWD_BWD=0: the fp32-pipe pair + v_pre images
-        lean = os.environ.get("GSDF_MLP_LEAN_BWD_BWD", "1") != "0" and L.gsdf_mlp_bwd_is_one_pass(nl, dims_c) == 1
+        # recomputes it from the ReLU masks (gsdf_mlp_bwd_bwd with bwd_ws = NULL); other topologies: the fp32-pipe pair + v_pre images
+        lean = L.gsdf_mlp_bwd_is_one_pass(nl, dims_c) == 1
         bws = None if lean else torch.empty(L.gsdf_mlp_bwd_ws_bytes(n, nl), dtype=torch.uint8, device=dev)
         capi.check(_timed("mlp_bwd_data", L.gsdf_mlp_bwd, n, nl, dims_c, f32(dec.params_), f32(dec.biases_), f32(fb), f32(acts), f32(e0),
                           f32(g0), None, None, ptr(bws), capi.stream()), "mlp_bwd")

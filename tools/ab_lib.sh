@@ -1,15 +1,17 @@
 #!/bin/bash
 # Run ON THE GPU BOX: bench.py (headline command, short) with the product library and with compile-time variants of it (tools/build_variants.sh),
-# interleaved.  usage: tools/ab_lib.sh <reps> <variant>[,ENV=VALUE...] [...]    ("base" = the product library; ENV=VALUE pairs are exported for that run)
+# interleaved.  usage: tools/ab_lib.sh <reps> <variant>[,ENV=VALUE|--bench-flag=value ...] [...]    ("base" = the product library; ENV=VALUE pairs are
+# exported for that run, items starting with -- are passed to bench.py, e.g. base,--hashgrid-resident=2)
 REPS=$1; shift
 L=gs-sdf_amd/lib
 cp $L/libgsdf_hip.so /tmp/base.so
 for r in $(seq $REPS); do
   for spec in "$@"; do
     v=${spec%%,*}
-    envs=$(echo "$spec" | tr ',' '\n' | tail -n +2 | tr '\n' ' ')
+    envs=$(echo "$spec" | tr ',' '\n' | tail -n +2 | grep -v '^--' | tr '\n' ' ')
+    flags=$(echo "$spec" | tr ',' '\n' | tail -n +2 | grep '^--' | tr '=\n' '  ')
     if [ $v = base ]; then cp /tmp/base.so $L/libgsdf_hip.so; else cp $L/variants/$v/libgsdf_hip.so $L/libgsdf_hip.so; fi
-    env $envs timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-secondary 2>/dev/null | tail -1 > /tmp/line.json
+    env $envs timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-secondary $flags 2>/dev/null | tail -1 > /tmp/line.json
     python - "$spec" <<'PY'
 import json, sys
 try:
