@@ -42,7 +42,7 @@ __device__ __forceinline__ void lds_add(float *p, float v) { atomicAdd(p, v); }
 // Measured at cfg3 (tools/exp_raster_quads.py, library variants of tools/build_variants.sh; backward + unpack, ms): batch 116 at 4 workgroups per CU
 // 0.750; without the SLP vectoriser (its packed-fp32 forms cost more moves than they save: 106 -> 96 registers) 0.731; v_rcp_f32 for 1 / (1 - alpha)
 // instead of the IEEE division sequence 0.719; batch 92 at 5 workgroups per CU 0.692 (84: 0.764 — a smaller batch at the same occupancy costs more
-// than it gives); batch 76 at 6 per CU (80 registers, 27-32 spilled) 0.911.
+// than it gives); batch 76 at 6 per CU (80 registers, 27-32 spilled) 0.911; software-pipelined operand reads 0.713 (10 more spills) / 0.721 at 4 per CU.
 #ifndef RASTER_BWD_RCP
 #define RASTER_BWD_RCP(x) __builtin_amdgcn_rcpf(x)
 #endif

@@ -18,7 +18,8 @@ namespace gsdf {
 // (not blended), bit4 the median is updated here; positions it skips (alpha test failed, unreachable quad, pixel finished) stay 0.
 // Measured at cfg3 (tools/exp_raster_quads.py, library variants of tools/build_variants.sh; pack + mask + forward, ms): batch 192 at 5 workgroups
 // per CU 0.343, 160 at 6 0.313, 144 at 6 0.302, 128 at 7 0.299, 112 at 8 0.291, 240 at 4 0.330: the kernel is latency-bound (VALU issue 49 %, LDS
-// 26 % busy at 5 per CU), so the batch is what eight workgroups' LDS allows (62 registers: eight waves per SIMD fit).
+// 26 % busy at 5 per CU), so the batch is what eight workgroups' LDS allows (62 registers: eight waves per SIMD fit).  Requesting the next
+// iteration's q0..q2 before the current one computes (software pipeline, 63 registers) changes nothing: 0.302 against 0.296.
 #ifndef RASTER_FWD_QUADS_BATCH
 #define RASTER_FWD_QUADS_BATCH 120
 #endif

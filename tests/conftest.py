@@ -70,6 +70,6 @@ def pytest_sessionfinish(session, exitstatus):
             out = os.path.join(ROOT, "gpurun_out")
             os.makedirs(out, exist_ok=True)
             rows = [dict(case=c, tensor=nm, hip_vs_fp64_oracle_under_matched_decisions=st) for c, nm, st in util.MATCHED_LOG]
-            json.dump(rows, open(os.path.join(out, "parity_small_cases_r05.json"), "w"), indent=1)
+            json.dump(rows, open(os.path.join(out, "parity_small_cases_r06.json"), "w"), indent=1)
     except Exception:
         pass

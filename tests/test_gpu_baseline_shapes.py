@@ -14,7 +14,7 @@ recovered as 1 - alpha) must land comparably far from fp64 wherever the HIP kern
 1e-4 max(|ref|, mean|ref|) + PROJ_COND_C eps32 x the oracle's absolute-shadow bound of the expression tree (no straggler allowance),
 under the matched normal-flip decision, and cross-checked against the oracle's own fp32 builds; (c) one BASELINE shape runs with
 C = 2 cameras, `backgrounds` and tile `masks` (neural_gaussian.cpp:215-223 passes nullopt for both; the operator's signature has them).
-Every measurement is written to gpurun_out/parity_r05.json (committed copy: profiles/parity_r05.json)."""
+Every measurement is written to gpurun_out/parity_r06.json (committed copy: profiles/parity_r06.json)."""
 import json
 import os
 import time
@@ -29,7 +29,7 @@ from util import (RASTER_TENSORS, assert_equal_int, clean_parity_stats, hip_comp
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-OUT = os.path.join(ROOT, "gpurun_out", "parity_r05.json")
+OUT = os.path.join(ROOT, "gpurun_out", "parity_r06.json")
 PROJ_COND_C = 16.0      # operation depth of the projection backward's expression tree (x eps32 x sum of |terms|); largest factor any element needed is recorded (c_needed)
 
 SHAPES = {
