@@ -46,6 +46,9 @@ _SIGS = {
     "gsdf_rasterize_2dgs_bwd": (C.c_int, [_i64, _i64, _i64, _i32, _i32, _i32] + [_vp] * 28),
     "gsdf_rasterize_2dgs_fwd_instr": (C.c_int, [_i64, _i64, _i64, _i32, _i32, _i32] + [_vp] * 21),
     "gsdf_rasterize_2dgs_bwd_instr": (C.c_int, [_i64, _i64, _i64, _i32, _i32, _i32] + [_vp] * 29),
+    "gsdf_nan_rows_accumulate": (C.c_int, [_i64] + [_vp] * 5),
+    "gsdf_visible_gather": (C.c_int, [_i64] + [_vp] * 7),
+    "gsdf_rows_scatter_add": (C.c_int, [_i64, _i32, _vp, _i32, _vp, _vp, _vp]),
     "gsdf_render_post_fwd": (C.c_int, [_i64, _i32] + [_vp] * 10),
     "gsdf_render_post_bwd": (C.c_int, [_i64, _i32] + [_vp] * 12),
     "gsdf_hashgrid_offsets": (_i64, [_i32, _i32, _i32, _i32, _f32, _vp]),

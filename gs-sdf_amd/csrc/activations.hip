@@ -180,6 +180,72 @@ extern "C" int gsdf_isotropic_loss_fwd_bwd(int64_t M, const float *scales, const
   return GSDF_OK;
 }
 
+extern "C" int gsdf_nan_rows_accumulate(int64_t n, const float *offsets, const float *scaling, const float *quaternion, int32_t *total,
+                                        gsdf_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  GSDF_TIMED("gsdf_nan_rows_accumulate");
+  GSDF_REQUIRE(n >= 0 && total, "nan_rows_accumulate: bad arguments");
+  if (n == 0) return GSDF_OK;
+  GSDF_REQUIRE(offsets && scaling && quaternion, "nan_rows_accumulate: null buffer");
+  nan_rows_kernel<<<(unsigned)((n + 255) / 256), 256, 0, stream>>>(n, offsets, scaling, quaternion, total, nullptr);
+  GSDF_CHECK_LAUNCH("nan_rows_kernel");
+  return GSDF_OK;
+}
+
+// ---- row gathers / scatters of the visible set (what the reference writes as xyz.index_select(0, gaussian_ids) and index_add_) ----------
+namespace gsdf {
+__global__ void __launch_bounds__(256)
+    visible_gather_kernel(int64_t M, const int64_t *__restrict__ ids, const float *__restrict__ xyz, const float *__restrict__ opac,
+                          float *__restrict__ xyz_rows, float *__restrict__ opac_rows, float *__restrict__ ones) {
+  const int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (m >= M) return;
+  const int64_t g = ids[m];
+  if (xyz_rows != nullptr) { xyz_rows[3 * m] = xyz[3 * g]; xyz_rows[3 * m + 1] = xyz[3 * g + 1]; xyz_rows[3 * m + 2] = xyz[3 * g + 2]; }
+  if (opac_rows != nullptr) opac_rows[m] = opac[g];
+  if (ones != nullptr) ones[m] = 1.0f;
+}
+template <int COLS, bool UNIQUE>
+__global__ void __launch_bounds__(256)
+    rows_scatter_add_kernel(int64_t M, const int64_t *__restrict__ ids, const float *__restrict__ src, float *__restrict__ dst) {
+  const int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (m >= M) return;
+  const int64_t g = ids[m];
+#pragma unroll
+  for (int c = 0; c < COLS; ++c) {
+    if (UNIQUE) dst[COLS * g + c] += src[COLS * m + c];      // every destination row appears once: plain read-modify-write
+    else atomicAdd(dst + COLS * g + c, src[COLS * m + c]);
+  }
+}
+}  // namespace gsdf
+
+extern "C" int gsdf_visible_gather(int64_t M, const int64_t *gaussian_ids, const float *xyz, const float *opacities, float *xyz_rows,
+                                   float *opacity_rows, float *ones, gsdf_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  GSDF_TIMED("gsdf_visible_gather");
+  if (M == 0) return GSDF_OK;
+  GSDF_REQUIRE(M > 0 && gaussian_ids && (!xyz_rows || xyz) && (!opacity_rows || opacities), "visible_gather: bad arguments");
+  visible_gather_kernel<<<(unsigned)((M + 255) / 256), 256, 0, stream>>>(M, gaussian_ids, xyz, opacities, xyz_rows, opacity_rows, ones);
+  GSDF_CHECK_LAUNCH("visible_gather_kernel");
+  return GSDF_OK;
+}
+
+extern "C" int gsdf_rows_scatter_add(int64_t M, int cols, const int64_t *ids, int ids_unique, const float *src, float *dst, gsdf_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  GSDF_TIMED("gsdf_rows_scatter_add");
+  if (M == 0) return GSDF_OK;
+  GSDF_REQUIRE(M > 0 && ids && src && dst && (cols == 1 || cols == 3), "rows_scatter_add: bad arguments (cols 1 or 3)");
+  const unsigned grid = (unsigned)((M + 255) / 256);
+  if (cols == 3) {
+    if (ids_unique) rows_scatter_add_kernel<3, true><<<grid, 256, 0, stream>>>(M, ids, src, dst);
+    else rows_scatter_add_kernel<3, false><<<grid, 256, 0, stream>>>(M, ids, src, dst);
+  } else {
+    if (ids_unique) rows_scatter_add_kernel<1, true><<<grid, 256, 0, stream>>>(M, ids, src, dst);
+    else rows_scatter_add_kernel<1, false><<<grid, 256, 0, stream>>>(M, ids, src, dst);
+  }
+  GSDF_CHECK_LAUNCH("rows_scatter_add_kernel");
+  return GSDF_OK;
+}
+
 extern "C" int gsdf_nan_rows(int64_t n, const float *offsets, const float *scaling, const float *quaternion, int32_t *count,
                              uint8_t *mask, gsdf_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;

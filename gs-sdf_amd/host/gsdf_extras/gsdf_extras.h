@@ -237,6 +237,7 @@ class JointIteration {
   std::unique_ptr<JointStreams> streams_;
   std::function<void(torch::Tensor)> splat_hook_, sdf_hook_;
   std::function<void(std::map<std::string, torch::Tensor> &)> refine_hook_;
+  void count_nan_rows();
   void reduce_stats(std::initializer_list<const char *> keys);   // the hook on the statistics a consumer is about to use up, and only those
   std::map<std::string, int64_t> apply_row_map(RefinePlanArgs &pa);   // plan -> totals -> new buffers -> apply -> rebind
   void bind_views(const torch::Tensor &flat, const torch::Tensor &flat_grad, int64_t n);

@@ -383,7 +383,7 @@ std::map<std::string, int64_t> JointIteration::step(const Tensor &viewmat, const
   if (update) {
     adam_.step(/*zero_grad=*/fused_zero());
     if (!fused_zero()) flat_grad_.zero_();
-    if (cfg_.reference_terms) nan_total_.add_(nan_rows(views_[0], views_[1], views_[2]));   // prune_nan_gs's test, no host sync
+    if (cfg_.reference_terms) count_nan_rows();   // prune_nan_gs's test, no host sync
   }
   {
     c10::optional<StreamGuard> sg;
@@ -508,8 +508,11 @@ std::map<std::string, int64_t> JointIteration::step_direct(const Tensor &viewmat
   check(gsdf_tile_count(M, W, H, 16, fp(means2d), M ? radii.data_ptr<int32_t>() : nullptr, M ? tpg.data_ptr<int32_t>() : nullptr, cum.data_ptr<int64_t>(),
                         tws.data_ptr(), count_ptr(1), cur_stream()), "tile_encode(count)");
   // (while the host waits for I: the gathers and the colours, which the binning does not need)
-  Tensor samples = center ? xyz.index_select(0, gaussian_ids) : smp, samples_weights = center ? torch::ones({M, 1}, fopt) : sw;
-  Tensor pt_opac = opac.index_select(0, gaussian_ids);
+  // the visible rows of the activated parameters in one launch (xyz.index_select, opacities.index_select, torch::ones of the centre samples)
+  Tensor samples = center ? torch::empty({M, 3}, fopt) : smp, samples_weights = center ? torch::empty({M, 1}, fopt) : sw;
+  Tensor pt_opac = torch::empty({M}, fopt);
+  check(gsdf_visible_gather(M, M ? gaussian_ids.data_ptr<int64_t>() : nullptr, fp(xyz), fp(opac), center ? fpm(samples) : nullptr, fpm(pt_opac),
+                            center ? fpm(samples_weights) : nullptr, cur_stream()), "visible_gather");
   Tensor colors = torch::empty({M, 3}, fopt);
   check(gsdf_view_colors_fwd(M, Ksh, cfg_.sh_degree, fp(viewmat), fp(xyz), fp(sh), M ? camera_ids.data_ptr<int64_t>() : nullptr,
                              M ? gaussian_ids.data_ptr<int64_t>() : nullptr, fpm(colors), cur_stream()), "view_colors_fwd");
@@ -618,7 +621,7 @@ std::map<std::string, int64_t> JointIteration::step_direct(const Tensor &viewmat
     check(gsdf_splat_activations_bwd(N, fp(scales), fp(opac), nullptr /* xyz: accumulated in place */, fp(v_scales_act), fp(v_opac_dense), fpm(g_off),
                                      fpm(g_sc), fpm(g_op), cur_stream()), "splat_activations_bwd");
   };
-  v_opac_dense.index_add_(0, gaussian_ids, v_opac);
+  check(gsdf_rows_scatter_add(M, 1, M ? gaussian_ids.data_ptr<int64_t>() : nullptr, 1, fp(v_opac), fpm(v_opac_dense), cur_stream()), "rows_scatter_add(opacity)");
   if (center) projection_and_activations_bwd(Tensor());
   if (n_rest_ != 0) {
     seg(4).view({N, 1, 3}).add_(v_sh_tmp.narrow(1, 0, 1));
@@ -640,7 +643,8 @@ std::map<std::string, int64_t> JointIteration::step_direct(const Tensor &viewmat
     gs = f32c(gs, "samples gradient");
     gs.record_stream(main_stream);
     if (streams_->gate.armed) { streams_->gate.event.block(main_stream); streams_->gate.armed = false; }
-    if (center) g_off.index_add_(0, gaussian_ids, gs);
+    if (center)   // one camera: every splat appears once among the visible rows -> plain read-modify-write
+      check(gsdf_rows_scatter_add(M, 3, M ? gaussian_ids.data_ptr<int64_t>() : nullptr, 1, fp(gs), fpm(g_off), cur_stream()), "rows_scatter_add(samples)");
   }
   if (!center) projection_and_activations_bwd(gs);
   // ---- optimizers, each family on its leg's stream (view-parallel: the family's collective first, on the same stream)
@@ -648,7 +652,7 @@ std::map<std::string, int64_t> JointIteration::step_direct(const Tensor &viewmat
   if (update) {
     adam_.step(/*zero_grad=*/fused_zero());
     if (!fused_zero()) flat_grad_.zero_();
-    nan_total_.add_(nan_rows(views_[0], views_[1], views_[2]));   // prune_nan_gs's test, no host sync
+    count_nan_rows();   // prune_nan_gs's test, no host sync
   }
   {
     StreamGuard sg(streams_->side);
@@ -733,6 +737,13 @@ std::map<std::string, int64_t> JointIteration::apply_row_map(RefinePlanArgs &pa)
   adam_.replace_group(0, flat_, flat_grad_, m_new, v_new, sizes);
   state_ = std::move(state_new);
   return out;
+}
+
+// prune_nan_gs's per-iteration test (neural_gaussian.cpp:907-916) added to the running total in ONE launch (no memset, no add kernel)
+void JointIteration::count_nan_rows() {
+  torch::NoGradGuard ng;
+  const int64_t n = anchors_.size(0);
+  check(gsdf_nan_rows_accumulate(n, fp(views_[0]), fp(views_[1]), fp(views_[2]), nan_total_.data_ptr<int32_t>(), cur_stream()), "nan_rows_accumulate");
 }
 
 // The view-parallel hook reduces statistics IN PLACE (sum of grad2d / count, max of vis / radii over the ranks), which is not idempotent: every

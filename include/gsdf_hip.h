@@ -529,6 +529,15 @@ int gsdf_splat_activations_bwd(int64_t n, const float *scales, const float *opac
                                const float *v_scales, const float *v_opacities, float *g_offsets, float *g_log_scales,
                                float *g_logit_opacities, gsdf_stream_t stream);
 
+/* Row gathers / scatters of the visible set (ABI 8) — what the caller writes as xyz.index_select(0, gaussian_ids), opacities.index_select,
+ * torch::ones and index_add_ (include/neural_gaussian/neural_gaussian.cpp:259-262 centre samples; the samples' gradient back into the offsets):
+ *   visible_gather: xyz_rows[m] = xyz[ids[m]], opacity_rows[m] = opacities[ids[m]], ones[m] = 1 (any output may be NULL);
+ *   rows_scatter_add: dst[ids[m], :] += src[m, :], cols = 1 or 3; ids_unique != 0 (one camera: every splat appears once) -> plain
+ *   read-modify-write, else atomics. */
+int gsdf_visible_gather(int64_t n_visible, const int64_t *gaussian_ids, const float *xyz, const float *opacities, float *xyz_rows,
+                        float *opacity_rows, float *ones, gsdf_stream_t stream);
+int gsdf_rows_scatter_add(int64_t n_rows, int cols, const int64_t *ids, int ids_unique, const float *src, float *dst, gsdf_stream_t stream);
+
 /* isotropic regulariser of the visible splats (include/neural_mapping/neural_mapping.cpp:268-276):
  *     loss[0] = mean over [M,2] of |scale - mean(scale, -1)| with scale = scales[gaussian_ids][:, 0:2]  (= sum |s_u - s_v| / 2M);
  *     bwd ACCUMULATES v_loss[0] * d loss / d scales into v_scales [N,3]. */
@@ -543,6 +552,9 @@ int gsdf_isotropic_loss_fwd_bwd(int64_t n_visible, const float *scales, const in
  * with a NaN in offsets [n,3] / scaling [n,3] / quaternion [n,4]; mask u8 [n] (optional) marks them. */
 int gsdf_nan_rows(int64_t n, const float *offsets, const float *scaling, const float *quaternion, int32_t *count, uint8_t *mask,
                   gsdf_stream_t stream);
+/* the same test ADDED to a running total (no memset, no separate add: one launch per iteration in the joint step) */
+int gsdf_nan_rows_accumulate(int64_t n, const float *offsets, const float *scaling, const float *quaternion, int32_t *total,
+                             gsdf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * a8  NeuralGS::update_state (include/neural_gaussian/neural_gaussian.cpp:626-680) in one launch: the densification

@@ -3,9 +3,9 @@
 # ONE workload per run: the headline command only (--no-secondary --no-cpu-baseline), so that one CSV row = one kernel of one workload; the
 # detail record written next to each CSV (…detail.json: all_steps.mean_sdf_points, mean_M, mean_I over EVERY step the process ran, warm-up
 # included) holds the unit counts the row's average belongs to.
-# usage: tools/collect_profiles.sh r05 [quick]
+# usage: tools/collect_profiles.sh r06 [quick]
 set -u
-TAG=${1:-r05}
+TAG=${1:-r06}
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
@@ -31,5 +31,13 @@ for c in FETCH_SIZE WRITE_SIZE "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU" "SQ_WAVE_CYCL
   name=$(echo $c | tr ' ' '+')
   run pmc_$name --kernel-trace --pmc $c --output-format csv -d /tmp/p -- $B --steps 5 --warmup 1 --no-overlap
   python $REPO/tools/summarize_rocprof.py /tmp/p $OUT/${TAG}_bench_cfg3_pmc_$name.csv > /dev/null
+done
+# 4) round 6: the L1 / L2 / TA side of the kernels the TWO-STREAM step launches (the RESIDENT hash-grid forward, 3 workgroups per CU): the headline
+#    command without --no-overlap (counter collection serialises the kernels: the resident kernel's own figures)
+for c in "TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_PENDING_STALL_CYCLES_sum TCP_TOTAL_CACHE_ACCESSES_sum" \
+         "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_REQ_sum" "TA_TA_BUSY_sum TA_BUSY_avr GRBM_GUI_ACTIVE"; do
+  name=$(echo $c | tr ' ' '+')
+  run pmc2s_$name --kernel-trace --pmc $c --output-format csv -d /tmp/p -- $B --steps 5 --warmup 1
+  python $REPO/tools/summarize_rocprof.py /tmp/p $OUT/${TAG}_bench_cfg3_pmc2s_$name.csv > /dev/null
 done
 ls -la $OUT
