@@ -156,6 +156,7 @@ __global__ void __launch_bounds__(RT, RASTER_BWD_QUADS_WGS)
   float bgdot = 0.f;
   if (backgrounds != nullptr)
     bgdot = backgrounds[3 * cam] * vCr + backgrounds[3 * cam + 1] * vCg + backgrounds[3 * cam + 2] * vCb;
+  const float tfa = T_final * (vA - bgdot);   // the alpha / background term of every pair of this pixel: T_final (vA - bg . vC) / (1 - alpha)
   float T = T_final;
   float bCr = 0.f, bCg = 0.f, bCb = 0.f, bNx = 0.f, bNy = 0.f, bNz = 0.f, bD = 0.f;
 
@@ -274,7 +275,7 @@ __global__ void __launch_bounds__(RT, RASTER_BWD_QUADS_WGS)
         float v_alpha = (cR * T - bCr * ra) * vCr + (cG * T - bCg * ra) * vCg + (cB * T - bCb * ra) * vCb;
         v_alpha += (nX * T - bNx * ra) * vNx + (nY * T - bNy * ra) * vNy + (nZ * T - bNz * ra) * vNz;
         v_alpha += (e.dep * T - bD * ra) * vD;
-        v_alpha += T_final * ra * (vA - bgdot);
+        v_alpha += tfa * ra;
         const float v_dep = fac * vD + ((bstart + t) == med_idx ? vMed : 0.f);
         bCr += cR * fac; bCg += cG * fac; bCb += cB * fac;
         bNx += nX * fac; bNy += nY * fac; bNz += nZ * fac;

@@ -15,6 +15,7 @@ from concurrent.futures import ThreadPoolExecutor
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "gs-sdf_amd", "csrc")
 NO_CONTRACT = {"projection", "binning", "radix", "occupancy", "marching_cubes", "refine"}      # as the Makefile builds them
+NO_SLP = {"raster_fwd", "raster_bwd"}
 PAT = re.compile(r"- \.agpr_count:\s+(\d+).*?\.group_segment_fixed_size:\s+(\d+).*?\.max_flat_workgroup_size:\s+(\d+).*?\.name:\s+(\S+).*?"
                  r"\.private_segment_fixed_size:\s+(\d+).*?\.sgpr_count:\s+(\d+).*?\.sgpr_spill_count:\s+(\d+).*?\.vgpr_count:\s+(\d+).*?"
                  r"\.vgpr_spill_count:\s+(\d+)", re.S)
@@ -25,6 +26,8 @@ def assemble(src, out):
     cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", f"-I{ROOT}/include", f"-I{CSRC}", "--cuda-device-only", "-S", src, "-o", out]
     if stem in NO_CONTRACT:
         cmd.insert(4, "-ffp-contract=off")
+    if stem in NO_SLP:
+        cmd.insert(4, "-fno-slp-vectorize")
     subprocess.run(cmd, check=True, capture_output=True, cwd=CSRC)
     return out
 
