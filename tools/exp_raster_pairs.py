@@ -6,11 +6,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import gs_sdf_amd.capi as capi, gs_sdf_amd.ops as ops, gs_sdf_amd.synth as synth
 sys.path.insert(0, ROOT)
-from bench import WORKLOADS
+from bench import WORKLOADS, WORKLOAD_SIGMA_PX
 dev = torch.device("cuda:0")
 name = sys.argv[1] if len(sys.argv) > 1 else "cfg3_1M_1080p"
 N, W, H, deg, replica = WORKLOADS[name]
-sc = synth.make_scene(N, W, H, sh_degree=deg, seed=0, replica=replica)
+sc = synth.make_scene(N, W, H, sh_degree=deg, seed=0, replica=replica, sigma_px=WORKLOAD_SIGMA_PX.get(name, (0.5, 4.0)))
 vm = synth.make_views(2, seed=1)[1:2].to(dev)
 cnt = torch.zeros(16, dtype=torch.int64, device=dev)
 d = lambda t: t.to(dev)

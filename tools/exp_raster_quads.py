@@ -14,10 +14,10 @@ if len(sys.argv) > 2 and sys.argv[2] == "child":
     if os.environ.get("GSDF_EXP_LIB"):      # compile-time variant of the library (tools/build_variants.sh), this tool only
         capi.LIB_PATH = os.path.join(ROOT, "gs-sdf_amd", "lib", "variants", os.environ["GSDF_EXP_LIB"], "libgsdf_hip.so")
     import gs_sdf_amd.ops as ops, gs_sdf_amd.synth as synth
-    from bench import WORKLOADS
+    from bench import WORKLOADS, WORKLOAD_SIGMA_PX
     dev = torch.device("cuda:0")
     N, W, H, deg, replica = WORKLOADS[sys.argv[1]]
-    sc = synth.make_scene(N, W, H, sh_degree=deg, seed=0, replica=replica)
+    sc = synth.make_scene(N, W, H, sh_degree=deg, seed=0, replica=replica, sigma_px=WORKLOAD_SIGMA_PX.get(sys.argv[1], (0.5, 4.0)))
     vm = synth.make_views(2, seed=1)[1:2].to(dev)
     d = lambda t: t.to(dev)
     with torch.no_grad():
