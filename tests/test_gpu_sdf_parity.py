@@ -470,8 +470,9 @@ def test_xcd_partitioned_forward_is_bit_identical_to_the_plain_kernel(sdf, jac):
                                                 (dict(CFG, n_levels=5), 1, False)])
 def test_hashgrid_binned_scatter_matches_atomic_and_oracle(sdf, oracle, cfg, B, concentrated):
     """gsdf_hashgrid_bwd_binned (count -> plan -> emit -> apply, no global atomics) against the atomic kernel and the
-    oracle.  `concentrated`: every point in ONE cell of the coarsest level, so that a bucket receives more than
-    BIN_ITEM_MAX (512 K) records and is split into several work items (the atomic flush path of the apply kernel)."""
+    oracle.  `concentrated`: every point in ONE cell of the coarsest level, so that every level's buckets receive many times
+    the records of a work item (32 K at this batch size) and are split: the items of a bucket meet in a 64-bit global tile by
+    integer atomics, so the split buckets are bit-reproducible too (round 6; the uniform case splits level 0's nine tiles)."""
     import ctypes as C
     import gs_sdf_amd.capi as capi
     dev = torch.device("cuda:0")
@@ -523,11 +524,11 @@ def test_hashgrid_binned_scatter_matches_atomic_and_oracle(sdf, oracle, cfg, B, 
     torch.cuda.synchronize()
     assert_close(got2, vt_o, 1e-4, "binned scatter, reused workspace")
     within_record_rounding(got2, "binned scatter, reused workspace")
-    if not concentrated:       # no bucket is split (<= 2^19 records per tile): bit-reproducible
-        got3 = torch.zeros_like(seed)
-        capi.check(L.gsdf_hashgrid_bwd_binned(B, *c, capi.f32(xd), capi.f32(vd), capi.f32(got3), capi.ptr(ws), nbytes, capi.stream()), "binned")
-        torch.cuda.synchronize()
-        assert torch.equal(got2, got3), "binned scatter is not bit-reproducible"
+    # whole and split buckets alike: every sum is an integer sum, whatever the order of arrival
+    got3 = torch.zeros_like(seed)
+    capi.check(L.gsdf_hashgrid_bwd_binned(B, *c, capi.f32(xd), capi.f32(vd), capi.f32(got3), capi.ptr(ws), nbytes, capi.stream()), "binned")
+    torch.cuda.synchronize()
+    assert torch.equal(got2, got3), "binned scatter is not bit-reproducible"
 
 
 def test_encoder_backward_takes_binned_path_for_large_batches(sdf, oracle, monkeypatch):
