@@ -109,6 +109,8 @@ def main():
     ap.add_argument("--splat-order", default="as-given", choices=["morton", "as-given"],
                     help="memory order of the splat set: the synthetic scene's random order, or Morton order of the centres "
                          "(trainer.morton_order; measured: no gain, the fine hash-grid levels scatter either way, DESIGN.md section 11)")
+    ap.add_argument("--step-trace", default="", help="write a device timeline of the C-ABI entry points (begin us, end us, duration, name; HIP events, no "
+                    "profiler) of six steps after the timed region to this file")
     ap.add_argument("--hashgrid-resident", type=int, default=-1,
                     help="C++ step, two streams: workgroups per CU of the stencil hash-grid forward's resident grid (JointConfig::hashgrid_resident; "
                          "-1 = its default, 0 = the full grid)")
@@ -509,6 +511,17 @@ def main():
         step(nxt + i)
     nxt += min(10, args.steps)
     kern_all = timers_end()[0]
+    if args.step_trace and impl == "cpp" and rank == 0:
+        # a device timeline of the entry points without a profiler attached: begin / end of every C-ABI call over a few more steps
+        torch.cuda.synchronize()
+        capi.timing_begin(None)
+        for i in range(6):
+            step(nxt + i)
+        nxt += 6
+        torch.cuda.synchronize()
+        with open(args.step_trace, "w") as f:
+            for name, a, b in capi.timing_trace():
+                f.write(f"{a * 1e3:10.1f} {b * 1e3:10.1f} {(b - a) * 1e3:8.1f} {name}\n")
     # The roofline kernels ALONE on the chip: the same step on ONE stream (a second JointIteration, same scene and views), HIP events on that
     # stream.  In the two-stream step a launch's duration includes the slowdown from the other leg's kernels running beside it (this round the
     # hash-grid forward runs beside the compositing backward: 2.4 ms there, 1.7 ms alone, the step equally fast) — `roofline.frac` keeps the

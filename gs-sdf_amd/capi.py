@@ -15,7 +15,7 @@ _lib = None
 
 _i64, _i32, _f32, _u64, _vp, _sz = C.c_int64, C.c_int, C.c_float, C.c_uint64, C.c_void_p, C.c_size_t
 
-ABI_VERSION = 8      # include/gsdf_hip.h: GSDF_ABI_VERSION this binding was written against
+ABI_VERSION = 9      # include/gsdf_hip.h: GSDF_ABI_VERSION this binding was written against
 
 
 class RasterInstr(C.Structure):
@@ -28,6 +28,7 @@ _SIGS = {
     "gsdf_last_error": (C.c_char_p, []),
     "gsdf_timing_begin": (C.c_int, [C.c_char_p]),
     "gsdf_timing_end": (_sz, [C.c_char_p, _sz]),
+    "gsdf_timing_trace": (_sz, [C.c_char_p, _sz]),
     "gsdf_host_words_alloc": (C.c_int, [_i32, _vp, _vp]),
     "gsdf_host_words_free": (C.c_int, [_vp]),
     "gsdf_projection_2dgs_ws_bytes": (_sz, [_i64, _i64]),
@@ -64,6 +65,7 @@ _SIGS = {
     "gsdf_hashgrid_bwd_binned": (C.c_int, [_i64, _i32, _i32, _i32, _i32, _f32] + [_vp] * 4 + [_sz, _vp]),
     "gsdf_hashgrid_bwd_binned_stencil": (C.c_int, [_i64, _i64, _i32, _i32, _i32, _i32, _i32, _f32] + [_vp] * 4 + [_sz, _vp]),
     "gsdf_hashgrid_bwd_bwd": (C.c_int, [_i64, _i32, _i32, _i32, _i32, _f32] + [_vp] * 8),
+    "gsdf_hashgrid_bwd_bwd_bwd": (C.c_int, [_i64, _i32, _i32, _i32, _i32, _f32] + [_vp] * 11),
     "gsdf_mlp_fwd": (C.c_int, [_i64, _i32] + [_vp] * 7),
     "gsdf_mlp_acts_floats": (_sz, [_i64, _i32]),
     "gsdf_mlp_bwd_ws_bytes": (_sz, [_i64, _i32]),
@@ -218,6 +220,17 @@ def timing_end():
     buf = C.create_string_buffer(1 << 16)      # one line per entry point: ~100 lines of < 100 bytes at most
     lib().gsdf_timing_end(buf, len(buf))
     return _parse_timing(buf.value.decode())
+
+
+def timing_trace():
+    """-> [(entry point, begin_ms, end_ms)] in call order, relative to the first call's begin event; stops the timing."""
+    buf = C.create_string_buffer(1 << 22)      # (the call hands the collection over once: one buffer large enough for ~50 k calls)
+    lib().gsdf_timing_trace(buf, len(buf))
+    out = []
+    for ln in buf.value.decode().splitlines():
+        name, a, b = ln.split()
+        out.append((name, float(a), float(b)))
+    return out
 
 
 def _parse_timing(txt):

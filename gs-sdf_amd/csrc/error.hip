@@ -135,3 +135,31 @@ extern "C" size_t gsdf_timing_end(char *buf, size_t cap) {
   }
   return out.size() + 1;
 }
+
+// one line per timed call in the order of the calls, "name begin_ms end_ms" relative to the first call's begin event (events of different streams
+// compare on one device): a device timeline of the entry points without a profiler attached (bench.py --step-trace).  Stops the timing like _end.
+extern "C" size_t gsdf_timing_trace(char *buf, size_t cap) {
+  gsdf::g_timing_on.store(0);
+  std::vector<gsdf::TimedCall> calls;
+  {
+    std::lock_guard<std::mutex> lock(gsdf::g_timing_mutex);
+    calls.swap(gsdf::g_timed);
+  }
+  std::string out;
+  char line[256];
+  for (auto &c : calls) (void)hipEventSynchronize(c.b);
+  for (auto &c : calls) {
+    float a = 0.f, b = 0.f;
+    if (hipEventElapsedTime(&a, calls[0].a, c.a) == hipSuccess && hipEventElapsedTime(&b, calls[0].a, c.b) == hipSuccess) {
+      snprintf(line, sizeof(line), "%s %.6f %.6f\n", c.name, a, b);
+      out += line;
+    }
+  }
+  for (auto &c : calls) { (void)hipEventDestroy(c.a); (void)hipEventDestroy(c.b); }
+  if (buf != nullptr && cap > 0) {
+    const size_t n = out.size() < cap - 1 ? out.size() : cap - 1;
+    memcpy(buf, out.data(), n);
+    buf[n] = 0;
+  }
+  return out.size() + 1;
+}

@@ -489,6 +489,72 @@ __global__ void __launch_bounds__(HGB_THREADS)
   }
 }
 
+// third order: the backward of the double backward above, for lam_x (the gradient arriving at g_x) and mu (arriving at g_vfeat; NULL = zero).
+// What a loss on the analytic Hessian needs (LocalMap::get_gradient(hessian = true, numerical_grad = 0) + curvate_loss,
+// /root/reference/include/neural_net/local_map.cpp:151-168, include/neural_mapping/neural_mapping.cpp:117-121).  Trilinear weights: the second
+// derivatives of a corner weight are the mixed ones, s_d s_e scale^2 w_r (r the remaining axis); the third is s_x s_y s_z scale^3.
+// Off the hot path (curvate_weight is 0 in every shipped configuration): the 4-lanes-per-(point, level) form of the kernels above, atomics on the table.
+template <bool WANT_TABLE>
+__global__ void __launch_bounds__(HGB_THREADS)
+    hashgrid_bwd3_kernel(int64_t B, HgLevels lv, const float *__restrict__ x, const float *__restrict__ table,
+                         const float *__restrict__ v_feat, const float *__restrict__ vv_x, const float *__restrict__ lam_x,
+                         const float *__restrict__ mu, float *__restrict__ t_vfeat, float *__restrict__ t_table,
+                         float *__restrict__ t_vv, float *__restrict__ t_x) {
+  const int lane = threadIdx.x & 63;
+  const int f = lane & 1, xb = (lane >> 1) & 1, level = lane >> 2;
+  const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= B) return;  // wave-uniform
+  float tvx = 0.f, tvy = 0.f, tvz = 0.f, txx = 0.f, txy = 0.f, txz = 0.f, tvf = 0.f;
+  if (level < lv.n_levels) {
+    Cell c;
+    load_cell(lv, level, x, b, table, c);
+    const float vf = v_feat[(b * lv.n_levels + level) * 2 + f];
+    const float m = mu != nullptr ? mu[(b * lv.n_levels + level) * 2 + f] : 0.f;
+    const float ax = vv_x[3 * b], ay = vv_x[3 * b + 1], az = vv_x[3 * b + 2];
+    const float lx = lam_x[3 * b], ly = lam_x[3 * b + 1], lz = lam_x[3 * b + 2];
+    float *tt = t_table + (int64_t)lv.offset[level] * 2 + f;
+    const float *tb = table + (int64_t)lv.offset[level] * 2 + f;
+    const float wx = xb ? c.fr[0] : 1.f - c.fr[0], sx = xb ? 1.f : -1.f;
+    const float s1 = c.scale, s2 = c.scale * c.scale, s3 = s2 * c.scale;
+    // symmetric pair sums of (vv, lam)
+    const float pxy = ax * ly + ay * lx, pxz = ax * lz + az * lx, pyz = ay * lz + az * ly;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int hy = k & 1, hz = k >> 1;
+      const uint32_t idx = grid_index(c.hsize, c.res, c.g0[0] + xb, c.g0[1] + hy, c.g0[2] + hz);
+      const float wy = hy ? c.fr[1] : 1.f - c.fr[1], wz = hz ? c.fr[2] : 1.f - c.fr[2];
+      const float sy = hy ? 1.f : -1.f, sz = hz ? 1.f : -1.f;
+      const float dx = sx * wy * wz, dy = sy * wx * wz, dz = sz * wx * wy;          // d w / d pos
+      const float dxy = sx * sy * wz, dxz = sx * sz * wy, dyz = sy * sz * wx;      // mixed second derivatives
+      const float A = s1 * (ax * dx + ay * dy + az * dz);
+      const float Bk = s2 * (pxy * dxy + pxz * dxz + pyz * dyz);
+      const float th = tb[2 * (int64_t)idx];
+      if (WANT_TABLE) atomicAdd(tt + 2 * (int64_t)idx, vf * Bk + m * A);
+      tvf += Bk * th;
+      const float q = vf * th, r = m * th;
+      tvx += q * s2 * (ly * dxy + lz * dxz) + r * s1 * dx;
+      tvy += q * s2 * (lx * dxy + lz * dyz) + r * s1 * dy;
+      tvz += q * s2 * (lx * dxz + ly * dyz) + r * s1 * dz;
+      const float d3 = s3 * sx * sy * sz;
+      txx += q * d3 * pyz + r * s2 * (ay * dxy + az * dxz);
+      txy += q * d3 * pxz + r * s2 * (ax * dxy + az * dyz);
+      txz += q * d3 * pxy + r * s2 * (ax * dxz + ay * dyz);
+    }
+  }
+  if (t_vfeat != nullptr) {
+    tvf += dpp_mov<0x4E>(tvf);  // quad_perm [2,3,0,1]: add the other x-corner's partial (same feature)
+    if (xb == 0 && level < lv.n_levels) t_vfeat[(b * lv.n_levels + level) * 2 + f] = tvf;
+  }
+  if (t_vv != nullptr) {
+    tvx = wave_sum_to_lane63(tvx); tvy = wave_sum_to_lane63(tvy); tvz = wave_sum_to_lane63(tvz);
+    if (lane == 63) { t_vv[3 * b] = tvx; t_vv[3 * b + 1] = tvy; t_vv[3 * b + 2] = tvz; }
+  }
+  if (t_x != nullptr) {
+    txx = wave_sum_to_lane63(txx); txy = wave_sum_to_lane63(txy); txz = wave_sum_to_lane63(txz);
+    if (lane == 63) { t_x[3 * b] = txx; t_x[3 * b + 1] = txy; t_x[3 * b + 2] = txz; }
+  }
+}
+
 }  // namespace gsdf
 
 using namespace gsdf;
@@ -637,5 +703,23 @@ extern "C" int gsdf_hashgrid_bwd_bwd(int64_t B, int n_levels, int n_feat, int lo
   }
 #undef L
   GSDF_CHECK_LAUNCH("hashgrid_bwd_bwd_kernel");
+  return GSDF_OK;
+}
+
+extern "C" int gsdf_hashgrid_bwd_bwd_bwd(int64_t B, int n_levels, int n_feat, int log2_hashmap, int base_res, float per_level_scale,
+                                         const float *x, const float *table, const float *v_feat, const float *vv_x, const float *lam_x,
+                                         const float *mu_vfeat, float *t_vfeat, float *t_table, float *t_vv, float *t_x, gsdf_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  GSDF_TIMED("gsdf_hashgrid_bwd_bwd_bwd");
+  int rc = check_cfg(n_levels, n_feat, log2_hashmap, base_res, per_level_scale, "hashgrid_bwd_bwd_bwd");
+  if (rc) return rc;
+  if (B == 0 || (!t_vfeat && !t_table && !t_vv && !t_x)) return GSDF_OK;
+  GSDF_REQUIRE(x && table && v_feat && vv_x && lam_x, "hashgrid_bwd_bwd_bwd: null buffer");
+  HgLevels lv;
+  build_levels(n_levels, log2_hashmap, base_res, per_level_scale, &lv, nullptr);
+  const unsigned nb = (unsigned)((B + 3) / 4);
+  if (t_table) hashgrid_bwd3_kernel<true><<<nb, HG_THREADS, 0, stream>>>(B, lv, x, table, v_feat, vv_x, lam_x, mu_vfeat, t_vfeat, t_table, t_vv, t_x);
+  else hashgrid_bwd3_kernel<false><<<nb, HG_THREADS, 0, stream>>>(B, lv, x, table, v_feat, vv_x, lam_x, mu_vfeat, t_vfeat, t_table, t_vv, t_x);
+  GSDF_CHECK_LAUNCH("hashgrid_bwd3_kernel");
   return GSDF_OK;
 }

@@ -25,20 +25,21 @@ std::vector<int64_t> cfg_pack(const GridCfg &c) {
   return {c.L, c.F, c.H, c.R, bits, c.stencil_n, c.merge_levels};
 }
 
-// (v_feat, x, table) -> (v_x, v_table): the encoding's backward as a differentiable op (grad of grad)
-// The double-backward operators below are evaluated by kernels inside a backward(): libtorch records nothing for them, so a THIRD derivative
-// (LocalMap::get_gradient with hessian = true and numerical_grad = 0, then a loss on the Hessian — the reference's curvate_weight > 0,
-// /root/reference/include/neural_net/local_map.cpp:163-168; default 0.0, config/base.yaml:32) would silently be missing.  When such a backward runs
-// with create_graph = true its results pass through this node: their VALUES are exact (second order), differentiating them again raises.
+// Orders of differentiation.  LocalMap::get_gradient with hessian = true and numerical_grad = 0, then a loss on the Hessian (the reference's
+// curvate_weight > 0, /root/reference/include/neural_net/local_map.cpp:163-168, neural_mapping.cpp:117-121; default 0.0, config/base.yaml:32) takes a
+// THIRD derivative of the encoding: GridFwd -> GridBwd -> GridBwd2 (the double backward as an operator of its own, round 6) -> gsdf_hashgrid_bwd_bwd_bwd.
+// The decoder's part of that loss needs nothing new: the Hessian row sums depend on the decoder through v_feat = d sdf / d feat only, and d loss /
+// d v_feat arrives at MlpBwd's double backward like the eikonal term's.  What is evaluated by kernels inside a backward() and has no operator of
+// its own — the decoder's double backward, the encoding's third order — passes through this node when create_graph = true: the VALUES are exact,
+// differentiating them again (a fourth derivative of the encoding, a third of the decoder's weight path) raises instead of silently missing a term.
 struct ThirdOrderGuard : public torch::autograd::Function<ThirdOrderGuard> {
   static Tensor forward(AutogradContext *, const Tensor &value, const Tensor &anchor) {
     (void)anchor;   // an input that requires grad: it puts this node on the graph
     return value.view_as(value);
   }
   static tensor_list backward(AutogradContext *, tensor_list) {
-    TORCH_CHECK(false, "TCNNEncoding / TCNNNetwork: third-order derivatives are not implemented (a loss on the analytic Hessian, curvate_weight > 0 with "
-                       "numerical_grad = 0); use the numerical branch of LocalMap::get_gradient (numerical_grad = 1), whose Hessian is first order in "
-                       "the network");
+    TORCH_CHECK(false, "TCNNEncoding / TCNNNetwork: derivatives of this order are not implemented (the encoding is differentiable three times — a "
+                       "loss on the analytic Hessian trains —, the decoder's weight path twice)");
     return {};
   }
 };
@@ -76,34 +77,87 @@ struct GridBwd : public torch::autograd::Function<GridBwd> {
     }
     return {v_x, v_table};
   }
+  static tensor_list backward(AutogradContext *ctx, tensor_list g);
+};
+
+// the grid's double backward: (vv_x, v_feat, x, table) -> (g_vfeat, g_x, g_table), one kernel (+ the binned scatter for large batches)
+static void grid_double_backward(const GridCfg &c, const Tensor &vv, const Tensor &v_feat, const Tensor &x, const Tensor &table, Tensor &g_vfeat,
+                                 Tensor &g_x, Tensor &g_table) {
+  const int64_t B = x.size(0);
+  // large batches: the table part of the double backward through the binned scatter's second-order form (no global atomics)
+  const size_t binned = (g_table.defined() && B >= 24576) ? gsdf_hashgrid_bwd_binned_ws_bytes(B, c.L, c.F, c.H, c.R, c.S) : 0;
+  if (binned) {
+    Tensor ws = empty_like_opts(x, {(int64_t)binned}, torch::kUInt8);
+    check(gsdf_hashgrid_bwd_binned2(B, c.L, c.F, c.H, c.R, c.S, fp(x), nullptr, fp(v_feat), fp(vv), fpm(g_table), ws.data_ptr(), binned,
+                                    cur_stream()), "TCNNEncoding double backward (binned scatter)");
+  }
+  if (g_vfeat.defined() || g_x.defined() || (g_table.defined() && !binned))
+    check(gsdf_hashgrid_bwd_bwd(B, c.L, c.F, c.H, c.R, c.S, fp(x), fp(table), fp(v_feat), fp(vv), fpm(g_vfeat),
+                                binned ? nullptr : fpm(g_table), fpm(g_x), cur_stream()),
+          "TCNNEncoding double backward");
+}
+
+// The double backward as an operator (create_graph = true while it runs: LocalMap::get_gradient's second autograd::grad call, local_map.cpp:163-166);
+// its own backward is the encoding's THIRD order, gsdf_hashgrid_bwd_bwd_bwd.
+struct GridBwd2 : public torch::autograd::Function<GridBwd2> {
+  static tensor_list forward(AutogradContext *ctx, const Tensor &vv_, const Tensor &v_feat, const Tensor &x, const Tensor &table,
+                             std::vector<int64_t> cfgv, bool want_vfeat, bool want_x, bool want_table) {
+    const GridCfg c = cfg_of(c10::IValue(cfgv));
+    Tensor vv = f32c(vv_, "vv_x");
+    Tensor g_vfeat = want_vfeat ? torch::empty_like(v_feat) : Tensor();
+    Tensor g_x = want_x ? torch::empty_like(x) : Tensor();
+    Tensor g_table = want_table ? torch::zeros_like(table) : Tensor();
+    grid_double_backward(c, vv, v_feat, x, table, g_vfeat, g_x, g_table);
+    ctx->save_for_backward({vv, v_feat, x, table});
+    ctx->saved_data["cfg"] = cfgv;
+    tensor_list out = {g_vfeat, g_x, g_table};
+    std::vector<Tensor> dead;
+    for (int i = 0; i < 3; ++i) {
+      if (!out[i].defined()) out[i] = torch::zeros({0}, x.options());
+      // (a loss on the TABLE gradient of the double backward is nobody's path: not differentiable here)
+      if (out[i].numel() == 0 || i == 2) dead.push_back(out[i]);
+    }
+    ctx->mark_non_differentiable(dead);
+    return out;
+  }
   static tensor_list backward(AutogradContext *ctx, tensor_list g) {
     auto s = ctx->get_saved_variables();
-    const Tensor &v_feat = s[0], &x = s[1], &table = s[2];
+    const Tensor &vv = s[0], &v_feat = s[1], &x = s[2], &table = s[3];
     const GridCfg c = cfg_of(ctx->saved_data["cfg"]);
-    if (!g[0].defined()) return {Tensor(), Tensor(), Tensor(), Tensor(), Tensor()};
-    Tensor vv = f32c(g[0], "vv_x");
-    Tensor g_vfeat = ctx->needs_input_grad(0) ? torch::empty_like(v_feat) : Tensor();
-    Tensor g_x = ctx->needs_input_grad(1) ? torch::empty_like(x) : Tensor();
-    Tensor g_table = ctx->needs_input_grad(2) ? torch::zeros_like(table) : Tensor();
+    tensor_list none(8);
+    if (!g[0].defined() && !g[1].defined()) return none;
     const int64_t B = x.size(0);
-    // large batches: the table part of the double backward through the binned scatter's second-order form (no global atomics)
-    const size_t binned = (g_table.defined() && B >= 24576) ? gsdf_hashgrid_bwd_binned_ws_bytes(B, c.L, c.F, c.H, c.R, c.S) : 0;
-    if (binned) {
-      Tensor ws = empty_like_opts(x, {(int64_t)binned}, torch::kUInt8);
-      check(gsdf_hashgrid_bwd_binned2(B, c.L, c.F, c.H, c.R, c.S, fp(x), nullptr, fp(v_feat), fp(vv), fpm(g_table), ws.data_ptr(), binned,
-                                      cur_stream()), "TCNNEncoding double backward (binned scatter)");
-    }
-    if (g_vfeat.defined() || g_x.defined() || (g_table.defined() && !binned)) {
-      Tensor none;
-      check(gsdf_hashgrid_bwd_bwd(B, c.L, c.F, c.H, c.R, c.S, fp(x), fp(table), fp(v_feat), fp(vv), fpm(g_vfeat),
-                                  binned ? nullptr : fpm(g_table), fpm(g_x), cur_stream()),
-            "TCNNEncoding double backward");
-    }
-    // (anchor: the first saved input that is part of a graph)
+    Tensor mu = g[0].defined() ? f32c(g[0], "gradient of g_vfeat") : Tensor();
+    Tensor lam = g[1].defined() ? f32c(g[1], "gradient of g_x") : torch::zeros_like(x);
+    Tensor t_vv = ctx->needs_input_grad(0) ? torch::empty_like(vv) : Tensor();
+    Tensor t_vfeat = ctx->needs_input_grad(1) ? torch::empty_like(v_feat) : Tensor();
+    Tensor t_x = ctx->needs_input_grad(2) ? torch::empty_like(x) : Tensor();
+    Tensor t_table = ctx->needs_input_grad(3) ? torch::zeros_like(table) : Tensor();
+    check(gsdf_hashgrid_bwd_bwd_bwd(B, c.L, c.F, c.H, c.R, c.S, fp(x), fp(table), fp(v_feat), fp(vv), fp(lam), fp(mu), fpm(t_vfeat), fpm(t_table),
+                                    fpm(t_vv), fpm(t_x), cur_stream()), "TCNNEncoding third-order backward");
     const Tensor &anchor = table.requires_grad() ? table : (x.requires_grad() ? x : v_feat);
-    return {guard3(g_vfeat, anchor), guard3(g_x, anchor), guard3(g_table, anchor), Tensor(), Tensor()};
+    return {guard3(t_vv, anchor), guard3(t_vfeat, anchor), guard3(t_x, anchor), guard3(t_table, anchor), Tensor(), Tensor(), Tensor(), Tensor()};
   }
 };
+
+tensor_list GridBwd::backward(AutogradContext *ctx, tensor_list g) {
+  auto s = ctx->get_saved_variables();
+  const Tensor &v_feat = s[0], &x = s[1], &table = s[2];
+  if (!g[0].defined()) return {Tensor(), Tensor(), Tensor(), Tensor(), Tensor()};
+  if (torch::GradMode::is_enabled()) {   // create_graph = true: the double backward stays on the graph (third order)
+    auto o = GridBwd2::apply(g[0], v_feat, x, table, ctx->saved_data["cfg"].toIntVector(), ctx->needs_input_grad(0), ctx->needs_input_grad(1),
+                             ctx->needs_input_grad(2));
+    return {ctx->needs_input_grad(0) ? o[0] : Tensor(), ctx->needs_input_grad(1) ? o[1] : Tensor(), ctx->needs_input_grad(2) ? o[2] : Tensor(), Tensor(),
+            Tensor()};
+  }
+  const GridCfg c = cfg_of(ctx->saved_data["cfg"]);
+  Tensor vv = f32c(g[0], "vv_x");
+  Tensor g_vfeat = ctx->needs_input_grad(0) ? torch::empty_like(v_feat) : Tensor();
+  Tensor g_x = ctx->needs_input_grad(1) ? torch::empty_like(x) : Tensor();
+  Tensor g_table = ctx->needs_input_grad(2) ? torch::zeros_like(table) : Tensor();
+  grid_double_backward(c, vv, v_feat, x, table, g_vfeat, g_x, g_table);
+  return {g_vfeat, g_x, g_table, Tensor(), Tensor()};
+}
 
 struct GridFwd : public torch::autograd::Function<GridFwd> {
   static Tensor forward(AutogradContext *ctx, const Tensor &x_, const Tensor &table_, std::vector<int64_t> cfgv) {

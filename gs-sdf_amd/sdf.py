@@ -139,29 +139,77 @@ class _GridBwd(torch.autograd.Function):
     @staticmethod
     def backward(ctx, vv_x, _vv_table):
         # second order w.r.t. the table gradient output is never requested by the reference
-        L = capi.lib()
         v_feat, x, table = ctx.saved_tensors
-        B = x.shape[0]
         need_vf, need_x, need_t = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2]
         if vv_x is None:
             return None, None, None, None, None, None, None, None, None
-        g_vfeat = torch.empty_like(v_feat) if need_vf else None
-        g_x = torch.empty_like(x) if need_x else None
-        g_table = torch.zeros_like(table) if need_t else None
-        vv_x = vv_x.contiguous()
-        # table part: large batches take the binned scatter's second-order form (no global atomics), like the first order
-        nbytes = 0
-        if need_t and os.environ.get("GSDF_HASHGRID_BINNED", "auto") != "0" and \
-                (os.environ.get("GSDF_HASHGRID_BINNED") == "1" or B >= BINNED_MIN_POINTS):
-            nbytes = L.gsdf_hashgrid_bwd_binned_ws_bytes(B, *ctx.cfg)
-        if nbytes:
-            ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
-            capi.check(_timed("hashgrid_bwd_bwd_table", L.gsdf_hashgrid_bwd_binned2, B, *ctx.cfg, f32(x), None, f32(v_feat), f32(vv_x),
-                              f32(g_table), ptr(ws), nbytes, capi.stream()), "hashgrid_bwd_binned2")
-        if need_vf or need_x or (need_t and not nbytes):
-            capi.check(_timed("hashgrid_bwd_bwd", L.gsdf_hashgrid_bwd_bwd, B, *ctx.cfg, f32(x), f32(table), f32(v_feat),
-                              f32(vv_x), f32(g_vfeat), f32(None if nbytes else g_table), f32(g_x), capi.stream()), "hashgrid_bwd_bwd")
+        if torch.is_grad_enabled():      # create_graph=True: the double backward stays on the graph (a loss on the analytic Hessian)
+            g_vfeat, g_x, g_table = _GridBwd2.apply(vv_x, v_feat, x, table, ctx.cfg, need_vf, need_x, need_t)
+            return (g_vfeat if need_vf else None), (g_x if need_x else None), (g_table if need_t else None), None, None, None, None, None, None
+        g_vfeat, g_x, g_table = _grid_double_backward(ctx.cfg, vv_x, v_feat, x, table, need_vf, need_x, need_t)
         return g_vfeat, g_x, g_table, None, None, None, None, None, None
+
+
+def _grid_double_backward(cfg, vv_x, v_feat, x, table, need_vf, need_x, need_t):
+    L = capi.lib()
+    B = x.shape[0]
+    g_vfeat = torch.empty_like(v_feat) if need_vf else None
+    g_x = torch.empty_like(x) if need_x else None
+    g_table = torch.zeros_like(table) if need_t else None
+    vv_x = vv_x.contiguous()
+    # table part: large batches take the binned scatter's second-order form (no global atomics), like the first order
+    nbytes = 0
+    if need_t and os.environ.get("GSDF_HASHGRID_BINNED", "auto") != "0" and \
+            (os.environ.get("GSDF_HASHGRID_BINNED") == "1" or B >= BINNED_MIN_POINTS):
+        nbytes = L.gsdf_hashgrid_bwd_binned_ws_bytes(B, *cfg)
+    if nbytes:
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+        capi.check(_timed("hashgrid_bwd_bwd_table", L.gsdf_hashgrid_bwd_binned2, B, *cfg, f32(x), None, f32(v_feat), f32(vv_x),
+                          f32(g_table), ptr(ws), nbytes, capi.stream()), "hashgrid_bwd_binned2")
+    if need_vf or need_x or (need_t and not nbytes):
+        capi.check(_timed("hashgrid_bwd_bwd", L.gsdf_hashgrid_bwd_bwd, B, *cfg, f32(x), f32(table), f32(v_feat),
+                          f32(vv_x), f32(g_vfeat), f32(None if nbytes else g_table), f32(g_x), capi.stream()), "hashgrid_bwd_bwd")
+    return g_vfeat, g_x, g_table
+
+
+class _GridBwd2(torch.autograd.Function):
+    """(vv_x, v_feat, x, table) -> (g_vfeat, g_x, g_table): the encoding's double backward as an operator of its own; its backward is the
+    THIRD order (include/gsdf_hip.h: gsdf_hashgrid_bwd_bwd_bwd) — LocalMap::get_gradient(hessian=True, numerical_grad=False) followed by
+    loss::curvate_loss, /root/reference/include/neural_net/local_map.cpp:151-168, include/neural_mapping/neural_mapping.cpp:117-121."""
+
+    @staticmethod
+    def forward(ctx, vv_x, v_feat, x, table, cfg, need_vf, need_x, need_t):
+        g_vfeat, g_x, g_table = _grid_double_backward(cfg, vv_x, v_feat, x, table, need_vf, need_x, need_t)
+        ctx.save_for_backward(vv_x.contiguous(), v_feat, x, table)
+        ctx.cfg = cfg
+        out, dead = [], []
+        for i, t in enumerate((g_vfeat, g_x, g_table)):
+            if t is None:
+                t = torch.zeros(0, device=x.device)
+            if t.numel() == 0 or i == 2:      # (a loss on the TABLE gradient of the double backward is nobody's path)
+                dead.append(t)
+            out.append(t)
+        ctx.mark_non_differentiable(*dead)
+        return tuple(out)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, mu, lam, _nu):
+        vv_x, v_feat, x, table = ctx.saved_tensors
+        if mu is None and lam is None:
+            return (None,) * 8
+        L = capi.lib()
+        B = x.shape[0]
+        lam = torch.zeros_like(x) if lam is None else lam.contiguous()
+        mu = None if mu is None else mu.contiguous()
+        need = ctx.needs_input_grad
+        t_vv = torch.empty_like(vv_x) if need[0] else None
+        t_vfeat = torch.empty_like(v_feat) if need[1] else None
+        t_x = torch.empty_like(x) if need[2] else None
+        t_table = torch.zeros_like(table) if need[3] else None
+        capi.check(_timed("hashgrid_bwd_bwd_bwd", L.gsdf_hashgrid_bwd_bwd_bwd, B, *ctx.cfg, f32(x), f32(table), f32(v_feat), f32(vv_x), f32(lam),
+                          f32(mu), f32(t_vfeat), f32(t_table), f32(t_vv), f32(t_x), capi.stream()), "hashgrid_bwd_bwd_bwd")
+        return t_vv, t_vfeat, t_x, t_table, None, None, None, None
 
 
 class _GridFwd(torch.autograd.Function):

@@ -40,7 +40,7 @@ const char *gsdf_last_error(void);
 /* ABI version; bumped on any signature change.  Every binding compares gsdf_abi_version() of the library it loaded with the
  * GSDF_ABI_VERSION of the header it was written against and refuses to run on a mismatch (gs_sdf_amd/capi.py: lib(); the C++
  * operator layer: gsplat_ops.cpp static initialiser): a stale libgsdf_hip.so fails at load, not on the device. */
-#define GSDF_ABI_VERSION 8
+#define GSDF_ABI_VERSION 9
 int gsdf_abi_version(void);
 
 /* Optional per-entry-point device timing (bench.py's roofline leg, for callers in any language): between gsdf_timing_begin and
@@ -51,6 +51,9 @@ int gsdf_abi_version(void);
  * ~10 us of host time per timed call; nothing is recorded (one atomic load per call) while timing is off. */
 int gsdf_timing_begin(const char *only_csv);
 size_t gsdf_timing_end(char *buf, size_t cap);
+/* the same collection as a device timeline: one line per timed call in call order, "name begin_ms end_ms" relative to the first call's begin event
+ * (stops the timing like gsdf_timing_end; returns the bytes needed) */
+size_t gsdf_timing_trace(char *buf, size_t cap);
 
 /* Host-visible count words.  The packed operators hand the HOST a size between two launches (P1: visible splats, P3: intersections, the
  * visible set of the joint iteration): a device scalar read back with a copy + a stream synchronisation costs 30-50 us of idle queue per
@@ -310,6 +313,14 @@ int gsdf_hashgrid_bwd_binned2(int64_t B, int n_levels, int n_feat, int log2_hash
 int gsdf_hashgrid_bwd_bwd(int64_t B, int n_levels, int n_feat, int log2_hashmap, int base_res,
                           float per_level_scale, const float *x, const float *table, const float *v_feat,
                           const float *vv_x, float *g_vfeat, float *g_table, float *g_x, gsdf_stream_t stream);
+/* Third order: the backward of gsdf_hashgrid_bwd_bwd.  With (g_vfeat, g_table, g_x) its outputs for (v_feat, vv_x), given lam_x [B,3] (the gradient
+ * arriving at g_x) and mu_vfeat [B, L*F] (arriving at g_vfeat; NULL = zero) returns d/d v_feat (t_vfeat, overwritten), d/d table (t_table,
+ * ACCUMULATES), d/d vv_x (t_vv, overwritten) and d/d x (t_x, overwritten); any may be NULL.  What a loss on the analytic Hessian needs:
+ * LocalMap::get_gradient(hessian = true, numerical_grad = 0) + curvate_loss, include/neural_net/local_map.cpp:151-168,
+ * include/neural_mapping/neural_mapping.cpp:117-121 (curvate_weight > 0). */
+int gsdf_hashgrid_bwd_bwd_bwd(int64_t B, int n_levels, int n_feat, int log2_hashmap, int base_res, float per_level_scale,
+                              const float *x, const float *table, const float *v_feat, const float *vv_x, const float *lam_x,
+                              const float *mu_vfeat, float *t_vfeat, float *t_table, float *t_vv, float *t_x, gsdf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * S2  TCNNNetwork::forward — fully fused width-64 ReLU MLP (fp32 MFMA)

@@ -398,6 +398,17 @@ def grid_bwd_bwd(x, table, v_feat, vv_x, cfg=GRID_DEFAULT, prec="f32"):
     return g_vfeat, g_table, g_x
 
 
+def grid_bwd3(x, table, v_feat, vv_x, lam_x, mu=None, cfg=GRID_DEFAULT, prec="f32"):
+    """third order: the backward of grid_bwd_bwd for lam_x (arriving at g_x) and mu (arriving at g_vfeat) -> (t_vfeat, t_table, t_vv, t_x)"""
+    dt = _dt(prec)
+    x, table, v_feat, vv_x, lam_x, mu = _c(x, dt), _c(table, dt), _c(v_feat, dt), _c(vv_x, dt), _c(lam_x, dt), _c(mu, dt)
+    offs, _ = grid_offsets(cfg)
+    t_vfeat = np.zeros_like(v_feat); t_table = np.zeros(table.shape, np.float64); t_vv = np.zeros_like(x); t_x = np.zeros_like(x)
+    _lib("sdf", prec).orc_grid_bwd3(C.c_int64(x.shape[0]), *_gargs(cfg), _p(offs), _p(x), _p(table), _p(v_feat), _p(vv_x), _p(lam_x), _p(mu),
+                                    _p(t_vfeat), _p(t_table), _p(t_vv), _p(t_x))
+    return t_vfeat, t_table, t_vv, t_x
+
+
 def mlp_fwd(x, dims, weights, biases=None, want_acts=False, prec="f32"):
     dt = _dt(prec)
     x, weights, biases = _c(x, dt), _c(weights, dt), _c(biases, dt)

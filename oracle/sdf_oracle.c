@@ -216,6 +216,62 @@ void orc_grid_bwd_bwd(int64_t B, int n_levels, int n_feat, int log2_hashmap, int
   }
 }
 
+/* S1 third order: the backward of the double backward above.  With (g_vfeat, g_table, g_x) = orc_grid_bwd_bwd(x, table, v_feat, vv_x), given
+ * lam_x [B,3] (the gradient arriving at g_x) and mu [B,L*F] (arriving at g_vfeat; NULL = zero) returns
+ *   t_vfeat [B,L*F] = d/d v_feat,  t_table (ACCUMULATE, double) = d/d table,  t_vv [B,3] = d/d vv_x,  t_x [B,3] = d/d x.
+ * What a loss on the analytic Hessian needs (LocalMap::get_gradient with hessian = true, numerical_grad = 0, then curvate_loss:
+ * /root/reference/include/neural_net/local_map.cpp:151-168, include/neural_mapping/neural_mapping.cpp:117-121).  Trilinear weights: the second
+ * derivatives are the mixed ones only, the third derivative is d3w/dxdydz = +-scale^3. */
+void orc_grid_bwd3(int64_t B, int n_levels, int n_feat, int log2_hashmap, int base_res, float per_level_scale,
+                   const int64_t *offsets, const REAL *x, const REAL *table, const REAL *v_feat, const REAL *vv_x,
+                   const REAL *lam_x, const REAL *mu, REAL *t_vfeat, double *t_table, REAL *t_vv, REAL *t_x) {
+  grid_cfg_t c = {n_levels, n_feat, log2_hashmap, base_res, per_level_scale};
+  const int F = n_feat;
+  for (int64_t b = 0; b < B; ++b) {
+    REAL tv[3] = {0, 0, 0}, tx[3] = {0, 0, 0};
+    const REAL *vv = vv_x + 3 * b, *lam = lam_x + 3 * b;
+    for (int l = 0; l < n_levels; ++l) {
+      corner_t cr;
+      level_corners(&c, offsets, l, x + 3 * b, &cr);
+      const REAL s1 = cr.scale, s2 = cr.scale * cr.scale, s3 = cr.scale * cr.scale * cr.scale;
+      for (int f = 0; f < F; ++f) {
+        const REAL vf = v_feat[b * n_levels * F + l * F + f];
+        const REAL m = mu ? mu[b * n_levels * F + l * F + f] : 0;
+        REAL tvf = 0;
+        for (int k = 0; k < 8; ++k) {
+          const int64_t e = (offsets[l] + cr.idx[k]) * F + f;
+          const REAL th = table[e];
+          REAL A = 0, Bk = 0;
+          for (int d = 0; d < 3; ++d) {
+            A += vv[d] * cr.dw[k][d];
+            for (int ee = 0; ee < 3; ++ee) Bk += vv[d] * lam[ee] * cr.ddw[k][d][ee];
+          }
+          A *= s1; Bk *= s2;
+          if (t_table) t_table[e] += (double)(vf * Bk + m * A);
+          tvf += Bk * th;
+          /* sign of the third derivative: the product of the three corner signs */
+          const REAL sg3 = (REAL)((((k >> 0) & 1) ? 1 : -1) * (((k >> 1) & 1) ? 1 : -1) * (((k >> 2) & 1) ? 1 : -1));
+          for (int d = 0; d < 3; ++d) {
+            REAL a2 = 0, a4 = 0;
+            for (int ee = 0; ee < 3; ++ee) {
+              a2 += lam[ee] * cr.ddw[k][d][ee];            /* d/d vv_d of B */
+              a4 += vv[ee] * cr.ddw[k][ee][d];             /* d/d x_d of A (the mu term) */
+            }
+            /* d/d x_d of B: the pairs (p, q) with {p, q, d} = {0, 1, 2} */
+            const int p = (d + 1) % 3, q = (d + 2) % 3;
+            const REAL a3 = sg3 * (vv[p] * lam[q] + vv[q] * lam[p]);
+            tv[d] += vf * th * s2 * a2 + m * th * s1 * cr.dw[k][d];
+            tx[d] += vf * th * s3 * a3 + m * th * s2 * a4;
+          }
+        }
+        if (t_vfeat) t_vfeat[b * n_levels * F + l * F + f] = tvf;
+      }
+    }
+    if (t_vv) for (int d = 0; d < 3; ++d) t_vv[3 * b + d] = tv[d];
+    if (t_x) for (int d = 0; d < 3; ++d) t_x[3 * b + d] = tx[d];
+  }
+}
+
 /* ---------------------------------------------------------------------------------------
  * S2 decoder MLP.  n_layers linear layers, dims[0..n_layers]; weights row-major [out][in]
  * concatenated, biases concatenated (NULL = bias free); ReLU after every layer but the last.

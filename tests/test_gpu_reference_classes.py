@@ -109,6 +109,17 @@ def test_reference_local_map_on_the_dropin_matches_gsdf_model(host, ref, impl):
             out.append((ga.detach(), gt))
         assert float(out[1][1].abs().max()) > 0
         assert rel(out[0][0], out[1][0]) < 1e-5 and rel(out[0][1], out[1][1]) < 1e-5    # measured 4e-7, 3e-7
+        # the reference's curvature term (curvate_weight > 0: neural_mapping.cpp:117-121, loss.cpp:85-90) on the ANALYTIC Hessian (local_map.cpp:163-168):
+        # a third derivative of the drop-in encoder (gsdf_hashgrid_bwd_bwd_bwd) under the reference's own libtorch decoder, against gsdf_model's
+        # (fused decoder + its double backward)
+        out = []
+        for m_, table in ((cm, cm.encoder.params_), (rl, rl.named_parameters()["encoder_local_map"])):
+            x = xyz[:8000].clone()
+            hess = m_.get_gradient(x, 0.02, None, True, False)[1]
+            (gt,) = torch.autograd.grad(hess.sum(-1).abs().mean(), [table])
+            out.append((hess.detach(), gt))
+        assert float(out[1][1].abs().max()) > 0 and float(out[1][0].abs().max()) > 0
+        assert rel(out[0][0], out[1][0]) < 1e-4 and rel(out[0][1], out[1][1]) < 1e-4
     # occupancy structure, intersection, sampling
     n = 4000
     origin = torch.tensor([0.0, 0.0, 5.5], device=dev).expand(n, 3).contiguous()

@@ -66,11 +66,31 @@ def test_hashgrid_fwd_bwd_bwdbwd(sdf, oracle, cfg, B):
     assert_close(v_x, vx_o, REL, "v_x")
     assert_close(v_t.view(-1, 2), vt_o, REL, "v_table")
     vv = torch.randn(B, 3, generator=g)
-    g_v, g_t, g_x = torch.autograd.grad((v_x * vv.to(dev)).sum(), (vd, enc.params_, xd))
+    vvd = vv.to(dev).requires_grad_(True)
+    g_v, g_t, g_x = torch.autograd.grad((v_x * vvd).sum(), (vd, enc.params_, xd), create_graph=True)
     gv_o, gt_o, gx_o = oracle.grid_bwd_bwd(n(x), n(table).reshape(-1, 2), n(v), n(vv), cfg, prec=PREC)
     assert_close(g_v, gv_o, REL, "double backward: d/d v_feat")
     assert_close(g_t.view(-1, 2), gt_o, REL, "double backward: d/d table")
     assert_close(g_x, gx_o, REL, "double backward: d/d x")
+    # third order (a loss on the analytic Hessian, local_map.cpp:163-168): loss3 = <lam, g_x> (+ <mu, g_v>); the oracle's orc_grid_bwd3 is pinned
+    # to a torch-fp64 autograd restatement on the CPU (tests/test_oracle_sdf_selfcheck.py)
+    lam = torch.randn(B, 3, generator=g)
+    mu = torch.randn(B, feat.shape[1], generator=g)
+    for use_mu in (False, True):
+        loss3 = (g_x * lam.to(dev)).sum() + ((g_v * mu.to(dev)).sum() if use_mu else 0.0)
+        t_v, t_t, t_vv, t_x = torch.autograd.grad(loss3, (vd, enc.params_, vvd, xd), retain_graph=True)
+        o_v, o_t, o_vv, o_x = oracle.grid_bwd3(n(x), n(table).reshape(-1, 2), n(v), n(vv), n(lam), n(mu) if use_mu else None, cfg, prec=PREC)
+        if B >= 100:
+            assert_close(t_v, o_v, REL, "third order: d/d v_feat")
+            assert_close(t_t.view(-1, 2), o_t, REL, "third order: d/d table")
+            assert_close(t_vv, o_vv, REL, "third order: d/d vv_x")
+            assert_close(t_x, o_x, REL, "third order: d/d x")
+        else:
+            # a single point: an entry's value is a sum of three mixed-derivative products that may cancel (fp32 in the kernel and in the f32
+            # oracle, differently associated), and there is no tensor mean to judge it against: the bar is relative to the tensor's maximum
+            for got, ref, what in ((t_v, o_v, "v_feat"), (t_t.view(-1, 2), o_t, "table"), (t_vv, o_vv, "vv_x"), (t_x, o_x, "x")):
+                e = np.abs(n(got).astype(np.float64) - ref).max()
+                assert e <= REL * np.abs(ref).max() + 1e-30, f"third order: d/d {what}: {e:.3e} against max {np.abs(ref).max():.3e}"
 
 
 def _near_relu_kink(x, dims, W, b, eps=1e-5):

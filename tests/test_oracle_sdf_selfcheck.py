@@ -67,11 +67,24 @@ def test_grid_fwd_bwd_bwdbwd_match_autograd(oracle):
     np.testing.assert_allclose(np.einsum("bfd,bf->bd", jac, v.detach().numpy()), vx_o, rtol=1e-10, atol=1e-12)
     # double backward: loss2 = <vv, v_x>
     vv = torch.randn(B, 3, generator=g, dtype=torch.float64)
-    g_v, g_t, g_x = torch.autograd.grad((v_x * vv).sum(), (v, ta, xa))
-    gv_o, gt_o, gx_o = oracle.grid_bwd_bwd(x.numpy(), table.numpy(), v.detach().numpy(), vv.numpy(), cfg, prec="f64")
-    np.testing.assert_allclose(gv_o, g_v.numpy(), rtol=1e-10, atol=1e-12)
-    np.testing.assert_allclose(gt_o, g_t.numpy(), rtol=1e-10, atol=1e-12)
-    np.testing.assert_allclose(gx_o, g_x.numpy(), rtol=1e-9, atol=1e-10)
+    vv.requires_grad_(True)
+    g_v, g_t, g_x = torch.autograd.grad((v_x * vv).sum(), (v, ta, xa), create_graph=True)
+    gv_o, gt_o, gx_o = oracle.grid_bwd_bwd(x.numpy(), table.numpy(), v.detach().numpy(), vv.detach().numpy(), cfg, prec="f64")
+    np.testing.assert_allclose(gv_o, g_v.detach().numpy(), rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(gt_o, g_t.detach().numpy(), rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(gx_o, g_x.detach().numpy(), rtol=1e-9, atol=1e-10)
+    # third order (a loss on the analytic Hessian, local_map.cpp:163-168): loss3 = <lam, g_x> + <mu, g_v>
+    lam = torch.randn(B, 3, generator=g, dtype=torch.float64)
+    mu = torch.randn(B, feat.shape[1], generator=g, dtype=torch.float64)
+    for use_mu in (False, True):
+        loss3 = (g_x * lam).sum() + ((g_v * mu).sum() if use_mu else 0.0)
+        t_v, t_t, t_vv, t_x = torch.autograd.grad(loss3, (v, ta, vv, xa), retain_graph=True)
+        o_v, o_t, o_vv, o_x = oracle.grid_bwd3(x.numpy(), table.numpy(), v.detach().numpy(), vv.detach().numpy(), lam.numpy(),
+                                               mu.numpy() if use_mu else None, cfg, prec="f64")
+        np.testing.assert_allclose(o_v, t_v.numpy(), rtol=1e-9, atol=1e-9)
+        np.testing.assert_allclose(o_t, t_t.numpy(), rtol=1e-9, atol=1e-9)
+        np.testing.assert_allclose(o_vv, t_vv.numpy(), rtol=1e-9, atol=1e-8)
+        np.testing.assert_allclose(o_x, t_x.numpy(), rtol=1e-8, atol=1e-6)
 
 
 def test_mlp_and_head_match_torch(oracle):
