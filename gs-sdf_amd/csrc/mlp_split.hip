@@ -87,11 +87,23 @@ struct SplitLds {
 // forward
 // LDS image of layer l: [o_tile][k_step][term][64 lanes] x uint4 = the A operand of lane (row o = 32 o_tile + (lane & 31), half)
 // ----------------------------------------------------------------------------------------------
+// valu_last (round 6): an output layer of <= 4 neurons (the SDF head: sdf, isigma) is 32 fp32 FMAs per lane and output instead of a 32-row MFMA tile
+// of which 2 rows are used (24 of the 192 MFMAs of a tile, and the operand split of a whole hidden layer in front of them): its weights are staged
+// as plain floats [o][half][tile t][register r] = W_last[o][32 t + d_row(r, half)] — the neuron order of a lane's accumulator registers.
 __device__ void stage_split_fwd(const MlpDesc &d, const SplitLds &sl, const float *__restrict__ W, const float *__restrict__ bias,
-                                uint4 *lds_w, float *lds_b) {
+                                uint4 *lds_w, float *lds_b, bool valu_last = false) {
   for (int l = 0; l < d.n_layers; ++l) {
     const int I = l == 0 ? d.d_in : HID;
     const int O = l == d.n_layers - 1 ? d.d_out : HID;
+    if (valu_last && l == d.n_layers - 1) {
+      float *dst = reinterpret_cast<float *>(lds_w + sl.off4[l]);
+      for (int u = threadIdx.x; u < 4 * 64; u += blockDim.x) {
+        const int o = u >> 6, h = (u >> 5) & 1, t = (u >> 4) & 1, r = u & 15;
+        dst[u] = o < O ? W[d.w_off[l] + o * I + 32 * t + d_row(r, h)] : 0.f;
+      }
+      for (int e = threadIdx.x; e < HID; e += blockDim.x) lds_b[l * HID + e] = (d.has_bias && e < O) ? bias[d.b_off[l] + e] : 0.f;
+      continue;
+    }
     const int otiles = l == d.n_layers - 1 ? 1 : 2;
     const int ksteps = I / 16;
     const float *Wl = W + d.w_off[l];
@@ -142,7 +154,7 @@ __device__ __forceinline__ void load_bias(const float *lds_b, int l, int h, int 
 // MASKED: the ReLUs are replaced by the saved masks of an earlier forward pass (`mask_acts` = that pass's acts buffer), no biases:
 // y = W_{n-1} D_{n-2} ... D_0 W_0 x, the tangent pass of the decoder's DOUBLE backward (gsdf_mlp_bwd_bwd); `acts` receives the tangent
 // images t_0 .. t_{n-2} (no masks of its own).
-template <int D_IN, int THREADS, bool MASKED = false>
+template <int D_IN, int THREADS, bool MASKED = false, bool VALU_LAST = false>
 __global__ void __launch_bounds__(THREADS)
     mlp_fwd_split_kernel(int64_t B, MlpDesc d, SplitLds sl, const float *__restrict__ W, const float *__restrict__ bias,
                          const float *__restrict__ in, float *__restrict__ out, float *__restrict__ acts,
@@ -150,7 +162,7 @@ __global__ void __launch_bounds__(THREADS)
   extern __shared__ __attribute__((aligned(16))) uint4 smem4[];
   float *lds_b = reinterpret_cast<float *>(smem4);   // [MAX_LAYERS][64]
   uint4 *lds_w = smem4 + MAX_LAYERS * HID / 4;
-  stage_split_fwd(d, sl, W, bias, lds_w, lds_b);
+  stage_split_fwd(d, sl, W, bias, lds_w, lds_b, VALU_LAST);
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int h = lane >> 5, pl = lane & 31;
@@ -223,6 +235,29 @@ __global__ void __launch_bounds__(THREADS)
       };
       const uint4 *w = lds_w + sl.off4[l];
       const bool last = l == d.n_layers - 1;
+      if (VALU_LAST && last) {
+        // the output layer on the vector pipe: this lane's 32 hidden values against their weights (one broadcast ds_read_b128 per four), the two
+        // halves of a point added through the crossbar; fp32 FMAs in neuron order of the registers
+        const float4 *wl = reinterpret_cast<const float4 *>(w);
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+          if (o < d.d_out) {
+            float sacc = 0.f;
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                const float4 wv = wl[((o * 2 + h) * 2 + t) * 4 + q];
+                sacc = fmaf(wv.x, cur[t][4 * q], sacc); sacc = fmaf(wv.y, cur[t][4 * q + 1], sacc);
+                sacc = fmaf(wv.z, cur[t][4 * q + 2], sacc); sacc = fmaf(wv.w, cur[t][4 * q + 3], sacc);
+              }
+            sacc += __shfl_xor(sacc, 32, 64);
+            if (!MASKED && d.has_bias) sacc += lds_b[l * HID + o];
+            if (live && h == (o & 1)) out[p * d.d_out + o] = sacc;
+          }
+        }
+        continue;
+      }
       v16f acc0, acc1;
       load_bias(lds_b, l, h, MASKED ? 0 : d.has_bias, acc0, acc1);
       unsigned m0 = 0, m1 = 0;
@@ -254,7 +289,7 @@ __global__ void __launch_bounds__(THREADS)
         for (int r = 0; r < 16; ++r) cur[0][r] = acc0[r] + accb[r];
       }
     }
-    if (live) {
+    if (live && !VALU_LAST) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int o = d_row(r, h);
@@ -941,8 +976,13 @@ int mlp_fwd_masked_split_launch(int64_t B, const MlpDesc &d, const float *W, con
   const size_t lds = split_fwd_lds(d, &sl);
   if (lds > 160 * 1024) return 0;
   const unsigned grid = split_grid(B, SPLIT_FWD_THREADS / 64);
-  GSDF_HIP(hipFuncSetAttribute((const void *)mlp_fwd_split_kernel<32, SPLIT_FWD_THREADS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "mlp_fwd_masked_split attr");
-  mlp_fwd_split_kernel<32, SPLIT_FWD_THREADS, true><<<grid, SPLIT_FWD_THREADS, lds, stream>>>(B, d, sl, W, nullptr, vv_in, out, tangent, mask_acts);
+  if (d.d_out <= 4) {
+    GSDF_HIP(hipFuncSetAttribute((const void *)mlp_fwd_split_kernel<32, SPLIT_FWD_THREADS, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "mlp_fwd_masked_split attr");
+    mlp_fwd_split_kernel<32, SPLIT_FWD_THREADS, true, true><<<grid, SPLIT_FWD_THREADS, lds, stream>>>(B, d, sl, W, nullptr, vv_in, out, tangent, mask_acts);
+  } else {
+    GSDF_HIP(hipFuncSetAttribute((const void *)mlp_fwd_split_kernel<32, SPLIT_FWD_THREADS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "mlp_fwd_masked_split attr");
+    mlp_fwd_split_kernel<32, SPLIT_FWD_THREADS, true><<<grid, SPLIT_FWD_THREADS, lds, stream>>>(B, d, sl, W, nullptr, vv_in, out, tangent, mask_acts);
+  }
   GSDF_CHECK_LAUNCH("mlp_fwd_split_kernel<masked>");
   return 1;
 }
@@ -958,7 +998,10 @@ int mlp_fwd_split_launch(int64_t B, const MlpDesc &d, const float *W, const floa
   //  0.70 ms at 8; without the saved activations all three take 0.52 ms: occupancy is not what bounds this kernel; round 5: 4 waves per
   //  workgroup — one per SIMD, so that the compositing backward's waves could share the CU in the two-stream step — 203 against 209 it/s)
   const unsigned grid = split_grid(B, SPLIT_FWD_THREADS / 64);
-  if (d.d_in == 32) {
+  if (d.d_in == 32 && d.d_out <= 4) {   // the SDF head: output layer on the vector pipe
+    GSDF_HIP(hipFuncSetAttribute((const void *)mlp_fwd_split_kernel<32, SPLIT_FWD_THREADS, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "mlp_fwd_split attr");
+    mlp_fwd_split_kernel<32, SPLIT_FWD_THREADS, false, true><<<grid, SPLIT_FWD_THREADS, lds, stream>>>(B, d, sl, W, bias, in, out, acts);
+  } else if (d.d_in == 32) {
     GSDF_HIP(hipFuncSetAttribute((const void *)mlp_fwd_split_kernel<32, SPLIT_FWD_THREADS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "mlp_fwd_split attr");
     mlp_fwd_split_kernel<32, SPLIT_FWD_THREADS><<<grid, SPLIT_FWD_THREADS, lds, stream>>>(B, d, sl, W, bias, in, out, acts);
   } else {
