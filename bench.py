@@ -109,6 +109,8 @@ def main():
     ap.add_argument("--splat-order", default="as-given", choices=["morton", "as-given"],
                     help="memory order of the splat set: the synthetic scene's random order, or Morton order of the centres "
                          "(trainer.morton_order; measured: no gain, the fine hash-grid levels scatter either way, DESIGN.md section 11)")
+    ap.add_argument("--deterministic", action="store_true", help="gsdf_deterministic(1): order-independent accumulation (fixed-point compositing "
+                    "gradients, ordered loss reductions, partial-buffer decoder gradients) — a validation mode, ~2 ms per step")
     ap.add_argument("--step-trace", default="", help="write a device timeline of the C-ABI entry points (begin us, end us, duration, name; HIP events, no "
                     "profiler) of six steps after the timed region to this file")
     ap.add_argument("--hashgrid-resident", type=int, default=-1,
@@ -123,6 +125,9 @@ def main():
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         # invoked as `python bench.py --gpus N` (no launcher): start the N ranks ourselves, one process per GPU
         sys.exit(spawn_ranks(args.gpus))
+    if args.deterministic:
+        import gs_sdf_amd.capi as _capi
+        _capi.lib().gsdf_deterministic(1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -603,7 +608,7 @@ def main():
                 "workload": f"{args.workload}: {N} random Gaussians, {W}x{H}, sh_degree {deg}, 1 view/GPU/step",
                 "M": round(a["M"]), "I": round(a["I"]), "L": round(a["I"] / a["T"]), "sdf_points_per_step": round(a["sdf_pts"]),
                 "sdf_points": None if args.no_sdf else f"7 x ({a['n_ray']:.0f} ray + {a['n_gs']:.0f} splat samples), hash grid 2^19 x 16 x 2, fused 64-wide decoder",
-                "sdf_config": None if args.no_sdf else args.sdf_config,
+                "sdf_config": None if args.no_sdf else (args.sdf_config + (" (deterministic mode)" if args.deterministic else "")),
                 "ray_batch_short": None if args.no_sdf else ("sampled in the step (a16)" if batcher is not None else "pool of 8 pre-generated batches"),
                 "ray_batch": None if batcher is None else {
                     "mode": "the reference's per-iteration ray-batch construction inside the timed step, one step ahead on its own stream (benchlib/raybatch.py; "

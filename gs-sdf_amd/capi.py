@@ -26,6 +26,7 @@ class RasterInstr(C.Structure):
 _SIGS = {
     "gsdf_abi_version": (C.c_int, []),
     "gsdf_last_error": (C.c_char_p, []),
+    "gsdf_deterministic": (C.c_int, [C.c_int]),
     "gsdf_timing_begin": (C.c_int, [C.c_char_p]),
     "gsdf_timing_end": (_sz, [C.c_char_p, _sz]),
     "gsdf_timing_trace": (_sz, [C.c_char_p, _sz]),
@@ -207,6 +208,21 @@ def count_via_host_word(launch, device, upper=None):
     if v < 0 or (upper is not None and v > upper):
         raise RuntimeError(f"count_via_host_word: implausible count {v} (expected 0..{upper})")
     return v
+
+
+class deterministic:
+    """`with capi.deterministic():` — order-independent accumulation in the kernels this thread launches (include/gsdf_hip.h: gsdf_deterministic)"""
+
+    def __init__(self, on=True):
+        self.on = bool(on)
+
+    def __enter__(self):
+        self.before = lib().gsdf_deterministic(1 if self.on else 0)
+        return self
+
+    def __exit__(self, *exc):
+        lib().gsdf_deterministic(self.before)
+        return False
 
 
 def timing_begin(only=None):

@@ -38,11 +38,13 @@ __global__ void __launch_bounds__(256)
   }
 }
 
+static __device__ DetScalarSlot g_det_isotropic;   // deterministic mode: the ordered finish of the loss value (both kernels: never at once)
+
 // ---- isotropic regulariser of the visible splats (neural_mapping.cpp:268-276): scale = get_scale()[gaussian_ids][:, 0:2];
 // loss = (scale - scale.mean(-1, keepdim)).abs().mean() = sum_m |s_u - s_v| / (2 M).  One launch each way instead of ~12.
 __global__ void __launch_bounds__(256)
     isotropic_fwd_kernel(int64_t M, const float *__restrict__ scales, const int64_t *__restrict__ ids, float inv_2m,
-                         float *__restrict__ loss) {
+                         float *__restrict__ loss, bool det) {
   __shared__ float s_part[4];
   float c = 0.f;
   // capped grid + grid-stride loop: atomics on ONE address serialise (~88 per microsecond)
@@ -53,10 +55,7 @@ __global__ void __launch_bounds__(256)
   const float ws = wave_sum_to_lane63(c);
   if ((threadIdx.x & 63) == 63) s_part[threadIdx.x >> 6] = ws;
   __syncthreads();
-  if (threadIdx.x == 0) {
-    const float t = (s_part[0] + s_part[1]) + (s_part[2] + s_part[3]);
-    if (t != 0.f) atomicAdd(loss, t);
-  }
+  finish_scalars((s_part[0] + s_part[1]) + (s_part[2] + s_part[3]), 0.f, loss, nullptr, det ? &g_det_isotropic : nullptr);
 }
 
 __global__ void __launch_bounds__(256)
@@ -74,7 +73,7 @@ __global__ void __launch_bounds__(256)
 // value and gradient in one launch (the joint step: no separate launch, no memset for a number only the log reads); `loss` ACCUMULATES
 __global__ void __launch_bounds__(256)
     isotropic_fwd_bwd_kernel(int64_t M, const float *__restrict__ scales, const int64_t *__restrict__ ids, float inv_2m,
-                             const float *__restrict__ v_loss, float *__restrict__ loss, float *__restrict__ v_scales) {
+                             const float *__restrict__ v_loss, float *__restrict__ loss, float *__restrict__ v_scales, bool det) {
   __shared__ float s_part[4];
   float c = 0.f;
   const float vl = v_loss[0];
@@ -89,10 +88,7 @@ __global__ void __launch_bounds__(256)
   const float ws = wave_sum_to_lane63(c);
   if ((threadIdx.x & 63) == 63) s_part[threadIdx.x >> 6] = ws;
   __syncthreads();
-  if (threadIdx.x == 0) {
-    const float t = (s_part[0] + s_part[1]) + (s_part[2] + s_part[3]);
-    if (t != 0.f) atomicAdd(loss, t);
-  }
+  finish_scalars((s_part[0] + s_part[1]) + (s_part[2] + s_part[3]), 0.f, loss, nullptr, det ? &g_det_isotropic : nullptr);
 }
 
 // ---- NeuralGS::prune_nan_gs's test (neural_gaussian.cpp:907-916): rows with a NaN in offsets / scaling / quaternion
@@ -152,7 +148,7 @@ extern "C" int gsdf_isotropic_loss_fwd(int64_t M, const float *scales, const int
   if (M == 0) return GSDF_OK;
   GSDF_REQUIRE(scales && gaussian_ids, "isotropic_loss_fwd: null buffer");
   const int64_t blocks = (M + 255) / 256;
-  isotropic_fwd_kernel<<<(unsigned)(blocks > 512 ? 512 : blocks), 256, 0, stream>>>(M, scales, gaussian_ids, 0.5f / (float)M, loss);
+  isotropic_fwd_kernel<<<(unsigned)(blocks > 512 ? 512 : blocks), 256, 0, stream>>>(M, scales, gaussian_ids, 0.5f / (float)M, loss, deterministic());
   GSDF_CHECK_LAUNCH("isotropic_fwd_kernel");
   return GSDF_OK;
 }
@@ -175,7 +171,7 @@ extern "C" int gsdf_isotropic_loss_fwd_bwd(int64_t M, const float *scales, const
   if (M == 0) return GSDF_OK;
   GSDF_REQUIRE(M > 0 && scales && gaussian_ids && v_loss && loss && v_scales, "isotropic_loss_fwd_bwd: bad arguments");
   const int64_t blocks = (M + 255) / 256;
-  isotropic_fwd_bwd_kernel<<<(unsigned)(blocks > 1024 ? 1024 : blocks), 256, 0, stream>>>(M, scales, gaussian_ids, 0.5f / (float)M, v_loss, loss, v_scales);
+  isotropic_fwd_bwd_kernel<<<(unsigned)(blocks > 1024 ? 1024 : blocks), 256, 0, stream>>>(M, scales, gaussian_ids, 0.5f / (float)M, v_loss, loss, v_scales, deterministic());
   GSDF_CHECK_LAUNCH("isotropic_fwd_bwd_kernel");
   return GSDF_OK;
 }

@@ -94,6 +94,8 @@ struct TimedScope {
 // CU-masked stream (workgroups are dealt round-robin over the enabled XCDs only).  A locality hint for the XCD-aware
 // kernels (tile bands of the compositing kernels, level groups of the hash-grid forward), never a correctness input.
 int xcd_count(hipStream_t stream);
+// gsdf_deterministic(): the process asked for order-independent accumulation (fixed point / ordered reductions) in the kernels it launches
+bool deterministic();
 
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 
@@ -101,5 +103,55 @@ __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 // word.  (Round 4 wrote it with a plain store + __threadfence_system(): on gfx950 that fence writes the whole L2's dirty lines back — 8-65 us
 // beside a kernel of the other leg — although the host reads nothing but the word.)
 __device__ __forceinline__ void store_host_visible(int64_t *p, int64_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+
+
+// ---- the last step of a one-value-per-workgroup reduction (loss values) -----------------------------------------------------------------------
+// Thread 0 of every workgroup holds its workgroup's value(s) and the outputs ACCUMULATE.  Default: one float atomic per workgroup (their order varies
+// from launch to launch: the value wanders in its last bits).  Deterministic mode (gsdf_deterministic; `slot` non-null): the values wait in a
+// device-global slot of the kernel, the LAST workgroup to arrive (a ticket) sums them in index order — a fixed tree — and adds the totals with one
+// atomic each; the ticket resets itself.  One slot per kernel: a kernel must not run on two streams at once in that mode.  Call with all 256
+// threads of the workgroup.
+static constexpr int DET_MAX_BLOCKS = 16384;
+struct DetScalarSlot {
+  float part[2][DET_MAX_BLOCKS];
+  unsigned ticket;
+};
+#ifdef __HIPCC__
+// (the ordered path is a call: its registers must not count against the occupancy targets of the kernels that end with it)
+static __device__ __noinline__ void finish_scalars_ordered(float t0, float t1, float *o0, float *o1, DetScalarSlot *slot) {
+  __shared__ bool s_last;
+  __shared__ float s_red[2][4];
+  if (threadIdx.x == 0) {
+    __hip_atomic_store(&slot->part[0][blockIdx.x], t0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&slot->part[1][blockIdx.x], t1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __threadfence();
+    s_last = atomicAdd(&slot->ticket, 1u) == gridDim.x - 1;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  __threadfence();
+  float a = 0.f, b = 0.f;
+  for (unsigned i = threadIdx.x; i < gridDim.x; i += 256) {
+    a += __hip_atomic_load(&slot->part[0][i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    b += __hip_atomic_load(&slot->part[1][i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  a = wave_sum_to_lane63(a); b = wave_sum_to_lane63(b);      // (a fixed butterfly: the same tree every launch)
+  if ((threadIdx.x & 63) == 63) { s_red[0][threadIdx.x >> 6] = a; s_red[1][threadIdx.x >> 6] = b; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    slot->ticket = 0u;
+    const float ta = (s_red[0][0] + s_red[0][1]) + (s_red[0][2] + s_red[0][3]), tb = (s_red[1][0] + s_red[1][1]) + (s_red[1][2] + s_red[1][3]);
+    if (ta != 0.f) atomicAdd(o0, ta);
+    if (o1 != nullptr && tb != 0.f) atomicAdd(o1, tb);
+  }
+}
+__device__ __forceinline__ void finish_scalars(float t0, float t1, float *__restrict__ o0, float *__restrict__ o1, DetScalarSlot *slot) {
+  if (slot != nullptr) { finish_scalars_ordered(t0, t1, o0, o1, slot); return; }
+  if (threadIdx.x == 0) {
+    if (t0 != 0.f) atomicAdd(o0, t0);
+    if (o1 != nullptr && t1 != 0.f) atomicAdd(o1, t1);
+  }
+}
+#endif
 
 }  // namespace gsdf

@@ -40,6 +40,10 @@ void timing_push(const char *name, hipEvent_t a, hipEvent_t b) {
   g_timed.push_back({name, a, b});
 }
 
+// process-wide, not per thread: a training step's backward kernels are launched by libtorch's autograd thread, not by the thread that asked
+static std::atomic<int> g_deterministic{0};
+bool deterministic() { return g_deterministic.load(std::memory_order_relaxed) != 0; }
+
 static thread_local char g_err[512] = "";
 void set_error(const char *fmt, ...) {
   va_list ap;
@@ -76,6 +80,12 @@ extern "C" int gsdf_host_words_alloc(int n_words, int64_t **host_view, int64_t *
 extern "C" int gsdf_host_words_free(int64_t *host_view) {
   if (host_view != nullptr) GSDF_HIP(hipHostFree(host_view), "host_words_free");
   return GSDF_OK;
+}
+
+extern "C" int gsdf_deterministic(int on) {
+  const int before = gsdf::g_deterministic.load();
+  if (on >= 0) gsdf::g_deterministic.store(on != 0);
+  return before;
 }
 
 extern "C" int gsdf_stream_set_xcds(gsdf_stream_t stream, int n_xcds) {

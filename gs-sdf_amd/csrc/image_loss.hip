@@ -24,9 +24,10 @@ __device__ __forceinline__ float il_at(const float *__restrict__ img, int H, int
   return (x >= 0 && x < W && y >= 0 && y < H) ? img[((int64_t)y * W + x) * 3 + c] : 0.f;
 }
 
+static __device__ DetScalarSlot g_det_l1_dssim;   // deterministic mode: the ordered finish of the two sums
 __global__ void __launch_bounds__(256, 6)
     l1_dssim_fwd_kernel(int H, int W, const float *__restrict__ img, const float *__restrict__ gt, Win11 win,
-                        float *__restrict__ sums, float *__restrict__ maps) {
+                        float *__restrict__ sums, float *__restrict__ maps, bool det) {
   __shared__ float sx[IL_HY][IL_HX + 1], sy[IL_HY][IL_HX + 1];
   __shared__ float row[5][IL_HY][IL_TX + 1];
   __shared__ float red[2][4];
@@ -92,10 +93,8 @@ __global__ void __launch_bounds__(256, 6)
   __syncthreads();
   if ((tid & 63) == 0) { red[0][tid >> 6] = l1; red[1][tid >> 6] = ss; }
   __syncthreads();
-  if (tid == 0) {
-    atomicAdd(sums, red[0][0] + red[0][1] + red[0][2] + red[0][3]);
-    atomicAdd(sums + 1, red[1][0] + red[1][1] + red[1][2] + red[1][3]);
-  }
+  finish_scalars(red[0][0] + red[0][1] + red[0][2] + red[0][3], red[1][0] + red[1][1] + red[1][2] + red[1][3], sums, sums + 1,
+                 det ? &g_det_l1_dssim : nullptr);
 }
 
 // v_img(p) = g_l1 * sign(I - G) + g_ss * [ T(dmu1) + 2 I T(dE11) + G T(dE12) ](p),  T = correlation with the FLIPPED window.
@@ -168,7 +167,7 @@ extern "C" int gsdf_l1_dssim_fwd(int height, int width, const float *img, const 
   for (int k = 0; k < 11; ++k) w.w[k] = window11_host[k];
   GSDF_HIP(hipMemsetAsync(sums, 0, 2 * sizeof(float), stream), "l1_dssim_fwd memset");
   const int n_tiles = ((width + IL_TX - 1) / IL_TX) * ((height + IL_TY - 1) / IL_TY);
-  l1_dssim_fwd_kernel<<<n_tiles < 1024 ? n_tiles : 1024, 256, 0, stream>>>(height, width, img, gt, w, sums, maps);
+  l1_dssim_fwd_kernel<<<n_tiles < 1024 ? n_tiles : 1024, 256, 0, stream>>>(height, width, img, gt, w, sums, maps, deterministic());
   GSDF_CHECK_LAUNCH("l1_dssim_fwd_kernel");
   return GSDF_OK;
 }

@@ -881,7 +881,8 @@ static int launch_bwd_split(int64_t B, const MlpDesc &d, const SplitLds &sl, int
     chunk = part + (int64_t)n_part * n_elem;
     if (NL == 5) g_img = (float *)(((uintptr_t)(chunk + (int64_t)RED_CHUNKS * n_elem) + 255) & ~(uintptr_t)255);
   }
-  if (ws == nullptr || many_tiles)
+  GSDF_REQUIRE(ws != nullptr || !deterministic(), "mlp_bwd (one pass): the deterministic mode needs the workspace of the per-wave partial buffers");
+  if (ws == nullptr || (many_tiles && !deterministic()))   // (deterministic mode: no atomic exit whatever the batch size)
     return launch_bwd_kernels<NL, BIAS, false, MODE>(grid, lds, g_img, B, d, sl, lds_w4, W, in, acts, v_out, v_in, v_W, v_b, 0, mask_acts, stream);
   int rc = launch_bwd_kernels<NL, BIAS, true, MODE>(grid, lds, g_img, B, d, sl, lds_w4, W, in, acts, v_out, v_in, part, part + n_w, n_elem, mask_acts, stream);
   if (rc < 0) return rc;

@@ -34,11 +34,13 @@ __device__ __forceinline__ void nl_normal(const float *pu, const float *pd, cons
   o.n[0] = o.c[0] * inv; o.n[1] = o.c[1] * inv; o.n[2] = o.c[2] * inv;
 }
 
+static __device__ DetScalarSlot g_det_normal_fwd, g_det_normal_bwd;   // deterministic mode: the ordered finish of the loss value
+
 template <bool BWD>
 __global__ void __launch_bounds__(256)
     normal_loss_kernel(int H, int W, NlCam cam, const float *__restrict__ depth, const float *__restrict__ alpha,
                        const float *__restrict__ rnormal, float *__restrict__ sum, const float *__restrict__ v_loss,
-                       float *__restrict__ v_depth, float *__restrict__ v_rnormal) {
+                       float *__restrict__ v_depth, float *__restrict__ v_rnormal, bool det) {
   constexpr int HALO = BWD ? 2 : 1, S = NL_T + 2 * HALO;
   __shared__ float P[S][S][3];
   __shared__ float G[BWD ? NL_T + 2 : 1][BWD ? NL_T + 2 : 1][6];  // (v_dx, v_dy) on the halo-1 ring (backward only)
@@ -157,7 +159,8 @@ __global__ void __launch_bounds__(256)
     for (int s = 32; s >= 1; s >>= 1) wg_term += __shfl_xor(wg_term, s, 64);
     if ((tid & 63) == 0) red[tid >> 6] = wg_term;
     __syncthreads();
-    if (tid == 0) atomicAdd(sum, (red[0] + red[1] + red[2] + red[3]) * (1.0f / ((float)H * (float)W)));
+    finish_scalars((red[0] + red[1] + red[2] + red[3]) * (1.0f / ((float)H * (float)W)), 0.f, sum, nullptr,
+                   det ? (BWD ? &g_det_normal_bwd : &g_det_normal_fwd) : nullptr);
   }
 }
 
@@ -182,7 +185,7 @@ extern "C" int gsdf_normal_consistency_fwd(int height, int width, const float *i
   nl_cam(intrinsics4_host, pose_c2w_host, &cam);
   GSDF_HIP(hipMemsetAsync(loss, 0, sizeof(float), stream), "normal_consistency memset");
   const int n_tiles = ((width + NL_T - 1) / NL_T) * ((height + NL_T - 1) / NL_T);
-  normal_loss_kernel<false><<<n_tiles < 1024 ? n_tiles : 1024, 256, 0, stream>>>(height, width, cam, depth, alpha, render_normal, loss, nullptr, nullptr, nullptr);
+  normal_loss_kernel<false><<<n_tiles < 1024 ? n_tiles : 1024, 256, 0, stream>>>(height, width, cam, depth, alpha, render_normal, loss, nullptr, nullptr, nullptr, deterministic());
   GSDF_CHECK_LAUNCH("normal_loss_kernel<fwd>");
   return GSDF_OK;
 }
@@ -201,7 +204,7 @@ extern "C" int gsdf_normal_consistency_fwd_bwd(int height, int width, const floa
   const int n_tiles = ((width + NL_T - 1) / NL_T) * ((height + NL_T - 1) / NL_T);
   // capped grid: the value is one address (one atomic per workgroup)
   normal_loss_kernel<true><<<n_tiles < 2048 ? n_tiles : 2048, 256, 0, stream>>>(height, width, cam, depth, alpha, render_normal, loss, v_loss, v_depth,
-                                                                               v_render_normal);
+                                                                               v_render_normal, deterministic());
   GSDF_CHECK_LAUNCH("normal_loss_kernel<fwd+bwd>");
   return GSDF_OK;
 }
@@ -218,7 +221,7 @@ extern "C" int gsdf_normal_consistency_bwd(int height, int width, const float *i
   nl_cam(intrinsics4_host, pose_c2w_host, &cam);
   const int n_tiles = ((width + NL_T - 1) / NL_T) * ((height + NL_T - 1) / NL_T);
   normal_loss_kernel<true><<<n_tiles, 256, 0, stream>>>(height, width, cam, depth, alpha, render_normal, nullptr, v_loss, v_depth,
-                                                      v_render_normal);
+                                                      v_render_normal, false);
   GSDF_CHECK_LAUNCH("normal_loss_kernel<bwd>");
   return GSDF_OK;
 }

@@ -14,6 +14,8 @@
 // single 84-byte RECORD ([M][21] floats), three records are flushed per wave instruction with the
 // 21 fields in consecutive lanes (<= 2 lines per splat), and a streaming epilogue unpacks the
 // records into the operator's six gradient tensors (+ the densification signal).
+#include <type_traits>
+
 #include "raster_quad.h"
 
 namespace gsdf {
@@ -55,14 +57,34 @@ __device__ __forceinline__ void lds_add(float *p, float v) { atomicAdd(p, v); }
 static constexpr int BQB = RASTER_BWD_QUADS_BATCH;
 static constexpr int BQ_CHUNKS = (BQB + 63) / 64;
 static constexpr int NACC_D = 20;   // double fields of a record: 0-18 as NACC's 0-18, 19 padding (the 4-value butterfly's fourth output)
-template <bool ABSGRAD>
+// DETERMINISTIC (gsdf_deterministic, round 6): every accumulator is a 64-bit FIXED-POINT integer — the LDS records (ds_add_u64 instead of
+// ds_add_f64), the global records (global_atomic_add_x2 instead of the float atomics) — so that neither the order in which the quads of a tile
+// reach a record nor the order in which the tiles reach a splat changes a bit of the result.  The unit is 2^(e - 34) with 2^e the first power of
+// two above the largest upstream gradient of the launch (a max-reduction pass: the contributions are linear in the upstream gradients): 5.8e-11
+// of that maximum.  A tile sum of 2^13 times the maximum or more cannot be told from an overflow of the 8160-tile total: it poisons the
+// launch's outputs with NaN instead (a degenerate splat; the float path would return its huge gradient).
+static constexpr int DET_UNIT_SHIFT = 34;
+static constexpr long long DET_ADDEND_CAP = 1LL << 54, DET_TILE_CAP = 1LL << 47;
+struct DetHeader {
+  double to_fix;        // 2^(34 - e)
+  double from_fix;      // 2^(e - 34)
+  unsigned max_bits;    // bit pattern of the largest |upstream gradient| (atomicMax)
+  unsigned poisoned;    // a tile sum out of range, or a non-finite upstream gradient
+};
+__device__ __forceinline__ long long det_fix(float r, double to_fix) {
+  double x = (double)r * to_fix;
+  x = fmin(fmax(x, -(double)DET_ADDEND_CAP), (double)DET_ADDEND_CAP);   // (a NaN becomes the cap: poisoned by the tile check)
+  return __double2ll_rn(x);
+}
+
+template <bool ABSGRAD, bool DET = false>
 struct BwdQuadsLds {
   float4 q0[BQB], q1[BQB], q2[BQB], q3[BQB], q4[BQB];   // q3.x = M_w.x (the forward's record has D there)
   float mwy[BQB];
   unsigned long long m64[BQB];
-  double acc[BQB][NACC_D];
-  float acc2[BQB][2];                       // v_means2d of the low-pass branch (rare): float adds
-  float acc_abs[ABSGRAD ? BQB : 1][2];
+  double acc[BQB][NACC_D];                  // (DET: the same 8 bytes as long long)
+  typename std::conditional<DET, long long, float>::type acc2[BQB][2];                       // v_means2d of the low-pass branch (rare): float adds
+  typename std::conditional<DET, long long, float>::type acc_abs[ABSGRAD ? BQB : 1][2];
   unsigned char list[64][BQB];
   unsigned short cmask[4][BQB];    // per wave: quad bits of the staged splats that reach the wave's quadrant (compacted, list order)
   unsigned char cslot[4][BQB];     //           and their slots
@@ -71,19 +93,30 @@ struct BwdQuadsLds {
 static_assert(BQB % 4 == 0 && BQB <= 256, "raster_bwd_quads: list words, byte slots");
 static_assert(sizeof(BwdQuadsLds<false>) * RASTER_BWD_QUADS_WGS <= 160 * 1024, "raster_bwd_quads: LDS per workgroup against the stated workgroups per CU");
 static_assert(sizeof(BwdQuadsLds<true>) * RASTER_BWD_QUADS_WGS <= 160 * 1024, "raster_bwd_quads (absgrad): LDS per workgroup against the stated workgroups per CU");
+static constexpr int RASTER_BWD_DET_WGS = 4;
+static_assert(sizeof(BwdQuadsLds<true, true>) * RASTER_BWD_DET_WGS <= 160 * 1024, "raster_bwd_quads (deterministic): LDS per workgroup");
 
 // Adds the LDS records of this wave's slots (slot = 4 lane + wave, thread_slot) to the global record array and clears them.
 // Three splats per instruction: lane = 21 j + k -> field k of the wave's j-th slot of this round.
-template <bool ABSGRAD>
-__device__ __forceinline__ void flush_records_quads(BwdQuadsLds<ABSGRAD> &lds, int wave, int lane, int g_mine, float *__restrict__ grec,
-                                                    float *__restrict__ grec_abs) {
+template <bool ABSGRAD, bool DET>
+__device__ __forceinline__ void flush_records_quads(BwdQuadsLds<ABSGRAD, DET> &lds, int wave, int lane, int g_mine, float *__restrict__ grec,
+                                                    float *__restrict__ grec_abs, DetHeader *__restrict__ det) {
   if (ABSGRAD) {
     const int slot = 4 * lane + wave;
     if (g_mine >= 0 && slot < BQB) {
 #pragma unroll
       for (int k = 0; k < 2; ++k) {
-        const float v = lds.acc_abs[slot][k];
-        if (v != 0.f) { lds.acc_abs[slot][k] = 0.f; atomicAdd(grec_abs + 2 * (int64_t)g_mine + k, v); }
+        if (DET) {
+          const long long v = (long long)lds.acc_abs[slot][k];
+          if (v != 0) {
+            lds.acc_abs[slot][k] = 0;
+            atomicAdd(reinterpret_cast<unsigned long long *>(grec_abs) + 2 * (int64_t)g_mine + k, (unsigned long long)v);
+            if (v >= DET_TILE_CAP || v <= -DET_TILE_CAP) det->poisoned = 1u;
+          }
+        } else {
+          const float v = (float)lds.acc_abs[slot][k];
+          if (v != 0.f) { lds.acc_abs[slot][k] = 0; atomicAdd(grec_abs + 2 * (int64_t)g_mine + k, v); }
+        }
       }
     }
   }
@@ -95,24 +128,34 @@ __device__ __forceinline__ void flush_records_quads(BwdQuadsLds<ABSGRAD> &lds, i
     const int g = __shfl(g_mine, sl & 63, 64);
     const int slot = 4 * sl + wave;
     if (j < 3 && sl < PER_WAVE && slot < BQB && g >= 0) {
-      float v;
-      if (k < 19) {
-        double *a = &lds.acc[slot][k];
-        const double d = *a;
-        v = (float)d;
-        if (d != 0.0) *a = 0.0;
+      if (DET) {
+        long long *a = k < 19 ? reinterpret_cast<long long *>(&lds.acc[slot][k]) : reinterpret_cast<long long *>(&lds.acc2[slot][k - 19]);
+        const long long v = *a;
+        if (v != 0) {
+          *a = 0;
+          atomicAdd(reinterpret_cast<unsigned long long *>(grec) + (int64_t)g * NACC + k, (unsigned long long)v);
+          if (v >= DET_TILE_CAP || v <= -DET_TILE_CAP) det->poisoned = 1u;
+        }
       } else {
-        float *a = &lds.acc2[slot][k - 19];
-        v = *a;
-        if (v != 0.f) *a = 0.f;
+        float v;
+        if (k < 19) {
+          double *a = &lds.acc[slot][k];
+          const double d = *a;
+          v = (float)d;
+          if (d != 0.0) *a = 0.0;
+        } else {
+          float *a = reinterpret_cast<float *>(&lds.acc2[slot][k - 19]);
+          v = *a;
+          if (v != 0.f) *a = 0.f;
+        }
+        if (v != 0.f) atomicAdd(grec + (int64_t)g * NACC + k, v);
       }
-      if (v != 0.f) atomicAdd(grec + (int64_t)g * NACC + k, v);
     }
   }
 }
 
-template <bool ABSGRAD, bool COUNT = false>
-__global__ void __launch_bounds__(RT, RASTER_BWD_QUADS_WGS)
+template <bool ABSGRAD, bool COUNT = false, bool DET = false>
+__global__ void __launch_bounds__(RT, DET ? RASTER_BWD_DET_WGS : RASTER_BWD_QUADS_WGS)
     raster_bwd_quads_kernel(int n_xcd, int64_t total_tiles, int64_t n_tiles, int64_t I, int W, int H, int tw,
                             const float4 *__restrict__ rec, const unsigned long long *__restrict__ pair_masks,
                             const float *__restrict__ backgrounds, const uint8_t *__restrict__ masks,
@@ -122,8 +165,9 @@ __global__ void __launch_bounds__(RT, RASTER_BWD_QUADS_WGS)
                             const float *__restrict__ v_render_depths, const float *__restrict__ v_render_alphas,
                             const float *__restrict__ v_render_normals, const float *__restrict__ v_render_median,
                             float *__restrict__ grec, float *__restrict__ grec_abs, const float *__restrict__ final_T,
-                            unsigned long long *__restrict__ counters = nullptr) {
-  __shared__ BwdQuadsLds<ABSGRAD> lds;
+                            unsigned long long *__restrict__ counters = nullptr, DetHeader *__restrict__ det = nullptr) {
+  __shared__ BwdQuadsLds<ABSGRAD, DET> lds;
+  const double to_fix = DET ? det->to_fix : 0.0;
   unsigned long long c_visit = 0, c_live = 0, c_valid = 0;
   const int64_t tile = xcd_tile_index(total_tiles, n_xcd);
   if (tile >= total_tiles) return;
@@ -162,7 +206,7 @@ __global__ void __launch_bounds__(RT, RASTER_BWD_QUADS_WGS)
 
   if (tid == 0) lds.bin_final_max = -1;
   for (int i = tid; i < BQB * NACC_D; i += RT) (&lds.acc[0][0])[i] = 0.0;
-  for (int i = tid; i < BQB * 2; i += RT) { (&lds.acc2[0][0])[i] = 0.f; if (ABSGRAD) (&lds.acc_abs[0][0])[i] = 0.f; }
+  for (int i = tid; i < BQB * 2; i += RT) { (&lds.acc2[0][0])[i] = 0; if (ABSGRAD) (&lds.acc_abs[0][0])[i] = 0; }
   __syncthreads();
   // last contributor of the quad (4 lanes), of the wave, of the tile
   const int quad_bin_final = quad_imax(bin_final);
@@ -184,7 +228,7 @@ __global__ void __launch_bounds__(RT, RASTER_BWD_QUADS_WGS)
   const int nb = (last - start + BQB - 1) / BQB;
   for (int b = nb - 1; b >= 0; --b) {
     __syncthreads();  // barrier A: previous batch fully consumed, its accumulators complete
-    flush_records_quads<ABSGRAD>(lds, wave, lane, g_mine, grec, grec_abs);
+    flush_records_quads<ABSGRAD, DET>(lds, wave, lane, g_mine, grec, grec_abs, det);
     g_mine = -1;
     const int32_t bstart = start + b * BQB;
     const int32_t idx = bstart + slot;
@@ -311,46 +355,98 @@ __global__ void __launch_bounds__(RT, RASTER_BWD_QUADS_WGS)
         const float v4[4] = {g_dx, g_dy, g_mwz, 0.f};   // slots 16..18 (+ padding)
         const float r1 = quad_transpose_reduce4(v4, lane);
         if (quad_valid) {
-          double *a = &lds.acc[t][0];
+          if (DET) {
+            unsigned long long *a = reinterpret_cast<unsigned long long *>(&lds.acc[t][0]);
 #pragma unroll
-          for (int i = 0; i < 4; ++i) atomicAdd(a + f0 + i, (double)r4[i]);
-          atomicAdd(a + f4, (double)r1);
+            for (int i = 0; i < 4; ++i) atomicAdd(a + f0 + i, (unsigned long long)det_fix(r4[i], to_fix));
+            atomicAdd(a + f4, (unsigned long long)det_fix(r1, to_fix));
+          } else {
+            double *a = &lds.acc[t][0];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) atomicAdd(a + f0 + i, (double)r4[i]);
+            atomicAdd(a + f4, (double)r1);
+          }
         }
       }
       if (any2) {  // screen-space low-pass branch (rare)
-        float r = quad_sum(g_x); if ((lane & 3) == 0 && r != 0.f) lds_add(&lds.acc2[t][0], r);
-        r = quad_sum(g_y); if ((lane & 3) == 0 && r != 0.f) lds_add(&lds.acc2[t][1], r);
+        auto add2 = [&](auto *p, float r) {
+          if ((lane & 3) == 0 && r != 0.f) {
+            if constexpr (DET) atomicAdd(reinterpret_cast<unsigned long long *>(p), (unsigned long long)det_fix(r, to_fix));
+            else lds_add(reinterpret_cast<float *>(p), r);
+          }
+        };
+        add2(&lds.acc2[t][0], quad_sum(g_x));
+        add2(&lds.acc2[t][1], quad_sum(g_y));
         if (ABSGRAD) {
-          r = quad_sum(fabsf(g_x)); if ((lane & 3) == 0 && r != 0.f) lds_add(&lds.acc_abs[t][0], r);
-          r = quad_sum(fabsf(g_y)); if ((lane & 3) == 0 && r != 0.f) lds_add(&lds.acc_abs[t][1], r);
+          add2(&lds.acc_abs[t][0], quad_sum(fabsf(g_x)));
+          add2(&lds.acc_abs[t][1], quad_sum(fabsf(g_y)));
         }
       }
     }
   }
   __syncthreads();
-  flush_records_quads<ABSGRAD>(lds, wave, lane, g_mine, grec, grec_abs);
+  flush_records_quads<ABSGRAD, DET>(lds, wave, lane, g_mine, grec, grec_abs, det);
   if (COUNT && lane == 0) { atomicAdd(counters + 4, c_visit); atomicAdd(counters + 5, c_live); atomicAdd(counters + 6, c_valid); }
 }
 
 // Streaming epilogue: unpack the 80-byte records into the operator's gradient tensors and derive the
 // densification signal (SPEC S-4, 2DGS convention consumed at neural_gaussian.cpp:660-665):
 // v_densify = (dL/dM_u.z, dL/dM_v.z) * M_w.z.
+// deterministic mode: the largest |upstream gradient| of the launch (unsigned max of bit patterns: order-independent) and the header made of it
+__global__ void __launch_bounds__(256)
+    det_upstream_max_kernel(int64_t P, const float *__restrict__ v_rc, const float *__restrict__ v_rd, const float *__restrict__ v_ra,
+                            const float *__restrict__ v_rn, const float *__restrict__ v_rm, DetHeader *__restrict__ det) {
+  __shared__ unsigned s_max;
+  if (threadIdx.x == 0) s_max = 0u;
+  __syncthreads();
+  unsigned m = 0u;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < P; i += (int64_t)gridDim.x * 256) {
+    const float v[9] = {v_rc[3 * i], v_rc[3 * i + 1], v_rc[3 * i + 2], v_rd[i], v_ra[i], v_rn[3 * i], v_rn[3 * i + 1], v_rn[3 * i + 2], v_rm[i]};
+#pragma unroll
+    for (int k = 0; k < 9; ++k) m = max(m, __float_as_uint(v[k]) & 0x7FFFFFFFu);   // (a NaN / Inf pattern is above every finite one)
+  }
+  atomicMax(&s_max, m);
+  __syncthreads();
+  if (threadIdx.x == 0 && s_max) atomicMax(&det->max_bits, s_max);
+}
+__global__ void det_header_kernel(DetHeader *__restrict__ det) {
+  const unsigned b = det->max_bits;
+  int e = (int)(b >> 23) - 126;                    // max < 2^e
+  if (b >= 0x7F800000u) { det->poisoned = 1u; e = 0; }
+  if (b == 0u) e = -100;
+  det->to_fix = ldexp(1.0, DET_UNIT_SHIFT - e);
+  det->from_fix = ldexp(1.0, e - DET_UNIT_SHIFT);
+}
+
+template <bool DET>
 __global__ void __launch_bounds__(256)
     unpack_records_kernel(int64_t M, const float *__restrict__ grec, const float *__restrict__ grec_abs,
                           const float *__restrict__ means2d, const float *__restrict__ ray_transforms,
                           float *__restrict__ v_means2d, float *__restrict__ v_ray_transforms,
                           float *__restrict__ v_colors, float *__restrict__ v_opacities, float *__restrict__ v_normals,
-                          float *__restrict__ v_densify, float *__restrict__ v_means2d_abs) {
+                          float *__restrict__ v_densify, float *__restrict__ v_means2d_abs, const DetHeader *__restrict__ det = nullptr) {
   const int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (m >= M) return;
-  float r[NACC];
+  float r[NACC], rabs[2] = {0.f, 0.f};
+  if (DET) {
+    const double from_fix = det->poisoned ? (double)__builtin_nanf("") : det->from_fix;
+    const long long *g64 = reinterpret_cast<const long long *>(grec);
 #pragma unroll
-  for (int k = 0; k < NACC; ++k) r[k] = grec[m * NACC + k];
+    for (int k = 0; k < NACC; ++k) r[k] = (float)((double)g64[m * NACC + k] * from_fix);
+    if (v_means2d_abs != nullptr) {
+      const long long *a64 = reinterpret_cast<const long long *>(grec_abs);
+      rabs[0] = (float)((double)a64[2 * m] * from_fix); rabs[1] = (float)((double)a64[2 * m + 1] * from_fix);
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < NACC; ++k) r[k] = grec[m * NACC + k];
+    if (v_means2d_abs != nullptr) { rabs[0] = grec_abs[2 * m]; rabs[1] = grec_abs[2 * m + 1]; }
+  }
 #pragma unroll
   for (int k = 0; k < 3; ++k) { v_colors[3 * m + k] = r[k]; v_normals[3 * m + k] = r[3 + k]; }
   v_opacities[m] = r[6];
   v_means2d[2 * m] = r[19]; v_means2d[2 * m + 1] = r[20];
-  if (v_means2d_abs != nullptr) { v_means2d_abs[2 * m] = grec_abs[2 * m]; v_means2d_abs[2 * m + 1] = grec_abs[2 * m + 1]; }
+  if (v_means2d_abs != nullptr) { v_means2d_abs[2 * m] = rabs[0]; v_means2d_abs[2 * m + 1] = rabs[1]; }
   // moments -> dL/dM.  With h_u = m_x M_w - M_u, h_v = m_y M_w - M_v evaluated at the splat centre (m_x, m_y):
   //   v_hu = h_v x V0 + M_w x Vy,   v_hv = V0 x h_u + Vx x M_w,
   //   dL/dM_u = -v_hu,   dL/dM_v = -v_hv,
@@ -388,8 +484,9 @@ __global__ void __launch_bounds__(256)
 
 using namespace gsdf;
 
+// (sized for the deterministic mode's 64-bit records whether or not it is on: the size query and the launch cannot disagree)
 static size_t bwd_records_bytes(int64_t M) {
-  return align_up((size_t)(M > 0 ? M : 1) * NACC * sizeof(float), 256) + align_up((size_t)(M > 0 ? M : 1) * 2 * sizeof(float), 256) + 256;
+  return align_up((size_t)(M > 0 ? M : 1) * NACC * sizeof(long long), 256) + align_up((size_t)(M > 0 ? M : 1) * 2 * sizeof(long long), 256) + 256;
 }
 // gradient records + room for the pack / mask passes (used when the caller does not hand over the forward's workspace)
 extern "C" size_t gsdf_rasterize_2dgs_bwd_ws_bytes(int64_t M, int64_t I) { return bwd_records_bytes(M) + raster_pack_bytes(M, I); }
@@ -416,10 +513,20 @@ static int rasterize_bwd_launch(int64_t C, int64_t M, int64_t I, int width, int 
                "rasterize_bwd: null input");
   const int tw = (width + TILE - 1) / TILE, th = (height + TILE - 1) / TILE;
   const int64_t n_tiles = (int64_t)tw * th, total = n_tiles * C;
+  const bool det = deterministic() && counters == nullptr;
+  const size_t rec_size = det ? sizeof(long long) : sizeof(float);
   float *grec = (float *)ws;
-  float *grec_abs = (float *)((char *)ws + align_up((size_t)M * NACC * sizeof(float), 256));
-  GSDF_HIP(hipMemsetAsync(grec, 0, (size_t)M * NACC * sizeof(float), stream), "rasterize_bwd memset");
-  if (v_means2d_abs) GSDF_HIP(hipMemsetAsync(grec_abs, 0, (size_t)M * 2 * sizeof(float), stream), "rasterize_bwd memset");
+  float *grec_abs = (float *)((char *)ws + align_up((size_t)M * NACC * rec_size, 256));
+  DetHeader *det_hdr = (DetHeader *)((char *)ws + bwd_records_bytes(M) - 256);
+  GSDF_HIP(hipMemsetAsync(grec, 0, (size_t)M * NACC * rec_size, stream), "rasterize_bwd memset");
+  if (v_means2d_abs) GSDF_HIP(hipMemsetAsync(grec_abs, 0, (size_t)M * 2 * rec_size, stream), "rasterize_bwd memset");
+  if (det) {
+    GSDF_HIP(hipMemsetAsync(det_hdr, 0, sizeof(DetHeader), stream), "rasterize_bwd memset");
+    det_upstream_max_kernel<<<1024, 256, 0, stream>>>(C * (int64_t)height * width, v_render_colors, v_render_depths, v_render_alphas, v_render_normals,
+                                                      v_render_median, det_hdr);
+    det_header_kernel<<<1, 1, 0, stream>>>(det_hdr);
+    GSDF_CHECK_LAUNCH("det_header_kernel");
+  }
   if (I > 0) {
     const int n_xcd = xcd_count(stream);
     if (fwd_ws == nullptr) {   // no forward workspace handed over: run the pack + mask passes into this call's own
@@ -431,7 +538,11 @@ static int rasterize_bwd_launch(int64_t C, int64_t M, int64_t I, int width, int 
 #define QARGS n_xcd, total, n_tiles, I, width, height, tw, (const float4 *)ws_records(fwd_ws), ws_masks(fwd_ws, M), backgrounds, masks, isect_offsets, \
               flatten_ids, render_alphas, last_ids, median_ids, v_render_colors, v_render_depths, v_render_alphas, v_render_normals,               \
               v_render_median, grec, grec_abs, final_T
-    if (counters != nullptr && v_means2d_abs)
+    if (det && v_means2d_abs)
+      raster_bwd_quads_kernel<true, false, true><<<xcd_grid(total, n_xcd), RT, 0, stream>>>(QARGS, nullptr, det_hdr);
+    else if (det)
+      raster_bwd_quads_kernel<false, false, true><<<xcd_grid(total, n_xcd), RT, 0, stream>>>(QARGS, nullptr, det_hdr);
+    else if (counters != nullptr && v_means2d_abs)
       raster_bwd_quads_kernel<true, true><<<xcd_grid(total, n_xcd), RT, 0, stream>>>(QARGS, counters);
     else if (counters != nullptr)
       raster_bwd_quads_kernel<false, true><<<xcd_grid(total, n_xcd), RT, 0, stream>>>(QARGS, counters);
@@ -442,9 +553,13 @@ static int rasterize_bwd_launch(int64_t C, int64_t M, int64_t I, int width, int 
 #undef QARGS
     GSDF_CHECK_LAUNCH("raster_bwd_quads_kernel");
   }
-  unpack_records_kernel<<<(unsigned)((M + 255) / 256), 256, 0, stream>>>(M, grec, grec_abs, means2d, ray_transforms, v_means2d,
-                                                                       v_ray_transforms, v_colors, v_opacities,
-                                                                       v_normals, v_densify, v_means2d_abs);
+  if (det)
+    unpack_records_kernel<true><<<(unsigned)((M + 255) / 256), 256, 0, stream>>>(M, grec, grec_abs, means2d, ray_transforms, v_means2d, v_ray_transforms,
+                                                                                 v_colors, v_opacities, v_normals, v_densify, v_means2d_abs, det_hdr);
+  else
+    unpack_records_kernel<false><<<(unsigned)((M + 255) / 256), 256, 0, stream>>>(M, grec, grec_abs, means2d, ray_transforms, v_means2d,
+                                                                                  v_ray_transforms, v_colors, v_opacities,
+                                                                                  v_normals, v_densify, v_means2d_abs);
   GSDF_CHECK_LAUNCH("unpack_records_kernel");
   return GSDF_OK;
 }

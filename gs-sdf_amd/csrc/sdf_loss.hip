@@ -58,21 +58,19 @@ __device__ __forceinline__ float sigmoidf(float x) { return 1.0f / (1.0f + __exp
 
 // 256-thread block sum -> ONE atomic per block on the loss value (atomics on one address serialise at ~88 per microsecond:
 // one per wave cost 0.1 ms at 4.5e5 points)
-__device__ __forceinline__ void block_sum_to_loss(float contrib, float *__restrict__ loss) {
+static __device__ DetScalarSlot g_det_sdf_loss[3];   // deterministic mode: the ordered finish of the loss value, one slot per kernel
+__device__ __forceinline__ void block_sum_to_loss(float contrib, float *__restrict__ loss, DetScalarSlot *det) {
   __shared__ float s_part[4];
   const float ws = wave_sum_to_lane63(contrib);
   if ((threadIdx.x & 63) == 63) s_part[threadIdx.x >> 6] = ws;
   __syncthreads();
-  if (threadIdx.x == 0) {
-    const float t = (s_part[0] + s_part[1]) + (s_part[2] + s_part[3]);
-    if (t != 0.f) atomicAdd(loss, t);
-  }
+  finish_scalars((s_part[0] + s_part[1]) + (s_part[2] + s_part[3]), 0.f, loss, nullptr, det);
 }
 
 __global__ void __launch_bounds__(256)
     sdf_ray_loss_kernel(int64_t n, int stencil, const float *__restrict__ attr, int ld, const float *__restrict__ gt,
                         float bce_isigma, float delta, float w_eik, float *__restrict__ loss,
-                        float *__restrict__ v_attr) {
+                        float *__restrict__ v_attr, bool det) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   float contrib = 0.f;
   if (i < n) {
@@ -116,7 +114,7 @@ __global__ void __launch_bounds__(256)
       }
     }
   }
-  block_sum_to_loss(contrib, loss);
+  block_sum_to_loss(contrib, loss, det ? &g_det_sdf_loss[0] : nullptr);
 }
 
 // loss::gs_sdf_loss (/root/reference/include/optimizer/loss.cpp:7-11): 0.5 * sum_i w_i * sdf_i^2, with the row gather of
@@ -128,7 +126,7 @@ __global__ void __launch_bounds__(256)
 __global__ void __launch_bounds__(256)
     gs_sdf_loss_kernel(int64_t n, int stencil, const float *__restrict__ attr, int ld, const float *__restrict__ weights,
                        const int64_t *__restrict__ ids, float scale, float delta, float w_eik, float *__restrict__ loss,
-                       float *__restrict__ v_attr) {
+                       float *__restrict__ v_attr, bool det) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   float contrib = 0.f;
   if (i < n) {
@@ -157,7 +155,7 @@ __global__ void __launch_bounds__(256)
       }
     }
   }
-  block_sum_to_loss(contrib, loss);
+  block_sum_to_loss(contrib, loss, det ? &g_det_sdf_loss[1] : nullptr);
 }
 
 
@@ -183,7 +181,7 @@ __global__ void __launch_bounds__(256)
                              const float *__restrict__ jac, const float *__restrict__ gt, const float *__restrict__ weights,
                              const int64_t *__restrict__ ids, float bce_isigma, float w_sdf, float w_gs, float map_size_inv, float delta,
                              float w_eik, float w_align, float *__restrict__ loss, float *__restrict__ v_attr,
-                             float *__restrict__ vv_x, float *__restrict__ u0) {
+                             float *__restrict__ vv_x, float *__restrict__ u0, bool det) {
   static_assert(NF == 32, "8 lanes x 4 features");
   __shared__ float s_part[4];
   float contrib = 0.f;
@@ -278,10 +276,7 @@ __global__ void __launch_bounds__(256)
   const float ws = wave_sum_to_lane63(contrib);
   if ((threadIdx.x & 63) == 63) s_part[threadIdx.x >> 6] = ws;
   __syncthreads();
-  if (threadIdx.x == 0) {
-    const float t = (s_part[0] + s_part[1]) + (s_part[2] + s_part[3]);
-    if (t != 0.f) atomicAdd(loss, t);
-  }
+  finish_scalars((s_part[0] + s_part[1]) + (s_part[2] + s_part[3]), 0.f, loss, nullptr, det ? &g_det_sdf_loss[2] : nullptr);
 }
 
 }  // namespace gsdf
@@ -325,8 +320,10 @@ extern "C" int gsdf_sdf_ray_loss(int64_t n, int stencil, const float *attr, int 
   GSDF_REQUIRE(n > 0 && ld >= 2 && attr && gt_sdf && loss && v_attr, "sdf_ray_loss: bad arguments");
   GSDF_REQUIRE(!stencil || delta > 0.f, "sdf_ray_loss: delta must be positive");
   GSDF_HIP(hipMemsetAsync(loss, 0, 4, stream), "sdf_ray_loss memset");
+  const bool det = deterministic();
+  GSDF_REQUIRE(!det || (n + 255) / 256 <= DET_MAX_BLOCKS, "sdf_ray_loss: deterministic mode takes at most %d rows", DET_MAX_BLOCKS * 256);
   sdf_ray_loss_kernel<<<(unsigned)((n + 255) / 256), 256, 0, stream>>>(n, stencil, attr, ld, gt_sdf, bce_isigma, delta,
-                                                                       w_eik, loss, v_attr);
+                                                                       w_eik, loss, v_attr, det);
   GSDF_CHECK_LAUNCH("sdf_ray_loss_kernel");
   return GSDF_OK;
 }
@@ -341,8 +338,10 @@ extern "C" int gsdf_gs_sdf_eik_loss(int64_t n, int stencil, const float *attr, i
   GSDF_HIP(hipMemsetAsync(loss, 0, 4, stream), "gs_sdf_loss memset");
   if (n == 0) return GSDF_OK;
   GSDF_REQUIRE(attr && weights && v_attr, "gs_sdf_loss: null buffer");
+  const bool det = deterministic();
+  GSDF_REQUIRE(!det || (n + 255) / 256 <= DET_MAX_BLOCKS, "gs_sdf_loss: deterministic mode takes at most %d rows", DET_MAX_BLOCKS * 256);
   gs_sdf_loss_kernel<<<(unsigned)((n + 255) / 256), 256, 0, stream>>>(n, stencil, attr, ld, weights, ids, scale, delta,
-                                                                      w_eik, loss, v_attr);
+                                                                      w_eik, loss, v_attr, det);
   GSDF_CHECK_LAUNCH("gs_sdf_loss_kernel");
   return GSDF_OK;
 }
@@ -368,7 +367,7 @@ extern "C" int gsdf_sdf_analytic_loss(int64_t n, int64_t n_ray, int stencil, con
   const int64_t blocks = (n + 31) / 32;          // 8 lanes per point
   sdf_analytic_loss_kernel<32><<<(unsigned)(blocks > 2048 ? 2048 : blocks), 256, 0, stream>>>(n, n_ray, stencil, attr, ld, g0, jac, gt_sdf, weights,
                                                                                            ids, bce_isigma, w_sdf, w_gs, map_size_inv, delta,
-                                                                                           w_eik, w_align, loss, v_attr, vv_x, u0);
+                                                                                           w_eik, w_align, loss, v_attr, vv_x, u0, deterministic());
   GSDF_CHECK_LAUNCH("sdf_analytic_loss_kernel");
   return GSDF_OK;
 }

@@ -191,7 +191,7 @@ struct CouplingFn : public torch::autograd::Function<CouplingFn> {
     if (auto *gate = reinterpret_cast<gsdf_extras::StreamGate *>(ctx->saved_data["gate"].toInt())) gate->record_here();
     // the binned scatter does not cover every grid (log2_hashmap_size >= 20, more than 4096 tiles: ws_bytes == 0): those take
     // the atomic kernel, like TCNNEncoding's own backward and the Python mirror
-    const size_t nb = nq >= 24576 ? gsdf_hashgrid_bwd_binned_ws_bytes(nq, c.L, c.F, c.H, c.R, c.S) : 0;
+    const size_t nb = (nq >= 24576 || gsdf_deterministic(-1)) ? gsdf_hashgrid_bwd_binned_ws_bytes(nq, c.L, c.F, c.H, c.R, c.S) : 0;   // (deterministic mode: no atomic scatter)
     if (nb > 0) {
       int merge = 0;
       for (int l = 0; l < c.L; ++l)
@@ -325,7 +325,7 @@ struct AnalyticFn : public torch::autograd::Function<AnalyticFn> {
                            ws2.data_ptr(), cur_stream()), "mlp_bwd_bwd");
     // table: first-order (v_feat) and second-order (g0, vv_x) contributions of every corner in ONE scatter
     Tensor vvx = scaled(vv_x);
-    const size_t nb = n >= 24576 ? gsdf_hashgrid_bwd_binned_ws_bytes(n, L, F, H, R, S) : 0;
+    const size_t nb = (n >= 24576 || gsdf_deterministic(-1)) ? gsdf_hashgrid_bwd_binned_ws_bytes(n, L, F, H, R, S) : 0;   // (deterministic mode: no atomic scatter)
     if (nb > 0) {
       Tensor bws2 = empty_like_opts(feat, {(int64_t)nb}, torch::kUInt8);
       check(gsdf_hashgrid_bwd_binned2(n, L, F, H, R, S, fp(x01), fp(v_feat), fp(g0), fp(vvx), fpm(table_grad), bws2.data_ptr(), nb, cur_stream()),

@@ -111,6 +111,7 @@ PYBIND11_MODULE(_gsdf_host, m) {
            py::arg("ray_sdf"), py::arg("upstream"), py::arg("update") = true, py::arg("cam_host") = std::vector<float>(),
            py::call_guard<py::gil_scoped_release>())       // step() runs the autograd engine
       .def("sync", &gsdf_extras::JointIteration::sync)
+      .def("last_losses", &gsdf_extras::JointIteration::last_losses)
       .def("set_grad_hooks", &gsdf_extras::JointIteration::set_grad_hooks)
       .def("splat_flat", &gsdf_extras::JointIteration::splat_flat)
       .def("splat_flat_grad", &gsdf_extras::JointIteration::splat_flat_grad)

@@ -57,7 +57,7 @@ struct GridBwd : public torch::autograd::Function<GridBwd> {
     Tensor v_x = torch::empty_like(x);
     Tensor v_table = want_table ? torch::zeros_like(table) : Tensor();
     // large batches: the table gradient without global atomics (gsdf_hashgrid_bwd_binned), d/dx from the plain kernel
-    const size_t binned = (want_table && B >= 24576) ? gsdf_hashgrid_bwd_binned_ws_bytes(B, c.L, c.F, c.H, c.R, c.S) : 0;
+    const size_t binned = (want_table && (B >= 24576 || gsdf_deterministic(-1))) ? gsdf_hashgrid_bwd_binned_ws_bytes(B, c.L, c.F, c.H, c.R, c.S) : 0;
     if (binned) {
       Tensor ws = empty_like_opts(x, {(int64_t)binned}, torch::kUInt8);
       check(gsdf_hashgrid_bwd(B, c.L, c.F, c.H, c.R, c.S, fp(x), fp(table), fp(v_feat), nullptr, fpm(v_x), cur_stream()),
@@ -85,7 +85,7 @@ static void grid_double_backward(const GridCfg &c, const Tensor &vv, const Tenso
                                  Tensor &g_x, Tensor &g_table) {
   const int64_t B = x.size(0);
   // large batches: the table part of the double backward through the binned scatter's second-order form (no global atomics)
-  const size_t binned = (g_table.defined() && B >= 24576) ? gsdf_hashgrid_bwd_binned_ws_bytes(B, c.L, c.F, c.H, c.R, c.S) : 0;
+  const size_t binned = (g_table.defined() && (B >= 24576 || gsdf_deterministic(-1))) ? gsdf_hashgrid_bwd_binned_ws_bytes(B, c.L, c.F, c.H, c.R, c.S) : 0;
   if (binned) {
     Tensor ws = empty_like_opts(x, {(int64_t)binned}, torch::kUInt8);
     check(gsdf_hashgrid_bwd_binned2(B, c.L, c.F, c.H, c.R, c.S, fp(x), nullptr, fp(v_feat), fp(vv), fpm(g_table), ws.data_ptr(), binned,

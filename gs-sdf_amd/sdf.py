@@ -75,7 +75,7 @@ def scatter_table_grad(B, cfg, x, table, v_feat, v_table, v_x=None, stencil=None
     L = capi.lib()
     mode = os.environ.get("GSDF_HASHGRID_BINNED", "auto")
     nbytes = 0
-    if v_table is not None and mode != "0" and (mode == "1" or B >= BINNED_MIN_POINTS):
+    if v_table is not None and mode != "0" and (mode == "1" or B >= BINNED_MIN_POINTS or L.gsdf_deterministic(-1)):
         nbytes = L.gsdf_hashgrid_bwd_binned_ws_bytes(B, *cfg)
     if nbytes:
         if v_x is not None:
@@ -160,7 +160,7 @@ def _grid_double_backward(cfg, vv_x, v_feat, x, table, need_vf, need_x, need_t):
     # table part: large batches take the binned scatter's second-order form (no global atomics), like the first order
     nbytes = 0
     if need_t and os.environ.get("GSDF_HASHGRID_BINNED", "auto") != "0" and \
-            (os.environ.get("GSDF_HASHGRID_BINNED") == "1" or B >= BINNED_MIN_POINTS):
+            (os.environ.get("GSDF_HASHGRID_BINNED") == "1" or B >= BINNED_MIN_POINTS or L.gsdf_deterministic(-1)):
         nbytes = L.gsdf_hashgrid_bwd_binned_ws_bytes(B, *cfg)
     if nbytes:
         ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)

@@ -43,6 +43,16 @@ const char *gsdf_last_error(void);
 #define GSDF_ABI_VERSION 9
 int gsdf_abi_version(void);
 
+/* Deterministic mode (process-wide — a step's backward kernels are launched by the autograd engine's thread, not by the caller's; on != 0 switches
+ * it on, on == 0 off, on < 0 only asks; returns the previous setting).  While it is on, the entry points accumulate in an order-independent way, so that
+ * two runs from the same state produce the same bits: the compositing backward sums its records in 64-bit fixed point (unit 2^-34 of the
+ * launch's largest upstream gradient; a tile sum of 2^13 times that maximum or more poisons the outputs with NaN), the loss values are reduced in
+ * a fixed order (one device-global slot per kernel: such a kernel must not run on two streams at once), the decoder's weight gradients leave
+ * through per-wave partial buffers.  The table scatter is order-independent in either mode; the atomic fall-backs for tiny batches
+ * (gsdf_hashgrid_bwd, the fp32-pipe decoder kernels) are not covered: the host layers route around them while the mode is on.  The integer
+ * outputs and every forward pass are deterministic in either mode.  Costs about 2 ms per step at the headline workload: a validation mode. */
+int gsdf_deterministic(int on);
+
 /* Optional per-entry-point device timing (bench.py's roofline leg, for callers in any language): between gsdf_timing_begin and
  * gsdf_timing_end every timed entry point records a HIP event pair on ITS OWN stream around everything it launches (an operator
  * such as gsdf_hashgrid_bwd_binned2 is several kernels).  only_csv: NULL = all, else a comma-separated list of entry-point names.

@@ -220,6 +220,12 @@ def test_neural_gs_training_schedule_matches_python_mirror(host):
     """30 iterations of render -> L1 -> backward -> Adam -> train_callback with refinement every 4 iterations from 9 on and an
     opacity reset at 20: the two implementations must take every discrete decision identically (same splat count after every
     iteration) and carry the same parameters and Adam moments."""
+    import gs_sdf_amd.capi as capi
+    with capi.deterministic():       # round 6: order-independent accumulation in the compositing backward, so that the element-wise bar below is the
+        _training_schedule(host)     # 1.5e-3 of the elements (4e-3 while two runs of ONE implementation differed by their atomics)
+
+
+def _training_schedule(host):
     kw = dict(refine_start_iter=8, refine_every=4, reset_every=20, grow_grad2d=2e-7, center_reg=True, sh_degree_interval=10)
     cg, pg, cam, poses = scene_models(host, **kw)
     copt, popt = cg.make_optimizer(), pg.make_optimizer()
@@ -247,10 +253,11 @@ def test_neural_gs_training_schedule_matches_python_mirror(host):
     if flipped:
         return                                             # the element-wise comparison below needs the same splat set
     assert torch.equal(cg.anchors_, pg.anchors_)
-    # Two runs of the SAME implementation differ here too: the compositing backward accumulates with fp32 atomics (order varies run to run) and
-    # Adam turns a sign flip of a vanishing gradient into a full +-lr step, 30 iterations deep.  Measured over repeated runs: 0.5-1.05e-3 of the
-    # elements of a tensor end up above 1e-4 (worst ~7e-3); the allowance is 4e-3 of the elements (the bar itself stays 1e-4).
-    OUT = 4e-3
+    # The two sides fuse their activations differently, and Adam turns a sign flip of a vanishing gradient into a full +-lr step, 30 iterations
+    # deep: a few elements end up above 1e-4.  In deterministic mode (above) that is all there is — without it two runs of the SAME implementation
+    # differed by their fp32 atomics (0.5-1.05e-3 of the elements above 1e-4, bar 4e-3 in round 5).  Measured in deterministic mode: 230 of 213 k
+    # offsets (1.08e-3), the same number in every run; the allowance is 1.5e-3 of the elements.
+    OUT = 1.5e-3
     fin = lambda t: torch.nan_to_num(t, neginf=-1e4)       # split children: log(0) in the unused third scale (as the reference)
     for k, f in enumerate(PFIELDS):
         a, b = getattr(cg, f).detach(), getattr(pg, f).detach()
