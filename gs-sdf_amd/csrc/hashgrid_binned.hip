@@ -41,7 +41,7 @@ static constexpr int BIN_PTS = GSDF_BIN_PTS;            // points per emit workg
 static constexpr int BIN_G = 2;                        // levels per emit workgroup (16 B of v_feat per point)
 static constexpr int BIN_MAX_LOCAL = 256;              // buckets one emit workgroup can address
 #ifndef GSDF_BIN_GPW
-#define GSDF_BIN_GPW 4
+#define GSDF_BIN_GPW 1
 #endif
 static constexpr int BIN_GPW = GSDF_BIN_GPW;           // level groups one emit workgroup walks (its points' feature rows are read once per GPW groups)
 #ifndef GSDF_BIN_ITEM_MIN
@@ -393,10 +393,12 @@ __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v, int lane) {
 // one thread per (point, level of the group); PTS points x G levels per workgroup = PTS * G * 8 records staged in LDS.
 // The records of a workgroup leave as one run per bucket: the fewer buckets a workgroup addresses and the more points it
 // holds, the longer the runs (PTS * G * 8 / (G * 128 tiles) records of 8 bytes)
-// Round 6: a workgroup walks GPW level groups of ITS points one after the other instead of one.  A point's feature gradients are a 128-byte
-// row of which one level group uses 16 bytes: with one group per workgroup every row was fetched by eight workgroups (FETCH_SIZE 0.48 GB for
-// 0.12 GB of inputs, as much as the records the pass writes — the pass is HBM-bound).  With GPW = 4 a workgroup consumes a 64-byte half row
-// per point, prefetched into registers before the first group.
+// Round 6, measured and NOT adopted (GPW stays 1; the template parameter is kept for the experiment): a workgroup that walks GPW level groups of ITS
+// points one after the other.  A point's feature gradients are a 128-byte row of which one level group uses 16 bytes: with one group per workgroup
+// every row is fetched by eight workgroups (FETCH_SIZE 0.48 GB for 0.12 GB of inputs, as much as the records the pass writes).  GPW = 4 (a 64-byte
+// half row per point, prefetched into registers) removes those fetches and changes nothing: 230 us either way at 0.44 M points (GPW 1 / 2 / 4 / 8:
+// 231 / 241 / 229 / 229 us), 4 % slower at 3 M (97 registers instead of 68) — the re-fetches are L2 hits, the pass is bound by its 8-byte-record
+// runs of 16 (128 B) landing in 1900 buckets.
 template <int PTS, int G, int GPW>
 __global__ void __launch_bounds__(PTS * G)
     bin_emit_kernel(int64_t B, HgLevels lv, BinPlan bp, BinStencil stn, const float *__restrict__ x,
