@@ -10,7 +10,7 @@ workload = sys.argv[2] if len(sys.argv) > 2 else "cfg3_1M_1080p"
 short = workload.split("_")[0]
 root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
 OPS = {"hashgrid_fwd": ["hashgrid_fwd_kernel", "hashgrid_fwd_xcd_kernel", "hashgrid_fwd_stencil_kernel"],
-       "hashgrid_bwd": ["bin_vmax_kernel", "bin_count_kernel", "bin_plan_kernel", "bin_emit_kernel", "bin_apply_kernel"],
+       "hashgrid_bwd": ["bin_vmax_kernel", "bin_count_kernel", "bin_plan_kernel", "bin_emit_kernel", "bin_apply_kernel", "bin_reduce_kernel"],
        "hashgrid_bwd_atomic": ["hashgrid_bwd_kernel<true"], "hashgrid_bwd_input": ["hashgrid_bwd_kernel<false", "hashgrid_bwd_jac_kernel"],
        "rasterize_2dgs_fwd": ["raster_fwd_quads_kernel", "raster_pack_kernel", "raster_mask_kernel"], "rasterize_2dgs_bwd": ["raster_bwd_quads_kernel", "unpack_records_kernel"], "mlp_fwd": ["mlp_fwd_kernel", "mlp_fwd_split_kernel"],
        "mlp_bwd": ["mlp_bwd_split_kernel"], "mlp_bwd_data": ["mlp_bwd_data_kernel"], "mlp_bwd_weights": ["mlp_bwd_weights_kernel"], "l1_dssim_fwd": ["l1_dssim_fwd_kernel"],
