@@ -114,3 +114,21 @@ def test_joint_iteration_is_bit_reproducible(host):
     assert torch.equal(a[0], b[0]), "splat parameters differ between two deterministic runs"
     assert torch.equal(a[1], b[1]), "SDF parameters differ between two deterministic runs"
     assert a[2] == b[2], "loss values differ between two deterministic runs"
+
+
+def test_timing_trace_is_a_timeline_of_the_entry_points():
+    """gsdf_timing_trace (include/gsdf_hip.h): the HIP-event pairs of the C-ABI timers in call order, begin <= end, relative to the first call"""
+    import gs_sdf_amd.capi as capi
+    dev = torch.device("cuda:0")
+    L = capi.lib()
+    x = torch.rand(5000, 3, device=dev)
+    table = torch.rand(7634944, 2, device=dev)
+    feat = torch.empty(5000, 32, device=dev)
+    capi.timing_begin(None)
+    for _ in range(3):
+        capi.check(L.gsdf_hashgrid_fwd(5000, 16, 2, 19, 32, 2.0, capi.f32(x), capi.f32(table), capi.f32(feat), capi.stream()), "fwd")
+    torch.cuda.synchronize()
+    tr = capi.timing_trace()
+    assert [n for n, _, _ in tr] == ["gsdf_hashgrid_fwd"] * 3
+    assert tr[0][1] == 0.0 and all(b >= a >= 0.0 for _, a, b in tr) and tr[1][1] >= tr[0][2] - 1e-3 and tr[2][1] >= tr[1][2] - 1e-3
+    assert capi.timing_trace() == []          # the collection is handed over once
