@@ -49,7 +49,9 @@ int gsdf_abi_version(void);
  * launch's largest upstream gradient; a tile sum of 2^13 times that maximum or more poisons the outputs with NaN), the loss values are reduced in
  * a fixed order (one device-global slot per kernel: such a kernel must not run on two streams at once), the decoder's weight gradients leave
  * through per-wave partial buffers.  The table scatter is order-independent in either mode; the atomic fall-backs for tiny batches
- * (gsdf_hashgrid_bwd, the fp32-pipe decoder kernels) are not covered: the host layers route around them while the mode is on.  The integer
+ * (gsdf_hashgrid_bwd, the fp32-pipe decoder kernels) and the float atomics that sum a splat's gradient over SEVERAL cameras of one call (C > 1 in
+ * the projection / view-colour backward, densify statistics) are not covered: the host layers route around the former while the mode is on, the
+ * training loop renders one camera per call.  The integer
  * outputs and every forward pass are deterministic in either mode.  Costs about 2 ms per step at the headline workload: a validation mode. */
 int gsdf_deterministic(int on);
 
