@@ -116,6 +116,9 @@ def main():
     ap.add_argument("--hashgrid-resident", type=int, default=-1,
                     help="C++ step, two streams: workgroups per CU of the stencil hash-grid forward's resident grid (JointConfig::hashgrid_resident; "
                          "-1 = its default, 0 = the full grid)")
+    ap.add_argument("--samples-grad-first", type=int, default=-1,
+                    help="C++ step: 1 = the SDF node sends the samples' gradient on its way before the regularisers' launches "
+                         "(JointConfig::samples_grad_first, the default), 0 = the whole first order at backward time")
     ap.add_argument("--collective", default="all_reduce", choices=["all_reduce", "reduce_scatter_all_gather"],
                     help="N > 1: how a parameter family's flat gradient buffer is summed over the ranks")
     args = ap.parse_args()

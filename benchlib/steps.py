@@ -23,7 +23,7 @@ def make_cpp_iteration(args, sc, params, dev, W, H, deg, views):
         dec.biases_ = lm.decoder.biases_.detach().clone()
     fields = [params.views[k].detach().clone() for k in ("offsets", "scaling", "quaternion", "opacity", "features_dc", "features_rest")]
     ji = host.JointIteration(params.anchors, fields, enc, dec, [0.0, 0.0, 5.5], 16.0, 0.02, 8, W, H, deg, not args.no_overlap, analytic, ref_terms,
-                            args.sample_mode == "center", getattr(args, "hashgrid_resident", -1))   # level 8: 1/16 m leaves in 16 m
+                            args.sample_mode == "center", getattr(args, "hashgrid_resident", -1), getattr(args, "samples_grad_first", -1))   # level 8: 1/16 m leaves in 16 m
     gq = torch.Generator().manual_seed(4)
     pool = [((torch.rand(32768, 3, generator=gq) - 0.5) * 14.0 + torch.tensor([0.0, 0.0, 5.5])).to(dev) for _ in range(8)]
     ray_sdf = [(torch.randn(32768, 1, generator=gq) * 0.02).to(dev) for _ in range(8)]

@@ -15,7 +15,7 @@ _lib = None
 
 _i64, _i32, _f32, _u64, _vp, _sz = C.c_int64, C.c_int, C.c_float, C.c_uint64, C.c_void_p, C.c_size_t
 
-ABI_VERSION = 9      # include/gsdf_hip.h: GSDF_ABI_VERSION this binding was written against
+ABI_VERSION = 10     # include/gsdf_hip.h: GSDF_ABI_VERSION this binding was written against
 
 
 class RasterInstr(C.Structure):
@@ -77,6 +77,7 @@ _SIGS = {
     "gsdf_mlp_bwd_bwd_ws_bytes": (_sz, [_i64, _i32]),
     "gsdf_mlp_bwd_bwd": (C.c_int, [_i64, _i32] + [_vp] * 10),
     "gsdf_hashgrid_bwd_binned2": (C.c_int, [_i64, _i32, _i32, _i32, _i32, _f32] + [_vp] * 6 + [_sz, _vp]),
+    "gsdf_sdf_data_term_grad": (C.c_int, [_i64, _i64, _vp, _i32, _vp, _vp, _vp] + [_f32] * 3 + [_vp] * 2),
     "gsdf_sdf_analytic_loss": (C.c_int, [_i64, _i64, _i32, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp] + [_f32] * 7 + [_vp] * 5),
     "gsdf_l1_dssim_fwd": (C.c_int, [_i32, _i32] + [_vp] * 6),
     "gsdf_l1_dssim_bwd": (C.c_int, [_i32, _i32] + [_vp] * 5 + [_f32, _f32, _vp, _vp]),

@@ -159,6 +159,53 @@ __global__ void __launch_bounds__(256)
 }
 
 
+// The data term of one base row and its gradient with respect to the decoder's outputs: rows [0, n_ray) w_sdf * loss::sdf_loss (mean over the
+// per-ray batch), rows [n_ray, n) w_gs * loss::gs_sdf_loss.  Shared by sdf_analytic_loss_kernel and sdf_data_term_grad_kernel: the same operations
+// in the same order, i.e. the same bits from either.
+__device__ __forceinline__ void data_term(bool ray, float s, float raw, float g, float w, float bce_isigma, float w_sdf, float w_gs, float inv_n,
+                                          float &c_pt, float &va0, float &va1) {
+#pragma clang fp contract(off)   // (which products fuse with which sums is the compiler's choice per call site: none, so that both kernels round alike)
+  if (ray) {
+    const float br = 100.0f * raw;
+    const float sp = br > 20.0f ? raw : log1pf(expf(br)) * 0.01f;
+    const float dsp = br > 20.0f ? 1.0f : sigmoidf(br);
+    const float is0 = 1.0f + sp * bce_isigma;
+    const float is = fminf(is0, 500.0f);
+    const float dis_draw = is0 <= 500.0f ? dsp * bce_isigma : 0.0f;
+    const float x = -s * is, u = -g * is;
+    const float t0 = sigmoidf(u);
+    const float t = fminf(fmaxf(t0, 1e-7f), 1.0f - 1e-7f);
+    const float dt_du = (t0 >= 1e-7f && t0 <= 1.0f - 1e-7f) ? t0 * (1.0f - t0) : 0.0f;
+    const float bce = (1.0f - t) * x + fmaxf(-x, 0.0f) + log1pf(expf(-fabsf(x)));
+    const float dx = sigmoidf(x) - t, dt = -x;
+    const float d_is = dx * (-s) + dt * dt_du * (-g);
+    c_pt += w_sdf * bce * inv_n;
+    va0 = w_sdf * dx * (-is) * inv_n;
+    va1 = w_sdf * d_is * dis_draw * inv_n;
+  } else {
+    c_pt += 0.5f * w_gs * w * s * s;
+    va0 = w_gs * w * s;
+  }
+}
+
+// d (data terms) / d attr of the base rows ALONE (what sdf_analytic_loss_kernel writes as v_attr): it needs neither the stencil rows nor g0, so
+// the joint iteration can send the samples' gradient on its way (decoder backward -> Jacobian contraction) before the regularisers' inputs exist.
+__global__ void __launch_bounds__(256)
+    sdf_data_term_grad_kernel(int64_t n, int64_t n_ray, const float *__restrict__ attr, int ld, const float *__restrict__ gt,
+                              const float *__restrict__ weights, const int64_t *__restrict__ ids, float bce_isigma, float w_sdf, float w_gs,
+                              float *__restrict__ v_attr) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const bool ray = i < n_ray;
+  const float inv_n = 1.0f / (float)(ray ? n_ray : n - n_ray);
+  float c_pt = 0.f, va0 = 0.f, va1 = 0.f;
+  data_term(ray, attr[i * ld], ray ? attr[i * ld + 1] : 0.f, ray ? gt[i] : 0.f, ray ? 0.f : weights[ids != nullptr ? ids[i - n_ray] : i - n_ray], bce_isigma,
+            w_sdf, w_gs, inv_n, c_pt, va0, va1);
+  v_attr[i * ld] = va0;
+  if (ld > 1) v_attr[i * ld + 1] = va1;
+  for (int c = 2; c < ld; ++c) v_attr[i * ld + c] = 0.f;
+}
+
 // ---- the reference's DEFAULT regulariser: analytic SDF gradient (numerical_grad: 0, config/base.yaml:13) ------------------
 // NeuralSLAM::sdf_regularization (/root/reference/include/neural_mapping/neural_mapping.cpp:106-136) with
 // LocalMap::get_gradient's autograd branch (include/neural_net/local_map.cpp:151-172):
@@ -199,30 +246,8 @@ __global__ void __launch_bounds__(256)
     const float inv_n = 1.0f / (float)(ray ? n_ray : n - n_ray);
     const float s = attr[ic * ld];
     float c_pt = 0.f, va0 = 0.f, va1 = 0.f;
-    if (ray) {
-      const float raw = attr[ic * ld + 1], g = gt[ic];
-      const float br = 100.0f * raw;
-      const float sp = br > 20.0f ? raw : log1pf(expf(br)) * 0.01f;
-      const float dsp = br > 20.0f ? 1.0f : sigmoidf(br);
-      const float is0 = 1.0f + sp * bce_isigma;
-      const float is = fminf(is0, 500.0f);
-      const float dis_draw = is0 <= 500.0f ? dsp * bce_isigma : 0.0f;
-      const float x = -s * is, u = -g * is;
-      const float t0 = sigmoidf(u);
-      const float t = fminf(fmaxf(t0, 1e-7f), 1.0f - 1e-7f);
-      const float dt_du = (t0 >= 1e-7f && t0 <= 1.0f - 1e-7f) ? t0 * (1.0f - t0) : 0.0f;
-      const float bce = (1.0f - t) * x + fmaxf(-x, 0.0f) + log1pf(expf(-fabsf(x)));
-      const float dx = sigmoidf(x) - t, dt = -x;
-      const float d_is = dx * (-s) + dt * dt_du * (-g);
-      c_pt += w_sdf * bce * inv_n;
-      va0 = w_sdf * dx * (-is) * inv_n;
-      va1 = w_sdf * d_is * dis_draw * inv_n;
-    } else {
-      const int64_t j = ic - n_ray;
-      const float w = weights[ids != nullptr ? ids[j] : j];
-      c_pt += 0.5f * w_gs * w * s * s;
-      va0 = w_gs * w * s;
-    }
+    data_term(ray, s, ray ? attr[ic * ld + 1] : 0.f, ray ? gt[ic] : 0.f, ray ? 0.f : weights[ids != nullptr ? ids[ic - n_ray] : ic - n_ray], bce_isigma,
+              w_sdf, w_gs, inv_n, c_pt, va0, va1);
     // analytic gradient in world units: this lane's 4 features
     const float4 *J4 = reinterpret_cast<const float4 *>(jac + ic * (int64_t)(NF * 3) + 12 * q);
     const float4 j0 = J4[0], j1 = J4[1], j2 = J4[2];
@@ -266,9 +291,11 @@ __global__ void __launch_bounds__(256)
       *reinterpret_cast<float4 *>(u0 + i * (int64_t)NF + 4 * q) = uo;
       if (q == 0) {
         contrib += c_pt;
-        v_attr[i * ld] = va0;
-        if (ld > 1) v_attr[i * ld + 1] = va1;       // (0 for a splat-sample row)
-        for (int c = 2; c < ld; ++c) v_attr[i * ld + c] = 0.f;
+        if (v_attr != nullptr) {                      // (NULL: gsdf_sdf_data_term_grad has written it already)
+          v_attr[i * ld] = va0;
+          if (ld > 1) v_attr[i * ld + 1] = va1;       // (0 for a splat-sample row)
+          for (int c = 2; c < ld; ++c) v_attr[i * ld + c] = 0.f;
+        }
         vv_x[3 * i] = vx; vv_x[3 * i + 1] = vy; vv_x[3 * i + 2] = vz;
       }
     }
@@ -363,11 +390,24 @@ extern "C" int gsdf_sdf_analytic_loss(int64_t n, int64_t n_ray, int stencil, con
   GSDF_REQUIRE(!(stencil && w_align != 0.f) || delta > 0.f, "sdf_analytic_loss: delta must be positive");
   GSDF_HIP(hipMemsetAsync(loss, 0, 4, stream), "sdf_analytic_loss memset");
   if (n == 0) return GSDF_OK;
-  GSDF_REQUIRE(attr && g0 && jac && v_attr && vv_x && u0 && (n_ray == 0 || gt_sdf) && (n_ray == n || weights), "sdf_analytic_loss: null buffer");
+  GSDF_REQUIRE(attr && g0 && jac && vv_x && u0 && (n_ray == 0 || gt_sdf) && (n_ray == n || weights), "sdf_analytic_loss: null buffer");
   const int64_t blocks = (n + 31) / 32;          // 8 lanes per point
   sdf_analytic_loss_kernel<32><<<(unsigned)(blocks > 2048 ? 2048 : blocks), 256, 0, stream>>>(n, n_ray, stencil, attr, ld, g0, jac, gt_sdf, weights,
                                                                                            ids, bce_isigma, w_sdf, w_gs, map_size_inv, delta,
                                                                                            w_eik, w_align, loss, v_attr, vv_x, u0, deterministic());
   GSDF_CHECK_LAUNCH("sdf_analytic_loss_kernel");
+  return GSDF_OK;
+}
+
+extern "C" int gsdf_sdf_data_term_grad(int64_t n, int64_t n_ray, const float *attr, int ld, const float *gt_sdf, const float *weights, const int64_t *ids,
+                                       float bce_isigma, float w_sdf, float w_gs, float *v_attr, gsdf_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  GSDF_TIMED("gsdf_sdf_data_term_grad");
+  GSDF_REQUIRE(n >= 0 && n_ray >= 0 && n_ray <= n, "sdf_data_term_grad: bad arguments");
+  GSDF_REQUIRE(ld >= (n_ray > 0 ? 2 : 1), "sdf_data_term_grad: decoder output too narrow");
+  if (n == 0) return GSDF_OK;
+  GSDF_REQUIRE(attr && v_attr && (n_ray == 0 || gt_sdf) && (n_ray == n || weights), "sdf_data_term_grad: null buffer");
+  sdf_data_term_grad_kernel<<<(unsigned)((n + 255) / 256), 256, 0, stream>>>(n, n_ray, attr, ld, gt_sdf, weights, ids, bce_isigma, w_sdf, w_gs, v_attr);
+  GSDF_CHECK_LAUNCH("sdf_data_term_grad_kernel");
   return GSDF_OK;
 }

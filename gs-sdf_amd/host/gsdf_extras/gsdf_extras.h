@@ -63,6 +63,10 @@ torch::Tensor gs_sdf_coupling(const torch::Tensor &samples, const torch::Tensor 
 //             detached, :448-451) + w_align * mean |analytic - numerical.detach()| (6 forward-only stencil rows, :126-134).
 // Either part may be empty (undefined tensor).  d loss / d samples is returned to autograd; the encoder's table gradient and the decoder's
 // unit_upstream: the caller promises to call backward() on the returned loss itself (upstream gradient exactly 1): three scaling launches go.
+// first_order_in_forward (needs unit_upstream): the FIRST-ORDER chain (data-term gradient -> one-pass decoder backward -> Jacobian contraction =
+// d loss / d samples, `samples_grad_ready` recorded behind it) runs inside the forward call, ahead of the stencil rows' decoder pass, the e0
+// backward and the loss kernel: the splat leg gets its samples' gradient earlier by those three launches; the first order's parameter gradients
+// are then accumulated at forward time.  Same bits as the backward-time order in deterministic mode (tests/test_gpu_host_layer.py).
 // weight / bias gradients are ACCUMULATED IN PLACE into table_grad / decoder_grad / bias_grad (views of the flat gradient buffer):
 // one-pass decoder backward, decoder double backward (gsdf_mlp_bwd_bwd), ONE binned scatter carrying the first- and second-order
 // table gradient (gsdf_hashgrid_bwd_binned2).  dec may carry biases (config "bias": true = the torch decoder's topology).
@@ -70,7 +74,8 @@ torch::Tensor joint_sdf_loss_analytic(const torch::Tensor &ray_xyz, const torch:
                                       const torch::Tensor &ids, const torch::Tensor &weights, ::TCNNEncoding &enc, ::TCNNNetwork &dec,
                                       const std::vector<float> &map_origin, double map_size_inv, double bce_isigma, double w_sdf, double w_gs,
                                       double delta, double w_eik, double w_align, torch::Tensor table_grad, torch::Tensor decoder_grad,
-                                      torch::Tensor bias_grad, StreamGate *samples_grad_ready = nullptr, bool unit_upstream = false);
+                                      torch::Tensor bias_grad, StreamGate *samples_grad_ready = nullptr, bool unit_upstream = false,
+                                      bool first_order_in_forward = false);
 
 // render_normal_weight's term (neural_mapping.cpp:243-266): mean(alpha^2 - nan_to_num((depth_to_normal(depth) * alpha) . render_normal)),
 // alpha detached.  depth [H,W,1], alpha [H,W,1], render_normal [H,W,3] (world); intrinsics {fx, fy, cx, cy} and the camera->world pose
@@ -105,6 +110,10 @@ class FusedAdam {
   int add_group(const torch::Tensor &flat, const torch::Tensor &flat_grad, const std::vector<int64_t> &sizes, const std::vector<double> &lrs);
   void set_lr(int group, int segment, double lr) { groups_.at(group).lrs.at(segment) = (float)lr; }
   void step(bool zero_grad = false);   // zero_grad: the gradient buffers are zeroed as they are consumed (no fill launches)
+  // step() of group 0 in two launches (same bits): step_tail — everything behind its first `head_segments` segments, and the other groups; the step
+  // count advances —, then step_head — those first segments, whose gradient arrives last
+  void step_tail(int head_segments, bool zero_grad = false);
+  void step_head(int head_segments, bool zero_grad = false);
   int64_t step_count() const { return t_; }
   // refinement (optimizer_utils.cpp:5-165 on flat buffers): the group's buffers are replaced by re-materialised ones of another row count;
   // `sizes` = the new segment sizes (learning rates are kept); the step count is kept, as torch::optim::Adam's per-parameter state keeps it
@@ -148,6 +157,8 @@ struct JointConfig {
   // config/base.yaml -> 0): one stochastic point on every visible splat's disc, weight exp(-|eps|^2 / 2) (neural_gaussian.cpp:259-265)
   bool center_reg = true;
   bool two_streams = false;   // the SDF network's work on a second HIP stream beside the splat leg (bench.py's overlapped schedule)
+  bool samples_grad_first = true;   // two_streams + analytic, direct splat leg: joint_sdf_loss_analytic(first_order_in_forward) — the samples' gradient (what the splats'
+                              // optimizer and the next render wait for) leaves the SDF leg before the stencil rows' decoder pass, the e0 backward and the loss kernel
   int hashgrid_resident = 3;  // two_streams + analytic only: workgroups per CU of the stencil hash-grid forward's RESIDENT grid (gsdf_hashgrid_fwd_stencil_resident):
                               // the rest of every CU stays free for the splat leg's kernels; 0 = the full grid.  Round 6 (tools/ab_lib.sh, same box, two runs
                               // each): 2 -> 4.51 ms per step (hash-grid forward 2.11 ms beside the compositing backward), 3 -> 4.26 (1.62 ms = its time alone:
@@ -242,7 +253,7 @@ class JointIteration {
   std::map<std::string, int64_t> apply_row_map(RefinePlanArgs &pa);   // plan -> totals -> new buffers -> apply -> rebind
   void bind_views(const torch::Tensor &flat, const torch::Tensor &flat_grad, int64_t n);
   // the splat leg without the autograd engine (step_direct): loss weights as device scalars, a never-written zero image, scratch
-  torch::Tensor w_one_, w_normal_, w_iso_, zero_image_, scratch_;
+  torch::Tensor w_one_, one0_, w_normal_, w_iso_, zero_image_, scratch_;
   std::vector<torch::Tensor> last_losses_;
   bool direct_ok(const torch::Tensor &viewmat) const;
   std::map<std::string, int64_t> step_direct(const torch::Tensor &viewmat, const torch::Tensor &K, const torch::Tensor &target,

@@ -213,7 +213,7 @@ struct AnalyticFn : public torch::autograd::Function<AnalyticFn> {
   static Tensor forward(AutogradContext *ctx, const Tensor &ray_xyz, const Tensor &gt_sdf, const Tensor &samples, const Tensor &ids_,
                         const Tensor &weights, const Tensor &table_, const Tensor &W_, const Tensor &bias_, Tensor table_grad, Tensor decoder_grad,
                         Tensor bias_grad, std::vector<int64_t> iv, std::vector<double> dv, int64_t gate_handle) {
-    // iv = {L, F, H, R, dims...}; dv = {S, origin x3, map_size_inv, bce_isigma, w_sdf, w_gs, delta, w_eik, w_align, unit_upstream}
+    // iv = {L, F, H, R, dims...}; dv = {S, origin x3, map_size_inv, bce_isigma, w_sdf, w_gs, delta, w_eik, w_align, unit_upstream, first_order_in_forward}
     const int L = (int)iv[0], F = (int)iv[1], H = (int)iv[2], R = (int)iv[3];
     const std::vector<int> dims(iv.begin() + 4, iv.end());
     const float S = (float)dv[0];
@@ -245,6 +245,33 @@ struct AnalyticFn : public torch::autograd::Function<AnalyticFn> {
     Tensor attr = empty_like_opts(xs, {nq, d_out}, torch::kFloat32);
     Tensor acts = empty_like_opts(xs, {(int64_t)gsdf_mlp_acts_floats(n, nl)}, torch::kFloat32);
     check(gsdf_mlp_fwd(n, nl, dims.data(), fp(W), fp(bias), fp(feat), fpm(attr), fpm(acts), cur_stream()), "mlp_fwd");
+    Tensor gt = n_ray > 0 ? f32c(gt_sdf.detach().reshape({-1}), "gt_sdf") : Tensor();
+    Tensor w = n > n_ray ? f32c(weights.detach().reshape({-1}), "weights") : Tensor();
+    Tensor v_attr = empty_like_opts(xs, {n, d_out}, torch::kFloat32);
+    // first_order_in_forward (with unit_upstream: the caller backwards this node's output directly, gradient exactly 1): the FIRST-ORDER chain runs here, ahead of everything the
+    // regularisers need.  d (data terms) / d attr needs the base rows' outputs only, so the decoder's one-pass backward and the Jacobian contraction
+    // that gives the splat leg its samples' gradient — what the splats' optimizer and the next render wait for — are launched before the six
+    // blocks of stencil rows go through the decoder, before the e0 backward and before the loss kernel; those move to where nobody but the SDF
+    // optimizer waits for them.  The parameter gradients of the first order are accumulated here in that case, not in backward().
+    const bool eager = dv.size() > 12 && dv[11] != 0.0 && dv[12] != 0.0;
+    Tensor v_feat, v_samples;
+    if (eager) {
+      check(gsdf_sdf_data_term_grad(n, n_ray, fp(attr), (int)d_out, fp(gt), fp(w), (n > n_ray && ids.defined()) ? ids.data_ptr<int64_t>() : nullptr,
+                                    (float)bce_isigma, (float)w_sdf, (float)w_gs, fpm(v_attr), cur_stream()), "sdf_data_term_grad");
+      v_feat = empty_like_opts(xs, {n, nf}, torch::kFloat32);
+      Tensor ws = empty_like_opts(xs, {(int64_t)gsdf_mlp_bwd_ws_bytes_for(n, nl, dims.data(), 1)}, torch::kUInt8);
+      check(gsdf_mlp_bwd(n, nl, dims.data(), fp(W), fp(bias), fp(feat), fp(acts), fp(v_attr), fpm(v_feat), fpm(decoder_grad),
+                         bias.defined() ? fpm(bias_grad) : nullptr, ws.data_ptr(), cur_stream()), "mlp_bwd");
+      if (samples.requires_grad() && n > n_ray) {
+        v_samples = torch::zeros({samples.size(0), 3}, xs.options().dtype(torch::kFloat32).requires_grad(false));
+        check(gsdf_hashgrid_bwd_jac_scatter(n - n_ray, L, F, fp(jac) + n_ray * nf * 3, fp(v_feat) + n_ray * nf, (float)map_size_inv,
+                                            ids.defined() ? ids.data_ptr<int64_t>() : nullptr, fpm(v_samples), cur_stream()), "hashgrid_bwd_jac_scatter");
+      }
+      if (auto *gate = reinterpret_cast<gsdf_extras::StreamGate *>(gate_handle)) {
+        gate->record_here();
+        gate->payload = v_samples.defined() ? v_samples.data_ptr() : nullptr;
+      }
+    }
     if (stencil)   // forward-only rows: the numerical gradient of the align term is detached
       check(gsdf_mlp_fwd(6 * n, nl, dims.data(), fp(W), fp(bias), fp(feat) + n * nf, fpm(attr) + n * d_out, nullptr, cur_stream()), "mlp_fwd");
     // g0 = d sdf / d features: the decoder's backward of e_0; its per-layer gradients stay in `bws` for the double backward
@@ -262,17 +289,20 @@ struct AnalyticFn : public torch::autograd::Function<AnalyticFn> {
     Tensor bws = lean ? empty_like_opts(xs, {0}, torch::kUInt8) : empty_like_opts(xs, {(int64_t)gsdf_mlp_bwd_ws_bytes(n, nl)}, torch::kUInt8);
     check(gsdf_mlp_bwd(n, nl, dims.data(), fp(W), fp(bias), fp(feat), fp(acts), fp(e0), fpm(g0), nullptr, nullptr, lean ? nullptr : bws.data_ptr(),
                        cur_stream()), "mlp_bwd");
-    Tensor loss = empty_like_opts(xs, {}, torch::kFloat32), v_attr = empty_like_opts(xs, {n, d_out}, torch::kFloat32);
+    Tensor loss = empty_like_opts(xs, {}, torch::kFloat32);
     Tensor vv_x = empty_like_opts(xs, {n, 3}, torch::kFloat32), u0 = empty_like_opts(xs, {n, nf}, torch::kFloat32);
-    Tensor gt = n_ray > 0 ? f32c(gt_sdf.detach().reshape({-1}), "gt_sdf") : Tensor();
-    Tensor w = n > n_ray ? f32c(weights.detach().reshape({-1}), "weights") : Tensor();
     check(gsdf_sdf_analytic_loss(n, n_ray, stencil ? 1 : 0, fp(attr), (int)d_out, fp(g0), nf, fp(jac), fp(gt), fp(w),
                                  (n > n_ray && ids.defined()) ? ids.data_ptr<int64_t>() : nullptr, (float)bce_isigma, (float)w_sdf, (float)w_gs,
-                                 (float)map_size_inv, (float)delta, (float)w_eik, (float)w_align, fpm(loss), fpm(v_attr), fpm(vv_x), fpm(u0),
+                                 (float)map_size_inv, (float)delta, (float)w_eik, (float)w_align, fpm(loss), eager ? nullptr : fpm(v_attr), fpm(vv_x), fpm(u0),
                                  cur_stream()), "sdf_analytic_loss");
     // (tensors that travel to backward without autograd's saved-tensor version check: the in-place gradient sinks)
     ctx->save_for_backward({ids.defined() ? ids : torch::zeros({0}, xs.options().dtype(torch::kInt64)), x01, feat, jac, acts, bws, e0, g0, v_attr, vv_x, u0,
                             table, W, bias.defined() ? bias : torch::zeros({0}, xs.options())});
+    ctx->saved_data["eager"] = eager;
+    if (eager) {
+      ctx->saved_data["v_feat"] = v_feat;
+      if (v_samples.defined()) ctx->saved_data["v_samples"] = v_samples;
+    }
     ctx->saved_data["table_grad"] = table_grad;
     ctx->saved_data["decoder_grad"] = decoder_grad;
     ctx->saved_data["bias_grad"] = bias_grad.defined() ? bias_grad : torch::zeros({0}, xs.options());
@@ -303,7 +333,17 @@ struct AnalyticFn : public torch::autograd::Function<AnalyticFn> {
     // unit_upstream: the caller backwards this node's output directly (gradient exactly 1): no scaling launches
     const bool unit = dv.size() > 11 && dv[11] != 0.0;
     auto scaled = [&](const Tensor &t) { return unit ? t : (t * g[0]).contiguous(); };
-    Tensor v_out = scaled(v_attr), v_feat = empty_like_opts(feat, {n, nf}, torch::kFloat32);
+    const bool eager = ctx->saved_data["eager"].toBool();   // the first order ran in forward(): its gradients are where they belong already
+    Tensor v_feat;
+    if (eager) {
+      v_feat = ctx->saved_data["v_feat"].toTensor();
+      if (ctx->saved_data.count("v_samples")) {   // the only reference leaves with the result: the engine's gradient accumulator keeps the buffer instead of copying it
+        out[2] = ctx->saved_data["v_samples"].toTensor();
+        ctx->saved_data.erase("v_samples");
+      }
+    } else {
+    Tensor v_out = scaled(v_attr);
+    v_feat = empty_like_opts(feat, {n, nf}, torch::kFloat32);
     // first order: data terms through the decoder (one pass: input + parameter gradients)
     Tensor ws = empty_like_opts(feat, {(int64_t)gsdf_mlp_bwd_ws_bytes_for(n, nl, dims.data(), 1)}, torch::kUInt8);
     check(gsdf_mlp_bwd(n, nl, dims.data(), fp(W), fp(bias), fp(feat), fp(acts), fp(v_out), fpm(v_feat), fpm(decoder_grad),
@@ -317,6 +357,7 @@ struct AnalyticFn : public torch::autograd::Function<AnalyticFn> {
       out[2] = v_samples;
     }
     if (auto *gate = reinterpret_cast<gsdf_extras::StreamGate *>(ctx->saved_data["gate"].toInt())) gate->record_here();
+    }
     // second order: the regularisers reach the decoder weights through g0 = W_0^T D_0 ... e_0 (nobody waits for it but the optimizer:
     // issued after the samples' gradient, which the splat leg's backward is waiting for)
     Tensor vv_in = scaled(u0), g_vout = torch::empty_like(e0);
@@ -388,8 +429,9 @@ struct IsotropicFn : public torch::autograd::Function<IsotropicFn> {
 Tensor joint_sdf_loss_analytic(const Tensor &ray_xyz, const Tensor &gt_sdf, const Tensor &samples, const Tensor &ids, const Tensor &weights,
                                ::TCNNEncoding &enc, ::TCNNNetwork &dec, const std::vector<float> &origin, double map_size_inv, double bce_isigma,
                                double w_sdf, double w_gs, double delta, double w_eik, double w_align, Tensor table_grad, Tensor decoder_grad,
-                               Tensor bias_grad, StreamGate *samples_grad_ready, bool unit_upstream) {
+                               Tensor bias_grad, StreamGate *samples_grad_ready, bool unit_upstream, bool first_order_in_forward) {
   TORCH_CHECK(origin.size() == 3, "joint_sdf_loss_analytic: map_origin needs 3 entries");
+  TORCH_CHECK(unit_upstream || !first_order_in_forward, "joint_sdf_loss_analytic: first_order_in_forward needs unit_upstream (the gradients leave before backward() is called)");
   TORCH_CHECK(table_grad.defined() && table_grad.numel() == enc.params_.numel() && table_grad.is_contiguous() && decoder_grad.defined() &&
                   decoder_grad.numel() == dec.params_.numel() && decoder_grad.is_contiguous() &&
                   (!dec.biases_.defined() || (bias_grad.defined() && bias_grad.numel() == dec.biases_.numel() && bias_grad.is_contiguous())),
@@ -397,7 +439,7 @@ Tensor joint_sdf_loss_analytic(const Tensor &ray_xyz, const Tensor &gt_sdf, cons
   std::vector<int64_t> iv = {enc.n_levels_, enc.n_feat_, enc.log2_hashmap_, enc.base_res_};
   iv.insert(iv.end(), dec.dims_.begin(), dec.dims_.end());
   std::vector<double> dv = {enc.per_level_scale_, origin[0], origin[1], origin[2], map_size_inv, bce_isigma, w_sdf, w_gs, delta, w_eik, w_align,
-                            unit_upstream ? 1.0 : 0.0};
+                            unit_upstream ? 1.0 : 0.0, first_order_in_forward ? 1.0 : 0.0};
   // autograd::Function::apply wants defined tensors: an empty tensor stands for "absent"
   const auto opt = enc.params_.options().requires_grad(false);
   auto e = [&](const Tensor &t) { return t.defined() ? t : torch::empty({0}, opt); };
@@ -487,6 +529,46 @@ void FusedAdam::step(bool zero_grad) {
                      : gsdf_adam_step(g.flat.numel(), (int)g.lrs.size(), g.begins.data(), g.lrs.data(), fpm(g.flat), fp(g.grad), fpm(g.m), fpm(g.v),
                                       (float)b1_, (float)b2_, (float)eps_, t_, cur_stream())),
           "adam_step");
+}
+
+// The step of group 0 in two launches: step_tail() — the elements behind the first `head_segments` segments (from the next multiple of 4 on: the
+// kernel's vectors stay aligned) and every other group, the step count advances — and later step_head(), the elements before that point.  For a
+// caller whose first segments' gradient arrives last (the joint iteration: the offsets' gradient waits for the SDF leg, the other 11 of a splat's
+// 14 parameters do not).  Elementwise, so the two launches write the bits step() writes.
+static void adam_range(const Tensor &flat, const Tensor &grad, const Tensor &m, const Tensor &v, const std::vector<int64_t> &begins, const std::vector<float> &lrs,
+                       int64_t e0, int64_t e1, bool zero_grad, double b1, double b2, double eps, int64_t t) {
+  if (e1 <= e0) return;
+  std::vector<int64_t> bg;
+  std::vector<float> lr;
+  for (size_t k = 0; k < begins.size(); ++k) {
+    const int64_t end = k + 1 < begins.size() ? begins[k + 1] : flat.numel();
+    if (end <= e0 && k + 1 < begins.size()) continue;   // wholly before the range
+    if (begins[k] >= e1) break;
+    bg.push_back(std::max<int64_t>(begins[k] - e0, 0));
+    lr.push_back(lrs[k]);
+  }
+  float *p = flat.data_ptr<float>() + e0, *g = grad.data_ptr<float>() + e0, *mm = m.data_ptr<float>() + e0, *vv = v.data_ptr<float>() + e0;
+  check(zero_grad ? gsdf_adam_step_zero_grad(e1 - e0, (int)lr.size(), bg.data(), lr.data(), p, g, mm, vv, (float)b1, (float)b2, (float)eps, t, cur_stream())
+                  : gsdf_adam_step(e1 - e0, (int)lr.size(), bg.data(), lr.data(), p, g, mm, vv, (float)b1, (float)b2, (float)eps, t, cur_stream()),
+        "adam_step");
+}
+static int64_t head_end(const std::vector<int64_t> &begins, int head_segments, int64_t n) {
+  const int64_t b = head_segments < (int)begins.size() ? begins[head_segments] : n;
+  return std::min<int64_t>((b + 3) / 4 * 4, n);
+}
+void FusedAdam::step_tail(int head_segments, bool zero_grad) {
+  torch::NoGradGuard ng;
+  ++t_;
+  for (size_t gi = 0; gi < groups_.size(); ++gi) {
+    Group &g = groups_[gi];
+    adam_range(g.flat, g.grad, g.m, g.v, g.begins, g.lrs, gi == 0 ? head_end(g.begins, head_segments, g.flat.numel()) : 0, g.flat.numel(), zero_grad, b1_, b2_,
+               eps_, t_);
+  }
+}
+void FusedAdam::step_head(int head_segments, bool zero_grad) {
+  torch::NoGradGuard ng;
+  Group &g = groups_.at(0);
+  adam_range(g.flat, g.grad, g.m, g.v, g.begins, g.lrs, 0, head_end(g.begins, head_segments, g.flat.numel()), zero_grad, b1_, b2_, eps_, t_);
 }
 
 void FusedAdam::replace_group(int group, const Tensor &flat, const Tensor &flat_grad, const Tensor &m, const Tensor &v, const std::vector<int64_t> &sizes) {

@@ -557,7 +557,7 @@ std::map<std::string, int64_t> JointIteration::step_direct(const Tensor &viewmat
     ResidentGridHint hint(ResidentGridHint::of(cfg_));
     sdf_loss = joint_sdf_loss_analytic(ray_pts, ray_sdf, has ? samples_cut : Tensor(), has ? ids : Tensor(), has ? w_all : Tensor(), *enc_, *dec_, origin_,
                                        map_size_inv_, bce_isigma_, cfg_.sdf_w, cfg_.gs_sdf_w, cfg_.sdf_delta, cfg_.eik_w, cfg_.align_w, tg, dg, bg,
-                                       &streams_->gate, /*unit_upstream=*/true);
+                                       &streams_->gate, /*unit_upstream=*/true, /*first_order_in_forward=*/cfg_.samples_grad_first);
   }
   // ---- the splat leg's losses (values kept for the caller) and their gradients
   std::vector<float> intr, pose;
@@ -631,17 +631,28 @@ std::map<std::string, int64_t> JointIteration::step_direct(const Tensor &viewmat
     check(gsdf_normal_consistency_fwd(H, W, intr.data(), pose.data(), fp(d1), fp(ra), fp(nw), fpm(l_normal), cur_stream()), "normal_consistency_fwd");
     check(gsdf_isotropic_loss_fwd(M, fp(scales), M ? gaussian_ids.data_ptr<int64_t>() : nullptr, fpm(l_iso), cur_stream()), "isotropic_loss_fwd");
   }
+  // centre mode, no collective: the samples' gradient reaches the offsets alone, so the optimizer's step over the other 11 of a splat's 14 parameters
+  // (scaling, quaternion, opacity, colours) does not wait for the SDF leg — only the offsets' step stays behind the gate (FusedAdam::step_tail / _head)
+  const bool split_adam = update && center && !splat_hook_ && cfg_.samples_grad_first;
+  if (split_adam) adam_.step_tail(/*head_segments=*/1, /*zero_grad=*/fused_zero());
   // ---- the SDF leg's backward on the second stream, then its d loss / d samples on this one
   {
     StreamGuard sg(streams_->side);
     torch::AutoGradMode grad_on(true);
-    sdf_loss.backward();
+    if (!one0_.defined()) one0_ = torch::ones({}, fopt);
+    torch::autograd::backward({sdf_loss}, {one0_});   // (a kept scalar 1: no fill launch for the root gradient on the loop)
     if (!streams_->gate.armed) streams_->gate.record_here();
   }
   Tensor gs = samples_cut.grad();
   if (gs.defined()) {
     gs = f32c(gs, "samples gradient");
     gs.record_stream(main_stream);
+    if (streams_->gate.payload != nullptr && streams_->gate.payload != gs.data_ptr()) {   // the event was recorded at forward time for another buffer: the engine
+      StreamGuard sg(streams_->side);                                                     // copied it on the second stream during backward — wait for all of that
+      streams_->gate.record_here();
+      sizes["samples_grad_copied"] = 1;
+    }
+    streams_->gate.payload = nullptr;
     if (streams_->gate.armed) { streams_->gate.event.block(main_stream); streams_->gate.armed = false; }
     if (center)   // one camera: every splat appears once among the visible rows -> plain read-modify-write
       check(gsdf_rows_scatter_add(M, 3, M ? gaussian_ids.data_ptr<int64_t>() : nullptr, 1, fp(gs), fpm(g_off), cur_stream()), "rows_scatter_add(samples)");
@@ -650,7 +661,8 @@ std::map<std::string, int64_t> JointIteration::step_direct(const Tensor &viewmat
   // ---- optimizers, each family on its leg's stream (view-parallel: the family's collective first, on the same stream)
   if (splat_hook_) splat_hook_(flat_grad_);
   if (update) {
-    adam_.step(/*zero_grad=*/fused_zero());
+    if (split_adam) adam_.step_head(/*head_segments=*/1, /*zero_grad=*/fused_zero());
+    else adam_.step(/*zero_grad=*/fused_zero());
     if (!fused_zero()) flat_grad_.zero_();
     count_nan_rows();   // prune_nan_gs's test, no host sync
   }

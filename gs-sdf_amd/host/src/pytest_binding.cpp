@@ -98,15 +98,16 @@ PYBIND11_MODULE(_gsdf_host, m) {
   py::class_<gsdf_extras::JointIteration, std::shared_ptr<gsdf_extras::JointIteration>>(m, "JointIteration")
       .def(py::init([](const torch::Tensor &anchors, const std::vector<torch::Tensor> &fields, std::shared_ptr<TCNNEncoding> enc,
                        std::shared_ptr<TCNNNetwork> dec, std::vector<float> origin, double map_size, double bce_sigma, int occ_level, int width,
-                       int height, int sh_degree, bool two_streams, bool analytic, bool reference_terms, bool center_reg, int hashgrid_resident) {
+                       int height, int sh_degree, bool two_streams, bool analytic, bool reference_terms, bool center_reg, int hashgrid_resident, int samples_grad_first) {
         gsdf_extras::JointConfig cfg;
         cfg.width = width; cfg.height = height; cfg.sh_degree = sh_degree; cfg.two_streams = two_streams;
         cfg.analytic = analytic; cfg.reference_terms = reference_terms; cfg.center_reg = center_reg;
         if (hashgrid_resident >= 0) cfg.hashgrid_resident = hashgrid_resident;
+        if (samples_grad_first >= 0) cfg.samples_grad_first = samples_grad_first != 0;
         return std::make_shared<gsdf_extras::JointIteration>(anchors, fields, enc, dec, origin, map_size, bce_sigma, occ_level, cfg);
       }), py::arg("anchors"), py::arg("fields"), py::arg("enc"), py::arg("dec"), py::arg("origin"), py::arg("map_size"), py::arg("bce_sigma"),
            py::arg("occ_level"), py::arg("width"), py::arg("height"), py::arg("sh_degree"), py::arg("two_streams"), py::arg("analytic") = true,
-           py::arg("reference_terms") = true, py::arg("center_reg") = true, py::arg("hashgrid_resident") = -1)
+           py::arg("reference_terms") = true, py::arg("center_reg") = true, py::arg("hashgrid_resident") = -1, py::arg("samples_grad_first") = -1)
       .def("step", &gsdf_extras::JointIteration::step, py::arg("viewmat"), py::arg("K"), py::arg("target"), py::arg("ray_pts"),
            py::arg("ray_sdf"), py::arg("upstream"), py::arg("update") = true, py::arg("cam_host") = std::vector<float>(),
            py::call_guard<py::gil_scoped_release>())       // step() runs the autograd engine
@@ -175,11 +176,13 @@ PYBIND11_MODULE(_gsdf_host, m) {
   m.def("joint_sdf_loss_analytic", [](py::object ray_xyz, py::object gt, py::object samples, py::object ids, py::object weights,
                                       std::shared_ptr<TCNNEncoding> enc, std::shared_ptr<TCNNNetwork> dec, std::vector<float> origin,
                                       double map_size_inv, double bce_isigma, double w_sdf, double w_gs, double delta, double w_eik, double w_align,
-                                      torch::Tensor table_grad, torch::Tensor decoder_grad, py::object bias_grad) {
+                                      torch::Tensor table_grad, torch::Tensor decoder_grad, py::object bias_grad, bool unit_upstream, bool first_order_in_forward) {
     auto t = [](const py::object &o) { return o.is_none() ? torch::Tensor() : o.cast<torch::Tensor>(); };
     return gsdf_extras::joint_sdf_loss_analytic(t(ray_xyz), t(gt), t(samples), t(ids), t(weights), *enc, *dec, origin, map_size_inv, bce_isigma,
-                                                w_sdf, w_gs, delta, w_eik, w_align, table_grad, decoder_grad, t(bias_grad));
-  });
+                                                w_sdf, w_gs, delta, w_eik, w_align, table_grad, decoder_grad, t(bias_grad), nullptr, unit_upstream, first_order_in_forward);
+  }, py::arg("ray_xyz"), py::arg("gt_sdf"), py::arg("samples"), py::arg("ids"), py::arg("weights"), py::arg("enc"), py::arg("dec"), py::arg("origin"),
+     py::arg("map_size_inv"), py::arg("bce_isigma"), py::arg("w_sdf"), py::arg("w_gs"), py::arg("delta"), py::arg("w_eik"), py::arg("w_align"),
+     py::arg("table_grad"), py::arg("decoder_grad"), py::arg("bias_grad"), py::arg("unit_upstream") = false, py::arg("first_order_in_forward") = false);
   m.def("normal_consistency_loss", &gsdf_extras::normal_consistency_loss);
   m.def("isotropic_loss", &gsdf_extras::isotropic_loss);
   m.def("render_post", &gsdf_extras::render_post);

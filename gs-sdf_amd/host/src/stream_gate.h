@@ -7,6 +7,8 @@ namespace gsdf_extras {
 struct StreamGate {
   at::cuda::CUDAEvent event;
   bool armed = false;
+  const void *payload = nullptr;   // the tensor the event stands for, when it was recorded ahead of the autograd pass that hands it over (joint_sdf_loss_analytic,
+                                   // first_order_in_forward): a consumer that receives another buffer (the engine copied it) must wait for that one instead
   void record_here() {   // on the current stream
     event.record(c10::hip::getCurrentHIPStreamMasqueradingAsCUDA());
     armed = true;

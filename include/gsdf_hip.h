@@ -40,7 +40,7 @@ const char *gsdf_last_error(void);
 /* ABI version; bumped on any signature change.  Every binding compares gsdf_abi_version() of the library it loaded with the
  * GSDF_ABI_VERSION of the header it was written against and refuses to run on a mismatch (gs_sdf_amd/capi.py: lib(); the C++
  * operator layer: gsplat_ops.cpp static initialiser): a stale libgsdf_hip.so fails at load, not on the device. */
-#define GSDF_ABI_VERSION 9
+#define GSDF_ABI_VERSION 10
 int gsdf_abi_version(void);
 
 /* Deterministic mode (process-wide — a step's backward kernels are launched by the autograd engine's thread, not by the caller's; on != 0 switches
@@ -436,12 +436,18 @@ int gsdf_gs_sdf_eik_loss(int64_t n, int stencil, const float *attr, int ld, cons
  *     w_sdf * loss::sdf_loss against gt_sdf [n_ray]; rows [n_ray, n) = the visible splats' samples, w_gs * loss::gs_sdf_loss with
  *     weights[ids[i - n_ray]] (ids NULL: weights[i - n_ray]).  The regularisers are means over each set separately, as the two
  *     sdf_regularization calls of the iteration are (neural_mapping.cpp:183-186, 448-451).  attr [(stencil ? 7 : 1) n, ld].
- *     Outputs: loss[0]; v_attr [n, ld] = d loss / d attr of the BASE rows (the stencil rows are detached); vv_x [n,3] =
+ *     Outputs: loss[0]; v_attr [n, ld] (may be NULL) = d loss / d attr of the BASE rows (the stencil rows are detached); vv_x [n,3] =
  *     d loss / d (J^T g0); u0 [n,32] = J vv_x = d loss / d g0. */
 int gsdf_sdf_analytic_loss(int64_t n, int64_t n_ray, int stencil, const float *attr, int ld, const float *g0, int n_feat,
                            const float *jac, const float *gt_sdf, const float *weights, const int64_t *ids, float bce_isigma,
                            float w_sdf, float w_gs, float map_size_inv, float delta, float w_eik, float w_align, float *loss,
                            float *v_attr, float *vv_x, float *u0, gsdf_stream_t stream);
+/*  gsdf_sdf_data_term_grad: v_attr [n, ld] of gsdf_sdf_analytic_loss ALONE (the same bits) — d (data terms) / d attr of the base rows needs the
+ *     decoder's output at the base rows and nothing else (neither the stencil rows, nor g0, nor the Jacobian).  A caller on whose critical path the
+ *     samples' gradient lies (the joint iteration: decoder backward -> Jacobian contraction -> the splats' optimizer -> the next render) launches
+ *     this first and passes v_attr = NULL to gsdf_sdf_analytic_loss later. */
+int gsdf_sdf_data_term_grad(int64_t n, int64_t n_ray, const float *attr, int ld, const float *gt_sdf, const float *weights, const int64_t *ids,
+                            float bce_isigma, float w_sdf, float w_gs, float *v_attr, gsdf_stream_t stream);
 int gsdf_sdf_ray_loss(int64_t n, int stencil, const float *attr, int ld, const float *gt_sdf, float bce_isigma,
                       float delta, float w_eik, float *loss, float *v_attr, gsdf_stream_t stream);
 

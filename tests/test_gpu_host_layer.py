@@ -167,6 +167,68 @@ def test_cpp_gs_sdf_coupling_node_matches_python_mirror(host, delta, n):
     assert_close(d_grad, grp.flat_grad[nt:nt + d_grad.numel()], 1e-4, "decoder gradient (in place)")   # fp32 atomics: launch-to-launch order
 
 
+def test_joint_sdf_node_first_order_at_forward_time_is_the_same_node(host):
+    """gsdf_extras::joint_sdf_loss_analytic with first_order_in_forward runs its first-order chain (gsdf_sdf_data_term_grad -> one-pass decoder backward ->
+    Jacobian contraction) inside forward(), ahead of the stencil rows' decoder pass and the loss kernel: the samples' gradient leaves earlier, nothing
+    else changes.  Deterministic mode: loss, d/d samples and every parameter gradient are the SAME BITS as the node that does it all in backward(), and
+    (itself compared with the Python mirror by tests/test_gpu_cpp_model.py).  Also: gsdf_sdf_data_term_grad writes the v_attr of gsdf_sdf_analytic_loss bit for bit."""
+    import gs_sdf_amd.capi as capi
+    import gs_sdf_amd.sdf as sdf
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(16)
+    M, n_ids, n_ray = 60000, 41000, 30000
+    ray = ((torch.rand(n_ray, 3, generator=g) - 0.5) * 3.6).to(dev)
+    gt = (torch.randn(n_ray, 1, generator=g) * 0.05).to(dev)
+    pts = ((torch.rand(M, 3, generator=g) - 0.5) * 3.6).to(dev)
+    ids = torch.randperm(M, generator=g)[:n_ids].sort().values.to(dev)
+    w_all = torch.rand(M, 1, generator=g).to(dev)
+    lm = sdf.LocalMap([0.1, -0.2, 0.3], 4.0, bce_sigma=0.02, decoder_implementation=1, device=dev, seed=6)
+    with torch.no_grad():
+        lm.encoder.params_.copy_(((torch.rand(lm.encoder.params_.numel(), generator=torch.Generator().manual_seed(1)) * 2 - 1) * 0.05).to(dev))
+    enc = host.TCNNEncoding(16, 2, 19, 32, 2.0)
+    enc.params_ = lm.encoder.params_.detach().clone()
+    dec = host.TCNNNetwork(32, 2, 64, 3)
+    dec.params_ = lm.decoder.params_.detach().clone()
+    res = []
+    with capi.deterministic():
+        for unit in (False, True):
+            t_grad, d_grad = torch.zeros_like(enc.params_), torch.zeros_like(dec.params_)
+            x = pts.clone().requires_grad_(True)
+            loss = host.joint_sdf_loss_analytic(ray, gt, x, ids, w_all, enc, dec, [float(v) for v in lm._origin], float(lm.map_size_inv),
+                                                1.0 / 0.02, 1.0, 1e-2, 0.02, 0.1, 0.1, t_grad, d_grad, None, unit_upstream=True, first_order_in_forward=unit)
+            if unit:   # the first order has been accumulated already: d/d samples is complete before backward() is called
+                torch.cuda.synchronize()
+                assert float(d_grad.abs().sum()) > 0
+            loss.backward()
+            torch.cuda.synchronize()
+            res.append((loss.detach().clone(), x.grad.clone(), t_grad, d_grad))
+    for k, what in enumerate(("loss", "d/d samples", "table gradient", "decoder gradient")):
+        assert torch.equal(res[0][k], res[1][k]), f"{what}: the forward-time first order is not the backward-time one bit for bit"
+    assert float(res[1][1].abs().sum()) > 0 and float(res[1][2].abs().sum()) > 0
+    # the data-term gradient kernel against the loss kernel's v_attr
+    n, ld = 50000, 2
+    attr = (torch.randn(7 * n, ld, generator=g) * 0.1).to(dev)
+    g0 = torch.randn(n, 32, generator=g).to(dev)
+    jac = torch.randn(n, 32, 3, generator=g).to(dev)
+    gts = (torch.randn(20000, generator=g) * 0.05).to(dev)
+    wts = torch.rand(n - 20000, generator=g).to(dev)
+    loss, va, vb = torch.zeros(1, device=dev), torch.empty(n, ld, device=dev), torch.full((n, ld), 7.0, device=dev)
+    vvx, u0 = torch.empty(n, 3, device=dev), torch.empty(n, 32, device=dev)
+    p = lambda t: t.data_ptr()
+    L, st = capi.lib(), capi.stream()
+    with capi.deterministic():      # (the loss value's reduction order is fixed: the two launches give the same bits)
+        capi.check(L.gsdf_sdf_analytic_loss(n, 20000, 1, p(attr), ld, p(g0), 32, p(jac), p(gts), p(wts), None, 50.0, 1.0, 1e-2, 0.25, 0.02, 0.1, 0.1,
+                                             p(loss), p(va), p(vvx), p(u0), st), "sdf_analytic_loss")
+        capi.check(L.gsdf_sdf_data_term_grad(n, 20000, p(attr), ld, p(gts), p(wts), None, 50.0, 1.0, 1e-2, p(vb), st), "sdf_data_term_grad")
+        torch.cuda.synchronize()
+        assert torch.equal(va, vb)
+        loss2 = torch.zeros(1, device=dev)
+        capi.check(L.gsdf_sdf_analytic_loss(n, 20000, 1, p(attr), ld, p(g0), 32, p(jac), p(gts), p(wts), None, 50.0, 1.0, 1e-2, 0.25, 0.02, 0.1, 0.1,
+                                             p(loss2), None, p(vvx), p(u0), st), "sdf_analytic_loss")      # v_attr = NULL: not written
+        torch.cuda.synchronize()
+    assert torch.equal(loss2, loss) and float(loss) != 0.0
+
+
 @pytest.mark.parametrize("N", [1, 2, 3, 4, 5000, 200_000])
 def test_distCUDA2(host, oracle, N):
     import gs_sdf_amd.ops as ops
