@@ -434,17 +434,13 @@ def main():
     torch.cuda.synchronize()
     # Steady-state warm-up, independent of --warmup: a fresh box starts at idle clocks with a cold caching allocator, and a
     # 5-step warm-up (50 ms) measures the ramp, not the step (round 2: the driver's 20-step run read 80 it/s where longer runs
-    # read 100-110).  Untimed steps continue until the GPU has been busy for GSDF_BENCH_MIN_WARM_S seconds (default 1.5 s, at
-    # most 300 steps); every rank takes the same number (the count is agreed through the slowest rank).
-    min_warm_s, extra_warm = float(os.environ.get("GSDF_BENCH_MIN_WARM_S", "1.5")), 0
-    t_w = time.perf_counter()
-    while extra_warm < 300:
-        go = torch.tensor([1.0 if time.perf_counter() - t_w < min_warm_s else 0.0], device=dev)
-        if dist is not None:
-            dist.all_reduce(go, op=dist.ReduceOp.MAX)
-        if float(go.item()) == 0.0:
-            break
-        for _ in range(10):
+    # read 100-110).  A FIXED number of untimed steps (GSDF_BENCH_WARM_STEPS, default 300: 1.2-1.5 s of GPU time; the compact line reports it
+    # as internal_warmup_steps): the step time depends on the view (p10 / p90 of the step 3.6 / 4.7 ms over the 200 views), so the timed region
+    # must be the SAME steps of the run every time — rounds 2-6 warmed up for 1.5 s of wall time, which ended after 290 or 300 steps by a hair and
+    # moved a 20-step timed region by ten views (4.05 against 4.27 ms for the same code, round 6).
+    extra_warm, warm_steps = 0, max(0, int(os.environ.get("GSDF_BENCH_WARM_STEPS", "300")))
+    while extra_warm < warm_steps:
+        for _ in range(min(10, warm_steps - extra_warm)):
             step(args.warmup + extra_warm)
             extra_warm += 1
         torch.cuda.synchronize()

@@ -67,8 +67,8 @@ def cpp_step(args, sc, views, K, ug6, target, N, W, H, deg, dev):
     for i in range(args.warmup):
         ji.step(views[i % nv][None], K, target, pool[i % 8], ray_sdf[i % 8], up, True, cams[i % nv])
     torch.cuda.synchronize()
-    t_w, i = time.perf_counter(), args.warmup
-    while time.perf_counter() - t_w < float(os.environ.get("GSDF_BENCH_MIN_WARM_S", "1.5")) and i < args.warmup + 300:     # steady state, as the Python step
+    i = args.warmup
+    while i < args.warmup + max(0, int(os.environ.get("GSDF_BENCH_WARM_STEPS", "300"))):     # steady state, as the headline step: a fixed count, so that the timed region is the same views every run
         ji.step(views[i % nv][None], K, target, pool[i % 8], ray_sdf[i % 8], up, True, cams[i % nv])
         i += 1
         if i % 10 == 0:
