@@ -581,12 +581,6 @@ std::map<std::string, int64_t> JointIteration::step_direct(const Tensor &viewmat
     check(gsdf_normal_consistency_bwd(H, W, intr.data(), pose.data(), fp(d1), fp(ra), fp(nw), fp(w_normal_), fpm(v_d1), fpm(v_nw), cur_stream()),
           "normal_consistency_bwd");
   Tensor v_scales_act = scratch_.narrow(0, 0, 3 * N).view({N, 3}), v_opac_dense = scratch_.narrow(0, 3 * N, N);
-  if (fused_values)
-    check(gsdf_isotropic_loss_fwd_bwd(M, fp(scales), M ? gaussian_ids.data_ptr<int64_t>() : nullptr, fp(w_iso_), fpm(l_iso), fpm(v_scales_act), cur_stream()),
-          "isotropic_loss_fwd_bwd");
-  else
-    check(gsdf_isotropic_loss_bwd(M, fp(scales), M ? gaussian_ids.data_ptr<int64_t>() : nullptr, fp(w_iso_), fpm(v_scales_act), cur_stream()),
-          "isotropic_loss_bwd");
   // ---- backward through the epilogue, the compositing, the colours and the projection
   Tensor v_rc = img(3), v_rd = img(1), v_ra = img(1), v_rn = img(3);
   check(gsdf_render_post_bwd(P, 1, fp(viewmat), fp(rd), fp(ra), nullptr, fp(v_nw), fp(v_c3), fp(v_d1), fpm(v_rc), fpm(v_rd), fpm(v_ra), fpm(v_rn), cur_stream()),
@@ -598,6 +592,14 @@ std::map<std::string, int64_t> JointIteration::step_direct(const Tensor &viewmat
                                 I ? flat.data_ptr<int32_t>() : nullptr, fp(ra), last.data_ptr<int32_t>(), med.data_ptr<int32_t>(), fp(v_rc), fp(v_rd), fp(v_ra),
                                 fp(v_rn), fp(zero_image_), fpm(v_means2d), fpm(v_rt), fpm(v_colors), fpm(v_opac), fpm(v_normals), fpm(v_dens), nullptr,
                                 rws.data_ptr(), fp(fT), raster_fws.data_ptr(), cur_stream()), "rasterize_bwd");
+  // the isotropic term feeds the projection's backward alone (the scales' gradient): behind the compositing backward, which the decoder's forward on the
+  // second stream ends up waiting for (a decoder workgroup needs a whole CU) — nothing that is not an input of it runs in front of it
+  if (fused_values)
+    check(gsdf_isotropic_loss_fwd_bwd(M, fp(scales), M ? gaussian_ids.data_ptr<int64_t>() : nullptr, fp(w_iso_), fpm(l_iso), fpm(v_scales_act), cur_stream()),
+          "isotropic_loss_fwd_bwd");
+  else
+    check(gsdf_isotropic_loss_bwd(M, fp(scales), M ? gaussian_ids.data_ptr<int64_t>() : nullptr, fp(w_iso_), fpm(v_scales_act), cur_stream()),
+          "isotropic_loss_bwd");
   // train_callback -> update_state (neural_gaussian.cpp:626-680): needs the densify gradient only
   update_state(state_, v_dens, gaussian_ids, vis, radii, N, 1, W, H, false);
   Tensor v_sh_tmp;
