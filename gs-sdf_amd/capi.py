@@ -57,6 +57,7 @@ _SIGS = {
     "gsdf_hashgrid_fwd": (C.c_int, [_i64, _i32, _i32, _i32, _i32, _f32] + [_vp] * 4),
     "gsdf_hashgrid_fwd_jac": (C.c_int, [_i64, _i32, _i32, _i32, _i32, _f32] + [_vp] * 5),
     "gsdf_hashgrid_fwd_jac_rows": (C.c_int, [_i64, _i64, _i32, _i32, _i32, _i32, _f32] + [_vp] * 5),
+    "gsdf_hashgrid_fwd_stencil_points": (C.c_int, [_i64, _vp, _i64, _vp, _vp, _f32, _vp, _f32, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _vp, _vp, _vp, _vp]),
     "gsdf_hashgrid_fwd_stencil": (C.c_int, [_i64, _i64, _i64, _i32, _i32, _i32, _i32, _f32] + [_vp] * 5),
     "gsdf_hashgrid_fwd_stencil_resident": (C.c_int, [_i32]),
     "gsdf_hashgrid_bwd_jac": (C.c_int, [_i64, _i32, _i32] + [_vp] * 4),

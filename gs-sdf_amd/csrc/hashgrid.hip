@@ -201,20 +201,66 @@ struct XcdSlots {
 // IDX: the integer type of the row / feature offsets.  int32_t when 7 n rows x 16 levels x 2 features x 3 (the Jacobian's floats) stay below
 // 2^31 (any batch of the reference's iteration): the 7 rows' addresses are then one 32-bit offset each against a uniform base instead of
 // 64-bit pairs the compiler hoists out of the resident grid's chunk loop (round 5: 128 registers with 4 of them spilled).
-template <bool JAC, typename IDX>
+// GEN (gsdf_hashgrid_fwd_stencil_points): the 7 rows of a group are MADE here from the group's world point instead of being read from a [7 n, 3]
+// buffer that a launch in front of this one wrote (gsdf_sdf_query_points2): base row = rows [0, n_a) of `a`, then rows ids[j] (or j) of `b`, mapped to
+// the unit cube; rows 1..6 = the point moved by +-delta along x, y, z IN WORLD UNITS and mapped again.  The operations are those of
+// sdf_query_points2_kernel as hipcc compiles it (d = x - p; (d + d) * inv; fma(., 0.5, 0.5)), spelled out and kept from contracting: the same bits.
+// The quad of level 0 writes the rows to x_out (the table scatter of the backward reads the base rows).  One launch and 18 of a lane's 21 position
+// loads less; the level slots of a point sit on different XCDs, so every slot derives the rows again (9 map evaluations).
+struct StencilGen {
+  const float *a, *b;
+  const int64_t *ids;
+  int64_t n_a;
+  float delta, px, py, pz, inv;
+  float *x_out;
+};
+__device__ __forceinline__ float unit_coord(float x, float p, float inv) {
+#pragma clang fp contract(off)
+  const float d = x - p;
+  const float m = (d + d) * inv;
+  return __builtin_fmaf(m, 0.5f, 0.5f);
+}
+template <typename IDX>
+__device__ __forceinline__ void stencil_rows(const StencilGen &sg, IDX n, IDX g, bool write, float (&xr)[7][3]) {
+#pragma clang fp contract(off)
+  const int64_t j = (int64_t)g;
+  const float *src = j < sg.n_a ? sg.a + 3 * j : sg.b + 3 * (sg.ids != nullptr ? sg.ids[j - sg.n_a] : j - sg.n_a);
+  const float w[3] = {src[0], src[1], src[2]}, p[3] = {sg.px, sg.py, sg.pz};
+#pragma unroll
+  for (int d = 0; d < 3; ++d) xr[0][d] = unit_coord(w[d], p[d], sg.inv);
+#pragma unroll
+  for (int r = 1; r < 7; ++r) {
+    const int axis = (r - 1) >> 1;
+    const float moved = w[axis] + (((r - 1) & 1) ? -sg.delta : sg.delta);
+#pragma unroll
+    for (int d = 0; d < 3; ++d) xr[r][d] = d == axis ? unit_coord(moved, p[d], sg.inv) : xr[0][d];
+  }
+  if (write) {
+#pragma unroll
+    for (int r = 0; r < 7; ++r) {
+      float *o = sg.x_out + 3 * ((int64_t)g + (int64_t)r * (int64_t)n);
+      o[0] = xr[r][0]; o[1] = xr[r][1]; o[2] = xr[r][2];
+    }
+  }
+}
+
+template <bool JAC, typename IDX, bool GEN = false>
 __device__ __forceinline__ void stencil_chunk(IDX n, const HgLevels &lv, int level, int f, int xb, IDX g, const float *__restrict__ x,
-                                              const float *__restrict__ table, float *__restrict__ feat, float *__restrict__ jac) {
+                                              const float *__restrict__ table, float *__restrict__ feat, float *__restrict__ jac,
+                                              const StencilGen &sg) {
   const float scale = lv.scale[level];
   const uint32_t res = lv.res[level], hsize = lv.hsize[level];
   const float *tb = table + (int64_t)lv.offset[level] * 2 + f;
   uint32_t cg[7][3];
   float fr[7][3];
+  float xr[7][3];
+  if (GEN) stencil_rows<IDX>(sg, n, g, level == 0 && xb == 0 && f == 0, xr);
 #pragma unroll
   for (int r = 0; r < 7; ++r) {
     const IDX b = g + (IDX)r * n;
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
-      const float pos = fmaf(scale, x[3 * b + d], 0.5f);
+      const float pos = fmaf(scale, GEN ? xr[r][d] : x[3 * b + d], 0.5f);
       const float fl = floorf(pos);
       cg[r][d] = (uint32_t)(int32_t)fl;
       fr[r][d] = pos - fl;
@@ -259,10 +305,11 @@ __device__ __forceinline__ void stencil_chunk(IDX n, const HgLevels &lv, int lev
   }
 }
 
-template <bool JAC, bool RESIDENT, typename IDX>
+template <bool JAC, bool RESIDENT, typename IDX, bool GEN = false>
 __global__ void __launch_bounds__(HG_THREADS, 4)   // <= 128 registers: three resident waves per SIMD leave room for a 96-register wave of another kernel
     hashgrid_fwd_stencil_kernel(int64_t n_, HgLevels lv, XcdSlots xl, int n_xcd, int ppw, int64_t chunks_, int64_t chunk_stride_,
-                                const float *__restrict__ x, const float *__restrict__ table, float *__restrict__ feat, float *__restrict__ jac) {
+                                const float *__restrict__ x, const float *__restrict__ table, float *__restrict__ feat, float *__restrict__ jac,
+                                StencilGen sg) {
   const IDX n = (IDX)n_, chunks = (IDX)chunks_, chunk_stride = (IDX)chunk_stride_;
   const int xcd = blockIdx.x % n_xcd;
   const int nl = xl.count[xcd];
@@ -277,13 +324,13 @@ __global__ void __launch_bounds__(HG_THREADS, 4)   // <= 128 registers: three re
     const IDX g = (chunk * 4 + (IDX)(threadIdx.x >> 6)) * ppw + pw;
     if (g >= n) return;
     if (mode != 0 && (int)(chunk % (mode >> 4)) != (mode & 15)) return;
-    stencil_chunk<JAC, IDX>(n, lv, level, f, xb, g, x, table, feat, jac);
+    stencil_chunk<JAC, IDX, GEN>(n, lv, level, f, xb, g, x, table, feat, jac, sg);
   } else {           // a grid of chunk_stride workgroups per XCD that walks the chunks (see launch_fwd_stencil)
     for (IDX chunk = (IDX)(blockIdx.x / n_xcd); chunk < chunks; chunk += chunk_stride) {
       const IDX g = (chunk * 4 + (IDX)(threadIdx.x >> 6)) * ppw + pw;
       if (g >= n) break;
       if (mode != 0 && (int)(chunk % (mode >> 4)) != (mode & 15)) continue;
-      stencil_chunk<JAC, IDX>(n, lv, level, f, xb, g, x, table, feat, jac);
+      stencil_chunk<JAC, IDX, GEN>(n, lv, level, f, xb, g, x, table, feat, jac, sg);
     }
   }
 }
@@ -363,9 +410,9 @@ static bool make_stencil_slots(int n_levels, int n_xcd, XcdSlots *xs, int *ppw) 
 
 static thread_local int tl_stencil_resident = -1;   // <= 0: the full grid
 
-template <bool JAC>
+template <bool JAC, bool GEN = false>
 static void launch_fwd_stencil(int64_t n, const HgLevels &lv, int n_levels, const float *x, const float *table, float *feat,
-                               float *jac, hipStream_t stream) {
+                               float *jac, hipStream_t stream, const StencilGen &sg = StencilGen{}) {
   XcdSlots xs;
   int ppw = 1, n_xcd = xcd_count(stream);
   if (n_xcd != 8 || 7 * n < 65536 || !make_stencil_slots(n_levels, n_xcd, &xs, &ppw)) {
@@ -387,7 +434,7 @@ static void launch_fwd_stencil(int64_t n, const HgLevels &lv, int n_levels, cons
     if (stride % 3 == 0) ++stride;   // slots dealt by chunk % 3: every workgroup sees all three residues in turn
   }
   const bool idx32 = 7 * n * (int64_t)n_levels * 6 < (int64_t)1 << 31;
-#define STENCIL(RES, IDX, grid) hashgrid_fwd_stencil_kernel<JAC, RES, IDX><<<(unsigned)((grid) * n_xcd), HG_THREADS, 0, stream>>>(n, lv, xs, n_xcd, ppw, chunks, stride, x, table, feat, jac)
+#define STENCIL(RES, IDX, grid) hashgrid_fwd_stencil_kernel<JAC, RES, IDX, GEN><<<(unsigned)((grid) * n_xcd), HG_THREADS, 0, stream>>>(n, lv, xs, n_xcd, ppw, chunks, stride, x, table, feat, jac, sg)
   if (stride < chunks) { if (idx32) STENCIL(true, int32_t, stride); else STENCIL(true, int64_t, stride); }
   else { if (idx32) STENCIL(false, int32_t, chunks); else STENCIL(false, int64_t, chunks); }
 #undef STENCIL
@@ -629,6 +676,28 @@ extern "C" int gsdf_hashgrid_fwd_stencil(int64_t B, int64_t stencil_n, int64_t j
   if (jac_rows > 0) launch_fwd_stencil<true>(stencil_n, lv, n_levels, x, table, feat, jac, stream);
   else launch_fwd_stencil<false>(stencil_n, lv, n_levels, x, table, feat, nullptr, stream);
   GSDF_CHECK_LAUNCH("hashgrid_fwd_stencil_kernel");
+  return GSDF_OK;
+}
+
+extern "C" int gsdf_hashgrid_fwd_stencil_points(int64_t n_a, const float *xyz_a, int64_t n_b, const float *xyz_b, const int64_t *ids_b, float delta,
+                                                const float *origin_host, float map_size_inv, int want_jac, int n_levels, int n_feat, int log2_hashmap,
+                                                int base_res, float per_level_scale, const float *table, float *x_out, float *feat, float *jac,
+                                                gsdf_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  GSDF_TIMED("gsdf_hashgrid_fwd_stencil");
+  int rc = check_cfg(n_levels, n_feat, log2_hashmap, base_res, per_level_scale, "hashgrid_fwd_stencil_points");
+  if (rc) return rc;
+  GSDF_REQUIRE(n_a >= 0 && n_b >= 0 && origin_host, "hashgrid_fwd_stencil_points: bad arguments");
+  const int64_t n = n_a + n_b;
+  if (n == 0) return GSDF_OK;
+  GSDF_REQUIRE((n_a == 0 || xyz_a) && (n_b == 0 || xyz_b) && table && x_out && feat && (jac || !want_jac), "hashgrid_fwd_stencil_points: null buffer");
+  GSDF_REQUIRE(delta > 0.f, "hashgrid_fwd_stencil_points: delta must be positive");
+  HgLevels lv;
+  build_levels(n_levels, log2_hashmap, base_res, per_level_scale, &lv, nullptr);
+  const StencilGen sg{xyz_a, xyz_b, ids_b, n_a, delta, origin_host[0], origin_host[1], origin_host[2], map_size_inv, x_out};
+  if (want_jac) launch_fwd_stencil<true, true>(n, lv, n_levels, nullptr, table, feat, jac, stream, sg);
+  else launch_fwd_stencil<false, true>(n, lv, n_levels, nullptr, table, feat, nullptr, stream, sg);
+  GSDF_CHECK_LAUNCH("hashgrid_fwd_stencil_kernel<points>");
   return GSDF_OK;
 }
 

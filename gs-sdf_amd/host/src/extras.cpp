@@ -234,13 +234,19 @@ struct AnalyticFn : public torch::autograd::Function<AnalyticFn> {
     const int64_t K = stencil ? 7 : 1, nq = K * n;
     const int nf = L * F, nl = (int)dims.size() - 1;
     Tensor x01 = empty_like_opts(xs, {nq, 3}, torch::kFloat32);
-    check(gsdf_sdf_query_points2(n_ray, fp(ray), n_smp, fp(smp), ids.defined() ? ids.data_ptr<int64_t>() : nullptr, stencil ? 1 : 0, (float)delta, origin,
-                                 (float)map_size_inv, fpm(x01), cur_stream()), "sdf_query_points");
     Tensor feat = empty_like_opts(xs, {nq, nf}, torch::kFloat32), jac = empty_like_opts(xs, {n, nf, 3}, torch::kFloat32);
-    if (stencil)
-      check(gsdf_hashgrid_fwd_stencil(nq, n, n, L, F, H, R, S, fp(x01), fp(table), fpm(feat), fpm(jac), cur_stream()), "hashgrid_fwd_stencil");
-    else
-      check(gsdf_hashgrid_fwd_jac_rows(nq, n, L, F, H, R, S, fp(x01), fp(table), fpm(feat), fpm(jac), cur_stream()), "hashgrid_fwd_jac");
+    if (stencil && delta > 0.0) {   // the query points are made inside the encoder's launch (the same rows, bit for bit, written to x01 by it)
+      check(gsdf_hashgrid_fwd_stencil_points(n_ray, fp(ray), n_smp, fp(smp), ids.defined() ? ids.data_ptr<int64_t>() : nullptr, (float)delta, origin,
+                                             (float)map_size_inv, 1, L, F, H, R, S, fp(table), fpm(x01), fpm(feat), fpm(jac), cur_stream()),
+            "hashgrid_fwd_stencil_points");
+    } else {
+      check(gsdf_sdf_query_points2(n_ray, fp(ray), n_smp, fp(smp), ids.defined() ? ids.data_ptr<int64_t>() : nullptr, stencil ? 1 : 0, (float)delta, origin,
+                                   (float)map_size_inv, fpm(x01), cur_stream()), "sdf_query_points");
+      if (stencil)
+        check(gsdf_hashgrid_fwd_stencil(nq, n, n, L, F, H, R, S, fp(x01), fp(table), fpm(feat), fpm(jac), cur_stream()), "hashgrid_fwd_stencil");
+      else
+        check(gsdf_hashgrid_fwd_jac_rows(nq, n, L, F, H, R, S, fp(x01), fp(table), fpm(feat), fpm(jac), cur_stream()), "hashgrid_fwd_jac");
+    }
     const int64_t d_out = dims.back();
     Tensor attr = empty_like_opts(xs, {nq, d_out}, torch::kFloat32);
     Tensor acts = empty_like_opts(xs, {(int64_t)gsdf_mlp_acts_floats(n, nl)}, torch::kFloat32);

@@ -111,8 +111,10 @@ std::vector<Tensor> render_post(const Tensor &render_colors, const Tensor &rende
 }
 
 struct JointStreams {
-  // (a high-priority queue for the SDF leg was measured and costs 1-5 % of the step)
-  c10::hip::HIPStreamMasqueradingAsCUDA side = c10::hip::getStreamFromPoolMasqueradingAsCUDA(false);
+  // a high-priority queue for the SDF leg: it cost 1-5 % of the step while the splat leg's chain was the longer one (rounds 3-5); with the samples' gradient
+  // first the SDF leg's chain of kernels IS the step (hash-grid forward -> decoder -> scatter -> Adam -> next forward: 3.7 ms alone under a 4.0 ms step), and its
+  // queue going first is worth 0.5 % (3.977 against 3.998 ms, three interleaved pairs on one box)
+  c10::hip::HIPStreamMasqueradingAsCUDA side = c10::hip::getStreamFromPoolMasqueradingAsCUDA(true);
   at::cuda::CUDAEvent fwd_done, entry, side_done;
   StreamGate gate;
   bool side_pending = false;

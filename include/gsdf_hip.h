@@ -273,6 +273,15 @@ int gsdf_hashgrid_fwd_jac_rows(int64_t B, int64_t jac_rows, int n_levels, int n_
 int gsdf_hashgrid_fwd_stencil(int64_t B, int64_t stencil_n, int64_t jac_rows, int n_levels, int n_feat, int log2_hashmap,
                               int base_res, float per_level_scale, const float *x, const float *table, float *feat,
                               float *jac, gsdf_stream_t stream);
+/*  gsdf_hashgrid_fwd_stencil_points: gsdf_sdf_query_points2 (stencil rows) and gsdf_hashgrid_fwd_stencil in ONE launch — the joint iteration's SDF
+ *     batch starts from world points (n_a rows of xyz_a, then rows ids_b[j] — or j — of xyz_b), and the 7 encoder rows of a point are made inside the
+ *     encoder's kernel with the query-points kernel's own operations (the same bits) instead of being written by one launch and read back by the next
+ *     (18 of a lane's 21 position loads go, the kernel drops from 110 to 83 registers).  x_out [7 n, 3] receives exactly what gsdf_sdf_query_points2
+ *     writes (the backward's table scatter reads its base rows); feat [7 n, L F], jac [n, L F, 3] (want_jac != 0) as gsdf_hashgrid_fwd_stencil. */
+int gsdf_hashgrid_fwd_stencil_points(int64_t n_a, const float *xyz_a, int64_t n_b, const float *xyz_b, const int64_t *ids_b, float delta,
+                                     const float *origin_host, float map_size_inv, int want_jac, int n_levels, int n_feat, int log2_hashmap,
+                                     int base_res, float per_level_scale, const float *table, float *x_out, float *feat, float *jac,
+                                     gsdf_stream_t stream);
 /* Launch hint for gsdf_hashgrid_fwd_stencil on the CALLING THREAD (round 5): wgs_per_cu > 0 launches a RESIDENT grid of that many
  * 256-thread workgroups per CU which walks the batch, instead of one workgroup per chunk; 0 = the full grid; -1 = back to the default
  * (environment GSDF_HASHGRID_RESIDENT, else 0).  The gathers are bound by the L1's miss queue, which two waves per SIMD keep nearly as
