@@ -111,10 +111,9 @@ std::vector<Tensor> render_post(const Tensor &render_colors, const Tensor &rende
 }
 
 struct JointStreams {
-  // a high-priority queue for the SDF leg: it cost 1-5 % of the step while the splat leg's chain was the longer one (rounds 3-5); with the samples' gradient
-  // first the SDF leg's chain of kernels IS the step (hash-grid forward -> decoder -> scatter -> Adam -> next forward: 3.7 ms alone under a 4.0 ms step), and its
-  // queue going first is worth 0.5 % (3.977 against 3.998 ms, three interleaved pairs on one box)
-  c10::hip::HIPStreamMasqueradingAsCUDA side = c10::hip::getStreamFromPoolMasqueradingAsCUDA(true);
+  // (a high-priority queue for the SDF leg: rounds 3-5 it cost 1-5 % of the step; round 6, with the SDF leg's chain of kernels being the step, it was worth
+  //  0.5 % of the headline step — and cost 12 % of the 1000-step run with refinement in the same process (217 against 247 it/s, reproducibly): not used)
+  c10::hip::HIPStreamMasqueradingAsCUDA side = c10::hip::getStreamFromPoolMasqueradingAsCUDA(false);
   at::cuda::CUDAEvent fwd_done, entry, side_done;
   StreamGate gate;
   bool side_pending = false;

@@ -196,5 +196,8 @@ def test_direct_splat_leg_with_sh_degree_3(tmp_path):
     assert float(ref["splat"].abs().sum()) > 0
     # two separate runs of the same kernels, both in deterministic mode (round 6: with fp32 atomics arriving in a different order a handful of the
     # 1.5e8 elements — sums of hundreds of cancelling terms — differed beyond 1e-4, 12 allowed, and once in ~10 runs there were more)
-    assert_close(got["splat"], ref["splat"], 1e-4, "direct vs autograd: splat gradients (SH degree 3)", outlier_frac=1e-9)
+    # (the autograd composition still sums through libtorch's index_add_ — float atomics —, so up to 12 of the 1.77e8 elements, sums of thousands of
+    #  cancelling terms at L = 5187 splats per tile, land off the 1e-4 bar by a few per cent of the tensor's mean magnitude: 4.0e-2 seen once; a wrong
+    #  segment split or a missing term moves millions of elements)
+    assert_close(got["splat"], ref["splat"], 1e-4, "direct vs autograd: splat gradients (SH degree 3)", outlier_frac=1e-9, outlier_rel=1e-1)
     assert_close(got["sdf"][0], ref["sdf"][0], 1e-4, "direct vs autograd: SDF network gradients")
