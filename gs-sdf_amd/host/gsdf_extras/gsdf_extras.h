@@ -162,7 +162,8 @@ struct JointConfig {
   int hashgrid_resident = 3;  // two_streams + analytic only: workgroups per CU of the stencil hash-grid forward's RESIDENT grid (gsdf_hashgrid_fwd_stencil_resident):
                               // the rest of every CU stays free for the splat leg's kernels; 0 = the full grid.  Round 6 (tools/ab_lib.sh, same box, two runs
                               // each): 2 -> 4.51 ms per step (hash-grid forward 2.11 ms beside the compositing backward), 3 -> 4.26 (1.62 ms = its time alone:
-                              // three 128-register waves + one 96-register wave of the quad-list backward fill a SIMD's file), 4 -> 4.57, 5 -> 4.48, 6 -> 4.45, 1 -> 5.8
+                              // three 128-register waves + one 96-register wave of the quad-list backward fill a SIMD's file), 4 -> 4.57, 5 -> 4.48, 6 -> 4.45, 1 -> 5.8;
+                              // end of round 6 (the kernel fed with world points: 83 registers): 3 -> 3.86-3.88, 4 -> 3.92-3.93, 5 -> 3.97, 0 -> 3.98, 2 -> 4.04
 };
 
 // the refinement policy's configuration: GSConfig's fields (config/base.yaml:60-74) + the scene scale NeuralGS keeps (neural_gaussian.cpp:286-290)
