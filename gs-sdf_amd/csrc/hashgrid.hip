@@ -422,6 +422,18 @@ static void launch_fwd_stencil(int64_t n, const HgLevels &lv, int n_levels, cons
     n_xcd = 1;
     ppw = 1;
   }
+  if (GEN) {   // the quad of level 0 writes the rows a point was made into: the map must give level 0 to one XCD for EVERY chunk (all built-in maps do)
+    bool whole = false;
+    for (int k = 0; k < n_xcd; ++k)
+      for (int j = 0; j < xs.count[k]; ++j) whole = whole || (xs.lvl[k][j] == 0 && xs.mode[k][j] == 0);
+    if (!whole) {
+      xs = XcdSlots{};
+      xs.count[0] = n_levels;
+      for (int j = 0; j < n_levels; ++j) xs.lvl[0][j] = (unsigned char)j;
+      n_xcd = 1;
+      ppw = 1;
+    }
+  }
   const int64_t chunks = (n + 4 * ppw - 1) / (4 * ppw);
   // Resident grid (gsdf_hashgrid_fwd_stencil_resident(w) on this thread): w workgroups per CU (w * 32 per XCD)
   // that walk the chunks, instead of one workgroup per chunk.  The gathers are bound by the L1's miss queue, which two waves per SIMD keep
