@@ -265,11 +265,12 @@ struct AnalyticFn : public torch::autograd::Function<AnalyticFn> {
       check(gsdf_sdf_data_term_grad(n, n_ray, fp(attr), (int)d_out, fp(gt), fp(w), (n > n_ray && ids.defined()) ? ids.data_ptr<int64_t>() : nullptr,
                                     (float)bce_isigma, (float)w_sdf, (float)w_gs, fpm(v_attr), cur_stream()), "sdf_data_term_grad");
       v_feat = empty_like_opts(xs, {n, nf}, torch::kFloat32);
+      const bool want_samples = samples.requires_grad() && n > n_ray;
+      if (want_samples) v_samples = torch::zeros({samples.size(0), 3}, xs.options().dtype(torch::kFloat32).requires_grad(false));   // (its fill in front of the backward, not between it and the contraction)
       Tensor ws = empty_like_opts(xs, {(int64_t)gsdf_mlp_bwd_ws_bytes_for(n, nl, dims.data(), 1)}, torch::kUInt8);
       check(gsdf_mlp_bwd(n, nl, dims.data(), fp(W), fp(bias), fp(feat), fp(acts), fp(v_attr), fpm(v_feat), fpm(decoder_grad),
                          bias.defined() ? fpm(bias_grad) : nullptr, ws.data_ptr(), cur_stream()), "mlp_bwd");
-      if (samples.requires_grad() && n > n_ray) {
-        v_samples = torch::zeros({samples.size(0), 3}, xs.options().dtype(torch::kFloat32).requires_grad(false));
+      if (want_samples) {
         check(gsdf_hashgrid_bwd_jac_scatter(n - n_ray, L, F, fp(jac) + n_ray * nf * 3, fp(v_feat) + n_ray * nf, (float)map_size_inv,
                                             ids.defined() ? ids.data_ptr<int64_t>() : nullptr, fpm(v_samples), cur_stream()), "hashgrid_bwd_jac_scatter");
       }
