@@ -56,7 +56,9 @@ PYBIND11_MODULE(_gsdf_host, m) {
       .def(py::init<double, double, double>(), py::arg("beta1") = 0.9, py::arg("beta2") = 0.999, py::arg("eps") = 1e-15)
       .def("add_group", &gsdf_extras::FusedAdam::add_group)
       .def("set_lr", &gsdf_extras::FusedAdam::set_lr)
-      .def("step", &gsdf_extras::FusedAdam::step, py::arg("zero_grad") = false);
+      .def("step", &gsdf_extras::FusedAdam::step, py::arg("zero_grad") = false)
+      .def("step_tail", &gsdf_extras::FusedAdam::step_tail, py::arg("head_segments"), py::arg("zero_grad") = false)
+      .def("step_head", &gsdf_extras::FusedAdam::step_head, py::arg("head_segments"), py::arg("zero_grad") = false);
   m.def("marching_cubes", [](const torch::Tensor &grid, float thresh, std::vector<float> lower, std::vector<float> upper) {
     TORCH_CHECK(lower.size() == 3 && upper.size() == 3, "marching_cubes: lower / upper need 3 entries");
     return mc::marching_cubes_wrapper(grid, thresh, lower.data(), upper.data());       // as cumcubes.cpp:9-27 calls it

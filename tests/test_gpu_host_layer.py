@@ -386,6 +386,23 @@ def test_cpp_fused_extras_match_python_mirror(host):
         o1.step(bool(it % 2)); o2.step(zero_grad=bool(it % 2))      # odd steps: the launch also zeroes the gradient it consumed
         assert torch.equal(g1, g2) and bool((g1 == 0).all()) == bool(it % 2)
     assert torch.equal(f1, f2)
+    # the step in two launches (JointIteration: the offsets' gradient arrives last): everything behind the first segment(s), then the head — the same bits,
+    # whatever the alignment of the boundary (1003 and 1003 + 4096 are not multiples of 4) and with empty segments in the list
+    for sizes2, heads in (([1003, 4096, 7, 2501], (1, 2)), ([1203, 1203, 1604, 401, 1203, 0], (1,)), ([8, 0, 5], (1, 2))):
+        lrs2 = [1e-3 * (k + 1) for k in range(len(sizes2))]
+        flat = torch.randn(sum(sizes2), generator=g).to(dev)
+        for head in heads:
+            fa, fb = flat.clone(), flat.clone()
+            ga, gb = torch.zeros_like(flat), torch.zeros_like(flat)
+            oa = host.FusedAdam(0.9, 0.999, 1e-15); oa.add_group(fa, ga, sizes2, lrs2)
+            ob = host.FusedAdam(0.9, 0.999, 1e-15); ob.add_group(fb, gb, sizes2, lrs2)
+            for it in range(3):
+                gr = torch.randn(flat.numel(), generator=g).to(dev)
+                ga.copy_(gr); gb.copy_(gr)
+                oa.step(bool(it % 2))
+                ob.step_tail(head, bool(it % 2)); ob.step_head(head, bool(it % 2))
+                assert torch.equal(ga, gb)
+            assert torch.equal(fa, fb), (sizes2, head)
 
 
 @pytest.mark.parametrize("degree", [1, 2, 3, 4])
