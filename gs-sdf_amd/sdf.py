@@ -680,17 +680,19 @@ class _SdfBatchAnalytic(torch.autograd.Function):
         stencil = bool(w_align != 0.0) and n > 0
         K = 7 if stencil else 1
         x01 = torch.empty(K * n, 3, dtype=torch.float32, device=dev)
-        capi.check(L.gsdf_sdf_query_points(n, int(stencil), f32(xs), float(delta or 0.0), (C.c_float * 3)(*lm._origin),
-                                           float(lm.map_size_inv), f32(x01), capi.stream()), "sdf_query_points")
         table = enc.params_.view(-1, cfg[1])
         nf, nl = cfg[0] * cfg[1], len(dims) - 1
         dims_c = (C.c_int * len(dims))(*dims)
         feat = torch.empty(K * n, nf, dtype=torch.float32, device=dev)
         jac = torch.empty(n, nf, 3, dtype=torch.float32, device=dev)
-        if stencil and _stencil_fwd((n, 0), K * n):
-            capi.check(_timed("hashgrid_fwd", L.gsdf_hashgrid_fwd_stencil, K * n, n, n, *cfg, f32(x01), f32(table), f32(feat), f32(jac),
-                              capi.stream()), "hashgrid_fwd_stencil")
+        org = (C.c_float * 3)(*lm._origin)
+        if stencil and delta and _stencil_fwd((n, 0), K * n):
+            # the query points are made inside the encoder's launch (gsdf_hashgrid_fwd_stencil_points: the same rows, features and Jacobians, bit for bit)
+            capi.check(_timed("hashgrid_fwd", L.gsdf_hashgrid_fwd_stencil_points, n, f32(xs), 0, None, None, float(delta), org, float(lm.map_size_inv), 1,
+                              *cfg, f32(table), f32(x01), f32(feat), f32(jac), capi.stream()), "hashgrid_fwd_stencil_points")
         else:
+            capi.check(L.gsdf_sdf_query_points(n, int(stencil), f32(xs), float(delta or 0.0), org, float(lm.map_size_inv), f32(x01), capi.stream()),
+                       "sdf_query_points")
             capi.check(_timed("hashgrid_fwd", L.gsdf_hashgrid_fwd_jac_rows, K * n, n, *cfg, f32(x01), f32(table), f32(feat), f32(jac),
                               capi.stream()), "hashgrid_fwd_jac")
         attr = torch.empty(K * n, dims[-1], dtype=torch.float32, device=dev)
