@@ -145,16 +145,19 @@ struct CouplingFn : public torch::autograd::Function<CouplingFn> {
                         int64_t gate_handle) {
     const CouplingCfg c = coupling_cfg(iv, dv);
     Tensor ids = ids_.contiguous(), table = f32c(table_.detach(), "encoder params"), W = f32c(W_.detach(), "decoder params");
-    Tensor xs = f32c(samples.detach().index_select(0, ids), "samples");
-    const int64_t n = xs.size(0), K = c.delta > 0 ? 7 : 1, nq = K * n;
+    Tensor smp = f32c(samples.detach(), "samples"), xs = smp;   // (xs: device / dtype donor of the buffers below)
+    const int64_t n = ids.size(0), K = c.delta > 0 ? 7 : 1, nq = K * n;
     const int nf = c.L * c.F, nl = (int)c.dims.size() - 1;
     Tensor x01 = empty_like_opts(xs, {nq, 3}, torch::kFloat32);
-    check(gsdf_sdf_query_points(n, K == 7, fp(xs), (float)c.delta, c.origin, (float)c.map_size_inv, fpm(x01), cur_stream()), "sdf_query_points");
     Tensor feat = empty_like_opts(xs, {nq, nf}, torch::kFloat32), jac = empty_like_opts(xs, {n, nf, 3}, torch::kFloat32);
-    if (K == 7 && n > 0)
-      check(gsdf_hashgrid_fwd_stencil(nq, n, n, c.L, c.F, c.H, c.R, c.S, fp(x01), fp(table), fpm(feat), fpm(jac), cur_stream()), "hashgrid_fwd_stencil");
-    else
+    if (K == 7 && n > 0) {   // rows ids[j] of the samples, their 6 stencil points and the encoder in one launch
+      check(gsdf_hashgrid_fwd_stencil_points(0, nullptr, n, fp(smp), ids.data_ptr<int64_t>(), (float)c.delta, c.origin, (float)c.map_size_inv, 1, c.L, c.F, c.H, c.R,
+                                             c.S, fp(table), fpm(x01), fpm(feat), fpm(jac), cur_stream()), "hashgrid_fwd_stencil_points");
+    } else {
+      Tensor rows = f32c(smp.index_select(0, ids), "samples");
+      check(gsdf_sdf_query_points(n, K == 7, fp(rows), (float)c.delta, c.origin, (float)c.map_size_inv, fpm(x01), cur_stream()), "sdf_query_points");
       check(gsdf_hashgrid_fwd_jac_rows(nq, n, c.L, c.F, c.H, c.R, c.S, fp(x01), fp(table), fpm(feat), fpm(jac), cur_stream()), "hashgrid_fwd_jac");
+    }
     Tensor attr = empty_like_opts(xs, {nq, (int64_t)c.dims.back()}, torch::kFloat32);
     Tensor acts = empty_like_opts(xs, {(int64_t)gsdf_mlp_acts_floats(nq, nl)}, torch::kFloat32);
     check(gsdf_mlp_fwd(nq, nl, c.dims.data(), fp(W), nullptr, fp(feat), fpm(attr), fpm(acts), cur_stream()), "mlp_fwd");
