@@ -75,3 +75,29 @@ def test_stencil_forward_from_world_points_is_the_two_launches(resident, n_a, m_
     assert torch.equal(f_ref, f_got), "features"
     assert torch.equal(j_ref, j_got), "Jacobians"
     assert float(f_got.abs().sum()) > 0 and float(j_got.abs().sum()) > 0
+
+
+def test_stencil_forward_from_world_points_with_64_bit_row_offsets():
+    """3.3 M base points: 7 n x 16 levels x 6 floats pass 2^31, the kernels take their 64-bit row-offset instantiations — same bits from both entry points."""
+    import ctypes as C
+    import gs_sdf_amd.capi as capi
+    import gs_sdf_amd.sdf as sdf
+    dev = torch.device("cuda:0")
+    n = 3_300_000
+    g = torch.Generator().manual_seed(41)
+    a = ((torch.rand(n, 3, generator=g) - 0.5) * 14.0 + torch.tensor([0.0, 0.0, 5.5])).to(dev)
+    c = (16, 2, 19, 32, 2.0)
+    table = (sdf.TCNNEncoding(3, None, "enc", dev, seed=3).params_.detach() * 1e3).contiguous()
+    L = capi.lib()
+    org, inv, delta = (C.c_float * 3)(0.0, 0.0, 5.5), 1.0 / 16.0, 0.02
+    p = lambda t: None if t is None else t.data_ptr()
+    x_ref, x_got = torch.empty(7 * n, 3, device=dev), torch.zeros(7 * n, 3, device=dev)
+    f_ref, f_got = torch.empty(7 * n, 32, device=dev), torch.zeros(7 * n, 32, device=dev)
+    j_ref, j_got = torch.empty(n, 32, 3, device=dev), torch.zeros(n, 32, 3, device=dev)
+    capi.check(L.gsdf_sdf_query_points2(n, p(a), 0, None, None, 1, delta, org, inv, p(x_ref), capi.stream()), "query_points2")
+    capi.check(L.gsdf_hashgrid_fwd_stencil(7 * n, n, n, *c, p(x_ref), p(table), p(f_ref), p(j_ref), capi.stream()), "stencil")
+    capi.check(L.gsdf_hashgrid_fwd_stencil_points(n, p(a), 0, None, None, delta, org, inv, 1, *c, p(table), p(x_got), p(f_got), p(j_got), capi.stream()),
+               "stencil_points")
+    torch.cuda.synchronize()
+    assert torch.equal(x_ref, x_got) and torch.equal(f_ref, f_got) and torch.equal(j_ref, j_got)
+    assert float(f_got[-1].abs().sum()) > 0
